@@ -1,0 +1,235 @@
+"""Pins the CPU oracle (oracle/tgx_oracle.c) against the reference's own known-answer tests
+(tests/golden/reference_vectors.json, transcribed from /root/reference/term-guard/src/**)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+
+
+def _ratio_ok(op, ratios, thr):
+    oks = [r >= thr for r in ratios]
+    if op == "all":
+        return all(oks)
+    if op == "any":
+        return any(oks)
+    kind, k = op.split(":")
+    k = int(k)
+    return {"exactly": sum(oks) == k, "at_least": sum(oks) >= k, "at_most": sum(oks) <= k}[kind]
+
+
+def test_completeness_vectors(golden):
+    for case in golden["completeness"]:
+        ratios = []
+        for c in case["cols"]:
+            vals, validity = orc.column_from_list(case["columns"][c], np.int64)
+            out = orc.count(validity, len(vals))
+            assert out.total == len(vals)
+            assert out.non_null == sum(v is not None for v in case["columns"][c])
+            if out.total:
+                ratios.append(out.non_null / out.total)
+        if case["status"] == "skipped":
+            assert not ratios
+            continue
+        metric = sum(ratios) / len(ratios)  # core/unified.rs:69-73
+        if "metric" in case:
+            assert metric == case["metric"], case["ref"]
+        ok = _ratio_ok(case["operator"], ratios, case["threshold"])
+        assert ok == (case["status"] == "success"), case["ref"]
+
+
+def test_statistics_vectors(golden):
+    for case in golden["statistics"]:
+        vals, validity = orc.column_from_list(case["values"], np.float64)
+        st = orc.stats(vals, validity)
+        if case["status"] == "failure" and "message_contains" in case:
+            assert not st.has_value  # "mean is null (no non-null values)"
+            continue
+        got = {"mean": st.mean, "min": st.min_f, "max": st.max_f, "sum": st.sum_f}[case["stat"]]
+        assert got == case["metric"], case["ref"]
+        assert abs(got - case["assertion"][1]) < 1e-10
+
+
+def test_uniqueness_vectors(golden):
+    for case in golden["uniqueness"]:
+        offs, data, validity = orc.utf8_from_list(case["values"])
+        d = orc.distinct_utf8(offs, data, validity)
+        n = d.total
+        if case["status"] == "skipped":
+            assert n == 0
+            continue
+        kind = case["kind"]
+        if kind in ("full_uniqueness", "distinctness"):
+            metric = d.distinct / n
+        elif kind == "unique_value_ratio":
+            metric = d.groups_once / n
+        elif kind == "unique_with_nulls_include":
+            metric = (d.distinct + (1 if d.non_null < n else 0)) / n
+        elif kind == "primary_key":
+            nulls = n - d.non_null
+            if nulls > 0:
+                assert case["message_contains"] == "NULL values"
+                continue
+            if d.distinct != n:
+                assert case["message_contains"] == "duplicate values"
+                continue
+            metric = 1.0
+        assert metric == case["metric"], case["ref"]
+
+
+def test_analyzer_vectors(golden):
+    a = golden["analyzers"]
+    ids, idv = orc.column_from_list(a["table"]["id"], np.int64)
+    vals, vv = orc.column_from_list(a["table"]["value"], np.float64)
+    no, nd, nv = orc.utf8_from_list(a["table"]["name"])
+    for e in a["expect"]:
+        an = e["analyzer"]
+        if an == "completeness":
+            c = orc.count(idv, len(ids))
+            assert (c.total, c.non_null) == (e["state"]["total_count"], e["state"]["non_null_count"])
+            assert c.non_null / c.total == e["metric"]
+        elif an == "distinctness":
+            d = orc.distinct_utf8(no, nd, nv)
+            # DistinctnessAnalyzer: denominator is COUNT(col) (analyzers/basic/distinctness.rs:113-116)
+            assert (d.non_null, d.distinct) == (e["state"]["total_count"], e["state"]["distinct_count"])
+            assert d.distinct / d.non_null == e["metric"]
+        elif an == "mean":
+            st = orc.stats(vals, vv)
+            assert (st.sum_f, st.non_null) == (e["state"]["sum"], e["state"]["count"])
+            assert st.mean == e["metric"]
+        elif an == "min":
+            assert orc.stats(vals, vv).min_f == e["metric"]
+        elif an == "max":
+            assert orc.stats(vals, vv).max_f == e["metric"]
+        elif an == "sum":
+            assert orc.stats(vals, vv).sum_f == e["metric"]
+        elif an == "size":
+            assert orc.count(idv, len(ids)).total == e["metric"]
+    # all-null edge: analyzers/basic/tests.rs:296-326
+    v, val = orc.column_from_list([None, None, None], np.float64)
+    st = orc.stats(v, val)
+    assert st.total == 3 and st.non_null == 0 and not st.has_value
+
+
+def test_correlation_vectors(golden):
+    c = golden["correlation"]
+    x = np.arange(c["n"], dtype=np.float64)
+    y = 2.0 * x + 1.0
+    st = orc.comoments(x, y)
+    assert st.n == 100
+    assert abs(orc.pearson(st) - c["pearson"]["value"]) < c["pearson"]["tol"]
+    assert c["covariance"]["lo"] < orc.covariance(st) < c["covariance"]["hi"]
+    sp = orc.spearman_state(x, y)
+    assert abs(orc.pearson(sp) - c["spearman"]["value"]) < c["spearman"]["tol"]
+    online = orc.corr_online(x, y)
+    assert abs(online.corr - 1.0) < 1e-12 and abs(online.covar_samp - orc.covariance(st)) < 1e-9
+    # int64 input is CAST AS DOUBLE
+    st_i = orc.comoments(np.arange(100, dtype=np.int64), y)
+    assert st_i.sum_xy == st.sum_xy
+
+
+def _series(spec):
+    if isinstance(spec, str):
+        lo, hi = spec.split("..")
+        return [float(i) for i in range(int(lo), int(hi) + 1)]
+    return [float("nan") if v == "nan" else float(v) for v in spec]
+
+
+@pytest.mark.parametrize("parity_mode", [0, 1])
+def test_kll_vectors(golden, parity_mode):
+    for case in golden["kll"]:
+        if "error_bound" in case:
+            assert abs(orc.Kll(case["k"]).error_bound - case["error_bound"]) < 0.001
+            continue
+        if "merge" in case:
+            parts = []
+            for spec in case["merge"]:
+                s = orc.Kll(case["k"], parity_mode, 7)
+                for v in _series(spec):
+                    s.update(v)
+                parts.append(s)
+            sk = parts[0]
+            for p in parts[1:]:
+                sk.merge(p)
+        else:
+            sk = orc.Kll(case["k"], parity_mode, 7)
+            for v in _series(case["input"]):
+                sk.update(v)
+        assert sk.count == case["count"], case["ref"]
+        for chk in case["checks"]:
+            q = sk.quantile(chk["phi"])
+            if "equals" in chk:
+                assert q == chk["equals"]
+            else:
+                assert abs(q - chk["expected"]) / chk["expected"] < chk["rel_err_lt"], (case["ref"], q)
+
+
+def test_kll_empty_and_errors():
+    sk = orc.Kll(100)
+    with pytest.raises(ValueError):
+        sk.quantile(0.5)  # kll_sketch.rs:471-476
+    with pytest.raises(ValueError):
+        orc.Kll(1)  # k must be at least 2 (kll_sketch.rs:167-169)
+    a, b = orc.Kll(100), orc.Kll(200)
+    with pytest.raises(ValueError):
+        a.merge(b)  # kll_sketch.rs:328-333
+    sk.update(1.0)
+    with pytest.raises(ValueError):
+        sk.quantile(1.5)
+
+
+def test_kll_reference_keeps_every_item():
+    """Compactor::compact (kll_sketch.rs:57-76) returns the de-selected half to the caller, which
+    pushes it one level up, and keeps the selected half in place: no item is ever dropped."""
+    sk = orc.Kll(100)
+    for i in range(5000):
+        sk.update(float(i))
+    assert sk.num_retained == 5000
+    assert [orc.lib().orc_kll_level_capacity(200, l) for l in range(7)] == [200, 133, 100, 50, 25, 4, 4]
+    assert [orc.lib().orc_kll_level_capacity(6, l) for l in range(6)] == [6, 8, 4, 4, 4, 4]
+
+
+def test_siphash_structure_known_answer():
+    """SipHash-2-4 reference vector from the SipHash paper (key 00..0f, message 00..0e) checks the
+    round/finalisation structure that the 1-3 variant (Rust DefaultHasher) shares."""
+    key = bytes(range(16))
+    k0 = int.from_bytes(key[:8], "little")
+    k1 = int.from_bytes(key[8:], "little")
+    msg = bytes(range(15))
+    assert orc.lib().orc_siphash(2, 4, k0, k1, msg, len(msg)) == 0xA129CA6149BE45E5
+
+
+def test_stats_semantics():
+    # SUM(int64) wraps; AVG(int64) sums doubles
+    v = np.array([2**62, 2**62, 2**62], dtype=np.int64)
+    st = orc.stats(v)
+    assert st.sum_i_wrapping == ((3 * 2**62 + 2**63) % 2**64) - 2**63
+    assert st.mean == float(2**62)
+    # total order for floats: -0.0 < +0.0, NaN above +inf
+    f = np.array([0.0, -0.0, float("inf"), float("nan")], dtype=np.float64)
+    st = orc.stats(f)
+    assert math.copysign(1.0, st.min_f) == -1.0 and st.min_f == 0.0
+    assert math.isnan(st.max_f)
+    # sample variance of 1..5 = 2.5
+    st = orc.stats(np.array([1, 2, 3, 4, 5], dtype=np.float64))
+    assert st.var_samp == 2.5 and st.has_variance
+    assert not orc.stats(np.array([1.0])).has_variance
+    # sliced arrays: offset applies to values and validity bits alike
+    vals = np.arange(20, dtype=np.int64)
+    mask = np.ones(20, dtype=bool)
+    mask[7] = False
+    st = orc.stats(vals, orc.pack_validity(mask), n=10, offset=5)
+    assert (st.total, st.non_null, st.min_i, st.max_i) == (10, 9, 5, 14)
+    assert st.sum_i_wrapping == sum(range(5, 15)) - 7
+
+
+def test_distinct_semantics():
+    v = np.array([1, 1, 2, 3, 3, 3, 9], dtype=np.int64)
+    d = orc.distinct_bits64(v)
+    assert (d.distinct, d.groups_once) == (4, 2)
+    mask = np.array([1, 1, 1, 1, 1, 1, 0], dtype=bool)
+    d = orc.distinct_bits64(v, orc.pack_validity(mask))
+    assert (d.non_null, d.distinct, d.groups_once) == (6, 3, 2)  # one NULL row = a group of one
+    f = np.array([0.0, -0.0, 1.0], dtype=np.float64)
+    assert orc.distinct_bits64(f.view(np.uint64)).distinct == 3  # by bit pattern
