@@ -1,0 +1,245 @@
+/*
+ * tgx.h -- C ABI of libtgx, the MI355X (gfx950) execution path for term-guard's Arrow-batch
+ * check evaluator.
+ *
+ * The reference (term-guard 0.0.2, /root/reference/term-guard/src = "TG/") has no FFI of its own:
+ * every check is a SQL string handed to DataFusion (`ctx.sql(..).collect()`), e.g.
+ * TG/constraints/completeness.rs:158-167.  The drop-in boundary is therefore the reference's own
+ * extension traits -- `Constraint::evaluate` (TG/core/constraint.rs:187-225) and
+ * `Analyzer::{compute_state_from_data, merge_states, compute_metric_from_state}`
+ * (TG/analyzers/traits.rs:65-148).  A `GpuConstraint: Constraint` on the Rust side (INTEGRATION.md
+ * shows the binding) streams the table's RecordBatches, hands the raw Arrow buffers of each needed
+ * column to `tgx_update`, and reads the aggregates back with `tgx_finalize`; each entry point
+ * below names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - plain C, no C++ / torch / HIP types in any signature; HIP streams travel as `void*`.
+ *   - every function returns a tgx_status and, when `err` is non-NULL, fills it on failure;
+ *     nothing aborts or throws across the boundary (maps to TermError::Internal, TG/error.rs:89-90).
+ *   - column buffers follow the Arrow C Data Interface layout (LSB-first validity bitmap, NULL
+ *     when the array has no nulls; `offset` counts slots and applies to validity and values alike).
+ *   - the caller owns column buffers; HOST buffers may be released when tgx_update returns, DEVICE
+ *     buffers must stay alive until the next tgx_finalize / tgx_state_sync on that state.
+ *   - handles are not thread-safe; distinct handles are independent.  One HIP stream per state.
+ *   - there is NO CPU fallback: without a usable gfx950 device tgx_init fails with TGX_NO_DEVICE
+ *     and every compute entry point fails with it too.
+ */
+#ifndef TGX_H
+#define TGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGX_ABI_VERSION 1
+
+typedef enum tgx_status {
+  TGX_OK = 0,
+  TGX_INVALID_ARGUMENT = 1,
+  TGX_UNSUPPORTED = 2, /* type/shape/pattern outside the path: caller falls back to the stock SQL constraint */
+  TGX_DEVICE_ERROR = 3,
+  TGX_OUT_OF_MEMORY = 4,
+  TGX_INTERNAL = 5,
+  TGX_NO_DEVICE = 6
+} tgx_status;
+
+typedef struct tgx_error {
+  int32_t code; /* tgx_status */
+  char msg[256];
+} tgx_error;
+
+/* ---- column views (Arrow layout) ------------------------------------------------------- */
+typedef enum tgx_type {
+  TGX_INT64 = 1,
+  TGX_FLOAT64 = 2,
+  TGX_UTF8 = 3,        /* int32 offsets */
+  TGX_LARGE_UTF8 = 4,  /* int64 offsets */
+  TGX_DICT32_UTF8 = 5  /* int32 indices in `values`, Utf8 dictionary in `dictionary` */
+} tgx_type;
+
+typedef enum tgx_memspace { TGX_MEM_HOST = 0, TGX_MEM_DEVICE = 1 } tgx_memspace;
+
+typedef struct tgx_column {
+  int32_t type;            /* tgx_type */
+  int32_t mem;             /* tgx_memspace: where every buffer below lives */
+  int64_t length;          /* rows */
+  int64_t offset;          /* Arrow `offset`: first logical slot */
+  int64_t null_count;      /* -1 = unknown */
+  const uint8_t *validity; /* may be NULL (no nulls) */
+  const void *values;      /* fixed-width values / dictionary indices */
+  const void *offsets;     /* Utf8: length+1 (+offset) int32/int64 offsets */
+  const uint8_t *data;     /* Utf8: value bytes */
+  const struct tgx_column *dictionary; /* TGX_DICT32_UTF8 only */
+} tgx_column;
+
+/* ---- check specs: the aggregates the reference's constraints emit as SQL ------------------ */
+typedef enum tgx_check_kind {
+  /* COUNT(*), COUNT(col)                       TG/constraints/completeness.rs:158-163,
+   *                                            TG/analyzers/basic/{size,completeness}.rs */
+  TGX_CHECK_COUNT = 1,
+  /* MIN MAX SUM AVG [STDDEV VARIANCE]          TG/constraints/statistics.rs:45-74, :263;
+   *                                            TG/analyzers/basic/{min_max,mean,sum}.rs */
+  TGX_CHECK_NUMERIC_STATS = 2,
+  /* COUNT(DISTINCT col) [+ GROUP BY col counts] TG/constraints/uniqueness.rs:612-617, 671-681, 709-715 */
+  TGX_CHECK_DISTINCT = 3,
+  /* COUNT(CASE WHEN [TRIM(]c[)] ~|~* 'pat' [OR c IS NULL] THEN 1 END), COUNT(*)
+   *                                            TG/constraints/format.rs:750-776 */
+  TGX_CHECK_REGEX_MATCH = 4,
+  /* KllSketch::update over the column's non-NULL, non-NaN values
+   *                                            TG/analyzers/advanced/kll_sketch.rs:195-229 */
+  TGX_CHECK_KLL = 5,
+  /* n, Sx, Sy, Sxx, Syy, Sxy over rows with both columns non-NULL (CAST AS DOUBLE)
+   *                                            TG/analyzers/advanced/correlation.rs:239-249 */
+  TGX_CHECK_COMOMENTS = 6
+} tgx_check_kind;
+
+enum {
+  TGX_FLAG_VARIANCE = 1u << 0,          /* NUMERIC_STATS: also sample variance / stddev */
+  TGX_FLAG_MULTIPLICITY = 1u << 1,      /* DISTINCT: also #groups with cnt == 1 (NULL is a group) */
+  TGX_FLAG_TRIM = 1u << 2,              /* REGEX: TRIM(col) (U+0020 only) before matching */
+  TGX_FLAG_CASE_INSENSITIVE = 1u << 3,  /* REGEX: `~*` */
+  TGX_FLAG_NULL_IS_VALID = 1u << 4      /* REGEX: `OR col IS NULL` */
+};
+
+typedef struct tgx_check_spec {
+  int32_t kind;         /* tgx_check_kind */
+  int32_t column;       /* index into the columns array handed to tgx_update */
+  int32_t column2;      /* COMOMENTS: second column; otherwise -1 */
+  uint32_t flags;
+  const char *pattern;  /* REGEX: pattern bytes (Rust `regex` syntax), not NUL-terminated */
+  uint64_t pattern_len;
+  uint32_t kll_k;       /* KLL: k >= 2 */
+  uint32_t reserved;
+} tgx_check_spec;
+
+/* One result per spec.  Fields outside the spec's kind are zero. */
+typedef struct tgx_result {
+  int32_t kind;
+  int32_t is_float;     /* NUMERIC_STATS: column type */
+  int64_t total;        /* COUNT(*)  (rows seen) */
+  int64_t non_null;     /* COUNT(col); COMOMENTS: rows with both sides non-NULL */
+  /* NUMERIC_STATS */
+  int32_t has_value;    /* 0 => MIN/MAX/SUM/AVG are SQL NULL (no non-NULL rows) */
+  int32_t has_variance; /* 0 => STDDEV/VARIANCE are SQL NULL (fewer than 2 rows) */
+  int64_t min_i, max_i; /* Int64 columns */
+  double min_f, max_f;  /* Float64 columns: IEEE totalOrder; Int64 columns: the same as double */
+  int64_t sum_i;        /* SUM(Int64), wrapping */
+  double sum_f;         /* SUM(Float64) / SUM(CAST(Int64 AS DOUBLE)) */
+  double mean;          /* AVG */
+  double var_samp, stddev_samp;
+  /* DISTINCT */
+  int64_t distinct;     /* COUNT(DISTINCT col) */
+  int64_t groups_once;  /* SUM(CASE WHEN cnt = 1 ...) over GROUP BY col */
+  /* REGEX_MATCH */
+  int64_t matches;
+  /* COMOMENTS */
+  double sum_x, sum_y, sum_x2, sum_y2, sum_xy;
+  /* KLL: read through tgx_kll_* below */
+  uint64_t kll_n;
+} tgx_result;
+
+typedef struct tgx_options {
+  int32_t device_id;       /* -1 = current HIP device */
+  int32_t reserved;
+  uint64_t distinct_capacity_hint; /* expected rows per DISTINCT column (0 = grow on demand) */
+} tgx_options;
+
+typedef struct tgx_plan tgx_plan;
+typedef struct tgx_state tgx_state;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+uint32_t tgx_abi_version(void);
+/* Selects the device and checks it is gfx950.  No reference counterpart (the reference has no
+ * device); called once per process before any other compute entry point. */
+tgx_status tgx_init(const tgx_options *opts, tgx_error *err);
+tgx_status tgx_shutdown(void);
+const char *tgx_status_name(int32_t status);
+
+/* Plan = the fused set of aggregates a ValidationSuite needs, grouped so each column buffer is
+ * read once.  Replaces the per-constraint `format!("SELECT ...")` + `ctx.sql()` planning in
+ * TG/core/suite.rs:67-100 (one scan per constraint). Regex patterns are validated
+ * (TG/security.rs:152-183) and compiled here. */
+tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_specs, tgx_plan **out,
+                           tgx_error *err);
+void tgx_plan_destroy(tgx_plan *plan);
+size_t tgx_plan_num_specs(const tgx_plan *plan);
+
+/* State = `Analyzer::State` for every spec of the plan (TG/analyzers/traits.rs:154-179).
+ * `hip_stream` is a hipStream_t (NULL = a stream the library creates). */
+tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **out, tgx_error *err);
+void tgx_state_destroy(tgx_state *state);
+
+/* One call per RecordBatch: replaces DataFusion's accumulator `update_batch` for the plan's
+ * aggregates (`Analyzer::compute_state_from_data`, TG/analyzers/traits.rs:98-111).  Asynchronous
+ * on the state's stream. `columns[i]` is column i of the batch; unused columns may be zeroed. */
+tgx_status tgx_update(const tgx_plan *plan, tgx_state *state, const tgx_column *columns,
+                      size_t n_columns, tgx_error *err);
+
+/* `AnalyzerState::merge` (TG/analyzers/traits.rs:160-170): folds srcs into dst.  Exact for every
+ * kind, including DISTINCT (set union), unlike the reference's DistinctnessState::merge upper
+ * bound (TG/analyzers/basic/distinctness.rs:77-92). */
+tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state *const *srcs, size_t n_srcs,
+                     tgx_error *err);
+
+/* `Analyzer::compute_metric_from_state` inputs (TG/analyzers/traits.rs:113-122): waits for the
+ * stream and writes one tgx_result per spec. Ratios, thresholds, assertions and messages stay
+ * on the caller's side (TG/constraints/*.rs). The state stays usable. */
+tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *state, tgx_result *results,
+                        size_t n_results, tgx_error *err);
+tgx_status tgx_state_sync(tgx_state *state, tgx_error *err);
+tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *state, tgx_error *err);
+
+/* Wire form of a state (the counterpart of the serde_json states the reference's
+ * IncrementalAnalysisRunner stores, TG/analyzers/incremental/runner.rs:71-111); used to ship
+ * partial states between ranks. `*len` receives the size needed/written. */
+tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *state, uint8_t *buf, size_t cap,
+                               size_t *len, tgx_error *err);
+tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t *buf, size_t len,
+                                 tgx_state **out, tgx_error *err);
+
+/* ---- KllSketch accessors (TG/analyzers/advanced/kll_sketch.rs:246-322, 368-399) ------------- */
+tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *state, size_t spec_index, double phi,
+                            double *out, tgx_error *err);
+tgx_status tgx_kll_summary(const tgx_plan *plan, tgx_state *state, size_t spec_index, uint64_t *n,
+                           double *min_value, double *max_value, uint64_t *num_levels,
+                           uint64_t *num_retained, tgx_error *err);
+/* copies level `level`'s items (weight 2^level each); *count receives the item count */
+tgx_status tgx_kll_level_items(const tgx_plan *plan, tgx_state *state, size_t spec_index,
+                               uint64_t level, double *out, uint64_t cap, uint64_t *count,
+                               tgx_error *err);
+double tgx_kll_relative_error_bound(uint32_t k);
+
+/* ---- exact DISTINCT across ranks: hash-owner key exchange -------------
+ * export: partitions this state's key set by owner = mix(key) % world into `world` contiguous
+ *   runs of 16-byte records in device memory the state owns (valid until the next call on the
+ *   state); counts[r] = records for rank r.
+ * import: replaces the state's key set with the union of the given records (device memory),
+ *   marking the state "owner-partitioned" so that tgx_merge adds its counts instead of uniting. */
+tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *state, size_t spec_index,
+                               uint32_t world, const void **device_records, uint64_t *counts,
+                               tgx_error *err);
+tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *state, size_t spec_index,
+                               const void *device_records, uint64_t n_records, tgx_error *err);
+
+/* ---- measurement ----------------------------------------------------------------------------
+ * Per-kernel HIP-event timing on the state's stream (what bench.py's `roofline` uses).
+ * Kernel names: "scan", "count", "distinct", "regex", "kll", "comoments". */
+tgx_status tgx_profile_enable(tgx_state *state, int32_t on);
+tgx_status tgx_profile_get(tgx_state *state, const char *kernel, double *total_ms,
+                           uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err);
+tgx_status tgx_profile_reset(tgx_state *state);
+
+/* ---- host-side rules the Rust shim shares with the reference -------------------------------- */
+/* SqlSecurity::validate_regex_pattern (TG/security.rs:152-183) + "does the engine cover it". */
+tgx_status tgx_regex_validate(const char *pattern, size_t len, uint32_t flags, tgx_error *err);
+/* Host-side `is_match` of the compiled automaton for one value (debug / small inputs). */
+tgx_status tgx_regex_is_match(const char *pattern, size_t plen, uint32_t flags, const uint8_t *value,
+                              size_t vlen, int32_t *matched, tgx_error *err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGX_H */

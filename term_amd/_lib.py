@@ -1,0 +1,352 @@
+"""ctypes binding of libtgx.so (include/tgx.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+# enums of include/tgx.h
+COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS = 1, 2, 3, 4, 5, 6
+FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
+INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8 = 1, 2, 3, 4, 5
+MEM_HOST, MEM_DEVICE = 0, 1
+STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
+                4: "TGX_OUT_OF_MEMORY", 5: "TGX_INTERNAL", 6: "TGX_NO_DEVICE"}
+
+
+class TgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(code, code), msg))
+        self.code = code
+        self.status = STATUS_NAMES.get(code, str(code))
+        self.msg = msg
+
+
+class _Error(C.Structure):
+    _fields_ = [("code", C.c_int32), ("msg", C.c_char * 256)]
+
+
+class _Column(C.Structure):
+    pass
+
+
+_Column._fields_ = [
+    ("type", C.c_int32), ("mem", C.c_int32), ("length", C.c_int64), ("offset", C.c_int64),
+    ("null_count", C.c_int64), ("validity", C.c_void_p), ("values", C.c_void_p), ("offsets", C.c_void_p),
+    ("data", C.c_void_p), ("dictionary", C.POINTER(_Column)),
+]
+
+
+class CheckSpec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("column", C.c_int32), ("column2", C.c_int32), ("flags", C.c_uint32),
+                ("pattern", C.c_char_p), ("pattern_len", C.c_uint64), ("kll_k", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("is_float", C.c_int32), ("total", C.c_int64), ("non_null", C.c_int64),
+        ("has_value", C.c_int32), ("has_variance", C.c_int32), ("min_i", C.c_int64), ("max_i", C.c_int64),
+        ("min_f", C.c_double), ("max_f", C.c_double), ("sum_i", C.c_int64), ("sum_f", C.c_double),
+        ("mean", C.c_double), ("var_samp", C.c_double), ("stddev_samp", C.c_double),
+        ("distinct", C.c_int64), ("groups_once", C.c_int64), ("matches", C.c_int64),
+        ("sum_x", C.c_double), ("sum_y", C.c_double), ("sum_x2", C.c_double), ("sum_y2", C.c_double),
+        ("sum_xy", C.c_double), ("kll_n", C.c_uint64),
+    ]
+
+
+class _Options(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("reserved", C.c_int32), ("distinct_capacity_hint", C.c_uint64)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libtgx.so")
+
+
+def abi_symbols():
+    """Every function name include/tgx.h declares (parsed from the header)."""
+    with open(os.path.join(_ROOT, "include", "tgx.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgx_[a-z0-9_]+)\s*\(", text)))
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                "term_amd/libtgx.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C term_amd/csrc` (hipcc, gfx950). term_amd has no CPU fallback.")
+        L = C.CDLL(path)
+        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        E = C.POINTER(_Error)
+        L.tgx_abi_version.restype = C.c_uint32
+        L.tgx_status_name.restype = C.c_char_p
+        L.tgx_status_name.argtypes = [C.c_int32]
+        L.tgx_init.argtypes = [C.POINTER(_Options), E]
+        L.tgx_plan_create.argtypes = [C.POINTER(CheckSpec), sz, C.POINTER(vp), E]
+        L.tgx_plan_destroy.argtypes = [vp]
+        L.tgx_plan_destroy.restype = None
+        L.tgx_plan_num_specs.argtypes = [vp]
+        L.tgx_plan_num_specs.restype = sz
+        L.tgx_state_create.argtypes = [vp, vp, C.POINTER(vp), E]
+        L.tgx_state_destroy.argtypes = [vp]
+        L.tgx_state_destroy.restype = None
+        L.tgx_update.argtypes = [vp, vp, C.POINTER(_Column), sz, E]
+        L.tgx_merge.argtypes = [vp, vp, C.POINTER(vp), sz, E]
+        L.tgx_finalize.argtypes = [vp, vp, C.POINTER(Result), sz, E]
+        L.tgx_state_sync.argtypes = [vp, E]
+        L.tgx_state_reset.argtypes = [vp, vp, E]
+        L.tgx_state_serialize.argtypes = [vp, vp, vp, sz, C.POINTER(sz), E]
+        L.tgx_state_deserialize.argtypes = [vp, vp, sz, C.POINTER(vp), E]
+        L.tgx_kll_quantile.argtypes = [vp, vp, sz, C.c_double, C.POINTER(C.c_double), E]
+        L.tgx_kll_summary.argtypes = [vp, vp, sz, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(u64), C.POINTER(u64), E]
+        L.tgx_kll_level_items.argtypes = [vp, vp, sz, u64, vp, u64, C.POINTER(u64), E]
+        L.tgx_kll_relative_error_bound.argtypes = [C.c_uint32]
+        L.tgx_kll_relative_error_bound.restype = C.c_double
+        L.tgx_distinct_export.argtypes = [vp, vp, sz, C.c_uint32, C.POINTER(vp), C.POINTER(u64), E]
+        L.tgx_distinct_import.argtypes = [vp, vp, sz, vp, u64, E]
+        L.tgx_profile_enable.argtypes = [vp, C.c_int32]
+        L.tgx_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), E]
+        L.tgx_profile_reset.argtypes = [vp]
+        L.tgx_regex_validate.argtypes = [C.c_char_p, sz, C.c_uint32, E]
+        L.tgx_regex_is_match.argtypes = [C.c_char_p, sz, C.c_uint32, C.c_char_p, sz, C.POINTER(C.c_int32), E]
+        _LIB = L
+    return _LIB
+
+
+def _check(status, err):
+    if status != 0:
+        raise TgxError(status, err.msg.decode("utf-8", "replace"))
+
+
+_INITED = False
+
+
+def init(device_id=-1, distinct_capacity_hint=0):
+    """tgx_init: selects the gfx950 device. Raises TgxError(TGX_NO_DEVICE) when there is none."""
+    global _INITED
+    err = _Error()
+    opts = _Options(device_id, 0, distinct_capacity_hint)
+    _check(lib().tgx_init(C.byref(opts), C.byref(err)), err)
+    _INITED = True
+
+
+def _ptr_of(buf):
+    """address of a numpy array / torch tensor / int / None, plus whether it is device memory"""
+    if buf is None:
+        return None, None
+    if isinstance(buf, int):
+        return buf, None
+    if hasattr(buf, "data_ptr"):  # torch tensor
+        return buf.data_ptr(), buf.is_cuda
+    if hasattr(buf, "ctypes"):  # numpy
+        return buf.ctypes.data, False
+    raise TypeError("unsupported buffer type %r" % type(buf))
+
+
+class Column:
+    """A tgx_column view. Keeps the Python buffers alive while the view exists."""
+
+    def __init__(self, type, length, values=None, validity=None, offsets=None, data=None, offset=0,
+                 null_count=-1, mem=None):
+        self._keep = (values, validity, offsets, data)
+        c = _Column()
+        c.type = type
+        c.length = length
+        c.offset = offset
+        c.null_count = null_count
+        spaces = set()
+        for name, buf in (("values", values), ("validity", validity), ("offsets", offsets), ("data", data)):
+            p, is_dev = _ptr_of(buf)
+            setattr(c, name, p)
+            if is_dev is not None:
+                spaces.add(bool(is_dev))
+        if mem is None:
+            if len(spaces) > 1:
+                raise ValueError("a column's buffers must all live in one memory space")
+            mem = MEM_DEVICE if (spaces and spaces.pop()) else MEM_HOST
+        c.mem = mem
+        self.c = c
+
+    @staticmethod
+    def int64(values, validity=None, length=None, offset=0):
+        n = (len(values) - offset) if length is None else length
+        return Column(INT64, n, values=values, validity=validity, offset=offset)
+
+    @staticmethod
+    def float64(values, validity=None, length=None, offset=0):
+        n = (len(values) - offset) if length is None else length
+        return Column(FLOAT64, n, values=values, validity=validity, offset=offset)
+
+    @staticmethod
+    def utf8(offsets, data, validity=None, length=None, offset=0):
+        n = (len(offsets) - 1 - offset) if length is None else length
+        return Column(UTF8, n, offsets=offsets, data=data, validity=validity, offset=offset)
+
+    @staticmethod
+    def from_arrow(arr):
+        """pyarrow Array (Int64 / Float64 / Utf8, host memory) -> Column view of its buffers."""
+        import numpy as np
+        import pyarrow as pa
+
+        bufs = arr.buffers()
+
+        def view(b, dtype):
+            return None if b is None else np.frombuffer(b, dtype=dtype)
+
+        validity = view(bufs[0], np.uint8) if arr.null_count else None
+        if pa.types.is_int64(arr.type):
+            return Column(INT64, len(arr), values=view(bufs[1], np.int64), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count)
+        if pa.types.is_float64(arr.type):
+            return Column(FLOAT64, len(arr), values=view(bufs[1], np.float64), validity=validity,
+                          offset=arr.offset, null_count=arr.null_count)
+        if pa.types.is_string(arr.type):
+            data = view(bufs[2], np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
+            return Column(UTF8, len(arr), offsets=view(bufs[1], np.int32), data=data, validity=validity,
+                          offset=arr.offset, null_count=arr.null_count)
+        raise TgxError(2, "unsupported Arrow type %s" % arr.type)
+
+
+def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0):
+    pat = pattern.encode("utf-8") if isinstance(pattern, str) else pattern
+    return CheckSpec(kind, column, column2, flags, pat, len(pat) if pat else 0, kll_k, 0)
+
+
+class Plan:
+    def __init__(self, specs):
+        self._specs = list(specs)
+        arr = (CheckSpec * max(1, len(self._specs)))(*self._specs)
+        h = C.c_void_p()
+        err = _Error()
+        _check(lib().tgx_plan_create(arr, len(self._specs), C.byref(h), C.byref(err)), err)
+        self.h = h
+        self.n = len(self._specs)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().tgx_plan_destroy(self.h)
+            self.h = None
+
+
+class State:
+    def __init__(self, plan, stream=None, _handle=None):
+        self.plan = plan
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = C.c_void_p()
+        err = _Error()
+        _check(lib().tgx_state_create(plan.h, stream, C.byref(h), C.byref(err)), err)
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().tgx_state_destroy(self.h)
+            self.h = None
+
+    def update(self, columns):
+        cols = list(columns)
+        arr = (_Column * max(1, len(cols)))(*[c.c if c is not None else _Column() for c in cols])
+        err = _Error()
+        _check(lib().tgx_update(self.plan.h, self.h, arr, len(cols), C.byref(err)), err)
+        self._keep = cols  # device buffers must outlive the asynchronous kernels
+
+    def finalize(self):
+        res = (Result * max(1, self.plan.n))()
+        err = _Error()
+        _check(lib().tgx_finalize(self.plan.h, self.h, res, self.plan.n, C.byref(err)), err)
+        self._keep = None
+        return list(res)[: self.plan.n]
+
+    def sync(self):
+        err = _Error()
+        _check(lib().tgx_state_sync(self.h, C.byref(err)), err)
+
+    def reset(self):
+        err = _Error()
+        _check(lib().tgx_state_reset(self.plan.h, self.h, C.byref(err)), err)
+
+    def merge(self, others):
+        hs = (C.c_void_p * max(1, len(others)))(*[o.h for o in others])
+        err = _Error()
+        _check(lib().tgx_merge(self.plan.h, self.h, hs, len(others), C.byref(err)), err)
+
+    def serialize(self):
+        n = C.c_size_t()
+        err = _Error()
+        _check(lib().tgx_state_serialize(self.plan.h, self.h, None, 0, C.byref(n), C.byref(err)), err)
+        buf = (C.c_uint8 * max(1, n.value))()
+        _check(lib().tgx_state_serialize(self.plan.h, self.h, buf, n.value, C.byref(n), C.byref(err)), err)
+        return bytes(buf[: n.value])
+
+    @staticmethod
+    def deserialize(plan, blob):
+        h = C.c_void_p()
+        err = _Error()
+        buf = (C.c_uint8 * max(1, len(blob))).from_buffer_copy(blob) if blob else (C.c_uint8 * 1)()
+        _check(lib().tgx_state_deserialize(plan.h, buf, len(blob), C.byref(h), C.byref(err)), err)
+        return State(plan, _handle=h)
+
+    # KLL
+    def kll_quantile(self, spec_index, phi):
+        out = C.c_double()
+        err = _Error()
+        _check(lib().tgx_kll_quantile(self.plan.h, self.h, spec_index, phi, C.byref(out), C.byref(err)), err)
+        return out.value
+
+    def kll_summary(self, spec_index):
+        n, lv, rt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        mn, mx = C.c_double(), C.c_double()
+        err = _Error()
+        _check(lib().tgx_kll_summary(self.plan.h, self.h, spec_index, C.byref(n), C.byref(mn), C.byref(mx),
+                                     C.byref(lv), C.byref(rt), C.byref(err)), err)
+        return dict(n=n.value, min=mn.value, max=mx.value, num_levels=lv.value, num_retained=rt.value)
+
+    def kll_level_items(self, spec_index, level):
+        import numpy as np
+
+        cnt = C.c_uint64()
+        err = _Error()
+        _check(lib().tgx_kll_level_items(self.plan.h, self.h, spec_index, level, None, 0, C.byref(cnt),
+                                         C.byref(err)), err)
+        out = np.zeros(max(1, cnt.value), dtype=np.float64)
+        _check(lib().tgx_kll_level_items(self.plan.h, self.h, spec_index, level, out.ctypes.data, cnt.value,
+                                         C.byref(cnt), C.byref(err)), err)
+        return out[: cnt.value]
+
+    # distinct key exchange
+    def distinct_export(self, spec_index, world):
+        ptr = C.c_void_p()
+        counts = (C.c_uint64 * world)()
+        err = _Error()
+        _check(lib().tgx_distinct_export(self.plan.h, self.h, spec_index, world, C.byref(ptr), counts,
+                                         C.byref(err)), err)
+        return ptr.value, list(counts)
+
+    def distinct_import(self, spec_index, device_ptr, n_records):
+        err = _Error()
+        _check(lib().tgx_distinct_import(self.plan.h, self.h, spec_index, device_ptr, n_records, C.byref(err)),
+               err)
+
+    # profiling
+    def profile_enable(self, on=True):
+        lib().tgx_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        lib().tgx_profile_reset(self.h)
+
+    def profile_get(self, kernel):
+        ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
+        err = _Error()
+        _check(lib().tgx_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(b), C.byref(err)),
+               err)
+        return dict(total_ms=ms.value, launches=n.value, bytes=b.value)

@@ -1,0 +1,200 @@
+// internal.h -- host-side structures behind the opaque handles of include/tgx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tgx.h"
+#include "kernels/device_types.h"
+#include "kernels/distinct_types.h"
+#include "kll_host.h"
+
+namespace tgx {
+
+// ---- kernel launchers (defined in kernels/*.hip) ----------------------------------------------
+void launch_scan_pivot(const ScanColDesc *d_cols, int n_cols, double *d_pivots, int32_t *d_pivot_set,
+                       const int32_t *d_acc_index, hipStream_t stream);
+void launch_scan_main_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
+                           ScanPartial *d_partials, hipStream_t stream);
+void launch_scan_reduce_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
+                             ScanPartial *d_partials, ScanAcc *d_accs, const int32_t *d_acc_index,
+                             hipStream_t stream);
+void launch_count(const CountColDesc *d_cols, int n_cols, int blocks_per_col,
+                  unsigned long long *d_block_counts, CountAcc *d_accs, const int32_t *d_acc_index,
+                  hipStream_t stream);
+size_t comoments_partial_bytes();
+void launch_comoments(const ComomentColDesc *d_descs, int n_pairs, int blocks_per_pair,
+                      void *d_partials, ComomentAcc *d_accs, const int32_t *d_acc_index,
+                      hipStream_t stream);
+void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
+                          unsigned long long *d_counters, hipStream_t stream);
+void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
+                            unsigned long long *d_counters, hipStream_t stream);
+void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
+                        unsigned long long *d_counters, hipStream_t stream);
+void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,
+                           unsigned long long *d_counters, hipStream_t stream);
+void launch_hash_import(const KeyRecord *recs, uint64_t n, const HashSetView &dst, int want_mult,
+                        unsigned long long *d_counters, hipStream_t stream);
+void launch_hash_export_count(const HashSetView &src, uint32_t world, unsigned long long *d_counts,
+                              hipStream_t stream);
+void launch_hash_export_scatter(const HashSetView &src, uint32_t world, int want_mult,
+                                unsigned long long *d_cursors, KeyRecord *out, hipStream_t stream);
+void launch_bitmap_export_count(const BitmapView &bm, uint32_t world, unsigned long long *d_counts,
+                                hipStream_t stream);
+void launch_bitmap_export_scatter(const BitmapView &bm, uint32_t world, int want_mult,
+                                  unsigned long long *d_cursors, KeyRecord *out, hipStream_t stream);
+
+// ---- plan ---------------------------------------------------------------------------------------
+struct ScanTask {
+  int column;
+  bool variance;
+};
+struct CountTask {
+  int column;
+};
+struct DistinctTask {
+  int column;
+  bool multiplicity;
+  int scan_slot;  // scan task that provides MIN/MAX for the bitmap decision
+};
+struct ComomentTask {
+  int col_x, col_y;
+};
+struct KllTask {
+  int column;
+  uint32_t k;
+};
+
+enum class Source { kScan, kCount };
+
+struct SpecBinding {
+  int kind;
+  int slot;         // task index within its kind
+  Source count_src; // TGX_CHECK_COUNT: where total / non_null come from
+};
+
+}  // namespace tgx
+
+struct tgx_plan {
+  std::vector<tgx_check_spec> specs;
+  std::vector<std::string> patterns;
+  std::vector<tgx::SpecBinding> bind;
+  std::vector<tgx::ScanTask> scan;
+  std::vector<tgx::CountTask> count;
+  std::vector<tgx::DistinctTask> distinct;
+  std::vector<tgx::ComomentTask> como;
+  std::vector<tgx::KllTask> kll;
+  int n_columns_needed = 0;  // 1 + max column index
+  void *regex = nullptr;     // tgx::RegexPlan (regex_device.cpp)
+};
+
+namespace tgx {
+
+// device buffer that grows on demand
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) {
+    o.p = nullptr;
+    o.cap = 0;
+  }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      cap = o.cap;
+      o.p = nullptr;
+      o.cap = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  template <class T>
+  T *as() const {
+    return (T *)p;
+  }
+};
+
+enum class DistinctMode { kUndecided, kBitmap, kHash, kHostOnly };
+
+struct DistinctState {
+  DistinctMode mode = DistinctMode::kUndecided;
+  int col_type = 0;
+  // bitmap
+  DevBuf seen, twice;
+  int64_t base = 0;
+  uint64_t range = 0;
+  // hash
+  DevBuf keys, dup;
+  uint64_t capacity = 0;         // slots (power of two)
+  uint64_t rows_upper_bound = 0; // host-side bound on keys in the table
+  // counters (device) + host-side totals
+  DevBuf counters;
+  int64_t total_rows = 0;  // COUNT(*) over batches handled on this device
+  // host-only part (deserialized / merged-in owner-partitioned partial states)
+  bool partitioned = false;
+  uint64_t h_total = 0, h_non_null = 0, h_distinct = 0, h_twice = 0, h_empty_rows = 0;
+  // export scratch
+  DevBuf export_records, export_counts;
+};
+
+struct ProfileEntry {
+  double total_ms = 0;
+  uint64_t launches = 0;
+  uint64_t bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<uint64_t> pending_bytes;
+};
+
+}  // namespace tgx
+
+struct tgx_state {
+  const tgx_plan *plan = nullptr;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool device_ready = false;  // device-side buffers allocated
+  int64_t batches = 0;
+  std::vector<int> col_types;  // per plan column, 0 = not seen yet
+
+  // device accumulators
+  tgx::DevBuf d_scan_acc, d_count_acc, d_como_acc, d_pivots, d_pivot_set;
+  // per-update scratch
+  tgx::DevBuf d_scan_desc, d_scan_index, d_scan_partials;
+  tgx::DevBuf d_count_desc, d_count_index, d_count_blocks;
+  tgx::DevBuf d_como_desc, d_como_index, d_como_partials;
+  std::vector<std::unique_ptr<tgx::DevBuf>> staging;  // host columns copied to the device
+  size_t staging_used = 0;
+
+  // host accumulators: contributions merged in from other states / deserialized blobs
+  std::vector<tgx::ScanAcc> h_scan;
+  std::vector<tgx::CountAcc> h_count;
+  std::vector<tgx::ComomentAcc> h_como;
+  std::vector<tgx::DistinctState> distinct;
+  std::vector<tgx::KllHost> h_kll;
+  void *kll = nullptr;    // tgx::KllDeviceState (kll_device.cpp)
+  void *regex = nullptr;  // tgx::RegexState (regex_device.cpp)
+
+  // rows handled by host-answered COUNT tasks (columns without a validity buffer)
+  bool profiling = false;
+  std::map<std::string, tgx::ProfileEntry> profile;
+};

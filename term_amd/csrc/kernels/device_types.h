@@ -1,0 +1,82 @@
+// Device-visible descriptors and partial-state layouts shared by the HIP kernels and the C-ABI
+// host code (term_amd/csrc/tgx_api.cpp).  gfx950 only.
+#pragma once
+#include <stdint.h>
+
+namespace tgx {
+
+constexpr int kScanBlock = 256;      // 4 waves of 64
+constexpr int kWavesPerBlock = 4;
+constexpr int kTileRows = 512;       // rows one wave consumes per iteration: 4 x (64 lanes x 16 B)
+constexpr int kMaxScanBlocksPerCol = 2048;  // 256 CUs x 8 resident 256-thread blocks
+
+// One numeric column of one batch, as the scan kernel sees it.
+struct ScanColDesc {
+  const void *values;       // element 0 of the Arrow values buffer (int64 / float64)
+  const uint8_t *validity;  // LSB-first bitmap or nullptr
+  int64_t offset;           // Arrow offset (slots)
+  int64_t length;           // rows
+  int64_t head;             // rows [0, head): ragged edge, per-lane path
+  int64_t n_tiles;          // full kTileRows tiles starting at row `head` (0 => whole column ragged)
+  int32_t is_float;
+  int32_t want_variance;
+  const double *pivot;      // device scalar: shift for the variance lanes (may be nullptr)
+};
+
+// Per (column, block) partial written by scan_kernel; reduced in fixed order by scan_reduce_kernel.
+struct ScanPartial {
+  int64_t non_null;
+  int64_t min_k, max_k;     // int64 values, or IEEE totalOrder keys of the doubles
+  uint64_t sum_lo;          // int64 columns: 128-bit two's complement sum
+  int64_t sum_hi;
+  double sum, comp;         // float64 columns: two-sum compensated sum (sum + comp)
+  double s1, s2;            // sum(x - pivot), sum((x - pivot)^2) over doubles
+};
+
+// Running per-column state (device resident between batches, merged on the host at finalize).
+struct ScanAcc {
+  int64_t total;            // rows seen
+  int64_t non_null;
+  int64_t min_k, max_k;
+  uint64_t sum_lo;
+  int64_t sum_hi;
+  double sum, comp;
+  // variance lanes as (n, mean, M2) so batches / ranks merge with Chan's formula
+  int64_t var_n;
+  double var_mean, var_m2;
+  int32_t is_float;
+  int32_t pad;
+};
+
+// Validity-only columns (COUNT(*), COUNT(col)).
+struct CountColDesc {
+  const uint8_t *validity;  // never nullptr here (no-validity columns are answered on the host)
+  int64_t offset;
+  int64_t length;
+};
+
+struct CountAcc {
+  int64_t total;
+  int64_t non_null;
+};
+
+// Two-column raw co-moments.
+struct ComomentColDesc {
+  const void *x, *y;
+  const uint8_t *xv, *yv;
+  int64_t xoff, yoff;
+  int64_t length;
+  int32_t x_is_float, y_is_float;
+};
+
+struct ComomentAcc {
+  int64_t total;
+  int64_t n;
+  double s[5], c[5];  // sum_x, sum_y, sum_x2, sum_y2, sum_xy as (sum, compensation)
+};
+
+__host__ __device__ inline int64_t f64_total_key(int64_t bits) {
+  return bits ^ (int64_t)(((uint64_t)(bits >> 63)) >> 1);
+}
+
+}  // namespace tgx

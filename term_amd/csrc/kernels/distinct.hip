@@ -1,0 +1,355 @@
+// distinct.hip -- exact COUNT(DISTINCT col) and GROUP BY col multiplicity for gfx950.
+//
+//   COUNT(DISTINCT c)                                   TG/constraints/uniqueness.rs:612-617
+//   SUM(CASE WHEN cnt = 1 ...) over GROUP BY c          TG/constraints/uniqueness.rs:671-681
+//
+// Keys are 64-bit patterns (Int64 values; Float64 by bit pattern, as DataFusion hashes floats).
+// Two device-resident set representations, chosen per column by the host from the running
+// MIN/MAX of the column (tgx_api.cpp):
+//   * range bitmap: 1 bit per value of [base, base + range) (+1 "seen twice" bit when multiplicity
+//     is wanted).  global atomicOr per row; the bit's previous value says whether the key is new.
+//   * open-addressing hash set (linear probing, 64-bit atomicCAS claim), capacity 2^k >= 2 x keys;
+//     the all-ones pattern doubles as EMPTY and is tracked by a side counter.
+// Device-scope atomics execute at the memory side, so inserts from all 8 XCDs are coherent
+// (MI355X_MICROARCH.md "Global float atomics" / SURVEY.md section 7 notes).  Counters are
+// block-reduced first: one atomicAdd per block, not per row.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "distinct_types.h"
+
+namespace tgx {
+
+typedef const int64_t __attribute__((address_space(1))) *global_i64_ptr;
+typedef const uint8_t __attribute__((address_space(1))) *global_u8_ptr;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  // splitmix64 finaliser
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+
+__device__ __forceinline__ void block_add2(unsigned long long a, unsigned long long b,
+                                           unsigned long long *ga, unsigned long long *gb) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    a += __shfl_down(a, d, 64);
+    b += __shfl_down(b, d, 64);
+  }
+  __shared__ unsigned long long sa[4], sb[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sa[wave] = a;
+    sb[wave] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long ta = sa[0] + sa[1] + sa[2] + sa[3], tb = sb[0] + sb[1] + sb[2] + sb[3];
+    if (ta) atomicAdd(ga, ta);
+    if (tb) atomicAdd(gb, tb);
+  }
+}
+
+// returns 1 if the key was new; *became_dup = 1 if this insert is the key's second sighting
+__device__ __forceinline__ int hash_insert(const HashSetView &t, uint64_t key, int want_mult,
+                                           int weight_two, int *became_dup) {
+  uint64_t h = mix64(key) & t.mask;
+  for (;;) {
+    unsigned long long old =
+        atomicCAS((unsigned long long *)&t.keys[h], (unsigned long long)kEmptyKey,
+                  (unsigned long long)key);
+    if (old == kEmptyKey) {
+      if (want_mult && weight_two) {
+        atomicOr(&t.dup[h >> 5], 1u << (h & 31));
+        *became_dup = 1;
+      }
+      return 1;
+    }
+    if (old == key) {
+      if (want_mult) {
+        const uint32_t bit = 1u << (h & 31);
+        // plain read first: most duplicates of a hot key find the bit already set
+        if (!(__hip_atomic_load(&t.dup[h >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
+          uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
+          *became_dup = (prev & bit) ? 0 : 1;
+        }
+      }
+      return 0;
+    }
+    h = (h + 1) & t.mask;
+  }
+}
+
+// One row per lane, grid-stride.  counters: [0] distinct, [1] keys seen at least twice,
+// [2] rows whose key is the all-ones pattern (EMPTY stand-in), [3] non-null rows.
+__global__ __launch_bounds__(256) void distinct_hash_kernel(DistinctColDesc d, HashSetView t,
+                                                             unsigned long long *counters) {
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  unsigned long long n_new = 0, n_dup = 0, n_empty = 0, n_valid = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
+    bool valid = true;
+    if (vbits) {
+      int64_t b = d.offset + i;
+      valid = (vbits[b >> 3] >> (b & 7)) & 1;
+    }
+    if (!valid) continue;
+    n_valid++;
+    uint64_t key = (uint64_t)vals[i];
+    if (key == kEmptyKey) {
+      n_empty++;
+      continue;
+    }
+    int became_dup = 0;
+    n_new += hash_insert(t, key, d.want_multiplicity, 0, &became_dup);
+    n_dup += became_dup;
+  }
+  block_add2(n_new, n_dup, &counters[0], &counters[1]);
+  __syncthreads();
+  block_add2(n_empty, n_valid, &counters[2], &counters[3]);
+}
+
+// Range bitmap: bit (key - base) of `seen`; `twice` marks keys seen again.
+__global__ __launch_bounds__(256) void distinct_bitmap_kernel(DistinctColDesc d, BitmapView bm,
+                                                               unsigned long long *counters) {
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  unsigned long long n_new = 0, n_dup = 0, n_out = 0, n_valid = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
+    bool valid = true;
+    if (vbits) {
+      int64_t b = d.offset + i;
+      valid = (vbits[b >> 3] >> (b & 7)) & 1;
+    }
+    if (!valid) continue;
+    n_valid++;
+    uint64_t rel = (uint64_t)vals[i] - (uint64_t)bm.base;  // wraps for keys below base
+    if (rel >= bm.range) {
+      n_out++;  // host guarantees this cannot happen; counted so a violation is detected
+      continue;
+    }
+    const uint32_t bit = 1u << (rel & 31);
+    uint32_t prev = atomicOr(&bm.seen[rel >> 5], bit);
+    if (!(prev & bit)) {
+      n_new++;
+    } else if (d.want_multiplicity) {
+      uint32_t p2 = atomicOr(&bm.twice[rel >> 5], bit);
+      if (!(p2 & bit)) n_dup++;
+    }
+  }
+  block_add2(n_new, n_dup, &counters[0], &counters[1]);
+  __syncthreads();
+  block_add2(n_out, n_valid, &counters[4], &counters[3]);
+}
+
+// Re-inserts every key of `src` into `dst` (growth, merge, bitmap -> hash conversion).
+__global__ __launch_bounds__(256) void hash_rehash_kernel(HashSetView src, HashSetView dst,
+                                                           int want_mult,
+                                                           unsigned long long *counters) {
+  unsigned long long n_new = 0, n_dup = 0;
+  const uint64_t cap = src.mask + 1;
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap;
+       s += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t key = src.keys[s];
+    if (key == kEmptyKey) continue;
+    int two = want_mult ? ((src.dup[s >> 5] >> (s & 31)) & 1) : 0;
+    int became_dup = 0;
+    int is_new = hash_insert(dst, key, want_mult, two, &became_dup);
+    if (!is_new && want_mult && two) {
+      // key present on both sides and already a duplicate on the source side: hash_insert has
+      // set the bit (or found it set); became_dup tells whether it was newly set
+    }
+    n_new += is_new;
+    n_dup += became_dup;
+  }
+  block_add2(n_new, n_dup, &counters[0], &counters[1]);
+}
+
+__global__ __launch_bounds__(256) void bitmap_to_hash_kernel(BitmapView bm, HashSetView dst,
+                                                              int want_mult,
+                                                              unsigned long long *counters) {
+  unsigned long long n_new = 0, n_dup = 0, n_empty = 0;
+  const uint64_t words = (bm.range + 31) >> 5;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words;
+       w += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t seen = bm.seen[w];
+    uint32_t twice = want_mult ? bm.twice[w] : 0;
+    while (seen) {
+      int b = __builtin_ctz(seen);
+      seen &= seen - 1;
+      uint64_t key = (uint64_t)bm.base + (w << 5) + (uint64_t)b;
+      if (key == kEmptyKey) {  // cannot live in the table: goes to the side counter
+        n_empty += ((twice >> b) & 1) ? 2 : 1;
+        continue;
+      }
+      int became_dup = 0;
+      n_new += hash_insert(dst, key, want_mult, (twice >> b) & 1, &became_dup);
+      n_dup += became_dup;
+    }
+  }
+  block_add2(n_new, n_dup, &counters[0], &counters[1]);
+  __syncthreads();
+  block_add2(n_empty, 0ull, &counters[2], &counters[5]);
+}
+
+// Inserts 16-byte {key, count} records (count saturates at 2) -- merge / cross-rank import.
+__global__ __launch_bounds__(256) void hash_import_kernel(const KeyRecord *recs, uint64_t n,
+                                                           HashSetView dst, int want_mult,
+                                                           unsigned long long *counters) {
+  unsigned long long n_new = 0, n_dup = 0, n_empty = 0, n_empty_dup = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    KeyRecord r = recs[i];
+    if (r.key == kEmptyKey) {
+      n_empty += r.count;
+      continue;
+    }
+    int became_dup = 0;
+    n_new += hash_insert(dst, r.key, want_mult, r.count >= 2, &became_dup);
+    n_dup += became_dup;
+  }
+  block_add2(n_new, n_dup, &counters[0], &counters[1]);
+  __syncthreads();
+  block_add2(n_empty, n_empty_dup, &counters[2], &counters[5]);
+}
+
+// Export: pass 1 counts records per owner, pass 2 scatters them (owner = mix(key) % world).
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t world) {
+  return (uint32_t)((mix64(key ^ 0x9e3779b97f4a7c15ULL) >> 32) % world);
+}
+
+__global__ __launch_bounds__(256) void hash_export_count_kernel(HashSetView src, uint32_t world,
+                                                                 unsigned long long *owner_counts) {
+  const uint64_t cap = src.mask + 1;
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap;
+       s += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t key = src.keys[s];
+    if (key == kEmptyKey) continue;
+    atomicAdd(&owner_counts[owner_of(key, world)], 1ull);
+  }
+}
+
+__global__ __launch_bounds__(256) void hash_export_scatter_kernel(HashSetView src, uint32_t world,
+                                                                   int want_mult,
+                                                                   unsigned long long *cursors,
+                                                                   KeyRecord *out) {
+  const uint64_t cap = src.mask + 1;
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap;
+       s += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t key = src.keys[s];
+    if (key == kEmptyKey) continue;
+    unsigned long long pos = atomicAdd(&cursors[owner_of(key, world)], 1ull);
+    KeyRecord r;
+    r.key = key;
+    r.count = (want_mult && ((src.dup[s >> 5] >> (s & 31)) & 1)) ? 2 : 1;
+    out[pos] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void bitmap_export_count_kernel(BitmapView bm, uint32_t world,
+                                                                   unsigned long long *owner_counts) {
+  const uint64_t words = (bm.range + 31) >> 5;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words;
+       w += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t seen = bm.seen[w];
+    while (seen) {
+      int b = __builtin_ctz(seen);
+      seen &= seen - 1;
+      uint64_t key = (uint64_t)bm.base + (w << 5) + (uint64_t)b;
+      atomicAdd(&owner_counts[owner_of(key, world)], 1ull);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bitmap_export_scatter_kernel(BitmapView bm, uint32_t world,
+                                                                     int want_mult,
+                                                                     unsigned long long *cursors,
+                                                                     KeyRecord *out) {
+  const uint64_t words = (bm.range + 31) >> 5;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words;
+       w += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t seen = bm.seen[w];
+    uint32_t twice = want_mult ? bm.twice[w] : 0;
+    while (seen) {
+      int b = __builtin_ctz(seen);
+      seen &= seen - 1;
+      uint64_t key = (uint64_t)bm.base + (w << 5) + (uint64_t)b;
+      unsigned long long pos = atomicAdd(&cursors[owner_of(key, world)], 1ull);
+      KeyRecord r;
+      r.key = key;
+      r.count = ((twice >> b) & 1) ? 2 : 1;
+      out[pos] = r;
+    }
+  }
+}
+
+static inline int grid_for(uint64_t items) {
+  uint64_t blocks = (items + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return (int)blocks;
+}
+
+void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
+                          unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(distinct_hash_kernel, dim3(grid_for((uint64_t)d.length)), dim3(256), 0, stream,
+                     d, t, d_counters);
+}
+
+void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
+                            unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(distinct_bitmap_kernel, dim3(grid_for((uint64_t)d.length)), dim3(256), 0,
+                     stream, d, bm, d_counters);
+}
+
+void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
+                        unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(hash_rehash_kernel, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream, src,
+                     dst, want_mult, d_counters);
+}
+
+void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,
+                           unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(bitmap_to_hash_kernel, dim3(grid_for((bm.range + 31) >> 5)), dim3(256), 0,
+                     stream, bm, dst, want_mult, d_counters);
+}
+
+void launch_hash_import(const KeyRecord *recs, uint64_t n, const HashSetView &dst, int want_mult,
+                        unsigned long long *d_counters, hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(hash_import_kernel, dim3(grid_for(n)), dim3(256), 0, stream, recs, n, dst,
+                     want_mult, d_counters);
+}
+
+void launch_hash_export_count(const HashSetView &src, uint32_t world, unsigned long long *d_counts,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(hash_export_count_kernel, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream,
+                     src, world, d_counts);
+}
+
+void launch_hash_export_scatter(const HashSetView &src, uint32_t world, int want_mult,
+                                unsigned long long *d_cursors, KeyRecord *out, hipStream_t stream) {
+  hipLaunchKernelGGL(hash_export_scatter_kernel, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream,
+                     src, world, want_mult, d_cursors, out);
+}
+
+void launch_bitmap_export_count(const BitmapView &bm, uint32_t world, unsigned long long *d_counts,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL(bitmap_export_count_kernel, dim3(grid_for((bm.range + 31) >> 5)), dim3(256), 0,
+                     stream, bm, world, d_counts);
+}
+
+void launch_bitmap_export_scatter(const BitmapView &bm, uint32_t world, int want_mult,
+                                  unsigned long long *d_cursors, KeyRecord *out,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(bitmap_export_scatter_kernel, dim3(grid_for((bm.range + 31) >> 5)), dim3(256),
+                     0, stream, bm, world, want_mult, d_cursors, out);
+}
+
+}  // namespace tgx

@@ -1,0 +1,48 @@
+// Views of the device-resident key sets behind TGX_CHECK_DISTINCT (see distinct.hip).
+#pragma once
+#include <stdint.h>
+
+namespace tgx {
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFULL;
+
+struct DistinctColDesc {
+  const void *values;       // int64 / float64 bit patterns
+  const uint8_t *validity;  // or nullptr
+  int64_t offset;
+  int64_t length;
+  int32_t want_multiplicity;
+  int32_t pad;
+};
+
+struct HashSetView {
+  uint64_t *keys;  // capacity = mask + 1 slots, kEmptyKey = free
+  uint32_t *dup;   // 1 bit per slot: key seen at least twice (only with multiplicity)
+  uint64_t mask;
+};
+
+struct BitmapView {
+  uint32_t *seen;   // bit (key - base)
+  uint32_t *twice;  // same indexing; only with multiplicity
+  int64_t base;
+  uint64_t range;   // number of representable keys
+};
+
+// 16-byte record used by merge / serialize / the cross-rank key exchange.
+struct KeyRecord {
+  uint64_t key;
+  uint64_t count;  // saturates at 2
+};
+
+// counters[] slots shared by the kernels of distinct.hip
+enum {
+  kCntDistinct = 0,   // keys in the set (excluding the EMPTY stand-in)
+  kCntTwice = 1,      // keys seen at least twice
+  kCntEmptyRows = 2,  // rows (or record counts) carrying the all-ones key
+  kCntValidRows = 3,  // non-null rows scanned
+  kCntOutOfRange = 4, // bitmap mode: keys outside [base, base+range) -- must stay 0
+  kCntSpare = 5,
+  kNumDistinctCounters = 8
+};
+
+}  // namespace tgx

@@ -1,0 +1,1396 @@
+// tgx_api.cpp -- the C ABI of include/tgx.h: plans, states, batch updates, merges, results.
+//
+// Host-side only bookkeeping lives here; every per-row computation is a HIP kernel under
+// kernels/.  There is no CPU fallback: without a gfx950 device the compute entry points fail.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "internal.h"
+#include "kll_device.h"
+#include "regex_device.h"
+
+using namespace tgx;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+static tgx_status fail(tgx_error *err, tgx_status code, const char *fmt, ...) {
+  if (err) {
+    err->code = (int32_t)code;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err->msg, sizeof(err->msg), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(err, e_ == hipErrorOutOfMemory ? TGX_OUT_OF_MEMORY : TGX_DEVICE_ERROR,      \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                             \
+  } while (0)
+
+#define TGX_TRY(expr)                  \
+  do {                                 \
+    tgx_status s_ = (expr);            \
+    if (s_ != TGX_OK) return s_;       \
+  } while (0)
+
+extern "C" const char *tgx_status_name(int32_t s) {
+  switch (s) {
+    case TGX_OK: return "TGX_OK";
+    case TGX_INVALID_ARGUMENT: return "TGX_INVALID_ARGUMENT";
+    case TGX_UNSUPPORTED: return "TGX_UNSUPPORTED";
+    case TGX_DEVICE_ERROR: return "TGX_DEVICE_ERROR";
+    case TGX_OUT_OF_MEMORY: return "TGX_OUT_OF_MEMORY";
+    case TGX_INTERNAL: return "TGX_INTERNAL";
+    case TGX_NO_DEVICE: return "TGX_NO_DEVICE";
+    default: return "TGX_UNKNOWN";
+  }
+}
+
+extern "C" uint32_t tgx_abi_version(void) { return TGX_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// device context
+namespace {
+struct Context {
+  std::mutex mu;
+  bool inited = false;
+  int device = -1;
+  int n_cu = 256;
+  uint64_t distinct_hint = 0;
+  char arch[64] = {0};
+} g_ctx;
+}  // namespace
+
+extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) {
+  std::lock_guard<std::mutex> lock(g_ctx.mu);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(err, TGX_NO_DEVICE, "no HIP device visible (%s); libtgx has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  int dev = opts ? opts->device_id : -1;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  }
+  if (dev >= count) return fail(err, TGX_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", dev, count);
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(err, TGX_NO_DEVICE, "device %d is %s; libtgx kernels are built for gfx950 only", dev,
+                prop.gcnArchName);
+  g_ctx.device = dev;
+  g_ctx.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  snprintf(g_ctx.arch, sizeof(g_ctx.arch), "%s", prop.gcnArchName);
+  g_ctx.distinct_hint = opts ? opts->distinct_capacity_hint : 0;
+  g_ctx.inited = true;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_ctx.mu);
+  g_ctx.inited = false;
+  return TGX_OK;
+}
+
+static tgx_status need_device(tgx_error *err) {
+  if (!g_ctx.inited)
+    return fail(err, TGX_NO_DEVICE, "tgx_init has not succeeded: no gfx950 device, and libtgx has no CPU path");
+  return TGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan
+extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_specs, tgx_plan **out,
+                                      tgx_error *err) {
+  if (!out) return fail(err, TGX_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (n_specs > 0 && !specs) return fail(err, TGX_INVALID_ARGUMENT, "specs is NULL");
+  std::unique_ptr<tgx_plan> plan(new tgx_plan());
+  plan->specs.assign(specs, specs + n_specs);
+  plan->patterns.resize(n_specs);
+  plan->bind.resize(n_specs);
+  auto find_scan = [&](int col) -> int {
+    for (size_t i = 0; i < plan->scan.size(); i++)
+      if (plan->scan[i].column == col) return (int)i;
+    return -1;
+  };
+  auto need_scan = [&](int col, bool var) -> int {
+    int s = find_scan(col);
+    if (s < 0) {
+      plan->scan.push_back({col, var});
+      s = (int)plan->scan.size() - 1;
+    } else if (var) {
+      plan->scan[s].variance = true;
+    }
+    return s;
+  };
+  int max_col = -1;
+  // pass 1: everything except COUNT
+  for (size_t i = 0; i < n_specs; i++) {
+    tgx_check_spec &sp = plan->specs[i];
+    if (sp.column < 0) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: negative column index", i);
+    max_col = std::max(max_col, sp.column);
+    plan->bind[i].kind = sp.kind;
+    plan->bind[i].slot = -1;
+    plan->bind[i].count_src = Source::kCount;
+    switch (sp.kind) {
+      case TGX_CHECK_COUNT:
+        break;
+      case TGX_CHECK_NUMERIC_STATS:
+        plan->bind[i].slot = need_scan(sp.column, (sp.flags & TGX_FLAG_VARIANCE) != 0);
+        break;
+      case TGX_CHECK_DISTINCT: {
+        int slot = -1;
+        for (size_t d = 0; d < plan->distinct.size(); d++)
+          if (plan->distinct[d].column == sp.column) slot = (int)d;
+        bool mult = (sp.flags & TGX_FLAG_MULTIPLICITY) != 0;
+        if (slot < 0) {
+          plan->distinct.push_back({sp.column, mult, -1});
+          slot = (int)plan->distinct.size() - 1;
+        } else if (mult) {
+          plan->distinct[slot].multiplicity = true;
+        }
+        plan->bind[i].slot = slot;
+        break;
+      }
+      case TGX_CHECK_COMOMENTS: {
+        if (sp.column2 < 0) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: COMOMENTS needs column2", i);
+        max_col = std::max(max_col, sp.column2);
+        int slot = -1;
+        for (size_t c = 0; c < plan->como.size(); c++)
+          if (plan->como[c].col_x == sp.column && plan->como[c].col_y == sp.column2) slot = (int)c;
+        if (slot < 0) {
+          plan->como.push_back({sp.column, sp.column2});
+          slot = (int)plan->como.size() - 1;
+        }
+        plan->bind[i].slot = slot;
+        break;
+      }
+      case TGX_CHECK_KLL: {
+        if (sp.kll_k < 2) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: k must be at least 2", i);
+        int slot = -1;
+        for (size_t c = 0; c < plan->kll.size(); c++)
+          if (plan->kll[c].column == sp.column && plan->kll[c].k == sp.kll_k) slot = (int)c;
+        if (slot < 0) {
+          plan->kll.push_back({sp.column, sp.kll_k});
+          slot = (int)plan->kll.size() - 1;
+        }
+        plan->bind[i].slot = slot;
+        break;
+      }
+      case TGX_CHECK_REGEX_MATCH: {
+        if (!sp.pattern && sp.pattern_len) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: pattern is NULL", i);
+        plan->patterns[i].assign(sp.pattern ? sp.pattern : "", sp.pattern_len);
+        int slot = -1;
+        tgx_status st = regex_plan_add(plan.get(), (int)i, &slot, err);
+        if (st != TGX_OK) return st;
+        plan->bind[i].slot = slot;
+        break;
+      }
+      default:
+        return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: unknown check kind %d", i, sp.kind);
+    }
+  }
+  // Int64 DISTINCT columns want the running MIN/MAX for the range-bitmap decision
+  for (auto &d : plan->distinct) d.scan_slot = need_scan(d.column, false);
+  // pass 2: COUNT rides on a scan of the same column when there is one
+  for (size_t i = 0; i < n_specs; i++) {
+    tgx_check_spec &sp = plan->specs[i];
+    if (sp.kind != TGX_CHECK_COUNT) continue;
+    int s = find_scan(sp.column);
+    if (s >= 0) {
+      plan->bind[i].slot = s;
+      plan->bind[i].count_src = Source::kScan;
+      continue;
+    }
+    int slot = -1;
+    for (size_t c = 0; c < plan->count.size(); c++)
+      if (plan->count[c].column == sp.column) slot = (int)c;
+    if (slot < 0) {
+      plan->count.push_back({sp.column});
+      slot = (int)plan->count.size() - 1;
+    }
+    plan->bind[i].slot = slot;
+    plan->bind[i].count_src = Source::kCount;
+  }
+  plan->n_columns_needed = max_col + 1;
+  // re-point pattern pointers at the plan-owned copies
+  for (size_t i = 0; i < n_specs; i++) {
+    plan->specs[i].pattern = plan->patterns[i].empty() ? nullptr : plan->patterns[i].data();
+    plan->specs[i].pattern_len = plan->patterns[i].size();
+  }
+  *out = plan.release();
+  return TGX_OK;
+}
+
+extern "C" void tgx_plan_destroy(tgx_plan *plan) {
+  if (!plan) return;
+  regex_plan_free(plan);
+  delete plan;
+}
+extern "C" size_t tgx_plan_num_specs(const tgx_plan *plan) { return plan ? plan->specs.size() : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// state
+static ScanAcc scan_acc_identity() {
+  ScanAcc a;
+  memset(&a, 0, sizeof(a));
+  a.min_k = INT64_MAX;
+  a.max_k = INT64_MIN;
+  return a;
+}
+
+static void host_two_sum(double &s, double &c, double x) {
+  double t = s + x;
+  double bp = t - s;
+  c += (s - (t - bp)) + (x - bp);
+  s = t;
+}
+
+static void scan_acc_merge(ScanAcc &a, const ScanAcc &b) {
+  if (b.total == 0) return;
+  a.is_float = b.is_float;
+  a.total += b.total;
+  a.non_null += b.non_null;
+  a.min_k = std::min(a.min_k, b.min_k);
+  a.max_k = std::max(a.max_k, b.max_k);
+  uint64_t lo = a.sum_lo + b.sum_lo;
+  a.sum_hi += b.sum_hi + (lo < a.sum_lo ? 1 : 0);
+  a.sum_lo = lo;
+  double c = a.comp + b.comp;
+  host_two_sum(a.sum, c, b.sum);
+  a.comp = c;
+  if (b.var_n > 0) {
+    if (a.var_n == 0) {
+      a.var_n = b.var_n;
+      a.var_mean = b.var_mean;
+      a.var_m2 = b.var_m2;
+    } else {
+      double na = (double)a.var_n, nb = (double)b.var_n, n = na + nb;
+      double delta = b.var_mean - a.var_mean;
+      a.var_mean += delta * nb / n;
+      a.var_m2 += b.var_m2 + delta * delta * na * nb / n;
+      a.var_n += b.var_n;
+    }
+  }
+}
+
+static void como_acc_merge(ComomentAcc &a, const ComomentAcc &b) {
+  a.total += b.total;
+  a.n += b.n;
+  for (int k = 0; k < 5; k++) {
+    a.c[k] += b.c[k];
+    host_two_sum(a.s[k], a.c[k], b.s[k]);
+  }
+}
+
+static void state_init_host(tgx_state *st, const tgx_plan *plan) {
+  st->plan = plan;
+  st->col_types.assign(plan->n_columns_needed, 0);
+  st->h_scan.assign(plan->scan.size(), scan_acc_identity());
+  st->h_count.assign(plan->count.size(), CountAcc{0, 0});
+  ComomentAcc z;
+  memset(&z, 0, sizeof(z));
+  st->h_como.assign(plan->como.size(), z);
+  st->distinct.clear();
+  st->distinct.resize(plan->distinct.size());
+  st->h_kll.clear();
+  st->h_kll.resize(plan->kll.size());
+  for (size_t i = 0; i < plan->kll.size(); i++) st->h_kll[i].k = plan->kll[i].k;
+  regex_state_init(st);
+  kll_state_init(st);
+}
+
+static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
+  if (st->device_ready) return TGX_OK;
+  TGX_TRY(need_device(err));
+  const tgx_plan *plan = st->plan;
+  if (!st->stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    st->own_stream = true;
+  }
+  if (!plan->scan.empty()) {
+    std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
+    HIP_TRY(st->d_scan_acc.reserve(init.size() * sizeof(ScanAcc)));
+    HIP_TRY(hipMemcpy(st->d_scan_acc.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
+    HIP_TRY(st->d_pivots.reserve(plan->scan.size() * sizeof(double)));
+    HIP_TRY(st->d_pivot_set.reserve(plan->scan.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemset(st->d_pivots.p, 0, plan->scan.size() * sizeof(double)));
+    HIP_TRY(hipMemset(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t)));
+  }
+  if (!plan->count.empty()) {
+    HIP_TRY(st->d_count_acc.reserve(plan->count.size() * sizeof(CountAcc)));
+    HIP_TRY(hipMemset(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc)));
+  }
+  if (!plan->como.empty()) {
+    HIP_TRY(st->d_como_acc.reserve(plan->como.size() * sizeof(ComomentAcc)));
+    HIP_TRY(hipMemset(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc)));
+  }
+  for (auto &d : st->distinct) {
+    HIP_TRY(d.counters.reserve(kNumDistinctCounters * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long)));
+  }
+  st->device_ready = true;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **out,
+                                       tgx_error *err) {
+  if (!plan || !out) return fail(err, TGX_INVALID_ARGUMENT, "plan/out is NULL");
+  *out = nullptr;
+  tgx_state *st = new tgx_state();
+  state_init_host(st, plan);
+  st->stream = (hipStream_t)hip_stream;
+  st->own_stream = false;
+  *out = st;
+  return TGX_OK;
+}
+
+extern "C" void tgx_state_destroy(tgx_state *st) {
+  if (!st) return;
+  if (st->device_ready && st->stream) (void)hipStreamSynchronize(st->stream);
+  for (auto &kv : st->profile)
+    for (auto &ev : kv.second.pending) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+  regex_state_free(st);
+  kll_state_free(st);
+  if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
+  delete st;
+}
+
+extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) {
+  if (!st) return fail(err, TGX_INVALID_ARGUMENT, "state is NULL");
+  if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
+  hipStream_t stream = st->stream;
+  bool own = st->own_stream;
+  bool prof = st->profiling;
+  // drop device buffers of the variable-size parts, keep the stream
+  regex_state_free(st);
+  kll_state_free(st);
+  st->d_scan_acc.release();
+  st->d_count_acc.release();
+  st->d_como_acc.release();
+  st->d_pivots.release();
+  st->d_pivot_set.release();
+  st->device_ready = false;
+  st->batches = 0;
+  state_init_host(st, plan);
+  st->stream = stream;
+  st->own_stream = own;
+  st->profiling = prof;
+  return TGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling
+static void prof_begin(tgx_state *st, const char *name, uint64_t bytes, hipEvent_t *e0, hipEvent_t *e1) {
+  *e0 = *e1 = nullptr;
+  if (!st->profiling) return;
+  if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) {
+    *e0 = *e1 = nullptr;
+    return;
+  }
+  (void)hipEventRecord(*e0, st->stream);
+  ProfileEntry &pe = st->profile[name];
+  pe.pending_bytes.push_back(bytes);
+}
+static void prof_end(tgx_state *st, const char *name, hipEvent_t e0, hipEvent_t e1) {
+  if (!st->profiling || !e0) return;
+  (void)hipEventRecord(e1, st->stream);
+  st->profile[name].pending.emplace_back(e0, e1);
+}
+struct ProfScope {
+  tgx_state *st;
+  const char *name;
+  hipEvent_t e0, e1;
+  ProfScope(tgx_state *s, const char *n, uint64_t bytes) : st(s), name(n) { prof_begin(s, n, bytes, &e0, &e1); }
+  ~ProfScope() { prof_end(st, name, e0, e1); }
+};
+
+extern "C" tgx_status tgx_profile_enable(tgx_state *st, int32_t on) {
+  if (!st) return TGX_INVALID_ARGUMENT;
+  st->profiling = on != 0;
+  return TGX_OK;
+}
+
+static void prof_resolve(tgx_state *st) {
+  for (auto &kv : st->profile) {
+    ProfileEntry &pe = kv.second;
+    for (size_t i = 0; i < pe.pending.size(); i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pe.pending[i].first, pe.pending[i].second) == hipSuccess) {
+        pe.total_ms += ms;
+        pe.launches += 1;
+        pe.bytes += i < pe.pending_bytes.size() ? pe.pending_bytes[i] : 0;
+      }
+      (void)hipEventDestroy(pe.pending[i].first);
+      (void)hipEventDestroy(pe.pending[i].second);
+    }
+    pe.pending.clear();
+    pe.pending_bytes.clear();
+  }
+}
+
+extern "C" tgx_status tgx_profile_get(tgx_state *st, const char *kernel, double *total_ms,
+                                      uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err) {
+  if (!st || !kernel) return fail(err, TGX_INVALID_ARGUMENT, "state/kernel is NULL");
+  if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
+  prof_resolve(st);
+  auto it = st->profile.find(kernel);
+  if (total_ms) *total_ms = it == st->profile.end() ? 0.0 : it->second.total_ms;
+  if (launches) *launches = it == st->profile.end() ? 0 : it->second.launches;
+  if (algorithmic_bytes) *algorithmic_bytes = it == st->profile.end() ? 0 : it->second.bytes;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_profile_reset(tgx_state *st) {
+  if (!st) return TGX_INVALID_ARGUMENT;
+  if (st->device_ready) (void)hipStreamSynchronize(st->stream);
+  prof_resolve(st);
+  st->profile.clear();
+  return TGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// update
+static bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
+
+static size_t validity_bytes(const tgx_column &c) { return (size_t)((c.offset + c.length + 7) / 8); }
+
+// copies a HOST column's buffers to the device; `out` is the device view
+static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx_error *err) {
+  *out = c;
+  if (c.mem == TGX_MEM_DEVICE) return TGX_OK;
+  if (c.mem != TGX_MEM_HOST) return fail(err, TGX_INVALID_ARGUMENT, "unknown memory space %d", c.mem);
+  auto stage = [&](const void *src, size_t bytes, const void **dst) -> tgx_status {
+    *dst = nullptr;
+    if (!src || bytes == 0) return TGX_OK;
+    if (st->staging_used == st->staging.size()) st->staging.emplace_back(new DevBuf());
+    DevBuf *b = st->staging[st->staging_used++].get();
+    HIP_TRY(b->reserve(bytes + 16));
+    HIP_TRY(hipMemcpyAsync(b->p, src, bytes, hipMemcpyHostToDevice, st->stream));
+    *dst = b->p;
+    return TGX_OK;
+  };
+  const void *p = nullptr;
+  TGX_TRY(stage(c.validity, c.validity ? validity_bytes(c) : 0, &p));
+  out->validity = (const uint8_t *)p;
+  if (is_numeric(c.type)) {
+    TGX_TRY(stage(c.values, (size_t)(c.offset + c.length) * 8, &p));
+    out->values = p;
+  } else if (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) {
+    const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
+    size_t n_off = (size_t)(c.offset + c.length + 1);
+    TGX_TRY(stage(c.offsets, n_off * ow, &p));
+    out->offsets = p;
+    int64_t end = 0;
+    if (c.offsets && c.length + c.offset >= 0)
+      end = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[n_off - 1] : ((const int64_t *)c.offsets)[n_off - 1];
+    TGX_TRY(stage(c.data, (size_t)end, &p));
+    out->data = (const uint8_t *)p;
+  } else {
+    return fail(err, TGX_UNSUPPORTED, "column type %d is not supported", c.type);
+  }
+  out->mem = TGX_MEM_DEVICE;
+  return TGX_OK;
+}
+
+static void fill_scan_desc(const tgx_column &c, bool variance, const double *pivot, ScanColDesc *d) {
+  d->values = c.values;
+  d->validity = c.validity;
+  d->offset = c.offset;
+  d->length = c.length;
+  d->is_float = c.type == TGX_FLOAT64;
+  d->want_variance = variance ? 1 : 0;
+  d->pivot = pivot;
+  int64_t head = (64 - (c.offset & 63)) & 63;
+  if (head > c.length) head = c.length;
+  int64_t n_tiles = (c.length - head) / kTileRows;
+  const uintptr_t vaddr = (uintptr_t)c.values + (uintptr_t)(c.offset + head) * 8;
+  const uintptr_t baddr = (uintptr_t)c.validity + (uintptr_t)((c.offset + head) >> 3);
+  if ((vaddr & 15) != 0 || (c.validity && (baddr & 7) != 0)) n_tiles = 0;  // per-lane path
+  d->head = n_tiles > 0 ? head : 0;
+  d->n_tiles = n_tiles;
+}
+
+static int scan_blocks_for(const ScanColDesc &d, int n_cols_in_launch) {
+  int64_t want;
+  if (d.n_tiles > 0)
+    want = (d.n_tiles + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);  // >= 4 tiles per wave
+  else
+    want = (d.length + kScanBlock * 8 - 1) / (kScanBlock * 8);
+  int cap = std::max(32, (g_ctx.n_cu * 8) / std::max(1, n_cols_in_launch));
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+static uint64_t next_pow2(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+static tgx_status distinct_read_counters(tgx_state *st, DistinctState &ds, unsigned long long *out,
+                                         tgx_error *err) {
+  memset(out, 0, kNumDistinctCounters * sizeof(unsigned long long));
+  if (!ds.counters.p) return TGX_OK;
+  HIP_TRY(hipMemcpyAsync(out, ds.counters.p, kNumDistinctCounters * sizeof(unsigned long long),
+                         hipMemcpyDeviceToHost, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  return TGX_OK;
+}
+
+static HashSetView hash_view(const DistinctState &ds) {
+  HashSetView v;
+  v.keys = ds.keys.as<uint64_t>();
+  v.dup = ds.dup.as<uint32_t>();
+  v.mask = ds.capacity - 1;
+  return v;
+}
+static BitmapView bitmap_view(const DistinctState &ds) {
+  BitmapView v;
+  v.seen = ds.seen.as<uint32_t>();
+  v.twice = ds.twice.as<uint32_t>();
+  v.base = ds.base;
+  v.range = ds.range;
+  return v;
+}
+
+// allocate an empty table of `capacity` slots into (keys, dup)
+static tgx_status hash_alloc(tgx_state *st, DevBuf &keys, DevBuf &dup, uint64_t capacity, bool mult,
+                             tgx_error *err) {
+  HIP_TRY(keys.reserve(capacity * sizeof(uint64_t)));
+  HIP_TRY(hipMemsetAsync(keys.p, 0xFF, capacity * sizeof(uint64_t), st->stream));
+  if (mult) {
+    HIP_TRY(dup.reserve((capacity / 32 + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(dup.p, 0, (capacity / 32 + 1) * sizeof(uint32_t), st->stream));
+  }
+  return TGX_OK;
+}
+
+// make sure the hash table can take `incoming` more keys at load factor <= 0.5
+static tgx_status hash_ensure(tgx_state *st, DistinctState &ds, bool mult, uint64_t incoming,
+                              tgx_error *err) {
+  if (ds.capacity == 0) {
+    uint64_t want = std::max<uint64_t>(incoming, g_ctx.distinct_hint);
+    ds.capacity = next_pow2(std::max<uint64_t>(2 * want, 1024));
+    TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, err));
+    ds.rows_upper_bound = 0;
+  }
+  if (2 * (ds.rows_upper_bound + incoming) <= ds.capacity) {
+    ds.rows_upper_bound += incoming;
+    return TGX_OK;
+  }
+  // the bound says it might not fit: read the real key count
+  unsigned long long c[kNumDistinctCounters];
+  TGX_TRY(distinct_read_counters(st, ds, c, err));
+  uint64_t actual = c[kCntDistinct];
+  if (2 * (actual + incoming) <= ds.capacity) {
+    ds.rows_upper_bound = actual + incoming;
+    return TGX_OK;
+  }
+  uint64_t new_cap = next_pow2(2 * (actual + incoming));
+  DevBuf nk, nd;
+  TGX_TRY(hash_alloc(st, nk, nd, new_cap, mult, err));
+  HashSetView src = hash_view(ds);
+  HashSetView dst{nk.as<uint64_t>(), nd.as<uint32_t>(), new_cap - 1};
+  // re-insertion recounts distinct / twice: zero those two counters first
+  HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));
+  launch_hash_rehash(src, dst, mult ? 1 : 0, ds.counters.as<unsigned long long>(), st->stream);
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  std::swap(ds.keys.p, nk.p);
+  std::swap(ds.keys.cap, nk.cap);
+  std::swap(ds.dup.p, nd.p);
+  std::swap(ds.dup.cap, nd.cap);
+  ds.capacity = new_cap;
+  ds.rows_upper_bound = actual + incoming;
+  return TGX_OK;
+}
+
+static tgx_status bitmap_to_hash(tgx_state *st, DistinctState &ds, bool mult, uint64_t incoming,
+                                 tgx_error *err) {
+  unsigned long long c[kNumDistinctCounters];
+  TGX_TRY(distinct_read_counters(st, ds, c, err));
+  uint64_t actual = c[kCntDistinct];
+  ds.capacity = 0;
+  ds.rows_upper_bound = 0;
+  uint64_t want = std::max<uint64_t>(actual + incoming, g_ctx.distinct_hint);
+  ds.capacity = next_pow2(std::max<uint64_t>(2 * want, 1024));
+  TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, err));
+  HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));
+  launch_bitmap_to_hash(bitmap_view(ds), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
+                        st->stream);
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.seen.release();
+  ds.twice.release();
+  ds.mode = DistinctMode::kHash;
+  ds.rows_upper_bound = actual;
+  return TGX_OK;
+}
+
+static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
+  const DistinctTask &task = st->plan->distinct[slot];
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = task.multiplicity;
+  if (!is_numeric(c.type))
+    return fail(err, TGX_UNSUPPORTED, "DISTINCT on column type %d is not supported yet", c.type);
+  ds.col_type = c.type;
+  ds.total_rows += c.length;
+  if (c.length == 0) return TGX_OK;
+  DistinctColDesc d;
+  d.values = c.values;
+  d.validity = c.validity;
+  d.offset = c.offset;
+  d.length = c.length;
+  d.want_multiplicity = mult ? 1 : 0;
+  d.pad = 0;
+  const uint64_t bytes = (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
+
+  // Int64: the scan of this batch has already folded the column's MIN/MAX into the running state
+  bool have_range = false;
+  int64_t lo = 0, hi = 0;
+  if (c.type == TGX_INT64 && (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap)) {
+    ScanAcc acc;
+    HIP_TRY(hipMemcpyAsync(&acc, st->d_scan_acc.as<ScanAcc>() + task.scan_slot, sizeof(ScanAcc),
+                           hipMemcpyDeviceToHost, st->stream));
+    HIP_TRY(hipStreamSynchronize(st->stream));
+    if (acc.non_null > 0) {
+      have_range = true;
+      lo = acc.min_k;
+      hi = acc.max_k;
+    }
+  }
+  if (ds.mode == DistinctMode::kUndecided) {
+    bool use_bitmap = false;
+    if (c.type == TGX_INT64 && have_range) {
+      // unsigned width of [lo, hi]; bitmap when it is at most 16 bits per expected row and <= 2^34
+      uint64_t width = (uint64_t)hi - (uint64_t)lo;
+      uint64_t expect = std::max<uint64_t>((uint64_t)c.length, g_ctx.distinct_hint);
+      if (width < (1ull << 34) && width / 16 <= expect) {
+        uint64_t slack = std::min<uint64_t>(width / 2 + 64, 1ull << 30);
+        int64_t base = (lo < INT64_MIN + (int64_t)slack) ? INT64_MIN : lo - (int64_t)slack;
+        uint64_t top = (hi > INT64_MAX - (int64_t)slack) ? (uint64_t)INT64_MAX : (uint64_t)(hi + (int64_t)slack);
+        ds.base = base;
+        ds.range = top - (uint64_t)base + 1;
+        use_bitmap = true;
+      }
+    } else if (c.type == TGX_INT64 && !have_range) {
+      return TGX_OK;  // batch of NULLs only: nothing to insert, decide later
+    }
+    if (use_bitmap) {
+      size_t words = (size_t)((ds.range + 31) / 32) + 2;
+      HIP_TRY(ds.seen.reserve(words * 4));
+      HIP_TRY(hipMemsetAsync(ds.seen.p, 0, words * 4, st->stream));
+      if (mult) {
+        HIP_TRY(ds.twice.reserve(words * 4));
+        HIP_TRY(hipMemsetAsync(ds.twice.p, 0, words * 4, st->stream));
+      }
+      ds.mode = DistinctMode::kBitmap;
+    } else {
+      ds.mode = DistinctMode::kHash;
+    }
+  }
+  if (ds.mode == DistinctMode::kBitmap) {
+    bool fits = have_range && lo >= ds.base && (uint64_t)hi - (uint64_t)ds.base < ds.range;
+    if (!fits) TGX_TRY(bitmap_to_hash(st, ds, mult, (uint64_t)c.length, err));
+  }
+  if (ds.mode == DistinctMode::kBitmap) {
+    ProfScope ps(st, "distinct", bytes);
+    launch_distinct_bitmap(d, bitmap_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+  } else {
+    TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
+    ProfScope ps(st, "distinct", bytes);
+    launch_distinct_hash(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+  }
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_column *columns,
+                                 size_t n_columns, tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if ((int)n_columns < plan->n_columns_needed)
+    return fail(err, TGX_INVALID_ARGUMENT, "plan reads column %d but only %zu columns were passed",
+                plan->n_columns_needed - 1, n_columns);
+  if (n_columns > 0 && !columns) return fail(err, TGX_INVALID_ARGUMENT, "columns is NULL");
+  TGX_TRY(need_device(err));
+  TGX_TRY(state_init_device(st, err));
+
+  // which columns does the plan touch, and do they agree on the row count
+  std::vector<char> used(plan->n_columns_needed, 0);
+  for (auto &t : plan->scan) used[t.column] = 1;
+  for (auto &t : plan->count) used[t.column] = 1;
+  for (auto &t : plan->distinct) used[t.column] = 1;
+  for (auto &t : plan->como) used[t.col_x] = used[t.col_y] = 1;
+  for (auto &t : plan->kll) used[t.column] = 1;
+  regex_mark_used(plan, used);
+  int64_t nrows = -1;
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!used[i]) continue;
+    const tgx_column &c = columns[i];
+    if (c.length < 0 || c.offset < 0) return fail(err, TGX_INVALID_ARGUMENT, "column %d: negative length/offset", i);
+    if (nrows < 0) nrows = c.length;
+    if (c.length != nrows)
+      return fail(err, TGX_INVALID_ARGUMENT, "column %d has %lld rows, expected %lld", i, (long long)c.length,
+                  (long long)nrows);
+    if (c.type < TGX_INT64 || c.type > TGX_DICT32_UTF8) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
+    if (st->col_types[i] == 0) st->col_types[i] = c.type;
+    if (st->col_types[i] != c.type)
+      return fail(err, TGX_INVALID_ARGUMENT, "column %d changed type between batches (%d -> %d)", i,
+                  st->col_types[i], c.type);
+    if (c.length > 0) {
+      if (is_numeric(c.type) && !c.values) return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
+      if ((c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && !c.offsets)
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets is NULL", i);
+    }
+  }
+  if (nrows < 0) nrows = 0;
+
+  // device views of every used column
+  st->staging_used = 0;
+  std::vector<tgx_column> dev(plan->n_columns_needed);
+  bool any_host = false;
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!used[i]) continue;
+    if (columns[i].mem == TGX_MEM_HOST && columns[i].length > 0) any_host = true;
+    if (columns[i].length == 0) {
+      dev[i] = columns[i];
+      continue;
+    }
+    TGX_TRY(stage_column(st, columns[i], &dev[i], err));
+  }
+
+  if (nrows > 0) {
+    // ---- numeric scan: all columns of the batch in launches of <= kMaxScanColsPerLaunch ----
+    {
+      std::vector<ScanColDesc> descs;
+      std::vector<int32_t> index;
+      bool any_var = false;
+      uint64_t bytes = 0;
+      for (size_t s = 0; s < plan->scan.size(); s++) {
+        const tgx_column &c = dev[plan->scan[s].column];
+        if (!is_numeric(c.type)) {
+          // a scan task that only exists for DISTINCT's range decision does not apply to strings
+          bool needed_by_stats = false;
+          for (size_t i = 0; i < plan->specs.size(); i++)
+            if (plan->specs[i].kind == TGX_CHECK_NUMERIC_STATS && plan->bind[i].slot == (int)s) needed_by_stats = true;
+          if (needed_by_stats)
+            return fail(err, TGX_INVALID_ARGUMENT, "NUMERIC_STATS on non-numeric column %d (type %d)",
+                        plan->scan[s].column, c.type);
+          continue;
+        }
+        ScanColDesc d;
+        fill_scan_desc(c, plan->scan[s].variance, st->d_pivots.as<double>() + s, &d);
+        any_var |= plan->scan[s].variance;
+        descs.push_back(d);
+        index.push_back((int32_t)s);
+        bytes += (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
+      }
+      if (!descs.empty()) {
+        const int n = (int)descs.size();
+        int blocks = 1;
+        for (auto &d : descs) blocks = std::max(blocks, scan_blocks_for(d, n));
+        HIP_TRY(st->d_scan_desc.reserve(n * sizeof(ScanColDesc)));
+        HIP_TRY(st->d_scan_index.reserve(n * sizeof(int32_t)));
+        HIP_TRY(st->d_scan_partials.reserve((size_t)n * blocks * sizeof(ScanPartial)));
+        // descriptors are tiny; a blocking copy keeps the host vectors' lifetime trivial
+        HIP_TRY(hipMemcpyAsync(st->d_scan_desc.p, descs.data(), n * sizeof(ScanColDesc), hipMemcpyHostToDevice, st->stream));
+        HIP_TRY(hipMemcpyAsync(st->d_scan_index.p, index.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st->stream));
+        HIP_TRY(hipStreamSynchronize(st->stream));
+        if (any_var)
+          launch_scan_pivot(st->d_scan_desc.as<ScanColDesc>(), n, st->d_pivots.as<double>(),
+                            st->d_pivot_set.as<int32_t>(), st->d_scan_index.as<int32_t>(), st->stream);
+        {
+          ProfScope ps(st, "scan", bytes);
+          launch_scan_main_only(st->d_scan_desc.as<ScanColDesc>(), n, blocks, st->d_scan_partials.as<ScanPartial>(),
+                                st->stream);
+        }
+        launch_scan_reduce_only(st->d_scan_desc.as<ScanColDesc>(), n, blocks, st->d_scan_partials.as<ScanPartial>(),
+                                st->d_scan_acc.as<ScanAcc>(), st->d_scan_index.as<int32_t>(), st->stream);
+      }
+    }
+    // ---- validity-only columns ----
+    {
+      std::vector<CountColDesc> descs;
+      std::vector<int32_t> index;
+      uint64_t bytes = 0;
+      int64_t max_words = 0;
+      for (size_t s = 0; s < plan->count.size(); s++) {
+        const tgx_column &c = dev[plan->count[s].column];
+        if (!c.validity) {  // no validity buffer: COUNT(col) = COUNT(*) = length, no kernel needed
+          st->h_count[s].total += c.length;
+          st->h_count[s].non_null += c.length;
+          continue;
+        }
+        descs.push_back({c.validity, c.offset, c.length});
+        index.push_back((int32_t)s);
+        bytes += (uint64_t)(c.length + 7) / 8;
+        max_words = std::max<int64_t>(max_words, (c.length + 63) / 64 + 1);
+      }
+      if (!descs.empty()) {
+        const int n = (int)descs.size();
+        int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (max_words + 256 * 4 - 1) / (256 * 4)),
+                                            std::max(8, (g_ctx.n_cu * 8) / n));
+        HIP_TRY(st->d_count_desc.reserve(n * sizeof(CountColDesc)));
+        HIP_TRY(st->d_count_index.reserve(n * sizeof(int32_t)));
+        HIP_TRY(st->d_count_blocks.reserve((size_t)n * blocks * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpyAsync(st->d_count_desc.p, descs.data(), n * sizeof(CountColDesc), hipMemcpyHostToDevice, st->stream));
+        HIP_TRY(hipMemcpyAsync(st->d_count_index.p, index.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st->stream));
+        HIP_TRY(hipStreamSynchronize(st->stream));
+        ProfScope ps(st, "count", bytes);
+        launch_count(st->d_count_desc.as<CountColDesc>(), n, blocks, st->d_count_blocks.as<unsigned long long>(),
+                     st->d_count_acc.as<CountAcc>(), st->d_count_index.as<int32_t>(), st->stream);
+      }
+    }
+    // ---- co-moments ----
+    if (!plan->como.empty()) {
+      std::vector<ComomentColDesc> descs;
+      std::vector<int32_t> index;
+      uint64_t bytes = 0;
+      for (size_t s = 0; s < plan->como.size(); s++) {
+        const tgx_column &x = dev[plan->como[s].col_x], &y = dev[plan->como[s].col_y];
+        if (!is_numeric(x.type) || !is_numeric(y.type))
+          return fail(err, TGX_INVALID_ARGUMENT, "COMOMENTS needs numeric columns (%d, %d)", x.type, y.type);
+        ComomentColDesc d;
+        d.x = x.values;
+        d.y = y.values;
+        d.xv = x.validity;
+        d.yv = y.validity;
+        d.xoff = x.offset;
+        d.yoff = y.offset;
+        d.length = x.length;
+        d.x_is_float = x.type == TGX_FLOAT64;
+        d.y_is_float = y.type == TGX_FLOAT64;
+        descs.push_back(d);
+        index.push_back((int32_t)s);
+        bytes += (uint64_t)x.length * 16 + (x.validity ? (uint64_t)(x.length + 7) / 8 : 0) +
+                 (y.validity ? (uint64_t)(y.length + 7) / 8 : 0);
+      }
+      const int n = (int)descs.size();
+      int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (nrows + 256 * 16 - 1) / (256 * 16)),
+                                          std::max(32, (g_ctx.n_cu * 8) / n));
+      HIP_TRY(st->d_como_desc.reserve(n * sizeof(ComomentColDesc)));
+      HIP_TRY(st->d_como_index.reserve(n * sizeof(int32_t)));
+      HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
+      HIP_TRY(hipMemcpyAsync(st->d_como_desc.p, descs.data(), n * sizeof(ComomentColDesc), hipMemcpyHostToDevice, st->stream));
+      HIP_TRY(hipMemcpyAsync(st->d_como_index.p, index.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st->stream));
+      HIP_TRY(hipStreamSynchronize(st->stream));
+      ProfScope ps(st, "comoments", bytes);
+      launch_comoments(st->d_como_desc.as<ComomentColDesc>(), n, blocks, st->d_como_partials.p,
+                       st->d_como_acc.as<ComomentAcc>(), st->d_como_index.as<int32_t>(), st->stream);
+    }
+    // ---- exact distinct ----
+    for (size_t s = 0; s < plan->distinct.size(); s++)
+      TGX_TRY(distinct_update(st, s, dev[plan->distinct[s].column], err));
+    // ---- KLL ----
+    for (size_t s = 0; s < plan->kll.size(); s++)
+      TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
+    // ---- regex ----
+    TGX_TRY(regex_update(st, dev.data(), err));
+  }
+  st->batches++;
+  if (any_host) HIP_TRY(hipStreamSynchronize(st->stream));
+  return TGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather: the merged (device + host) view of a state
+namespace {
+struct DistinctTotals {
+  uint64_t total = 0, non_null = 0, distinct = 0, twice = 0, empty_rows = 0;
+};
+struct Gathered {
+  std::vector<ScanAcc> scan;
+  std::vector<CountAcc> count;
+  std::vector<ComomentAcc> como;
+  std::vector<DistinctTotals> distinct;
+};
+}  // namespace
+
+static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t, tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  unsigned long long c[kNumDistinctCounters];
+  memset(c, 0, sizeof(c));
+  if (st->device_ready) TGX_TRY(distinct_read_counters(st, ds, c, err));
+  if (c[kCntOutOfRange] != 0)
+    return fail(err, TGX_INTERNAL, "distinct: %llu keys fell outside the range bitmap", c[kCntOutOfRange]);
+  const uint64_t empty_rows = c[kCntEmptyRows] + ds.h_empty_rows;
+  t->total = (uint64_t)ds.total_rows + ds.h_total;
+  t->non_null = c[kCntValidRows] + ds.h_non_null;
+  t->distinct = c[kCntDistinct] + ds.h_distinct + (empty_rows > 0 ? 1 : 0);
+  t->twice = c[kCntTwice] + ds.h_twice + (empty_rows > 1 ? 1 : 0);
+  t->empty_rows = empty_rows;
+  return TGX_OK;
+}
+
+static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
+  const tgx_plan *plan = st->plan;
+  g->scan = st->h_scan;
+  g->count = st->h_count;
+  g->como = st->h_como;
+  g->distinct.resize(plan->distinct.size());
+  if (st->device_ready) {
+    HIP_TRY(hipStreamSynchronize(st->stream));
+    if (!plan->scan.empty()) {
+      std::vector<ScanAcc> d(plan->scan.size());
+      HIP_TRY(hipMemcpy(d.data(), st->d_scan_acc.p, d.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < d.size(); i++) scan_acc_merge(g->scan[i], d[i]);
+    }
+    if (!plan->count.empty()) {
+      std::vector<CountAcc> d(plan->count.size());
+      HIP_TRY(hipMemcpy(d.data(), st->d_count_acc.p, d.size() * sizeof(CountAcc), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < d.size(); i++) {
+        g->count[i].total += d[i].total;
+        g->count[i].non_null += d[i].non_null;
+      }
+    }
+    if (!plan->como.empty()) {
+      std::vector<ComomentAcc> d(plan->como.size());
+      HIP_TRY(hipMemcpy(d.data(), st->d_como_acc.p, d.size() * sizeof(ComomentAcc), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < d.size(); i++) como_acc_merge(g->como[i], d[i]);
+    }
+  }
+  for (size_t i = 0; i < plan->distinct.size(); i++) TGX_TRY(distinct_totals(st, i, &g->distinct[i], err));
+  return TGX_OK;
+}
+
+static double key_to_double(int64_t k) {
+  int64_t bits = f64_total_key(k);  // the transform is an involution
+  double d;
+  memcpy(&d, &bits, 8);
+  return d;
+}
+
+static double i128_to_double(uint64_t lo, int64_t hi) {
+  __int128 v = ((__int128)hi << 64) | (__int128)lo;
+  return (double)v;
+}
+
+static void fill_stats(const ScanAcc &a, bool variance, tgx_result *r) {
+  r->is_float = a.is_float;
+  r->total = a.total;
+  r->non_null = a.non_null;
+  r->has_value = a.non_null > 0;
+  if (!r->has_value) {
+    r->min_f = r->max_f = r->mean = NAN;
+    r->var_samp = r->stddev_samp = NAN;
+    return;
+  }
+  if (a.is_float) {
+    r->min_f = key_to_double(a.min_k);
+    r->max_f = key_to_double(a.max_k);
+    r->sum_f = isfinite(a.sum) ? a.sum + a.comp : a.sum;
+    r->sum_i = 0;
+  } else {
+    r->min_i = a.min_k;
+    r->max_i = a.max_k;
+    r->min_f = (double)a.min_k;
+    r->max_f = (double)a.max_k;
+    r->sum_i = (int64_t)a.sum_lo;  // SUM(Int64) wraps
+    r->sum_f = i128_to_double(a.sum_lo, a.sum_hi);
+  }
+  r->mean = r->sum_f / (double)a.non_null;
+  r->var_samp = r->stddev_samp = NAN;
+  if (variance && a.var_n >= 2) {
+    r->has_variance = 1;
+    r->var_samp = a.var_m2 / (double)(a.var_n - 1);
+    r->stddev_samp = sqrt(r->var_samp);
+  }
+}
+
+extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_result *results,
+                                   size_t n_results, tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if (n_results < plan->specs.size() || (!results && !plan->specs.empty()))
+    return fail(err, TGX_INVALID_ARGUMENT, "results has room for %zu of %zu specs", n_results, plan->specs.size());
+  Gathered g;
+  TGX_TRY(gather(st, &g, err));
+  for (size_t i = 0; i < plan->specs.size(); i++) {
+    tgx_result *r = &results[i];
+    memset(r, 0, sizeof(*r));
+    const SpecBinding &b = plan->bind[i];
+    r->kind = b.kind;
+    switch (b.kind) {
+      case TGX_CHECK_COUNT:
+        if (b.count_src == Source::kScan) {
+          r->total = g.scan[b.slot].total;
+          r->non_null = g.scan[b.slot].non_null;
+        } else {
+          r->total = g.count[b.slot].total;
+          r->non_null = g.count[b.slot].non_null;
+        }
+        break;
+      case TGX_CHECK_NUMERIC_STATS:
+        fill_stats(g.scan[b.slot], plan->scan[b.slot].variance, r);
+        break;
+      case TGX_CHECK_DISTINCT: {
+        const DistinctTotals &t = g.distinct[b.slot];
+        r->total = (int64_t)t.total;
+        r->non_null = (int64_t)t.non_null;
+        r->distinct = (int64_t)t.distinct;
+        // groups with cnt == 1: keys seen exactly once, plus the NULL group when it has one row
+        r->groups_once = (int64_t)(t.distinct - t.twice) + ((t.total - t.non_null) == 1 ? 1 : 0);
+        break;
+      }
+      case TGX_CHECK_COMOMENTS: {
+        const ComomentAcc &a = g.como[b.slot];
+        r->total = a.total;
+        r->non_null = a.n;
+        double v[5];
+        for (int k = 0; k < 5; k++) v[k] = isfinite(a.s[k]) ? a.s[k] + a.c[k] : a.s[k];
+        r->sum_x = v[0];
+        r->sum_y = v[1];
+        r->sum_x2 = v[2];
+        r->sum_y2 = v[3];
+        r->sum_xy = v[4];
+        break;
+      }
+      case TGX_CHECK_KLL:
+        TGX_TRY(kll_fill_result(st, b.slot, r, err));
+        break;
+      case TGX_CHECK_REGEX_MATCH:
+        TGX_TRY(regex_fill_result(st, b.slot, r, err));
+        break;
+      default:
+        break;
+    }
+  }
+  return TGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// distinct: export / import / merge
+static tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t world,
+                                       const void **device_records, uint64_t *counts, tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = st->plan->distinct[slot].multiplicity;
+  TGX_TRY(state_init_device(st, err));
+  std::vector<unsigned long long> h_counts(world, 0);
+  unsigned long long c[kNumDistinctCounters];
+  TGX_TRY(distinct_read_counters(st, ds, c, err));
+  const uint64_t n_keys = c[kCntDistinct];
+  const uint64_t empty_rows = c[kCntEmptyRows];
+  HIP_TRY(ds.export_counts.reserve(2 * world * sizeof(unsigned long long)));
+  unsigned long long *d_counts = ds.export_counts.as<unsigned long long>();
+  unsigned long long *d_cursors = d_counts + world;
+  HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * world * sizeof(unsigned long long), st->stream));
+  if (ds.mode == DistinctMode::kHash)
+    launch_hash_export_count(hash_view(ds), world, d_counts, st->stream);
+  else if (ds.mode == DistinctMode::kBitmap)
+    launch_bitmap_export_count(bitmap_view(ds), world, d_counts, st->stream);
+  HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, world * sizeof(unsigned long long), hipMemcpyDeviceToHost, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  // the all-ones key lives in a side counter; it travels as one extra record to its owner
+  uint32_t empty_owner = 0;
+  if (empty_rows > 0) {
+    // same owner function as the kernels (distinct.hip owner_of)
+    uint64_t x = kEmptyKey ^ 0x9e3779b97f4a7c15ULL;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL; x ^= x >> 27; x *= 0x94d049bb133111ebULL; x ^= x >> 31;
+    empty_owner = (uint32_t)((x >> 32) % world);
+    h_counts[empty_owner] += 1;
+  }
+  std::vector<unsigned long long> starts(world, 0);
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < world; r++) {
+    starts[r] = total;
+    total += h_counts[r];
+  }
+  (void)n_keys;
+  HIP_TRY(ds.export_records.reserve(std::max<uint64_t>(total, 1) * sizeof(KeyRecord)));
+  HIP_TRY(hipMemcpyAsync(d_cursors, starts.data(), world * sizeof(unsigned long long), hipMemcpyHostToDevice, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  if (ds.mode == DistinctMode::kHash)
+    launch_hash_export_scatter(hash_view(ds), world, mult ? 1 : 0, d_cursors, ds.export_records.as<KeyRecord>(), st->stream);
+  else if (ds.mode == DistinctMode::kBitmap)
+    launch_bitmap_export_scatter(bitmap_view(ds), world, mult ? 1 : 0, d_cursors, ds.export_records.as<KeyRecord>(), st->stream);
+  if (empty_rows > 0) {
+    KeyRecord rec{kEmptyKey, std::min<uint64_t>(empty_rows, 2)};
+    uint64_t pos = starts[empty_owner] + h_counts[empty_owner] - 1;
+    HIP_TRY(hipMemcpyAsync(ds.export_records.as<KeyRecord>() + pos, &rec, sizeof(rec), hipMemcpyHostToDevice, st->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  for (uint32_t r = 0; r < world; r++) counts[r] = h_counts[r];
+  *device_records = ds.export_records.p;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, size_t spec_index,
+                                          uint32_t world, const void **device_records, uint64_t *counts,
+                                          tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
+    return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
+  if (world == 0 || !device_records || !counts) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
+  TGX_TRY(need_device(err));
+  return distinct_export_impl(st, plan->bind[spec_index].slot, world, device_records, counts, err);
+}
+
+// union `n` device records into the state's set (switching it to hash mode)
+static tgx_status distinct_import_records(tgx_state *st, size_t slot, const KeyRecord *d_recs, uint64_t n,
+                                          tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = st->plan->distinct[slot].multiplicity;
+  TGX_TRY(state_init_device(st, err));
+  if (ds.mode == DistinctMode::kBitmap) TGX_TRY(bitmap_to_hash(st, ds, mult, n, err));
+  ds.mode = DistinctMode::kHash;
+  TGX_TRY(hash_ensure(st, ds, mult, n, err));
+  // the EMPTY stand-in's rows arrive through counters[2]; [5] is scratch
+  launch_hash_import(d_recs, n, hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(), st->stream);
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, size_t spec_index,
+                                          const void *device_records, uint64_t n_records, tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
+    return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
+  TGX_TRY(need_device(err));
+  const size_t slot = plan->bind[spec_index].slot;
+  DistinctState &ds = st->distinct[slot];
+  TGX_TRY(state_init_device(st, err));
+  // keep the row counts, replace the key set
+  unsigned long long c[kNumDistinctCounters];
+  TGX_TRY(distinct_read_counters(st, ds, c, err));
+  const unsigned long long valid_rows = c[kCntValidRows];
+  ds.seen.release();
+  ds.twice.release();
+  ds.keys.release();
+  ds.dup.release();
+  ds.capacity = 0;
+  ds.rows_upper_bound = 0;
+  ds.mode = DistinctMode::kHash;
+  unsigned long long zero[kNumDistinctCounters];
+  memset(zero, 0, sizeof(zero));
+  zero[kCntValidRows] = valid_rows;
+  HIP_TRY(hipMemcpy(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice));
+  TGX_TRY(distinct_import_records(st, slot, (const KeyRecord *)device_records, n_records, err));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.partitioned = true;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state *const *srcs, size_t n_srcs,
+                                tgx_error *err) {
+  if (!plan || !dst || dst->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "dst does not belong to plan");
+  for (size_t i = 0; i < n_srcs; i++) {
+    tgx_state *src = srcs ? srcs[i] : nullptr;
+    if (!src || src->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "src %zu does not belong to plan", i);
+    if (src == dst) return fail(err, TGX_INVALID_ARGUMENT, "src %zu is dst", i);
+    Gathered g;
+    // distinct totals are handled set-wise below; gather the fixed-size parts
+    {
+      std::vector<DistinctState> hold;  // gather() reads distinct counters too; harmless
+      TGX_TRY(gather(src, &g, err));
+    }
+    for (size_t k = 0; k < g.scan.size(); k++) scan_acc_merge(dst->h_scan[k], g.scan[k]);
+    for (size_t k = 0; k < g.count.size(); k++) {
+      dst->h_count[k].total += g.count[k].total;
+      dst->h_count[k].non_null += g.count[k].non_null;
+    }
+    for (size_t k = 0; k < g.como.size(); k++) como_acc_merge(dst->h_como[k], g.como[k]);
+    for (size_t k = 0; k < plan->distinct.size(); k++) {
+      DistinctState &s = src->distinct[k];
+      DistinctState &d = dst->distinct[k];
+      const bool src_has_set = s.mode == DistinctMode::kBitmap || s.mode == DistinctMode::kHash;
+      if (s.partitioned || !src_has_set) {
+        // owner-partitioned (or count-only) partial: key sets are disjoint by construction
+        if (src_has_set && !s.partitioned)
+          return fail(err, TGX_INTERNAL, "distinct merge: unexpected state");
+        const DistinctTotals &t = g.distinct[k];
+        // remove the +1 adjustments distinct_totals() made for the EMPTY stand-in: they are re-derived
+        d.h_total += t.total;
+        d.h_non_null += t.non_null;
+        d.h_distinct += t.distinct - (t.empty_rows > 0 ? 1 : 0);
+        d.h_twice += t.twice - (t.empty_rows > 1 ? 1 : 0);
+        d.h_empty_rows += t.empty_rows;
+        if (s.partitioned) d.partitioned = true;
+      } else {
+        // exact set union on the device
+        TGX_TRY(need_device(err));
+        const void *recs = nullptr;
+        uint64_t cnt = 0;
+        TGX_TRY(distinct_export_impl(src, k, 1, &recs, &cnt, err));
+        TGX_TRY(state_init_device(dst, err));
+        TGX_TRY(distinct_import_records(dst, k, (const KeyRecord *)recs, cnt, err));
+        HIP_TRY(hipStreamSynchronize(dst->stream));
+        d.h_total += (uint64_t)s.total_rows + s.h_total;
+        unsigned long long c[kNumDistinctCounters];
+        TGX_TRY(distinct_read_counters(src, s, c, err));
+        d.h_non_null += c[kCntValidRows] + s.h_non_null;
+        d.h_distinct += s.h_distinct;
+        d.h_twice += s.h_twice;
+        d.h_empty_rows += s.h_empty_rows;
+      }
+    }
+    TGX_TRY(kll_merge_states(dst, src, err));
+    TGX_TRY(regex_merge_states(dst, src, err));
+  }
+  return TGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wire form
+namespace {
+struct Writer {
+  uint8_t *buf;
+  size_t cap, len = 0;
+  void put(const void *p, size_t n) {
+    if (buf && len + n <= cap) memcpy(buf + len, p, n);
+    len += n;
+  }
+  template <class T>
+  void pod(const T &v) { put(&v, sizeof(T)); }
+};
+struct Reader {
+  const uint8_t *buf;
+  size_t len, pos = 0;
+  bool ok = true;
+  void get(void *p, size_t n) {
+    if (pos + n > len) {
+      ok = false;
+      memset(p, 0, n);
+      return;
+    }
+    memcpy(p, buf + pos, n);
+    pos += n;
+  }
+  template <class T>
+  T pod() {
+    T v;
+    get(&v, sizeof(T));
+    return v;
+  }
+};
+constexpr uint32_t kWireMagic = 0x53584754;  // "TGXS"
+constexpr uint32_t kWireVersion = 1;
+}  // namespace
+
+extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, uint8_t *buf, size_t cap,
+                                          size_t *len, tgx_error *err) {
+  if (!plan || !st || st->plan != plan || !len) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
+  Gathered g;
+  TGX_TRY(gather(st, &g, err));
+  Writer w{buf, cap};
+  w.pod(kWireMagic);
+  w.pod(kWireVersion);
+  w.pod((uint32_t)g.scan.size());
+  w.pod((uint32_t)g.count.size());
+  w.pod((uint32_t)g.como.size());
+  w.pod((uint32_t)g.distinct.size());
+  w.pod((uint32_t)plan->kll.size());
+  w.pod((uint32_t)regex_num_tasks(plan));
+  for (auto &a : g.scan) w.pod(a);
+  for (auto &a : g.count) w.pod(a);
+  for (auto &a : g.como) w.pod(a);
+  for (size_t k = 0; k < g.distinct.size(); k++) {
+    DistinctState &ds = st->distinct[k];
+    const DistinctTotals &t = g.distinct[k];
+    const bool has_set = ds.mode == DistinctMode::kBitmap || ds.mode == DistinctMode::kHash;
+    uint32_t partitioned = (ds.partitioned || !has_set) ? 1 : 0;
+    w.pod(partitioned);
+    w.pod((uint32_t)0);
+    w.pod(t);
+    uint64_t n_records = 0;
+    if (!partitioned) {
+      // non-partitioned sets travel with their keys so the receiver can take an exact union
+      const void *recs = nullptr;
+      TGX_TRY(distinct_export_impl(st, k, 1, &recs, &n_records, err));
+      w.pod(n_records);
+      size_t bytes = (size_t)n_records * sizeof(KeyRecord);
+      if (w.buf && w.len + bytes <= w.cap)
+        HIP_TRY(hipMemcpy(w.buf + w.len, recs, bytes, hipMemcpyDeviceToHost));
+      w.len += bytes;
+    } else {
+      w.pod(n_records);
+    }
+  }
+  TGX_TRY(kll_serialize(st, &w.len, w.buf, w.cap, err));
+  TGX_TRY(regex_serialize(st, &w.len, w.buf, w.cap, err));
+  *len = w.len;
+  if (buf && w.len > cap) return fail(err, TGX_INVALID_ARGUMENT, "buffer too small: need %zu bytes", w.len);
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t *buf, size_t len,
+                                            tgx_state **out, tgx_error *err) {
+  if (!plan || !buf || !out) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
+  *out = nullptr;
+  Reader r{buf, len};
+  if (r.pod<uint32_t>() != kWireMagic) return fail(err, TGX_INVALID_ARGUMENT, "not a tgx state blob");
+  if (r.pod<uint32_t>() != kWireVersion) return fail(err, TGX_INVALID_ARGUMENT, "state blob version mismatch");
+  uint32_t n_scan = r.pod<uint32_t>(), n_count = r.pod<uint32_t>(), n_como = r.pod<uint32_t>(),
+           n_dist = r.pod<uint32_t>(), n_kll = r.pod<uint32_t>(), n_regex = r.pod<uint32_t>();
+  if (n_scan != plan->scan.size() || n_count != plan->count.size() || n_como != plan->como.size() ||
+      n_dist != plan->distinct.size() || n_kll != plan->kll.size() || n_regex != regex_num_tasks(plan))
+    return fail(err, TGX_INVALID_ARGUMENT, "state blob was produced by a different plan");
+  std::unique_ptr<tgx_state, void (*)(tgx_state *)> st(new tgx_state(), tgx_state_destroy);
+  state_init_host(st.get(), plan);
+  for (auto &a : st->h_scan) a = r.pod<ScanAcc>();
+  for (auto &a : st->h_count) a = r.pod<CountAcc>();
+  for (auto &a : st->h_como) a = r.pod<ComomentAcc>();
+  for (size_t k = 0; k < n_dist; k++) {
+    DistinctState &ds = st->distinct[k];
+    uint32_t partitioned = r.pod<uint32_t>();
+    (void)r.pod<uint32_t>();
+    DistinctTotals t = r.pod<DistinctTotals>();
+    uint64_t n_records = r.pod<uint64_t>();
+    if (!r.ok) break;
+    if (partitioned) {
+      ds.partitioned = true;
+      ds.h_total = t.total;
+      ds.h_non_null = t.non_null;
+      ds.h_distinct = t.distinct - (t.empty_rows > 0 ? 1 : 0);
+      ds.h_twice = t.twice - (t.empty_rows > 1 ? 1 : 0);
+      ds.h_empty_rows = t.empty_rows;
+    } else {
+      // rebuild the key set on the device from the records
+      size_t bytes = (size_t)n_records * sizeof(KeyRecord);
+      if (r.pos + bytes > r.len) {
+        r.ok = false;
+        break;
+      }
+      tgx_status s = need_device(err);
+      if (s != TGX_OK) return s;
+      s = state_init_device(st.get(), err);
+      if (s != TGX_OK) return s;
+      DevBuf tmp;
+      HIP_TRY(tmp.reserve(std::max<size_t>(bytes, 16)));
+      HIP_TRY(hipMemcpy(tmp.p, r.buf + r.pos, bytes, hipMemcpyHostToDevice));
+      r.pos += bytes;
+      s = distinct_import_records(st.get(), k, tmp.as<KeyRecord>(), n_records, err);
+      if (s != TGX_OK) return s;
+      HIP_TRY(hipStreamSynchronize(st->stream));
+      ds.h_total = t.total;
+      ds.h_non_null = t.non_null;
+    }
+  }
+  if (r.ok) {
+    tgx_status s = kll_deserialize(st.get(), r.buf, r.len, &r.pos, err);
+    if (s != TGX_OK) return s;
+    s = regex_deserialize(st.get(), r.buf, r.len, &r.pos, err);
+    if (s != TGX_OK) return s;
+  }
+  if (!r.ok) return fail(err, TGX_INVALID_ARGUMENT, "truncated state blob");
+  *out = st.release();
+  return TGX_OK;
+}

@@ -1,0 +1,369 @@
+"""-m gpu parity tests: libtgx (HIP kernels behind the C ABI) vs the CPU oracle on the same seeded
+inputs. Counts / min / max / distinct are bit-exact; float aggregates within 1e-6 relative (north star),
+in practice ~1e-15 because the device sums are compensated."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+import term_amd as T
+from _lib_spec import spec
+from gpu_util import make_f64, make_i64, numeric_column, pad_validity, rel_err, run_plan, to_device
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6  # north star: float aggregates within 1e-6 relative
+
+
+def check_stats(res, st, variance=False):
+    assert res.total == st.total
+    assert res.non_null == st.non_null
+    assert bool(res.has_value) == bool(st.has_value)
+    if not st.has_value:
+        return
+    if st.is_float:
+        assert orc.nan_equal(res.min_f, st.min_f) and orc.nan_equal(res.max_f, st.max_f)
+        assert math.copysign(1, res.min_f) == math.copysign(1, st.min_f)
+        assert rel_err(res.sum_f, st.sum_hi) < TOL
+    else:
+        assert (res.min_i, res.max_i) == (st.min_i, st.max_i)
+        assert res.sum_i == st.sum_i_wrapping
+        assert rel_err(res.sum_f, st.sum_hi) < 1e-15
+    assert rel_err(res.mean, st.sum_hi / st.non_null) < TOL
+    assert rel_err(res.mean, st.mean) < TOL
+    if variance:
+        assert bool(res.has_variance) == bool(st.has_variance)
+        if st.has_variance:
+            assert rel_err(res.var_samp, st.var_samp) < TOL
+            assert rel_err(res.stddev_samp, st.stddev_samp) < TOL
+
+
+@pytest.mark.parametrize("device", [True, False])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 511, 512, 513, 4096, 100_003, 1_000_000])
+def test_numeric_stats_sizes(n, device):
+    rng = np.random.default_rng(1000 + n)
+    iv, ivv = make_i64(rng, n, -(2**40), 2**40, null_frac=0.05)
+    fv, fvv = make_f64(rng, n, "uniform", null_frac=0.05)
+    gv, _ = make_f64(rng, n, "normal", null_frac=0.0)
+    cols = [numeric_column(iv, ivv, device), numeric_column(fv, fvv, device), numeric_column(gv, None, device)]
+    specs = [spec(T.NUMERIC_STATS, 0, flags=T.FLAG_VARIANCE), spec(T.NUMERIC_STATS, 1, flags=T.FLAG_VARIANCE),
+             spec(T.NUMERIC_STATS, 2), spec(T.COUNT, 0), spec(T.COUNT, 2)]
+    res, _, _ = run_plan(specs, [cols])
+    check_stats(res[0], orc.stats(iv, ivv), variance=True)
+    check_stats(res[1], orc.stats(fv, fvv), variance=True)
+    check_stats(res[2], orc.stats(gv, None))
+    c = orc.count(ivv, n)
+    assert (res[3].total, res[3].non_null) == (c.total, c.non_null)
+    assert (res[4].total, res[4].non_null) == (n, n)
+
+
+@pytest.mark.parametrize("offset", [0, 1, 7, 8, 63, 64, 65, 129, 1000])
+def test_sliced_arrays(offset):
+    """Arrow `offset` applies to validity bits and value slots alike; not a multiple of 8 or 64."""
+    rng = np.random.default_rng(7 + offset)
+    total = 20_000 + offset
+    iv, ivv = make_i64(rng, total, -1000, 1000, null_frac=0.1)
+    fv, fvv = make_f64(rng, total, "normal", null_frac=0.1)
+    n = total - offset - 13
+    cols = [numeric_column(iv, ivv, True, offset=offset, length=n),
+            numeric_column(fv, fvv, True, offset=offset, length=n)]
+    specs = [spec(T.NUMERIC_STATS, 0), spec(T.NUMERIC_STATS, 1), spec(T.COUNT, 1)]
+    res, _, _ = run_plan(specs, [cols])
+    check_stats(res[0], orc.stats(iv, ivv, n=n, offset=offset))
+    check_stats(res[1], orc.stats(fv, fvv, n=n, offset=offset))
+    c = orc.count(fvv, n, offset=offset)
+    assert (res[2].total, res[2].non_null) == (c.total, c.non_null)
+
+
+def test_count_only_columns():
+    """COUNT on columns whose values are never read: validity popcount with ragged bit offsets."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    for n, offset in [(1, 0), (5, 3), (64, 0), (1000, 61), (100_000, 5), (1_000_003, 77)]:
+        mask = rng.random(n + offset) >= 0.3
+        validity = pad_validity(orc.pack_validity(mask))
+        dv = to_device(validity)
+        # 1-byte misaligned validity base pointer as well
+        shifted = torch.zeros(len(validity) + 8, dtype=torch.uint8, device="cuda")
+        shifted[1:1 + len(validity)] = dv
+        cols = [T.Column(T.INT64, n, values=None, validity=dv, offset=offset),
+                T.Column(T.INT64, n, values=None, validity=shifted[1:], offset=offset)]
+        res, _, _ = run_plan([spec(T.COUNT, 0), spec(T.COUNT, 1)], [cols])
+        c = orc.count(validity, n, offset=offset)
+        for r in res:
+            assert (r.total, r.non_null) == (c.total, c.non_null), (n, offset)
+
+
+def test_special_float_values():
+    vals = np.array([0.0, -0.0, 1.5, -2.5, float("inf"), 5e-324, -5e-324, 1e308, 1e308], dtype=np.float64)
+    res, _, _ = run_plan([spec(T.NUMERIC_STATS, 0)], [[numeric_column(vals, None, True)]])
+    st = orc.stats(vals)
+    assert res[0].min_f == st.min_f and res[0].max_f == st.max_f == float("inf")
+    assert res[0].sum_f == float("inf")
+    # NaN sorts above +inf in IEEE totalOrder (arrow-arith aggregate); -0.0 below +0.0
+    vals = np.array([0.0, -0.0, float("nan"), 3.0], dtype=np.float64)
+    res, _, _ = run_plan([spec(T.NUMERIC_STATS, 0)], [[numeric_column(vals, None, True)]])
+    assert math.isnan(res[0].max_f) and res[0].min_f == 0.0 and math.copysign(1, res[0].min_f) == -1
+    assert math.isnan(res[0].sum_f)
+    # all NULL => SQL NULL aggregates
+    vals = np.zeros(100, dtype=np.float64)
+    validity = orc.pack_validity(np.zeros(100, dtype=bool))
+    res, _, _ = run_plan([spec(T.NUMERIC_STATS, 0)], [[numeric_column(vals, validity, True)]])
+    assert res[0].total == 100 and res[0].non_null == 0 and not res[0].has_value
+
+
+def test_int64_extremes_and_wrapping_sum():
+    vals = np.array([2**62, 2**62, 2**62, -(2**63), 2**63 - 1, -5], dtype=np.int64)
+    res, _, _ = run_plan([spec(T.NUMERIC_STATS, 0)], [[numeric_column(vals, None, True)]])
+    st = orc.stats(vals)
+    assert res[0].sum_i == st.sum_i_wrapping
+    assert (res[0].min_i, res[0].max_i) == (-(2**63), 2**63 - 1)
+    exact = sum(int(v) for v in vals)
+    assert res[0].sum_f == float(exact)
+
+
+def test_ill_conditioned_sum_is_still_accurate():
+    """Compensated device sums: large cancelling terms do not destroy a small true total."""
+    rng = np.random.default_rng(11)
+    big = rng.standard_normal(200_000) * 1e12
+    vals = np.concatenate([big, -big, np.full(1000, 0.125)])
+    rng.shuffle(vals)
+    res, _, _ = run_plan([spec(T.NUMERIC_STATS, 0)], [[numeric_column(vals, None, True)]])
+    assert rel_err(res[0].sum_f, 125.0) < 1e-9
+
+
+@pytest.mark.parametrize("n_batches", [1, 3, 17])
+def test_multi_batch_equals_single_pass(n_batches):
+    rng = np.random.default_rng(99)
+    n = 50_000
+    iv, ivv = make_i64(rng, n, 0, 5000, null_frac=0.02)
+    fv, fvv = make_f64(rng, n, "uniform", null_frac=0.02)
+    specs = [spec(T.NUMERIC_STATS, 0, flags=T.FLAG_VARIANCE), spec(T.NUMERIC_STATS, 1, flags=T.FLAG_VARIANCE),
+             spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.COMOMENTS, 0, column2=1)]
+    bounds = np.linspace(0, n, n_batches + 1).astype(int)
+    batches = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        batches.append([numeric_column(iv, ivv, True, offset=int(a), length=int(b - a)),
+                        numeric_column(fv, fvv, True, offset=int(a), length=int(b - a))])
+    res, _, _ = run_plan(specs, batches)
+    check_stats(res[0], orc.stats(iv, ivv), variance=True)
+    check_stats(res[1], orc.stats(fv, fvv), variance=True)
+    d = orc.distinct_bits64(iv, ivv)
+    assert (res[2].total, res[2].non_null, res[2].distinct, res[2].groups_once) == \
+        (d.total, d.non_null, d.distinct, d.groups_once)
+    cm = orc.comoments(iv, fv, ivv, fvv)
+    assert res[3].non_null == cm.n
+    for got, want in [(res[3].sum_x, cm.sum_x), (res[3].sum_y, cm.sum_y), (res[3].sum_x2, cm.sum_x2),
+                      (res[3].sum_y2, cm.sum_y2), (res[3].sum_xy, cm.sum_xy)]:
+        assert rel_err(got, want) < TOL
+
+
+@pytest.mark.parametrize("case", ["bitmap_dense", "bitmap_dups", "hash_wide", "hash_float", "permutation",
+                                  "all_ones_key", "all_null", "single_null"])
+def test_distinct_modes(case):
+    rng = np.random.default_rng(hash(case) % 2**32)
+    n = 200_000
+    validity = None
+    if case == "bitmap_dense":
+        vals, validity = make_i64(rng, n, 0, n // 2, null_frac=0.05)
+    elif case == "bitmap_dups":
+        vals, validity = make_i64(rng, n, -50, 50, null_frac=0.5)
+    elif case == "hash_wide":
+        vals, validity = make_i64(rng, n, -(2**62), 2**62, null_frac=0.05)
+        vals[: n // 4] = vals[n // 4: n // 2]  # duplicates
+    elif case == "hash_float":
+        f = np.round(rng.standard_normal(n), 2)
+        f[:10] = 0.0
+        f[10:20] = -0.0
+        vals = f.view(np.int64).copy()
+    elif case == "permutation":
+        vals = rng.permutation(n).astype(np.int64)
+    elif case == "all_ones_key":
+        vals = rng.integers(-3, 3, size=n, dtype=np.int64)  # includes -1 = 0xFFFF...FFFF
+        vals = np.concatenate([vals, np.array([-(2**62), 2**62 - 1], dtype=np.int64)])  # force hash mode
+        n = len(vals)
+    elif case == "all_null":
+        vals = np.zeros(n, dtype=np.int64)
+        validity = orc.pack_validity(np.zeros(n, dtype=bool))
+    elif case == "single_null":
+        vals = np.arange(n, dtype=np.int64)
+        mask = np.ones(n, dtype=bool)
+        mask[12345] = False
+        validity = orc.pack_validity(mask)
+    if case == "hash_float":
+        col = numeric_column(vals.view(np.float64), None, True)
+    else:
+        col = numeric_column(vals, validity, True)
+    res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], [[col]])
+    d = orc.distinct_bits64(vals.view(np.uint64), validity, n=n)
+    got = (res[0].total, res[0].non_null, res[0].distinct, res[0].groups_once)
+    assert got == (d.total, d.non_null, d.distinct, d.groups_once), case
+
+
+def test_distinct_bitmap_escapes_to_hash_on_out_of_range_batch():
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 1000, size=50_000, dtype=np.int64)
+    b = rng.integers(10**12, 10**12 + 1000, size=50_000, dtype=np.int64)
+    c = rng.integers(-500, 1500, size=50_000, dtype=np.int64)
+    res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.NUMERIC_STATS, 0)],
+                         [[numeric_column(x, None, True)] for x in (a, b, c)])
+    allv = np.concatenate([a, b, c])
+    d = orc.distinct_bits64(allv.view(np.uint64))
+    assert (res[0].distinct, res[0].groups_once) == (d.distinct, d.groups_once)
+    check_stats(res[1], orc.stats(allv))
+
+
+def test_hash_growth_across_batches():
+    rng = np.random.default_rng(6)
+    parts = [rng.integers(-(2**60), 2**60, size=30_000, dtype=np.int64) for _ in range(8)]
+    parts[5][:1000] = parts[0][:1000]
+    res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)],
+                         [[numeric_column(p, None, True)] for p in parts])
+    d = orc.distinct_bits64(np.concatenate(parts).view(np.uint64))
+    assert (res[0].distinct, res[0].groups_once) == (d.distinct, d.groups_once)
+
+
+def test_comoments_and_correlation_formulas(golden):
+    c = golden["correlation"]
+    x = np.arange(c["n"], dtype=np.float64)
+    y = 2.0 * x + 1.0
+    res, _, _ = run_plan([spec(T.COMOMENTS, 0, column2=1)],
+                         [[numeric_column(x, None, True), numeric_column(y, None, True)]])
+    st = orc.Comoments(int(res[0].non_null), res[0].sum_x, res[0].sum_y, res[0].sum_x2, res[0].sum_y2,
+                       res[0].sum_xy)
+    assert abs(orc.pearson(st) - 1.0) < c["pearson"]["tol"]
+    assert c["covariance"]["lo"] < orc.covariance(st) < c["covariance"]["hi"]
+    # mixed int64 / float64 with nulls on both sides
+    rng = np.random.default_rng(8)
+    n = 300_001
+    iv, ivv = make_i64(rng, n, -10_000, 10_000, null_frac=0.1)
+    fv, fvv = make_f64(rng, n, "normal", null_frac=0.1)
+    res, _, _ = run_plan([spec(T.COMOMENTS, 0, column2=1)],
+                         [[numeric_column(iv, ivv, True), numeric_column(fv, fvv, True)]])
+    cm = orc.comoments(iv, fv, ivv, fvv)
+    assert res[0].non_null == cm.n and res[0].total == n
+    for got, want in [(res[0].sum_x, cm.sum_x), (res[0].sum_y, cm.sum_y), (res[0].sum_x2, cm.sum_x2),
+                      (res[0].sum_y2, cm.sum_y2), (res[0].sum_xy, cm.sum_xy)]:
+        assert rel_err(got, want) < TOL
+
+
+def test_reference_known_answer_vectors_numeric(golden):
+    """The reference's own unit-test vectors through the HIP path (host-resident Arrow buffers)."""
+    for case in golden["statistics"]:
+        vals, validity = orc.column_from_list(case["values"], np.float64)
+        res, _, _ = run_plan([spec(T.NUMERIC_STATS, 0)], [[numeric_column(vals, validity, False)]])
+        r = res[0]
+        if case["status"] == "failure" and "message_contains" in case:
+            assert not r.has_value
+            continue
+        got = {"mean": r.mean, "min": r.min_f, "max": r.max_f, "sum": r.sum_f}[case["stat"]]
+        assert got == case["metric"], case["ref"]
+    for case in golden["completeness"]:
+        for cname in case["cols"]:
+            vals, validity = orc.column_from_list(case["columns"][cname], np.int64)
+            if len(vals) == 0:
+                continue
+            res, _, _ = run_plan([spec(T.COUNT, 0)], [[numeric_column(vals, validity, False)]])
+            assert res[0].total == len(vals)
+            assert res[0].non_null == sum(v is not None for v in case["columns"][cname])
+    a = golden["analyzers"]
+    ids, idv = orc.column_from_list(a["table"]["id"], np.int64)
+    vals, vv = orc.column_from_list(a["table"]["value"], np.float64)
+    res, _, _ = run_plan([spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 1), spec(T.DISTINCT, 0)],
+                         [[numeric_column(ids, idv, False), numeric_column(vals, vv, False)]])
+    assert (res[0].total, res[0].non_null) == (5, 4)
+    assert (res[1].sum_f, res[1].non_null, res[1].mean, res[1].min_f, res[1].max_f) == (100.0, 4, 25.0, 10.0, 40.0)
+    assert res[2].distinct == 4
+
+
+def test_merge_and_serialize_roundtrip():
+    rng = np.random.default_rng(21)
+    n = 120_000
+    iv, ivv = make_i64(rng, n, 0, 40_000, null_frac=0.03)
+    fv, fvv = make_f64(rng, n, "uniform", null_frac=0.03)
+    specs = [spec(T.NUMERIC_STATS, 0, flags=T.FLAG_VARIANCE), spec(T.NUMERIC_STATS, 1), spec(T.COUNT, 1),
+             spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.COMOMENTS, 0, column2=1)]
+    T.init()
+    plan = T.Plan(specs)
+    half = n // 2 + 17
+    states = []
+    for a, b in [(0, half), (half, n)]:
+        st = T.State(plan)
+        st.update([numeric_column(iv, ivv, True, offset=a, length=b - a),
+                   numeric_column(fv, fvv, True, offset=a, length=b - a)])
+        states.append(st)
+    # serialize -> deserialize -> merge (AnalyzerState::merge semantics, exact for DISTINCT)
+    blob = states[1].serialize()
+    other = T.State.deserialize(plan, blob)
+    states[0].merge([other])
+    res = states[0].finalize()
+    check_stats(res[0], orc.stats(iv, ivv), variance=True)
+    check_stats(res[1], orc.stats(fv, fvv))
+    d = orc.distinct_bits64(iv, ivv)
+    assert (res[3].total, res[3].non_null, res[3].distinct, res[3].groups_once) == \
+        (d.total, d.non_null, d.distinct, d.groups_once)
+    cm = orc.comoments(iv, fv, ivv, fvv)
+    assert res[4].non_null == cm.n and rel_err(res[4].sum_xy, cm.sum_xy) < TOL
+
+
+def test_distinct_owner_exchange_single_process():
+    """The cross-rank exact-distinct protocol with both 'ranks' in one process: export by owner,
+    swap the runs, import, then merge the owner-partitioned counts."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    n = 100_000
+    vals = rng.integers(0, 60_000, size=n, dtype=np.int64)
+    wide = rng.integers(-(2**61), 2**61, size=n, dtype=np.int64)
+    for data in (vals, wide):
+        T.init()
+        plan = T.Plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)])
+        world = 2
+        shards = [data[: n // 3], data[n // 3:]]
+        states, exported = [], []
+        for sh in shards:
+            st = T.State(plan)
+            st.update([numeric_column(sh, None, True)])
+            ptr, counts = st.distinct_export(0, world)
+            # copy the runs out: the export buffer belongs to the state
+            total = sum(counts)
+            recs = torch.empty(total * 2, dtype=torch.int64, device="cuda")
+            import ctypes
+
+            torch.cuda.synchronize()
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMemcpy(ctypes.c_void_p(recs.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(total * 16),
+                          ctypes.c_int(3))
+            states.append(st)
+            exported.append((recs, counts))
+        for r in range(world):
+            parts = []
+            for recs, counts in exported:
+                start = sum(counts[:r])
+                parts.append(recs[2 * start: 2 * (start + counts[r])])
+            mine = torch.cat(parts).contiguous()
+            torch.cuda.synchronize()
+            states[r].distinct_import(0, mine.data_ptr(), mine.numel() // 2)
+        states[0].merge([states[1]])
+        res = states[0].finalize()
+        d = orc.distinct_bits64(data.view(np.uint64))
+        assert (res[0].total, res[0].non_null, res[0].distinct, res[0].groups_once) == \
+            (d.total, d.non_null, d.distinct, d.groups_once)
+
+
+def test_errors_are_reported_not_thrown():
+    T.init()
+    plan = T.Plan([spec(T.NUMERIC_STATS, 0)])
+    st = T.State(plan)
+    with pytest.raises(T.TgxError) as e:
+        st.update([])
+    assert e.value.status == "TGX_INVALID_ARGUMENT"
+    a = np.arange(10, dtype=np.int64)
+    plan2 = T.Plan([spec(T.NUMERIC_STATS, 0), spec(T.NUMERIC_STATS, 1)])
+    st2 = T.State(plan2)
+    with pytest.raises(T.TgxError):
+        st2.update([numeric_column(a, None, True), numeric_column(a[:5].copy(), None, True)])  # ragged batch
+    with pytest.raises(T.TgxError):
+        T.Plan([spec(99, 0)])
