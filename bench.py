@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- validated rows/s of the fused check suite on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (tgx_state_reset -> tgx_update -> [cross-rank merge] -> tgx_finalize)
+over one synthetic, device-resident batch of the 16-column "null + range + unique" table
+(term_amd/synth.py):
+    Completeness x16 + Min/Max/Mean x16 + FullUniqueness on 2 columns.
+Rows are sharded by row range across ranks (strong scaling: the table size is fixed); each rank scans
+its shard, exact distinct exchanges keys with one all-to-all (hash-owner partitioning), and the packed
+partial states are all-gathered and merged in rank order on every rank.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming ceiling)
+
+
+class DevPtr:
+    """expose a raw device pointer to torch through __cuda_array_interface__ (no copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
+                                         "version": 2}
+
+
+def build_suite(T, spec, layout, unique_cols):
+    specs = []
+    for ci in range(len(layout)):
+        specs.append(spec(T.COUNT, ci))           # completeness
+        specs.append(spec(T.NUMERIC_STATS, ci))   # has_min / has_max / has_mean
+    for ci in unique_cols:
+        specs.append(spec(T.DISTINCT, ci))        # validates_uniqueness (FullUniqueness)
+    return specs
+
+
+def exchange_distinct(T, torch, dist, st, spec_indices, world, rank):
+    """hash-owner all-to-all of the local key sets (16-byte records), then import the owned keys"""
+    for si in spec_indices:
+        ptr, counts = st.distinct_export(si, world)
+        total = sum(counts)
+        send = torch.as_tensor(DevPtr(ptr, max(total, 1) * 16), device="cuda").view(torch.int64)[: total * 2]
+        send_counts = torch.tensor(counts, dtype=torch.int64, device="cuda")
+        recv_counts = torch.empty(world, dtype=torch.int64, device="cuda")
+        dist.all_to_all_single(recv_counts, send_counts)
+        rc = recv_counts.tolist()
+        recv = torch.empty(sum(rc) * 2, dtype=torch.int64, device="cuda")
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[c * 2 for c in rc],
+                               input_split_sizes=[c * 2 for c in counts])
+        torch.cuda.synchronize()
+        st.distinct_import(si, recv.data_ptr(), sum(rc))
+
+
+def allgather_merge(T, torch, dist, plan, st, world, rank):
+    """all-gather the packed partial states and fold them in rank order (same result on every rank)"""
+    blob = st.serialize()
+    n = torch.tensor([len(blob)], dtype=torch.int64, device="cuda")
+    sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    mine = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+    mine[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    gathered = [torch.empty(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    merged = None
+    for r in range(world):
+        part = T.State.deserialize(plan, bytes(gathered[r][: sizes[r]].cpu().numpy()))
+        if merged is None:
+            merged = part
+        else:
+            merged.merge([part])
+    return merged
+
+
+def cpu_baseline(torch, layout, unique_cols, table, sample_rows):
+    """The oracle (a scalar port of the reference semantics -- NOT term-guard itself, which cannot be built
+    here) timed on one host core over the first `sample_rows` rows of the same table."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_binding as orc
+
+    host = []
+    for vals, validity in table:
+        v = vals[:sample_rows].cpu().numpy()
+        b = None if validity is None else validity[: (sample_rows + 7) // 8 + 8].cpu().numpy()
+        host.append((np.ascontiguousarray(v), b))
+    t0 = time.perf_counter()
+    for ci, (v, b) in enumerate(host):
+        orc.count(b, sample_rows)  # completeness: one scan per constraint, as the reference does
+        orc.stats(v, b, n=sample_rows)
+    for ci in unique_cols:
+        v, b = host[ci]
+        orc.distinct_bits64(v.view(np.uint64), b, n=sample_rows)
+    dt = time.perf_counter() - t0
+    return {"value": sample_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "first %d rows x %d cols of the same table, oracle/tgx_oracle.c single thread, %.1f s"
+                      % (sample_rows, len(layout), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="total rows of the table (all ranks)")
+    ap.add_argument("--seed", type=int, default=0x7E570004)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import term_amd as T
+    from term_amd import synth
+    from term_amd._lib import spec
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    layout, unique_cols = synth.COLUMNS_16, synth.UNIQUE_COLUMNS_16
+    n_total = (args.rows // (64 * world)) * 64 * world  # 64-row aligned shard boundaries
+    n_local = n_total // world
+    row0 = rank * n_local
+
+    T.init(device_id=local_rank, distinct_capacity_hint=n_total)
+    specs = build_suite(T, spec, layout, unique_cols)
+    distinct_spec_idx = [i for i, s in enumerate(specs) if s.kind == T.DISTINCT]
+    plan = T.Plan(specs)
+    stream = torch.cuda.Stream()
+    st = T.State(plan, stream=stream.cuda_stream)
+
+    table = synth.make_table(layout, row0, n_local, n_total, args.seed, "cuda")
+    columns = []
+    for (kind, _), (vals, validity) in zip(layout, table):
+        ctor = T.Column.float64 if kind.startswith("f_") else T.Column.int64
+        columns.append(ctor(vals, validity, length=n_local))
+    torch.cuda.synchronize()
+
+    def step():
+        st.reset()
+        st.update(columns)
+        if world > 1:
+            exchange_distinct(T, torch, dist, st, distinct_spec_idx, world, rank)
+            merged = allgather_merge(T, torch, dist, plan, st, world, rank)
+            return merged.finalize()
+        return st.finalize()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    st.profile_enable(True)
+    st.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    prof = st.profile_get("scan")
+    prof_d = st.profile_get("distinct")
+    st.profile_enable(False)
+
+    # ---- verification outside the timed region: closed-form facts of the synthetic table ----
+    verified = None
+    if not args.no_verify:
+        by_col = {}
+        for s, r in zip(specs, res):
+            by_col.setdefault(s.column, {})[s.kind] = r
+        ok = True
+        for ci, (kind, has_validity) in enumerate(layout):
+            c, stt = by_col[ci][T.COUNT], by_col[ci][T.NUMERIC_STATS]
+            ok &= c.total == n_total and stt.total == n_total and c.non_null == stt.non_null
+            if not has_validity:
+                ok &= c.non_null == n_total
+            else:
+                ok &= abs(c.non_null / n_total - (1 - synth.NULL_RATE)) < 1e-3
+        d_id, d_k = by_col[0][T.DISTINCT], by_col[1][T.DISTINCT]
+        ok &= d_id.distinct == n_total  # bijective id column: uniqueness ratio exactly 1.0
+        ok &= by_col[0][T.NUMERIC_STATS].min_i == 0 and by_col[0][T.NUMERIC_STATS].max_i == n_total - 1
+        ok &= by_col[0][T.NUMERIC_STATS].sum_i == n_total * (n_total - 1) // 2
+        ok &= 0 < d_k.distinct <= max(1, n_total // 10)
+        verified = bool(ok)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        rows_per_s = n_total * args.steps / dt
+        alg_suite = synth.algorithmic_bytes(layout, n_total)
+        scan_ms = prof["total_ms"] / max(1, prof["launches"])
+        scan_bytes = prof["bytes"] / max(1, prof["launches"])
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "validated rows/sec, 16-col null+range+unique suite",
+            "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
+            "config": {"workload": "16-col (8 int64 + 8 float64, 12 nullable) null+range+unique suite: "
+                                   "completeness x16, min/max/mean x16, uniqueness x2",
+                       "rows_total": n_total, "rows_per_gpu": n_local, "cols": len(layout),
+                       "parallelism": "row-range shards x%d" % world,
+                       "suite_algorithmic_bytes": alg_suite,
+                       "suite_hbm_gbs": alg_suite / (dt / args.steps) / 1e9,
+                       "suite_frac_of_8TBs": alg_suite / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                       "distinct_ms_per_step": prof_d["total_ms"] / max(1, args.steps),
+                       "verified": verified},
+            "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, layout, unique_cols, table,
+                                               min(args.cpu_sample_rows, n_local))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

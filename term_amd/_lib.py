@@ -75,6 +75,26 @@ def abi_symbols():
 _LIB = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch's wheel carries its own libamdhip64.so (same SONAME as
+    /opt/rocm's); if libtgx.so pulled in the system copy first and torch its own copy later, the second
+    runtime to initialise finds no device.  Loading torch's copy first makes both resolve to it."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        found = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        found = None
+    if found is None or not found.origin:
+        return
+    cand = os.path.join(os.path.dirname(found.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -83,6 +103,7 @@ def lib():
             raise ImportError(
                 "term_amd/libtgx.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C term_amd/csrc` (hipcc, gfx950). term_amd has no CPU fallback.")
+        _preload_hip_runtime()
         L = C.CDLL(path)
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
         E = C.POINTER(_Error)

@@ -14,6 +14,7 @@ static tgx_status kfail(tgx_error *err, tgx_status code, const char *msg) {
 }
 void kll_state_init(tgx_state *) {}
 void kll_state_free(tgx_state *) {}
+void kll_state_reset(tgx_state *) {}
 tgx_status kll_update(tgx_state *, size_t, const tgx_column &, tgx_error *err) {
   return kfail(err, TGX_UNSUPPORTED, "KLL is not implemented yet");
 }

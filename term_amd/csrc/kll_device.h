@@ -5,6 +5,7 @@
 namespace tgx {
 void kll_state_init(tgx_state *st);
 void kll_state_free(tgx_state *st);
+void kll_state_reset(tgx_state *st);
 tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &col, tgx_error *err);
 // folds the device-side sketch of every KLL task into st->h_kll (leaves the device side empty)
 tgx_status kll_flush(tgx_state *st, tgx_error *err);

@@ -19,6 +19,7 @@ size_t regex_num_tasks(const tgx_plan *) { return 0; }
 void regex_mark_used(const tgx_plan *, std::vector<char> &) {}
 void regex_state_init(tgx_state *) {}
 void regex_state_free(tgx_state *) {}
+void regex_state_reset(tgx_state *) {}
 tgx_status regex_update(tgx_state *, const tgx_column *, tgx_error *) { return TGX_OK; }
 tgx_status regex_fill_result(tgx_state *, int, tgx_result *, tgx_error *) { return TGX_OK; }
 tgx_status regex_merge_states(tgx_state *, tgx_state *, tgx_error *) { return TGX_OK; }

@@ -11,6 +11,7 @@ size_t regex_num_tasks(const tgx_plan *plan);
 void regex_mark_used(const tgx_plan *plan, std::vector<char> &used);
 void regex_state_init(tgx_state *st);
 void regex_state_free(tgx_state *st);
+void regex_state_reset(tgx_state *st);
 tgx_status regex_update(tgx_state *st, const tgx_column *dev_columns, tgx_error *err);
 tgx_status regex_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *err);
 tgx_status regex_merge_states(tgx_state *dst, tgx_state *src, tgx_error *err);

@@ -381,23 +381,46 @@ extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) {
 extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
-  hipStream_t stream = st->stream;
-  bool own = st->own_stream;
-  bool prof = st->profiling;
-  // drop device buffers of the variable-size parts, keep the stream
-  regex_state_free(st);
-  kll_state_free(st);
-  st->d_scan_acc.release();
-  st->d_count_acc.release();
-  st->d_como_acc.release();
-  st->d_pivots.release();
-  st->d_pivot_set.release();
-  st->device_ready = false;
+  // host side back to the identity; device buffers are kept and re-zeroed (no hipFree / hipMalloc)
   st->batches = 0;
-  state_init_host(st, plan);
-  st->stream = stream;
-  st->own_stream = own;
-  st->profiling = prof;
+  st->col_types.assign(plan->n_columns_needed, 0);
+  st->h_scan.assign(plan->scan.size(), scan_acc_identity());
+  st->h_count.assign(plan->count.size(), CountAcc{0, 0});
+  ComomentAcc z;
+  memset(&z, 0, sizeof(z));
+  st->h_como.assign(plan->como.size(), z);
+  for (auto &d : st->distinct) {
+    d.mode = DistinctMode::kUndecided;
+    d.col_type = 0;
+    d.base = 0;
+    d.range = 0;
+    d.capacity = 0;  // buffers stay allocated; hash_ensure / the bitmap path clear them before use
+    d.rows_upper_bound = 0;
+    d.total_rows = 0;
+    d.partitioned = false;
+    d.h_total = d.h_non_null = d.h_distinct = d.h_twice = d.h_empty_rows = 0;
+  }
+  for (size_t i = 0; i < st->h_kll.size(); i++) {
+    st->h_kll[i] = KllHost();
+    st->h_kll[i].k = plan->kll[i].k;
+  }
+  kll_state_reset(st);
+  regex_state_reset(st);
+  if (st->device_ready) {
+    if (!plan->scan.empty()) {
+      std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
+      HIP_TRY(hipMemcpy(st->d_scan_acc.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemsetAsync(st->d_pivots.p, 0, plan->scan.size() * sizeof(double), st->stream));
+      HIP_TRY(hipMemsetAsync(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t), st->stream));
+    }
+    if (!plan->count.empty())
+      HIP_TRY(hipMemsetAsync(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc), st->stream));
+    if (!plan->como.empty())
+      HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
+    for (auto &d : st->distinct)
+      if (d.counters.p)
+        HIP_TRY(hipMemsetAsync(d.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
+  }
   return TGX_OK;
 }
 
@@ -737,12 +760,12 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   TGX_TRY(state_init_device(st, err));
 
   // which columns does the plan touch, and do they agree on the row count
-  std::vector<char> used(plan->n_columns_needed, 0);
-  for (auto &t : plan->scan) used[t.column] = 1;
+  std::vector<char> used(plan->n_columns_needed, 0), reads_values(plan->n_columns_needed, 0);
+  for (auto &t : plan->scan) used[t.column] = reads_values[t.column] = 1;
   for (auto &t : plan->count) used[t.column] = 1;
-  for (auto &t : plan->distinct) used[t.column] = 1;
-  for (auto &t : plan->como) used[t.col_x] = used[t.col_y] = 1;
-  for (auto &t : plan->kll) used[t.column] = 1;
+  for (auto &t : plan->distinct) used[t.column] = reads_values[t.column] = 1;
+  for (auto &t : plan->como) used[t.col_x] = used[t.col_y] = reads_values[t.col_x] = reads_values[t.col_y] = 1;
+  for (auto &t : plan->kll) used[t.column] = reads_values[t.column] = 1;
   regex_mark_used(plan, used);
   int64_t nrows = -1;
   for (int i = 0; i < plan->n_columns_needed; i++) {
@@ -759,7 +782,8 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       return fail(err, TGX_INVALID_ARGUMENT, "column %d changed type between batches (%d -> %d)", i,
                   st->col_types[i], c.type);
     if (c.length > 0) {
-      if (is_numeric(c.type) && !c.values) return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
+      if (is_numeric(c.type) && reads_values[i] && !c.values)
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
       if ((c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && !c.offsets)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets is NULL", i);
     }
