@@ -34,6 +34,9 @@ void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
+void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu,
+                      hipStream_t stream);
+void launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
                         unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,
@@ -144,6 +147,8 @@ struct DistinctState {
   DevBuf seen, twice;
   int64_t base = 0;
   uint64_t range = 0;
+  // range-partitioned population of the bitmap (big batches)
+  DevBuf lists, cursors;
   // hash
   DevBuf keys, dup;
   uint64_t capacity = 0;         // slots (power of two)

@@ -40,15 +40,20 @@ __device__ __forceinline__ void block_add2(unsigned long long a, unsigned long l
     a += __shfl_down(a, d, 64);
     b += __shfl_down(b, d, 64);
   }
-  __shared__ unsigned long long sa[4], sb[4];
+  __shared__ unsigned long long sa[16], sb[16];
   const int wave = threadIdx.x >> 6;
+  const int n_waves = (blockDim.x + 63) >> 6;
   if ((threadIdx.x & 63) == 0) {
     sa[wave] = a;
     sb[wave] = b;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long ta = sa[0] + sa[1] + sa[2] + sa[3], tb = sb[0] + sb[1] + sb[2] + sb[3];
+    unsigned long long ta = 0, tb = 0;
+    for (int w = 0; w < n_waves; w++) {
+      ta += sa[w];
+      tb += sb[w];
+    }
     if (ta) atomicAdd(ga, ta);
     if (tb) atomicAdd(gb, tb);
   }
@@ -64,8 +69,10 @@ __device__ __forceinline__ int hash_insert(const HashSetView &t, uint64_t key, i
                   (unsigned long long)key);
     if (old == kEmptyKey) {
       if (want_mult && weight_two) {
-        atomicOr(&t.dup[h >> 5], 1u << (h & 31));
-        *became_dup = 1;
+        // another thread that found this key may already have set the bit: count it once
+        const uint32_t bit = 1u << (h & 31);
+        uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
+        *became_dup = (prev & bit) ? 0 : 1;
       }
       return 1;
     }
@@ -146,6 +153,147 @@ __global__ __launch_bounds__(256) void distinct_bitmap_kernel(DistinctColDesc d,
   block_add2(n_new, n_dup, &counters[0], &counters[1]);
   __syncthreads();
   block_add2(n_out, n_valid, &counters[4], &counters[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Range-partitioned bitmap population: the fast path for big batches of a dense-range Int64 column.
+// A global atomicOr per row runs at ~27 G rows/s on MI355X (memory-side atomics); replaying bucketed
+// keys against an LDS-resident slice of the bitmap is bounded by HBM traffic instead:
+//   phase 1 reads 8 B/row and writes 4 B/row, phase 2 reads 4 B/row (+ the bitmap once).
+//
+// Phase 1.  One 1024-thread workgroup takes tiles of 32768 rows.  Each key gets its bucket and an
+// in-tile rank from an LDS histogram (ds_add_rtn), the workgroup reserves room in every bucket list it
+// touches with ONE global atomicAdd per (tile, bucket), and every lane then stores its 32-bit in-bucket
+// offset.  A list that is full (skewed data) spills to the global atomicOr path, so the result is exact
+// for any distribution and only the speed depends on the spread.
+__global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionParams p,
+                                                                      unsigned long long *counters) {
+  __shared__ uint32_t hist[kMaxPartitions];
+  __shared__ uint32_t gbase[kMaxPartitions];
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)p.values + p.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)p.validity;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t sub_mask = (1ull << p.sub_bits) - 1;
+  unsigned long long n_valid = 0;
+  const int64_t n_tiles = (p.length + kPartitionTile - 1) / kPartitionTile;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint32_t b = tid; b < p.n_buckets; b += kPartitionThreads) hist[b] = 0;
+    __syncthreads();
+    const int64_t row0 = tile * kPartitionTile;
+    uint32_t rel[kPartitionKeysPerThread];   // in-bucket offset
+    uint32_t info[kPartitionKeysPerThread];  // bucket << 16 | rank in tile, or ~0 for NULL / no row
+#pragma unroll
+    for (int j = 0; j < kPartitionKeysPerThread; j++) {
+      const int64_t i = row0 + (int64_t)j * kPartitionThreads + tid;
+      bool valid = i < p.length;
+      int64_t key = 0;
+      if (valid) {
+        key = vals[i];
+        if (vbits) {
+          const int64_t bit = p.offset + i;
+          valid = (vbits[bit >> 3] >> (bit & 7)) & 1;
+        }
+      }
+      const uint64_t r = (uint64_t)key - (uint64_t)p.base;
+      info[j] = 0xFFFFFFFFu;
+      rel[j] = 0;
+      if (valid) {
+        const uint32_t b = (uint32_t)(r >> p.sub_bits);
+        const uint32_t rank = atomicAdd(&hist[b], 1u);
+        info[j] = (b << 16) | rank;
+        rel[j] = (uint32_t)(r & sub_mask);
+        n_valid++;
+      }
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < p.n_buckets; b += kPartitionThreads) {
+      const uint32_t h = hist[b];
+      uint32_t g = 0;
+      if (h) {
+        // cap < 2^32 (checked on the host); a start at or past cap means the whole run spills
+        const unsigned long long at = atomicAdd(&p.cursors[b], (unsigned long long)h);
+        g = at >= p.cap ? 0xFFFFFFFFu : (uint32_t)at;
+      }
+      gbase[b] = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPartitionKeysPerThread; j++) {
+      if (info[j] == 0xFFFFFFFFu) continue;
+      const uint32_t b = info[j] >> 16;
+      const uint64_t pos = (uint64_t)gbase[b] + (info[j] & 0xFFFFu);
+      if (gbase[b] != 0xFFFFFFFFu && pos < p.cap) {
+        p.lists[(uint64_t)b * p.cap + pos] = rel[j];
+      } else {
+        // spill: straight into the global bitmap
+        const uint64_t r = ((uint64_t)b << p.sub_bits) | rel[j];
+        const uint32_t bit = 1u << (r & 31);
+        const uint32_t prev = atomicOr(&p.seen[r >> 5], bit);
+        if ((prev & bit) && p.want_multiplicity) atomicOr(&p.twice[r >> 5], bit);
+      }
+    }
+    __syncthreads();
+  }
+  block_add2(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+// Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of
+// earlier batches and this batch's spills), replay list b with LDS atomics, store it back, and add the
+// slice's popcounts to the totals (counters[kCntDistinct] / [kCntTwice] are zeroed before the launch).
+__global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(PartitionParams p,
+                                                                         unsigned long long *counters) {
+  __shared__ uint32_t lds[kSliceWordsLds];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  const uint32_t slice_words = (uint32_t)((1ull << p.sub_bits) >> 5);
+  uint32_t *l_seen = lds;
+  uint32_t *l_twice = lds + slice_words;  // only with multiplicity (host guarantees 2*slice_words fit)
+  uint32_t *g_seen = p.seen + (uint64_t)b * slice_words;
+  uint32_t *g_twice = p.want_multiplicity ? p.twice + (uint64_t)b * slice_words : nullptr;
+  for (uint32_t w = tid * 4; w < slice_words; w += kPartitionThreads * 4) {
+    *(uint4 *)&l_seen[w] = *(const uint4 *)&g_seen[w];
+    if (g_twice) *(uint4 *)&l_twice[w] = *(const uint4 *)&g_twice[w];
+  }
+  __syncthreads();
+  unsigned long long cnt = p.cursors[b];
+  if (cnt > p.cap) cnt = p.cap;
+  const uint32_t *list = p.lists + (uint64_t)b * p.cap;
+  const uint64_t n4 = cnt & ~3ull;
+  for (uint64_t i = (uint64_t)tid * 4; i < n4; i += (uint64_t)kPartitionThreads * 4) {
+    const uint4 k = *(const uint4 *)&list[i];
+    const uint32_t ks[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t bit = 1u << (ks[u] & 31);
+      if (g_twice) {
+        const uint32_t prev = atomicOr(&l_seen[ks[u] >> 5], bit);
+        if (prev & bit) atomicOr(&l_twice[ks[u] >> 5], bit);
+      } else {
+        atomicOr(&l_seen[ks[u] >> 5], bit);
+      }
+    }
+  }
+  if (tid < (cnt & 3)) {
+    const uint32_t kk = list[n4 + tid];
+    const uint32_t bit = 1u << (kk & 31);
+    const uint32_t prev = atomicOr(&l_seen[kk >> 5], bit);
+    if (g_twice && (prev & bit)) atomicOr(&l_twice[kk >> 5], bit);
+  }
+  __syncthreads();
+  unsigned long long n_seen = 0, n_twice = 0;
+  for (uint32_t w = tid * 4; w < slice_words; w += kPartitionThreads * 4) {
+    const uint4 s4 = *(const uint4 *)&l_seen[w];
+    *(uint4 *)&g_seen[w] = s4;
+    n_seen += __builtin_popcount(s4.x) + __builtin_popcount(s4.y) + __builtin_popcount(s4.z) +
+              __builtin_popcount(s4.w);
+    if (g_twice) {
+      const uint4 t4 = *(const uint4 *)&l_twice[w];
+      *(uint4 *)&g_twice[w] = t4;
+      n_twice += __builtin_popcount(t4.x) + __builtin_popcount(t4.y) + __builtin_popcount(t4.z) +
+                 __builtin_popcount(t4.w);
+    }
+  }
+  block_add2(n_seen, n_twice, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
 // Re-inserts every key of `src` into `dst` (growth, merge, bitmap -> hash conversion).
@@ -287,6 +435,20 @@ __global__ __launch_bounds__(256) void bitmap_export_scatter_kernel(BitmapView b
       out[pos] = r;
     }
   }
+}
+
+void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu,
+                      hipStream_t stream) {
+  int64_t n_tiles = (p.length + kPartitionTile - 1) / kPartitionTile;
+  int grid = (int)(n_tiles < (int64_t)n_cu * 2 ? n_tiles : (int64_t)n_cu * 2);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(partition_kernel, dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
+}
+
+void launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(bucket_apply_kernel, dim3(p.n_buckets), dim3(kPartitionThreads), 0, stream, p,
+                     d_counters);
 }
 
 static inline int grid_for(uint64_t items) {

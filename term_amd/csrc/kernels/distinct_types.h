@@ -28,6 +28,33 @@ struct BitmapView {
   uint64_t range;   // number of representable keys
 };
 
+// Range-partitioned population of the bitmap (distinct.hip, partition_kernel / bucket_apply_kernel):
+// phase 1 scatters (key - base) into P = ceil(range / 2^sub_bits) bucket lists of 32-bit in-bucket
+// offsets; phase 2 replays each list against its 2^sub_bits-bit slice of the bitmap held in LDS.
+constexpr uint32_t kMaxPartitions = 4096;
+constexpr int kPartitionThreads = 1024;
+constexpr int kPartitionKeysPerThread = 32;
+constexpr int kPartitionTile = kPartitionThreads * kPartitionKeysPerThread;  // 32768 keys
+constexpr int kSliceWordsLds = 32768;  // 128 KiB of LDS bitmap per workgroup
+
+struct PartitionParams {
+  const void *values;
+  const uint8_t *validity;
+  int64_t offset;
+  int64_t length;
+  int64_t base;
+  uint64_t range;
+  uint32_t sub_bits;   // log2(keys per bucket)
+  uint32_t n_buckets;  // P
+  uint64_t cap;        // list capacity per bucket (keys), multiple of 4
+  uint32_t *lists;     // P x cap
+  unsigned long long *cursors;  // P, zeroed per batch
+  uint32_t *seen;      // global bitmap (rounded up to whole slices)
+  uint32_t *twice;     // or nullptr
+  int32_t want_multiplicity;
+  int32_t pad;
+};
+
 // 16-byte record used by merge / serialize / the cross-rank key exchange.
 struct KeyRecord {
   uint64_t key;

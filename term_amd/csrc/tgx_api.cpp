@@ -711,7 +711,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       uint64_t width = (uint64_t)hi - (uint64_t)lo;
       uint64_t expect = std::max<uint64_t>((uint64_t)c.length, g_ctx.distinct_hint);
       if (width < (1ull << 34) && width / 16 <= expect) {
-        uint64_t slack = std::min<uint64_t>(width / 2 + 64, 1ull << 30);
+        uint64_t slack = std::min<uint64_t>(width / 8 + 64, 1ull << 30);
         int64_t base = (lo < INT64_MIN + (int64_t)slack) ? INT64_MIN : lo - (int64_t)slack;
         uint64_t top = (hi > INT64_MAX - (int64_t)slack) ? (uint64_t)INT64_MAX : (uint64_t)(hi + (int64_t)slack);
         ds.base = base;
@@ -722,7 +722,8 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       return TGX_OK;  // batch of NULLs only: nothing to insert, decide later
     }
     if (use_bitmap) {
-      size_t words = (size_t)((ds.range + 31) / 32) + 2;
+      // whole 2^20-bit slices, so the partitioned path can move slices through LDS
+      size_t words = (size_t)(((ds.range + (1u << 20) - 1) >> 20) << 15) + 4;
       HIP_TRY(ds.seen.reserve(words * 4));
       HIP_TRY(hipMemsetAsync(ds.seen.p, 0, words * 4, st->stream));
       if (mult) {
@@ -739,8 +740,43 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     if (!fits) TGX_TRY(bitmap_to_hash(st, ds, mult, (uint64_t)c.length, err));
   }
   if (ds.mode == DistinctMode::kBitmap) {
-    ProfScope ps(st, "distinct", bytes);
-    launch_distinct_bitmap(d, bitmap_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+    // big batch over a dense range: bucket the keys and replay them against LDS-resident slices
+    const uint32_t sub_bits = mult ? 19 : 20;
+    const uint64_t n_buckets = (ds.range + (1ull << sub_bits) - 1) >> sub_bits;
+    const bool partitioned = c.length >= (1 << 20) && n_buckets <= kMaxPartitions &&
+                             (uint64_t)c.length * 64 >= ds.range;
+    if (partitioned) {
+      PartitionParams pp;
+      pp.values = c.values;
+      pp.validity = c.validity;
+      pp.offset = c.offset;
+      pp.length = c.length;
+      pp.base = ds.base;
+      pp.range = ds.range;
+      pp.sub_bits = sub_bits;
+      pp.n_buckets = (uint32_t)n_buckets;
+      uint64_t cap = (uint64_t)c.length / n_buckets;
+      cap = cap + cap / 4 + 4096;
+      pp.cap = (cap + 3) & ~3ull;
+      pp.want_multiplicity = mult ? 1 : 0;
+      pp.pad = 0;
+      HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * sizeof(uint32_t)));
+      HIP_TRY(ds.cursors.reserve(pp.n_buckets * sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
+      pp.lists = ds.lists.as<uint32_t>();
+      pp.cursors = ds.cursors.as<unsigned long long>();
+      pp.seen = ds.seen.as<uint32_t>();
+      pp.twice = mult ? ds.twice.as<uint32_t>() : nullptr;
+      unsigned long long *cnt = ds.counters.as<unsigned long long>();
+      ProfScope ps(st, "distinct", bytes);
+      launch_partition(pp, cnt, g_ctx.n_cu, st->stream);
+      // phase 2 recomputes the totals from the slices
+      HIP_TRY(hipMemsetAsync(cnt + kCntDistinct, 0, 2 * sizeof(unsigned long long), st->stream));
+      launch_bucket_apply(pp, cnt, st->stream);
+    } else {
+      ProfScope ps(st, "distinct", bytes);
+      launch_distinct_bitmap(d, bitmap_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+    }
   } else {
     TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
     ProfScope ps(st, "distinct", bytes);

@@ -202,6 +202,38 @@ def test_distinct_modes(case):
     assert got == (d.total, d.non_null, d.distinct, d.groups_once), case
 
 
+@pytest.mark.parametrize("mult", [False, True])
+@pytest.mark.parametrize("shape", ["uniform", "skewed", "permutation", "two_batches"])
+def test_distinct_partitioned_bitmap(shape, mult):
+    """>= 2^20-row batches over a dense range take the bucket + LDS-slice path; skew spills to atomics."""
+    rng = np.random.default_rng(abs(hash((shape, mult))) % 2**32)
+    n = 3_000_017
+    validity = None
+    if shape == "uniform":
+        vals, validity = make_i64(rng, n, -1_000_000, 1_500_000, null_frac=0.05)
+    elif shape == "skewed":
+        vals = rng.integers(0, 4_000_000, size=n, dtype=np.int64)
+        hot = rng.random(n) < 0.9
+        vals[hot] = rng.integers(2_000_000, 2_000_512, size=int(hot.sum()), dtype=np.int64)
+    elif shape == "permutation":
+        vals = rng.permutation(n).astype(np.int64) + 10**12
+    else:
+        vals = rng.integers(0, 3_000_000, size=n, dtype=np.int64)
+    flags = T.FLAG_MULTIPLICITY if mult else 0
+    if shape == "two_batches":
+        half = n // 2
+        batches = [[numeric_column(vals, None, True, offset=0, length=half)],
+                   [numeric_column(vals, None, True, offset=half, length=n - half)]]
+    else:
+        batches = [[numeric_column(vals, validity, True)]]
+    res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=flags), spec(T.NUMERIC_STATS, 0)], batches, hint=n)
+    d = orc.distinct_bits64(vals.view(np.uint64), validity, n=n)
+    assert (res[0].total, res[0].non_null, res[0].distinct) == (d.total, d.non_null, d.distinct)
+    if mult:
+        assert res[0].groups_once == d.groups_once
+    check_stats(res[1], orc.stats(vals, validity))
+
+
 def test_distinct_bitmap_escapes_to_hash_on_out_of_range_batch():
     rng = np.random.default_rng(5)
     a = rng.integers(0, 1000, size=50_000, dtype=np.int64)
