@@ -34,9 +34,10 @@ void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
-void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu,
+void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, int kpt,
                       hipStream_t stream);
-void launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters, hipStream_t stream);
+hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
+                               hipStream_t stream);
 void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
                         unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,

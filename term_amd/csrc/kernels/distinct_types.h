@@ -31,7 +31,8 @@ struct BitmapView {
 // Range-partitioned population of the bitmap (distinct.hip, partition_kernel / bucket_apply_kernel):
 // phase 1 scatters (key - base) into P = ceil(range / 2^sub_bits) bucket lists of 32-bit in-bucket
 // offsets; phase 2 replays each list against its 2^sub_bits-bit slice of the bitmap held in LDS.
-constexpr uint32_t kMaxPartitions = 4096;
+constexpr uint32_t kMaxPartitions = 2048;
+constexpr uint32_t kListPad = 0xFFFFFFFFu;  // filler of the 16-slot aligned runs in the bucket lists
 constexpr int kPartitionThreads = 1024;
 constexpr int kPartitionKeysPerThread = 32;
 constexpr int kPartitionTile = kPartitionThreads * kPartitionKeysPerThread;  // 32768 keys
@@ -46,9 +47,9 @@ struct PartitionParams {
   uint64_t range;
   uint32_t sub_bits;   // log2(keys per bucket)
   uint32_t n_buckets;  // P
-  uint64_t cap;        // list capacity per bucket (keys), multiple of 4
+  uint64_t cap;        // list capacity per bucket (32-bit slots), multiple of 16
   uint32_t *lists;     // P x cap
-  unsigned long long *cursors;  // P, zeroed per batch
+  unsigned long long *cursors;  // [0,P): next free slot per list (zeroed per batch); [P,2P): valid-length limits (all-ones)
   uint32_t *seen;      // global bitmap (rounded up to whole slices)
   uint32_t *twice;     // or nullptr
   int32_t want_multiplicity;

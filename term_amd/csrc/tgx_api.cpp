@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -741,10 +742,15 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
   }
   if (ds.mode == DistinctMode::kBitmap) {
     // big batch over a dense range: bucket the keys and replay them against LDS-resident slices
-    const uint32_t sub_bits = mult ? 19 : 20;
+    // slices of 2^sub_bits keys: as many buckets as fit the phase-1 histogram (<= 2048 targeted) so
+    // every CU has lists to replay (<= 1024 targeted: longer runs per tile); one slice (two with multiplicity) must fit 128 KiB of LDS
+    uint32_t sub_bits = 14;
+    while (sub_bits < (mult ? 19u : 20u) && ((ds.range + (1ull << sub_bits) - 1) >> sub_bits) > 1024) sub_bits++;
     const uint64_t n_buckets = (ds.range + (1ull << sub_bits) - 1) >> sub_bits;
+    uint64_t cap_slots = (uint64_t)c.length / std::max<uint64_t>(n_buckets, 1);
+    cap_slots = cap_slots + cap_slots / 4 + 16 * (((uint64_t)c.length >> 15) + 1) + 4096;
     const bool partitioned = c.length >= (1 << 20) && n_buckets <= kMaxPartitions &&
-                             (uint64_t)c.length * 64 >= ds.range;
+                             (uint64_t)c.length * 64 >= ds.range && cap_slots < (1ull << 32) - 64;
     if (partitioned) {
       PartitionParams pp;
       pp.values = c.values;
@@ -755,24 +761,29 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       pp.range = ds.range;
       pp.sub_bits = sub_bits;
       pp.n_buckets = (uint32_t)n_buckets;
+      // runs are padded to 16 slots per (tile, bucket): budget the average load + 25 % + the padding
+      const uint64_t tiles = ((uint64_t)c.length + kPartitionTile - 1) / kPartitionTile;
       uint64_t cap = (uint64_t)c.length / n_buckets;
-      cap = cap + cap / 4 + 4096;
-      pp.cap = (cap + 3) & ~3ull;
+      cap = cap + cap / 4 + 16 * tiles + 4096;
+      pp.cap = (cap + 15) & ~15ull;
       pp.want_multiplicity = mult ? 1 : 0;
       pp.pad = 0;
       HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * sizeof(uint32_t)));
-      HIP_TRY(ds.cursors.reserve(pp.n_buckets * sizeof(unsigned long long)));
+      HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
       HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
+      HIP_TRY(hipMemsetAsync(ds.cursors.as<unsigned long long>() + pp.n_buckets, 0xFF,
+                             pp.n_buckets * sizeof(unsigned long long), st->stream));
       pp.lists = ds.lists.as<uint32_t>();
       pp.cursors = ds.cursors.as<unsigned long long>();
       pp.seen = ds.seen.as<uint32_t>();
       pp.twice = mult ? ds.twice.as<uint32_t>() : nullptr;
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
       ProfScope ps(st, "distinct", bytes);
-      launch_partition(pp, cnt, g_ctx.n_cu, st->stream);
+      static const int kpt = getenv("TGX_PARTITION_KPT") ? atoi(getenv("TGX_PARTITION_KPT")) : 32;
+      launch_partition(pp, cnt, g_ctx.n_cu, kpt == 16 ? 16 : 32, st->stream);
       // phase 2 recomputes the totals from the slices
       HIP_TRY(hipMemsetAsync(cnt + kCntDistinct, 0, 2 * sizeof(unsigned long long), st->stream));
-      launch_bucket_apply(pp, cnt, st->stream);
+      HIP_TRY(launch_bucket_apply(pp, cnt, st->stream));
     } else {
       ProfScope ps(st, "distinct", bytes);
       launch_distinct_bitmap(d, bitmap_view(ds), ds.counters.as<unsigned long long>(), st->stream);
