@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
       global_i64x2_ptr pv = (global_i64x2_ptr)(vals + row0) + tid;
 #pragma unroll
       for (int j = 0; j < KPT / 2; j++) {
-        i64x2 v = pv[(int64_t)j * kPartitionThreads];
+        i64x2 v = (p.pad & 2) ? __builtin_nontemporal_load(&pv[(int64_t)j * kPartitionThreads]) : pv[(int64_t)j * kPartitionThreads];
         key[2 * j] = v.x;
         key[2 * j + 1] = v.y;
       }
@@ -312,7 +312,10 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
       if (g != 0xFFFFFFFFu) {
         const uint32_t padded = (h + 15u) & ~15u;
         uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;
-        for (uint32_t i = lane; i < padded; i += 64) dst[i] = i < h ? sorted[o + i] : kListPad;
+        for (uint32_t i = lane; i < padded; i += 64) {
+          const uint32_t v = i < h ? sorted[o + i] : kListPad;
+          if (p.pad & 1) __builtin_nontemporal_store(v, &dst[i]); else dst[i] = v;
+        }
       } else {
         for (uint32_t i = lane; i < h; i += 64) {
           // spill: straight into the global bitmap

@@ -1,0 +1,331 @@
+// kll.hip -- KLL quantile sketch construction on gfx950.
+//
+// The reference drives KllSketch::update one value at a time on the host
+// (TG/analyzers/advanced/kll_sketch.rs:195-229: push to the level-0 buffer, sort + halve when it is
+// full, cascade).  Here every workgroup sketches its own row range with the same primitive --
+// "sort a buffer, keep every other item, promote them one level (weight x2)" -- at a fixed run length:
+//   level 0      : up to 1023 raw items (weight 1)
+//   level l >= 1 : zero or one sorted run of exactly 512 items (weight 2^l)
+// Inserting a run into an occupied level merges the two runs (bitonic merge in LDS), keeps every
+// other item and carries the result one level up, like a binary counter.  Workgroup sketches are then
+// combined pairwise by the same insertion (a log2(G)-round tree) and folded into the state's running
+// sketch, so the whole column costs one HBM pass; nothing but the final ~100 KiB sketch ever reaches
+// the host.  Total weight is preserved exactly (sum over levels of items x 2^level == n).
+#include <hip/hip_runtime.h>
+
+#include "kll_types.h"
+
+namespace tgx {
+
+typedef const int64_t __attribute__((address_space(1))) *global_i64_ptr;
+typedef const uint8_t __attribute__((address_space(1))) *global_u8_ptr;
+
+constexpr int kKllThreads = 256;
+
+__device__ __forceinline__ uint64_t kll_mix(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+
+// full ascending bitonic sort of buf[0..1023] by 256 threads
+__device__ void block_sort_1024(double *buf) {
+  const uint32_t t0 = threadIdx.x;
+  for (uint32_t k = 2; k <= 1024; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (uint32_t u = 0; u < 2; u++) {
+        const uint32_t t = t0 + u * kKllThreads;  // comparator index 0..511
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t p = i | j;
+        const double a = buf[i], b = buf[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          buf[i] = b;
+          buf[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// buf[0..511] ascending and buf[512..1023] DESCENDING (a bitonic sequence) -> fully ascending
+__device__ void block_bitonic_merge_1024(double *buf) {
+  const uint32_t t0 = threadIdx.x;
+  for (uint32_t j = 512; j > 0; j >>= 1) {
+#pragma unroll
+    for (uint32_t u = 0; u < 2; u++) {
+      const uint32_t t = t0 + u * kKllThreads;
+      const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+      const uint32_t p = i | j;
+      const double a = buf[i], b = buf[p];
+      if (a > b) {
+        buf[i] = b;
+        buf[p] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Inserts the sorted 512-item run held in buf[0..511] at `level` of sketch s (global memory),
+// carrying upwards while the level is occupied.  buf (1024 doubles of LDS) is scratch.
+__device__ void insert_run(KllDeviceSketch *s, uint32_t level, double *buf, uint64_t salt) {
+  const uint32_t t = threadIdx.x;
+  for (;;) {
+    const uint64_t mask = s->level_mask;  // uniform: every thread reads the same word
+    __syncthreads();
+    if (level >= kKllMaxLevels) return;  // unreachable for n < 2^56
+    if (!((mask >> level) & 1)) {
+      double *dst = s->runs[level];
+      dst[t] = buf[t];
+      dst[t + 256] = buf[t + 256];
+      __syncthreads();
+      if (t == 0) s->level_mask = mask | (1ull << level);
+      __threadfence_block();
+      __syncthreads();
+      return;
+    }
+    // occupied: merge the stored run (loaded reversed into the upper half) with the incoming one
+    const double *src = s->runs[level];
+    buf[1023 - t] = src[t];
+    buf[1023 - (t + 256)] = src[t + 256];
+    __syncthreads();
+    block_bitonic_merge_1024(buf);
+    const uint32_t parity = (uint32_t)(kll_mix(salt ^ ((uint64_t)level << 40) ^ mask) >> 33) & 1u;
+    const double a = buf[2 * t + parity], b = buf[2 * (t + 256) + parity];
+    __syncthreads();
+    buf[t] = a;
+    buf[t + 256] = b;
+    __syncthreads();
+    if (t == 0) s->level_mask = mask & ~(1ull << level);
+    __syncthreads();
+    level += 1;
+  }
+}
+
+// sorts buf[0..1023] (raw items), halves them into buf[0..511] and inserts the run at level 1
+__device__ void compact_level0(KllDeviceSketch *s, double *buf, uint64_t salt) {
+  const uint32_t t = threadIdx.x;
+  block_sort_1024(buf);
+  const uint32_t parity = (uint32_t)(kll_mix(salt ^ 0x5bd1e995ULL) >> 35) & 1u;
+  const double a = buf[2 * t + parity], b = buf[2 * (t + 256) + parity];
+  __syncthreads();
+  buf[t] = a;
+  buf[t + 256] = b;
+  __syncthreads();
+  insert_run(s, 1, buf, salt);
+}
+
+// block-wide exclusive prefix sum of a small per-thread count; returns the total through *total
+__device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < kKllThreads / 64; w++) {
+    if (w < wave) base += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  *total = tot;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// One workgroup sketches rows [wg * chunk, (wg+1) * chunk) of the column into sketches[wg].
+__global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, int64_t chunk,
+                                                                 KllDeviceSketch *sketches,
+                                                                 uint64_t salt0) {
+  __shared__ double staging[2048 + 1024];  // carried raw items + one step of new ones
+  __shared__ double buf[1024];
+  __shared__ uint32_t wave_tot[kKllThreads / 64];
+  __shared__ double red_min[kKllThreads / 64], red_max[kKllThreads / 64];
+  __shared__ unsigned long long red_n[kKllThreads / 64];
+  KllDeviceSketch *s = sketches + blockIdx.x;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) {
+    s->n = 0;
+    s->level_mask = 0;
+    s->lv0_count = 0;
+    s->min_v = __longlong_as_double(0x7FF0000000000000LL);
+    s->max_v = __longlong_as_double((long long)0xFFF0000000000000ULL);
+  }
+  __syncthreads();
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk;
+  int64_t r1 = r0 + chunk;
+  if (r1 > d.length) r1 = d.length;
+  uint32_t staged = 0;  // uniform
+  double mn = __longlong_as_double(0x7FF0000000000000LL), mx = -mn;
+  unsigned long long cnt = 0;
+  const uint64_t salt = salt0 ^ ((uint64_t)blockIdx.x * 0x9e3779b97f4a7c15ULL);
+  for (int64_t base = r0; base < r1; base += 1024) {
+    double v[4];
+    uint32_t okm = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = base + t + u * kKllThreads;
+      bool ok = i < r1;
+      int64_t bits = ok ? vals[i] : 0;
+      if (ok && vbits) {
+        const int64_t b = d.offset + i;
+        ok = (vbits[b >> 3] >> (b & 7)) & 1;
+      }
+      const double x = d.is_float ? __longlong_as_double(bits) : (double)bits;
+      ok = ok && (x == x);  // KllSketch::update drops NaN (kll_sketch.rs:197-199)
+      v[u] = x;
+      okm |= (uint32_t)ok << u;
+    }
+    uint32_t total;
+    uint32_t pos = staged + block_exclusive_scan(__builtin_popcount(okm), wave_tot, &total);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if ((okm >> u) & 1) {
+        staging[pos++] = v[u];
+        mn = v[u] < mn ? v[u] : mn;
+        mx = v[u] > mx ? v[u] : mx;
+        cnt++;
+      }
+    }
+    staged += total;
+    __syncthreads();
+    while (staged >= 1024) {
+      // take the LAST 1024 staged items, so the carried prefix does not have to move
+      const uint32_t from = staged - 1024;
+#pragma unroll
+      for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = staging[from + t + u * kKllThreads];
+      __syncthreads();
+      compact_level0(s, buf, salt ^ (uint64_t)(base + staged));
+      staged = from;
+    }
+  }
+  // leftovers (< 1024 raw items) are the sketch's level 0
+  for (uint32_t i = t; i < staged; i += kKllThreads) s->lv0[i] = staging[i];
+  // block reduce n / min / max
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    cnt += __shfl_down(cnt, dlt, 64);
+    const double omn = __shfl_down(mn, dlt, 64), omx = __shfl_down(mx, dlt, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  if ((t & 63) == 0) {
+    red_n[t >> 6] = cnt;
+    red_min[t >> 6] = mn;
+    red_max[t >> 6] = mx;
+  }
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long n = 0;
+    double a = red_min[0], b = red_max[0];
+    for (int w = 0; w < kKllThreads / 64; w++) {
+      n += red_n[w];
+      a = red_min[w] < a ? red_min[w] : a;
+      b = red_max[w] > b ? red_max[w] : b;
+    }
+    s->n = n;
+    s->min_v = a;
+    s->max_v = b;
+    s->lv0_count = staged;
+  }
+}
+
+// dst += src (both in global memory); one workgroup.
+__device__ void sketch_add(KllDeviceSketch *dst, const KllDeviceSketch *src, double *buf,
+                           double *staging, uint64_t salt) {
+  const uint32_t t = threadIdx.x;
+  const unsigned long long src_n = src->n;
+  if (src_n == 0) return;  // uniform
+  // level 0: concatenate the raw items; 1024 or more -> compact 1024 of them
+  const uint32_t a = dst->lv0_count, b = src->lv0_count;
+  for (uint32_t i = t; i < a; i += kKllThreads) staging[i] = dst->lv0[i];
+  for (uint32_t i = t; i < b; i += kKllThreads) staging[a + i] = src->lv0[i];
+  __syncthreads();
+  uint32_t staged = a + b;
+  if (staged >= 1024) {
+    const uint32_t from = staged - 1024;
+#pragma unroll
+    for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = staging[from + t + u * kKllThreads];
+    __syncthreads();
+    compact_level0(dst, buf, salt ^ staged);
+    staged = from;
+  }
+  for (uint32_t i = t; i < staged; i += kKllThreads) dst->lv0[i] = staging[i];
+  __syncthreads();
+  // runs: insert each of src's runs
+  const uint64_t src_mask = src->level_mask;
+  for (uint32_t l = 1; l < kKllMaxLevels; l++) {
+    if (!((src_mask >> l) & 1)) continue;
+    buf[t] = src->runs[l][t];
+    buf[t + 256] = src->runs[l][t + 256];
+    __syncthreads();
+    insert_run(dst, l, buf, salt ^ ((uint64_t)l << 20));
+  }
+  if (t == 0) {
+    dst->lv0_count = staged;
+    dst->n += src_n;
+    dst->min_v = src->min_v < dst->min_v ? src->min_v : dst->min_v;
+    dst->max_v = src->max_v > dst->max_v ? src->max_v : dst->max_v;
+  }
+  __syncthreads();
+}
+
+// one round of the pairwise tree: sketches[2*i*stride] += sketches[(2*i+1)*stride]
+__global__ __launch_bounds__(kKllThreads) void kll_tree_kernel(KllDeviceSketch *sketches, int count,
+                                                                int stride, uint64_t salt) {
+  __shared__ double staging[2048];
+  __shared__ double buf[1024];
+  const int a = 2 * blockIdx.x * stride, b = a + stride;
+  if (b >= count) return;
+  sketch_add(sketches + a, sketches + b, buf, staging, salt ^ ((uint64_t)a << 8) ^ (uint64_t)stride);
+}
+
+// state += batch
+__global__ __launch_bounds__(kKllThreads) void kll_fold_kernel(KllDeviceSketch *state,
+                                                                const KllDeviceSketch *batch,
+                                                                uint64_t salt) {
+  __shared__ double staging[2048];
+  __shared__ double buf[1024];
+  sketch_add(state, batch, buf, staging, salt);
+}
+
+__global__ void kll_init_kernel(KllDeviceSketch *s) {
+  if (threadIdx.x == 0) {
+    s->n = 0;
+    s->level_mask = 0;
+    s->lv0_count = 0;
+    s->min_v = __longlong_as_double(0x7FF0000000000000LL);
+    s->max_v = __longlong_as_double((long long)0xFFF0000000000000ULL);
+  }
+}
+
+void launch_kll_init(KllDeviceSketch *s, hipStream_t stream) {
+  hipLaunchKernelGGL(kll_init_kernel, dim3(1), dim3(64), 0, stream, s);
+}
+
+// sketches: scratch for `groups` per-workgroup sketches; result folded into `state`
+void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
+                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream) {
+  hipLaunchKernelGGL(kll_build_kernel, dim3(groups), dim3(kKllThreads), 0, stream, d, chunk, sketches,
+                     salt);
+  for (int stride = 1; stride < groups; stride <<= 1) {
+    int pairs = (groups + 2 * stride - 1) / (2 * stride);
+    hipLaunchKernelGGL(kll_tree_kernel, dim3(pairs), dim3(kKllThreads), 0, stream, sketches, groups,
+                       stride, salt + (uint64_t)stride);
+  }
+  hipLaunchKernelGGL(kll_fold_kernel, dim3(1), dim3(kKllThreads), 0, stream, state, sketches,
+                     salt ^ 0xabcdefULL);
+}
+
+}  // namespace tgx

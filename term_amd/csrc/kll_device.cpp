@@ -1,42 +1,256 @@
-// kll_device.cpp -- placeholder until kernels/kll.hip lands: KLL specs are refused at update time.
+// kll_device.cpp -- KLL tasks of a state: device sketching (kernels/kll.hip) + host-side merge/query.
 #include "kll_device.h"
 
+#include <math.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
+#include "kernels/kll_types.h"
+
 namespace tgx {
-static tgx_status kfail(tgx_error *err, tgx_status code, const char *msg) {
+
+void launch_kll_init(KllDeviceSketch *s, hipStream_t stream);
+void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
+                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream);
+
+namespace {
+struct KllDeviceState {
+  std::vector<DevBuf> sketch;  // running device sketch per task
+  std::vector<char> dirty;     // device sketch holds data not yet folded into h_kll
+  DevBuf scratch;              // per-workgroup sketches of the batch being processed
+  uint64_t salt = 0x6b6c6c5f74677821ULL;
+};
+
+tgx_status kfail(tgx_error *err, tgx_status code, const char *fmt, ...) {
   if (err) {
     err->code = code;
-    snprintf(err->msg, sizeof(err->msg), "%s", msg);
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err->msg, sizeof(err->msg), fmt, ap);
+    va_end(ap);
   }
   return code;
 }
-void kll_state_init(tgx_state *) {}
-void kll_state_free(tgx_state *) {}
-void kll_state_reset(tgx_state *) {}
-tgx_status kll_update(tgx_state *, size_t, const tgx_column &, tgx_error *err) {
-  return kfail(err, TGX_UNSUPPORTED, "KLL is not implemented yet");
+#define KHIP(expr)                                                                                   \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return kfail(err, e_ == hipErrorOutOfMemory ? TGX_OUT_OF_MEMORY : TGX_DEVICE_ERROR, "%s failed: %s", \
+                   #expr, hipGetErrorString(e_));                                                    \
+  } while (0)
+
+KllDeviceState *dev(tgx_state *st) { return (KllDeviceState *)st->kll; }
+}  // namespace
+
+void kll_state_init(tgx_state *st) {
+  if (st->kll) return;
+  KllDeviceState *k = new KllDeviceState();
+  k->sketch.resize(st->plan->kll.size());
+  k->dirty.assign(st->plan->kll.size(), 0);
+  st->kll = k;
 }
-tgx_status kll_flush(tgx_state *, tgx_error *) { return TGX_OK; }
-tgx_status kll_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *) {
-  r->kll_n = st->h_kll[slot].n;
+
+void kll_state_free(tgx_state *st) {
+  delete dev(st);
+  st->kll = nullptr;
+}
+
+void kll_state_reset(tgx_state *st) {
+  KllDeviceState *k = dev(st);
+  if (!k) return;
+  for (size_t i = 0; i < k->sketch.size(); i++) {
+    if (k->sketch[i].p) launch_kll_init(k->sketch[i].as<KllDeviceSketch>(), st->stream);
+    k->dirty[i] = 0;
+  }
+}
+
+tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
+  KllDeviceState *k = dev(st);
+  if (c.type != TGX_INT64 && c.type != TGX_FLOAT64)
+    return kfail(err, TGX_UNSUPPORTED, "KLL needs a numeric column (type %d)", c.type);
+  if (c.length == 0) return TGX_OK;
+  if (!k->sketch[slot].p) {
+    KHIP(k->sketch[slot].reserve(sizeof(KllDeviceSketch)));
+    launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream);
+  }
+  // one workgroup per >= 64 Ki rows, at most 512 of them (121 MiB of scratch sketches)
+  int64_t groups = (c.length + 65535) / 65536;
+  groups = std::max<int64_t>(1, std::min<int64_t>(groups, 512));
+  int64_t chunk = (c.length + groups - 1) / groups;
+  chunk = (chunk + 1023) / 1024 * 1024;
+  groups = (c.length + chunk - 1) / chunk;
+  KHIP(k->scratch.reserve((size_t)groups * sizeof(KllDeviceSketch)));
+  KllColDesc d;
+  d.values = c.values;
+  d.validity = c.validity;
+  d.offset = c.offset;
+  d.length = c.length;
+  d.is_float = c.type == TGX_FLOAT64;
+  d.pad = 0;
+  k->salt = k->salt * 6364136223846793005ULL + 1442695040888963407ULL;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    (void)hipEventRecord(e0, st->stream);
+  }
+  launch_kll_update(d, (int)groups, chunk, k->scratch.as<KllDeviceSketch>(),
+                    k->sketch[slot].as<KllDeviceSketch>(), k->salt, st->stream);
+  if (st->profiling && e0 && e1) {
+    (void)hipEventRecord(e1, st->stream);
+    ProfileEntry &pe = st->profile["kll"];
+    pe.pending.emplace_back(e0, e1);
+    pe.pending_bytes.push_back((uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0));
+  }
+  k->dirty[slot] = 1;
   return TGX_OK;
 }
-tgx_status kll_merge_states(tgx_state *, tgx_state *, tgx_error *) { return TGX_OK; }
-tgx_status kll_serialize(tgx_state *, size_t *, uint8_t *, size_t, tgx_error *) { return TGX_OK; }
-tgx_status kll_deserialize(tgx_state *, const uint8_t *, size_t, size_t *, tgx_error *) { return TGX_OK; }
+
+tgx_status kll_flush(tgx_state *st, tgx_error *err) {
+  KllDeviceState *k = dev(st);
+  if (!k) return TGX_OK;
+  for (size_t i = 0; i < k->sketch.size(); i++) {
+    if (!k->dirty[i]) continue;
+    std::vector<uint8_t> raw(sizeof(KllDeviceSketch));
+    KHIP(hipStreamSynchronize(st->stream));
+    KHIP(hipMemcpy(raw.data(), k->sketch[i].p, raw.size(), hipMemcpyDeviceToHost));
+    const KllDeviceSketch *s = (const KllDeviceSketch *)raw.data();
+    KllHost part;
+    part.k = st->h_kll[i].k;
+    part.n = s->n;
+    part.min_v = s->min_v;
+    part.max_v = s->max_v;
+    if (s->lv0_count) part.add_level_items(0, s->lv0, s->lv0_count);
+    for (int l = 1; l < kKllMaxLevels; l++)
+      if ((s->level_mask >> l) & 1) part.add_level_items((size_t)l, s->runs[l], kKllRunItems);
+    if (!st->h_kll[i].merge(part)) return kfail(err, TGX_INTERNAL, "KLL merge failed");
+    launch_kll_init(k->sketch[i].as<KllDeviceSketch>(), st->stream);
+    k->dirty[i] = 0;
+  }
+  return TGX_OK;
+}
+
+tgx_status kll_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *err) {
+  tgx_status s = kll_flush(st, err);
+  if (s != TGX_OK) return s;
+  r->kll_n = st->h_kll[slot].n;
+  r->non_null = (int64_t)st->h_kll[slot].n;
+  return TGX_OK;
+}
+
+tgx_status kll_merge_states(tgx_state *dst, tgx_state *src, tgx_error *err) {
+  tgx_status s = kll_flush(dst, err);
+  if (s != TGX_OK) return s;
+  s = kll_flush(src, err);
+  if (s != TGX_OK) return s;
+  for (size_t i = 0; i < dst->h_kll.size(); i++)
+    if (!dst->h_kll[i].merge(src->h_kll[i]))
+      return kfail(err, TGX_INVALID_ARGUMENT, "Cannot merge sketches with different k values: %u vs %u",
+                   dst->h_kll[i].k, src->h_kll[i].k);
+  return TGX_OK;
+}
+
+// wire: per task  u32 k, u32 n_levels, u64 n, f64 min, f64 max, then per level u32 count + items
+tgx_status kll_serialize(tgx_state *st, size_t *len, uint8_t *buf, size_t cap, tgx_error *err) {
+  tgx_status s = kll_flush(st, err);
+  if (s != TGX_OK) return s;
+  auto put = [&](const void *p, size_t n) {
+    if (buf && *len + n <= cap) memcpy(buf + *len, p, n);
+    *len += n;
+  };
+  for (auto &h : st->h_kll) {
+    uint32_t k = h.k, nl = (uint32_t)h.levels.size();
+    put(&k, 4);
+    put(&nl, 4);
+    put(&h.n, 8);
+    put(&h.min_v, 8);
+    put(&h.max_v, 8);
+    for (auto &lv : h.levels) {
+      uint32_t c = (uint32_t)lv.size();
+      put(&c, 4);
+      put(lv.data(), (size_t)c * 8);
+    }
+  }
+  return TGX_OK;
+}
+
+tgx_status kll_deserialize(tgx_state *st, const uint8_t *buf, size_t len, size_t *pos, tgx_error *err) {
+  auto get = [&](void *p, size_t n) -> bool {
+    if (*pos + n > len) return false;
+    memcpy(p, buf + *pos, n);
+    *pos += n;
+    return true;
+  };
+  for (auto &h : st->h_kll) {
+    uint32_t k = 0, nl = 0;
+    if (!get(&k, 4) || !get(&nl, 4) || !get(&h.n, 8) || !get(&h.min_v, 8) || !get(&h.max_v, 8))
+      return kfail(err, TGX_INVALID_ARGUMENT, "truncated state blob (kll)");
+    if (k != h.k) return kfail(err, TGX_INVALID_ARGUMENT, "state blob was produced with k=%u, plan has k=%u", k, h.k);
+    if (nl > 64) return kfail(err, TGX_INVALID_ARGUMENT, "corrupt state blob (kll levels)");
+    h.levels.assign(nl, {});
+    for (uint32_t l = 0; l < nl; l++) {
+      uint32_t c = 0;
+      if (!get(&c, 4) || c > (1u << 20)) return kfail(err, TGX_INVALID_ARGUMENT, "truncated state blob (kll)");
+      h.levels[l].resize(c);
+      if (!get(h.levels[l].data(), (size_t)c * 8)) return kfail(err, TGX_INVALID_ARGUMENT, "truncated state blob (kll)");
+    }
+  }
+  return TGX_OK;
+}
+
+static tgx_status kll_slot(const tgx_plan *plan, tgx_state *st, size_t spec_index, int *slot, tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return kfail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_KLL)
+    return kfail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a KLL check", spec_index);
+  *slot = plan->bind[spec_index].slot;
+  return kll_flush(st, err);
+}
+
 }  // namespace tgx
 
-extern "C" tgx_status tgx_kll_quantile(const tgx_plan *, tgx_state *, size_t, double, double *, tgx_error *err) {
-  return tgx::kfail(err, TGX_UNSUPPORTED, "KLL is not implemented yet");
+using namespace tgx;
+
+extern "C" tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *st, size_t spec_index, double phi,
+                                       double *out, tgx_error *err) {
+  int slot = 0;
+  tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
+  if (s != TGX_OK) return s;
+  if (!out) return kfail(err, TGX_INVALID_ARGUMENT, "out is NULL");
+  int rc = st->h_kll[slot].quantile(phi, out);
+  // messages of KllSketch::get_quantile (kll_sketch.rs:247-257)
+  if (rc == 1) return kfail(err, TGX_INVALID_ARGUMENT, "Cannot compute quantile on empty sketch");
+  if (rc == 2) return kfail(err, TGX_INVALID_ARGUMENT, "Quantile phi must be in [0, 1], got %g", phi);
+  return TGX_OK;
 }
-extern "C" tgx_status tgx_kll_summary(const tgx_plan *, tgx_state *, size_t, uint64_t *, double *, double *,
-                                      uint64_t *, uint64_t *, tgx_error *err) {
-  return tgx::kfail(err, TGX_UNSUPPORTED, "KLL is not implemented yet");
+
+extern "C" tgx_status tgx_kll_summary(const tgx_plan *plan, tgx_state *st, size_t spec_index, uint64_t *n,
+                                      double *min_value, double *max_value, uint64_t *num_levels,
+                                      uint64_t *num_retained, tgx_error *err) {
+  int slot = 0;
+  tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
+  if (s != TGX_OK) return s;
+  const KllHost &h = st->h_kll[slot];
+  if (n) *n = h.n;
+  if (min_value) *min_value = h.min_v;
+  if (max_value) *max_value = h.max_v;
+  if (num_levels) *num_levels = h.levels.size();
+  if (num_retained) *num_retained = h.retained();
+  return TGX_OK;
 }
-extern "C" tgx_status tgx_kll_level_items(const tgx_plan *, tgx_state *, size_t, uint64_t, double *, uint64_t,
-                                          uint64_t *, tgx_error *err) {
-  return tgx::kfail(err, TGX_UNSUPPORTED, "KLL is not implemented yet");
+
+extern "C" tgx_status tgx_kll_level_items(const tgx_plan *plan, tgx_state *st, size_t spec_index,
+                                          uint64_t level, double *out, uint64_t cap, uint64_t *count,
+                                          tgx_error *err) {
+  int slot = 0;
+  tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
+  if (s != TGX_OK) return s;
+  const KllHost &h = st->h_kll[slot];
+  uint64_t c = level < h.levels.size() ? h.levels[level].size() : 0;
+  if (count) *count = c;
+  if (out)
+    for (uint64_t i = 0; i < c && i < cap; i++) out[i] = h.levels[level][i];
+  return TGX_OK;
 }
-extern "C" double tgx_kll_relative_error_bound(uint32_t k) { return 1.65 / __builtin_sqrt((double)k); }
+
+extern "C" double tgx_kll_relative_error_bound(uint32_t k) { return 1.65 / sqrt((double)k); }

@@ -767,7 +767,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       cap = cap + cap / 4 + 16 * tiles + 4096;
       pp.cap = (cap + 15) & ~15ull;
       pp.want_multiplicity = mult ? 1 : 0;
-      pp.pad = 0;
+      pp.pad = getenv("TGX_ABLATE") ? atoi(getenv("TGX_ABLATE")) : 0;
       HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * sizeof(uint32_t)));
       HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
       HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));

@@ -1,0 +1,157 @@
+"""-m gpu: KLL sketches built by kernels/kll.hip, queried through the C ABI.
+
+Parity rule (DESIGN.md "KLL"): the reference's own sketch keeps every item (Compactor::compact hands one
+half up and keeps the other), so it cannot be run at bench sizes and its answers drift far from the true
+quantiles (its tests allow 60-85 % relative error).  The GPU sketch is a weight-preserving KLL; it must
+(a) satisfy every assertion the reference's tests make, (b) stay within the stated rank error
+eps = 1.65/sqrt(k) of the exact quantile, and (c) agree with the oracle within the reference's tolerance."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+import term_amd as T
+from _lib_spec import spec
+from gpu_util import numeric_column, run_plan
+
+pytestmark = pytest.mark.gpu
+
+
+def rank_error(sorted_vals, q, phi):
+    """|rank(q) - phi*n| / n using the closest rank of q in the exact data"""
+    n = len(sorted_vals)
+    lo = np.searchsorted(sorted_vals, q, side="left")
+    hi = np.searchsorted(sorted_vals, q, side="right")
+    target = phi * n
+    if lo <= target <= hi:
+        return 0.0
+    return min(abs(lo - target), abs(hi - target)) / n
+
+
+def total_weight(st, idx):
+    s = st.kll_summary(idx)
+    return sum(len(st.kll_level_items(idx, l)) << l for l in range(s["num_levels"]))
+
+
+def test_reference_known_answers(golden):
+    for case in golden["kll"]:
+        if "error_bound" in case:
+            assert abs(T.lib().tgx_kll_relative_error_bound(case["k"]) - case["error_bound"]) < 0.001
+            continue
+
+        def series(s):
+            if isinstance(s, str):
+                lo, hi = s.split("..")
+                return np.arange(int(lo), int(hi) + 1, dtype=np.float64)
+            return np.array([float("nan") if v == "nan" else float(v) for v in s], dtype=np.float64)
+
+        T.init()
+        plan = T.Plan([spec(T.KLL, 0, kll_k=case["k"])])
+        if "merge" in case:
+            parts = []
+            for sp in case["merge"]:
+                st = T.State(plan)
+                st.update([numeric_column(series(sp), None, True)])
+                parts.append(st)
+            st = parts[0]
+            st.merge(parts[1:])
+        else:
+            st = T.State(plan)
+            st.update([numeric_column(series(case["input"]), None, True)])
+        res = st.finalize()
+        assert res[0].kll_n == case["count"], case["ref"]
+        for chk in case["checks"]:
+            q = st.kll_quantile(0, chk["phi"])
+            if "equals" in chk:
+                assert q == chk["equals"]
+            else:
+                assert abs(q - chk["expected"]) / chk["expected"] < chk["rel_err_lt"]
+                # and far tighter than the reference's own tolerance: these inputs fit level 0 unsampled
+                assert abs(q - chk["expected"]) <= 2.0
+
+
+def test_empty_and_bad_phi():
+    T.init()
+    plan = T.Plan([spec(T.KLL, 0, kll_k=100)])
+    st = T.State(plan)
+    with pytest.raises(T.TgxError) as e:
+        st.kll_quantile(0, 0.5)
+    assert "empty sketch" in str(e.value)  # kll_sketch.rs:247-251
+    st.update([numeric_column(np.array([1.0, 2.0]), None, True)])
+    with pytest.raises(T.TgxError) as e:
+        st.kll_quantile(0, 1.5)
+    assert "phi must be in [0, 1]" in str(e.value)
+    with pytest.raises(T.TgxError):
+        T.Plan([spec(T.KLL, 0, kll_k=1)])  # k must be at least 2 (kll_sketch.rs:167-169)
+
+
+@pytest.mark.parametrize("dist", ["uniform", "normal", "lognormal", "sorted", "few_values"])
+@pytest.mark.parametrize("n", [5_000, 300_000, 5_000_000])
+def test_rank_error_within_stated_eps(dist, n):
+    rng = np.random.default_rng(abs(hash((dist, n))) % 2**32)
+    if dist == "uniform":
+        vals = rng.random(n) * 1000
+    elif dist == "normal":
+        vals = rng.standard_normal(n)
+    elif dist == "lognormal":
+        vals = np.exp(rng.standard_normal(n) * 3)
+    elif dist == "sorted":
+        vals = np.arange(n, dtype=np.float64)
+    else:
+        vals = rng.integers(0, 7, size=n).astype(np.float64)
+    mask = rng.random(n) >= 0.05
+    vals[rng.random(n) < 0.01] = np.nan  # NaN is dropped like NULL
+    validity = orc.pack_validity(mask)
+    k = 200
+    res, plan, st = run_plan([spec(T.KLL, 0, kll_k=k), spec(T.COUNT, 0)], [[numeric_column(vals, validity, True)]])
+    kept = vals[mask & ~np.isnan(vals)]
+    assert res[0].kll_n == len(kept)
+    summ = st.kll_summary(0)
+    assert summ["n"] == len(kept) and summ["min"] == kept.min() and summ["max"] == kept.max()
+    assert total_weight(st, 0) == len(kept)  # weight-preserving compaction
+    assert summ["num_retained"] <= 1024 * (summ["num_levels"] + 1)
+    srt = np.sort(kept)
+    eps = 1.65 / math.sqrt(k)
+    worst = 0.0
+    for phi in [0.01, 0.05, 0.25, 0.5, 0.75, 0.9, 0.95, 0.99]:
+        q = st.kll_quantile(0, phi)
+        worst = max(worst, rank_error(srt, q, phi))
+    assert worst < eps
+    assert worst < 0.02  # in practice the 512-item runs give ~0.1-1 %
+    assert st.kll_quantile(0, 0.0) == kept.min() and st.kll_quantile(0, 1.0) == kept.max()
+    # monotone quantiles within [min, max] (tests/advanced_analytics_integration.rs:100-116)
+    qs = [st.kll_quantile(0, p) for p in (0.25, 0.5, 0.75, 0.95)]
+    assert qs == sorted(qs) and kept.min() <= qs[0] and qs[-1] <= kept.max()
+
+
+def test_int64_column_and_batches_and_serialize():
+    rng = np.random.default_rng(77)
+    n = 1_200_000
+    vals = rng.integers(-10**6, 10**6, size=n, dtype=np.int64)
+    T.init()
+    plan = T.Plan([spec(T.KLL, 0, kll_k=200), spec(T.NUMERIC_STATS, 0)])
+    a, b = T.State(plan), T.State(plan)
+    cut = [0, 100_000, 100_001, 650_000, n]
+    for i, (lo, hi) in enumerate(zip(cut[:-1], cut[1:])):
+        (a if i % 2 == 0 else b).update([numeric_column(vals, None, True, offset=lo, length=hi - lo)])
+    other = T.State.deserialize(plan, b.serialize())
+    a.merge([other])
+    res = a.finalize()
+    assert res[0].kll_n == n and res[1].non_null == n
+    srt = np.sort(vals.astype(np.float64))
+    assert total_weight(a, 0) == n
+    for phi in (0.1, 0.5, 0.9, 0.99):
+        assert rank_error(srt, a.kll_quantile(0, phi), phi) < 0.02
+
+
+def test_against_oracle_within_reference_tolerance():
+    """Same input through the oracle's restatement of the reference sketch: both answers must lie within the
+    reference tests' own relative tolerance of the truth (kll_sketch.rs:459-468)."""
+    vals = np.arange(1000, dtype=np.float64)
+    sk = orc.Kll(100, 0)
+    sk.update_many(vals)
+    res, plan, st = run_plan([spec(T.KLL, 0, kll_k=100)], [[numeric_column(vals, None, True)]])
+    for phi, truth in ((0.5, 500.0), (0.9, 900.0)):
+        assert abs(sk.quantile(phi) - truth) / truth < 0.85
+        assert abs(st.kll_quantile(0, phi) - truth) / truth < 0.85
