@@ -1,0 +1,28 @@
+// Descriptors of the pattern-match kernel (regex.hip).
+#pragma once
+#include <stdint.h>
+
+namespace tgx {
+
+constexpr uint32_t kRegexLdsEntries = 24576;  // 48 KiB of LDS for the transition table
+
+struct RegexColDesc {
+  const void *offsets;      // int32 or int64 value offsets
+  const uint8_t *data;      // UTF-8 bytes
+  const uint8_t *validity;  // or nullptr
+  int64_t offset;           // Arrow offset
+  int64_t length;
+  int32_t large_offsets;    // 1 = int64 offsets (LargeUtf8)
+  int32_t trim;             // TRIM(col): strip U+0020 on both ends before matching
+  int32_t null_is_valid;    // NULL rows count as matches
+  int32_t pad;
+};
+
+struct DfaView {
+  const uint16_t *table;       // n_states x n_classes
+  const uint8_t *byte_class;   // 256
+  const uint8_t *accept_end;   // n_states
+  uint32_t n_states, n_classes, start, pad;
+};
+
+}  // namespace tgx

@@ -1,0 +1,1158 @@
+// regex_compile.cpp -- see regex_compile.h.
+#include "regex_compile.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <set>
+
+#include "unicode_tables.h"
+
+namespace tgx {
+namespace rx {
+
+namespace {
+
+constexpr uint32_t kMaxCp = 0x10FFFF;
+constexpr int kMaxRepeat = 1000;
+constexpr size_t kMaxNfaStates = 200000;
+constexpr size_t kMaxDfaStates = 20000;
+
+struct Range {
+  uint32_t lo, hi;
+};
+typedef std::vector<Range> ClassSet;
+
+void normalize(ClassSet &c) {
+  std::sort(c.begin(), c.end(), [](const Range &a, const Range &b) { return a.lo < b.lo; });
+  ClassSet out;
+  for (const Range &r : c) {
+    if (!out.empty() && r.lo <= out.back().hi + 1) {
+      if (r.hi > out.back().hi) out.back().hi = r.hi;
+    } else {
+      out.push_back(r);
+    }
+  }
+  c.swap(out);
+}
+
+ClassSet negate(ClassSet c) {
+  normalize(c);
+  ClassSet out;
+  uint32_t next = 0;
+  for (const Range &r : c) {
+    if (r.lo > next) out.push_back({next, r.lo - 1});
+    next = r.hi + 1;
+  }
+  if (next <= kMaxCp) out.push_back({next, kMaxCp});
+  return out;
+}
+
+bool contains(const ClassSet &c, uint32_t cp) {
+  size_t lo = 0, hi = c.size();
+  while (lo < hi) {
+    size_t mid = (lo + hi) / 2;
+    if (c[mid].hi < cp)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < c.size() && c[lo].lo <= cp;
+}
+
+// simple case folding closure of a class (tgx_fold_pairs: every ordered pair of each orbit)
+void case_fold(ClassSet &c) {
+  normalize(c);
+  ClassSet extra;
+  for (uint32_t i = 0; i < tgx_n_fold_pairs; i++)
+    if (contains(c, tgx_fold_pairs[i][0])) extra.push_back({tgx_fold_pairs[i][1], tgx_fold_pairs[i][1]});
+  c.insert(c.end(), extra.begin(), extra.end());
+  normalize(c);
+}
+
+bool table_lookup(const std::string &name, ClassSet *out) {
+  for (uint32_t i = 0; i < tgx_n_utables; i++) {
+    if (name == tgx_utables[i].name) {
+      out->clear();
+      for (uint32_t k = 0; k < tgx_utables[i].count; k++)
+        out->push_back({tgx_utables[i].ranges[k].lo, tgx_utables[i].ranges[k].hi});
+      return true;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------- AST
+struct Node {
+  enum Kind { kEmpty, kClass, kStart, kEnd, kConcat, kAlt, kRepeat } kind = kEmpty;
+  ClassSet cls;
+  std::vector<std::unique_ptr<Node>> kids;
+  int min = 0, max = 0;  // kRepeat; max < 0 = unbounded
+};
+typedef std::unique_ptr<Node> NodeP;
+
+NodeP mk(Node::Kind k) {
+  NodeP n(new Node());
+  n->kind = k;
+  return n;
+}
+
+struct Flags {
+  bool i = false, s = false, x = false, swap_greed = false;
+};
+
+struct Parser {
+  std::vector<uint32_t> p;  // pattern as code points
+  size_t pos = 0;
+  CompileStatus status = kOk;
+  std::string msg;
+  int depth = 0;
+
+  bool fail(CompileStatus st, const std::string &m) {
+    if (status == kOk) {
+      status = st;
+      msg = m;
+    }
+    return false;
+  }
+  bool eof() const { return pos >= p.size(); }
+  uint32_t peek(size_t k = 0) const { return pos + k < p.size() ? p[pos + k] : 0xFFFFFFFFu; }
+  bool eat(uint32_t c) {
+    if (peek() == c) {
+      pos++;
+      return true;
+    }
+    return false;
+  }
+
+  static bool decode_utf8(const char *s, size_t n, std::vector<uint32_t> *out) {
+    size_t i = 0;
+    while (i < n) {
+      uint8_t b = (uint8_t)s[i];
+      uint32_t cp;
+      int len;
+      if (b < 0x80) {
+        cp = b;
+        len = 1;
+      } else if ((b & 0xE0) == 0xC0) {
+        cp = b & 0x1F;
+        len = 2;
+      } else if ((b & 0xF0) == 0xE0) {
+        cp = b & 0x0F;
+        len = 3;
+      } else if ((b & 0xF8) == 0xF0) {
+        cp = b & 0x07;
+        len = 4;
+      } else {
+        return false;
+      }
+      if (i + len > n) return false;
+      for (int k = 1; k < len; k++) {
+        uint8_t c = (uint8_t)s[i + k];
+        if ((c & 0xC0) != 0x80) return false;
+        cp = (cp << 6) | (c & 0x3F);
+      }
+      out->push_back(cp);
+      i += len;
+    }
+    return true;
+  }
+
+  void skip_verbose(const Flags &f) {
+    if (!f.x) return;
+    for (;;) {
+      uint32_t c = peek();
+      if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == 0x0B) {
+        pos++;
+      } else if (c == '#') {
+        while (!eof() && peek() != '\n') pos++;
+      } else {
+        break;
+      }
+    }
+  }
+
+  NodeP literal(uint32_t cp, const Flags &f) {
+    NodeP n = mk(Node::kClass);
+    n->cls.push_back({cp, cp});
+    if (f.i) case_fold(n->cls);
+    return n;
+  }
+
+  // ---- alternation
+  NodeP parse_alt(Flags f) {
+    if (++depth > 200) {
+      fail(kInvalid, "exceeded the maximum nesting depth");
+      return nullptr;
+    }
+    std::vector<NodeP> branches;
+    branches.push_back(parse_concat(f));
+    if (status != kOk) return nullptr;
+    while (peek() == '|') {
+      pos++;
+      branches.push_back(parse_concat(f));
+      if (status != kOk) return nullptr;
+    }
+    depth--;
+    if (branches.size() == 1) return std::move(branches[0]);
+    NodeP n = mk(Node::kAlt);
+    n->kids = std::move(branches);
+    return n;
+  }
+
+  // flags set by a bare (?i) group apply to the rest of the enclosing group: `f` is passed by reference
+  NodeP parse_concat(Flags &f) {
+    NodeP cat = mk(Node::kConcat);
+    for (;;) {
+      skip_verbose(f);
+      uint32_t c = peek();
+      if (eof() || c == '|' || c == ')') break;
+      NodeP atom = parse_atom(f);
+      if (status != kOk) return nullptr;
+      if (!atom) continue;  // a flag-only group
+      // repetition operators
+      for (;;) {
+        skip_verbose(f);
+        uint32_t q = peek();
+        int mn, mx;
+        if (q == '*') {
+          mn = 0;
+          mx = -1;
+          pos++;
+        } else if (q == '+') {
+          mn = 1;
+          mx = -1;
+          pos++;
+        } else if (q == '?') {
+          mn = 0;
+          mx = 1;
+          pos++;
+        } else if (q == '{') {
+          size_t save = pos;
+          if (!parse_counted(&mn, &mx)) {
+            if (status != kOk) return nullptr;
+            pos = save;
+            fail(kInvalid, "repetition quantifier expects a valid decimal");
+            return nullptr;
+          }
+        } else {
+          break;
+        }
+        if (peek() == '?') pos++;  // lazy: irrelevant for is_match
+        if (atom->kind == Node::kStart || atom->kind == Node::kEnd) {
+          // regex-syntax accepts repetition of assertions (x* of an anchor = optional anchor)
+        }
+        NodeP rep = mk(Node::kRepeat);
+        rep->min = mn;
+        rep->max = mx;
+        rep->kids.push_back(std::move(atom));
+        atom = std::move(rep);
+      }
+      cat->kids.push_back(std::move(atom));
+    }
+    if (cat->kids.empty()) return mk(Node::kEmpty);
+    if (cat->kids.size() == 1) return std::move(cat->kids[0]);
+    return cat;
+  }
+
+  bool parse_decimal(int *out) {
+    if (!(peek() >= '0' && peek() <= '9')) return false;
+    long v = 0;
+    while (peek() >= '0' && peek() <= '9') {
+      v = v * 10 + (long)(peek() - '0');
+      if (v > 100000) {
+        fail(kInvalid, "repetition count too large");
+        return false;
+      }
+      pos++;
+    }
+    *out = (int)v;
+    return true;
+  }
+
+  bool parse_counted(int *mn, int *mx) {
+    pos++;  // {
+    while (peek() == ' ') pos++;
+    if (!parse_decimal(mn)) return false;
+    while (peek() == ' ') pos++;
+    if (eat('}')) {
+      *mx = *mn;
+    } else if (eat(',')) {
+      while (peek() == ' ') pos++;
+      if (eat('}')) {
+        *mx = -1;
+      } else {
+        if (!parse_decimal(mx)) return false;
+        while (peek() == ' ') pos++;
+        if (!eat('}')) return false;
+        if (*mx < *mn) {
+          fail(kInvalid, "invalid repetition count range, the start must be <= the end");
+          return false;
+        }
+      }
+    } else {
+      return false;
+    }
+    if (*mn > kMaxRepeat || *mx > kMaxRepeat) {
+      fail(kUnsupported, "counted repetition above 1000 is not supported by the GPU engine");
+      return false;
+    }
+    return true;
+  }
+
+  NodeP parse_atom(Flags &f) {
+    uint32_t c = peek();
+    if (c == '(') return parse_group(f);
+    if (c == '[') {
+      NodeP n = mk(Node::kClass);
+      if (!parse_class(f, &n->cls)) return nullptr;
+      return n;
+    }
+    if (c == '.') {
+      pos++;
+      NodeP n = mk(Node::kClass);
+      if (f.s)
+        n->cls.push_back({0, kMaxCp});
+      else
+        n->cls = negate({{'\n', '\n'}});
+      return n;
+    }
+    if (c == '^') {
+      pos++;
+      return mk(Node::kStart);
+    }
+    if (c == '$') {
+      pos++;
+      return mk(Node::kEnd);
+    }
+    if (c == '*' || c == '+' || c == '?') {
+      fail(kInvalid, "repetition operator missing expression");
+      return nullptr;
+    }
+    if (c == '{') {
+      fail(kInvalid, "repetition operator missing expression");
+      return nullptr;
+    }
+    if (c == '\\') return parse_escape_atom(f);
+    pos++;
+    return literal(c, f);
+  }
+
+  NodeP parse_group(Flags &f) {
+    pos++;  // (
+    Flags inner = f;
+    if (peek() == '?') {
+      // (?:...)  (?P<name>...)  (?<name>...)  (?flags)  (?flags:...)
+      if (peek(1) == 'P' && peek(2) == '<') {
+        pos += 3;
+        if (!skip_group_name()) return nullptr;
+      } else if (peek(1) == '<' && peek(2) != '=' && peek(2) != '!') {
+        pos += 2;
+        if (!skip_group_name()) return nullptr;
+      } else if (peek(1) == '=' || peek(1) == '!' || (peek(1) == '<' && (peek(2) == '=' || peek(2) == '!'))) {
+        fail(kInvalid, "look-around, including look-ahead and look-behind, is not supported");
+        return nullptr;
+      } else if (peek(1) == 'P' && (peek(2) == '=' || peek(2) == '>')) {
+        fail(kInvalid, "backreferences are not supported");
+        return nullptr;
+      } else {
+        pos++;  // ?
+        bool neg = false, any = false;
+        for (;;) {
+          uint32_t c = peek();
+          if (c == ':' || c == ')') break;
+          if (c == '-') {
+            if (neg) {
+              fail(kInvalid, "dangling flag negation operator");
+              return nullptr;
+            }
+            neg = true;
+            pos++;
+            continue;
+          }
+          any = true;
+          bool on = !neg;
+          switch (c) {
+            case 'i': inner.i = on; break;
+            case 's': inner.s = on; break;
+            case 'x': inner.x = on; break;
+            case 'U': inner.swap_greed = on; break;
+            case 'R': break;  // CRLF mode only changes multi-line anchors
+            case 'm':
+              if (on) {
+                fail(kUnsupported, "multi-line mode (?m) is not supported by the GPU engine");
+                return nullptr;
+              }
+              break;
+            case 'u':
+              if (!on) {
+                fail(kUnsupported, "(?-u) byte-oriented mode is not supported by the GPU engine");
+                return nullptr;
+              }
+              break;
+            default:
+              fail(kInvalid, "unrecognized flag");
+              return nullptr;
+          }
+          pos++;
+        }
+        if (!any && !neg && peek() == ')') {
+          fail(kInvalid, "missing flags");  // "(?)"
+          return nullptr;
+        }
+        if (eat(')')) {
+          f = inner;  // applies to the rest of the enclosing group
+          return nullptr;
+        }
+        pos++;  // ':'
+      }
+    }
+    NodeP body = parse_alt(inner);
+    if (status != kOk) return nullptr;
+    if (!eat(')')) {
+      fail(kInvalid, "unclosed group");
+      return nullptr;
+    }
+    return body;
+  }
+
+  bool skip_group_name() {
+    size_t n = 0;
+    while (!eof() && peek() != '>') {
+      uint32_t c = peek();
+      bool ok = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_' || c == '.' || c == '[' || c == ']' ||
+                (n > 0 && c >= '0' && c <= '9') || c > 0x7F;
+      if (!ok) return fail(kInvalid, "invalid capture group character");
+      pos++;
+      n++;
+    }
+    if (n == 0 || !eat('>')) return fail(kInvalid, "empty or unclosed capture group name");
+    return true;
+  }
+
+  static int hexval(uint32_t c) {
+    if (c >= '0' && c <= '9') return (int)(c - '0');
+    if (c >= 'a' && c <= 'f') return (int)(c - 'a' + 10);
+    if (c >= 'A' && c <= 'F') return (int)(c - 'A' + 10);
+    return -1;
+  }
+
+  bool parse_hex(int digits, uint32_t *out) {
+    // \xNN, \uNNNN, \UNNNNNNNN or the braced form \x{N...}
+    uint32_t v = 0;
+    if (peek() == '{') {
+      pos++;
+      int n = 0;
+      while (peek() != '}') {
+        int h = hexval(peek());
+        if (h < 0 || n >= 8) return fail(kInvalid, "invalid hexadecimal escape");
+        v = v * 16 + (uint32_t)h;
+        n++;
+        pos++;
+      }
+      pos++;
+      if (n == 0) return fail(kInvalid, "empty hexadecimal escape");
+    } else {
+      for (int k = 0; k < digits; k++) {
+        int h = hexval(peek());
+        if (h < 0) return fail(kInvalid, "invalid hexadecimal escape");
+        v = v * 16 + (uint32_t)h;
+        pos++;
+      }
+    }
+    if (v > kMaxCp || (v >= 0xD800 && v <= 0xDFFF)) return fail(kInvalid, "hexadecimal escape is not a Unicode scalar value");
+    *out = v;
+    return true;
+  }
+
+  // \d \w \s \p{..} and negations; returns false (without error) when `c` is not a class escape
+  bool class_escape(uint32_t c, const Flags &f, ClassSet *out, bool *is_class) {
+    *is_class = true;
+    switch (c) {
+      case 'd': table_lookup("perl_digit", out); return true;
+      case 'D': table_lookup("perl_digit", out); *out = negate(*out); return true;
+      case 's': table_lookup("perl_space", out); return true;
+      case 'S': table_lookup("perl_space", out); *out = negate(*out); return true;
+      case 'w': table_lookup("perl_word", out); return true;
+      case 'W': table_lookup("perl_word", out); *out = negate(*out); return true;
+      case 'p':
+      case 'P': {
+        std::string name;
+        bool neg = c == 'P';
+        if (peek() == '{') {
+          pos++;
+          if (peek() == '^') {
+            neg = !neg;
+            pos++;
+          }
+          while (!eof() && peek() != '}') {
+            name.push_back((char)peek());
+            pos++;
+          }
+          if (!eat('}')) return fail(kInvalid, "unclosed Unicode class");
+        } else {
+          if (eof()) return fail(kInvalid, "incomplete escape sequence");
+          name.push_back((char)peek());
+          pos++;
+        }
+        if (!unicode_property(name, out)) return false;
+        if (neg) *out = negate(*out);
+        (void)f;
+        return true;
+      }
+      default:
+        *is_class = false;
+        return true;
+    }
+  }
+
+  bool unicode_property(std::string name, ClassSet *out) {
+    // General_Category / a few binary properties and scripts; name matching is loose like UAX44-LM3
+    std::string key;
+    for (char ch : name)
+      if (ch != ' ' && ch != '_' && ch != '-') key.push_back((char)tolower((unsigned char)ch));
+    size_t eq = key.find('=');
+    std::string lhs = eq == std::string::npos ? "" : key.substr(0, eq);
+    if (eq != std::string::npos) key = key.substr(eq + 1);
+    static const char *const gc_long[][2] = {
+        {"letter", "L"}, {"uppercaseletter", "Lu"}, {"lowercaseletter", "Ll"}, {"titlecaseletter", "Lt"},
+        {"modifierletter", "Lm"}, {"otherletter", "Lo"}, {"mark", "M"}, {"nonspacingmark", "Mn"},
+        {"spacingmark", "Mc"}, {"enclosingmark", "Me"}, {"number", "N"}, {"decimalnumber", "Nd"},
+        {"letternumber", "Nl"}, {"othernumber", "No"}, {"punctuation", "P"}, {"connectorpunctuation", "Pc"},
+        {"dashpunctuation", "Pd"}, {"openpunctuation", "Ps"}, {"closepunctuation", "Pe"},
+        {"initialpunctuation", "Pi"}, {"finalpunctuation", "Pf"}, {"otherpunctuation", "Po"}, {"symbol", "S"},
+        {"mathsymbol", "Sm"}, {"currencysymbol", "Sc"}, {"modifiersymbol", "Sk"}, {"othersymbol", "So"},
+        {"separator", "Z"}, {"spaceseparator", "Zs"}, {"lineseparator", "Zl"}, {"paragraphseparator", "Zp"},
+        {"other", "C"}, {"control", "Cc"}, {"format", "Cf"}, {"privateuse", "Co"}, {"unassigned", "Cn"},
+        {"digit", "Nd"}, {"punct", "P"}};
+    for (auto &g : gc_long)
+      if (key == g[0]) key = g[1];
+    std::string lower = key;
+    for (auto &ch : lower) ch = (char)tolower((unsigned char)ch);
+    for (uint32_t i = 0; i < tgx_n_utables; i++) {
+      std::string t = tgx_utables[i].name;  // gc_Lu, prop_Alphabetic, script_Greek
+      size_t us = t.find('_');
+      std::string kind = t.substr(0, us), val = t.substr(us + 1);
+      if (kind == "perl") continue;
+      std::string v2;
+      for (char ch : val)
+        if (ch != '_') v2.push_back((char)tolower((unsigned char)ch));
+      if (v2 != lower) continue;
+      if (!lhs.empty()) {
+        bool ok = (kind == "gc" && (lhs == "gc" || lhs == "generalcategory")) ||
+                  (kind == "script" && (lhs == "sc" || lhs == "script"));
+        if (!ok) continue;
+      }
+      out->clear();
+      for (uint32_t k = 0; k < tgx_utables[i].count; k++)
+        out->push_back({tgx_utables[i].ranges[k].lo, tgx_utables[i].ranges[k].hi});
+      return true;
+    }
+    if (lower == "any") {
+      out->assign(1, Range{0, kMaxCp});
+      return true;
+    }
+    if (lower == "ascii") {
+      out->assign(1, Range{0, 0x7F});
+      return true;
+    }
+    return fail(kUnsupported, "Unicode property \\p{" + name + "} is not in the GPU engine's tables");
+  }
+
+  // single-code-point escapes shared by atoms and classes; *handled=false if `c` is not one
+  bool simple_escape(uint32_t c, uint32_t *cp, bool *handled) {
+    *handled = true;
+    switch (c) {
+      case 'n': *cp = '\n'; return true;
+      case 't': *cp = '\t'; return true;
+      case 'r': *cp = '\r'; return true;
+      case 'f': *cp = '\f'; return true;
+      case 'v': *cp = 0x0B; return true;
+      case 'a': *cp = 0x07; return true;
+      case '0': *cp = 0; return fail(kInvalid, "octal escapes are not supported");
+      case 'x': return parse_hex(2, cp);
+      case 'u': return parse_hex(4, cp);
+      case 'U': return parse_hex(8, cp);
+      default: break;
+    }
+    // regex-syntax: any ASCII punctuation may be escaped; letters/digits without a meaning may not
+    bool punct = c < 0x80 && !((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) && c > ' ';
+    if (punct || c == ' ') {
+      *cp = c;
+      return true;
+    }
+    *handled = false;
+    return true;
+  }
+
+  NodeP parse_escape_atom(const Flags &f) {
+    pos++;  // backslash
+    if (eof()) {
+      fail(kInvalid, "incomplete escape sequence, reached end of pattern prematurely");
+      return nullptr;
+    }
+    uint32_t c = peek();
+    pos++;
+    if (c == 'A') return mk(Node::kStart);
+    if (c == 'z') return mk(Node::kEnd);
+    if (c == 'b' || c == 'B') {
+      fail(kUnsupported, "word boundary assertions are not supported by the GPU engine");
+      return nullptr;
+    }
+    if (c >= '1' && c <= '9') {
+      fail(kInvalid, "backreferences are not supported");
+      return nullptr;
+    }
+    ClassSet cs;
+    bool is_class = false;
+    if (!class_escape(c, f, &cs, &is_class)) return nullptr;
+    if (is_class) {
+      NodeP n = mk(Node::kClass);
+      n->cls = cs;
+      if (f.i) case_fold(n->cls);
+      return n;
+    }
+    uint32_t cp = 0;
+    bool handled = false;
+    if (!simple_escape(c, &cp, &handled)) return nullptr;
+    if (!handled) {
+      fail(kInvalid, "unrecognized escape sequence");
+      return nullptr;
+    }
+    return literal(cp, f);
+  }
+
+  bool posix_class(const std::string &name, ClassSet *out) {
+    struct P {
+      const char *n;
+      ClassSet s;
+    };
+    static const P tbl[] = {
+        {"alnum", {{'0', '9'}, {'A', 'Z'}, {'a', 'z'}}},
+        {"alpha", {{'A', 'Z'}, {'a', 'z'}}},
+        {"ascii", {{0, 0x7F}}},
+        {"blank", {{'\t', '\t'}, {' ', ' '}}},
+        {"cntrl", {{0, 0x1F}, {0x7F, 0x7F}}},
+        {"digit", {{'0', '9'}}},
+        {"graph", {{'!', '~'}}},
+        {"lower", {{'a', 'z'}}},
+        {"print", {{' ', '~'}}},
+        {"punct", {{'!', '/'}, {':', '@'}, {'[', '`'}, {'{', '~'}}},
+        {"space", {{'\t', '\r'}, {' ', ' '}}},
+        {"upper", {{'A', 'Z'}}},
+        {"word", {{'0', '9'}, {'A', 'Z'}, {'_', '_'}, {'a', 'z'}}},
+        {"xdigit", {{'0', '9'}, {'A', 'F'}, {'a', 'f'}}},
+    };
+    for (auto &e : tbl)
+      if (name == e.n) {
+        *out = e.s;
+        return true;
+      }
+    return false;
+  }
+
+  bool parse_class(const Flags &f, ClassSet *out) {
+    pos++;  // [
+    bool neg = eat('^');
+    ClassSet acc;
+    bool first = true;
+    for (;;) {
+      if (eof()) return fail(kInvalid, "unclosed character class");
+      uint32_t c = peek();
+      if (c == ']' && !first) {
+        pos++;
+        break;
+      }
+      first = false;
+      if (c == '[') {
+        if (peek(1) == ':') {
+          // [:name:] / [:^name:]
+          size_t save = pos;
+          pos += 2;
+          bool pneg = eat('^');
+          std::string name;
+          while (!eof() && peek() != ':' && name.size() < 16) {
+            name.push_back((char)peek());
+            pos++;
+          }
+          ClassSet pc;
+          if (peek() == ':' && peek(1) == ']' && posix_class(name, &pc)) {
+            pos += 2;
+            if (pneg) pc = negate(pc);
+            acc.insert(acc.end(), pc.begin(), pc.end());
+            continue;
+          }
+          pos = save;
+        }
+        ClassSet nested;
+        if (!parse_class(f, &nested)) return false;
+        acc.insert(acc.end(), nested.begin(), nested.end());
+        continue;
+      }
+      if ((c == '&' && peek(1) == '&') || (c == '-' && peek(1) == '-') || (c == '~' && peek(1) == '~'))
+        return fail(kUnsupported, "character class set operations are not supported by the GPU engine");
+      uint32_t lo;
+      bool lo_is_class = false;
+      ClassSet cs;
+      if (!class_item(f, &lo, &cs, &lo_is_class)) return false;
+      if (lo_is_class) {
+        acc.insert(acc.end(), cs.begin(), cs.end());
+        continue;
+      }
+      if (peek() == '-' && peek(1) != ']' && !eof()) {
+        if (peek(1) == '-') return fail(kUnsupported, "character class set operations are not supported by the GPU engine");
+        pos++;  // -
+        uint32_t hi;
+        bool hi_is_class = false;
+        ClassSet hs;
+        if (!class_item(f, &hi, &hs, &hi_is_class)) return false;
+        if (hi_is_class) return fail(kInvalid, "invalid character class range, a class is not a valid range endpoint");
+        if (hi < lo) return fail(kInvalid, "invalid character class range, the start must be <= the end");
+        acc.push_back({lo, hi});
+      } else {
+        acc.push_back({lo, lo});
+      }
+    }
+    normalize(acc);
+    if (f.i) case_fold(acc);
+    if (neg) acc = negate(acc);
+    *out = acc;
+    return true;
+  }
+
+  bool class_item(const Flags &f, uint32_t *cp, ClassSet *cs, bool *is_class) {
+    *is_class = false;
+    uint32_t c = peek();
+    pos++;
+    if (c != '\\') {
+      *cp = c;
+      return true;
+    }
+    if (eof()) return fail(kInvalid, "incomplete escape sequence, reached end of pattern prematurely");
+    uint32_t e = peek();
+    pos++;
+    if (e == 'b') {
+      *cp = 0x08;  // inside a class \b is backspace in regex-syntax
+      return true;
+    }
+    if (!class_escape(e, f, cs, is_class)) return false;
+    if (*is_class) return true;
+    bool handled = false;
+    if (!simple_escape(e, cp, &handled)) return false;
+    if (!handled) return fail(kInvalid, "unrecognized escape sequence");
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------- NFA
+struct NState {
+  enum Type { kByte, kSplit, kEmpty, kAssertStart, kAssertEnd, kMatch } type;
+  uint8_t lo = 0, hi = 0;
+  int out = -1, out1 = -1;
+};
+
+struct ByteSeq {
+  int n;
+  uint8_t lo[4], hi[4];
+};
+
+void push_seq(std::vector<ByteSeq> *out, uint32_t s, uint32_t e, int n) {
+  ByteSeq q;
+  q.n = n;
+  if (n == 1) {
+    q.lo[0] = (uint8_t)s;
+    q.hi[0] = (uint8_t)e;
+  } else {
+    static const uint8_t lead[5] = {0, 0, 0xC0, 0xE0, 0xF0};
+    for (int i = 0; i < n; i++) {
+      int shift = 6 * (n - 1 - i);
+      uint8_t a = (uint8_t)((s >> shift) & 0x3F), b = (uint8_t)((e >> shift) & 0x3F);
+      if (i == 0) {
+        a = (uint8_t)(lead[n] | (s >> shift));
+        b = (uint8_t)(lead[n] | (e >> shift));
+      } else {
+        a |= 0x80;
+        b |= 0x80;
+      }
+      q.lo[i] = a;
+      q.hi[i] = b;
+    }
+  }
+  out->push_back(q);
+}
+
+// split [s, e] (same UTF-8 length n) so every byte position ranges independently (utf8-ranges algorithm)
+void split_same_len(uint32_t s, uint32_t e, int n, std::vector<ByteSeq> *out) {
+  for (int i = 1; i < n; i++) {
+    uint32_t m = (1u << (6 * i)) - 1;
+    if ((s & ~m) != (e & ~m)) {
+      if ((s & m) != 0) {
+        split_same_len(s, s | m, n, out);
+        split_same_len((s | m) + 1, e, n, out);
+        return;
+      }
+      if ((e & m) != m) {
+        split_same_len(s, (e & ~m) - 1, n, out);
+        split_same_len(e & ~m, e, n, out);
+        return;
+      }
+    }
+  }
+  push_seq(out, s, e, n);
+}
+
+void utf8_sequences(const ClassSet &cls, std::vector<ByteSeq> *out) {
+  static const uint32_t bounds[4][2] = {{0, 0x7F}, {0x80, 0x7FF}, {0x800, 0xFFFF}, {0x10000, 0x10FFFF}};
+  for (const Range &r : cls) {
+    // drop surrogates
+    Range parts[2];
+    int np = 0;
+    if (r.hi < 0xD800 || r.lo > 0xDFFF) {
+      parts[np++] = r;
+    } else {
+      if (r.lo < 0xD800) parts[np++] = {r.lo, 0xD7FF};
+      if (r.hi > 0xDFFF) parts[np++] = {0xE000, r.hi};
+    }
+    for (int k = 0; k < np; k++)
+      for (int n = 1; n <= 4; n++) {
+        uint32_t lo = std::max(parts[k].lo, bounds[n - 1][0]), hi = std::min(parts[k].hi, bounds[n - 1][1]);
+        if (lo <= hi) split_same_len(lo, hi, n, out);
+      }
+  }
+}
+
+struct Nfa {
+  std::vector<NState> st;
+  bool overflow = false;
+  int add(NState::Type t, int out = -1, int out1 = -1, uint8_t lo = 0, uint8_t hi = 0) {
+    if (st.size() >= kMaxNfaStates) {
+      overflow = true;
+      return 0;
+    }
+    NState s;
+    s.type = t;
+    s.out = out;
+    s.out1 = out1;
+    s.lo = lo;
+    s.hi = hi;
+    st.push_back(s);
+    return (int)st.size() - 1;
+  }
+
+  // byte-range trie of a class's sequences, all leaves -> next
+  int build_class(const std::vector<ByteSeq> &seqs, size_t a, size_t b, int depth, int next) {
+    // seqs[a..b) share their first `depth` byte ranges; group by range at `depth`
+    int alt = -1;
+    size_t i = a;
+    std::vector<int> heads;
+    while (i < b) {
+      size_t j = i + 1;
+      while (j < b && seqs[j].lo[depth] == seqs[i].lo[depth] && seqs[j].hi[depth] == seqs[i].hi[depth] &&
+             seqs[j].n == seqs[i].n)
+        j++;
+      int target;
+      if (seqs[i].n == depth + 1)
+        target = next;
+      else
+        target = build_class(seqs, i, j, depth + 1, next);
+      heads.push_back(add(NState::kByte, target, -1, seqs[i].lo[depth], seqs[i].hi[depth]));
+      i = j;
+    }
+    if (heads.empty()) return -1;
+    alt = heads.back();
+    for (size_t k = heads.size() - 1; k-- > 0;) alt = add(NState::kSplit, heads[k], alt);
+    return alt;
+  }
+
+  int compile(const Node *n, int next) {
+    if (overflow) return next;
+    switch (n->kind) {
+      case Node::kEmpty:
+        return next;
+      case Node::kStart:
+        return add(NState::kAssertStart, next);
+      case Node::kEnd:
+        return add(NState::kAssertEnd, next);
+      case Node::kClass: {
+        std::vector<ByteSeq> seqs;
+        utf8_sequences(n->cls, &seqs);
+        if (seqs.empty()) return add(NState::kByte, next, -1, 1, 0);  // empty class: matches nothing
+        std::sort(seqs.begin(), seqs.end(), [](const ByteSeq &x, const ByteSeq &y) {
+          if (x.n != y.n) return x.n < y.n;
+          for (int i = 0; i < x.n; i++) {
+            if (x.lo[i] != y.lo[i]) return x.lo[i] < y.lo[i];
+            if (x.hi[i] != y.hi[i]) return x.hi[i] < y.hi[i];
+          }
+          return false;
+        });
+        return build_class(seqs, 0, seqs.size(), 0, next);
+      }
+      case Node::kConcat: {
+        int cur = next;
+        for (size_t i = n->kids.size(); i-- > 0;) cur = compile(n->kids[i].get(), cur);
+        return cur;
+      }
+      case Node::kAlt: {
+        std::vector<int> heads;
+        for (auto &k : n->kids) heads.push_back(compile(k.get(), next));
+        int alt = heads.back();
+        for (size_t k = heads.size() - 1; k-- > 0;) alt = add(NState::kSplit, heads[k], alt);
+        return alt;
+      }
+      case Node::kRepeat: {
+        const Node *body = n->kids[0].get();
+        int cur = next;
+        if (n->max < 0) {
+          // body* : loop = Split(body -> loop, next)
+          int loop = add(NState::kSplit, -1, next);
+          int b = compile(body, loop);
+          st[loop].out = b;
+          cur = loop;
+        } else {
+          for (int k = n->min; k < n->max; k++) {
+            int b = compile(body, cur);
+            cur = add(NState::kSplit, b, next);
+          }
+        }
+        for (int k = 0; k < n->min; k++) cur = compile(body, cur);
+        return cur;
+      }
+    }
+    return next;
+  }
+};
+
+// ------------------------------------------------------------------------------------------- DFA
+struct Builder {
+  const Nfa &nfa;
+  explicit Builder(const Nfa &n) : nfa(n) {}
+  std::vector<int> stack;
+  std::vector<uint32_t> mark;
+  uint32_t epoch = 0;
+
+  // epsilon closure of `seeds`; keeps byte / match / assert-end states
+  void closure(const std::vector<int> &seeds, bool at_start, bool at_end, std::vector<int> *out) {
+    if (mark.size() != nfa.st.size()) mark.assign(nfa.st.size(), 0);
+    epoch++;
+    stack.assign(seeds.begin(), seeds.end());
+    while (!stack.empty()) {
+      int s = stack.back();
+      stack.pop_back();
+      if (s < 0 || mark[s] == epoch) continue;
+      mark[s] = epoch;
+      const NState &n = nfa.st[s];
+      switch (n.type) {
+        case NState::kEmpty:
+          stack.push_back(n.out);
+          break;
+        case NState::kSplit:
+          stack.push_back(n.out);
+          stack.push_back(n.out1);
+          break;
+        case NState::kAssertStart:
+          if (at_start) stack.push_back(n.out);
+          break;
+        case NState::kAssertEnd:
+          if (at_end)
+            stack.push_back(n.out);
+          else
+            out->push_back(s);
+          break;
+        case NState::kByte:
+        case NState::kMatch:
+          out->push_back(s);
+          break;
+      }
+    }
+    std::sort(out->begin(), out->end());
+    out->erase(std::unique(out->begin(), out->end()), out->end());
+  }
+
+  bool has_match(const std::vector<int> &set) const {
+    for (int s : set)
+      if (nfa.st[s].type == NState::kMatch) return true;
+    return false;
+  }
+};
+
+}  // namespace
+
+CompileStatus validate_pattern_rules(const char *pattern, size_t len, std::string *msg) {
+  // SqlSecurity::validate_regex_pattern, TG/security.rs:152-183 and check_redos_patterns :258-281
+  if (len > 1000) {
+    *msg = "Regex pattern too long (max 1000 characters)";
+    return kRejected;
+  }
+  if (memchr(pattern, 0, len) != nullptr) {
+    *msg = "Regex pattern cannot contain null bytes";
+    return kRejected;
+  }
+  static const char *const dangerous[] = {"(.*)*", "(.*)+", "(a+)+", "(a*)*"};
+  std::string p(pattern, len);
+  for (const char *d : dangerous)
+    if (p.find(d) != std::string::npos) {
+      *msg = "Regex pattern might cause ReDoS attack";
+      return kRejected;
+    }
+  return kOk;
+}
+
+CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Dfa *out, std::string *msg) {
+  Parser ps;
+  if (!Parser::decode_utf8(pattern, len, &ps.p)) {
+    *msg = "Invalid regex pattern: pattern is not valid UTF-8";
+    return kInvalid;
+  }
+  Flags f;
+  f.i = case_insensitive;
+  NodeP ast = ps.parse_alt(f);
+  if (ps.status == kOk && !ps.eof()) {
+    if (ps.peek() == ')')
+      ps.fail(kInvalid, "unopened group");
+    else
+      ps.fail(kInvalid, "unexpected character");
+  }
+  if (ps.status != kOk) {
+    *msg = (ps.status == kInvalid ? "Invalid regex pattern: " : "") + ps.msg;
+    return ps.status;
+  }
+  Nfa nfa;
+  int match = nfa.add(NState::kMatch);
+  int start = nfa.compile(ast.get(), match);
+  if (nfa.overflow) {
+    *msg = "pattern expands to too many NFA states for the GPU engine";
+    return kUnsupported;
+  }
+
+  // byte classes from every byte-range boundary
+  bool boundary[257];
+  memset(boundary, 0, sizeof(boundary));
+  boundary[0] = true;
+  for (const NState &s : nfa.st)
+    if (s.type == NState::kByte && s.lo <= s.hi) {
+      boundary[s.lo] = true;
+      boundary[(int)s.hi + 1] = true;
+    }
+  int ncls = 0;
+  uint8_t rep[256];
+  for (int b = 0; b < 256; b++) {
+    if (boundary[b]) {
+      rep[ncls] = (uint8_t)b;
+      ncls++;
+    }
+    out->byte_class[b] = (uint8_t)(ncls - 1);
+  }
+
+  Builder bld(nfa);
+  std::vector<int> init_unanchored, init_start;
+  bld.closure({start}, false, false, &init_unanchored);
+  bld.closure({start}, true, false, &init_start);
+
+  std::map<std::vector<int>, int> ids;
+  std::vector<std::vector<int>> sets;
+  // ids: 0 = DEAD (empty set), 1 = MATCHED
+  sets.push_back({});
+  ids[{}] = 0;
+  sets.push_back({-1});
+  auto intern = [&](const std::vector<int> &set) -> int {
+    if (bld.has_match(set)) return 1;
+    auto it = ids.find(set);
+    if (it != ids.end()) return it->second;
+    int id = (int)sets.size();
+    ids[set] = id;
+    sets.push_back(set);
+    return id;
+  };
+  int start_id = intern(init_start);
+  std::vector<uint16_t> table;
+  std::vector<uint8_t> acc_end;
+  // accept-at-end of the start state uses both assertions at once (empty haystack)
+  for (size_t cur = 0; cur < sets.size(); cur++) {
+    if (sets.size() > kMaxDfaStates) {
+      *msg = "pattern needs more than 20000 DFA states; not supported by the GPU engine";
+      return kUnsupported;
+    }
+    table.resize((cur + 1) * (size_t)ncls);
+    acc_end.resize(cur + 1);
+    if (cur == 0) {
+      for (int c = 0; c < ncls; c++) table[c] = 0;
+      acc_end[0] = 0;
+      continue;
+    }
+    if (cur == 1) {
+      for (int c = 0; c < ncls; c++) table[ncls + c] = 1;
+      acc_end[1] = 1;
+      continue;
+    }
+    const std::vector<int> set = sets[cur];
+    {
+      std::vector<int> endc;
+      if ((int)cur == start_id) {
+        bld.closure({start}, true, true, &endc);
+      } else {
+        std::vector<int> seeds;
+        for (int s : set)
+          if (nfa.st[s].type == NState::kAssertEnd) seeds.push_back(nfa.st[s].out);
+        bld.closure(seeds, false, true, &endc);
+      }
+      acc_end[cur] = bld.has_match(endc) ? 1 : 0;
+    }
+    for (int c = 0; c < ncls; c++) {
+      const uint8_t byte = rep[c];
+      std::vector<int> seeds;
+      for (int s : set) {
+        const NState &n = nfa.st[s];
+        if (n.type == NState::kByte && n.lo <= byte && byte <= n.hi) seeds.push_back(n.out);
+      }
+      std::vector<int> next;
+      bld.closure(seeds, false, false, &next);
+      // unanchored search: a match may also begin at the next position
+      next.insert(next.end(), init_unanchored.begin(), init_unanchored.end());
+      std::sort(next.begin(), next.end());
+      next.erase(std::unique(next.begin(), next.end()), next.end());
+      int id = intern(next);
+      table.resize(std::max(table.size(), (cur + 1) * (size_t)ncls));
+      table[cur * ncls + c] = (uint16_t)id;
+    }
+  }
+  const int n_states = (int)sets.size();
+  // states from which neither MATCHED nor an accept-at-end state is reachable are DEAD
+  std::vector<char> alive(n_states, 0);
+  std::vector<std::vector<int>> rev(n_states);
+  for (int s = 0; s < n_states; s++)
+    for (int c = 0; c < ncls; c++) rev[table[(size_t)s * ncls + c]].push_back(s);
+  std::vector<int> work;
+  for (int s = 0; s < n_states; s++)
+    if (s == 1 || acc_end[s]) {
+      alive[s] = 1;
+      work.push_back(s);
+    }
+  while (!work.empty()) {
+    int s = work.back();
+    work.pop_back();
+    for (int p : rev[s])
+      if (!alive[p]) {
+        alive[p] = 1;
+        work.push_back(p);
+      }
+  }
+  for (auto &t : table)
+    if (!alive[t]) t = 0;
+  out->n_states = (uint32_t)n_states;
+  out->n_classes = (uint32_t)ncls;
+  out->start = alive[start_id] ? (uint32_t)start_id : 0u;
+  out->table = table;
+  out->accept_at_end = acc_end;
+  return kOk;
+}
+
+bool dfa_is_match(const Dfa &d, const uint8_t *s, size_t n) {
+  uint32_t st = d.start;
+  for (size_t i = 0; i < n && st > 1; i++) st = d.table[(size_t)st * d.n_classes + d.byte_class[s[i]]];
+  return st == 1 || d.accept_at_end[st] != 0;
+}
+
+}  // namespace rx
+}  // namespace tgx

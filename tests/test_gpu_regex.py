@@ -1,0 +1,120 @@
+"""-m gpu: pattern checks through the HIP match kernel vs the oracle (bit-exact match counts)."""
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+import term_amd as T
+from _lib_spec import spec
+from gpu_util import pad_validity, run_plan, to_device
+from test_regex_host import pattern_of
+
+pytestmark = pytest.mark.gpu
+
+
+def utf8_column(offsets, data, validity, device, offset=0, length=None, large=False):
+    validity = pad_validity(validity)
+    data = np.concatenate([data, np.zeros(16, np.uint8)])
+    offs = offsets.astype(np.int64) if large else offsets
+    if device:
+        offs_d, data_d, val_d = to_device(offs), to_device(data), to_device(validity)
+    else:
+        offs_d, data_d, val_d = offs, data, validity
+    n = (len(offsets) - 1 - offset) if length is None else length
+    return T.Column(T.LARGE_UTF8 if large else T.UTF8, n, offsets=offs_d, data=data_d, validity=val_d,
+                    offset=offset)
+
+
+def synth_strings(rng, n, kind):
+    out = []
+    for i in range(n):
+        r = rng.random()
+        if kind == "email":
+            if r < 0.80:
+                s = "user%d@example%d.com" % (i, i % 1000)
+            elif r < 0.85:
+                s = "  padded%d@host.org " % i
+            elif r < 0.90:
+                s = "no-at-sign-%d.example.com" % i
+            elif r < 0.93:
+                s = "Ünï%d@exämple.com" % i
+            elif r < 0.95:
+                s = ""
+            elif r < 0.97:
+                s = "a@b@c%d.com" % i
+            else:
+                s = None
+        elif kind == "mixed":
+            choices = ["192.168.%d.%d" % (i % 256, (i * 7) % 300), "2023-12-25T10:30:%02dZ" % (i % 60),
+                       "ABC%03d" % (i % 1000), "abc%03d" % (i % 1000), "550e8400-e29b-41d4-a716-%012x" % i,
+                       "123-45-%04d" % (i % 10000), "٣٤-%d" % i, "x" * (i % 70), None, "line\nbreak%d" % i]
+            s = choices[int(r * len(choices)) % len(choices)]
+        out.append(s)
+    return out
+
+
+def test_reference_format_vectors_on_gpu(golden):
+    for case in golden["format"]:
+        vals = case["values"]
+        if not vals:
+            continue
+        pat = pattern_of(case, golden["patterns"])
+        flags = (T.FLAG_TRIM if case.get("trim") else 0) | \
+                (T.FLAG_CASE_INSENSITIVE if case.get("case_sensitive") is False else 0) | \
+                (T.FLAG_NULL_IS_VALID if case.get("null_is_valid", True) else 0)
+        offs, data, validity = orc.utf8_from_list(vals)
+        for device in (True, False):
+            res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, flags=flags, pattern=pat)],
+                                 [[utf8_column(offs, data, validity, device)]])
+            assert res[0].total == len(vals)
+            assert res[0].matches / res[0].total == case["metric"], case["ref"]
+
+
+@pytest.mark.parametrize("kind", ["email", "mixed"])
+def test_seeded_columns_match_oracle_bit_exact(kind, golden):
+    rng = np.random.default_rng(5 if kind == "email" else 6)
+    n = 200_003
+    vals = synth_strings(rng, n, kind)
+    offs, data, validity = orc.utf8_from_list(vals)
+    P = golden["patterns"]
+    checks = [(r"@", 0), (r"^[^@]+@[^@]+\.[^@]+$", T.FLAG_NULL_IS_VALID), (P["email"], T.FLAG_TRIM),
+              (P["email"], T.FLAG_NULL_IS_VALID), (P["ipv4"], 0), (P["iso8601_datetime"], T.FLAG_NULL_IS_VALID),
+              (r"^[A-Z]{3}\d{3}$", T.FLAG_CASE_INSENSITIVE), (P["uuid"], 0), (P["social_security_number"], T.FLAG_TRIM),
+              (r"^\d+-\d+$", 0), (r"^x{10,61}$", 0), (r"^.*$", 0)]
+    specs = [spec(T.REGEX_MATCH, 0, flags=f, pattern=p) for p, f in checks]
+    res, _, _ = run_plan(specs, [[utf8_column(offs, data, validity, True)]])
+    for (p, f), r in zip(checks, res):
+        want = orc.Regex(p, bool(f & T.FLAG_CASE_INSENSITIVE)).count_utf8(
+            offs, data, validity, trim=bool(f & T.FLAG_TRIM), null_is_valid=bool(f & T.FLAG_NULL_IS_VALID))
+        assert (r.total, r.matches) == (want.total, want.matches), p
+
+
+def test_sliced_large_offsets_batches_and_merge(golden):
+    rng = np.random.default_rng(9)
+    n = 50_000
+    vals = synth_strings(rng, n, "email")
+    offs, data, validity = orc.utf8_from_list(vals)
+    pat = golden["patterns"]["email"]
+    flags = T.FLAG_TRIM
+    T.init()
+    plan = T.Plan([spec(T.REGEX_MATCH, 0, flags=flags, pattern=pat), spec(T.COUNT, 0)])
+    a, b = T.State(plan), T.State(plan)
+    cuts = [0, 7, 12_345, 12_346, 40_001, n]
+    for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        col = utf8_column(offs, data, validity, device=(i % 2 == 0), offset=lo, length=hi - lo, large=(i % 3 == 0))
+        (a if i < 3 else b).update([col])
+    a.merge([T.State.deserialize(plan, b.serialize())])
+    res = a.finalize()
+    want = orc.Regex(pat).count_utf8(offs, data, validity, trim=True, null_is_valid=False)
+    assert (res[0].total, res[0].matches) == (want.total, want.matches)
+    c = orc.count(validity, n)
+    assert (res[1].total, res[1].non_null) == (c.total, c.non_null)
+
+
+def test_big_table_automaton_runs_from_global_memory():
+    """a DFA larger than the 48 KiB LDS budget takes the global-memory table path"""
+    pat = r"^(?:[a-z]{1,40}\d{1,40}[A-Z]{1,40}){1,3}$"
+    vals = ["abc123XYZ", "a1A" * 3, "abc", "a1Ab2Bc3Cd4D", "", None, "zz99QQzz9Q"] * 1000
+    offs, data, validity = orc.utf8_from_list(vals)
+    res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, pattern=pat)], [[utf8_column(offs, data, validity, True)]])
+    want = orc.Regex(pat).count_utf8(offs, data, validity, null_is_valid=False)
+    assert (res[0].total, res[0].matches) == (want.total, want.matches)
