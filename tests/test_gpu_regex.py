@@ -100,7 +100,7 @@ def test_sliced_large_offsets_batches_and_merge(golden):
     a, b = T.State(plan), T.State(plan)
     cuts = [0, 7, 12_345, 12_346, 40_001, n]
     for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
-        col = utf8_column(offs, data, validity, device=(i % 2 == 0), offset=lo, length=hi - lo, large=(i % 3 == 0))
+        col = utf8_column(offs, data, validity, device=(i % 2 == 0), offset=lo, length=hi - lo, large=(i >= 3))
         (a if i < 3 else b).update([col])
     a.merge([T.State.deserialize(plan, b.serialize())])
     res = a.finalize()
