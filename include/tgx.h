@@ -214,10 +214,13 @@ double tgx_kll_relative_error_bound(uint32_t k);
 
 /* ---- exact DISTINCT across ranks: hash-owner key exchange -------------
  * export: partitions this state's key set by owner = mix(key) % world into `world` contiguous
- *   runs of 16-byte records in device memory the state owns (valid until the next call on the
+ *   runs of fixed-size records (tgx_distinct_record_bytes) in device memory the state owns (valid until the next call on the
  *   state); counts[r] = records for rank r.
  * import: replaces the state's key set with the union of the given records (device memory),
  *   marking the state "owner-partitioned" so that tgx_merge adds its counts instead of uniting. */
+/* bytes per exchange record: 16 ({key, count}) for Int64/Float64 columns, 32 ({hash_a, hash_b, count, 0})
+ * for Utf8 columns, whose values travel as 128-bit fingerprints */
+size_t tgx_distinct_record_bytes(const tgx_plan *plan, const tgx_state *state, size_t spec_index);
 tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *state, size_t spec_index,
                                uint32_t world, const void **device_records, uint64_t *counts,
                                tgx_error *err);

@@ -134,6 +134,8 @@ def lib():
         L.tgx_kll_relative_error_bound.restype = C.c_double
         L.tgx_distinct_export.argtypes = [vp, vp, sz, C.c_uint32, C.POINTER(vp), C.POINTER(u64), E]
         L.tgx_distinct_import.argtypes = [vp, vp, sz, vp, u64, E]
+        L.tgx_distinct_record_bytes.argtypes = [vp, vp, sz]
+        L.tgx_distinct_record_bytes.restype = sz
         L.tgx_profile_enable.argtypes = [vp, C.c_int32]
         L.tgx_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), E]
         L.tgx_profile_reset.argtypes = [vp]
@@ -352,6 +354,9 @@ class State:
         _check(lib().tgx_distinct_export(self.plan.h, self.h, spec_index, world, C.byref(ptr), counts,
                                          C.byref(err)), err)
         return ptr.value, list(counts)
+
+    def distinct_record_bytes(self, spec_index):
+        return lib().tgx_distinct_record_bytes(self.plan.h, self.h, spec_index)
 
     def distinct_import(self, spec_index, device_ptr, n_records):
         err = _Error()

@@ -38,6 +38,17 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
                       hipStream_t stream);
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
                                hipStream_t stream);
+void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+                          int64_t length, int large_offsets, int want_mult, const HashSetView &t,
+                          unsigned long long *d_counters, hipStream_t stream);
+void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,
+                           unsigned long long *d_counters, hipStream_t stream);
+void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
+                           unsigned long long *d_counters, hipStream_t stream);
+void launch_hash_export_count128(const HashSetView &src, uint32_t world, unsigned long long *d_counts,
+                                 hipStream_t stream);
+void launch_hash_export_scatter128(const HashSetView &src, uint32_t world, int want_mult,
+                                   unsigned long long *d_cursors, KeyRecord128 *out, hipStream_t stream);
 void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
                         unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,
@@ -150,7 +161,8 @@ struct DistinctState {
   uint64_t range = 0;
   // range-partitioned population of the bitmap (big batches)
   DevBuf lists, cursors;
-  // hash
+  // hash (wide = 128-bit fingerprint keys of a Utf8 column: two words per slot, 32-byte records)
+  bool wide = false;
   DevBuf keys, dup;
   uint64_t capacity = 0;         // slots (power of two)
   uint64_t rows_upper_bound = 0; // host-side bound on keys in the table

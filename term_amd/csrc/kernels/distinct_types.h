@@ -16,7 +16,7 @@ struct DistinctColDesc {
 };
 
 struct HashSetView {
-  uint64_t *keys;  // capacity = mask + 1 slots, kEmptyKey = free
+  uint64_t *keys;  // capacity = mask + 1 slots, kEmptyKey = free; 128-bit sets use two words per slot
   uint32_t *dup;   // 1 bit per slot: key seen at least twice (only with multiplicity)
   uint64_t mask;
 };
@@ -60,6 +60,13 @@ struct PartitionParams {
 struct KeyRecord {
   uint64_t key;
   uint64_t count;  // saturates at 2
+};
+
+// 32-byte record of the 128-bit fingerprint sets (Utf8 columns, distinct128.hip)
+struct KeyRecord128 {
+  uint64_t a, b;   // the two 64-bit hashes
+  uint64_t count;  // saturates at 2
+  uint64_t pad;
 };
 
 // counters[] slots shared by the kernels of distinct.hip

@@ -395,6 +395,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
     d.col_type = 0;
     d.base = 0;
     d.range = 0;
+    d.wide = false;
     d.capacity = 0;  // buffers stay allocated; hash_ensure / the bitmap path clear them before use
     d.rows_upper_bound = 0;
     d.total_rows = 0;
@@ -603,9 +604,10 @@ static BitmapView bitmap_view(const DistinctState &ds) {
 
 // allocate an empty table of `capacity` slots into (keys, dup)
 static tgx_status hash_alloc(tgx_state *st, DevBuf &keys, DevBuf &dup, uint64_t capacity, bool mult,
-                             tgx_error *err) {
-  HIP_TRY(keys.reserve(capacity * sizeof(uint64_t)));
-  HIP_TRY(hipMemsetAsync(keys.p, 0xFF, capacity * sizeof(uint64_t), st->stream));
+                             bool wide, tgx_error *err) {
+  const size_t slot_bytes = wide ? 16 : 8;
+  HIP_TRY(keys.reserve(capacity * slot_bytes));
+  HIP_TRY(hipMemsetAsync(keys.p, 0xFF, capacity * slot_bytes, st->stream));
   if (mult) {
     HIP_TRY(dup.reserve((capacity / 32 + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(dup.p, 0, (capacity / 32 + 1) * sizeof(uint32_t), st->stream));
@@ -619,7 +621,7 @@ static tgx_status hash_ensure(tgx_state *st, DistinctState &ds, bool mult, uint6
   if (ds.capacity == 0) {
     uint64_t want = std::max<uint64_t>(incoming, g_ctx.distinct_hint);
     ds.capacity = next_pow2(std::max<uint64_t>(2 * want, 1024));
-    TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, err));
+    TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, ds.wide, err));
     ds.rows_upper_bound = 0;
   }
   if (2 * (ds.rows_upper_bound + incoming) <= ds.capacity) {
@@ -636,12 +638,15 @@ static tgx_status hash_ensure(tgx_state *st, DistinctState &ds, bool mult, uint6
   }
   uint64_t new_cap = next_pow2(2 * (actual + incoming));
   DevBuf nk, nd;
-  TGX_TRY(hash_alloc(st, nk, nd, new_cap, mult, err));
+  TGX_TRY(hash_alloc(st, nk, nd, new_cap, mult, ds.wide, err));
   HashSetView src = hash_view(ds);
   HashSetView dst{nk.as<uint64_t>(), nd.as<uint32_t>(), new_cap - 1};
   // re-insertion recounts distinct / twice: zero those two counters first
   HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));
-  launch_hash_rehash(src, dst, mult ? 1 : 0, ds.counters.as<unsigned long long>(), st->stream);
+  if (ds.wide)
+    launch_hash_rehash128(src, dst, mult ? 1 : 0, ds.counters.as<unsigned long long>(), st->stream);
+  else
+    launch_hash_rehash(src, dst, mult ? 1 : 0, ds.counters.as<unsigned long long>(), st->stream);
   HIP_TRY(hipStreamSynchronize(st->stream));
   std::swap(ds.keys.p, nk.p);
   std::swap(ds.keys.cap, nk.cap);
@@ -661,7 +666,7 @@ static tgx_status bitmap_to_hash(tgx_state *st, DistinctState &ds, bool mult, ui
   ds.rows_upper_bound = 0;
   uint64_t want = std::max<uint64_t>(actual + incoming, g_ctx.distinct_hint);
   ds.capacity = next_pow2(std::max<uint64_t>(2 * want, 1024));
-  TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, err));
+  TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, ds.wide, err));
   HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));
   launch_bitmap_to_hash(bitmap_view(ds), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
                         st->stream);
@@ -677,6 +682,21 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
+  if (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) {
+    // values are reduced to 128-bit fingerprints on the fly (kernels/distinct128.hip)
+    ds.col_type = c.type;
+    ds.total_rows += c.length;
+    if (c.length == 0) return TGX_OK;
+    if (ds.mode == DistinctMode::kUndecided) {
+      ds.mode = DistinctMode::kHash;
+      ds.wide = true;
+    }
+    TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
+    ProfScope ps(st, "distinct", 0);
+    launch_distinct_utf8(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, mult ? 1 : 0,
+                         hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+    return TGX_OK;
+  }
   if (!is_numeric(c.type))
     return fail(err, TGX_UNSUPPORTED, "DISTINCT on column type %d is not supported yet", c.type);
   ds.col_type = c.type;
@@ -1106,6 +1126,15 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
         if (b.count_src == Source::kScan) {
           r->total = g.scan[b.slot].total;
           r->non_null = g.scan[b.slot].non_null;
+          // a scan task that only exists for DISTINCT's range decision does not run on Utf8 columns:
+          // there the distinct kernel has counted the non-NULL rows
+          const int col = plan->scan[b.slot].column;
+          if (g.scan[b.slot].total == 0)
+            for (size_t d = 0; d < plan->distinct.size(); d++)
+              if (plan->distinct[d].column == col && g.distinct[d].total > 0) {
+                r->total = (int64_t)g.distinct[d].total;
+                r->non_null = (int64_t)g.distinct[d].non_null;
+              }
         } else {
           r->total = g.count[b.slot].total;
           r->non_null = g.count[b.slot].non_null;
@@ -1165,7 +1194,9 @@ static tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t worl
   unsigned long long *d_counts = ds.export_counts.as<unsigned long long>();
   unsigned long long *d_cursors = d_counts + world;
   HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * world * sizeof(unsigned long long), st->stream));
-  if (ds.mode == DistinctMode::kHash)
+  if (ds.mode == DistinctMode::kHash && ds.wide)
+    launch_hash_export_count128(hash_view(ds), world, d_counts, st->stream);
+  else if (ds.mode == DistinctMode::kHash)
     launch_hash_export_count(hash_view(ds), world, d_counts, st->stream);
   else if (ds.mode == DistinctMode::kBitmap)
     launch_bitmap_export_count(bitmap_view(ds), world, d_counts, st->stream);
@@ -1187,10 +1218,14 @@ static tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t worl
     total += h_counts[r];
   }
   (void)n_keys;
-  HIP_TRY(ds.export_records.reserve(std::max<uint64_t>(total, 1) * sizeof(KeyRecord)));
+  const size_t rec_bytes = ds.wide ? sizeof(KeyRecord128) : sizeof(KeyRecord);
+  HIP_TRY(ds.export_records.reserve(std::max<uint64_t>(total, 1) * rec_bytes));
   HIP_TRY(hipMemcpyAsync(d_cursors, starts.data(), world * sizeof(unsigned long long), hipMemcpyHostToDevice, st->stream));
   HIP_TRY(hipStreamSynchronize(st->stream));
-  if (ds.mode == DistinctMode::kHash)
+  if (ds.mode == DistinctMode::kHash && ds.wide)
+    launch_hash_export_scatter128(hash_view(ds), world, mult ? 1 : 0, d_cursors, ds.export_records.as<KeyRecord128>(),
+                                  st->stream);
+  else if (ds.mode == DistinctMode::kHash)
     launch_hash_export_scatter(hash_view(ds), world, mult ? 1 : 0, d_cursors, ds.export_records.as<KeyRecord>(), st->stream);
   else if (ds.mode == DistinctMode::kBitmap)
     launch_bitmap_export_scatter(bitmap_view(ds), world, mult ? 1 : 0, d_cursors, ds.export_records.as<KeyRecord>(), st->stream);
@@ -1205,6 +1240,15 @@ static tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t worl
   return TGX_OK;
 }
 
+extern "C" size_t tgx_distinct_record_bytes(const tgx_plan *plan, const tgx_state *st, size_t spec_index) {
+  if (!plan || !st || st->plan != plan || spec_index >= plan->specs.size() ||
+      plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
+    return 0;
+  const DistinctState &ds = st->distinct[plan->bind[spec_index].slot];
+  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8;
+  return wide ? sizeof(KeyRecord128) : sizeof(KeyRecord);
+}
+
 extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                           uint32_t world, const void **device_records, uint64_t *counts,
                                           tgx_error *err) {
@@ -1217,16 +1261,24 @@ extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, s
 }
 
 // union `n` device records into the state's set (switching it to hash mode)
-static tgx_status distinct_import_records(tgx_state *st, size_t slot, const KeyRecord *d_recs, uint64_t n,
+static tgx_status distinct_import_records(tgx_state *st, size_t slot, const void *d_recs, uint64_t n, bool wide,
                                           tgx_error *err) {
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;
   TGX_TRY(state_init_device(st, err));
   if (ds.mode == DistinctMode::kBitmap) TGX_TRY(bitmap_to_hash(st, ds, mult, n, err));
+  if (ds.mode == DistinctMode::kHash && ds.capacity > 0 && ds.wide != wide)
+    return fail(err, TGX_INVALID_ARGUMENT, "distinct: cannot unite a Utf8 key set with a numeric one");
   ds.mode = DistinctMode::kHash;
+  ds.wide = wide;
   TGX_TRY(hash_ensure(st, ds, mult, n, err));
   // the EMPTY stand-in's rows arrive through counters[2]; [5] is scratch
-  launch_hash_import(d_recs, n, hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(), st->stream);
+  if (wide)
+    launch_hash_import128((const KeyRecord128 *)d_recs, n, hash_view(ds), mult ? 1 : 0,
+                          ds.counters.as<unsigned long long>(), st->stream);
+  else
+    launch_hash_import((const KeyRecord *)d_recs, n, hash_view(ds), mult ? 1 : 0,
+                       ds.counters.as<unsigned long long>(), st->stream);
   return TGX_OK;
 }
 
@@ -1243,6 +1295,7 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   unsigned long long c[kNumDistinctCounters];
   TGX_TRY(distinct_read_counters(st, ds, c, err));
   const unsigned long long valid_rows = c[kCntValidRows];
+  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8;
   ds.seen.release();
   ds.twice.release();
   ds.keys.release();
@@ -1254,7 +1307,7 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   memset(zero, 0, sizeof(zero));
   zero[kCntValidRows] = valid_rows;
   HIP_TRY(hipMemcpy(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice));
-  TGX_TRY(distinct_import_records(st, slot, (const KeyRecord *)device_records, n_records, err));
+  TGX_TRY(distinct_import_records(st, slot, device_records, n_records, wide, err));
   HIP_TRY(hipStreamSynchronize(st->stream));
   ds.partitioned = true;
   return TGX_OK;
@@ -1302,7 +1355,7 @@ extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state 
         uint64_t cnt = 0;
         TGX_TRY(distinct_export_impl(src, k, 1, &recs, &cnt, err));
         TGX_TRY(state_init_device(dst, err));
-        TGX_TRY(distinct_import_records(dst, k, (const KeyRecord *)recs, cnt, err));
+        TGX_TRY(distinct_import_records(dst, k, recs, cnt, s.wide, err));
         HIP_TRY(hipStreamSynchronize(dst->stream));
         d.h_total += (uint64_t)s.total_rows + s.h_total;
         unsigned long long c[kNumDistinctCounters];
@@ -1379,7 +1432,7 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
     const bool has_set = ds.mode == DistinctMode::kBitmap || ds.mode == DistinctMode::kHash;
     uint32_t partitioned = (ds.partitioned || !has_set) ? 1 : 0;
     w.pod(partitioned);
-    w.pod((uint32_t)0);
+    w.pod((uint32_t)(ds.wide ? 1 : 0));
     w.pod(t);
     uint64_t n_records = 0;
     if (!partitioned) {
@@ -1387,7 +1440,7 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
       const void *recs = nullptr;
       TGX_TRY(distinct_export_impl(st, k, 1, &recs, &n_records, err));
       w.pod(n_records);
-      size_t bytes = (size_t)n_records * sizeof(KeyRecord);
+      size_t bytes = (size_t)n_records * (ds.wide ? sizeof(KeyRecord128) : sizeof(KeyRecord));
       if (w.buf && w.len + bytes <= w.cap)
         HIP_TRY(hipMemcpy(w.buf + w.len, recs, bytes, hipMemcpyDeviceToHost));
       w.len += bytes;
@@ -1422,7 +1475,7 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
   for (size_t k = 0; k < n_dist; k++) {
     DistinctState &ds = st->distinct[k];
     uint32_t partitioned = r.pod<uint32_t>();
-    (void)r.pod<uint32_t>();
+    const bool wide = r.pod<uint32_t>() != 0;
     DistinctTotals t = r.pod<DistinctTotals>();
     uint64_t n_records = r.pod<uint64_t>();
     if (!r.ok) break;
@@ -1435,7 +1488,7 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
       ds.h_empty_rows = t.empty_rows;
     } else {
       // rebuild the key set on the device from the records
-      size_t bytes = (size_t)n_records * sizeof(KeyRecord);
+      size_t bytes = (size_t)n_records * (wide ? sizeof(KeyRecord128) : sizeof(KeyRecord));
       if (r.pos + bytes > r.len) {
         r.ok = false;
         break;
@@ -1448,7 +1501,7 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
       HIP_TRY(tmp.reserve(std::max<size_t>(bytes, 16)));
       HIP_TRY(hipMemcpy(tmp.p, r.buf + r.pos, bytes, hipMemcpyHostToDevice));
       r.pos += bytes;
-      s = distinct_import_records(st.get(), k, tmp.as<KeyRecord>(), n_records, err);
+      s = distinct_import_records(st.get(), k, tmp.p, n_records, wide, err);
       if (s != TGX_OK) return s;
       HIP_TRY(hipStreamSynchronize(st->stream));
       ds.h_total = t.total;

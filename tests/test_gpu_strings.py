@@ -1,0 +1,135 @@
+"""-m gpu: COUNT(DISTINCT) / value-count checks on Utf8 columns (128-bit fingerprint sets) vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+import term_amd as T
+from _lib_spec import spec
+from gpu_util import run_plan
+from test_gpu_regex import utf8_column
+
+pytestmark = pytest.mark.gpu
+
+
+def check(res, d):
+    assert (res.total, res.non_null, res.distinct, res.groups_once) == (d.total, d.non_null, d.distinct, d.groups_once)
+
+
+def test_reference_uniqueness_vectors(golden):
+    """constraints/uniqueness.rs:907-1070 (all on Utf8 columns) through the HIP path"""
+    for case in golden["uniqueness"]:
+        vals = case["values"]
+        if not vals:
+            continue
+        offs, data, validity = orc.utf8_from_list(vals)
+        res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)],
+                             [[utf8_column(offs, data, validity, False)]])
+        r, n = res[0], len(vals)
+        kind = case["kind"]
+        if kind in ("full_uniqueness", "distinctness"):
+            assert r.distinct / n == case["metric"], case["ref"]
+        elif kind == "unique_value_ratio":
+            assert r.groups_once / n == case["metric"], case["ref"]
+        elif kind == "unique_with_nulls_include":
+            assert (r.distinct + (1 if r.non_null < n else 0)) / n == case["metric"], case["ref"]
+        elif kind == "primary_key":
+            nulls = n - r.non_null
+            if "NULL" in case.get("message_contains", ""):
+                assert nulls > 0
+            elif "duplicate" in case.get("message_contains", ""):
+                assert nulls == 0 and r.distinct != n
+            else:
+                assert nulls == 0 and r.distinct == n
+    a = golden["analyzers"]["table"]["name"]
+    offs, data, validity = orc.utf8_from_list(a)
+    res, _, _ = run_plan([spec(T.DISTINCT, 0)], [[utf8_column(offs, data, validity, False)]])
+    assert (res[0].non_null, res[0].distinct) == (4, 3)  # analyzers/basic/tests.rs:116-128
+
+
+def make_strings(rng, n, card):
+    keys = rng.integers(0, card, size=n)
+    vals = []
+    for i, k in enumerate(keys):
+        r = k % 7
+        if r == 0:
+            vals.append("k%d" % k)
+        elif r == 1:
+            vals.append("user-%d@example.com" % k)
+        elif r == 2:
+            vals.append("x" * (k % 50) + str(k))
+        elif r == 3:
+            vals.append("Ünï-%d-ß" % k)
+        elif r == 4:
+            vals.append("" if k % 11 == 4 else "e%d" % k)
+        elif r == 5:
+            vals.append(None if i % 3 == 0 else "n%d" % k)
+        else:
+            vals.append("a much longer value that spans several eight byte words %d" % k)
+    return vals
+
+
+@pytest.mark.parametrize("n,card", [(1000, 50), (200_000, 30_000), (300_000, 10**9)])
+def test_seeded_strings(n, card):
+    rng = np.random.default_rng(n + card % 1000)
+    vals = make_strings(rng, n, card)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.distinct_utf8(offs, data, validity)
+    for large in (False, True):
+        res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.COUNT, 0)],
+                             [[utf8_column(offs, data, validity, True, large=large)]])
+        check(res[0], want)
+        assert res[1].non_null == want.non_null
+
+
+def test_same_value_at_every_alignment_hashes_equal():
+    """the fingerprint reads aligned 8-byte words; it must not depend on where a value sits in memory"""
+    vals = []
+    for pad in range(9):
+        vals.append("p" * pad)              # shifts the alignment of what follows
+        vals.append("the-same-value-0123456789")
+    offs, data, validity = orc.utf8_from_list(vals)
+    res, _, _ = run_plan([spec(T.DISTINCT, 0)], [[utf8_column(offs, data, validity, True)]])
+    assert res[0].distinct == orc.distinct_utf8(offs, data, validity).distinct == 10
+
+
+def test_batches_merge_serialize_and_exchange():
+    import torch
+
+    rng = np.random.default_rng(3)
+    n = 120_000
+    vals = make_strings(rng, n, 40_000)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.distinct_utf8(offs, data, validity)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)])
+    cuts = [0, 30_000, 30_001, 90_000, n]
+    states = [T.State(plan), T.State(plan)]
+    for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        states[i % 2].update([utf8_column(offs, data, validity, True, offset=lo, length=hi - lo)])
+    # (1) exact union through serialize -> deserialize -> merge
+    a = T.State.deserialize(plan, states[0].serialize())
+    a.merge([T.State.deserialize(plan, states[1].serialize())])
+    check(a.finalize()[0], want)
+    # (2) hash-owner exchange between the two "ranks", then count-only merge
+    assert states[0].distinct_record_bytes(0) == 32
+    world, exported = 2, []
+    for st in states:
+        ptr, counts = st.distinct_export(0, world)
+        total = sum(counts)
+
+        class P:
+            __cuda_array_interface__ = {"shape": (max(total, 1) * 32,), "typestr": "|u1", "data": (ptr, False),
+                                        "version": 2}
+
+        recs = torch.as_tensor(P(), device="cuda")[: total * 32].clone()
+        exported.append((recs, counts))
+    for r in range(world):
+        parts = []
+        for recs, counts in exported:
+            start = sum(counts[:r])
+            parts.append(recs[32 * start: 32 * (start + counts[r])])
+        mine = torch.cat(parts).contiguous()
+        torch.cuda.synchronize()
+        states[r].distinct_import(0, mine.data_ptr(), mine.numel() // 32)
+    states[0].merge([states[1]])
+    check(states[0].finalize()[0], want)
