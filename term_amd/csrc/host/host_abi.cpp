@@ -1,0 +1,217 @@
+// host_abi.cpp -- the C bridge of include/tgx_host.h over host/term_guard.{h,cpp}.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/tgx_host.h"
+#include "json.h"
+#include "term_guard.h"
+
+using namespace term_guard;
+
+namespace term_guard {
+void add_constraint_from_json(Check::Builder &b, const json::Value &c);
+}
+
+static tgx_status hfail(tgx_error *err, tgx_status code, const std::string &msg) {
+  if (err) {
+    err->code = code;
+    snprintf(err->msg, sizeof(err->msg), "%s", msg.c_str());
+  }
+  return code;
+}
+
+static char *dup_string(const std::string &s) {
+  char *p = (char *)malloc(s.size() + 1);
+  if (p) memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+extern "C" void tgx_host_free(char *s) { free(s); }
+
+extern "C" tgx_status tgx_host_run_suite_json(const char *suite_json, const char *const *column_names,
+                                              size_t n_columns, const tgx_column *columns, size_t n_batches,
+                                              char **out_json, tgx_error *err) {
+  if (!suite_json || !out_json || (n_columns && (!column_names || (n_batches && !columns))))
+    return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  *out_json = nullptr;
+  try {
+    ValidationSuite suite = suite_from_json(suite_json);
+    Table t;
+    for (size_t i = 0; i < n_columns; i++) t.column_names.push_back(column_names[i]);
+    for (size_t b = 0; b < n_batches; b++) {
+      Batch batch;
+      batch.columns.assign(columns + b * n_columns, columns + (b + 1) * n_columns);
+      t.batches.push_back(std::move(batch));
+    }
+    Context ctx;
+    if (n_columns > 0) ctx.register_table(suite.table_name(), std::move(t));
+    ValidationResult r = suite.run(ctx);
+    *out_json = dup_string(r.to_json());
+    return TGX_OK;
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  }
+}
+
+static std::shared_ptr<Constraint> constraint_from_json_text(const char *text) {
+  json::Value v;
+  std::string perr;
+  if (!json::parse(text, &v, &perr)) throw TermError{TermError::Internal, "constraint JSON: " + perr};
+  Check::Builder b = Check::builder("c");
+  add_constraint_from_json(b, v);
+  Check c = b.build();
+  return c.constraints().at(0);
+}
+
+extern "C" tgx_status tgx_host_constraint_plan_json(const char *constraint_json, char **out_json, tgx_error *err) {
+  if (!constraint_json || !out_json) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  *out_json = nullptr;
+  try {
+    auto c = constraint_from_json_text(constraint_json);
+    std::string o = "{\"name\": " + json::quote(c->name()) + ", \"requests\": [";
+    auto reqs = c->plan();
+    for (size_t i = 0; i < reqs.size(); i++) {
+      const SpecRequest &r = reqs[i];
+      if (i) o += ", ";
+      o += "{\"kind\": " + std::to_string(r.kind) + ", \"column\": " + json::quote(r.column) + ", \"column2\": " +
+           json::quote(r.column2) + ", \"flags\": " + std::to_string(r.flags) + ", \"pattern\": " + json::quote(r.pattern) +
+           ", \"kll_k\": " + std::to_string(r.kll_k) + "}";
+    }
+    o += "]}";
+    *out_json = dup_string(o);
+    return TGX_OK;
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  }
+}
+
+namespace {
+struct FakeQuantiles {
+  std::vector<std::vector<std::pair<double, double>>> per_request;
+};
+double fake_quantile(const void *ctx, size_t idx, double phi) {
+  const FakeQuantiles *f = (const FakeQuantiles *)ctx;
+  for (auto &kv : f->per_request.at(idx))
+    if (kv.first == phi) return kv.second;
+  throw TermError{TermError::Internal, "results_json has no quantile for phi=" + rust_f64(phi)};
+}
+}  // namespace
+
+extern "C" tgx_status tgx_host_constraint_verdict_json(const char *constraint_json, const char *results_json,
+                                                       char **out_json, tgx_error *err) {
+  if (!constraint_json || !results_json || !out_json) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  *out_json = nullptr;
+  try {
+    auto c = constraint_from_json_text(constraint_json);
+    json::Value rv;
+    std::string perr;
+    if (!json::parse(results_json, &rv, &perr) || !rv.is(json::Value::Array))
+      return hfail(err, TGX_INVALID_ARGUMENT, "results JSON must be an array: " + perr);
+    std::vector<tgx_result> results(rv.arr.size());
+    FakeQuantiles fq;
+    fq.per_request.resize(rv.arr.size());
+    for (size_t i = 0; i < rv.arr.size(); i++) {
+      const json::Value &o = rv.arr[i];
+      tgx_result &r = results[i];
+      memset(&r, 0, sizeof(r));
+      r.is_float = (int32_t)o.get_num("is_float");
+      r.total = (int64_t)o.get_num("total");
+      r.non_null = (int64_t)o.get_num("non_null");
+      r.has_value = (int32_t)o.get_num("has_value");
+      r.has_variance = (int32_t)o.get_num("has_variance");
+      r.min_i = (int64_t)o.get_num("min_i");
+      r.max_i = (int64_t)o.get_num("max_i");
+      r.min_f = o.get_num("min_f");
+      r.max_f = o.get_num("max_f");
+      r.sum_i = (int64_t)o.get_num("sum_i");
+      r.sum_f = o.get_num("sum_f");
+      r.mean = o.get_num("mean");
+      r.var_samp = o.get_num("var_samp");
+      r.stddev_samp = o.get_num("stddev_samp");
+      r.distinct = (int64_t)o.get_num("distinct");
+      r.groups_once = (int64_t)o.get_num("groups_once");
+      r.matches = (int64_t)o.get_num("matches");
+      r.sum_x = o.get_num("sum_x");
+      r.sum_y = o.get_num("sum_y");
+      r.sum_x2 = o.get_num("sum_x2");
+      r.sum_y2 = o.get_num("sum_y2");
+      r.sum_xy = o.get_num("sum_xy");
+      r.kll_n = (uint64_t)o.get_num("kll_n");
+      if (const json::Value *q = o.get("quantiles"))
+        for (auto &kv : q->obj) fq.per_request[i].emplace_back(atof(kv.first.c_str()), kv.second.num);
+    }
+    const size_t want = c->plan().size();
+    if (results.size() != want)
+      return hfail(err, TGX_INVALID_ARGUMENT,
+                   "constraint plans " + std::to_string(want) + " aggregates, got " + std::to_string(results.size()));
+    Constraint::Inputs in;
+    for (auto &r : results) in.results.push_back(&r);
+    in.ctx = &fq;
+    in.quantile = fake_quantile;
+    ConstraintResult cr = c->evaluate(in);
+    const char *st = cr.status == ConstraintStatus::Success ? "success" : cr.status == ConstraintStatus::Failure ? "failure" : "skipped";
+    std::string o = std::string("{\"status\": \"") + st + "\", \"metric\": ";
+    if (cr.metric && !std::isnan(*cr.metric) && !std::isinf(*cr.metric)) {
+      char buf[64];
+      snprintf(buf, sizeof(buf), "%.17g", *cr.metric);
+      o += buf;
+    } else {
+      o += "null";
+    }
+    o += ", \"message\": " + (cr.message ? json::quote(*cr.message) : std::string("null")) + ", \"name\": " +
+         json::quote(c->name()) + "}";
+    *out_json = dup_string(o);
+    return TGX_OK;
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  }
+}
+
+extern "C" tgx_status tgx_host_validate_identifier(const char *identifier, tgx_error *err) {
+  if (!identifier) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  auto e = validate_identifier(identifier);
+  if (e) return hfail(err, TGX_INVALID_ARGUMENT, e->display());
+  return TGX_OK;
+}
+
+namespace term_guard {
+ValidationSuite suite_from_json(const std::string &text);
+}
+
+extern "C" tgx_status tgx_host_assertion_json(const char *assertion_json, double value, int32_t *holds,
+                                              char **description, tgx_error *err) {
+  if (!assertion_json) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  try {
+    // reuse the constraint parser: wrap the assertion into a size constraint
+    std::string wrapped = std::string("{\"type\": \"size\", \"assertion\": ") + assertion_json + "}";
+    auto c = constraint_from_json_text(wrapped.c_str());
+    tgx_result r;
+    memset(&r, 0, sizeof(r));
+    // evaluate through Size: metric == total; only exact for integral values, so parse the assertion directly too
+    json::Value v;
+    std::string perr;
+    json::parse(assertion_json, &v, &perr);
+    Assertion a = Assertion::equals(0);
+    const std::string k = v.get_str("kind");
+    const json::Value *args = v.get("args");
+    auto arg = [&](size_t i) { return args && args->arr.size() > i ? args->arr[i].num : 0.0; };
+    if (k == "equals") a = Assertion::equals(arg(0));
+    else if (k == "not_equals") a = Assertion::not_equals(arg(0));
+    else if (k == "greater_than") a = Assertion::greater_than(arg(0));
+    else if (k == "greater_than_or_equal") a = Assertion::greater_than_or_equal(arg(0));
+    else if (k == "less_than") a = Assertion::less_than(arg(0));
+    else if (k == "less_than_or_equal") a = Assertion::less_than_or_equal(arg(0));
+    else if (k == "between") a = Assertion::between(arg(0), arg(1));
+    else if (k == "not_between") a = Assertion::not_between(arg(0), arg(1));
+    if (holds) *holds = a.evaluate(value) ? 1 : 0;
+    if (description) *description = dup_string(a.description());
+    return TGX_OK;
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  }
+}

@@ -1,0 +1,423 @@
+"""Python face of the host-side mirror of term-guard's builder API (term_amd/csrc/host/term_guard.h).
+
+Same names and argument meaning as the reference (core/check.rs, core/suite.rs, constraints/assertion.rs,
+core/builder_extensions.rs); a suite is serialised to the JSON of include/tgx_host.h and run by libtgx:
+
+    suite = (ValidationSuite.builder("users").table_name("users")
+             .check(Check.builder("required").level(Level.ERROR)
+                    .completeness("user_id", CompletenessOptions.full())
+                    .has_min("age", Assertion.GreaterThanOrEqual(0.0)).build())
+             .build())
+    result = suite.run({"user_id": col, "age": col})     # dict of term_amd.Column, or a pyarrow Table
+    result.is_success(), result.report.issues, result.to_json()
+"""
+import ctypes as C
+import json
+
+from . import _lib
+from ._lib import Column, TgxError, _Column, _Error
+
+
+class Level:
+    INFO, WARNING, ERROR = "info", "warning", "error"
+    Info, Warning, Error = INFO, WARNING, ERROR
+
+
+class Assertion:
+    """constraints/assertion.rs:27-46"""
+
+    def __init__(self, kind, *args):
+        self.kind, self.args = kind, [float(a) for a in args]
+
+    @staticmethod
+    def Equals(v): return Assertion("equals", v)
+    @staticmethod
+    def NotEquals(v): return Assertion("not_equals", v)
+    @staticmethod
+    def GreaterThan(v): return Assertion("greater_than", v)
+    @staticmethod
+    def GreaterThanOrEqual(v): return Assertion("greater_than_or_equal", v)
+    @staticmethod
+    def LessThan(v): return Assertion("less_than", v)
+    @staticmethod
+    def LessThanOrEqual(v): return Assertion("less_than_or_equal", v)
+    @staticmethod
+    def Between(lo, hi): return Assertion("between", lo, hi)
+    @staticmethod
+    def NotBetween(lo, hi): return Assertion("not_between", lo, hi)
+
+    def to_json(self):
+        return {"kind": self.kind, "args": self.args}
+
+    def evaluate(self, value):
+        holds = C.c_int32()
+        err = _Error()
+        _host_check(_host().tgx_host_assertion_json(json.dumps(self.to_json()).encode(), float(value), C.byref(holds),
+                                                    None, C.byref(err)), err)
+        return bool(holds.value)
+
+    def description(self):
+        out = C.c_char_p()
+        err = _Error()
+        _host_check(_host().tgx_host_assertion_json(json.dumps(self.to_json()).encode(), 0.0, None, C.byref(out),
+                                                    C.byref(err)), err)
+        return _take(out)
+
+    __str__ = description
+
+
+class LogicalOperator:
+    """core/logical.rs:32-45"""
+    All, Any = "all", "any"
+
+    @staticmethod
+    def Exactly(n): return {"exactly": int(n)}
+    @staticmethod
+    def AtLeast(n): return {"at_least": int(n)}
+    @staticmethod
+    def AtMost(n): return {"at_most": int(n)}
+
+
+class CompletenessOptions:
+    """core/builder_extensions.rs:14-80"""
+
+    def __init__(self, threshold=1.0, operator=LogicalOperator.All):
+        self.threshold_, self.operator_ = threshold, operator
+
+    @staticmethod
+    def full(): return CompletenessOptions(1.0)
+    @staticmethod
+    def threshold(t): return CompletenessOptions(t)
+    @staticmethod
+    def at_least(n): return CompletenessOptions(1.0, LogicalOperator.AtLeast(n))
+    @staticmethod
+    def any(): return CompletenessOptions(1.0, LogicalOperator.Any)
+
+    def with_operator(self, op):
+        self.operator_ = op
+        return self
+
+
+class ConstraintOptions(CompletenessOptions):
+    """core/unified.rs:131-191"""
+
+    @staticmethod
+    def new(): return ConstraintOptions()
+
+    def with_threshold(self, t):
+        self.threshold_ = t
+        return self
+
+
+class FormatOptions:
+    """constraints/format.rs:367-470"""
+
+    def __init__(self, case_sensitive=True, trim_before_check=False, null_is_valid=True):
+        self.case_sensitive_, self.trim_, self.null_is_valid_ = case_sensitive, trim_before_check, null_is_valid
+
+    @staticmethod
+    def new(): return FormatOptions()
+    @staticmethod
+    def case_insensitive(): return FormatOptions(case_sensitive=False)
+    @staticmethod
+    def strict(): return FormatOptions(null_is_valid=False)
+    @staticmethod
+    def lenient(): return FormatOptions(False, True, True)
+    @staticmethod
+    def with_trimming(): return FormatOptions(trim_before_check=True)
+
+    def case_sensitive(self, v):
+        self.case_sensitive_ = v
+        return self
+
+    def trim_before_check(self, v):
+        self.trim_ = v
+        return self
+
+    def null_is_valid(self, v):
+        self.null_is_valid_ = v
+        return self
+
+    def to_json(self):
+        return {"case_sensitive": self.case_sensitive_, "trim_before_check": self.trim_,
+                "null_is_valid": self.null_is_valid_}
+
+
+class NullHandling:
+    Exclude, Include, Distinct = "exclude", "include", "distinct"
+
+
+def _cols(columns):
+    return [columns] if isinstance(columns, str) else list(columns)
+
+
+class CheckBuilder:
+    """core/check.rs:217-2310 (the hot-path subset listed in SURVEY.md section 8a)"""
+
+    def __init__(self, name):
+        self._c = {"name": name, "level": Level.WARNING, "constraints": []}
+
+    def level(self, level):
+        self._c["level"] = level
+        return self
+
+    def description(self, d):
+        self._c["description"] = d
+        return self
+
+    def _add(self, **kw):
+        self._c["constraints"].append(kw)
+        return self
+
+    def has_size(self, assertion):
+        return self._add(type="size", assertion=assertion.to_json())
+
+    def completeness(self, columns, options=None):
+        o = options or CompletenessOptions.full()
+        return self._add(type="completeness", columns=_cols(columns), operator=o.operator_, threshold=o.threshold_)
+
+    def any_complete(self, columns):
+        return self._add(type="completeness", columns=_cols(columns), operator="any", threshold=1.0)
+
+    def at_least_complete(self, n, columns, threshold):
+        return self._add(type="completeness", columns=_cols(columns), operator={"at_least": n}, threshold=threshold)
+
+    def exactly_complete(self, n, columns, threshold):
+        return self._add(type="completeness", columns=_cols(columns), operator={"exactly": n}, threshold=threshold)
+
+    def statistic(self, column, statistic, assertion, p=0.5):
+        return self._add(type="statistic", column=column, statistic=statistic, p=p, assertion=assertion.to_json())
+
+    def has_min(self, column, assertion): return self.statistic(column, "min", assertion)
+    def has_max(self, column, assertion): return self.statistic(column, "max", assertion)
+    def has_mean(self, column, assertion): return self.statistic(column, "mean", assertion)
+    def has_sum(self, column, assertion): return self.statistic(column, "sum", assertion)
+    def has_standard_deviation(self, column, assertion): return self.statistic(column, "standard_deviation", assertion)
+    def has_variance(self, column, assertion): return self.statistic(column, "variance", assertion)
+
+    def uniqueness(self, columns, kind, threshold=1.0, assertion=None, null_handling=NullHandling.Exclude):
+        kw = dict(type="uniqueness", columns=_cols(columns), kind=kind, threshold=threshold, null_handling=null_handling)
+        if assertion is not None:
+            kw["assertion"] = assertion.to_json()
+        return self._add(**kw)
+
+    def validates_uniqueness(self, columns, threshold): return self.uniqueness(columns, "full_uniqueness", threshold)
+    def validates_distinctness(self, columns, assertion): return self.uniqueness(columns, "distinctness", assertion=assertion)
+    def validates_unique_value_ratio(self, columns, assertion):
+        return self.uniqueness(columns, "unique_value_ratio", assertion=assertion)
+    def validates_primary_key(self, columns): return self.uniqueness(columns, "primary_key")
+    def validates_uniqueness_with_nulls(self, columns, threshold, null_handling):
+        return self.uniqueness(columns, "unique_with_nulls", threshold, null_handling=null_handling)
+
+    def primary_key(self, columns):
+        return self.completeness(columns, CompletenessOptions.full()).validates_uniqueness(columns, 1.0)
+
+    def has_format(self, column, fmt, threshold, options=None, **kw):
+        return self._add(type="format", column=column, format=fmt, threshold=threshold,
+                         options=(options or FormatOptions()).to_json(), **kw)
+
+    def validates_regex(self, column, pattern, threshold): return self.has_format(column, "regex", threshold, pattern=pattern)
+    def validates_regex_with_options(self, column, pattern, threshold, options):
+        return self.has_format(column, "regex", threshold, options, pattern=pattern)
+    def validates_email(self, column, threshold): return self.has_format(column, "email", threshold)
+    def validates_url(self, column, threshold, allow_localhost=False):
+        return self.has_format(column, "url", threshold, allow_localhost=allow_localhost)
+    def validates_credit_card(self, column, threshold, detect_only=False):
+        return self.has_format(column, "credit_card", threshold, detect_only=detect_only)
+    def validates_phone(self, column, threshold, country=None):
+        kw = {"country": country} if country else {}
+        return self.has_format(column, "phone", threshold, FormatOptions.with_trimming(), **kw)
+    def validates_postal_code(self, column, threshold, country):
+        return self.has_format(column, "postal_code", threshold, FormatOptions.with_trimming(), country=country)
+    def validates_uuid(self, column, threshold): return self.has_format(column, "uuid", threshold)
+    def validates_ipv4(self, column, threshold): return self.has_format(column, "ipv4", threshold)
+    def validates_ipv6(self, column, threshold): return self.has_format(column, "ipv6", threshold)
+    def validates_json(self, column, threshold): return self.has_format(column, "json", threshold)
+    def validates_iso8601_datetime(self, column, threshold): return self.has_format(column, "iso8601_datetime", threshold)
+    def email(self, column, threshold): return self.has_format(column, "email", threshold, FormatOptions(True, True, False))
+    def contains_ssn(self, column, threshold):
+        return self.has_format(column, "social_security_number", threshold, FormatOptions.with_trimming())
+
+    def has_approx_quantile(self, column, quantile, assertion):
+        return self._add(type="quantile", column=column, quantile=quantile, assertion=assertion.to_json())
+
+    def has_correlation(self, column1, column2, assertion):
+        return self._add(type="correlation", column1=column1, column2=column2, assertion=assertion.to_json())
+
+    def build(self):
+        return Check(self._c)
+
+
+class Check:
+    def __init__(self, spec):
+        self.spec = spec
+
+    @staticmethod
+    def builder(name):
+        return CheckBuilder(name)
+
+    def name(self): return self.spec["name"]
+    def level(self): return self.spec["level"]
+
+
+class Issue:
+    def __init__(self, d):
+        self.check_name, self.constraint_name = d["check_name"], d["constraint_name"]
+        self.level, self.message, self.metric = d["level"], d["message"], d.get("metric")
+
+
+class Metrics:
+    def __init__(self, d):
+        self.total_checks, self.passed_checks = d["total_checks"], d["passed_checks"]
+        self.failed_checks, self.skipped_checks = d["failed_checks"], d["skipped_checks"]
+        self.execution_time_ms, self.custom_metrics = d["execution_time_ms"], d.get("custom_metrics", {})
+
+
+class Report:
+    def __init__(self, d):
+        self.suite_name, self.timestamp = d["suite_name"], d["timestamp"]
+        self.metrics = Metrics(d["metrics"])
+        self.issues = [Issue(i) for i in d["issues"]]
+
+    def has_errors(self): return any(i.level == Level.ERROR for i in self.issues)
+    def has_warnings(self): return any(i.level == Level.WARNING for i in self.issues)
+
+
+class ValidationResult:
+    """core/result.rs:123-196"""
+
+    def __init__(self, text):
+        self._json = text
+        d = json.loads(text)
+        self.status = d["status"]
+        self.report = Report(d["report"])
+
+    def is_success(self): return self.status == "success"
+    def is_failure(self): return self.status == "failure"
+    def metrics(self): return self.report.metrics if self.is_success() else None
+    def to_json(self): return self._json
+
+
+class ValidationSuiteBuilder:
+    def __init__(self, name):
+        self._s = {"name": name, "table_name": "data", "checks": []}
+
+    def description(self, d):
+        self._s["description"] = d
+        return self
+
+    def table_name(self, t):
+        self._s["table_name"] = t
+        return self
+
+    def check(self, c):
+        self._s["checks"].append(c.spec)
+        return self
+
+    def with_optimizer(self, _enabled):
+        return self
+
+    def build(self):
+        return ValidationSuite(self._s)
+
+
+def _arrow_batches(table):
+    """pyarrow Table / RecordBatch -> (names, [[Column, ...] per batch])"""
+    import pyarrow as pa
+
+    if isinstance(table, pa.RecordBatch):
+        table = pa.Table.from_batches([table])
+    names = table.column_names
+    batches = []
+    for rb in table.to_batches():
+        batches.append([Column.from_arrow(rb.column(i)) for i in range(rb.num_columns)])
+    if not batches:
+        batches = []
+    return names, batches
+
+
+class ValidationSuite:
+    def __init__(self, spec):
+        self.spec = spec
+
+    @staticmethod
+    def builder(name):
+        return ValidationSuiteBuilder(name)
+
+    def name(self): return self.spec["name"]
+
+    def run(self, table):
+        """table: dict name -> term_amd.Column (one batch), a list of such dicts (batches), a pyarrow Table /
+        RecordBatch, or None (no table registered)."""
+        if table is None:
+            names, batches = [], []
+        elif isinstance(table, dict):
+            names, batches = list(table.keys()), [list(table.values())]
+        elif isinstance(table, (list, tuple)):
+            names = list(table[0].keys()) if table else []
+            batches = [[b[n] for n in names] for b in table]
+        else:
+            names, batches = _arrow_batches(table)
+        n_cols, n_batches = len(names), len(batches)
+        name_arr = (C.c_char_p * max(1, n_cols))(*[n.encode() for n in names])
+        flat = [c.c for b in batches for c in b]
+        col_arr = (_Column * max(1, len(flat)))(*flat)
+        out = C.c_char_p()
+        err = _Error()
+        _host_check(_host().tgx_host_run_suite_json(json.dumps(self.spec).encode(), name_arr, n_cols, col_arr,
+                                                    n_batches, C.byref(out), C.byref(err)), err)
+        return ValidationResult(_take(out))
+
+
+# ---------------------------------------------------------------------------------------------- bridge
+_HOST = None
+
+
+def _host():
+    global _HOST
+    if _HOST is None:
+        L = _lib.lib()
+        E = C.POINTER(_Error)
+        L.tgx_host_run_suite_json.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(_Column),
+                                              C.c_size_t, C.POINTER(C.c_char_p), E]
+        L.tgx_host_constraint_plan_json.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), E]
+        L.tgx_host_constraint_verdict_json.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), E]
+        L.tgx_host_validate_identifier.argtypes = [C.c_char_p, E]
+        L.tgx_host_assertion_json.argtypes = [C.c_char_p, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), E]
+        L.tgx_host_free.argtypes = [C.c_void_p]
+        L.tgx_host_free.restype = None
+        _HOST = L
+    return _HOST
+
+
+def _host_check(status, err):
+    if status != 0:
+        raise TgxError(status, err.msg.decode("utf-8", "replace"))
+
+
+def _take(out):
+    text = out.value.decode("utf-8")
+    _host().tgx_host_free(C.cast(out, C.c_void_p))
+    return text
+
+
+def constraint_plan(constraint):
+    """the aggregates one constraint (a dict as CheckBuilder builds them) asks for"""
+    out = C.c_char_p()
+    err = _Error()
+    _host_check(_host().tgx_host_constraint_plan_json(json.dumps(constraint).encode(), C.byref(out), C.byref(err)), err)
+    return json.loads(_take(out))
+
+
+def constraint_verdict(constraint, results):
+    """Constraint::evaluate's verdict half on given aggregates (list of dicts with tgx_result field names)"""
+    out = C.c_char_p()
+    err = _Error()
+    _host_check(_host().tgx_host_constraint_verdict_json(json.dumps(constraint).encode(), json.dumps(results).encode(),
+                                                         C.byref(out), C.byref(err)), err)
+    return json.loads(_take(out))
+
+
+def validate_identifier(identifier):
+    err = _Error()
+    _host_check(_host().tgx_host_validate_identifier(identifier.encode(), C.byref(err)), err)
