@@ -14,7 +14,6 @@ partial states are all-gathered and merged in rank order on every rank.
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -26,14 +25,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming ceiling)
 
 
-class DevPtr:
-    """expose a raw device pointer to torch through __cuda_array_interface__ (no copy)"""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
-                                         "version": 2}
-
-
 def build_suite(T, spec, layout, unique_cols):
     specs = []
     for ci in range(len(layout)):
@@ -42,45 +33,6 @@ def build_suite(T, spec, layout, unique_cols):
     for ci in unique_cols:
         specs.append(spec(T.DISTINCT, ci))        # validates_uniqueness (FullUniqueness)
     return specs
-
-
-def exchange_distinct(T, torch, dist, st, spec_indices, world, rank):
-    """hash-owner all-to-all of the local key sets (16-byte records), then import the owned keys"""
-    for si in spec_indices:
-        ptr, counts = st.distinct_export(si, world)
-        total = sum(counts)
-        send = torch.as_tensor(DevPtr(ptr, max(total, 1) * 16), device="cuda").view(torch.int64)[: total * 2]
-        send_counts = torch.tensor(counts, dtype=torch.int64, device="cuda")
-        recv_counts = torch.empty(world, dtype=torch.int64, device="cuda")
-        dist.all_to_all_single(recv_counts, send_counts)
-        rc = recv_counts.tolist()
-        recv = torch.empty(sum(rc) * 2, dtype=torch.int64, device="cuda")
-        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[c * 2 for c in rc],
-                               input_split_sizes=[c * 2 for c in counts])
-        torch.cuda.synchronize()
-        st.distinct_import(si, recv.data_ptr(), sum(rc))
-
-
-def allgather_merge(T, torch, dist, plan, st, world, rank):
-    """all-gather the packed partial states and fold them in rank order (same result on every rank)"""
-    blob = st.serialize()
-    n = torch.tensor([len(blob)], dtype=torch.int64, device="cuda")
-    sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    mine = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-    mine[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
-    gathered = [torch.empty(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    merged = None
-    for r in range(world):
-        part = T.State.deserialize(plan, bytes(gathered[r][: sizes[r]].cpu().numpy()))
-        if merged is None:
-            merged = part
-        else:
-            merged.merge([part])
-    return merged
 
 
 def cpu_baseline(torch, layout, unique_cols, table, sample_rows):
@@ -130,6 +82,7 @@ def main():
     import term_amd as T
     from term_amd import synth
     from term_amd._lib import spec
+    from term_amd.distributed import allgather_merge, exchange_distinct
 
     torch.cuda.set_device(local_rank)
     dist = None
@@ -164,8 +117,8 @@ def main():
         st.reset()
         st.update(columns)
         if world > 1:
-            exchange_distinct(T, torch, dist, st, distinct_spec_idx, world, rank)
-            merged = allgather_merge(T, torch, dist, plan, st, world, rank)
+            exchange_distinct(st, distinct_spec_idx, dist, world)
+            merged = allgather_merge(plan, st, dist, world, device="cuda")
             return merged.finalize()
         return st.finalize()
 

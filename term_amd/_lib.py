@@ -66,10 +66,13 @@ def lib_path():
 
 def abi_symbols():
     """Every function name include/tgx.h declares (parsed from the header)."""
-    with open(os.path.join(_ROOT, "include", "tgx.h")) as f:
-        text = f.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(tgx_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in ("tgx.h", "tgx_host.h"):
+        with open(os.path.join(_ROOT, "include", header)) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(tgx_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 _LIB = None
