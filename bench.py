@@ -82,7 +82,7 @@ def main():
     import term_amd as T
     from term_amd import synth
     from term_amd._lib import spec
-    from term_amd.distributed import allgather_merge, exchange_distinct
+    from term_amd.distributed import agree_on_ranges, allgather_merge, exchange_distinct_auto
 
     torch.cuda.set_device(local_rank)
     dist = None
@@ -99,12 +99,21 @@ def main():
     n_local = n_total // world
     row0 = rank * n_local
 
-    T.init(device_id=local_rank, distinct_capacity_hint=n_total)
+    T.init(device_id=local_rank, distinct_capacity_hint=n_local)
     specs = build_suite(T, spec, layout, unique_cols)
-    distinct_spec_idx = [i for i, s in enumerate(specs) if s.kind == T.DISTINCT]
-    plan = T.Plan(specs)
+    n_stats = sum(1 for s in specs if s.kind != T.DISTINCT)
     stream = torch.cuda.Stream()
-    st = T.State(plan, stream=stream.cuda_stream)
+    if world == 1:
+        # one fused plan: every column buffer is read by one scan; the unique columns feed the distinct pass
+        plan = T.Plan(specs)
+        st = T.State(plan, stream=stream.cuda_stream)
+    else:
+        # row shards: stats first, so the ranks can agree on the unique columns' global value ranges and build
+        # congruent range bitmaps (tgx_distinct_range_hint) whose slices are swapped with one all-to-all
+        plan = T.Plan(specs[:n_stats])
+        plan_d = T.Plan(specs[n_stats:])
+        st = T.State(plan, stream=stream.cuda_stream)
+        st_d = T.State(plan_d, stream=stream.cuda_stream)
 
     table = synth.make_table(layout, row0, n_local, n_total, args.seed, "cuda")
     columns = []
@@ -116,11 +125,22 @@ def main():
     def step():
         st.reset()
         st.update(columns)
-        if world > 1:
-            exchange_distinct(st, distinct_spec_idx, dist, world)
-            merged = allgather_merge(plan, st, dist, world, device="cuda")
-            return merged.finalize()
-        return st.finalize()
+        if world == 1:
+            return st.finalize()
+        local = st.finalize()
+        st_d.reset()
+        minmax = []
+        for s in specs[n_stats:]:
+            r = next(x for sp, x in zip(specs[:n_stats], local) if sp.kind == T.NUMERIC_STATS and sp.column == s.column)
+            minmax.append((bool(r.has_value) and not r.is_float, r.min_i, r.max_i))
+        for j, rng in enumerate(agree_on_ranges(minmax, dist)):
+            if rng is not None:
+                st_d.distinct_range_hint(j, rng[0], rng[1])
+        st_d.update(columns)
+        exchange_distinct_auto(st_d, list(range(len(specs) - n_stats)), dist, world, rank)
+        merged = allgather_merge(plan, st, dist, world, device="cuda")
+        merged_d = allgather_merge(plan_d, st_d, dist, world, device="cuda")
+        return merged.finalize() + merged_d.finalize()
 
     def fence():
         torch.cuda.synchronize()
@@ -132,6 +152,9 @@ def main():
         res = step()
     st.profile_enable(True)
     st.profile_reset()
+    if world > 1:
+        st_d.profile_enable(True)
+        st_d.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -143,7 +166,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = st.profile_get("scan")
-    prof_d = st.profile_get("distinct")
+    prof_d = (st if world == 1 else st_d).profile_get("distinct")
     st.profile_enable(False)
 
     # ---- verification outside the timed region: closed-form facts of the synthetic table ----

@@ -227,6 +227,24 @@ tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *state, size_t sp
 tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *state, size_t spec_index,
                                const void *device_records, uint64_t n_records, tgx_error *err);
 
+/* Range-bitmap shortcut of the exchange, for Int64 columns whose global value range is dense:
+ *   1. all ranks agree on the column's global [lo, hi] (all-reduce of their MIN/MAX) and call
+ *      tgx_distinct_range_hint before the first batch: every rank then builds a bitmap with base = lo, so the
+ *      bitmaps are congruent; keys outside [lo, hi] are counted and make tgx_finalize fail (never a wrong count);
+ *   2. tgx_distinct_bitmap_view exposes the bitmap (device pointers, 32-bit words); ranks all-to-all equal
+ *      slices of it (a few hundred MB per rank instead of 16 bytes per key);
+ *   3. tgx_distinct_adopt_slices ORs the received slices (`n_slices` x `slice_words` words, contiguous; the
+ *      "seen twice" slices too when the check wants multiplicity) into the rank's owned slice, whose first bit
+ *      stands for key `slice_base`, and marks the state owner-partitioned.
+ * tgx_distinct_bitmap_view returns TGX_UNSUPPORTED when the set is a hash table: use export / import then. */
+tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *state, size_t spec_index, int64_t lo, int64_t hi,
+                                   tgx_error *err);
+tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *state, size_t spec_index, int64_t *base,
+                                    uint64_t *n_words, const void **seen, const void **twice, tgx_error *err);
+tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *state, size_t spec_index, int64_t slice_base,
+                                     const void *seen_slices, const void *twice_slices, uint32_t n_slices,
+                                     uint64_t slice_words, tgx_error *err);
+
 /* ---- measurement ----------------------------------------------------------------------------
  * Per-kernel HIP-event timing on the state's stream (what bench.py's `roofline` uses).
  * Kernel names: "scan", "count", "distinct", "regex", "kll", "comoments". */

@@ -137,6 +137,9 @@ def lib():
         L.tgx_kll_relative_error_bound.restype = C.c_double
         L.tgx_distinct_export.argtypes = [vp, vp, sz, C.c_uint32, C.POINTER(vp), C.POINTER(u64), E]
         L.tgx_distinct_import.argtypes = [vp, vp, sz, vp, u64, E]
+        L.tgx_distinct_range_hint.argtypes = [vp, vp, sz, C.c_int64, C.c_int64, E]
+        L.tgx_distinct_bitmap_view.argtypes = [vp, vp, sz, C.POINTER(C.c_int64), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), E]
+        L.tgx_distinct_adopt_slices.argtypes = [vp, vp, sz, C.c_int64, vp, vp, C.c_uint32, u64, E]
         L.tgx_distinct_record_bytes.argtypes = [vp, vp, sz]
         L.tgx_distinct_record_bytes.restype = sz
         L.tgx_profile_enable.argtypes = [vp, C.c_int32]
@@ -357,6 +360,24 @@ class State:
         _check(lib().tgx_distinct_export(self.plan.h, self.h, spec_index, world, C.byref(ptr), counts,
                                          C.byref(err)), err)
         return ptr.value, list(counts)
+
+    def distinct_range_hint(self, spec_index, lo, hi):
+        err = _Error()
+        _check(lib().tgx_distinct_range_hint(self.plan.h, self.h, spec_index, int(lo), int(hi), C.byref(err)), err)
+
+    def distinct_bitmap_view(self, spec_index):
+        """(base, n_words, seen_ptr, twice_ptr or None); raises TGX_UNSUPPORTED when the set is a hash table"""
+        base, n = C.c_int64(), C.c_uint64()
+        seen, twice = C.c_void_p(), C.c_void_p()
+        err = _Error()
+        _check(lib().tgx_distinct_bitmap_view(self.plan.h, self.h, spec_index, C.byref(base), C.byref(n),
+                                              C.byref(seen), C.byref(twice), C.byref(err)), err)
+        return base.value, n.value, seen.value, twice.value
+
+    def distinct_adopt_slices(self, spec_index, slice_base, seen_ptr, twice_ptr, n_slices, slice_words):
+        err = _Error()
+        _check(lib().tgx_distinct_adopt_slices(self.plan.h, self.h, spec_index, int(slice_base), seen_ptr, twice_ptr,
+                                               n_slices, slice_words, C.byref(err)), err)
 
     def distinct_record_bytes(self, spec_index):
         return lib().tgx_distinct_record_bytes(self.plan.h, self.h, spec_index)

@@ -49,6 +49,9 @@ void launch_hash_export_count128(const HashSetView &src, uint32_t world, unsigne
                                  hipStream_t stream);
 void launch_hash_export_scatter128(const HashSetView &src, uint32_t world, int want_mult,
                                    unsigned long long *d_cursors, KeyRecord128 *out, hipStream_t stream);
+void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
+                         uint64_t slice_words, uint32_t *out_seen, uint32_t *out_twice,
+                         unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
                         unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,
@@ -159,6 +162,10 @@ struct DistinctState {
   DevBuf seen, twice;
   int64_t base = 0;
   uint64_t range = 0;
+  uint64_t bitmap_words = 0;  // allocated 32-bit words of `seen` (whole 2^20-bit slices)
+  // caller-declared global value range (tgx_distinct_range_hint): congruent bitmaps on every rank
+  bool has_hint = false;
+  int64_t hint_lo = 0, hint_hi = 0;
   // range-partitioned population of the bitmap (big batches)
   DevBuf lists, cursors;
   // hash (wide = 128-bit fingerprint keys of a Utf8 column: two words per slot, 32-byte records)

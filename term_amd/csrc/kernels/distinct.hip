@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint64_t sub_mask = (1ull << p.sub_bits) - 1;
   const bool wide = (((uintptr_t)p.values + (uintptr_t)p.offset * 8) & 15) == 0;  // 16-byte loads legal
-  unsigned long long n_valid = 0;
+  unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     for (uint32_t b = tid; b < kMaxPartitions; b += kPartitionThreads) hist[b] = 0;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
         key[2 * j] = v.x;
         key[2 * j + 1] = v.y;
       }
-      ok = KPT == 32 ? 0xFFFFFFFFu : ((1u << KPT) - 1u);
+      ok = (uint32_t)((1ull << KPT) - 1ull);
       if (vbits) {
         if ((p.offset & 1) == 0) {
           // the lane's two rows of a pair sit in one validity byte: one byte load per pair
@@ -253,15 +253,22 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
     __syncthreads();  // hist is zero
     uint32_t rel[KPT];   // in-bucket offset
     uint32_t info[KPT];  // bucket << 16 | rank in tile
+    n_valid += __builtin_popcount(ok);
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
-      const uint32_t b = (uint32_t)(r >> p.sub_bits);
+      const uint64_t b64 = r >> p.sub_bits;
+      if (((ok >> j) & 1) && b64 >= p.n_buckets) {
+        // outside the declared range (only possible with a caller-supplied range hint): never inserted,
+        // counted so that tgx_finalize reports it instead of returning a wrong count
+        ok &= ~(1u << j);
+        n_out++;
+      }
+      const uint32_t b = (uint32_t)b64;
       rel[j] = (uint32_t)(r & sub_mask);
       info[j] = 0;
       if ((ok >> j) & 1) info[j] = (b << 16) | atomicAdd(&hist[b], 1u);
     }
-    n_valid += __builtin_popcount(ok);
     __syncthreads();
     // ---- exclusive scan of hist (2 entries per thread) + one global reservation per touched bucket ----
     {
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
     }
     __syncthreads();
   }
-  block_add2(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+  block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
 }
 
 // Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of
@@ -459,74 +466,110 @@ __global__ __launch_bounds__(256) void hash_import_kernel(const KeyRecord *recs,
   block_add2(n_empty, n_empty_dup, &counters[2], &counters[5]);
 }
 
-// Export: pass 1 counts records per owner, pass 2 scatters them (owner = mix(key) % world).
+// Export: pass 1 counts records per owner, pass 2 scatters them (owner = mix(key) % world).  Both passes
+// aggregate per workgroup in LDS first: one global atomic per (workgroup, owner) instead of one per key
+// (all ranks' keys contend on only `world` counters otherwise).
+constexpr uint32_t kMaxWorld = 256;
+
 __device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t world) {
   return (uint32_t)((mix64(key ^ 0x9e3779b97f4a7c15ULL) >> 32) % world);
 }
 
-__global__ __launch_bounds__(256) void hash_export_count_kernel(HashSetView src, uint32_t world,
-                                                                 unsigned long long *owner_counts) {
-  const uint64_t cap = src.mask + 1;
-  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap;
-       s += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t key = src.keys[s];
-    if (key == kEmptyKey) continue;
-    atomicAdd(&owner_counts[owner_of(key, world)], 1ull);
+struct HashSource {
+  HashSetView v;
+  int want_mult;
+  typedef KeyRecord Rec;
+  __device__ uint64_t items() const { return v.mask + 1; }
+  template <class F>
+  __device__ void for_each(uint64_t s, F f) const {
+    const uint64_t key = v.keys[s];
+    if (key == kEmptyKey) return;
+    f(key, (want_mult && ((v.dup[s >> 5] >> (s & 31)) & 1)) ? 2u : 1u);
   }
-}
+};
 
-__global__ __launch_bounds__(256) void hash_export_scatter_kernel(HashSetView src, uint32_t world,
-                                                                   int want_mult,
-                                                                   unsigned long long *cursors,
-                                                                   KeyRecord *out) {
-  const uint64_t cap = src.mask + 1;
-  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap;
-       s += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t key = src.keys[s];
-    if (key == kEmptyKey) continue;
-    unsigned long long pos = atomicAdd(&cursors[owner_of(key, world)], 1ull);
-    KeyRecord r;
-    r.key = key;
-    r.count = (want_mult && ((src.dup[s >> 5] >> (s & 31)) & 1)) ? 2 : 1;
-    out[pos] = r;
-  }
-}
-
-__global__ __launch_bounds__(256) void bitmap_export_count_kernel(BitmapView bm, uint32_t world,
-                                                                   unsigned long long *owner_counts) {
-  const uint64_t words = (bm.range + 31) >> 5;
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words;
-       w += (uint64_t)gridDim.x * blockDim.x) {
+struct BitmapSource {
+  BitmapView bm;
+  int want_mult;
+  typedef KeyRecord Rec;
+  __device__ uint64_t items() const { return (bm.range + 31) >> 5; }
+  template <class F>
+  __device__ void for_each(uint64_t w, F f) const {
     uint32_t seen = bm.seen[w];
+    const uint32_t twice = want_mult ? bm.twice[w] : 0;
     while (seen) {
-      int b = __builtin_ctz(seen);
+      const int b = __builtin_ctz(seen);
       seen &= seen - 1;
-      uint64_t key = (uint64_t)bm.base + (w << 5) + (uint64_t)b;
-      atomicAdd(&owner_counts[owner_of(key, world)], 1ull);
+      f((uint64_t)bm.base + (w << 5) + (uint64_t)b, ((twice >> b) & 1) ? 2u : 1u);
     }
   }
+};
+
+template <class Src>
+__global__ __launch_bounds__(256) void export_count_kernel(Src src, uint32_t world,
+                                                            unsigned long long *owner_counts) {
+  __shared__ unsigned int cnt[kMaxWorld];
+  for (uint32_t t = threadIdx.x; t < world; t += 256) cnt[t] = 0;
+  __syncthreads();
+  const uint64_t n = src.items();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    src.for_each(i, [&](uint64_t key, uint32_t) { atomicAdd(&cnt[owner_of(key, world)], 1u); });
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < world; t += 256)
+    if (cnt[t]) atomicAdd(&owner_counts[t], (unsigned long long)cnt[t]);
 }
 
-__global__ __launch_bounds__(256) void bitmap_export_scatter_kernel(BitmapView bm, uint32_t world,
-                                                                     int want_mult,
-                                                                     unsigned long long *cursors,
-                                                                     KeyRecord *out) {
-  const uint64_t words = (bm.range + 31) >> 5;
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words;
-       w += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t seen = bm.seen[w];
-    uint32_t twice = want_mult ? bm.twice[w] : 0;
-    while (seen) {
-      int b = __builtin_ctz(seen);
-      seen &= seen - 1;
-      uint64_t key = (uint64_t)bm.base + (w << 5) + (uint64_t)b;
-      unsigned long long pos = atomicAdd(&cursors[owner_of(key, world)], 1ull);
-      KeyRecord r;
-      r.key = key;
-      r.count = ((twice >> b) & 1) ? 2 : 1;
-      out[pos] = r;
-    }
+template <class Src>
+__global__ __launch_bounds__(256) void export_scatter_kernel(Src src, uint32_t world,
+                                                              unsigned long long *cursors, KeyRecord *out) {
+  __shared__ unsigned int cnt[kMaxWorld];
+  __shared__ unsigned long long pos[kMaxWorld];
+  const uint64_t n = src.items();
+  const uint64_t step = (uint64_t)gridDim.x * 256;
+  const uint64_t rounded = (n + step - 1) / step * step;
+  for (uint64_t base = (uint64_t)blockIdx.x * 256; base < rounded; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    for (uint32_t t = threadIdx.x; t < world; t += 256) cnt[t] = 0;
+    __syncthreads();
+    if (i < n) src.for_each(i, [&](uint64_t key, uint32_t) { atomicAdd(&cnt[owner_of(key, world)], 1u); });
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < world; t += 256)
+      pos[t] = cnt[t] ? atomicAdd(&cursors[t], (unsigned long long)cnt[t]) : 0ull;
+    __syncthreads();
+    if (i < n)
+      src.for_each(i, [&](uint64_t key, uint32_t count) {
+        const unsigned long long p = atomicAdd(&pos[owner_of(key, world)], 1ull);
+        KeyRecord r;
+        r.key = key;
+        r.count = count;
+        out[p] = r;
+      });
+    __syncthreads();
   }
+}
+
+// Cross-rank reduction of congruent range bitmaps: slice k of the result is the OR of slice k of every
+// rank's bitmap; a key is "seen twice" if any rank saw it twice or two ranks saw it at all.
+__global__ __launch_bounds__(256) void bitmap_adopt_kernel(const uint32_t *seen_slices,
+                                                            const uint32_t *twice_slices, uint32_t n_slices,
+                                                            uint64_t slice_words, uint32_t *out_seen,
+                                                            uint32_t *out_twice,
+                                                            unsigned long long *counters) {
+  unsigned long long n_seen = 0, n_twice = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < slice_words;
+       w += (uint64_t)gridDim.x * 256) {
+    uint32_t acc_seen = 0, acc_twice = 0;
+    for (uint32_t s = 0; s < n_slices; s++) {
+      const uint32_t x = seen_slices[(uint64_t)s * slice_words + w];
+      if (twice_slices) acc_twice |= (acc_seen & x) | twice_slices[(uint64_t)s * slice_words + w];
+      acc_seen |= x;
+    }
+    out_seen[w] = acc_seen;
+    if (out_twice) out_twice[w] = acc_twice;
+    n_seen += __builtin_popcount(acc_seen);
+    n_twice += __builtin_popcount(acc_twice);
+  }
+  block_add2(n_seen, n_twice, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
 void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, int kpt,
@@ -600,29 +643,42 @@ void launch_hash_import(const KeyRecord *recs, uint64_t n, const HashSetView &ds
                      want_mult, d_counters);
 }
 
+static void check_world(uint32_t world) { (void)world; }
+
 void launch_hash_export_count(const HashSetView &src, uint32_t world, unsigned long long *d_counts,
                               hipStream_t stream) {
-  hipLaunchKernelGGL(hash_export_count_kernel, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream,
-                     src, world, d_counts);
+  check_world(world);
+  HashSource s{src, 0};
+  hipLaunchKernelGGL(export_count_kernel<HashSource>, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream, s,
+                     world, d_counts);
 }
 
 void launch_hash_export_scatter(const HashSetView &src, uint32_t world, int want_mult,
                                 unsigned long long *d_cursors, KeyRecord *out, hipStream_t stream) {
-  hipLaunchKernelGGL(hash_export_scatter_kernel, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream,
-                     src, world, want_mult, d_cursors, out);
+  HashSource s{src, want_mult};
+  hipLaunchKernelGGL(export_scatter_kernel<HashSource>, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream, s,
+                     world, d_cursors, out);
 }
 
 void launch_bitmap_export_count(const BitmapView &bm, uint32_t world, unsigned long long *d_counts,
                                 hipStream_t stream) {
-  hipLaunchKernelGGL(bitmap_export_count_kernel, dim3(grid_for((bm.range + 31) >> 5)), dim3(256), 0,
-                     stream, bm, world, d_counts);
+  BitmapSource s{bm, 0};
+  hipLaunchKernelGGL(export_count_kernel<BitmapSource>, dim3(grid_for((bm.range + 31) >> 5)), dim3(256), 0,
+                     stream, s, world, d_counts);
 }
 
 void launch_bitmap_export_scatter(const BitmapView &bm, uint32_t world, int want_mult,
-                                  unsigned long long *d_cursors, KeyRecord *out,
-                                  hipStream_t stream) {
-  hipLaunchKernelGGL(bitmap_export_scatter_kernel, dim3(grid_for((bm.range + 31) >> 5)), dim3(256),
-                     0, stream, bm, world, want_mult, d_cursors, out);
+                                  unsigned long long *d_cursors, KeyRecord *out, hipStream_t stream) {
+  BitmapSource s{bm, want_mult};
+  hipLaunchKernelGGL(export_scatter_kernel<BitmapSource>, dim3(grid_for((bm.range + 31) >> 5)), dim3(256), 0,
+                     stream, s, world, d_cursors, out);
+}
+
+void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
+                         uint64_t slice_words, uint32_t *out_seen, uint32_t *out_twice,
+                         unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(bitmap_adopt_kernel, dim3(grid_for(slice_words)), dim3(256), 0, stream, seen_slices,
+                     twice_slices, n_slices, slice_words, out_seen, out_twice, d_counters);
 }
 
 }  // namespace tgx

@@ -396,6 +396,8 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
     d.base = 0;
     d.range = 0;
     d.wide = false;
+    d.has_hint = false;
+    d.bitmap_words = 0;
     d.capacity = 0;  // buffers stay allocated; hash_ensure / the bitmap path clear them before use
     d.rows_upper_bound = 0;
     d.total_rows = 0;
@@ -714,7 +716,11 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
   // Int64: the scan of this batch has already folded the column's MIN/MAX into the running state
   bool have_range = false;
   int64_t lo = 0, hi = 0;
-  if (c.type == TGX_INT64 && (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap)) {
+  if (c.type == TGX_INT64 && ds.has_hint) {
+    have_range = true;  // the caller vouches for [lo, hi]; keys outside it are counted and reported
+    lo = ds.hint_lo;
+    hi = ds.hint_hi;
+  } else if (c.type == TGX_INT64 && (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap)) {
     ScanAcc acc;
     HIP_TRY(hipMemcpyAsync(&acc, st->d_scan_acc.as<ScanAcc>() + task.scan_slot, sizeof(ScanAcc),
                            hipMemcpyDeviceToHost, st->stream));
@@ -732,7 +738,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       uint64_t width = (uint64_t)hi - (uint64_t)lo;
       uint64_t expect = std::max<uint64_t>((uint64_t)c.length, g_ctx.distinct_hint);
       if (width < (1ull << 34) && width / 16 <= expect) {
-        uint64_t slack = std::min<uint64_t>(width / 8 + 64, 1ull << 30);
+        uint64_t slack = ds.has_hint ? 0 : std::min<uint64_t>(width / 8 + 64, 1ull << 30);
         int64_t base = (lo < INT64_MIN + (int64_t)slack) ? INT64_MIN : lo - (int64_t)slack;
         uint64_t top = (hi > INT64_MAX - (int64_t)slack) ? (uint64_t)INT64_MAX : (uint64_t)(hi + (int64_t)slack);
         ds.base = base;
@@ -745,6 +751,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     if (use_bitmap) {
       // whole 2^20-bit slices, so the partitioned path can move slices through LDS
       size_t words = (size_t)(((ds.range + (1u << 20) - 1) >> 20) << 15) + 4;
+      ds.bitmap_words = words - 4;
       HIP_TRY(ds.seen.reserve(words * 4));
       HIP_TRY(hipMemsetAsync(ds.seen.p, 0, words * 4, st->stream));
       if (mult) {
@@ -889,6 +896,21 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
             return fail(err, TGX_INVALID_ARGUMENT, "NUMERIC_STATS on non-numeric column %d (type %d)",
                         plan->scan[s].column, c.type);
           continue;
+        }
+        {
+          // a scan that only feeds DISTINCT's range decision is not needed once the range is declared
+          bool bound = false, all_hinted = true, any_distinct = false;
+          for (size_t i = 0; i < plan->specs.size(); i++) {
+            const SpecBinding &b = plan->bind[i];
+            if (b.slot == (int)s && (b.kind == TGX_CHECK_NUMERIC_STATS || (b.kind == TGX_CHECK_COUNT && b.count_src == Source::kScan)))
+              bound = true;
+          }
+          for (size_t dd = 0; dd < plan->distinct.size(); dd++)
+            if (plan->distinct[dd].scan_slot == (int)s) {
+              any_distinct = true;
+              all_hinted &= st->distinct[dd].has_hint;
+            }
+          if (!bound && any_distinct && all_hinted) continue;
         }
         ScanColDesc d;
         fill_scan_desc(c, plan->scan[s].variance, st->d_pivots.as<double>() + s, &d);
@@ -1255,7 +1277,8 @@ extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, s
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
-  if (world == 0 || !device_records || !counts) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
+  if (world == 0 || world > 256 || !device_records || !counts)
+    return fail(err, TGX_INVALID_ARGUMENT, "bad arguments (world must be 1..256)");
   TGX_TRY(need_device(err));
   return distinct_export_impl(st, plan->bind[spec_index].slot, world, device_records, counts, err);
 }
@@ -1309,6 +1332,85 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   HIP_TRY(hipMemcpy(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice));
   TGX_TRY(distinct_import_records(st, slot, device_records, n_records, wide, err));
   HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.partitioned = true;
+  return TGX_OK;
+}
+
+static tgx_status distinct_slot_of(const tgx_plan *plan, tgx_state *st, size_t spec_index, size_t *slot,
+                                   tgx_error *err) {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
+    return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
+  *slot = (size_t)plan->bind[spec_index].slot;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *st, size_t spec_index, int64_t lo,
+                                              int64_t hi, tgx_error *err) {
+  size_t slot = 0;
+  TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
+  DistinctState &ds = st->distinct[slot];
+  if (ds.mode != DistinctMode::kUndecided)
+    return fail(err, TGX_INVALID_ARGUMENT, "range hint must be given before the first batch (after tgx_state_reset)");
+  if (hi < lo) return fail(err, TGX_INVALID_ARGUMENT, "range hint: hi < lo");
+  ds.has_hint = true;
+  ds.hint_lo = lo;
+  ds.hint_hi = hi;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *st, size_t spec_index, int64_t *base,
+                                               uint64_t *n_words, const void **seen, const void **twice,
+                                               tgx_error *err) {
+  size_t slot = 0;
+  TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
+  DistinctState &ds = st->distinct[slot];
+  if (ds.mode != DistinctMode::kBitmap)
+    return fail(err, TGX_UNSUPPORTED, "the key set is not a range bitmap; use tgx_distinct_export / _import");
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  if (base) *base = ds.base;
+  if (n_words) *n_words = ds.bitmap_words;
+  if (seen) *seen = ds.seen.p;
+  if (twice) *twice = st->plan->distinct[slot].multiplicity ? ds.twice.p : nullptr;
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *st, size_t spec_index,
+                                                int64_t slice_base, const void *seen_slices,
+                                                const void *twice_slices, uint32_t n_slices, uint64_t slice_words,
+                                                tgx_error *err) {
+  size_t slot = 0;
+  TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
+  TGX_TRY(need_device(err));
+  TGX_TRY(state_init_device(st, err));
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = plan->distinct[slot].multiplicity;
+  if (!seen_slices || n_slices == 0 || slice_words == 0) return fail(err, TGX_INVALID_ARGUMENT, "bad slice arguments");
+  if (mult && !twice_slices) return fail(err, TGX_INVALID_ARGUMENT, "this check needs the 'twice' slices too");
+  if (ds.wide) return fail(err, TGX_INVALID_ARGUMENT, "Utf8 key sets have no range bitmap");
+  unsigned long long c[kNumDistinctCounters];
+  TGX_TRY(distinct_read_counters(st, ds, c, err));
+  DevBuf new_seen, new_twice;
+  HIP_TRY(new_seen.reserve(slice_words * 4 + 16));
+  if (mult) HIP_TRY(new_twice.reserve(slice_words * 4 + 16));
+  unsigned long long zero[kNumDistinctCounters];
+  memset(zero, 0, sizeof(zero));
+  zero[kCntValidRows] = c[kCntValidRows];
+  zero[kCntOutOfRange] = c[kCntOutOfRange];
+  HIP_TRY(hipMemcpyAsync(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice, st->stream));
+  launch_bitmap_adopt((const uint32_t *)seen_slices, mult ? (const uint32_t *)twice_slices : nullptr, n_slices,
+                      slice_words, new_seen.as<uint32_t>(), mult ? new_twice.as<uint32_t>() : nullptr,
+                      ds.counters.as<unsigned long long>(), st->stream);
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.seen = std::move(new_seen);
+  ds.twice = std::move(new_twice);
+  ds.keys.release();
+  ds.dup.release();
+  ds.capacity = 0;
+  ds.mode = DistinctMode::kBitmap;
+  ds.base = slice_base;
+  ds.range = slice_words * 32;
+  ds.bitmap_words = slice_words;
   ds.partitioned = true;
   return TGX_OK;
 }

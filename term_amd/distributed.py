@@ -47,6 +47,57 @@ def exchange_distinct(state, spec_indices, dist, world):
         state.distinct_import(si, recv.data_ptr(), sum(rc))
 
 
+def exchange_distinct_bitmaps(state, spec_index, dist, world, rank):
+    """Range-bitmap form of the exchange: all ranks hold congruent bitmaps (tgx_distinct_range_hint); each sends
+    slice r to rank r (equal splits), ORs what it receives and keeps the owned slice.  ~range/8 bytes per rank
+    instead of 16 bytes per key.  Raises TgxError(TGX_UNSUPPORTED) when the set is a hash table."""
+    import torch
+
+    base, n_words, seen_ptr, twice_ptr = state.distinct_bitmap_view(spec_index)
+    slice_words = ((n_words + world - 1) // world + 3) // 4 * 4
+    padded = slice_words * world
+
+    def swap(ptr):
+        src = torch.as_tensor(_DevPtr(ptr, n_words * 4), device="cuda").view(torch.int32)
+        send = torch.zeros(padded, dtype=torch.int32, device="cuda")
+        send[:n_words] = src
+        recv = torch.empty(padded, dtype=torch.int32, device="cuda")
+        dist.all_to_all_single(recv, send)
+        return recv
+
+    recv_seen = swap(seen_ptr)
+    recv_twice = swap(twice_ptr) if twice_ptr else None
+    torch.cuda.synchronize()
+    state.distinct_adopt_slices(spec_index, base + rank * slice_words * 32, recv_seen.data_ptr(),
+                                recv_twice.data_ptr() if recv_twice is not None else None, world, slice_words)
+
+
+def exchange_distinct_auto(state, spec_indices, dist, world, rank):
+    """bitmap slices where the key set is a range bitmap, 16/32-byte key records otherwise"""
+    for si in spec_indices:
+        try:
+            exchange_distinct_bitmaps(state, si, dist, world, rank)
+        except T.TgxError as e:
+            if e.status != "TGX_UNSUPPORTED":
+                raise
+            exchange_distinct(state, [si], dist, world)
+
+
+def agree_on_ranges(local_minmax, dist, device="cuda"):
+    """local_minmax: list of (has_value, min, max) per DISTINCT column -> list of global (lo, hi) or None"""
+    import torch
+
+    i64max, i64min = (1 << 63) - 1, -(1 << 63)
+    los = torch.tensor([m[1] if m[0] else i64max for m in local_minmax], dtype=torch.int64, device=device)
+    his = torch.tensor([m[2] if m[0] else i64min for m in local_minmax], dtype=torch.int64, device=device)
+    dist.all_reduce(los, op=dist.ReduceOp.MIN)
+    dist.all_reduce(his, op=dist.ReduceOp.MAX)
+    out = []
+    for lo, hi in zip(los.tolist(), his.tolist()):
+        out.append((lo, hi) if lo <= hi else None)
+    return out
+
+
 def allgather_blobs(blob, dist, world, device="cpu"):
     """all-gather variable-size byte strings (sizes first, then padded payloads)"""
     import torch

@@ -399,3 +399,76 @@ def test_errors_are_reported_not_thrown():
         st2.update([numeric_column(a, None, True), numeric_column(a[:5].copy(), None, True)])  # ragged batch
     with pytest.raises(T.TgxError):
         T.Plan([spec(99, 0)])
+
+
+@pytest.mark.parametrize("mult", [False, True])
+def test_distinct_bitmap_slice_exchange_single_process(mult):
+    """the range-bitmap form of the cross-rank exchange with three 'ranks' in one process: agree on [lo, hi],
+    build congruent bitmaps, swap equal slices, OR + popcount the owned slice, merge the counts"""
+    import torch
+
+    rng = np.random.default_rng(77)
+    n, world = 3_500_000, 3
+    vals = rng.integers(-200_000, 2_300_000, size=n, dtype=np.int64)
+    vals[: n // 5] = vals[n // 5: 2 * n // 5]  # cross-shard duplicates
+    mask = rng.random(n) >= 0.03
+    validity = orc.pack_validity(mask)
+    flags = T.FLAG_MULTIPLICITY if mult else 0
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=flags)])
+    bounds = [0, 1_000_000 // 64 * 64, 2_400_000 // 64 * 64, n]
+    lo, hi = int(vals[mask].min()), int(vals[mask].max())
+    states, views = [], []
+    for r in range(world):
+        st = T.State(plan)
+        st.distinct_range_hint(0, lo, hi)
+        a, b = bounds[r], bounds[r + 1]
+        st.update([numeric_column(vals, validity, True, offset=a, length=b - a)])
+        states.append(st)
+        views.append(st.distinct_bitmap_view(0))
+    base, n_words = views[0][0], views[0][1]
+    assert all(v[0] == base and v[1] == n_words for v in views)  # congruent bitmaps
+    slice_words = ((n_words + world - 1) // world + 3) // 4 * 4
+    padded = slice_words * world
+
+    class P:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def padded_copy(ptr):
+        t = torch.zeros(padded, dtype=torch.int32, device="cuda")
+        t[:n_words] = torch.as_tensor(P(ptr, n_words * 4), device="cuda").view(torch.int32)
+        return t
+
+    seen = [padded_copy(v[2]) for v in views]
+    twice = [padded_copy(v[3]) for v in views] if mult else None
+    for r in range(world):
+        recv_seen = torch.cat([s[r * slice_words:(r + 1) * slice_words] for s in seen]).contiguous()
+        recv_twice = torch.cat([s[r * slice_words:(r + 1) * slice_words] for s in twice]).contiguous() if mult else None
+        torch.cuda.synchronize()
+        states[r].distinct_adopt_slices(0, base + r * slice_words * 32, recv_seen.data_ptr(),
+                                        recv_twice.data_ptr() if mult else None, world, slice_words)
+    blobs = [s.serialize() for s in states]
+    assert all(len(b) < 200 for b in blobs)  # owner-partitioned states travel as counts only
+    from term_amd.distributed import merge_blobs
+
+    res = merge_blobs(plan, blobs).finalize()
+    d = orc.distinct_bits64(vals.view(np.uint64), validity)
+    assert (res[0].total, res[0].non_null, res[0].distinct) == (d.total, d.non_null, d.distinct)
+    if mult:
+        assert res[0].groups_once == d.groups_once
+
+
+def test_range_hint_violation_is_reported_not_miscounted():
+    vals = np.arange(2_000_000, dtype=np.int64)
+    vals[123_456] = 5_000_000_000  # outside the declared range
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0)])
+    st = T.State(plan)
+    st.distinct_range_hint(0, 0, 1_999_999)
+    st.update([numeric_column(vals, None, True)])
+    with pytest.raises(T.TgxError) as e:
+        st.finalize()
+    assert "outside the range bitmap" in str(e.value)
+    with pytest.raises(T.TgxError):
+        st.distinct_range_hint(0, 0, 10)  # only before the first batch
