@@ -197,6 +197,16 @@ def main():
         scan_ms = prof["total_ms"] / max(1, prof["launches"])
         scan_bytes = prof["bytes"] / max(1, prof["launches"])
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel from the committed PMC passes of this same command
+        # (profiles/r01_pmc_*.json: separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE x2 correction applied)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_1Brows_16cols.json")) as f:
+                pmc = json.load(f)
+            if pmc["rows_total"] == n_total and pmc["n_gpus"] == world:
+                traffic = pmc["scan_kernel_traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "validated rows/sec, 16-col null+range+unique suite",
             "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
@@ -212,7 +222,7 @@ def main():
                        "distinct_ms_per_step": prof_d["total_ms"] / max(1, args.steps),
                        "verified": verified},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes},
         }
         if not args.no_cpu_baseline:
