@@ -34,8 +34,7 @@ void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
-void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, int kpt,
-                      hipStream_t stream);
+void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, hipStream_t stream);
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
                                hipStream_t stream);
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,

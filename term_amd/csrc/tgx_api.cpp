@@ -794,7 +794,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       cap = cap + cap / 4 + 16 * tiles + 4096;
       pp.cap = (cap + 15) & ~15ull;
       pp.want_multiplicity = mult ? 1 : 0;
-      pp.pad = getenv("TGX_ABLATE") ? atoi(getenv("TGX_ABLATE")) : 0;
+      pp.pad = 0;
       HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * sizeof(uint32_t)));
       HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
       HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
@@ -806,8 +806,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       pp.twice = mult ? ds.twice.as<uint32_t>() : nullptr;
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
       ProfScope ps(st, "distinct", bytes);
-      static const int kpt = getenv("TGX_PARTITION_KPT") ? atoi(getenv("TGX_PARTITION_KPT")) : 32;
-      launch_partition(pp, cnt, g_ctx.n_cu, kpt == 16 ? 16 : 32, st->stream);
+      launch_partition(pp, cnt, g_ctx.n_cu, st->stream);
       // phase 2 recomputes the totals from the slices
       HIP_TRY(hipMemsetAsync(cnt + kCntDistinct, 0, 2 * sizeof(unsigned long long), st->stream));
       HIP_TRY(launch_bucket_apply(pp, cnt, st->stream));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <counter> [bench args...]  -- one rocprofv3 --pmc pass (counters in their own run)
+# usage: tools/pmc_bench.sh <tag> <counter> [bench args...]  -- one rocprofv3 --pmc pass (counters in their own run)
 tag=$1; shift; ctr=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py "$@" > gpurun_out/pmc_$tag.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [bench args...]   -- rocprofv3 kernel stats of bench.py, tgx kernels only
+# usage: tools/prof_bench.sh <tag> [bench args...]   -- rocprofv3 kernel stats of bench.py, tgx kernels only
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py "$@" > gpurun_out/prof_$tag.log 2>&1
