@@ -7,7 +7,7 @@
 // checks (TG/constraints/completeness.rs:158-163, TG/constraints/statistics.rs:45-74).
 //
 // HBM-bound: 8 B of value + 1 bit of validity per row, nothing is re-read.  Layout of the hot loop:
-//   * a wave consumes a 512-row tile per iteration = 4 x global_load_dwordx4 per lane (4 KiB per
+//   * a wave consumes a 512-row tile per iteration = 4 x nontemporal global_load_dwordx4 per lane (4 KiB per
 //     wave in flight, 16 B/lane coalesced),
 //   * the tile's 8 validity words are wave-uniform and fetched through the scalar cache
 //     (s_load), COUNT(col) is an s_bcnt1 on them -- no per-lane work for the null count,
@@ -114,7 +114,13 @@ __device__ void scan_ragged(const ScanColDesc &c, int64_t r0, int64_t r1, int la
   }
 }
 
-template <bool IS_FLOAT, bool VAR>
+template <int VARIANT>
+__device__ __forceinline__ i64x2 tile_load(global_i64x2_ptr p) {
+  if (VARIANT & 1) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+template <bool IS_FLOAT, bool VAR, int VARIANT>
 __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_global,
                                            int64_t n_waves, int lane, LaneAcc &a,
                                            int64_t &tile_count, double pivot) {
@@ -125,12 +131,35 @@ __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_gl
   const uint32_t sh = 2u * (uint32_t)(lane & 31);
   const bool upper = lane >= 32;
   int64_t cnt = 0;
-  for (int64_t t = wave_global; t < c.n_tiles; t += n_waves) {
+  constexpr bool kPrefetch = (VARIANT & 2) != 0;
+  i64x2 n0, n1, n2, n3;
+  int64_t t = wave_global;
+  if (kPrefetch && t < c.n_tiles) {
     global_i64x2_ptr p = vp + t * (kTileRows / 2) + lane;
-    i64x2 v0 = p[0];
-    i64x2 v1 = p[64];
-    i64x2 v2 = p[128];
-    i64x2 v3 = p[192];
+    n0 = tile_load<VARIANT>(p);
+    n1 = tile_load<VARIANT>(p + 64);
+    n2 = tile_load<VARIANT>(p + 128);
+    n3 = tile_load<VARIANT>(p + 192);
+  }
+  for (; t < c.n_tiles; t += n_waves) {
+    i64x2 v0, v1, v2, v3;
+    if (kPrefetch) {
+      v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+      const int64_t tn = t + n_waves;
+      if (tn < c.n_tiles) {
+        global_i64x2_ptr pn = vp + tn * (kTileRows / 2) + lane;
+        n0 = tile_load<VARIANT>(pn);
+        n1 = tile_load<VARIANT>(pn + 64);
+        n2 = tile_load<VARIANT>(pn + 128);
+        n3 = tile_load<VARIANT>(pn + 192);
+      }
+    } else {
+      global_i64x2_ptr p = vp + t * (kTileRows / 2) + lane;
+      v0 = tile_load<VARIANT>(p);
+      v1 = tile_load<VARIANT>(p + 64);
+      v2 = tile_load<VARIANT>(p + 128);
+      v3 = tile_load<VARIANT>(p + 192);
+    }
     uint64_t w0 = ~0ull, w1 = ~0ull, w2 = ~0ull, w3 = ~0ull, w4 = ~0ull, w5 = ~0ull, w6 = ~0ull,
              w7 = ~0ull;
     if (has_validity) {
@@ -184,7 +213,7 @@ __device__ __forceinline__ LaneAcc acc_shfl_down(const LaneAcc &a, int d) {
   return b;
 }
 
-template <bool IS_FLOAT, bool VAR>
+template <bool IS_FLOAT, bool VAR, int VARIANT>
 __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out, int wave,
                                           int lane) {
   LaneAcc a;
@@ -194,7 +223,7 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
   const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
   int64_t tile_count = 0;
   if (c.n_tiles > 0) {
-    scan_tiles<IS_FLOAT, VAR>(c, wave_global, n_waves, lane, a, tile_count, pivot);
+    scan_tiles<IS_FLOAT, VAR, VARIANT>(c, wave_global, n_waves, lane, a, tile_count, pivot);
     // ragged edges belong to the last block (it has the least tile work when tiles % grid != 0)
     if (blockIdx.x == gridDim.x - 1) {
       const int64_t tail0 = c.head + c.n_tiles * kTileRows;
@@ -240,6 +269,7 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
   }
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanColDesc *__restrict__ cols,
                                                            ScanPartial *__restrict__ partials) {
   const ScanColDesc c = cols[blockIdx.y];
@@ -248,14 +278,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanColDesc *__r
   ScanPartial *out = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (c.is_float) {
     if (c.want_variance)
-      scan_body<true, true>(c, out, wave, lane);
+      scan_body<true, true, VARIANT>(c, out, wave, lane);
     else
-      scan_body<true, false>(c, out, wave, lane);
+      scan_body<true, false, VARIANT>(c, out, wave, lane);
   } else {
     if (c.want_variance)
-      scan_body<false, true>(c, out, wave, lane);
+      scan_body<false, true, VARIANT>(c, out, wave, lane);
     else
-      scan_body<false, false>(c, out, wave, lane);
+      scan_body<false, false, VARIANT>(c, out, wave, lane);
   }
 }
 
@@ -430,7 +460,7 @@ void launch_scan(const ScanColDesc *d_cols, int n_cols, int blocks_per_col, Scan
   if (any_variance)
     hipLaunchKernelGGL(scan_pivot_kernel, dim3(n_cols), dim3(256), 0, stream, d_cols, d_pivots,
                        d_pivot_set, d_acc_index);
-  hipLaunchKernelGGL(scan_kernel, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, d_cols,
+  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, d_cols,
                      d_partials);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, d_cols, d_partials,
                      blocks_per_col, d_accs, d_acc_index);
@@ -438,7 +468,9 @@ void launch_scan(const ScanColDesc *d_cols, int n_cols, int blocks_per_col, Scan
 
 void launch_scan_main_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
                            ScanPartial *d_partials, hipStream_t stream) {
-  hipLaunchKernelGGL(scan_kernel, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, d_cols,
+  // VARIANT bit 0 = nontemporal loads, bit 1 = next tile requested before the current one is consumed.
+  // Measured at 1 G rows x 16 columns (ms per launch): 0: 21.11, 1: 20.95, 2: 21.24, 3: 20.74 -> 3.
+  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, d_cols,
                      d_partials);
 }
 
