@@ -93,7 +93,10 @@ typedef enum tgx_check_kind {
   TGX_CHECK_KLL = 5,
   /* n, Sx, Sy, Sxx, Syy, Sxy over rows with both columns non-NULL (CAST AS DOUBLE)
    *                                            TG/analyzers/advanced/correlation.rs:239-249 */
-  TGX_CHECK_COMOMENTS = 6
+  TGX_CHECK_COMOMENTS = 6,
+  /* n and the sums of SQL RANK() ranks (min-rank ties) of both columns over rows with both non-NULL
+   * (CAST AS DOUBLE), reported in sum_x .. sum_xy          TG/analyzers/advanced/correlation.rs:334-350 */
+  TGX_CHECK_SPEARMAN = 7
 } tgx_check_kind;
 
 enum {
@@ -101,13 +104,16 @@ enum {
   TGX_FLAG_MULTIPLICITY = 1u << 1,      /* DISTINCT: also #groups with cnt == 1 (NULL is a group) */
   TGX_FLAG_TRIM = 1u << 2,              /* REGEX: TRIM(col) (U+0020 only) before matching */
   TGX_FLAG_CASE_INSENSITIVE = 1u << 3,  /* REGEX: `~*` */
-  TGX_FLAG_NULL_IS_VALID = 1u << 4      /* REGEX: `OR col IS NULL` */
+  TGX_FLAG_NULL_IS_VALID = 1u << 4,     /* REGEX: `OR col IS NULL` */
+  /* SPEARMAN: exact sums instead of the reference's UInt64 arithmetic, whose rank products and sums wrap
+   * modulo 2^64 (from about 3.8 M rows on) */
+  TGX_FLAG_EXACT_RANK_SUMS = 1u << 5
 };
 
 typedef struct tgx_check_spec {
   int32_t kind;         /* tgx_check_kind */
   int32_t column;       /* index into the columns array handed to tgx_update */
-  int32_t column2;      /* COMOMENTS: second column; otherwise -1 */
+  int32_t column2;      /* COMOMENTS / SPEARMAN: second column; otherwise -1 */
   uint32_t flags;
   const char *pattern;  /* REGEX: pattern bytes (Rust `regex` syntax), not NUL-terminated */
   uint64_t pattern_len;

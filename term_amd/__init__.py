@@ -22,6 +22,8 @@ from ._lib import (  # noqa: F401
     REGEX_MATCH,
     KLL,
     COMOMENTS,
+    SPEARMAN,
+    FLAG_EXACT_RANK_SUMS,
     FLAG_VARIANCE,
     FLAG_MULTIPLICITY,
     FLAG_TRIM,

@@ -7,8 +7,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 
 # enums of include/tgx.h
-COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS = 1, 2, 3, 4, 5, 6
+COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN = 1, 2, 3, 4, 5, 6, 7
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
+FLAG_EXACT_RANK_SUMS = 32
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8 = 1, 2, 3, 4, 5
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",

@@ -108,6 +108,7 @@ struct tgx_plan {
   std::vector<tgx::KllTask> kll;
   int n_columns_needed = 0;  // 1 + max column index
   void *regex = nullptr;     // tgx::RegexPlan (regex_device.cpp)
+  void *spearman = nullptr;  // tgx::SpearmanPlan (spearman_device.cpp)
 };
 
 namespace tgx {
@@ -217,6 +218,7 @@ struct tgx_state {
   std::vector<tgx::KllHost> h_kll;
   void *kll = nullptr;    // tgx::KllDeviceState (kll_device.cpp)
   void *regex = nullptr;  // tgx::RegexState (regex_device.cpp)
+  void *spearman = nullptr;  // tgx::SpearmanState (spearman_device.cpp)
 
   // rows handled by host-answered COUNT tasks (columns without a validity buffer)
   bool profiling = false;

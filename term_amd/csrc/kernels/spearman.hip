@@ -1,0 +1,187 @@
+// spearman.hip -- Spearman rank-correlation state on gfx950.
+//
+// The reference computes it in SQL (TG/analyzers/advanced/correlation.rs:334-350):
+//   WITH ranked AS (SELECT RANK() OVER (ORDER BY CAST(x AS DOUBLE)) rank_x, RANK() OVER (ORDER BY CAST(y AS DOUBLE)) rank_y
+//                   FROM data WHERE x IS NOT NULL AND y IS NOT NULL)
+//   SELECT COUNT(*), SUM(rank_x), SUM(rank_y), SUM(rank_x*rank_x), SUM(rank_y*rank_y), SUM(rank_x*rank_y)
+// i.e. two global sorts with min-rank ties and UInt64 arithmetic that wraps (the sums of squares overflow past
+// ~3.8 M rows).  Not mergeable (`:103-109`), so the state keeps the (x, y) pairs of every batch and ranks them at
+// finalize.  Off the hot path (SURVEY.md section 8d times it separately): the two device sorts and the max-scan use
+// rocPRIM's radix_sort_pairs / inclusive_scan (a plain library primitive); compaction, tie ranking and the
+// sums are kernels of this file.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device_types.h"
+
+namespace tgx {
+
+typedef const int64_t __attribute__((address_space(1))) *global_i64_ptr;
+typedef const uint8_t __attribute__((address_space(1))) *global_u8_ptr;
+
+__device__ __forceinline__ uint64_t sort_key(int64_t bits, int is_float) {
+  const double d = is_float ? __longlong_as_double(bits) : (double)bits;  // CAST(c AS DOUBLE)
+  const int64_t k = f64_total_key(__double_as_longlong(d));
+  return (uint64_t)k ^ 0x8000000000000000ULL;  // signed total order -> unsigned radix order
+}
+
+// appends the (x, y) sort keys of rows where both sides are non-NULL; *count is the running pair count
+__global__ __launch_bounds__(256) void spearman_compact_kernel(ComomentColDesc d, uint64_t *kx, uint64_t *ky,
+                                                                unsigned long long *count) {
+  global_i64_ptr x = (global_i64_ptr)(uintptr_t)((const int64_t *)d.x + d.xoff);
+  global_i64_ptr y = (global_i64_ptr)(uintptr_t)((const int64_t *)d.y + d.yoff);
+  global_u8_ptr xv = (global_u8_ptr)(uintptr_t)d.xv;
+  global_u8_ptr yv = (global_u8_ptr)(uintptr_t)d.yv;
+  __shared__ unsigned long long block_base;
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  const int64_t rounded = (d.length + step - 1) / step * step;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < rounded; base += step) {
+    const int64_t i = base + threadIdx.x;
+    bool ok = i < d.length;
+    if (ok && xv) ok = (xv[(d.xoff + i) >> 3] >> ((d.xoff + i) & 7)) & 1;
+    if (ok && yv) ok = (yv[(d.yoff + i) >> 3] >> ((d.yoff + i) & 7)) & 1;
+    const unsigned long long ballot = __ballot(ok);
+    const uint32_t before = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      block_base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    if (ok) {
+      uint32_t off = before;
+      for (uint32_t w = 0; w < wave; w++) off += wave_cnt[w];
+      kx[block_base + off] = sort_key(x[i], d.x_is_float);
+      ky[block_base + off] = sort_key(y[i], d.y_is_float);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void iota_kernel(uint32_t *idx, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    idx[i] = (uint32_t)i;
+}
+
+// start position of each tie run (0 elsewhere); an inclusive max-scan turns it into "first position of my run"
+__global__ void run_heads_kernel(const uint64_t *sorted, uint64_t n, uint64_t *heads) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    heads[i] = (i > 0 && sorted[i] != sorted[i - 1]) ? i : 0;
+}
+
+// RANK(): 1 + first position of the tie run, scattered back to the original row order
+__global__ void scatter_ranks_kernel(const uint64_t *run_start, const uint32_t *idx_sorted, uint64_t n,
+                                     uint64_t *rank) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    rank[idx_sorted[i]] = run_start[i] + 1;
+}
+
+struct RankSums {
+  unsigned long long wrapped[5];   // UInt64 arithmetic of the reference: sums and products wrap modulo 2^64
+  unsigned long long exact_lo[5];  // the same sums without wrapping, 128 bits
+  unsigned long long exact_hi[5];
+};
+
+__global__ __launch_bounds__(256) void rank_sums_kernel(const uint64_t *rx, const uint64_t *ry, uint64_t n,
+                                                         RankSums *partials) {
+  unsigned long long w[5] = {0, 0, 0, 0, 0};
+  unsigned __int128 e[5] = {0, 0, 0, 0, 0};
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long a = rx[i], b = ry[i];
+    w[0] += a;
+    w[1] += b;
+    w[2] += a * a;
+    w[3] += b * b;
+    w[4] += a * b;
+    e[0] += a;
+    e[1] += b;
+    e[2] += (unsigned __int128)a * a;
+    e[3] += (unsigned __int128)b * b;
+    e[4] += (unsigned __int128)a * b;
+  }
+  __shared__ RankSums sh[256 / 64];
+  // wave reduce through shuffles of 64-bit halves
+  for (int k = 0; k < 5; k++) {
+    unsigned long long lo = (unsigned long long)e[k], hi = (unsigned long long)(e[k] >> 64), ww = w[k];
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      const unsigned long long olo = __shfl_down(lo, dlt, 64), ohi = __shfl_down(hi, dlt, 64);
+      ww += __shfl_down(ww, dlt, 64);
+      const unsigned long long s = lo + olo;
+      hi += ohi + (s < lo ? 1 : 0);
+      lo = s;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      sh[threadIdx.x >> 6].wrapped[k] = ww;
+      sh[threadIdx.x >> 6].exact_lo[k] = lo;
+      sh[threadIdx.x >> 6].exact_hi[k] = hi;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    RankSums r = sh[0];
+    for (int wv = 1; wv < 4; wv++)
+      for (int k = 0; k < 5; k++) {
+        r.wrapped[k] += sh[wv].wrapped[k];
+        const unsigned long long s = r.exact_lo[k] + sh[wv].exact_lo[k];
+        r.exact_hi[k] += sh[wv].exact_hi[k] + (s < r.exact_lo[k] ? 1 : 0);
+        r.exact_lo[k] = s;
+      }
+    partials[blockIdx.x] = r;
+  }
+}
+
+static int grid_of(uint64_t n) {
+  uint64_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+void launch_spearman_compact(const ComomentColDesc &d, uint64_t *kx, uint64_t *ky, unsigned long long *count,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(spearman_compact_kernel, dim3(grid_of((uint64_t)d.length)), dim3(256), 0, stream, d, kx, ky, count);
+}
+
+size_t spearman_rank_sums_bytes() { return sizeof(RankSums); }
+
+// ranks `keys` (n sort keys, clobbered) into `rank` (original order). scratch buffers: n entries each.
+// Returns the rocPRIM temp bytes needed when temp == nullptr.
+hipError_t spearman_rank(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
+                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream) {
+  size_t sort_bytes = 0, scan_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u,
+                                           stream);
+  if (e != hipSuccess) return e;
+  e = rocprim::inclusive_scan(nullptr, scan_bytes, heads, heads, (size_t)n, rocprim::maximum<uint64_t>(), stream);
+  if (e != hipSuccess) return e;
+  const size_t need = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  if (temp == nullptr) {
+    *temp_bytes = need;
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_of(n)), dim3(256), 0, stream, idx, n);
+  size_t tb = *temp_bytes;
+  e = rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(run_heads_kernel, dim3(grid_of(n)), dim3(256), 0, stream, keys_sorted, n, heads);
+  tb = *temp_bytes;
+  e = rocprim::inclusive_scan(temp, tb, heads, heads, (size_t)n, rocprim::maximum<uint64_t>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(scatter_ranks_kernel, dim3(grid_of(n)), dim3(256), 0, stream, heads, idx_sorted, n, rank);
+  return hipGetLastError();
+}
+
+int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, void *partials, hipStream_t stream) {
+  const int g = grid_of(n);
+  hipLaunchKernelGGL(rank_sums_kernel, dim3(g), dim3(256), 0, stream, rx, ry, n, (RankSums *)partials);
+  return g;
+}
+
+}  // namespace tgx

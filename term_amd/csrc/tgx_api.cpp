@@ -15,6 +15,7 @@
 #include "internal.h"
 #include "kll_device.h"
 #include "regex_device.h"
+#include "spearman_device.h"
 
 using namespace tgx;
 
@@ -200,6 +201,14 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
         plan->bind[i].slot = slot;
         break;
       }
+      case TGX_CHECK_SPEARMAN: {
+        max_col = std::max(max_col, sp.column2);
+        int slot = -1;
+        tgx_status st = spearman_plan_add(plan.get(), (int)i, &slot, err);
+        if (st != TGX_OK) return st;
+        plan->bind[i].slot = slot;
+        break;
+      }
       default:
         return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: unknown check kind %d", i, sp.kind);
     }
@@ -239,6 +248,7 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
 extern "C" void tgx_plan_destroy(tgx_plan *plan) {
   if (!plan) return;
   regex_plan_free(plan);
+  spearman_plan_free(plan);
   delete plan;
 }
 extern "C" size_t tgx_plan_num_specs(const tgx_plan *plan) { return plan ? plan->specs.size() : 0; }
@@ -312,6 +322,7 @@ static void state_init_host(tgx_state *st, const tgx_plan *plan) {
   for (size_t i = 0; i < plan->kll.size(); i++) st->h_kll[i].k = plan->kll[i].k;
   regex_state_init(st);
   kll_state_init(st);
+  spearman_state_init(st);
 }
 
 static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
@@ -369,6 +380,7 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
     }
   regex_state_free(st);
   kll_state_free(st);
+  spearman_state_free(st);
   if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
   delete st;
 }
@@ -410,6 +422,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   }
   kll_state_reset(st);
   regex_state_reset(st);
+  spearman_state_reset(st);
   if (st->device_ready) {
     if (!plan->scan.empty()) {
       std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
@@ -840,6 +853,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   for (auto &t : plan->como) used[t.col_x] = used[t.col_y] = reads_values[t.col_x] = reads_values[t.col_y] = 1;
   for (auto &t : plan->kll) used[t.column] = reads_values[t.column] = 1;
   regex_mark_used(plan, used);
+  spearman_mark_used(plan, used, reads_values);
   int64_t nrows = -1;
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!used[i]) continue;
@@ -1019,6 +1033,8 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
     // ---- regex ----
     TGX_TRY(regex_update(st, dev.data(), err));
+    // ---- Spearman: keep the pairs, rank at finalize ----
+    TGX_TRY(spearman_update(st, dev.data(), err));
   }
   st->batches++;
   if (any_host) HIP_TRY(hipStreamSynchronize(st->stream));
@@ -1191,6 +1207,9 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
         break;
       case TGX_CHECK_REGEX_MATCH:
         TGX_TRY(regex_fill_result(st, b.slot, r, err));
+        break;
+      case TGX_CHECK_SPEARMAN:
+        TGX_TRY(spearman_fill_result(st, b.slot, r, err));
         break;
       default:
         break;
@@ -1421,6 +1440,7 @@ extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state 
     tgx_state *src = srcs ? srcs[i] : nullptr;
     if (!src || src->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "src %zu does not belong to plan", i);
     if (src == dst) return fail(err, TGX_INVALID_ARGUMENT, "src %zu is dst", i);
+    TGX_TRY(spearman_check_mergeable(src, err));
     Gathered g;
     // distinct totals are handled set-wise below; gather the fixed-size parts
     {
@@ -1513,6 +1533,7 @@ constexpr uint32_t kWireVersion = 1;
 extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, uint8_t *buf, size_t cap,
                                           size_t *len, tgx_error *err) {
   if (!plan || !st || st->plan != plan || !len) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
+  TGX_TRY(spearman_check_mergeable(st, err));
   Gathered g;
   TGX_TRY(gather(st, &g, err));
   Writer w{buf, cap};
