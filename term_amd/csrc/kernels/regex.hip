@@ -5,9 +5,13 @@
 // The host compiles the pattern (Rust `regex` syntax, unanchored search, Unicode classes expanded to
 // UTF-8) into a byte DFA (regex/regex_compile.cpp).  One row per lane: the lane walks its value's bytes
 // through `state = table[state * n_classes + class[byte]]` with the table held in LDS (<= 48 KiB, else it
-// stays in global memory / L2), leaving early once the automaton has matched or died.  Value bytes are
-// fetched as aligned 8-byte words (neighbouring lanes read neighbouring strings, so the words of a wave
-// fall in a few cache lines).  Match counts are block-reduced and added with one atomic per block.
+// stays in global memory / L2), leaving early once the automaton has matched or died.  A wave takes 64
+// consecutive rows, whose value bytes are one contiguous span: the span is copied into LDS with coalesced
+// 16-byte loads and each lane then reads its own value from LDS as aligned 8-byte words (per-lane global loads
+// at a ~28-byte stride ran the kernel at 1.2 TB/s, the staged form at 2.3 TB/s); spans longer than 4 KiB fall
+// back to per-lane global reads.  Evaluating several patterns of one column in the same pass was tried and was
+// slower than one pass each (6.6 ms vs 4.6 ms for three patterns on 100 M rows): the per-byte dependent LDS
+// lookups, not the reads, bound the kernel.  Match counts are block-reduced: one atomic per block.
 #include <hip/hip_runtime.h>
 
 #include "regex_types.h"
@@ -20,32 +24,65 @@ typedef const int32_t __attribute__((address_space(1))) *global_i32_ptr;
 typedef const int64_t __attribute__((address_space(1))) *global_i64_ptr;
 typedef const uint16_t __attribute__((address_space(1))) *global_u16_ptr;
 
-template <bool LDS_TABLE>
+constexpr uint32_t kStageBytes = 4096;  // LDS staging per wave: 64 consecutive values up to 64 B on average
+
+// walks value bytes [b, e) (absolute offsets into `data`) through the automaton; STAGED means the bytes
+// [stage_base, ...) are already in LDS (16-byte aligned image of the wave's contiguous value span)
+template <bool LDS_TABLE, bool STAGED>
+__device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_table, const uint8_t *s_class,
+                                         uintptr_t data, int64_t b, int64_t e, const uint8_t *stage,
+                                         int64_t stage_base) {
+  global_u16_ptr g_table = (global_u16_ptr)(uintptr_t)dfa.table;
+  const uint32_t ncls = dfa.n_classes;
+  uint32_t st = dfa.start;
+  int64_t p = b;
+  while (p < e && st > 1) {
+    uint64_t word;
+    if (STAGED) {
+      word = *(const uint64_t *)(stage + ((p - stage_base) & ~(int64_t)7));
+    } else {
+      word = *(global_u64_ptr)((data + (uintptr_t)p) & ~(uintptr_t)7);
+    }
+    const uint32_t skip = STAGED ? (uint32_t)((p - stage_base) & 7) : (uint32_t)((data + (uintptr_t)p) & 7);
+    uint64_t w = word >> (8 * skip);
+    uint32_t nb = 8 - skip;
+    if (e - p < (int64_t)nb) nb = (uint32_t)(e - p);
+    p += nb;
+    for (uint32_t k = 0; k < nb && st > 1; k++) {
+      const uint32_t c = s_class[w & 0xFF];
+      w >>= 8;
+      st = LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
+    }
+  }
+  return st;
+}
+
+// TABLE_ENTRIES: LDS budget of the transition table (0 = the table stays in global memory / L2).  The small
+// instance leaves room for 6 workgroups per CU, the large one for 3.
+template <int TABLE_ENTRIES>
 __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaView dfa,
                                                            unsigned long long *counters) {
-  __shared__ uint16_t s_table[LDS_TABLE ? kRegexLdsEntries : 1];
+  constexpr bool LDS_TABLE = TABLE_ENTRIES > 0;
+  __shared__ uint16_t s_table[LDS_TABLE ? TABLE_ENTRIES : 1];
   __shared__ uint8_t s_class[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kStageBytes + 32];
   __shared__ unsigned long long s_part[4];
   const uint32_t n_entries = dfa.n_states * dfa.n_classes;
   if (LDS_TABLE)
     for (uint32_t i = threadIdx.x; i < n_entries; i += 256) s_table[i] = dfa.table[i];
   s_class[threadIdx.x] = dfa.byte_class[threadIdx.x];
   __syncthreads();
-  global_u16_ptr g_table = (global_u16_ptr)(uintptr_t)dfa.table;
   global_u8_ptr g_acc = (global_u8_ptr)(uintptr_t)dfa.accept_end;
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   const uintptr_t data = (uintptr_t)d.data;
-  const uint32_t ncls = dfa.n_classes;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t *stage = s_stage[wave];
   unsigned long long matches = 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
-    const int64_t slot = d.offset + i;
-    bool valid = true;
-    if (vbits) valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
-    if (!valid) {
-      matches += d.null_is_valid ? 1 : 0;
-      continue;
-    }
+  const int64_t n_groups = (d.length + 63) / 64;  // 64 consecutive rows per wave step
+  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
+    const int64_t i = g * 64 + lane;
+    const bool in = i < d.length;
+    const int64_t slot = d.offset + (in ? i : d.length - 1);
     int64_t b, e;
     if (d.large_offsets) {
       global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
@@ -56,29 +93,43 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
       b = off[slot];
       e = off[slot + 1];
     }
-    if (d.trim) {
-      // SQL TRIM(col) = btrim(col, ' '): U+0020 only
-      global_u8_ptr bytes = (global_u8_ptr)data;
-      while (b < e && bytes[b] == 0x20) b++;
-      while (e > b && bytes[e - 1] == 0x20) e--;
+    bool valid = in;
+    if (in && vbits) valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
+    // the wave's values are contiguous: [b of lane 0, e of the last lane)
+    const int64_t span_b = __shfl(b, 0, 64), span_e = __shfl(e, 63, 64);
+    const int64_t stage_base = span_b & ~(int64_t)15;
+    const bool staged = span_e - stage_base <= (int64_t)kStageBytes;  // wave-uniform
+    if (staged) {
+      // coalesced 16-byte loads of the span into LDS (values of NULL rows included; never interpreted)
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
+      global_u4_ptr src = (global_u4_ptr)(data + (uintptr_t)stage_base);
+      const int64_t n16 = (span_e - stage_base + 15) >> 4;
+      for (int64_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + 16 * k) = src[k];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    uint32_t st = dfa.start;
-    uintptr_t p = data + (uintptr_t)b;
-    const uintptr_t pe = data + (uintptr_t)e;
-    while (p < pe && st > 1) {
-      const uint64_t word = *(global_u64_ptr)(p & ~(uintptr_t)7);
-      const uint32_t skip = (uint32_t)(p & 7);
-      uint64_t w = word >> (8 * skip);
-      uint32_t nb = 8 - skip;
-      if (pe - p < nb) nb = (uint32_t)(pe - p);
-      p += nb;
-      for (uint32_t k = 0; k < nb && st > 1; k++) {
-        const uint32_t c = s_class[w & 0xFF];
-        w >>= 8;
-        st = LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
+    if (valid) {
+      if (d.trim) {
+        // SQL TRIM(col) = btrim(col, ' '): U+0020 only
+        if (staged) {
+          while (b < e && stage[b - stage_base] == 0x20) b++;
+          while (e > b && stage[e - 1 - stage_base] == 0x20) e--;
+        } else {
+          global_u8_ptr bytes = (global_u8_ptr)data;
+          while (b < e && bytes[b] == 0x20) b++;
+          while (e > b && bytes[e - 1] == 0x20) e--;
+        }
       }
+      const uint32_t st = staged ? walk<LDS_TABLE, true>(dfa, s_table, s_class, data, b, e, stage, stage_base)
+                                 : walk<LDS_TABLE, false>(dfa, s_table, s_class, data, b, e, nullptr, 0);
+      matches += (st == 1 || g_acc[st]) ? 1 : 0;
+    } else if (in) {
+      matches += d.null_is_valid ? 1 : 0;
     }
-    matches += (st == 1 || g_acc[st]) ? 1 : 0;
+    // the stage is reused by the next step of this wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) matches += __shfl_down(matches, dlt, 64);
@@ -93,12 +144,16 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
 void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long *d_counters, int n_cu,
                   hipStream_t stream) {
   int64_t blocks = (d.length + 255) / 256;
-  if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+  if (blocks > (int64_t)n_cu * 6) blocks = (int64_t)n_cu * 6;
   if (blocks < 1) blocks = 1;
-  if ((uint64_t)dfa.n_states * dfa.n_classes <= kRegexLdsEntries)
-    hipLaunchKernelGGL(regex_match_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+  const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
+  if (entries <= 4096)
+    hipLaunchKernelGGL(regex_match_kernel<4096>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+  else if (entries <= kRegexLdsEntries)
+    hipLaunchKernelGGL(regex_match_kernel<(int)kRegexLdsEntries>, dim3((int)blocks), dim3(256), 0, stream, d, dfa,
+                       d_counters);
   else
-    hipLaunchKernelGGL(regex_match_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+    hipLaunchKernelGGL(regex_match_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
 }
 
 }  // namespace tgx

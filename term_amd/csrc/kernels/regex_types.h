@@ -4,7 +4,7 @@
 
 namespace tgx {
 
-constexpr uint32_t kRegexLdsEntries = 24576;  // 48 KiB of LDS for the transition table
+constexpr uint32_t kRegexLdsEntries = 16384;  // 32 KiB of LDS for the transition table
 
 struct RegexColDesc {
   const void *offsets;      // int32 or int64 value offsets

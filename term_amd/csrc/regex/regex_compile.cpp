@@ -1140,11 +1140,69 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
   }
   for (auto &t : table)
     if (!alive[t]) t = 0;
-  out->n_states = (uint32_t)n_states;
-  out->n_classes = (uint32_t)ncls;
-  out->start = alive[start_id] ? (uint32_t)start_id : 0u;
-  out->table = table;
-  out->accept_at_end = acc_end;
+  // ---- minimise: Moore partition refinement (DEAD and MATCHED keep ids 0 and 1), then merge byte classes
+  // whose columns are identical.  Unicode classes expand to many byte-sequence states that are
+  // equivalent (`^\\d{5}$`: 403 -> a few dozen states), which is what makes most tables fit in LDS.
+  std::vector<int> part(n_states);
+  for (int s = 0; s < n_states; s++) part[s] = s == 0 ? 0 : s == 1 ? 1 : (acc_end[s] ? 2 : 3);
+  int n_parts = 0;  // partitions after the previous round (the initial labelling may leave ids unused)
+  for (;;) {
+    std::map<std::vector<int>, int> sig_ids;
+    std::vector<int> next(n_states);
+    // keep 0 and 1 fixed
+    sig_ids[{-1}] = 0;
+    sig_ids[{-2}] = 1;
+    std::vector<int> sig((size_t)ncls + 1);
+    for (int s = 0; s < n_states; s++) {
+      if (s == 0) { next[s] = 0; continue; }
+      if (s == 1) { next[s] = 1; continue; }
+      sig[0] = part[s];
+      for (int c = 0; c < ncls; c++) sig[(size_t)c + 1] = part[table[(size_t)s * ncls + c]];
+      auto it = sig_ids.find(sig);
+      if (it == sig_ids.end()) it = sig_ids.emplace(sig, (int)sig_ids.size()).first;
+      next[s] = it->second;
+    }
+    const int n_next = (int)sig_ids.size();
+    part.swap(next);
+    if (n_next == n_parts) break;
+    n_parts = n_next;
+  }
+  // a partition id may be unused (e.g. no accept-at-end states): compact ids, keeping 0 and 1
+  std::vector<int> remap(n_parts, -1);
+  remap[0] = 0;
+  remap[1] = 1;
+  int m_states = 2;
+  for (int s = 0; s < n_states; s++)
+    if (remap[part[s]] < 0) remap[part[s]] = m_states++;
+  std::vector<uint16_t> mtable((size_t)m_states * ncls, 0);
+  std::vector<uint8_t> macc(m_states, 0);
+  for (int c = 0; c < ncls; c++) mtable[(size_t)ncls + c] = 1;
+  macc[1] = 1;
+  for (int s = 2; s < n_states; s++) {
+    const int q = remap[part[s]];
+    macc[q] = acc_end[s];
+    for (int c = 0; c < ncls; c++) mtable[(size_t)q * ncls + c] = (uint16_t)remap[part[table[(size_t)s * ncls + c]]];
+  }
+  // merge identical columns
+  std::map<std::vector<uint16_t>, int> col_ids;
+  std::vector<int> cls_map(ncls);
+  for (int c = 0; c < ncls; c++) {
+    std::vector<uint16_t> col(m_states);
+    for (int q = 0; q < m_states; q++) col[q] = mtable[(size_t)q * ncls + c];
+    auto it = col_ids.find(col);
+    if (it == col_ids.end()) it = col_ids.emplace(col, (int)col_ids.size()).first;
+    cls_map[c] = it->second;
+  }
+  const int m_cls = (int)col_ids.size();
+  std::vector<uint16_t> ftable((size_t)m_states * m_cls);
+  for (int q = 0; q < m_states; q++)
+    for (int c = 0; c < ncls; c++) ftable[(size_t)q * m_cls + cls_map[c]] = mtable[(size_t)q * ncls + c];
+  for (int b = 0; b < 256; b++) out->byte_class[b] = (uint8_t)cls_map[out->byte_class[b]];
+  out->n_states = (uint32_t)m_states;
+  out->n_classes = (uint32_t)m_cls;
+  out->start = alive[start_id] ? (uint32_t)remap[part[start_id]] : 0u;
+  out->table = ftable;
+  out->accept_at_end = macc;
   return kOk;
 }
 
