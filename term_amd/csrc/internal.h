@@ -16,27 +16,25 @@
 namespace tgx {
 
 // ---- kernel launchers (defined in kernels/*.hip) ----------------------------------------------
-void launch_scan_pivot(const ScanColDesc *d_cols, int n_cols, double *d_pivots, int32_t *d_pivot_set,
-                       const int32_t *d_acc_index, hipStream_t stream);
-void launch_scan_main_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
-                           ScanPartial *d_partials, hipStream_t stream);
-void launch_scan_reduce_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
-                             ScanPartial *d_partials, ScanAcc *d_accs, const int32_t *d_acc_index,
-                             hipStream_t stream);
-void launch_count(const CountColDesc *d_cols, int n_cols, int blocks_per_col,
-                  unsigned long long *d_block_counts, CountAcc *d_accs, const int32_t *d_acc_index,
-                  hipStream_t stream);
+void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set, hipStream_t stream);
+void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
+                           hipStream_t stream);
+void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
+                             ScanAcc *d_accs, hipStream_t stream);
+void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,
+                  CountAcc *d_accs, hipStream_t stream);
 size_t comoments_partial_bytes();
-void launch_comoments(const ComomentColDesc *d_descs, int n_pairs, int blocks_per_pair,
-                      void *d_partials, ComomentAcc *d_accs, const int32_t *d_acc_index,
-                      hipStream_t stream);
+void launch_comoments(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, void *d_partials,
+                      ComomentAcc *d_accs, hipStream_t stream);
 void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
 void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, hipStream_t stream);
-hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
-                               hipStream_t stream);
+hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters, hipStream_t stream);
+void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
+                         uint64_t slice_words, uint32_t *out_seen, uint32_t *out_twice,
+                         unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
@@ -48,9 +46,6 @@ void launch_hash_export_count128(const HashSetView &src, uint32_t world, unsigne
                                  hipStream_t stream);
 void launch_hash_export_scatter128(const HashSetView &src, uint32_t world, int want_mult,
                                    unsigned long long *d_cursors, KeyRecord128 *out, hipStream_t stream);
-void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
-                         uint64_t slice_words, uint32_t *out_seen, uint32_t *out_twice,
-                         unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_rehash(const HashSetView &src, const HashSetView &dst, int want_mult,
                         unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_to_hash(const BitmapView &bm, const HashSetView &dst, int want_mult,
@@ -204,9 +199,7 @@ struct tgx_state {
   // device accumulators
   tgx::DevBuf d_scan_acc, d_count_acc, d_como_acc, d_pivots, d_pivot_set;
   // per-update scratch
-  tgx::DevBuf d_scan_desc, d_scan_index, d_scan_partials;
-  tgx::DevBuf d_count_desc, d_count_index, d_count_blocks;
-  tgx::DevBuf d_como_desc, d_como_index, d_como_partials;
+  tgx::DevBuf d_scan_partials, d_count_blocks, d_como_partials;
   std::vector<std::unique_ptr<tgx::DevBuf>> staging;  // host columns copied to the device
   size_t staging_used = 0;
 

@@ -31,9 +31,9 @@ __device__ __forceinline__ bool cm_valid(global_u8_ptr v, int64_t bit) {
   return v == nullptr ? true : ((v[bit >> 3] >> (bit & 7)) & 1) != 0;
 }
 
-__global__ __launch_bounds__(256) void comoments_kernel(const ComomentColDesc *__restrict__ descs,
+__global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
                                                          ComomentPartial *__restrict__ partials) {
-  const ComomentColDesc d = descs[blockIdx.y];
+  const ComomentColDesc d = L.pairs[blockIdx.y];
   global_i64_ptr x = (global_i64_ptr)(uintptr_t)((const int64_t *)d.x + d.xoff);
   global_i64_ptr y = (global_i64_ptr)(uintptr_t)((const int64_t *)d.y + d.yoff);
   global_u8_ptr xv = (global_u8_ptr)(uintptr_t)d.xv;
@@ -102,13 +102,13 @@ __global__ __launch_bounds__(256) void comoments_kernel(const ComomentColDesc *_
 }
 
 __global__ __launch_bounds__(64) void comoments_reduce_kernel(
-    const ComomentColDesc *__restrict__ descs, const ComomentPartial *__restrict__ partials,
-    int blocks_per_pair, ComomentAcc *__restrict__ accs, const int32_t *__restrict__ acc_index) {
+    const ComomentLaunch L, const ComomentPartial *__restrict__ partials, int blocks_per_pair,
+    ComomentAcc *__restrict__ accs) {
   const int pair = blockIdx.x;
   if (threadIdx.x != 0) return;
   // serial fixed-order fold: <= 2048 partials, deterministic
-  ComomentAcc &a = accs[acc_index[pair]];
-  a.total += descs[pair].length;
+  ComomentAcc &a = accs[L.acc_index[pair]];
+  a.total += L.pairs[pair].length;
   for (int i = 0; i < blocks_per_pair; i++) {
     const ComomentPartial &p = partials[(size_t)pair * blocks_per_pair + i];
     a.n += p.n;
@@ -121,13 +121,12 @@ __global__ __launch_bounds__(64) void comoments_reduce_kernel(
 
 size_t comoments_partial_bytes() { return sizeof(ComomentPartial); }
 
-void launch_comoments(const ComomentColDesc *d_descs, int n_pairs, int blocks_per_pair,
-                      void *d_partials, ComomentAcc *d_accs, const int32_t *d_acc_index,
-                      hipStream_t stream) {
-  hipLaunchKernelGGL(comoments_kernel, dim3(blocks_per_pair, n_pairs), dim3(256), 0, stream, d_descs,
+void launch_comoments(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, void *d_partials,
+                      ComomentAcc *d_accs, hipStream_t stream) {
+  hipLaunchKernelGGL(comoments_kernel, dim3(blocks_per_pair, n_pairs), dim3(256), 0, stream, L,
                      (ComomentPartial *)d_partials);
-  hipLaunchKernelGGL(comoments_reduce_kernel, dim3(n_pairs), dim3(64), 0, stream, d_descs,
-                     (const ComomentPartial *)d_partials, blocks_per_pair, d_accs, d_acc_index);
+  hipLaunchKernelGGL(comoments_reduce_kernel, dim3(n_pairs), dim3(64), 0, stream, L,
+                     (const ComomentPartial *)d_partials, blocks_per_pair, d_accs);
 }
 
 }  // namespace tgx

@@ -48,11 +48,24 @@ struct ScanAcc {
   int32_t pad;
 };
 
+// Launch descriptors travel BY VALUE in the kernel-argument segment (no host->device copy, no
+// synchronisation per batch, nothing to keep alive): at most kMaxColsPerLaunch columns per launch.
+constexpr int kMaxColsPerLaunch = 24;
+struct ScanLaunch {
+  ScanColDesc cols[kMaxColsPerLaunch];
+  int32_t acc_index[kMaxColsPerLaunch];  // running-state slot of each column
+};
+
 // Validity-only columns (COUNT(*), COUNT(col)).
 struct CountColDesc {
   const uint8_t *validity;  // never nullptr here (no-validity columns are answered on the host)
   int64_t offset;
   int64_t length;
+};
+
+struct CountLaunch {
+  CountColDesc cols[kMaxColsPerLaunch];
+  int32_t acc_index[kMaxColsPerLaunch];
 };
 
 struct CountAcc {
@@ -67,6 +80,11 @@ struct ComomentColDesc {
   int64_t xoff, yoff;
   int64_t length;
   int32_t x_is_float, y_is_float;
+};
+
+struct ComomentLaunch {
+  ComomentColDesc pairs[kMaxColsPerLaunch];
+  int32_t acc_index[kMaxColsPerLaunch];
 };
 
 struct ComomentAcc {

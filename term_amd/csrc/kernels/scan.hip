@@ -270,9 +270,9 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
 }
 
 template <int VARIANT>
-__global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanColDesc *__restrict__ cols,
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanLaunch L,
                                                            ScanPartial *__restrict__ partials) {
-  const ScanColDesc c = cols[blockIdx.y];
+  const ScanColDesc c = L.cols[blockIdx.y];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   ScanPartial *out = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -291,14 +291,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanColDesc *__r
 
 // Folds the per-block partials of each column (fixed order => bitwise reproducible) and merges
 // the batch into the running per-column state.  grid = columns, block = 64 (one wave).
-__global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanColDesc *__restrict__ cols,
+__global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
                                                           const ScanPartial *__restrict__ partials,
                                                           int blocks_per_col,
-                                                          ScanAcc *__restrict__ accs,
-                                                          const int32_t *__restrict__ acc_index) {
+                                                          ScanAcc *__restrict__ accs) {
   const int col = blockIdx.x;
   const int lane = threadIdx.x;
-  const ScanColDesc c = cols[col];
+  const ScanColDesc c = L.cols[col];
   const ScanPartial *p = partials + (size_t)col * blocks_per_col;
   LaneAcc a;
   acc_init(a);
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanColDesc *__re
     acc_merge(a, b, c.is_float);
   }
   if (lane == 0) {
-    ScanAcc &s = accs[acc_index[col]];
+    ScanAcc &s = accs[L.acc_index[col]];
     s.is_float = c.is_float;
     s.total += c.length;
     s.non_null += a.cnt;
@@ -359,13 +358,12 @@ __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanColDesc *__re
 // Picks the variance pivot of a column: the mean of (up to) the first 256 valid values of the first
 // batch.  Any finite pivot gives the right answer; one near the data keeps s2 - s1^2/n well
 // conditioned.  A pivot that is already set (later batches) is kept.
-__global__ __launch_bounds__(256) void scan_pivot_kernel(const ScanColDesc *__restrict__ cols,
+__global__ __launch_bounds__(256) void scan_pivot_kernel(const ScanLaunch L,
                                                           double *__restrict__ pivots,
-                                                          int32_t *__restrict__ pivot_set,
-                                                          const int32_t *__restrict__ acc_index) {
-  const ScanColDesc c = cols[blockIdx.x];
+                                                          int32_t *__restrict__ pivot_set) {
+  const ScanColDesc c = L.cols[blockIdx.x];
   if (!c.want_variance) return;
-  const int slot = acc_index[blockIdx.x];
+  const int slot = L.acc_index[blockIdx.x];
   if (pivot_set[slot]) return;
   __shared__ double s_sum[256];
   __shared__ int s_cnt[256];
@@ -406,9 +404,9 @@ __global__ __launch_bounds__(256) void scan_pivot_kernel(const ScanColDesc *__re
 // ---------------------------------------------------------------------------------------------
 // COUNT(*) / COUNT(col) for columns whose values are not needed: popcount of the validity bits.
 // grid = (blocks, columns).  Reads ceil(n/8) bytes per column.
-__global__ __launch_bounds__(256) void count_kernel(const CountColDesc *__restrict__ cols,
+__global__ __launch_bounds__(256) void count_kernel(const CountLaunch L,
                                                      unsigned long long *__restrict__ block_counts) {
-  const CountColDesc c = cols[blockIdx.y];
+  const CountColDesc c = L.cols[blockIdx.y];
   const int64_t bit0 = c.offset, bit1 = c.offset + c.length;
   // words of the 8-byte aligned bitmap view that intersect [bit0, bit1)
   const uintptr_t base = (uintptr_t)c.validity;
@@ -434,11 +432,10 @@ __global__ __launch_bounds__(256) void count_kernel(const CountColDesc *__restri
         (unsigned long long)(s[0] + s[1] + s[2] + s[3]);
 }
 
-__global__ __launch_bounds__(64) void count_reduce_kernel(const CountColDesc *__restrict__ cols,
+__global__ __launch_bounds__(64) void count_reduce_kernel(const CountLaunch L,
                                                            const unsigned long long *__restrict__ bc,
                                                            int blocks_per_col,
-                                                           CountAcc *__restrict__ accs,
-                                                           const int32_t *__restrict__ acc_index) {
+                                                           CountAcc *__restrict__ accs) {
   const int col = blockIdx.x;
   int64_t cnt = 0;
   for (int i = threadIdx.x; i < blocks_per_col; i += 64)
@@ -446,54 +443,37 @@ __global__ __launch_bounds__(64) void count_reduce_kernel(const CountColDesc *__
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) cnt += shfl_down_i64(cnt, d);
   if (threadIdx.x == 0) {
-    CountAcc &a = accs[acc_index[col]];
-    a.total += cols[col].length;
+    CountAcc &a = accs[L.acc_index[col]];
+    a.total += L.cols[col].length;
     a.non_null += cnt;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// host launchers (called from tgx_api.cpp)
-void launch_scan(const ScanColDesc *d_cols, int n_cols, int blocks_per_col, ScanPartial *d_partials,
-                 ScanAcc *d_accs, const int32_t *d_acc_index, double *d_pivots, int32_t *d_pivot_set,
-                 bool any_variance, hipStream_t stream) {
-  if (any_variance)
-    hipLaunchKernelGGL(scan_pivot_kernel, dim3(n_cols), dim3(256), 0, stream, d_cols, d_pivots,
-                       d_pivot_set, d_acc_index);
-  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, d_cols,
-                     d_partials);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, d_cols, d_partials,
-                     blocks_per_col, d_accs, d_acc_index);
+// host launchers (called from tgx_api.cpp); `n_cols` <= kMaxColsPerLaunch
+void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(scan_pivot_kernel, dim3(n_cols), dim3(256), 0, stream, L, d_pivots, d_pivot_set);
 }
 
-void launch_scan_main_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
-                           ScanPartial *d_partials, hipStream_t stream) {
+void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
+                           hipStream_t stream) {
   // VARIANT bit 0 = nontemporal loads, bit 1 = next tile requested before the current one is consumed.
   // Measured at 1 G rows x 16 columns (ms per launch): 0: 21.11, 1: 20.95, 2: 21.24, 3: 20.74 -> 3.
-  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, d_cols,
-                     d_partials);
+  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, L, d_partials);
 }
 
-void launch_scan_reduce_only(const ScanColDesc *d_cols, int n_cols, int blocks_per_col,
-                             ScanPartial *d_partials, ScanAcc *d_accs, const int32_t *d_acc_index,
-                             hipStream_t stream) {
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, d_cols, d_partials,
-                     blocks_per_col, d_accs, d_acc_index);
+void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
+                             ScanAcc *d_accs, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, L, d_partials, blocks_per_col,
+                     d_accs);
 }
 
-void launch_scan_pivot(const ScanColDesc *d_cols, int n_cols, double *d_pivots, int32_t *d_pivot_set,
-                       const int32_t *d_acc_index, hipStream_t stream) {
-  hipLaunchKernelGGL(scan_pivot_kernel, dim3(n_cols), dim3(256), 0, stream, d_cols, d_pivots,
-                     d_pivot_set, d_acc_index);
-}
-
-void launch_count(const CountColDesc *d_cols, int n_cols, int blocks_per_col,
-                  unsigned long long *d_block_counts, CountAcc *d_accs, const int32_t *d_acc_index,
-                  hipStream_t stream) {
-  hipLaunchKernelGGL(count_kernel, dim3(blocks_per_col, n_cols), dim3(256), 0, stream, d_cols,
-                     d_block_counts);
-  hipLaunchKernelGGL(count_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, d_cols, d_block_counts,
-                     blocks_per_col, d_accs, d_acc_index);
+void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,
+                  CountAcc *d_accs, hipStream_t stream) {
+  hipLaunchKernelGGL(count_kernel, dim3(blocks_per_col, n_cols), dim3(256), 0, stream, L, d_block_counts);
+  hipLaunchKernelGGL(count_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, L, d_block_counts,
+                     blocks_per_col, d_accs);
 }
 
 }  // namespace tgx

@@ -932,28 +932,32 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         index.push_back((int32_t)s);
         bytes += (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
       }
-      if (!descs.empty()) {
-        const int n = (int)descs.size();
+      // launches of <= kMaxColsPerLaunch columns; descriptors travel in the kernel arguments
+      for (size_t c0 = 0; c0 < descs.size(); c0 += kMaxColsPerLaunch) {
+        const int n = (int)std::min<size_t>(kMaxColsPerLaunch, descs.size() - c0);
+        ScanLaunch L;
+        memset(&L, 0, sizeof(L));
         int blocks = 1;
-        for (auto &d : descs) blocks = std::max(blocks, scan_blocks_for(d, n));
-        HIP_TRY(st->d_scan_desc.reserve(n * sizeof(ScanColDesc)));
-        HIP_TRY(st->d_scan_index.reserve(n * sizeof(int32_t)));
-        HIP_TRY(st->d_scan_partials.reserve((size_t)n * blocks * sizeof(ScanPartial)));
-        // descriptors are tiny; a blocking copy keeps the host vectors' lifetime trivial
-        HIP_TRY(hipMemcpyAsync(st->d_scan_desc.p, descs.data(), n * sizeof(ScanColDesc), hipMemcpyHostToDevice, st->stream));
-        HIP_TRY(hipMemcpyAsync(st->d_scan_index.p, index.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st->stream));
-        HIP_TRY(hipStreamSynchronize(st->stream));
-        if (any_var)
-          launch_scan_pivot(st->d_scan_desc.as<ScanColDesc>(), n, st->d_pivots.as<double>(),
-                            st->d_pivot_set.as<int32_t>(), st->d_scan_index.as<int32_t>(), st->stream);
-        {
-          ProfScope ps(st, "scan", bytes);
-          launch_scan_main_only(st->d_scan_desc.as<ScanColDesc>(), n, blocks, st->d_scan_partials.as<ScanPartial>(),
-                                st->stream);
+        uint64_t chunk_bytes = 0;
+        bool chunk_var = false;
+        for (int k = 0; k < n; k++) {
+          L.cols[k] = descs[c0 + k];
+          L.acc_index[k] = index[c0 + k];
+          blocks = std::max(blocks, scan_blocks_for(L.cols[k], n));
+          chunk_bytes += (uint64_t)L.cols[k].length * 8 + (L.cols[k].validity ? (uint64_t)(L.cols[k].length + 7) / 8 : 0);
+          chunk_var |= L.cols[k].want_variance != 0;
         }
-        launch_scan_reduce_only(st->d_scan_desc.as<ScanColDesc>(), n, blocks, st->d_scan_partials.as<ScanPartial>(),
-                                st->d_scan_acc.as<ScanAcc>(), st->d_scan_index.as<int32_t>(), st->stream);
+        HIP_TRY(st->d_scan_partials.reserve((size_t)n * blocks * sizeof(ScanPartial)));
+        if (chunk_var) launch_scan_pivot(L, n, st->d_pivots.as<double>(), st->d_pivot_set.as<int32_t>(), st->stream);
+        {
+          ProfScope ps(st, "scan", chunk_bytes);
+          launch_scan_main_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->stream);
+        }
+        launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
+                                st->stream);
       }
+      (void)any_var;
+      (void)bytes;
     }
     // ---- validity-only columns ----
     {
@@ -973,20 +977,23 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         bytes += (uint64_t)(c.length + 7) / 8;
         max_words = std::max<int64_t>(max_words, (c.length + 63) / 64 + 1);
       }
-      if (!descs.empty()) {
-        const int n = (int)descs.size();
+      for (size_t c0 = 0; c0 < descs.size(); c0 += kMaxColsPerLaunch) {
+        const int n = (int)std::min<size_t>(kMaxColsPerLaunch, descs.size() - c0);
+        CountLaunch L;
+        memset(&L, 0, sizeof(L));
+        uint64_t chunk_bytes = 0;
+        for (int k = 0; k < n; k++) {
+          L.cols[k] = descs[c0 + k];
+          L.acc_index[k] = index[c0 + k];
+          chunk_bytes += (uint64_t)(L.cols[k].length + 7) / 8;
+        }
         int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (max_words + 256 * 4 - 1) / (256 * 4)),
                                             std::max(8, (g_ctx.n_cu * 8) / n));
-        HIP_TRY(st->d_count_desc.reserve(n * sizeof(CountColDesc)));
-        HIP_TRY(st->d_count_index.reserve(n * sizeof(int32_t)));
         HIP_TRY(st->d_count_blocks.reserve((size_t)n * blocks * sizeof(unsigned long long)));
-        HIP_TRY(hipMemcpyAsync(st->d_count_desc.p, descs.data(), n * sizeof(CountColDesc), hipMemcpyHostToDevice, st->stream));
-        HIP_TRY(hipMemcpyAsync(st->d_count_index.p, index.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st->stream));
-        HIP_TRY(hipStreamSynchronize(st->stream));
-        ProfScope ps(st, "count", bytes);
-        launch_count(st->d_count_desc.as<CountColDesc>(), n, blocks, st->d_count_blocks.as<unsigned long long>(),
-                     st->d_count_acc.as<CountAcc>(), st->d_count_index.as<int32_t>(), st->stream);
+        ProfScope ps(st, "count", chunk_bytes);
+        launch_count(L, n, blocks, st->d_count_blocks.as<unsigned long long>(), st->d_count_acc.as<CountAcc>(), st->stream);
       }
+      (void)bytes;
     }
     // ---- co-moments ----
     if (!plan->como.empty()) {
@@ -1012,18 +1019,20 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         bytes += (uint64_t)x.length * 16 + (x.validity ? (uint64_t)(x.length + 7) / 8 : 0) +
                  (y.validity ? (uint64_t)(y.length + 7) / 8 : 0);
       }
-      const int n = (int)descs.size();
-      int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (nrows + 256 * 16 - 1) / (256 * 16)),
-                                          std::max(32, (g_ctx.n_cu * 8) / n));
-      HIP_TRY(st->d_como_desc.reserve(n * sizeof(ComomentColDesc)));
-      HIP_TRY(st->d_como_index.reserve(n * sizeof(int32_t)));
-      HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
-      HIP_TRY(hipMemcpyAsync(st->d_como_desc.p, descs.data(), n * sizeof(ComomentColDesc), hipMemcpyHostToDevice, st->stream));
-      HIP_TRY(hipMemcpyAsync(st->d_como_index.p, index.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st->stream));
-      HIP_TRY(hipStreamSynchronize(st->stream));
-      ProfScope ps(st, "comoments", bytes);
-      launch_comoments(st->d_como_desc.as<ComomentColDesc>(), n, blocks, st->d_como_partials.p,
-                       st->d_como_acc.as<ComomentAcc>(), st->d_como_index.as<int32_t>(), st->stream);
+      for (size_t c0 = 0; c0 < descs.size(); c0 += kMaxColsPerLaunch) {
+        const int n = (int)std::min<size_t>(kMaxColsPerLaunch, descs.size() - c0);
+        ComomentLaunch L;
+        memset(&L, 0, sizeof(L));
+        for (int k = 0; k < n; k++) {
+          L.pairs[k] = descs[c0 + k];
+          L.acc_index[k] = index[c0 + k];
+        }
+        int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (nrows + 256 * 16 - 1) / (256 * 16)),
+                                            std::max(32, (g_ctx.n_cu * 8) / n));
+        HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
+        ProfScope ps(st, "comoments", bytes * n / descs.size());
+        launch_comoments(L, n, blocks, st->d_como_partials.p, st->d_como_acc.as<ComomentAcc>(), st->stream);
+      }
     }
     // ---- exact distinct ----
     for (size_t s = 0; s < plan->distinct.size(); s++)
