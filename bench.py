@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the N>1 code path (range agreement, bitmap-slice exchange, all-gather merge) even "
+                         "with one rank: a self-test of the multi-GPU step on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,11 +89,13 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    distributed = world > 1 or args.force_distributed
+    if distributed:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -103,7 +108,7 @@ def main():
     specs = build_suite(T, spec, layout, unique_cols)
     n_stats = sum(1 for s in specs if s.kind != T.DISTINCT)
     stream = torch.cuda.Stream()
-    if world == 1:
+    if not distributed:
         # one fused plan: every column buffer is read by one scan; the unique columns feed the distinct pass
         plan = T.Plan(specs)
         st = T.State(plan, stream=stream.cuda_stream)
@@ -125,7 +130,7 @@ def main():
     def step():
         st.reset()
         st.update(columns)
-        if world == 1:
+        if not distributed:
             return st.finalize()
         local = st.finalize()
         st_d.reset()
@@ -144,7 +149,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -152,7 +157,7 @@ def main():
         res = step()
     st.profile_enable(True)
     st.profile_reset()
-    if world > 1:
+    if distributed:
         st_d.profile_enable(True)
         st_d.profile_reset()
     fence()
@@ -161,12 +166,12 @@ def main():
         res = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = st.profile_get("scan")
-    prof_d = (st if world == 1 else st_d).profile_get("distinct")
+    prof_d = (st_d if distributed else st).profile_get("distinct")
     st.profile_enable(False)
 
     # ---- verification outside the timed region: closed-form facts of the synthetic table ----
@@ -228,10 +233,16 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, layout, unique_cols, table,
                                                min(args.cpu_sample_rows, n_local))
-        print(json.dumps(out))
-    if world > 1:
+        line = json.dumps(out)
+    else:
+        line = None
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the ONE JSON line, last thing on stdout (RCCL prints its version banner on teardown)
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
