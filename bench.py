@@ -85,7 +85,7 @@ def main():
     import term_amd as T
     from term_amd import synth
     from term_amd._lib import spec
-    from term_amd.distributed import agree_on_ranges, allgather_merge, exchange_distinct_auto
+    from term_amd.distributed import agree_on_ranges, allgather_many, exchange_distinct_auto, merge_blobs
 
     torch.cuda.set_device(local_rank)
     dist = None
@@ -138,13 +138,14 @@ def main():
         for s in specs[n_stats:]:
             r = next(x for sp, x in zip(specs[:n_stats], local) if sp.kind == T.NUMERIC_STATS and sp.column == s.column)
             minmax.append((bool(r.has_value) and not r.is_float, r.min_i, r.max_i))
-        for j, rng in enumerate(agree_on_ranges(minmax, dist)):
+        for j, rng in enumerate(agree_on_ranges(minmax, dist, world)):
             if rng is not None:
                 st_d.distinct_range_hint(j, rng[0], rng[1])
         st_d.update(columns)
         exchange_distinct_auto(st_d, list(range(len(specs) - n_stats)), dist, world, rank)
-        merged = allgather_merge(plan, st, dist, world, device="cuda")
-        merged_d = allgather_merge(plan_d, st_d, dist, world, device="cuda")
+        per_rank = allgather_many([st.serialize(), st_d.serialize()], dist, world, device="cuda")
+        merged = merge_blobs(plan, [p[0] for p in per_rank])
+        merged_d = merge_blobs(plan_d, [p[1] for p in per_rank])
         return merged.finalize() + merged_d.finalize()
 
     def fence():
