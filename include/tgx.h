@@ -138,7 +138,7 @@ typedef struct tgx_result {
   double var_samp, stddev_samp;
   /* DISTINCT */
   int64_t distinct;     /* COUNT(DISTINCT col) */
-  int64_t groups_once;  /* SUM(CASE WHEN cnt = 1 ...) over GROUP BY col */
+  int64_t groups_once;  /* SUM(CASE WHEN cnt = 1 ...) over GROUP BY col; only with TGX_FLAG_MULTIPLICITY, else 0 */
   /* REGEX_MATCH */
   int64_t matches;
   /* COMOMENTS */

@@ -1195,7 +1195,10 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
         r->non_null = (int64_t)t.non_null;
         r->distinct = (int64_t)t.distinct;
         // groups with cnt == 1: keys seen exactly once, plus the NULL group when it has one row
-        r->groups_once = (int64_t)(t.distinct - t.twice) + ((t.total - t.non_null) == 1 ? 1 : 0);
+        // (only tracked when the spec asks for TGX_FLAG_MULTIPLICITY; 0 otherwise)
+        r->groups_once = plan->distinct[b.slot].multiplicity
+                             ? (int64_t)(t.distinct - t.twice) + ((t.total - t.non_null) == 1 ? 1 : 0)
+                             : 0;
         break;
       }
       case TGX_CHECK_COMOMENTS: {

@@ -1,0 +1,98 @@
+"""-m gpu: BASELINE.json configs[1] at full size (100 M rows x 8 Int64/Float64 columns, null + range + unique
+suite) checked through size-independent properties -- the oracle cannot cover 100 M rows in seconds:
+closed forms of the synthetic table, additivity over row ranges (merge of shards == whole), idempotence of
+re-inserting the same rows into a key set."""
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+import term_amd as T
+from _lib_spec import spec
+from term_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N = 100_000_000
+LAYOUT = [("id_perm", False), ("k_mod10", True), ("i_wide", True), ("i_small", True),
+          ("f_uniform", True), ("f_normal", True), ("f_expo", True), ("f_uniform", False)]
+
+
+def columns_of(table, lo=0, n=N):
+    cols = []
+    for (kind, _), (vals, validity) in zip(LAYOUT, table):
+        ctor = T.Column.float64 if kind.startswith("f_") else T.Column.int64
+        cols.append(ctor(vals, validity, length=n, offset=lo))
+    return cols
+
+
+def test_c2_null_range_unique_suite_at_100m_rows():
+    import torch
+
+    T.init(distinct_capacity_hint=N)
+    table = synth.make_table(LAYOUT, 0, N, N, 0x7E570002, "cuda")
+    specs = []
+    for ci in range(len(LAYOUT)):
+        specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci, flags=T.FLAG_VARIANCE)]
+    specs += [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.DISTINCT, 1), spec(T.DISTINCT, 3)]
+    plan = T.Plan(specs)
+    whole = T.State(plan)
+    whole.update(columns_of(table))
+    res = whole.finalize()
+    cnt = {ci: res[2 * ci] for ci in range(8)}
+    st = {ci: res[2 * ci + 1] for ci in range(8)}
+    d_id, d_k, d_small = res[16], res[17], res[18]
+    # ---- closed forms
+    assert all(cnt[ci].total == N and st[ci].total == N for ci in range(8))
+    assert cnt[0].non_null == N and cnt[7].non_null == N
+    for ci in (1, 2, 3, 4, 5, 6):
+        assert abs(cnt[ci].non_null / N - 0.95) < 2e-4 and cnt[ci].non_null == st[ci].non_null
+    assert (st[0].min_i, st[0].max_i, st[0].sum_i) == (0, N - 1, N * (N - 1) // 2)
+    assert st[0].mean == (N - 1) / 2 and abs(st[0].var_samp - N * (N + 1) / 12) < 1e-9 * N * N
+    assert (d_id.distinct, d_id.groups_once, d_id.non_null) == (N, N, N)      # bijective id: uniqueness 1.0
+    assert 0 <= st[1].min_i and st[1].max_i < N // 10 and d_k.distinct <= N // 10
+    assert d_k.distinct > 0.99 * (N // 10)                                     # ~9.5 draws per key: almost all keys hit
+    assert (st[3].min_i, st[3].max_i, d_small.distinct) == (-500, 499, 1000)
+    assert 0.0 <= st[4].min_f and st[4].max_f < 1000.0 and abs(st[4].mean - 500.0) < 0.2
+    assert abs(st[5].mean) < 1e-3 and abs(st[5].stddev_samp - 1.0) < 1e-3
+    assert st[6].min_f >= 0.0 and abs(st[6].mean - 50.0) < 0.05
+    # ---- a sample of the same table against the oracle (first 2 M rows), bit-exact / 1e-6
+    m = 2_000_000
+    sample = T.State(plan)
+    sample.update(columns_of(table, 0, m))
+    rs = sample.finalize()
+    for ci, (kind, has_validity) in enumerate(LAYOUT):
+        vals = table[ci][0][:m].cpu().numpy()
+        validity = table[ci][1][: m // 8 + 64].cpu().numpy() if has_validity else None
+        o = orc.stats(np.ascontiguousarray(vals), validity, n=m)
+        r = rs[2 * ci + 1]
+        assert r.non_null == o.non_null
+        if kind.startswith("f_"):
+            assert (r.min_f, r.max_f) == (o.min_f, o.max_f) and abs(r.sum_f - o.sum_hi) <= 1e-6 * abs(o.sum_hi)
+        else:
+            assert (r.min_i, r.max_i, r.sum_i) == (o.min_i, o.max_i, o.sum_i_wrapping)
+        assert abs(r.var_samp - o.var_samp) <= 1e-6 * o.var_samp
+    od = orc.distinct_bits64(np.ascontiguousarray(table[1][0][:m].cpu().numpy()).view(np.uint64),
+                             table[1][1][: m // 8 + 64].cpu().numpy(), n=m)
+    assert rs[17].distinct == od.distinct
+    # ---- additivity: three ragged row ranges merged == the whole (AnalyzerState::merge, exact for DISTINCT)
+    cuts = [0, 33_333_312, 70_000_064, N]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p = T.State(plan)
+        p.update(columns_of(table, lo, hi - lo))
+        parts.append(p)
+    parts[0].merge(parts[1:])
+    rm = parts[0].finalize()
+    for a, b in zip(res, rm):
+        assert (a.total, a.non_null, a.min_i, a.max_i, a.sum_i, a.distinct, a.groups_once) == \
+            (b.total, b.non_null, b.min_i, b.max_i, b.sum_i, b.distinct, b.groups_once)
+        assert (a.min_f, a.max_f) == (b.min_f, b.max_f) or (np.isnan(a.min_f) and np.isnan(b.min_f))
+        assert abs(a.sum_f - b.sum_f) <= 1e-12 * max(1.0, abs(a.sum_f))
+        assert abs(a.var_samp - b.var_samp) <= 1e-9 * max(1.0, abs(a.var_samp)) or a.kind != T.NUMERIC_STATS
+    # ---- idempotence: feeding the same rows again changes no key set, only the row counts
+    whole.update(columns_of(table, 0, 10_000_000))
+    r2 = whole.finalize()
+    assert (r2[16].distinct, r2[17].distinct, r2[18].distinct) == (d_id.distinct, d_k.distinct, d_small.distinct)
+    assert r2[16].total == N + 10_000_000 and r2[16].groups_once == N - 10_000_000
+    del table
+    torch.cuda.empty_cache()
