@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     if (in && vbits) valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
     // the wave's values are contiguous: [b of lane 0, e of the last lane)
     const int64_t span_b = __shfl(b, 0, 64), span_e = __shfl(e, 63, 64);
-    const int64_t stage_base = span_b & ~(int64_t)15;
+    // 16-byte blocks by ABSOLUTE address: a block that holds one byte of the buffer lies in the same page, so
+    // the rounded-out copy cannot fault whatever the alignment of `data`
+    const int64_t stage_base = span_b - (int64_t)((data + (uintptr_t)span_b) & 15);
     const bool staged = span_e - stage_base <= (int64_t)kStageBytes;  // wave-uniform
     if (staged) {
       // coalesced 16-byte loads of the span into LDS (values of NULL rows included; never interpreted)

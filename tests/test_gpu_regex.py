@@ -118,3 +118,26 @@ def test_big_table_automaton_runs_from_global_memory():
     res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, pattern=pat)], [[utf8_column(offs, data, validity, True)]])
     want = orc.Regex(pat).count_utf8(offs, data, validity, null_is_valid=False)
     assert (res[0].total, res[0].matches) == (want.total, want.matches)
+
+
+def test_unaligned_buffers(golden):
+    """value bytes / offsets / validity that do not start on 16-byte boundaries (views into larger buffers)"""
+    import torch
+
+    rng = np.random.default_rng(12)
+    vals = synth_strings(rng, 20_001, "email")
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.Regex(golden["patterns"]["email"]).count_utf8(offs, data, validity, trim=True, null_is_valid=True)
+    wantd = orc.distinct_utf8(offs, data, validity)
+    for shift in (1, 3, 8, 13):
+        d = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+        d[shift:shift + len(data)] = torch.from_numpy(data).cuda()
+        v = torch.zeros(len(validity) + 64, dtype=torch.uint8, device="cuda")
+        v[shift:shift + len(validity)] = torch.from_numpy(validity).cuda()
+        o = torch.zeros(len(offs) + 8, dtype=torch.int32, device="cuda")
+        o[1:1 + len(offs)] = torch.from_numpy(offs).cuda()
+        col = T.Column(T.UTF8, len(vals), offsets=o[1:], data=d[shift:], validity=v[shift:])
+        res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, pattern=golden["patterns"]["email"],
+                                   flags=T.FLAG_TRIM | T.FLAG_NULL_IS_VALID), spec(T.DISTINCT, 0)], [[col]])
+        assert (res[0].total, res[0].matches) == (want.total, want.matches), shift
+        assert (res[1].non_null, res[1].distinct) == (wantd.non_null, wantd.distinct), shift
