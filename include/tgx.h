@@ -57,7 +57,12 @@ typedef enum tgx_type {
   TGX_FLOAT64 = 2,
   TGX_UTF8 = 3,        /* int32 offsets */
   TGX_LARGE_UTF8 = 4,  /* int64 offsets */
-  TGX_DICT32_UTF8 = 5  /* int32 indices in `values`, Utf8 dictionary in `dictionary` */
+  /* Dictionary<Int32, Utf8|LargeUtf8>: int32 indices in `values` (validity/offset/length describe the
+   * indices), the dictionary is a Utf8 column view of its own (any memory space). COUNT, DISTINCT and
+   * REGEX_MATCH give the results of the decoded column: string work runs once per dictionary entry,
+   * every batch may bring its own dictionary (unused and repeated entries allowed). A row whose dictionary
+   * VALUE is NULL is a NULL row for DISTINCT and REGEX_MATCH. */
+  TGX_DICT32_UTF8 = 5
 } tgx_type;
 
 typedef enum tgx_memspace { TGX_MEM_HOST = 0, TGX_MEM_DEVICE = 1 } tgx_memspace;
@@ -192,7 +197,7 @@ tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state *const *src
 
 /* `Analyzer::compute_metric_from_state` inputs (TG/analyzers/traits.rs:113-122): waits for the
  * stream and writes one tgx_result per spec. Ratios, thresholds, assertions and messages stay
- * on the caller's side (TG/constraints/*.rs). The state stays usable. */
+ * on the caller's side (TG/constraints/ *.rs). The state stays usable. */
 tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *state, tgx_result *results,
                         size_t n_results, tgx_error *err);
 tgx_status tgx_state_sync(tgx_state *state, tgx_error *err);

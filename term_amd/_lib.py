@@ -186,8 +186,8 @@ class Column:
     """A tgx_column view. Keeps the Python buffers alive while the view exists."""
 
     def __init__(self, type, length, values=None, validity=None, offsets=None, data=None, offset=0,
-                 null_count=-1, mem=None):
-        self._keep = (values, validity, offsets, data)
+                 null_count=-1, mem=None, dictionary=None):
+        self._keep = (values, validity, offsets, data, dictionary)
         c = _Column()
         c.type = type
         c.length = length
@@ -204,6 +204,8 @@ class Column:
                 raise ValueError("a column's buffers must all live in one memory space")
             mem = MEM_DEVICE if (spaces and spaces.pop()) else MEM_HOST
         c.mem = mem
+        if dictionary is not None:
+            c.dictionary = C.pointer(dictionary.c)
         self.c = c
 
     @staticmethod
@@ -222,8 +224,20 @@ class Column:
         return Column(UTF8, n, offsets=offsets, data=data, validity=validity, offset=offset)
 
     @staticmethod
+    def large_utf8(offsets, data, validity=None, length=None, offset=0):
+        n = (len(offsets) - 1 - offset) if length is None else length
+        return Column(LARGE_UTF8, n, offsets=offsets, data=data, validity=validity, offset=offset)
+
+    @staticmethod
+    def dict32_utf8(indices, dictionary, validity=None, length=None, offset=0):
+        """Dictionary<Int32, Utf8>: int32 `indices` into `dictionary` (a utf8 / large_utf8 Column)."""
+        n = (len(indices) - offset) if length is None else length
+        return Column(DICT32_UTF8, n, values=indices, validity=validity, offset=offset, dictionary=dictionary)
+
+    @staticmethod
     def from_arrow(arr):
-        """pyarrow Array (Int64 / Float64 / Utf8, host memory) -> Column view of its buffers."""
+        """pyarrow Array (Int64 / Float64 / Utf8 / LargeUtf8 / Dictionary<Int32, Utf8>, host memory) -> Column
+        view of its buffers."""
         import numpy as np
         import pyarrow as pa
 
@@ -243,6 +257,15 @@ class Column:
             data = view(bufs[2], np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
             return Column(UTF8, len(arr), offsets=view(bufs[1], np.int32), data=data, validity=validity,
                           offset=arr.offset, null_count=arr.null_count)
+        if pa.types.is_large_string(arr.type):
+            data = view(bufs[2], np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
+            return Column(LARGE_UTF8, len(arr), offsets=view(bufs[1], np.int64), data=data, validity=validity,
+                          offset=arr.offset, null_count=arr.null_count)
+        if (pa.types.is_dictionary(arr.type) and pa.types.is_int32(arr.type.index_type)
+                and (pa.types.is_string(arr.type.value_type) or pa.types.is_large_string(arr.type.value_type))):
+            return Column(DICT32_UTF8, len(arr), values=view(bufs[1], np.int32), validity=validity,
+                          offset=arr.offset, null_count=arr.null_count,
+                          dictionary=Column.from_arrow(arr.dictionary))
         raise TgxError(2, "unsupported Arrow type %s" % arr.type)
 
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -38,6 +39,15 @@ void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slic
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
+void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
+                            int64_t dict_length, const uint8_t *hits, int null_is_valid,
+                            unsigned long long *d_counters, hipStream_t stream);
+void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
+                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, uint32_t *usage,
+                       unsigned long long *d_counters, hipStream_t stream);
+void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+                        int64_t length, int large_offsets, int want_mult, const uint32_t *usage,
+                        const HashSetView &t, unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
@@ -176,6 +186,8 @@ struct DistinctState {
   uint64_t h_total = 0, h_non_null = 0, h_distinct = 0, h_twice = 0, h_empty_rows = 0;
   // export scratch
   DevBuf export_records, export_counts;
+  // Dictionary<Int32, Utf8> batches: per-entry reference counts (saturating at 2)
+  DevBuf dict_usage;
 };
 
 struct ProfileEntry {
@@ -202,6 +214,7 @@ struct tgx_state {
   tgx::DevBuf d_scan_partials, d_count_blocks, d_como_partials;
   std::vector<std::unique_ptr<tgx::DevBuf>> staging;  // host columns copied to the device
   size_t staging_used = 0;
+  std::deque<tgx_column> dict_views;  // device views of the dictionaries of the batch being updated
 
   // host accumulators: contributions merged in from other states / deserialized blobs
   std::vector<tgx::ScanAcc> h_scan;

@@ -125,9 +125,12 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
       }
       const uint32_t st = staged ? walk<LDS_TABLE, true>(dfa, s_table, s_class, data, b, e, stage, stage_base)
                                  : walk<LDS_TABLE, false>(dfa, s_table, s_class, data, b, e, nullptr, 0);
-      matches += (st == 1 || g_acc[st]) ? 1 : 0;
+      const bool hit = st == 1 || g_acc[st];
+      matches += hit ? 1 : 0;
+      if (d.hits) d.hits[i] = hit ? 1 : 0;
     } else if (in) {
       matches += d.null_is_valid ? 1 : 0;
+      if (d.hits) d.hits[i] = 2;
     }
     // the stage is reused by the next step of this wave
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

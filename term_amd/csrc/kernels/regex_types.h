@@ -16,6 +16,7 @@ struct RegexColDesc {
   int32_t trim;             // TRIM(col): strip U+0020 on both ends before matching
   int32_t null_is_valid;    // NULL rows count as matches
   int32_t pad;
+  uint8_t *hits;            // optional: one byte per row (1 match, 0 no match, 2 NULL row) -- dictionary columns
 };
 
 struct DfaView {

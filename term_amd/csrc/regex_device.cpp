@@ -26,6 +26,7 @@ struct RegexPlan {
 };
 struct RegexTaskState {
   DevBuf table, byte_class, accept_end, counters;
+  DevBuf dict_hits;  // Dictionary columns: one hit byte per dictionary entry of the current batch
   uint64_t h_total = 0, h_matches = 0;  // merged-in / deserialized contributions
   uint64_t total = 0;                   // rows handled on this device
 };
@@ -136,7 +137,8 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     const RegexTask &t = rp->tasks[i];
     RegexTaskState &ts = rs->tasks[i];
     const tgx_column &c = dev[t.column];
-    if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8)
+    const bool is_dict = c.type == TGX_DICT32_UTF8;
+    if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && !is_dict)
       return rfail(err, TGX_UNSUPPORTED, "REGEX_MATCH needs a Utf8 column (column %d has type %d)", t.column, c.type);
     if (!ts.table.p) {
       const rx::Dfa &d = t.dfa;
@@ -151,13 +153,17 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     }
     ts.total += (uint64_t)c.length;
     if (c.length == 0) continue;
+    // a dictionary column is matched once per ENTRY; the rows then only gather the per-entry verdicts
+    const tgx_column &sc = is_dict ? *c.dictionary : c;
+    if (is_dict) RHIP(ts.dict_hits.reserve((size_t)sc.length + 32));
     RegexColDesc d;
-    d.offsets = c.offsets;
-    d.data = c.data;
-    d.validity = c.validity;
-    d.offset = c.offset;
-    d.length = c.length;
-    d.large_offsets = c.type == TGX_LARGE_UTF8;
+    d.offsets = sc.offsets;
+    d.data = sc.data;
+    d.validity = sc.validity;
+    d.offset = sc.offset;
+    d.length = sc.length;
+    d.large_offsets = sc.type == TGX_LARGE_UTF8;
+    d.hits = is_dict ? ts.dict_hits.as<uint8_t>() : nullptr;
     d.trim = (t.flags & TGX_FLAG_TRIM) != 0;
     d.null_is_valid = (t.flags & TGX_FLAG_NULL_IS_VALID) != 0;
     d.pad = 0;
@@ -172,7 +178,15 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
       (void)hipEventRecord(e0, st->stream);
-    launch_regex(d, v, ts.counters.as<unsigned long long>(), n_cu, st->stream);
+    if (!is_dict) {
+      launch_regex(d, v, ts.counters.as<unsigned long long>(), n_cu, st->stream);
+    } else {
+      // counters[1] soaks up the per-entry match count, counters[0] receives the per-row one
+      if (sc.length > 0) launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
+      launch_dict_count_hits((const int32_t *)c.values, c.validity, c.offset, c.length, sc.length,
+                             ts.dict_hits.as<uint8_t>(), (t.flags & TGX_FLAG_NULL_IS_VALID) != 0,
+                             ts.counters.as<unsigned long long>(), st->stream);
+    }
     if (st->profiling && e0 && e1) {
       (void)hipEventRecord(e1, st->stream);
       ProfileEntry &pe = st->profile["regex"];

@@ -518,8 +518,20 @@ static bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
 static size_t validity_bytes(const tgx_column &c) { return (size_t)((c.offset + c.length + 7) / 8); }
 
 // copies a HOST column's buffers to the device; `out` is the device view
+static bool is_string(int t) { return t == TGX_UTF8 || t == TGX_LARGE_UTF8; }
+
 static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx_error *err) {
   *out = c;
+  if (c.type == TGX_DICT32_UTF8) {
+    // the dictionary is a column of its own (and may live in a different memory space than the indices)
+    st->dict_views.emplace_back();
+    tgx_column *dv = &st->dict_views.back();
+    if (c.dictionary->length == 0)
+      *dv = *c.dictionary;
+    else
+      TGX_TRY(stage_column(st, *c.dictionary, dv, err));
+    out->dictionary = dv;
+  }
   if (c.mem == TGX_MEM_DEVICE) return TGX_OK;
   if (c.mem != TGX_MEM_HOST) return fail(err, TGX_INVALID_ARGUMENT, "unknown memory space %d", c.mem);
   auto stage = [&](const void *src, size_t bytes, const void **dst) -> tgx_status {
@@ -548,6 +560,9 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
       end = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[n_off - 1] : ((const int64_t *)c.offsets)[n_off - 1];
     TGX_TRY(stage(c.data, (size_t)end, &p));
     out->data = (const uint8_t *)p;
+  } else if (c.type == TGX_DICT32_UTF8) {
+    TGX_TRY(stage(c.values, (size_t)(c.offset + c.length) * 4, &p));
+    out->values = p;
   } else {
     return fail(err, TGX_UNSUPPORTED, "column type %d is not supported", c.type);
   }
@@ -712,6 +727,28 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
                          hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
     return TGX_OK;
   }
+  if (c.type == TGX_DICT32_UTF8) {
+    // string work once per dictionary entry: count references per entry, then insert the fingerprints of the
+    // referenced entries -- identical set contents to the plain Utf8 path (kernels/dict.hip)
+    const tgx_column &dict = *c.dictionary;
+    ds.col_type = c.type;
+    ds.total_rows += c.length;
+    if (c.length == 0 || dict.length == 0) return TGX_OK;
+    if (ds.mode == DistinctMode::kUndecided) {
+      ds.mode = DistinctMode::kHash;
+      ds.wide = true;
+    }
+    TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)std::min<int64_t>(c.length, dict.length), err));
+    HIP_TRY(ds.dict_usage.reserve((size_t)dict.length * 4 + 16));
+    HIP_TRY(hipMemsetAsync(ds.dict_usage.p, 0, (size_t)dict.length * 4, st->stream));
+    ProfScope ps(st, "distinct", 0);
+    launch_dict_usage((const int32_t *)c.values, c.validity, c.offset, c.length, dict.validity, dict.offset,
+                      dict.length, ds.dict_usage.as<uint32_t>(), ds.counters.as<unsigned long long>(), st->stream);
+    launch_dict_insert(dict.offsets, dict.data, dict.validity, dict.offset, dict.length,
+                       dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, ds.dict_usage.as<uint32_t>(), hash_view(ds),
+                       ds.counters.as<unsigned long long>(), st->stream);
+    return TGX_OK;
+  }
   if (!is_numeric(c.type))
     return fail(err, TGX_UNSUPPORTED, "DISTINCT on column type %d is not supported yet", c.type);
   ds.col_type = c.type;
@@ -874,11 +911,21 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       if ((c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && !c.offsets)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets is NULL", i);
     }
+    if (c.type == TGX_DICT32_UTF8) {
+      const tgx_column *dc = c.dictionary;
+      if (!dc || !is_string(dc->type))
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: a Dictionary<Int32, Utf8> column needs a Utf8/LargeUtf8 dictionary", i);
+      if (dc->length < 0 || dc->offset < 0 || (dc->length > 0 && !dc->offsets))
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: malformed dictionary", i);
+      if (c.length > 0 && reads_values[i] && !c.values)
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: indices (values) is NULL", i);
+    }
   }
   if (nrows < 0) nrows = 0;
 
   // device views of every used column
   st->staging_used = 0;
+  st->dict_views.clear();
   std::vector<tgx_column> dev(plan->n_columns_needed);
   bool any_host = false;
   for (int i = 0; i < plan->n_columns_needed; i++) {
@@ -1297,7 +1344,7 @@ extern "C" size_t tgx_distinct_record_bytes(const tgx_plan *plan, const tgx_stat
       plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return 0;
   const DistinctState &ds = st->distinct[plan->bind[spec_index].slot];
-  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8;
+  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8 || ds.col_type == TGX_DICT32_UTF8;
   return wide ? sizeof(KeyRecord128) : sizeof(KeyRecord);
 }
 
@@ -1348,7 +1395,7 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   unsigned long long c[kNumDistinctCounters];
   TGX_TRY(distinct_read_counters(st, ds, c, err));
   const unsigned long long valid_rows = c[kCntValidRows];
-  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8;
+  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8 || ds.col_type == TGX_DICT32_UTF8;
   ds.seen.release();
   ds.twice.release();
   ds.keys.release();
