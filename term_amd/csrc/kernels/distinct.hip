@@ -14,6 +14,7 @@
 // (MI355X_MICROARCH.md "Global float atomics" / SURVEY.md section 7 notes).  Counters are
 // block-reduced first: one atomicAdd per block, not per row.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "device_types.h"
 #include "distinct_types.h"
@@ -172,9 +173,10 @@ __global__ __launch_bounds__(256) void distinct_bitmap_kernel(DistinctColDesc d,
 // loads one tile's keys + validity into registers.  Validity bytes are requested BEFORE the keys so that
 // turning them into the `ok` mask only waits for those (vmcnt retires in order) and the 16-byte key loads
 // stay in flight.
-template <int KPT>
+template <int THREADS, int KPT>
 __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, int64_t tile, bool wide,
                                                     int64_t (&key)[KPT], uint32_t &ok) {
+  constexpr int kPartitionThreads = THREADS;  // (shadows the namespace constant inside this function)
   constexpr int kTile = kPartitionThreads * KPT;
   global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)p.values + p.offset);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)p.validity;
@@ -241,9 +243,28 @@ __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, in
   }
 }
 
-template <int KPT>
-__global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionParams p,
-                                                                      unsigned long long *counters) {
+// THREADS x KPT keys per tile, up to MAXP = 2 * THREADS buckets, runs padded to PAD slots.  <1024, 32>: one
+// workgroup per CU (152 KiB of LDS); <512, 32>: two per CU, so one loads while the other sorts.
+#ifdef TGX_PARTITION_TIMING
+#define TGX_ABL(bit) if (p.pad & (bit)) { __syncthreads(); continue; }
+#define TGX_T_DECL long long t_acc[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+#define TGX_T_START t_prev = clock64();
+#define TGX_T_WAIT __builtin_amdgcn_s_waitcnt(0);
+#define TGX_T_MARK(i) { long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
+#define TGX_T_FLUSH if (threadIdx.x == 0) for (int i = 0; i < 5; i++) atomicAdd(&counters[8 + i], (unsigned long long)t_acc[i]);
+#else
+#define TGX_ABL(bit)
+#define TGX_T_DECL
+#define TGX_T_START
+#define TGX_T_WAIT
+#define TGX_T_MARK(i)
+#define TGX_T_FLUSH
+#endif
+template <int THREADS, int KPT, int PAD>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
+    PartitionParams p, unsigned long long *counters) {
+  constexpr int kPartitionThreads = THREADS;
+  constexpr uint32_t kMaxPartitions = 2 * THREADS;
   constexpr int kTile = kPartitionThreads * KPT;
   __shared__ uint32_t sorted[kTile];              // the tile, grouped by bucket
   __shared__ uint32_t hist[kMaxPartitions];       // pass 1: keys per bucket; pass 2: placement cursors
@@ -252,32 +273,44 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
   __shared__ uint32_t wave_sums[16];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
-  const uint64_t sub_mask = (1ull << p.sub_bits) - 1;
+  const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
   const bool wide = (((uintptr_t)p.values + (uintptr_t)p.offset * 8) & 15) == 0;  // 16-byte loads legal
   unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
-  int64_t key[KPT];
+  uint32_t rel[KPT];  // key - base of the tile's rows: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31)
   uint32_t ok = 0;
+  TGX_T_DECL
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    TGX_T_START
     // (requesting tile t+1 here-after, before the stores of tile t, was tried: the 64 extra live registers spill
     //  at 1024 threads/workgroup and the kernel ran 7.6 ms instead of 4.1 ms)
-    partition_load_tile<KPT>(p, tile, wide, key, ok);
+    {
+      int64_t key[KPT];
+      partition_load_tile<THREADS, KPT>(p, tile, wide, key, ok);
+      TGX_T_WAIT TGX_T_MARK(0)
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
+        if (((ok >> j) & 1) && (r >> p.sub_bits) >= p.n_buckets) {
+          // outside the declared range (only possible with a caller-supplied range hint): never inserted,
+          // counted so that tgx_finalize reports it instead of returning a wrong count
+          ok &= ~(1u << j);
+          n_out++;
+        }
+        rel[j] = (uint32_t)r;  // the 64-bit keys die here: half the registers for the rest of the tile
+      }
+    }
     for (uint32_t b = tid; b < kMaxPartitions; b += kPartitionThreads) hist[b] = 0;
     __syncthreads();  // hist is zero
-    // ---- pass 1: count keys per bucket (the keys stay in registers; nothing else is kept per key) ----
+    // ---- pass 1: count keys per bucket ----
+    TGX_ABL(32)
 #pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      const uint64_t b64 = ((uint64_t)key[j] - (uint64_t)p.base) >> p.sub_bits;
-      if (((ok >> j) & 1) && b64 >= p.n_buckets) {
-        // outside the declared range (only possible with a caller-supplied range hint): never inserted,
-        // counted so that tgx_finalize reports it instead of returning a wrong count
-        ok &= ~(1u << j);
-        n_out++;
-      }
-      if ((ok >> j) & 1) atomicAdd(&hist[(uint32_t)b64], 1u);
-    }
+    for (int j = 0; j < KPT; j++)
+      if ((ok >> j) & 1) atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
     n_valid += __builtin_popcount(ok);
     __syncthreads();
+    TGX_T_MARK(1)
+    TGX_ABL(16)
     // ---- exclusive scan of the counts (2 entries per thread) + one global reservation per touched bucket ----
     {
       const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
@@ -302,7 +335,7 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
         const uint32_t b = 2 * tid + k, h = k ? h1 : h0;
         uint32_t g = 0;
         if (h) {
-          const unsigned long long padded = (h + 15u) & ~15u;
+          const unsigned long long padded = (h + (PAD - 1u)) & ~(PAD - 1u);
           const unsigned long long at = atomicAdd(&p.cursors[b], padded);
           // cap < 2^32 (checked on the host); a run that does not fit spills as a whole
           if (at + padded > p.cap) {
@@ -317,36 +350,76 @@ __global__ __launch_bounds__(kPartitionThreads) void partition_kernel(PartitionP
       }
     }
     __syncthreads();
+    TGX_T_WAIT TGX_T_MARK(2)
+    TGX_ABL(8)
     // ---- pass 2: counting sort into LDS ----
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       if (!((ok >> j) & 1)) continue;
-      const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
-      const uint32_t pos = atomicAdd(&hist[(uint32_t)(r >> p.sub_bits)], 1u);
-      sorted[pos] = (uint32_t)(r & sub_mask);
+      const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+      sorted[pos] = rel[j] & sub_mask;
     }
     __syncthreads();
-    // ---- each wave streams whole runs out: full 64-byte chunks only ----
-    for (uint32_t b = wave; b < p.n_buckets; b += kPartitionThreads / 64) {
-      const uint32_t o = toff[b], h = toff[b + 1] - o;
-      if (h == 0) continue;
-      const uint32_t g = gbase[b];
-      if (g != 0xFFFFFFFFu) {
-        const uint32_t padded = (h + 15u) & ~15u;
-        uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;
-        for (uint32_t i = lane; i < padded; i += 64) dst[i] = i < h ? sorted[o + i] : kListPad;
-      } else {
-        for (uint32_t i = lane; i < h; i += 64) {
-          // spill: straight into the global bitmap
-          const uint64_t r = ((uint64_t)b << p.sub_bits) | sorted[o + i];
-          const uint32_t bit = 1u << (r & 31);
-          const uint32_t prev = atomicOr(&p.seen[r >> 5], bit);
-          if ((prev & bit) && p.want_multiplicity) atomicOr(&p.twice[r >> 5], bit);
+    TGX_T_MARK(3)
+    TGX_ABL(4)
+    // ---- each wave streams whole runs out, 16 bytes per lane.  The wave owns buckets wave, wave + NW, ...;
+    // lane m keeps the (offset, count, global start) of the m-th and (m+64)-th of them in registers, so a
+    // step needs no LDS round trip for the bookkeeping.  Four groups of 16 lanes take four buckets per step
+    // (a group covers 64 slots per pass; runs average kTile/P keys).  The cost of this phase is per store
+    // instruction, not per byte: 4-byte-per-lane stores of the same runs took 2.3 ms instead of 1.0 ms.
+    {
+      constexpr uint32_t NW = THREADS / 64;  // waves per workgroup
+      static_assert(kMaxPartitions / NW <= 128, "two metadata sets per lane");
+      static_assert(PAD % 4 == 0, "16-byte stores");
+      uint32_t m_o[2], m_h[2], m_g[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        const uint32_t b = (lane + 64 * s2) * NW + wave;
+        const bool in = b < p.n_buckets;
+        const uint32_t o = in ? toff[b] : 0;
+        m_o[s2] = o;
+        m_h[s2] = in ? toff[b + 1] - o : 0;
+        m_g[s2] = in ? gbase[b] : 0;
+      }
+      const uint32_t n_meta = (p.n_buckets > wave) ? (p.n_buckets - wave + NW - 1) / NW : 0;
+      const uint32_t grp = lane >> 4, sub = lane & 15;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        const uint32_t m_end = n_meta > 64u * s2 ? (n_meta - 64u * s2 < 64u ? n_meta - 64u * s2 : 64u) : 0;
+        for (uint32_t m0 = 0; m0 < m_end; m0 += 4) {
+          const uint32_t m = m0 + grp, src = m & 63;
+          const uint32_t o = __shfl(m_o[s2], src, 64), g = __shfl(m_g[s2], src, 64);
+          uint32_t h = __shfl(m_h[s2], src, 64);
+          if (m >= m_end) h = 0;
+          if (h == 0) continue;
+          const uint32_t b = (m + 64 * s2) * NW + wave;
+          if (g != 0xFFFFFFFFu) {
+            const uint32_t padded = (h + (PAD - 1u)) & ~(PAD - 1u);
+            uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;  // 16-byte aligned: cap and g are multiples of PAD
+            for (uint32_t i = 4 * sub; i < padded; i += 64) {
+              uint4 v;
+              v.x = i < h ? sorted[o + i] : kListPad;
+              v.y = i + 1 < h ? sorted[o + i + 1] : kListPad;
+              v.z = i + 2 < h ? sorted[o + i + 2] : kListPad;
+              v.w = i + 3 < h ? sorted[o + i + 3] : kListPad;
+              *(uint4 *)&dst[i] = v;
+            }
+          } else {
+            for (uint32_t i = sub; i < h; i += 16) {
+              // spill: straight into the global bitmap
+              const uint64_t r = ((uint64_t)b << p.sub_bits) | sorted[o + i];
+              const uint32_t bit = 1u << (r & 31);
+              const uint32_t prev = atomicOr(&p.seen[r >> 5], bit);
+              if ((prev & bit) && p.want_multiplicity) atomicOr(&p.twice[r >> 5], bit);
+            }
+          }
         }
       }
     }
     __syncthreads();
+    TGX_T_WAIT TGX_T_MARK(4)
   }
+  TGX_T_FLUSH
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
 }
 
@@ -375,18 +448,31 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
   if (cnt > limit) cnt = limit;
   const uint32_t *list = p.lists + (uint64_t)b * p.cap;
   // lists are made of 16-slot aligned runs, so cnt is a multiple of 4; kListPad slots are filler
-  for (uint64_t i = (uint64_t)tid * 4; i < cnt; i += (uint64_t)kPartitionThreads * 4) {
-    const uint4 k = *(const uint4 *)&list[i];
-    const uint32_t ks[4] = {k.x, k.y, k.z, k.w};
+  // four 16-byte loads in flight per lane before the first LDS atomic
+  constexpr uint64_t kStep = (uint64_t)kPartitionThreads * 4;
+  for (uint64_t i0 = (uint64_t)tid * 4; i0 < cnt; i0 += 4 * kStep) {
+    uint4 k4[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (ks[u] == kListPad) continue;
-      const uint32_t bit = 1u << (ks[u] & 31);
-      if (g_twice) {
-        const uint32_t prev = atomicOr(&l_seen[ks[u] >> 5], bit);
-        if (prev & bit) atomicOr(&l_twice[ks[u] >> 5], bit);
-      } else {
-        atomicOr(&l_seen[ks[u] >> 5], bit);
+    for (int q = 0; q < 4; q++) {
+      const uint64_t i = i0 + q * kStep;
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 v = {kListPad, kListPad, kListPad, kListPad};
+      if (i < cnt) v = __builtin_nontemporal_load((const u32x4 *)&list[i]);
+      k4[q] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t ks[4] = {k4[q].x, k4[q].y, k4[q].z, k4[q].w};
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (ks[u] == kListPad) continue;
+        const uint32_t bit = 1u << (ks[u] & 31);
+        if (g_twice) {
+          const uint32_t prev = atomicOr(&l_seen[ks[u] >> 5], bit);
+          if (prev & bit) atomicOr(&l_twice[ks[u] >> 5], bit);
+        } else {
+          atomicOr(&l_seen[ks[u] >> 5], bit);
+        }
       }
     }
   }
@@ -589,8 +675,9 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   int64_t n_tiles = (p.length + kPartitionTile - 1) / kPartitionTile;
   int grid = (int)(n_tiles < (int64_t)n_cu ? n_tiles : (int64_t)n_cu);  // 152 KiB of LDS: one workgroup per CU
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(partition_kernel<kPartitionKeysPerThread>, dim3(grid), dim3(kPartitionThreads), 0, stream,
-                     p, d_counters);
+  // (512-thread workgroups, two per CU, were measured slower: twice the runs at half the length)
+  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, 16>), dim3(grid),
+                     dim3(kPartitionThreads), 0, stream, p, d_counters);
 }
 
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
