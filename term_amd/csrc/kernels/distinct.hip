@@ -245,181 +245,187 @@ __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, in
 
 // THREADS x KPT keys per tile, up to MAXP = 2 * THREADS buckets, runs padded to PAD slots.  <1024, 32>: one
 // workgroup per CU (152 KiB of LDS); <512, 32>: two per CU, so one loads while the other sorts.
-#ifdef TGX_PARTITION_TIMING
-#define TGX_ABL(bit) if (p.pad & (bit)) { __syncthreads(); continue; }
-#define TGX_T_DECL long long t_acc[5] = {0, 0, 0, 0, 0}, t_prev = 0;
-#define TGX_T_START t_prev = clock64();
-#define TGX_T_WAIT __builtin_amdgcn_s_waitcnt(0);
-#define TGX_T_MARK(i) { long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
-#define TGX_T_FLUSH if (threadIdx.x == 0) for (int i = 0; i < 5; i++) atomicAdd(&counters[8 + i], (unsigned long long)t_acc[i]);
-#else
-#define TGX_ABL(bit)
-#define TGX_T_DECL
-#define TGX_T_START
-#define TGX_T_WAIT
-#define TGX_T_MARK(i)
-#define TGX_T_FLUSH
-#endif
-template <int THREADS, int KPT, int PAD>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
-    PartitionParams p, unsigned long long *counters) {
-  constexpr int kPartitionThreads = THREADS;
-  constexpr uint32_t kMaxPartitions = 2 * THREADS;
-  constexpr int kTile = kPartitionThreads * KPT;
-  __shared__ uint32_t sorted[kTile];              // the tile, grouped by bucket
-  __shared__ uint32_t hist[kMaxPartitions];       // pass 1: keys per bucket; pass 2: placement cursors
-  __shared__ uint32_t toff[kMaxPartitions + 1];   // exclusive prefix of the counts (toff[P] = tile total)
-  __shared__ uint32_t gbase[kMaxPartitions];      // start of the run in the bucket's global list
-  __shared__ uint32_t wave_sums[16];
+// ---- the per-tile body shared by both partition kernels -------------------------------------------------
+// THREADS x KPT keys per tile (32768 either way), up to MAXP buckets, runs padded to PAD slots.
+//   pass 1   LDS histogram of the tile's keys per bucket
+//   scan     exclusive prefix of the counts + ONE global atomicAdd per touched bucket reserving the run
+//   pass 2   counting sort of the 20-bit sub-keys into LDS      (hook `mid` runs just before it)
+//   stores   each wave streams whole runs out, 16 bytes per lane (hook `before_stores` runs just before)
+// (the hooks are where a software-pipelined caller would request the next tile; unused today)
+template <int THREADS, int KPT, int MAXP, int PAD, class MidFn, class StoreFn>
+__device__ __forceinline__ void partition_process_tile(const PartitionParams &p, uint32_t *sorted, uint32_t *hist,
+                                                       uint32_t *toff, uint32_t *gbase, uint32_t *wave_sums,
+                                                       const uint32_t (&rel)[KPT], uint64_t ok, MidFn &&mid,
+                                                       StoreFn &&before_stores) {
+  constexpr uint32_t NW = THREADS / 64;       // waves per workgroup
+  constexpr int BPT = MAXP / THREADS;         // buckets per thread in the scan
+  constexpr int NS = MAXP / (NW * 64);        // run-metadata sets per lane in the store phase
+  static_assert(MAXP % THREADS == 0 && MAXP % (NW * 64) == 0 && PAD % 4 == 0, "shape");
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
+  for (uint32_t b = tid; b < (uint32_t)MAXP; b += THREADS) hist[b] = 0;
+  __syncthreads();  // hist is zero
+  // ---- pass 1: count keys per bucket ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++)
+    if ((ok >> j) & 1) atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+  __syncthreads();
+  // ---- exclusive scan of the counts (BPT entries per thread) + one global reservation per touched bucket ----
+  {
+    uint32_t h[BPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < BPT; k++) {
+      h[k] = hist[BPT * tid + k];
+      sum += h[k];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t up = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t excl = incl - sum;
+    for (uint32_t w = 0; w < wave; w++) excl += wave_sums[w];
+#pragma unroll
+    for (int k = 0; k < BPT; k++) {
+      const uint32_t b = BPT * tid + k;
+      toff[b] = excl;
+      hist[b] = excl;  // becomes the placement cursor of pass 2
+      uint32_t g = 0;
+      if (h[k]) {
+        const unsigned long long padded = (h[k] + (PAD - 1u)) & ~(PAD - 1u);
+        const unsigned long long at = atomicAdd(&p.cursors[b], padded);
+        // cap < 2^32 (checked on the host); a run that does not fit spills as a whole
+        if (at + padded > p.cap) {
+          // every later reservation fails too, so the list is valid exactly up to the first failure
+          atomicMin(&p.cursors[p.n_buckets + b], at);
+          g = 0xFFFFFFFFu;
+        } else {
+          g = (uint32_t)at;
+        }
+      }
+      gbase[b] = g;
+      excl += h[k];
+    }
+    if (tid == THREADS - 1) toff[MAXP] = excl;
+  }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);  // the hooks stay where they are written
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- pass 2: counting sort into LDS ----
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    if (!((ok >> j) & 1)) continue;
+    const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+    sorted[pos] = rel[j] & sub_mask;
+  }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  before_stores();
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- each wave streams whole runs out, 16 bytes per lane.  The wave owns buckets wave, wave + NW, ...;
+  // lane m keeps the (offset, count, global start) of the (m + 64 s)-th of them in registers, so a step needs
+  // no LDS round trip for the bookkeeping.  Four groups of 16 lanes take four buckets per step (a group covers
+  // 64 slots per pass; runs average kTile/P keys).  The cost of this phase is per store instruction, not per
+  // byte: 4-byte-per-lane stores of the same runs took 2.3 ms instead of 1.0 ms.
+  {
+    uint32_t m_o[NS], m_h[NS], m_g[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2++) {
+      const uint32_t b = (lane + 64 * s2) * NW + wave;
+      const bool in = b < p.n_buckets;
+      const uint32_t o = in ? toff[b] : 0;
+      m_o[s2] = o;
+      m_h[s2] = in ? toff[b + 1] - o : 0;
+      m_g[s2] = in ? gbase[b] : 0;
+    }
+    const uint32_t n_meta = (p.n_buckets > wave) ? (p.n_buckets - wave + NW - 1) / NW : 0;
+    const uint32_t grp = lane >> 4, sub = lane & 15;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2++) {
+      const uint32_t m_end = n_meta > 64u * s2 ? (n_meta - 64u * s2 < 64u ? n_meta - 64u * s2 : 64u) : 0;
+      for (uint32_t m0 = 0; m0 < m_end; m0 += 4) {
+        const uint32_t m = m0 + grp, src = m & 63;
+        const uint32_t o = __shfl(m_o[s2], src, 64), g = __shfl(m_g[s2], src, 64);
+        uint32_t h = __shfl(m_h[s2], src, 64);
+        if (m >= m_end) h = 0;
+        if (h == 0) continue;
+        const uint32_t b = (m + 64 * s2) * NW + wave;
+        if (g != 0xFFFFFFFFu) {
+          const uint32_t padded = (h + (PAD - 1u)) & ~(PAD - 1u);
+          uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;  // 16-byte aligned: cap and g are multiples of PAD
+          for (uint32_t i = 4 * sub; i < padded; i += 64) {
+            uint4 v;
+            v.x = i < h ? sorted[o + i] : kListPad;
+            v.y = i + 1 < h ? sorted[o + i + 1] : kListPad;
+            v.z = i + 2 < h ? sorted[o + i + 2] : kListPad;
+            v.w = i + 3 < h ? sorted[o + i + 3] : kListPad;
+            *(uint4 *)&dst[i] = v;
+          }
+        } else {
+          for (uint32_t i = sub; i < h; i += 16) {
+            // spill: straight into the global bitmap
+            const uint64_t r = ((uint64_t)b << p.sub_bits) | sorted[o + i];
+            const uint32_t bit = 1u << (r & 31);
+            const uint32_t prev = atomicOr(&p.seen[r >> 5], bit);
+            if ((prev & bit) && p.want_multiplicity) atomicOr(&p.twice[r >> 5], bit);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// key - base of one tile: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31).  Keys outside the declared
+// range (only possible with a caller-supplied range hint) are never inserted but counted, so that tgx_finalize
+// reports them instead of returning a wrong count.
+template <int KPT>
+__device__ __forceinline__ void partition_relative(const PartitionParams &p, const int64_t (&key)[KPT],
+                                                   uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out) {
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
+    if (((ok >> j) & 1) && (r >> p.sub_bits) >= p.n_buckets) {
+      ok &= ~(1ull << j);
+      n_out++;
+    }
+    rel[j] = (uint32_t)r;  // the 64-bit keys die here
+    asm volatile("" : "+v"(rel[j]));  // (keeps the compiler from re-deriving rel from the keys later)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// 1024 threads x 32 keys, one workgroup per CU (152 KiB of LDS); any alignment, ragged last tile.
+template <int THREADS, int KPT, int MAXP, int PAD>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
+    PartitionParams p, unsigned long long *counters) {
+  constexpr int kTile = THREADS * KPT;
+  __shared__ uint32_t sorted[kTile];     // the tile, grouped by bucket
+  __shared__ uint32_t hist[MAXP];        // pass 1: keys per bucket; pass 2: placement cursors
+  __shared__ uint32_t toff[MAXP + 1];    // exclusive prefix of the counts (toff[P] = tile total)
+  __shared__ uint32_t gbase[MAXP];       // start of the run in the bucket's global list
+  __shared__ uint32_t wave_sums[16];
   const bool wide = (((uintptr_t)p.values + (uintptr_t)p.offset * 8) & 15) == 0;  // 16-byte loads legal
   unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
-  uint32_t rel[KPT];  // key - base of the tile's rows: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31)
-  uint32_t ok = 0;
-  TGX_T_DECL
+  uint32_t rel[KPT];
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    TGX_T_START
-    // (requesting tile t+1 here-after, before the stores of tile t, was tried: the 64 extra live registers spill
-    //  at 1024 threads/workgroup and the kernel ran 7.6 ms instead of 4.1 ms)
+    uint64_t ok;
     {
       int64_t key[KPT];
-      partition_load_tile<THREADS, KPT>(p, tile, wide, key, ok);
-      TGX_T_WAIT TGX_T_MARK(0)
-#pragma unroll
-      for (int j = 0; j < KPT; j++) {
-        const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
-        if (((ok >> j) & 1) && (r >> p.sub_bits) >= p.n_buckets) {
-          // outside the declared range (only possible with a caller-supplied range hint): never inserted,
-          // counted so that tgx_finalize reports it instead of returning a wrong count
-          ok &= ~(1u << j);
-          n_out++;
-        }
-        rel[j] = (uint32_t)r;  // the 64-bit keys die here: half the registers for the rest of the tile
-      }
+      uint32_t ok32 = 0;
+      partition_load_tile<THREADS, KPT>(p, tile, wide, key, ok32);
+      ok = ok32;
+      partition_relative<KPT>(p, key, rel, ok, n_out);
     }
-    for (uint32_t b = tid; b < kMaxPartitions; b += kPartitionThreads) hist[b] = 0;
-    __syncthreads();  // hist is zero
-    // ---- pass 1: count keys per bucket ----
-    TGX_ABL(32)
-#pragma unroll
-    for (int j = 0; j < KPT; j++)
-      if ((ok >> j) & 1) atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
-    n_valid += __builtin_popcount(ok);
-    __syncthreads();
-    TGX_T_MARK(1)
-    TGX_ABL(16)
-    // ---- exclusive scan of the counts (2 entries per thread) + one global reservation per touched bucket ----
-    {
-      const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
-      uint32_t incl = h0 + h1;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += up;
-      }
-      if (lane == 63) wave_sums[wave] = incl;
-      __syncthreads();
-      uint32_t wbase = 0;
-      for (uint32_t w = 0; w < wave; w++) wbase += wave_sums[w];
-      const uint32_t excl = wbase + incl - (h0 + h1);
-      toff[2 * tid] = excl;
-      toff[2 * tid + 1] = excl + h0;
-      if (tid == kPartitionThreads - 1) toff[kMaxPartitions] = excl + h0 + h1;
-      hist[2 * tid] = excl;  // becomes the placement cursor of pass 2
-      hist[2 * tid + 1] = excl + h0;
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const uint32_t b = 2 * tid + k, h = k ? h1 : h0;
-        uint32_t g = 0;
-        if (h) {
-          const unsigned long long padded = (h + (PAD - 1u)) & ~(PAD - 1u);
-          const unsigned long long at = atomicAdd(&p.cursors[b], padded);
-          // cap < 2^32 (checked on the host); a run that does not fit spills as a whole
-          if (at + padded > p.cap) {
-            // every later reservation fails too, so the list is valid exactly up to the first failure
-            atomicMin(&p.cursors[p.n_buckets + b], at);
-            g = 0xFFFFFFFFu;
-          } else {
-            g = (uint32_t)at;
-          }
-        }
-        gbase[b] = g;
-      }
-    }
-    __syncthreads();
-    TGX_T_WAIT TGX_T_MARK(2)
-    TGX_ABL(8)
-    // ---- pass 2: counting sort into LDS ----
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-      if (!((ok >> j) & 1)) continue;
-      const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
-      sorted[pos] = rel[j] & sub_mask;
-    }
-    __syncthreads();
-    TGX_T_MARK(3)
-    TGX_ABL(4)
-    // ---- each wave streams whole runs out, 16 bytes per lane.  The wave owns buckets wave, wave + NW, ...;
-    // lane m keeps the (offset, count, global start) of the m-th and (m+64)-th of them in registers, so a
-    // step needs no LDS round trip for the bookkeeping.  Four groups of 16 lanes take four buckets per step
-    // (a group covers 64 slots per pass; runs average kTile/P keys).  The cost of this phase is per store
-    // instruction, not per byte: 4-byte-per-lane stores of the same runs took 2.3 ms instead of 1.0 ms.
-    {
-      constexpr uint32_t NW = THREADS / 64;  // waves per workgroup
-      static_assert(kMaxPartitions / NW <= 128, "two metadata sets per lane");
-      static_assert(PAD % 4 == 0, "16-byte stores");
-      uint32_t m_o[2], m_h[2], m_g[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        const uint32_t b = (lane + 64 * s2) * NW + wave;
-        const bool in = b < p.n_buckets;
-        const uint32_t o = in ? toff[b] : 0;
-        m_o[s2] = o;
-        m_h[s2] = in ? toff[b + 1] - o : 0;
-        m_g[s2] = in ? gbase[b] : 0;
-      }
-      const uint32_t n_meta = (p.n_buckets > wave) ? (p.n_buckets - wave + NW - 1) / NW : 0;
-      const uint32_t grp = lane >> 4, sub = lane & 15;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        const uint32_t m_end = n_meta > 64u * s2 ? (n_meta - 64u * s2 < 64u ? n_meta - 64u * s2 : 64u) : 0;
-        for (uint32_t m0 = 0; m0 < m_end; m0 += 4) {
-          const uint32_t m = m0 + grp, src = m & 63;
-          const uint32_t o = __shfl(m_o[s2], src, 64), g = __shfl(m_g[s2], src, 64);
-          uint32_t h = __shfl(m_h[s2], src, 64);
-          if (m >= m_end) h = 0;
-          if (h == 0) continue;
-          const uint32_t b = (m + 64 * s2) * NW + wave;
-          if (g != 0xFFFFFFFFu) {
-            const uint32_t padded = (h + (PAD - 1u)) & ~(PAD - 1u);
-            uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;  // 16-byte aligned: cap and g are multiples of PAD
-            for (uint32_t i = 4 * sub; i < padded; i += 64) {
-              uint4 v;
-              v.x = i < h ? sorted[o + i] : kListPad;
-              v.y = i + 1 < h ? sorted[o + i + 1] : kListPad;
-              v.z = i + 2 < h ? sorted[o + i + 2] : kListPad;
-              v.w = i + 3 < h ? sorted[o + i + 3] : kListPad;
-              *(uint4 *)&dst[i] = v;
-            }
-          } else {
-            for (uint32_t i = sub; i < h; i += 16) {
-              // spill: straight into the global bitmap
-              const uint64_t r = ((uint64_t)b << p.sub_bits) | sorted[o + i];
-              const uint32_t bit = 1u << (r & 31);
-              const uint32_t prev = atomicOr(&p.seen[r >> 5], bit);
-              if ((prev & bit) && p.want_multiplicity) atomicOr(&p.twice[r >> 5], bit);
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    TGX_T_WAIT TGX_T_MARK(4)
+    n_valid += __builtin_popcountll(ok);
+    partition_process_tile<THREADS, KPT, MAXP, PAD>(p, sorted, hist, toff, gbase, wave_sums, rel, ok, [] {}, [] {});
   }
-  TGX_T_FLUSH
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
 }
 
@@ -675,9 +681,11 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   int64_t n_tiles = (p.length + kPartitionTile - 1) / kPartitionTile;
   int grid = (int)(n_tiles < (int64_t)n_cu ? n_tiles : (int64_t)n_cu);  // 152 KiB of LDS: one workgroup per CU
   if (grid < 1) grid = 1;
-  // (512-thread workgroups, two per CU, were measured slower: twice the runs at half the length)
-  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, 16>), dim3(grid),
-                     dim3(kPartitionThreads), 0, stream, p, d_counters);
+  // (software-pipelined variants -- next tile requested before this tile's stores, either in the 128-register
+  //  budget of 1024 threads or as 512 threads x 64 keys with 256 registers -- spill and ran 3.3 / 6.0 ms
+  //  against 3.0 ms: the load and store phases already run at HBM rate, only the LDS phases are exposed)
+  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16>),
+                     dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
 }
 
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,

@@ -77,11 +77,7 @@ enum {
   kCntValidRows = 3,  // non-null rows scanned
   kCntOutOfRange = 4, // bitmap mode: keys outside [base, base+range) -- must stay 0
   kCntSpare = 5,
-#ifdef TGX_PARTITION_TIMING
-  kNumDistinctCounters = 16
-#else
   kNumDistinctCounters = 8
-#endif
 };
 
 }  // namespace tgx

@@ -844,7 +844,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       cap = cap + cap / 4 + 16 * tiles + 4096;
       pp.cap = (cap + 15) & ~15ull;
       pp.want_multiplicity = mult ? 1 : 0;
-      pp.pad = getenv("TGX_ABLATE") ? atoi(getenv("TGX_ABLATE")) : 0;
+      pp.pad = 0;
       HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * sizeof(uint32_t)));
       HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
       HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
@@ -1116,10 +1116,6 @@ static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t,
   unsigned long long c[kNumDistinctCounters];
   memset(c, 0, sizeof(c));
   if (st->device_ready) TGX_TRY(distinct_read_counters(st, ds, c, err));
-#ifdef TGX_PARTITION_TIMING
-  fprintf(stderr, "partition phases (cycles, thread 0 of every workgroup): load %llu pass1 %llu scan+atomics %llu pass2 %llu storeout %llu\n",
-          c[8], c[9], c[10], c[11], c[12]);
-#endif
   if (c[kCntOutOfRange] != 0)
     return fail(err, TGX_INTERNAL, "distinct: %llu keys fell outside the range bitmap", c[kCntOutOfRange]);
   const uint64_t empty_rows = c[kCntEmptyRows] + ds.h_empty_rows;
