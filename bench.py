@@ -143,7 +143,7 @@ def main():
                 st_d.distinct_range_hint(j, rng[0], rng[1])
         st_d.update(columns)
         exchange_distinct_auto(st_d, list(range(len(specs) - n_stats)), dist, world, rank)
-        per_rank = allgather_many([st.serialize(), st_d.serialize()], dist, world, device="cuda")
+        per_rank = allgather_many([st.serialize(), st_d.serialize()], dist, world, device="cuda", cache_key="bench")
         merged = merge_blobs(plan, [p[0] for p in per_rank])
         merged_d = merge_blobs(plan_d, [p[1] for p in per_rank])
         return merged.finalize() + merged_d.finalize()

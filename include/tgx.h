@@ -244,9 +244,11 @@ tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *state, size_t sp
  *      bitmaps are congruent; keys outside [lo, hi] are counted and make tgx_finalize fail (never a wrong count);
  *   2. tgx_distinct_bitmap_view exposes the bitmap (device pointers, 32-bit words); ranks all-to-all equal
  *      slices of it (a few hundred MB per rank instead of 16 bytes per key);
- *   3. tgx_distinct_adopt_slices ORs the received slices (`n_slices` x `slice_words` words, contiguous; the
- *      "seen twice" slices too when the check wants multiplicity) into the rank's owned slice, whose first bit
- *      stands for key `slice_base`, and marks the state owner-partitioned.
+ *   3. tgx_distinct_adopt_slices ORs the received slices (`n_slices` slices of `slice_words` words, slice i at
+ *      word offset i * `slice_stride_words` -- 0 means packed, i.e. slice_words -- so the receive buffer of an
+ *      all-to-all that carries several columns per peer is used in place; the "seen twice" slices too when
+ *      the check wants multiplicity) into the rank's owned slice, whose first bit stands for key `slice_base`,
+ *      and marks the state owner-partitioned.
  * tgx_distinct_bitmap_view returns TGX_UNSUPPORTED when the set is a hash table: use export / import then. */
 tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *state, size_t spec_index, int64_t lo, int64_t hi,
                                    tgx_error *err);
@@ -254,7 +256,7 @@ tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *state, size
                                     uint64_t *n_words, const void **seen, const void **twice, tgx_error *err);
 tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *state, size_t spec_index, int64_t slice_base,
                                      const void *seen_slices, const void *twice_slices, uint32_t n_slices,
-                                     uint64_t slice_words, tgx_error *err);
+                                     uint64_t slice_words, uint64_t slice_stride_words, tgx_error *err);
 
 /* ---- measurement ----------------------------------------------------------------------------
  * Per-kernel HIP-event timing on the state's stream (what bench.py's `roofline` uses).

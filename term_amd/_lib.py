@@ -140,7 +140,7 @@ def lib():
         L.tgx_distinct_import.argtypes = [vp, vp, sz, vp, u64, E]
         L.tgx_distinct_range_hint.argtypes = [vp, vp, sz, C.c_int64, C.c_int64, E]
         L.tgx_distinct_bitmap_view.argtypes = [vp, vp, sz, C.POINTER(C.c_int64), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), E]
-        L.tgx_distinct_adopt_slices.argtypes = [vp, vp, sz, C.c_int64, vp, vp, C.c_uint32, u64, E]
+        L.tgx_distinct_adopt_slices.argtypes = [vp, vp, sz, C.c_int64, vp, vp, C.c_uint32, u64, u64, E]
         L.tgx_distinct_record_bytes.argtypes = [vp, vp, sz]
         L.tgx_distinct_record_bytes.restype = sz
         L.tgx_profile_enable.argtypes = [vp, C.c_int32]
@@ -398,10 +398,11 @@ class State:
                                               C.byref(seen), C.byref(twice), C.byref(err)), err)
         return base.value, n.value, seen.value, twice.value
 
-    def distinct_adopt_slices(self, spec_index, slice_base, seen_ptr, twice_ptr, n_slices, slice_words):
+    def distinct_adopt_slices(self, spec_index, slice_base, seen_ptr, twice_ptr, n_slices, slice_words,
+                              slice_stride_words=0):
         err = _Error()
         _check(lib().tgx_distinct_adopt_slices(self.plan.h, self.h, spec_index, int(slice_base), seen_ptr, twice_ptr,
-                                               n_slices, slice_words, C.byref(err)), err)
+                                               n_slices, slice_words, slice_stride_words, C.byref(err)), err)
 
     def distinct_record_bytes(self, spec_index):
         return lib().tgx_distinct_record_bytes(self.plan.h, self.h, spec_index)

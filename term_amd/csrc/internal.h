@@ -34,7 +34,7 @@ void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
 void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, hipStream_t stream);
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
-                         uint64_t slice_words, uint32_t *out_seen, uint32_t *out_twice,
+                         uint64_t slice_words, uint64_t stride_words, uint32_t *out_seen, uint32_t *out_twice,
                          unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
@@ -188,6 +188,9 @@ struct DistinctState {
   DevBuf export_records, export_counts;
   // Dictionary<Int32, Utf8> batches: per-entry reference counts (saturating at 2)
   DevBuf dict_usage;
+  // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
+  // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
+  DevBuf spare_seen, spare_twice;
 };
 
 struct ProfileEntry {

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void export_scatter_kernel(Src src, uint32_t w
 // rank's bitmap; a key is "seen twice" if any rank saw it twice or two ranks saw it at all.
 __global__ __launch_bounds__(256) void bitmap_adopt_kernel(const uint32_t *seen_slices,
                                                             const uint32_t *twice_slices, uint32_t n_slices,
-                                                            uint64_t slice_words, uint32_t *out_seen,
+                                                            uint64_t slice_words, uint64_t stride, uint32_t *out_seen,
                                                             uint32_t *out_twice,
                                                             unsigned long long *counters) {
   unsigned long long n_seen = 0, n_twice = 0;
@@ -664,8 +664,8 @@ __global__ __launch_bounds__(256) void bitmap_adopt_kernel(const uint32_t *seen_
        w += (uint64_t)gridDim.x * 256) {
     uint32_t acc_seen = 0, acc_twice = 0;
     for (uint32_t s = 0; s < n_slices; s++) {
-      const uint32_t x = seen_slices[(uint64_t)s * slice_words + w];
-      if (twice_slices) acc_twice |= (acc_seen & x) | twice_slices[(uint64_t)s * slice_words + w];
+      const uint32_t x = seen_slices[(uint64_t)s * stride + w];
+      if (twice_slices) acc_twice |= (acc_seen & x) | twice_slices[(uint64_t)s * stride + w];
       acc_seen |= x;
     }
     out_seen[w] = acc_seen;
@@ -777,10 +777,10 @@ void launch_bitmap_export_scatter(const BitmapView &bm, uint32_t world, int want
 }
 
 void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
-                         uint64_t slice_words, uint32_t *out_seen, uint32_t *out_twice,
+                         uint64_t slice_words, uint64_t stride_words, uint32_t *out_seen, uint32_t *out_twice,
                          unsigned long long *d_counters, hipStream_t stream) {
   hipLaunchKernelGGL(bitmap_adopt_kernel, dim3(grid_for(slice_words)), dim3(256), 0, stream, seen_slices,
-                     twice_slices, n_slices, slice_words, out_seen, out_twice, d_counters);
+                     twice_slices, n_slices, slice_words, stride_words, out_seen, out_twice, d_counters);
 }
 
 }  // namespace tgx

@@ -802,6 +802,8 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       // whole 2^20-bit slices, so the partitioned path can move slices through LDS
       size_t words = (size_t)(((ds.range + (1u << 20) - 1) >> 20) << 15) + 4;
       ds.bitmap_words = words - 4;
+      if (ds.seen.cap < words * 4 && ds.spare_seen.cap >= words * 4) std::swap(ds.seen, ds.spare_seen);
+      if (ds.twice.cap < words * 4 && ds.spare_twice.cap >= words * 4) std::swap(ds.twice, ds.spare_twice);
       HIP_TRY(ds.seen.reserve(words * 4));
       HIP_TRY(hipMemsetAsync(ds.seen.p, 0, words * 4, st->stream));
       if (mult) {
@@ -1455,7 +1457,7 @@ extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *
 extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                                 int64_t slice_base, const void *seen_slices,
                                                 const void *twice_slices, uint32_t n_slices, uint64_t slice_words,
-                                                tgx_error *err) {
+                                                uint64_t slice_stride_words, tgx_error *err) {
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   TGX_TRY(need_device(err));
@@ -1463,11 +1465,13 @@ extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state 
   DistinctState &ds = st->distinct[slot];
   const bool mult = plan->distinct[slot].multiplicity;
   if (!seen_slices || n_slices == 0 || slice_words == 0) return fail(err, TGX_INVALID_ARGUMENT, "bad slice arguments");
+  if (slice_stride_words == 0) slice_stride_words = slice_words;
+  if (slice_stride_words < slice_words) return fail(err, TGX_INVALID_ARGUMENT, "slice stride shorter than a slice");
   if (mult && !twice_slices) return fail(err, TGX_INVALID_ARGUMENT, "this check needs the 'twice' slices too");
   if (ds.wide) return fail(err, TGX_INVALID_ARGUMENT, "Utf8 key sets have no range bitmap");
   unsigned long long c[kNumDistinctCounters];
   TGX_TRY(distinct_read_counters(st, ds, c, err));
-  DevBuf new_seen, new_twice;
+  DevBuf &new_seen = ds.spare_seen, &new_twice = ds.spare_twice;
   HIP_TRY(new_seen.reserve(slice_words * 4 + 16));
   if (mult) HIP_TRY(new_twice.reserve(slice_words * 4 + 16));
   unsigned long long zero[kNumDistinctCounters];
@@ -1476,13 +1480,11 @@ extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state 
   zero[kCntOutOfRange] = c[kCntOutOfRange];
   HIP_TRY(hipMemcpyAsync(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice, st->stream));
   launch_bitmap_adopt((const uint32_t *)seen_slices, mult ? (const uint32_t *)twice_slices : nullptr, n_slices,
-                      slice_words, new_seen.as<uint32_t>(), mult ? new_twice.as<uint32_t>() : nullptr,
+                      slice_words, slice_stride_words, new_seen.as<uint32_t>(), mult ? new_twice.as<uint32_t>() : nullptr,
                       ds.counters.as<unsigned long long>(), st->stream);
   HIP_TRY(hipStreamSynchronize(st->stream));
-  ds.seen = std::move(new_seen);
-  ds.twice = std::move(new_twice);
-  ds.keys.release();
-  ds.dup.release();
+  std::swap(ds.seen, ds.spare_seen);  // the old bitmap stays around as the spare of the next round
+  std::swap(ds.twice, ds.spare_twice);
   ds.capacity = 0;
   ds.mode = DistinctMode::kBitmap;
   ds.base = slice_base;

@@ -64,7 +64,9 @@ def exchange_distinct_bitmaps(state, spec_indices, dist, world, rank):
         if twice_ptr:
             parts.append((si, base, n_words, twice_ptr, sw, True))
     row = sum(p[4] for p in parts)  # words every rank sends to every other rank
-    send = torch.zeros(world, row, dtype=torch.int32, device="cuda")
+    # everything below is ordered on torch's CURRENT stream only (no device-wide synchronize), so a caller can
+    # keep an unrelated scan running on another stream while the slices travel
+    send = torch.empty(world, row, dtype=torch.int32, device="cuda")
     col = 0
     for si, base, n_words, ptr, sw, _ in parts:
         src = torch.as_tensor(_DevPtr(ptr, n_words * 4), device="cuda").view(torch.int32)
@@ -72,22 +74,27 @@ def exchange_distinct_bitmaps(state, spec_indices, dist, world, rank):
         if full:
             send[:full, col:col + sw] = src[: full * sw].view(full, sw)
         rest = n_words - full * sw
+        if full < world:
+            send[full:, col:col + sw] = 0  # the padding past the end of the bitmap
         if rest:
             send[full, col:col + rest] = src[full * sw:]
         col += sw
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv.view(-1), send.view(-1))
+    torch.cuda.current_stream().synchronize()
     col = 0
-    slices = {}
+    done = set()
     for si, base, n_words, ptr, sw, is_twice in parts:
-        slices.setdefault(si, {})["twice" if is_twice else "seen"] = recv[:, col:col + sw].contiguous()
-        slices[si]["base"], slices[si]["sw"] = base, sw
-        col += sw
-    torch.cuda.synchronize()
-    for si, d in slices.items():
-        tw = d.get("twice")
-        state.distinct_adopt_slices(si, d["base"] + rank * d["sw"] * 32, d["seen"].data_ptr(),
-                                    tw.data_ptr() if tw is not None else None, world, d["sw"])
+        if si in done:
+            continue
+        done.add(si)
+        seen_ptr = recv.data_ptr() + 4 * col
+        has_twice = any(p[0] == si and p[5] for p in parts)
+        twice_ptr = recv.data_ptr() + 4 * (col + sw) if has_twice else None
+        # the received slices are used in place: slice of peer i at word offset i * row
+        state.distinct_adopt_slices(si, base + rank * sw * 32, seen_ptr, twice_ptr, world, sw, row)
+        col += sw * (2 if has_twice else 1)
+    # (tgx_distinct_adopt_slices returns after its kernel has finished: `recv` may be freed now)
 
 
 def exchange_distinct_auto(state, spec_indices, dist, world, rank):
@@ -128,39 +135,57 @@ def agree_on_ranges(local_minmax, dist, world, device="cuda"):
     return res
 
 
-def allgather_blobs(blob, dist, world, device="cpu"):
-    """all-gather one byte string per rank.  Blobs of owner-partitioned states have the same size on every rank,
-    so the common case is ONE collective: the payload travels with an 8-byte length prefix in a buffer of the
-    local size; only if the sizes turn out to differ is a second, padded round needed."""
+_GATHER_CAPACITY = {}  # cache_key -> bytes per rank agreed for the one-collective fast path
+
+
+def allgather_blobs(blob, dist, world, device="cpu", cache_key=None):
+    """all-gather one byte string per rank.
+
+    Every rank sends a 16-byte header (payload length, capacity it needs) + payload in a buffer of an agreed
+    capacity: ONE all_gather_into_tensor, one host->device and one device->host copy.  The capacity is agreed by a
+    size round the first time (and remembered under `cache_key`, e.g. the plan, when given); if any rank's payload
+    has outgrown it, every rank sees that in the headers and all repeat the round with the larger capacity."""
     import struct
 
     import torch
 
-    payload = struct.pack("<Q", len(blob)) + bytes(blob)
-    mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([len(payload)], dtype=torch.int64, device=device))
-    sizes = [int(x.item()) for x in sizes]
-    mx = max(sizes)
-    if mx != len(payload):
-        mine = torch.cat([mine, torch.zeros(mx - len(payload), dtype=torch.uint8, device=device)])
-    gathered = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    out = []
-    for r in range(world):
-        raw = bytes(gathered[r].cpu().numpy())
-        (n,) = struct.unpack("<Q", raw[:8])
-        out.append(raw[8:8 + n])
-    return out
+    blob = bytes(blob)
+
+    def agree():
+        sizes = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(sizes, torch.tensor([len(blob)], dtype=torch.int64, device=device))
+        need = int(sizes.max().item())
+        return (need + need // 2 + 16 + 255) // 256 * 256
+
+    cap = _GATHER_CAPACITY.get(cache_key) if cache_key is not None else None
+    if cap is None:
+        cap = agree()
+    while True:
+        fits = len(blob) + 16 <= cap
+        buf = bytearray(cap)
+        struct.pack_into("<QQ", buf, 0, len(blob) if fits else 0, len(blob) + 16)
+        if fits:
+            buf[16:16 + len(blob)] = blob
+        mine = torch.frombuffer(buf, dtype=torch.uint8).to(device)
+        out = torch.empty(world * cap, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(out, mine)
+        raw = bytes(out.cpu().numpy())
+        heads = [struct.unpack_from("<QQ", raw, r * cap) for r in range(world)]
+        need = max(h[1] for h in heads)
+        if need <= cap:
+            if cache_key is not None:
+                _GATHER_CAPACITY[cache_key] = cap
+            return [raw[r * cap + 16: r * cap + 16 + heads[r][0]] for r in range(world)]
+        cap = (need + need // 2 + 255) // 256 * 256  # the same on every rank: all saw the same headers
 
 
-def allgather_many(blobs, dist, world, device="cpu"):
+def allgather_many(blobs, dist, world, device="cpu", cache_key=None):
     """several blobs per rank (e.g. the stats state and the distinct state) in the collectives of one"""
     import struct
 
     packed = b"".join(struct.pack("<Q", len(b)) + bytes(b) for b in blobs)
     out = []
-    for raw in allgather_blobs(packed, dist, world, device):
+    for raw in allgather_blobs(packed, dist, world, device, cache_key):
         parts, pos = [], 0
         for _ in blobs:
             (n,) = struct.unpack("<Q", raw[pos:pos + 8])

@@ -75,6 +75,18 @@ WORKER = textwrap.dedent('''
                want_median=float(np.median(fv[mask])),
                regex=[res[6].total, res[6].matches], want_regex=[n, sum(1 for s in strs if "@" in s)],
                blob=merged.serialize().hex()[:64])
+    # the one-collective gather: ragged sizes, a cached capacity that one rank outgrows, empty payloads
+    from term_amd.distributed import agree_on_ranges, allgather_blobs, allgather_many
+    g = allgather_blobs(b"x" * (10 + rank), dist, world, cache_key="t")
+    assert [len(x) for x in g] == [10, 11] and g[1] == b"x" * 11
+    g = allgather_blobs(b"y" * (5000 * (rank + 1)), dist, world, cache_key="t")
+    assert [len(x) for x in g] == [5000, 10000] and g[1] == b"y" * 10000
+    g = allgather_blobs(b"", dist, world, cache_key="t")
+    assert g == [b"", b""]
+    g = allgather_many([b"a" * rank, b"bb"], dist, world)
+    assert g == [[b"", b"bb"], [b"a", b"bb"]]
+    r = agree_on_ranges([(True, 5 - rank, 100 + rank), (rank == 1, -7, 7), (False, 0, 0)], dist, world, device="cpu")
+    assert r == [(4, 101), (-7, 7), None], r
     print("RESULT " + json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

@@ -446,8 +446,17 @@ def test_distinct_bitmap_slice_exchange_single_process(mult):
         recv_seen = torch.cat([s[r * slice_words:(r + 1) * slice_words] for s in seen]).contiguous()
         recv_twice = torch.cat([s[r * slice_words:(r + 1) * slice_words] for s in twice]).contiguous() if mult else None
         torch.cuda.synchronize()
-        states[r].distinct_adopt_slices(0, base + r * slice_words * 32, recv_seen.data_ptr(),
-                                        recv_twice.data_ptr() if mult else None, world, slice_words)
+        if r % 2 == 0:
+            states[r].distinct_adopt_slices(0, base + r * slice_words * 32, recv_seen.data_ptr(),
+                                            recv_twice.data_ptr() if mult else None, world, slice_words)
+        else:
+            # strided form: seen and twice slices interleaved per peer, as an all-to-all of several parts leaves them
+            both = torch.stack([recv_seen.view(world, slice_words),
+                                (recv_twice if mult else recv_seen).view(world, slice_words)], dim=1).contiguous()
+            torch.cuda.synchronize()
+            states[r].distinct_adopt_slices(0, base + r * slice_words * 32, both.data_ptr(),
+                                            both.data_ptr() + 4 * slice_words if mult else None, world, slice_words,
+                                            2 * slice_words)
     blobs = [s.serialize() for s in states]
     assert all(len(b) < 200 for b in blobs)  # owner-partitioned states travel as counts only
     from term_amd.distributed import merge_blobs
