@@ -142,11 +142,90 @@ __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_
   return base + incl - v;
 }
 
+constexpr int kKllRowsPerThread = 8;
+constexpr int kKllStepRows = kKllThreads * kKllRowsPerThread;  // 2048 rows per workgroup step
+
+// loads 8 rows per thread of the 2048-row step at `base` (row pairs base + 2 (t + 256 u) + {0, 1}: one
+// global_load_dwordx4 per pair when the buffer allows); returns the mask of rows that enter the sketch
+// (in range, non-NULL, not NaN: KllSketch::update drops NaN, kll_sketch.rs:197-199)
+__device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i64_ptr vals, global_u8_ptr vbits,
+                                                  int64_t base, int64_t r1, bool wide,
+                                                  double (&v)[kKllRowsPerThread]) {
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  typedef const i64x2 __attribute__((address_space(1))) *global_i64x2_ptr;
+  uint32_t okm = 0;
+  int64_t bits[kKllRowsPerThread];
+  if (wide && base + kKllStepRows <= r1) {
+    uint8_t vb[kKllRowsPerThread / 2];
+    const bool pair_bytes = ((d.offset + base) & 1) == 0;  // both rows of a pair share a validity byte
+    if (vbits && pair_bytes) {
+#pragma unroll
+      for (int u = 0; u < kKllRowsPerThread / 2; u++)
+        vb[u] = vbits[(d.offset + base + 2 * (threadIdx.x + u * kKllThreads)) >> 3];
+    }
+    global_i64x2_ptr pv = (global_i64x2_ptr)(vals + base) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < kKllRowsPerThread / 2; u++) {
+      const i64x2 x = __builtin_nontemporal_load(pv + u * kKllThreads);
+      bits[2 * u] = x.x;
+      bits[2 * u + 1] = x.y;
+    }
+    okm = (1u << kKllRowsPerThread) - 1u;
+    if (vbits && pair_bytes) {
+      okm = 0;
+#pragma unroll
+      for (int u = 0; u < kKllRowsPerThread / 2; u++) {
+        const int64_t b = d.offset + base + 2 * (threadIdx.x + u * kKllThreads);
+        okm |= (uint32_t)((vb[u] >> (b & 7)) & 3) << (2 * u);
+      }
+    } else if (vbits) {
+      okm = 0;
+#pragma unroll
+      for (int q = 0; q < kKllRowsPerThread; q++) {
+        const int64_t b = d.offset + base + 2 * (threadIdx.x + (q / 2) * kKllThreads) + (q & 1);
+        okm |= (uint32_t)((vbits[b >> 3] >> (b & 7)) & 1) << q;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < kKllRowsPerThread; q++) {
+      const int64_t i = base + 2 * (threadIdx.x + (q / 2) * kKllThreads) + (q & 1);
+      bool ok = i < r1;
+      bits[q] = ok ? vals[i] : 0;
+      if (ok && vbits) {
+        const int64_t b = d.offset + i;
+        ok = (vbits[b >> 3] >> (b & 7)) & 1;
+      }
+      okm |= (uint32_t)ok << q;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kKllRowsPerThread; q++) {
+    const double x = d.is_float ? __longlong_as_double(bits[q]) : (double)bits[q];
+    if (!(x == x)) okm &= ~(1u << q);
+    v[q] = x;
+  }
+  return okm;
+}
+
 // One workgroup sketches rows [wg * chunk, (wg+1) * chunk) of the column into sketches[wg].
+//
+// Sorting every 1024 values (the level-0 compaction) costs ~40 LDS compare-exchanges per value: 36.6 ms per
+// 1 G-row column.  The KLL sampler (Karnin-Lang-Liberty, sec. 3.2 "sampling": below the lowest kept level an
+// item of weight 2^l is ONE uniformly chosen member of 2^l consecutive stream items) removes that work
+// without touching the error budget: the V values of the range (V is counted first) are cut into
+//     a_top segments of 1024 * 2^top values, then one optional segment of 1024 * 2^l values for every
+//     l < top (the binary digits of the rest), then < 1024 raw values,
+// i.e. V = sum_l a_l * 1024 * 2^l + r exactly.  A level-l segment contributes one uniformly chosen value per
+// group of 2^l consecutive values -- 1024 values of weight 2^l, sorted, halved to a run of 512 at level l+1 --
+// and the r raw values are the sketch's level 0, so the total weight is still exactly V.  `top` grows with
+// the batch (2^top ~ rows / 2^22): rank variance added by sampling is <= rows * 2^top / 4, i.e. a relative
+// standard error <= 2.5e-4 next to the 2e-3 of the level structure itself; batches under 8 M rows are not
+// sampled at all.
 __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, int64_t chunk,
                                                                  KllDeviceSketch *sketches,
-                                                                 uint64_t salt0) {
-  __shared__ double staging[2048 + 1024];  // carried raw items + one step of new ones
+                                                                 uint64_t salt0, uint32_t top) {
+  __shared__ double ring[4096];  // four batches of sampled values: slot = sampled index & 4095 (a step brings <= 2)
   __shared__ double buf[1024];
   __shared__ uint32_t wave_tot[kKllThreads / 64];
   __shared__ double red_min[kKllThreads / 64], red_max[kKllThreads / 64];
@@ -166,53 +245,24 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
   const int64_t r0 = (int64_t)blockIdx.x * chunk;
   int64_t r1 = r0 + chunk;
   if (r1 > d.length) r1 = d.length;
-  uint32_t staged = 0;  // uniform
+  const uint64_t salt = salt0 ^ ((uint64_t)blockIdx.x * 0x9e3779b97f4a7c15ULL);
+  const bool wide = (((uintptr_t)(vals + r0)) & 15) == 0;  // chunk is a multiple of the step: parity holds
+
+  // ---- pass 1: V = values of the range that enter the sketch, their min / max ----
   double mn = __longlong_as_double(0x7FF0000000000000LL), mx = -mn;
   unsigned long long cnt = 0;
-  const uint64_t salt = salt0 ^ ((uint64_t)blockIdx.x * 0x9e3779b97f4a7c15ULL);
-  for (int64_t base = r0; base < r1; base += 1024) {
-    double v[4];
-    uint32_t okm = 0;
+  for (int64_t base = r0; base < r1; base += kKllStepRows) {
+    double v[kKllRowsPerThread];
+    const uint32_t okm = kll_load_step(d, vals, vbits, base, r1, wide, v);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int64_t i = base + t + u * kKllThreads;
-      bool ok = i < r1;
-      int64_t bits = ok ? vals[i] : 0;
-      if (ok && vbits) {
-        const int64_t b = d.offset + i;
-        ok = (vbits[b >> 3] >> (b & 7)) & 1;
-      }
-      const double x = d.is_float ? __longlong_as_double(bits) : (double)bits;
-      ok = ok && (x == x);  // KllSketch::update drops NaN (kll_sketch.rs:197-199)
-      v[u] = x;
-      okm |= (uint32_t)ok << u;
-    }
-    uint32_t total;
-    uint32_t pos = staged + block_exclusive_scan(__builtin_popcount(okm), wave_tot, &total);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < kKllRowsPerThread; u++) {
       if ((okm >> u) & 1) {
-        staging[pos++] = v[u];
         mn = v[u] < mn ? v[u] : mn;
         mx = v[u] > mx ? v[u] : mx;
         cnt++;
       }
     }
-    staged += total;
-    __syncthreads();
-    while (staged >= 1024) {
-      // take the LAST 1024 staged items, so the carried prefix does not have to move
-      const uint32_t from = staged - 1024;
-#pragma unroll
-      for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = staging[from + t + u * kKllThreads];
-      __syncthreads();
-      compact_level0(s, buf, salt ^ (uint64_t)(base + staged));
-      staged = from;
-    }
   }
-  // leftovers (< 1024 raw items) are the sketch's level 0
-  for (uint32_t i = t; i < staged; i += kKllThreads) s->lv0[i] = staging[i];
-  // block reduce n / min / max
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
     cnt += __shfl_down(cnt, dlt, 64);
@@ -226,19 +276,101 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
     red_max[t >> 6] = mx;
   }
   __syncthreads();
-  if (t == 0) {
-    unsigned long long n = 0;
+  uint64_t V = 0;
+  {
     double a = red_min[0], b = red_max[0];
     for (int w = 0; w < kKllThreads / 64; w++) {
-      n += red_n[w];
+      V += red_n[w];
       a = red_min[w] < a ? red_min[w] : a;
       b = red_max[w] > b ? red_max[w] : b;
     }
-    s->n = n;
-    s->min_v = a;
-    s->max_v = b;
-    s->lv0_count = staged;
+    if (t == 0) {
+      s->n = V;
+      s->min_v = a;
+      s->max_v = b;
+    }
   }
+
+  // ---- the cut of [0, V): level-top segments, then the binary digits X of the rest, then the raw tail ----
+  const uint64_t top_items = 1024ull << top;
+  const uint64_t end_top = (V / top_items) * top_items;           // values sampled at level `top`
+  const uint32_t X = (uint32_t)((V - end_top) >> 10);             // < 2^top: digit l = a segment of level l
+  const uint64_t raw_start = end_top + ((uint64_t)X << 10);       // first raw value
+  const uint64_t batches_top = end_top >> (10 + top);
+  // batch cursor (uniform): sampled batch `kb` covers values [jb0, jb1) at level lb
+  uint64_t kb = 0, jb0 = 0, jb1 = 0;
+  uint32_t lb = 0, xrest = X;  // xrest: digits of X not yet opened
+  bool have_batch = false;
+  auto open_batch = [&]() {
+    if (kb < batches_top) {
+      lb = top;
+      jb0 = kb << (10 + top);
+      jb1 = jb0 + top_items;
+      have_batch = true;
+    } else if (xrest) {
+      lb = 31 - __builtin_clz(xrest);
+      xrest &= ~(1u << lb);
+      jb0 = jb1 > end_top ? jb1 : end_top;
+      jb1 = jb0 + (1024ull << lb);
+      have_batch = true;
+    } else {
+      have_batch = false;
+    }
+  };
+  open_batch();
+
+  // ---- pass 2: sample ----
+  uint64_t consumed = 0;  // values seen so far (uniform)
+  for (int64_t base = r0; base < r1; base += kKllStepRows) {
+    double v[kKllRowsPerThread];
+    const uint32_t okm = kll_load_step(d, vals, vbits, base, r1, wide, v);
+    uint32_t total;
+    uint64_t j = consumed + block_exclusive_scan(__builtin_popcount(okm), wave_tot, &total);
+#pragma unroll
+    for (int u = 0; u < kKllRowsPerThread; u++) {
+      if (!((okm >> u) & 1)) continue;
+      if (j >= raw_start) {
+        s->lv0[j - raw_start] = v[u];
+      } else {
+        uint32_t level;
+        uint64_t seg0, sampled0;  // first value / first sampled index of the value's segment
+        if (j < end_top) {
+          level = top;
+          seg0 = 0;
+          sampled0 = 0;
+        } else {
+          const uint32_t q = (uint32_t)((j - end_top) >> 10);  // < X
+          level = 31 - __builtin_clz(X ^ q);                    // the digit of X that q falls under
+          const uint32_t before = X & ~((2u << level) - 1u);    // 1024-value blocks of the higher digits
+          seg0 = end_top + ((uint64_t)before << 10);
+          sampled0 = (batches_top + __builtin_popcount(before)) << 10;
+        }
+        const uint64_t o = j - seg0, g = o >> level;
+        const uint64_t pick = kll_mix(salt ^ ((uint64_t)level << 56) ^ (g + (seg0 << 8))) & ((1ull << level) - 1);
+        if ((o & ((1ull << level) - 1)) == pick) ring[(sampled0 + g) & 4095] = v[u];
+      }
+      j++;
+    }
+    consumed += total;
+    __syncthreads();
+    while (have_batch && consumed >= jb1) {  // uniform: every pick of batch kb has been written
+#pragma unroll
+      for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = ring[((kb & 3) << 10) + t + u * kKllThreads];
+      __syncthreads();
+      // sort, keep every other value (weight 2^(lb+1)), insert the run one level up
+      block_sort_1024(buf);
+      const uint32_t parity = (uint32_t)(kll_mix(salt ^ 0x5bd1e995ULL ^ (kb << 1)) >> 35) & 1u;
+      const double a = buf[2 * t + parity], b = buf[2 * (t + 256) + parity];
+      __syncthreads();
+      buf[t] = a;
+      buf[t + 256] = b;
+      __syncthreads();
+      insert_run(s, lb + 1, buf, salt ^ (kb << 24));
+      kb++;
+      open_batch();
+    }
+  }
+  if (t == 0) s->lv0_count = (uint32_t)(V - raw_start);
 }
 
 // dst += src (both in global memory); one workgroup.
@@ -317,8 +449,11 @@ void launch_kll_init(KllDeviceSketch *s, hipStream_t stream) {
 // sketches: scratch for `groups` per-workgroup sketches; result folded into `state`
 void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
                        KllDeviceSketch *state, uint64_t salt, hipStream_t stream) {
+  // sampling level: 2^top ~ rows / 2^22 (none below 8 M rows), see kll_build_kernel
+  uint32_t top = 0;
+  while (top < 16 && (d.length >> (23 + top)) > 0) top++;
   hipLaunchKernelGGL(kll_build_kernel, dim3(groups), dim3(kKllThreads), 0, stream, d, chunk, sketches,
-                     salt);
+                     salt, top);
   for (int stride = 1; stride < groups; stride <<= 1) {
     int pairs = (groups + 2 * stride - 1) / (2 * stride);
     hipLaunchKernelGGL(kll_tree_kernel, dim3(pairs), dim3(kKllThreads), 0, stream, sketches, groups,

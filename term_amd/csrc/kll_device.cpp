@@ -76,11 +76,11 @@ tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error
     KHIP(k->sketch[slot].reserve(sizeof(KllDeviceSketch)));
     launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream);
   }
-  // one workgroup per >= 64 Ki rows, at most 512 of them (121 MiB of scratch sketches)
+  // one workgroup per >= 64 Ki rows, at most 1024 of them (235 MiB of scratch sketches)
   int64_t groups = (c.length + 65535) / 65536;
-  groups = std::max<int64_t>(1, std::min<int64_t>(groups, 512));
+  groups = std::max<int64_t>(1, std::min<int64_t>(groups, 1024));
   int64_t chunk = (c.length + groups - 1) / groups;
-  chunk = (chunk + 1023) / 1024 * 1024;
+  chunk = (chunk + 2047) / 2048 * 2048;
   groups = (c.length + chunk - 1) / chunk;
   KHIP(k->scratch.reserve((size_t)groups * sizeof(KllDeviceSketch)));
   KllColDesc d;

@@ -125,6 +125,40 @@ def test_rank_error_within_stated_eps(dist, n):
     assert qs == sorted(qs) and kept.min() <= qs[0] and qs[-1] <= kept.max()
 
 
+@pytest.mark.parametrize("dist", ["uniform", "sorted", "sawtooth", "reversed_blocks"])
+@pytest.mark.parametrize("n,offset", [(20_000_000, 0), (33_554_432 + 12_345, 3)])
+def test_sampled_batches_keep_exact_weight_and_tight_rank_error(dist, n, offset):
+    """batches of 8 M rows and more go through the KLL sampler (one uniformly chosen value per 2^l consecutive
+    values below the kept levels, kernels/kll.hip): total weight must still equal the number of values exactly
+    and the rank error must stay an order of magnitude below the stated eps, whatever the arrangement --
+    sorted input, a sawtooth whose period equals the sampling group, block-reversed input"""
+    rng = np.random.default_rng(n % 1000 + len(dist))
+    m = n + offset
+    if dist == "uniform":
+        vals = rng.random(m) * 1000
+    elif dist == "sorted":
+        vals = np.arange(m, dtype=np.float64)
+    elif dist == "sawtooth":
+        vals = (np.arange(m) % 4).astype(np.float64) * 1e6 + np.arange(m) * 1e-3  # period = group of 2^2 values
+    else:
+        idx = np.arange(m)
+        vals = ((idx // 4096) * 4096 + (4095 - idx % 4096)).astype(np.float64)
+    mask = rng.random(m) >= 0.03
+    vals[rng.random(m) < 0.002] = np.nan
+    validity = orc.pack_validity(mask)
+    col = numeric_column(vals, validity, True, offset=offset, length=n)
+    res, plan, st = run_plan([spec(T.KLL, 0, kll_k=200)], [[col]])
+    v, mk = vals[offset:], mask[offset:]
+    kept = v[mk & ~np.isnan(v)]
+    assert res[0].kll_n == len(kept)
+    assert total_weight(st, 0) == len(kept)
+    summ = st.kll_summary(0)
+    assert summ["min"] == kept.min() and summ["max"] == kept.max()
+    srt = np.sort(kept)
+    worst = max(rank_error(srt, st.kll_quantile(0, phi), phi) for phi in np.linspace(0.01, 0.99, 50))
+    assert worst < 0.01, worst
+
+
 def test_int64_column_and_batches_and_serialize():
     rng = np.random.default_rng(77)
     n = 1_200_000
