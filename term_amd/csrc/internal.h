@@ -39,15 +39,20 @@ void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slic
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
+int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
 void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
-                            int64_t dict_length, const uint8_t *hits, int null_is_valid,
-                            unsigned long long *d_counters, hipStream_t stream);
+                            int64_t dict_length, int dict_has_nulls, const uint8_t *hits, int null_is_valid,
+                            unsigned long long *d_counters, int n_cu, hipStream_t stream);
+size_t dict_usage_words(int64_t dict_length);
+size_t dict_usage_scratch_bytes(int64_t length, int64_t dict_length, int want_mult, int n_cu);
 void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
-                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, uint32_t *usage,
-                       unsigned long long *d_counters, hipStream_t stream);
+                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, int want_mult,
+                       uint32_t *seen, uint32_t *twice, uint32_t *scratch, unsigned long long *d_counters, int n_cu,
+                       hipStream_t stream);
 void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
-                        int64_t length, int large_offsets, int want_mult, const uint32_t *usage,
-                        const HashSetView &t, unsigned long long *d_counters, hipStream_t stream);
+                        int64_t length, int large_offsets, int want_mult, const uint32_t *seen,
+                        const uint32_t *twice, const HashSetView &t, unsigned long long *d_counters,
+                        hipStream_t stream);
 void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
@@ -187,7 +192,7 @@ struct DistinctState {
   // export scratch
   DevBuf export_records, export_counts;
   // Dictionary<Int32, Utf8> batches: per-entry reference counts (saturating at 2)
-  DevBuf dict_usage;
+  DevBuf dict_usage, dict_scratch;  // seen | twice bitmaps over the entries; per-workgroup slices
   // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
   // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
   DevBuf spare_seen, spare_twice;

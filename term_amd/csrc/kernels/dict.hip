@@ -18,7 +18,6 @@ namespace tgx {
 typedef const uint8_t __attribute__((address_space(1))) *global_u8_ptr;
 typedef const int32_t __attribute__((address_space(1))) *global_i32_ptr;
 
-constexpr int kDictLdsEntries = 16384;  // usage histogram in LDS (64 KiB) up to this dictionary size
 
 struct DictRowsDesc {
   const int32_t *indices;   // element 0 of the indices buffer
@@ -42,88 +41,226 @@ __device__ __forceinline__ void dict_block_add(unsigned long long a, unsigned lo
   }
 }
 
-// matches += hits[index] for valid rows (hit byte: 1 = entry matches, 2 = entry is NULL), null_is_valid for NULL rows
-__global__ __launch_bounds__(256) void dict_count_hits_kernel(DictRowsDesc d, const uint8_t *hits,
-                                                               int null_is_valid,
-                                                               unsigned long long *counters) {
+// Streams the index column once: f(e, valid) for every row.  Rows are taken four at a time with one
+// global_load_dwordx4 per lane (after a scalar head up to the first 16-byte aligned index), four loads in flight
+// per lane; the four validity bits of a quad come from a 16-bit window of the bitmap.
+template <class F>
+__device__ __forceinline__ void dict_for_each_row(const DictRowsDesc &d, F &&f) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef const i32x4 __attribute__((address_space(1))) *global_i32x4_ptr;
   global_i32_ptr idx = (global_i32_ptr)(uintptr_t)(d.indices + d.offset);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
-  global_u8_ptr h = (global_u8_ptr)(uintptr_t)hits;
-  unsigned long long matches = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.length; i += (int64_t)gridDim.x * 256) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t head = (int64_t)(((16 - ((uintptr_t)(d.indices + d.offset) & 15)) & 15) >> 2);
+  if (head > d.length) head = d.length;
+  const int64_t n_quads = (d.length - head) >> 2;
+  auto one = [&](int64_t i) {
     bool valid = true;
     if (vbits) valid = (vbits[(d.offset + i) >> 3] >> ((d.offset + i) & 7)) & 1;
+    f(idx[i], valid);
+  };
+  // scalar head and tail (at most 3 + 3 rows)
+  if (tid < head) one(tid);
+  if (tid < d.length - head - 4 * n_quads) one(head + 4 * n_quads + tid);
+  global_i32x4_ptr quads = (global_i32x4_ptr)(idx + head);
+  for (int64_t q0 = tid; q0 < n_quads; q0 += 4 * stride) {
+    i32x4 v[4];
+    uint32_t bits[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t q = q0 + u * stride;
+      const bool in = q < n_quads;
+      bits[u] = in ? 0xFu : 0u;
+      if (in && vbits) {
+        const int64_t b = d.offset + head + 4 * q;
+        uint32_t w = vbits[b >> 3];
+        if ((b & 7) > 4) w |= (uint32_t)vbits[(b >> 3) + 1] << 8;  // the quad straddles a byte
+        bits[u] = (w >> (b & 7)) & 0xFu;
+      }
+      v[u] = __builtin_nontemporal_load(quads + (in ? q : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (q0 + u * stride >= n_quads) continue;
+      f(v[u].x, (bits[u] & 1) != 0);
+      f(v[u].y, (bits[u] & 2) != 0);
+      f(v[u].z, (bits[u] & 4) != 0);
+      f(v[u].w, (bits[u] & 8) != 0);
+    }
+  }
+}
+
+constexpr int kDictLdsWords = 32768;  // 128 KiB of LDS bitmaps: 1 Mi entries (one bitmap) or 512 Ki (two)
+constexpr int kDictThreads = 1024;    // one workgroup per CU, 16 waves
+
+__device__ __forceinline__ void dict_block_add1024(unsigned long long a, unsigned long long *ga) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) a += __shfl_down(a, d, 64);
+  __shared__ unsigned long long sa[16];
+  if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; w++) t += sa[w];
+    if (t) atomicAdd(ga, t);
+  }
+}
+
+// matches += hits[index] for valid rows (hit byte: 1 = entry matches, 2 = entry is NULL), null_is_valid for NULL
+// rows.  LDS: the per-entry verdicts as a bitmap in LDS (dictionaries without NULL values, <= 1 Mi entries), so
+// the per-row lookup is an LDS read instead of a scattered global byte load.
+template <bool LDS>
+__global__ __launch_bounds__(kDictThreads) void dict_count_hits_kernel(DictRowsDesc d, const uint8_t *hits,
+                                                                        int null_is_valid,
+                                                                        unsigned long long *counters) {
+  __shared__ uint32_t match_bits[LDS ? kDictLdsWords : 1];
+  global_u8_ptr h = (global_u8_ptr)(uintptr_t)hits;
+  if (LDS) {
+    const int64_t words = (d.dict_length + 31) >> 5;
+    for (int64_t w = threadIdx.x; w < words; w += kDictThreads) {
+      uint32_t m = 0;
+      for (int k = 0; k < 32; k++) {
+        const int64_t e = 32 * w + k;
+        if (e < d.dict_length && h[e] == 1) m |= 1u << k;
+      }
+      match_bits[w] = m;
+    }
+    __syncthreads();
+  }
+  unsigned long long matches = 0;
+  dict_for_each_row(d, [&](int32_t e, bool valid) {
     if (valid) {
-      const int32_t e = idx[i];
-      const uint8_t hv = (e >= 0 && e < d.dict_length) ? h[e] : 0;
-      matches += hv == 1 ? 1 : (hv == 2 && null_is_valid) ? 1 : 0;  // 2: the dictionary VALUE is NULL
+      if (e < 0 || e >= d.dict_length) return;
+      if (LDS) {
+        matches += (match_bits[e >> 5] >> (e & 31)) & 1;
+      } else {
+        const uint8_t hv = h[e];
+        matches += hv == 1 ? 1 : (hv == 2 && null_is_valid) ? 1 : 0;  // 2: the dictionary VALUE is NULL
+      }
     } else {
       matches += null_is_valid ? 1 : 0;
     }
-  }
-  dict_block_add(matches, &counters[0]);
+  });
+  dict_block_add1024(matches, &counters[0]);
 }
 
-// usage[e] = min(2, number of valid rows referencing entry e); counters[kCntValidRows] += valid rows
-__global__ __launch_bounds__(256) void dict_usage_kernel(DictRowsDesc d, uint32_t *usage,
-                                                          unsigned long long *counters) {
-  __shared__ uint32_t hist[kDictLdsEntries];
-  const bool small = d.dict_length <= kDictLdsEntries;
-  if (small) {
-    for (int64_t e = threadIdx.x; e < d.dict_length; e += 256) hist[e] = 0;
+// Which dictionary entries do the valid rows reference, and which more than once?
+// LDS = true : every workgroup keeps private seen / twice bitmaps in LDS and writes them to its slice of
+//              `slices` ([workgroup][seen words | twice words]); launch_dict_usage then ORs the slices
+//              (two workgroups that each saw an entry once make it "twice") into `seen` / `twice`.
+// LDS = false: dictionaries beyond the LDS budget -- test-before-set atomicOr straight into `seen` / `twice`.
+// counters[kCntValidRows] += valid rows.
+template <bool LDS, bool MULT>
+__global__ __launch_bounds__(kDictThreads) void dict_usage_kernel(DictRowsDesc d, uint32_t *seen, uint32_t *twice,
+                                                                   uint32_t *slices, unsigned long long *counters) {
+  __shared__ uint32_t bits[LDS ? kDictLdsWords : 1];
+  const uint32_t words = (uint32_t)((d.dict_length + 31) >> 5);
+  uint32_t *l_seen = bits, *l_twice = bits + words;
+  if (LDS) {
+    for (uint32_t w = threadIdx.x; w < (MULT ? 2 : 1) * words; w += kDictThreads) bits[w] = 0;
     __syncthreads();
   }
-  global_i32_ptr idx = (global_i32_ptr)(uintptr_t)(d.indices + d.offset);
-  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   global_u8_ptr dvbits = (global_u8_ptr)(uintptr_t)d.dict_validity;
   unsigned long long n_valid = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.length; i += (int64_t)gridDim.x * 256) {
-    bool valid = true;
-    if (vbits) valid = (vbits[(d.offset + i) >> 3] >> ((d.offset + i) & 7)) & 1;
-    if (!valid) continue;
-    const int32_t e = idx[i];
-    if (e < 0 || e >= d.dict_length) continue;  // malformed index: ignored (Arrow validates these)
-    if (dvbits && !((dvbits[(d.dict_offset + e) >> 3] >> ((d.dict_offset + e) & 7)) & 1)) continue;  // NULL value
+  dict_for_each_row(d, [&](int32_t e, bool valid) {
+    if (!valid) return;
+    if (e < 0 || e >= d.dict_length) return;  // malformed index: ignored (Arrow validates these)
+    if (dvbits && !((dvbits[(d.dict_offset + e) >> 3] >> ((d.dict_offset + e) & 7)) & 1)) return;  // NULL value
     n_valid++;
-    if (small) {
-      if (hist[e] < 2) atomicAdd(&hist[e], 1u);
-    } else if (usage[e] < 2) {
-      atomicAdd(&usage[e], 1u);
+    const uint32_t bit = 1u << (e & 31), w = (uint32_t)e >> 5;
+    uint32_t *s_ = LDS ? l_seen : seen, *t_ = LDS ? l_twice : twice;
+    if (MULT) {
+      if (!(t_[w] & bit)) {  // once an entry is known to be referenced twice there is nothing left to record
+        if (s_[w] & bit) {
+          atomicOr(&t_[w], bit);
+        } else {
+          const uint32_t prev = atomicOr(&s_[w], bit);
+          if (prev & bit) atomicOr(&t_[w], bit);
+        }
+      }
+    } else if (!(s_[w] & bit)) {
+      atomicOr(&s_[w], bit);
     }
-  }
-  if (small) {
+  });
+  if (LDS) {
     __syncthreads();
-    for (int64_t e = threadIdx.x; e < d.dict_length; e += 256) {
-      const uint32_t c = hist[e] > 2 ? 2 : hist[e];
-      if (c && usage[e] < 2) atomicAdd(&usage[e], c);
-    }
+    uint32_t *mine = slices + (size_t)blockIdx.x * (MULT ? 2 : 1) * words;
+    for (uint32_t w = threadIdx.x; w < (MULT ? 2 : 1) * words; w += kDictThreads) mine[w] = bits[w];
   }
-  dict_block_add(n_valid, &counters[kCntValidRows]);
+  dict_block_add1024(n_valid, &counters[kCntValidRows]);
 }
 
-static int dict_grid(int64_t n) {
-  int64_t b = (n + 255) / 256;
+// OR of the workgroups' slices; an entry is referenced twice if any workgroup saw it twice or two saw it at all
+__global__ __launch_bounds__(256) void dict_usage_reduce_kernel(const uint32_t *slices, uint32_t n_slices,
+                                                                 uint32_t words, int mult, uint32_t *seen,
+                                                                 uint32_t *twice) {
+  const uint32_t stride = (mult ? 2 : 1) * words;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) {
+    uint32_t acc_seen = 0, acc_twice = 0;
+    for (uint32_t s2 = 0; s2 < n_slices; s2++) {
+      const uint32_t x = slices[(size_t)s2 * stride + w];
+      if (mult) acc_twice |= (acc_seen & x) | slices[(size_t)s2 * stride + words + w];
+      acc_seen |= x;
+    }
+    seen[w] = acc_seen;
+    if (mult) twice[w] = acc_twice;
+  }
+}
+
+static int dict_grid(int64_t n, int n_cu) {
+  int64_t b = (n / 16 + kDictThreads - 1) / kDictThreads;  // 16 rows per thread per trip
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
+  if (b > n_cu) b = n_cu;  // 128 KiB of LDS: one workgroup per CU
   return (int)b;
 }
 
 void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
-                            int64_t dict_length, const uint8_t *hits, int null_is_valid,
-                            unsigned long long *d_counters, hipStream_t stream) {
+                            int64_t dict_length, int dict_has_nulls, const uint8_t *hits, int null_is_valid,
+                            unsigned long long *d_counters, int n_cu, hipStream_t stream) {
   DictRowsDesc d{indices, validity, offset, length, nullptr, 0, dict_length};
-  hipLaunchKernelGGL(dict_count_hits_kernel, dim3(dict_grid(length)), dim3(256), 0, stream, d, hits, null_is_valid,
-                     d_counters);
+  const int grid = dict_grid(length, n_cu);
+  if (!dict_has_nulls && dict_length <= (int64_t)kDictLdsWords * 32)
+    hipLaunchKernelGGL(dict_count_hits_kernel<true>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
+                       null_is_valid, d_counters);
+  else
+    hipLaunchKernelGGL(dict_count_hits_kernel<false>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
+                       null_is_valid, d_counters);
 }
 
+size_t dict_usage_words(int64_t dict_length) { return (size_t)((dict_length + 31) >> 5); }
+
+// scratch bytes launch_dict_usage needs for the per-workgroup slices (0: the global-atomics path is used)
+size_t dict_usage_scratch_bytes(int64_t length, int64_t dict_length, int want_mult, int n_cu) {
+  const size_t words = dict_usage_words(dict_length) * (want_mult ? 2 : 1);
+  if (words > (size_t)kDictLdsWords) return 0;
+  return (size_t)dict_grid(length, n_cu) * words * sizeof(uint32_t);
+}
+
+// seen / twice: bitmaps of dict_usage_words(dict_length) words each (twice only written with want_mult);
+// the global-atomics path needs them zeroed by the caller
 void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
-                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, uint32_t *usage,
-                       unsigned long long *d_counters, hipStream_t stream) {
+                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, int want_mult,
+                       uint32_t *seen, uint32_t *twice, uint32_t *scratch, unsigned long long *d_counters, int n_cu,
+                       hipStream_t stream) {
   DictRowsDesc d{indices, validity, offset, length, dict_validity, dict_offset, dict_length};
-  // the LDS histogram is flushed once per workgroup: fewer, fatter workgroups for small dictionaries
-  int grid = dict_grid(length);
-  if (dict_length <= kDictLdsEntries && grid > 512) grid = 512;
-  hipLaunchKernelGGL(dict_usage_kernel, dim3(grid), dim3(256), 0, stream, d, usage, d_counters);
+  const int grid = dict_grid(length, n_cu);
+  const bool lds = dict_usage_scratch_bytes(length, dict_length, want_mult, n_cu) != 0;
+  const dim3 g(grid), b(kDictThreads);
+  if (lds) {
+    if (want_mult)
+      hipLaunchKernelGGL((dict_usage_kernel<true, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+    else
+      hipLaunchKernelGGL((dict_usage_kernel<true, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+    const uint32_t words = (uint32_t)dict_usage_words(dict_length);
+    hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256),
+                       dim3(256), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
+  } else {
+    if (want_mult)
+      hipLaunchKernelGGL((dict_usage_kernel<false, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+    else
+      hipLaunchKernelGGL((dict_usage_kernel<false, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+  }
 }
 
 }  // namespace tgx

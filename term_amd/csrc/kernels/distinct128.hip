@@ -216,13 +216,14 @@ __global__ __launch_bounds__(256) void hash_export_scatter128_kernel(HashSetView
 
 // ---- Dictionary<Int32, Utf8> columns (see dict.hip): fingerprints per dictionary entry, inserted with the
 // multiplicity the usage pass counted (0 = unreferenced entry, skipped)
-__global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, const uint32_t *usage, HashSetView t,
+__global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, const uint32_t *seen,
+                                                           const uint32_t *twice, HashSetView t,
                                                            unsigned long long *counters) {
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)dict.validity;
   unsigned long long n_new = 0, n_dup = 0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < dict.length; e += (int64_t)gridDim.x * 256) {
-    const uint32_t u = usage[e];
-    if (u == 0) continue;
+    if (!((seen[e >> 5] >> (e & 31)) & 1)) continue;  // unreferenced entry
+    const uint32_t u = (dict.want_multiplicity && ((twice[e >> 5] >> (e & 31)) & 1)) ? 2 : 1;
     const int64_t slot = dict.offset + e;
     if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) continue;  // a NULL dictionary value
     int64_t b, en;
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, cons
 }
 
 void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
-                        int64_t length, int large_offsets, int want_mult, const uint32_t *usage,
-                        const HashSetView &t, unsigned long long *d_counters, hipStream_t stream) {
+                        int64_t length, int large_offsets, int want_mult, const uint32_t *seen,
+                        const uint32_t *twice, const HashSetView &t, unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
   d.offsets = offsets;
   d.data = data;
@@ -258,7 +259,7 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
   int64_t blocks = (length + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(dict_insert_kernel, dim3((int)blocks), dim3(256), 0, stream, d, usage, t, d_counters);
+  hipLaunchKernelGGL(dict_insert_kernel, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
 }
 
 static inline int grid_for128(uint64_t items) {

@@ -125,14 +125,7 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
   if (!st->plan->regex) return TGX_OK;
   const RegexPlan *rp = rplan(st->plan);
   RegexState *rs = rstate(st);
-  int n_cu = 256;
-  {
-    int devid = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-  }
+  const int n_cu = tgx_num_cus();
   for (size_t i = 0; i < rp->tasks.size(); i++) {
     const RegexTask &t = rp->tasks[i];
     RegexTaskState &ts = rs->tasks[i];
@@ -184,8 +177,9 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
       // counters[1] soaks up the per-entry match count, counters[0] receives the per-row one
       if (sc.length > 0) launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
       launch_dict_count_hits((const int32_t *)c.values, c.validity, c.offset, c.length, sc.length,
-                             ts.dict_hits.as<uint8_t>(), (t.flags & TGX_FLAG_NULL_IS_VALID) != 0,
-                             ts.counters.as<unsigned long long>(), st->stream);
+                             sc.validity != nullptr, ts.dict_hits.as<uint8_t>(),
+                             (t.flags & TGX_FLAG_NULL_IS_VALID) != 0, ts.counters.as<unsigned long long>(), n_cu,
+                             st->stream);
     }
     if (st->profiling && e0 && e1) {
       (void)hipEventRecord(e1, st->stream);

@@ -74,6 +74,10 @@ struct Context {
 } g_ctx;
 }  // namespace
 
+namespace tgx {
+int tgx_num_cus() { return g_ctx.n_cu > 0 ? g_ctx.n_cu : 256; }
+}  // namespace tgx
+
 extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) {
   std::lock_guard<std::mutex> lock(g_ctx.mu);
   int count = 0;
@@ -739,13 +743,20 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       ds.wide = true;
     }
     TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)std::min<int64_t>(c.length, dict.length), err));
-    HIP_TRY(ds.dict_usage.reserve((size_t)dict.length * 4 + 16));
-    HIP_TRY(hipMemsetAsync(ds.dict_usage.p, 0, (size_t)dict.length * 4, st->stream));
+    const size_t uw = dict_usage_words(dict.length);
+    HIP_TRY(ds.dict_usage.reserve(2 * uw * 4 + 16));
+    const size_t scratch = dict_usage_scratch_bytes(c.length, dict.length, mult ? 1 : 0, g_ctx.n_cu);
+    if (scratch)
+      HIP_TRY(ds.dict_scratch.reserve(scratch));
+    else
+      HIP_TRY(hipMemsetAsync(ds.dict_usage.p, 0, 2 * uw * 4, st->stream));  // the global-atomics path accumulates
+    uint32_t *u_seen = ds.dict_usage.as<uint32_t>(), *u_twice = u_seen + uw;
     ProfScope ps(st, "distinct", 0);
     launch_dict_usage((const int32_t *)c.values, c.validity, c.offset, c.length, dict.validity, dict.offset,
-                      dict.length, ds.dict_usage.as<uint32_t>(), ds.counters.as<unsigned long long>(), st->stream);
+                      dict.length, mult ? 1 : 0, u_seen, u_twice, ds.dict_scratch.as<uint32_t>(),
+                      ds.counters.as<unsigned long long>(), g_ctx.n_cu, st->stream);
     launch_dict_insert(dict.offsets, dict.data, dict.validity, dict.offset, dict.length,
-                       dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, ds.dict_usage.as<uint32_t>(), hash_view(ds),
+                       dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, u_seen, u_twice, hash_view(ds),
                        ds.counters.as<unsigned long long>(), st->stream);
     return TGX_OK;
   }
