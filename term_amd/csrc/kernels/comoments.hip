@@ -41,8 +41,49 @@ __global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
   double s[5] = {0, 0, 0, 0, 0}, c[5] = {0, 0, 0, 0, 0};
   int64_t n = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < d.length;
-       i0 += 4 * stride) {
+  auto fold = [&](int64_t xb, int64_t yb, bool ok) {
+    double a = d.x_is_float ? __longlong_as_double(xb) : (double)xb;
+    double b = d.y_is_float ? __longlong_as_double(yb) : (double)yb;
+    a = ok ? a : 0.0;
+    b = ok ? b : 0.0;
+    n += ok ? 1 : 0;
+    cm_two_sum(s[0], c[0], a);
+    cm_two_sum(s[1], c[1], b);
+    cm_two_sum(s[2], c[2], a * a);
+    cm_two_sum(s[3], c[3], b * b);
+    cm_two_sum(s[4], c[4], a * b);
+  };
+  const bool wide =
+      ((((uintptr_t)((const int64_t *)d.x + d.xoff)) | ((uintptr_t)((const int64_t *)d.y + d.yoff))) & 15) == 0;
+  int64_t done = 0;  // rows [0, done) are handled by the wide path
+  if (wide) {
+    // row pairs: one global_load_dwordx4 per column per pair, four pairs in flight per lane
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    typedef const i64x2 __attribute__((address_space(1))) *global_i64x2_ptr;
+    global_i64x2_ptr x2 = (global_i64x2_ptr)x, y2 = (global_i64x2_ptr)y;
+    const int64_t n_pairs = d.length >> 1;
+    done = 2 * n_pairs;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < n_pairs; p0 += 4 * stride) {
+      i64x2 xq[4], yq[4];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t p = p0 + u * stride;
+        const bool in = p < n_pairs;
+        const int64_t q = in ? p : 0;
+        ok[2 * u] = in && cm_valid(xv, d.xoff + 2 * q) && cm_valid(yv, d.yoff + 2 * q);
+        ok[2 * u + 1] = in && cm_valid(xv, d.xoff + 2 * q + 1) && cm_valid(yv, d.yoff + 2 * q + 1);
+        xq[u] = __builtin_nontemporal_load(x2 + q);
+        yq[u] = __builtin_nontemporal_load(y2 + q);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        fold(xq[u].x, yq[u].x, ok[2 * u]);
+        fold(xq[u].y, yq[u].y, ok[2 * u + 1]);
+      }
+    }
+  }
+  for (int64_t i0 = done + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < d.length; i0 += 4 * stride) {
     int64_t xb[4], yb[4];
     bool ok[4];
 #pragma unroll
@@ -54,18 +95,7 @@ __global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
       ok[u] = in && cm_valid(xv, d.xoff + (in ? i : 0)) && cm_valid(yv, d.yoff + (in ? i : 0));
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      double a = d.x_is_float ? __longlong_as_double(xb[u]) : (double)xb[u];
-      double b = d.y_is_float ? __longlong_as_double(yb[u]) : (double)yb[u];
-      a = ok[u] ? a : 0.0;
-      b = ok[u] ? b : 0.0;
-      n += ok[u] ? 1 : 0;
-      cm_two_sum(s[0], c[0], a);
-      cm_two_sum(s[1], c[1], b);
-      cm_two_sum(s[2], c[2], a * a);
-      cm_two_sum(s[3], c[3], b * b);
-      cm_two_sum(s[4], c[4], a * b);
-    }
+    for (int u = 0; u < 4; u++) fold(xb[u], yb[u], ok[u]);
   }
   // wave reduce
 #pragma unroll
