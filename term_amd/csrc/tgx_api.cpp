@@ -519,8 +519,6 @@ extern "C" tgx_status tgx_profile_reset(tgx_state *st) {
 // update
 static bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
 
-static size_t validity_bytes(const tgx_column &c) { return (size_t)((c.offset + c.length + 7) / 8); }
-
 // copies a HOST column's buffers to the device; `out` is the device view
 static bool is_string(int t) { return t == TGX_UTF8 || t == TGX_LARGE_UTF8; }
 
@@ -548,24 +546,35 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
     *dst = b->p;
     return TGX_OK;
   };
+  // Only the window the batch views is copied: a sliced array (offset > 0 into big buffers) costs its own rows,
+  // not everything before them.  The window starts at slot e0 = offset rounded down to 64 (keeps the validity
+  // byte / word alignment the kernels like); the device view gets offset - e0 as its Arrow offset.
+  const int64_t e0 = c.offset & ~(int64_t)63;
+  const int64_t slots = c.offset - e0 + c.length;  // slots of the window
+  out->offset = c.offset - e0;
   const void *p = nullptr;
-  TGX_TRY(stage(c.validity, c.validity ? validity_bytes(c) : 0, &p));
+  TGX_TRY(stage(c.validity ? c.validity + (e0 >> 3) : nullptr, c.validity ? (size_t)((slots + 7) / 8) : 0, &p));
   out->validity = (const uint8_t *)p;
   if (is_numeric(c.type)) {
-    TGX_TRY(stage(c.values, (size_t)(c.offset + c.length) * 8, &p));
+    TGX_TRY(stage(c.values ? (const uint8_t *)c.values + (size_t)e0 * 8 : nullptr, (size_t)slots * 8, &p));
     out->values = p;
   } else if (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) {
     const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
-    size_t n_off = (size_t)(c.offset + c.length + 1);
-    TGX_TRY(stage(c.offsets, n_off * ow, &p));
+    TGX_TRY(stage(c.offsets ? (const uint8_t *)c.offsets + (size_t)e0 * ow : nullptr, (size_t)(slots + 1) * ow, &p));
     out->offsets = p;
-    int64_t end = 0;
-    if (c.offsets && c.length + c.offset >= 0)
-      end = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[n_off - 1] : ((const int64_t *)c.offsets)[n_off - 1];
-    TGX_TRY(stage(c.data, (size_t)end, &p));
-    out->data = (const uint8_t *)p;
+    int64_t first = 0, end = 0;
+    if (c.offsets) {
+      first = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[c.offset] : ((const int64_t *)c.offsets)[c.offset];
+      end = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[c.offset + c.length]
+                    : ((const int64_t *)c.offsets)[c.offset + c.length];
+    }
+    // value bytes [first, end) only; the device pointer is rebased so that the original offsets still index it
+    // (16 bytes of slack in front: the pattern kernel stages 16-byte blocks by absolute address)
+    const int64_t lead = first & 15;
+    TGX_TRY(stage(c.data ? c.data + (first - lead) : nullptr, (size_t)(end - first + lead), &p));
+    out->data = p ? (const uint8_t *)p - (first - lead) : nullptr;
   } else if (c.type == TGX_DICT32_UTF8) {
-    TGX_TRY(stage(c.values, (size_t)(c.offset + c.length) * 4, &p));
+    TGX_TRY(stage(c.values ? (const uint8_t *)c.values + (size_t)e0 * 4 : nullptr, (size_t)slots * 4, &p));
     out->values = p;
   } else {
     return fail(err, TGX_UNSUPPORTED, "column type %d is not supported", c.type);

@@ -133,3 +133,30 @@ def test_batches_merge_serialize_and_exchange():
         states[r].distinct_import(0, mine.data_ptr(), mine.numel() // 32)
     states[0].merge([states[1]])
     check(states[0].finalize()[0], want)
+
+
+def test_host_slices_stage_only_their_window(golden):
+    """HOST columns viewed at a large Arrow offset: the staged window (not the buffers from their start) must give
+    the results of the same rows on the device -- numeric, Utf8, LargeUtf8 and pattern checks"""
+    from gpu_util import numeric_column
+
+    rng = np.random.default_rng(99)
+    n = 300_000
+    vals = make_strings(rng, n, 20_000)
+    offs, data, validity = orc.utf8_from_list(vals)
+    ints = rng.integers(-1000, 1000, size=n, dtype=np.int64)
+    mask = rng.random(n) >= 0.1
+    iv = orc.pack_validity(mask)
+    for lo, m in ((0, 1000), (64, 70_000), (123_457, 100_001), (n - 77, 77)):
+        specs = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.REGEX_MATCH, 0, pattern=r"^user-\d+@"),
+                 spec(T.NUMERIC_STATS, 1), spec(T.DISTINCT, 1), spec(T.COUNT, 0)]
+        for large in (False, True):
+            got = run_plan(specs, [[utf8_column(offs, data, validity, False, offset=lo, length=m, large=large),
+                                    numeric_column(ints, iv, False, offset=lo, length=m)]])[0]
+            want = run_plan(specs, [[utf8_column(offs, data, validity, True, offset=lo, length=m, large=large),
+                                     numeric_column(ints, iv, True, offset=lo, length=m)]])[0]
+            for g, w in zip(got, want):
+                assert (g.total, g.non_null, g.distinct, g.groups_once, g.matches, g.min_i, g.max_i, g.sum_i) == \
+                       (w.total, w.non_null, w.distinct, w.groups_once, w.matches, w.min_i, w.max_i, w.sum_i)
+            d = orc.distinct_utf8(offs, data, validity, n=m, offset=lo)
+            check(got[0], d)
