@@ -213,15 +213,18 @@ __device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i6
 // Sorting every 1024 values (the level-0 compaction) costs ~40 LDS compare-exchanges per value: 36.6 ms per
 // 1 G-row column.  The KLL sampler (Karnin-Lang-Liberty, sec. 3.2 "sampling": below the lowest kept level an
 // item of weight 2^l is ONE uniformly chosen member of 2^l consecutive stream items) removes that work
-// without touching the error budget: the V values of the range (V is counted first) are cut into
+// without touching the error budget, arranged so that the total weight stays exact.  The V values of the range
+// (NULL / NaN excluded) are cut into
 //     a_top segments of 1024 * 2^top values, then one optional segment of 1024 * 2^l values for every
-//     l < top (the binary digits of the rest), then < 1024 raw values,
-// i.e. V = sum_l a_l * 1024 * 2^l + r exactly.  A level-l segment contributes one uniformly chosen value per
-// group of 2^l consecutive values -- 1024 values of weight 2^l, sorted, halved to a run of 512 at level l+1 --
-// and the r raw values are the sketch's level 0, so the total weight is still exactly V.  `top` grows with
-// the batch (2^top ~ rows / 2^22): rank variance added by sampling is <= rows * 2^top / 4, i.e. a relative
-// standard error <= 2.5e-4 next to the 2e-3 of the level structure itself; batches under 8 M rows are not
-// sampled at all.
+//     l < top (the binary digits of the rest), then < 1024 raw values:   V = sum_l a_l * 1024 * 2^l + r.
+// A level-l segment contributes one uniformly chosen value per group of 2^l consecutive values -- 1024 values
+// of weight 2^l, sorted, halved to a run of 512 at level l+1 -- and the r raw values are the sketch's level 0.
+// V is not known in advance, so the range is streamed ONCE at level `top` (phase A: whole level-top segments
+// are cut as they complete; n / min / max come out of the same pass) and only the rows after the last complete
+// segment -- fewer than 1024 * 2^top values -- are read again (phase B) to place the lower digits and the raw
+// tail.  `top` grows with the batch (2^top ~ rows / 2^22): rank variance added by sampling is <= rows * 2^top / 4,
+// i.e. a relative standard error <= 2.5e-4 next to the 2e-3 of the level structure itself; batches under 8 M rows
+// are not sampled at all (top = 0: phase A is then the plain "sort every 1024 values").
 __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, int64_t chunk,
                                                                  KllDeviceSketch *sketches,
                                                                  uint64_t salt0, uint32_t top) {
@@ -229,7 +232,6 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
   __shared__ double buf[1024];
   __shared__ uint32_t wave_tot[kKllThreads / 64];
   __shared__ double red_min[kKllThreads / 64], red_max[kKllThreads / 64];
-  __shared__ unsigned long long red_n[kKllThreads / 64];
   KllDeviceSketch *s = sketches + blockIdx.x;
   const uint32_t t = threadIdx.x;
   if (t == 0) {
@@ -247,80 +249,31 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
   if (r1 > d.length) r1 = d.length;
   const uint64_t salt = salt0 ^ ((uint64_t)blockIdx.x * 0x9e3779b97f4a7c15ULL);
   const bool wide = (((uintptr_t)(vals + r0)) & 15) == 0;  // chunk is a multiple of the step: parity holds
-
-  // ---- pass 1: V = values of the range that enter the sketch, their min / max ----
-  double mn = __longlong_as_double(0x7FF0000000000000LL), mx = -mn;
-  unsigned long long cnt = 0;
-  for (int64_t base = r0; base < r1; base += kKllStepRows) {
-    double v[kKllRowsPerThread];
-    const uint32_t okm = kll_load_step(d, vals, vbits, base, r1, wide, v);
-#pragma unroll
-    for (int u = 0; u < kKllRowsPerThread; u++) {
-      if ((okm >> u) & 1) {
-        mn = v[u] < mn ? v[u] : mn;
-        mx = v[u] > mx ? v[u] : mx;
-        cnt++;
-      }
-    }
-  }
-#pragma unroll
-  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-    cnt += __shfl_down(cnt, dlt, 64);
-    const double omn = __shfl_down(mn, dlt, 64), omx = __shfl_down(mx, dlt, 64);
-    mn = omn < mn ? omn : mn;
-    mx = omx > mx ? omx : mx;
-  }
-  if ((t & 63) == 0) {
-    red_n[t >> 6] = cnt;
-    red_min[t >> 6] = mn;
-    red_max[t >> 6] = mx;
-  }
-  __syncthreads();
-  uint64_t V = 0;
-  {
-    double a = red_min[0], b = red_max[0];
-    for (int w = 0; w < kKllThreads / 64; w++) {
-      V += red_n[w];
-      a = red_min[w] < a ? red_min[w] : a;
-      b = red_max[w] > b ? red_max[w] : b;
-    }
-    if (t == 0) {
-      s->n = V;
-      s->min_v = a;
-      s->max_v = b;
-    }
-  }
-
-  // ---- the cut of [0, V): level-top segments, then the binary digits X of the rest, then the raw tail ----
   const uint64_t top_items = 1024ull << top;
-  const uint64_t end_top = (V / top_items) * top_items;           // values sampled at level `top`
-  const uint32_t X = (uint32_t)((V - end_top) >> 10);             // < 2^top: digit l = a segment of level l
-  const uint64_t raw_start = end_top + ((uint64_t)X << 10);       // first raw value
-  const uint64_t batches_top = end_top >> (10 + top);
-  // batch cursor (uniform): sampled batch `kb` covers values [jb0, jb1) at level lb
-  uint64_t kb = 0, jb0 = 0, jb1 = 0;
-  uint32_t lb = 0, xrest = X;  // xrest: digits of X not yet opened
-  bool have_batch = false;
-  auto open_batch = [&]() {
-    if (kb < batches_top) {
-      lb = top;
-      jb0 = kb << (10 + top);
-      jb1 = jb0 + top_items;
-      have_batch = true;
-    } else if (xrest) {
-      lb = 31 - __builtin_clz(xrest);
-      xrest &= ~(1u << lb);
-      jb0 = jb1 > end_top ? jb1 : end_top;
-      jb1 = jb0 + (1024ull << lb);
-      have_batch = true;
-    } else {
-      have_batch = false;
-    }
-  };
-  open_batch();
 
-  // ---- pass 2: sample ----
-  uint64_t consumed = 0;  // values seen so far (uniform)
+  // sorts the 1024 sampled values of batch kb (weight 2^level), keeps every other one, inserts the run above
+  auto flush_batch = [&](uint64_t kb, uint32_t level) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = ring[((kb & 3) << 10) + t + u * kKllThreads];
+    __syncthreads();
+    block_sort_1024(buf);
+    const uint32_t parity = (uint32_t)(kll_mix(salt ^ 0x5bd1e995ULL ^ (kb << 1)) >> 35) & 1u;
+    const double a = buf[2 * t + parity], b = buf[2 * (t + 256) + parity];
+    __syncthreads();
+    buf[t] = a;
+    buf[t + 256] = b;
+    __syncthreads();
+    insert_run(s, level + 1, buf, salt ^ (kb << 24));
+  };
+  auto pick_of = [&](uint32_t level, uint64_t seg0, uint64_t g) -> uint64_t {
+    return kll_mix(salt ^ ((uint64_t)level << 56) ^ (g + (seg0 << 8))) & ((1ull << level) - 1);
+  };
+
+  // ---- phase A: stream the range once; every value is a candidate of a level-top group ----
+  double mn = __longlong_as_double(0x7FF0000000000000LL), mx = -mn;
+  uint64_t consumed = 0, kb = 0;               // values seen so far / level-top batches flushed (uniform)
+  int64_t tail_base = r0;                      // first step holding values past the last complete batch
+  uint64_t tail_consumed = 0;                  // values before that step
   for (int64_t base = r0; base < r1; base += kKllStepRows) {
     double v[kKllRowsPerThread];
     const uint32_t okm = kll_load_step(d, vals, vbits, base, r1, wide, v);
@@ -329,45 +282,93 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
 #pragma unroll
     for (int u = 0; u < kKllRowsPerThread; u++) {
       if (!((okm >> u) & 1)) continue;
-      if (j >= raw_start) {
-        s->lv0[j - raw_start] = v[u];
-      } else {
-        uint32_t level;
-        uint64_t seg0, sampled0;  // first value / first sampled index of the value's segment
-        if (j < end_top) {
-          level = top;
-          seg0 = 0;
-          sampled0 = 0;
-        } else {
-          const uint32_t q = (uint32_t)((j - end_top) >> 10);  // < X
-          level = 31 - __builtin_clz(X ^ q);                    // the digit of X that q falls under
-          const uint32_t before = X & ~((2u << level) - 1u);    // 1024-value blocks of the higher digits
-          seg0 = end_top + ((uint64_t)before << 10);
-          sampled0 = (batches_top + __builtin_popcount(before)) << 10;
-        }
-        const uint64_t o = j - seg0, g = o >> level;
-        const uint64_t pick = kll_mix(salt ^ ((uint64_t)level << 56) ^ (g + (seg0 << 8))) & ((1ull << level) - 1);
-        if ((o & ((1ull << level) - 1)) == pick) ring[(sampled0 + g) & 4095] = v[u];
-      }
+      mn = v[u] < mn ? v[u] : mn;
+      mx = v[u] > mx ? v[u] : mx;
+      const uint64_t g = j >> top;
+      if ((j & ((1ull << top) - 1)) == pick_of(top, 0, g)) ring[g & 4095] = v[u];
       j++;
     }
+    const uint64_t before = consumed;
     consumed += total;
     __syncthreads();
-    while (have_batch && consumed >= jb1) {  // uniform: every pick of batch kb has been written
-#pragma unroll
-      for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = ring[((kb & 3) << 10) + t + u * kKllThreads];
-      __syncthreads();
-      // sort, keep every other value (weight 2^(lb+1)), insert the run one level up
-      block_sort_1024(buf);
-      const uint32_t parity = (uint32_t)(kll_mix(salt ^ 0x5bd1e995ULL ^ (kb << 1)) >> 35) & 1u;
-      const double a = buf[2 * t + parity], b = buf[2 * (t + 256) + parity];
-      __syncthreads();
-      buf[t] = a;
-      buf[t + 256] = b;
-      __syncthreads();
-      insert_run(s, lb + 1, buf, salt ^ (kb << 24));
+    while (consumed >= (kb + 1) * top_items) {  // uniform: every pick of batch kb has been written
+      flush_batch(kb, top);
       kb++;
-      open_batch();
+      const uint64_t end = kb * top_items;
+      tail_base = consumed > end ? base : base + kKllStepRows;
+      tail_consumed = consumed > end ? before : consumed;
+    }
+  }
+  const uint64_t V = consumed;
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    const double omn = __shfl_down(mn, dlt, 64), omx = __shfl_down(mx, dlt, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  if ((t & 63) == 0) {
+    red_min[t >> 6] = mn;
+    red_max[t >> 6] = mx;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = red_min[0], b = red_max[0];
+    for (int w = 0; w < kKllThreads / 64; w++) {
+      a = red_min[w] < a ? red_min[w] : a;
+      b = red_max[w] > b ? red_max[w] : b;
+    }
+    s->n = V;
+    s->min_v = a;
+    s->max_v = b;
+  }
+
+  // ---- phase B: the values after the last level-top segment: the binary digits X of their count, then raw ----
+  const uint64_t end_top = kb * top_items;
+  const uint32_t X = (uint32_t)((V - end_top) >> 10);        // < 2^top: digit l = one segment of level l
+  const uint64_t raw_start = end_top + ((uint64_t)X << 10);  // first raw value
+  const uint64_t batches_top = kb;
+  uint32_t xrest = X, lb = 0;
+  uint64_t jb1 = end_top;  // end of the open lower-level batch
+  bool have_batch = false;
+  auto open_batch = [&]() {
+    have_batch = xrest != 0;
+    if (have_batch) {
+      lb = 31 - __builtin_clz(xrest);
+      xrest &= ~(1u << lb);
+      jb1 += 1024ull << lb;
+    }
+  };
+  open_batch();
+  if (V > end_top) {
+    consumed = tail_consumed;
+    for (int64_t base = tail_base; base < r1; base += kKllStepRows) {
+      double v[kKllRowsPerThread];
+      const uint32_t okm = kll_load_step(d, vals, vbits, base, r1, wide, v);
+      uint32_t total;
+      uint64_t j = consumed + block_exclusive_scan(__builtin_popcount(okm), wave_tot, &total);
+#pragma unroll
+      for (int u = 0; u < kKllRowsPerThread; u++) {
+        if (!((okm >> u) & 1)) continue;
+        if (j >= raw_start) {
+          s->lv0[j - raw_start] = v[u];
+        } else if (j >= end_top) {
+          const uint32_t q = (uint32_t)((j - end_top) >> 10);   // < X
+          const uint32_t level = 31 - __builtin_clz(X ^ q);      // the digit of X that q falls under
+          const uint32_t before = X & ~((2u << level) - 1u);     // 1024-value blocks of the higher digits
+          const uint64_t seg0 = end_top + ((uint64_t)before << 10);
+          const uint64_t sampled0 = (batches_top + __builtin_popcount(before)) << 10;
+          const uint64_t o = j - seg0, g = o >> level;
+          if ((o & ((1ull << level) - 1)) == pick_of(level, seg0, g)) ring[(sampled0 + g) & 4095] = v[u];
+        }
+        j++;
+      }
+      consumed += total;
+      __syncthreads();
+      while (have_batch && consumed >= jb1) {
+        flush_batch(kb, lb);
+        kb++;
+        open_batch();
+      }
     }
   }
   if (t == 0) s->lv0_count = (uint32_t)(V - raw_start);
