@@ -62,7 +62,13 @@ typedef enum tgx_type {
    * REGEX_MATCH give the results of the decoded column: string work runs once per dictionary entry,
    * every batch may bring its own dictionary (unused and repeated entries allowed). A row whose dictionary
    * VALUE is NULL is a NULL row for DISTINCT and REGEX_MATCH. */
-  TGX_DICT32_UTF8 = 5
+  TGX_DICT32_UTF8 = 5,
+  /* Utf8View (what DataFusion reads Parquet strings as): 16-byte views in `values` -- {int32 length, 12 inline
+   * bytes} for length <= 12, else {int32 length, 4-byte prefix, int32 buffer index, int32 offset} -- and
+   * `n_variadic` data buffers.  `variadic` is a HOST array of the buffers' pointers (the buffers themselves live
+   * in `mem`); `variadic_sizes` (bytes, host array) is required for TGX_MEM_HOST columns, which are staged.
+   * COUNT, DISTINCT and REGEX_MATCH give the results of the same values held as Utf8. */
+  TGX_UTF8_VIEW = 6
 } tgx_type;
 
 typedef enum tgx_memspace { TGX_MEM_HOST = 0, TGX_MEM_DEVICE = 1 } tgx_memspace;
@@ -78,6 +84,10 @@ typedef struct tgx_column {
   const void *offsets;     /* Utf8: length+1 (+offset) int32/int64 offsets */
   const uint8_t *data;     /* Utf8: value bytes */
   const struct tgx_column *dictionary; /* TGX_DICT32_UTF8 only */
+  const uint8_t *const *variadic;      /* TGX_UTF8_VIEW only: host array of n_variadic data buffer pointers */
+  const int64_t *variadic_sizes;       /* TGX_UTF8_VIEW only: host array of their sizes in bytes (HOST columns) */
+  int32_t n_variadic;
+  int32_t reserved;
 } tgx_column;
 
 /* ---- check specs: the aggregates the reference's constraints emit as SQL ------------------ */

@@ -33,6 +33,8 @@ from ._lib import (  # noqa: F401
     FLOAT64,
     UTF8,
     LARGE_UTF8,
+    DICT32_UTF8,
+    UTF8_VIEW,
     MEM_HOST,
     MEM_DEVICE,
 )

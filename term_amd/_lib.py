@@ -10,7 +10,7 @@ _ROOT = os.path.dirname(_HERE)
 COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN = 1, 2, 3, 4, 5, 6, 7
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
-INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8 = 1, 2, 3, 4, 5
+INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW = 1, 2, 3, 4, 5, 6
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
                 4: "TGX_OUT_OF_MEMORY", 5: "TGX_INTERNAL", 6: "TGX_NO_DEVICE"}
@@ -36,6 +36,8 @@ _Column._fields_ = [
     ("type", C.c_int32), ("mem", C.c_int32), ("length", C.c_int64), ("offset", C.c_int64),
     ("null_count", C.c_int64), ("validity", C.c_void_p), ("values", C.c_void_p), ("offsets", C.c_void_p),
     ("data", C.c_void_p), ("dictionary", C.POINTER(_Column)),
+    ("variadic", C.POINTER(C.c_void_p)), ("variadic_sizes", C.POINTER(C.c_int64)), ("n_variadic", C.c_int32),
+    ("reserved", C.c_int32),
 ]
 
 
@@ -186,8 +188,8 @@ class Column:
     """A tgx_column view. Keeps the Python buffers alive while the view exists."""
 
     def __init__(self, type, length, values=None, validity=None, offsets=None, data=None, offset=0,
-                 null_count=-1, mem=None, dictionary=None):
-        self._keep = (values, validity, offsets, data, dictionary)
+                 null_count=-1, mem=None, dictionary=None, variadic=None):
+        self._keep = (values, validity, offsets, data, dictionary, variadic)
         c = _Column()
         c.type = type
         c.length = length
@@ -199,6 +201,20 @@ class Column:
             setattr(c, name, p)
             if is_dev is not None:
                 spaces.add(bool(is_dev))
+        if variadic is not None:
+            # Utf8View data buffers: a host array of their pointers (+ sizes, needed to stage HOST buffers)
+            ptrs = (C.c_void_p * max(1, len(variadic)))()
+            sizes = (C.c_int64 * max(1, len(variadic)))()
+            for k, buf in enumerate(variadic):
+                pk, is_dev = _ptr_of(buf)
+                ptrs[k] = pk
+                sizes[k] = int(buf.nbytes) if hasattr(buf, "nbytes") else int(buf.numel() * buf.element_size())
+                if is_dev is not None:
+                    spaces.add(bool(is_dev))
+            c.variadic = C.cast(ptrs, C.POINTER(C.c_void_p))
+            c.variadic_sizes = C.cast(sizes, C.POINTER(C.c_int64))
+            c.n_variadic = len(variadic)
+            self._keep += (ptrs, sizes)
         if mem is None:
             if len(spaces) > 1:
                 raise ValueError("a column's buffers must all live in one memory space")
@@ -227,6 +243,12 @@ class Column:
     def large_utf8(offsets, data, validity=None, length=None, offset=0):
         n = (len(offsets) - 1 - offset) if length is None else length
         return Column(LARGE_UTF8, n, offsets=offsets, data=data, validity=validity, offset=offset)
+
+    @staticmethod
+    def utf8_view(views, buffers, validity=None, length=None, offset=0):
+        """Utf8View: `views` = 16 bytes per row (uint8 buffer of 16 * rows bytes), `buffers` = list of data buffers"""
+        n = (len(views) // 16 - offset) if length is None else length
+        return Column(UTF8_VIEW, n, values=views, validity=validity, offset=offset, variadic=list(buffers))
 
     @staticmethod
     def dict32_utf8(indices, dictionary, validity=None, length=None, offset=0):
@@ -261,6 +283,9 @@ class Column:
             data = view(bufs[2], np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
             return Column(LARGE_UTF8, len(arr), offsets=view(bufs[1], np.int64), data=data, validity=validity,
                           offset=arr.offset, null_count=arr.null_count)
+        if hasattr(pa.types, "is_string_view") and pa.types.is_string_view(arr.type):
+            return Column(UTF8_VIEW, len(arr), values=view(bufs[1], np.uint8), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count, variadic=[view(b, np.uint8) for b in bufs[2:]])
         if (pa.types.is_dictionary(arr.type) and pa.types.is_int32(arr.type.index_type)
                 and (pa.types.is_string(arr.type.value_type) or pa.types.is_large_string(arr.type.value_type))):
             return Column(DICT32_UTF8, len(arr), values=view(bufs[1], np.int32), validity=validity,

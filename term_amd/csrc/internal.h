@@ -36,7 +36,8 @@ hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_c
 void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
                          uint64_t slice_words, uint64_t stride_words, uint32_t *out_seen, uint32_t *out_twice,
                          unsigned long long *d_counters, hipStream_t stream);
-void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *views,
+                          const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
@@ -223,6 +224,9 @@ struct tgx_state {
   std::vector<std::unique_ptr<tgx::DevBuf>> staging;  // host columns copied to the device
   size_t staging_used = 0;
   std::deque<tgx_column> dict_views;  // device views of the dictionaries of the batch being updated
+  // host copies of Utf8View buffer-pointer tables whose asynchronous upload may still be pending; dropped
+  // wherever the stream is synchronized (gather / reset)
+  std::deque<std::vector<const uint8_t *>> ptr_tables;
 
   // host accumulators: contributions merged in from other states / deserialized blobs
   std::vector<tgx::ScanAcc> h_scan;

@@ -117,6 +117,8 @@ struct Utf8ColDesc {
   int64_t length;
   int32_t large_offsets;
   int32_t want_multiplicity;
+  const void *views;              // Utf8View: 16-byte views (then offsets / data are unused)
+  const uint8_t *const *buffers;  // Utf8View: device array of the data buffers' device pointers
 };
 
 __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashSetView t,
@@ -129,7 +131,19 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
     if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) continue;
     n_valid++;
     int64_t b, e;
-    if (d.large_offsets) {
+    uintptr_t base = (uintptr_t)d.data;
+    if (d.views) {
+      global_i32_ptr vw = (global_i32_ptr)((uintptr_t)d.views + (uintptr_t)slot * 16);
+      const int32_t len = vw[0];
+      b = 0;
+      e = len;
+      if (len <= 12) {
+        base = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
+      } else {
+        const int32_t bi = vw[2], bo = vw[3];
+        base = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
+      }
+    } else if (d.large_offsets) {
       global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
       b = off[slot];
       e = off[slot + 1];
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
       e = off[slot + 1];
     }
     uint64_t fa, fb;
-    fingerprint((uintptr_t)d.data + (uintptr_t)b, (uint64_t)(e - b), &fa, &fb);
+    fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &fa, &fb);
     int became_dup = 0;
     n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
     n_dup += became_dup;
@@ -251,6 +265,8 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
   Utf8ColDesc d;
   d.offsets = offsets;
   d.data = data;
+  d.views = nullptr;
+  d.buffers = nullptr;
   d.validity = validity;
   d.offset = offset;
   d.length = length;
@@ -269,12 +285,15 @@ static inline int grid_for128(uint64_t items) {
   return (int)blocks;
 }
 
-void launch_distinct_utf8(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *views,
+                          const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
   d.offsets = offsets;
   d.data = data;
+  d.views = views;
+  d.buffers = buffers;
   d.validity = validity;
   d.offset = offset;
   d.length = length;

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   __syncthreads();
   global_u8_ptr g_acc = (global_u8_ptr)(uintptr_t)dfa.accept_end;
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
-  const uintptr_t data = (uintptr_t)d.data;
+  const uintptr_t data0 = (uintptr_t)d.data;
+  const bool is_view = d.views != nullptr;  // uniform
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *stage = s_stage[wave];
   unsigned long long matches = 0;
@@ -83,8 +84,26 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     const int64_t i = g * 64 + lane;
     const bool in = i < d.length;
     const int64_t slot = d.offset + (in ? i : d.length - 1);
+    bool valid = in;
+    if (in && vbits) valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
     int64_t b, e;
-    if (d.large_offsets) {
+    uintptr_t data = data0;  // base the value's [b, e) refers to
+    if (is_view && !valid) {
+      b = e = 0;  // the view of a NULL slot is arbitrary: never parsed
+    } else if (is_view) {
+      // {length, inline bytes | prefix, buffer, offset}: the value is wherever the view says (no common span)
+      typedef const int32_t __attribute__((address_space(1))) *gi32;
+      gi32 vw = (gi32)((uintptr_t)d.views + (uintptr_t)slot * 16);
+      const int32_t len = vw[0];
+      b = 0;
+      e = len;
+      if (len <= 12) {
+        data = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
+      } else {
+        const int32_t bi = vw[2], bo = vw[3];
+        data = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
+      }
+    } else if (d.large_offsets) {
       global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
       b = off[slot];
       e = off[slot + 1];
@@ -93,19 +112,17 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
       b = off[slot];
       e = off[slot + 1];
     }
-    bool valid = in;
-    if (in && vbits) valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
     // the wave's values are contiguous: [b of lane 0, e of the last lane)
     const int64_t span_b = __shfl(b, 0, 64), span_e = __shfl(e, 63, 64);
     // 16-byte blocks by ABSOLUTE address: a block that holds one byte of the buffer lies in the same page, so
     // the rounded-out copy cannot fault whatever the alignment of `data`
-    const int64_t stage_base = span_b - (int64_t)((data + (uintptr_t)span_b) & 15);
-    const bool staged = span_e - stage_base <= (int64_t)kStageBytes;  // wave-uniform
+    const int64_t stage_base = span_b - (int64_t)((data0 + (uintptr_t)span_b) & 15);
+    const bool staged = !is_view && span_e - stage_base <= (int64_t)kStageBytes;  // wave-uniform
     if (staged) {
       // coalesced 16-byte loads of the span into LDS (values of NULL rows included; never interpreted)
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
-      global_u4_ptr src = (global_u4_ptr)(data + (uintptr_t)stage_base);
+      global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)stage_base);
       const int64_t n16 = (span_e - stage_base + 15) >> 4;
       for (int64_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + 16 * k) = src[k];
       __builtin_amdgcn_wave_barrier();

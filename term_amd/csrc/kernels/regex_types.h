@@ -17,6 +17,8 @@ struct RegexColDesc {
   int32_t null_is_valid;    // NULL rows count as matches
   int32_t pad;
   uint8_t *hits;            // optional: one byte per row (1 match, 0 no match, 2 NULL row) -- dictionary columns
+  const void *views;        // Utf8View: 16-byte views (then offsets / data are unused)
+  const uint8_t *const *buffers;  // Utf8View: device array of the data buffers' device pointers
 };
 
 struct DfaView {

@@ -131,7 +131,8 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     RegexTaskState &ts = rs->tasks[i];
     const tgx_column &c = dev[t.column];
     const bool is_dict = c.type == TGX_DICT32_UTF8;
-    if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && !is_dict)
+    const bool is_view = c.type == TGX_UTF8_VIEW;
+    if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && !is_dict && !is_view)
       return rfail(err, TGX_UNSUPPORTED, "REGEX_MATCH needs a Utf8 column (column %d has type %d)", t.column, c.type);
     if (!ts.table.p) {
       const rx::Dfa &d = t.dfa;
@@ -157,6 +158,8 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     d.length = sc.length;
     d.large_offsets = sc.type == TGX_LARGE_UTF8;
     d.hits = is_dict ? ts.dict_hits.as<uint8_t>() : nullptr;
+    d.views = is_view ? c.values : nullptr;
+    d.buffers = is_view ? c.variadic : nullptr;
     d.trim = (t.flags & TGX_FLAG_TRIM) != 0;
     d.null_is_valid = (t.flags & TGX_FLAG_NULL_IS_VALID) != 0;
     d.pad = 0;

@@ -398,6 +398,7 @@ extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) {
 extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
+  st->ptr_tables.clear();
   // host side back to the identity; device buffers are kept and re-zeroed (no hipFree / hipMalloc)
   st->batches = 0;
   st->col_types.assign(plan->n_columns_needed, 0);
@@ -521,6 +522,7 @@ static bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
 
 // copies a HOST column's buffers to the device; `out` is the device view
 static bool is_string(int t) { return t == TGX_UTF8 || t == TGX_LARGE_UTF8; }
+static bool is_any_string(int t) { return is_string(t) || t == TGX_UTF8_VIEW; }
 
 static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx_error *err) {
   *out = c;
@@ -534,8 +536,8 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
       TGX_TRY(stage_column(st, *c.dictionary, dv, err));
     out->dictionary = dv;
   }
-  if (c.mem == TGX_MEM_DEVICE) return TGX_OK;
-  if (c.mem != TGX_MEM_HOST) return fail(err, TGX_INVALID_ARGUMENT, "unknown memory space %d", c.mem);
+  if (c.mem != TGX_MEM_HOST && c.mem != TGX_MEM_DEVICE)
+    return fail(err, TGX_INVALID_ARGUMENT, "unknown memory space %d", c.mem);
   auto stage = [&](const void *src, size_t bytes, const void **dst) -> tgx_status {
     *dst = nullptr;
     if (!src || bytes == 0) return TGX_OK;
@@ -546,6 +548,23 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
     *dst = b->p;
     return TGX_OK;
   };
+  if (c.type == TGX_UTF8_VIEW) {
+    // the kernels read the data buffers through a DEVICE table of their (device) pointers
+    st->ptr_tables.emplace_back((size_t)std::max(c.n_variadic, 1), nullptr);
+    std::vector<const uint8_t *> &table = st->ptr_tables.back();
+    for (int32_t k = 0; k < c.n_variadic; k++) {
+      table[k] = c.variadic[k];
+      if (c.mem == TGX_MEM_HOST) {
+        const void *q = nullptr;
+        TGX_TRY(stage(c.variadic[k], (size_t)c.variadic_sizes[k], &q));
+        table[k] = (const uint8_t *)q;
+      }
+    }
+    const void *dt = nullptr;
+    TGX_TRY(stage(table.data(), table.size() * sizeof(void *), &dt));
+    out->variadic = (const uint8_t *const *)dt;
+  }
+  if (c.mem == TGX_MEM_DEVICE) return TGX_OK;
   // Only the window the batch views is copied: a sliced array (offset > 0 into big buffers) costs its own rows,
   // not everything before them.  The window starts at slot e0 = offset rounded down to 64 (keeps the validity
   // byte / word alignment the kernels like); the device view gets offset - e0 as its Arrow offset.
@@ -575,6 +594,9 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
     out->data = p ? (const uint8_t *)p - (first - lead) : nullptr;
   } else if (c.type == TGX_DICT32_UTF8) {
     TGX_TRY(stage(c.values ? (const uint8_t *)c.values + (size_t)e0 * 4 : nullptr, (size_t)slots * 4, &p));
+    out->values = p;
+  } else if (c.type == TGX_UTF8_VIEW) {
+    TGX_TRY(stage(c.values ? (const uint8_t *)c.values + (size_t)e0 * 16 : nullptr, (size_t)slots * 16, &p));
     out->values = p;
   } else {
     return fail(err, TGX_UNSUPPORTED, "column type %d is not supported", c.type);
@@ -725,7 +747,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
-  if (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) {
+  if (is_any_string(c.type)) {
     // values are reduced to 128-bit fingerprints on the fly (kernels/distinct128.hip)
     ds.col_type = c.type;
     ds.total_rows += c.length;
@@ -736,8 +758,10 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     }
     TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
     ProfScope ps(st, "distinct", 0);
-    launch_distinct_utf8(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, mult ? 1 : 0,
-                         hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+    const bool view = c.type == TGX_UTF8_VIEW;
+    launch_distinct_utf8(c.offsets, c.data, view ? c.values : nullptr, view ? c.variadic : nullptr, c.validity,
+                         c.offset, c.length, c.type == TGX_LARGE_UTF8, mult ? 1 : 0, hash_view(ds),
+                         ds.counters.as<unsigned long long>(), st->stream);
     return TGX_OK;
   }
   if (c.type == TGX_DICT32_UTF8) {
@@ -922,7 +946,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     if (c.length != nrows)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d has %lld rows, expected %lld", i, (long long)c.length,
                   (long long)nrows);
-    if (c.type < TGX_INT64 || c.type > TGX_DICT32_UTF8) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
+    if (c.type < TGX_INT64 || c.type > TGX_UTF8_VIEW) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
     if (st->col_types[i] == 0) st->col_types[i] = c.type;
     if (st->col_types[i] != c.type)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d changed type between batches (%d -> %d)", i,
@@ -932,6 +956,13 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
       if ((c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && !c.offsets)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets is NULL", i);
+    }
+    if (c.type == TGX_UTF8_VIEW && c.length > 0) {
+      if (!c.values) return fail(err, TGX_INVALID_ARGUMENT, "column %d: views (values) is NULL", i);
+      if (c.n_variadic < 0 || (c.n_variadic > 0 && !c.variadic))
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: malformed variadic buffer list", i);
+      if (c.mem == TGX_MEM_HOST && c.n_variadic > 0 && !c.variadic_sizes)
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: HOST Utf8View columns need variadic_sizes", i);
     }
     if (c.type == TGX_DICT32_UTF8) {
       const tgx_column *dc = c.dictionary;
@@ -1157,6 +1188,7 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   g->distinct.resize(plan->distinct.size());
   if (st->device_ready) {
     HIP_TRY(hipStreamSynchronize(st->stream));
+    st->ptr_tables.clear();
     if (!plan->scan.empty()) {
       std::vector<ScanAcc> d(plan->scan.size());
       HIP_TRY(hipMemcpy(d.data(), st->d_scan_acc.p, d.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost));
@@ -1366,7 +1398,7 @@ extern "C" size_t tgx_distinct_record_bytes(const tgx_plan *plan, const tgx_stat
       plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return 0;
   const DistinctState &ds = st->distinct[plan->bind[spec_index].slot];
-  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8 || ds.col_type == TGX_DICT32_UTF8;
+  const bool wide = ds.wide || is_any_string(ds.col_type) || ds.col_type == TGX_DICT32_UTF8;
   return wide ? sizeof(KeyRecord128) : sizeof(KeyRecord);
 }
 
@@ -1417,7 +1449,7 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   unsigned long long c[kNumDistinctCounters];
   TGX_TRY(distinct_read_counters(st, ds, c, err));
   const unsigned long long valid_rows = c[kCntValidRows];
-  const bool wide = ds.wide || ds.col_type == TGX_UTF8 || ds.col_type == TGX_LARGE_UTF8 || ds.col_type == TGX_DICT32_UTF8;
+  const bool wide = ds.wide || is_any_string(ds.col_type) || ds.col_type == TGX_DICT32_UTF8;
   ds.seen.release();
   ds.twice.release();
   ds.keys.release();
