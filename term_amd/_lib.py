@@ -44,7 +44,8 @@ _Column._fields_ = [
 class CheckSpec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("column", C.c_int32), ("column2", C.c_int32), ("flags", C.c_uint32),
                 ("pattern", C.c_char_p), ("pattern_len", C.c_uint64), ("kll_k", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("columns", C.POINTER(C.c_int32)), ("n_columns", C.c_uint32),
+                ("reserved2", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -294,9 +295,17 @@ class Column:
         raise TgxError(2, "unsupported Arrow type %s" % arr.type)
 
 
-def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0):
+def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0, columns=None):
+    """columns=[a, b, ...]: DISTINCT over the tuple of those columns (COUNT(DISTINCT (a, b)))"""
     pat = pattern.encode("utf-8") if isinstance(pattern, str) else pattern
-    return CheckSpec(kind, column, column2, flags, pat, len(pat) if pat else 0, kll_k, 0)
+    s = CheckSpec(kind, column, column2, flags, pat, len(pat) if pat else 0, kll_k, 0)
+    if columns is not None and len(columns) >= 2:
+        arr = (C.c_int32 * len(columns))(*columns)
+        s.columns = C.cast(arr, C.POINTER(C.c_int32))
+        s.n_columns = len(columns)
+        s._keep_columns = arr
+        s.column = columns[0]
+    return s
 
 
 class Plan:

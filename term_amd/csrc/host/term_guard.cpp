@@ -2,6 +2,7 @@
 // next to each constraint; the aggregates come from libtgx (one fused plan per suite run).
 #include "term_guard.h"
 
+#include <deque>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -461,12 +462,16 @@ class UniquenessConstraint : public Constraint {
     return cols_.size() == 1 ? std::optional<std::string>(cols_[0]) : std::nullopt;
   }
   std::vector<SpecRequest> plan() const override {
-    if (cols_.size() != 1)
-      throw TermError{TermError::NotSupported,
-                      "multi-column uniqueness (COUNT(DISTINCT (a, b))) is not on the GPU path yet"};
+    if (cols_.size() > 8)
+      throw TermError{TermError::NotSupported, "uniqueness over more than 8 columns is not on the GPU path"};
     SpecRequest r;
     r.kind = TGX_CHECK_DISTINCT;
     r.column = cols_[0];
+    // COUNT(DISTINCT (a, b)) / GROUP BY a, b (uniqueness.rs:557-562, 687-699): the tuple is one value.  The
+    // multi-column Distinctness SQL concatenates COALESCE(CAST(c AS VARCHAR), '<NULL>') with '|' (:643-647); the
+    // tuple gives the same count unless values contain '|' or the literal '<NULL>' (where the concatenation
+    // conflates different rows).
+    if (cols_.size() >= 2) r.columns = cols_;
     if (t_.kind == UniquenessType::UniqueValueRatio) r.flags = TGX_FLAG_MULTIPLICITY;
     return {r};
   }
@@ -480,7 +485,7 @@ class UniquenessConstraint : public Constraint {
       case UniquenessType::FullUniqueness:
       case UniquenessType::UniqueWithNulls: {
         double unique = (double)r->distinct;
-        if (t_.kind == UniquenessType::UniqueWithNulls) {
+        if (t_.kind == UniquenessType::UniqueWithNulls && cols_.size() == 1) {  // multi-column: plain tuple count (:579-585, 600-607)
           if (t_.null_handling == NullHandling::Include) unique += nulls > 0 ? 1.0 : 0.0;  // COALESCE(c, '<NULL>')
           if (t_.null_handling == NullHandling::Distinct) unique += nulls;                 // :594-598
         }
@@ -836,6 +841,7 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
   std::vector<Planned> planned;
   std::vector<tgx_check_spec> specs;
   std::vector<SpecRequest> spec_requests;  // owns the pattern strings the specs point to
+  std::deque<std::vector<int32_t>> tuple_columns;  // owns the column lists of tuple specs
   auto column_index = [&](const std::string &name) -> int {
     if (!table) return -1;
     for (size_t i = 0; i < table->column_names.size(); i++)
@@ -862,8 +868,10 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
         for (SpecRequest &r : p.requests) {
           if (r.column.empty() && r.kind == TGX_CHECK_COUNT && !table->column_names.empty())
             r.column = table->column_names[0];
-          for (const std::string *col : {&r.column, &r.column2}) {
-            if (col == &r.column2 && r.kind != TGX_CHECK_COMOMENTS) continue;
+          std::vector<const std::string *> named = {&r.column};
+          if (r.kind == TGX_CHECK_COMOMENTS) named.push_back(&r.column2);
+          for (const std::string &c2 : r.columns) named.push_back(&c2);
+          for (const std::string *col : named) {
             if (column_index(*col) < 0) {
               p.error = TermError{TermError::DataFusion, "Schema error: No field named " + *col + "."}.display();
               break;
@@ -882,8 +890,8 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
       size_t found = spec_requests.size();
       for (size_t i = 0; i < spec_requests.size(); i++) {
         const SpecRequest &q = spec_requests[i];
-        if (q.kind == r.kind && q.column == r.column && q.column2 == r.column2 && q.flags == r.flags &&
-            q.pattern == r.pattern && q.kll_k == r.kll_k)
+        if (q.kind == r.kind && q.column == r.column && q.column2 == r.column2 && q.columns == r.columns &&
+            q.flags == r.flags && q.pattern == r.pattern && q.kll_k == r.kll_k)
           found = i;
       }
       if (found == spec_requests.size()) spec_requests.push_back(r);
@@ -900,6 +908,12 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
     s.pattern = r.pattern.empty() ? nullptr : r.pattern.data();
     s.pattern_len = r.pattern.size();
     s.kll_k = r.kll_k;
+    if (r.columns.size() >= 2) {
+      tuple_columns.emplace_back();
+      for (const std::string &c2 : r.columns) tuple_columns.back().push_back(column_index(c2));
+      s.columns = tuple_columns.back().data();
+      s.n_columns = (uint32_t)tuple_columns.back().size();
+    }
     specs.push_back(s);
   }
 

@@ -120,6 +120,7 @@ struct StatisticType {
 struct SpecRequest {
   int kind = 0;  // tgx_check_kind
   std::string column, column2;
+  std::vector<std::string> columns;  // DISTINCT over a tuple of columns (then `column` is columns[0])
   uint32_t flags = 0;
   std::string pattern;
   uint32_t kll_k = 0;

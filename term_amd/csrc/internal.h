@@ -54,6 +54,8 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
                         int64_t length, int large_offsets, int want_mult, const uint32_t *seen,
                         const uint32_t *twice, const HashSetView &t, unsigned long long *d_counters,
                         hipStream_t stream);
+void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
+                           hipStream_t stream);
 void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
@@ -89,6 +91,7 @@ struct DistinctTask {
   int column;
   bool multiplicity;
   int scan_slot;  // scan task that provides MIN/MAX for the bitmap decision
+  std::vector<int> tuple;  // >= 2 columns: COUNT(DISTINCT (a, b, ...)); `column` is then tuple[0]
 };
 struct ComomentTask {
   int col_x, col_y;

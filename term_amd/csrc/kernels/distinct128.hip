@@ -228,6 +228,70 @@ __global__ __launch_bounds__(256) void hash_export_scatter128_kernel(HashSetView
   }
 }
 
+// ---- tuples of columns: COUNT(DISTINCT (a, b, ...)) / GROUP BY a, b, ... ------------------------------------
+// Every component is reduced to 128 bits (numeric: its bit pattern; string: the fingerprint above; NULL: a
+// marker no value maps to) and the components are chained position by position into the tuple's fingerprint.
+__global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSetView t, unsigned long long *counters) {
+  unsigned long long n_new = 0, n_dup = 0, n_valid = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
+    uint64_t fa = 0x6a09e667f3bcc908ULL, fb = 0xbb67ae8584caa73bULL;
+    bool all_valid = true;
+    for (int c = 0; c < d.n_cols; c++) {
+      const TupleCol &col = d.cols[c];
+      const int64_t slot = col.offset + i;
+      global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)col.validity;
+      uint64_t ca, cb;
+      if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) {
+        all_valid = false;
+        ca = 0x4e554c4c4e554c4cULL;  // "NULLNULL": tagged below so that no value of any type collides with it
+        cb = 0;
+      } else if (col.kind == 0) {  // Int64 / Float64: the 64 bits themselves
+        ca = (uint64_t)((global_i64_ptr)(uintptr_t)col.values)[slot];
+        cb = 1;
+      } else {
+        int64_t b, e;
+        uintptr_t base = (uintptr_t)col.data;
+        if (col.kind == 3) {
+          global_i32_ptr vw = (global_i32_ptr)((uintptr_t)col.values + (uintptr_t)slot * 16);
+          const int32_t len = vw[0];
+          b = 0;
+          e = len;
+          if (len <= 12) {
+            base = (uintptr_t)col.values + (uintptr_t)slot * 16 + 4;
+          } else {
+            const int32_t bi = vw[2], bo = vw[3];
+            base = (uintptr_t)col.buffers[bi] + (uintptr_t)(uint32_t)bo;
+          }
+        } else if (col.kind == 2) {
+          global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
+          b = off[slot];
+          e = off[slot + 1];
+        } else {
+          global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
+          b = off[slot];
+          e = off[slot + 1];
+        }
+        fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &ca, &cb);
+        cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
+      }
+      fa = rotl64(fa ^ mix64w(ca + 0x165667b19e3779f9ULL * (uint64_t)(c + 1)), 27) * 0x9fb21c651e98df25ULL + cb;
+      fb = rotl64(fb ^ mix64w(cb ^ rotl64(ca, 32) ^ 0x27d4eb2f165667c5ULL), 31) * 0xd6e8feb86659fd93ULL + ca;
+    }
+    fa = mix64w(fa);
+    fb = mix64w(fb ^ rotl64(fa, 17));
+    if (fa == kEmptyKey) fa -= 1;
+    if (fb == kEmptyKey) fb -= 1;
+    n_valid += all_valid ? 1 : 0;
+    int became_dup = 0;
+    n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
+    n_dup += became_dup;
+  }
+  block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
+  __syncthreads();
+  block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
 // ---- Dictionary<Int32, Utf8> columns (see dict.hip): fingerprints per dictionary entry, inserted with the
 // multiplicity the usage pass counted (0 = unreferenced entry, skipped)
 __global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, const uint32_t *seen,
@@ -278,6 +342,8 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
   hipLaunchKernelGGL(dict_insert_kernel, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
 }
 
+void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
+                           hipStream_t stream);
 static inline int grid_for128(uint64_t items) {
   uint64_t blocks = (items + 255) / 256;
   if (blocks < 1) blocks = 1;
@@ -326,6 +392,12 @@ void launch_hash_export_scatter128(const HashSetView &src, uint32_t world, int w
                                    unsigned long long *d_cursors, KeyRecord128 *out, hipStream_t stream) {
   hipLaunchKernelGGL(hash_export_scatter128_kernel, dim3(grid_for128(src.mask + 1)), dim3(256), 0, stream, src,
                      world, want_mult, d_cursors, out);
+}
+
+void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(distinct_tuple_kernel, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, t,
+                     d_counters);
 }
 
 }  // namespace tgx

@@ -80,4 +80,23 @@ enum {
   kNumDistinctCounters = 8
 };
 
+// one component of a tuple key (distinct_tuple_kernel)
+struct TupleCol {
+  int32_t kind;  // 0 Int64 / Float64 (bit pattern), 1 Utf8, 2 LargeUtf8, 3 Utf8View
+  int32_t pad;
+  const void *values;             // numeric values / Utf8View views
+  const void *offsets;            // Utf8 / LargeUtf8
+  const uint8_t *data;
+  const uint8_t *const *buffers;  // Utf8View
+  const uint8_t *validity;
+  int64_t offset;
+};
+constexpr int kMaxTupleCols = 8;
+struct TupleDesc {
+  TupleCol cols[kMaxTupleCols];
+  int32_t n_cols;
+  int32_t want_multiplicity;
+  int64_t length;
+};
+
 }  // namespace tgx

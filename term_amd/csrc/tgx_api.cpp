@@ -146,6 +146,22 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
   // pass 1: everything except COUNT
   for (size_t i = 0; i < n_specs; i++) {
     tgx_check_spec &sp = plan->specs[i];
+    std::vector<int> tuple;
+    if (sp.kind == TGX_CHECK_DISTINCT && sp.n_columns >= 2) {
+      if (sp.n_columns > (uint32_t)kMaxTupleCols || !sp.columns)
+        return fail(err, TGX_UNSUPPORTED, "spec %zu: DISTINCT over %u columns (2..%d supported)", i, sp.n_columns,
+                    kMaxTupleCols);
+      for (uint32_t k = 0; k < sp.n_columns; k++) {
+        if (sp.columns[k] < 0) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: negative column index", i);
+        tuple.push_back(sp.columns[k]);
+        max_col = std::max(max_col, sp.columns[k]);
+      }
+      sp.column = tuple[0];
+    } else if (sp.kind != TGX_CHECK_DISTINCT && sp.n_columns >= 2) {
+      return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: only DISTINCT takes a column list", i);
+    }
+    sp.columns = nullptr;  // the caller's array is not kept: the task holds its own copy
+    sp.n_columns = (uint32_t)tuple.size();
     if (sp.column < 0) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: negative column index", i);
     max_col = std::max(max_col, sp.column);
     plan->bind[i].kind = sp.kind;
@@ -160,10 +176,10 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
       case TGX_CHECK_DISTINCT: {
         int slot = -1;
         for (size_t d = 0; d < plan->distinct.size(); d++)
-          if (plan->distinct[d].column == sp.column) slot = (int)d;
+          if (plan->distinct[d].column == sp.column && plan->distinct[d].tuple == tuple) slot = (int)d;
         bool mult = (sp.flags & TGX_FLAG_MULTIPLICITY) != 0;
         if (slot < 0) {
-          plan->distinct.push_back({sp.column, mult, -1});
+          plan->distinct.push_back({sp.column, mult, -1, tuple});
           slot = (int)plan->distinct.size() - 1;
         } else if (mult) {
           plan->distinct[slot].multiplicity = true;
@@ -218,7 +234,8 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
     }
   }
   // Int64 DISTINCT columns want the running MIN/MAX for the range-bitmap decision
-  for (auto &d : plan->distinct) d.scan_slot = need_scan(d.column, false);
+  for (auto &d : plan->distinct)
+    if (d.tuple.empty()) d.scan_slot = need_scan(d.column, false);
   // pass 2: COUNT rides on a scan of the same column when there is one
   for (size_t i = 0; i < n_specs; i++) {
     tgx_check_spec &sp = plan->specs[i];
@@ -743,6 +760,48 @@ static tgx_status bitmap_to_hash(tgx_state *st, DistinctState &ds, bool mult, ui
   return TGX_OK;
 }
 
+// COUNT(DISTINCT (a, b, ...)): every row's tuple goes into the 128-bit fingerprint set (kernels/distinct128.hip)
+static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *dev, tgx_error *err) {
+  const DistinctTask &task = st->plan->distinct[slot];
+  DistinctState &ds = st->distinct[slot];
+  TupleDesc d;
+  memset(&d, 0, sizeof(d));
+  d.n_cols = (int32_t)task.tuple.size();
+  d.want_multiplicity = task.multiplicity ? 1 : 0;
+  d.length = dev[task.tuple[0]].length;
+  for (size_t k = 0; k < task.tuple.size(); k++) {
+    const tgx_column &c = dev[task.tuple[k]];
+    TupleCol &tc = d.cols[k];
+    tc.validity = c.validity;
+    tc.offset = c.offset;
+    if (is_numeric(c.type)) {
+      tc.kind = 0;
+      tc.values = c.values;
+    } else if (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) {
+      tc.kind = c.type == TGX_UTF8 ? 1 : 2;
+      tc.offsets = c.offsets;
+      tc.data = c.data;
+    } else if (c.type == TGX_UTF8_VIEW) {
+      tc.kind = 3;
+      tc.values = c.values;
+      tc.buffers = c.variadic;
+    } else {
+      return fail(err, TGX_UNSUPPORTED, "DISTINCT over a tuple: column type %d is not supported", c.type);
+    }
+  }
+  ds.col_type = TGX_UTF8;  // a 128-bit fingerprint set, like a string column's
+  ds.total_rows += d.length;
+  if (d.length == 0) return TGX_OK;
+  if (ds.mode == DistinctMode::kUndecided) {
+    ds.mode = DistinctMode::kHash;
+    ds.wide = true;
+  }
+  TGX_TRY(hash_ensure(st, ds, task.multiplicity, (uint64_t)d.length, err));
+  ProfScope ps(st, "distinct", 0);
+  launch_distinct_tuple(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+  return TGX_OK;
+}
+
 static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
@@ -932,7 +991,10 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   std::vector<char> used(plan->n_columns_needed, 0), reads_values(plan->n_columns_needed, 0);
   for (auto &t : plan->scan) used[t.column] = reads_values[t.column] = 1;
   for (auto &t : plan->count) used[t.column] = 1;
-  for (auto &t : plan->distinct) used[t.column] = reads_values[t.column] = 1;
+  for (auto &t : plan->distinct) {
+    used[t.column] = reads_values[t.column] = 1;
+    for (int c : t.tuple) used[c] = reads_values[c] = 1;
+  }
   for (auto &t : plan->como) used[t.col_x] = used[t.col_y] = reads_values[t.col_x] = reads_values[t.col_y] = 1;
   for (auto &t : plan->kll) used[t.column] = reads_values[t.column] = 1;
   regex_mark_used(plan, used);
@@ -1136,7 +1198,10 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     }
     // ---- exact distinct ----
     for (size_t s = 0; s < plan->distinct.size(); s++)
-      TGX_TRY(distinct_update(st, s, dev[plan->distinct[s].column], err));
+      if (plan->distinct[s].tuple.empty())
+        TGX_TRY(distinct_update(st, s, dev[plan->distinct[s].column], err));
+      else
+        TGX_TRY(distinct_tuple_update(st, s, dev.data(), err));
     // ---- KLL ----
     for (size_t s = 0; s < plan->kll.size(); s++)
       TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
@@ -1278,7 +1343,7 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
           const int col = plan->scan[b.slot].column;
           if (g.scan[b.slot].total == 0)
             for (size_t d = 0; d < plan->distinct.size(); d++)
-              if (plan->distinct[d].column == col && g.distinct[d].total > 0) {
+              if (plan->distinct[d].column == col && plan->distinct[d].tuple.empty() && g.distinct[d].total > 0) {
                 r->total = (int64_t)g.distinct[d].total;
                 r->non_null = (int64_t)g.distinct[d].non_null;
               }
@@ -1297,7 +1362,7 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
         r->distinct = (int64_t)t.distinct;
         // groups with cnt == 1: keys seen exactly once, plus the NULL group when it has one row
         // (only tracked when the spec asks for TGX_FLAG_MULTIPLICITY; 0 otherwise)
-        r->groups_once = plan->distinct[b.slot].multiplicity
+        r->groups_once = (plan->specs[i].flags & TGX_FLAG_MULTIPLICITY)
                              ? (int64_t)(t.distinct - t.twice) + ((t.total - t.non_null) == 1 ? 1 : 0)
                              : 0;
         break;

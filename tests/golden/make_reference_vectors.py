@@ -76,6 +76,14 @@ uniqueness = [
          status="skipped"),
 ]
 
+# multi-column: COUNT(DISTINCT (col1, col2)) / the '|'-concatenation of COALESCE(CAST(c AS VARCHAR), '<NULL>')
+uniqueness_multi = [
+    dict(ref="constraints/uniqueness.rs:1009-1023", kind="full_uniqueness", col1=["A", "B", "A"], col2=["1", "2", "2"],
+         threshold=0.9, status="success", metric=1.0),
+    dict(ref="constraints/uniqueness.rs:1025-1041", kind="distinctness", col1=["A", "B", "A"], col2=["1", "2", "1"],
+         assertion=["greater_than", 0.5], status="success", metric=2.0 / 3.0),
+]
+
 EMAIL = "email"
 fmt = [
     dict(ref="constraints/format.rs:917-934", format="email", threshold=0.7,
@@ -240,7 +248,8 @@ assertion = [
     dict(kind="not_between", args=[10.0, 20.0], value=15.0, ok=False, text="not between 10 and 20"),
 ]
 
-out = dict(completeness=completeness, statistics=statistics, uniqueness=uniqueness, format=fmt,
+out = dict(completeness=completeness, statistics=statistics, uniqueness=uniqueness,
+           uniqueness_multi=uniqueness_multi, format=fmt,
            patterns=patterns, analyzers=analyzers, correlation=correlation, kll=kll, assertion=assertion)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 with open(path, "w") as f:

@@ -160,3 +160,63 @@ def test_host_slices_stage_only_their_window(golden):
                        (w.total, w.non_null, w.distinct, w.groups_once, w.matches, w.min_i, w.max_i, w.sum_i)
             d = orc.distinct_utf8(offs, data, validity, n=m, offset=lo)
             check(got[0], d)
+
+
+def test_distinct_over_column_tuples():
+    """COUNT(DISTINCT (a, b, ...)) / GROUP BY a, b, ...: the tuple is one value, NULL components included
+    (constraints/uniqueness.rs:557-562, 687-699, 709-715); checked against a Python Counter of the rows"""
+    from collections import Counter
+
+    from gpu_util import numeric_column
+
+    rng = np.random.default_rng(21)
+    n = 150_000
+    strs = make_strings(rng, n, 300)
+    ints = rng.integers(0, 40, size=n, dtype=np.int64)
+    flts = rng.integers(0, 5, size=n).astype(np.float64)
+    flts[rng.random(n) < 0.1] = -0.0  # by bit pattern: -0.0 and 0.0 are different components
+    imask, fmask = rng.random(n) >= 0.1, rng.random(n) >= 0.2
+    offs, data, svalid = orc.utf8_from_list(strs)
+    iv, fv = orc.pack_validity(imask), orc.pack_validity(fmask)
+
+    def rows(cols):
+        out = []
+        for i in range(n):
+            t = []
+            for c in cols:
+                if c == 0:
+                    t.append(strs[i])
+                elif c == 1:
+                    t.append(int(ints[i]) if imask[i] else None)
+                else:
+                    t.append(float(flts[i]).hex() if fmask[i] else None)
+            out.append(tuple(t))
+        return out
+
+    for large in (False, True):
+        columns = [utf8_column(offs, data, svalid, True, large=large), numeric_column(ints, iv, True),
+                   numeric_column(flts, fv, True)]
+        for cols in ([0, 1], [1, 2], [2, 1, 0]):
+            cnt = Counter(rows(cols))
+            res, plan, st = run_plan([spec(T.DISTINCT, cols[0], columns=cols, flags=T.FLAG_MULTIPLICITY),
+                                      spec(T.DISTINCT, cols[0], columns=cols)], [columns])
+            want = (n, sum(1 for t in rows(cols) if None not in t), len(cnt), sum(1 for v in cnt.values() if v == 1))
+            assert (res[0].total, res[0].non_null, res[0].distinct, res[0].groups_once) == want
+            assert (res[1].total, res[1].non_null, res[1].distinct, res[1].groups_once) == want[:3] + (0,)
+    # batches + serialize / merge: the union is by tuple VALUE
+    plan = T.Plan([spec(T.DISTINCT, 0, columns=[0, 1], flags=T.FLAG_MULTIPLICITY)])
+    a, b = T.State(plan), T.State(plan)
+    half = n // 2 // 64 * 64
+    a.update([utf8_column(offs, data, svalid, True, length=half), numeric_column(ints, iv, True, length=half)])
+    b.update([utf8_column(offs, data, svalid, True, offset=half, length=n - half),
+              numeric_column(ints, iv, True, offset=half, length=n - half)])
+    m = T.State.deserialize(plan, a.serialize())
+    m.merge([T.State.deserialize(plan, b.serialize())])
+    cnt = Counter(rows([0, 1]))
+    r = m.finalize()[0]
+    assert (r.total, r.distinct, r.groups_once) == (n, len(cnt), sum(1 for v in cnt.values() if v == 1))
+    # too many columns / a column list on another check kind
+    with pytest.raises(T.TgxError):
+        T.Plan([spec(T.DISTINCT, 0, columns=list(range(9)))])
+    with pytest.raises(T.TgxError):
+        T.Plan([spec(T.COUNT, 0, columns=[0, 1])])

@@ -75,6 +75,17 @@ def test_reference_vectors_end_to_end(golden):
             assert r.is_failure() and case["message_contains"] in r.report.issues[0].message
         else:
             assert m.skipped_checks == 1
+    # multi-column uniqueness: COUNT(DISTINCT (col1, col2)) as ONE tuple check (constraints/uniqueness.rs:1009-1041)
+    for case in golden["uniqueness_multi"]:
+        tbl = arrow_table(col1=(pa.string(), case["col1"]), col2=(pa.string(), case["col2"]))
+        b = Check.builder("chk").level(Level.ERROR)
+        if case["kind"] == "full_uniqueness":
+            b.validates_uniqueness(["col1", "col2"], case["threshold"])
+        else:
+            b.validates_distinctness(["col1", "col2"], Assertion(*case["assertion"]))
+        r = ValidationSuite.builder("s").check(b.build()).build().run(tbl)
+        assert r.is_success(), case["ref"]
+        assert abs(r.report.metrics.custom_metrics["chk." + case["kind"]] - case["metric"]) < 1e-12
     # formats
     for case in golden["format"]:
         fmt = case["format"]
