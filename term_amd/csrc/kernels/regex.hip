@@ -28,7 +28,7 @@ constexpr uint32_t kStageBytes = 4096;  // LDS staging per wave: 64 consecutive 
 
 // walks value bytes [b, e) (absolute offsets into `data`) through the automaton; STAGED means the bytes
 // [stage_base, ...) are already in LDS (16-byte aligned image of the wave's contiguous value span)
-template <bool LDS_TABLE, bool STAGED>
+template <bool LDS_TABLE, bool STAGED, bool DIRECT>
 __device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_table, const uint8_t *s_class,
                                          uintptr_t data, int64_t b, int64_t e, const uint8_t *stage,
                                          int64_t stage_base) {
@@ -49,9 +49,10 @@ __device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_t
     if (e - p < (int64_t)nb) nb = (uint32_t)(e - p);
     p += nb;
     for (uint32_t k = 0; k < nb && st > 1; k++) {
-      const uint32_t c = s_class[w & 0xFF];
+      // DIRECT: the table has one column per BYTE (small automata), so a step is one LDS lookup instead of two
+      const uint32_t c = DIRECT ? (uint32_t)(w & 0xFF) : s_class[w & 0xFF];
       w >>= 8;
-      st = LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
+      st = DIRECT ? s_table[(st << 8) + c] : LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
     }
   }
   return st;
@@ -59,7 +60,7 @@ __device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_t
 
 // TABLE_ENTRIES: LDS budget of the transition table (0 = the table stays in global memory / L2).  The small
 // instance leaves room for 6 workgroups per CU, the large one for 3.
-template <int TABLE_ENTRIES>
+template <int TABLE_ENTRIES, bool DIRECT = false>
 __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaView dfa,
                                                            unsigned long long *counters) {
   constexpr bool LDS_TABLE = TABLE_ENTRIES > 0;
@@ -80,38 +81,58 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   uint8_t *stage = s_stage[wave];
   unsigned long long matches = 0;
   const int64_t n_groups = (d.length + 63) / 64;  // 64 consecutive rows per wave step
-  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
-    const int64_t i = g * 64 + lane;
-    const bool in = i < d.length;
-    const int64_t slot = d.offset + (in ? i : d.length - 1);
-    bool valid = in;
-    if (in && vbits) valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
+  // row descriptor of lane `lane` in group g: value bytes [b, e) relative to `data`, validity
+  struct Row {
     int64_t b, e;
-    uintptr_t data = data0;  // base the value's [b, e) refers to
-    if (is_view && !valid) {
-      b = e = 0;  // the view of a NULL slot is arbitrary: never parsed
+    uintptr_t data;
+    bool valid, in;
+  };
+  auto fetch = [&](int64_t g) -> Row {
+    Row r;
+    const int64_t i = g * 64 + lane;
+    r.in = i < d.length;
+    const int64_t slot = d.offset + (r.in ? i : d.length - 1);
+    r.valid = r.in;
+    if (r.in && vbits) r.valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
+    r.data = data0;
+    if (is_view && !r.valid) {
+      r.b = r.e = 0;  // the view of a NULL slot is arbitrary: never parsed
     } else if (is_view) {
       // {length, inline bytes | prefix, buffer, offset}: the value is wherever the view says (no common span)
       typedef const int32_t __attribute__((address_space(1))) *gi32;
       gi32 vw = (gi32)((uintptr_t)d.views + (uintptr_t)slot * 16);
       const int32_t len = vw[0];
-      b = 0;
-      e = len;
+      r.b = 0;
+      r.e = len;
       if (len <= 12) {
-        data = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
+        r.data = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
       } else {
         const int32_t bi = vw[2], bo = vw[3];
-        data = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
+        r.data = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
       }
     } else if (d.large_offsets) {
       global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
-      b = off[slot];
-      e = off[slot + 1];
+      r.b = off[slot];
+      r.e = off[slot + 1];
     } else {
       global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
-      b = off[slot];
-      e = off[slot + 1];
+      r.b = off[slot];
+      r.e = off[slot + 1];
     }
+    return r;
+  };
+  const int64_t g_stride = (int64_t)gridDim.x * 4;
+  int64_t g = (int64_t)blockIdx.x * 4 + wave;
+  Row next = fetch(g < n_groups ? g : 0);
+  for (; g < n_groups; g += g_stride) {
+    // the offsets / validity of the NEXT group are requested before this group's bytes are staged and walked: the
+    // two dependent memory latencies per step (offsets, then bytes) overlap across steps
+    const Row cur = next;
+    if (g + g_stride < n_groups) next = fetch(g + g_stride);
+    const int64_t i = g * 64 + lane;
+    const bool in = cur.in, valid = cur.valid;
+    int64_t b = cur.b, e = cur.e;
+    const uintptr_t data = cur.data;
     // the wave's values are contiguous: [b of lane 0, e of the last lane)
     const int64_t span_b = __shfl(b, 0, 64), span_e = __shfl(e, 63, 64);
     // 16-byte blocks by ABSOLUTE address: a block that holds one byte of the buffer lies in the same page, so
@@ -140,8 +161,8 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
           while (e > b && bytes[e - 1] == 0x20) e--;
         }
       }
-      const uint32_t st = staged ? walk<LDS_TABLE, true>(dfa, s_table, s_class, data, b, e, stage, stage_base)
-                                 : walk<LDS_TABLE, false>(dfa, s_table, s_class, data, b, e, nullptr, 0);
+      const uint32_t st = staged ? walk<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data, b, e, stage, stage_base)
+                                 : walk<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, data, b, e, nullptr, 0);
       const bool hit = st == 1 || g_acc[st];
       matches += hit ? 1 : 0;
       if (d.hits) d.hits[i] = hit ? 1 : 0;
@@ -169,7 +190,9 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
   if (blocks > (int64_t)n_cu * 6) blocks = (int64_t)n_cu * 6;
   if (blocks < 1) blocks = 1;
   const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
-  if (entries <= 4096)
+  if (dfa.n_classes == 256 && dfa.direct && entries <= 4096)
+    hipLaunchKernelGGL((regex_match_kernel<4096, true>), dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+  else if (entries <= 4096)
     hipLaunchKernelGGL(regex_match_kernel<4096>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
   else if (entries <= kRegexLdsEntries)
     hipLaunchKernelGGL(regex_match_kernel<(int)kRegexLdsEntries>, dim3((int)blocks), dim3(256), 0, stream, d, dfa,

@@ -25,7 +25,8 @@ struct DfaView {
   const uint16_t *table;       // n_states x n_classes
   const uint8_t *byte_class;   // 256
   const uint8_t *accept_end;   // n_states
-  uint32_t n_states, n_classes, start, pad;
+  uint32_t n_states, n_classes, start;
+  uint32_t direct;  // 1: `table` has 256 columns, one per byte value (byte_class is the identity)
 };
 
 }  // namespace tgx

@@ -2,6 +2,7 @@
 // kernel at update time (kernels/regex.hip), counts merged like any other additive state.
 #include "regex_device.h"
 
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -26,6 +27,7 @@ struct RegexPlan {
 };
 struct RegexTaskState {
   DevBuf table, byte_class, accept_end, counters;
+  bool direct = false;  // the uploaded table is byte-indexed (256 columns)
   DevBuf dict_hits;  // Dictionary columns: one hit byte per dictionary entry of the current batch
   uint64_t h_total = 0, h_matches = 0;  // merged-in / deserialized contributions
   uint64_t total = 0;                   // rows handled on this device
@@ -136,12 +138,25 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
       return rfail(err, TGX_UNSUPPORTED, "REGEX_MATCH needs a Utf8 column (column %d has type %d)", t.column, c.type);
     if (!ts.table.p) {
       const rx::Dfa &d = t.dfa;
-      RHIP(ts.table.reserve(d.table.size() * sizeof(uint16_t) + 16));
+      // tiny automata (<= 16 states) travel with one table column per BYTE: one LDS lookup per input byte instead
+      // of class + transition (the kernel is bound by those lookups, not by HBM).  Only while the table still fits
+      // the 8 KiB instance: a byte-indexed 32 KiB table halves the workgroups per CU and ran 1.6x SLOWER.
+      ts.direct = (uint64_t)d.n_states * 256 <= 4096;
+      std::vector<uint16_t> table = d.table;
+      uint8_t cls[256];
+      memcpy(cls, d.byte_class, 256);
+      if (ts.direct) {
+        table.assign((size_t)d.n_states * 256, 0);
+        for (uint32_t s2 = 0; s2 < d.n_states; s2++)
+          for (uint32_t b = 0; b < 256; b++) table[(size_t)s2 * 256 + b] = d.table[(size_t)s2 * d.n_classes + d.byte_class[b]];
+        for (uint32_t b = 0; b < 256; b++) cls[b] = (uint8_t)b;
+      }
+      RHIP(ts.table.reserve(table.size() * sizeof(uint16_t) + 16));
       RHIP(ts.byte_class.reserve(256));
       RHIP(ts.accept_end.reserve(d.accept_at_end.size() + 16));
       RHIP(ts.counters.reserve(16));
-      RHIP(hipMemcpy(ts.table.p, d.table.data(), d.table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-      RHIP(hipMemcpy(ts.byte_class.p, d.byte_class, 256, hipMemcpyHostToDevice));
+      RHIP(hipMemcpy(ts.table.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      RHIP(hipMemcpy(ts.byte_class.p, cls, 256, hipMemcpyHostToDevice));
       RHIP(hipMemcpy(ts.accept_end.p, d.accept_at_end.data(), d.accept_at_end.size(), hipMemcpyHostToDevice));
       RHIP(hipMemset(ts.counters.p, 0, 16));
     }
@@ -168,9 +183,9 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     v.byte_class = ts.byte_class.as<uint8_t>();
     v.accept_end = ts.accept_end.as<uint8_t>();
     v.n_states = t.dfa.n_states;
-    v.n_classes = t.dfa.n_classes;
+    v.n_classes = ts.direct ? 256 : t.dfa.n_classes;
     v.start = t.dfa.start;
-    v.pad = 0;
+    v.direct = ts.direct ? 1 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
       (void)hipEventRecord(e0, st->stream);
