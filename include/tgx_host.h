@@ -56,6 +56,27 @@ tgx_status tgx_host_validate_identifier(const char *identifier, tgx_error *err);
 tgx_status tgx_host_assertion_json(const char *assertion_json, double value, int32_t *holds, char **description,
                                    tgx_error *err);
 
+/* ---- analyzers (TG/analyzers/traits.rs:65-179, runner.rs:64-202) --------------------------------------------
+ * Analysis JSON: {"table_name": "data", "continue_on_error": true, "analyzers": [
+ *     {"type": "size"}, {"type": "completeness|distinctness|mean|min|max|sum|standard_deviation", "column": "c"},
+ *     {"type": "correlation", "column1": "a", "column2": "b", "method": "pearson|spearman|covariance"}]}
+ * AnalysisRunner::run: every analyzer's aggregates planned into ONE tgx_plan, one pass over the table.  Returns
+ *   {"metrics": {metric_key: {"type": "Double|Long|Map", "value": ..}},      (MetricValue's serde form, types.rs:11-35)
+ *    "states":  {metric_key: {..the AnalyzerState's serde fields..}},
+ *    "errors":  [{"analyzer_name": "..", "error": ".."}]}                        (context.rs:118-123)
+ * With continue_on_error false the first failing analyzer makes the call fail with "Analyzer {name} failed". */
+tgx_status tgx_host_run_analysis_json(const char *analysis_json, const char *const *column_names, size_t n_columns,
+                                      const tgx_column *columns, size_t n_batches, char **out_json, tgx_error *err);
+
+/* AnalyzerState::merge of the analyzer's state type over a JSON array of states; needs no device. */
+tgx_status tgx_host_merge_states_json(const char *analyzer_json, const char *states_json, char **out_state_json,
+                                      tgx_error *err);
+
+/* Analyzer::compute_metric_from_state; needs no device.  An AnalyzerError (e.g. NoData) is returned as
+ * TGX_INVALID_ARGUMENT with the reference's Display text in err->msg. */
+tgx_status tgx_host_metric_from_state_json(const char *analyzer_json, const char *state_json, char **out_metric_json,
+                                           tgx_error *err);
+
 void tgx_host_free(char *s);
 
 #ifdef __cplusplus

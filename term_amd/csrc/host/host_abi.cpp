@@ -5,6 +5,7 @@
 
 #include "../../../include/tgx_host.h"
 #include "json.h"
+#include "analyzers.h"
 #include "term_guard.h"
 
 using namespace term_guard;
@@ -211,6 +212,78 @@ extern "C" tgx_status tgx_host_assertion_json(const char *assertion_json, double
     if (holds) *holds = a.evaluate(value) ? 1 : 0;
     if (description) *description = dup_string(a.description());
     return TGX_OK;
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  }
+}
+
+// ---- analyzers
+static json::Value parse_json_text(const char *text, const char *what) {
+  json::Value v;
+  std::string perr;
+  if (!json::parse(text, &v, &perr)) throw TermError{TermError::Internal, std::string(what) + " JSON: " + perr};
+  return v;
+}
+
+extern "C" tgx_status tgx_host_run_analysis_json(const char *analysis_json, const char *const *column_names,
+                                                 size_t n_columns, const tgx_column *columns, size_t n_batches,
+                                                 char **out_json, tgx_error *err) {
+  if (!analysis_json || !out_json || (n_columns && (!column_names || (n_batches && !columns))))
+    return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  *out_json = nullptr;
+  try {
+    json::Value v = parse_json_text(analysis_json, "analysis");
+    AnalysisRunner runner;
+    runner.table_name(v.get_str("table_name", "data")).continue_on_error(v.get_bool("continue_on_error", true));
+    if (const json::Value *as = v.get("analyzers"))
+      for (const json::Value &a : as->arr) runner.add(analyzer_from_json(a));
+    Table t;
+    for (size_t i = 0; i < n_columns; i++) t.column_names.push_back(column_names[i]);
+    for (size_t b = 0; b < n_batches; b++) {
+      Batch batch;
+      batch.columns.assign(columns + b * n_columns, columns + (b + 1) * n_columns);
+      t.batches.push_back(std::move(batch));
+    }
+    Context ctx;
+    if (n_columns > 0) ctx.register_table(v.get_str("table_name", "data"), std::move(t));
+    *out_json = dup_string(runner.run(ctx).to_json());
+    return TGX_OK;
+  } catch (const AnalyzerError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.text);
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  }
+}
+
+extern "C" tgx_status tgx_host_merge_states_json(const char *analyzer_json, const char *states_json,
+                                                 char **out_state_json, tgx_error *err) {
+  if (!analyzer_json || !states_json || !out_state_json) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  *out_state_json = nullptr;
+  try {
+    auto a = analyzer_from_json(parse_json_text(analyzer_json, "analyzer"));
+    json::Value states = parse_json_text(states_json, "states");
+    if (states.type != json::Value::Array) return hfail(err, TGX_INVALID_ARGUMENT, "states must be a JSON array");
+    *out_state_json = dup_string(json_dump(a->merge_states(states.arr)));
+    return TGX_OK;
+  } catch (const AnalyzerError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.text);
+  } catch (const TermError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  }
+}
+
+extern "C" tgx_status tgx_host_metric_from_state_json(const char *analyzer_json, const char *state_json,
+                                                      char **out_metric_json, tgx_error *err) {
+  if (!analyzer_json || !state_json || !out_metric_json) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
+  *out_metric_json = nullptr;
+  try {
+    auto a = analyzer_from_json(parse_json_text(analyzer_json, "analyzer"));
+    *out_metric_json = dup_string(a->metric_from_state(parse_json_text(state_json, "state")).to_json());
+    return TGX_OK;
+  } catch (const AnalyzerError &e) {
+    return hfail(err, TGX_INVALID_ARGUMENT, e.text);
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
   }

@@ -357,24 +357,127 @@ class ValidationSuite:
     def run(self, table):
         """table: dict name -> term_amd.Column (one batch), a list of such dicts (batches), a pyarrow Table /
         RecordBatch, or None (no table registered)."""
-        if table is None:
-            names, batches = [], []
-        elif isinstance(table, dict):
-            names, batches = list(table.keys()), [list(table.values())]
-        elif isinstance(table, (list, tuple)):
-            names = list(table[0].keys()) if table else []
-            batches = [[b[n] for n in names] for b in table]
-        else:
-            names, batches = _arrow_batches(table)
-        n_cols, n_batches = len(names), len(batches)
-        name_arr = (C.c_char_p * max(1, n_cols))(*[n.encode() for n in names])
-        flat = [c.c for b in batches for c in b]
-        col_arr = (_Column * max(1, len(flat)))(*flat)
+        name_arr, n_cols, col_arr, n_batches, _keep = _flatten_table(table)
         out = C.c_char_p()
         err = _Error()
         _host_check(_host().tgx_host_run_suite_json(json.dumps(self.spec).encode(), name_arr, n_cols, col_arr,
                                                     n_batches, C.byref(out), C.byref(err)), err)
         return ValidationResult(_take(out))
+
+
+def _flatten_table(table):
+    if table is None:
+        names, batches = [], []
+    elif isinstance(table, dict):
+        names, batches = list(table.keys()), [list(table.values())]
+    elif isinstance(table, (list, tuple)):
+        names = list(table[0].keys()) if table else []
+        batches = [[b[n] for n in names] for b in table]
+    else:
+        names, batches = _arrow_batches(table)
+    n_cols, n_batches = len(names), len(batches)
+    name_arr = (C.c_char_p * max(1, n_cols))(*[n.encode() for n in names])
+    flat = [c.c for b in batches for c in b]
+    col_arr = (_Column * max(1, len(flat)))(*flat)
+    return name_arr, n_cols, col_arr, n_batches, batches
+
+
+# ---------------------------------------------------------------------------------------------- analyzers
+class _Analyzer:
+    """mirror of TG/analyzers/traits.rs Analyzer: name / metric_key / merge_states / compute_metric_from_state"""
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def name(self):
+        return self.spec["type"]
+
+    def metric_key(self):
+        t = self.spec["type"]
+        if t in ("size", "standard_deviation"):  # standard_deviation.rs does not override metric_key
+            return t
+        if t == "correlation":
+            return "correlation_%s_%s_%s" % (self.spec.get("method", "pearson"), self.spec["column1"], self.spec["column2"])
+        return "%s.%s" % (t, self.spec["column"])
+
+    def merge_states(self, states):
+        out = C.c_char_p()
+        err = _Error()
+        _host_check(_host().tgx_host_merge_states_json(json.dumps(self.spec).encode(), json.dumps(states).encode(),
+                                                       C.byref(out), C.byref(err)), err)
+        return json.loads(_take(out))
+
+    def compute_metric_from_state(self, state):
+        """-> MetricValue as {"type": "Double"|"Long"|"Map", "value": ...}; raises TgxError with the
+        reference's AnalyzerError text (e.g. 'No data available for analysis')"""
+        out = C.c_char_p()
+        err = _Error()
+        _host_check(_host().tgx_host_metric_from_state_json(json.dumps(self.spec).encode(), json.dumps(state).encode(),
+                                                            C.byref(out), C.byref(err)), err)
+        return json.loads(_take(out))
+
+
+def SizeAnalyzer(): return _Analyzer({"type": "size"})
+def CompletenessAnalyzer(column): return _Analyzer({"type": "completeness", "column": column})
+def DistinctnessAnalyzer(column): return _Analyzer({"type": "distinctness", "column": column})
+def MeanAnalyzer(column): return _Analyzer({"type": "mean", "column": column})
+def MinAnalyzer(column): return _Analyzer({"type": "min", "column": column})
+def MaxAnalyzer(column): return _Analyzer({"type": "max", "column": column})
+def SumAnalyzer(column): return _Analyzer({"type": "sum", "column": column})
+def StandardDeviationAnalyzer(column): return _Analyzer({"type": "standard_deviation", "column": column})
+
+
+def CorrelationAnalyzer(column1, column2, method="pearson"):
+    return _Analyzer({"type": "correlation", "column1": column1, "column2": column2, "method": method})
+
+
+class AnalyzerContext:
+    """TG/analyzers/context.rs: metrics by key, errors; plus the analyzers' states (for merges across shards)"""
+
+    def __init__(self, text):
+        d = json.loads(text)
+        self.metrics, self.states, self._errors = d["metrics"], d["states"], d["errors"]
+
+    def get_metric(self, key):
+        return self.metrics.get(key)
+
+    def has_errors(self):
+        return bool(self._errors)
+
+    def errors(self):
+        return self._errors
+
+
+class AnalysisRunner:
+    """TG/analyzers/runner.rs:64-202 -- but ONE pass over the table for all analyzers"""
+
+    def __init__(self):
+        self._analyzers, self._continue, self._table = [], True, "data"
+
+    def add(self, analyzer):
+        self._analyzers.append(analyzer)
+        return self
+
+    def continue_on_error(self, flag):
+        self._continue = bool(flag)
+        return self
+
+    def table_name(self, name):
+        self._table = name
+        return self
+
+    def analyzer_count(self):
+        return len(self._analyzers)
+
+    def run(self, table):
+        spec = {"table_name": self._table, "continue_on_error": self._continue,
+                "analyzers": [a.spec for a in self._analyzers]}
+        name_arr, n_cols, col_arr, n_batches, _keep = _flatten_table(table)
+        out = C.c_char_p()
+        err = _Error()
+        _host_check(_host().tgx_host_run_analysis_json(json.dumps(spec).encode(), name_arr, n_cols, col_arr, n_batches,
+                                                       C.byref(out), C.byref(err)), err)
+        return AnalyzerContext(_take(out))
 
 
 # ---------------------------------------------------------------------------------------------- bridge
@@ -392,6 +495,10 @@ def _host():
         L.tgx_host_constraint_verdict_json.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), E]
         L.tgx_host_validate_identifier.argtypes = [C.c_char_p, E]
         L.tgx_host_assertion_json.argtypes = [C.c_char_p, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), E]
+        L.tgx_host_run_analysis_json.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(_Column),
+                                                 C.c_size_t, C.POINTER(C.c_char_p), E]
+        L.tgx_host_merge_states_json.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), E]
+        L.tgx_host_metric_from_state_json.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), E]
         L.tgx_host_free.argtypes = [C.c_void_p]
         L.tgx_host_free.restype = None
         _HOST = L
