@@ -111,7 +111,11 @@ typedef enum tgx_check_kind {
   TGX_CHECK_COMOMENTS = 6,
   /* n and the sums of SQL RANK() ranks (min-rank ties) of both columns over rows with both non-NULL
    * (CAST AS DOUBLE), reported in sum_x .. sum_xy          TG/analyzers/advanced/correlation.rs:334-350 */
-  TGX_CHECK_SPEARMAN = 7
+  TGX_CHECK_SPEARMAN = 7,
+  /* COUNT(CASE WHEN LENGTH(c) >= length_min AND LENGTH(c) <= length_max OR c IS NULL THEN 1 END), COUNT(*):
+   * LENGTH counts characters (code points), NULL rows always count    TG/constraints/length.rs:36-45, 167-171.
+   * Result: total, matches. */
+  TGX_CHECK_LENGTH = 8
 } tgx_check_kind;
 
 enum {
@@ -143,6 +147,8 @@ typedef struct tgx_check_spec {
   const int32_t *columns;
   uint32_t n_columns;
   uint32_t reserved2;
+  uint64_t length_min;  /* LENGTH: inclusive bounds in characters; length_max = UINT64_MAX: no upper bound */
+  uint64_t length_max;
 } tgx_check_spec;
 
 /* One result per spec.  Fields outside the spec's kind are zero. */

@@ -23,6 +23,7 @@ from ._lib import (  # noqa: F401
     KLL,
     COMOMENTS,
     SPEARMAN,
+    LENGTH,
     FLAG_EXACT_RANK_SUMS,
     FLAG_VARIANCE,
     FLAG_MULTIPLICITY,

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 
 # enums of include/tgx.h
-COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN = 1, 2, 3, 4, 5, 6, 7
+COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 1, 2, 3, 4, 5, 6, 7, 8
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW = 1, 2, 3, 4, 5, 6
@@ -45,7 +45,7 @@ class CheckSpec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("column", C.c_int32), ("column2", C.c_int32), ("flags", C.c_uint32),
                 ("pattern", C.c_char_p), ("pattern_len", C.c_uint64), ("kll_k", C.c_uint32),
                 ("reserved", C.c_uint32), ("columns", C.POINTER(C.c_int32)), ("n_columns", C.c_uint32),
-                ("reserved2", C.c_uint32)]
+                ("reserved2", C.c_uint32), ("length_min", C.c_uint64), ("length_max", C.c_uint64)]
 
 
 class Result(C.Structure):
@@ -295,10 +295,13 @@ class Column:
         raise TgxError(2, "unsupported Arrow type %s" % arr.type)
 
 
-def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0, columns=None):
-    """columns=[a, b, ...]: DISTINCT over the tuple of those columns (COUNT(DISTINCT (a, b)))"""
+def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0, columns=None, length_min=0, length_max=None):
+    """columns=[a, b, ...]: DISTINCT over the tuple of those columns (COUNT(DISTINCT (a, b)));
+    length_min / length_max (None = unbounded): LENGTH bounds in characters"""
     pat = pattern.encode("utf-8") if isinstance(pattern, str) else pattern
     s = CheckSpec(kind, column, column2, flags, pat, len(pat) if pat else 0, kll_k, 0)
+    s.length_min = length_min
+    s.length_max = (1 << 64) - 1 if length_max is None else length_max
     if columns is not None and len(columns) >= 2:
         arr = (C.c_int32 * len(columns))(*columns)
         s.columns = C.cast(arr, C.POINTER(C.c_int32))

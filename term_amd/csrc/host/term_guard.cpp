@@ -575,6 +575,48 @@ class FormatConstraint : public Constraint {
   FormatOptions o_;
 };
 
+// constraints/length.rs:19-231: COUNT(CASE WHEN <cond on LENGTH(c)> OR c IS NULL THEN 1 END) / COUNT(*) must be 1.0
+class LengthConstraint : public Constraint {
+ public:
+  LengthConstraint(std::string col, std::string kind, uint64_t a, uint64_t b) : col_(std::move(col)), kind_(std::move(kind)), a_(a), b_(b) {
+    require_identifier(col_);
+    if (kind_ != "min" && kind_ != "max" && kind_ != "between" && kind_ != "exactly" && kind_ != "not_empty")
+      throw TermError{TermError::Internal, "unknown length assertion '" + kind_ + "'"};
+  }
+  std::string name() const override {  // length.rs:48-56
+    return kind_ == "min" ? "min_length" : kind_ == "max" ? "max_length" : kind_ == "between" ? "length_between"
+           : kind_ == "exactly" ? "exact_length" : "not_empty";
+  }
+  std::string description() const {  // :59-67
+    if (kind_ == "min") return "at least " + std::to_string(a_) + " characters";
+    if (kind_ == "max") return "at most " + std::to_string(a_) + " characters";
+    if (kind_ == "between") return "between " + std::to_string(a_) + " and " + std::to_string(b_) + " characters";
+    if (kind_ == "exactly") return "exactly " + std::to_string(a_) + " characters";
+    return "not empty";
+  }
+  std::optional<std::string> column() const override { return col_; }
+  std::vector<SpecRequest> plan() const override {
+    SpecRequest r;
+    r.kind = TGX_CHECK_LENGTH;
+    r.column = col_;
+    r.length_min = kind_ == "min" || kind_ == "between" || kind_ == "exactly" ? a_ : kind_ == "not_empty" ? 1 : 0;
+    r.length_max = kind_ == "max" || kind_ == "exactly" ? a_ : kind_ == "between" ? b_ : ~0ull;
+    return {r};
+  }
+  ConstraintResult evaluate(const Inputs &in) const override {
+    const tgx_result *r = in.results[0];
+    if (r->total == 0) return ConstraintResult::skipped("No data to validate");  // NULLIF(COUNT(*), 0) (:167-193)
+    const double ratio = (double)r->matches * 1.0 / (double)r->total;
+    if (ratio >= 1.0) return ConstraintResult::success_with_metric(ratio);
+    return ConstraintResult::failure_with_metric(
+        ratio, "Length constraint failed: " + fixed(ratio * 100.0, 2) + "% of values are " + description());
+  }
+
+ private:
+  std::string col_, kind_;
+  uint64_t a_, b_;
+};
+
 // constraints/quantile.rs:228-345 (QuantileValidation::Single)
 class QuantileConstraint : public Constraint {
  public:
@@ -705,6 +747,9 @@ Check::Builder &Check::Builder::validates_uniqueness_with_nulls(std::vector<std:
 Check::Builder &Check::Builder::primary_key(std::vector<std::string> columns) {
   completeness(columns, CompletenessOptions::full());
   return validates_uniqueness(std::move(columns), 1.0);
+}
+Check::Builder &Check::Builder::length(std::string column, std::string kind, uint64_t a, uint64_t b) {
+  return constraint(std::make_shared<LengthConstraint>(std::move(column), std::move(kind), a, b));
 }
 Check::Builder &Check::Builder::has_format(std::string column, FormatType format, double threshold, FormatOptions o) {
   return constraint(std::make_shared<FormatConstraint>(std::move(column), std::move(format), threshold, o));
@@ -891,7 +936,8 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
       for (size_t i = 0; i < spec_requests.size(); i++) {
         const SpecRequest &q = spec_requests[i];
         if (q.kind == r.kind && q.column == r.column && q.column2 == r.column2 && q.columns == r.columns &&
-            q.flags == r.flags && q.pattern == r.pattern && q.kll_k == r.kll_k)
+            q.flags == r.flags && q.pattern == r.pattern && q.kll_k == r.kll_k && q.length_min == r.length_min &&
+            q.length_max == r.length_max)
           found = i;
       }
       if (found == spec_requests.size()) spec_requests.push_back(r);
@@ -908,6 +954,8 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
     s.pattern = r.pattern.empty() ? nullptr : r.pattern.data();
     s.pattern_len = r.pattern.size();
     s.kll_k = r.kll_k;
+    s.length_min = r.length_min;
+    s.length_max = r.length_max;
     if (r.columns.size() >= 2) {
       tuple_columns.emplace_back();
       for (const std::string &c2 : r.columns) tuple_columns.back().push_back(column_index(c2));
@@ -1127,6 +1175,8 @@ void add_constraint_from_json(Check::Builder &b, const json::Value &c) {
     const std::string nh = c.get_str("null_handling", "exclude");
     t.null_handling = nh == "include" ? NullHandling::Include : nh == "distinct" ? NullHandling::Distinct : NullHandling::Exclude;
     b.uniqueness(strings_from(c.get("columns")), t);
+  } else if (type == "length") {
+    b.length(c.get_str("column"), c.get_str("kind"), (uint64_t)c.get_num("a", 0), (uint64_t)c.get_num("b", 0));
   } else if (type == "format") {
     static const char *const names[] = {"regex", "email", "url", "credit_card", "phone", "postal_code", "uuid", "ipv4",
                                         "ipv6", "json", "iso8601_datetime", "social_security_number"};

@@ -124,6 +124,7 @@ struct SpecRequest {
   uint32_t flags = 0;
   std::string pattern;
   uint32_t kll_k = 0;
+  uint64_t length_min = 0, length_max = ~0ull;  // LENGTH: inclusive character-count bounds
 };
 
 // ---- core/constraint.rs:187-225.  `evaluate(&SessionContext)` is split in two so scans can be fused:
@@ -217,6 +218,13 @@ class Check::Builder {
   Builder &validates_uniqueness_with_nulls(std::vector<std::string> columns, double threshold, NullHandling h);
   Builder &primary_key(std::vector<std::string> columns);  // builder_extensions.rs:276-295
   // check.rs:829-1260, builder_extensions.rs:309-420
+  // check.rs:518-623, 1777-1785 + constraints/length.rs (kind: min | max | between | exactly | not_empty)
+  Builder &length(std::string column, std::string kind, uint64_t a, uint64_t b);
+  Builder &has_min_length(std::string column, uint64_t n) { return length(std::move(column), "min", n, 0); }
+  Builder &has_max_length(std::string column, uint64_t n) { return length(std::move(column), "max", n, 0); }
+  Builder &has_length_between(std::string column, uint64_t lo, uint64_t hi) { return length(std::move(column), "between", lo, hi); }
+  Builder &has_exact_length(std::string column, uint64_t n) { return length(std::move(column), "exactly", n, 0); }
+  Builder &is_not_empty(std::string column) { return length(std::move(column), "not_empty", 0, 0); }
   Builder &has_format(std::string column, FormatType format, double threshold, FormatOptions options);
   Builder &validates_regex(std::string column, std::string pattern, double threshold);
   Builder &validates_email(std::string column, double threshold);

@@ -21,6 +21,11 @@ struct RegexColDesc {
   const uint8_t *const *buffers;  // Utf8View: device array of the data buffers' device pointers
 };
 
+// LENGTH check (kernels/regex.hip: length_kernel): inclusive character-count bounds
+struct LengthBounds {
+  uint64_t min_chars, max_chars;
+};
+
 struct DfaView {
   const uint16_t *table;       // n_states x n_classes
   const uint8_t *byte_class;   // 256

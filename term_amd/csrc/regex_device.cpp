@@ -12,6 +12,8 @@
 
 namespace tgx {
 
+void launch_length(const RegexColDesc &d, const LengthBounds &lb, unsigned long long *d_counters, int n_cu,
+                   hipStream_t stream);
 void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long *d_counters, int n_cu,
                   hipStream_t stream);
 
@@ -21,6 +23,8 @@ struct RegexTask {
   uint32_t flags;
   std::string pattern;
   rx::Dfa dfa;
+  bool is_length = false;  // TGX_CHECK_LENGTH: no automaton, character-count bounds instead
+  uint64_t len_min = 0, len_max = 0;
 };
 struct RegexPlan {
   std::vector<RegexTask> tasks;
@@ -72,10 +76,29 @@ tgx_status regex_plan_add(tgx_plan *plan, int spec_index, int *slot, tgx_error *
   if (!plan->regex) plan->regex = new RegexPlan();
   RegexPlan *rp = (RegexPlan *)plan->regex;
   const tgx_check_spec &sp = plan->specs[spec_index];
+  if (sp.kind == TGX_CHECK_LENGTH) {
+    if (sp.length_min > sp.length_max) return rfail(err, TGX_INVALID_ARGUMENT, "LENGTH: length_min > length_max");
+    for (size_t i = 0; i < rp->tasks.size(); i++)
+      if (rp->tasks[i].is_length && rp->tasks[i].column == sp.column && rp->tasks[i].len_min == sp.length_min &&
+          rp->tasks[i].len_max == sp.length_max) {
+        *slot = (int)i;
+        return TGX_OK;
+      }
+    RegexTask t;
+    t.column = sp.column;
+    t.flags = TGX_FLAG_NULL_IS_VALID;  // "OR col IS NULL" is part of the check (length.rs:169)
+    t.is_length = true;
+    t.len_min = sp.length_min;
+    t.len_max = sp.length_max;
+    rp->tasks.push_back(std::move(t));
+    *slot = (int)rp->tasks.size() - 1;
+    return TGX_OK;
+  }
   const std::string &pat = plan->patterns[spec_index];
   const uint32_t flags = sp.flags & (TGX_FLAG_TRIM | TGX_FLAG_CASE_INSENSITIVE | TGX_FLAG_NULL_IS_VALID);
   for (size_t i = 0; i < rp->tasks.size(); i++)
-    if (rp->tasks[i].column == sp.column && rp->tasks[i].flags == flags && rp->tasks[i].pattern == pat) {
+    if (!rp->tasks[i].is_length && rp->tasks[i].column == sp.column && rp->tasks[i].flags == flags &&
+        rp->tasks[i].pattern == pat) {
       *slot = (int)i;
       return TGX_OK;
     }
@@ -135,8 +158,13 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     const bool is_dict = c.type == TGX_DICT32_UTF8;
     const bool is_view = c.type == TGX_UTF8_VIEW;
     if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && !is_dict && !is_view)
-      return rfail(err, TGX_UNSUPPORTED, "REGEX_MATCH needs a Utf8 column (column %d has type %d)", t.column, c.type);
-    if (!ts.table.p) {
+      return rfail(err, TGX_UNSUPPORTED, "%s needs a Utf8 column (column %d has type %d)",
+                   t.is_length ? "LENGTH" : "REGEX_MATCH", t.column, c.type);
+    if (t.is_length && !ts.counters.p) {
+      RHIP(ts.counters.reserve(16));
+      RHIP(hipMemsetAsync(ts.counters.p, 0, 16, st->stream));  // ordered with the kernels of this (non-blocking) stream
+    }
+    if (!t.is_length && !ts.table.p) {
       const rx::Dfa &d = t.dfa;
       // tiny automata (<= 16 states) travel with one table column per BYTE: one LDS lookup per input byte instead
       // of class + transition (the kernel is bound by those lookups, not by HBM).  Only while the table still fits
@@ -158,7 +186,7 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
       RHIP(hipMemcpy(ts.table.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       RHIP(hipMemcpy(ts.byte_class.p, cls, 256, hipMemcpyHostToDevice));
       RHIP(hipMemcpy(ts.accept_end.p, d.accept_at_end.data(), d.accept_at_end.size(), hipMemcpyHostToDevice));
-      RHIP(hipMemset(ts.counters.p, 0, 16));
+      RHIP(hipMemsetAsync(ts.counters.p, 0, 16, st->stream));  // ordered with the kernels of this (non-blocking) stream
     }
     ts.total += (uint64_t)c.length;
     if (c.length == 0) continue;
@@ -189,11 +217,20 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
       (void)hipEventRecord(e0, st->stream);
+    const LengthBounds lb{t.len_min, t.len_max};
     if (!is_dict) {
-      launch_regex(d, v, ts.counters.as<unsigned long long>(), n_cu, st->stream);
+      if (t.is_length)
+        launch_length(d, lb, ts.counters.as<unsigned long long>(), n_cu, st->stream);
+      else
+        launch_regex(d, v, ts.counters.as<unsigned long long>(), n_cu, st->stream);
     } else {
       // counters[1] soaks up the per-entry match count, counters[0] receives the per-row one
-      if (sc.length > 0) launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
+      if (sc.length > 0) {
+        if (t.is_length)
+          launch_length(d, lb, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
+        else
+          launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
+      }
       launch_dict_count_hits((const int32_t *)c.values, c.validity, c.offset, c.length, sc.length,
                              sc.validity != nullptr, ts.dict_hits.as<uint8_t>(),
                              (t.flags & TGX_FLAG_NULL_IS_VALID) != 0, ts.counters.as<unsigned long long>(), n_cu,

@@ -212,6 +212,13 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
         plan->bind[i].slot = slot;
         break;
       }
+      case TGX_CHECK_LENGTH: {
+        int slot = -1;
+        tgx_status st = regex_plan_add(plan.get(), (int)i, &slot, err);
+        if (st != TGX_OK) return st;
+        plan->bind[i].slot = slot;
+        break;
+      }
       case TGX_CHECK_REGEX_MATCH: {
         if (!sp.pattern && sp.pattern_len) return fail(err, TGX_INVALID_ARGUMENT, "spec %zu: pattern is NULL", i);
         plan->patterns[i].assign(sp.pattern ? sp.pattern : "", sp.pattern_len);
@@ -354,26 +361,28 @@ static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
     HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
     st->own_stream = true;
   }
+  // (zero-fills go through the state's own stream: it is non-blocking, so a null-stream hipMemset could still be
+  //  in flight when the first kernel on it starts)
   if (!plan->scan.empty()) {
     std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
     HIP_TRY(st->d_scan_acc.reserve(init.size() * sizeof(ScanAcc)));
     HIP_TRY(hipMemcpy(st->d_scan_acc.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
     HIP_TRY(st->d_pivots.reserve(plan->scan.size() * sizeof(double)));
     HIP_TRY(st->d_pivot_set.reserve(plan->scan.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemset(st->d_pivots.p, 0, plan->scan.size() * sizeof(double)));
-    HIP_TRY(hipMemset(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(st->d_pivots.p, 0, plan->scan.size() * sizeof(double), st->stream));
+    HIP_TRY(hipMemsetAsync(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t), st->stream));
   }
   if (!plan->count.empty()) {
     HIP_TRY(st->d_count_acc.reserve(plan->count.size() * sizeof(CountAcc)));
-    HIP_TRY(hipMemset(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc)));
+    HIP_TRY(hipMemsetAsync(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc), st->stream));
   }
   if (!plan->como.empty()) {
     HIP_TRY(st->d_como_acc.reserve(plan->como.size() * sizeof(ComomentAcc)));
-    HIP_TRY(hipMemset(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc)));
+    HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
   }
   for (auto &d : st->distinct) {
     HIP_TRY(d.counters.reserve(kNumDistinctCounters * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
   }
   st->device_ready = true;
   return TGX_OK;
@@ -1383,6 +1392,7 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
       case TGX_CHECK_KLL:
         TGX_TRY(kll_fill_result(st, b.slot, r, err));
         break;
+      case TGX_CHECK_LENGTH:
       case TGX_CHECK_REGEX_MATCH:
         TGX_TRY(regex_fill_result(st, b.slot, r, err));
         break;

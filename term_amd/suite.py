@@ -212,6 +212,17 @@ class CheckBuilder:
     def primary_key(self, columns):
         return self.completeness(columns, CompletenessOptions.full()).validates_uniqueness(columns, 1.0)
 
+    # check.rs:518-623, 1777-1785 (constraints/length.rs)
+    def length(self, column, kind, a=0, b=0):
+        """kind: min | max | between | exactly | not_empty"""
+        return self._add(type="length", column=column, kind=kind, a=a, b=b)
+
+    def has_min_length(self, column, n): return self.length(column, "min", n)
+    def has_max_length(self, column, n): return self.length(column, "max", n)
+    def has_length_between(self, column, lo, hi): return self.length(column, "between", lo, hi)
+    def has_exact_length(self, column, n): return self.length(column, "exactly", n)
+    def is_not_empty(self, column): return self.length(column, "not_empty")
+
     def has_format(self, column, fmt, threshold, options=None, **kw):
         return self._add(type="format", column=column, format=fmt, threshold=threshold,
                          options=(options or FormatOptions()).to_json(), **kw)

@@ -84,6 +84,30 @@ uniqueness_multi = [
          assertion=["greater_than", 0.5], status="success", metric=2.0 / 3.0),
 ]
 
+# constraints/length.rs:246-438
+length = [
+    dict(ref="constraints/length.rs:248-267", kind="min", a=5, values=["hello", "world", "testing", "great", N],
+         status="success", metric=1.0, name="min_length"),
+    dict(ref="constraints/length.rs:269-288", kind="min", a=5, values=["hi", "hello", "a", "testing", N],
+         status="failure", metric=0.6, message_contains="at least 5 characters"),
+    dict(ref="constraints/length.rs:290-302", kind="max", a=10, values=["hi", "hey", "test", N],
+         status="success", metric=1.0, name="max_length"),
+    dict(ref="constraints/length.rs:304-322", kind="max", a=10,
+         values=["short", "this is a very long string that exceeds the limit", "ok", N],
+         status="failure", metric=0.75, message_contains="at most 10 characters"),
+    dict(ref="constraints/length.rs:324-347", kind="between", a=3, b=10,
+         values=["hello", "testing", "hi", "this is way too long", N],
+         status="failure", metric=0.6, message_contains="between 3 and 10 characters", name="length_between"),
+    dict(ref="constraints/length.rs:349-369", kind="exactly", a=5, values=["hello", "world", "test", "testing", N],
+         status="failure", metric=0.6, message_contains="exactly 5 characters", name="exact_length"),
+    dict(ref="constraints/length.rs:371-391", kind="not_empty", values=["hello", "a", "", "testing", N],
+         status="failure", metric=0.8, message_contains="not empty", name="not_empty"),
+    dict(ref="constraints/length.rs:393-412", kind="min", a=2, values=["hello", "\u4f60\u597d", "\U0001f980\U0001f525", "caf\u00e9", N],
+         status="success", metric=1.0),
+    dict(ref="constraints/length.rs:414-426", kind="min", a=5, values=[N, N, N], status="success", metric=1.0),
+    dict(ref="constraints/length.rs:428-438", kind="min", a=5, values=[], status="skipped"),
+]
+
 EMAIL = "email"
 fmt = [
     dict(ref="constraints/format.rs:917-934", format="email", threshold=0.7,
@@ -249,7 +273,7 @@ assertion = [
 ]
 
 out = dict(completeness=completeness, statistics=statistics, uniqueness=uniqueness,
-           uniqueness_multi=uniqueness_multi, format=fmt,
+           uniqueness_multi=uniqueness_multi, length=length, format=fmt,
            patterns=patterns, analyzers=analyzers, correlation=correlation, kll=kll, assertion=assertion)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 with open(path, "w") as f:

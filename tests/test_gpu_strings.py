@@ -220,3 +220,40 @@ def test_distinct_over_column_tuples():
         T.Plan([spec(T.DISTINCT, 0, columns=list(range(9)))])
     with pytest.raises(T.TgxError):
         T.Plan([spec(T.COUNT, 0, columns=[0, 1])])
+
+
+@pytest.mark.parametrize("layout", ["utf8", "large", "view", "dict"])
+def test_length_check_counts_characters(layout):
+    """LENGTH(col) bounds in CHARACTERS, NULL rows always satisfied (constraints/length.rs:36-45, 167-171)"""
+    from test_gpu_dictionary import encode
+    from test_gpu_utf8view import view_column
+
+    rng = np.random.default_rng(17)
+    n = 120_000
+    alphabet = ["a", "Z", "é", "ß", "你", "🦀", " ", "0"]
+    vals = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.05:
+            vals.append(None)
+        else:
+            k = int(rng.integers(0, 40)) if r < 0.9 else int(rng.integers(0, 600))
+            vals.append("".join(alphabet[int(x)] for x in rng.integers(0, len(alphabet), size=k)))
+    if layout == "dict":
+        vals = [None if v is None else v[:30] for v in vals[:40_000]]
+        n = len(vals)
+    bounds = [(0, None), (1, None), (5, None), (0, 10), (3, 10), (5, 5), (0, 0), (100, 400), (13, 13)]
+    specs = [spec(T.LENGTH, 0, length_min=lo, length_max=hi) for lo, hi in bounds]
+    if layout == "view":
+        col = view_column(vals, rng, True)
+    elif layout == "dict":
+        col = encode(vals, rng)
+    else:
+        offs, data, validity = orc.utf8_from_list(vals)
+        col = utf8_column(offs, data, validity, True, large=(layout == "large"))
+    res, _, _ = run_plan(specs, [[col]])
+    for (lo, hi), r in zip(bounds, res):
+        want = sum(1 for v in vals if v is None or (len(v) >= lo and (hi is None or len(v) <= hi)))
+        assert (r.total, r.matches) == (n, want), (layout, lo, hi)
+    with pytest.raises(T.TgxError):
+        T.Plan([spec(T.LENGTH, 0, length_min=5, length_max=4)])

@@ -86,6 +86,22 @@ def test_reference_vectors_end_to_end(golden):
         r = ValidationSuite.builder("s").check(b.build()).build().run(tbl)
         assert r.is_success(), case["ref"]
         assert abs(r.report.metrics.custom_metrics["chk." + case["kind"]] - case["metric"]) < 1e-12
+    # length (constraints/length.rs:246-438)
+    for case in golden["length"]:
+        tbl = arrow_table(text=(pa.string(), case["values"]))
+        b = Check.builder("chk").level(Level.ERROR).length("text", case["kind"], case.get("a", 0), case.get("b", 0))
+        r = ValidationSuite.builder("s").check(b.build()).build().run(tbl)
+        m = r.report.metrics
+        if case["status"] == "success":
+            assert r.is_success() and m.passed_checks == 1, (case["ref"], [i.message for i in r.report.issues])
+            assert list(m.custom_metrics.values()) == [case["metric"]]
+        elif case["status"] == "failure":
+            assert r.is_failure() and case["message_contains"] in r.report.issues[0].message, case["ref"]
+            assert r.report.issues[0].metric == case["metric"]
+        else:
+            assert m.skipped_checks == 1
+        if "name" in case and case["status"] == "success":
+            assert list(m.custom_metrics.keys()) == ["chk." + case["name"]]
     # formats
     for case in golden["format"]:
         fmt = case["format"]
