@@ -18,6 +18,7 @@
  *                           iso8601_datetime|social_security_number", "pattern": "...", "allow_localhost": false,
  *                           "detect_only": false, "country": "US", "threshold": 1.0,
  *                           "options": {"case_sensitive": true, "trim_before_check": false, "null_is_valid": true}},
+ *       {"type": "containment", "column": "c", "allowed_values": ["a", "b"]},
  *       {"type": "length", "column": "c", "kind": "min|max|between|exactly|not_empty", "a": n, "b": m},
  *       {"type": "quantile", "column": "c", "quantile": 0.5, "assertion": A},
  *       {"type": "correlation", "column1": "a", "column2": "b", "assertion": A}]}]}

@@ -617,6 +617,50 @@ class LengthConstraint : public Constraint {
   uint64_t a_, b_;
 };
 
+// constraints/values.rs:200-330: COUNT(CASE WHEN c IN ('a', 'b', ..) THEN 1 END) / COUNT(*) WHERE c IS NOT NULL == 1.0.
+// The IN-list is matched as the anchored alternation ^(?:a|b|..)$ of the escaped literals by the pattern kernel
+// (Rust's `$` is the end of the text, so this is exact string equality).
+class ContainmentConstraint : public Constraint {
+ public:
+  ContainmentConstraint(std::string col, std::vector<std::string> allowed) : col_(std::move(col)), allowed_(std::move(allowed)) {
+    if (allowed_.empty()) throw TermError{TermError::Internal, "containment needs at least one allowed value"};
+  }
+  std::string name() const override { return "containment"; }
+  std::optional<std::string> column() const override { return col_; }
+  static std::string escape(const std::string &lit) {  // regex::escape
+    std::string o;
+    for (char ch : lit) {
+      if (strchr("\\.+*?()|[]{}^$#&-~", ch) && ch != 0) o.push_back('\\');
+      o.push_back(ch);
+    }
+    return o;
+  }
+  std::vector<SpecRequest> plan() const override {
+    SpecRequest cnt;
+    cnt.kind = TGX_CHECK_COUNT;
+    cnt.column = col_;
+    SpecRequest m;
+    m.kind = TGX_CHECK_REGEX_MATCH;
+    m.column = col_;
+    m.pattern = "^(?:";
+    for (size_t i = 0; i < allowed_.size(); i++) m.pattern += (i ? "|" : "") + escape(allowed_[i]);
+    m.pattern += ")$";
+    m.flags = 0;  // NULL rows are outside the WHERE clause
+    return {cnt, m};
+  }
+  ConstraintResult evaluate(const Inputs &in) const override {
+    const double total = (double)in.results[0]->non_null, valid = (double)in.results[1]->matches;
+    if (total == 0.0) return ConstraintResult::skipped("No non-null data to validate");  // values.rs:274-276
+    const double ratio = valid / total;
+    if (ratio == 1.0) return ConstraintResult::success_with_metric(ratio);
+    return ConstraintResult::failure_with_metric(ratio, rust_f64(total - valid) + " values are not in the allowed set");
+  }
+
+ private:
+  std::string col_;
+  std::vector<std::string> allowed_;
+};
+
 // constraints/quantile.rs:228-345 (QuantileValidation::Single)
 class QuantileConstraint : public Constraint {
  public:
@@ -747,6 +791,9 @@ Check::Builder &Check::Builder::validates_uniqueness_with_nulls(std::vector<std:
 Check::Builder &Check::Builder::primary_key(std::vector<std::string> columns) {
   completeness(columns, CompletenessOptions::full());
   return validates_uniqueness(std::move(columns), 1.0);
+}
+Check::Builder &Check::Builder::is_contained_in(std::string column, std::vector<std::string> allowed) {
+  return constraint(std::make_shared<ContainmentConstraint>(std::move(column), std::move(allowed)));
 }
 Check::Builder &Check::Builder::length(std::string column, std::string kind, uint64_t a, uint64_t b) {
   return constraint(std::make_shared<LengthConstraint>(std::move(column), std::move(kind), a, b));
@@ -1175,6 +1222,8 @@ void add_constraint_from_json(Check::Builder &b, const json::Value &c) {
     const std::string nh = c.get_str("null_handling", "exclude");
     t.null_handling = nh == "include" ? NullHandling::Include : nh == "distinct" ? NullHandling::Distinct : NullHandling::Exclude;
     b.uniqueness(strings_from(c.get("columns")), t);
+  } else if (type == "containment") {
+    b.is_contained_in(c.get_str("column"), strings_from(c.get("allowed_values")));
   } else if (type == "length") {
     b.length(c.get_str("column"), c.get_str("kind"), (uint64_t)c.get_num("a", 0), (uint64_t)c.get_num("b", 0));
   } else if (type == "format") {

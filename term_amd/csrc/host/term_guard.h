@@ -219,6 +219,7 @@ class Check::Builder {
   Builder &primary_key(std::vector<std::string> columns);  // builder_extensions.rs:276-295
   // check.rs:829-1260, builder_extensions.rs:309-420
   // check.rs:518-623, 1777-1785 + constraints/length.rs (kind: min | max | between | exactly | not_empty)
+  Builder &is_contained_in(std::string column, std::vector<std::string> allowed_values);  // constraints/values.rs:200-218
   Builder &length(std::string column, std::string kind, uint64_t a, uint64_t b);
   Builder &has_min_length(std::string column, uint64_t n) { return length(std::move(column), "min", n, 0); }
   Builder &has_max_length(std::string column, uint64_t n) { return length(std::move(column), "max", n, 0); }

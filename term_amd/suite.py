@@ -212,6 +212,10 @@ class CheckBuilder:
     def primary_key(self, columns):
         return self.completeness(columns, CompletenessOptions.full()).validates_uniqueness(columns, 1.0)
 
+    def is_contained_in(self, column, allowed_values):
+        """constraints/values.rs:200-330: every non-NULL value is one of `allowed_values`"""
+        return self._add(type="containment", column=column, allowed_values=list(allowed_values))
+
     # check.rs:518-623, 1777-1785 (constraints/length.rs)
     def length(self, column, kind, a=0, b=0):
         """kind: min | max | between | exactly | not_empty"""

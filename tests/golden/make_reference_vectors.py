@@ -108,6 +108,17 @@ length = [
     dict(ref="constraints/length.rs:428-438", kind="min", a=5, values=[], status="skipped"),
 ]
 
+# constraints/values.rs:520-601 (ContainmentConstraint)
+containment = [
+    dict(ref="constraints/values.rs:522-542", values=["active", "inactive", "pending", "invalid_status"],
+         allowed=["active", "inactive", "pending", "archived"], status="failure", metric=0.75,
+         message_contains="values are not in the allowed set"),
+    dict(ref="constraints/values.rs:544-559", values=["active", "inactive", "pending"],
+         allowed=["active", "inactive", "pending", "archived"], status="success", metric=1.0),
+    dict(ref="constraints/values.rs:589-601", values=["active", N, "inactive", N], allowed=["active", "inactive"],
+         status="success", metric=1.0),
+]
+
 EMAIL = "email"
 fmt = [
     dict(ref="constraints/format.rs:917-934", format="email", threshold=0.7,
@@ -273,7 +284,7 @@ assertion = [
 ]
 
 out = dict(completeness=completeness, statistics=statistics, uniqueness=uniqueness,
-           uniqueness_multi=uniqueness_multi, length=length, format=fmt,
+           uniqueness_multi=uniqueness_multi, length=length, containment=containment, format=fmt,
            patterns=patterns, analyzers=analyzers, correlation=correlation, kll=kll, assertion=assertion)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 with open(path, "w") as f:

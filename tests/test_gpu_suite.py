@@ -102,6 +102,21 @@ def test_reference_vectors_end_to_end(golden):
             assert m.skipped_checks == 1
         if "name" in case and case["status"] == "success":
             assert list(m.custom_metrics.keys()) == ["chk." + case["name"]]
+    # containment (constraints/values.rs:520-601): the IN-list runs as an anchored alternation on the pattern kernel
+    for case in golden["containment"]:
+        tbl = arrow_table(text_col=(pa.string(), case["values"]))
+        b = Check.builder("chk").level(Level.ERROR).is_contained_in("text_col", case["allowed"])
+        r = ValidationSuite.builder("s").check(b.build()).build().run(tbl)
+        if case["status"] == "success":
+            assert r.is_success() and r.report.metrics.custom_metrics["chk.containment"] == case["metric"], case["ref"]
+        else:
+            assert r.is_failure() and case["message_contains"] in r.report.issues[0].message
+            assert r.report.issues[0].metric == case["metric"]
+    tbl = arrow_table(t=(pa.string(), ["a.b", "a|b", "axb", "it's", "", None]))
+    r = ValidationSuite.builder("s").check(Check.builder("chk").level(Level.ERROR)
+                                           .is_contained_in("t", ["a.b", "a|b", "it's", ""]).build()).build().run(tbl)
+    assert r.is_failure() and r.report.issues[0].message == "1 values are not in the allowed set"  # only "axb"
+    assert r.report.issues[0].metric == 0.8
     # formats
     for case in golden["format"]:
         fmt = case["format"]
