@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="total rows of the table (all ranks)")
     ap.add_argument("--seed", type=int, default=0x7E570004)
-    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 24)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-distributed", action="store_true",

@@ -971,3 +971,21 @@ void orc_regex_count_utf8(const orc_regex *re, const int32_t *offsets, const uin
     out->matches += orc_regex_is_match(re, data + b, (size_t)(e - b));
   }
 }
+
+/* TG/constraints/length.rs:36-45, 167-171: matches = rows where LENGTH(c) in [min_chars, max_chars] OR c IS NULL;
+ * total = COUNT(*).  LENGTH counts characters: bytes that do not continue a UTF-8 sequence (10xxxxxx). */
+void orc_length_count_utf8(const int32_t *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+                           int64_t n, uint64_t min_chars, uint64_t max_chars, orc_match_t *out) {
+  out->total = n;
+  out->matches = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (!bit_set(validity, offset + i)) {
+      out->matches += 1;
+      continue;
+    }
+    uint64_t chars = 0;
+    for (int64_t p = offsets[offset + i]; p < offsets[offset + i + 1]; p++) chars += (data[p] & 0xC0) != 0x80;
+    out->matches += chars >= min_chars && chars <= max_chars;
+  }
+}
+

@@ -144,6 +144,8 @@ typedef struct {
   int64_t matches;
 } orc_match_t;
 /* COUNT(CASE WHEN [TRIM(]c[)] ~ pat [OR c IS NULL] THEN 1 END), COUNT(*) */
+void orc_length_count_utf8(const int32_t *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+                           int64_t n, uint64_t min_chars, uint64_t max_chars, orc_match_t *out);
 void orc_regex_count_utf8(const orc_regex *re, const int32_t *offsets, const uint8_t *data,
                           const uint8_t *validity, int64_t offset, int64_t n, int trim,
                           int null_is_valid, orc_match_t *out);

@@ -97,6 +97,7 @@ def _declare(L):
         L.orc_regex_free.argtypes = [vp]
         L.orc_regex_is_match.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.orc_regex_count_utf8.argtypes = [vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.POINTER(Match)]
+        L.orc_length_count_utf8.argtypes = [vp, vp, vp, i64, i64, u64, u64, C.POINTER(Match)]
 
 
 # ---------------------------------------------------------------- Arrow-layout helpers (numpy)
@@ -271,6 +272,14 @@ class Regex:
         lib().orc_regex_count_utf8(self._h, _p(offsets), _p(data), _p(validity), offset, n, int(trim),
                                    int(null_is_valid), C.byref(out))
         return out
+
+
+def length_count_utf8(offsets, data, validity=None, n=None, offset=0, min_chars=0, max_chars=None):
+    out = Match()
+    n = len(offsets) - 1 - offset if n is None else n
+    lib().orc_length_count_utf8(_p(offsets), _p(data), _p(validity), offset, n, min_chars,
+                                (1 << 64) - 1 if max_chars is None else max_chars, C.byref(out))
+    return out
 
 
 def nan_equal(a, b):

@@ -252,8 +252,10 @@ def test_length_check_counts_characters(layout):
         offs, data, validity = orc.utf8_from_list(vals)
         col = utf8_column(offs, data, validity, True, large=(layout == "large"))
     res, _, _ = run_plan(specs, [[col]])
+    o_offs, o_data, o_validity = orc.utf8_from_list(vals)
     for (lo, hi), r in zip(bounds, res):
-        want = sum(1 for v in vals if v is None or (len(v) >= lo and (hi is None or len(v) <= hi)))
+        want = orc.length_count_utf8(o_offs, o_data, o_validity, min_chars=lo, max_chars=hi).matches
+        assert want == sum(1 for v in vals if v is None or (len(v) >= lo and (hi is None or len(v) <= hi)))
         assert (r.total, r.matches) == (n, want), (layout, lo, hi)
     with pytest.raises(T.TgxError):
         T.Plan([spec(T.LENGTH, 0, length_min=5, length_max=4)])

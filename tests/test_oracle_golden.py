@@ -233,3 +233,18 @@ def test_distinct_semantics():
     assert (d.non_null, d.distinct, d.groups_once) == (6, 3, 2)  # one NULL row = a group of one
     f = np.array([0.0, -0.0, 1.0], dtype=np.float64)
     assert orc.distinct_bits64(f.view(np.uint64)).distinct == 3  # by bit pattern
+
+
+def test_length_vectors(golden):
+    """constraints/length.rs:246-438: ratio = rows with LENGTH(c) inside the bounds OR NULL, over all rows"""
+    for case in golden["length"]:
+        vals = case["values"]
+        if not vals:
+            continue
+        offs, data, validity = orc.utf8_from_list(vals)
+        k, a, b = case["kind"], case.get("a", 0), case.get("b", 0)
+        lo = a if k in ("min", "between", "exactly") else 1 if k == "not_empty" else 0
+        hi = a if k in ("max", "exactly") else b if k == "between" else None
+        m = orc.length_count_utf8(offs, data, validity, min_chars=lo, max_chars=hi)
+        assert m.matches / m.total == case["metric"], case["ref"]
+
