@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_t
 
 // TABLE_ENTRIES: LDS budget of the transition table (0 = the table stays in global memory / L2).  The small
 // instance leaves room for 6 workgroups per CU, the large one for 3.
-template <int TABLE_ENTRIES, bool DIRECT = false>
+template <int TABLE_ENTRIES, bool DIRECT = false, bool VIEW = false>
 __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaView dfa,
                                                            unsigned long long *counters) {
   constexpr bool LDS_TABLE = TABLE_ENTRIES > 0;
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   global_u8_ptr g_acc = (global_u8_ptr)(uintptr_t)dfa.accept_end;
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   const uintptr_t data0 = (uintptr_t)d.data;
-  const bool is_view = d.views != nullptr;  // uniform
+  constexpr bool is_view = VIEW;  // Utf8View columns run their own instance: no data-dependent branches in the
+                                  // offset path, so its loads are all issued before the first wait
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *stage = s_stage[wave];
   unsigned long long matches = 0;
@@ -92,32 +93,34 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     const int64_t i = g * 64 + lane;
     r.in = i < d.length;
     const int64_t slot = d.offset + (r.in ? i : d.length - 1);
-    r.valid = r.in;
-    if (r.in && vbits) r.valid = (vbits[slot >> 3] >> (slot & 7)) & 1;
+    const uint32_t vbyte = vbits ? (uint32_t)vbits[slot >> 3] : 0xFFu;  // requested first, used last
     r.data = data0;
-    if (is_view && !r.valid) {
-      r.b = r.e = 0;  // the view of a NULL slot is arbitrary: never parsed
-    } else if (is_view) {
-      // {length, inline bytes | prefix, buffer, offset}: the value is wherever the view says (no common span)
-      typedef const int32_t __attribute__((address_space(1))) *gi32;
-      gi32 vw = (gi32)((uintptr_t)d.views + (uintptr_t)slot * 16);
-      const int32_t len = vw[0];
+    if (!is_view) {
+      if (d.large_offsets) {
+        global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
+        r.b = off[slot];
+        r.e = off[slot + 1];
+      } else {
+        global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
+        r.b = off[slot];
+        r.e = off[slot + 1];
+      }
+      r.valid = r.in && ((vbyte >> (slot & 7)) & 1);
+    } else {
+      // {length, inline bytes | prefix, buffer, offset}: the value is wherever the view says (no common span).
+      // The 16 view bytes are always readable; what they SAY is only trusted for valid rows (the view of a NULL
+      // slot is arbitrary)
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef const i32x4 __attribute__((address_space(1))) *gi32x4;
+      const i32x4 vw = *(gi32x4)((uintptr_t)d.views + (uintptr_t)slot * 16);
+      r.valid = r.in && ((vbyte >> (slot & 7)) & 1);
+      const int32_t len = r.valid ? vw.x : 0;
       r.b = 0;
       r.e = len;
-      if (len <= 12) {
+      if (len <= 12)
         r.data = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
-      } else {
-        const int32_t bi = vw[2], bo = vw[3];
-        r.data = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
-      }
-    } else if (d.large_offsets) {
-      global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
-      r.b = off[slot];
-      r.e = off[slot + 1];
-    } else {
-      global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
-      r.b = off[slot];
-      r.e = off[slot + 1];
+      else
+        r.data = (uintptr_t)d.buffers[vw.z] + (uintptr_t)(uint32_t)vw.w;
     }
     return r;
   };
@@ -275,15 +278,23 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
   if (blocks > (int64_t)n_cu * 6) blocks = (int64_t)n_cu * 6;
   if (blocks < 1) blocks = 1;
   const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
+  const dim3 grid((int)blocks), block(256);
+#define TGX_RX(ENTRIES, DIRECT)                                                                                      \
+  do {                                                                                                               \
+    if (d.views)                                                                                                     \
+      hipLaunchKernelGGL((regex_match_kernel<ENTRIES, DIRECT, true>), grid, block, 0, stream, d, dfa, d_counters);   \
+    else                                                                                                             \
+      hipLaunchKernelGGL((regex_match_kernel<ENTRIES, DIRECT, false>), grid, block, 0, stream, d, dfa, d_counters);  \
+  } while (0)
   if (dfa.n_classes == 256 && dfa.direct && entries <= 4096)
-    hipLaunchKernelGGL((regex_match_kernel<4096, true>), dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+    TGX_RX(4096, true);
   else if (entries <= 4096)
-    hipLaunchKernelGGL(regex_match_kernel<4096>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+    TGX_RX(4096, false);
   else if (entries <= kRegexLdsEntries)
-    hipLaunchKernelGGL(regex_match_kernel<(int)kRegexLdsEntries>, dim3((int)blocks), dim3(256), 0, stream, d, dfa,
-                       d_counters);
+    TGX_RX((int)kRegexLdsEntries, false);
   else
-    hipLaunchKernelGGL(regex_match_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, d, dfa, d_counters);
+    TGX_RX(0, false);
+#undef TGX_RX
 }
 
 }  // namespace tgx
