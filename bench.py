@@ -85,7 +85,7 @@ def main():
     import term_amd as T
     from term_amd import synth
     from term_amd._lib import spec
-    from term_amd.distributed import agree_on_ranges, allgather_many, exchange_distinct_auto, merge_blobs
+    from term_amd.distributed import sharded_suite_step
 
     torch.cuda.set_device(local_rank)
     dist = None
@@ -128,25 +128,12 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        st.reset()
-        st.update(columns)
         if not distributed:
+            st.reset()
+            st.update(columns)
             return st.finalize()
-        local = st.finalize()
-        st_d.reset()
-        minmax = []
-        for s in specs[n_stats:]:
-            r = next(x for sp, x in zip(specs[:n_stats], local) if sp.kind == T.NUMERIC_STATS and sp.column == s.column)
-            minmax.append((bool(r.has_value) and not r.is_float, r.min_i, r.max_i))
-        for j, rng in enumerate(agree_on_ranges(minmax, dist, world)):
-            if rng is not None:
-                st_d.distinct_range_hint(j, rng[0], rng[1])
-        st_d.update(columns)
-        exchange_distinct_auto(st_d, list(range(len(specs) - n_stats)), dist, world, rank)
-        per_rank = allgather_many([st.serialize(), st_d.serialize()], dist, world, device="cuda", cache_key="bench")
-        merged = merge_blobs(plan, [p[0] for p in per_rank])
-        merged_d = merge_blobs(plan_d, [p[1] for p in per_rank])
-        return merged.finalize() + merged_d.finalize()
+        return sharded_suite_step(plan, st, plan_d, st_d, specs[:n_stats], specs[n_stats:], columns, dist, world, rank,
+                                  cache_key="bench")
 
     def fence():
         torch.cuda.synchronize()

@@ -210,3 +210,33 @@ def merge_blobs(plan, blobs):
 def allgather_merge(plan, state_or_blob, dist, world, device="cpu"):
     blob = state_or_blob if isinstance(state_or_blob, (bytes, bytearray)) else state_or_blob.serialize()
     return merge_blobs(plan, allgather_blobs(blob, dist, world, device))
+
+
+def sharded_suite_step(plan, state, plan_d, state_d, stat_specs, distinct_specs, columns, dist, world, rank,
+                       cache_key=None):
+    """One step of a row-sharded suite on this rank (what bench.py times for N > 1):
+
+        scan of the local shard -> ranks agree on the DISTINCT columns' global value ranges -> congruent range
+        bitmaps (tgx_distinct_range_hint) -> one all-to-all of bitmap slices (hash-owner key exchange where a set
+        is not a bitmap) -> one all-gather of the packed partial states -> identical rank-ordered merge everywhere.
+
+    `plan` / `state` hold the additive checks (`stat_specs`), `plan_d` / `state_d` the DISTINCT checks
+    (`distinct_specs`); returns the merged results of both, in that order."""
+    state.reset()
+    state.update(columns)
+    local = state.finalize()
+    state_d.reset()
+    minmax = []
+    for s in distinct_specs:
+        r = next((x for sp, x in zip(stat_specs, local) if sp.kind == T.NUMERIC_STATS and sp.column == s.column), None)
+        minmax.append((bool(r.has_value) and not r.is_float, r.min_i, r.max_i) if r is not None else (False, 0, 0))
+    for j, rng in enumerate(agree_on_ranges(minmax, dist, world)):
+        if rng is not None:
+            state_d.distinct_range_hint(j, rng[0], rng[1])
+    state_d.update(columns)
+    exchange_distinct_auto(state_d, list(range(len(distinct_specs))), dist, world, rank)
+    per_rank = allgather_many([state.serialize(), state_d.serialize()], dist, world, device="cuda", cache_key=cache_key)
+    merged = merge_blobs(plan, [p[0] for p in per_rank])
+    merged_d = merge_blobs(plan_d, [p[1] for p in per_rank])
+    return merged.finalize() + merged_d.finalize()
+
