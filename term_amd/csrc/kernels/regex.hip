@@ -58,6 +58,57 @@ __device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_t
   return st;
 }
 
+// two values per lane walked in lockstep: the two chains of dependent LDS lookups interleave (the walk is bound by
+// lookup latency, not by issue), so the second value comes almost for free
+template <bool LDS_TABLE, bool STAGED, bool DIRECT>
+__device__ __forceinline__ void walk2(const DfaView &dfa, const uint16_t *s_table, const uint8_t *s_class,
+                                      uintptr_t data0, int64_t b0, int64_t e0, uintptr_t data1, int64_t b1,
+                                      int64_t e1, const uint8_t *stage, int64_t stage_base, uint32_t *out0,
+                                      uint32_t *out1) {
+  global_u16_ptr g_table = (global_u16_ptr)(uintptr_t)dfa.table;
+  const uint32_t ncls = dfa.n_classes;
+  uint32_t st0 = dfa.start, st1 = dfa.start;
+  int64_t p0 = b0, p1 = b1;
+  auto load = [&](uintptr_t data, int64_t p, uint32_t *skip) -> uint64_t {
+    if (STAGED) {
+      *skip = (uint32_t)((p - stage_base) & 7);
+      return *(const uint64_t *)(stage + ((p - stage_base) & ~(int64_t)7));
+    }
+    *skip = (uint32_t)((data + (uintptr_t)p) & 7);
+    return *(global_u64_ptr)((data + (uintptr_t)p) & ~(uintptr_t)7);
+  };
+  auto step = [&](uint32_t st, uint64_t &w) -> uint32_t {
+    const uint32_t c = DIRECT ? (uint32_t)(w & 0xFF) : s_class[w & 0xFF];
+    w >>= 8;
+    return DIRECT ? s_table[(st << 8) + c] : LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
+  };
+  for (;;) {
+    const bool a0 = p0 < e0 && st0 > 1, a1 = p1 < e1 && st1 > 1;
+    if (!a0 && !a1) break;
+    uint32_t skip0 = 0, skip1 = 0, nb0 = 0, nb1 = 0;
+    uint64_t w0 = 0, w1 = 0;
+    if (a0) {
+      w0 = load(data0, p0, &skip0) >> (8 * skip0);
+      nb0 = 8 - skip0;
+      if (e0 - p0 < (int64_t)nb0) nb0 = (uint32_t)(e0 - p0);
+      p0 += nb0;
+    }
+    if (a1) {
+      w1 = load(data1, p1, &skip1) >> (8 * skip1);
+      nb1 = 8 - skip1;
+      if (e1 - p1 < (int64_t)nb1) nb1 = (uint32_t)(e1 - p1);
+      p1 += nb1;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      if (k < nb0 && st0 > 1) st0 = step(st0, w0);
+      if (k < nb1 && st1 > 1) st1 = step(st1, w1);
+    }
+  }
+  *out0 = st0;
+  *out1 = st1;
+}
+
 // TABLE_ENTRIES: LDS budget of the transition table (0 = the table stays in global memory / L2).  The small
 // instance leaves room for 6 workgroups per CU, the large one for 3.
 template <int TABLE_ENTRIES, bool DIRECT = false, bool VIEW = false>
@@ -81,18 +132,21 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *stage = s_stage[wave];
   unsigned long long matches = 0;
-  const int64_t n_groups = (d.length + 63) / 64;  // 64 consecutive rows per wave step
-  // row descriptor of lane `lane` in group g: value bytes [b, e) relative to `data`, validity
+  // A wave step takes 128 consecutive rows, two per lane (rows `lane` and `lane + 64` of the step): twice the bytes
+  // in flight for the same LDS, and the two values of a lane are walked in lockstep.  When the 128 values do not
+  // fit the stage the two 64-row halves are staged one after the other; a half that still does not fit is read
+  // straight from global memory.
+  const int64_t n_groups = (d.length + 127) / 128;
+  // row descriptor: value bytes [b, e) relative to `data` (raw offsets, also for NULL rows), validity
   struct Row {
     int64_t b, e;
     uintptr_t data;
     bool valid, in;
   };
-  auto fetch = [&](int64_t g) -> Row {
+  auto fetch = [&](int64_t i) -> Row {
     Row r;
-    const int64_t i = g * 64 + lane;
     r.in = i < d.length;
-    const int64_t slot = d.offset + (r.in ? i : d.length - 1);
+    const int64_t slot = d.offset + (r.in ? i : d.length - 1);  // rows past the end repeat the last row
     const uint32_t vbyte = vbits ? (uint32_t)vbits[slot >> 3] : 0xFFu;  // requested first, used last
     r.data = data0;
     if (!is_view) {
@@ -124,58 +178,94 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     }
     return r;
   };
-  const int64_t g_stride = (int64_t)gridDim.x * 4;
-  int64_t g = (int64_t)blockIdx.x * 4 + wave;
-  Row next = fetch(g < n_groups ? g : 0);
-  for (; g < n_groups; g += g_stride) {
-    // the offsets / validity of the NEXT group are requested before this group's bytes are staged and walked: the
-    // two dependent memory latencies per step (offsets, then bytes) overlap across steps
-    const Row cur = next;
-    if (g + g_stride < n_groups) next = fetch(g + g_stride);
-    const int64_t i = g * 64 + lane;
-    const bool in = cur.in, valid = cur.valid;
-    int64_t b = cur.b, e = cur.e;
-    const uintptr_t data = cur.data;
-    // the wave's values are contiguous: [b of lane 0, e of the last lane)
-    const int64_t span_b = __shfl(b, 0, 64), span_e = __shfl(e, 63, 64);
-    // 16-byte blocks by ABSOLUTE address: a block that holds one byte of the buffer lies in the same page, so
-    // the rounded-out copy cannot fault whatever the alignment of `data`
-    const int64_t stage_base = span_b - (int64_t)((data0 + (uintptr_t)span_b) & 15);
-    const bool staged = !is_view && span_e - stage_base <= (int64_t)kStageBytes;  // wave-uniform
-    if (staged) {
-      // coalesced 16-byte loads of the span into LDS (values of NULL rows included; never interpreted)
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
-      global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)stage_base);
-      const int64_t n16 = (span_e - stage_base + 15) >> 4;
-      for (int64_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + 16 * k) = src[k];
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    if (valid) {
-      if (d.trim) {
-        // SQL TRIM(col) = btrim(col, ' '): U+0020 only
-        if (staged) {
-          while (b < e && stage[b - stage_base] == 0x20) b++;
-          while (e > b && stage[e - 1 - stage_base] == 0x20) e--;
-        } else {
-          global_u8_ptr bytes = (global_u8_ptr)data;
-          while (b < e && bytes[b] == 0x20) b++;
-          while (e > b && bytes[e - 1] == 0x20) e--;
-        }
+  // copies bytes [base, span_e) of the value buffer into the wave's stage.  16-byte blocks by ABSOLUTE address: a
+  // block that holds one byte of the buffer lies in the same page, so the rounded-out copy cannot fault whatever
+  // the alignment of `data` (values of NULL rows are copied too; never interpreted)
+  auto stage_in = [&](int64_t base, int64_t span_e) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
+    global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)base);
+    const int64_t n16 = (span_e - base + 15) >> 4;
+    for (int64_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + 16 * k) = src[k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  auto stage_done = [&]() {  // every lane is done with the stage: the next copy may overwrite it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto align16 = [&](int64_t span_b) -> int64_t { return span_b - (int64_t)((data0 + (uintptr_t)span_b) & 15); };
+  // walk bounds of a row: NULL rows walk nothing; SQL TRIM(col) = btrim(col, ' '): U+0020 only
+  auto bounds = [&](const Row &r, bool staged, int64_t base, int64_t *wb, int64_t *we) {
+    int64_t b = r.b, e = r.valid ? r.e : r.b;
+    if (d.trim) {
+      if (staged) {
+        while (b < e && stage[b - base] == 0x20) b++;
+        while (e > b && stage[e - 1 - base] == 0x20) e--;
+      } else {
+        global_u8_ptr bytes = (global_u8_ptr)r.data;
+        while (b < e && bytes[b] == 0x20) b++;
+        while (e > b && bytes[e - 1] == 0x20) e--;
       }
-      const uint32_t st = staged ? walk<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data, b, e, stage, stage_base)
-                                 : walk<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, data, b, e, nullptr, 0);
+    }
+    *wb = b;
+    *we = e;
+  };
+  auto account = [&](const Row &r, int64_t i, uint32_t st) {
+    if (r.valid) {
       const bool hit = st == 1 || g_acc[st];
       matches += hit ? 1 : 0;
       if (d.hits) d.hits[i] = hit ? 1 : 0;
-    } else if (in) {
+    } else if (r.in) {
       matches += d.null_is_valid ? 1 : 0;
       if (d.hits) d.hits[i] = 2;
     }
-    // the stage is reused by the next step of this wave
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  };
+  const int64_t g_stride = (int64_t)gridDim.x * 4;
+  int64_t g = (int64_t)blockIdx.x * 4 + wave;
+  Row n0 = fetch((g < n_groups ? g : 0) * 128 + lane), n1 = fetch((g < n_groups ? g : 0) * 128 + 64 + lane);
+  for (; g < n_groups; g += g_stride) {
+    // the offsets / validity of the NEXT step are requested before this step's bytes are staged and walked
+    const Row r0 = n0, r1 = n1;
+    if (g + g_stride < n_groups) {
+      n0 = fetch((g + g_stride) * 128 + lane);
+      n1 = fetch((g + g_stride) * 128 + 64 + lane);
+    }
+    const int64_t i0 = g * 128 + lane, i1 = i0 + 64;
+    uint32_t st0 = 0, st1 = 0;
+    int64_t wb0, we0, wb1, we1;
+    if (is_view) {
+      bounds(r0, false, 0, &wb0, &we0);
+      bounds(r1, false, 0, &wb1, &we1);
+      walk2<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, r0.data, wb0, we0, r1.data, wb1, we1, nullptr, 0, &st0, &st1);
+    } else {
+      // the step's values are contiguous: [b of its first row, e of its last)
+      const int64_t b_first = __shfl(r0.b, 0, 64), e_half = __shfl(r0.e, 63, 64), e_last = __shfl(r1.e, 63, 64);
+      const int64_t base = align16(b_first);
+      if (e_last - base <= (int64_t)kStageBytes) {  // wave-uniform
+        stage_in(base, e_last);
+        bounds(r0, true, base, &wb0, &we0);
+        bounds(r1, true, base, &wb1, &we1);
+        walk2<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data0, wb0, we0, data0, wb1, we1, stage, base, &st0, &st1);
+        stage_done();
+      } else {
+        const bool fit0 = e_half - base <= (int64_t)kStageBytes;
+        if (fit0) stage_in(base, e_half);
+        bounds(r0, fit0, base, &wb0, &we0);
+        st0 = fit0 ? walk<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data0, wb0, we0, stage, base)
+                   : walk<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, data0, wb0, we0, nullptr, 0);
+        if (fit0) stage_done();
+        const int64_t base1 = align16(__shfl(r1.b, 0, 64));
+        const bool fit1 = e_last - base1 <= (int64_t)kStageBytes;
+        if (fit1) stage_in(base1, e_last);
+        bounds(r1, fit1, base1, &wb1, &we1);
+        st1 = fit1 ? walk<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data0, wb1, we1, stage, base1)
+                   : walk<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, data0, wb1, we1, nullptr, 0);
+        if (fit1) stage_done();
+      }
+    }
+    account(r0, i0, st0);
+    account(r1, i1, st1);
   }
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) matches += __shfl_down(matches, dlt, 64);
@@ -274,7 +364,7 @@ void launch_length(const RegexColDesc &d, const LengthBounds &lb, unsigned long 
 
 void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long *d_counters, int n_cu,
                   hipStream_t stream) {
-  int64_t blocks = (d.length + 255) / 256;
+  int64_t blocks = (d.length + 511) / 512;  // 128 rows per wave step, four waves
   if (blocks > (int64_t)n_cu * 6) blocks = (int64_t)n_cu * 6;
   if (blocks < 1) blocks = 1;
   const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
