@@ -143,40 +143,74 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     uintptr_t data;
     bool valid, in;
   };
-  auto fetch = [&](int64_t i) -> Row {
+  // What a step requests up front.  Offsets: ONE load per row -- a row's end is the next row's start, fetched from
+  // the neighbouring lane when the step is used (rows past the end of the column read the end offset, so they
+  // come out empty), plus the step's end offset (`tail`, one address for the whole wave).
+  struct Step {
+    int64_t b0, b1, tail;  // !VIEW: raw offsets
+    uint32_t vb0, vb1;     // validity bytes
+    Row v0, v1;            // VIEW: complete rows
+  };
+  auto offset_at = [&](int64_t row) -> int64_t {
+    const int64_t slot = d.offset + (row < d.length ? row : d.length);
+    return d.large_offsets ? ((global_i64_ptr)(uintptr_t)d.offsets)[slot]
+                           : (int64_t)((global_i32_ptr)(uintptr_t)d.offsets)[slot];
+  };
+  auto view_row = [&](int64_t i) -> Row {
+    // {length, inline bytes | prefix, buffer, offset}: the value is wherever the view says (no common span).
+    // The 16 view bytes are always readable; what they SAY is only trusted for valid rows (the view of a NULL
+    // slot is arbitrary)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef const i32x4 __attribute__((address_space(1))) *gi32x4;
     Row r;
     r.in = i < d.length;
-    const int64_t slot = d.offset + (r.in ? i : d.length - 1);  // rows past the end repeat the last row
-    const uint32_t vbyte = vbits ? (uint32_t)vbits[slot >> 3] : 0xFFu;  // requested first, used last
-    r.data = data0;
-    if (!is_view) {
-      if (d.large_offsets) {
-        global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
-        r.b = off[slot];
-        r.e = off[slot + 1];
-      } else {
-        global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
-        r.b = off[slot];
-        r.e = off[slot + 1];
-      }
-      r.valid = r.in && ((vbyte >> (slot & 7)) & 1);
-    } else {
-      // {length, inline bytes | prefix, buffer, offset}: the value is wherever the view says (no common span).
-      // The 16 view bytes are always readable; what they SAY is only trusted for valid rows (the view of a NULL
-      // slot is arbitrary)
-      typedef int i32x4 __attribute__((ext_vector_type(4)));
-      typedef const i32x4 __attribute__((address_space(1))) *gi32x4;
-      const i32x4 vw = *(gi32x4)((uintptr_t)d.views + (uintptr_t)slot * 16);
-      r.valid = r.in && ((vbyte >> (slot & 7)) & 1);
-      const int32_t len = r.valid ? vw.x : 0;
-      r.b = 0;
-      r.e = len;
-      if (len <= 12)
-        r.data = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
-      else
-        r.data = (uintptr_t)d.buffers[vw.z] + (uintptr_t)(uint32_t)vw.w;
-    }
+    const int64_t slot = d.offset + (r.in ? i : d.length - 1);
+    const uint32_t vbyte = vbits ? (uint32_t)vbits[slot >> 3] : 0xFFu;
+    const i32x4 vw = *(gi32x4)((uintptr_t)d.views + (uintptr_t)slot * 16);
+    r.valid = r.in && ((vbyte >> (slot & 7)) & 1);
+    const int32_t len = r.valid ? vw.x : 0;
+    r.b = 0;
+    r.e = len;
+    if (len <= 12)
+      r.data = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
+    else
+      r.data = (uintptr_t)d.buffers[vw.z] + (uintptr_t)(uint32_t)vw.w;
     return r;
+  };
+  auto fetch = [&](int64_t g) -> Step {
+    Step s;
+    const int64_t i0 = g * 128 + lane, i1 = i0 + 64;
+    if (is_view) {
+      s.v0 = view_row(i0);
+      s.v1 = view_row(i1);
+      return s;
+    }
+    const int64_t s0 = d.offset + (i0 < d.length ? i0 : d.length - 1), s1 = d.offset + (i1 < d.length ? i1 : d.length - 1);
+    s.vb0 = vbits ? (uint32_t)vbits[s0 >> 3] : 0xFFu;
+    s.vb1 = vbits ? (uint32_t)vbits[s1 >> 3] : 0xFFu;
+    s.b0 = offset_at(i0);
+    s.b1 = offset_at(i1);
+    s.tail = offset_at(g * 128 + 128);
+    return s;
+  };
+  auto rows_of = [&](const Step &s, int64_t g, Row *r0, Row *r1) {
+    if (is_view) {
+      *r0 = s.v0;
+      *r1 = s.v1;
+      return;
+    }
+    const int64_t i0 = g * 128 + lane, i1 = i0 + 64;
+    const int64_t next0 = __shfl_down(s.b0, 1, 64), next1 = __shfl_down(s.b1, 1, 64), first1 = __shfl(s.b1, 0, 64);
+    r0->b = s.b0;
+    r0->e = lane < 63 ? next0 : first1;
+    r1->b = s.b1;
+    r1->e = lane < 63 ? next1 : s.tail;
+    r0->data = r1->data = data0;
+    r0->in = i0 < d.length;
+    r1->in = i1 < d.length;
+    const int64_t s0 = d.offset + (r0->in ? i0 : d.length - 1), s1 = d.offset + (r1->in ? i1 : d.length - 1);
+    r0->valid = r0->in && ((s.vb0 >> (s0 & 7)) & 1);
+    r1->valid = r1->in && ((s.vb1 >> (s1 & 7)) & 1);
   };
   // copies bytes [base, span_e) of the value buffer into the wave's stage.  16-byte blocks by ABSOLUTE address: a
   // block that holds one byte of the buffer lies in the same page, so the rounded-out copy cannot fault whatever
@@ -223,14 +257,13 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   };
   const int64_t g_stride = (int64_t)gridDim.x * 4;
   int64_t g = (int64_t)blockIdx.x * 4 + wave;
-  Row n0 = fetch((g < n_groups ? g : 0) * 128 + lane), n1 = fetch((g < n_groups ? g : 0) * 128 + 64 + lane);
+  Step nxt = fetch(g < n_groups ? g : 0);
   for (; g < n_groups; g += g_stride) {
     // the offsets / validity of the NEXT step are requested before this step's bytes are staged and walked
-    const Row r0 = n0, r1 = n1;
-    if (g + g_stride < n_groups) {
-      n0 = fetch((g + g_stride) * 128 + lane);
-      n1 = fetch((g + g_stride) * 128 + 64 + lane);
-    }
+    const Step cur = nxt;
+    if (g + g_stride < n_groups) nxt = fetch(g + g_stride);
+    Row r0, r1;
+    rows_of(cur, g, &r0, &r1);
     const int64_t i0 = g * 128 + lane, i1 = i0 + 64;
     uint32_t st0 = 0, st1 = 0;
     int64_t wb0, we0, wb1, we1;
