@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
     global_i64x2_ptr x2 = (global_i64x2_ptr)x, y2 = (global_i64x2_ptr)y;
     const int64_t n_pairs = d.length >> 1;
     done = 2 * n_pairs;
+    const bool x_even = (d.xoff & 1) == 0, y_even = (d.yoff & 1) == 0;
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < n_pairs; p0 += 4 * stride) {
       i64x2 xq[4], yq[4];
       bool ok[8];
@@ -71,8 +72,20 @@ __global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
         const int64_t p = p0 + u * stride;
         const bool in = p < n_pairs;
         const int64_t q = in ? p : 0;
-        ok[2 * u] = in && cm_valid(xv, d.xoff + 2 * q) && cm_valid(yv, d.yoff + 2 * q);
-        ok[2 * u + 1] = in && cm_valid(xv, d.xoff + 2 * q + 1) && cm_valid(yv, d.yoff + 2 * q + 1);
+        // both rows of a pair share a validity byte when the Arrow offset is even: one byte load per column
+        uint32_t xb2 = 3, yb2 = 3;
+        if (xv) {
+          const int64_t b = d.xoff + 2 * q;
+          xb2 = x_even ? ((uint32_t)xv[b >> 3] >> (b & 7)) & 3u
+                       : (uint32_t)cm_valid(xv, b) | ((uint32_t)cm_valid(xv, b + 1) << 1);
+        }
+        if (yv) {
+          const int64_t b = d.yoff + 2 * q;
+          yb2 = y_even ? ((uint32_t)yv[b >> 3] >> (b & 7)) & 3u
+                       : (uint32_t)cm_valid(yv, b) | ((uint32_t)cm_valid(yv, b + 1) << 1);
+        }
+        ok[2 * u] = in && (xb2 & yb2 & 1u);
+        ok[2 * u + 1] = in && ((xb2 & yb2) >> 1);
         xq[u] = __builtin_nontemporal_load(x2 + q);
         yq[u] = __builtin_nontemporal_load(y2 + q);
       }

@@ -116,6 +116,13 @@ def column_from_list(values, dtype):
     return arr, (None if mask.all() else pack_validity(mask))
 
 
+def unpack_validity(validity, n):
+    """LSB-first bitmap -> bool mask of n rows (None = all valid)"""
+    if validity is None:
+        return np.ones(n, dtype=bool)
+    return np.unpackbits(np.asarray(validity, dtype=np.uint8), bitorder="little")[:n].astype(bool)
+
+
 def utf8_from_list(values):
     """['a', None] -> (offsets int32, data uint8, validity or None)"""
     mask = np.array([v is not None for v in values], dtype=bool)

@@ -279,6 +279,18 @@ def test_comoments_and_correlation_formulas(golden):
     for got, want in [(res[0].sum_x, cm.sum_x), (res[0].sum_y, cm.sum_y), (res[0].sum_x2, cm.sum_x2),
                       (res[0].sum_y2, cm.sum_y2), (res[0].sum_xy, cm.sum_xy)]:
         assert rel_err(got, want) < TOL
+    # sliced views: every combination of even / odd Arrow offsets (the wide path reads validity per row pair) and
+    # 16-byte aligned / unaligned value pointers
+    for xo, yo, m in ((0, 0, 1001), (2, 4, 70_000), (1, 1, 70_001), (3, 8, 99_999), (6, 5, 64)):
+        res, _, _ = run_plan([spec(T.COMOMENTS, 0, column2=1)],
+                             [[numeric_column(iv, ivv, True, offset=xo, length=m),
+                               numeric_column(fv, fvv, True, offset=yo, length=m)]])
+        cm = orc.comoments(iv[xo:xo + m].copy(), fv[yo:yo + m].copy(),
+                           orc.pack_validity(orc.unpack_validity(ivv, n)[xo:xo + m]),
+                           orc.pack_validity(orc.unpack_validity(fvv, n)[yo:yo + m]))
+        assert res[0].non_null == cm.n and res[0].total == m, (xo, yo, m)
+        for got, want in [(res[0].sum_x, cm.sum_x), (res[0].sum_y, cm.sum_y), (res[0].sum_xy, cm.sum_xy)]:
+            assert rel_err(got, want) < TOL, (xo, yo, m)
 
 
 def test_reference_known_answer_vectors_numeric(golden):
