@@ -142,7 +142,7 @@ __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_
   return base + incl - v;
 }
 
-constexpr int kKllRowsPerThread = 8;
+constexpr int kKllRowsPerThread = 16;
 constexpr int kKllStepRows = kKllThreads * kKllRowsPerThread;  // 2048 rows per workgroup step
 
 // loads 8 rows per thread of the 2048-row step at `base` (row pairs base + 2 (t + 256 u) + {0, 1}: one
@@ -228,7 +228,7 @@ __device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i6
 __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, int64_t chunk,
                                                                  KllDeviceSketch *sketches,
                                                                  uint64_t salt0, uint32_t top) {
-  __shared__ double ring[4096];  // four batches of sampled values: slot = sampled index & 4095 (a step brings <= 2)
+  __shared__ double ring[8192];  // eight batches of sampled values: slot = sampled index & 8191 (a step brings <= 4)
   __shared__ double buf[1024];
   __shared__ uint32_t wave_tot[kKllThreads / 64];
   __shared__ double red_min[kKllThreads / 64], red_max[kKllThreads / 64];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
   // sorts the 1024 sampled values of batch kb (weight 2^level), keeps every other one, inserts the run above
   auto flush_batch = [&](uint64_t kb, uint32_t level) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = ring[((kb & 3) << 10) + t + u * kKllThreads];
+    for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = ring[((kb & 7) << 10) + t + u * kKllThreads];
     __syncthreads();
     block_sort_1024(buf);
     const uint32_t parity = (uint32_t)(kll_mix(salt ^ 0x5bd1e995ULL ^ (kb << 1)) >> 35) & 1u;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
       mn = v[u] < mn ? v[u] : mn;
       mx = v[u] > mx ? v[u] : mx;
       const uint64_t g = j >> top;
-      if ((j & ((1ull << top) - 1)) == pick_of(top, 0, g)) ring[g & 4095] = v[u];
+      if ((j & ((1ull << top) - 1)) == pick_of(top, 0, g)) ring[g & 8191] = v[u];
       j++;
     }
     const uint64_t before = consumed;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
           const uint64_t seg0 = end_top + ((uint64_t)before << 10);
           const uint64_t sampled0 = (batches_top + __builtin_popcount(before)) << 10;
           const uint64_t o = j - seg0, g = o >> level;
-          if ((o & ((1ull << level) - 1)) == pick_of(level, seg0, g)) ring[(sampled0 + g) & 4095] = v[u];
+          if ((o & ((1ull << level) - 1)) == pick_of(level, seg0, g)) ring[(sampled0 + g) & 8191] = v[u];
         }
         j++;
       }

@@ -80,7 +80,7 @@ tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error
   int64_t groups = (c.length + 65535) / 65536;
   groups = std::max<int64_t>(1, std::min<int64_t>(groups, 1024));
   int64_t chunk = (c.length + groups - 1) / groups;
-  chunk = (chunk + 2047) / 2048 * 2048;
+  chunk = (chunk + 4095) / 4096 * 4096;
   groups = (c.length + chunk - 1) / chunk;
   KHIP(k->scratch.reserve((size_t)groups * sizeof(KllDeviceSketch)));
   KllColDesc d;
