@@ -173,13 +173,14 @@ __global__ __launch_bounds__(256) void distinct_bitmap_kernel(DistinctColDesc d,
 // loads one tile's keys + validity into registers.  Validity bytes are requested BEFORE the keys so that
 // turning them into the `ok` mask only waits for those (vmcnt retires in order) and the 16-byte key loads
 // stay in flight.
-template <int THREADS, int KPT>
+template <int THREADS, int KPT, bool VALIDITY>
 __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, int64_t tile, bool wide,
                                                     int64_t (&key)[KPT], uint32_t &ok) {
   constexpr int kPartitionThreads = THREADS;  // (shadows the namespace constant inside this function)
   constexpr int kTile = kPartitionThreads * KPT;
   global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)p.values + p.offset);
-  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)p.validity;
+  // VALIDITY = false: the column has no validity bitmap (its own instance: no byte loads, fewer live registers)
+  global_u8_ptr vbits = VALIDITY ? (global_u8_ptr)(uintptr_t)p.validity : (global_u8_ptr) nullptr;
   const uint32_t tid = threadIdx.x;
   const int64_t row0 = tile * kTile;
   const bool full = row0 + kTile <= p.length;
@@ -401,7 +402,7 @@ __device__ __forceinline__ void partition_relative(const PartitionParams &p, con
 }
 
 // 1024 threads x 32 keys, one workgroup per CU (152 KiB of LDS); any alignment, ragged last tile.
-template <int THREADS, int KPT, int MAXP, int PAD>
+template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
     PartitionParams p, unsigned long long *counters) {
   constexpr int kTile = THREADS * KPT;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
     {
       int64_t key[KPT];
       uint32_t ok32 = 0;
-      partition_load_tile<THREADS, KPT>(p, tile, wide, key, ok32);
+      partition_load_tile<THREADS, KPT, VALIDITY>(p, tile, wide, key, ok32);
       ok = ok32;
       partition_relative<KPT>(p, key, rel, ok, n_out);
     }
@@ -684,8 +685,12 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   // (software-pipelined variants -- next tile requested before this tile's stores, either in the 128-register
   //  budget of 1024 threads or as 512 threads x 64 keys with 256 registers -- spill and ran 3.3 / 6.0 ms
   //  against 3.0 ms: the load and store phases already run at HBM rate, only the LDS phases are exposed)
-  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16>),
-                     dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
+  if (p.validity)
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, true>),
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
+  else
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, false>),
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
 }
 
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
