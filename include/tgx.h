@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define TGX_ABI_VERSION 1
+/* 2: tgx_column grew the Utf8View fields, tgx_check_spec the column list and LENGTH bounds,
+ *    tgx_distinct_adopt_slices a slice stride */
+#define TGX_ABI_VERSION 2
 
 typedef enum tgx_status {
   TGX_OK = 0,
