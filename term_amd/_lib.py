@@ -10,6 +10,7 @@ _ROOT = os.path.dirname(_HERE)
 COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 1, 2, 3, 4, 5, 6, 7, 8
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
+ABI_VERSION = 2  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW = 1, 2, 3, 4, 5, 6
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
@@ -115,6 +116,9 @@ def lib():
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
         E = C.POINTER(_Error)
         L.tgx_abi_version.restype = C.c_uint32
+        if L.tgx_abi_version() != ABI_VERSION:
+            raise ImportError("term_amd/libtgx.so speaks ABI %d, this binding ABI %d: rebuild it (make -C term_amd/csrc)"
+                              % (L.tgx_abi_version(), ABI_VERSION))
         L.tgx_status_name.restype = C.c_char_p
         L.tgx_status_name.argtypes = [C.c_int32]
         L.tgx_init.argtypes = [C.POINTER(_Options), E]
