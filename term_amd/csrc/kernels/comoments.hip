@@ -148,16 +148,33 @@ __global__ __launch_bounds__(64) void comoments_reduce_kernel(
     const ComomentLaunch L, const ComomentPartial *__restrict__ partials, int blocks_per_pair,
     ComomentAcc *__restrict__ accs) {
   const int pair = blockIdx.x;
-  if (threadIdx.x != 0) return;
-  // serial fixed-order fold: <= 2048 partials, deterministic
-  ComomentAcc &a = accs[L.acc_index[pair]];
-  a.total += L.pairs[pair].length;
-  for (int i = 0; i < blocks_per_pair; i++) {
+  // fixed-order fold, 64 lanes wide: lane l folds its contiguous slice of the partials in order, lane 0 then folds
+  // the 64 lane results in order -- the same association for a given grid shape, so results are reproducible
+  __shared__ ComomentPartial lane_sum[64];
+  const int lane = threadIdx.x;
+  const int per = (blocks_per_pair + 63) / 64;
+  ComomentPartial a;
+  a.n = 0;
+  for (int k = 0; k < 5; k++) a.s[k] = a.c[k] = 0.0;
+  for (int i = lane * per; i < (lane + 1) * per && i < blocks_per_pair; i++) {
     const ComomentPartial &p = partials[(size_t)pair * blocks_per_pair + i];
     a.n += p.n;
     for (int k = 0; k < 5; k++) {
       a.c[k] += p.c[k];
       cm_two_sum(a.s[k], a.c[k], p.s[k]);
+    }
+  }
+  lane_sum[lane] = a;
+  __syncthreads();
+  if (lane != 0) return;
+  ComomentAcc &acc = accs[L.acc_index[pair]];
+  acc.total += L.pairs[pair].length;
+  for (int l = 0; l < 64; l++) {
+    const ComomentPartial &p = lane_sum[l];
+    acc.n += p.n;
+    for (int k = 0; k < 5; k++) {
+      acc.c[k] += p.c[k];
+      cm_two_sum(acc.s[k], acc.c[k], p.s[k]);
     }
   }
 }
