@@ -60,7 +60,7 @@ tgx_status tgx_host_assertion_json(const char *assertion_json, double value, int
 
 /* ---- analyzers (TG/analyzers/traits.rs:65-179, runner.rs:64-202) --------------------------------------------
  * Analysis JSON: {"table_name": "data", "continue_on_error": true, "analyzers": [
- *     {"type": "size"}, {"type": "completeness|distinctness|mean|min|max|sum|standard_deviation", "column": "c"},
+ *     {"type": "size"}, {"type": "completeness|distinctness|approx_count_distinct|mean|min|max|sum|standard_deviation", "column": "c"},
  *     {"type": "correlation", "column1": "a", "column2": "b", "method": "pearson|spearman|covariance"}]}
  * AnalysisRunner::run: every analyzer's aggregates planned into ONE tgx_plan, one pass over the table.  Returns
  *   {"metrics": {metric_key: {"type": "Double|Long|Map", "value": ..}},      (MetricValue's serde form, types.rs:11-35)

@@ -183,6 +183,30 @@ class DistinctnessAnalyzer : public ColumnAnalyzer {  // basic/distinctness.rs
   }
 };
 
+// advanced/approx_count_distinct.rs: APPROX_DISTINCT(col) (DataFusion's HyperLogLog, a third-party estimate whose
+// value is unpinned by the reference's tests) and COUNT(col).  The device path counts EXACTLY (kernels/distinct*.hip),
+// which is the value the estimate approximates; state fields, the max-merge and the metric type are the reference's.
+class ApproxCountDistinctAnalyzer : public ColumnAnalyzer {
+ public:
+  using ColumnAnalyzer::ColumnAnalyzer;
+  std::string name() const override { return "approx_count_distinct"; }
+  std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_DISTINCT, column_)}; }
+  json::Value state_from_results(const std::vector<const tgx_result *> &r, const std::vector<int> &) const override {
+    return jobj({{"approx_distinct_count", jnum((double)r[0]->distinct)}, {"total_count", jnum((double)r[0]->non_null)}});
+  }
+  json::Value merge_states(const std::vector<json::Value> &states) const override {  // :45-61: max of the counts
+    uint64_t d = 0, t = 0;
+    for (auto &s : states) {
+      d = std::max(d, u(s, "approx_distinct_count"));
+      t += u(s, "total_count");
+    }
+    return jobj({{"approx_distinct_count", jnum((double)d)}, {"total_count", jnum((double)t)}});
+  }
+  MetricValue metric_from_state(const json::Value &s) const override {  // :126-128
+    return MetricValue::of_long((int64_t)u(s, "approx_distinct_count"));
+  }
+};
+
 // SUM(col) comes back as Float64 for Float64 columns and Int64 (wrapping) for Int64 columns
 double sql_sum(const tgx_result *r) { return r->is_float ? r->sum_f : (double)r->sum_i; }
 
@@ -389,6 +413,7 @@ std::shared_ptr<Analyzer> analyzer_from_json(const json::Value &v) {
   if (t == "size") return std::make_shared<SizeAnalyzer>();
   if (t == "completeness") return std::make_shared<CompletenessAnalyzer>(col());
   if (t == "distinctness") return std::make_shared<DistinctnessAnalyzer>(col());
+  if (t == "approx_count_distinct") return std::make_shared<ApproxCountDistinctAnalyzer>(col());
   if (t == "mean") return std::make_shared<MeanAnalyzer>(col());
   if (t == "min") return std::make_shared<MinMaxAnalyzer>(col(), false);
   if (t == "max") return std::make_shared<MinMaxAnalyzer>(col(), true);

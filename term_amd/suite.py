@@ -435,6 +435,7 @@ class _Analyzer:
 def SizeAnalyzer(): return _Analyzer({"type": "size"})
 def CompletenessAnalyzer(column): return _Analyzer({"type": "completeness", "column": column})
 def DistinctnessAnalyzer(column): return _Analyzer({"type": "distinctness", "column": column})
+def ApproxCountDistinctAnalyzer(column): return _Analyzer({"type": "approx_count_distinct", "column": column})
 def MeanAnalyzer(column): return _Analyzer({"type": "mean", "column": column})
 def MinAnalyzer(column): return _Analyzer({"type": "min", "column": column})
 def MaxAnalyzer(column): return _Analyzer({"type": "max", "column": column})

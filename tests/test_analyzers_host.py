@@ -42,6 +42,11 @@ def test_metric_rules_and_errors():
     assert m == {"total_count": 6, "distinct_count": 5}
     m = S.DistinctnessAnalyzer("c").merge_states([{"total_count": 2, "distinct_count": 9}])
     assert m["distinct_count"] == 2
+    # approx_count_distinct.rs:45-61, 126-128: counts merge by max, the metric is a Long
+    a = S.ApproxCountDistinctAnalyzer("c")
+    m = a.merge_states([{"approx_distinct_count": 7, "total_count": 10}, {"approx_distinct_count": 9, "total_count": 5}])
+    assert m == {"approx_distinct_count": 9, "total_count": 15}
+    assert a.compute_metric_from_state(m) == {"type": "Long", "value": 9} and a.metric_key() == "approx_count_distinct.c"
     # NoData (mean.rs:147-152, sum.rs:145-151, min_max.rs:167-172)
     for an, st in ((S.MeanAnalyzer("c"), {"sum": 0.0, "count": 0}), (S.SumAnalyzer("c"), {"sum": 0.0, "has_values": False}),
                    (S.MinAnalyzer("c"), {"min": None, "max": None}), (S.MaxAnalyzer("c"), {"min": None, "max": None})):

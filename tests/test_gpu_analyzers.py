@@ -64,6 +64,9 @@ def test_runner_tests_of_the_reference():
         assert ctx.get_metric(key) is not None, key
     assert ctx.get_metric("sum.id")["value"] == 15.0 and ctx.get_metric("max.id")["value"] == 5.0
     assert ctx.get_metric("mean.value")["value"] == 32.5 and ctx.get_metric("distinctness.value")["value"] == 1.0
+    ctx = S.AnalysisRunner().add(S.ApproxCountDistinctAnalyzer("value")).run(tbl)
+    assert ctx.get_metric("approx_count_distinct.value") == {"type": "Long", "value": 4}
+    assert ctx.states["approx_count_distinct.value"] == {"approx_distinct_count": 4, "total_count": 4}
 
 
 def test_edge_tables_and_type_quirks(golden):
