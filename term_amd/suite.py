@@ -552,3 +552,183 @@ def constraint_verdict(constraint, results):
 def validate_identifier(identifier):
     err = _Error()
     _host_check(_host().tgx_host_validate_identifier(identifier.encode(), C.byref(err)), err)
+
+
+# ---------------------------------------------------------------------------------------------- incremental analysis
+class InMemoryStateStore:
+    """TG/analyzers/incremental/state_store.rs StateStore: partition -> {metric_key: state}"""
+
+    def __init__(self):
+        self._p = {}
+
+    def load_state(self, partition):
+        return dict(self._p.get(partition, {}))
+
+    def save_state(self, partition, state_map):
+        self._p[partition] = dict(state_map)
+
+    def list_partitions(self):
+        return sorted(self._p)
+
+    def delete_partition(self, partition):
+        self._p.pop(partition, None)
+
+
+class FileSystemStateStore:
+    """state_store.rs:37-190: <base>/<partition>/<metric_key>.json, each file the serde_json form of the analyzer's
+    state struct -- the states produced here use the reference's field names, so a directory written by either side
+    can be read by the other."""
+
+    def __init__(self, base_path):
+        import os
+
+        self._base = str(base_path)
+        os.makedirs(self._base, exist_ok=True)
+
+    def _dir(self, partition):
+        import os
+
+        return os.path.join(self._base, partition)
+
+    def load_state(self, partition):
+        import os
+
+        out, d = {}, self._dir(partition)
+        if not os.path.isdir(d):
+            return out
+        for name in sorted(os.listdir(d)):
+            if name.endswith(".json"):
+                with open(os.path.join(d, name)) as f:
+                    out[name[:-5]] = json.load(f)
+        return out
+
+    def save_state(self, partition, state_map):
+        import os
+
+        d = self._dir(partition)
+        os.makedirs(d, exist_ok=True)
+        for key, state in state_map.items():
+            with open(os.path.join(d, key + ".json"), "w") as f:
+                json.dump(state, f)
+
+    def list_partitions(self):
+        import os
+
+        return sorted(n for n in os.listdir(self._base) if os.path.isdir(os.path.join(self._base, n)))
+
+    def delete_partition(self, partition):
+        import shutil
+
+        shutil.rmtree(self._dir(partition), ignore_errors=True)
+
+
+def _state_is_empty(analyzer, state):
+    """AnalyzerState::is_empty of the mirrored state types"""
+    t = analyzer.spec["type"]
+    if t in ("size", "mean", "standard_deviation"):
+        return state.get("count", 0) == 0
+    if t in ("completeness", "distinctness", "approx_count_distinct"):
+        return state.get("total_count", 0) == 0
+    if t in ("min", "max"):
+        return state.get("min") is None and state.get("max") is None
+    if t == "sum":
+        return not state.get("has_values", False)
+    return False  # correlation: the trait default
+
+
+class IncrementalAnalysisRunner:
+    """TG/analyzers/incremental/runner.rs:102-430.  Each partition's states come from ONE fused pass on the GPU
+    (AnalysisRunner); merging and metrics are the reference's state algebra (csrc/host/analyzers.cpp)."""
+
+    def __init__(self, state_store, fail_fast=True, save_empty_states=False, max_merge_batch_size=100):
+        self._store, self._analyzers = state_store, []
+        self._fail_fast, self._save_empty, self._batch = fail_fast, save_empty_states, max_merge_batch_size
+
+    def add_analyzer(self, analyzer):
+        self._analyzers.append(analyzer)
+        return self
+
+    def analyzer_count(self):
+        return len(self._analyzers)
+
+    def list_partitions(self):
+        return self._store.list_partitions()
+
+    def delete_partition(self, partition):
+        self._store.delete_partition(partition)
+
+    def _fresh(self, table):
+        r = AnalysisRunner().continue_on_error(True)
+        for a in self._analyzers:
+            r.add(a)
+        ctx = r.run(table)
+        if ctx.has_errors() and self._fail_fast:
+            raise TgxError(1, ctx.errors()[0]["error"])
+        return ctx
+
+    def analyze_partition(self, table, partition):
+        """runner.rs:139-213: states of `table` saved under `partition`, metrics returned"""
+        ctx = self._fresh(table)
+        states = {a.metric_key(): ctx.states[a.metric_key()] for a in self._analyzers if a.metric_key() in ctx.states}
+        self._store.save_state(partition, {k: v for k, v in states.items()
+                                           if self._save_empty or not _state_is_empty(self._by_key(k), v)})
+        return ctx
+
+    def _by_key(self, key):
+        return next(a for a in self._analyzers if a.metric_key() == key)
+
+    def _finish(self, merged_by_key, errors):
+        metrics = {}
+        for a in self._analyzers:
+            key = a.metric_key()
+            if key not in merged_by_key:
+                continue
+            try:
+                metrics[key] = a.compute_metric_from_state(merged_by_key[key])
+            except TgxError as e:
+                if self._fail_fast:
+                    raise
+                errors.append({"analyzer_name": a.name(), "error": e.msg})
+        return AnalyzerContext(json.dumps({"metrics": metrics, "states": merged_by_key, "errors": errors}))
+
+    def analyze_incremental(self, table, partition):
+        """runner.rs:216-317: new data's states merged into the partition's stored states"""
+        existing = self._store.load_state(partition)
+        ctx = self._fresh(table)
+        merged, errors = {}, list(ctx.errors())
+        for a in self._analyzers:
+            key = a.metric_key()
+            if key not in ctx.states:
+                continue
+            new = ctx.states[key]
+            try:
+                merged[key] = a.merge_states([existing[key], new]) if key in existing else new
+            except TgxError as e:
+                if self._fail_fast:
+                    raise
+                errors.append({"analyzer_name": a.name(), "error": e.msg})
+        self._store.save_state(partition, {k: v for k, v in merged.items()
+                                           if self._save_empty or not _state_is_empty(self._by_key(k), v)})
+        return self._finish(merged, errors)
+
+    def analyze_partitions(self, partitions):
+        """runner.rs:320-414: metrics over the union of stored partitions, no data access"""
+        partitions = list(partitions)
+        by_key, errors = {}, []
+        for i in range(0, len(partitions), self._batch):
+            for p in partitions[i:i + self._batch]:
+                for key, st in self._store.load_state(p).items():
+                    by_key.setdefault(key, []).append(st)
+        merged = {}
+        for a in self._analyzers:
+            key = a.metric_key()
+            if not by_key.get(key):
+                continue
+            try:
+                merged[key] = a.merge_states(by_key[key])
+            except TgxError as e:
+                if self._fail_fast:
+                    raise
+                errors.append({"analyzer_name": a.name(), "error": e.msg})
+        return self._finish(merged, errors)
+

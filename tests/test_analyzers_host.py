@@ -111,3 +111,27 @@ def test_correlation_state_algebra(golden):
     assert p.compute_metric_from_state(state([1, 1, 1], [2, 3, 4], "Pearson"))["value"] == 0.0
     with pytest.raises(T.TgxError, match="Cannot merge rank-based correlation states"):
         S.CorrelationAnalyzer("x", "y", "spearman").merge_states([state(xs, ys, "Spearman")])
+
+
+def test_incremental_runner_merges_stored_states_without_data(tmp_path):
+    """TG/analyzers/incremental/runner.rs:320-414 over a FileSystemStateStore laid out like the reference's
+    (state_store.rs:37-127: <base>/<partition>/<metric_key>.json, serde field names) -- no device involved"""
+    store = S.FileSystemStateStore(tmp_path / "states")
+    store.save_state("2024-01-01", {"size": {"count": 10}, "completeness.v": {"total_count": 10, "non_null_count": 8},
+                                    "mean.v": {"sum": 100.0, "count": 4}, "min.v": {"min": 10.0, "max": 30.0}})
+    store.save_state("2024-01-02", {"size": {"count": 20}, "completeness.v": {"total_count": 20, "non_null_count": 18},
+                                    "mean.v": {"sum": 50.0, "count": 2}, "min.v": {"min": 5.0, "max": 40.0}})
+    assert store.list_partitions() == ["2024-01-01", "2024-01-02"]
+    import json, os
+    assert json.load(open(os.path.join(tmp_path, "states", "2024-01-01", "mean.v.json"))) == {"sum": 100.0, "count": 4}
+    r = (S.IncrementalAnalysisRunner(store).add_analyzer(S.SizeAnalyzer()).add_analyzer(S.CompletenessAnalyzer("v"))
+         .add_analyzer(S.MeanAnalyzer("v")).add_analyzer(S.MinAnalyzer("v")).add_analyzer(S.SumAnalyzer("v")))
+    ctx = r.analyze_partitions(["2024-01-01", "2024-01-02"])
+    assert ctx.get_metric("size") == {"type": "Long", "value": 30}
+    assert ctx.get_metric("completeness.v")["value"] == 26 / 30
+    assert ctx.get_metric("mean.v")["value"] == 25.0 and ctx.get_metric("min.v")["value"] == 5.0
+    assert ctx.get_metric("sum.v") is None  # no stored state for that analyzer: skipped (runner.rs:357-362)
+    assert S.IncrementalAnalysisRunner(store).analyze_partitions([]).metrics == {}
+    r.delete_partition("2024-01-01")
+    assert r.list_partitions() == ["2024-01-02"]
+    assert r.analyze_partitions(["2024-01-01", "2024-01-02"]).get_metric("size")["value"] == 20

@@ -115,3 +115,44 @@ def test_standard_deviation_and_correlation_analyzers():
     whole = ctx.states[an.metric_key()]
     assert merged["n"] == whole["n"] and abs(merged["sum_xy"] - whole["sum_xy"]) <= 1e-9 * whole["sum_xy"]
     assert abs(an.compute_metric_from_state(merged)["value"] - 1.0) < 1e-12
+
+
+def test_incremental_runner_partitions_equal_the_whole_table(tmp_path):
+    """TG/analyzers/incremental/runner.rs: analyze_partition per day + analyze_partitions over the stored states ==
+    one run over all rows; analyze_incremental grows a partition in place"""
+    import numpy as np
+
+    rng = np.random.default_rng(3)
+    n = 30_000
+    v = rng.standard_normal(n) * 50
+    mask = rng.random(n) >= 0.1
+    x = rng.random(n)
+    tbl = pa.table({"v": pa.array(np.where(mask, v, np.nan), pa.float64(), mask=~mask), "x": pa.array(x, pa.float64()),
+                    "y": pa.array(3 * x + rng.standard_normal(n) * 0.1, pa.float64())})
+    analyzers = [S.SizeAnalyzer(), S.CompletenessAnalyzer("v"), S.MeanAnalyzer("v"), S.MinAnalyzer("v"), S.MaxAnalyzer("v"),
+                 S.SumAnalyzer("v"), S.StandardDeviationAnalyzer("v"), S.CorrelationAnalyzer("x", "y", "pearson")]
+    whole = S.AnalysisRunner()
+    for a in analyzers:
+        whole.add(a)
+    want = whole.run(tbl)
+    for store in (S.InMemoryStateStore(), S.FileSystemStateStore(tmp_path / "s")):
+        r = S.IncrementalAnalysisRunner(store)
+        for a in analyzers:
+            r.add_analyzer(a)
+        r.analyze_partition(tbl.slice(0, 10_000), "p0")
+        r.analyze_partition(tbl.slice(10_000, 5_000), "p1")
+        r.analyze_incremental(tbl.slice(15_000, 7_000), "p1")      # p1 now covers rows 10000..22000
+        ctx_last = r.analyze_incremental(tbl.slice(22_000), "p2")  # a partition that did not exist yet
+        assert ctx_last.get_metric("size")["value"] == 8000
+        got = r.analyze_partitions(r.list_partitions())
+        assert got.get_metric("size") == want.get_metric("size")
+        assert got.get_metric("completeness.v") == want.get_metric("completeness.v")
+        assert got.get_metric("min.v") == want.get_metric("min.v") and got.get_metric("max.v") == want.get_metric("max.v")
+        for key in ("mean.v", "sum.v", "correlation_pearson_x_y"):
+            a, b = got.get_metric(key)["value"], want.get_metric(key)["value"]
+            assert abs(a - b) <= 1e-9 * abs(b), key
+        sa = {k: x_["value"] for k, x_ in got.get_metric("standard_deviation")["value"].items()}
+        sb = {k: x_["value"] for k, x_ in want.get_metric("standard_deviation")["value"].items()}
+        assert sa["count"] == sb["count"]
+        for k in ("mean", "std_dev", "sample_variance"):
+            assert abs(sa[k] - sb[k]) <= 1e-9 * abs(sb[k]), k
