@@ -253,7 +253,7 @@ __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, in
 //   pass 2   counting sort of the 20-bit sub-keys into LDS      (hook `mid` runs just before it)
 //   stores   each wave streams whole runs out, 16 bytes per lane (hook `before_stores` runs just before)
 // (the hooks are where a software-pipelined caller would request the next tile; unused today)
-template <int THREADS, int KPT, int MAXP, int PAD, class MidFn, class StoreFn>
+template <int THREADS, int KPT, int MAXP, int PAD, bool KEY16, class MidFn, class StoreFn>
 __device__ __forceinline__ void partition_process_tile(const PartitionParams &p, uint32_t *sorted, uint32_t *hist,
                                                        uint32_t *toff, uint32_t *gbase, uint32_t *wave_sums,
                                                        const uint32_t (&rel)[KPT], uint64_t ok, MidFn &&mid,
@@ -262,6 +262,10 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   constexpr int BPT = MAXP / THREADS;         // buckets per thread in the scan
   constexpr int NS = MAXP / (NW * 64);        // run-metadata sets per lane in the store phase
   static_assert(MAXP % THREADS == 0 && MAXP % (NW * 64) == 0 && PAD % 4 == 0, "shape");
+  // KEY16: buckets of <= 2^16 keys, so a list entry is 2 bytes: half the list traffic.  Runs are padded to 32 slots
+  // (64 bytes) by REPEATING their last key (a set union is idempotent; not used with multiplicity), since no
+  // 16-bit value is left over as a filler.
+  constexpr uint32_t RPAD = KEY16 ? 32u : (uint32_t)PAD;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
@@ -297,7 +301,7 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
       hist[b] = excl;  // becomes the placement cursor of pass 2
       uint32_t g = 0;
       if (h[k]) {
-        const unsigned long long padded = (h[k] + (PAD - 1u)) & ~(PAD - 1u);
+        const unsigned long long padded = (h[k] + (RPAD - 1u)) & ~(RPAD - 1u);
         const unsigned long long at = atomicAdd(&p.cursors[b], padded);
         // cap < 2^32 (checked on the host); a run that does not fit spills as a whole
         if (at + padded > p.cap) {
@@ -345,11 +349,14 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
       m_g[s2] = in ? gbase[b] : 0;
     }
     const uint32_t n_meta = (p.n_buckets > wave) ? (p.n_buckets - wave + NW - 1) / NW : 0;
-    const uint32_t grp = lane >> 4, sub = lane & 15;
+    // lanes per bucket and buckets per step: 16 x 4 with 4-byte entries, 4 x 16 with 2-byte entries (a lane always
+    // stores 16 bytes; runs average kTile / P keys)
+    constexpr uint32_t LPB = KEY16 ? 4u : 16u, BPS = 64u / LPB, KPL = KEY16 ? 8u : 4u;
+    const uint32_t grp = lane / LPB, sub = lane % LPB;
 #pragma unroll
     for (int s2 = 0; s2 < NS; s2++) {
       const uint32_t m_end = n_meta > 64u * s2 ? (n_meta - 64u * s2 < 64u ? n_meta - 64u * s2 : 64u) : 0;
-      for (uint32_t m0 = 0; m0 < m_end; m0 += 4) {
+      for (uint32_t m0 = 0; m0 < m_end; m0 += BPS) {
         const uint32_t m = m0 + grp, src = m & 63;
         const uint32_t o = __shfl(m_o[s2], src, 64), g = __shfl(m_g[s2], src, 64);
         uint32_t h = __shfl(m_h[s2], src, 64);
@@ -357,18 +364,34 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
         if (h == 0) continue;
         const uint32_t b = (m + 64 * s2) * NW + wave;
         if (g != 0xFFFFFFFFu) {
-          const uint32_t padded = (h + (PAD - 1u)) & ~(PAD - 1u);
-          uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;  // 16-byte aligned: cap and g are multiples of PAD
-          for (uint32_t i = 4 * sub; i < padded; i += 64) {
-            uint4 v;
-            v.x = i < h ? sorted[o + i] : kListPad;
-            v.y = i + 1 < h ? sorted[o + i + 1] : kListPad;
-            v.z = i + 2 < h ? sorted[o + i + 2] : kListPad;
-            v.w = i + 3 < h ? sorted[o + i + 3] : kListPad;
-            *(uint4 *)&dst[i] = v;
+          const uint32_t padded = (h + (RPAD - 1u)) & ~(RPAD - 1u);
+          if (KEY16) {
+            // 16-byte aligned: cap and g are multiples of 32 two-byte slots
+            uint16_t *dst = (uint16_t *)p.lists + (uint64_t)b * p.cap + g;
+            for (uint32_t i = KPL * sub; i < padded; i += KPL * LPB) {
+              uint32_t k8[8];
+#pragma unroll
+              for (uint32_t j = 0; j < 8; j++) k8[j] = sorted[o + (i + j < h ? i + j : h - 1)];
+              uint4 v;
+              v.x = k8[0] | (k8[1] << 16);
+              v.y = k8[2] | (k8[3] << 16);
+              v.z = k8[4] | (k8[5] << 16);
+              v.w = k8[6] | (k8[7] << 16);
+              *(uint4 *)&dst[i] = v;
+            }
+          } else {
+            uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;  // 16-byte aligned: cap and g are multiples of PAD
+            for (uint32_t i = KPL * sub; i < padded; i += KPL * LPB) {
+              uint4 v;
+              v.x = i < h ? sorted[o + i] : kListPad;
+              v.y = i + 1 < h ? sorted[o + i + 1] : kListPad;
+              v.z = i + 2 < h ? sorted[o + i + 2] : kListPad;
+              v.w = i + 3 < h ? sorted[o + i + 3] : kListPad;
+              *(uint4 *)&dst[i] = v;
+            }
           }
         } else {
-          for (uint32_t i = sub; i < h; i += 16) {
+          for (uint32_t i = sub; i < h; i += LPB) {
             // spill: straight into the global bitmap
             const uint64_t r = ((uint64_t)b << p.sub_bits) | sorted[o + i];
             const uint32_t bit = 1u << (r & 31);
@@ -402,7 +425,7 @@ __device__ __forceinline__ void partition_relative(const PartitionParams &p, con
 }
 
 // 1024 threads x 32 keys, one workgroup per CU (152 KiB of LDS); any alignment, ragged last tile.
-template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY>
+template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
     PartitionParams p, unsigned long long *counters) {
   constexpr int kTile = THREADS * KPT;
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
       partition_relative<KPT>(p, key, rel, ok, n_out);
     }
     n_valid += __builtin_popcountll(ok);
-    partition_process_tile<THREADS, KPT, MAXP, PAD>(p, sorted, hist, toff, gbase, wave_sums, rel, ok, [] {}, [] {});
+    partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16>(p, sorted, hist, toff, gbase, wave_sums, rel, ok, [] {}, [] {});
   }
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
 }
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of
 // earlier batches and this batch's spills), replay list b with LDS atomics, store it back, and add the
 // slice's popcounts to the totals (counters[kCntDistinct] / [kCntTwice] are zeroed before the launch).
-template <int LDS_WORDS>
+template <int LDS_WORDS, bool KEY16 = false>
 __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(PartitionParams p,
                                                                          unsigned long long *counters) {
   // static LDS: gfx950 lets one workgroup declare up to 160 KiB statically (dynamic LDS is capped lower)
@@ -453,6 +476,32 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
   unsigned long long cnt = p.cursors[b];
   const unsigned long long limit = p.cursors[p.n_buckets + b];  // start of the first run that spilled
   if (cnt > limit) cnt = limit;
+  if (KEY16) {
+    // 2-byte entries, eight per 16-byte load; runs are padded with repeats of real keys, so every entry counts
+    const uint16_t *list16 = (const uint16_t *)p.lists + (uint64_t)b * p.cap;
+    constexpr uint64_t kStep16 = (uint64_t)kPartitionThreads * 8;
+    for (uint64_t i0 = (uint64_t)tid * 8; i0 < cnt; i0 += 4 * kStep16) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 k4[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint64_t i = i0 + q * kStep16;
+        k4[q] = u32x4{0, 0, 0, 0};
+        if (i < cnt) k4[q] = __builtin_nontemporal_load((const u32x4 *)&list16[i]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (i0 + q * kStep16 >= cnt) continue;
+        const uint32_t w4[4] = {k4[q].x, k4[q].y, k4[q].z, k4[q].w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t ka = w4[u] & 0xFFFFu, kb = w4[u] >> 16;
+          atomicOr(&l_seen[ka >> 5], 1u << (ka & 31));
+          atomicOr(&l_seen[kb >> 5], 1u << (kb & 31));
+        }
+      }
+    }
+  } else {
   const uint32_t *list = p.lists + (uint64_t)b * p.cap;
   // lists are made of 16-slot aligned runs, so cnt is a multiple of 4; kListPad slots are filler
   // four 16-byte loads in flight per lane before the first LDS atomic
@@ -482,6 +531,7 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
         }
       }
     }
+  }
   }
   __syncthreads();
   unsigned long long n_seen = 0, n_twice = 0;
@@ -685,22 +735,28 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   // (software-pipelined variants -- next tile requested before this tile's stores, either in the 128-register
   //  budget of 1024 threads or as 512 threads x 64 keys with 256 registers -- spill and ran 3.3 / 6.0 ms
   //  against 3.0 ms: the load and store phases already run at HBM rate, only the LDS phases are exposed)
-  if (p.validity)
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, true>),
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
-  else
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, false>),
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);
+#define TGX_PART(VAL, K16)                                                                                          \
+  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16>), \
+                     dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters)
+  if (p.key16) {
+    if (p.validity) TGX_PART(true, true); else TGX_PART(false, true);
+  } else {
+    if (p.validity) TGX_PART(true, false); else TGX_PART(false, false);
+  }
+#undef TGX_PART
 }
 
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
                                hipStream_t stream) {
   const size_t words = ((size_t)1 << p.sub_bits) / 32 * (p.want_multiplicity ? 2 : 1);
   const dim3 grid(p.n_buckets), block(kPartitionThreads);
-#define TGX_APPLY(W)                                                                       \
-  if (words <= W) {                                                                        \
-    hipLaunchKernelGGL(bucket_apply_kernel<W>, grid, block, 0, stream, p, d_counters);     \
-    return hipGetLastError();                                                              \
+#define TGX_APPLY(W)                                                                                  \
+  if (words <= W) {                                                                                   \
+    if (p.key16)                                                                                      \
+      hipLaunchKernelGGL((bucket_apply_kernel<W, true>), grid, block, 0, stream, p, d_counters);      \
+    else                                                                                              \
+      hipLaunchKernelGGL((bucket_apply_kernel<W, false>), grid, block, 0, stream, p, d_counters);     \
+    return hipGetLastError();                                                                         \
   }
   TGX_APPLY(1024)
   TGX_APPLY(2048)

@@ -47,13 +47,13 @@ struct PartitionParams {
   uint64_t range;
   uint32_t sub_bits;   // log2(keys per bucket)
   uint32_t n_buckets;  // P
-  uint64_t cap;        // list capacity per bucket (32-bit slots), multiple of 16
-  uint32_t *lists;     // P x cap
+  uint64_t cap;        // list capacity per bucket in slots (4-byte slots, multiple of 16; key16: 2-byte slots, of 32)
+  uint32_t *lists;     // P x cap slots
   unsigned long long *cursors;  // [0,P): next free slot per list (zeroed per batch); [P,2P): valid-length limits (all-ones)
   uint32_t *seen;      // global bitmap (rounded up to whole slices)
   uint32_t *twice;     // or nullptr
   int32_t want_multiplicity;
-  int32_t pad;
+  int32_t key16;       // 1: sub_bits <= 16 and list entries are 2 bytes (never with multiplicity)
 };
 
 // 16-byte record used by merge / serialize / the cross-rank key exchange.

@@ -937,6 +937,19 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     // every CU has lists to replay (<= 1024 targeted: longer runs per tile); one slice (two with multiplicity) must fit 128 KiB of LDS
     uint32_t sub_bits = 14;
     while (sub_bits < (mult ? 19u : 20u) && ((ds.range + (1ull << sub_bits) - 1) >> sub_bits) > 1024) sub_bits++;
+    // ranges up to 2048 x 2^16 values (134 M): buckets of <= 2^16 keys make a list entry 2 bytes instead of 4 --
+    // half the list traffic for more, shorter runs (not with multiplicity: run padding repeats keys)
+    bool key16 = false;
+    if (!mult && sub_bits > 16) {
+      uint32_t s16 = 14;
+      while (s16 < 16 && ((ds.range + (1ull << s16) - 1) >> s16) > kMaxPartitions) s16++;
+      if (((ds.range + (1ull << s16) - 1) >> s16) <= kMaxPartitions) {
+        key16 = true;
+        sub_bits = s16;
+      }
+    } else if (!mult) {
+      key16 = true;  // sub_bits <= 16 already
+    }
     const uint64_t n_buckets = (ds.range + (1ull << sub_bits) - 1) >> sub_bits;
     uint64_t cap_slots = (uint64_t)c.length / std::max<uint64_t>(n_buckets, 1);
     cap_slots = cap_slots + cap_slots / 4 + 16 * (((uint64_t)c.length >> 15) + 1) + 4096;
@@ -955,11 +968,11 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       // runs are padded to 16 slots per (tile, bucket): budget the average load + 25 % + the padding
       const uint64_t tiles = ((uint64_t)c.length + kPartitionTile - 1) / kPartitionTile;
       uint64_t cap = (uint64_t)c.length / n_buckets;
-      cap = cap + cap / 4 + 16 * tiles + 4096;
-      pp.cap = (cap + 15) & ~15ull;
+      cap = cap + cap / 4 + (key16 ? 32 : 16) * tiles + 4096;
+      pp.cap = key16 ? (cap + 31) & ~31ull : (cap + 15) & ~15ull;
       pp.want_multiplicity = mult ? 1 : 0;
-      pp.pad = 0;
-      HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * sizeof(uint32_t)));
+      pp.key16 = key16 ? 1 : 0;
+      HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * (key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
       HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
       HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
       HIP_TRY(hipMemsetAsync(ds.cursors.as<unsigned long long>() + pp.n_buckets, 0xFF,
