@@ -728,9 +728,9 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   int64_t n_tiles = (p.length + kPartitionTile - 1) / kPartitionTile;
   int grid = (int)(n_tiles < (int64_t)n_cu ? n_tiles : (int64_t)n_cu);  // 152 KiB of LDS: one workgroup per CU
   if (grid < 1) grid = 1;
-  // (software-pipelined variants -- next tile requested before this tile's stores, either in the 128-register
-  //  budget of 1024 threads or as 512 threads x 64 keys with 256 registers -- spill and ran 3.3 / 6.0 ms
-  //  against 3.0 ms: the load and store phases already run at HBM rate, only the LDS phases are exposed)
+  // (software-pipelined variants -- next tile requested before this tile's stores -- were measured three times:
+  //  with spills 3.3 ms, as 512 threads x 64 keys with 256 registers 6.0 ms, and spill-free 2.9 ms against
+  //  2.7 ms without: the load and store phases already run at HBM rate and the other CUs fill the gaps)
 #define TGX_PART(VAL, K16)                                                                                          \
   hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16>), \
                      dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters)
