@@ -882,6 +882,11 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     have_range = true;  // the caller vouches for [lo, hi]; keys outside it are counted and reported
     lo = ds.hint_lo;
     hi = ds.hint_hi;
+  } else if (c.type == TGX_INT64 && ds.mode == DistinctMode::kUndecided && c.length < (1 << 16)) {
+    // a stream of small batches (DataFusion hands out 8192 rows at a time): reading the column's MIN/MAX back
+    // costs a stream synchronisation per batch (65 us vs 10 us per update); such a state goes straight to the
+    // hash set, whose inserts need no range and no synchronisation
+    ds.mode = DistinctMode::kHash;
   } else if (c.type == TGX_INT64 && (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap)) {
     ScanAcc acc;
     HIP_TRY(hipMemcpyAsync(&acc, st->d_scan_acc.as<ScanAcc>() + task.scan_slot, sizeof(ScanAcc),

@@ -23,14 +23,17 @@ def main():
     for ci in range(len(layout)):
         specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci)]
     specs_d = specs + [spec(T.DISTINCT, 0), spec(T.DISTINCT, 1)]
-    for name, sp in (("null+range x8", specs), ("null+range x8 + unique x2", specs_d)):
+    host_table = [(v.cpu().numpy(), None if b is None else b.cpu().numpy()) for v, b in table]
+    for name, sp, where in (("null+range x8", specs, "device"), ("null+range x8 + unique x2", specs_d, "device"),
+                            ("null+range x8", specs, "host")):
         plan = T.Plan(sp)
         st = T.State(plan)
+        src = table if where == "device" else host_table
         for batch_rows in (n, 65536, 8192):
             cols_per_batch = []
             for lo in range(0, n, batch_rows):
                 cols = []
-                for (kind, _), (vals, validity) in zip(layout, table):
+                for (kind, _), (vals, validity) in zip(layout, src):
                     ctor = T.Column.float64 if kind.startswith("f_") else T.Column.int64
                     cols.append(ctor(vals, validity, length=batch_rows, offset=lo))
                 cols_per_batch.append(cols)
@@ -45,7 +48,7 @@ def main():
                 st.update(cols)
             res = st.finalize()
             dt = time.perf_counter() - t0
-            print(json.dumps({"suite": name, "rows": n, "batch_rows": batch_rows, "updates": len(cols_per_batch),
+            print(json.dumps({"suite": name, "buffers": where, "rows": n, "batch_rows": batch_rows, "updates": len(cols_per_batch),
                               "total_ms": dt * 1e3, "us_per_update": dt * 1e6 / len(cols_per_batch),
                               "rows_per_s": n / dt, "distinct0": res[-2].distinct if len(sp) > 16 else None}))
 
