@@ -226,6 +226,11 @@ struct tgx_state {
   tgx::DevBuf d_scan_partials, d_count_blocks, d_como_partials;
   std::vector<std::unique_ptr<tgx::DevBuf>> staging;  // host columns copied to the device
   size_t staging_used = 0;
+  // small HOST buffers of one update are gathered in a pinned arena and cross PCIe in ONE copy (a DataFusion batch
+  // is 8192 rows: a dozen 64-KiB buffers, 12 us of call overhead each when copied one by one)
+  void *arena_host = nullptr;  // hipHostMalloc
+  tgx::DevBuf arena_dev;
+  size_t arena_used = 0;
   std::deque<tgx_column> dict_views;  // device views of the dictionaries of the batch being updated
   // host copies of Utf8View buffer-pointer tables whose asynchronous upload may still be pending; dropped
   // wherever the stream is synchronized (gather / reset)

@@ -411,6 +411,7 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   regex_state_free(st);
   kll_state_free(st);
   spearman_state_free(st);
+  if (st->arena_host) (void)hipHostFree(st->arena_host);
   if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
   delete st;
 }
@@ -547,6 +548,9 @@ extern "C" tgx_status tgx_profile_reset(tgx_state *st) {
 static bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
 
 // copies a HOST column's buffers to the device; `out` is the device view
+constexpr size_t kArenaBytes = 8u << 20;        // pinned staging arena per state
+constexpr size_t kArenaMaxBuffer = 256u << 10;  // buffers up to this size go through it
+
 static bool is_string(int t) { return t == TGX_UTF8 || t == TGX_LARGE_UTF8; }
 static bool is_any_string(int t) { return is_string(t) || t == TGX_UTF8_VIEW; }
 
@@ -567,6 +571,20 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
   auto stage = [&](const void *src, size_t bytes, const void **dst) -> tgx_status {
     *dst = nullptr;
     if (!src || bytes == 0) return TGX_OK;
+    // HOST columns: tgx_update synchronises the stream before it returns, so the pinned arena is free again
+    if (c.mem == TGX_MEM_HOST && bytes <= kArenaMaxBuffer) {
+      if (!st->arena_host) {
+        HIP_TRY(hipHostMalloc(&st->arena_host, kArenaBytes, hipHostMallocDefault));
+        HIP_TRY(st->arena_dev.reserve(kArenaBytes));
+      }
+      const size_t at = (st->arena_used + 63) & ~(size_t)63;
+      if (at + bytes + 16 <= kArenaBytes) {
+        memcpy((char *)st->arena_host + at, src, bytes);
+        st->arena_used = at + bytes + 16;
+        *dst = (const char *)st->arena_dev.p + at;
+        return TGX_OK;
+      }
+    }
     if (st->staging_used == st->staging.size()) st->staging.emplace_back(new DevBuf());
     DevBuf *b = st->staging[st->staging_used++].get();
     HIP_TRY(b->reserve(bytes + 16));
@@ -1067,6 +1085,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
 
   // device views of every used column
   st->staging_used = 0;
+  st->arena_used = 0;
   st->dict_views.clear();
   std::vector<tgx_column> dev(plan->n_columns_needed);
   bool any_host = false;
@@ -1078,6 +1097,10 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       continue;
     }
     TGX_TRY(stage_column(st, columns[i], &dev[i], err));
+  }
+  if (st->arena_used) {
+    HIP_TRY(hipMemcpyAsync(st->arena_dev.p, st->arena_host, st->arena_used, hipMemcpyHostToDevice, st->stream));
+    st->arena_used = 0;
   }
 
   if (nrows > 0) {
