@@ -228,9 +228,15 @@ struct tgx_state {
   size_t staging_used = 0;
   // small HOST buffers of one update are gathered in a pinned arena and cross PCIe in ONE copy (a DataFusion batch
   // is 8192 rows: a dozen 64-KiB buffers, 12 us of call overhead each when copied one by one)
-  void *arena_host = nullptr;  // hipHostMalloc
-  tgx::DevBuf arena_dev;
+  // two arenas take turns, each guarded by an event recorded after the update that used it, so an update whose
+  // HOST buffers all fitted returns without synchronising the stream
+  void *arena_host[2] = {nullptr, nullptr};  // hipHostMalloc
+  tgx::DevBuf arena_dev[2];
+  hipEvent_t arena_event[2] = {nullptr, nullptr};
+  bool arena_busy[2] = {false, false};
+  int arena_cur = 0;
   size_t arena_used = 0;
+  bool host_direct = false;  // this update copied a HOST buffer straight from the caller's memory
   std::deque<tgx_column> dict_views;  // device views of the dictionaries of the batch being updated
   // host copies of Utf8View buffer-pointer tables whose asynchronous upload may still be pending; dropped
   // wherever the stream is synchronized (gather / reset)

@@ -411,7 +411,10 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   regex_state_free(st);
   kll_state_free(st);
   spearman_state_free(st);
-  if (st->arena_host) (void)hipHostFree(st->arena_host);
+  for (int k = 0; k < 2; k++) {
+    if (st->arena_event[k]) (void)hipEventDestroy(st->arena_event[k]);
+    if (st->arena_host[k]) (void)hipHostFree(st->arena_host[k]);
+  }
   if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
   delete st;
 }
@@ -573,18 +576,25 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
     if (!src || bytes == 0) return TGX_OK;
     // HOST columns: tgx_update synchronises the stream before it returns, so the pinned arena is free again
     if (c.mem == TGX_MEM_HOST && bytes <= kArenaMaxBuffer) {
-      if (!st->arena_host) {
-        HIP_TRY(hipHostMalloc(&st->arena_host, kArenaBytes, hipHostMallocDefault));
-        HIP_TRY(st->arena_dev.reserve(kArenaBytes));
+      const int k = st->arena_cur;
+      if (!st->arena_host[k]) {
+        HIP_TRY(hipHostMalloc(&st->arena_host[k], kArenaBytes, hipHostMallocDefault));
+        HIP_TRY(st->arena_dev[k].reserve(kArenaBytes));
+        HIP_TRY(hipEventCreateWithFlags(&st->arena_event[k], hipEventDisableTiming));
+      }
+      if (st->arena_busy[k]) {  // the update that used this arena two turns ago (almost always long done)
+        HIP_TRY(hipEventSynchronize(st->arena_event[k]));
+        st->arena_busy[k] = false;
       }
       const size_t at = (st->arena_used + 63) & ~(size_t)63;
       if (at + bytes + 16 <= kArenaBytes) {
-        memcpy((char *)st->arena_host + at, src, bytes);
+        memcpy((char *)st->arena_host[k] + at, src, bytes);
         st->arena_used = at + bytes + 16;
-        *dst = (const char *)st->arena_dev.p + at;
+        *dst = (const char *)st->arena_dev[k].p + at;
         return TGX_OK;
       }
     }
+    if (c.mem == TGX_MEM_HOST) st->host_direct = true;
     if (st->staging_used == st->staging.size()) st->staging.emplace_back(new DevBuf());
     DevBuf *b = st->staging[st->staging_used++].get();
     HIP_TRY(b->reserve(bytes + 16));
@@ -1085,7 +1095,9 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
 
   // device views of every used column
   st->staging_used = 0;
+  if (st->arena_used) (void)hipStreamSynchronize(st->stream);  // an update that failed half way left it in use
   st->arena_used = 0;
+  st->host_direct = false;
   st->dict_views.clear();
   std::vector<tgx_column> dev(plan->n_columns_needed);
   bool any_host = false;
@@ -1098,10 +1110,10 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     }
     TGX_TRY(stage_column(st, columns[i], &dev[i], err));
   }
-  if (st->arena_used) {
-    HIP_TRY(hipMemcpyAsync(st->arena_dev.p, st->arena_host, st->arena_used, hipMemcpyHostToDevice, st->stream));
-    st->arena_used = 0;
-  }
+  const bool arena_in_use = st->arena_used != 0;
+  if (arena_in_use)
+    HIP_TRY(hipMemcpyAsync(st->arena_dev[st->arena_cur].p, st->arena_host[st->arena_cur], st->arena_used,
+                           hipMemcpyHostToDevice, st->stream));
 
   if (nrows > 0) {
     // ---- numeric scan: all columns of the batch in launches of <= kMaxScanColsPerLaunch ----
@@ -1261,7 +1273,15 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     TGX_TRY(spearman_update(st, dev.data(), err));
   }
   st->batches++;
-  if (any_host) HIP_TRY(hipStreamSynchronize(st->stream));
+  if (arena_in_use) {
+    // the arena (and its device twin) are free again once everything this update queued has run
+    HIP_TRY(hipEventRecord(st->arena_event[st->arena_cur], st->stream));
+    st->arena_busy[st->arena_cur] = true;
+    st->arena_cur ^= 1;
+    st->arena_used = 0;
+  }
+  // HOST buffers copied straight from the caller's memory are borrowed only until tgx_update returns
+  if (any_host && st->host_direct) HIP_TRY(hipStreamSynchronize(st->stream));
   return TGX_OK;
 }
 
