@@ -63,7 +63,7 @@ typedef enum tgx_type {
    * indices), the dictionary is a Utf8 column view of its own (any memory space). COUNT, DISTINCT and
    * REGEX_MATCH give the results of the decoded column: string work runs once per dictionary entry,
    * every batch may bring its own dictionary (unused and repeated entries allowed). A row whose dictionary
-   * VALUE is NULL is a NULL row for DISTINCT and REGEX_MATCH. */
+   * VALUE is NULL is a NULL row for every check (Arrow's logical nulls). */
   TGX_DICT32_UTF8 = 5,
   /* Utf8View (what DataFusion reads Parquet strings as): 16-byte views in `values` -- {int32 length, 12 inline
    * bytes} for length <= 12, else {int32 length, 4-byte prefix, int32 buffer index, int32 offset} -- and

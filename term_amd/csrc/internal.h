@@ -44,6 +44,9 @@ int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
 void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
                             int64_t dict_length, int dict_has_nulls, const uint8_t *hits, int null_is_valid,
                             unsigned long long *d_counters, int n_cu, hipStream_t stream);
+void launch_dict_count(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
+                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, CountAcc *acc, int n_cu,
+                       hipStream_t stream);
 size_t dict_usage_words(int64_t dict_length);
 size_t dict_usage_scratch_bytes(int64_t length, int64_t dict_length, int want_mult, int n_cu);
 void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,

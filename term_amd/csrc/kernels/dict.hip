@@ -11,6 +11,7 @@
 //                    dict_insert_kernel inserts the fingerprints of referenced entries into the state's set.
 #include <hip/hip_runtime.h>
 
+#include "device_types.h"
 #include "distinct_types.h"
 
 namespace tgx {
@@ -191,6 +192,19 @@ __global__ __launch_bounds__(kDictThreads) void dict_usage_kernel(DictRowsDesc d
   dict_block_add1024(n_valid, &counters[kCntValidRows]);
 }
 
+// COUNT(*) / COUNT(col) of a dictionary column whose dictionary holds NULL values: a row counts when its index is
+// valid AND the value it points at is
+__global__ __launch_bounds__(kDictThreads) void dict_count_kernel(DictRowsDesc d, CountAcc *acc) {
+  global_u8_ptr dvbits = (global_u8_ptr)(uintptr_t)d.dict_validity;
+  unsigned long long n = 0;
+  dict_for_each_row(d, [&](int32_t e, bool valid) {
+    if (!valid || e < 0 || e >= d.dict_length) return;
+    n += (dvbits[(d.dict_offset + e) >> 3] >> ((d.dict_offset + e) & 7)) & 1;
+  });
+  dict_block_add1024(n, (unsigned long long *)&acc->non_null);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)&acc->total, (unsigned long long)d.length);
+}
+
 // OR of the workgroups' slices; an entry is referenced twice if any workgroup saw it twice or two saw it at all
 __global__ __launch_bounds__(256) void dict_usage_reduce_kernel(const uint32_t *slices, uint32_t n_slices,
                                                                  uint32_t words, int mult, uint32_t *seen,
@@ -226,6 +240,13 @@ void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int
   else
     hipLaunchKernelGGL(dict_count_hits_kernel<false>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
                        null_is_valid, d_counters);
+}
+
+void launch_dict_count(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
+                       const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, CountAcc *acc, int n_cu,
+                       hipStream_t stream) {
+  DictRowsDesc d{indices, validity, offset, length, dict_validity, dict_offset, dict_length};
+  hipLaunchKernelGGL(dict_count_kernel, dim3(dict_grid(length, n_cu)), dim3(kDictThreads), 0, stream, d, acc);
 }
 
 size_t dict_usage_words(int64_t dict_length) { return (size_t)((dict_length + 31) >> 5); }

@@ -1191,6 +1191,13 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       int64_t max_words = 0;
       for (size_t s = 0; s < plan->count.size(); s++) {
         const tgx_column &c = dev[plan->count[s].column];
+        if (c.type == TGX_DICT32_UTF8 && c.dictionary->validity && c.dictionary->length > 0) {
+          // a row whose dictionary VALUE is NULL is a NULL row (Arrow's logical nulls): count through the indices
+          launch_dict_count((const int32_t *)c.values, c.validity, c.offset, c.length, c.dictionary->validity,
+                            c.dictionary->offset, c.dictionary->length, st->d_count_acc.as<CountAcc>() + s, g_ctx.n_cu,
+                            st->stream);
+          continue;
+        }
         if (!c.validity) {  // no validity buffer: COUNT(col) = COUNT(*) = length, no kernel needed
           st->h_count[s].total += c.length;
           st->h_count[s].non_null += c.length;

@@ -137,3 +137,41 @@ def test_from_arrow_dictionary():
     assert res[1].matches == want_m
     res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], [[T.Column.from_arrow(sl)]])
     check(res[0], want_s)
+
+
+@pytest.mark.parametrize("mult", [False, True])
+def test_dictionary_beyond_the_lds_budget(mult):
+    """1.2 M entries: the per-entry bitmaps no longer fit LDS (1 Mi verdict bits, 512 Ki with multiplicity), so the
+    rows go through the test-before-set global path; a NULL dictionary VALUE makes its rows NULL rows"""
+    import torch
+
+    rng = np.random.default_rng(31 + mult)
+    card, n = 1_200_000, 2_000_000
+    ids = np.arange(card)
+    width = 7
+    digits = ((ids[:, None] // 10 ** np.arange(width - 1, -1, -1)) % 10 + ord("0")).astype(np.uint8)
+    data = np.concatenate([np.full((card, 1), ord("k"), np.uint8), digits], axis=1).reshape(-1)  # "k0000123"
+    offs = (np.arange(card + 1) * (width + 1)).astype(np.int32)
+    dvalid = np.ones(card, dtype=bool)
+    dvalid[[5, 77, 1_100_000]] = False  # NULL dictionary values
+    idx = rng.integers(0, card // 2, size=n).astype(np.int32)  # half of the entries are never referenced
+    idx[:10] = [5, 5, 77, 1_100_000, 3, 3, 4, 1_199_999, 1_199_999, 1_199_998]
+    mask = rng.random(n) >= 0.05
+    mask[:10] = True
+    dcol = T.Column.utf8(to_device(offs), to_device(np.concatenate([data, np.zeros(16, np.uint8)])),
+                         validity=to_device(pad_validity(orc.pack_validity(dvalid))), length=card)
+    col = T.Column.dict32_utf8(to_device(idx), dcol, validity=to_device(pad_validity(orc.pack_validity(mask))), length=n)
+    flags = T.FLAG_MULTIPLICITY if mult else 0
+    res, _, _ = run_plan([spec(T.DISTINCT, 0, flags=flags), spec(T.REGEX_MATCH, 0, pattern=r"7$"),
+                          spec(T.REGEX_MATCH, 0, pattern=r"7$", flags=T.FLAG_NULL_IS_VALID), spec(T.COUNT, 0)], [[col]])
+    live = mask & dvalid[idx]                      # rows that carry a value
+    used, counts = np.unique(idx[live], return_counts=True)
+    assert (res[0].total, res[0].non_null, res[0].distinct) == (n, int(live.sum()), len(used))
+    if mult:
+        assert res[0].groups_once == int((counts == 1).sum()) + (1 if n - int(live.sum()) == 1 else 0)
+    ends7 = (idx % 10 == 7) & live
+    assert res[1].matches == int(ends7.sum())
+    assert res[2].matches == int(ends7.sum()) + int((~live).sum())
+    assert (res[3].total, res[3].non_null) == (n, int(live.sum()))  # COUNT: Arrow's logical nulls
+    res, _, _ = run_plan([spec(T.COUNT, 0)], [[col]])  # COUNT alone (no DISTINCT to lean on)
+    assert (res[0].total, res[0].non_null) == (n, int(live.sum()))
