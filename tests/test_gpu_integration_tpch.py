@@ -90,3 +90,37 @@ def test_mixed_suite_one_pass_and_analyzers():
     assert ctx.get_metric("distinctness.c_nationkey")["value"] == 0.025 and ctx.get_metric("max.c_custkey")["value"] == 1000.0
     want_mean = sum(((i * 31) % 10000) / 100.0 for i in range(1, 1001)) / 1000
     assert abs(ctx.get_metric("mean.c_acctbal")["value"] - want_mean) < 1e-9
+
+
+def test_performance_regression_thresholds():
+    """term-guard/tests/performance_regression_test.rs: 10 k rows -- completeness < 300 ms (:146), statistics
+    < 300 ms (:182), six constraints < 400 ms (:225); 50 k rows, ten constraints < 1000 ms (:317).  (Wall clock of
+    ValidationSuite.run including planning, pattern compilation and the JSON bridge; first call warmed up.)"""
+    import time
+
+    def timed(suite, tbl):
+        suite.run(tbl)
+        t0 = time.perf_counter()
+        r = suite.run(tbl)
+        return (time.perf_counter() - t0) * 1e3, r
+
+    t10 = customer(10_000)
+    ms, _ = timed(ValidationSuite.builder("s").check(Check.builder("c").level(Level.ERROR)
+                                                  .completeness(["c_custkey"]).build()).build(), t10)
+    assert ms < 300
+    ms, _ = timed(ValidationSuite.builder("s").check(
+        Check.builder("c").level(Level.ERROR).has_min("c_acctbal", Assertion.GreaterThanOrEqual(0.0))
+        .has_max("c_acctbal", Assertion.LessThan(1000.0)).has_mean("c_acctbal", Assertion.Between(0.0, 100.0)).build()).build(), t10)
+    assert ms < 300
+    six = (Check.builder("c").level(Level.ERROR).completeness(["c_custkey"]).validates_uniqueness(["c_custkey"], 1.0)
+           .has_min("c_acctbal", Assertion.GreaterThanOrEqual(0.0)).has_max("c_acctbal", Assertion.LessThan(1000.0))
+           .validates_regex("c_phone", r"^\d{2}-\d{3}-\d{3}-\d{4}$", 1.0).has_min_length("c_name", 5))
+    ms, r = timed(ValidationSuite.builder("s").check(six.build()).build(), t10)
+    assert ms < 400 and r.is_success()
+    ten = (Check.builder("c").level(Level.ERROR).completeness(["c_custkey"]).completeness(["c_name"])
+           .validates_uniqueness(["c_custkey"], 1.0).validates_distinctness(["c_mktsegment"], Assertion.LessThan(0.1))
+           .has_min("c_acctbal", Assertion.GreaterThanOrEqual(0.0)).has_max("c_acctbal", Assertion.LessThan(1000.0))
+           .has_mean("c_acctbal", Assertion.Between(0.0, 100.0)).validates_regex("c_phone", r"^\d{2}-", 1.0)
+           .has_max_length("c_name", 25).is_contained_in("c_mktsegment", SEGMENTS))
+    ms, r = timed(ValidationSuite.builder("s").check(ten.build()).build(), customer(50_000))
+    assert ms < 1000 and r.is_success()
