@@ -47,6 +47,12 @@ void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int
 void launch_dict_count(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
                        const uint8_t *dict_validity, int64_t dict_offset, int64_t dict_length, CountAcc *acc, int n_cu,
                        hipStream_t stream);
+int dict_fuse_capacity(int64_t length, int64_t dict_length, int want_mult, int n_cu);
+void launch_dict_usage_fused(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
+                             int64_t dict_length, int want_mult, int n_patterns, const uint8_t *const *hits,
+                             unsigned long long *const *pattern_counters, const int32_t *null_is_valid, uint32_t *seen,
+                             uint32_t *twice, uint32_t *scratch, unsigned long long *d_counters, int n_cu,
+                             hipStream_t stream);
 size_t dict_usage_words(int64_t dict_length);
 size_t dict_usage_scratch_bytes(int64_t length, int64_t dict_length, int want_mult, int n_cu);
 void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
@@ -134,28 +140,41 @@ namespace tgx {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  bool owned = true;  // false: a slice of somebody else's allocation (borrow())
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) {
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), owned(o.owned) {
     o.p = nullptr;
     o.cap = 0;
+    o.owned = true;
   }
   DevBuf &operator=(DevBuf &&o) noexcept {
     if (this != &o) {
       release();
       p = o.p;
       cap = o.cap;
+      owned = o.owned;
       o.p = nullptr;
       o.cap = 0;
+      o.owned = true;
     }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    owned = true;
+  }
+  // a slice of a pool that outlives this object (the per-task counters of a state live in one allocation, so that
+  // finalize reads all of them back with ONE copy)
+  void borrow(void *ptr, size_t bytes) {
+    release();
+    p = ptr;
+    cap = bytes;
+    owned = false;
   }
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
@@ -205,6 +224,17 @@ struct DistinctState {
   DevBuf spare_seen, spare_twice;
 };
 
+// pattern checks of a dictionary column whose row gather rides on the column's DISTINCT pass (kernels/dict.hip)
+struct DictGather {
+  const uint8_t *hits;          // per-entry verdict bytes
+  unsigned long long *counters;  // counters[0] receives the matches
+  int32_t null_is_valid;
+};
+struct DictFuse {
+  std::map<int, int> capacity;                         // column -> pattern checks the fused pass can take
+  std::map<int, std::vector<DictGather>> by_column;    // filled by regex_update
+};
+
 struct ProfileEntry {
   double total_ms = 0;
   uint64_t launches = 0;
@@ -225,6 +255,7 @@ struct tgx_state {
 
   // device accumulators
   tgx::DevBuf d_scan_acc, d_count_acc, d_como_acc, d_pivots, d_pivot_set;
+  tgx::DevBuf d_distinct_counters;  // [distinct task][kNumDistinctCounters]: every DistinctState::counters is a slice
   // per-update scratch
   tgx::DevBuf d_scan_partials, d_count_blocks, d_como_partials;
   std::vector<std::unique_ptr<tgx::DevBuf>> staging;  // host columns copied to the device

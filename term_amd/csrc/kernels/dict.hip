@@ -10,6 +10,7 @@
 //                    referenced (saturating at 2, per-workgroup LDS histogram for small dictionaries);
 //                    dict_insert_kernel inserts the fingerprints of referenced entries into the state's set.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "device_types.h"
 #include "distinct_types.h"
@@ -94,6 +95,7 @@ __device__ __forceinline__ void dict_for_each_row(const DictRowsDesc &d, F &&f) 
 
 constexpr int kDictLdsWords = 32768;  // 128 KiB of LDS bitmaps: 1 Mi entries (one bitmap) or 512 Ki (two)
 constexpr int kDictThreads = 1024;    // one workgroup per CU, 16 waves
+constexpr int kDictMaxFused = 4;      // pattern checks that can ride on the DISTINCT pass of a column
 
 __device__ __forceinline__ void dict_block_add1024(unsigned long long a, unsigned long long *ga) {
 #pragma unroll
@@ -108,6 +110,20 @@ __device__ __forceinline__ void dict_block_add1024(unsigned long long a, unsigne
   }
 }
 
+// 32 per-entry verdict bytes (1 = match; 0 / 2 = not) -> one bitmap word.  `hits` is 16-byte aligned and padded by
+// 32 bytes (regex_device.cpp), so the two 16-byte loads of the last word stay inside the allocation.
+__device__ __forceinline__ uint32_t dict_pack_hits(const uint8_t *hits, uint32_t w, int64_t dict_length) {
+  typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+  const u64x2 *p = (const u64x2 *)(hits + 32ull * w);
+  const u64x2 a = p[0], b = p[1];
+  const unsigned long long ones = 0x0101010101010101ull, gather = 0x0102040810204080ull;
+  uint32_t m = (uint32_t)(((a.x & ones) * gather) >> 56) | (uint32_t)(((a.y & ones) * gather) >> 56) << 8 |
+               (uint32_t)(((b.x & ones) * gather) >> 56) << 16 | (uint32_t)(((b.y & ones) * gather) >> 56) << 24;
+  const int64_t left = dict_length - 32ll * w;
+  if (left < 32) m &= left <= 0 ? 0u : ((1u << left) - 1u);
+  return m;
+}
+
 // matches += hits[index] for valid rows (hit byte: 1 = entry matches, 2 = entry is NULL), null_is_valid for NULL
 // rows.  LDS: the per-entry verdicts as a bitmap in LDS (dictionaries without NULL values, <= 1 Mi entries), so
 // the per-row lookup is an LDS read instead of a scattered global byte load.
@@ -119,14 +135,8 @@ __global__ __launch_bounds__(kDictThreads) void dict_count_hits_kernel(DictRowsD
   global_u8_ptr h = (global_u8_ptr)(uintptr_t)hits;
   if (LDS) {
     const int64_t words = (d.dict_length + 31) >> 5;
-    for (int64_t w = threadIdx.x; w < words; w += kDictThreads) {
-      uint32_t m = 0;
-      for (int k = 0; k < 32; k++) {
-        const int64_t e = 32 * w + k;
-        if (e < d.dict_length && h[e] == 1) m |= 1u << k;
-      }
-      match_bits[w] = m;
-    }
+    for (int64_t w = threadIdx.x; w < words; w += kDictThreads)
+      match_bits[w] = dict_pack_hits(hits, (uint32_t)w, d.dict_length);
     __syncthreads();
   }
   unsigned long long matches = 0;
@@ -205,23 +215,98 @@ __global__ __launch_bounds__(kDictThreads) void dict_count_kernel(DictRowsDesc d
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)&acc->total, (unsigned long long)d.length);
 }
 
-// OR of the workgroups' slices; an entry is referenced twice if any workgroup saw it twice or two saw it at all
-__global__ __launch_bounds__(256) void dict_usage_reduce_kernel(const uint32_t *slices, uint32_t n_slices,
-                                                                 uint32_t words, int mult, uint32_t *seen,
-                                                                 uint32_t *twice) {
+// The fused row pass of a dictionary column that carries a DISTINCT check AND pattern / length checks: the indices
+// are read ONCE; the lane updates the workgroup's seen / twice bitmaps and looks its entry up in the per-entry
+// verdict bitmap of every pattern (all in LDS).  Per pattern, matches go to counters[k][0].
+struct DictFuseParams {
+  const uint8_t *hits[kDictMaxFused];         // per-entry verdict bytes (1 = match) of pattern k
+  unsigned long long *counters[kDictMaxFused];
+  int32_t null_is_valid[kDictMaxFused];
+  int32_t k;
+};
+
+template <bool MULT>
+__global__ __launch_bounds__(kDictThreads) void dict_fused_kernel(DictRowsDesc d, DictFuseParams f, uint32_t *slices,
+                                                                   unsigned long long *counters) {
+  __shared__ uint32_t bits[kDictLdsWords];
+  const uint32_t words = (uint32_t)((d.dict_length + 31) >> 5);
+  const uint32_t usage_words = (MULT ? 2u : 1u) * words;
+  uint32_t *l_seen = bits, *l_twice = bits + words, *l_hits = bits + usage_words;
+  for (uint32_t w = threadIdx.x; w < usage_words; w += kDictThreads) bits[w] = 0;
+  for (int k = 0; k < f.k; k++) {
+    for (uint32_t w = threadIdx.x; w < words; w += kDictThreads)
+      l_hits[(uint32_t)k * words + w] = dict_pack_hits(f.hits[k], w, d.dict_length);
+  }
+  __syncthreads();
+  unsigned long long n_valid = 0, matches[kDictMaxFused] = {0, 0, 0, 0};
+  dict_for_each_row(d, [&](int32_t e, bool valid) {
+    if (!valid) {
+#pragma unroll
+      for (int k = 0; k < kDictMaxFused; k++) matches[k] += (k < f.k && f.null_is_valid[k]) ? 1 : 0;
+      return;
+    }
+    if (e < 0 || e >= d.dict_length) return;  // malformed index: ignored (Arrow validates these)
+    n_valid++;
+    const uint32_t bit = 1u << (e & 31), w = (uint32_t)e >> 5;
+#pragma unroll
+    for (int k = 0; k < kDictMaxFused; k++)
+      if (k < f.k) matches[k] += (l_hits[(uint32_t)k * words + w] >> (e & 31)) & 1;
+    if (MULT) {
+      if (!(l_twice[w] & bit)) {
+        if (l_seen[w] & bit) {
+          atomicOr(&l_twice[w], bit);
+        } else {
+          const uint32_t prev = atomicOr(&l_seen[w], bit);
+          if (prev & bit) atomicOr(&l_twice[w], bit);
+        }
+      }
+    } else if (!(l_seen[w] & bit)) {
+      atomicOr(&l_seen[w], bit);
+    }
+  });
+  __syncthreads();
+  uint32_t *mine = slices + (size_t)blockIdx.x * usage_words;
+  for (uint32_t w = threadIdx.x; w < usage_words; w += kDictThreads) mine[w] = bits[w];
+  dict_block_add1024(n_valid, &counters[kCntValidRows]);
+  for (int k = 0; k < f.k; k++) {
+    __syncthreads();
+    dict_block_add1024(matches[k], &f.counters[k][0]);
+  }
+}
+
+// OR of the workgroups' slices; an entry is referenced twice if any workgroup saw it twice or two saw it at all.
+// A workgroup owns 64 words; its 16 waves split the slices (a single thread walking all 256 slices of a word was
+// 60 us of dependent-latency per column, whatever the dictionary size), then combine through LDS.
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void dict_usage_reduce_kernel(const uint32_t *slices, uint32_t n_slices,
+                                                                            uint32_t words, int mult, uint32_t *seen,
+                                                                            uint32_t *twice) {
+  __shared__ uint32_t part_seen[16][64], part_twice[16][64];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t w = blockIdx.x * 64 + lane;
   const uint32_t stride = (mult ? 2 : 1) * words;
-  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) {
-    uint32_t acc_seen = 0, acc_twice = 0;
-    for (uint32_t s2 = 0; s2 < n_slices; s2++) {
+  uint32_t acc_seen = 0, acc_twice = 0;
+  if (w < words) {
+#pragma unroll 4
+    for (uint32_t s2 = wave; s2 < n_slices; s2 += 16) {
       const uint32_t x = slices[(size_t)s2 * stride + w];
       if (mult) acc_twice |= (acc_seen & x) | slices[(size_t)s2 * stride + words + w];
+      acc_seen |= x;
+    }
+  }
+  part_seen[wave][lane] = acc_seen;
+  part_twice[wave][lane] = acc_twice;
+  __syncthreads();
+  if (wave == 0 && w < words) {
+    for (int k = 1; k < 16; k++) {
+      const uint32_t x = part_seen[k][lane];
+      acc_twice |= (acc_seen & x) | part_twice[k][lane];
       acc_seen |= x;
     }
     seen[w] = acc_seen;
     if (mult) twice[w] = acc_twice;
   }
 }
-
 static int dict_grid(int64_t n, int n_cu) {
   int64_t b = (n / 16 + kDictThreads - 1) / kDictThreads;  // 16 rows per thread per trip
   if (b < 1) b = 1;
@@ -249,6 +334,39 @@ void launch_dict_count(const int32_t *indices, const uint8_t *validity, int64_t 
   hipLaunchKernelGGL(dict_count_kernel, dim3(dict_grid(length, n_cu)), dim3(kDictThreads), 0, stream, d, acc);
 }
 
+// how many pattern checks (<= 4) fit next to the usage bitmaps in the fused pass; 0: not fusable
+int dict_fuse_capacity(int64_t length, int64_t dict_length, int want_mult, int n_cu) {
+  const size_t words = (size_t)((dict_length + 31) >> 5);
+  const size_t usage = words * (want_mult ? 2 : 1);
+  if (words == 0 || usage >= (size_t)kDictLdsWords) return 0;
+  const size_t k = ((size_t)kDictLdsWords - usage) / words;
+  return (int)(k > (size_t)kDictMaxFused ? (size_t)kDictMaxFused : k);
+}
+
+// launch_dict_usage with up to 4 pattern gathers riding on the same pass (see dict_fused_kernel)
+void launch_dict_usage_fused(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
+                             int64_t dict_length, int want_mult, int n_patterns, const uint8_t *const *hits,
+                             unsigned long long *const *pattern_counters, const int32_t *null_is_valid, uint32_t *seen,
+                             uint32_t *twice, uint32_t *scratch, unsigned long long *d_counters, int n_cu,
+                             hipStream_t stream) {
+  DictRowsDesc d{indices, validity, offset, length, nullptr, 0, dict_length};
+  DictFuseParams f;
+  memset(&f, 0, sizeof(f));
+  f.k = n_patterns;
+  for (int k = 0; k < n_patterns; k++) {
+    f.hits[k] = hits[k];
+    f.counters[k] = pattern_counters[k];
+    f.null_is_valid[k] = null_is_valid[k];
+  }
+  const int grid = dict_grid(length, n_cu);
+  if (want_mult)
+    hipLaunchKernelGGL(dict_fused_kernel<true>, dim3(grid), dim3(kDictThreads), 0, stream, d, f, scratch, d_counters);
+  else
+    hipLaunchKernelGGL(dict_fused_kernel<false>, dim3(grid), dim3(kDictThreads), 0, stream, d, f, scratch, d_counters);
+  const uint32_t words = (uint32_t)((dict_length + 31) >> 5);
+  hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 63) / 64), dim3(kReduceThreads), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
+}
+
 size_t dict_usage_words(int64_t dict_length) { return (size_t)((dict_length + 31) >> 5); }
 
 // scratch bytes launch_dict_usage needs for the per-workgroup slices (0: the global-atomics path is used)
@@ -274,8 +392,7 @@ void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t 
     else
       hipLaunchKernelGGL((dict_usage_kernel<true, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
     const uint32_t words = (uint32_t)dict_usage_words(dict_length);
-    hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256),
-                       dim3(256), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
+    hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 63) / 64), dim3(kReduceThreads), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
   } else {
     if (want_mult)
       hipLaunchKernelGGL((dict_usage_kernel<false, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);

@@ -38,6 +38,9 @@ struct RegexTaskState {
 };
 struct RegexState {
   std::vector<RegexTaskState> tasks;
+  DevBuf counter_pool;  // [task][2]: every RegexTaskState::counters is a slice, so results come back in ONE copy
+  std::vector<unsigned long long> fetched;  // host copy of the pool, valid while `fetched_ok` (inside one API call)
+  bool fetched_ok = false;
 };
 
 tgx_status rfail(tgx_error *err, tgx_status code, const char *fmt, ...) {
@@ -142,14 +145,16 @@ void regex_state_reset(tgx_state *st) {
   if (!rs) return;
   for (auto &t : rs->tasks) {
     t.h_total = t.h_matches = t.total = 0;
-    if (t.counters.p) (void)hipMemsetAsync(t.counters.p, 0, 8, st->stream);
   }
+  if (rs->counter_pool.p) (void)hipMemsetAsync(rs->counter_pool.p, 0, rs->tasks.size() * 16, st->stream);
+  rs->fetched_ok = false;
 }
 
-tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
+tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, DictFuse *fuse) {
   if (!st->plan->regex) return TGX_OK;
   const RegexPlan *rp = rplan(st->plan);
   RegexState *rs = rstate(st);
+  rs->fetched_ok = false;
   const int n_cu = tgx_num_cus();
   for (size_t i = 0; i < rp->tasks.size(); i++) {
     const RegexTask &t = rp->tasks[i];
@@ -160,9 +165,12 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
     if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && !is_dict && !is_view)
       return rfail(err, TGX_UNSUPPORTED, "%s needs a Utf8 column (column %d has type %d)",
                    t.is_length ? "LENGTH" : "REGEX_MATCH", t.column, c.type);
-    if (t.is_length && !ts.counters.p) {
-      RHIP(ts.counters.reserve(16));
-      RHIP(hipMemsetAsync(ts.counters.p, 0, 16, st->stream));  // ordered with the kernels of this (non-blocking) stream
+    if (!rs->counter_pool.p) {
+      RHIP(rs->counter_pool.reserve(rs->tasks.size() * 16));
+      // zero-filled on the state's (non-blocking) stream: ordered with the kernels that add to the counters
+      RHIP(hipMemsetAsync(rs->counter_pool.p, 0, rs->tasks.size() * 16, st->stream));
+      for (size_t k = 0; k < rs->tasks.size(); k++)
+        rs->tasks[k].counters.borrow((char *)rs->counter_pool.p + 16 * k, 16);
     }
     if (!t.is_length && !ts.table.p) {
       const rx::Dfa &d = t.dfa;
@@ -182,11 +190,9 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
       RHIP(ts.table.reserve(table.size() * sizeof(uint16_t) + 16));
       RHIP(ts.byte_class.reserve(256));
       RHIP(ts.accept_end.reserve(d.accept_at_end.size() + 16));
-      RHIP(ts.counters.reserve(16));
       RHIP(hipMemcpy(ts.table.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       RHIP(hipMemcpy(ts.byte_class.p, cls, 256, hipMemcpyHostToDevice));
       RHIP(hipMemcpy(ts.accept_end.p, d.accept_at_end.data(), d.accept_at_end.size(), hipMemcpyHostToDevice));
-      RHIP(hipMemsetAsync(ts.counters.p, 0, 16, st->stream));  // ordered with the kernels of this (non-blocking) stream
     }
     ts.total += (uint64_t)c.length;
     if (c.length == 0) continue;
@@ -231,10 +237,21 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
         else
           launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
       }
-      launch_dict_count_hits((const int32_t *)c.values, c.validity, c.offset, c.length, sc.length,
-                             sc.validity != nullptr, ts.dict_hits.as<uint8_t>(),
-                             (t.flags & TGX_FLAG_NULL_IS_VALID) != 0, ts.counters.as<unsigned long long>(), n_cu,
-                             st->stream);
+      bool fused = false;
+      if (fuse) {
+        auto cap = fuse->capacity.find(t.column);
+        if (cap != fuse->capacity.end() && (int)fuse->by_column[t.column].size() < cap->second) {
+          // the caller reads the indices once for this column: DISTINCT usage + this gather in one pass
+          fuse->by_column[t.column].push_back({ts.dict_hits.as<uint8_t>(), ts.counters.as<unsigned long long>(),
+                                               (t.flags & TGX_FLAG_NULL_IS_VALID) != 0});
+          fused = true;
+        }
+      }
+      if (!fused)
+        launch_dict_count_hits((const int32_t *)c.values, c.validity, c.offset, c.length, sc.length,
+                               sc.validity != nullptr, ts.dict_hits.as<uint8_t>(),
+                               (t.flags & TGX_FLAG_NULL_IS_VALID) != 0, ts.counters.as<unsigned long long>(), n_cu,
+                               st->stream);
     }
     if (st->profiling && e0 && e1) {
       (void)hipEventRecord(e1, st->stream);
@@ -246,10 +263,30 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
   return TGX_OK;
 }
 
+// One copy of every task's counters; regex_totals() then answers from the host copy until regex_fetch_end().
+// tgx_finalize / serialize / merge bracket their per-task loops with these (33 synchronous 8-byte copies were
+// 1 ms of a 31 ms step).
+tgx_status regex_fetch_begin(tgx_state *st, tgx_error *err) {
+  RegexState *rs = rstate(st);
+  if (!rs || !rs->counter_pool.p) return TGX_OK;
+  rs->fetched.resize(rs->tasks.size() * 2);
+  RHIP(hipStreamSynchronize(st->stream));
+  RHIP(hipMemcpy(rs->fetched.data(), rs->counter_pool.p, rs->tasks.size() * 16, hipMemcpyDeviceToHost));
+  rs->fetched_ok = true;
+  return TGX_OK;
+}
+
+void regex_fetch_end(tgx_state *st) {
+  if (rstate(st)) rstate(st)->fetched_ok = false;
+}
+
 static tgx_status regex_totals(tgx_state *st, size_t i, uint64_t *total, uint64_t *matches, tgx_error *err) {
-  RegexTaskState &ts = rstate(st)->tasks[i];
+  RegexState *rs = rstate(st);
+  RegexTaskState &ts = rs->tasks[i];
   unsigned long long dev_matches = 0;
-  if (ts.counters.p) {
+  if (rs->fetched_ok) {
+    dev_matches = rs->fetched[2 * i];
+  } else if (ts.counters.p) {
     RHIP(hipStreamSynchronize(st->stream));
     RHIP(hipMemcpy(&dev_matches, ts.counters.p, 8, hipMemcpyDeviceToHost));
   }
@@ -269,25 +306,37 @@ tgx_status regex_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *
 
 tgx_status regex_merge_states(tgx_state *dst, tgx_state *src, tgx_error *err) {
   if (!dst->regex) return TGX_OK;
+  tgx_status fs = regex_fetch_begin(src, err);
+  if (fs != TGX_OK) return fs;
   for (size_t i = 0; i < rstate(dst)->tasks.size(); i++) {
     uint64_t total = 0, matches = 0;
     tgx_status s = regex_totals(src, i, &total, &matches, err);
-    if (s != TGX_OK) return s;
+    if (s != TGX_OK) {
+      regex_fetch_end(src);
+      return s;
+    }
     rstate(dst)->tasks[i].h_total += total;
     rstate(dst)->tasks[i].h_matches += matches;
   }
+  regex_fetch_end(src);
   return TGX_OK;
 }
 
 tgx_status regex_serialize(tgx_state *st, size_t *len, uint8_t *buf, size_t cap, tgx_error *err) {
   if (!st->regex) return TGX_OK;
+  tgx_status fs = regex_fetch_begin(st, err);
+  if (fs != TGX_OK) return fs;
   for (size_t i = 0; i < rstate(st)->tasks.size(); i++) {
     uint64_t v[2] = {0, 0};
     tgx_status s = regex_totals(st, i, &v[0], &v[1], err);
-    if (s != TGX_OK) return s;
+    if (s != TGX_OK) {
+      regex_fetch_end(st);
+      return s;
+    }
     if (buf && *len + 16 <= cap) memcpy(buf + *len, v, 16);
     *len += 16;
   }
+  regex_fetch_end(st);
   return TGX_OK;
 }
 

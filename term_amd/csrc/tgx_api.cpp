@@ -380,9 +380,12 @@ static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
     HIP_TRY(st->d_como_acc.reserve(plan->como.size() * sizeof(ComomentAcc)));
     HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
   }
-  for (auto &d : st->distinct) {
-    HIP_TRY(d.counters.reserve(kNumDistinctCounters * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
+  if (!st->distinct.empty()) {
+    const size_t each = kNumDistinctCounters * sizeof(unsigned long long);
+    HIP_TRY(st->d_distinct_counters.reserve(st->distinct.size() * each));
+    HIP_TRY(hipMemsetAsync(st->d_distinct_counters.p, 0, st->distinct.size() * each, st->stream));
+    for (size_t i = 0; i < st->distinct.size(); i++)
+      st->distinct[i].counters.borrow((char *)st->d_distinct_counters.p + i * each, each);
   }
   st->device_ready = true;
   return TGX_OK;
@@ -469,9 +472,9 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
       HIP_TRY(hipMemsetAsync(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc), st->stream));
     if (!plan->como.empty())
       HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
-    for (auto &d : st->distinct)
-      if (d.counters.p)
-        HIP_TRY(hipMemsetAsync(d.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
+    if (st->d_distinct_counters.p)
+      HIP_TRY(hipMemsetAsync(st->d_distinct_counters.p, 0,
+                             st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long), st->stream));
   }
   return TGX_OK;
 }
@@ -839,7 +842,8 @@ static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_co
   return TGX_OK;
 }
 
-static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
+static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err,
+                                  const std::vector<DictGather> *gathers = nullptr) {
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
@@ -881,9 +885,25 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       HIP_TRY(hipMemsetAsync(ds.dict_usage.p, 0, 2 * uw * 4, st->stream));  // the global-atomics path accumulates
     uint32_t *u_seen = ds.dict_usage.as<uint32_t>(), *u_twice = u_seen + uw;
     ProfScope ps(st, "distinct", 0);
-    launch_dict_usage((const int32_t *)c.values, c.validity, c.offset, c.length, dict.validity, dict.offset,
-                      dict.length, mult ? 1 : 0, u_seen, u_twice, ds.dict_scratch.as<uint32_t>(),
-                      ds.counters.as<unsigned long long>(), g_ctx.n_cu, st->stream);
+    if (gathers && !gathers->empty() && scratch) {
+      // the column's pattern / length checks ride on this pass: the indices are read once
+      const uint8_t *hits[4];
+      unsigned long long *pc[4];
+      int32_t niv[4];
+      const int k = (int)std::min<size_t>(gathers->size(), 4);
+      for (int i = 0; i < k; i++) {
+        hits[i] = (*gathers)[i].hits;
+        pc[i] = (*gathers)[i].counters;
+        niv[i] = (*gathers)[i].null_is_valid;
+      }
+      launch_dict_usage_fused((const int32_t *)c.values, c.validity, c.offset, c.length, dict.length, mult ? 1 : 0, k,
+                              hits, pc, niv, u_seen, u_twice, ds.dict_scratch.as<uint32_t>(),
+                              ds.counters.as<unsigned long long>(), g_ctx.n_cu, st->stream);
+    } else {
+      launch_dict_usage((const int32_t *)c.values, c.validity, c.offset, c.length, dict.validity, dict.offset,
+                        dict.length, mult ? 1 : 0, u_seen, u_twice, ds.dict_scratch.as<uint32_t>(),
+                        ds.counters.as<unsigned long long>(), g_ctx.n_cu, st->stream);
+    }
     launch_dict_insert(dict.offsets, dict.data, dict.validity, dict.offset, dict.length,
                        dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, u_seen, u_twice, hash_view(ds),
                        ds.counters.as<unsigned long long>(), st->stream);
@@ -1266,16 +1286,37 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       }
     }
     // ---- exact distinct ----
+    // dictionary columns with a DISTINCT check and pattern / length checks: the patterns are matched on the
+    // dictionary ENTRIES first (regex_update), their per-row gathers then ride on the DISTINCT pass
+    DictFuse fuse;
+    for (size_t s = 0; s < plan->distinct.size(); s++) {
+      const DistinctTask &t = plan->distinct[s];
+      if (!t.tuple.empty()) continue;
+      const tgx_column &c = dev[t.column];
+      if (c.type != TGX_DICT32_UTF8 || c.length == 0 || c.dictionary->length == 0 || c.dictionary->validity) continue;
+      if (dict_usage_scratch_bytes(c.length, c.dictionary->length, t.multiplicity ? 1 : 0, g_ctx.n_cu) == 0) continue;
+      const int cap = dict_fuse_capacity(c.length, c.dictionary->length, t.multiplicity ? 1 : 0, g_ctx.n_cu);
+      if (cap > 0 && !fuse.capacity.count(t.column)) fuse.capacity[t.column] = cap;
+    }
+    TGX_TRY(regex_update(st, dev.data(), err, &fuse));
+    std::map<int, bool> fuse_done;
     for (size_t s = 0; s < plan->distinct.size(); s++)
-      if (plan->distinct[s].tuple.empty())
-        TGX_TRY(distinct_update(st, s, dev[plan->distinct[s].column], err));
-      else
+      if (plan->distinct[s].tuple.empty()) {
+        const int col = plan->distinct[s].column;
+        const std::vector<DictGather> *g = nullptr;
+        auto it = fuse.by_column.find(col);
+        if (it != fuse.by_column.end() && !fuse_done[col]) {
+          g = &it->second;
+          fuse_done[col] = true;
+        }
+        TGX_TRY(distinct_update(st, s, dev[col], err, g));
+      } else {
         TGX_TRY(distinct_tuple_update(st, s, dev.data(), err));
+      }
+    // (gathers handed out but not consumed -- cannot happen: every fusable column has exactly one DISTINCT task)
     // ---- KLL ----
     for (size_t s = 0; s < plan->kll.size(); s++)
       TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
-    // ---- regex ----
-    TGX_TRY(regex_update(st, dev.data(), err));
     // ---- Spearman: keep the pairs, rank at finalize ----
     TGX_TRY(spearman_update(st, dev.data(), err));
   }
@@ -1306,11 +1347,16 @@ struct Gathered {
 };
 }  // namespace
 
-static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t, tgx_error *err) {
+// `pre`: the counters of all tasks, already read back in one copy (gather); nullptr: read this task's now
+static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t, tgx_error *err,
+                                  const unsigned long long *pre = nullptr) {
   DistinctState &ds = st->distinct[slot];
   unsigned long long c[kNumDistinctCounters];
   memset(c, 0, sizeof(c));
-  if (st->device_ready) TGX_TRY(distinct_read_counters(st, ds, c, err));
+  if (pre)
+    memcpy(c, pre + slot * kNumDistinctCounters, sizeof(c));
+  else if (st->device_ready)
+    TGX_TRY(distinct_read_counters(st, ds, c, err));
   if (c[kCntOutOfRange] != 0)
     return fail(err, TGX_INTERNAL, "distinct: %llu keys fell outside the range bitmap", c[kCntOutOfRange]);
   const uint64_t empty_rows = c[kCntEmptyRows] + ds.h_empty_rows;
@@ -1350,7 +1396,14 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
       for (size_t i = 0; i < d.size(); i++) como_acc_merge(g->como[i], d[i]);
     }
   }
-  for (size_t i = 0; i < plan->distinct.size(); i++) TGX_TRY(distinct_totals(st, i, &g->distinct[i], err));
+  std::vector<unsigned long long> all;
+  if (st->device_ready && st->d_distinct_counters.p) {
+    all.resize(plan->distinct.size() * kNumDistinctCounters);
+    HIP_TRY(hipMemcpy(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+  }
+  for (size_t i = 0; i < plan->distinct.size(); i++)
+    TGX_TRY(distinct_totals(st, i, &g->distinct[i], err, all.empty() ? nullptr : all.data()));
   return TGX_OK;
 }
 
@@ -1405,6 +1458,11 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
     return fail(err, TGX_INVALID_ARGUMENT, "results has room for %zu of %zu specs", n_results, plan->specs.size());
   Gathered g;
   TGX_TRY(gather(st, &g, err));
+  struct FetchScope {  // pattern / length counters: one readback for all tasks, dropped on every way out
+    tgx_state *s;
+    ~FetchScope() { regex_fetch_end(s); }
+  } fetch_scope{st};
+  if (st->regex) TGX_TRY(regex_fetch_begin(st, err));
   for (size_t i = 0; i < plan->specs.size(); i++) {
     tgx_result *r = &results[i];
     memset(r, 0, sizeof(*r));
