@@ -3,16 +3,25 @@
 //   COUNT(CASE WHEN [TRIM(]c[)] ~ 'pat' [OR c IS NULL] THEN 1 END)      TG/constraints/format.rs:762-776
 //
 // The host compiles the pattern (Rust `regex` syntax, unanchored search, Unicode classes expanded to
-// UTF-8) into a byte DFA (regex/regex_compile.cpp).  One row per lane: the lane walks its value's bytes
-// through `state = table[state * n_classes + class[byte]]` with the table held in LDS (<= 48 KiB, else it
-// stays in global memory / L2), leaving early once the automaton has matched or died.  A wave takes 64
-// consecutive rows, whose value bytes are one contiguous span: the span is copied into LDS with coalesced
-// 16-byte loads and each lane then reads its own value from LDS as aligned 8-byte words (per-lane global loads
-// at a ~28-byte stride ran the kernel at 1.2 TB/s, the staged form at 2.3 TB/s); spans longer than 4 KiB fall
-// back to per-lane global reads.  Evaluating several patterns of one column in the same pass was tried and was
-// slower than one pass each (6.6 ms vs 4.6 ms for three patterns on 100 M rows): the per-byte dependent LDS
-// lookups, not the reads, bound the kernel.  Match counts are block-reduced: one atomic per block.
-#include <hip/hip_runtime.h>
+// UTF-8) into a byte DFA (regex/regex_compile.cpp).  Rows are walked one per lane, two rows per lane in lockstep:
+// `state = table[state][class[byte]]` with table and class table held in LDS (<= 32 KiB of table, else it stays in
+// global memory / L2).  A wave step takes 128 consecutive rows, whose value bytes are one contiguous span: the span
+// is copied into LDS with coalesced 16-byte loads and each lane reads its own values from there (per-lane global
+// loads at a ~28-byte stride ran the kernel at 1.2 TB/s, the staged form at 2.3 TB/s); spans longer than 4 KiB
+// fall back to per-lane global reads.  What the counters said, in the order it was found (100 M rows x 28 B):
+//   * ~10 VALU instructions per byte and chain (tests per byte, 64-bit shifts)            1.29 ms
+//   * prescaled table + absorbing final states + whole-chunk loop (Tbl, walk2_staged): 3-4 instructions per byte,
+//     but every chunk was an UNALIGNED ds_read_b64: 62 LDS cycles per wave instruction
+//     (SQ_LDS_UNALIGNED_STALL = 60 % of SQ_LDS_IDX_ACTIVE)                                  1.37 ms
+//   * chunks cut from aligned words (ChunkFeed)                                             1.02 ms
+//   * LDS sized per launch, grid = exactly the resident workgroups (7 per CU)              0.86-0.93 ms
+// VALU (~55 %), LDS (~45 %) and HBM (~65 % of the achievable rate) are now about equally loaded.  Evaluating
+// several patterns of one column in the same pass was tried earlier and was slower than one pass each.  Match
+// counts are block-reduced: one atomic per block.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "regex_types.h"
 
@@ -26,17 +35,45 @@ typedef const uint16_t __attribute__((address_space(1))) *global_u16_ptr;
 
 constexpr uint32_t kStageBytes = 4096;  // LDS staging per wave: 64 consecutive values up to 64 B on average
 
-// walks value bytes [b, e) (absolute offsets into `data`) through the automaton; STAGED means the bytes
-// [stage_base, ...) are already in LDS (16-byte aligned image of the wave's contiguous value span)
+// Table formats.  In global memory (DfaView) an entry is the next STATE (0 = dead, 1 = matched, both final).  The
+// copy a workgroup keeps in LDS is PRESCALED: an entry is the BYTE OFFSET of the next state's row (state x row
+// bytes), the class table holds class x 2, and the rows of the two final states are made absorbing -- so a step is
+// `bfe; add; ds_read_u16` with no test per byte (the walk was bound by instruction issue, ~10 VALU per byte, not by
+// HBM or LDS).  `Tbl` hides the difference; `term` is the largest final value (1, or one row).
+// LDS layout (dynamic allocation, FIXED offsets for everything a byte step touches, so the addresses fold into the
+// ds_read offset field): class table, the four waves' stages, then this automaton's table and accept flags.
+constexpr uint32_t kLdsClassOff = 0;                                       // u16[256] (class x 2) / u8[256]
+constexpr uint32_t kLdsStageOff = 512;                                     // 4 x (kStageBytes + 32)
+constexpr uint32_t kLdsTableOff = kLdsStageOff + 4 * (kStageBytes + 32);  // u16[n_states x n_classes]
+
+template <bool LDS_TABLE, bool DIRECT>
+struct Tbl {
+  const uint8_t *lds;  // base of the dynamic LDS allocation
+  global_u16_ptr g_table;
+  uint32_t ncls, row_bytes, start, term;
+  __device__ __forceinline__ uint32_t step(uint32_t st, uint32_t byte) const {
+    if (LDS_TABLE) {
+      // ABSOLUTE LDS addresses: the kernel has no static LDS, so its dynamic block starts at LDS address 0 (checked
+      // at kernel entry) and class / table offsets become the immediate offset of the ds_read -- through the
+      // `extern __shared__` symbol every lookup paid an extra add of the (link-time) base
+      typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
+      const uint32_t c2 = DIRECT ? byte << 1 : (uint32_t) * (lds_u16_ptr)(uintptr_t)(kLdsClassOff + (byte << 1));
+      return *(lds_u16_ptr)(uintptr_t)(kLdsTableOff + st + c2);
+    }
+    return g_table[st * ncls + lds[kLdsClassOff + byte]];
+  }
+  __device__ __forceinline__ uint32_t state_of(uint32_t st) const { return LDS_TABLE ? st / row_bytes : st; }
+};
+
+// walks value bytes [b, e) (absolute offsets into `data`) through the automaton, one aligned 8-byte word at a time
+// (a word that holds a byte of the buffer lies in the buffer's pages); STAGED means the bytes [stage_base, ...) are
+// already in LDS (16-byte aligned image of the wave's contiguous value span)
 template <bool LDS_TABLE, bool STAGED, bool DIRECT>
-__device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_table, const uint8_t *s_class,
-                                         uintptr_t data, int64_t b, int64_t e, const uint8_t *stage,
-                                         int64_t stage_base) {
-  global_u16_ptr g_table = (global_u16_ptr)(uintptr_t)dfa.table;
-  const uint32_t ncls = dfa.n_classes;
-  uint32_t st = dfa.start;
+__device__ __forceinline__ uint32_t walk(const Tbl<LDS_TABLE, DIRECT> &t, uintptr_t data, int64_t b, int64_t e,
+                                         const uint8_t *stage, int64_t stage_base) {
+  uint32_t st = t.start;
   int64_t p = b;
-  while (p < e && st > 1) {
+  while (p < e && st > t.term) {
     uint64_t word;
     if (STAGED) {
       word = *(const uint64_t *)(stage + ((p - stage_base) & ~(int64_t)7));
@@ -48,42 +85,26 @@ __device__ __forceinline__ uint32_t walk(const DfaView &dfa, const uint16_t *s_t
     uint32_t nb = 8 - skip;
     if (e - p < (int64_t)nb) nb = (uint32_t)(e - p);
     p += nb;
-    for (uint32_t k = 0; k < nb && st > 1; k++) {
-      // DIRECT: the table has one column per BYTE (small automata), so a step is one LDS lookup instead of two
-      const uint32_t c = DIRECT ? (uint32_t)(w & 0xFF) : s_class[w & 0xFF];
+    for (uint32_t k = 0; k < nb && st > t.term; k++) {
+      st = t.step(st, (uint32_t)(w & 0xFF));
       w >>= 8;
-      st = DIRECT ? s_table[(st << 8) + c] : LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
     }
   }
   return st;
 }
 
-// two values per lane walked in lockstep: the two chains of dependent LDS lookups interleave (the walk is bound by
-// lookup latency, not by issue), so the second value comes almost for free
-template <bool LDS_TABLE, bool STAGED, bool DIRECT>
-__device__ __forceinline__ void walk2(const DfaView &dfa, const uint16_t *s_table, const uint8_t *s_class,
-                                      uintptr_t data0, int64_t b0, int64_t e0, uintptr_t data1, int64_t b1,
-                                      int64_t e1, const uint8_t *stage, int64_t stage_base, uint32_t *out0,
-                                      uint32_t *out1) {
-  global_u16_ptr g_table = (global_u16_ptr)(uintptr_t)dfa.table;
-  const uint32_t ncls = dfa.n_classes;
-  uint32_t st0 = dfa.start, st1 = dfa.start;
+// two values per lane walked in lockstep from global memory (Utf8View rows, values that do not fit the stage)
+template <bool LDS_TABLE, bool DIRECT>
+__device__ __forceinline__ void walk2(const Tbl<LDS_TABLE, DIRECT> &t, uintptr_t data0, int64_t b0, int64_t e0,
+                                      uintptr_t data1, int64_t b1, int64_t e1, uint32_t *out0, uint32_t *out1) {
+  uint32_t st0 = t.start, st1 = t.start;
   int64_t p0 = b0, p1 = b1;
   auto load = [&](uintptr_t data, int64_t p, uint32_t *skip) -> uint64_t {
-    if (STAGED) {
-      *skip = (uint32_t)((p - stage_base) & 7);
-      return *(const uint64_t *)(stage + ((p - stage_base) & ~(int64_t)7));
-    }
     *skip = (uint32_t)((data + (uintptr_t)p) & 7);
     return *(global_u64_ptr)((data + (uintptr_t)p) & ~(uintptr_t)7);
   };
-  auto step = [&](uint32_t st, uint64_t &w) -> uint32_t {
-    const uint32_t c = DIRECT ? (uint32_t)(w & 0xFF) : s_class[w & 0xFF];
-    w >>= 8;
-    return DIRECT ? s_table[(st << 8) + c] : LDS_TABLE ? s_table[st * ncls + c] : g_table[st * ncls + c];
-  };
   for (;;) {
-    const bool a0 = p0 < e0 && st0 > 1, a1 = p1 < e1 && st1 > 1;
+    const bool a0 = p0 < e0 && st0 > t.term, a1 = p1 < e1 && st1 > t.term;
     if (!a0 && !a1) break;
     uint32_t skip0 = 0, skip1 = 0, nb0 = 0, nb1 = 0;
     uint64_t w0 = 0, w1 = 0;
@@ -101,36 +122,158 @@ __device__ __forceinline__ void walk2(const DfaView &dfa, const uint16_t *s_tabl
     }
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
-      if (k < nb0 && st0 > 1) st0 = step(st0, w0);
-      if (k < nb1 && st1 > 1) st1 = step(st1, w1);
+      if (k < nb0 && st0 > t.term) st0 = t.step(st0, (uint32_t)(w0 >> (8 * k)) & 0xFF);
+      if (k < nb1 && st1 > t.term) st1 = t.step(st1, (uint32_t)(w1 >> (8 * k)) & 0xFF);
     }
   }
   *out0 = st0;
   *out1 = st1;
 }
 
-// TABLE_ENTRIES: LDS budget of the transition table (0 = the table stays in global memory / L2).  The small
-// instance leaves room for 6 workgroups per CU, the large one for 3.
-template <int TABLE_ENTRIES, bool DIRECT = false, bool VIEW = false>
-__global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaView dfa,
+// The fast path: two STAGED values per lane, prescaled LDS table.  Value bytes are taken eight at a time from the
+// value's own start, so only a value's LAST chunk is partial: loop A runs the whole chunks with three or four
+// instructions per byte and chain (the final states absorb, a chain that is out of whole chunks is kept by a select
+// per chunk), loop B the 0..7 tail bytes with a select per byte.  Both chains always execute, interleaved -- no
+// divergent blocks inside the loop.
+// A chunk is cut out of ALIGNED 8-byte LDS words (one new word per chunk, funnel-shifted against the previous
+// one): an unaligned `ds_read_b64` is served lane by lane -- SQ_LDS_UNALIGNED_STALL showed 62 LDS cycles per such
+// wave instruction, 60 % of all LDS cycles of the kernel.  The stage has 32 bytes of slack for the read-ahead.
+struct ChunkFeed {
+  uint32_t a;       // LDS offset of the next aligned word
+  uint32_t s;       // byte shift of the value inside its first word (0..7)
+  uint32_t c0, c1;  // the current aligned word
+  __device__ __forceinline__ void start(const uint8_t *stage, uint32_t o) {
+    a = o & ~7u;
+    s = o & 7u;
+    const uint64_t w = *(const uint64_t *)(stage + a);
+    c0 = (uint32_t)w;
+    c1 = (uint32_t)(w >> 32);
+    a += 8;
+  }
+  // the next eight value bytes (lo, hi).  The feed always moves on -- a chain that has run out of whole chunks
+  // keeps reading (and discarding) what follows its value; `limit` keeps that inside the stage
+  __device__ __forceinline__ void next(const uint8_t *stage, uint32_t limit, uint32_t *lo, uint32_t *hi) {
+    const uint64_t w = *(const uint64_t *)(stage + a);
+    const uint32_t n0 = (uint32_t)w, n1 = (uint32_t)(w >> 32);
+    const bool up = (s & 4) != 0;
+    const uint32_t x0 = up ? c1 : c0, x1 = up ? n0 : c1, x2 = up ? n1 : n0;
+    *lo = __builtin_amdgcn_alignbyte(x1, x0, s);  // shift by s & 3 bytes
+    *hi = __builtin_amdgcn_alignbyte(x2, x1, s);
+    c0 = n0;
+    c1 = n1;
+    a = a + 8 < limit ? a + 8 : limit;
+  }
+};
+
+template <bool DIRECT>
+__device__ __forceinline__ void walk2_staged(const Tbl<true, DIRECT> &t, const uint8_t *stage, uint32_t o0,
+                                             uint32_t n0, uint32_t o1, uint32_t n1, uint32_t *out0, uint32_t *out1) {
+  uint32_t st0 = t.start, st1 = t.start;
+  const uint32_t full0 = n0 >> 3, full1 = n1 >> 3;
+  const uint32_t limit = kStageBytes + 16;  // last aligned word of the stage (+ 32 bytes of slack)
+  ChunkFeed f0, f1;
+  f0.start(stage, o0);
+  f1.start(stage, o1);
+  for (uint32_t it = 0;; it++) {  // `it` is wave-uniform
+    const bool a0 = it < full0, a1 = it < full1;
+    if (!((a0 && st0 > t.term) || (a1 && st1 > t.term))) break;
+    uint32_t l0, h0, l1, h1;
+    f0.next(stage, limit, &l0, &h0);
+    f1.next(stage, limit, &l1, &h1);
+    uint32_t x0 = st0, x1 = st1;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      x0 = t.step(x0, ((k < 4 ? l0 : h0) >> (8 * (k & 3))) & 0xFF);
+      x1 = t.step(x1, ((k < 4 ? l1 : h1) >> (8 * (k & 3))) & 0xFF);
+    }
+    st0 = a0 ? x0 : st0;
+    st1 = a1 ? x1 : st1;
+  }
+  // the 0..7 tail bytes of the chains that are still undecided (final states need no more input)
+  const uint32_t r0 = st0 > t.term ? n0 & 7 : 0, r1 = st1 > t.term ? n1 & 7 : 0;
+  uint32_t rmax = r0 > r1 ? r0 : r1;
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    const uint32_t o = __shfl_xor(rmax, dlt, 64);
+    rmax = o > rmax ? o : rmax;
+  }
+  rmax = __builtin_amdgcn_readfirstlane(rmax);
+  if (rmax) {
+    uint32_t l0, h0, l1, h1;
+    f0.start(stage, o0 + 8 * full0);
+    f1.start(stage, o1 + 8 * full1);
+    f0.next(stage, limit, &l0, &h0);
+    f1.next(stage, limit, &l1, &h1);
+#pragma unroll
+    for (uint32_t k = 0; k < 7; k++) {
+      if (k < rmax) {  // wave-uniform
+        const uint32_t x0 = t.step(st0, ((k < 4 ? l0 : h0) >> (8 * (k & 3))) & 0xFF);
+        const uint32_t x1 = t.step(st1, ((k < 4 ? l1 : h1) >> (8 * (k & 3))) & 0xFF);
+        st0 = k < r0 ? x0 : st0;
+        st1 = k < r1 ? x1 : st1;
+      }
+    }
+  }
+  *out0 = st0;
+  *out1 = st1;
+}
+
+// LDS_TABLE: the transition table lives in LDS (prescaled, see Tbl), else in global memory / L2.  LDS is sized per
+// launch (dynamic): stage + exactly this automaton's table, class table and accept flags -- the kernel hides the
+// latency of its per-step loads with resident waves only, so every workgroup that fits counts (5 instead of 6 per
+// CU cost 35 %): small automata run 8 workgroups per CU.
+struct RegexLds {
+  uint32_t accept_off, total;
+};
+static inline RegexLds regex_lds_layout(uint32_t n_states, uint32_t n_classes, bool lds_table) {
+  RegexLds l;
+  const uint32_t table_bytes = lds_table ? (n_states * n_classes * 2 + 15) / 16 * 16 : 0;
+  l.accept_off = kLdsTableOff + table_bytes;
+  l.total = (l.accept_off + (lds_table ? n_states : 0) + 15) / 16 * 16 + 32;  // + the block reduction's 4 x 8 B
+  return l;
+}
+
+template <bool LDS_TABLE, bool DIRECT = false, bool VIEW = false>
+__global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaView dfa, RegexLds lds,
                                                            unsigned long long *counters) {
-  constexpr bool LDS_TABLE = TABLE_ENTRIES > 0;
-  __shared__ uint16_t s_table[LDS_TABLE ? TABLE_ENTRIES : 1];
-  __shared__ uint8_t s_class[256];
-  __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kStageBytes + 32];
-  __shared__ unsigned long long s_part[4];
+  // no static LDS: the dynamic block then starts at LDS address 0 and the fixed offsets above are plain immediates
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  unsigned long long *const s_part = (unsigned long long *)(s_dyn + lds.total - 32);
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_dyn != 0) __builtin_trap();  // see Tbl::step
+  uint8_t *const s_stage0 = s_dyn + kLdsStageOff;
+  uint16_t *const s_table = (uint16_t *)(s_dyn + kLdsTableOff);
+  uint16_t *const s_class2 = (uint16_t *)(s_dyn + kLdsClassOff);
+  uint8_t *const s_class = s_dyn + kLdsClassOff;     // global-table instance: plain classes
+  uint8_t *const s_accept = s_dyn + lds.accept_off;  // accept-at-end flags: a row's verdict is one LDS read, not a
+                                                     // dependent global load at the end of every wave step
   const uint32_t n_entries = dfa.n_states * dfa.n_classes;
-  if (LDS_TABLE)
-    for (uint32_t i = threadIdx.x; i < n_entries; i += 256) s_table[i] = dfa.table[i];
-  s_class[threadIdx.x] = dfa.byte_class[threadIdx.x];
+  const uint32_t row_bytes = dfa.n_classes * 2;
+  if (LDS_TABLE) {
+    // prescaled copy (see Tbl): entry = byte offset of the next state's row; rows 0 (dead) and 1 (matched) absorb
+    for (uint32_t i = threadIdx.x; i < n_entries; i += 256) {
+      const uint32_t row = i / dfa.n_classes;
+      s_table[i] = (uint16_t)((row <= 1 ? row : (uint32_t)dfa.table[i]) * row_bytes);
+    }
+    s_class2[threadIdx.x] = (uint16_t)(dfa.byte_class[threadIdx.x] * 2u);
+    for (uint32_t i = threadIdx.x; i < dfa.n_states; i += 256) s_accept[i] = i == 1 ? 1 : dfa.accept_end[i];
+  } else {
+    s_class[threadIdx.x] = dfa.byte_class[threadIdx.x];
+  }
   __syncthreads();
+  Tbl<LDS_TABLE, DIRECT> tbl;
+  tbl.lds = s_dyn;
+  tbl.g_table = (global_u16_ptr)(uintptr_t)dfa.table;
+  tbl.ncls = dfa.n_classes;
+  tbl.row_bytes = row_bytes;
+  tbl.start = LDS_TABLE ? dfa.start * row_bytes : dfa.start;
+  tbl.term = LDS_TABLE ? row_bytes : 1;
   global_u8_ptr g_acc = (global_u8_ptr)(uintptr_t)dfa.accept_end;
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   const uintptr_t data0 = (uintptr_t)d.data;
   constexpr bool is_view = VIEW;  // Utf8View columns run their own instance: no data-dependent branches in the
                                   // offset path, so its loads are all issued before the first wait
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *stage = s_stage[wave];
+  uint8_t *stage = s_stage0 + wave * (kStageBytes + 32);
   unsigned long long matches = 0;
   // A wave step takes 128 consecutive rows, two per lane (rows `lane` and `lane + 64` of the step): twice the bytes
   // in flight for the same LDS, and the two values of a lane are walked in lockstep.  When the 128 values do not
@@ -245,9 +388,10 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     *wb = b;
     *we = e;
   };
-  auto account = [&](const Row &r, int64_t i, uint32_t st) {
+  auto account = [&](const Row &r, int64_t i, uint32_t st_raw) {
     if (r.valid) {
-      const bool hit = st == 1 || g_acc[st];
+      const uint32_t st = tbl.state_of(st_raw);
+      const bool hit = LDS_TABLE ? s_accept[st] != 0 : (st == 1 || g_acc[st]);
       matches += hit ? 1 : 0;
       if (d.hits) d.hits[i] = hit ? 1 : 0;
     } else if (r.in) {
@@ -270,7 +414,7 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     if (is_view) {
       bounds(r0, false, 0, &wb0, &we0);
       bounds(r1, false, 0, &wb1, &we1);
-      walk2<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, r0.data, wb0, we0, r1.data, wb1, we1, nullptr, 0, &st0, &st1);
+      walk2<LDS_TABLE, DIRECT>(tbl, r0.data, wb0, we0, r1.data, wb1, we1, &st0, &st1);
     } else {
       // the step's values are contiguous: [b of its first row, e of its last)
       const int64_t b_first = __shfl(r0.b, 0, 64), e_half = __shfl(r0.e, 63, 64), e_last = __shfl(r1.e, 63, 64);
@@ -279,21 +423,27 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
         stage_in(base, e_last);
         bounds(r0, true, base, &wb0, &we0);
         bounds(r1, true, base, &wb1, &we1);
-        walk2<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data0, wb0, we0, data0, wb1, we1, stage, base, &st0, &st1);
+        if constexpr (LDS_TABLE) {
+          walk2_staged<DIRECT>(tbl, stage, (uint32_t)(wb0 - base), (uint32_t)(we0 - wb0), (uint32_t)(wb1 - base),
+                               (uint32_t)(we1 - wb1), &st0, &st1);
+        } else {
+          st0 = walk<LDS_TABLE, true, DIRECT>(tbl, data0, wb0, we0, stage, base);
+          st1 = walk<LDS_TABLE, true, DIRECT>(tbl, data0, wb1, we1, stage, base);
+        }
         stage_done();
       } else {
         const bool fit0 = e_half - base <= (int64_t)kStageBytes;
         if (fit0) stage_in(base, e_half);
         bounds(r0, fit0, base, &wb0, &we0);
-        st0 = fit0 ? walk<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data0, wb0, we0, stage, base)
-                   : walk<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, data0, wb0, we0, nullptr, 0);
+        st0 = fit0 ? walk<LDS_TABLE, true, DIRECT>(tbl, data0, wb0, we0, stage, base)
+                   : walk<LDS_TABLE, false, DIRECT>(tbl, data0, wb0, we0, nullptr, 0);
         if (fit0) stage_done();
         const int64_t base1 = align16(__shfl(r1.b, 0, 64));
         const bool fit1 = e_last - base1 <= (int64_t)kStageBytes;
         if (fit1) stage_in(base1, e_last);
         bounds(r1, fit1, base1, &wb1, &we1);
-        st1 = fit1 ? walk<LDS_TABLE, true, DIRECT>(dfa, s_table, s_class, data0, wb1, we1, stage, base1)
-                   : walk<LDS_TABLE, false, DIRECT>(dfa, s_table, s_class, data0, wb1, we1, nullptr, 0);
+        st1 = fit1 ? walk<LDS_TABLE, true, DIRECT>(tbl, data0, wb1, we1, stage, base1)
+                   : walk<LDS_TABLE, false, DIRECT>(tbl, data0, wb1, we1, nullptr, 0);
         if (fit1) stage_done();
       }
     }
@@ -397,26 +547,43 @@ void launch_length(const RegexColDesc &d, const LengthBounds &lb, unsigned long 
 
 void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long *d_counters, int n_cu,
                   hipStream_t stream) {
-  int64_t blocks = (d.length + 511) / 512;  // 128 rows per wave step, four waves
-  if (blocks > (int64_t)n_cu * 6) blocks = (int64_t)n_cu * 6;
-  if (blocks < 1) blocks = 1;
   const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
-  const dim3 grid((int)blocks), block(256);
-#define TGX_RX(ENTRIES, DIRECT)                                                                                      \
-  do {                                                                                                               \
-    if (d.views)                                                                                                     \
-      hipLaunchKernelGGL((regex_match_kernel<ENTRIES, DIRECT, true>), grid, block, 0, stream, d, dfa, d_counters);   \
-    else                                                                                                             \
-      hipLaunchKernelGGL((regex_match_kernel<ENTRIES, DIRECT, false>), grid, block, 0, stream, d, dfa, d_counters);  \
+  const bool direct = dfa.n_classes == 256 && dfa.direct && entries <= 4096;
+  const bool in_lds = direct || entries <= kRegexLdsEntries;
+  const RegexLds lds = regex_lds_layout(dfa.n_states, dfa.n_classes, in_lds);
+  const bool view = d.views != nullptr;
+  // persistent grid: exactly the workgroups that stay resident (LDS, and 7 rather than 8 waves per SIMD at this
+  // kernel's 88 SGPRs / 66 VGPRs) -- one workgroup more than fit runs as a second round: 1.09 ms instead of 0.91 ms
+  auto resident = [&](auto kernel, int id) -> int64_t {
+    static std::mutex mu;
+    static std::map<std::pair<int, uint32_t>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({id, lds.total});
+    if (it != cache.end()) return it->second;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds.total) != hipSuccess || occ < 1) occ = 4;
+    // the occupancy API answers one workgroup too many for 256-thread kernels with 81..96 SGPRs (these instances
+    // have 88..91; 800 SGPRs per SIMD / (96 + 16) = 7 waves): MI355X_MICROARCH.md, "Correctness boundaries"
+    if (occ > 7) occ = 7;
+    cache[{id, lds.total}] = occ;
+    return occ;
+  };
+  int64_t max_blocks = (d.length + 511) / 512;  // 128 rows per wave step, four waves
+  if (max_blocks < 1) max_blocks = 1;
+  const dim3 block(256);
+#define TGX_RX(LDS, DIRECT, VIEW, ID)                                                                            \
+  do {                                                                                                           \
+    auto k = regex_match_kernel<LDS, DIRECT, VIEW>;                                                              \
+    const int64_t blocks = std::min<int64_t>(max_blocks, (int64_t)n_cu * resident(k, ID));                       \
+    hipLaunchKernelGGL(k, dim3((int)blocks), block, lds.total, stream, d, dfa, lds, d_counters);                 \
   } while (0)
-  if (dfa.n_classes == 256 && dfa.direct && entries <= 4096)
-    TGX_RX(4096, true);
-  else if (entries <= 4096)
-    TGX_RX(4096, false);
-  else if (entries <= kRegexLdsEntries)
-    TGX_RX((int)kRegexLdsEntries, false);
-  else
-    TGX_RX(0, false);
+  if (direct) {
+    if (view) TGX_RX(true, true, true, 0); else TGX_RX(true, true, false, 1);
+  } else if (in_lds) {
+    if (view) TGX_RX(true, false, true, 2); else TGX_RX(true, false, false, 3);
+  } else {
+    if (view) TGX_RX(false, false, true, 4); else TGX_RX(false, false, false, 5);
+  }
 #undef TGX_RX
 }
 
