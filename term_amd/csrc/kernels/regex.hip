@@ -18,6 +18,8 @@
 // VALU (~55 %), LDS (~45 %) and HBM (~65 % of the achievable rate) are now about equally loaded.  Evaluating
 // several patterns of one column in the same pass was tried earlier and was slower than one pass each.  Match
 // counts are block-reduced: one atomic per block.
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <map>
 #include <mutex>
