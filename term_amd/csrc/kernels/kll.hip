@@ -121,6 +121,31 @@ __device__ void compact_level0(KllDeviceSketch *s, double *buf, uint64_t salt) {
   insert_run(s, 1, buf, salt);
 }
 
+// the same with ONE barrier: the caller alternates between two `wave_tot` buffers from call to call (a wave that
+// runs ahead writes the other buffer; it cannot come round to this one again before everybody has passed the next
+// call's barrier, i.e. has finished reading here).  The barriers were the cost of phase A: 3 per 2048-row step ran
+// 2.13 ms per 1 G-row column, a fourth one 3.07 ms.
+__device__ __forceinline__ uint32_t block_exclusive_scan1(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kKllThreads / 64; w++) {
+    const uint32_t x = wave_tot[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
 // block-wide exclusive prefix sum of a small per-thread count; returns the total through *total
 __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,38 +170,52 @@ __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_
 constexpr int kKllRowsPerThread = 16;
 constexpr int kKllStepRows = kKllThreads * kKllRowsPerThread;  // 2048 rows per workgroup step
 
-// loads 8 rows per thread of the 2048-row step at `base` (row pairs base + 2 (t + 256 u) + {0, 1}: one
-// global_load_dwordx4 per pair when the buffer allows); returns the mask of rows that enter the sketch
-// (in range, non-NULL, not NaN: KllSketch::update drops NaN, kll_sketch.rs:197-199)
-__device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i64_ptr vals, global_u8_ptr vbits,
-                                                  int64_t base, int64_t r1, bool wide,
-                                                  double (&v)[kKllRowsPerThread]) {
+// The 16 rows a thread takes of the 2048-row step at `base` (row pairs base + 2 (t + 256 u) + {0, 1}: one
+// global_load_dwordx4 per pair when the buffer allows).  Split in two so that phase A can request the NEXT step's
+// rows before it works on the current ones: with two workgroups per CU (64 KiB ring) nothing else hides the load
+// latency -- unprefetched the kernel streamed at 3.1 TB/s.
+struct KllRaw {
+  int64_t bits[kKllRowsPerThread];
+  uint8_t vb[kKllRowsPerThread / 2];
+  bool fast;  // whole step, 16-byte aligned: `bits` (and `vb` when pair_bytes) are in flight
+};
+
+__device__ __forceinline__ void kll_issue(const KllColDesc &d, global_i64_ptr vals, global_u8_ptr vbits, int64_t base,
+                                          int64_t r1, bool wide, KllRaw &raw) {
   typedef long long i64x2 __attribute__((ext_vector_type(2)));
   typedef const i64x2 __attribute__((address_space(1))) *global_i64x2_ptr;
+  raw.fast = wide && base + kKllStepRows <= r1;
+  if (!raw.fast) return;
+  const bool pair_bytes = ((d.offset + base) & 1) == 0;  // both rows of a pair share a validity byte
+  if (vbits && pair_bytes) {
+#pragma unroll
+    for (int u = 0; u < kKllRowsPerThread / 2; u++)
+      raw.vb[u] = vbits[(d.offset + base + 2 * (threadIdx.x + u * kKllThreads)) >> 3];
+  }
+  global_i64x2_ptr pv = (global_i64x2_ptr)(vals + base) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < kKllRowsPerThread / 2; u++) {
+    const i64x2 x = __builtin_nontemporal_load(pv + u * kKllThreads);
+    raw.bits[2 * u] = x.x;
+    raw.bits[2 * u + 1] = x.y;
+  }
+}
+
+// values + the mask of rows that enter the sketch (in range, non-NULL, not NaN: KllSketch::update drops NaN,
+// kll_sketch.rs:197-199)
+__device__ __forceinline__ uint32_t kll_finish(const KllColDesc &d, global_i64_ptr vals, global_u8_ptr vbits,
+                                               int64_t base, int64_t r1, KllRaw &raw,
+                                               double (&v)[kKllRowsPerThread]) {
   uint32_t okm = 0;
-  int64_t bits[kKllRowsPerThread];
-  if (wide && base + kKllStepRows <= r1) {
-    uint8_t vb[kKllRowsPerThread / 2];
-    const bool pair_bytes = ((d.offset + base) & 1) == 0;  // both rows of a pair share a validity byte
-    if (vbits && pair_bytes) {
-#pragma unroll
-      for (int u = 0; u < kKllRowsPerThread / 2; u++)
-        vb[u] = vbits[(d.offset + base + 2 * (threadIdx.x + u * kKllThreads)) >> 3];
-    }
-    global_i64x2_ptr pv = (global_i64x2_ptr)(vals + base) + threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < kKllRowsPerThread / 2; u++) {
-      const i64x2 x = __builtin_nontemporal_load(pv + u * kKllThreads);
-      bits[2 * u] = x.x;
-      bits[2 * u + 1] = x.y;
-    }
+  if (raw.fast) {
+    const bool pair_bytes = ((d.offset + base) & 1) == 0;
     okm = (1u << kKllRowsPerThread) - 1u;
     if (vbits && pair_bytes) {
       okm = 0;
 #pragma unroll
       for (int u = 0; u < kKllRowsPerThread / 2; u++) {
         const int64_t b = d.offset + base + 2 * (threadIdx.x + u * kKllThreads);
-        okm |= (uint32_t)((vb[u] >> (b & 7)) & 3) << (2 * u);
+        okm |= (uint32_t)((raw.vb[u] >> (b & 7)) & 3) << (2 * u);
       }
     } else if (vbits) {
       okm = 0;
@@ -191,7 +230,7 @@ __device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i6
     for (int q = 0; q < kKllRowsPerThread; q++) {
       const int64_t i = base + 2 * (threadIdx.x + (q / 2) * kKllThreads) + (q & 1);
       bool ok = i < r1;
-      bits[q] = ok ? vals[i] : 0;
+      raw.bits[q] = ok ? vals[i] : 0;
       if (ok && vbits) {
         const int64_t b = d.offset + i;
         ok = (vbits[b >> 3] >> (b & 7)) & 1;
@@ -199,13 +238,25 @@ __device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i6
       okm |= (uint32_t)ok << q;
     }
   }
+  // rows that do not enter the sketch leave as NaN: min / max then need no test per value (v_min_f64 / v_max_f64
+  // return the other operand), and "enters the sketch" is x == x
+  const double nan = __longlong_as_double(0x7FF8000000000000LL);
 #pragma unroll
   for (int q = 0; q < kKllRowsPerThread; q++) {
-    const double x = d.is_float ? __longlong_as_double(bits[q]) : (double)bits[q];
+    double x = d.is_float ? __longlong_as_double(raw.bits[q]) : (double)raw.bits[q];
+    x = ((okm >> q) & 1) ? x : nan;
     if (!(x == x)) okm &= ~(1u << q);
     v[q] = x;
   }
   return okm;
+}
+
+__device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i64_ptr vals, global_u8_ptr vbits,
+                                                  int64_t base, int64_t r1, bool wide,
+                                                  double (&v)[kKllRowsPerThread]) {
+  KllRaw raw;
+  kll_issue(d, vals, vbits, base, r1, wide, raw);
+  return kll_finish(d, vals, vbits, base, r1, raw, v);
 }
 
 // One workgroup sketches rows [wg * chunk, (wg+1) * chunk) of the column into sketches[wg].
@@ -231,6 +282,8 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
   __shared__ double ring[8192];  // eight batches of sampled values: slot = sampled index & 8191 (a step brings <= 4)
   __shared__ double buf[1024];
   __shared__ uint32_t wave_tot[kKllThreads / 64];
+  __shared__ uint32_t wave_tot2[2][kKllThreads / 64];  // phase A's one-barrier scan alternates between the two
+  uint32_t step_parity = 0;
   __shared__ double red_min[kKllThreads / 64], red_max[kKllThreads / 64];
   KllDeviceSketch *s = sketches + blockIdx.x;
   const uint32_t t = threadIdx.x;
@@ -274,23 +327,50 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
   uint64_t consumed = 0, kb = 0;               // values seen so far / level-top batches flushed (uniform)
   int64_t tail_base = r0;                      // first step holding values past the last complete batch
   uint64_t tail_consumed = 0;                  // values before that step
+  KllRaw raw;
+  kll_issue(d, vals, vbits, r0, r1, wide, raw);
   for (int64_t base = r0; base < r1; base += kKllStepRows) {
     double v[kKllRowsPerThread];
-    const uint32_t okm = kll_load_step(d, vals, vbits, base, r1, wide, v);
+    const uint32_t okm = kll_finish(d, vals, vbits, base, r1, raw, v);
+    if (base + kKllStepRows < r1) kll_issue(d, vals, vbits, base + kKllStepRows, r1, wide, raw);  // in flight below
     uint32_t total;
-    uint64_t j = consumed + block_exclusive_scan(__builtin_popcount(okm), wave_tot, &total);
+    uint64_t j = consumed + block_exclusive_scan1(__builtin_popcount(okm), wave_tot2[step_parity], &total);
+    step_parity ^= 1;
+    if (top >= 4) {
+      // a thread's <= 16 values are consecutive in j, so they lie in at most two level-top groups: two picks
+      // (two 64-bit hashes) per step instead of one per value; positions are compared as 32-bit offsets from the
+      // thread's first one.  The loop was the kernel's bound (35 VALU instructions per value at two waves per
+      // SIMD): no branch per value, NaN-ignoring min / max (kll_finish).
+      const uint64_t g0 = j >> top;
+      const uint64_t d0 = (g0 << top) + pick_of(top, 0, g0) - j;            // < 16: the pick of g0 is one of ours
+      const uint64_t d1 = ((g0 + 1) << top) + pick_of(top, 0, g0 + 1) - j;  // < 16: the pick of g0 + 1 is
+      const uint32_t w0 = d0 < 64 ? (uint32_t)d0 : 64u, w1 = d1 < 64 ? (uint32_t)d1 : 64u;
+      uint32_t jr = 0;
 #pragma unroll
-    for (int u = 0; u < kKllRowsPerThread; u++) {
-      if (!((okm >> u) & 1)) continue;
-      mn = v[u] < mn ? v[u] : mn;
-      mx = v[u] > mx ? v[u] : mx;
-      const uint64_t g = j >> top;
-      if ((j & ((1ull << top) - 1)) == pick_of(top, 0, g)) ring[g & 8191] = v[u];
-      j++;
+      for (int u = 0; u < kKllRowsPerThread; u++) {
+        const uint32_t ok = (okm >> u) & 1;
+        mn = __builtin_fmin(mn, v[u]);
+        mx = __builtin_fmax(mx, v[u]);
+        if (ok && jr == w0) ring[g0 & 8191] = v[u];
+        if (ok && jr == w1) ring[(g0 + 1) & 8191] = v[u];
+        jr += ok;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kKllRowsPerThread; u++) {
+        if (!((okm >> u) & 1)) continue;
+        mn = v[u] < mn ? v[u] : mn;
+        mx = v[u] > mx ? v[u] : mx;
+        const uint64_t g = j >> top;
+        if ((j & ((1ull << top) - 1)) == pick_of(top, 0, g)) ring[g & 8191] = v[u];
+        j++;
+      }
     }
     const uint64_t before = consumed;
     consumed += total;
-    __syncthreads();
+    // (the picks of batch kb must be in the ring before it is flushed; no other step-to-step hazard: the scan
+    // alternates its buffers, and ring slots are reused eight batches later, with this barrier in between)
+    if (consumed >= (kb + 1) * top_items) __syncthreads();
     while (consumed >= (kb + 1) * top_items) {  // uniform: every pick of batch kb has been written
       flush_batch(kb, top);
       kb++;
@@ -453,6 +533,8 @@ void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDevice
   // sampling level: 2^top ~ rows / 2^22 (none below 8 M rows), see kll_build_kernel
   uint32_t top = 0;
   while (top < 16 && (d.length >> (23 + top)) > 0) top++;
+  // (measured on 1 G rows, 1024 workgroups: top - 1 / - 2 / - 3 = 2.39 / 2.92 / 3.87 ms instead of 2.10 -- a flush
+  // (sort of 1024 + insert) costs ~35 us per workgroup; top + 2 / + 4 = 3.36 / 4.97 ms -- the tail re-read of phase B)
   hipLaunchKernelGGL(kll_build_kernel, dim3(groups), dim3(kKllThreads), 0, stream, d, chunk, sketches,
                      salt, top);
   for (int stride = 1; stride < groups; stride <<= 1) {
