@@ -1280,7 +1280,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
           L.acc_index[k] = index[c0 + k];
         }
         int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (nrows + 256 * 16 - 1) / (256 * 16)),
-                                            std::max(32, (g_ctx.n_cu * 8) / n));
+                                            std::max(32, (g_ctx.n_cu * 12) / n));  // 4/5/6/8/12 per CU: 6.8/6.4/6.2/6.5/6.0 ms (2 pairs, 1 G rows)
         HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
         ProfScope ps(st, "comoments", bytes * n / descs.size());
         launch_comoments(L, n, blocks, st->d_como_partials.p, st->d_como_acc.as<ComomentAcc>(), st->stream);
