@@ -938,9 +938,13 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     ds.mode = DistinctMode::kHash;
   } else if (c.type == TGX_INT64 && (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap)) {
     ScanAcc acc;
-    HIP_TRY(hipMemcpyAsync(&acc, st->d_scan_acc.as<ScanAcc>() + task.scan_slot, sizeof(ScanAcc),
-                           hipMemcpyDeviceToHost, st->stream));
-    HIP_TRY(hipStreamSynchronize(st->stream));
+    if (st->scan_snapshot_valid) {
+      acc = st->scan_snapshot[task.scan_slot];  // read back once for all DISTINCT columns of this update
+    } else {
+      HIP_TRY(hipMemcpyAsync(&acc, st->d_scan_acc.as<ScanAcc>() + task.scan_slot, sizeof(ScanAcc),
+                             hipMemcpyDeviceToHost, st->stream));
+      HIP_TRY(hipStreamSynchronize(st->stream));
+    }
     if (acc.non_null > 0) {
       have_range = true;
       lo = acc.min_k;
@@ -1300,6 +1304,32 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       if (cap > 0 && !fuse.capacity.count(t.column)) fuse.capacity[t.column] = cap;
     }
     TGX_TRY(regex_update(st, dev.data(), err, &fuse));
+    {
+      // Int64 columns decide bitmap vs hash from the running MIN / MAX of the scan: with several such columns the
+      // accumulators come back in ONE copy and one stream synchronisation instead of one per column
+      int need = 0;
+      for (size_t s = 0; s < plan->distinct.size(); s++) {
+        const DistinctTask &t = plan->distinct[s];
+        if (!t.tuple.empty()) continue;
+        const tgx_column &c = dev[t.column];
+        const DistinctState &ds = st->distinct[s];
+        if (c.type != TGX_INT64 || c.length == 0 || ds.has_hint) continue;
+        if (ds.mode == DistinctMode::kUndecided && c.length < (1 << 16)) continue;
+        if (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap) need++;
+      }
+      st->scan_snapshot_valid = false;
+      if (need >= 2 && !plan->scan.empty()) {
+        st->scan_snapshot.resize(plan->scan.size());
+        HIP_TRY(hipMemcpyAsync(st->scan_snapshot.data(), st->d_scan_acc.p, plan->scan.size() * sizeof(ScanAcc),
+                               hipMemcpyDeviceToHost, st->stream));
+        HIP_TRY(hipStreamSynchronize(st->stream));
+        st->scan_snapshot_valid = true;
+      }
+    }
+    struct SnapshotScope {
+      tgx_state *s;
+      ~SnapshotScope() { s->scan_snapshot_valid = false; }
+    } snapshot_scope{st};
     std::map<int, bool> fuse_done;
     for (size_t s = 0; s < plan->distinct.size(); s++)
       if (plan->distinct[s].tuple.empty()) {
