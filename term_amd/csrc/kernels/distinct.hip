@@ -500,7 +500,8 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
   } else {
   const uint32_t *list = p.lists + (uint64_t)b * p.cap;
   // lists are made of 16-slot aligned runs, so cnt is a multiple of 4; kListPad slots are filler
-  // four 16-byte loads in flight per lane before the first LDS atomic
+  // four 16-byte loads in flight per lane before the first LDS atomic (requesting the NEXT four before the atomics
+  // of the current ones -- the pipeline that pays in dict.hip / kll.hip -- measured 1.01 ms instead of 0.93 here)
   constexpr uint64_t kStep = (uint64_t)kPartitionThreads * 4;
   for (uint64_t i0 = (uint64_t)tid * 4; i0 < cnt; i0 += 4 * kStep) {
     uint4 k4[4];
