@@ -175,3 +175,35 @@ def test_dictionary_beyond_the_lds_budget(mult):
     assert (res[3].total, res[3].non_null) == (n, int(live.sum()))  # COUNT: Arrow's logical nulls
     res, _, _ = run_plan([spec(T.COUNT, 0)], [[col]])  # COUNT alone (no DISTINCT to lean on)
     assert (res[0].total, res[0].non_null) == (n, int(live.sum()))
+
+
+@pytest.mark.parametrize("mult", [False, True])
+@pytest.mark.parametrize("n,card", [(70_000, 50), (300_000, 40_000)])
+def test_many_checks_ride_on_the_distinct_pass(n, card, mult):
+    """A dictionary column with a DISTINCT check and SIX pattern / length checks: up to four gathers are fused into the
+    usage pass (kernels/dict.hip: dict_fused_kernel), the rest run on their own -- every count as on the plain column,
+    over two batches with different dictionaries."""
+    rng = np.random.default_rng(n * 3 + card + int(mult))
+    vals = make_strings(rng, n, card)
+    pats = [(EMAIL, 0), (r"@", T.FLAG_NULL_IS_VALID), (r"^[a-z]", T.FLAG_CASE_INSENSITIVE), (r"\d\d", T.FLAG_TRIM),
+            (r"com$", T.FLAG_TRIM | T.FLAG_NULL_IS_VALID)]
+    specs = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY if mult else 0)]
+    specs += [spec(T.REGEX_MATCH, 0, flags=f, pattern=p) for p, f in pats]
+    specs += [spec(T.LENGTH, 0, length_min=3, length_max=20), spec(T.COUNT, 0)]
+    half = n // 2
+    batches = [[encode(vals[:half], rng, extra_entries=["zz@zz.com"], repeat_entries=True)],
+               [encode(vals[half:], rng, repeat_entries=False)]]
+    res, _, _ = run_plan(specs, batches)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want_d = orc.distinct_utf8(offs, data, validity)
+    assert res[0].distinct == want_d.distinct and res[0].non_null == want_d.non_null
+    if mult:
+        check(res[0], want_d)
+    for r, (p, f) in zip(res[1:], pats):
+        rx = orc.Regex(p, case_insensitive=bool(f & T.FLAG_CASE_INSENSITIVE))
+        want = rx.count_utf8(offs, data, validity, trim=bool(f & T.FLAG_TRIM),
+                             null_is_valid=bool(f & T.FLAG_NULL_IS_VALID)).matches
+        assert (r.total, r.matches) == (n, want), p
+    want_len = orc.length_count_utf8(offs, data, validity, min_chars=3, max_chars=20).matches
+    assert (res[6].total, res[6].matches) == (n, want_len)
+    assert (res[7].total, res[7].non_null) == (n, want_d.non_null)
