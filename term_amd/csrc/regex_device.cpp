@@ -175,8 +175,8 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, Di
     if (!t.is_length && !ts.table.p) {
       const rx::Dfa &d = t.dfa;
       // tiny automata (<= 16 states) travel with one table column per BYTE: one LDS lookup per input byte instead
-      // of class + transition (the kernel is bound by those lookups, not by HBM).  Only while the table still fits
-      // the 8 KiB instance: a byte-indexed 32 KiB table halves the workgroups per CU and ran 1.6x SLOWER.
+      // of class + transition.  Only while the table stays small (8 KiB): the kernel hides its load latency with
+      // resident workgroups (7 per CU at <= 22 KiB of LDS each), and a byte-indexed 32 KiB table ran 1.6x SLOWER.
       ts.direct = (uint64_t)d.n_states * 256 <= 4096;
       std::vector<uint16_t> table = d.table;
       uint8_t cls[256];
