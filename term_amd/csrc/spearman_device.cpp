@@ -28,6 +28,10 @@ struct SpearmanTaskState {
 };
 struct SpearmanState {
   std::vector<SpearmanTaskState> tasks;
+  // work buffers of the ranking (sorted keys, permutation, run heads, ranks, sort scratch): 40 bytes per pair, shared by
+  // the tasks (they are ranked one after the other) and kept between calls -- allocating and freeing them inside
+  // every fill_result was 160 ms of a 188 ms step at 100 M rows (hipMalloc / hipFree of 4.4 GB)
+  DevBuf keys_sorted, idx, idx_sorted, heads, rx, ry, temp, partials;
 };
 
 tgx_status sfail(tgx_error *err, tgx_status code, const char *fmt, ...) {
@@ -165,7 +169,9 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   r->non_null = (int64_t)m;
   if (m == 0) return TGX_OK;
   if (m > 0xFFFFFFF0ull) return sfail(err, TGX_UNSUPPORTED, "SPEARMAN over more than 2^32 rows is not supported");
-  DevBuf keys_sorted, idx, idx_sorted, heads, rx, ry, temp, partials;
+  SpearmanState *ws = sstate(st);
+  DevBuf &keys_sorted = ws->keys_sorted, &idx = ws->idx, &idx_sorted = ws->idx_sorted, &heads = ws->heads,
+         &rx = ws->rx, &ry = ws->ry, &temp = ws->temp, &partials = ws->partials;
   SHIP(keys_sorted.reserve(m * 8));
   SHIP(idx.reserve(m * 4));
   SHIP(idx_sorted.reserve(m * 4));
