@@ -28,7 +28,10 @@ __device__ __forceinline__ uint64_t sort_key(int64_t bits, int is_float) {
   return (uint64_t)k ^ 0x8000000000000000ULL;  // signed total order -> unsigned radix order
 }
 
-// appends the (x, y) sort keys of rows where both sides are non-NULL; *count is the running pair count
+// appends the (x, y) sort keys of rows where both sides are non-NULL; *count is the running pair count.
+// A workgroup takes 2048 consecutive rows per trip, eight per thread: one global atomic (and three barriers) per 2048
+// rows -- with 256 rows per trip the kernel ran at 0.7 TB/s, bound by the latency of that atomic.
+constexpr int kCompactRows = 8;
 __global__ __launch_bounds__(256) void spearman_compact_kernel(ComomentColDesc d, uint64_t *kx, uint64_t *ky,
                                                                 unsigned long long *count) {
   global_i64_ptr x = (global_i64_ptr)(uintptr_t)((const int64_t *)d.x + d.xoff);
@@ -38,27 +41,44 @@ __global__ __launch_bounds__(256) void spearman_compact_kernel(ComomentColDesc d
   __shared__ unsigned long long block_base;
   __shared__ uint32_t wave_cnt[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t step = (int64_t)gridDim.x * 256;
+  constexpr int64_t kTrip = 256 * kCompactRows;
+  const int64_t step = (int64_t)gridDim.x * kTrip;
   const int64_t rounded = (d.length + step - 1) / step * step;
-  for (int64_t base = (int64_t)blockIdx.x * 256; base < rounded; base += step) {
-    const int64_t i = base + threadIdx.x;
-    bool ok = i < d.length;
-    if (ok && xv) ok = (xv[(d.xoff + i) >> 3] >> ((d.xoff + i) & 7)) & 1;
-    if (ok && yv) ok = (yv[(d.yoff + i) >> 3] >> ((d.yoff + i) & 7)) & 1;
-    const unsigned long long ballot = __ballot(ok);
-    const uint32_t before = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(ballot);
+  for (int64_t base = (int64_t)blockIdx.x * kTrip; base < rounded; base += step) {
+    uint32_t okm = 0;
+    int64_t vx[kCompactRows], vy[kCompactRows];
+#pragma unroll
+    for (int u = 0; u < kCompactRows; u++) {
+      const int64_t i = base + u * 256 + threadIdx.x;  // coalesced; the order of the pairs does not matter
+      bool ok = i < d.length;
+      if (ok && xv) ok = (xv[(d.xoff + i) >> 3] >> ((d.xoff + i) & 7)) & 1;
+      if (ok && yv) ok = (yv[(d.yoff + i) >> 3] >> ((d.yoff + i) & 7)) & 1;
+      vx[u] = i < d.length ? x[i] : 0;
+      vy[u] = i < d.length ? y[i] : 0;
+      okm |= (uint32_t)ok << u;
+    }
+    const uint32_t mine = __builtin_popcount(okm);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t up = __shfl_up(incl, dlt, 64);
+      if (lane >= (uint32_t)dlt) incl += up;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
       block_base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
     }
     __syncthreads();
-    if (ok) {
-      uint32_t off = before;
-      for (uint32_t w = 0; w < wave; w++) off += wave_cnt[w];
-      kx[block_base + off] = sort_key(x[i], d.x_is_float);
-      ky[block_base + off] = sort_key(y[i], d.y_is_float);
+    uint64_t off = block_base + incl - mine;
+    for (uint32_t w = 0; w < wave; w++) off += wave_cnt[w];
+#pragma unroll
+    for (int u = 0; u < kCompactRows; u++) {
+      if (!((okm >> u) & 1)) continue;
+      kx[off] = sort_key(vx[u], d.x_is_float);
+      ky[off] = sort_key(vy[u], d.y_is_float);
+      off++;
     }
     __syncthreads();
   }
