@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=100_000_000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--view", action="store_true", help="hold the column as Utf8View (16-byte views + one data buffer)")
     args = ap.parse_args()
     import torch
     import term_amd as T
@@ -52,6 +53,15 @@ def main():
     offsets, data, validity, L, expect = make_column(torch, args.rows)
     col = T.Column(T.LARGE_UTF8, args.rows, offsets=offsets, data=data, validity=validity)
     alg_bytes = args.rows * (8 + L) + args.rows // 8
+    if args.view:
+        # Utf8View (DataFusion's default string layout since 43): {len, 4-byte prefix, buffer index, offset} per row
+        n = args.rows
+        views = torch.zeros(n, 4, dtype=torch.int32, device="cuda")
+        views[:, 0] = L
+        views[:, 1] = data[: n * L].view(n, L)[:, :4].contiguous().view(torch.int32).view(n)
+        views[:, 3] = (torch.arange(n, dtype=torch.int64, device="cuda") * L).to(torch.int32)
+        col = T.Column.utf8_view(views.view(torch.uint8).view(-1), [data], validity=validity, length=n)
+        alg_bytes = args.rows * (16 + L) + args.rows // 8
     sets = {"contains '@'": [r"@"], "simple e-mail": [r"^[^@]+@[^@]+\.[^@]+$"], "FormatType::Email": [EMAIL],
             "all three": [r"@", r"^[^@]+@[^@]+\.[^@]+$", EMAIL]}
     for name, pats in sets.items():
