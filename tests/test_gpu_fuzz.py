@@ -1,6 +1,8 @@
 """-m gpu: seeded differential runs -- random tables, random batch cuts and Arrow offsets, random mixes of checks in
 ONE plan, device and host buffers, states reused across tgx_state_reset -- against the oracle on the whole table.
 Integer results bit-exact; float aggregates within 1e-9 relative (north-star bar: 1e-6)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -33,7 +35,7 @@ def random_column(rng, n, kind):
     return v, mask
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TGX_FUZZ_SEEDS", "24"))))
 def test_random_plans_against_the_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 63, 64, 65, 1000, 8191, 50_000, 300_000, 1_300_000]))
@@ -87,7 +89,10 @@ def test_random_plans_against_the_oracle(seed):
                     if np.isfinite(want.sum_hi):
                         assert rel_err(r.sum_f, want.sum_hi) < 1e-9 and rel_err(r.mean, want.mean) < 1e-9
                     else:
-                        assert orc.nan_equal(r.sum_f, want.sum_hi)
+                        # a Float64 SUM whose running value overflows is order dependent (DataFusion adds per-batch SIMD
+                        # partial sums, the oracle adds row by row, the GPU adds per-workgroup partials): +-inf in one
+                        # order can be -+inf or NaN (inf - inf) in another.  What is pinned: the sum is not finite.
+                        assert not np.isfinite(r.sum_f)
                 if (s_.flags & T.FLAG_VARIANCE) and want.has_variance and np.isfinite(want.var_samp):
                     assert bool(r.has_variance)
                     assert rel_err(r.var_samp, want.var_samp) < 1e-6 or abs(r.var_samp - want.var_samp) < 1e-300
@@ -131,7 +136,7 @@ def random_strings(rng, n):
     return out
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TGX_FUZZ_STRING_SEEDS", "16"))))
 def test_random_string_plans_against_the_oracle(seed):
     from test_gpu_dictionary import encode
     from test_gpu_regex import utf8_column
