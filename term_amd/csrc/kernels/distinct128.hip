@@ -80,21 +80,29 @@ __device__ __forceinline__ void block_add2w(unsigned long long a, unsigned long 
 // returns 1 if (a, b) was new; *became_dup = 1 if this insert marks the key as seen twice
 __device__ __forceinline__ int hash_insert128(const HashSetView &t, uint64_t a, uint64_t b, int want_mult,
                                               int weight_two, int *became_dup) {
+  // ONE read-modify-write per new key: the CAS on the first word claims the slot, the owner then publishes the
+  // second word with a plain (device-scope) store.  Every atomic is executed at the memory side as a 64-byte
+  // read-modify-write -- with a CAS on each word the kernel wrote 142 bytes per inserted key.
+  // A lane that meets its own first word in a slot whose second word is not there yet goes round the probe loop
+  // again WITHOUT moving on (no nested spin: the owner may be a lane of the same wave, which publishes in this same
+  // loop body before the wave comes round).
   uint64_t h = a & t.mask;
   for (;;) {
     unsigned long long *w0 = (unsigned long long *)&t.keys[2 * h];
     unsigned long long *w1 = w0 + 1;
     const unsigned long long old0 = atomicCAS(w0, (unsigned long long)kEmptyKey, (unsigned long long)a);
-    if (old0 == kEmptyKey || old0 == a) {
-      const unsigned long long old1 = atomicCAS(w1, (unsigned long long)kEmptyKey, (unsigned long long)b);
-      const uint32_t bit = 1u << (h & 31);
-      if (old1 == kEmptyKey) {
-        if (want_mult && weight_two) {
-          const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
-          *became_dup = (prev & bit) ? 0 : 1;
-        }
-        return 1;
+    const uint32_t bit = 1u << (h & 31);
+    if (old0 == kEmptyKey) {
+      __hip_atomic_store(w1, (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (want_mult && weight_two) {
+        const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
+        *became_dup = (prev & bit) ? 0 : 1;
       }
+      return 1;
+    }
+    if (old0 == a) {
+      const unsigned long long old1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old1 == kEmptyKey) continue;  // claimed, second word on its way: look at this slot again
       if (old1 == b) {
         if (want_mult) {
           if (!(__hip_atomic_load(&t.dup[h >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
