@@ -8,6 +8,7 @@
  *   {"name": "...", "table_name": "data", "checks": [{"name": "...", "level": "error|warning|info",
  *     "constraints": [
  *       {"type": "size", "assertion": A},
+ *       {"type": "approx_count_distinct", "column": "c", "assertion": A},   (metric: the exact distinct count)
  *       {"type": "completeness", "columns": ["c", ...], "operator": "all"|"any"|{"at_least": n}|{"exactly": n}|
  *                                 {"at_most": n}, "threshold": 1.0},
  *       {"type": "statistic", "column": "c", "statistic": "min|max|mean|sum|standard_deviation|variance|median|

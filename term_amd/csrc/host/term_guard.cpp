@@ -661,6 +661,34 @@ class ContainmentConstraint : public Constraint {
   std::vector<std::string> allowed_;
 };
 
+// constraints/approx_count_distinct.rs:31-141: `SELECT APPROX_DISTINCT(col)` against an assertion.  DataFusion's
+// HyperLogLog estimate is third-party arithmetic (its hash is not reproducible here); the metric is the EXACT number
+// of distinct non-NULL values, i.e. the quantity the estimate approximates (the reference's own tests only bound it,
+// :186-347).  An empty or all-NULL column gives 0, not Skipped (:299-325).
+class ApproxCountDistinctConstraint : public Constraint {
+ public:
+  ApproxCountDistinctConstraint(std::string col, Assertion a) : col_(std::move(col)), a_(a) {}
+  std::string name() const override { return "approx_count_distinct"; }
+  std::optional<std::string> column() const override { return col_; }
+  std::vector<SpecRequest> plan() const override {
+    SpecRequest r;
+    r.kind = TGX_CHECK_DISTINCT;
+    r.column = col_;
+    return {r};
+  }
+  ConstraintResult evaluate(const Inputs &in) const override {
+    const double count = (double)in.results[0]->distinct;
+    if (a_.evaluate(count)) return ConstraintResult::success_with_metric(count);
+    return ConstraintResult::failure_with_metric(count, "Approximate distinct count " + rust_f64(count) +
+                                                            " does not satisfy assertion " + a_.description() +
+                                                            " for column '" + col_ + "'");
+  }
+
+ private:
+  std::string col_;
+  Assertion a_;
+};
+
 // constraints/quantile.rs:228-345 (QuantileValidation::Single)
 class QuantileConstraint : public Constraint {
  public:
@@ -737,6 +765,9 @@ Check::Builder Check::builder(std::string name) { return Builder(std::move(name)
 ValidationSuite::Builder ValidationSuite::builder(std::string name) { return Builder(std::move(name)); }
 
 Check::Builder &Check::Builder::has_size(Assertion a) { return constraint(std::make_shared<SizeConstraint>(a)); }
+Check::Builder &Check::Builder::has_approx_count_distinct(std::string column, Assertion a) {
+  return constraint(std::make_shared<ApproxCountDistinctConstraint>(std::move(column), a));
+}
 Check::Builder &Check::Builder::completeness(std::vector<std::string> columns, CompletenessOptions o) {
   return constraint(std::make_shared<CompletenessConstraint>(std::move(columns), o.op, o.threshold));
 }
@@ -1190,6 +1221,8 @@ void add_constraint_from_json(Check::Builder &b, const json::Value &c) {
   const std::string type = c.get_str("type");
   if (type == "size") {
     b.has_size(assertion_from(*c.get("assertion")));
+  } else if (type == "approx_count_distinct") {
+    b.has_approx_count_distinct(c.get_str("column"), assertion_from(*c.get("assertion")));
   } else if (type == "completeness") {
     CompletenessOptions o;
     o.op = operator_from(c.get("operator"));

@@ -192,6 +192,7 @@ class Check::Builder {
   Builder &constraint(std::shared_ptr<Constraint> c) { check_.constraints_.push_back(std::move(c)); return *this; }
   // check.rs:321 / :1743 / :2233-2300
   Builder &has_size(Assertion a);
+  Builder &has_approx_count_distinct(std::string column, Assertion a);  // core/check.rs:379-390 (metric: exact count)
   Builder &completeness(std::vector<std::string> columns, CompletenessOptions options);
   Builder &completeness(std::string column, CompletenessOptions options) {
     return completeness(std::vector<std::string>{std::move(column)}, options);

@@ -172,6 +172,10 @@ class CheckBuilder:
     def has_size(self, assertion):
         return self._add(type="size", assertion=assertion.to_json())
 
+    def has_approx_count_distinct(self, column, assertion):
+        """core/check.rs:379-390; the metric is the exact number of distinct non-NULL values"""
+        return self._add(type="approx_count_distinct", column=column, assertion=assertion.to_json())
+
     def completeness(self, columns, options=None):
         o = options or CompletenessOptions.full()
         return self._add(type="completeness", columns=_cols(columns), operator=o.operator_, threshold=o.threshold_)

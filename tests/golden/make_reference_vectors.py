@@ -119,6 +119,27 @@ containment = [
          status="success", metric=1.0),
 ]
 
+# constraints/approx_count_distinct.rs:186-347 (the reference's tests bound the HyperLogLog estimate; `exact` is the
+# number of distinct non-NULL values, which lies inside every one of those bounds)
+approx_count_distinct = [
+    dict(ref="constraints/approx_count_distinct.rs:190-203", dtype="int64", values=list(range(1000)),
+         assertion=["greater_than", 990.0], status="success", bounds=[990.0, 1e18], exact=1000.0),
+    dict(ref="constraints/approx_count_distinct.rs:206-225", dtype="int64", values=[1, 2, 3] * 100,
+         assertion=["less_than", 10.0], status="success", bounds=[0.0, 10.0], exact=3.0),
+    dict(ref="constraints/approx_count_distinct.rs:228-255", dtype="int64", values=[1, N, 2, N, 3, N, 1, 2, 3, N],
+         assertion=["between", 2.0, 5.0], status="success", bounds=[2.0, 5.0], exact=3.0),
+    dict(ref="constraints/approx_count_distinct.rs:258-273", dtype="int64", values=[i % 10 for i in range(50)],
+         assertion=["greater_than", 100.0], status="failure", bounds=[0.0, 20.0], exact=10.0,
+         message="Approximate distinct count 10 does not satisfy assertion greater than 100 for column 'test_col'"),
+    dict(ref="constraints/approx_count_distinct.rs:276-297", dtype="string",
+         values=["apple", "banana", "cherry", "apple", "banana", "date", "elderberry", N],
+         assertion=["between", 4.0, 6.0], status="success", bounds=[4.0, 6.0], exact=5.0),
+    dict(ref="constraints/approx_count_distinct.rs:300-311", dtype="int64", values=[],
+         assertion=["equals", 0.0], status="success", bounds=[0.0, 0.0], exact=0.0),
+    dict(ref="constraints/approx_count_distinct.rs:314-326", dtype="int64", values=[N, N, N, N, N],
+         assertion=["equals", 0.0], status="success", bounds=[0.0, 0.0], exact=0.0),
+]
+
 EMAIL = "email"
 fmt = [
     dict(ref="constraints/format.rs:917-934", format="email", threshold=0.7,
@@ -284,7 +305,7 @@ assertion = [
 ]
 
 out = dict(completeness=completeness, statistics=statistics, uniqueness=uniqueness,
-           uniqueness_multi=uniqueness_multi, length=length, containment=containment, format=fmt,
+           uniqueness_multi=uniqueness_multi, length=length, containment=containment, approx_count_distinct=approx_count_distinct, format=fmt,
            patterns=patterns, analyzers=analyzers, correlation=correlation, kll=kll, assertion=assertion)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 with open(path, "w") as f:

@@ -102,6 +102,20 @@ def test_reference_vectors_end_to_end(golden):
             assert m.skipped_checks == 1
         if "name" in case and case["status"] == "success":
             assert list(m.custom_metrics.keys()) == ["chk." + case["name"]]
+    # approx_count_distinct (constraints/approx_count_distinct.rs:186-347): the metric is the exact distinct count, which
+    # must lie inside the bounds the reference's tests put on DataFusion's HyperLogLog estimate
+    for case in golden["approx_count_distinct"]:
+        typ = pa.int64() if case["dtype"] == "int64" else pa.string()
+        tbl = arrow_table(test_col=(typ, case["values"]))
+        b = Check.builder("chk").level(Level.ERROR).has_approx_count_distinct("test_col", Assertion(*case["assertion"]))
+        r = ValidationSuite.builder("s").check(b.build()).build().run(tbl)
+        if case["status"] == "success":
+            assert r.is_success(), (case["ref"], [i.message for i in r.report.issues])
+            metric = r.report.metrics.custom_metrics["chk.approx_count_distinct"]
+        else:
+            assert r.is_failure() and r.report.issues[0].message == case["message"], case["ref"]
+            metric = r.report.issues[0].metric
+        assert metric == case["exact"] and case["bounds"][0] <= metric <= case["bounds"][1], case["ref"]
     # containment (constraints/values.rs:520-601): the IN-list runs as an anchored alternation on the pattern kernel
     for case in golden["containment"]:
         tbl = arrow_table(text_col=(pa.string(), case["values"]))
