@@ -77,11 +77,11 @@ class FakeDist:
         self._done()
 
 
+@pytest.mark.parametrize("world", [3, 8])  # 8: the row-shard layout of the 8-GPU node the scaling bench runs on
 @pytest.mark.parametrize("dense", [True, False])
-def test_three_simulated_ranks_match_one_state(dense):
+def test_simulated_ranks_match_one_state(dense, world):
     import torch
 
-    world = 3
     rng = np.random.default_rng(12 + dense)
     n = 2_400_000 + 64 * 7
     ids = rng.permutation(n).astype(np.int64)                       # unique, dense range -> bitmap slices
@@ -118,7 +118,7 @@ def test_three_simulated_ranks_match_one_state(dense):
             st, st_d = T.State(plan), T.State(plan_d)
             for _ in range(2):  # twice: buffers, cached gather capacity and range hints are reused across steps
                 res = sharded_suite_step(plan, st, plan_d, st_d, stat_specs, distinct_specs, shard, FakeDist(group, rank),
-                                         world, rank, cache_key="sim%d" % dense)
+                                         world, rank, cache_key="sim%d_%d" % (dense, world))
             results[rank] = res
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
