@@ -141,3 +141,39 @@ def test_unaligned_buffers(golden):
                                    flags=T.FLAG_TRIM | T.FLAG_NULL_IS_VALID), spec(T.DISTINCT, 0)], [[col]])
         assert (res[0].total, res[0].matches) == (want.total, want.matches), shift
         assert (res[1].non_null, res[1].distinct) == (wantd.non_null, wantd.distinct), shift
+
+
+def test_chunk_walk_boundaries():
+    """The staged walk takes a value eight bytes at a time from aligned LDS words (kernels/regex.hip: ChunkFeed,
+    walk2_staged): every value length 0..40 at every start alignment, 128-row spans that just fit / just exceed the
+    4 KiB stage (whole step, then half steps, then values read from global memory), values longer than the stage,
+    patterns that decide early (dead / matched) and late (`$`-anchored), TRIM on both ends."""
+    rng = np.random.default_rng(2024)
+    alphabet = np.frombuffer(b"ab01@. -_Xz9", dtype=np.uint8)
+
+    def rand_str(n):
+        return bytes(alphabet[rng.integers(0, len(alphabet), size=n)]).decode()
+
+    vals = []
+    for length in range(0, 41):          # every length, shifting the alignment of what follows
+        for _ in range(6):
+            vals.append(rand_str(length))
+    for total in (4096 - 64, 4096 - 16, 4096, 4096 + 16, 2 * 4096 - 16, 2 * 4096 + 64):
+        # 128 consecutive values whose span is `total` bytes (plus up to 15 bytes of alignment slack)
+        each, rest = divmod(total, 128)
+        vals += [rand_str(each + (1 if k < rest else 0)) for k in range(128)]
+    vals += [rand_str(5000), "x@y.z", rand_str(4097), None, rand_str(9000) + "@end.com", "", rand_str(33)] * 3
+    vals += ["  " + rand_str(k) + "   " for k in range(0, 24)] + [" ", "  ", "   "]
+    vals += [None if rng.random() < 0.1 else rand_str(int(rng.integers(0, 70))) for _ in range(20_000)]
+    offs, data, validity = orc.utf8_from_list(vals)
+    pats = [(r"@", 0), (r"^[ab01]+$", 0), (r"\.com$", T.FLAG_TRIM), (r"^[^@]+@[^@]+\.[^@]+$", T.FLAG_TRIM | T.FLAG_NULL_IS_VALID),
+            (r"a.*9$", 0), (r"^$", T.FLAG_TRIM), (r"(?:ab|ba){2}", T.FLAG_CASE_INSENSITIVE), (r"X{2,}z?9", 0)]
+    for large in (False, True):
+        for lead in (0, 5):  # a sliced batch: the step no longer starts at row 0 / byte 0
+            col = utf8_column(offs, data, validity, True, offset=lead, length=len(vals) - lead, large=large)
+            res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, pattern=p, flags=f) for p, f in pats], [[col]])
+            for r, (p, f) in zip(res, pats):
+                want = orc.Regex(p, case_insensitive=bool(f & T.FLAG_CASE_INSENSITIVE)).count_utf8(
+                    offs, data, validity, n=len(vals) - lead, offset=lead, trim=bool(f & T.FLAG_TRIM),
+                    null_is_valid=bool(f & T.FLAG_NULL_IS_VALID))
+                assert (r.total, r.matches) == (want.total, want.matches), (p, large, lead)
