@@ -211,7 +211,7 @@ def main():
                        "parallelism": "row-range shards x%d" % world,
                        "suite_algorithmic_bytes": alg_suite,
                        "suite_hbm_gbs": alg_suite / (dt / args.steps) / 1e9,
-                       "suite_frac_of_8TBs": alg_suite / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                       "suite_frac_of_8TBs": alg_suite / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world,  # per GPU
                        "distinct_ms_per_step": prof_d["total_ms"] / max(1, args.steps),
                        "verified": verified},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
