@@ -255,6 +255,7 @@ struct tgx_state {
 
   // device accumulators
   tgx::DevBuf d_scan_acc, d_count_acc, d_como_acc, d_pivots, d_pivot_set;
+  tgx::DevBuf d_scan_identity;  // the accumulators' identities, copied over d_scan_acc by reset
   std::vector<tgx::ScanAcc> scan_snapshot;  // host copy of d_scan_acc, valid inside one tgx_update (distinct_update)
   bool scan_snapshot_valid = false;
   tgx::DevBuf d_distinct_counters;  // [distinct task][kNumDistinctCounters]: every DistinctState::counters is a slice

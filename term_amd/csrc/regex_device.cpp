@@ -270,8 +270,9 @@ tgx_status regex_fetch_begin(tgx_state *st, tgx_error *err) {
   RegexState *rs = rstate(st);
   if (!rs || !rs->counter_pool.p) return TGX_OK;
   rs->fetched.resize(rs->tasks.size() * 2);
+  RHIP(hipMemcpyAsync(rs->fetched.data(), rs->counter_pool.p, rs->tasks.size() * 16, hipMemcpyDeviceToHost,
+                      st->stream));  // ordered on the state's stream: no wait for the rest of the device
   RHIP(hipStreamSynchronize(st->stream));
-  RHIP(hipMemcpy(rs->fetched.data(), rs->counter_pool.p, rs->tasks.size() * 16, hipMemcpyDeviceToHost));
   rs->fetched_ok = true;
   return TGX_OK;
 }
@@ -287,8 +288,8 @@ static tgx_status regex_totals(tgx_state *st, size_t i, uint64_t *total, uint64_
   if (rs->fetched_ok) {
     dev_matches = rs->fetched[2 * i];
   } else if (ts.counters.p) {
+    RHIP(hipMemcpyAsync(&dev_matches, ts.counters.p, 8, hipMemcpyDeviceToHost, st->stream));
     RHIP(hipStreamSynchronize(st->stream));
-    RHIP(hipMemcpy(&dev_matches, ts.counters.p, 8, hipMemcpyDeviceToHost));
   }
   *total = ts.total + ts.h_total;
   *matches = dev_matches + ts.h_matches;

@@ -366,7 +366,12 @@ static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
   if (!plan->scan.empty()) {
     std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
     HIP_TRY(st->d_scan_acc.reserve(init.size() * sizeof(ScanAcc)));
-    HIP_TRY(hipMemcpy(st->d_scan_acc.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
+    // the identities are kept on the device: tgx_state_reset then restores them with a copy ordered on the state's
+    // stream (a synchronous hipMemcpy in reset held the caller until every stream of the device had drained)
+    HIP_TRY(st->d_scan_identity.reserve(init.size() * sizeof(ScanAcc)));
+    HIP_TRY(hipMemcpy(st->d_scan_identity.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(st->d_scan_acc.p, st->d_scan_identity.p, init.size() * sizeof(ScanAcc),
+                           hipMemcpyDeviceToDevice, st->stream));
     HIP_TRY(st->d_pivots.reserve(plan->scan.size() * sizeof(double)));
     HIP_TRY(st->d_pivot_set.reserve(plan->scan.size() * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(st->d_pivots.p, 0, plan->scan.size() * sizeof(double), st->stream));
@@ -463,8 +468,8 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   spearman_state_reset(st);
   if (st->device_ready) {
     if (!plan->scan.empty()) {
-      std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
-      HIP_TRY(hipMemcpy(st->d_scan_acc.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpyAsync(st->d_scan_acc.p, st->d_scan_identity.p, plan->scan.size() * sizeof(ScanAcc),
+                             hipMemcpyDeviceToDevice, st->stream));
       HIP_TRY(hipMemsetAsync(st->d_pivots.p, 0, plan->scan.size() * sizeof(double), st->stream));
       HIP_TRY(hipMemsetAsync(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t), st->stream));
     }
@@ -1405,33 +1410,35 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   g->count = st->h_count;
   g->como = st->h_como;
   g->distinct.resize(plan->distinct.size());
+  std::vector<unsigned long long> all;
   if (st->device_ready) {
+    // every accumulator comes back with copies ordered on the state's OWN stream and one synchronisation of it: a
+    // synchronous hipMemcpy (null stream) also waits for the other streams of the device, e.g. another state's scan
+    std::vector<ScanAcc> d_scan(plan->scan.size());
+    std::vector<CountAcc> d_count(plan->count.size());
+    std::vector<ComomentAcc> d_como(plan->como.size());
+    if (!d_scan.empty())
+      HIP_TRY(hipMemcpyAsync(d_scan.data(), st->d_scan_acc.p, d_scan.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost,
+                             st->stream));
+    if (!d_count.empty())
+      HIP_TRY(hipMemcpyAsync(d_count.data(), st->d_count_acc.p, d_count.size() * sizeof(CountAcc),
+                             hipMemcpyDeviceToHost, st->stream));
+    if (!d_como.empty())
+      HIP_TRY(hipMemcpyAsync(d_como.data(), st->d_como_acc.p, d_como.size() * sizeof(ComomentAcc),
+                             hipMemcpyDeviceToHost, st->stream));
+    if (st->d_distinct_counters.p) {
+      all.resize(plan->distinct.size() * kNumDistinctCounters);
+      HIP_TRY(hipMemcpyAsync(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, st->stream));
+    }
     HIP_TRY(hipStreamSynchronize(st->stream));
     st->ptr_tables.clear();
-    if (!plan->scan.empty()) {
-      std::vector<ScanAcc> d(plan->scan.size());
-      HIP_TRY(hipMemcpy(d.data(), st->d_scan_acc.p, d.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < d.size(); i++) scan_acc_merge(g->scan[i], d[i]);
+    for (size_t i = 0; i < d_scan.size(); i++) scan_acc_merge(g->scan[i], d_scan[i]);
+    for (size_t i = 0; i < d_count.size(); i++) {
+      g->count[i].total += d_count[i].total;
+      g->count[i].non_null += d_count[i].non_null;
     }
-    if (!plan->count.empty()) {
-      std::vector<CountAcc> d(plan->count.size());
-      HIP_TRY(hipMemcpy(d.data(), st->d_count_acc.p, d.size() * sizeof(CountAcc), hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < d.size(); i++) {
-        g->count[i].total += d[i].total;
-        g->count[i].non_null += d[i].non_null;
-      }
-    }
-    if (!plan->como.empty()) {
-      std::vector<ComomentAcc> d(plan->como.size());
-      HIP_TRY(hipMemcpy(d.data(), st->d_como_acc.p, d.size() * sizeof(ComomentAcc), hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < d.size(); i++) como_acc_merge(g->como[i], d[i]);
-    }
-  }
-  std::vector<unsigned long long> all;
-  if (st->device_ready && st->d_distinct_counters.p) {
-    all.resize(plan->distinct.size() * kNumDistinctCounters);
-    HIP_TRY(hipMemcpy(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
-                      hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < d_como.size(); i++) como_acc_merge(g->como[i], d_como[i]);
   }
   for (size_t i = 0; i < plan->distinct.size(); i++)
     TGX_TRY(distinct_totals(st, i, &g->distinct[i], err, all.empty() ? nullptr : all.data()));
