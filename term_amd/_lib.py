@@ -375,12 +375,20 @@ class State:
         _check(lib().tgx_merge(self.plan.h, self.h, hs, len(others), C.byref(err)), err)
 
     def serialize(self):
+        """packed partial state.  One library call when the blob fits the buffer kept from the last call (every call
+        reads the accumulators back from the device), a second one with the reported size otherwise."""
         n = C.c_size_t()
         err = _Error()
-        _check(lib().tgx_state_serialize(self.plan.h, self.h, None, 0, C.byref(n), C.byref(err)), err)
-        buf = (C.c_uint8 * max(1, n.value))()
-        _check(lib().tgx_state_serialize(self.plan.h, self.h, buf, n.value, C.byref(n), C.byref(err)), err)
-        return bytes(buf[: n.value])
+        buf = getattr(self, "_ser_buf", None)
+        if buf is None:
+            buf = self._ser_buf = (C.c_uint8 * 8192)()
+        rc = lib().tgx_state_serialize(self.plan.h, self.h, buf, len(buf), C.byref(n), C.byref(err))
+        if rc != 0 and n.value > len(buf):  # "buffer too small": the needed size has been reported
+            buf = self._ser_buf = (C.c_uint8 * (n.value + n.value // 4))()
+            err = _Error()
+            rc = lib().tgx_state_serialize(self.plan.h, self.h, buf, len(buf), C.byref(n), C.byref(err))
+        _check(rc, err)
+        return bytes(memoryview(buf)[: n.value])
 
     @staticmethod
     def deserialize(plan, blob):
