@@ -34,9 +34,9 @@ def main():
     st = T.State(plan)
     st.update([(T.Column.float64 if k.startswith("f_") else T.Column.int64)(v, b, length=n) for (k, _), (v, b) in zip(layout, table)])
     want = [(r.total, r.non_null, r.distinct, r.sum_i) for r in st.finalize()]
-    # pinned first: allocated AFTER the pageable copy of the table existed, the pinned buffers measured 11.7 GB/s
-    # (both orders give 51-52 GB/s for whichever mode runs first; single-column probes give 52-55 GB/s for either
-    # kind of memory) -- placement of the host pages, not the staging path
+    # pinned first: pinned buffers allocated AFTER the pageable copy of the table had been made and used measured
+    # 11.7 GB/s; allocated first they give 51.5 GB/s, as the pageable pass does in either position, and single-column
+    # probes give 52-55 GB/s for both kinds of memory -- where the pinned pages end up, not the staging path
     for pinned in (True, False):
         host = []
         for vals, validity in table:
