@@ -218,7 +218,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(torch, layout, unique_cols, table,
                                                min(args.cpu_sample_rows, n_local))
         line = json.dumps(out)
