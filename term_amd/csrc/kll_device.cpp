@@ -113,8 +113,8 @@ tgx_status kll_flush(tgx_state *st, tgx_error *err) {
   for (size_t i = 0; i < k->sketch.size(); i++) {
     if (!k->dirty[i]) continue;
     std::vector<uint8_t> raw(sizeof(KllDeviceSketch));
+    KHIP(hipMemcpyAsync(raw.data(), k->sketch[i].p, raw.size(), hipMemcpyDeviceToHost, st->stream));
     KHIP(hipStreamSynchronize(st->stream));
-    KHIP(hipMemcpy(raw.data(), k->sketch[i].p, raw.size(), hipMemcpyDeviceToHost));
     const KllDeviceSketch *s = (const KllDeviceSketch *)raw.data();
     KllHost part;
     part.k = st->h_kll[i].k;

@@ -163,8 +163,8 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   r->total = ts.total_rows;
   unsigned long long m = 0;
   if (ts.count.p) {
+    SHIP(hipMemcpyAsync(&m, ts.count.p, 8, hipMemcpyDeviceToHost, st->stream));
     SHIP(hipStreamSynchronize(st->stream));
-    SHIP(hipMemcpy(&m, ts.count.p, 8, hipMemcpyDeviceToHost));
   }
   r->non_null = (int64_t)m;
   if (m == 0) return TGX_OK;

@@ -1699,7 +1699,8 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   unsigned long long zero[kNumDistinctCounters];
   memset(zero, 0, sizeof(zero));
   zero[kCntValidRows] = valid_rows;
-  HIP_TRY(hipMemcpy(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(ds.counters.p, zero, sizeof(zero), hipMemcpyHostToDevice, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));  // `zero` is on this stack frame
   TGX_TRY(distinct_import_records(st, slot, device_records, n_records, wide, err));
   HIP_TRY(hipStreamSynchronize(st->stream));
   ds.partitioned = true;
