@@ -84,3 +84,28 @@ def test_multi_batch_and_not_mergeable():
     assert e.value.status == "TGX_UNSUPPORTED"  # correlation.rs:103-109: rank-based states do not merge
     with pytest.raises(T.TgxError):
         st.serialize()
+
+
+def test_state_reuse_across_sizes_and_pairs():
+    """The ranking's work buffers stay with the state and are shared by its pairs (spearman_device.cpp): a small
+    table, a larger one, a small one again through the SAME state (reset in between), two pairs per plan, and batch
+    lengths that are no multiple of the compaction trip (2048 rows)."""
+    T.init()
+    plan = T.Plan([spec(T.SPEARMAN, 0, column2=1), spec(T.SPEARMAN, 1, column2=2)])
+    st = T.State(plan)
+    for n in (1500, 300_001, 777, 4097):
+        rng = np.random.default_rng(n)
+        a, av = make_f64(rng, n, "normal", null_frac=0.15)
+        b, bv = make_i64(rng, n, -1000, 1000, null_frac=0.05)
+        c, _ = make_f64(rng, n, "uniform")
+        st.reset()
+        cut = n // 3
+        for lo, hi in ((0, cut), (cut, n)):
+            st.update([numeric_column(a, av, True, offset=lo, length=hi - lo),
+                       numeric_column(b, bv, True, offset=lo, length=hi - lo),
+                       numeric_column(c, None, True, offset=lo, length=hi - lo)])
+        res = st.finalize()
+        for r, want in ((res[0], orc.spearman_state(a, b, av, bv)), (res[1], orc.spearman_state(b, c, bv, None))):
+            assert (r.total, r.non_null) == (n, want.n)
+            assert (r.sum_x, r.sum_y, r.sum_x2, r.sum_y2, r.sum_xy) == \
+                (want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy), n
