@@ -493,3 +493,34 @@ def test_range_hint_violation_is_reported_not_miscounted():
     assert "outside the range bitmap" in str(e.value)
     with pytest.raises(T.TgxError):
         st.distinct_range_hint(0, 0, 10)  # only before the first batch
+
+
+def test_several_distinct_columns_share_one_range_readback():
+    """Int64 columns decide bitmap vs hash from the scan's running MIN / MAX; with two or more of them the
+    accumulators are read back once per update (tgx_api.cpp: scan_snapshot).  Four columns with different fates over
+    three batches: dense range (bitmap), a range that widens in the second batch (bitmap regrown / escapes), sparse
+    (hash), and one that is all-NULL in the first batch (decides later)."""
+    rng = np.random.default_rng(77)
+    n = 3 * 120_000
+    dense = rng.integers(-40_000, 90_000, size=n, dtype=np.int64)
+    widening = rng.integers(0, 50_000, size=n, dtype=np.int64)
+    widening[120_000:240_000] += 10**9
+    sparse = rng.integers(-(2**61), 2**61, size=n, dtype=np.int64)
+    sparse[200_000:210_000] = sparse[:10_000]
+    late = rng.integers(5, 5000, size=n, dtype=np.int64)
+    late_valid = np.ones(n, dtype=bool)
+    late_valid[:120_000] = False
+    late_valid[rng.random(n) < 0.1] = False
+    cols = [(dense, None), (widening, None), (sparse, None), (late, orc.pack_validity(late_valid))]
+    specs = []
+    for ci in range(4):
+        specs += [spec(T.DISTINCT, ci, flags=T.FLAG_MULTIPLICITY if ci % 2 else 0), spec(T.NUMERIC_STATS, ci)]
+    batches = [[numeric_column(v, b, True, offset=lo, length=120_000) for v, b in cols] for lo in (0, 120_000, 240_000)]
+    res, _, _ = run_plan(specs, batches)
+    for ci, (v, b) in enumerate(cols):
+        d = orc.distinct_bits64(v.view(np.uint64), b, n=n)
+        r = res[2 * ci]
+        assert (r.total, r.non_null, r.distinct) == (d.total, d.non_null, d.distinct), ci
+        if ci % 2:
+            assert r.groups_once == d.groups_once, ci
+        check_stats(res[2 * ci + 1], orc.stats(v, b))
