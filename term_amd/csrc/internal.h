@@ -19,7 +19,7 @@ namespace tgx {
 // ---- kernel launchers (defined in kernels/*.hip) ----------------------------------------------
 void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set, hipStream_t stream);
 void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
-                           hipStream_t stream);
+                           ScanAcc *d_accs, hipStream_t stream);
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
                              ScanAcc *d_accs, hipStream_t stream);
 void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,

@@ -218,8 +218,43 @@ __device__ __forceinline__ LaneAcc acc_shfl_down(const LaneAcc &a, int d) {
   return b;
 }
 
+// merges one batch's folded partial `a` of a column into its running state (Chan's pairwise merge for the moments)
+__device__ __forceinline__ void scan_fold(ScanAcc &s, const LaneAcc &a, const ScanColDesc &c) {
+  s.is_float = c.is_float;
+  s.total += c.length;
+  s.non_null += a.cnt;
+  s.min_k = a.mn < s.min_k ? a.mn : s.min_k;
+  s.max_k = a.mx > s.max_k ? a.mx : s.max_k;
+  uint64_t lo = s.sum_lo + a.lo;
+  s.sum_hi += a.hi + (lo < s.sum_lo ? 1 : 0);
+  s.sum_lo = lo;
+  double comp = s.comp + a.c;
+  two_sum_add(s.sum, comp, a.s);
+  s.comp = comp;
+  if (c.want_variance && a.cnt > 0) {
+    // batch moments about the pivot -> (n, mean, M2), then Chan's pairwise merge
+    const double pivot = c.pivot ? *c.pivot : 0.0;
+    const double nb = (double)a.cnt;
+    const double mean_b = pivot + a.s1 / nb;
+    double m2_b = a.s2 - a.s1 * a.s1 / nb;
+    if (m2_b < 0.0) m2_b = 0.0;
+    if (s.var_n == 0) {
+      s.var_n = a.cnt;
+      s.var_mean = mean_b;
+      s.var_m2 = m2_b;
+    } else {
+      const double na = (double)s.var_n;
+      const double delta = mean_b - s.var_mean;
+      const double n = na + nb;
+      s.var_mean = s.var_mean + delta * nb / n;
+      s.var_m2 = s.var_m2 + m2_b + delta * delta * na * nb / n;
+      s.var_n += a.cnt;
+    }
+  }
+}
+
 template <bool IS_FLOAT, bool VAR, int VARIANT>
-__device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out, int wave,
+__device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out, ScanAcc *direct, int wave,
                                           int lane) {
   LaneAcc a;
   acc_init(a);
@@ -260,6 +295,14 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
       acc_merge(r, s_acc[w], IS_FLOAT);
       cnt += s_cnt[w];
     }
+    if (direct) {
+      // one workgroup per column (small batches): fold straight into the running state -- no reduce launch.  The
+      // reduce kernel would do exactly this with the one partial (merging identities is a no-op), so the results
+      // are the same bit for bit.
+      r.cnt += cnt;
+      scan_fold(*direct, r, c);
+      return;
+    }
     ScanPartial p;
     p.non_null = cnt + r.cnt;
     p.min_k = r.mn;
@@ -276,21 +319,23 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
 
 template <int VARIANT>
 __global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanLaunch L,
-                                                           ScanPartial *__restrict__ partials) {
+                                                           ScanPartial *__restrict__ partials,
+                                                           ScanAcc *__restrict__ accs) {
   const ScanColDesc c = L.cols[blockIdx.y];
+  ScanAcc *direct = (accs && gridDim.x == 1) ? accs + L.acc_index[blockIdx.y] : nullptr;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   ScanPartial *out = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (c.is_float) {
     if (c.want_variance)
-      scan_body<true, true, VARIANT>(c, out, wave, lane);
+      scan_body<true, true, VARIANT>(c, out, direct, wave, lane);
     else
-      scan_body<true, false, VARIANT>(c, out, wave, lane);
+      scan_body<true, false, VARIANT>(c, out, direct, wave, lane);
   } else {
     if (c.want_variance)
-      scan_body<false, true, VARIANT>(c, out, wave, lane);
+      scan_body<false, true, VARIANT>(c, out, direct, wave, lane);
     else
-      scan_body<false, false, VARIANT>(c, out, wave, lane);
+      scan_body<false, false, VARIANT>(c, out, direct, wave, lane);
   }
 }
 
@@ -324,40 +369,7 @@ __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
     LaneAcc b = acc_shfl_down(a, d);
     acc_merge(a, b, c.is_float);
   }
-  if (lane == 0) {
-    ScanAcc &s = accs[L.acc_index[col]];
-    s.is_float = c.is_float;
-    s.total += c.length;
-    s.non_null += a.cnt;
-    s.min_k = a.mn < s.min_k ? a.mn : s.min_k;
-    s.max_k = a.mx > s.max_k ? a.mx : s.max_k;
-    uint64_t lo = s.sum_lo + a.lo;
-    s.sum_hi += a.hi + (lo < s.sum_lo ? 1 : 0);
-    s.sum_lo = lo;
-    double comp = s.comp + a.c;
-    two_sum_add(s.sum, comp, a.s);
-    s.comp = comp;
-    if (c.want_variance && a.cnt > 0) {
-      // batch moments about the pivot -> (n, mean, M2), then Chan's pairwise merge
-      const double pivot = c.pivot ? *c.pivot : 0.0;
-      const double nb = (double)a.cnt;
-      const double mean_b = pivot + a.s1 / nb;
-      double m2_b = a.s2 - a.s1 * a.s1 / nb;
-      if (m2_b < 0.0) m2_b = 0.0;
-      if (s.var_n == 0) {
-        s.var_n = a.cnt;
-        s.var_mean = mean_b;
-        s.var_m2 = m2_b;
-      } else {
-        const double na = (double)s.var_n;
-        const double delta = mean_b - s.var_mean;
-        const double n = na + nb;
-        s.var_mean = s.var_mean + delta * nb / n;
-        s.var_m2 = s.var_m2 + m2_b + delta * delta * na * nb / n;
-        s.var_n += a.cnt;
-      }
-    }
-  }
+  if (lane == 0) scan_fold(accs[L.acc_index[col]], a, c);
 }
 
 // Picks the variance pivot of a column: the mean of (up to) the first 256 valid values of the first
@@ -461,11 +473,13 @@ void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_
   hipLaunchKernelGGL(scan_pivot_kernel, dim3(n_cols), dim3(256), 0, stream, L, d_pivots, d_pivot_set);
 }
 
+// d_accs != nullptr and blocks_per_col == 1: the kernel folds into the running states itself (no reduce launch)
 void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
-                           hipStream_t stream) {
+                           ScanAcc *d_accs, hipStream_t stream) {
   // VARIANT bit 0 = nontemporal loads, bit 1 = next tile requested before the current one is consumed.
   // Measured at 1 G rows x 16 columns (ms per launch): 0: 21.11, 1: 20.95, 2: 21.24, 3: 20.74 -> 3.
-  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, L, d_partials);
+  hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, L, d_partials,
+                     blocks_per_col == 1 ? d_accs : nullptr);
 }
 
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,

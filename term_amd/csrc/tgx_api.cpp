@@ -1205,10 +1205,12 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         if (chunk_var) launch_scan_pivot(L, n, st->d_pivots.as<double>(), st->d_pivot_set.as<int32_t>(), st->stream);
         {
           ProfScope ps(st, "scan", chunk_bytes);
-          launch_scan_main_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->stream);
-        }
-        launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
+          launch_scan_main_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
                                 st->stream);
+        }
+        if (blocks > 1)  // one workgroup per column folds into the running state itself (small batches: one launch)
+          launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
+                                  st->stream);
       }
       (void)any_var;
       (void)bytes;
