@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256) void scan_pivot_kernel(const ScanLaunch L,
 // COUNT(*) / COUNT(col) for columns whose values are not needed: popcount of the validity bits.
 // grid = (blocks, columns).  Reads ceil(n/8) bytes per column.
 __global__ __launch_bounds__(256) void count_kernel(const CountLaunch L,
-                                                     unsigned long long *__restrict__ block_counts) {
+                                                     unsigned long long *__restrict__ block_counts,
+                                                     CountAcc *__restrict__ direct) {
   const CountColDesc c = L.cols[blockIdx.y];
   const int64_t bit0 = c.offset, bit1 = c.offset + c.length;
   // words of the 8-byte aligned bitmap view that intersect [bit0, bit1)
@@ -444,9 +445,16 @@ __global__ __launch_bounds__(256) void count_kernel(const CountLaunch L,
   __shared__ int64_t s[kWavesPerBlock];
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0)
-    block_counts[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
-        (unsigned long long)(s[0] + s[1] + s[2] + s[3]);
+  if (threadIdx.x == 0) {
+    const int64_t total = s[0] + s[1] + s[2] + s[3];
+    if (direct && gridDim.x == 1) {  // one workgroup per column: no reduce launch (small batches)
+      CountAcc &a = direct[L.acc_index[blockIdx.y]];
+      a.total += c.length;
+      a.non_null += total;
+    } else {
+      block_counts[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned long long)total;
+    }
+  }
 }
 
 __global__ __launch_bounds__(64) void count_reduce_kernel(const CountLaunch L,
@@ -490,9 +498,11 @@ void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col
 
 void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,
                   CountAcc *d_accs, hipStream_t stream) {
-  hipLaunchKernelGGL(count_kernel, dim3(blocks_per_col, n_cols), dim3(256), 0, stream, L, d_block_counts);
-  hipLaunchKernelGGL(count_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, L, d_block_counts,
-                     blocks_per_col, d_accs);
+  hipLaunchKernelGGL(count_kernel, dim3(blocks_per_col, n_cols), dim3(256), 0, stream, L, d_block_counts,
+                     blocks_per_col == 1 ? d_accs : nullptr);
+  if (blocks_per_col > 1)
+    hipLaunchKernelGGL(count_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, L, d_block_counts,
+                       blocks_per_col, d_accs);
 }
 
 }  // namespace tgx
