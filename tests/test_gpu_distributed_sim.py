@@ -77,7 +77,7 @@ class FakeDist:
         self._done()
 
 
-@pytest.mark.parametrize("world", [3, 8])  # 8: the row-shard layout of the 8-GPU node the scaling bench runs on
+@pytest.mark.parametrize("world", [2, 3, 4, 8])  # 2 / 4 / 8: the row-shard layouts the scaling bench runs
 @pytest.mark.parametrize("dense", [True, False])
 def test_simulated_ranks_match_one_state(dense, world):
     import torch
