@@ -61,33 +61,40 @@ __device__ __forceinline__ void two_sum_add(double &s, double &c, double x) {
   c += e;
 }
 
+// The validity bit enters every select as a LANE MASK: ballot(valid) & ballot(compare) is one scalar AND, and
+// inverse_ballot hands the result to v_cndmask as its mask operand.  Written as `(valid && x < mn) ? x : mn` the
+// compiler selects twice (compare, then validity): 11 instead of 7 vector instructions per value for min + max, in a
+// kernel that is 87 % VALU-busy next to 78-83 % of the HBM peak.
 template <bool IS_FLOAT, bool VAR>
 __device__ __forceinline__ void acc_value(LaneAcc &a, int64_t bits, bool valid, double pivot) {
+  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+  const bool is_valid = __builtin_amdgcn_inverse_ballot_w64(vm);
   if (IS_FLOAT) {
-    int64_t k = f64_total_key(bits);
-    a.mn = (valid && k < a.mn) ? k : a.mn;
-    a.mx = (valid && k > a.mx) ? k : a.mx;
-    double x = valid ? __longlong_as_double(bits) : 0.0;
+    const int64_t k = f64_total_key(bits);
+    const bool lt = __builtin_amdgcn_inverse_ballot_w64(vm & __builtin_amdgcn_ballot_w64(k < a.mn));
+    const bool gt = __builtin_amdgcn_inverse_ballot_w64(vm & __builtin_amdgcn_ballot_w64(k > a.mx));
+    a.mn = lt ? k : a.mn;
+    a.mx = gt ? k : a.mx;
+    double x = is_valid ? __longlong_as_double(bits) : 0.0;
     two_sum_add(a.s, a.c, x);
     if (VAR) {
-      double d = valid ? (__longlong_as_double(bits) - pivot) : 0.0;
+      double d = is_valid ? (__longlong_as_double(bits) - pivot) : 0.0;
       a.s1 += d;
       a.s2 += d * d;
     }
   } else {
-    // (the validity bit is folded into the compare masks -- one scalar AND per select instead of a second pair of
-    //  selects -- and the 128-bit sum is one add / add-with-carry chain: the scan is as close to its VALU limit
-    //  (87 % busy at a 1.6 GHz shader clock) as to the HBM one)
-    const bool lt = valid & (bits < a.mn), gt = valid & (bits > a.mx);
+    const bool lt = __builtin_amdgcn_inverse_ballot_w64(vm & __builtin_amdgcn_ballot_w64(bits < a.mn));
+    const bool gt = __builtin_amdgcn_inverse_ballot_w64(vm & __builtin_amdgcn_ballot_w64(bits > a.mx));
     a.mn = lt ? bits : a.mn;
     a.mx = gt ? bits : a.mx;
-    const int64_t v = valid ? bits : 0;
+    // the 128-bit sum is one add / add-with-carry chain
+    const int64_t v = is_valid ? bits : 0;
     unsigned __int128 sum = ((unsigned __int128)a.hi << 64) | (unsigned __int128)a.lo;
     sum += (unsigned __int128)(__int128)v;
     a.lo = (uint64_t)sum;
     a.hi = (uint64_t)(sum >> 64);
     if (VAR) {
-      double d = valid ? ((double)bits - pivot) : 0.0;
+      double d = is_valid ? ((double)bits - pivot) : 0.0;
       a.s1 += d;
       a.s2 += d * d;
     }
