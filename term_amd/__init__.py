@@ -30,7 +30,9 @@ from ._lib import (  # noqa: F401
     FLAG_TRIM,
     FLAG_CASE_INSENSITIVE,
     FLAG_NULL_IS_VALID,
+    INT32,
     INT64,
+    FLOAT32,
     FLOAT64,
     UTF8,
     LARGE_UTF8,

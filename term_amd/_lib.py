@@ -11,7 +11,7 @@ COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
 ABI_VERSION = 2  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
-INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW = 1, 2, 3, 4, 5, 6
+INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
                 4: "TGX_OUT_OF_MEMORY", 5: "TGX_INTERNAL", 6: "TGX_NO_DEVICE"}
@@ -240,6 +240,18 @@ class Column:
         return Column(FLOAT64, n, values=values, validity=validity, offset=offset)
 
     @staticmethod
+    def int32(values, validity=None, length=None, offset=0):
+        """Int32 / Date32 / Time32: widened to Int64 on the device"""
+        n = (len(values) - offset) if length is None else length
+        return Column(INT32, n, values=values, validity=validity, offset=offset)
+
+    @staticmethod
+    def float32(values, validity=None, length=None, offset=0):
+        """Float32: widened to Float64 on the device"""
+        n = (len(values) - offset) if length is None else length
+        return Column(FLOAT32, n, values=values, validity=validity, offset=offset)
+
+    @staticmethod
     def utf8(offsets, data, validity=None, length=None, offset=0):
         n = (len(offsets) - 1 - offset) if length is None else length
         return Column(UTF8, n, offsets=offsets, data=data, validity=validity, offset=offset)
@@ -280,6 +292,17 @@ class Column:
         if pa.types.is_float64(arr.type):
             return Column(FLOAT64, len(arr), values=view(bufs[1], np.float64), validity=validity,
                           offset=arr.offset, null_count=arr.null_count)
+        t = arr.type
+        if pa.types.is_int32(t) or pa.types.is_date32(t) or pa.types.is_time32(t):
+            return Column(INT32, len(arr), values=view(bufs[1], np.int32), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count)
+        if pa.types.is_float32(t):
+            return Column(FLOAT32, len(arr), values=view(bufs[1], np.float32), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count)
+        if pa.types.is_timestamp(t) or pa.types.is_date64(t) or pa.types.is_time64(t) or pa.types.is_duration(t):
+            # Int64-shaped: the checks see the stored integer (microseconds, milliseconds, ...)
+            return Column(INT64, len(arr), values=view(bufs[1], np.int64), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count)
         if pa.types.is_string(arr.type):
             data = view(bufs[2], np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
             return Column(UTF8, len(arr), offsets=view(bufs[1], np.int32), data=data, validity=validity,

@@ -20,6 +20,7 @@ namespace tgx {
 void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set, hipStream_t stream);
 void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
                            ScanAcc *d_accs, hipStream_t stream);
+void launch_widen32(const void *src, void *dst, int64_t n, int is_float, int n_cu, hipStream_t stream);
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
                              ScanAcc *d_accs, hipStream_t stream);
 void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,
@@ -256,6 +257,13 @@ struct tgx_state {
   // device accumulators
   tgx::DevBuf d_scan_acc, d_count_acc, d_como_acc, d_pivots, d_pivot_set;
   tgx::DevBuf d_scan_identity;  // the accumulators' identities, copied over d_scan_acc by reset
+  struct Widen {
+    const void *src;
+    void *dst;
+    int64_t n;
+    int is_float;
+  };
+  std::vector<Widen> pending_widen;  // TGX_INT32 / TGX_FLOAT32 windows of the current update (stage_column)
   std::vector<tgx::ScanAcc> scan_snapshot;  // host copy of d_scan_acc, valid inside one tgx_update (distinct_update)
   bool scan_snapshot_valid = false;
   tgx::DevBuf d_distinct_counters;  // [distinct task][kNumDistinctCounters]: every DistinctState::counters is a slice

@@ -482,6 +482,43 @@ __global__ __launch_bounds__(64) void count_reduce_kernel(const CountLaunch L,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Int32 -> Int64 / Float32 -> Float64 over the rows a batch views (TGX_INT32 / TGX_FLOAT32 columns): four values per
+// lane and trip (one 16-byte load when the source is 16-byte aligned, two 16-byte stores).
+__global__ __launch_bounds__(256) void widen32_kernel(const void *__restrict__ src, void *__restrict__ dst, int64_t n,
+                                                      int is_float) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool aligned = (((uintptr_t)src) & 15) == 0;
+  const int64_t n4 = aligned ? n >> 2 : 0;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    if (is_float) {
+      const float4 v = ((const float4 *)src)[q];
+      double2 *o = (double2 *)dst + 2 * q;
+      o[0] = make_double2((double)v.x, (double)v.y);
+      o[1] = make_double2((double)v.z, (double)v.w);
+    } else {
+      const int4 v = ((const int4 *)src)[q];
+      longlong2 *o = (longlong2 *)dst + 2 * q;
+      o[0] = make_longlong2((long long)v.x, (long long)v.y);
+      o[1] = make_longlong2((long long)v.z, (long long)v.w);
+    }
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (is_float)
+      ((double *)dst)[i] = (double)((const float *)src)[i];
+    else
+      ((long long *)dst)[i] = (long long)((const int *)src)[i];
+  }
+}
+
+void launch_widen32(const void *src, void *dst, int64_t n, int is_float, int n_cu, hipStream_t stream) {
+  if (n <= 0) return;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(widen32_kernel, dim3((int)blocks), dim3(256), 0, stream, src, dst, n, is_float);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers (called from tgx_api.cpp); `n_cols` <= kMaxColsPerLaunch
 void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set,
                        hipStream_t stream) {

@@ -557,6 +557,7 @@ extern "C" tgx_status tgx_profile_reset(tgx_state *st) {
 // ------------------------------------------------------------------------------------------------
 // update
 static bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
+static bool is_numeric32(int t) { return t == TGX_INT32 || t == TGX_FLOAT32; }
 
 // copies a HOST column's buffers to the device; `out` is the device view
 constexpr size_t kArenaBytes = 8u << 20;        // pinned staging arena per state
@@ -626,14 +627,42 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
     TGX_TRY(stage(table.data(), table.size() * sizeof(void *), &dt));
     out->variadic = (const uint8_t *const *)dt;
   }
-  if (c.mem == TGX_MEM_DEVICE) return TGX_OK;
+  if (c.mem == TGX_MEM_DEVICE && !is_numeric32(c.type)) return TGX_OK;
   // Only the window the batch views is copied: a sliced array (offset > 0 into big buffers) costs its own rows,
   // not everything before them.  The window starts at slot e0 = offset rounded down to 64 (keeps the validity
   // byte / word alignment the kernels like); the device view gets offset - e0 as its Arrow offset.
   const int64_t e0 = c.offset & ~(int64_t)63;
   const int64_t slots = c.offset - e0 + c.length;  // slots of the window
-  out->offset = c.offset - e0;
   const void *p = nullptr;
+  if (is_numeric32(c.type)) {
+    // 4-byte numerics (include/tgx.h): the window is widened to 8-byte values in a staging buffer on the device; the
+    // kernels then see an Int64 / Float64 column.  DEVICE columns keep their validity bitmap and Arrow offset as they
+    // are (only the values move: slot e0 of the source becomes slot 0 of the widened buffer, so the bitmap of a device
+    // column is re-based by staging nothing and pointing at byte e0 / 8).
+    const bool host = c.mem == TGX_MEM_HOST;
+    const void *src = c.values ? (const uint8_t *)c.values + (size_t)e0 * 4 : nullptr;
+    if (host) {
+      TGX_TRY(stage(c.validity ? c.validity + (e0 >> 3) : nullptr, c.validity ? (size_t)((slots + 7) / 8) : 0, &p));
+      out->validity = (const uint8_t *)p;
+      TGX_TRY(stage(src, (size_t)slots * 4, &p));
+      src = p;
+    } else {
+      out->validity = c.validity ? c.validity + (e0 >> 3) : nullptr;
+    }
+    out->offset = c.offset - e0;
+    out->type = c.type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
+    out->values = nullptr;
+    if (src) {
+      if (st->staging_used == st->staging.size()) st->staging.emplace_back(new DevBuf());
+      DevBuf *w = st->staging[st->staging_used++].get();
+      HIP_TRY(w->reserve((size_t)slots * 8 + 16));
+      // launched by tgx_update once the pinned arena (small HOST buffers travel in it) has been uploaded
+      st->pending_widen.push_back({src, w->p, slots, c.type == TGX_FLOAT32 ? 1 : 0});
+      out->values = w->p;
+    }
+    return TGX_OK;
+  }
+  out->offset = c.offset - e0;
   TGX_TRY(stage(c.validity ? c.validity + (e0 >> 3) : nullptr, c.validity ? (size_t)((slots + 7) / 8) : 0, &p));
   out->validity = (const uint8_t *)p;
   if (is_numeric(c.type)) {
@@ -1093,13 +1122,13 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     if (c.length != nrows)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d has %lld rows, expected %lld", i, (long long)c.length,
                   (long long)nrows);
-    if (c.type < TGX_INT64 || c.type > TGX_UTF8_VIEW) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
+    if (c.type < TGX_INT64 || c.type > TGX_FLOAT32) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
     if (st->col_types[i] == 0) st->col_types[i] = c.type;
     if (st->col_types[i] != c.type)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d changed type between batches (%d -> %d)", i,
                   st->col_types[i], c.type);
     if (c.length > 0) {
-      if (is_numeric(c.type) && reads_values[i] && !c.values)
+      if ((is_numeric(c.type) || is_numeric32(c.type)) && reads_values[i] && !c.values)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
       if ((c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && !c.offsets)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets is NULL", i);
@@ -1129,6 +1158,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   st->arena_used = 0;
   st->host_direct = false;
   st->dict_views.clear();
+  st->pending_widen.clear();
   std::vector<tgx_column> dev(plan->n_columns_needed);
   bool any_host = false;
   for (int i = 0; i < plan->n_columns_needed; i++) {
@@ -1136,6 +1166,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     if (columns[i].mem == TGX_MEM_HOST && columns[i].length > 0) any_host = true;
     if (columns[i].length == 0) {
       dev[i] = columns[i];
+      if (is_numeric32(dev[i].type)) dev[i].type = dev[i].type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
       continue;
     }
     TGX_TRY(stage_column(st, columns[i], &dev[i], err));
@@ -1144,6 +1175,8 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   if (arena_in_use)
     HIP_TRY(hipMemcpyAsync(st->arena_dev[st->arena_cur].p, st->arena_host[st->arena_cur], st->arena_used,
                            hipMemcpyHostToDevice, st->stream));
+  for (const auto &w : st->pending_widen) launch_widen32(w.src, w.dst, w.n, w.is_float, g_ctx.n_cu, st->stream);
+  st->pending_widen.clear();
 
   if (nrows > 0) {
     // ---- numeric scan: all columns of the batch in launches of <= kMaxScanColsPerLaunch ----
