@@ -71,10 +71,11 @@ typedef enum tgx_type {
    * in `mem`); `variadic_sizes` (bytes, host array) is required for TGX_MEM_HOST columns, which are staged.
    * COUNT, DISTINCT and REGEX_MATCH give the results of the same values held as Utf8. */
   TGX_UTF8_VIEW = 6,
-  /* 4-byte numerics: Int32 (also Date32, Time32) and Float32.  `values` holds 4 bytes per row; the library widens
-   * the batch's window to Int64 / Float64 on the device (one extra pass over those columns) and every check then sees
-   * exactly the 64-bit column -- DataFusion's own coercion for SUM / AVG (Float64 accumulators) and value-preserving
-   * for MIN / MAX / COUNT(DISTINCT).  Int64-shaped Arrow types (Timestamp, Date64, Time64, Duration) are passed as
+  /* 4-byte numerics: Int32 (also Date32, Time32) and Float32.  `values` holds 4 bytes per row.  Every check sees
+   * exactly the Int64 / Float64 column the values stand for -- DataFusion's own coercion for SUM / AVG (Float64
+   * accumulators), value-preserving for MIN / MAX / COUNT(DISTINCT): COUNT and NUMERIC_STATS read the 4-byte values
+   * in place (widened in registers); for DISTINCT, KLL, COMOMENTS and SPEARMAN the batch's window is widened into a
+   * staging buffer on the device first (one extra pass over those columns).  Int64-shaped Arrow types (Timestamp, Date64, Time64, Duration) are passed as
    * TGX_INT64 as they are. */
   TGX_INT32 = 7,
   TGX_FLOAT32 = 8

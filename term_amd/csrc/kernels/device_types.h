@@ -21,6 +21,8 @@ struct ScanColDesc {
   int32_t is_float;
   int32_t want_variance;
   const double *pivot;      // device scalar: shift for the variance lanes (may be nullptr)
+  int32_t elem32;           // 1: `values` holds 4-byte elements (Int32 / Float32), widened as they are loaded
+  int32_t pad32;
 };
 
 // Per (column, block) partial written by scan_kernel; reduced in fixed order by scan_reduce_kernel.

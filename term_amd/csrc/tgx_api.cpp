@@ -566,7 +566,10 @@ constexpr size_t kArenaMaxBuffer = 256u << 10;  // buffers up to this size go th
 static bool is_string(int t) { return t == TGX_UTF8 || t == TGX_LARGE_UTF8; }
 static bool is_any_string(int t) { return is_string(t) || t == TGX_UTF8_VIEW; }
 
-static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx_error *err) {
+// `widen32`: a TGX_INT32 / TGX_FLOAT32 column is needed as 8-byte values (DISTINCT, KLL, co-moments, Spearman); the
+// scan alone reads 4-byte values as they are
+static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx_error *err,
+                               bool widen32 = true) {
   *out = c;
   if (c.type == TGX_DICT32_UTF8) {
     // the dictionary is a column of its own (and may live in a different memory space than the indices)
@@ -627,7 +630,7 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
     TGX_TRY(stage(table.data(), table.size() * sizeof(void *), &dt));
     out->variadic = (const uint8_t *const *)dt;
   }
-  if (c.mem == TGX_MEM_DEVICE && !is_numeric32(c.type)) return TGX_OK;
+  if (c.mem == TGX_MEM_DEVICE && !(is_numeric32(c.type) && widen32)) return TGX_OK;
   // Only the window the batch views is copied: a sliced array (offset > 0 into big buffers) costs its own rows,
   // not everything before them.  The window starts at slot e0 = offset rounded down to 64 (keeps the validity
   // byte / word alignment the kernels like); the device view gets offset - e0 as its Arrow offset.
@@ -650,6 +653,11 @@ static tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *o
       out->validity = c.validity ? c.validity + (e0 >> 3) : nullptr;
     }
     out->offset = c.offset - e0;
+    if (!widen32) {  // (a HOST column: the scan reads the staged 4-byte window)
+      out->values = src;
+      out->mem = TGX_MEM_DEVICE;
+      return TGX_OK;
+    }
     out->type = c.type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
     out->values = nullptr;
     if (src) {
@@ -701,15 +709,18 @@ static void fill_scan_desc(const tgx_column &c, bool variance, const double *piv
   d->validity = c.validity;
   d->offset = c.offset;
   d->length = c.length;
-  d->is_float = c.type == TGX_FLOAT64;
+  d->is_float = c.type == TGX_FLOAT64 || c.type == TGX_FLOAT32;
   d->want_variance = variance ? 1 : 0;
   d->pivot = pivot;
+  d->elem32 = is_numeric32(c.type) ? 1 : 0;
+  d->pad32 = 0;
+  const uintptr_t width = d->elem32 ? 4 : 8;  // a lane's pair of rows is one 2 x width load
   int64_t head = (64 - (c.offset & 63)) & 63;
   if (head > c.length) head = c.length;
   int64_t n_tiles = (c.length - head) / kTileRows;
-  const uintptr_t vaddr = (uintptr_t)c.values + (uintptr_t)(c.offset + head) * 8;
+  const uintptr_t vaddr = (uintptr_t)c.values + (uintptr_t)(c.offset + head) * width;
   const uintptr_t baddr = (uintptr_t)c.validity + (uintptr_t)((c.offset + head) >> 3);
-  if ((vaddr & 15) != 0 || (c.validity && (baddr & 7) != 0)) n_tiles = 0;  // per-lane path
+  if ((vaddr & (2 * width - 1)) != 0 || (c.validity && (baddr & 7) != 0)) n_tiles = 0;  // per-lane path
   d->head = n_tiles > 0 ? head : 0;
   d->n_tiles = n_tiles;
 }
@@ -1160,16 +1171,29 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   st->dict_views.clear();
   st->pending_widen.clear();
   std::vector<tgx_column> dev(plan->n_columns_needed);
+  // 4-byte numeric columns are widened to 8-byte values only for the passes that need them so
+  std::vector<char> needs_wide(plan->n_columns_needed, 0);
+  for (auto &t : plan->distinct) {
+    needs_wide[t.column] = 1;
+    for (int c2 : t.tuple) needs_wide[c2] = 1;
+  }
+  for (auto &t : plan->como) needs_wide[t.col_x] = needs_wide[t.col_y] = 1;
+  for (auto &t : plan->kll) needs_wide[t.column] = 1;
+  {
+    std::vector<char> sp_used(plan->n_columns_needed, 0), sp_vals(plan->n_columns_needed, 0);
+    spearman_mark_used(plan, sp_used, sp_vals);
+    for (int i = 0; i < plan->n_columns_needed; i++) needs_wide[i] |= sp_used[i];
+  }
   bool any_host = false;
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!used[i]) continue;
     if (columns[i].mem == TGX_MEM_HOST && columns[i].length > 0) any_host = true;
     if (columns[i].length == 0) {
       dev[i] = columns[i];
-      if (is_numeric32(dev[i].type)) dev[i].type = dev[i].type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
+      if (is_numeric32(dev[i].type) && needs_wide[i]) dev[i].type = dev[i].type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
       continue;
     }
-    TGX_TRY(stage_column(st, columns[i], &dev[i], err));
+    TGX_TRY(stage_column(st, columns[i], &dev[i], err, needs_wide[i] != 0));
   }
   const bool arena_in_use = st->arena_used != 0;
   if (arena_in_use)
@@ -1187,7 +1211,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       uint64_t bytes = 0;
       for (size_t s = 0; s < plan->scan.size(); s++) {
         const tgx_column &c = dev[plan->scan[s].column];
-        if (!is_numeric(c.type)) {
+        if (!is_numeric(c.type) && !is_numeric32(c.type)) {
           // a scan task that only exists for DISTINCT's range decision does not apply to strings
           bool needed_by_stats = false;
           for (size_t i = 0; i < plan->specs.size(); i++)
@@ -1217,7 +1241,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         any_var |= plan->scan[s].variance;
         descs.push_back(d);
         index.push_back((int32_t)s);
-        bytes += (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
+        bytes += (uint64_t)c.length * (is_numeric32(c.type) ? 4 : 8) + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
       }
       // launches of <= kMaxColsPerLaunch columns; descriptors travel in the kernel arguments
       for (size_t c0 = 0; c0 < descs.size(); c0 += kMaxColsPerLaunch) {
@@ -1231,7 +1255,8 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
           L.cols[k] = descs[c0 + k];
           L.acc_index[k] = index[c0 + k];
           blocks = std::max(blocks, scan_blocks_for(L.cols[k], n));
-          chunk_bytes += (uint64_t)L.cols[k].length * 8 + (L.cols[k].validity ? (uint64_t)(L.cols[k].length + 7) / 8 : 0);
+          chunk_bytes += (uint64_t)L.cols[k].length * (L.cols[k].elem32 ? 4 : 8) +
+                         (L.cols[k].validity ? (uint64_t)(L.cols[k].length + 7) / 8 : 0);
           chunk_var |= L.cols[k].want_variance != 0;
         }
         HIP_TRY(st->d_scan_partials.reserve((size_t)n * blocks * sizeof(ScanPartial)));

@@ -58,6 +58,40 @@ def test_checks_equal_the_widened_column(n, device):
     assert res[10].kll_n == int(mask.sum())
 
 
+@pytest.mark.parametrize("device", [True, False])
+@pytest.mark.parametrize("n,lead", [(5, 0), (700, 3), (70_000, 64), (1_000_003, 129)])
+def test_scan_reads_four_byte_values_in_place(n, lead, device):
+    """A column only the scan needs (COUNT, min / max / sum / mean / variance) is not widened: the tile path loads its
+    4-byte pairs directly (kernels/scan.hip: tile_load32).  Slices with odd and even offsets take the tile path or the
+    per-lane path depending on the alignment of the first pair."""
+    rng = np.random.default_rng(n + lead)
+    total = n + lead + 5
+    i32 = rng.integers(-2**31, 2**31, size=total, dtype=np.int64).astype(np.int32)
+    f32 = (rng.standard_normal(total) * 1e4).astype(np.float32)
+    f32[rng.random(total) < 0.01] = np.float32(np.inf)
+    mask = rng.random(total) >= 0.07
+    vb = orc.pack_validity(mask)
+    cols = [(i32, vb), (f32, None), (f32, vb)]
+    specs = []
+    for ci in range(3):
+        specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci, flags=T.FLAG_VARIANCE if ci != 1 else 0)]
+    res, _, _ = run_plan(specs, [[col32(v, b, device, offset=lead, length=n) for v, b in cols]])
+    for ci, (v, b) in enumerate(cols):
+        wide = v.astype(np.int64) if v.dtype == np.int32 else v.astype(np.float64)
+        c = orc.count(b, n, offset=lead)
+        assert (res[2 * ci].total, res[2 * ci].non_null) == (c.total, c.non_null)
+        want = orc.stats(wide, b, n=n, offset=lead)
+        r = res[2 * ci + 1]
+        assert (r.total, r.non_null) == (want.total, want.non_null)
+        if wide.dtype == np.int64:
+            assert (r.min_i, r.max_i, r.sum_i) == (want.min_i, want.max_i, want.sum_i_wrapping)
+        else:
+            assert (r.min_f, r.max_f) == (want.min_f, want.max_f)
+            assert (not np.isfinite(want.sum_hi) and not np.isfinite(r.sum_f)) or rel_err(r.sum_f, want.sum_hi) < 1e-9
+        if ci == 0 and want.has_variance:
+            assert rel_err(r.var_samp, want.var_samp) < 1e-9
+
+
 def test_from_arrow_32_bit_and_int64_shaped_types():
     import datetime
 
