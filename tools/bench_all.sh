@@ -10,6 +10,7 @@ run python tools/bench_regex.py                       # C3 (LargeUtf8)
 run python tools/bench_regex.py --view                # C3 held as Utf8View
 run python tools/bench_strings.py                     # string DISTINCT / LENGTH
 run python tools/bench_kll.py
+run python tools/bench_numeric32.py                   # Int32 / Float32 columns next to Int64 / Float64
 run python tools/bench_spearman.py
 run python tools/bench_batches.py                     # per-update cost of small batches (device / host buffers)
 run python tools/bench_host_batches.py                # PCIe-inclusive rate
