@@ -6,8 +6,9 @@ over one synthetic, device-resident batch of the 16-column "null + range + uniqu
 (term_amd/synth.py):
     Completeness x16 + Min/Max/Mean x16 + FullUniqueness on 2 columns.
 Rows are sharded by row range across ranks (strong scaling: the table size is fixed); each rank scans
-its shard, exact distinct exchanges keys with one all-to-all (hash-owner partitioning), and the packed
-partial states are all-gathered and merged in rank order on every rank.
+its shard, the ranks agree on the unique columns' value ranges, exact distinct swaps the slices of congruent
+range bitmaps with one all-to-all (16-byte key records by hash owner where a key set is not a bitmap), and the
+packed partial states are all-gathered and merged in rank order on every rank.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
