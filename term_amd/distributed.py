@@ -2,7 +2,8 @@
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests).  Every rank scans its own row range; then
-  * exact DISTINCT columns exchange their key sets once (hash-owner all-to-all of fixed-size records), after
+  * exact DISTINCT columns exchange their key sets once -- slices of congruent range bitmaps (all columns in one
+    all-to-all) where the agreed value range is dense, fixed-size key records by hash owner otherwise -- after
     which each rank holds a disjoint part of the global key set, and
   * the packed partial states (a few KiB) are all-gathered and folded in rank order on every rank, so all
     ranks finish with the same result (`AnalyzerState::merge`, analyzers/traits.rs:160-170).
