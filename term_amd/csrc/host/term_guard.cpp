@@ -29,6 +29,7 @@ std::string TermError::display() const {
     case SecurityError: return "Security error: " + message;
     case DataFusion: return "DataFusion error: " + message;
     case NotSupported: return "Operation not supported: " + message;
+    case Configuration: return "Configuration error: " + message;
     default: return "Internal error: " + message;
   }
 }
@@ -63,6 +64,31 @@ std::string rust_f64(double v) {
     out = "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
   }
   return neg ? "-" + out : out;
+}
+
+// Rust's `{:?}` for f64 (core::fmt::float::float_to_general_debug): shortest round-trip digits with at least one
+// fractional digit, scientific notation from 1e16 up and below 1e-4
+static std::string rust_f64_debug(double v) {
+  if (isnan(v) || isinf(v)) return rust_f64(v);
+  const double abs = fabs(v);
+  if (abs >= 1e16 || (abs != 0.0 && abs < 1e-4)) {
+    char buf[64];
+    for (int prec = 1; prec <= 17; prec++) {
+      snprintf(buf, sizeof(buf), "%.*e", prec - 1, v);
+      if (strtod(buf, nullptr) == v) break;
+    }
+    std::string t(buf);
+    const size_t epos = t.find('e');
+    std::string mant = t.substr(0, epos);
+    if (mant.find('.') != std::string::npos) {
+      while (mant.back() == '0') mant.pop_back();
+      if (mant.back() == '.') mant.pop_back();
+    }
+    return mant + "e" + std::to_string(atoi(t.c_str() + epos + 1));
+  }
+  std::string d = rust_f64(v);
+  if (d.find('.') == std::string::npos) d += ".0";
+  return d;
 }
 
 static std::string fixed(double v, int prec) {
@@ -396,6 +422,27 @@ class CompletenessConstraint : public Constraint {
 
 constexpr uint32_t kDefaultKllK = 200;
 
+// the value one statistic reads out of its aggregate (statistics.rs:278-308: Float64, else Int64 cast to f64);
+// false = SQL NULL.  `request` indexes the constraint's plan(): a NUMERIC_STATS request, or a KLL request for
+// Median / Percentile (APPROX_PERCENTILE_CONT in the reference, the KLL sketch here)
+static bool statistic_value(const StatisticType &st, const Constraint::Inputs &in, size_t request, double *value) {
+  const tgx_result *r = in.results[request];
+  switch (st.kind) {
+    case StatisticType::Min: *value = r->min_f; return r->has_value != 0;
+    case StatisticType::Max: *value = r->max_f; return r->has_value != 0;
+    case StatisticType::Mean: *value = r->mean; return r->has_value != 0;
+    case StatisticType::Sum: *value = r->is_float ? r->sum_f : (double)r->sum_i; return r->has_value != 0;
+    case StatisticType::StandardDeviation: *value = r->stddev_samp; return r->has_variance != 0;
+    case StatisticType::Variance: *value = r->var_samp; return r->has_variance != 0;
+    case StatisticType::Median:
+    case StatisticType::Percentile:
+      if (r->kll_n == 0) return false;
+      *value = in.quantile(in.ctx, request, st.kind == StatisticType::Median ? 0.5 : st.p);
+      return true;
+  }
+  return false;
+}
+
 // constraints/statistics.rs:174-330
 class StatisticalConstraint : public Constraint {
  public:
@@ -421,22 +468,8 @@ class StatisticalConstraint : public Constraint {
     return {r};
   }
   ConstraintResult evaluate(const Inputs &in) const override {
-    const tgx_result *r = in.results[0];
     double value = 0;
-    bool null = false;
-    switch (st_.kind) {
-      case StatisticType::Min: null = !r->has_value; value = r->min_f; break;
-      case StatisticType::Max: null = !r->has_value; value = r->max_f; break;
-      case StatisticType::Mean: null = !r->has_value; value = r->mean; break;
-      case StatisticType::Sum: null = !r->has_value; value = r->is_float ? r->sum_f : (double)r->sum_i; break;
-      case StatisticType::StandardDeviation: null = !r->has_variance; value = r->stddev_samp; break;
-      case StatisticType::Variance: null = !r->has_variance; value = r->var_samp; break;
-      case StatisticType::Median:
-      case StatisticType::Percentile:
-        null = r->kll_n == 0;
-        if (!null) value = in.quantile(in.ctx, 0, st_.kind == StatisticType::Median ? 0.5 : st_.p);
-        break;
-    }
+    const bool null = !statistic_value(st_, in, 0, &value);
     if (null) return ConstraintResult::failure(st_.name() + " is null (no non-null values)");  // statistics.rs:284-301
     if (a_.evaluate(value)) return ConstraintResult::success_with_metric(value);
     return ConstraintResult::failure_with_metric(value,
@@ -447,6 +480,66 @@ class StatisticalConstraint : public Constraint {
   std::string col_;
   StatisticType st_;
   Assertion a_;
+};
+
+// constraints/statistics.rs:376-531: several statistics of one column from ONE query; the metric of a success is the
+// first statistic's value (:498-500), failures are joined by "; " and carry no metric (:501-503)
+class MultiStatisticalConstraint : public Constraint {
+ public:
+  MultiStatisticalConstraint(std::string col, std::vector<std::pair<StatisticType, Assertion>> stats)
+      : col_(std::move(col)), stats_(std::move(stats)) {
+    require_identifier(col_);
+    for (auto &sa : stats_)
+      if (sa.first.kind == StatisticType::Percentile && !(sa.first.p >= 0.0 && sa.first.p <= 1.0))
+        throw TermError{TermError::SecurityError, "Percentile must be between 0.0 and 1.0"};  // :399-407
+    for (auto &sa : stats_) {
+      const bool q = sa.first.kind == StatisticType::Median || sa.first.kind == StatisticType::Percentile;
+      (q ? any_quantile_ : any_plain_) = true;
+      if (sa.first.kind == StatisticType::StandardDeviation || sa.first.kind == StatisticType::Variance) variance_ = true;
+    }
+  }
+  std::string name() const override { return "multi_statistical"; }
+  std::optional<std::string> column() const override { return col_; }
+  std::vector<SpecRequest> plan() const override {
+    std::vector<SpecRequest> out;
+    if (any_plain_) {
+      SpecRequest r;
+      r.kind = TGX_CHECK_NUMERIC_STATS;
+      r.column = col_;
+      r.flags = variance_ ? (uint32_t)TGX_FLAG_VARIANCE : 0u;
+      out.push_back(r);
+    }
+    if (any_quantile_) {
+      SpecRequest r;
+      r.kind = TGX_CHECK_KLL;
+      r.column = col_;
+      r.kll_k = kDefaultKllK;
+      out.push_back(r);
+    }
+    return out;
+  }
+  ConstraintResult evaluate(const Inputs &in) const override {
+    std::vector<std::string> failures;
+    std::optional<double> first_metric;
+    for (auto &sa : stats_) {
+      const bool q = sa.first.kind == StatisticType::Median || sa.first.kind == StatisticType::Percentile;
+      double value = 0;
+      if (!statistic_value(sa.first, in, q && any_plain_ ? 1 : 0, &value)) {
+        failures.push_back(sa.first.name() + " is null");  // :466-470
+        continue;
+      }
+      if (!first_metric) first_metric = value;
+      if (!sa.second.evaluate(value))
+        failures.push_back(sa.first.name() + " is " + rust_f64(value) + " which does not " + sa.second.description());
+    }
+    if (failures.empty()) return ConstraintResult::success_with_metric(first_metric ? *first_metric : 0.0);
+    return ConstraintResult::failure(join(failures, "; "));
+  }
+
+ private:
+  std::string col_;
+  std::vector<std::pair<StatisticType, Assertion>> stats_;
+  bool any_plain_ = false, any_quantile_ = false, variance_ = false;
 };
 
 // constraints/uniqueness.rs:380-860 (single-column forms)
@@ -689,12 +782,20 @@ class ApproxCountDistinctConstraint : public Constraint {
   Assertion a_;
 };
 
-// constraints/quantile.rs:228-345 (QuantileValidation::Single)
+// constraints/quantile.rs:144-497.  APPROX_PERCENTILE_CONT (DataFusion's t-digest) is the KLL sketch here: ONE
+// sketch of the column answers every quantile of the constraint (the reference already asks for all of them in one
+// query, :352-366).  Distribution / Custom have no evaluation in the reference either (:481-486).
 class QuantileConstraint : public Constraint {
  public:
-  QuantileConstraint(std::string col, double q, Assertion a) : col_(std::move(col)), q_(q), a_(a) {
+  QuantileConstraint(std::string col, QuantileValidation v) : col_(std::move(col)), v_(std::move(v)) {
     require_identifier(col_);
-    if (!(q >= 0.0 && q <= 1.0)) throw TermError{TermError::SecurityError, "Quantile must be between 0.0 and 1.0"};
+    auto in_range = [](double q) { return q >= 0.0 && q <= 1.0; };
+    for (auto &c : v_.checks)
+      if (!in_range(c.quantile)) throw TermError{TermError::Configuration, "Quantile must be between 0.0 and 1.0"};  // :47-52
+    if (v_.kind == QuantileValidation::Multiple && v_.checks.empty())
+      throw TermError{TermError::Configuration, "At least one quantile check is required"};  // :196-200
+    if (v_.kind == QuantileValidation::Single && v_.checks.size() != 1)
+      throw TermError{TermError::Internal, "a single quantile validation takes exactly one check"};
   }
   std::string name() const override { return "quantile"; }
   std::optional<std::string> column() const override { return col_; }
@@ -706,56 +807,144 @@ class QuantileConstraint : public Constraint {
     return {r};
   }
   ConstraintResult evaluate(const Inputs &in) const override {
+    if (v_.kind == QuantileValidation::Distribution || v_.kind == QuantileValidation::Custom)
+      return ConstraintResult::skipped("Validation type not yet implemented");  // :481-486
     if (in.results[0]->kll_n == 0) return ConstraintResult::skipped("No data to validate");
-    const double value = in.quantile(in.ctx, 0, q_);
-    if (a_.evaluate(value)) return ConstraintResult::success_with_metric(value);
-    return ConstraintResult::failure_with_metric(
-        value, "Quantile " + rust_f64(q_) + " is " + rust_f64(value) + " which does not " + a_.description());
+    switch (v_.kind) {
+      case QuantileValidation::Single: {  // :287-345
+        const QuantileCheck &c = v_.checks[0];
+        const double value = in.quantile(in.ctx, 0, c.quantile);
+        if (c.assertion.evaluate(value)) return ConstraintResult::success_with_metric(value);
+        return ConstraintResult::failure_with_metric(value, "Quantile " + rust_f64(c.quantile) + " is " + rust_f64(value) +
+                                                                " which does not " + c.assertion.description());
+      }
+      case QuantileValidation::Multiple: {  // :346-420
+        std::vector<std::string> failures;
+        for (const QuantileCheck &c : v_.checks) {
+          const double value = in.quantile(in.ctx, 0, c.quantile);
+          if (!c.assertion.evaluate(value))
+            failures.push_back("Q" + std::to_string((int32_t)(c.quantile * 100.0)) + " is " + rust_f64(value) +
+                               " which does not " + c.assertion.description());
+        }
+        if (failures.empty()) return ConstraintResult::success();
+        return ConstraintResult::failure(join(failures, "; "));
+      }
+      case QuantileValidation::Monotonic: {  // :421-480
+        std::vector<double> values;
+        for (double q : v_.quantiles) values.push_back(in.quantile(in.ctx, 0, q));
+        bool monotonic = true;
+        for (size_t i = 1; i < values.size() && monotonic; i++)
+          monotonic = v_.strict ? values[i] > values[i - 1] : values[i] >= values[i - 1];
+        if (monotonic) return ConstraintResult::success();
+        std::string list = "[";
+        for (size_t i = 0; i < values.size(); i++) list += (i ? ", " : "") + rust_f64_debug(values[i]);
+        return ConstraintResult::failure(std::string("Quantiles are not ") + (v_.strict ? "strictly" : "") +
+                                         " monotonic: " + list + "]");
+      }
+      default:
+        break;
+    }
+    return ConstraintResult::skipped("Validation type not yet implemented");
   }
 
  private:
   std::string col_;
-  double q_;
-  Assertion a_;
+  QuantileValidation v_;
 };
 
-// constraints/correlation.rs:299-375 (Pairwise Pearson = CORR(a, b))
+// constraints/correlation.rs:147-508.  Pearson (`CORR`), Covariance (`COVAR_SAMP`), Range (= Pairwise with Between,
+// :376-396) and Independence (`ABS(CORR) <= max`, :397-439) all read the six co-moments of one COMOMENTS request.
+// Spearman / Kendall / mutual information, MultiColumn and Stability are "not yet implemented" in the reference too
+// (:336-341, :440-442).  A Custom SQL expression cannot run on this path: NotSupported, so the caller falls back to
+// the stock SQL constraint (after the reference's own unsafe-content screen, :324-330).
 class CorrelationConstraint : public Constraint {
  public:
-  CorrelationConstraint(std::string c1, std::string c2, Assertion a) : c1_(std::move(c1)), c2_(std::move(c2)), a_(a) {
-    require_identifier(c1_);
-    require_identifier(c2_);
+  explicit CorrelationConstraint(CorrelationValidation v) : v_(std::move(v)) {
+    if (v_.kind == CorrelationValidation::MultiColumn) {
+      if (v_.columns.size() < 2)
+        throw TermError{TermError::Configuration, "At least 2 columns required for correlation analysis"};  // :178-182
+      for (auto &c : v_.columns) require_identifier(c);
+    } else {
+      require_identifier(v_.column1);
+      require_identifier(v_.column2);
+    }
+    if (v_.kind == CorrelationValidation::Independence && !(v_.max_correlation >= 0.0 && v_.max_correlation <= 1.0))
+      throw TermError{TermError::Configuration, "Max correlation must be between 0.0 and 1.0"};  // :253-257
   }
-  std::string name() const override { return "correlation"; }
+  std::string name() const override {  // :446-456
+    switch (v_.kind) {
+      case CorrelationValidation::Pairwise: return v_.type.constraint_name();
+      case CorrelationValidation::Range: return "correlation_range";
+      case CorrelationValidation::Independence: return "independence";
+      case CorrelationValidation::MultiColumn: return "multi_correlation";
+      default: return "correlation_stability";
+    }
+  }
+  bool on_device() const {
+    if (v_.kind == CorrelationValidation::Independence) return true;
+    if (v_.kind != CorrelationValidation::Pairwise && v_.kind != CorrelationValidation::Range) return false;
+    return v_.type.kind == CorrelationType::Pearson || v_.type.kind == CorrelationType::Covariance;
+  }
   std::vector<SpecRequest> plan() const override {
+    if ((v_.kind == CorrelationValidation::Pairwise || v_.kind == CorrelationValidation::Range) &&
+        v_.type.kind == CorrelationType::Custom && !custom_is_unsafe())
+      throw TermError{TermError::NotSupported, "custom correlation SQL expressions do not run on the GPU path"};
+    if (!on_device()) return {};
     SpecRequest r;
     r.kind = TGX_CHECK_COMOMENTS;
-    r.column = c1_;
-    r.column2 = c2_;
+    r.column = v_.column1;
+    r.column2 = v_.column2;
     return {r};
   }
   ConstraintResult evaluate(const Inputs &in) const override {
+    if (v_.kind == CorrelationValidation::MultiColumn || v_.kind == CorrelationValidation::Stability)
+      return ConstraintResult::skipped("Validation type not yet implemented");
+    if (v_.kind != CorrelationValidation::Independence) {
+      if (v_.type.kind == CorrelationType::Custom)
+        return ConstraintResult::failure("Custom SQL expression contains potentially unsafe content");
+      if (!on_device()) return ConstraintResult::skipped("Correlation type not yet implemented");
+    }
     const tgx_result *r = in.results[0];
     if (r->total == 0) return ConstraintResult::skipped("No data to validate");
-    // DataFusion's CORR: population covariance over the population standard deviations, 0 when either
-    // deviation is 0 (restated from the raw moments the kernel returns)
-    const double n = (double)r->non_null;
-    double value = 0.0;
-    if (n >= 1) {
-      const double cov = r->sum_xy / n - (r->sum_x / n) * (r->sum_y / n);
-      const double vx = r->sum_x2 / n - (r->sum_x / n) * (r->sum_x / n);
-      const double vy = r->sum_y2 / n - (r->sum_y / n) * (r->sum_y / n);
-      const double sx = vx > 0 ? sqrt(vx) : 0.0, sy = vy > 0 ? sqrt(vy) : 0.0;
-      value = (sx == 0.0 || sy == 0.0) ? 0.0 : cov / sx / sy;
+    if (v_.kind == CorrelationValidation::Independence) {
+      const double abs_corr = fabs(pearson(r));
+      if (abs_corr <= v_.max_correlation) return ConstraintResult::success_with_metric(abs_corr);
+      return ConstraintResult::failure_with_metric(
+          abs_corr, "Columns " + v_.column1 + " and " + v_.column2 + " have correlation " + rust_f64(abs_corr) +
+                        " exceeding independence threshold " + rust_f64(v_.max_correlation));
     }
-    if (a_.evaluate(value)) return ConstraintResult::success_with_metric(value);
-    return ConstraintResult::failure_with_metric(value, "Pearson correlation between " + c1_ + " and " + c2_ + " is " +
-                                                            rust_f64(value) + " which does not " + a_.description());
+    const Assertion a = v_.kind == CorrelationValidation::Range ? Assertion::between(v_.min, v_.max) : v_.assertion;
+    const double value = v_.type.kind == CorrelationType::Covariance ? covar_samp(r) : pearson(r);
+    if (a.evaluate(value)) return ConstraintResult::success_with_metric(value);
+    return ConstraintResult::failure_with_metric(value, v_.type.name() + " between " + v_.column1 + " and " + v_.column2 +
+                                                            " is " + rust_f64(value) + " which does not " + a.description());
   }
 
  private:
-  std::string c1_, c2_;
-  Assertion a_;
+  bool custom_is_unsafe() const {  // :324-330
+    std::string lower = v_.type.sql_expression;
+    for (auto &c : lower) c = (char)tolower((unsigned char)c);
+    return lower.find(';') != std::string::npos || lower.find("drop") != std::string::npos;
+  }
+  // DataFusion's CORR: population covariance over the population standard deviations, 0 when either deviation is
+  // 0 (restated from the raw moments the kernel returns)
+  static double pearson(const tgx_result *r) {
+    const double n = (double)r->non_null;
+    if (n < 1) return 0.0;
+    const double cov = r->sum_xy / n - (r->sum_x / n) * (r->sum_y / n);
+    const double vx = r->sum_x2 / n - (r->sum_x / n) * (r->sum_x / n);
+    const double vy = r->sum_y2 / n - (r->sum_y / n) * (r->sum_y / n);
+    const double sx = vx > 0 ? sqrt(vx) : 0.0, sy = vy > 0 ? sqrt(vy) : 0.0;
+    return (sx == 0.0 || sy == 0.0) ? 0.0 : cov / sx / sy;
+  }
+  // COVAR_SAMP = (Sxy - Sx Sy / n) / (n - 1); SQL NULL below two rows, which the reference reads as the raw slot
+  // value (`value(0)` without a null check, :355-362 -- unpinned): 0.0 here
+  static double covar_samp(const tgx_result *r) {
+    const double n = (double)r->non_null;
+    if (n < 2) return 0.0;
+    return (r->sum_xy - r->sum_x * r->sum_y / n) / (n - 1.0);
+  }
+  CorrelationValidation v_;
 };
 
 }  // namespace
@@ -887,10 +1076,48 @@ Check::Builder &Check::Builder::contains_ssn(std::string column, double threshol
   return has_format(std::move(column), ft(FormatType::SocialSecurityNumber), threshold, trimming());
 }
 Check::Builder &Check::Builder::has_approx_quantile(std::string column, double quantile, Assertion a) {
-  return constraint(std::make_shared<QuantileConstraint>(std::move(column), quantile, a));
+  QuantileValidation v;
+  v.kind = QuantileValidation::Single;
+  v.checks.push_back({quantile, a});
+  return quantile_validation(std::move(column), std::move(v));
 }
 Check::Builder &Check::Builder::has_correlation(std::string c1, std::string c2, Assertion a) {
-  return constraint(std::make_shared<CorrelationConstraint>(std::move(c1), std::move(c2), a));
+  CorrelationValidation v;
+  v.kind = CorrelationValidation::Pairwise;
+  v.column1 = std::move(c1);
+  v.column2 = std::move(c2);
+  v.assertion = a;
+  return correlation(std::move(v));
+}
+Check::Builder &Check::Builder::multi_statistic(std::string column, std::vector<std::pair<StatisticType, Assertion>> st) {
+  return constraint(std::make_shared<MultiStatisticalConstraint>(std::move(column), std::move(st)));
+}
+Check::Builder &Check::Builder::quantile_validation(std::string column, QuantileValidation v) {
+  return constraint(std::make_shared<QuantileConstraint>(std::move(column), std::move(v)));
+}
+Check::Builder &Check::Builder::correlation(CorrelationValidation v) {
+  return constraint(std::make_shared<CorrelationConstraint>(std::move(v)));
+}
+
+std::string CorrelationType::name() const {
+  switch (kind) {
+    case Pearson: return "Pearson correlation";
+    case Spearman: return "Spearman correlation";
+    case KendallTau: return "Kendall's tau";
+    case MutualInformation: return "mutual information";
+    case Covariance: return "covariance";
+    default: return "custom correlation";
+  }
+}
+std::string CorrelationType::constraint_name() const {
+  switch (kind) {
+    case Pearson: return "correlation";
+    case Spearman: return "spearman_correlation";
+    case KendallTau: return "kendall_correlation";
+    case MutualInformation: return "mutual_information";
+    case Covariance: return "covariance";
+    default: return "custom_correlation";
+  }
 }
 
 bool ValidationReport::has_errors() const {
@@ -1217,6 +1444,24 @@ static LogicalOperator operator_from(const json::Value *v) {
   throw TermError{TermError::Internal, "malformed operator"};
 }
 
+static StatisticType statistic_from(const std::string &s, double p) {
+  static const char *const names[] = {"min", "max", "mean", "sum", "standard_deviation", "variance", "median", "percentile"};
+  StatisticType st;
+  int k = -1;
+  for (int i = 0; i < 8; i++)
+    if (s == names[i]) k = i;
+  if (k < 0) throw TermError{TermError::Internal, "unknown statistic '" + s + "'"};
+  st.kind = (StatisticType::Kind)k;
+  st.p = p;
+  return st;
+}
+
+static const json::Value *need(const json::Value &c, const char *key) {
+  const json::Value *v = c.get(key);
+  if (!v) throw TermError{TermError::Internal, std::string("constraint JSON is missing '") + key + "'"};
+  return v;
+}
+
 void add_constraint_from_json(Check::Builder &b, const json::Value &c) {
   const std::string type = c.get_str("type");
   if (type == "size") {
@@ -1229,16 +1474,8 @@ void add_constraint_from_json(Check::Builder &b, const json::Value &c) {
     o.threshold = c.get_num("threshold", 1.0);
     b.completeness(strings_from(c.get("columns")), o);
   } else if (type == "statistic") {
-    static const char *const names[] = {"min", "max", "mean", "sum", "standard_deviation", "variance", "median", "percentile"};
-    StatisticType st;
-    const std::string s = c.get_str("statistic");
-    int k = -1;
-    for (int i = 0; i < 8; i++)
-      if (s == names[i]) k = i;
-    if (k < 0) throw TermError{TermError::Internal, "unknown statistic '" + s + "'"};
-    st.kind = (StatisticType::Kind)k;
-    st.p = c.get_num("p", 0.5);
-    b.statistic(c.get_str("column"), st, assertion_from(*c.get("assertion")));
+    b.statistic(c.get_str("column"), statistic_from(c.get_str("statistic"), c.get_num("p", 0.5)),
+                assertion_from(*need(c, "assertion")));
   } else if (type == "uniqueness") {
     UniquenessType t;
     const std::string k = c.get_str("kind", "full_uniqueness");
@@ -1280,10 +1517,61 @@ void add_constraint_from_json(Check::Builder &b, const json::Value &c) {
       o.null_is_valid = ov->get_bool("null_is_valid", true);
     }
     b.has_format(c.get_str("column"), f, c.get_num("threshold", 1.0), o);
+  } else if (type == "multi_statistic") {
+    std::vector<std::pair<StatisticType, Assertion>> stats;
+    if (const json::Value *sv = c.get("statistics"))
+      for (const json::Value &e : sv->arr)
+        stats.emplace_back(statistic_from(e.get_str("statistic"), e.get_num("p", 0.5)), assertion_from(*need(e, "assertion")));
+    b.multi_statistic(c.get_str("column"), std::move(stats));
   } else if (type == "quantile") {
-    b.has_approx_quantile(c.get_str("column"), c.get_num("quantile", 0.5), assertion_from(*c.get("assertion")));
+    QuantileValidation v;
+    const std::string k = c.get_str("validation", "single");
+    if (k == "single") {
+      v.kind = QuantileValidation::Single;
+      v.checks.push_back({c.get_num("quantile", 0.5), assertion_from(*need(c, "assertion"))});
+    } else if (k == "multiple") {
+      v.kind = QuantileValidation::Multiple;
+      if (const json::Value *cv = c.get("checks"))
+        for (const json::Value &e : cv->arr) v.checks.push_back({e.get_num("quantile", 0.5), assertion_from(*need(e, "assertion"))});
+    } else if (k == "monotonic") {
+      v.kind = QuantileValidation::Monotonic;
+      v.strict = c.get_bool("strict");
+      if (const json::Value *qv = c.get("quantiles"))
+        for (const json::Value &e : qv->arr)
+          if (e.is(json::Value::Number)) v.quantiles.push_back(e.num);
+    } else if (k == "distribution") {
+      v.kind = QuantileValidation::Distribution;
+    } else if (k == "custom") {
+      v.kind = QuantileValidation::Custom;
+    } else {
+      throw TermError{TermError::Internal, "unknown quantile validation '" + k + "'"};
+    }
+    b.quantile_validation(c.get_str("column"), std::move(v));
   } else if (type == "correlation") {
-    b.has_correlation(c.get_str("column1"), c.get_str("column2"), assertion_from(*c.get("assertion")));
+    CorrelationValidation v;
+    const std::string k = c.get_str("validation", "pairwise");
+    if (k == "pairwise") v.kind = CorrelationValidation::Pairwise;
+    else if (k == "range") v.kind = CorrelationValidation::Range;
+    else if (k == "independence") v.kind = CorrelationValidation::Independence;
+    else if (k == "multi_column") v.kind = CorrelationValidation::MultiColumn;
+    else if (k == "stability") v.kind = CorrelationValidation::Stability;
+    else throw TermError{TermError::Internal, "unknown correlation validation '" + k + "'"};
+    static const char *const types[] = {"pearson", "spearman", "kendall_tau", "mutual_information", "covariance", "custom"};
+    const std::string t = c.get_str("correlation_type", "pearson");
+    int ti = -1;
+    for (int i = 0; i < 6; i++)
+      if (t == types[i]) ti = i;
+    if (ti < 0) throw TermError{TermError::Internal, "unknown correlation type '" + t + "'"};
+    v.type.kind = (CorrelationType::Kind)ti;
+    v.type.sql_expression = c.get_str("sql_expression");
+    v.column1 = c.get_str("column1");
+    v.column2 = c.get_str("column2");
+    v.columns = strings_from(c.get("columns"));
+    if (v.kind == CorrelationValidation::Pairwise) v.assertion = assertion_from(*need(c, "assertion"));
+    v.min = c.get_num("min", 0.0);
+    v.max = c.get_num("max", 0.0);
+    v.max_correlation = c.get_num("max_correlation", 0.0);
+    b.correlation(std::move(v));
   } else {
     throw TermError{TermError::Internal, "unknown constraint type '" + type + "'"};
   }

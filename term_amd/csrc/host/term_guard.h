@@ -46,7 +46,7 @@ struct ConstraintResult {
 
 // TermError (error.rs:14-145): only the variants this path produces
 struct TermError {
-  enum Kind { Internal, SecurityError, DataFusion, NotSupported } kind = Internal;
+  enum Kind { Internal, SecurityError, DataFusion, NotSupported, Configuration } kind = Internal;
   std::string message;
   std::string display() const;  // thiserror Display strings, e.g. "Security error: ..."
 };
@@ -114,6 +114,35 @@ struct StatisticType {
   double p = 0.5;
   std::string name() const;             // "minimum", ...
   std::string constraint_name() const;  // "min", ...
+};
+
+// ---- constraints/quantile.rs:36-112
+struct QuantileCheck {
+  double quantile = 0.5;
+  Assertion assertion = Assertion::equals(0);
+};
+struct QuantileValidation {
+  enum Kind { Single, Multiple, Distribution, Monotonic, Custom } kind = Single;
+  std::vector<QuantileCheck> checks;  // Single: one entry; Multiple: one per quantile
+  std::vector<double> quantiles;      // Monotonic
+  bool strict = false;                // Monotonic
+};
+
+// ---- constraints/correlation.rs:19-117
+struct CorrelationType {
+  enum Kind { Pearson, Spearman, KendallTau, MutualInformation, Covariance, Custom } kind = Pearson;
+  std::string sql_expression;        // Custom
+  std::string name() const;             // "Pearson correlation", ...  (:39-48)
+  std::string constraint_name() const;  // "correlation", ...          (:51-60)
+};
+struct CorrelationValidation {
+  enum Kind { Pairwise, Range, MultiColumn, Independence, Stability } kind = Pairwise;
+  std::string column1, column2;
+  CorrelationType type;                       // Pairwise / Range
+  Assertion assertion = Assertion::equals(0);  // Pairwise
+  double min = 0, max = 0;                    // Range
+  double max_correlation = 0;                 // Independence
+  std::vector<std::string> columns;           // MultiColumn (needs >= 2)
 };
 
 // One aggregate a constraint needs; the suite runner resolves column names and fuses all requests.
@@ -244,6 +273,12 @@ class Check::Builder {
   // check.rs:414 / :478
   Builder &has_approx_quantile(std::string column, double quantile, Assertion a);
   Builder &has_correlation(std::string column1, std::string column2, Assertion a);
+  // the unified constraints handed to CheckBuilder::constraint(..) in the reference (core/check.rs:263):
+  // MultiStatisticalConstraint::new (constraints/statistics.rs:377-417), QuantileConstraint::new / ::multiple
+  // (constraints/quantile.rs:159-216), CorrelationConstraint::new / ::independence (constraints/correlation.rs:156-263)
+  Builder &multi_statistic(std::string column, std::vector<std::pair<StatisticType, Assertion>> statistics);
+  Builder &quantile_validation(std::string column, QuantileValidation validation);
+  Builder &correlation(CorrelationValidation validation);
   Check build() { return check_; }
 
  private:

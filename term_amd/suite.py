@@ -263,8 +263,116 @@ class CheckBuilder:
     def has_correlation(self, column1, column2, assertion):
         return self._add(type="correlation", column1=column1, column2=column2, assertion=assertion.to_json())
 
+    def constraint(self, c):
+        """core/check.rs:263: a constraint object (MultiStatisticalConstraint, QuantileConstraint,
+        CorrelationConstraint below) instead of a builder shorthand"""
+        return self._add(**c.spec)
+
     def build(self):
         return Check(self._c)
+
+
+class StatisticType:
+    """constraints/statistics.rs:24-43"""
+    Min, Max, Mean, Sum = "min", "max", "mean", "sum"
+    StandardDeviation, Variance, Median = "standard_deviation", "variance", "median"
+
+    @staticmethod
+    def Percentile(p): return ("percentile", p)
+
+
+class MultiStatisticalConstraint:
+    """constraints/statistics.rs:376-417: `statistics` = [(StatisticType, Assertion), ...] of one column"""
+
+    def __init__(self, column, statistics):
+        stats = []
+        for st, a in statistics:
+            name, p = st if isinstance(st, tuple) else (st, 0.5)
+            stats.append({"statistic": name, "p": p, "assertion": a.to_json()})
+        self.spec = {"type": "multi_statistic", "column": column, "statistics": stats}
+
+
+class QuantileCheck:
+    """constraints/quantile.rs:36-58"""
+
+    def __init__(self, quantile, assertion):
+        self.quantile, self.assertion = quantile, assertion
+
+    def to_json(self):
+        return {"quantile": self.quantile, "assertion": self.assertion.to_json()}
+
+
+class QuantileConstraint:
+    """constraints/quantile.rs:144-225 (QuantileValidation::Single / Multiple / Monotonic / Distribution / Custom)"""
+
+    def __init__(self, column, **spec):
+        self.spec = dict(type="quantile", column=column, **spec)
+
+    @staticmethod
+    def median(column, assertion):
+        return QuantileConstraint.percentile(column, 0.5, assertion)
+
+    @staticmethod
+    def percentile(column, quantile, assertion):
+        return QuantileConstraint(column, validation="single", quantile=quantile, assertion=assertion.to_json())
+
+    @staticmethod
+    def multiple(column, checks):
+        return QuantileConstraint(column, validation="multiple", checks=[c.to_json() for c in checks])
+
+    @staticmethod
+    def monotonic(column, quantiles, strict):
+        return QuantileConstraint(column, validation="monotonic", quantiles=list(quantiles), strict=bool(strict))
+
+    @staticmethod
+    def distribution(column):
+        return QuantileConstraint(column, validation="distribution")
+
+
+class CorrelationType:
+    """constraints/correlation.rs:19-36"""
+    Pearson, Spearman, KendallTau = "pearson", "spearman", "kendall_tau"
+    MutualInformation, Covariance, Custom = "mutual_information", "covariance", "custom"
+
+
+class CorrelationConstraint:
+    """constraints/correlation.rs:147-263 (CorrelationValidation::Pairwise / Range / Independence / MultiColumn /
+    Stability)"""
+
+    def __init__(self, **spec):
+        self.spec = dict(type="correlation", **spec)
+
+    @staticmethod
+    def pairwise(column1, column2, correlation_type, assertion, sql_expression=""):
+        return CorrelationConstraint(validation="pairwise", column1=column1, column2=column2,
+                                     correlation_type=correlation_type, assertion=assertion.to_json(),
+                                     sql_expression=sql_expression)
+
+    @staticmethod
+    def pearson(column1, column2, assertion):
+        return CorrelationConstraint.pairwise(column1, column2, CorrelationType.Pearson, assertion)
+
+    @staticmethod
+    def spearman(column1, column2, assertion):
+        return CorrelationConstraint.pairwise(column1, column2, CorrelationType.Spearman, assertion)
+
+    @staticmethod
+    def covariance(column1, column2, assertion):
+        return CorrelationConstraint.pairwise(column1, column2, CorrelationType.Covariance, assertion)
+
+    @staticmethod
+    def range(column1, column2, correlation_type, min, max):
+        return CorrelationConstraint(validation="range", column1=column1, column2=column2,
+                                     correlation_type=correlation_type, min=min, max=max)
+
+    @staticmethod
+    def independence(column1, column2, max_correlation):
+        return CorrelationConstraint(validation="independence", column1=column1, column2=column2,
+                                     max_correlation=max_correlation)
+
+    @staticmethod
+    def multi_column(columns, correlation_type=CorrelationType.Pearson):
+        return CorrelationConstraint(validation="multi_column", columns=list(columns), correlation_type=correlation_type)
 
 
 class Check:

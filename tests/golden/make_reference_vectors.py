@@ -304,7 +304,83 @@ assertion = [
     dict(kind="not_between", args=[10.0, 20.0], value=15.0, ok=False, text="not between 10 and 20"),
 ]
 
-out = dict(completeness=completeness, statistics=statistics, uniqueness=uniqueness,
+# ---- the unified constraints' own unit tests: MultiStatisticalConstraint, QuantileConstraint (Single / Multiple /
+# Monotonic), CorrelationConstraint (Pairwise / Range / Independence).  `constraint` is the suite-JSON form of the
+# constructor call the test makes (term_amd/suite.py); `table` the columns its fixture registers.
+_x = [float(i) for i in range(100)]
+_corr = dict(x=_x, y=[2.0 * i + (i % 10) - 5.0 for i in range(100)])      # constraints/correlation.rs:520-552
+_indep = dict(x=_x, y=[float((i * 37) % 100) for i in range(100)])          # constraints/correlation.rs:554-584
+_q100 = dict(value=[float(i) for i in range(1, 101)])                       # constraints/quantile.rs:529-530
+
+
+def _a(kind, *args):
+    return dict(kind=kind, args=list(args))
+
+
+constraint_variants = [
+    dict(ref="constraints/statistics.rs:642-662", table=dict(value=[10.0, 20.0, 30.0, 40.0]),
+         constraint=dict(type="multi_statistic", column="value", statistics=[
+             dict(statistic="min", p=0.5, assertion=_a("greater_than_or_equal", 10.0)),
+             dict(statistic="max", p=0.5, assertion=_a("less_than_or_equal", 40.0)),
+             dict(statistic="mean", p=0.5, assertion=_a("equals", 25.0)),
+             dict(statistic="sum", p=0.5, assertion=_a("equals", 100.0))]),
+         status="success", name="multi_statistical"),
+    dict(ref="constraints/statistics.rs:664-682", table=dict(value=[10.0, 20.0, 30.0]),
+         constraint=dict(type="multi_statistic", column="value", statistics=[
+             dict(statistic="min", p=0.5, assertion=_a("equals", 5.0)),
+             dict(statistic="max", p=0.5, assertion=_a("equals", 30.0))]),
+         status="failure", message_contains="minimum is 10", name="multi_statistical"),
+    dict(ref="constraints/quantile.rs:527-539", table=_q100,
+         constraint=dict(type="quantile", column="value", validation="single", quantile=0.5,
+                         assertion=_a("between", 45.0, 55.0)),
+         status="success", name="quantile"),
+    dict(ref="constraints/quantile.rs:541-553", table=_q100,
+         constraint=dict(type="quantile", column="value", validation="single", quantile=0.95,
+                         assertion=_a("between", 94.0, 96.0)),
+         status="success", name="quantile"),
+    dict(ref="constraints/quantile.rs:555-573", table=_q100,
+         constraint=dict(type="quantile", column="value", validation="multiple", checks=[
+             dict(quantile=0.25, assertion=_a("between", 24.0, 26.0)),
+             dict(quantile=0.75, assertion=_a("between", 74.0, 76.0))]),
+         status="success", name="quantile"),
+    dict(ref="constraints/quantile.rs:575-593", table=_q100,
+         constraint=dict(type="quantile", column="value", validation="monotonic", quantiles=[0.1, 0.5, 0.9],
+                         strict=True),
+         status="success", name="quantile"),
+    dict(ref="constraints/correlation.rs:586-598", table=_corr,
+         constraint=dict(type="correlation", validation="pairwise", correlation_type="pearson", column1="x",
+                         column2="y", assertion=_a("greater_than", 0.9)),
+         status="success", metric_gt=0.9, name="correlation"),
+    dict(ref="constraints/correlation.rs:600-612", table=_indep,
+         constraint=dict(type="correlation", validation="independence", column1="x", column2="y",
+                         max_correlation=0.3),
+         status="success", name="independence"),
+    dict(ref="constraints/correlation.rs:614-631", table=_corr,
+         constraint=dict(type="correlation", validation="range", correlation_type="pearson", column1="x",
+                         column2="y", min=0.8, max=1.0),
+         status="success", name="correlation_range"),
+]
+# constructor errors the same tests pin (text of the TermError)
+constraint_variant_errors = [
+    dict(ref="constraints/quantile.rs:595-603",
+         constraint=dict(type="quantile", column="value", validation="single", quantile=1.5,
+                         assertion=_a("less_than", 100.0)),
+         error_contains="Quantile must be between 0.0 and 1.0"),
+    dict(ref="constraints/correlation.rs:633-641",
+         constraint=dict(type="correlation", validation="independence", column1="x", column2="y",
+                         max_correlation=1.5),
+         error_contains="Max correlation must be between 0.0 and 1.0"),
+    dict(ref="constraints/correlation.rs:656-668",
+         constraint=dict(type="correlation", validation="multi_column", columns=["a"], correlation_type="pearson"),
+         error_contains="At least 2 columns required"),
+    dict(ref="constraints/statistics.rs:684-699",
+         constraint=dict(type="statistic", column="value", statistic="percentile", p=1.5,
+                         assertion=_a("less_than", 100.0)),
+         error_contains="Percentile must be between 0.0 and 1.0"),
+]
+
+out = dict(constraint_variants=constraint_variants, constraint_variant_errors=constraint_variant_errors,
+           completeness=completeness, statistics=statistics, uniqueness=uniqueness,
            uniqueness_multi=uniqueness_multi, length=length, containment=containment, approx_count_distinct=approx_count_distinct, format=fmt,
            patterns=patterns, analyzers=analyzers, correlation=correlation, kll=kll, assertion=assertion)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")

@@ -162,6 +162,54 @@ def make_users_csv(n):
     return buf.getvalue()
 
 
+def test_constraint_variant_vectors_end_to_end(golden):
+    """MultiStatisticalConstraint, QuantileConstraint (Single / Multiple / Monotonic) and CorrelationConstraint
+    (Pairwise / Range / Independence): the reference's unit tests (statistics.rs:642-682, quantile.rs:527-593,
+    correlation.rs:586-631) through ValidationSuite.run on the device"""
+
+    class Raw:  # CheckBuilder.constraint() takes any object with a `.spec`
+        def __init__(self, spec): self.spec = spec
+
+    for case in golden["constraint_variants"]:
+        tbl = arrow_table(**{c: (pa.float64(), v) for c, v in case["table"].items()})
+        r = (ValidationSuite.builder("s").check(Check.builder("chk").level(Level.ERROR)
+                                                .constraint(Raw(case["constraint"])).build()).build()).run(tbl)
+        m = r.report.metrics
+        if case["status"] == "success":
+            assert r.is_success() and m.passed_checks == 1, (case["ref"], r.to_json())
+            if "metric_gt" in case:
+                assert m.custom_metrics["chk." + case["name"]] > case["metric_gt"]
+        else:
+            assert r.is_failure() and m.failed_checks == 1, case["ref"]
+            assert r.report.issues[0].constraint_name == case["name"]
+            assert case["message_contains"] in r.report.issues[0].message
+    # all variants in ONE suite over one table: the KLL sketch and the co-moments are planned once
+    x = np.arange(1000, dtype=np.float64)
+    tbl = arrow_table(x=(pa.float64(), x), y=(pa.float64(), 2 * x + (np.arange(1000) % 10) - 5.0))
+    from term_amd.suite import (CorrelationConstraint, CorrelationType, MultiStatisticalConstraint, QuantileCheck,
+                                QuantileConstraint, StatisticType)
+    A = Assertion
+    chk = (Check.builder("chk").level(Level.ERROR)
+           .constraint(MultiStatisticalConstraint("x", [(StatisticType.Mean, A.Equals(499.5)), (StatisticType.Max, A.Equals(999)),
+                                                        (StatisticType.Median, A.Between(480, 520)),
+                                                        (StatisticType.StandardDeviation, A.Between(288, 289))]))
+           .constraint(QuantileConstraint.multiple("x", [QuantileCheck(0.25, A.Between(240, 260)),
+                                                         QuantileCheck(0.75, A.Between(740, 760))]))
+           .constraint(QuantileConstraint.monotonic("x", [0.1, 0.5, 0.9], True))
+           .constraint(CorrelationConstraint.covariance("x", "y", A.GreaterThan(0)))
+           .constraint(CorrelationConstraint.range("x", "y", CorrelationType.Pearson, 0.99, 1.0))
+           .constraint(CorrelationConstraint.independence("x", "y", 0.5))
+           .constraint(CorrelationConstraint.spearman("x", "y", A.GreaterThan(0))).build())
+    r = ValidationSuite.builder("s").check(chk).build().run(tbl)
+    m = r.report.metrics
+    assert (m.total_checks, m.passed_checks, m.failed_checks, m.skipped_checks) == (7, 5, 1, 1), r.to_json()
+    assert m.custom_metrics["chk.multi_statistical"] == 499.5  # the first statistic
+    st = orc.comoments(x, 2 * x + (np.arange(1000) % 10) - 5.0)
+    assert abs(m.custom_metrics["chk.covariance"] - orc.covariance(st)) <= 1e-9 * abs(orc.covariance(st))
+    (issue,) = r.report.issues
+    assert issue.constraint_name == "independence" and "exceeding independence threshold 0.5" in issue.message
+
+
 def test_config1_users_csv_plumbing():
     """BASELINE.json configs[0]: is_complete + has_min on a 10 k-row users.csv (host buffers in, verdict out)"""
     import pyarrow.csv as pcsv
