@@ -37,8 +37,11 @@ def build_suite(T, spec, layout, unique_cols):
 
 
 def cpu_baseline(torch, layout, unique_cols, table, sample_rows):
-    """The oracle (a scalar port of the reference semantics -- NOT term-guard itself, which cannot be built
-    here) timed on one host core over the first `sample_rows` rows of the same table."""
+    """The proxy CPU baseline of SURVEY.md section 8d: the oracle's restatement of the reference semantics (NOT
+    term-guard itself, which cannot be built here: no cargo / crates) on ALL host cores -- row-range partitions,
+    one pass per constraint, hash-set COUNT(DISTINCT) re-partitioned by owner, merge in partition order
+    (oracle/suite_mt.c) -- over the first `sample_rows` rows of the same table; the single-thread figure of the same
+    code is reported beside it (on a quarter of the sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_binding as orc
@@ -48,17 +51,28 @@ def cpu_baseline(torch, layout, unique_cols, table, sample_rows):
         v = vals[:sample_rows].cpu().numpy()
         b = None if validity is None else validity[: (sample_rows + 7) // 8 + 8].cpu().numpy()
         host.append((np.ascontiguousarray(v), b))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    best, runs = None, 0
+    t_all = time.perf_counter()
+    while runs < 5 and (runs == 0 or time.perf_counter() - t_all < 8.0):  # a many-core host finishes in < 1 s: repeat
+        t0 = time.perf_counter()
+        counts, stats, dist = orc.suite_mt(host, list(unique_cols), sample_rows, cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        runs += 1
+    ok = all(c.total == sample_rows for c in counts) and dist[0].distinct == dist[0].non_null  # ids are unique
+    one_rows = max(1 << 20, sample_rows // 4)
     t0 = time.perf_counter()
-    for ci, (v, b) in enumerate(host):
-        orc.count(b, sample_rows)  # completeness: one scan per constraint, as the reference does
-        orc.stats(v, b, n=sample_rows)
-    for ci in unique_cols:
-        v, b = host[ci]
-        orc.distinct_bits64(v.view(np.uint64), b, n=sample_rows)
-    dt = time.perf_counter() - t0
-    return {"value": sample_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": "first %d rows x %d cols of the same table, oracle/tgx_oracle.c single thread, %.1f s"
-                      % (sample_rows, len(layout), dt)}
+    orc.suite_mt(host, list(unique_cols), one_rows, 1)
+    dt1 = time.perf_counter() - t0
+    return {"value": sample_rows / best, "unit": "rows/s", "cores": cores, "kind": "port",
+            "single_thread_value": one_rows / dt1, "verified": bool(ok),
+            "sample": "first %d rows x %d cols of the same table, oracle/suite_mt.c on %d threads (best of %d runs, "
+                      "%.2f s each); single thread on the first %d rows (%.1f s)"
+                      % (sample_rows, len(layout), cores, runs, best, one_rows, dt1)}
 
 
 def main():

@@ -70,6 +70,20 @@ typedef struct {
 /* 64-bit fixed width keys compared by bit pattern (int64, and float64 as DataFusion hashes it) */
 int orc_distinct_bits64(const uint64_t *bits, const uint8_t *validity, int64_t offset, int64_t n,
                         orc_distinct_t *out);
+/* ---- the null + range + unique suite on T threads (suite_mt.c): what bench.py's cpu_baseline times.
+ * Row-range partitions, per-partition partial states, hash-set COUNT(DISTINCT) re-partitioned by owner, merge in
+ * partition order -- the shape DataFusion gives the reference's per-constraint queries (TG/core/suite.rs:67-100,
+ * TG/analyzers/traits.rs:160-170).  counts / stats: one per column; distinct: one per entry of unique_cols.
+ * Returns 0, -1 on allocation failure. */
+typedef struct {
+  const void *values;       /* int64 or float64, 8 bytes per row */
+  const uint8_t *validity;  /* NULL = no nulls */
+  int32_t is_float;
+  int32_t reserved;
+} orc_suite_column_t;
+int orc_suite_mt(const orc_suite_column_t *cols, int32_t n_cols, const int32_t *unique_cols, int32_t n_unique,
+                 int64_t n, int32_t n_threads, orc_count_t *counts, orc_stats_t *stats, orc_distinct_t *distinct);
+
 /* Utf8 (int32 offsets). */
 int orc_distinct_utf8(const int32_t *offsets, const uint8_t *data, const uint8_t *validity,
                       int64_t offset, int64_t n, orc_distinct_t *out);

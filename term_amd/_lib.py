@@ -375,7 +375,12 @@ class State:
         arr = (_Column * max(1, len(cols)))(*[c.c if c is not None else _Column() for c in cols])
         err = _Error()
         _check(lib().tgx_update(self.plan.h, self.h, arr, len(cols), C.byref(err)), err)
-        self._keep = cols  # device buffers must outlive the asynchronous kernels
+        # DEVICE buffers must outlive the asynchronous kernels of EVERY batch queued since the last finalize / sync
+        # (include/tgx.h): a streamed `update(b1); del b1; update(b2)` would otherwise hand b1's memory back to the
+        # allocator while the scan of b1 is still reading it
+        if getattr(self, "_keep", None) is None:
+            self._keep = []
+        self._keep.append(cols)
 
     def finalize(self):
         res = (Result * max(1, self.plan.n))()
@@ -387,10 +392,12 @@ class State:
     def sync(self):
         err = _Error()
         _check(lib().tgx_state_sync(self.h, C.byref(err)), err)
+        self._keep = None
 
     def reset(self):
         err = _Error()
-        _check(lib().tgx_state_reset(self.plan.h, self.h, C.byref(err)), err)
+        _check(lib().tgx_state_reset(self.plan.h, self.h, C.byref(err)), err)  # waits for the stream
+        self._keep = None
 
     def merge(self, others):
         hs = (C.c_void_p * max(1, len(others)))(*[o.h for o in others])

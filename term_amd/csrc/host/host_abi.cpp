@@ -52,8 +52,12 @@ extern "C" tgx_status tgx_host_run_suite_json(const char *suite_json, const char
     return TGX_OK;
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
   } catch (const std::exception &e) {
     return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }
 
@@ -86,6 +90,12 @@ extern "C" tgx_status tgx_host_constraint_plan_json(const char *constraint_json,
     return TGX_OK;
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }
 
@@ -168,16 +178,22 @@ extern "C" tgx_status tgx_host_constraint_verdict_json(const char *constraint_js
     return TGX_OK;
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
   } catch (const std::exception &e) {
     return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }
 
-extern "C" tgx_status tgx_host_validate_identifier(const char *identifier, tgx_error *err) {
+extern "C" tgx_status tgx_host_validate_identifier(const char *identifier, tgx_error *err) try {
   if (!identifier) return hfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
   auto e = validate_identifier(identifier);
   if (e) return hfail(err, TGX_INVALID_ARGUMENT, e->display());
   return TGX_OK;
+} catch (...) {
+  return hfail(err, TGX_INTERNAL, "C++ exception while validating the identifier");
 }
 
 namespace term_guard {
@@ -214,6 +230,12 @@ extern "C" tgx_status tgx_host_assertion_json(const char *assertion_json, double
     return TGX_OK;
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }
 
@@ -252,8 +274,12 @@ extern "C" tgx_status tgx_host_run_analysis_json(const char *analysis_json, cons
     return hfail(err, TGX_INVALID_ARGUMENT, e.text);
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
   } catch (const std::exception &e) {
     return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }
 
@@ -271,6 +297,12 @@ extern "C" tgx_status tgx_host_merge_states_json(const char *analyzer_json, cons
     return hfail(err, TGX_INVALID_ARGUMENT, e.text);
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }
 
@@ -286,5 +318,11 @@ extern "C" tgx_status tgx_host_metric_from_state_json(const char *analyzer_json,
     return hfail(err, TGX_INVALID_ARGUMENT, e.text);
   } catch (const TermError &e) {
     return hfail(err, TGX_INVALID_ARGUMENT, e.display());
+  } catch (const std::bad_alloc &) {
+    return hfail(err, TGX_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
+  } catch (const std::exception &e) {
+    return hfail(err, TGX_INTERNAL, e.what());
+  } catch (...) {
+    return hfail(err, TGX_INTERNAL, "unknown C++ exception");
   }
 }

@@ -2,10 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <deque>
 #include <map>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -15,6 +18,27 @@
 #include "kll_host.h"
 
 namespace tgx {
+
+// "nothing throws across the boundary" (include/tgx.h): every extern "C" entry point is a function-try-block whose
+// handler lands here (std::bad_alloc from a host container, std::out_of_range, ...)
+inline tgx_status abi_exception(tgx_error *err) {
+  tgx_status code = TGX_INTERNAL;
+  const char *what = "unknown C++ exception";
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    code = TGX_OUT_OF_MEMORY;
+    what = "host allocation failed (std::bad_alloc)";
+  } catch (const std::exception &e) {
+    what = e.what();
+  } catch (...) {
+  }
+  if (err) {
+    err->code = (int32_t)code;
+    snprintf(err->msg, sizeof(err->msg), "%s", what);
+  }
+  return code;
+}
 
 // ---- kernel launchers (defined in kernels/*.hip) ----------------------------------------------
 void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set, hipStream_t stream);

@@ -212,7 +212,7 @@ static tgx_status kll_slot(const tgx_plan *plan, tgx_state *st, size_t spec_inde
 using namespace tgx;
 
 extern "C" tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *st, size_t spec_index, double phi,
-                                       double *out, tgx_error *err) {
+                                       double *out, tgx_error *err) try {
   int slot = 0;
   tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
   if (s != TGX_OK) return s;
@@ -222,11 +222,13 @@ extern "C" tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *st, size
   if (rc == 1) return kfail(err, TGX_INVALID_ARGUMENT, "Cannot compute quantile on empty sketch");
   if (rc == 2) return kfail(err, TGX_INVALID_ARGUMENT, "Quantile phi must be in [0, 1], got %g", phi);
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" tgx_status tgx_kll_summary(const tgx_plan *plan, tgx_state *st, size_t spec_index, uint64_t *n,
                                       double *min_value, double *max_value, uint64_t *num_levels,
-                                      uint64_t *num_retained, tgx_error *err) {
+                                      uint64_t *num_retained, tgx_error *err) try {
   int slot = 0;
   tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
   if (s != TGX_OK) return s;
@@ -237,11 +239,13 @@ extern "C" tgx_status tgx_kll_summary(const tgx_plan *plan, tgx_state *st, size_
   if (num_levels) *num_levels = h.levels.size();
   if (num_retained) *num_retained = h.retained();
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" tgx_status tgx_kll_level_items(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                           uint64_t level, double *out, uint64_t cap, uint64_t *count,
-                                          tgx_error *err) {
+                                          tgx_error *err) try {
   int slot = 0;
   tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
   if (s != TGX_OK) return s;
@@ -251,6 +255,8 @@ extern "C" tgx_status tgx_kll_level_items(const tgx_plan *plan, tgx_state *st, s
   if (out)
     for (uint64_t i = 0; i < c && i < cap; i++) out[i] = h.levels[level][i];
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" double tgx_kll_relative_error_bound(uint32_t k) { return 1.65 / sqrt((double)k); }

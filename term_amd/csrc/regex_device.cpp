@@ -358,16 +358,18 @@ tgx_status regex_deserialize(tgx_state *st, const uint8_t *buf, size_t len, size
 
 using namespace tgx;
 
-extern "C" tgx_status tgx_regex_validate(const char *pattern, size_t len, uint32_t flags, tgx_error *err) {
+extern "C" tgx_status tgx_regex_validate(const char *pattern, size_t len, uint32_t flags, tgx_error *err) try {
   if (!pattern && len) return rfail(err, TGX_INVALID_ARGUMENT, "pattern is NULL");
   rx::Dfa dfa;
   return compile_checked(pattern ? pattern : "", len, flags, &dfa, err);
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 // Host-side walk of the compiled automaton for ONE value: a compile check for the caller (does this pattern
 // mean what I think), never used by tgx_update.
 extern "C" tgx_status tgx_regex_is_match(const char *pattern, size_t plen, uint32_t flags, const uint8_t *value,
-                                         size_t vlen, int32_t *matched, tgx_error *err) {
+                                         size_t vlen, int32_t *matched, tgx_error *err) try {
   if ((!pattern && plen) || (!value && vlen) || !matched) return rfail(err, TGX_INVALID_ARGUMENT, "NULL argument");
   rx::Dfa dfa;
   tgx_status s = compile_checked(pattern ? pattern : "", plen, flags, &dfa, err);
@@ -379,4 +381,6 @@ extern "C" tgx_status tgx_regex_is_match(const char *pattern, size_t plen, uint3
   }
   *matched = rx::dfa_is_match(dfa, value + b, e - b) ? 1 : 0;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }

@@ -78,7 +78,7 @@ namespace tgx {
 int tgx_num_cus() { return g_ctx.n_cu > 0 ? g_ctx.n_cu : 256; }
 }  // namespace tgx
 
-extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) {
+extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) try {
   std::lock_guard<std::mutex> lock(g_ctx.mu);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -102,12 +102,16 @@ extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) {
   g_ctx.distinct_hint = opts ? opts->distinct_capacity_hint : 0;
   g_ctx.inited = true;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
-extern "C" tgx_status tgx_shutdown(void) {
+extern "C" tgx_status tgx_shutdown(void) try {
   std::lock_guard<std::mutex> lock(g_ctx.mu);
   g_ctx.inited = false;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(nullptr);
 }
 
 static tgx_status need_device(tgx_error *err) {
@@ -119,7 +123,7 @@ static tgx_status need_device(tgx_error *err) {
 // ------------------------------------------------------------------------------------------------
 // plan
 extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_specs, tgx_plan **out,
-                                      tgx_error *err) {
+                                      tgx_error *err) try {
   if (!out) return fail(err, TGX_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   if (n_specs > 0 && !specs) return fail(err, TGX_INVALID_ARGUMENT, "specs is NULL");
@@ -271,6 +275,8 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
   }
   *out = plan.release();
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" void tgx_plan_destroy(tgx_plan *plan) {
@@ -397,7 +403,7 @@ static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
 }
 
 extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **out,
-                                       tgx_error *err) {
+                                       tgx_error *err) try {
   if (!plan || !out) return fail(err, TGX_INVALID_ARGUMENT, "plan/out is NULL");
   *out = nullptr;
   tgx_state *st = new tgx_state();
@@ -406,6 +412,8 @@ extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, t
   st->own_stream = false;
   *out = st;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" void tgx_state_destroy(tgx_state *st) {
@@ -427,13 +435,15 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   delete st;
 }
 
-extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) {
+extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
   if (!st) return fail(err, TGX_INVALID_ARGUMENT, "state is NULL");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
-extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) {
+extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   st->ptr_tables.clear();
@@ -482,6 +492,8 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
                              st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long), st->stream));
   }
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,10 +522,12 @@ struct ProfScope {
   ~ProfScope() { prof_end(st, name, e0, e1); }
 };
 
-extern "C" tgx_status tgx_profile_enable(tgx_state *st, int32_t on) {
+extern "C" tgx_status tgx_profile_enable(tgx_state *st, int32_t on) try {
   if (!st) return TGX_INVALID_ARGUMENT;
   st->profiling = on != 0;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(nullptr);
 }
 
 static void prof_resolve(tgx_state *st) {
@@ -535,7 +549,7 @@ static void prof_resolve(tgx_state *st) {
 }
 
 extern "C" tgx_status tgx_profile_get(tgx_state *st, const char *kernel, double *total_ms,
-                                      uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err) {
+                                      uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err) try {
   if (!st || !kernel) return fail(err, TGX_INVALID_ARGUMENT, "state/kernel is NULL");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   prof_resolve(st);
@@ -544,14 +558,18 @@ extern "C" tgx_status tgx_profile_get(tgx_state *st, const char *kernel, double 
   if (launches) *launches = it == st->profile.end() ? 0 : it->second.launches;
   if (algorithmic_bytes) *algorithmic_bytes = it == st->profile.end() ? 0 : it->second.bytes;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
-extern "C" tgx_status tgx_profile_reset(tgx_state *st) {
+extern "C" tgx_status tgx_profile_reset(tgx_state *st) try {
   if (!st) return TGX_INVALID_ARGUMENT;
   if (st->device_ready) (void)hipStreamSynchronize(st->stream);
   prof_resolve(st);
   st->profile.clear();
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1103,7 +1121,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
 }
 
 extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_column *columns,
-                                 size_t n_columns, tgx_error *err) {
+                                 size_t n_columns, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if ((int)n_columns < plan->n_columns_needed)
     return fail(err, TGX_INVALID_ARGUMENT, "plan reads column %d but only %zu columns were passed",
@@ -1427,6 +1445,8 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   // HOST buffers copied straight from the caller's memory are borrowed only until tgx_update returns
   if (any_host && st->host_direct) HIP_TRY(hipStreamSynchronize(st->stream));
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1550,7 +1570,7 @@ static void fill_stats(const ScanAcc &a, bool variance, tgx_result *r) {
 }
 
 extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_result *results,
-                                   size_t n_results, tgx_error *err) {
+                                   size_t n_results, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (n_results < plan->specs.size() || (!results && !plan->specs.empty()))
     return fail(err, TGX_INVALID_ARGUMENT, "results has room for %zu of %zu specs", n_results, plan->specs.size());
@@ -1628,6 +1648,8 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
     }
   }
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1703,7 +1725,7 @@ extern "C" size_t tgx_distinct_record_bytes(const tgx_plan *plan, const tgx_stat
 
 extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                           uint32_t world, const void **device_records, uint64_t *counts,
-                                          tgx_error *err) {
+                                          tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
@@ -1711,6 +1733,8 @@ extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, s
     return fail(err, TGX_INVALID_ARGUMENT, "bad arguments (world must be 1..256)");
   TGX_TRY(need_device(err));
   return distinct_export_impl(st, plan->bind[spec_index].slot, world, device_records, counts, err);
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 // union `n` device records into the state's set (switching it to hash mode)
@@ -1736,7 +1760,7 @@ static tgx_status distinct_import_records(tgx_state *st, size_t slot, const void
 }
 
 extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, size_t spec_index,
-                                          const void *device_records, uint64_t n_records, tgx_error *err) {
+                                          const void *device_records, uint64_t n_records, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
@@ -1765,6 +1789,8 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   HIP_TRY(hipStreamSynchronize(st->stream));
   ds.partitioned = true;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 static tgx_status distinct_slot_of(const tgx_plan *plan, tgx_state *st, size_t spec_index, size_t *slot,
@@ -1777,7 +1803,7 @@ static tgx_status distinct_slot_of(const tgx_plan *plan, tgx_state *st, size_t s
 }
 
 extern "C" tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *st, size_t spec_index, int64_t lo,
-                                              int64_t hi, tgx_error *err) {
+                                              int64_t hi, tgx_error *err) try {
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   DistinctState &ds = st->distinct[slot];
@@ -1788,11 +1814,13 @@ extern "C" tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *s
   ds.hint_lo = lo;
   ds.hint_hi = hi;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *st, size_t spec_index, int64_t *base,
                                                uint64_t *n_words, const void **seen, const void **twice,
-                                               tgx_error *err) {
+                                               tgx_error *err) try {
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   DistinctState &ds = st->distinct[slot];
@@ -1804,12 +1832,14 @@ extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *
   if (seen) *seen = ds.seen.p;
   if (twice) *twice = st->plan->distinct[slot].multiplicity ? ds.twice.p : nullptr;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                                 int64_t slice_base, const void *seen_slices,
                                                 const void *twice_slices, uint32_t n_slices, uint64_t slice_words,
-                                                uint64_t slice_stride_words, tgx_error *err) {
+                                                uint64_t slice_stride_words, tgx_error *err) try {
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   TGX_TRY(need_device(err));
@@ -1844,10 +1874,12 @@ extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state 
   ds.bitmap_words = slice_words;
   ds.partitioned = true;
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state *const *srcs, size_t n_srcs,
-                                tgx_error *err) {
+                                tgx_error *err) try {
   if (!plan || !dst || dst->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "dst does not belong to plan");
   for (size_t i = 0; i < n_srcs; i++) {
     tgx_state *src = srcs ? srcs[i] : nullptr;
@@ -1904,6 +1936,8 @@ extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state 
     TGX_TRY(regex_merge_states(dst, src, err));
   }
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1944,7 +1978,7 @@ constexpr uint32_t kWireVersion = 1;
 }  // namespace
 
 extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, uint8_t *buf, size_t cap,
-                                          size_t *len, tgx_error *err) {
+                                          size_t *len, tgx_error *err) try {
   if (!plan || !st || st->plan != plan || !len) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
   TGX_TRY(spearman_check_mergeable(st, err));
   Gathered g;
@@ -1988,10 +2022,12 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
   *len = w.len;
   if (buf && w.len > cap) return fail(err, TGX_INVALID_ARGUMENT, "buffer too small: need %zu bytes", w.len);
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }
 
 extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t *buf, size_t len,
-                                            tgx_state **out, tgx_error *err) {
+                                            tgx_state **out, tgx_error *err) try {
   if (!plan || !buf || !out) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
   *out = nullptr;
   Reader r{buf, len};
@@ -2022,12 +2058,14 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
       ds.h_twice = t.twice - (t.empty_rows > 1 ? 1 : 0);
       ds.h_empty_rows = t.empty_rows;
     } else {
-      // rebuild the key set on the device from the records
-      size_t bytes = (size_t)n_records * (wide ? sizeof(KeyRecord128) : sizeof(KeyRecord));
-      if (r.pos + bytes > r.len) {
+      // rebuild the key set on the device from the records.  n_records comes from the blob: bound it by the bytes
+      // that are really there BEFORE multiplying (a crafted count would wrap the product past the check)
+      const size_t rec_bytes = wide ? sizeof(KeyRecord128) : sizeof(KeyRecord);
+      if (n_records > (r.len - r.pos) / rec_bytes) {
         r.ok = false;
         break;
       }
+      size_t bytes = (size_t)n_records * rec_bytes;
       tgx_status s = need_device(err);
       if (s != TGX_OK) return s;
       s = state_init_device(st.get(), err);
@@ -2052,4 +2090,6 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
   if (!r.ok) return fail(err, TGX_INVALID_ARGUMENT, "truncated state blob");
   *out = st.release();
   return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
 }

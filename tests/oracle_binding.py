@@ -58,8 +58,14 @@ class Match(C.Structure):
     _fields_ = [("total", C.c_int64), ("matches", C.c_int64)]
 
 
+class SuiteColumn(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("is_float", C.c_int32), ("reserved", C.c_int32)]
+
+
 def _declare(L):
     vp, i64, u64, dbl = C.c_void_p, C.c_int64, C.c_uint64, C.c_double
+    L.orc_suite_mt.argtypes = [C.POINTER(SuiteColumn), C.c_int32, C.POINTER(C.c_int32), C.c_int32, i64, C.c_int32,
+                               C.POINTER(Count), C.POINTER(Stats), C.POINTER(Distinct)]
     L.orc_count.argtypes = [vp, i64, i64, C.POINTER(Count)]
     L.orc_stats_i64.argtypes = [vp, vp, i64, i64, C.POINTER(Stats)]
     L.orc_stats_f64.argtypes = [vp, vp, i64, i64, C.POINTER(Stats)]
@@ -171,6 +177,25 @@ def distinct_utf8(offsets, data, validity=None, n=None, offset=0):
     rc = lib().orc_distinct_utf8(_p(offsets), _p(data), _p(validity), offset, n, C.byref(out))
     assert rc == 0
     return out
+
+
+def suite_mt(columns, unique_cols, n, n_threads):
+    """The null + range + unique suite on `n_threads` threads (oracle/suite_mt.c): row-range partitions, hash-set
+    COUNT(DISTINCT), merge in partition order.  columns: [(values ndarray int64|float64, validity uint8 ndarray or
+    None)]; returns (counts, stats, distincts)."""
+    cols = (SuiteColumn * max(1, len(columns)))()
+    for i, (v, b) in enumerate(columns):
+        cols[i].values = v.ctypes.data
+        cols[i].validity = None if b is None else b.ctypes.data
+        cols[i].is_float = 1 if v.dtype == np.float64 else 0
+    uc = (C.c_int32 * max(1, len(unique_cols)))(*unique_cols)
+    counts = (Count * max(1, len(columns)))()
+    stats_ = (Stats * max(1, len(columns)))()
+    dist = (Distinct * max(1, len(unique_cols)))()
+    rc = lib().orc_suite_mt(cols, len(columns), uc, len(unique_cols), n, n_threads, counts, stats_, dist)
+    if rc != 0:
+        raise MemoryError("orc_suite_mt failed (%d)" % rc)
+    return list(counts)[: len(columns)], list(stats_)[: len(columns)], list(dist)[: len(unique_cols)]
 
 
 def _isf(a):

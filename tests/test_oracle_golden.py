@@ -248,3 +248,31 @@ def test_length_vectors(golden):
         m = orc.length_count_utf8(offs, data, validity, min_chars=lo, max_chars=hi)
         assert m.matches / m.total == case["metric"], case["ref"]
 
+
+
+def test_suite_mt_equals_single_thread():
+    """oracle/suite_mt.c (bench.py's nproc-thread cpu_baseline): partitioned partials + hash-set COUNT(DISTINCT) +
+    merge give the single-threaded oracle's results for every thread count, ragged tails included"""
+    rng = np.random.default_rng(11)
+    n = 100_003
+    iv = rng.integers(-5000, 5000, size=n, dtype=np.int64)
+    iv[7] = -1  # the all-ones bit pattern is a key like any other
+    fv = rng.standard_normal(n)
+    mask = rng.random(n) >= 0.07
+    validity = np.concatenate([orc.pack_validity(mask), np.zeros(8, np.uint8)])
+    cols = [(iv, validity), (fv, None), (np.arange(n, dtype=np.int64), validity)]
+    ref_c = [orc.count(b, n) for _, b in cols]
+    ref_s = [orc.stats(v, b, n=n) for v, b in cols]
+    ref_d = [orc.distinct_bits64(cols[c][0].view(np.uint64), cols[c][1], n=n) for c in (0, 2)]
+    for threads in (1, 2, 3, 8):
+        counts, stats, dist = orc.suite_mt(cols, [0, 2], n, threads)
+        for c in range(3):
+            assert (counts[c].total, counts[c].non_null) == (ref_c[c].total, ref_c[c].non_null)
+            s, r = stats[c], ref_s[c]
+            assert (s.total, s.non_null, s.has_value) == (r.total, r.non_null, r.has_value)
+            if r.is_float:
+                assert (s.min_f, s.max_f) == (r.min_f, r.max_f) and abs(s.sum_f - r.sum_hi) <= 1e-9 * abs(r.sum_hi) + 1e-9
+            else:
+                assert (s.min_i, s.max_i, s.sum_i_wrapping) == (r.min_i, r.max_i, r.sum_i_wrapping)
+        for d, r in zip(dist, ref_d):
+            assert (d.total, d.non_null, d.distinct) == (r.total, r.non_null, r.distinct), threads
