@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- validated rows/s of the fused check suite on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (tgx_state_reset -> tgx_update -> [cross-rank merge] -> tgx_finalize)
+A "step" is one pass of the hot path (tgx_state_reset -> tgx_update -> [tgx_allreduce] -> tgx_finalize)
 over one synthetic, device-resident batch of the 16-column "null + range + unique" table
 (term_amd/synth.py):
     Completeness x16 + Min/Max/Mean x16 + FullUniqueness on 2 columns.
-Rows are sharded by row range across ranks (strong scaling: the table size is fixed); each rank scans
-its shard, the ranks agree on the unique columns' value ranges, exact distinct swaps the slices of congruent
-range bitmaps with one all-to-all (16-byte key records by hash owner where a key set is not a bitmap), and the
-packed partial states are all-gathered and merged in rank order on every rank.
+Rows are sharded by row range across ranks (strong scaling: the table size is fixed); every rank runs the SAME fused
+plan on its shard, then tgx_allreduce (C ABI, RCCL over xGMI): the ranks agree on the unique columns' value ranges,
+exact distinct swaps slices of the range bitmaps (re-based on the agreed range on the fly) with one all-to-all --
+16-byte key records by hash owner where a key set is not a bitmap -- and the packed partial states are all-gathered
+and merged in rank order on every rank.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -100,7 +101,7 @@ def main():
     import term_amd as T
     from term_amd import synth
     from term_amd._lib import spec
-    from term_amd.distributed import sharded_suite_step
+    from term_amd.distributed import rccl_comm, sharded_suite_step
 
     torch.cuda.set_device(local_rank)
     dist = None
@@ -121,19 +122,11 @@ def main():
 
     T.init(device_id=local_rank, distinct_capacity_hint=n_local)
     specs = build_suite(T, spec, layout, unique_cols)
-    n_stats = sum(1 for s in specs if s.kind != T.DISTINCT)
     stream = torch.cuda.Stream()
-    if not distributed:
-        # one fused plan: every column buffer is read by one scan; the unique columns feed the distinct pass
-        plan = T.Plan(specs)
-        st = T.State(plan, stream=stream.cuda_stream)
-    else:
-        # row shards: stats first, so the ranks can agree on the unique columns' global value ranges and build
-        # congruent range bitmaps (tgx_distinct_range_hint) whose slices are swapped with one all-to-all
-        plan = T.Plan(specs[:n_stats])
-        plan_d = T.Plan(specs[n_stats:])
-        st = T.State(plan, stream=stream.cuda_stream)
-        st_d = T.State(plan_d, stream=stream.cuda_stream)
+    # one fused plan on every rank: every column buffer is read by one scan, the unique columns feed the distinct pass
+    plan = T.Plan(specs)
+    st = T.State(plan, stream=stream.cuda_stream)
+    comm = rccl_comm(dist, rank, world) if distributed else None  # the library's own RCCL communicator
 
     table = synth.make_table(layout, row0, n_local, n_total, args.seed, "cuda")
     columns = []
@@ -147,8 +140,7 @@ def main():
             st.reset()
             st.update(columns)
             return st.finalize()
-        return sharded_suite_step(plan, st, plan_d, st_d, specs[:n_stats], specs[n_stats:], columns, dist, world, rank,
-                                  cache_key="bench")
+        return sharded_suite_step(plan, st, columns, comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -160,9 +152,6 @@ def main():
         res = step()
     st.profile_enable(True)
     st.profile_reset()
-    if distributed:
-        st_d.profile_enable(True)
-        st_d.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -174,7 +163,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = st.profile_get("scan")
-    prof_d = (st_d if distributed else st).profile_get("distinct")
+    prof_d = st.profile_get("distinct")
     st.profile_enable(False)
 
     # ---- verification outside the timed region: closed-form facts of the synthetic table ----
@@ -241,6 +230,7 @@ def main():
         line = None
     if distributed:
         dist.barrier()
+        del comm  # ncclCommDestroy before the process group goes away
         dist.destroy_process_group()
     if line is not None:
         # the ONE JSON line, last thing on stdout (RCCL prints its version banner on teardown)

@@ -36,7 +36,8 @@ extern "C" {
 
 /* 2: tgx_column grew the Utf8View fields, tgx_check_spec the column list and LENGTH bounds,
  *    tgx_distinct_adopt_slices a slice stride */
-#define TGX_ABI_VERSION 2
+/* 3: tgx_comm / tgx_allreduce (the cross-rank step behind the C ABI) */
+#define TGX_ABI_VERSION 3
 
 typedef enum tgx_status {
   TGX_OK = 0,
@@ -292,6 +293,53 @@ tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *state, size
 tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *state, size_t spec_index, int64_t slice_base,
                                      const void *seen_slices, const void *twice_slices, uint32_t n_slices,
                                      uint64_t slice_words, uint64_t slice_stride_words, tgx_error *err);
+
+/* ---- the cross-rank step ------------------------------------------------
+ * Rows shard by row range, one process per GPU.  Every rank runs tgx_update on its shard; tgx_allreduce then turns
+ * each rank's state into the state of the WHOLE table -- `AnalyzerState::merge` (TG/analyzers/traits.rs:160-170)
+ * applied across ranks:
+ *   1. the ranks all-gather a few scalars per DISTINCT column: its MIN / MAX (the running values of the scan), the
+ *      kind of key set the rank built, its rows;
+ *   2. exact DISTINCT sets swap ONE all-to-all: where every rank holds a range bitmap, equal slices of the bitmaps,
+ *      re-based on the agreed global range on the fly (the local bitmaps need not be congruent), all columns in one
+ *      collective -- range / 8 bytes per rank and column; otherwise fixed-size key records by hash owner;
+ *   3. the packed partial states (a few KiB; KLL about 100 KiB) travel in one all-gather and are folded in rank
+ *      order, so every rank ends with bit-identical results.
+ * After the call tgx_finalize(state) returns the global results on every rank; the state keeps its device buffers
+ * for the next tgx_state_reset / tgx_update round.  SPEARMAN states cannot be reduced (TG's are unmergeable too,
+ * analyzers/advanced/correlation.rs:103-109): TGX_UNSUPPORTED.
+ *
+ * A tgx_comm is the transport: RCCL over xGMI (tgx_comm_create_rccl: the library dlopens librccl.so.1, calls
+ * ncclCommInitRank itself and owns the communicator; tgx_comm_adopt_rccl wraps a caller-owned ncclComm_t), or any
+ * transport of the caller's through tgx_comm_ops (MPI, gloo, the threaded stand-in of the tests).  All ranks must
+ * call tgx_allreduce with the same plan, in the same order. */
+typedef struct tgx_comm tgx_comm;
+typedef struct tgx_comm_ops {
+  void *ctx;
+  int32_t rank, world;
+  /* 1: the collectives below take DEVICE pointers and are ordered on `hip_stream`; 0: they take HOST pointers
+   * (the library stages through pinned memory and synchronises the stream itself) and may block */
+  int32_t device_buffers;
+  int32_t reserved;
+  /* every rank sends `bytes_per_peer` bytes to every rank: send / recv hold world blocks, block r goes to / comes
+   * from rank r */
+  int32_t (*alltoall)(void *ctx, const void *send, void *recv, size_t bytes_per_peer, void *hip_stream);
+  /* block r of send holds send_counts[r] elements of elem_bytes for rank r (packed back to back); recv likewise */
+  int32_t (*alltoallv)(void *ctx, const void *send, const uint64_t *send_counts, void *recv,
+                       const uint64_t *recv_counts, size_t elem_bytes, void *hip_stream);
+  /* every rank contributes `bytes` bytes; recv holds world blocks in rank order */
+  int32_t (*allgather)(void *ctx, const void *send, void *recv, size_t bytes, void *hip_stream);
+} tgx_comm_ops; /* every callback returns 0 on success */
+
+#define TGX_RCCL_UNIQUE_ID_BYTES 128
+tgx_status tgx_comm_create(const tgx_comm_ops *ops, tgx_comm **out, tgx_error *err);
+/* rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks by any means */
+tgx_status tgx_comm_rccl_unique_id(uint8_t id[TGX_RCCL_UNIQUE_ID_BYTES], tgx_error *err);
+tgx_status tgx_comm_create_rccl(const uint8_t id[TGX_RCCL_UNIQUE_ID_BYTES], int32_t rank, int32_t world,
+                                tgx_comm **out, tgx_error *err);
+tgx_status tgx_comm_adopt_rccl(void *nccl_comm, int32_t rank, int32_t world, tgx_comm **out, tgx_error *err);
+void tgx_comm_destroy(tgx_comm *comm);
+tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *state, tgx_comm *comm, tgx_error *err);
 
 /* ---- measurement ----------------------------------------------------------------------------
  * Per-kernel HIP-event timing on the state's stream (what bench.py's `roofline` uses).

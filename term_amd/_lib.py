@@ -10,7 +10,7 @@ _ROOT = os.path.dirname(_HERE)
 COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 1, 2, 3, 4, 5, 6, 7, 8
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
-ABI_VERSION = 2  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
+ABI_VERSION = 3  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
@@ -133,6 +133,13 @@ def lib():
         L.tgx_update.argtypes = [vp, vp, C.POINTER(_Column), sz, E]
         L.tgx_merge.argtypes = [vp, vp, C.POINTER(vp), sz, E]
         L.tgx_finalize.argtypes = [vp, vp, C.POINTER(Result), sz, E]
+        L.tgx_comm_create.argtypes = [C.POINTER(CommOps), C.POINTER(vp), E]
+        L.tgx_comm_rccl_unique_id.argtypes = [vp, E]
+        L.tgx_comm_create_rccl.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp), E]
+        L.tgx_comm_adopt_rccl.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp), E]
+        L.tgx_comm_destroy.argtypes = [vp]
+        L.tgx_comm_destroy.restype = None
+        L.tgx_allreduce.argtypes = [vp, vp, vp, E]
         L.tgx_state_sync.argtypes = [vp, E]
         L.tgx_state_reset.argtypes = [vp, vp, E]
         L.tgx_state_serialize.argtypes = [vp, vp, vp, sz, C.POINTER(sz), E]
@@ -228,6 +235,21 @@ class Column:
         if dictionary is not None:
             c.dictionary = C.pointer(dictionary.c)
         self.c = c
+
+    def sliced(self, offset, length):
+        """Arrow's Array::slice: the same buffers viewed from `offset` (relative to this view) for `length` rows"""
+        import copy
+
+        if offset < 0 or length < 0 or offset + length > self.c.length:
+            raise ValueError("slice [%d, %d) outside a column of %d rows" % (offset, offset + length, self.c.length))
+        out = copy.copy(self)  # shares the keep-alive references of the buffers
+        c = _Column()
+        C.memmove(C.byref(c), C.byref(self.c), C.sizeof(_Column))
+        c.offset = self.c.offset + offset
+        c.length = length
+        c.null_count = -1
+        out.c = c
+        return out
 
     @staticmethod
     def int64(values, validity=None, length=None, offset=0):
@@ -338,6 +360,75 @@ def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0, columns=None,
     return s
 
 
+# ---- the cross-rank step: transports and tgx_allreduce (include/tgx.h) ----------------------------------------
+_ALLTOALL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_ALLTOALLV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                            C.c_size_t, C.c_void_p)
+_ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("device_buffers", C.c_int32),
+                ("reserved", C.c_int32), ("alltoall", _ALLTOALL_FN), ("alltoallv", _ALLTOALLV_FN),
+                ("allgather", _ALLGATHER_FN)]
+
+
+RCCL_UNIQUE_ID_BYTES = 128
+
+
+class Comm:
+    """tgx_comm: the transport tgx_allreduce runs over."""
+
+    def __init__(self, handle, rank, world, keep=None):
+        self.h, self.rank, self.world, self._keep = handle, rank, world, keep
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().tgx_comm_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = (C.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
+        err = _Error()
+        _check(lib().tgx_comm_rccl_unique_id(buf, C.byref(err)), err)
+        return bytes(buf)
+
+    @staticmethod
+    def rccl(unique_id, rank, world):
+        """RCCL over xGMI: the library calls ncclCommInitRank itself (collective: every rank must call)"""
+        buf = (C.c_uint8 * RCCL_UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        h = C.c_void_p()
+        err = _Error()
+        _check(lib().tgx_comm_create_rccl(buf, rank, world, C.byref(h), C.byref(err)), err)
+        return Comm(h, rank, world)
+
+    @staticmethod
+    def custom(rank, world, alltoall, alltoallv, allgather, device_buffers=False):
+        """any transport: three Python callables over raw pointers (see tgx_comm_ops in include/tgx.h); they return
+        nothing and raise on failure"""
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a[1:])  # drop ctx
+                    return 0
+                except Exception:  # noqa: BLE001 -- must not unwind through the C frames
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+            return wrapped
+
+        ops = CommOps()
+        ops.rank, ops.world, ops.device_buffers = rank, world, 1 if device_buffers else 0
+        cbs = (_ALLTOALL_FN(guard(alltoall)), _ALLTOALLV_FN(guard(alltoallv)), _ALLGATHER_FN(guard(allgather)))
+        ops.alltoall, ops.alltoallv, ops.allgather = cbs
+        h = C.c_void_p()
+        err = _Error()
+        _check(lib().tgx_comm_create(C.byref(ops), C.byref(h), C.byref(err)), err)
+        return Comm(h, rank, world, keep=cbs)  # the C side keeps the function pointers: keep the thunks alive
+
+
 class Plan:
     def __init__(self, specs):
         self._specs = list(specs)
@@ -398,6 +489,12 @@ class State:
         err = _Error()
         _check(lib().tgx_state_reset(self.plan.h, self.h, C.byref(err)), err)  # waits for the stream
         self._keep = None
+
+    def allreduce(self, comm):
+        """tgx_allreduce: this rank's state becomes the state of the whole table (collective)"""
+        err = _Error()
+        _check(lib().tgx_allreduce(self.plan.h, self.h, comm.h, C.byref(err)), err)
+        self._keep = None  # the step ends with the stream drained
 
     def merge(self, others):
         hs = (C.c_void_p * max(1, len(others)))(*[o.h for o in others])

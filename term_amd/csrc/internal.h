@@ -61,6 +61,9 @@ hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_c
 void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
                          uint64_t slice_words, uint64_t stride_words, uint32_t *out_seen, uint32_t *out_twice,
                          unsigned long long *d_counters, hipStream_t stream);
+void launch_bitmap_rebase(const uint32_t *src, uint64_t src_words, long long delta_bits, uint32_t world,
+                          uint64_t slice_words, uint64_t row_words, uint64_t col_words, uint32_t *send,
+                          hipStream_t stream);
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *views,
                           const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
@@ -325,3 +328,20 @@ struct tgx_state {
   bool profiling = false;
   std::map<std::string, tgx::ProfileEntry> profile;
 };
+
+// ---- shared between tgx_api.cpp and allreduce.cpp ------------------------------------------------
+namespace tgx {
+tgx_status fail(tgx_error *err, tgx_status code, const char *fmt, ...);
+tgx_status need_device(tgx_error *err);
+tgx_status state_init_device(tgx_state *st, tgx_error *err);
+// partitions the task's key set by owner = mix(key) % world into runs of KeyRecord / KeyRecord128 (device memory
+// owned by the state); counts[r] = records for rank r
+tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t world, const void **device_records,
+                                uint64_t *counts, tgx_error *err);
+// unites `n` device records into the task's set (switching it to hash mode)
+tgx_status distinct_import_records(tgx_state *st, size_t slot, const void *d_recs, uint64_t n, bool wide,
+                                   tgx_error *err);
+int num_cus();
+int device_id();
+}  // namespace tgx
+

@@ -724,6 +724,28 @@ __global__ __launch_bounds__(256) void bitmap_adopt_kernel(const uint32_t *seen_
   block_add2(n_seen, n_twice, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
+// The send side of the cross-rank exchange (tgx_allreduce): cuts this rank's range bitmap, whose bit 0 stands for
+// key `base` of its own choosing, into `world` slices of `slice_words` words on the grid all ranks agreed on -- bit 0
+// of slice p stands for key global_lo + p * slice_words * 32.  delta_bits = global_lo - base, so word w of slice p is
+// bits [l, l + 32) of the local bitmap with l = (p * slice_words + w) * 32 + delta_bits, zero outside it.  The
+// local bitmaps therefore need not be congruent (no range hint, no second pass): re-basing rides on the copy into
+// the all-to-all's send buffer.  Block p of the send buffer starts at p * row_words; this column's slice at col_words.
+__global__ __launch_bounds__(256) void bitmap_rebase_kernel(const uint32_t *__restrict__ src, uint64_t src_words,
+                                                             long long delta_bits, uint32_t world,
+                                                             uint64_t slice_words, uint64_t row_words,
+                                                             uint64_t col_words, uint32_t *__restrict__ send) {
+  const uint64_t total = (uint64_t)world * slice_words;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t p = i / slice_words, w = i - p * slice_words;
+    const long long l = (long long)(i * 32) + delta_bits;
+    const long long wi = l >> 5;  // arithmetic shift: floor
+    const uint32_t sh = (uint32_t)(l & 31);
+    const uint32_t lo = (wi >= 0 && (uint64_t)wi < src_words) ? src[wi] : 0u;
+    const uint32_t hi = (wi + 1 >= 0 && (uint64_t)(wi + 1) < src_words) ? src[wi + 1] : 0u;
+    send[p * row_words + col_words + w] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+  }
+}
+
 void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu,
                       hipStream_t stream) {
   int64_t n_tiles = (p.length + kPartitionTile - 1) / kPartitionTile;
@@ -832,6 +854,13 @@ void launch_bitmap_export_scatter(const BitmapView &bm, uint32_t world, int want
   BitmapSource s{bm, want_mult};
   hipLaunchKernelGGL(export_scatter_kernel<BitmapSource>, dim3(grid_for((bm.range + 31) >> 5)), dim3(256), 0,
                      stream, s, world, d_cursors, out);
+}
+
+void launch_bitmap_rebase(const uint32_t *src, uint64_t src_words, long long delta_bits, uint32_t world,
+                          uint64_t slice_words, uint64_t row_words, uint64_t col_words, uint32_t *send,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(bitmap_rebase_kernel, dim3(grid_for((uint64_t)world * slice_words)), dim3(256), 0, stream, src,
+                     src_words, delta_bits, world, slice_words, row_words, col_words, send);
 }
 
 void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,

@@ -21,7 +21,7 @@ using namespace tgx;
 
 // ------------------------------------------------------------------------------------------------
 // errors
-static tgx_status fail(tgx_error *err, tgx_status code, const char *fmt, ...) {
+tgx_status tgx::fail(tgx_error *err, tgx_status code, const char *fmt, ...) {
   if (err) {
     err->code = (int32_t)code;
     va_list ap;
@@ -76,6 +76,8 @@ struct Context {
 
 namespace tgx {
 int tgx_num_cus() { return g_ctx.n_cu > 0 ? g_ctx.n_cu : 256; }
+int num_cus() { return tgx_num_cus(); }
+int device_id() { return g_ctx.device < 0 ? 0 : g_ctx.device; }
 }  // namespace tgx
 
 extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) try {
@@ -114,7 +116,7 @@ extern "C" tgx_status tgx_shutdown(void) try {
   return tgx::abi_exception(nullptr);
 }
 
-static tgx_status need_device(tgx_error *err) {
+tgx_status tgx::need_device(tgx_error *err) {
   if (!g_ctx.inited)
     return fail(err, TGX_NO_DEVICE, "tgx_init has not succeeded: no gfx950 device, and libtgx has no CPU path");
   return TGX_OK;
@@ -359,7 +361,7 @@ static void state_init_host(tgx_state *st, const tgx_plan *plan) {
   spearman_state_init(st);
 }
 
-static tgx_status state_init_device(tgx_state *st, tgx_error *err) {
+tgx_status tgx::state_init_device(tgx_state *st, tgx_error *err) {
   if (st->device_ready) return TGX_OK;
   TGX_TRY(need_device(err));
   const tgx_plan *plan = st->plan;
@@ -1654,7 +1656,7 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
 
 // ------------------------------------------------------------------------------------------------
 // distinct: export / import / merge
-static tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t world,
+tgx_status tgx::distinct_export_impl(tgx_state *st, size_t slot, uint32_t world,
                                        const void **device_records, uint64_t *counts, tgx_error *err) {
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;
@@ -1738,7 +1740,7 @@ extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, s
 }
 
 // union `n` device records into the state's set (switching it to hash mode)
-static tgx_status distinct_import_records(tgx_state *st, size_t slot, const void *d_recs, uint64_t n, bool wide,
+tgx_status tgx::distinct_import_records(tgx_state *st, size_t slot, const void *d_recs, uint64_t n, bool wide,
                                           tgx_error *err) {
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;

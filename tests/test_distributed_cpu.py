@@ -1,7 +1,9 @@
-"""world_size-2 `gloo` test of the N>1 path on CPU: row-range shards -> packed partial states -> all-gather ->
-rank-ordered merge (term_amd/distributed.py + tgx_state_deserialize / tgx_merge / tgx_finalize, none of which
-needs a device).  Per-shard aggregates come from the oracle here (there is no GPU in this container); the GPU
-box runs the same merge code on states produced by the kernels (bench.py --gpus N)."""
+"""world_size-2 `gloo` test of the N>1 path on CPU: row-range shards -> tgx_allreduce (the C entry point of the
+cross-rank step: facts all-gather, packed partial states in one all-gather with the agreed-capacity protocol,
+rank-ordered merge) over a torch.distributed transport with host buffers (term_amd.distributed.torch_dist_comm),
+none of which needs a device when the states are host-side.  Per-shard aggregates come from the oracle here (there
+is no GPU in this container); the GPU box runs the same entry point on states produced by the kernels (bench.py
+--gpus N over RCCL, tests/test_gpu_distributed_sim.py with threaded ranks)."""
 import os
 import subprocess
 import sys
@@ -18,7 +20,7 @@ WORKER = textwrap.dedent('''
     import term_amd as T
     from term_amd import wire
     from term_amd._lib import spec
-    from term_amd.distributed import allgather_merge, shard_rows
+    from term_amd.distributed import shard_rows, torch_dist_comm
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -59,7 +61,9 @@ WORKER = textwrap.dedent('''
         kll=[wire.kll_state(200, len(kept), float(kept.min()), float(kept.max()), [sorted(kept.tolist())[:1000]] if len(kept) <= 1000 else
              [[], sorted(kept.tolist())[::2]])],
         regex=[wire.regex_counts(rx.total, rx.matches)])
-    merged = allgather_merge(plan, blob, dist, world)
+    comm = torch_dist_comm(dist, rank, world)
+    merged = T.State.deserialize(plan, blob)     # this rank's partial state (host-side: no device needed)
+    merged.allreduce(comm)                       # -> the state of the whole table, on every rank
     res = merged.finalize()
     full_i, full_f = orc.stats(iv, allv), orc.stats(fv, allv)
     d = orc.distinct_bits64(iv.view(np.uint64), allv)
@@ -75,18 +79,21 @@ WORKER = textwrap.dedent('''
                want_median=float(np.median(fv[mask])),
                regex=[res[6].total, res[6].matches], want_regex=[n, sum(1 for s in strs if "@" in s)],
                blob=merged.serialize().hex()[:64])
-    # the one-collective gather: ragged sizes, a cached capacity that one rank outgrows, empty payloads
-    from term_amd.distributed import agree_on_ranges, allgather_blobs, allgather_many
-    g = allgather_blobs(b"x" * (10 + rank), dist, world, cache_key="t")
-    assert [len(x) for x in g] == [10, 11] and g[1] == b"x" * 11
-    g = allgather_blobs(b"y" * (5000 * (rank + 1)), dist, world, cache_key="t")
-    assert [len(x) for x in g] == [5000, 10000] and g[1] == b"y" * 10000
-    g = allgather_blobs(b"", dist, world, cache_key="t")
-    assert g == [b"", b""]
-    g = allgather_many([b"a" * rank, b"bb"], dist, world)
-    assert g == [[b"", b"bb"], [b"a", b"bb"]]
-    r = agree_on_ranges([(True, 5 - rank, 100 + rank), (rank == 1, -7, 7), (False, 0, 0)], dist, world, device="cpu")
-    assert r == [(4, 101), (-7, 7), None], r
+    # the agreed-capacity gather: a second plan on the same comm whose blobs differ in size per rank (rank 1 carries a
+    # KLL level of 5000 items, rank 0 none) and then outgrow the capacity agreed in the first round
+    plan2 = T.Plan([spec(T.KLL, 0, kll_k=200), spec(T.COUNT, 1)])
+    for scale in (1, 4):
+        items = sorted(float(i) for i in range(5000 * scale * rank))
+        lv = [items[:500], items[500:]] if items else []
+        part = T.State.deserialize(plan2, wire.pack(kll=[wire.kll_state(200, len(items), 0.0, max(1.0, float(len(items))), lv)] ,
+                                                    count=[wire.count_acc(10 + rank, 7)]))
+        part.allreduce(comm)
+        r2 = part.finalize()
+        assert r2[0].kll_n == 5000 * scale and (r2[1].total, r2[1].non_null) == (21, 14), (r2[0].kll_n, r2[1].total)
+    # an allreduce of an all-reduced state is the W-fold sum: the call is a plain cross-rank merge, nothing is cached
+    again = T.State.deserialize(plan, merged.serialize())
+    again.allreduce(comm)
+    assert again.finalize()[0].total == world * n
     print("RESULT " + json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,8 +1,9 @@
-"""-m gpu: the N > 1 step of bench.py (term_amd.distributed.sharded_suite_step) with THREE ranks simulated on one
-GPU: every rank is a thread with its own states and row shard; the collectives are a thread-barrier stand-in for
-torch.distributed (same call signatures, same data movement), so the range agreement, the bitmap-slice all-to-all
-with its in-place strided adoption, the hash-owner fallback, the one-collective state gather and the rank-ordered
-merge all run exactly as they do over RCCL.  The merged results must equal the single-state results of the table."""
+"""-m gpu: the N > 1 step of bench.py -- tgx_update on the rank's row shard, then tgx_allreduce (the C entry point of
+the cross-rank step) -- with 2 .. 8 ranks simulated on one GPU: every rank is a thread with its own state and row
+shard; the transport is the thread-barrier stand-in of term_amd.distributed.thread_comm (handed DEVICE pointers
+like RCCL, or HOST pointers like an MPI-style transport), so the facts gather, the all-to-all of re-based
+range-bitmap slices, the hash-owner record exchange, the agreed-capacity state gather and the rank-ordered merge
+all run exactly as they do over RCCL.  Every rank's results must equal the single-state results of the table."""
 import threading
 
 import numpy as np
@@ -12,74 +13,15 @@ import oracle_binding as orc
 import term_amd as T
 from _lib_spec import spec
 from gpu_util import numeric_column
-from term_amd.distributed import shard_rows, sharded_suite_step
+from term_amd.distributed import ThreadGroup, shard_rows, sharded_suite_step, thread_comm
 
 pytestmark = pytest.mark.gpu
 
 
-class FakeGroup:
-    def __init__(self, world):
-        self.world = world
-        self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
-
-
-class FakeDist:
-    """the subset of torch.distributed the step uses, for threads sharing one device"""
-
-    def __init__(self, group, rank):
-        self.g, self.rank = group, rank
-
-    def _publish(self, t):
-        import torch
-
-        torch.cuda.synchronize()
-        self.g.slots[self.rank] = t
-        self.g.barrier.wait()
-
-    def _done(self):
-        import torch
-
-        torch.cuda.synchronize()
-        self.g.barrier.wait()
-
-    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
-        w = self.g.world
-        isz = list(input_split_sizes) if input_split_sizes is not None else [inp.numel() // w] * w
-        self._publish((inp, isz))
-        pos = 0
-        for r in range(w):
-            src, sz = self.g.slots[r]
-            start, n = sum(sz[: self.rank]), sz[self.rank]
-            if output_split_sizes is not None:
-                assert output_split_sizes[r] == n
-            out[pos:pos + n] = src[start:start + n]
-            pos += n
-        self._done()
-
-    def all_gather_into_tensor(self, out, inp):
-        self._publish(inp)
-        n = inp.numel()
-        for r in range(self.g.world):
-            out[r * n:(r + 1) * n] = self.g.slots[r].to(out.device)
-        self._done()
-
-    def all_to_all(self, outs, ins):
-        self._publish(list(ins))
-        for r in range(self.g.world):
-            outs[r].copy_(self.g.slots[r][self.rank])
-        self._done()
-
-    def all_gather(self, outs, inp):
-        self._publish(inp)
-        for r in range(self.g.world):
-            outs[r].copy_(self.g.slots[r])
-        self._done()
-
-
 @pytest.mark.parametrize("world", [2, 3, 4, 8])  # 2 / 4 / 8: the row-shard layouts the scaling bench runs
 @pytest.mark.parametrize("dense", [True, False])
-def test_simulated_ranks_match_one_state(dense, world):
+@pytest.mark.parametrize("device_buffers", [True, False])
+def test_simulated_ranks_match_one_state(dense, world, device_buffers):
     import torch
 
     rng = np.random.default_rng(12 + dense)
@@ -94,20 +36,20 @@ def test_simulated_ranks_match_one_state(dense, world):
     masks = [None, rng.random(n) >= 0.07, rng.random(n) >= 0.2]
     cols_np = [ids, keys, flt]
     valid = [None if m is None else orc.pack_validity(m) for m in masks]
-    stat_specs = []
+    specs = []
     for ci in range(3):
-        stat_specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci)]
-    distinct_specs = [spec(T.DISTINCT, 0), spec(T.DISTINCT, 1, flags=T.FLAG_MULTIPLICITY)]
+        specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci)]
+    # (no NUMERIC_STATS spec is needed next to a DISTINCT one: the ranks agree on the range inside tgx_allreduce)
+    specs += [spec(T.DISTINCT, 0), spec(T.DISTINCT, 1, flags=T.FLAG_MULTIPLICITY)]
     T.init()
-    plan, plan_d = T.Plan(stat_specs), T.Plan(distinct_specs)
+    plan = T.Plan(specs)  # ONE fused plan, as on a single GPU
     # reference: one state over the whole table
     whole = [numeric_column(c, v, True) for c, v in zip(cols_np, valid)]
-    one, one_d = T.State(plan), T.State(plan_d)
+    one = T.State(plan)
     one.update(whole)
-    one_d.update(whole)
-    want = one.finalize() + one_d.finalize()
+    want = one.finalize()
 
-    group = FakeGroup(world)
+    group = ThreadGroup(world)
     results, errors = [None] * world, []
 
     def worker(rank):
@@ -115,10 +57,10 @@ def test_simulated_ranks_match_one_state(dense, world):
             torch.cuda.set_device(0)
             lo, hi = shard_rows(n, world, rank)
             shard = [numeric_column(c, v, True, offset=lo, length=hi - lo) for c, v in zip(cols_np, valid)]
-            st, st_d = T.State(plan), T.State(plan_d)
-            for _ in range(2):  # twice: buffers, cached gather capacity and range hints are reused across steps
-                res = sharded_suite_step(plan, st, plan_d, st_d, stat_specs, distinct_specs, shard, FakeDist(group, rank),
-                                         world, rank, cache_key="sim%d_%d" % (dense, world))
+            st = T.State(plan)
+            comm = thread_comm(group, rank, device_buffers=device_buffers)
+            for _ in range(2):  # twice: bitmap buffers, send / receive scratch and the agreed blob capacity are reused
+                res = sharded_suite_step(plan, st, shard, comm)
             results[rank] = res
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
@@ -141,7 +83,80 @@ def test_simulated_ranks_match_one_state(dense, world):
             if g.kind == T.NUMERIC_STATS and g.is_float:
                 assert (g.min_f, g.max_f) == (w.min_f, w.max_f)
                 assert abs(g.sum_f - w.sum_f) <= 1e-9 * abs(w.sum_f) and abs(g.mean - w.mean) <= 1e-9 * abs(w.mean)
+            if g.kind == T.NUMERIC_STATS:  # rank-ordered merge: bit-identical on every rank
+                assert (g.sum_f, g.mean) == (results[0][got.index(g)].sum_f, results[0][got.index(g)].mean)
     # exact facts, independent of the device path
     assert want[-2].distinct == n
     d = orc.distinct_bits64(keys.view(np.uint64), valid[1])
     assert (want[-1].distinct, want[-1].groups_once) == (d.distinct, d.groups_once)
+
+
+def _run_ranks(world, plan, shards_of, device_buffers=True, steps=1):
+    import torch
+
+    group = ThreadGroup(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            st = T.State(plan)
+            comm = thread_comm(group, rank, device_buffers=device_buffers)
+            shard = shards_of(rank)
+            for _ in range(steps):
+                res = sharded_suite_step(plan, st, shard, comm)
+            results[rank] = (res, st)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((rank, traceback.format_exc()))
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_ranks_with_unequal_ranges_empty_shards_and_mixed_key_sets(world):
+    """What row shards of real tables look like and the round-1 exchange could not take: local value
+    ranges that differ per rank (a sorted id column: every rank's bitmap has its own base), a rank whose shard of a
+    column is all NULL (it holds no key set but owns a slice), ranks that chose different kinds of key set (small
+    shards go to the hash set, big ones to a bitmap), and a DISTINCT column without any NUMERIC_STATS spec."""
+    rng = np.random.default_rng(5)
+    n = 1_200_000
+    ids = np.arange(n, dtype=np.int64) * 3 - 1_000_000            # sorted: rank r holds its own sub-range
+    grp = rng.integers(0, 50_000, size=n, dtype=np.int64)
+    mask = rng.random(n) >= 0.1
+    bounds = [0, 70_016]                                           # unequal shards
+    for r in range(1, world - 1):
+        bounds.append(bounds[-1] + (n - 70_016) // (world - 1) // 64 * 64)
+    bounds.append(n)
+    mask[bounds[-2]:] = False                                      # the last rank's shard of `grp` is all NULL
+    valid = orc.pack_validity(mask)
+    mix = rng.integers(0, 100_000, size=n, dtype=np.int64)         # dense everywhere ...
+    mix[: bounds[1]] = rng.integers(-2**62, 2**62, size=bounds[1], dtype=np.int64)  # ... but sparse on rank 0: a hash set
+    mix[5] = -1                                                    # the all-ones pattern travels in a side counter
+    specs = [spec(T.DISTINCT, 0), spec(T.DISTINCT, 1, flags=T.FLAG_MULTIPLICITY), spec(T.COUNT, 1),
+             spec(T.DISTINCT, 2, flags=T.FLAG_MULTIPLICITY)]
+    T.init()
+    plan = T.Plan(specs)
+
+    def shards_of(rank):
+        lo, hi = bounds[rank], bounds[rank + 1]
+        return [numeric_column(ids, None, True, offset=lo, length=hi - lo),
+                numeric_column(grp, valid, True, offset=lo, length=hi - lo),
+                numeric_column(mix, None, True, offset=lo, length=hi - lo)]
+
+    dm = orc.distinct_bits64(mix.view(np.uint64), None)
+    d = orc.distinct_bits64(grp.view(np.uint64), valid)
+    for res, _ in _run_ranks(world, plan, shards_of, steps=2):
+        assert (res[0].total, res[0].non_null, res[0].distinct) == (n, n, n)
+        assert (res[1].total, res[1].non_null, res[1].distinct, res[1].groups_once) == \
+            (n, d.non_null, d.distinct, d.groups_once)
+        assert (res[2].total, res[2].non_null) == (n, d.non_null)
+        assert (res[3].total, res[3].distinct, res[3].groups_once) == (n, dm.distinct, dm.groups_once)

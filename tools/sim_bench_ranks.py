@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py's N-rank step at its REAL sizes on one GPU: N threads, each with the row shard of the 1 G-row table that
-rank would hold (125 M rows x 16 columns at N = 8: 130 GB in all), the collectives replaced by the thread-barrier
-stand-in of tests/test_gpu_distributed_sim.py.  Checks the merged results against the closed-form facts bench.py
-verifies.  Not a timing tool (the ranks share the GPU): it exercises the exact buffer sizes, range hints and bitmap
-slices of the multi-GPU run (1 G-bit bitmaps, 16 MB slices) without an 8-GPU node.
+rank would hold (125 M rows x 16 columns at N = 8: 130 GB in all), the transport of tgx_allreduce replaced by the
+thread-barrier stand-in of term_amd.distributed.thread_comm (device pointers, as RCCL gets them).  Checks the merged
+results against the closed-form facts bench.py verifies.  Not a timing tool (the ranks share the GPU): it exercises
+the exact buffer sizes and bitmap slices of the multi-GPU run (1 G-bit bitmaps, 16 MB slices) without an 8-GPU node.
 
     python tools/sim_bench_ranks.py [--ranks 8] [--rows 1000000000]"""
 import argparse
@@ -26,20 +26,19 @@ def main():
     import term_amd as T
     from term_amd import synth
     from term_amd._lib import spec
-    from term_amd.distributed import sharded_suite_step
-    from test_gpu_distributed_sim import FakeDist, FakeGroup
+    from term_amd.distributed import ThreadGroup, sharded_suite_step, thread_comm
 
     world = args.ranks
     layout, unique_cols = synth.COLUMNS_16, synth.UNIQUE_COLUMNS_16
     n_total = (args.rows // (64 * world)) * 64 * world
     n_local = n_total // world
     T.init(device_id=0, distinct_capacity_hint=n_local)
-    stat_specs = []
+    specs = []
     for ci in range(len(layout)):
-        stat_specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci)]
-    distinct_specs = [spec(T.DISTINCT, ci) for ci in unique_cols]
-    plan, plan_d = T.Plan(stat_specs), T.Plan(distinct_specs)
-    group = FakeGroup(world)
+        specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci)]
+    specs += [spec(T.DISTINCT, ci) for ci in unique_cols]
+    plan = T.Plan(specs)
+    group = ThreadGroup(world)
     results, errors = [None] * world, []
 
     def worker(rank):
@@ -48,10 +47,10 @@ def main():
             table = synth.make_table(layout, rank * n_local, n_local, n_total, 0x7E570004, "cuda")
             cols = [(T.Column.float64 if k.startswith("f_") else T.Column.int64)(v, b, length=n_local)
                     for (k, _), (v, b) in zip(layout, table)]
-            st, st_d = T.State(plan), T.State(plan_d)
+            st = T.State(plan)
+            comm = thread_comm(group, rank, device_buffers=True)
             for _ in range(args.steps):
-                res = sharded_suite_step(plan, st, plan_d, st_d, stat_specs, distinct_specs, cols, FakeDist(group, rank),
-                                         world, rank, cache_key="simbench%d" % world)
+                res = sharded_suite_step(plan, st, cols, comm)
             results[rank] = res
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
@@ -64,7 +63,6 @@ def main():
         t.join()
     if errors:
         raise SystemExit("failed: %r" % errors)
-    specs = stat_specs + distinct_specs
     ok = True
     for rank in range(world):
         by_col = {}
