@@ -109,7 +109,7 @@ __device__ void insert_run(KllDeviceSketch *s, uint32_t level, double *buf, uint
 }
 
 // sorts buf[0..1023] (raw items), halves them into buf[0..511] and inserts the run at level 1
-__device__ void compact_level0(KllDeviceSketch *s, double *buf, uint64_t salt) {
+__device__ void compact_level0(KllDeviceSketch *s, double *buf, uint64_t salt, uint32_t shift) {
   const uint32_t t = threadIdx.x;
   block_sort_1024(buf);
   const uint32_t parity = (uint32_t)(kll_mix(salt ^ 0x5bd1e995ULL) >> 35) & 1u;
@@ -118,7 +118,7 @@ __device__ void compact_level0(KllDeviceSketch *s, double *buf, uint64_t salt) {
   buf[t] = a;
   buf[t + 256] = b;
   __syncthreads();
-  insert_run(s, 1, buf, salt);
+  insert_run(s, 1 + shift, buf, salt);
 }
 
 // the same with ONE barrier: the caller alternates between two `wave_tot` buffers from call to call (a wave that
@@ -276,9 +276,11 @@ __device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i6
 // tail.  `top` grows with the batch (2^top ~ rows / 2^22): rank variance added by sampling is <= rows * 2^top / 4,
 // i.e. a relative standard error <= 2.5e-4 next to the 2e-3 of the level structure itself; batches under 8 M rows
 // are not sampled at all (top = 0: phase A is then the plain "sort every 1024 values").
+// `shift`: the input values are pre-sampled items of weight 2^shift (the picks of the fused scan): runs land `shift`
+// levels higher, the loose items keep weight 2^shift (KllDeviceSketch::shift), n counts stream items.
 __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, int64_t chunk,
                                                                  KllDeviceSketch *sketches,
-                                                                 uint64_t salt0, uint32_t top) {
+                                                                 uint64_t salt0, uint32_t top, uint32_t shift) {
   __shared__ double ring[8192];  // eight batches of sampled values: slot = sampled index & 8191 (a step brings <= 4)
   __shared__ double buf[1024];
   __shared__ uint32_t wave_tot[kKllThreads / 64];
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
     s->n = 0;
     s->level_mask = 0;
     s->lv0_count = 0;
+    s->shift = shift;
     s->min_v = __longlong_as_double(0x7FF0000000000000LL);
     s->max_v = __longlong_as_double((long long)0xFFF0000000000000ULL);
   }
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
     buf[t] = a;
     buf[t + 256] = b;
     __syncthreads();
-    insert_run(s, level + 1, buf, salt ^ (kb << 24));
+    insert_run(s, level + 1 + shift, buf, salt ^ (kb << 24));
   };
   auto pick_of = [&](uint32_t level, uint64_t seg0, uint64_t g) -> uint64_t {
     return kll_mix(salt ^ ((uint64_t)level << 56) ^ (g + (seg0 << 8))) & ((1ull << level) - 1);
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, in
       a = red_min[w] < a ? red_min[w] : a;
       b = red_max[w] > b ? red_max[w] : b;
     }
-    s->n = V;
+    s->n = V << shift;
     s->min_v = a;
     s->max_v = b;
   }
@@ -471,7 +474,7 @@ __device__ void sketch_add(KllDeviceSketch *dst, const KllDeviceSketch *src, dou
 #pragma unroll
     for (int u = 0; u < 4; u++) buf[t + u * kKllThreads] = staging[from + t + u * kKllThreads];
     __syncthreads();
-    compact_level0(dst, buf, salt ^ staged);
+    compact_level0(dst, buf, salt ^ staged, dst->shift);  // (dst and src carry the same shift: one tree per input)
     staged = from;
   }
   for (uint32_t i = t; i < staged; i += kKllThreads) dst->lv0[i] = staging[i];
@@ -513,30 +516,74 @@ __global__ __launch_bounds__(kKllThreads) void kll_fold_kernel(KllDeviceSketch *
   sketch_add(state, batch, buf, staging, salt);
 }
 
-__global__ void kll_init_kernel(KllDeviceSketch *s) {
+__global__ void kll_init_kernel(KllDeviceSketch *s, uint32_t shift) {
   if (threadIdx.x == 0) {
     s->n = 0;
     s->level_mask = 0;
     s->lv0_count = 0;
+    s->shift = shift;
     s->min_v = __longlong_as_double(0x7FF0000000000000LL);
     s->max_v = __longlong_as_double((long long)0xFFF0000000000000ULL);
   }
 }
 
-void launch_kll_init(KllDeviceSketch *s, hipStream_t stream) {
-  hipLaunchKernelGGL(kll_init_kernel, dim3(1), dim3(64), 0, stream, s);
+// The fused scan's per-wave facts: the column's true NaN-ignoring MIN / MAX (the sampled picks need not contain
+// them; KllSketch::get_quantile answers phi = 0 / 1 with them, kll_sketch.rs:250-256) go into the running sketch.
+__global__ __launch_bounds__(256) void kll_meta_kernel(const KllWaveMeta *meta, int n_waves, KllDeviceSketch *state) {
+  double mn = __longlong_as_double(0x7FF0000000000000LL), mx = -mn;
+  for (int i = threadIdx.x; i < n_waves; i += 256) {
+    if (meta[i].count == 0) continue;
+    mn = meta[i].min_v < mn ? meta[i].min_v : mn;
+    mx = meta[i].max_v > mx ? meta[i].max_v : mx;
+  }
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    const double omn = __shfl_down(mn, dlt, 64), omx = __shfl_down(mx, dlt, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  __shared__ double smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      mn = smn[w] < mn ? smn[w] : mn;
+      mx = smx[w] > mx ? smx[w] : mx;
+    }
+    state->min_v = mn < state->min_v ? mn : state->min_v;
+    state->max_v = mx > state->max_v ? mx : state->max_v;
+  }
+}
+
+void launch_kll_meta(const KllWaveMeta *meta, int n_waves, KllDeviceSketch *state, hipStream_t stream) {
+  hipLaunchKernelGGL(kll_meta_kernel, dim3(1), dim3(256), 0, stream, meta, n_waves, state);
+}
+
+void launch_kll_init(KllDeviceSketch *s, hipStream_t stream, uint32_t shift) {
+  hipLaunchKernelGGL(kll_init_kernel, dim3(1), dim3(64), 0, stream, s, shift);
 }
 
 // sketches: scratch for `groups` per-workgroup sketches; result folded into `state`
-void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
-                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream) {
-  // sampling level: 2^top ~ rows / 2^22 (none below 8 M rows), see kll_build_kernel
+// the sampling level of a batch: 2^top ~ rows / 2^22 (none below 8 M rows), see kll_build_kernel
+uint32_t kll_top_for(int64_t rows) {
   uint32_t top = 0;
-  while (top < 16 && (d.length >> (23 + top)) > 0) top++;
+  while (top < 16 && (rows >> (23 + top)) > 0) top++;
+  return top;
+}
+
+// `presampled_shift` > 0: `d` holds picks of weight 2^shift (NaN = no pick): sketched without further sampling into a
+// state sketch of that shift
+void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
+                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream, uint32_t presampled_shift,
+                       bool no_sampling) {
+  uint32_t top = (presampled_shift || no_sampling) ? 0 : kll_top_for(d.length);
   // (measured on 1 G rows, 1024 workgroups: top - 1 / - 2 / - 3 = 2.39 / 2.92 / 3.87 ms instead of 2.10 -- a flush
   // (sort of 1024 + insert) costs ~35 us per workgroup; top + 2 / + 4 = 3.36 / 4.97 ms -- the tail re-read of phase B)
   hipLaunchKernelGGL(kll_build_kernel, dim3(groups), dim3(kKllThreads), 0, stream, d, chunk, sketches,
-                     salt, top);
+                     salt, top, presampled_shift);
   for (int stride = 1; stride < groups; stride <<= 1) {
     int pairs = (groups + 2 * stride - 1) / (2 * stride);
     hipLaunchKernelGGL(kll_tree_kernel, dim3(pairs), dim3(kKllThreads), 0, stream, sketches, groups,

@@ -13,7 +13,9 @@ struct KllDeviceSketch {
   double min_v, max_v;
   uint64_t level_mask;   // bit l: runs[l] is occupied
   uint32_t lv0_count;
-  uint32_t pad;
+  // a sketch of pre-sampled values (the picks of the fused scan, each standing for 2^shift stream items): its loose
+  // items weigh 2^shift, its runs sit `shift` levels higher, n counts stream items.  0 for sketches of raw values.
+  uint32_t shift;
   double lv0[kKllLv0Cap];
   double runs[kKllMaxLevels][kKllRunItems];  // runs[0] unused
 };
@@ -26,5 +28,28 @@ struct KllColDesc {
   int32_t is_float;
   int32_t pad;
 };
+
+// ---- the KLL sampler riding on the numeric scan (scan.hip): what one wave of the scan leaves behind for a column.
+// A wave's rows are a stream of their own; it cuts its non-NULL, non-NaN values into groups of 2^top consecutive
+// values and keeps ONE member of each, chosen by a counter hash (Karnin-Lang-Liberty sec. 3.2: an item of weight 2^l
+// below the lowest kept level is one uniformly chosen member of 2^l consecutive stream items).
+//   picks[wave * cap + g]        the chosen member of the wave's group g (weight 2^top), NaN past its last group
+//   left[wave * 2^top + i]       the < 2^top values after its last complete group (weight 1), NaN-padded
+//   meta[wave]                   values taken, NaN-ignoring min / max
+// so total weight = sum over waves of (groups * 2^top + leftovers) = the number of values, exactly.  Both arrays are
+// then sketched by kll_build_kernel (it drops NaN): the picks with shift = top, the leftovers with shift = 0.
+struct KllWaveMeta {
+  unsigned long long count;
+  double min_v, max_v;
+};
+struct ScanKll {
+  double *picks;      // nullptr: no KLL on this column
+  double *left;
+  KllWaveMeta *meta;
+  uint64_t salt;
+  int32_t top;        // 1 .. kScanKllMaxTop
+  int32_t cap;        // picks per wave
+};
+constexpr int kScanKllMaxTop = 8;
 
 }  // namespace tgx

@@ -471,9 +471,9 @@ def test_distinct_bitmap_slice_exchange_single_process(mult):
                                             2 * slice_words)
     blobs = [s.serialize() for s in states]
     assert all(len(b) < 200 for b in blobs)  # owner-partitioned states travel as counts only
-    from term_amd.distributed import merge_blobs
-
-    res = merge_blobs(plan, blobs).finalize()
+    merged = T.State.deserialize(plan, blobs[0])
+    merged.merge([T.State.deserialize(plan, b) for b in blobs[1:]])
+    res = merged.finalize()
     d = orc.distinct_bits64(vals.view(np.uint64), validity)
     assert (res[0].total, res[0].non_null, res[0].distinct) == (d.total, d.non_null, d.distinct)
     if mult:
