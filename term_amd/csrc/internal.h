@@ -44,6 +44,12 @@ inline tgx_status abi_exception(tgx_error *err) {
 void launch_scan_pivot(const ScanLaunch &L, int n_cols, double *d_pivots, int32_t *d_pivot_set, hipStream_t stream);
 void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
                            ScanAcc *d_accs, hipStream_t stream);
+void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t lds_bytes, ScanPartial *d_partials,
+                     hipStream_t stream);
+void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,
+                       ScanPartial *d_partials, void *d_como_partials, hipStream_t stream);
+void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, const void *d_partials,
+                             ComomentAcc *d_accs, hipStream_t stream);
 void launch_widen32(const void *src, void *dst, int64_t n, int is_float, int n_cu, hipStream_t stream);
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
                              ScanAcc *d_accs, hipStream_t stream);

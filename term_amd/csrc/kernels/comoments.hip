@@ -15,11 +15,6 @@ namespace tgx {
 typedef const int64_t __attribute__((address_space(1))) *global_i64_ptr;
 typedef const uint8_t __attribute__((address_space(1))) *global_u8_ptr;
 
-struct ComomentPartial {
-  int64_t n;
-  double s[5], c[5];
-};
-
 __device__ __forceinline__ void cm_two_sum(double &s, double &c, double x) {
   double t = s + x;
   double bp = t - s;
@@ -180,6 +175,13 @@ __global__ __launch_bounds__(64) void comoments_reduce_kernel(
 }
 
 size_t comoments_partial_bytes() { return sizeof(ComomentPartial); }
+
+// the fold alone: scan_pair_kernel leaves the same per-block partials
+void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, const void *d_partials,
+                             ComomentAcc *d_accs, hipStream_t stream) {
+  hipLaunchKernelGGL(comoments_reduce_kernel, dim3(n_pairs), dim3(64), 0, stream, L,
+                     (const ComomentPartial *)d_partials, blocks_per_pair, d_accs);
+}
 
 void launch_comoments(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, void *d_partials,
                       ComomentAcc *d_accs, hipStream_t stream) {

@@ -3,6 +3,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "kll_types.h"
+
 namespace tgx {
 
 constexpr int kScanBlock = 256;      // 4 waves of 64
@@ -23,6 +25,7 @@ struct ScanColDesc {
   const double *pivot;      // device scalar: shift for the variance lanes (may be nullptr)
   int32_t elem32;           // 1: `values` holds 4-byte elements (Int32 / Float32), widened as they are loaded
   int32_t pad32;
+  ScanKll kll;              // kll.picks != nullptr: the column's KLL sampler rides on this scan (kll_types.h)
 };
 
 // Per (column, block) partial written by scan_kernel; reduced in fixed order by scan_reduce_kernel.
@@ -58,6 +61,21 @@ struct ScanLaunch {
   int32_t acc_index[kMaxColsPerLaunch];  // running-state slot of each column
 };
 
+// Two columns scanned TOGETHER by one workgroup (scan_pair_kernel): their own aggregates as above plus the raw
+// co-moments over the rows where both are non-NULL -- a COMOMENTS check whose columns also carry NUMERIC_STATS /
+// COUNT / KLL checks costs no second pass over them.  Both columns share head / n_tiles (same length, offsets
+// congruent modulo 64).
+struct ScanPairDesc {
+  ScanColDesc x, y;
+  int32_t x_acc, y_acc;   // running-state slots of the two columns (-1: the column has no scan task of its own)
+  int32_t como_acc;       // running-state slot of the pair's co-moments
+  int32_t pad;
+};
+constexpr int kMaxPairsPerLaunch = 8;
+struct ScanPairLaunch {
+  ScanPairDesc pairs[kMaxPairsPerLaunch];
+};
+
 // Validity-only columns (COUNT(*), COUNT(col)).
 struct CountColDesc {
   const uint8_t *validity;  // never nullptr here (no-validity columns are answered on the host)
@@ -87,6 +105,12 @@ struct ComomentColDesc {
 struct ComomentLaunch {
   ComomentColDesc pairs[kMaxColsPerLaunch];
   int32_t acc_index[kMaxColsPerLaunch];
+};
+
+// per (pair, block) partial of the co-moment kernels (comoments.hip, scan_pair_kernel)
+struct ComomentPartial {
+  int64_t n;
+  double s[5], c[5];
 };
 
 struct ComomentAcc {

@@ -138,6 +138,134 @@ __device__ void scan_ragged(const ScanColDesc &c, int64_t r0, int64_t r1, int la
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The KLL sampler riding on the scan (kll_types.h, ScanKll): every wave keeps the values of its own row stream that
+// have not been grouped yet in a private LDS ring -- at most 2^top - 1 pending ones plus the 512 a tile brings --
+// and, whenever 2^top of them are complete, keeps one member of the group chosen by a counter hash.  Per value this
+// costs a ballot, an mbcnt and one LDS store next to the column's other accumulators; the column crosses HBM once.
+struct KllLane {
+  double mn, mx;           // NaN-ignoring MIN / MAX (KllSketch::update drops NaN, kll_sketch.rs:197-199)
+  uint32_t pending;        // values in the ring, wave-uniform
+  uint32_t groups;         // groups emitted so far, wave-uniform
+};
+
+__device__ __forceinline__ void kll_lane_init(KllLane &K) {
+  K.mn = __longlong_as_double(0x7FF0000000000000LL);
+  K.mx = -K.mn;
+  K.pending = 0;
+  K.groups = 0;
+}
+
+__device__ __forceinline__ uint64_t scan_mix(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+
+// LDS traffic between the lanes of ONE wave: program order is enough for the hardware (a wave's LDS instructions
+// execute in order), the fence keeps the compiler from moving the accesses across it
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one value per lane: `ok` = non-NULL and not NaN
+__device__ __forceinline__ void kll_push(KllLane &K, double *ring, double x, bool ok) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+  const uint32_t pos = K.pending + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  if (ok) ring[pos] = x;
+  K.pending += (uint32_t)__builtin_popcountll(m);
+  const double xn = ok ? x : __longlong_as_double(0x7FF8000000000000LL);
+  K.mn = __builtin_fmin(K.mn, xn);  // v_min_f64 / v_max_f64 return the other operand for a NaN
+  K.mx = __builtin_fmax(K.mx, xn);
+}
+
+// emits the complete groups of the ring and moves the rest to its front
+__device__ __forceinline__ void kll_drain(KllLane &K, double *ring, const ScanKll &q, uint32_t wave_slot, int lane) {
+  const uint32_t top = (uint32_t)q.top;
+  const uint32_t ng = K.pending >> top;
+  if (ng == 0) return;  // uniform
+  wave_lds_fence();
+  double *out = q.picks + (size_t)wave_slot * (size_t)q.cap;
+  for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+    const uint32_t g = g0 + (uint32_t)lane;
+    if (g < ng && K.groups + g < (uint32_t)q.cap) {
+      const uint64_t h = scan_mix(q.salt ^ ((uint64_t)wave_slot << 36) ^ (uint64_t)(K.groups + g));
+      out[K.groups + g] = ring[(g << top) + ((uint32_t)(h >> 20) & ((1u << top) - 1u))];
+    }
+  }
+  const uint32_t rem = K.pending & ((1u << top) - 1u), src = ng << top;  // src >= 2^top > rem: no overlap
+  wave_lds_fence();
+  for (uint32_t r = (uint32_t)lane; r < rem; r += 64) ring[r] = ring[src + r];
+  wave_lds_fence();
+  K.groups += ng;
+  K.pending = rem;
+}
+
+// end of the wave's stream: the pending values leave as weight-1 leftovers, unused slots as NaN
+__device__ __forceinline__ void kll_finish_wave(KllLane &K, double *ring, const ScanKll &q, uint32_t wave_slot, int lane) {
+  kll_drain(K, ring, q, wave_slot, lane);
+  wave_lds_fence();
+  const double nan = __longlong_as_double(0x7FF8000000000000LL);
+  double *left = q.left + ((size_t)wave_slot << q.top);
+  for (uint32_t i = (uint32_t)lane; i < (1u << q.top); i += 64) left[i] = i < K.pending ? ring[i] : nan;
+  double *out = q.picks + (size_t)wave_slot * (size_t)q.cap;
+  for (uint32_t g = K.groups + (uint32_t)lane; g < (uint32_t)q.cap; g += 64) out[g] = nan;
+  double mn = K.mn, mx = K.mx;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    mn = __builtin_fmin(mn, __shfl_down(mn, d, 64));
+    mx = __builtin_fmax(mx, __shfl_down(mx, d, 64));
+  }
+  if (lane == 0) {
+    KllWaveMeta m;
+    m.count = ((unsigned long long)K.groups << q.top) + K.pending;
+    m.min_v = mn;
+    m.max_v = mx;
+    q.meta[wave_slot] = m;
+  }
+}
+
+// the value a column hands its sketch: doubles as they are, Int64 cast (KllSketch takes f64)
+template <bool IS_FLOAT>
+__device__ __forceinline__ double kll_value(int64_t bits) {
+  return IS_FLOAT ? __longlong_as_double(bits) : (double)bits;
+}
+
+template <bool IS_FLOAT>
+__device__ __forceinline__ void kll_push_pair(KllLane &K, double *ring, i64x2 v, uint32_t two_bits) {
+  const double a = kll_value<IS_FLOAT>(v.x), b = kll_value<IS_FLOAT>(v.y);
+  kll_push(K, ring, a, (two_bits & 1u) != 0 && a == a);
+  kll_push(K, ring, b, (two_bits & 2u) != 0 && b == b);
+}
+
+// the same rows with the KLL sampler on: whole waves step together (the ring is a wave's), 64 rows per step
+template <bool IS_FLOAT, bool VAR>
+__device__ void scan_ragged_kll(const ScanColDesc &c, int64_t r0, int64_t r1, int lane, int stride, LaneAcc &a,
+                                double pivot, KllLane &K, double *ring, uint32_t wave_slot) {
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)c.values + c.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)c.validity;
+  for (int64_t i0 = r0; i0 < r1; i0 += stride) {  // uniform trip count
+    const int64_t i = i0 + lane;
+    const bool in = i < r1;
+    bool valid = in;
+    if (in && c.validity) {
+      int64_t b = c.offset + i;
+      valid = (vbits[b >> 3] >> (b & 7)) & 1;
+    }
+    const int64_t bits = in ? vals[i] : 0;
+    acc_value<IS_FLOAT, VAR>(a, bits, valid, pivot);
+    a.cnt += valid ? 1 : 0;
+    const double x = kll_value<IS_FLOAT>(bits);
+    kll_push(K, ring, x, valid && x == x);
+    kll_drain(K, ring, c.kll, wave_slot, lane);
+  }
+}
+
+
 template <int VARIANT>
 __device__ __forceinline__ i64x2 tile_load(global_i64x2_ptr p) {
   if (VARIANT & 1) return __builtin_nontemporal_load(p);
@@ -156,10 +284,11 @@ __device__ __forceinline__ i64x2 tile_load32(global_i32x2_ptr p) {
   return r;
 }
 
-template <bool IS_FLOAT, bool VAR, int VARIANT>
+template <bool IS_FLOAT, bool VAR, int VARIANT, bool KLL = false>
 __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_global,
                                            int64_t n_waves, int lane, LaneAcc &a,
-                                           int64_t &tile_count, double pivot) {
+                                           int64_t &tile_count, double pivot, KllLane *K = nullptr,
+                                           double *ring = nullptr, uint32_t wave_slot = 0) {
   global_i64x2_ptr vp =
       (global_i64x2_ptr)(uintptr_t)((const int64_t *)c.values + c.offset + c.head);
   global_i32x2_ptr vp32 =
@@ -214,10 +343,19 @@ __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_gl
     } else {
       cnt += kTileRows;
     }
-    acc_pair<IS_FLOAT, VAR>(a, v0, (uint32_t)((upper ? w1 : w0) >> sh) & 3u, pivot);
-    acc_pair<IS_FLOAT, VAR>(a, v1, (uint32_t)((upper ? w3 : w2) >> sh) & 3u, pivot);
-    acc_pair<IS_FLOAT, VAR>(a, v2, (uint32_t)((upper ? w5 : w4) >> sh) & 3u, pivot);
-    acc_pair<IS_FLOAT, VAR>(a, v3, (uint32_t)((upper ? w7 : w6) >> sh) & 3u, pivot);
+    const uint32_t b0 = (uint32_t)((upper ? w1 : w0) >> sh) & 3u, b1 = (uint32_t)((upper ? w3 : w2) >> sh) & 3u;
+    const uint32_t b2 = (uint32_t)((upper ? w5 : w4) >> sh) & 3u, b3 = (uint32_t)((upper ? w7 : w6) >> sh) & 3u;
+    acc_pair<IS_FLOAT, VAR>(a, v0, b0, pivot);
+    acc_pair<IS_FLOAT, VAR>(a, v1, b1, pivot);
+    acc_pair<IS_FLOAT, VAR>(a, v2, b2, pivot);
+    acc_pair<IS_FLOAT, VAR>(a, v3, b3, pivot);
+    if (KLL) {
+      kll_push_pair<IS_FLOAT>(*K, ring, v0, b0);
+      kll_push_pair<IS_FLOAT>(*K, ring, v1, b1);
+      kll_push_pair<IS_FLOAT>(*K, ring, v2, b2);
+      kll_push_pair<IS_FLOAT>(*K, ring, v3, b3);
+      kll_drain(*K, ring, c.kll, wave_slot, lane);
+    }
   }
   tile_count = cnt;
 }
@@ -290,7 +428,9 @@ __device__ __forceinline__ void scan_fold(ScanAcc &s, const LaneAcc &a, const Sc
   }
 }
 
-template <bool IS_FLOAT, bool VAR, int VARIANT>
+extern __shared__ double scan_dyn_lds[];  // KLL rings: one per (wave, sampled column) of the workgroup
+
+template <bool IS_FLOAT, bool VAR, int VARIANT, bool KLL = false>
 __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out, ScanAcc *direct, int wave,
                                           int lane) {
   LaneAcc a;
@@ -299,19 +439,35 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
   const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
   int64_t tile_count = 0;
+  KllLane K;
+  double *ring = nullptr;
+  if (KLL) {
+    kll_lane_init(K);
+    ring = scan_dyn_lds + (size_t)wave * ((1u << c.kll.top) + kTileRows);
+  }
+  const uint32_t wave_slot = (uint32_t)wave_global;
   if (c.n_tiles > 0) {
-    scan_tiles<IS_FLOAT, VAR, VARIANT>(c, wave_global, n_waves, lane, a, tile_count, pivot);
+    scan_tiles<IS_FLOAT, VAR, VARIANT, KLL>(c, wave_global, n_waves, lane, a, tile_count, pivot, &K, ring, wave_slot);
     // ragged edges belong to the last block (it has the least tile work when tiles % grid != 0)
     if (blockIdx.x == gridDim.x - 1) {
       const int64_t tail0 = c.head + c.n_tiles * kTileRows;
-      if (wave == 0) scan_ragged<IS_FLOAT, VAR>(c, 0, c.head, lane, 64, a, pivot);
-      if (wave == 1) scan_ragged<IS_FLOAT, VAR>(c, tail0, c.length, lane, 64, a, pivot);
+      if (KLL) {
+        if (wave == 0) scan_ragged_kll<IS_FLOAT, VAR>(c, 0, c.head, lane, 64, a, pivot, K, ring, wave_slot);
+        if (wave == 1) scan_ragged_kll<IS_FLOAT, VAR>(c, tail0, c.length, lane, 64, a, pivot, K, ring, wave_slot);
+      } else {
+        if (wave == 0) scan_ragged<IS_FLOAT, VAR>(c, 0, c.head, lane, 64, a, pivot);
+        if (wave == 1) scan_ragged<IS_FLOAT, VAR>(c, tail0, c.length, lane, 64, a, pivot);
+      }
     }
+  } else if (KLL) {
+    scan_ragged_kll<IS_FLOAT, VAR>(c, wave_global * 64, c.length, lane, (int)(n_waves * 64), a, pivot, K, ring,
+                                   wave_slot);
   } else {
     // unaligned or short column: every wave strides over rows
     scan_ragged<IS_FLOAT, VAR>(c, wave_global * 64, c.length, lane, (int)(n_waves * 64), a,
                                pivot);
   }
+  if (KLL) kll_finish_wave(K, ring, c.kll, wave_slot, lane);
   // wave reduce
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -376,6 +532,283 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const ScanLaunch L,
   }
 }
 
+
+// the same columns with their KLL samplers on (dynamic LDS: one ring per wave); never the small-batch direct fold
+template <int VARIANT>
+__global__ __launch_bounds__(kScanBlock) void scan_kll_kernel(const ScanLaunch L, ScanPartial *__restrict__ partials) {
+  const ScanColDesc c = L.cols[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  ScanPartial *out = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (c.is_float) {
+    if (c.want_variance)
+      scan_body<true, true, VARIANT, true>(c, out, nullptr, wave, lane);
+    else
+      scan_body<true, false, VARIANT, true>(c, out, nullptr, wave, lane);
+  } else {
+    if (c.want_variance)
+      scan_body<false, true, VARIANT, true>(c, out, nullptr, wave, lane);
+    else
+      scan_body<false, false, VARIANT, true>(c, out, nullptr, wave, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two columns per workgroup (ScanPairDesc): each column's own aggregates exactly as scan_body computes them, the raw
+// co-moments of the pair over the rows where both are non-NULL (TG/analyzers/advanced/correlation.rs:239-249: every
+// value CAST AS DOUBLE), and either column's KLL sampler -- a correlation check next to range / quantile checks on
+// the same columns reads them once.
+struct ComoLane {
+  double s[5], c[5];
+};
+
+__device__ __forceinline__ void como_fold(ComoLane &m, double a, double b, bool both) {
+  const unsigned long long bm = __builtin_amdgcn_ballot_w64(both);
+  const bool ok = __builtin_amdgcn_inverse_ballot_w64(bm);
+  a = ok ? a : 0.0;
+  b = ok ? b : 0.0;
+  two_sum_add(m.s[0], m.c[0], a);
+  two_sum_add(m.s[1], m.c[1], b);
+  two_sum_add(m.s[2], m.c[2], a * a);
+  two_sum_add(m.s[3], m.c[3], b * b);
+  two_sum_add(m.s[4], m.c[4], a * b);
+}
+
+template <bool XF, bool YF, bool KLL>
+__device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, LaneAcc &ay, ComoLane &m, i64x2 vx,
+                                          i64x2 vy, uint32_t bx, uint32_t by, KllLane &Kx, KllLane &Ky, double *rx,
+                                          double *ry) {
+  acc_pair<XF, false>(ax, vx, bx, 0.0);
+  acc_pair<YF, false>(ay, vy, by, 0.0);
+  const double x0 = kll_value<XF>(vx.x), x1 = kll_value<XF>(vx.y);
+  const double y0 = kll_value<YF>(vy.x), y1 = kll_value<YF>(vy.y);
+  como_fold(m, x0, y0, (bx & by & 1u) != 0);
+  como_fold(m, x1, y1, (bx & by & 2u) != 0);
+  if (KLL) {
+    if (P.x.kll.picks) {  // uniform
+      kll_push(Kx, rx, x0, (bx & 1u) != 0 && x0 == x0);
+      kll_push(Kx, rx, x1, (bx & 2u) != 0 && x1 == x1);
+    }
+    if (P.y.kll.picks) {
+      kll_push(Ky, ry, y0, (by & 1u) != 0 && y0 == y0);
+      kll_push(Ky, ry, y1, (by & 2u) != 0 && y1 == y1);
+    }
+  }
+}
+
+// one row per lane: ragged edges and pairs whose buffers do not allow tiles
+template <bool XF, bool YF, bool KLL>
+__device__ void pair_ragged(const ScanPairDesc &P, int64_t r0, int64_t r1, int lane, int stride, LaneAcc &ax,
+                            LaneAcc &ay, ComoLane &m, int64_t &n_both, KllLane &Kx, KllLane &Ky, double *rx, double *ry,
+                            uint32_t wave_slot) {
+  global_i64_ptr xs = (global_i64_ptr)(uintptr_t)((const int64_t *)P.x.values + P.x.offset);
+  global_i64_ptr ys = (global_i64_ptr)(uintptr_t)((const int64_t *)P.y.values + P.y.offset);
+  global_u8_ptr xv = (global_u8_ptr)(uintptr_t)P.x.validity, yv = (global_u8_ptr)(uintptr_t)P.y.validity;
+  for (int64_t i0 = r0; i0 < r1; i0 += stride) {  // uniform trip count: the KLL rings are a wave's
+    const int64_t i = i0 + lane;
+    const bool in = i < r1;
+    bool vx = in, vy = in;
+    if (in && xv) {
+      const int64_t b = P.x.offset + i;
+      vx = (xv[b >> 3] >> (b & 7)) & 1;
+    }
+    if (in && yv) {
+      const int64_t b = P.y.offset + i;
+      vy = (yv[b >> 3] >> (b & 7)) & 1;
+    }
+    const int64_t xb = in ? xs[i] : 0, yb = in ? ys[i] : 0;
+    acc_value<XF, false>(ax, xb, vx, 0.0);
+    acc_value<YF, false>(ay, yb, vy, 0.0);
+    ax.cnt += vx ? 1 : 0;
+    ay.cnt += vy ? 1 : 0;
+    const double a = kll_value<XF>(xb), b = kll_value<YF>(yb);
+    como_fold(m, a, b, vx && vy);
+    n_both += (vx && vy) ? 1 : 0;
+    if (KLL) {
+      if (P.x.kll.picks) {
+        kll_push(Kx, rx, a, vx && a == a);
+        kll_drain(Kx, rx, P.x.kll, wave_slot, lane);
+      }
+      if (P.y.kll.picks) {
+        kll_push(Ky, ry, b, vy && b == b);
+        kll_drain(Ky, ry, P.y.kll, wave_slot, lane);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void write_partial(ScanPartial *out, const LaneAcc &r, int64_t cnt) {
+  ScanPartial p;
+  p.non_null = cnt;
+  p.min_k = r.mn;
+  p.max_k = r.mx;
+  p.sum_lo = r.lo;
+  p.sum_hi = r.hi;
+  p.sum = r.s;
+  p.comp = r.c;
+  p.s1 = r.s1;
+  p.s2 = r.s2;
+  *out = p;
+}
+
+template <bool XF, bool YF, bool KLL>
+__device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *out_x, ScanPartial *out_y,
+                                          ComomentPartial *out_c, int wave, int lane) {
+  LaneAcc ax, ay;
+  acc_init(ax);
+  acc_init(ay);
+  ComoLane m;
+#pragma unroll
+  for (int k = 0; k < 5; k++) m.s[k] = m.c[k] = 0.0;
+  KllLane Kx, Ky;
+  kll_lane_init(Kx);
+  kll_lane_init(Ky);
+  double *rx = nullptr, *ry = nullptr;
+  if (KLL) {
+    // rings of the sampled columns of this wave, x first
+    const size_t rx_n = P.x.kll.picks ? ((size_t)1 << P.x.kll.top) + kTileRows : 0;
+    const size_t ry_n = P.y.kll.picks ? ((size_t)1 << P.y.kll.top) + kTileRows : 0;
+    rx = scan_dyn_lds + (size_t)wave * (rx_n + ry_n);
+    ry = rx + rx_n;
+  }
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+  const uint32_t wave_slot = (uint32_t)wave_global;
+  const ScanColDesc &cx = P.x, &cy = P.y;
+  int64_t cnt_x = 0, cnt_y = 0, n_both = 0;
+  if (cx.n_tiles > 0) {
+    global_i64x2_ptr px = (global_i64x2_ptr)(uintptr_t)((const int64_t *)cx.values + cx.offset + cx.head);
+    global_i64x2_ptr py = (global_i64x2_ptr)(uintptr_t)((const int64_t *)cy.values + cy.offset + cy.head);
+    const bool hx = cx.validity != nullptr, hy = cy.validity != nullptr;
+    const_u64_ptr wx = (const_u64_ptr)(uintptr_t)(cx.validity + ((cx.offset + cx.head) >> 3));
+    const_u64_ptr wy = (const_u64_ptr)(uintptr_t)(cy.validity + ((cy.offset + cy.head) >> 3));
+    const uint32_t sh = 2u * (uint32_t)(lane & 31);
+    const bool upper = lane >= 32;
+    for (int64_t t = wave_global; t < cx.n_tiles; t += n_waves) {
+      const int64_t p = t * (kTileRows / 2) + lane;
+      const i64x2 x0 = __builtin_nontemporal_load(px + p), x1 = __builtin_nontemporal_load(px + p + 64);
+      const i64x2 x2 = __builtin_nontemporal_load(px + p + 128), x3 = __builtin_nontemporal_load(px + p + 192);
+      const i64x2 y0 = __builtin_nontemporal_load(py + p), y1 = __builtin_nontemporal_load(py + p + 64);
+      const i64x2 y2 = __builtin_nontemporal_load(py + p + 128), y3 = __builtin_nontemporal_load(py + p + 192);
+      uint64_t a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) a[k] = b[k] = ~0ull;
+      if (hx) {
+        const_u64_ptr q = wx + t * (kTileRows / 64);
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = q[k];
+      }
+      if (hy) {
+        const_u64_ptr q = wy + t * (kTileRows / 64);
+#pragma unroll
+        for (int k = 0; k < 8; k++) b[k] = q[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        cnt_x += __builtin_popcountll(a[k]);
+        cnt_y += __builtin_popcountll(b[k]);
+        n_both += __builtin_popcountll(a[k] & b[k]);
+      }
+      pair_rows<XF, YF, KLL>(P, ax, ay, m, x0, y0, (uint32_t)((upper ? a[1] : a[0]) >> sh) & 3u,
+                             (uint32_t)((upper ? b[1] : b[0]) >> sh) & 3u, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, m, x1, y1, (uint32_t)((upper ? a[3] : a[2]) >> sh) & 3u,
+                             (uint32_t)((upper ? b[3] : b[2]) >> sh) & 3u, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, m, x2, y2, (uint32_t)((upper ? a[5] : a[4]) >> sh) & 3u,
+                             (uint32_t)((upper ? b[5] : b[4]) >> sh) & 3u, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, m, x3, y3, (uint32_t)((upper ? a[7] : a[6]) >> sh) & 3u,
+                             (uint32_t)((upper ? b[7] : b[6]) >> sh) & 3u, Kx, Ky, rx, ry);
+      if (KLL) {
+        if (P.x.kll.picks) kll_drain(Kx, rx, P.x.kll, wave_slot, lane);
+        if (P.y.kll.picks) kll_drain(Ky, ry, P.y.kll, wave_slot, lane);
+      }
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+      const int64_t tail0 = cx.head + cx.n_tiles * kTileRows;
+      if (wave == 0) pair_ragged<XF, YF, KLL>(P, 0, cx.head, lane, 64, ax, ay, m, n_both, Kx, Ky, rx, ry, wave_slot);
+      if (wave == 1)
+        pair_ragged<XF, YF, KLL>(P, tail0, cx.length, lane, 64, ax, ay, m, n_both, Kx, Ky, rx, ry, wave_slot);
+    }
+  } else {
+    pair_ragged<XF, YF, KLL>(P, wave_global * 64, cx.length, lane, (int)(n_waves * 64), ax, ay, m, n_both, Kx, Ky,
+                             rx, ry, wave_slot);
+  }
+  if (KLL) {
+    if (P.x.kll.picks) kll_finish_wave(Kx, rx, P.x.kll, wave_slot, lane);
+    if (P.y.kll.picks) kll_finish_wave(Ky, ry, P.y.kll, wave_slot, lane);
+  }
+  // wave reduce
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    LaneAcc bx = acc_shfl_down(ax, d), by = acc_shfl_down(ay, d);
+    acc_merge(ax, bx, XF);
+    acc_merge(ay, by, YF);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const double os = __shfl_down(m.s[k], d, 64), oc = __shfl_down(m.c[k], d, 64);
+      m.c[k] += oc;
+      two_sum_add(m.s[k], m.c[k], os);
+    }
+  }
+  __shared__ LaneAcc s_x[kWavesPerBlock], s_y[kWavesPerBlock];
+  __shared__ ComoLane s_m[kWavesPerBlock];
+  __shared__ int64_t s_n[kWavesPerBlock][3];
+  if (lane == 0) {
+    s_x[wave] = ax;
+    s_y[wave] = ay;
+    s_m[wave] = m;
+    s_n[wave][0] = cnt_x;
+    s_n[wave][1] = cnt_y;
+    s_n[wave][2] = n_both;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    LaneAcc rxa = s_x[0], rya = s_y[0];
+    ComomentPartial c;
+    c.n = s_n[0][2];
+    int64_t cx_n = s_n[0][0], cy_n = s_n[0][1];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      c.s[k] = s_m[0].s[k];
+      c.c[k] = s_m[0].c[k];
+    }
+    for (int w = 1; w < kWavesPerBlock; w++) {
+      acc_merge(rxa, s_x[w], XF);
+      acc_merge(rya, s_y[w], YF);
+      cx_n += s_n[w][0];
+      cy_n += s_n[w][1];
+      c.n += s_n[w][2];
+      for (int k = 0; k < 5; k++) {
+        c.c[k] += s_m[w].c[k];
+        two_sum_add(c.s[k], c.c[k], s_m[w].s[k]);
+      }
+    }
+    write_partial(out_x, rxa, cx_n + rxa.cnt);
+    write_partial(out_y, rya, cy_n + rya.cnt);
+    *out_c = c;
+  }
+}
+
+// grid = (blocks per pair, pairs); partials: [2 * pair + {0, 1}][block] for the columns, como: [pair][block]
+template <bool KLL>
+__global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(const ScanPairLaunch L, ScanPartial *__restrict__ partials,
+                                                                ComomentPartial *__restrict__ como) {
+  const ScanPairDesc &P = L.pairs[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  ScanPartial *ox = partials + ((size_t)2 * blockIdx.y) * gridDim.x + blockIdx.x;
+  ScanPartial *oy = partials + ((size_t)2 * blockIdx.y + 1) * gridDim.x + blockIdx.x;
+  ComomentPartial *oc = como + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const bool xf = P.x.is_float != 0, yf = P.y.is_float != 0;
+  if (xf && yf)
+    pair_body<true, true, KLL>(P, ox, oy, oc, wave, lane);
+  else if (xf)
+    pair_body<true, false, KLL>(P, ox, oy, oc, wave, lane);
+  else if (yf)
+    pair_body<false, true, KLL>(P, ox, oy, oc, wave, lane);
+  else
+    pair_body<false, false, KLL>(P, ox, oy, oc, wave, lane);
+}
+
 // Folds the per-block partials of each column (fixed order => bitwise reproducible) and merges
 // the batch into the running per-column state.  grid = columns, block = 64 (one wave).
 __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
@@ -384,6 +817,7 @@ __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
                                                           ScanAcc *__restrict__ accs) {
   const int col = blockIdx.x;
   const int lane = threadIdx.x;
+  if (L.acc_index[col] < 0) return;  // a column scanned only for what rode on it (KLL sampler, co-moments)
   const ScanColDesc c = L.cols[col];
   const ScanPartial *p = partials + (size_t)col * blocks_per_col;
   LaneAcc a;
@@ -567,6 +1001,23 @@ void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, 
   // Measured at 1 G rows x 16 columns (ms per launch): 0: 21.11, 1: 20.95, 2: 21.24, 3: 20.74 -> 3.
   hipLaunchKernelGGL(scan_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, L, d_partials,
                      blocks_per_col == 1 ? d_accs : nullptr);
+}
+
+// columns whose KLL samplers ride on the scan (d.kll.picks set): `lds_bytes` = the workgroup's rings
+void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t lds_bytes, ScanPartial *d_partials,
+                     hipStream_t stream) {
+  hipLaunchKernelGGL(scan_kll_kernel<1>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), lds_bytes, stream, L,
+                     d_partials);
+}
+
+void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,
+                       ScanPartial *d_partials, void *d_como_partials, hipStream_t stream) {
+  if (lds_bytes)
+    hipLaunchKernelGGL(scan_pair_kernel<true>, dim3(blocks_per_pair, n_pairs), dim3(kScanBlock), lds_bytes, stream, L,
+                       d_partials, (ComomentPartial *)d_como_partials);
+  else
+    hipLaunchKernelGGL(scan_pair_kernel<false>, dim3(blocks_per_pair, n_pairs), dim3(kScanBlock), 0, stream, L,
+                       d_partials, (ComomentPartial *)d_como_partials);
 }
 
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,

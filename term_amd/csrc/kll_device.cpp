@@ -12,14 +12,31 @@
 
 namespace tgx {
 
-void launch_kll_init(KllDeviceSketch *s, hipStream_t stream);
+void launch_kll_init(KllDeviceSketch *s, hipStream_t stream, uint32_t shift);
 void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
-                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream);
+                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream, uint32_t presampled_shift,
+                       bool no_sampling);
+void launch_kll_meta(const KllWaveMeta *meta, int n_waves, KllDeviceSketch *state, hipStream_t stream);
+uint32_t kll_top_for(int64_t rows);
 
 namespace {
+// what the scan leaves behind for a task whose sampler rode on it (kll_types.h, ScanKll)
+struct KllScanBuffers {
+  DevBuf picks, left, meta;
+  int64_t n_picks = 0, n_left = 0;
+  int n_waves = 0;
+  uint32_t top = 0;
+  bool pending = false;  // prepared for the batch being queued: kll_scan_finish sketches it
+};
+
 struct KllDeviceState {
   std::vector<DevBuf> sketch;  // running device sketch per task
   std::vector<char> dirty;     // device sketch holds data not yet folded into h_kll
+  // running sketch of pre-sampled values (the picks of the fused scan): loose items weigh 2^hi_shift
+  std::vector<DevBuf> sketch_hi;
+  std::vector<uint32_t> hi_shift;
+  std::vector<char> dirty_hi;
+  std::vector<KllScanBuffers> scan;
   DevBuf scratch;              // per-workgroup sketches of the batch being processed
   uint64_t salt = 0x6b6c6c5f74677821ULL;
 };
@@ -50,6 +67,10 @@ void kll_state_init(tgx_state *st) {
   KllDeviceState *k = new KllDeviceState();
   k->sketch.resize(st->plan->kll.size());
   k->dirty.assign(st->plan->kll.size(), 0);
+  k->sketch_hi.resize(st->plan->kll.size());
+  k->hi_shift.assign(st->plan->kll.size(), 0);
+  k->dirty_hi.assign(st->plan->kll.size(), 0);
+  k->scan.resize(st->plan->kll.size());
   st->kll = k;
 }
 
@@ -62,9 +83,100 @@ void kll_state_reset(tgx_state *st) {
   KllDeviceState *k = dev(st);
   if (!k) return;
   for (size_t i = 0; i < k->sketch.size(); i++) {
-    if (k->sketch[i].p) launch_kll_init(k->sketch[i].as<KllDeviceSketch>(), st->stream);
-    k->dirty[i] = 0;
+    if (k->sketch[i].p) launch_kll_init(k->sketch[i].as<KllDeviceSketch>(), st->stream, 0);
+    if (k->sketch_hi[i].p) launch_kll_init(k->sketch_hi[i].as<KllDeviceSketch>(), st->stream, k->hi_shift[i]);
+    k->dirty[i] = k->dirty_hi[i] = 0;
+    k->scan[i].pending = false;
   }
+}
+
+// groups / chunk of a build over `n` values: one workgroup per >= 64 Ki values, at most 1024 of them
+static void build_shape(int64_t n, int64_t *groups, int64_t *chunk) {
+  int64_t g = (n + 65535) / 65536;
+  g = std::max<int64_t>(1, std::min<int64_t>(g, 1024));
+  int64_t c = (n + g - 1) / g;
+  c = (c + 4095) / 4096 * 4096;
+  *groups = (n + c - 1) / c;
+  *chunk = c;
+}
+
+bool kll_scan_eligible(int64_t rows) { return kll_top_for(rows) >= 1; }
+
+tgx_status kll_scan_prepare(tgx_state *st, size_t slot, int64_t rows, int n_waves, int64_t max_rows_per_wave,
+                            ScanKll *out, tgx_error *err) {
+  KllDeviceState *k = dev(st);
+  KllScanBuffers &b = k->scan[slot];
+  const uint32_t top = std::min<uint32_t>(kll_top_for(rows), (uint32_t)kScanKllMaxTop);
+  const int64_t cap = ((max_rows_per_wave + 1024) >> top) + 2;
+  b.n_waves = n_waves;
+  b.top = top;
+  b.n_picks = (int64_t)n_waves * cap;
+  b.n_left = (int64_t)n_waves << top;
+  KHIP(b.picks.reserve((size_t)b.n_picks * 8 + 64));
+  KHIP(b.left.reserve((size_t)b.n_left * 8 + 64));
+  KHIP(b.meta.reserve((size_t)n_waves * sizeof(KllWaveMeta)));
+  k->salt = k->salt * 6364136223846793005ULL + 1442695040888963407ULL;
+  out->picks = b.picks.as<double>();
+  out->left = b.left.as<double>();
+  out->meta = b.meta.as<KllWaveMeta>();
+  out->salt = k->salt ^ 0x7363616e5f6b6c6cULL;
+  out->top = (int32_t)top;
+  out->cap = (int32_t)cap;
+  b.pending = true;
+  return TGX_OK;
+}
+
+// the scan of the batch has been queued: sketch what it leaves -- the leftovers (weight 1) into the running sketch,
+// the picks (weight 2^top) into the running sketch of that shift
+tgx_status kll_scan_finish(tgx_state *st, size_t slot, tgx_error *err) {
+  KllDeviceState *k = dev(st);
+  KllScanBuffers &b = k->scan[slot];
+  if (!b.pending) return TGX_OK;
+  b.pending = false;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+    (void)hipEventRecord(e0, st->stream);
+  if (!k->sketch[slot].p) {
+    KHIP(k->sketch[slot].reserve(sizeof(KllDeviceSketch)));
+    launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream, 0);
+  }
+  if (k->sketch_hi[slot].p && k->dirty_hi[slot] && k->hi_shift[slot] != b.top) {
+    // a batch of another size class: its picks weigh differently -- hand the old ones to the host first
+    tgx_status s = kll_flush(st, err);
+    if (s != TGX_OK) return s;
+  }
+  if (!k->sketch_hi[slot].p || k->hi_shift[slot] != b.top) {
+    KHIP(k->sketch_hi[slot].reserve(sizeof(KllDeviceSketch)));
+    k->hi_shift[slot] = b.top;
+    launch_kll_init(k->sketch_hi[slot].as<KllDeviceSketch>(), st->stream, b.top);
+  }
+  int64_t g_left, c_left, g_picks, c_picks;
+  build_shape(b.n_left, &g_left, &c_left);
+  build_shape(b.n_picks, &g_picks, &c_picks);
+  KHIP(k->scratch.reserve((size_t)std::max(g_left, g_picks) * sizeof(KllDeviceSketch)));
+  KllColDesc d;
+  memset(&d, 0, sizeof(d));
+  d.is_float = 1;
+  d.values = b.left.p;
+  d.length = b.n_left;
+  launch_kll_update(d, (int)g_left, c_left, k->scratch.as<KllDeviceSketch>(), k->sketch[slot].as<KllDeviceSketch>(),
+                    k->salt ^ 0x1111ULL, st->stream, 0, true);
+  d.values = b.picks.p;
+  d.length = b.n_picks;
+  launch_kll_update(d, (int)g_picks, c_picks, k->scratch.as<KllDeviceSketch>(),
+                    k->sketch_hi[slot].as<KllDeviceSketch>(), k->salt ^ 0x2222ULL, st->stream, b.top, true);
+  // (into both: either of them may end up without items -- no leftovers, or no complete group -- and an empty sketch
+  // is skipped by the merge)
+  launch_kll_meta(b.meta.as<KllWaveMeta>(), b.n_waves, k->sketch[slot].as<KllDeviceSketch>(), st->stream);
+  launch_kll_meta(b.meta.as<KllWaveMeta>(), b.n_waves, k->sketch_hi[slot].as<KllDeviceSketch>(), st->stream);
+  if (st->profiling && e0 && e1) {
+    (void)hipEventRecord(e1, st->stream);
+    ProfileEntry &pe = st->profile["kll"];
+    pe.pending.emplace_back(e0, e1);
+    pe.pending_bytes.push_back((uint64_t)(b.n_picks + b.n_left) * 8);
+  }
+  k->dirty[slot] = k->dirty_hi[slot] = 1;
+  return TGX_OK;
 }
 
 tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
@@ -74,7 +186,7 @@ tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error
   if (c.length == 0) return TGX_OK;
   if (!k->sketch[slot].p) {
     KHIP(k->sketch[slot].reserve(sizeof(KllDeviceSketch)));
-    launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream);
+    launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream, 0);
   }
   // one workgroup per >= 64 Ki rows, at most 1024 of them (235 MiB of scratch sketches)
   int64_t groups = (c.length + 65535) / 65536;
@@ -96,7 +208,7 @@ tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error
     (void)hipEventRecord(e0, st->stream);
   }
   launch_kll_update(d, (int)groups, chunk, k->scratch.as<KllDeviceSketch>(),
-                    k->sketch[slot].as<KllDeviceSketch>(), k->salt, st->stream);
+                    k->sketch[slot].as<KllDeviceSketch>(), k->salt, st->stream, 0, false);
   if (st->profiling && e0 && e1) {
     (void)hipEventRecord(e1, st->stream);
     ProfileEntry &pe = st->profile["kll"];
@@ -111,22 +223,27 @@ tgx_status kll_flush(tgx_state *st, tgx_error *err) {
   KllDeviceState *k = dev(st);
   if (!k) return TGX_OK;
   for (size_t i = 0; i < k->sketch.size(); i++) {
-    if (!k->dirty[i]) continue;
-    std::vector<uint8_t> raw(sizeof(KllDeviceSketch));
-    KHIP(hipMemcpyAsync(raw.data(), k->sketch[i].p, raw.size(), hipMemcpyDeviceToHost, st->stream));
-    KHIP(hipStreamSynchronize(st->stream));
-    const KllDeviceSketch *s = (const KllDeviceSketch *)raw.data();
-    KllHost part;
-    part.k = st->h_kll[i].k;
-    part.n = s->n;
-    part.min_v = s->min_v;
-    part.max_v = s->max_v;
-    if (s->lv0_count) part.add_level_items(0, s->lv0, s->lv0_count);
-    for (int l = 1; l < kKllMaxLevels; l++)
-      if ((s->level_mask >> l) & 1) part.add_level_items((size_t)l, s->runs[l], kKllRunItems);
-    if (!st->h_kll[i].merge(part)) return kfail(err, TGX_INTERNAL, "KLL merge failed");
-    launch_kll_init(k->sketch[i].as<KllDeviceSketch>(), st->stream);
-    k->dirty[i] = 0;
+    for (int hi = 0; hi < 2; hi++) {
+      DevBuf &buf = hi ? k->sketch_hi[i] : k->sketch[i];
+      char &dirty = hi ? k->dirty_hi[i] : k->dirty[i];
+      if (!dirty) continue;
+      std::vector<uint8_t> raw(sizeof(KllDeviceSketch));
+      KHIP(hipMemcpyAsync(raw.data(), buf.p, raw.size(), hipMemcpyDeviceToHost, st->stream));
+      KHIP(hipStreamSynchronize(st->stream));
+      const KllDeviceSketch *s = (const KllDeviceSketch *)raw.data();
+      KllHost part;
+      part.k = st->h_kll[i].k;
+      part.n = s->n;
+      part.min_v = s->min_v;
+      part.max_v = s->max_v;
+      // loose items weigh 2^shift (a sketch of pre-sampled picks), the runs were stored at their final levels
+      if (s->lv0_count) part.add_level_items(s->shift, s->lv0, s->lv0_count);
+      for (int l = 1; l < kKllMaxLevels; l++)
+        if ((s->level_mask >> l) & 1) part.add_level_items((size_t)l, s->runs[l], kKllRunItems);
+      if (!st->h_kll[i].merge(part)) return kfail(err, TGX_INTERNAL, "KLL merge failed");
+      launch_kll_init(buf.as<KllDeviceSketch>(), st->stream, hi ? k->hi_shift[i] : 0);
+      dirty = 0;
+    }
   }
   return TGX_OK;
 }

@@ -1223,12 +1223,67 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   st->pending_widen.clear();
 
   if (nrows > 0) {
-    // ---- numeric scan: all columns of the batch in launches of <= kMaxScanColsPerLaunch ----
+    // ---- what rides on the numeric scan of this batch (kernels/scan.hip) ----
+    // A COMOMENTS pair whose columns are plain 8-byte numerics is scanned by ONE workgroup per tile pair
+    // (scan_pair_kernel): both columns' own aggregates and the co-moments from one read.  A KLL task of a batch big
+    // enough to be sampled hands its sampler to the scan of its column (scan_kll_kernel / the pair kernel).  So a
+    // suite with range, quantile and correlation checks on the same columns reads them once.
+    const int n_plan_cols = plan->n_columns_needed;
+    std::vector<int> kll_on_col(n_plan_cols, -1), pair_of_col(n_plan_cols, -1);
+    std::vector<char> kll_fused(plan->kll.size(), 0), como_fused(plan->como.size(), 0);
+    auto scan_slot_of = [&](int col) -> int {
+      for (size_t q = 0; q < plan->scan.size(); q++)
+        if (plan->scan[q].column == col) return (int)q;
+      return -1;
+    };
+    auto plain8 = [&](int col) { return is_numeric(dev[col].type) && dev[col].values != nullptr; };
+    struct FusedPair {
+      int como, x, y;
+      ScanColDesc dx, dy;
+    };
+    std::vector<FusedPair> fused_pairs;
+    if (nrows >= (1 << 20)) {
+      for (size_t q = 0; q < plan->kll.size(); q++) {
+        const int col = plan->kll[q].column;
+        if (plain8(col) && kll_on_col[col] < 0 && kll_scan_eligible(nrows)) {
+          kll_on_col[col] = (int)q;
+          kll_fused[q] = 1;
+        }
+      }
+      for (size_t q = 0; q < plan->como.size() && fused_pairs.size() < (size_t)kMaxPairsPerLaunch; q++) {
+        const int x = plan->como[q].col_x, y = plan->como[q].col_y;
+        if (x == y || !plain8(x) || !plain8(y) || pair_of_col[x] >= 0 || pair_of_col[y] >= 0) continue;
+        const int sx = scan_slot_of(x), sy = scan_slot_of(y);
+        if ((sx >= 0 && plan->scan[sx].variance) || (sy >= 0 && plan->scan[sy].variance)) continue;
+        FusedPair fp;
+        fp.como = (int)q;
+        fp.x = x;
+        fp.y = y;
+        fill_scan_desc(dev[x], false, nullptr, &fp.dx);
+        fill_scan_desc(dev[y], false, nullptr, &fp.dy);
+        if (fp.dx.head != fp.dy.head || fp.dx.n_tiles != fp.dy.n_tiles) continue;  // tiles must line up
+        pair_of_col[x] = pair_of_col[y] = (int)fused_pairs.size();
+        como_fused[q] = 1;
+        fused_pairs.push_back(fp);
+      }
+    }
+    // waves of a fused launch and the most rows one of them sees (sizes the sampler's buffers)
+    auto fused_blocks = [&](const ScanColDesc &d, int n_tasks) -> int {
+      const int64_t units = d.n_tiles > 0 ? d.n_tiles : (d.length + 63) / 64;
+      int64_t want = (units + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+      const int64_t cap = std::max(32, (g_ctx.n_cu * 3) / std::max(1, n_tasks));
+      return (int)std::max<int64_t>(1, std::min(want, cap));
+    };
+    auto rows_per_wave = [&](const ScanColDesc &d, int blocks) -> int64_t {
+      const int64_t waves = (int64_t)blocks * kWavesPerBlock;
+      if (d.n_tiles > 0) return (d.n_tiles + waves - 1) / waves * kTileRows;
+      return ((d.length + 63) / 64 + waves - 1) / waves * 64;
+    };
+    // ---- numeric scan: all columns of the batch in launches of <= kMaxColsPerLaunch ----
     {
-      std::vector<ScanColDesc> descs;
-      std::vector<int32_t> index;
-      bool any_var = false;
-      uint64_t bytes = 0;
+      std::vector<ScanColDesc> descs, kll_descs;
+      std::vector<int32_t> index, kll_index;
+      std::vector<int> kll_slots;
       for (size_t s = 0; s < plan->scan.size(); s++) {
         const tgx_column &c = dev[plan->scan[s].column];
         if (!is_numeric(c.type) && !is_numeric32(c.type)) {
@@ -1241,7 +1296,8 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
                         plan->scan[s].column, c.type);
           continue;
         }
-        {
+        if (pair_of_col[plan->scan[s].column] >= 0) continue;  // scanned with its partner below
+        if (kll_on_col[plan->scan[s].column] < 0) {
           // a scan that only feeds DISTINCT's range decision is not needed once the range is declared
           bool bound = false, all_hinted = true, any_distinct = false;
           for (size_t i = 0; i < plan->specs.size(); i++) {
@@ -1258,10 +1314,25 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         }
         ScanColDesc d;
         fill_scan_desc(c, plan->scan[s].variance, st->d_pivots.as<double>() + s, &d);
-        any_var |= plan->scan[s].variance;
-        descs.push_back(d);
-        index.push_back((int32_t)s);
-        bytes += (uint64_t)c.length * (is_numeric32(c.type) ? 4 : 8) + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
+        if (kll_on_col[plan->scan[s].column] >= 0) {
+          kll_descs.push_back(d);
+          kll_index.push_back((int32_t)s);
+          kll_slots.push_back(kll_on_col[plan->scan[s].column]);
+        } else {
+          descs.push_back(d);
+          index.push_back((int32_t)s);
+        }
+      }
+      // sampled columns without a scan task of their own (a KLL check alone): scanned all the same, their column
+      // aggregates are dropped (acc_index -1)
+      for (size_t q = 0; q < plan->kll.size(); q++) {
+        const int col = plan->kll[q].column;
+        if (!kll_fused[q] || pair_of_col[col] >= 0 || scan_slot_of(col) >= 0) continue;
+        ScanColDesc d;
+        fill_scan_desc(dev[col], false, nullptr, &d);
+        kll_descs.push_back(d);
+        kll_index.push_back(-1);
+        kll_slots.push_back((int)q);
       }
       // launches of <= kMaxColsPerLaunch columns; descriptors travel in the kernel arguments
       for (size_t c0 = 0; c0 < descs.size(); c0 += kMaxColsPerLaunch) {
@@ -1290,8 +1361,86 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
           launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
                                   st->stream);
       }
-      (void)any_var;
-      (void)bytes;
+      // columns whose KLL samplers ride on the scan: columns of one launch share the sampling level (same rows)
+      for (size_t c0 = 0; c0 < kll_descs.size(); c0 += kMaxColsPerLaunch) {
+        const int n = (int)std::min<size_t>(kMaxColsPerLaunch, kll_descs.size() - c0);
+        ScanLaunch L;
+        memset(&L, 0, sizeof(L));
+        int blocks = 1;
+        uint64_t chunk_bytes = 0;
+        bool chunk_var = false;
+        for (int k = 0; k < n; k++) {
+          L.cols[k] = kll_descs[c0 + k];
+          L.acc_index[k] = kll_index[c0 + k];
+          blocks = std::max(blocks, fused_blocks(L.cols[k], n));
+          chunk_bytes += (uint64_t)L.cols[k].length * 8 + (L.cols[k].validity ? (uint64_t)(L.cols[k].length + 7) / 8 : 0);
+          chunk_var |= L.cols[k].want_variance != 0;
+        }
+        size_t lds = 0;
+        for (int k = 0; k < n; k++) {
+          TGX_TRY(kll_scan_prepare(st, (size_t)kll_slots[c0 + k], nrows, blocks * kWavesPerBlock,
+                                   rows_per_wave(L.cols[k], blocks), &L.cols[k].kll, err));
+          lds = std::max(lds, (size_t)kWavesPerBlock * (((size_t)1 << L.cols[k].kll.top) + kTileRows) * sizeof(double));
+        }
+        HIP_TRY(st->d_scan_partials.reserve((size_t)n * blocks * sizeof(ScanPartial)));
+        if (chunk_var) launch_scan_pivot(L, n, st->d_pivots.as<double>(), st->d_pivot_set.as<int32_t>(), st->stream);
+        {
+          ProfScope ps(st, "scan", chunk_bytes);
+          launch_scan_kll(L, n, blocks, lds, st->d_scan_partials.as<ScanPartial>(), st->stream);
+        }
+        launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
+                                st->stream);
+      }
+      // COMOMENTS pairs: both columns and their co-moments from one read
+      if (!fused_pairs.empty()) {
+        const int n = (int)fused_pairs.size();
+        ScanPairLaunch PL;
+        ScanLaunch RL;  // the same columns as the reduce kernel wants them: [2 k] = x, [2 k + 1] = y
+        ComomentLaunch CL;
+        memset(&PL, 0, sizeof(PL));
+        memset(&RL, 0, sizeof(RL));
+        memset(&CL, 0, sizeof(CL));
+        int blocks = 1;
+        uint64_t chunk_bytes = 0;
+        for (int k = 0; k < n; k++) blocks = std::max(blocks, fused_blocks(fused_pairs[k].dx, n));
+        size_t lds = 0;
+        for (int k = 0; k < n; k++) {
+          FusedPair &fp = fused_pairs[k];
+          ScanPairDesc &P = PL.pairs[k];
+          P.x = fp.dx;
+          P.y = fp.dy;
+          P.x_acc = scan_slot_of(fp.x);
+          P.y_acc = scan_slot_of(fp.y);
+          P.como_acc = fp.como;
+          size_t rings = 0;
+          for (int side = 0; side < 2; side++) {
+            ScanColDesc &d = side ? P.y : P.x;
+            const int col = side ? fp.y : fp.x;
+            if (kll_on_col[col] >= 0) {
+              TGX_TRY(kll_scan_prepare(st, (size_t)kll_on_col[col], nrows, blocks * kWavesPerBlock,
+                                       rows_per_wave(d, blocks), &d.kll, err));
+              rings += ((size_t)1 << d.kll.top) + kTileRows;
+            }
+            chunk_bytes += (uint64_t)d.length * 8 + (d.validity ? (uint64_t)(d.length + 7) / 8 : 0);
+          }
+          lds = std::max(lds, (size_t)kWavesPerBlock * rings * sizeof(double));
+          RL.cols[2 * k] = P.x;
+          RL.cols[2 * k + 1] = P.y;
+          RL.acc_index[2 * k] = P.x_acc;
+          RL.acc_index[2 * k + 1] = P.y_acc;
+          CL.pairs[k].length = P.x.length;
+          CL.acc_index[k] = fp.como;
+        }
+        HIP_TRY(st->d_scan_partials.reserve((size_t)2 * n * blocks * sizeof(ScanPartial)));
+        HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
+        {
+          ProfScope ps(st, "scan", chunk_bytes);
+          launch_scan_pairs(PL, n, blocks, lds, st->d_scan_partials.as<ScanPartial>(), st->d_como_partials.p, st->stream);
+        }
+        launch_scan_reduce_only(RL, 2 * n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
+                                st->stream);
+        launch_comoments_reduce(CL, n, blocks, st->d_como_partials.p, st->d_como_acc.as<ComomentAcc>(), st->stream);
+      }
     }
     // ---- validity-only columns ----
     {
@@ -1342,6 +1491,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       std::vector<int32_t> index;
       uint64_t bytes = 0;
       for (size_t s = 0; s < plan->como.size(); s++) {
+        if (como_fused[s]) continue;  // rode on the scan of its columns
         const tgx_column &x = dev[plan->como[s].col_x], &y = dev[plan->como[s].col_y];
         if (!is_numeric(x.type) || !is_numeric(y.type))
           return fail(err, TGX_INVALID_ARGUMENT, "COMOMENTS needs numeric columns (%d, %d)", x.type, y.type);
@@ -1371,7 +1521,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (nrows + 256 * 16 - 1) / (256 * 16)),
                                             std::max(32, (g_ctx.n_cu * 12) / n));  // 4/5/6/8/12 per CU: 6.8/6.4/6.2/6.5/6.0 ms (2 pairs, 1 G rows)
         HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
-        ProfScope ps(st, "comoments", bytes * n / descs.size());
+        ProfScope ps(st, "comoments", bytes * n / std::max<size_t>(descs.size(), 1));
         launch_comoments(L, n, blocks, st->d_como_partials.p, st->d_como_acc.as<ComomentAcc>(), st->stream);
       }
     }
@@ -1431,8 +1581,12 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       }
     // (gathers handed out but not consumed -- cannot happen: every fusable column has exactly one DISTINCT task)
     // ---- KLL ----
-    for (size_t s = 0; s < plan->kll.size(); s++)
-      TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
+    for (size_t s = 0; s < plan->kll.size(); s++) {
+      if (kll_fused[s])
+        TGX_TRY(kll_scan_finish(st, s, err));  // sketches the picks the scan left
+      else
+        TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
+    }
     // ---- Spearman: keep the pairs, rank at finalize ----
     TGX_TRY(spearman_update(st, dev.data(), err));
   }

@@ -189,3 +189,92 @@ def test_against_oracle_within_reference_tolerance():
     for phi, truth in ((0.5, 500.0), (0.9, 900.0)):
         assert abs(sk.quantile(phi) - truth) / truth < 0.85
         assert abs(st.kll_quantile(0, phi) - truth) / truth < 0.85
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fused path: a suite with range, quantile and correlation checks on the same columns reads them ONCE -- the KLL
+# sampler and the co-moment lanes ride on the numeric scan (kernels/scan.hip: scan_kll_kernel, scan_pair_kernel)
+@pytest.mark.parametrize("layout", ["aligned", "sliced", "misaligned"])
+def test_sampler_and_comoments_riding_on_the_scan_match_the_oracle(layout):
+    import torch
+
+    rng = np.random.default_rng(31 + len(layout))
+    n = 9_000_000 + 77  # big enough to be sampled (2^top = 2), ragged tail
+    x = rng.standard_normal(n) * 50 + 10
+    nan_at = rng.integers(0, n, 1000)
+    x[nan_at] = np.nan                            # NaN: a value for MIN/MAX/COUNT, dropped by the sketch
+    x[123] = -1e9
+    x[n - 5] = 1e9                                # the extremes sit in the ragged tail / a tile
+    y = 2 * x + rng.standard_normal(n)
+    y[np.isnan(y)] = 7.0
+    iv = rng.integers(-10**6, 10**6, size=n, dtype=np.int64)
+    single = rng.random(n) * 100                  # a sampled column that is in no pair
+    mx, my = rng.random(n) >= 0.05, rng.random(n) >= 0.2
+    my[nan_at] = False                            # (no NaN among the rows both columns have: finite co-moments)
+    off = {"aligned": 0, "sliced": 5, "misaligned": 1}[layout]
+    pad = np.zeros(off)
+
+    def dev(vals, mask):
+        full = np.concatenate([pad.astype(vals.dtype), vals])
+        t = torch.from_numpy(full).cuda()
+        validity = None
+        if mask is not None:
+            validity = torch.from_numpy(np.concatenate([orc.pack_validity(np.concatenate([np.ones(off, bool), mask])),
+                                                        np.zeros(64, np.uint8)])).cuda()
+        if layout == "misaligned":  # the values buffer starts 8 bytes past a 16-byte boundary: no tiles
+            ctor = T.Column.float64 if vals.dtype == np.float64 else T.Column.int64
+            if validity is None:
+                return ctor(t[1:], None, length=n)
+            # bitmap bit 0 belongs to the dropped slot: keep the Arrow offset for the validity only via a shifted copy
+            v2 = torch.from_numpy(np.concatenate([orc.pack_validity(mask), np.zeros(64, np.uint8)])).cuda()
+            return ctor(t[1:], v2, length=n)
+        ctor = T.Column.float64 if vals.dtype == np.float64 else T.Column.int64
+        return ctor(t, validity, length=n, offset=off)
+
+    cols = [dev(x, mx), dev(y, my), dev(iv, None), dev(single, mx)]
+    specs = [spec(T.NUMERIC_STATS, 0), spec(T.COUNT, 1), spec(T.NUMERIC_STATS, 2), spec(T.NUMERIC_STATS, 3),
+             spec(T.KLL, 0, kll_k=200), spec(T.KLL, 1, kll_k=200), spec(T.KLL, 2, kll_k=200), spec(T.KLL, 3, kll_k=200),
+             spec(T.COMOMENTS, 0, column2=1), spec(T.COMOMENTS, 2, column2=3)]
+    T.init()
+    plan = T.Plan(specs)
+    st = T.State(plan)
+    st.profile_enable(True)
+    st.update(cols)
+    res = st.finalize()
+    # nothing but the scan read the columns: no separate co-moment launch; the KLL work is the sketching of the picks
+    assert st.profile_get("comoments")["launches"] == 0
+    assert 0 < st.profile_get("kll")["bytes"] < 4 * n * 8
+    vx, vy = orc.pack_validity(mx), orc.pack_validity(my)
+    ox, oi, os_ = orc.stats(x, vx), orc.stats(iv, None), orc.stats(single, vx)
+    assert (res[0].non_null, res[2].non_null, res[3].non_null) == (ox.non_null, n, os_.non_null)
+    assert np.isnan(res[0].max_f) and res[0].min_f == ox.min_f   # totalOrder: NaN sorts last (arrow's total_cmp)
+    assert (res[2].min_i, res[2].max_i, res[2].sum_i) == (oi.min_i, oi.max_i, oi.sum_i_wrapping)
+    assert (res[3].min_f, res[3].max_f) == (os_.min_f, os_.max_f) and abs(res[3].sum_f - os_.sum_hi) <= 1e-9 * os_.sum_hi
+    assert (res[1].total, res[1].non_null) == (n, int(my.sum()))
+    for si, (vals, mask) in zip((4, 5, 6, 7), ((x, mx), (y, my), (iv.astype(np.float64), None), (single, mx))):
+        kept = vals if mask is None else vals[mask]
+        kept = np.sort(kept[~np.isnan(kept)])
+        summ = st.kll_summary(si)
+        assert (res[si].kll_n, summ["n"]) == (len(kept), len(kept)), si
+        assert total_weight(st, si) == len(kept)                 # weight preserved exactly through the sampler
+        assert (summ["min"], summ["max"]) == (kept[0], kept[-1])
+        for phi in (0.01, 0.25, 0.5, 0.75, 0.95, 0.99):
+            assert rank_error(kept, st.kll_quantile(si, phi), phi) < 1.65 / math.sqrt(200), (si, phi)
+    for si, (a, b, va, vb) in zip((8, 9), ((x, y, vx, vy), (iv, single, None, vx))):
+        o = orc.comoments(a, b, va, vb)
+        r = res[si]
+        assert (r.total, r.non_null) == (n, o.n)
+        for got, want in ((r.sum_x, o.sum_x), (r.sum_y, o.sum_y), (r.sum_x2, o.sum_x2), (r.sum_y2, o.sum_y2),
+                          (r.sum_xy, o.sum_xy)):
+            if np.isnan(want):
+                assert np.isnan(got)  # a NaN in a both-valid row poisons the sums, as in the oracle
+            else:
+                assert abs(got - want) <= 1e-9 * max(abs(want), 1.0)
+    # a second batch on the same state (other size class: not sampled) and a merge keep the weights exact
+    m = 3_000_000
+    st.update([c.sliced(0, m) for c in cols])
+    r2 = st.finalize()
+    for si, (vals, mask) in zip((4, 7), ((x, mx), (single, mx))):
+        kept = vals[:m][mask[:m]]
+        assert r2[si].kll_n == res[si].kll_n + int((~np.isnan(kept)).sum())
+        assert total_weight(st, si) == r2[si].kll_n
