@@ -356,6 +356,15 @@ tgx_status tgx_regex_validate(const char *pattern, size_t len, uint32_t flags, t
 tgx_status tgx_regex_is_match(const char *pattern, size_t plen, uint32_t flags, const uint8_t *value,
                               size_t vlen, int32_t *matched, tgx_error *err);
 
+/* Host-side walk of the PRODUCT automaton of up to 4 patterns -- the form in which several pattern checks of one
+ * column are evaluated on the device (one walk over the value decides all of them).  Bit k of *mask: pattern k
+ * matches `value`.  *grouped = 0 when the product exceeds the device's table limit: the patterns then run one by
+ * one (and *mask is computed that way).  TRIM is applied per pattern here; on the device only patterns with the same
+ * TRIM flag share a walk. */
+tgx_status tgx_regex_match_group(const char *const *patterns, const size_t *pattern_lens, const uint32_t *flags,
+                                 size_t n_patterns, const uint8_t *value, size_t vlen, uint32_t *mask,
+                                 int32_t *grouped, tgx_error *err);
+
 #ifdef __cplusplus
 }
 #endif

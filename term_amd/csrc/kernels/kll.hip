@@ -12,6 +12,7 @@
 // sketch, so the whole column costs one HBM pass; nothing but the final ~100 KiB sketch ever reaches
 // the host.  Total weight is preserved exactly (sum over levels of items x 2^level == n).
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "kll_types.h"
 
@@ -278,9 +279,14 @@ __device__ __forceinline__ uint32_t kll_load_step(const KllColDesc &d, global_i6
 // are not sampled at all (top = 0: phase A is then the plain "sort every 1024 values").
 // `shift`: the input values are pre-sampled items of weight 2^shift (the picks of the fused scan): runs land `shift`
 // levels higher, the loose items keep weight 2^shift (KllDeviceSketch::shift), n counts stream items.
-__global__ __launch_bounds__(kKllThreads) void kll_build_kernel(KllColDesc d, int64_t chunk,
-                                                                 KllDeviceSketch *sketches,
-                                                                 uint64_t salt0, uint32_t top, uint32_t shift) {
+__global__ __launch_bounds__(kKllThreads) void kll_build_kernel(const KllJobs J) {
+  const KllJob &job = J.job[blockIdx.y];
+  if ((int)blockIdx.x >= job.groups) return;  // (uniform: jobs of one launch differ in size)
+  const KllColDesc d = job.d;
+  const int64_t chunk = job.chunk;
+  KllDeviceSketch *sketches = job.sketches;
+  const uint64_t salt0 = job.salt;
+  const uint32_t top = job.top, shift = job.shift;
   __shared__ double ring[8192];  // eight batches of sampled values: slot = sampled index & 8191 (a step brings <= 4)
   __shared__ double buf[1024];
   __shared__ uint32_t wave_tot[kKllThreads / 64];
@@ -498,22 +504,22 @@ __device__ void sketch_add(KllDeviceSketch *dst, const KllDeviceSketch *src, dou
 }
 
 // one round of the pairwise tree: sketches[2*i*stride] += sketches[(2*i+1)*stride]
-__global__ __launch_bounds__(kKllThreads) void kll_tree_kernel(KllDeviceSketch *sketches, int count,
-                                                                int stride, uint64_t salt) {
+__global__ __launch_bounds__(kKllThreads) void kll_tree_kernel(const KllJobs J, int stride) {
   __shared__ double staging[2048];
   __shared__ double buf[1024];
+  const KllJob &job = J.job[blockIdx.y];
   const int a = 2 * blockIdx.x * stride, b = a + stride;
-  if (b >= count) return;
-  sketch_add(sketches + a, sketches + b, buf, staging, salt ^ ((uint64_t)a << 8) ^ (uint64_t)stride);
+  if (b >= job.groups) return;
+  sketch_add(job.sketches + a, job.sketches + b, buf, staging,
+             (job.salt + (uint64_t)stride) ^ ((uint64_t)a << 8) ^ (uint64_t)stride);
 }
 
 // state += batch
-__global__ __launch_bounds__(kKllThreads) void kll_fold_kernel(KllDeviceSketch *state,
-                                                                const KllDeviceSketch *batch,
-                                                                uint64_t salt) {
+__global__ __launch_bounds__(kKllThreads) void kll_fold_kernel(const KllJobs J) {
   __shared__ double staging[2048];
   __shared__ double buf[1024];
-  sketch_add(state, batch, buf, staging, salt);
+  const KllJob &job = J.job[blockIdx.x];
+  sketch_add(job.state, job.sketches, buf, staging, job.salt ^ 0xabcdefULL);
 }
 
 __global__ void kll_init_kernel(KllDeviceSketch *s, uint32_t shift) {
@@ -574,23 +580,27 @@ uint32_t kll_top_for(int64_t rows) {
   return top;
 }
 
-// `presampled_shift` > 0: `d` holds picks of weight 2^shift (NaN = no pick): sketched without further sampling into a
-// state sketch of that shift
-void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
-                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream, uint32_t presampled_shift,
-                       bool no_sampling) {
-  uint32_t top = (presampled_shift || no_sampling) ? 0 : kll_top_for(d.length);
-  // (measured on 1 G rows, 1024 workgroups: top - 1 / - 2 / - 3 = 2.39 / 2.92 / 3.87 ms instead of 2.10 -- a flush
-  // (sort of 1024 + insert) costs ~35 us per workgroup; top + 2 / + 4 = 3.36 / 4.97 ms -- the tail re-read of phase B)
-  hipLaunchKernelGGL(kll_build_kernel, dim3(groups), dim3(kKllThreads), 0, stream, d, chunk, sketches,
-                     salt, top, presampled_shift);
-  for (int stride = 1; stride < groups; stride <<= 1) {
-    int pairs = (groups + 2 * stride - 1) / (2 * stride);
-    hipLaunchKernelGGL(kll_tree_kernel, dim3(pairs), dim3(kKllThreads), 0, stream, sketches, groups,
-                       stride, salt + (uint64_t)stride);
+// jobs[k].sketches: scratch for jobs[k].groups per-workgroup sketches; each job's result is folded into its `state`.
+// Jobs that share a state must not share a launch (the fold is one workgroup per job).
+void launch_kll_jobs(const KllJob *jobs, int n_jobs, hipStream_t stream) {
+  for (int j0 = 0; j0 < n_jobs; j0 += kKllMaxJobs) {
+    const int n = n_jobs - j0 < kKllMaxJobs ? n_jobs - j0 : kKllMaxJobs;
+    KllJobs J;
+    memset(&J, 0, sizeof(J));
+    int max_groups = 1;
+    for (int k = 0; k < n; k++) {
+      J.job[k] = jobs[j0 + k];
+      max_groups = J.job[k].groups > max_groups ? J.job[k].groups : max_groups;
+    }
+    // (measured on 1 G rows, 1024 workgroups: top - 1 / - 2 / - 3 = 2.39 / 2.92 / 3.87 ms instead of 2.10 -- a flush
+    // (sort of 1024 + insert) costs ~35 us per workgroup; top + 2 / + 4 = 3.36 / 4.97 ms -- the tail re-read of phase B)
+    hipLaunchKernelGGL(kll_build_kernel, dim3(max_groups, n), dim3(kKllThreads), 0, stream, J);
+    for (int stride = 1; stride < max_groups; stride <<= 1) {
+      const int pairs = (max_groups + 2 * stride - 1) / (2 * stride);
+      hipLaunchKernelGGL(kll_tree_kernel, dim3(pairs, n), dim3(kKllThreads), 0, stream, J, stride);
+    }
+    hipLaunchKernelGGL(kll_fold_kernel, dim3(n), dim3(kKllThreads), 0, stream, J);
   }
-  hipLaunchKernelGGL(kll_fold_kernel, dim3(1), dim3(kKllThreads), 0, stream, state, sketches,
-                     salt ^ 0xabcdefULL);
 }
 
 }  // namespace tgx

@@ -29,6 +29,25 @@ struct KllColDesc {
   int32_t pad;
 };
 
+// Several sketching jobs in one launch sequence (grid.y = job): the columns of a batch -- and, on the fused path, the
+// picks and the leftovers of each -- go through build / tree rounds / fold side by side instead of one after the other
+// (a tree round is a handful of workgroups: latency, not work).
+struct KllJob {
+  KllColDesc d;
+  int64_t chunk;                 // rows per workgroup of the build
+  struct KllDeviceSketch *sketches;  // scratch: one sketch per workgroup
+  struct KllDeviceSketch *state;     // the running sketch the batch is folded into
+  uint64_t salt;
+  uint32_t top;                  // sampling level of the build (0: every value is kept)
+  uint32_t shift;                // the input values are pre-sampled items of weight 2^shift
+  int32_t groups;                // workgroups of the build
+  int32_t pad;
+};
+constexpr int kKllMaxJobs = 16;
+struct KllJobs {
+  KllJob job[kKllMaxJobs];
+};
+
 // ---- the KLL sampler riding on the numeric scan (scan.hip): what one wave of the scan leaves behind for a column.
 // A wave's rows are a stream of their own; it cuts its non-NULL, non-NaN values into groups of 2^top consecutive
 // values and keeps ONE member of each, chosen by a counter hash (Karnin-Lang-Liberty sec. 3.2: an item of weight 2^l

@@ -235,7 +235,9 @@ static inline RegexLds regex_lds_layout(uint32_t n_states, uint32_t n_classes, b
   return l;
 }
 
-template <bool LDS_TABLE, bool DIRECT = false, bool VIEW = false>
+// MULTI: the automaton is the PRODUCT of up to four patterns of the column (regex_compile.h, dfa_product): one walk
+// per value decides all of them -- k format checks on a column cost one pass over its bytes, not k.
+template <bool LDS_TABLE, bool DIRECT = false, bool VIEW = false, bool MULTI = false>
 __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaView dfa, RegexLds lds,
                                                            unsigned long long *counters) {
   // no static LDS: the dynamic block then starts at LDS address 0 and the fixed offsets above are plain immediates
@@ -254,10 +256,12 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     // prescaled copy (see Tbl): entry = byte offset of the next state's row; rows 0 (dead) and 1 (matched) absorb
     for (uint32_t i = threadIdx.x; i < n_entries; i += 256) {
       const uint32_t row = i / dfa.n_classes;
-      s_table[i] = (uint16_t)((row <= 1 ? row : (uint32_t)dfa.table[i]) * row_bytes);
+      const uint32_t n_final = MULTI ? dfa.n_final : 2u;
+      s_table[i] = (uint16_t)((row < n_final ? row : (uint32_t)dfa.table[i]) * row_bytes);
     }
     s_class2[threadIdx.x] = (uint16_t)(dfa.byte_class[threadIdx.x] * 2u);
-    for (uint32_t i = threadIdx.x; i < dfa.n_states; i += 256) s_accept[i] = i == 1 ? 1 : dfa.accept_end[i];
+    for (uint32_t i = threadIdx.x; i < dfa.n_states; i += 256)
+      s_accept[i] = MULTI ? dfa.accept_end[i] : (i == 1 ? 1 : dfa.accept_end[i]);
   } else {
     s_class[threadIdx.x] = dfa.byte_class[threadIdx.x];
   }
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   tbl.ncls = dfa.n_classes;
   tbl.row_bytes = row_bytes;
   tbl.start = LDS_TABLE ? dfa.start * row_bytes : dfa.start;
-  tbl.term = LDS_TABLE ? row_bytes : 1;
+  tbl.term = MULTI ? (LDS_TABLE ? (dfa.n_final - 1) * row_bytes : dfa.n_final - 1) : (LDS_TABLE ? row_bytes : 1);
   global_u8_ptr g_acc = (global_u8_ptr)(uintptr_t)dfa.accept_end;
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   const uintptr_t data0 = (uintptr_t)d.data;
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *stage = s_stage0 + wave * (kStageBytes + 32);
   unsigned long long matches = 0;
+  uint32_t multi[kMaxRegexGroup] = {0, 0, 0, 0};  // MULTI: matches per pattern (a lane sees < 2^32 rows)
   // A wave step takes 128 consecutive rows, two per lane (rows `lane` and `lane + 64` of the step): twice the bytes
   // in flight for the same LDS, and the two values of a lane are walked in lockstep.  When the 128 values do not
   // fit the stage the two 64-row halves are staged one after the other; a half that still does not fit is read
@@ -391,6 +396,25 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     *we = e;
   };
   auto account = [&](const Row &r, int64_t i, uint32_t st_raw) {
+    if (MULTI) {
+      if (!r.in) return;
+      // the state's accept mask decides every pattern of the group; a NULL row counts for the patterns that say so
+      uint32_t mask = d.null_mask, nul = 2;
+      if (r.valid) {
+        const uint32_t st = tbl.state_of(st_raw);
+        mask = LDS_TABLE ? (uint32_t)s_accept[st] : (uint32_t)g_acc[st];
+        nul = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kMaxRegexGroup; k++) {
+        if (k < d.n_pat) {  // uniform
+          const uint32_t hit = (mask >> k) & 1u;
+          multi[k] += hit;
+          if (d.hits_k[k]) d.hits_k[k][i] = (uint8_t)(nul ? 2u : hit);
+        }
+      }
+      return;
+    }
     if (r.valid) {
       const uint32_t st = tbl.state_of(st_raw);
       const bool hit = LDS_TABLE ? s_accept[st] != 0 : (st == 1 || g_acc[st]);
@@ -451,6 +475,22 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     }
     account(r0, i0, st0);
     account(r1, i1, st1);
+  }
+  if (MULTI) {
+    for (int k = 0; k < kMaxRegexGroup; k++) {
+      if (k >= d.n_pat) break;  // uniform
+      unsigned long long m = multi[k];
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1) m += __shfl_down(m, dlt, 64);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (t) atomicAdd(d.counters_k[k], t);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) matches += __shfl_down(matches, dlt, 64);
@@ -579,6 +619,22 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
     const int64_t blocks = std::min<int64_t>(max_blocks, (int64_t)n_cu * resident(k, ID));                       \
     hipLaunchKernelGGL(k, dim3((int)blocks), block, lds.total, stream, d, dfa, lds, d_counters);                 \
   } while (0)
+#define TGX_RXM(LDS, DIRECT, VIEW, ID)                                                                           \
+  do {                                                                                                           \
+    auto k = regex_match_kernel<LDS, DIRECT, VIEW, true>;                                                        \
+    const int64_t blocks = std::min<int64_t>(max_blocks, (int64_t)n_cu * resident(k, ID));                       \
+    hipLaunchKernelGGL(k, dim3((int)blocks), block, lds.total, stream, d, dfa, lds, d_counters);                 \
+  } while (0)
+  if (d.n_pat > 1) {  // a product automaton: several patterns in one walk
+    if (direct) {
+      if (view) TGX_RXM(true, true, true, 6); else TGX_RXM(true, true, false, 7);
+    } else if (in_lds) {
+      if (view) TGX_RXM(true, false, true, 8); else TGX_RXM(true, false, false, 9);
+    } else {
+      if (view) TGX_RXM(false, false, true, 10); else TGX_RXM(false, false, false, 11);
+    }
+    return;
+  }
   if (direct) {
     if (view) TGX_RX(true, true, true, 0); else TGX_RX(true, true, false, 1);
   } else if (in_lds) {
@@ -587,6 +643,7 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
     if (view) TGX_RX(false, false, true, 4); else TGX_RX(false, false, false, 5);
   }
 #undef TGX_RX
+#undef TGX_RXM
 }
 
 }  // namespace tgx

@@ -574,16 +574,43 @@ __device__ __forceinline__ void como_fold(ComoLane &m, double a, double b, bool 
   two_sum_add(m.s[4], m.c[4], a * b);
 }
 
+// The tile form: a lane's eight rows of a tile are summed with plain adds (seven roundings of a partial sum no larger
+// than eight terms: a relative error of a few 1e-16 of the partial), the partial then enters the running sum through
+// the two-sum.  The kernel is bound by instruction issue, and 5 x 7 operations per row for the compensation were a
+// third of them; the result stays far inside the 1e-6 the aggregates are held to (it moves in the 15th digit with
+// the tiling, not with the grid).
+struct ComoTile {
+  double t[5];
+};
+__device__ __forceinline__ void como_tile_add(ComoTile &q, double a, double b, bool both) {
+  const unsigned long long bm = __builtin_amdgcn_ballot_w64(both);
+  const bool ok = __builtin_amdgcn_inverse_ballot_w64(bm);
+  a = ok ? a : 0.0;
+  b = ok ? b : 0.0;
+  q.t[0] += a;
+  q.t[1] += b;
+  q.t[2] += a * a;
+  q.t[3] += b * b;
+  q.t[4] += a * b;
+}
+__device__ __forceinline__ void como_tile_flush(ComoLane &m, ComoTile &q) {
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    two_sum_add(m.s[k], m.c[k], q.t[k]);
+    q.t[k] = 0.0;
+  }
+}
+
 template <bool XF, bool YF, bool KLL>
-__device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, LaneAcc &ay, ComoLane &m, i64x2 vx,
+__device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, LaneAcc &ay, ComoTile &m, i64x2 vx,
                                           i64x2 vy, uint32_t bx, uint32_t by, KllLane &Kx, KllLane &Ky, double *rx,
                                           double *ry) {
   acc_pair<XF, false>(ax, vx, bx, 0.0);
   acc_pair<YF, false>(ay, vy, by, 0.0);
   const double x0 = kll_value<XF>(vx.x), x1 = kll_value<XF>(vx.y);
   const double y0 = kll_value<YF>(vy.x), y1 = kll_value<YF>(vy.y);
-  como_fold(m, x0, y0, (bx & by & 1u) != 0);
-  como_fold(m, x1, y1, (bx & by & 2u) != 0);
+  como_tile_add(m, x0, y0, (bx & by & 1u) != 0);
+  como_tile_add(m, x1, y1, (bx & by & 2u) != 0);
   if (KLL) {
     if (P.x.kll.picks) {  // uniform
       kll_push(Kx, rx, x0, (bx & 1u) != 0 && x0 == x0);
@@ -623,7 +650,8 @@ __device__ void pair_ragged(const ScanPairDesc &P, int64_t r0, int64_t r1, int l
     ay.cnt += vy ? 1 : 0;
     const double a = kll_value<XF>(xb), b = kll_value<YF>(yb);
     como_fold(m, a, b, vx && vy);
-    n_both += (vx && vy) ? 1 : 0;
+    n_both += (int64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vx && vy));  // wave-uniform, like the tiles'
+
     if (KLL) {
       if (P.x.kll.picks) {
         kll_push(Kx, rx, a, vx && a == a);
@@ -709,14 +737,18 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
         cnt_y += __builtin_popcountll(b[k]);
         n_both += __builtin_popcountll(a[k] & b[k]);
       }
-      pair_rows<XF, YF, KLL>(P, ax, ay, m, x0, y0, (uint32_t)((upper ? a[1] : a[0]) >> sh) & 3u,
+      ComoTile q;
+#pragma unroll
+      for (int k = 0; k < 5; k++) q.t[k] = 0.0;
+      pair_rows<XF, YF, KLL>(P, ax, ay, q, x0, y0, (uint32_t)((upper ? a[1] : a[0]) >> sh) & 3u,
                              (uint32_t)((upper ? b[1] : b[0]) >> sh) & 3u, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, m, x1, y1, (uint32_t)((upper ? a[3] : a[2]) >> sh) & 3u,
+      pair_rows<XF, YF, KLL>(P, ax, ay, q, x1, y1, (uint32_t)((upper ? a[3] : a[2]) >> sh) & 3u,
                              (uint32_t)((upper ? b[3] : b[2]) >> sh) & 3u, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, m, x2, y2, (uint32_t)((upper ? a[5] : a[4]) >> sh) & 3u,
+      pair_rows<XF, YF, KLL>(P, ax, ay, q, x2, y2, (uint32_t)((upper ? a[5] : a[4]) >> sh) & 3u,
                              (uint32_t)((upper ? b[5] : b[4]) >> sh) & 3u, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, m, x3, y3, (uint32_t)((upper ? a[7] : a[6]) >> sh) & 3u,
+      pair_rows<XF, YF, KLL>(P, ax, ay, q, x3, y3, (uint32_t)((upper ? a[7] : a[6]) >> sh) & 3u,
                              (uint32_t)((upper ? b[7] : b[6]) >> sh) & 3u, Kx, Ky, rx, ry);
+      como_tile_flush(m, q);
       if (KLL) {
         if (P.x.kll.picks) kll_drain(Kx, rx, P.x.kll, wave_slot, lane);
         if (P.y.kll.picks) kll_drain(Ky, ry, P.y.kll, wave_slot, lane);

@@ -13,9 +13,7 @@
 namespace tgx {
 
 void launch_kll_init(KllDeviceSketch *s, hipStream_t stream, uint32_t shift);
-void launch_kll_update(const KllColDesc &d, int groups, int64_t chunk, KllDeviceSketch *sketches,
-                       KllDeviceSketch *state, uint64_t salt, hipStream_t stream, uint32_t presampled_shift,
-                       bool no_sampling);
+void launch_kll_jobs(const KllJob *jobs, int n_jobs, hipStream_t stream);
 void launch_kll_meta(const KllWaveMeta *meta, int n_waves, KllDeviceSketch *state, hipStream_t stream);
 uint32_t kll_top_for(int64_t rows);
 
@@ -90,9 +88,10 @@ void kll_state_reset(tgx_state *st) {
   }
 }
 
-// groups / chunk of a build over `n` values: one workgroup per >= 64 Ki values, at most 1024 of them
+// groups / chunk of a build over `n` pre-sampled values: every 1024 of them are sorted by one workgroup, ~35 us a
+// time, so the work is spread wide (8 Ki values per workgroup, at most 1024 workgroups)
 static void build_shape(int64_t n, int64_t *groups, int64_t *chunk) {
-  int64_t g = (n + 65535) / 65536;
+  int64_t g = (n + 8191) / 8192;
   g = std::max<int64_t>(1, std::min<int64_t>(g, 1024));
   int64_t c = (n + g - 1) / g;
   c = (c + 4095) / 4096 * 4096;
@@ -106,7 +105,9 @@ tgx_status kll_scan_prepare(tgx_state *st, size_t slot, int64_t rows, int n_wave
                             ScanKll *out, tgx_error *err) {
   KllDeviceState *k = dev(st);
   KllScanBuffers &b = k->scan[slot];
-  const uint32_t top = std::min<uint32_t>(kll_top_for(rows), (uint32_t)kScanKllMaxTop);
+  // one level above the stand-alone kernel's: half the picks to sketch afterwards (the picks of a 1 G-row column are
+  // 3.9 M values at top = 8), for a sampling error that stays an order below the sketch's own (kll.hip)
+  const uint32_t top = std::min<uint32_t>(kll_top_for(rows) + 1, (uint32_t)kScanKllMaxTop);
   const int64_t cap = ((max_rows_per_wave + 1024) >> top) + 2;
   b.n_waves = n_waves;
   b.top = top;
@@ -127,55 +128,75 @@ tgx_status kll_scan_prepare(tgx_state *st, size_t slot, int64_t rows, int n_wave
 }
 
 // the scan of the batch has been queued: sketch what it leaves -- the leftovers (weight 1) into the running sketch,
-// the picks (weight 2^top) into the running sketch of that shift
-tgx_status kll_scan_finish(tgx_state *st, size_t slot, tgx_error *err) {
+// the picks (weight 2^top) into the running sketch of that shift.  All tasks of the batch side by side.
+tgx_status kll_scan_finish(tgx_state *st, tgx_error *err) {
   KllDeviceState *k = dev(st);
-  KllScanBuffers &b = k->scan[slot];
-  if (!b.pending) return TGX_OK;
-  b.pending = false;
+  if (!k) return TGX_OK;
+  std::vector<size_t> slots;
+  for (size_t i = 0; i < k->scan.size(); i++)
+    if (k->scan[i].pending) slots.push_back(i);
+  if (slots.empty()) return TGX_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
     (void)hipEventRecord(e0, st->stream);
-  if (!k->sketch[slot].p) {
-    KHIP(k->sketch[slot].reserve(sizeof(KllDeviceSketch)));
-    launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream, 0);
+  std::vector<KllJob> jobs;
+  std::vector<int64_t> scratch_at;
+  int64_t scratch_total = 0;
+  uint64_t bytes = 0;
+  for (size_t slot : slots) {
+    KllScanBuffers &b = k->scan[slot];
+    b.pending = false;
+    if (!k->sketch[slot].p) {
+      KHIP(k->sketch[slot].reserve(sizeof(KllDeviceSketch)));
+      launch_kll_init(k->sketch[slot].as<KllDeviceSketch>(), st->stream, 0);
+    }
+    if (k->sketch_hi[slot].p && k->dirty_hi[slot] && k->hi_shift[slot] != b.top) {
+      // a batch of another size class: its picks weigh differently -- hand the old ones to the host first
+      tgx_status s = kll_flush(st, err);
+      if (s != TGX_OK) return s;
+    }
+    if (!k->sketch_hi[slot].p || k->hi_shift[slot] != b.top) {
+      KHIP(k->sketch_hi[slot].reserve(sizeof(KllDeviceSketch)));
+      k->hi_shift[slot] = b.top;
+      launch_kll_init(k->sketch_hi[slot].as<KllDeviceSketch>(), st->stream, b.top);
+    }
+    for (int hi = 0; hi < 2; hi++) {
+      KllJob job;
+      memset(&job, 0, sizeof(job));
+      int64_t groups, chunk;
+      build_shape(hi ? b.n_picks : b.n_left, &groups, &chunk);
+      job.d.is_float = 1;
+      job.d.values = hi ? b.picks.p : b.left.p;
+      job.d.length = hi ? b.n_picks : b.n_left;
+      job.chunk = chunk;
+      job.state = (hi ? k->sketch_hi[slot] : k->sketch[slot]).as<KllDeviceSketch>();
+      job.salt = k->salt ^ (0x1111ULL * (uint64_t)(2 * slot + hi + 1));
+      job.top = 0;                 // the values are the sample: none of them is dropped again
+      job.shift = hi ? b.top : 0;
+      job.groups = (int32_t)groups;
+      scratch_at.push_back(scratch_total);
+      scratch_total += groups;
+      jobs.push_back(job);
+      bytes += (uint64_t)job.d.length * 8;
+    }
+    k->dirty[slot] = k->dirty_hi[slot] = 1;
   }
-  if (k->sketch_hi[slot].p && k->dirty_hi[slot] && k->hi_shift[slot] != b.top) {
-    // a batch of another size class: its picks weigh differently -- hand the old ones to the host first
-    tgx_status s = kll_flush(st, err);
-    if (s != TGX_OK) return s;
+  KHIP(k->scratch.reserve((size_t)scratch_total * sizeof(KllDeviceSketch)));
+  for (size_t j = 0; j < jobs.size(); j++) jobs[j].sketches = k->scratch.as<KllDeviceSketch>() + scratch_at[j];
+  launch_kll_jobs(jobs.data(), (int)jobs.size(), st->stream);
+  for (size_t slot : slots) {
+    KllScanBuffers &b = k->scan[slot];
+    // (into both: either of them may end up without items -- no leftovers, or no complete group -- and an empty sketch
+    // is skipped by the merge)
+    launch_kll_meta(b.meta.as<KllWaveMeta>(), b.n_waves, k->sketch[slot].as<KllDeviceSketch>(), st->stream);
+    launch_kll_meta(b.meta.as<KllWaveMeta>(), b.n_waves, k->sketch_hi[slot].as<KllDeviceSketch>(), st->stream);
   }
-  if (!k->sketch_hi[slot].p || k->hi_shift[slot] != b.top) {
-    KHIP(k->sketch_hi[slot].reserve(sizeof(KllDeviceSketch)));
-    k->hi_shift[slot] = b.top;
-    launch_kll_init(k->sketch_hi[slot].as<KllDeviceSketch>(), st->stream, b.top);
-  }
-  int64_t g_left, c_left, g_picks, c_picks;
-  build_shape(b.n_left, &g_left, &c_left);
-  build_shape(b.n_picks, &g_picks, &c_picks);
-  KHIP(k->scratch.reserve((size_t)std::max(g_left, g_picks) * sizeof(KllDeviceSketch)));
-  KllColDesc d;
-  memset(&d, 0, sizeof(d));
-  d.is_float = 1;
-  d.values = b.left.p;
-  d.length = b.n_left;
-  launch_kll_update(d, (int)g_left, c_left, k->scratch.as<KllDeviceSketch>(), k->sketch[slot].as<KllDeviceSketch>(),
-                    k->salt ^ 0x1111ULL, st->stream, 0, true);
-  d.values = b.picks.p;
-  d.length = b.n_picks;
-  launch_kll_update(d, (int)g_picks, c_picks, k->scratch.as<KllDeviceSketch>(),
-                    k->sketch_hi[slot].as<KllDeviceSketch>(), k->salt ^ 0x2222ULL, st->stream, b.top, true);
-  // (into both: either of them may end up without items -- no leftovers, or no complete group -- and an empty sketch
-  // is skipped by the merge)
-  launch_kll_meta(b.meta.as<KllWaveMeta>(), b.n_waves, k->sketch[slot].as<KllDeviceSketch>(), st->stream);
-  launch_kll_meta(b.meta.as<KllWaveMeta>(), b.n_waves, k->sketch_hi[slot].as<KllDeviceSketch>(), st->stream);
   if (st->profiling && e0 && e1) {
     (void)hipEventRecord(e1, st->stream);
     ProfileEntry &pe = st->profile["kll"];
     pe.pending.emplace_back(e0, e1);
-    pe.pending_bytes.push_back((uint64_t)(b.n_picks + b.n_left) * 8);
+    pe.pending_bytes.push_back(bytes);
   }
-  k->dirty[slot] = k->dirty_hi[slot] = 1;
   return TGX_OK;
 }
 
@@ -207,8 +228,16 @@ tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error
   if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
     (void)hipEventRecord(e0, st->stream);
   }
-  launch_kll_update(d, (int)groups, chunk, k->scratch.as<KllDeviceSketch>(),
-                    k->sketch[slot].as<KllDeviceSketch>(), k->salt, st->stream, 0, false);
+  KllJob job;
+  memset(&job, 0, sizeof(job));
+  job.d = d;
+  job.chunk = chunk;
+  job.sketches = k->scratch.as<KllDeviceSketch>();
+  job.state = k->sketch[slot].as<KllDeviceSketch>();
+  job.salt = k->salt;
+  job.top = kll_top_for(d.length);
+  job.groups = (int32_t)groups;
+  launch_kll_jobs(&job, 1, st->stream);
   if (st->profiling && e0 && e1) {
     (void)hipEventRecord(e1, st->stream);
     ProfileEntry &pe = st->profile["kll"];

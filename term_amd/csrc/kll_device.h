@@ -14,7 +14,7 @@ tgx_status kll_update(tgx_state *st, size_t slot, const tgx_column &col, tgx_err
 bool kll_scan_eligible(int64_t rows);
 tgx_status kll_scan_prepare(tgx_state *st, size_t slot, int64_t rows, int n_waves, int64_t max_rows_per_wave,
                             ScanKll *out, tgx_error *err);
-tgx_status kll_scan_finish(tgx_state *st, size_t slot, tgx_error *err);
+tgx_status kll_scan_finish(tgx_state *st, tgx_error *err);  // every prepared task of the batch
 // folds the device-side sketch of every KLL task into st->h_kll (leaves the device side empty)
 tgx_status kll_flush(tgx_state *st, tgx_error *err);
 tgx_status kll_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *err);

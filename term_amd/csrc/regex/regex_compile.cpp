@@ -1212,5 +1212,83 @@ bool dfa_is_match(const Dfa &d, const uint8_t *s, size_t n) {
   return st == 1 || d.accept_at_end[st] != 0;
 }
 
+bool dfa_product(const std::vector<const Dfa *> &parts, uint32_t max_entries, ProductDfa *out) {
+  const size_t k = parts.size();
+  if (k == 0 || k > 8) return false;
+  // common refinement of the byte classes: bytes with the same class in every part
+  std::map<std::vector<uint8_t>, uint32_t> class_ids;
+  std::vector<std::vector<uint8_t>> class_tuple;
+  for (uint32_t b = 0; b < 256; b++) {
+    std::vector<uint8_t> t(k);
+    for (size_t i = 0; i < k; i++) t[i] = parts[i]->byte_class[b];
+    auto it = class_ids.find(t);
+    if (it == class_ids.end()) {
+      it = class_ids.emplace(t, (uint32_t)class_tuple.size()).first;
+      class_tuple.push_back(t);
+    }
+    out->byte_class[b] = (uint8_t)it->second;
+    if (class_tuple.size() > 255) return false;
+  }
+  const uint32_t ncls = (uint32_t)class_tuple.size();
+  const uint32_t n_final = 1u << k;
+  auto decided = [](uint16_t s) { return s <= 1; };
+  std::map<std::vector<uint16_t>, uint32_t> ids;
+  std::vector<std::vector<uint16_t>> tuples;
+  // the 2^k decided tuples first: index = mask of the parts that matched
+  for (uint32_t m = 0; m < n_final; m++) {
+    std::vector<uint16_t> t(k);
+    for (size_t i = 0; i < k; i++) t[i] = (m >> i) & 1u;
+    ids[t] = m;
+    tuples.push_back(t);
+  }
+  auto id_of = [&](const std::vector<uint16_t> &t) -> uint32_t {
+    auto it = ids.find(t);
+    if (it != ids.end()) return it->second;
+    const uint32_t id = (uint32_t)tuples.size();
+    ids[t] = id;
+    tuples.push_back(t);
+    return id;
+  };
+  std::vector<uint16_t> start(k);
+  for (size_t i = 0; i < k; i++) start[i] = (uint16_t)parts[i]->start;
+  out->start = id_of(start);
+  std::vector<uint16_t> table;
+  for (uint32_t sidx = 0; sidx < tuples.size(); sidx++) {
+    if ((uint64_t)tuples.size() * ncls > max_entries || tuples.size() > 65000) return false;
+    const std::vector<uint16_t> cur = tuples[sidx];  // (copy: id_of grows `tuples`)
+    table.resize((size_t)(sidx + 1) * ncls);
+    for (uint32_t c = 0; c < ncls; c++) {
+      std::vector<uint16_t> nxt(k);
+      for (size_t i = 0; i < k; i++) {
+        const Dfa &d = *parts[i];
+        nxt[i] = decided(cur[i]) ? cur[i] : d.table[(size_t)cur[i] * d.n_classes + class_tuple[c][i]];
+      }
+      table[(size_t)sidx * ncls + c] = (uint16_t)id_of(nxt);
+    }
+  }
+  if ((uint64_t)tuples.size() * ncls > max_entries) return false;
+  out->n_parts = (uint32_t)k;
+  out->n_states = (uint32_t)tuples.size();
+  out->n_classes = ncls;
+  out->n_final = n_final;
+  out->table = std::move(table);
+  out->accept_mask.assign(tuples.size(), 0);
+  for (size_t sidx = 0; sidx < tuples.size(); sidx++) {
+    uint8_t m = 0;
+    for (size_t i = 0; i < k; i++) {
+      const uint16_t st = tuples[sidx][i];
+      if (st == 1 || parts[i]->accept_at_end[st] != 0) m |= (uint8_t)(1u << i);
+    }
+    out->accept_mask[sidx] = m;
+  }
+  return true;
+}
+
+uint32_t product_match_mask(const ProductDfa &d, const uint8_t *s, size_t n) {
+  uint32_t st = d.start;
+  for (size_t i = 0; i < n && st >= d.n_final; i++) st = d.table[(size_t)st * d.n_classes + d.byte_class[s[i]]];
+  return d.accept_mask[st];
+}
+
 }  // namespace rx
 }  // namespace tgx

@@ -41,5 +41,22 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
 // host-side walk of the automaton (used to check compiled patterns on small inputs)
 bool dfa_is_match(const Dfa &d, const uint8_t *s, size_t n);
 
+// Several patterns of ONE column in one walk: the product of their automata.  A product state is the tuple of the
+// parts' states; the input byte classes are the common refinement of theirs.  States 0 .. n_final - 1 are the tuples
+// whose every component is decided (DEAD or MATCHED): absorbing, state index = bit mask of the parts that matched.
+// accept_mask[s] has bit k set when part k matches a haystack that ends in state s.  Only reachable tuples are
+// built; false when the table would exceed `max_entries` (states x classes) or there are more than 8 parts --
+// the caller then walks the parts separately.
+struct ProductDfa {
+  uint32_t n_parts = 0;
+  uint32_t n_states = 0, n_classes = 0, start = 0, n_final = 0;
+  uint8_t byte_class[256];
+  std::vector<uint16_t> table;       // n_states * n_classes
+  std::vector<uint8_t> accept_mask;  // n_states
+};
+bool dfa_product(const std::vector<const Dfa *> &parts, uint32_t max_entries, ProductDfa *out);
+// bit k = part k matches
+uint32_t product_match_mask(const ProductDfa &d, const uint8_t *s, size_t n);
+
 }  // namespace rx
 }  // namespace tgx

@@ -26,8 +26,15 @@ struct RegexTask {
   bool is_length = false;  // TGX_CHECK_LENGTH: no automaton, character-count bounds instead
   uint64_t len_min = 0, len_max = 0;
 };
+// patterns of one column (same TRIM flag) whose product automaton fits the LDS table: decided in ONE walk
+struct RegexGroup {
+  std::vector<int> members;  // task indices, <= kMaxRegexGroup
+  rx::ProductDfa dfa;
+};
 struct RegexPlan {
   std::vector<RegexTask> tasks;
+  std::vector<RegexGroup> groups;
+  std::vector<int> group_of;  // per task: its group or -1
 };
 struct RegexTaskState {
   DevBuf table, byte_class, accept_end, counters;
@@ -36,8 +43,13 @@ struct RegexTaskState {
   uint64_t h_total = 0, h_matches = 0;  // merged-in / deserialized contributions
   uint64_t total = 0;                   // rows handled on this device
 };
+struct RegexGroupState {
+  DevBuf table, byte_class, accept_end;
+  bool direct = false, uploaded = false;
+};
 struct RegexState {
   std::vector<RegexTaskState> tasks;
+  std::vector<RegexGroupState> groups;
   DevBuf counter_pool;  // [task][2]: every RegexTaskState::counters is a slice, so results come back in ONE copy
   std::vector<unsigned long long> fetched;  // host copy of the pool, valid while `fetched_ok` (inside one API call)
   bool fetched_ok = false;
@@ -59,6 +71,12 @@ tgx_status rfail(tgx_error *err, tgx_status code, const char *fmt, ...) {
     if (e_ != hipSuccess)                                                                                  \
       return rfail(err, e_ == hipErrorOutOfMemory ? TGX_OUT_OF_MEMORY : TGX_DEVICE_ERROR, "%s failed: %s", \
                    #expr, hipGetErrorString(e_));                                                          \
+  } while (0)
+
+#define TGX_TRY_R(expr)          \
+  do {                           \
+    tgx_status s_ = (expr);      \
+    if (s_ != TGX_OK) return s_; \
   } while (0)
 
 const RegexPlan *rplan(const tgx_plan *p) { return (const RegexPlan *)p->regex; }
@@ -116,6 +134,39 @@ tgx_status regex_plan_add(tgx_plan *plan, int spec_index, int *slot, tgx_error *
   return TGX_OK;
 }
 
+// Called once every spec has been added: patterns of the same column and TRIM flag are grouped while the product of
+// their automata still fits the LDS transition table (k format checks on a column then cost one walk over its bytes;
+// TG/constraints/format.rs:750-776 issues one query per constraint).  Greedy, in task order.
+void regex_plan_finish(tgx_plan *plan) {
+  if (!plan->regex) return;
+  RegexPlan *rp = (RegexPlan *)plan->regex;
+  rp->groups.clear();
+  rp->group_of.assign(rp->tasks.size(), -1);
+  for (size_t i = 0; i < rp->tasks.size(); i++) {
+    if (rp->tasks[i].is_length || rp->group_of[i] >= 0) continue;
+    RegexGroup g;
+    g.members.push_back((int)i);
+    std::vector<const rx::Dfa *> parts = {&rp->tasks[i].dfa};
+    for (size_t j = i + 1; j < rp->tasks.size() && g.members.size() < (size_t)kMaxRegexGroup; j++) {
+      const RegexTask &a = rp->tasks[i], &b = rp->tasks[j];
+      if (b.is_length || rp->group_of[j] >= 0 || b.column != a.column ||
+          ((a.flags ^ b.flags) & TGX_FLAG_TRIM) != 0)
+        continue;
+      parts.push_back(&b.dfa);
+      rx::ProductDfa prod;
+      if (rx::dfa_product(parts, kRegexLdsEntries, &prod)) {
+        g.dfa = std::move(prod);
+        g.members.push_back((int)j);
+      } else {
+        parts.pop_back();
+      }
+    }
+    if (g.members.size() < 2) continue;
+    for (int m : g.members) rp->group_of[m] = (int)rp->groups.size();
+    rp->groups.push_back(std::move(g));
+  }
+}
+
 void regex_plan_free(tgx_plan *plan) {
   delete (RegexPlan *)plan->regex;
   plan->regex = nullptr;
@@ -132,6 +183,7 @@ void regex_state_init(tgx_state *st) {
   if (st->regex) return;
   RegexState *rs = new RegexState();
   rs->tasks.resize(regex_num_tasks(st->plan));
+  rs->groups.resize(st->plan->regex ? rplan(st->plan)->groups.size() : 0);
   st->regex = rs;
 }
 
@@ -150,68 +202,140 @@ void regex_state_reset(tgx_state *st) {
   rs->fetched_ok = false;
 }
 
+// the string layout one launch walks: the column itself, or the dictionary of a dictionary column (matched once per
+// ENTRY; the rows then only gather the per-entry verdicts)
+static void fill_col_desc(const tgx_column &c, uint32_t flags, RegexColDesc *d) {
+  const bool is_dict = c.type == TGX_DICT32_UTF8, is_view = c.type == TGX_UTF8_VIEW;
+  const tgx_column &sc = is_dict ? *c.dictionary : c;
+  memset(d, 0, sizeof(*d));
+  d->offsets = sc.offsets;
+  d->data = sc.data;
+  d->validity = sc.validity;
+  d->offset = sc.offset;
+  d->length = sc.length;
+  d->large_offsets = sc.type == TGX_LARGE_UTF8;
+  d->views = is_view ? c.values : nullptr;
+  d->buffers = is_view ? c.variadic : nullptr;
+  d->trim = (flags & TGX_FLAG_TRIM) != 0;
+  d->null_is_valid = (flags & TGX_FLAG_NULL_IS_VALID) != 0;
+}
+
+// uploads an automaton (byte-indexed when tiny: one LDS lookup per input byte instead of class + transition -- only
+// while the table stays small (8 KiB): the kernel hides its load latency with resident workgroups (7 per CU at
+// <= 22 KiB of LDS each), and a byte-indexed 32 KiB table ran 1.6x SLOWER)
+static tgx_status upload_dfa(uint32_t n_states, uint32_t n_classes, const uint8_t *byte_class,
+                             const std::vector<uint16_t> &src, const std::vector<uint8_t> &accept, DevBuf &d_table,
+                             DevBuf &d_class, DevBuf &d_accept, bool *direct, tgx_error *err) {
+  *direct = (uint64_t)n_states * 256 <= 4096;
+  std::vector<uint16_t> table = src;
+  uint8_t cls[256];
+  memcpy(cls, byte_class, 256);
+  if (*direct) {
+    table.assign((size_t)n_states * 256, 0);
+    for (uint32_t s2 = 0; s2 < n_states; s2++)
+      for (uint32_t b = 0; b < 256; b++) table[(size_t)s2 * 256 + b] = src[(size_t)s2 * n_classes + byte_class[b]];
+    for (uint32_t b = 0; b < 256; b++) cls[b] = (uint8_t)b;
+  }
+  RHIP(d_table.reserve(table.size() * sizeof(uint16_t) + 16));
+  RHIP(d_class.reserve(256));
+  RHIP(d_accept.reserve(accept.size() + 16));
+  RHIP(hipMemcpy(d_table.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  RHIP(hipMemcpy(d_class.p, cls, 256, hipMemcpyHostToDevice));
+  RHIP(hipMemcpy(d_accept.p, accept.data(), accept.size(), hipMemcpyHostToDevice));
+  return TGX_OK;
+}
+
 tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, DictFuse *fuse) {
   if (!st->plan->regex) return TGX_OK;
   const RegexPlan *rp = rplan(st->plan);
   RegexState *rs = rstate(st);
   rs->fetched_ok = false;
   const int n_cu = tgx_num_cus();
+  struct Timer {  // one "regex" profile entry per launch
+    tgx_state *st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit Timer(tgx_state *s) : st(s) {
+      if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+        (void)hipEventRecord(e0, st->stream);
+    }
+    ~Timer() {
+      if (st->profiling && e0 && e1) {
+        (void)hipEventRecord(e1, st->stream);
+        ProfileEntry &pe = st->profile["regex"];
+        pe.pending.emplace_back(e0, e1);
+        pe.pending_bytes.push_back(0);  // value bytes are data dependent; bench.py prices them itself
+      }
+    }
+  };
+  for (size_t i = 0; i < rp->tasks.size(); i++) {
+    const RegexTask &t = rp->tasks[i];
+    const tgx_column &c = dev[t.column];
+    if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && c.type != TGX_DICT32_UTF8 && c.type != TGX_UTF8_VIEW)
+      return rfail(err, TGX_UNSUPPORTED, "%s needs a Utf8 column (column %d has type %d)",
+                   t.is_length ? "LENGTH" : "REGEX_MATCH", t.column, c.type);
+  }
+  if (!rs->counter_pool.p && !rs->tasks.empty()) {
+    RHIP(rs->counter_pool.reserve(rs->tasks.size() * 16));
+    // zero-filled on the state's (non-blocking) stream: ordered with the kernels that add to the counters
+    RHIP(hipMemsetAsync(rs->counter_pool.p, 0, rs->tasks.size() * 16, st->stream));
+    for (size_t k = 0; k < rs->tasks.size(); k++)
+      rs->tasks[k].counters.borrow((char *)rs->counter_pool.p + 16 * k, 16);
+  }
+  std::vector<char> walked(rp->tasks.size(), 0);
+  // ---- groups: several patterns of a column in one walk (product automaton)
+  for (size_t g = 0; g < rp->groups.size(); g++) {
+    const RegexGroup &grp = rp->groups[g];
+    RegexGroupState &gs = rs->groups[g];
+    const tgx_column &c = dev[rp->tasks[grp.members[0]].column];
+    const bool is_dict = c.type == TGX_DICT32_UTF8;
+    const tgx_column &sc = is_dict ? *c.dictionary : c;
+    if (c.length == 0 || sc.length == 0) continue;
+    if (!gs.uploaded) {
+      TGX_TRY_R(upload_dfa(grp.dfa.n_states, grp.dfa.n_classes, grp.dfa.byte_class, grp.dfa.table, grp.dfa.accept_mask,
+                           gs.table, gs.byte_class, gs.accept_end, &gs.direct, err));
+      gs.uploaded = true;
+    }
+    RegexColDesc d;
+    fill_col_desc(c, rp->tasks[grp.members[0]].flags, &d);
+    d.n_pat = (int32_t)grp.members.size();
+    for (size_t k = 0; k < grp.members.size(); k++) {
+      const RegexTask &t = rp->tasks[grp.members[k]];
+      RegexTaskState &ts = rs->tasks[grp.members[k]];
+      if (t.flags & TGX_FLAG_NULL_IS_VALID) d.null_mask |= 1u << k;
+      if (is_dict) RHIP(ts.dict_hits.reserve((size_t)sc.length + 32));
+      d.hits_k[k] = is_dict ? ts.dict_hits.as<uint8_t>() : nullptr;
+      // dictionary columns: counters[1] soaks up the per-entry match count, counters[0] receives the per-row one
+      d.counters_k[k] = ts.counters.as<unsigned long long>() + (is_dict ? 1 : 0);
+      walked[grp.members[k]] = 1;
+    }
+    DfaView v;
+    v.table = gs.table.as<uint16_t>();
+    v.byte_class = gs.byte_class.as<uint8_t>();
+    v.accept_end = gs.accept_end.as<uint8_t>();
+    v.n_states = grp.dfa.n_states;
+    v.n_classes = gs.direct ? 256 : grp.dfa.n_classes;
+    v.start = grp.dfa.start;
+    v.direct = gs.direct ? 1 : 0;
+    v.n_final = grp.dfa.n_final;
+    Timer timer(st);
+    launch_regex(d, v, nullptr, n_cu, st->stream);
+  }
+  // ---- single patterns, LENGTH checks, and the per-row gathers of dictionary columns
   for (size_t i = 0; i < rp->tasks.size(); i++) {
     const RegexTask &t = rp->tasks[i];
     RegexTaskState &ts = rs->tasks[i];
     const tgx_column &c = dev[t.column];
     const bool is_dict = c.type == TGX_DICT32_UTF8;
-    const bool is_view = c.type == TGX_UTF8_VIEW;
-    if (c.type != TGX_UTF8 && c.type != TGX_LARGE_UTF8 && !is_dict && !is_view)
-      return rfail(err, TGX_UNSUPPORTED, "%s needs a Utf8 column (column %d has type %d)",
-                   t.is_length ? "LENGTH" : "REGEX_MATCH", t.column, c.type);
-    if (!rs->counter_pool.p) {
-      RHIP(rs->counter_pool.reserve(rs->tasks.size() * 16));
-      // zero-filled on the state's (non-blocking) stream: ordered with the kernels that add to the counters
-      RHIP(hipMemsetAsync(rs->counter_pool.p, 0, rs->tasks.size() * 16, st->stream));
-      for (size_t k = 0; k < rs->tasks.size(); k++)
-        rs->tasks[k].counters.borrow((char *)rs->counter_pool.p + 16 * k, 16);
-    }
-    if (!t.is_length && !ts.table.p) {
-      const rx::Dfa &d = t.dfa;
-      // tiny automata (<= 16 states) travel with one table column per BYTE: one LDS lookup per input byte instead
-      // of class + transition.  Only while the table stays small (8 KiB): the kernel hides its load latency with
-      // resident workgroups (7 per CU at <= 22 KiB of LDS each), and a byte-indexed 32 KiB table ran 1.6x SLOWER.
-      ts.direct = (uint64_t)d.n_states * 256 <= 4096;
-      std::vector<uint16_t> table = d.table;
-      uint8_t cls[256];
-      memcpy(cls, d.byte_class, 256);
-      if (ts.direct) {
-        table.assign((size_t)d.n_states * 256, 0);
-        for (uint32_t s2 = 0; s2 < d.n_states; s2++)
-          for (uint32_t b = 0; b < 256; b++) table[(size_t)s2 * 256 + b] = d.table[(size_t)s2 * d.n_classes + d.byte_class[b]];
-        for (uint32_t b = 0; b < 256; b++) cls[b] = (uint8_t)b;
-      }
-      RHIP(ts.table.reserve(table.size() * sizeof(uint16_t) + 16));
-      RHIP(ts.byte_class.reserve(256));
-      RHIP(ts.accept_end.reserve(d.accept_at_end.size() + 16));
-      RHIP(hipMemcpy(ts.table.p, table.data(), table.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-      RHIP(hipMemcpy(ts.byte_class.p, cls, 256, hipMemcpyHostToDevice));
-      RHIP(hipMemcpy(ts.accept_end.p, d.accept_at_end.data(), d.accept_at_end.size(), hipMemcpyHostToDevice));
-    }
+    if (!t.is_length && !ts.table.p && !walked[i])
+      TGX_TRY_R(upload_dfa(t.dfa.n_states, t.dfa.n_classes, t.dfa.byte_class, t.dfa.table, t.dfa.accept_at_end, ts.table,
+                           ts.byte_class, ts.accept_end, &ts.direct, err));
     ts.total += (uint64_t)c.length;
     if (c.length == 0) continue;
-    // a dictionary column is matched once per ENTRY; the rows then only gather the per-entry verdicts
     const tgx_column &sc = is_dict ? *c.dictionary : c;
     if (is_dict) RHIP(ts.dict_hits.reserve((size_t)sc.length + 32));
     RegexColDesc d;
-    d.offsets = sc.offsets;
-    d.data = sc.data;
-    d.validity = sc.validity;
-    d.offset = sc.offset;
-    d.length = sc.length;
-    d.large_offsets = sc.type == TGX_LARGE_UTF8;
+    fill_col_desc(c, t.flags, &d);
     d.hits = is_dict ? ts.dict_hits.as<uint8_t>() : nullptr;
-    d.views = is_view ? c.values : nullptr;
-    d.buffers = is_view ? c.variadic : nullptr;
-    d.trim = (t.flags & TGX_FLAG_TRIM) != 0;
-    d.null_is_valid = (t.flags & TGX_FLAG_NULL_IS_VALID) != 0;
-    d.pad = 0;
     DfaView v;
     v.table = ts.table.as<uint16_t>();
     v.byte_class = ts.byte_class.as<uint8_t>();
@@ -220,21 +344,20 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, Di
     v.n_classes = ts.direct ? 256 : t.dfa.n_classes;
     v.start = t.dfa.start;
     v.direct = ts.direct ? 1 : 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (st->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-      (void)hipEventRecord(e0, st->stream);
+    v.n_final = 2;
+    Timer timer(st);
     const LengthBounds lb{t.len_min, t.len_max};
     if (!is_dict) {
       if (t.is_length)
         launch_length(d, lb, ts.counters.as<unsigned long long>(), n_cu, st->stream);
-      else
+      else if (!walked[i])
         launch_regex(d, v, ts.counters.as<unsigned long long>(), n_cu, st->stream);
     } else {
       // counters[1] soaks up the per-entry match count, counters[0] receives the per-row one
       if (sc.length > 0) {
         if (t.is_length)
           launch_length(d, lb, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
-        else
+        else if (!walked[i])
           launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
       }
       bool fused = false;
@@ -252,12 +375,6 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, Di
                                sc.validity != nullptr, ts.dict_hits.as<uint8_t>(),
                                (t.flags & TGX_FLAG_NULL_IS_VALID) != 0, ts.counters.as<unsigned long long>(), n_cu,
                                st->stream);
-    }
-    if (st->profiling && e0 && e1) {
-      (void)hipEventRecord(e1, st->stream);
-      ProfileEntry &pe = st->profile["regex"];
-      pe.pending.emplace_back(e0, e1);
-      pe.pending_bytes.push_back(0);  // value bytes are data dependent; bench.py prices them itself
     }
   }
   return TGX_OK;
@@ -380,6 +497,48 @@ extern "C" tgx_status tgx_regex_is_match(const char *pattern, size_t plen, uint3
     while (e > b && value[e - 1] == 0x20) e--;
   }
   *matched = rx::dfa_is_match(dfa, value + b, e - b) ? 1 : 0;
+  return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
+}
+
+extern "C" tgx_status tgx_regex_match_group(const char *const *patterns, const size_t *pattern_lens,
+                                            const uint32_t *flags, size_t n_patterns, const uint8_t *value, size_t vlen,
+                                            uint32_t *mask, int32_t *grouped, tgx_error *err) try {
+  if (!patterns || !pattern_lens || !mask || (!value && vlen) || n_patterns == 0 || n_patterns > (size_t)kMaxRegexGroup)
+    return rfail(err, TGX_INVALID_ARGUMENT, "bad arguments (1..%d patterns)", kMaxRegexGroup);
+  std::vector<rx::Dfa> dfas(n_patterns);
+  std::vector<const rx::Dfa *> parts;
+  bool same_trim = true;
+  for (size_t k = 0; k < n_patterns; k++) {
+    const uint32_t f = flags ? flags[k] : 0;
+    tgx_status s = compile_checked(patterns[k] ? patterns[k] : "", pattern_lens[k], f, &dfas[k], err);
+    if (s != TGX_OK) return s;
+    parts.push_back(&dfas[k]);
+    same_trim &= ((f ^ (flags ? flags[0] : 0)) & TGX_FLAG_TRIM) == 0;
+  }
+  auto trimmed = [&](uint32_t f, size_t *b, size_t *e) {
+    *b = 0;
+    *e = vlen;
+    if (f & TGX_FLAG_TRIM) {
+      while (*b < *e && value[*b] == 0x20) (*b)++;
+      while (*e > *b && value[*e - 1] == 0x20) (*e)--;
+    }
+  };
+  rx::ProductDfa prod;
+  const bool ok = same_trim && rx::dfa_product(parts, kRegexLdsEntries, &prod);
+  if (grouped) *grouped = ok ? 1 : 0;
+  size_t b, e;
+  if (ok) {
+    trimmed(flags ? flags[0] : 0, &b, &e);
+    *mask = rx::product_match_mask(prod, value + b, e - b);
+    return TGX_OK;
+  }
+  *mask = 0;
+  for (size_t k = 0; k < n_patterns; k++) {
+    trimmed(flags ? flags[k] : 0, &b, &e);
+    if (rx::dfa_is_match(dfas[k], value + b, e - b)) *mask |= 1u << k;
+  }
   return TGX_OK;
 } catch (...) {
   return tgx::abi_exception(err);

@@ -6,6 +6,8 @@
 
 namespace tgx {
 tgx_status regex_plan_add(tgx_plan *plan, int spec_index, int *slot, tgx_error *err);
+// after the last regex_plan_add: groups the patterns of a column whose product automaton fits the LDS table
+void regex_plan_finish(tgx_plan *plan);
 void regex_plan_free(tgx_plan *plan);
 size_t regex_num_tasks(const tgx_plan *plan);
 void regex_mark_used(const tgx_plan *plan, std::vector<char> &used);

@@ -270,6 +270,7 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
     plan->bind[i].count_src = Source::kCount;
   }
   plan->n_columns_needed = max_col + 1;
+  regex_plan_finish(plan.get());
   // re-point pattern pointers at the plan-owned copies
   for (size_t i = 0; i < n_specs; i++) {
     plan->specs[i].pattern = plan->patterns[i].empty() ? nullptr : plan->patterns[i].data();
@@ -1581,12 +1582,9 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       }
     // (gathers handed out but not consumed -- cannot happen: every fusable column has exactly one DISTINCT task)
     // ---- KLL ----
-    for (size_t s = 0; s < plan->kll.size(); s++) {
-      if (kll_fused[s])
-        TGX_TRY(kll_scan_finish(st, s, err));  // sketches the picks the scan left
-      else
-        TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
-    }
+    TGX_TRY(kll_scan_finish(st, err));  // sketches the picks the scan left for the tasks that rode on it
+    for (size_t s = 0; s < plan->kll.size(); s++)
+      if (!kll_fused[s]) TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
     // ---- Spearman: keep the pairs, rank at finalize ----
     TGX_TRY(spearman_update(st, dev.data(), err));
   }

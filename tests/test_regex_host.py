@@ -120,3 +120,58 @@ def test_semantic_traps():
         assert engine(r"", "") and engine(r"^$", "") and not engine(r"^$", "x")
     assert product_is_match(r"^x$", "  x  ", T.FLAG_TRIM)
     assert not product_is_match(r"^x$", "\tx", T.FLAG_TRIM)  # tab is not trimmed
+
+
+def product_group_mask(patterns, flags, value):
+    n = len(patterns)
+    pbs = [p.encode() for p in patterns]
+    arr = (C.c_char_p * n)(*pbs)
+    lens = (C.c_size_t * n)(*[len(b) for b in pbs])
+    fl = (C.c_uint32 * n)(*flags)
+    vb = value.encode()
+    mask, grouped, err = C.c_uint32(), C.c_int32(), _Error()
+    rc = T.lib().tgx_regex_match_group(arr, lens, fl, n, vb, len(vb), C.byref(mask), C.byref(grouped), C.byref(err))
+    if rc != 0:
+        raise T.TgxError(rc, err.msg.decode())
+    return mask.value, bool(grouped.value)
+
+
+def test_product_automaton_of_several_patterns_decides_each_of_them(crosscheck, golden):
+    """Several pattern checks of one column share ONE walk on the device: the product of their automata
+    (regex_compile.cpp dfa_product).  Host-side walk of that product against the PyPI-`regex` truth of the cross-check
+    vectors: groups of 2 .. 4 patterns, every input any member of the group has a vector for."""
+    T.lib().tgx_regex_match_group.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                                              C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_int32), C.POINTER(_Error)]
+    truth, inputs = {}, {}
+    for c in crosscheck["cases"]:
+        key = (c["pattern"], c["flags"])
+        truth[(key, c["input"])] = c["match"]
+        inputs.setdefault(key, []).append(c["input"])
+    keys = sorted(inputs)
+    checked = grouped_groups = 0
+    for g0 in range(0, len(keys) - 1, 3):
+        group = keys[g0:g0 + 2 + (g0 // 3) % 3]            # sizes 2, 3, 4 in turn (overlapping windows)
+        group = [k for k in group if (k[1] & T.FLAG_TRIM) == (group[0][1] & T.FLAG_TRIM)]
+        if len(group) < 2:
+            continue
+        pats, fl = [k[0] for k in group], [k[1] for k in group]
+        pool = sorted({s for k in group for s in inputs[k]})[:: max(1, sum(len(inputs[k]) for k in group) // 24)]
+        for s in pool:
+            mask, grouped = product_group_mask(pats, fl, s)
+            grouped_groups += grouped
+            for bit, k in enumerate(group):
+                want = truth.get((k, s))
+                if want is None:
+                    want = product_is_match(k[0], s, k[1])   # no vector for this pair: the single automaton decides
+                assert bool((mask >> bit) & 1) == want, (pats, s, bit)
+                checked += 1
+    assert checked > 1000 and grouped_groups > 0
+    # the trio of BASELINE.json configs[2] fits one table
+    P = golden["patterns"]
+    trio = [r"@", r"^[^@]+@[^@]+\.[^@]+$", P["email"]]
+    for s, want in (("user000000001@example001.com", 0b111), ("user#example.com", 0), ("a@b", 0b001), ("a@b.c", 0b111),
+                    ("a@@b.c", 0b001), ("", 0)):
+        assert product_group_mask(trio, [0, 0, 0], s) == (want, True), s
+    with pytest.raises(T.TgxError):
+        product_group_mask(["(unclosed", "a"], [0, 0], "a")
