@@ -172,15 +172,19 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// one value per lane: `ok` = non-NULL and not NaN
+// one value per lane: `ok` = non-NULL and not NaN.  TRACK = false: the caller keeps the MIN / MAX itself (the pair
+// kernel's extreme filter)
+template <bool TRACK = true>
 __device__ __forceinline__ void kll_push(KllLane &K, double *ring, double x, bool ok) {
   const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
   const uint32_t pos = K.pending + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
   if (ok) ring[pos] = x;
   K.pending += (uint32_t)__builtin_popcountll(m);
-  const double xn = ok ? x : __longlong_as_double(0x7FF8000000000000LL);
-  K.mn = __builtin_fmin(K.mn, xn);  // v_min_f64 / v_max_f64 return the other operand for a NaN
-  K.mx = __builtin_fmax(K.mx, xn);
+  if (TRACK) {
+    const double xn = ok ? x : __longlong_as_double(0x7FF8000000000000LL);
+    K.mn = __builtin_fmin(K.mn, xn);  // v_min_f64 / v_max_f64 return the other operand for a NaN
+    K.mx = __builtin_fmax(K.mx, xn);
+  }
 }
 
 // emits the complete groups of the ring and moves the rest to its front
@@ -601,26 +605,138 @@ __device__ __forceinline__ void como_tile_flush(ComoLane &m, ComoTile &q) {
   }
 }
 
+// ---- the pair kernel's tile path.  It is bound by instruction issue, not by HBM (two columns' aggregates, the
+// co-moments and up to two samplers per row), so the per-value work is cut to what a value can change:
+//   * MIN / MAX: a value matters only if it lies outside what the WAVE has seen so far.  The wave keeps uniform
+//     bounds; a value is tested against them with two compares, and only a tile in which some lane holds a value
+//     outside them (after the first few tiles: almost none) runs the exact update -- IEEE totalOrder keys for
+//     doubles, as the single-column scan does -- and refreshes the bounds.  Doubles: NaN fails both compares and a
+//     bound that is a zero is nudged one denormal inward, so NaN and -0 / +0 always take the exact path.
+//   * SUM of a Float64 column: a lane's eight rows of a tile are added plainly, the partial enters the running sum
+//     through the two-sum (as the co-moments do, see ComoTile).
+//   * the samplers' NaN-ignoring MIN / MAX come out of the same exact path (KllLane::mn / mx are not touched per row).
+template <bool F>
+struct ColFast {
+  int64_t lo, hi;   // wave-uniform filter bounds: !F the Int64 values, F the bit patterns of the (nudged) doubles
+  double dmn, dmx;  // per lane: NaN-ignoring MIN / MAX over the values of the tiles that took the exact path
+  double tsum;      // F: plain partial sum of the tile
+};
+
+template <bool F>
+__device__ __forceinline__ void col_fast_init(ColFast<F> &c) {
+  c.dmn = __longlong_as_double(0x7FF0000000000000LL);
+  c.dmx = -c.dmn;
+  c.tsum = 0.0;
+  if (F) {
+    c.lo = 0x7FF0000000000000LL;                   // +inf: nothing is inside yet
+    c.hi = (int64_t)0xFFF0000000000000ULL;         // -inf
+  } else {
+    c.lo = INT64_MAX;
+    c.hi = INT64_MIN;
+  }
+}
+
+// the per-row part: range test (returns the lanes whose value lies outside the wave's bounds) and the sum
+template <bool F>
+__device__ __forceinline__ unsigned long long col_fast_value(ColFast<F> &c, LaneAcc &a, int64_t bits, bool valid) {
+  bool inside;
+  if (F) {
+    const double x = __longlong_as_double(bits);
+    inside = x >= __longlong_as_double(c.lo) && x <= __longlong_as_double(c.hi);
+    c.tsum += valid ? x : 0.0;
+  } else {
+    inside = bits >= c.lo && bits <= c.hi;
+    const int64_t v = valid ? bits : 0;
+    unsigned __int128 sum = ((unsigned __int128)a.hi << 64) | (unsigned __int128)a.lo;
+    sum += (unsigned __int128)(__int128)v;
+    a.lo = (uint64_t)sum;
+    a.hi = (uint64_t)(sum >> 64);
+  }
+  return __builtin_amdgcn_ballot_w64(valid && !inside);
+}
+
+// the exact MIN / MAX update of one value (what acc_value does, without the sums)
+template <bool F>
+__device__ __forceinline__ void col_exact_value(ColFast<F> &c, LaneAcc &a, int64_t bits, bool valid) {
+  const int64_t k = F ? f64_total_key(bits) : bits;
+  a.mn = (valid && k < a.mn) ? k : a.mn;
+  a.mx = (valid && k > a.mx) ? k : a.mx;
+  const double x = F ? __longlong_as_double(bits) : (double)bits;
+  const double xn = valid ? x : __longlong_as_double(0x7FF8000000000000LL);
+  c.dmn = __builtin_fmin(c.dmn, xn);
+  c.dmx = __builtin_fmax(c.dmx, xn);
+}
+
+// new bounds from the lanes' exact state
+template <bool F>
+__device__ __forceinline__ void col_refresh_bounds(ColFast<F> &c, const LaneAcc &a) {
+  if (F) {
+    double lo = c.dmn, hi = c.dmx;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo = __builtin_fmin(lo, __shfl_xor(lo, d, 64));
+      hi = __builtin_fmax(hi, __shfl_xor(hi, d, 64));
+    }
+    // a zero bound moves one denormal inward: -0 / +0 then always take the exact path (totalOrder tells them apart)
+    if (lo == 0.0) lo = __longlong_as_double(1LL);
+    if (hi == 0.0) hi = __longlong_as_double((long long)0x8000000000000001ULL);
+    const long long lb = __double_as_longlong(lo), hb = __double_as_longlong(hi);
+    c.lo = ((int64_t)__builtin_amdgcn_readfirstlane((int)(lb >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)lb);
+    c.hi = ((int64_t)__builtin_amdgcn_readfirstlane((int)(hb >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+  } else {
+    int64_t lo = a.mn, hi = a.mx;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int64_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
+      lo = ol < lo ? ol : lo;
+      hi = oh > hi ? oh : hi;
+    }
+    c.lo = ((int64_t)__builtin_amdgcn_readfirstlane((int)(lo >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    c.hi = ((int64_t)__builtin_amdgcn_readfirstlane((int)(hi >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+  }
+}
+
 template <bool XF, bool YF, bool KLL>
-__device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, LaneAcc &ay, ComoTile &m, i64x2 vx,
-                                          i64x2 vy, uint32_t bx, uint32_t by, KllLane &Kx, KllLane &Ky, double *rx,
-                                          double *ry) {
-  acc_pair<XF, false>(ax, vx, bx, 0.0);
-  acc_pair<YF, false>(ay, vy, by, 0.0);
+__device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, LaneAcc &ay, ColFast<XF> &fx,
+                                          ColFast<YF> &fy, unsigned long long &out_x, unsigned long long &out_y,
+                                          ComoTile &m, i64x2 vx, i64x2 vy, uint32_t bx, uint32_t by, KllLane &Kx,
+                                          KllLane &Ky, double *rx, double *ry) {
+  out_x |= col_fast_value<XF>(fx, ax, vx.x, (bx & 1u) != 0);
+  out_x |= col_fast_value<XF>(fx, ax, vx.y, (bx & 2u) != 0);
+  out_y |= col_fast_value<YF>(fy, ay, vy.x, (by & 1u) != 0);
+  out_y |= col_fast_value<YF>(fy, ay, vy.y, (by & 2u) != 0);
   const double x0 = kll_value<XF>(vx.x), x1 = kll_value<XF>(vx.y);
   const double y0 = kll_value<YF>(vy.x), y1 = kll_value<YF>(vy.y);
   como_tile_add(m, x0, y0, (bx & by & 1u) != 0);
   como_tile_add(m, x1, y1, (bx & by & 2u) != 0);
   if (KLL) {
     if (P.x.kll.picks) {  // uniform
-      kll_push(Kx, rx, x0, (bx & 1u) != 0 && x0 == x0);
-      kll_push(Kx, rx, x1, (bx & 2u) != 0 && x1 == x1);
+      kll_push<false>(Kx, rx, x0, (bx & 1u) != 0 && x0 == x0);
+      kll_push<false>(Kx, rx, x1, (bx & 2u) != 0 && x1 == x1);
     }
     if (P.y.kll.picks) {
-      kll_push(Ky, ry, y0, (by & 1u) != 0 && y0 == y0);
-      kll_push(Ky, ry, y1, (by & 2u) != 0 && y1 == y1);
+      kll_push<false>(Ky, ry, y0, (by & 1u) != 0 && y0 == y0);
+      kll_push<false>(Ky, ry, y1, (by & 2u) != 0 && y1 == y1);
     }
   }
+}
+
+template <bool F>
+__device__ __forceinline__ void col_exact_tile(ColFast<F> &c, LaneAcc &a, i64x2 v0, i64x2 v1, i64x2 v2, i64x2 v3,
+                                               uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+  col_exact_value<F>(c, a, v0.x, (b0 & 1u) != 0);
+  col_exact_value<F>(c, a, v0.y, (b0 & 2u) != 0);
+  col_exact_value<F>(c, a, v1.x, (b1 & 1u) != 0);
+  col_exact_value<F>(c, a, v1.y, (b1 & 2u) != 0);
+  col_exact_value<F>(c, a, v2.x, (b2 & 1u) != 0);
+  col_exact_value<F>(c, a, v2.y, (b2 & 2u) != 0);
+  col_exact_value<F>(c, a, v3.x, (b3 & 1u) != 0);
+  col_exact_value<F>(c, a, v3.y, (b3 & 2u) != 0);
+  col_refresh_bounds<F>(c, a);
 }
 
 // one row per lane: ragged edges and pairs whose buffers do not allow tiles
@@ -704,6 +820,10 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
   const uint32_t wave_slot = (uint32_t)wave_global;
   const ScanColDesc &cx = P.x, &cy = P.y;
   int64_t cnt_x = 0, cnt_y = 0, n_both = 0;
+  ColFast<XF> fx;
+  ColFast<YF> fy;
+  col_fast_init<XF>(fx);
+  col_fast_init<YF>(fy);
   if (cx.n_tiles > 0) {
     global_i64x2_ptr px = (global_i64x2_ptr)(uintptr_t)((const int64_t *)cx.values + cx.offset + cx.head);
     global_i64x2_ptr py = (global_i64x2_ptr)(uintptr_t)((const int64_t *)cy.values + cy.offset + cy.head);
@@ -740,15 +860,26 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
       ComoTile q;
 #pragma unroll
       for (int k = 0; k < 5; k++) q.t[k] = 0.0;
-      pair_rows<XF, YF, KLL>(P, ax, ay, q, x0, y0, (uint32_t)((upper ? a[1] : a[0]) >> sh) & 3u,
-                             (uint32_t)((upper ? b[1] : b[0]) >> sh) & 3u, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, q, x1, y1, (uint32_t)((upper ? a[3] : a[2]) >> sh) & 3u,
-                             (uint32_t)((upper ? b[3] : b[2]) >> sh) & 3u, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, q, x2, y2, (uint32_t)((upper ? a[5] : a[4]) >> sh) & 3u,
-                             (uint32_t)((upper ? b[5] : b[4]) >> sh) & 3u, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, q, x3, y3, (uint32_t)((upper ? a[7] : a[6]) >> sh) & 3u,
-                             (uint32_t)((upper ? b[7] : b[6]) >> sh) & 3u, Kx, Ky, rx, ry);
+      const uint32_t bx0 = (uint32_t)((upper ? a[1] : a[0]) >> sh) & 3u, bx1 = (uint32_t)((upper ? a[3] : a[2]) >> sh) & 3u;
+      const uint32_t bx2 = (uint32_t)((upper ? a[5] : a[4]) >> sh) & 3u, bx3 = (uint32_t)((upper ? a[7] : a[6]) >> sh) & 3u;
+      const uint32_t by0 = (uint32_t)((upper ? b[1] : b[0]) >> sh) & 3u, by1 = (uint32_t)((upper ? b[3] : b[2]) >> sh) & 3u;
+      const uint32_t by2 = (uint32_t)((upper ? b[5] : b[4]) >> sh) & 3u, by3 = (uint32_t)((upper ? b[7] : b[6]) >> sh) & 3u;
+      unsigned long long out_x = 0, out_y = 0;  // lanes holding a value outside the wave's bounds (uniform)
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x0, y0, bx0, by0, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x1, y1, bx1, by1, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x2, y2, bx2, by2, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x3, y3, bx3, by3, Kx, Ky, rx, ry);
+      if (out_x) col_exact_tile<XF>(fx, ax, x0, x1, x2, x3, bx0, bx1, bx2, bx3);
+      if (out_y) col_exact_tile<YF>(fy, ay, y0, y1, y2, y3, by0, by1, by2, by3);
       como_tile_flush(m, q);
+      if (XF) {
+        two_sum_add(ax.s, ax.c, fx.tsum);
+        fx.tsum = 0.0;
+      }
+      if (YF) {
+        two_sum_add(ay.s, ay.c, fy.tsum);
+        fy.tsum = 0.0;
+      }
       if (KLL) {
         if (P.x.kll.picks) kll_drain(Kx, rx, P.x.kll, wave_slot, lane);
         if (P.y.kll.picks) kll_drain(Ky, ry, P.y.kll, wave_slot, lane);
@@ -765,6 +896,11 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
                              rx, ry, wave_slot);
   }
   if (KLL) {
+    // the samplers' MIN / MAX: what the exact tiles saw, and what the ragged rows added to K.mn / K.mx themselves
+    Kx.mn = __builtin_fmin(Kx.mn, fx.dmn);
+    Kx.mx = __builtin_fmax(Kx.mx, fx.dmx);
+    Ky.mn = __builtin_fmin(Ky.mn, fy.dmn);
+    Ky.mx = __builtin_fmax(Ky.mx, fy.dmx);
     if (P.x.kll.picks) kll_finish_wave(Kx, rx, P.x.kll, wave_slot, lane);
     if (P.y.kll.picks) kll_finish_wave(Ky, ry, P.y.kll, wave_slot, lane);
   }

@@ -278,3 +278,62 @@ def test_sampler_and_comoments_riding_on_the_scan_match_the_oracle(layout):
         kept = vals[:m][mask[:m]]
         assert r2[si].kll_n == res[si].kll_n + int((~np.isnan(kept)).sum())
         assert total_weight(st, si) == r2[si].kll_n
+
+
+@pytest.mark.parametrize("case", ["zeros", "nan_payloads", "constant", "int_ties"])
+def test_pair_scan_min_max_are_exact_in_total_order(case):
+    """The pair kernel tests a value against the wave's running bounds and only runs the exact (IEEE totalOrder)
+    MIN / MAX update for tiles that hold a value outside them: -0 / +0, NaNs of either sign and payload, ties with the
+    current extreme and constant columns must come out bit for bit as the oracle's total_cmp says."""
+    import struct
+    import torch
+
+    rng = np.random.default_rng({"zeros": 1, "nan_payloads": 2, "constant": 3, "int_ties": 4}[case])
+    n = 1_500_000 + 13
+    if case == "zeros":
+        x = np.abs(rng.standard_normal(n)) + 1.0
+        x[rng.integers(0, n, 50)] = 0.0          # +0 is the minimum ...
+        x[700_001] = -0.0                        # ... until one -0 (equal to it for <, below it in totalOrder)
+        y = -np.abs(rng.standard_normal(n)) - 1.0
+        y[rng.integers(0, n, 50)] = -0.0         # -0 is the maximum until one +0
+        y[900_003] = 0.0
+    elif case == "nan_payloads":
+        x = rng.standard_normal(n)
+        bits = x.view(np.int64)
+        bits[5] = 0x7FF8000000000001             # +NaN, small payload
+        bits[1_000_000] = 0x7FFF00000000BEEF     # +NaN, bigger payload: the totalOrder maximum
+        bits[77] = struct.unpack("<q", struct.pack("<Q", 0xFFF8000000000003))[0]  # -NaN: the totalOrder minimum
+        y = rng.standard_normal(n) * 3
+    elif case == "constant":
+        x = np.full(n, 42.5)
+        y = np.full(n, -7.0)
+    else:
+        x = rng.integers(-500, 500, size=n).astype(np.float64)
+        y = rng.integers(0, 3, size=n).astype(np.float64)
+    iv = rng.integers(-500, 500, size=n, dtype=np.int64) if case == "int_ties" else rng.integers(-10**12, 10**12, size=n, dtype=np.int64)
+    mask = rng.random(n) >= 0.1
+    validity = torch.from_numpy(np.concatenate([orc.pack_validity(mask), np.zeros(64, np.uint8)])).cuda()
+    cols = [T.Column.float64(torch.from_numpy(x).cuda(), validity, length=n),
+            T.Column.float64(torch.from_numpy(y).cuda(), None, length=n),
+            T.Column.int64(torch.from_numpy(iv).cuda(), validity, length=n)]
+    # the pair: the two Float64 columns; for "int_ties" the Int64 column with the first one
+    pair = spec(T.COMOMENTS, 2, column2=0) if case == "int_ties" else spec(T.COMOMENTS, 0, column2=1)
+    specs = [spec(T.NUMERIC_STATS, 0), spec(T.NUMERIC_STATS, 1), spec(T.NUMERIC_STATS, 2), pair]
+    T.init()
+    plan = T.Plan(specs)
+    st = T.State(plan)
+    st.profile_enable(True)
+    st.update(cols)
+    res = st.finalize()
+    assert st.profile_get("comoments")["launches"] == 0  # the pair rode on the scan
+    v = orc.pack_validity(mask)
+    for r, (vals, vb) in zip(res[:3], ((x, v), (y, None), (iv, v))):
+        o = orc.stats(vals, vb)
+        assert r.non_null == o.non_null
+        if vals.dtype == np.float64:
+            got = (struct.pack("<d", r.min_f), struct.pack("<d", r.max_f))
+            assert got == (struct.pack("<d", o.min_f), struct.pack("<d", o.max_f)), case
+            if not np.isnan(o.sum_hi):
+                assert abs(r.sum_f - o.sum_hi) <= 1e-9 * max(1.0, abs(o.sum_hi))
+        else:
+            assert (r.min_i, r.max_i, r.sum_i) == (o.min_i, o.max_i, o.sum_i_wrapping)
