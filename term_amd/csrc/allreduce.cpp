@@ -342,6 +342,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   hipStream_t s = st->device_ready ? st->stream : nullptr;
 
   // ---- 1. facts --------------------------------------------------------------------------------------------
+  TGX_TRY(distinct_resolve_all(st, err));  // keys outside a sampled bitmap range are brought in first
   std::vector<ScanAcc> scan(plan->scan.size());
   if (st->device_ready) {
     if (!scan.empty())

@@ -62,6 +62,10 @@ void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
+int partition_grid(int64_t length, int n_cu);  // workgroups of launch_partition (= ScanPartials it writes with stats)
+void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream);
+void launch_distinct_outliers(const DistinctColDesc &d, int64_t base, uint64_t range, const HashSetView &t,
+                              unsigned long long *d_counters, hipStream_t stream);
 void launch_partition(const PartitionParams &p, unsigned long long *d_counters, int n_cu, hipStream_t stream);
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters, hipStream_t stream);
 void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slices, uint32_t n_slices,
@@ -253,6 +257,15 @@ struct DistinctState {
   DevBuf export_records, export_counts;
   // Dictionary<Int32, Utf8> batches: per-entry reference counts (saturating at 2)
   DevBuf dict_usage, dict_scratch;  // seen | twice bitmaps over the entries; per-workgroup slices
+  // The bitmap's range comes from a SAMPLE of the first batch (no scan of the column has to finish first, and the
+  // DISTINCT pass takes the column's range aggregates along): keys that fall outside it after all are counted by the
+  // kernels (kCntOutOfRange) and repaired at the next point the host looks at the state (distinct_resolve) from the
+  // batches retained here -- DEVICE views, which the caller keeps alive until tgx_finalize / tgx_state_sync
+  // (include/tgx.h); HOST batches are resolved before tgx_update returns.
+  bool speculative = false;
+  std::vector<tgx_column> retained;
+  DevBuf sample;         // DistinctSample
+  DevBuf stat_partials;  // ScanPartial per workgroup of the partition pass (PartitionParams::stats)
   // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
   // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
   DevBuf spare_seen, spare_twice;
@@ -297,8 +310,6 @@ struct tgx_state {
     int is_float;
   };
   std::vector<Widen> pending_widen;  // TGX_INT32 / TGX_FLOAT32 windows of the current update (stage_column)
-  std::vector<tgx::ScanAcc> scan_snapshot;  // host copy of d_scan_acc, valid inside one tgx_update (distinct_update)
-  bool scan_snapshot_valid = false;
   tgx::DevBuf d_distinct_counters;  // [distinct task][kNumDistinctCounters]: every DistinctState::counters is a slice
   // per-update scratch
   tgx::DevBuf d_scan_partials, d_count_blocks, d_como_partials;
@@ -347,6 +358,9 @@ tgx_status distinct_export_impl(tgx_state *st, size_t slot, uint32_t world, cons
 // unites `n` device records into the task's set (switching it to hash mode)
 tgx_status distinct_import_records(tgx_state *st, size_t slot, const void *d_recs, uint64_t n, bool wide,
                                    tgx_error *err);
+// brings in the keys that fell outside a sampled bitmap range (see DistinctState::speculative); a no-op otherwise
+tgx_status distinct_resolve(tgx_state *st, size_t slot, tgx_error *err);
+tgx_status distinct_resolve_all(tgx_state *st, tgx_error *err);
 int num_cus();
 int device_id();
 }  // namespace tgx

@@ -404,11 +404,30 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
 // key - base of one tile: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31).  Keys outside the declared
 // range (only possible with a caller-supplied range hint) are never inserted but counted, so that tgx_finalize
 // reports them instead of returning a wrong count.
-template <int KPT>
+// the column's own aggregates, taken while the 64-bit keys are still in registers (PartitionParams::stats)
+struct KeyStats {
+  int64_t mn, mx;
+  uint64_t lo;
+  int64_t hi;
+};
+
+template <int KPT, bool STATS>
 __device__ __forceinline__ void partition_relative(const PartitionParams &p, const int64_t (&key)[KPT],
-                                                   uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out) {
+                                                   uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out,
+                                                   KeyStats &ks) {
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
+    if (STATS) {
+      const bool valid = (ok >> j) & 1;
+      const int64_t k = key[j];
+      ks.mn = (valid && k < ks.mn) ? k : ks.mn;
+      ks.mx = (valid && k > ks.mx) ? k : ks.mx;
+      const int64_t v = valid ? k : 0;
+      unsigned __int128 sum = ((unsigned __int128)ks.hi << 64) | (unsigned __int128)ks.lo;
+      sum += (unsigned __int128)(__int128)v;
+      ks.lo = (uint64_t)sum;
+      ks.hi = (int64_t)(uint64_t)(sum >> 64);
+    }
     const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
     if (((ok >> j) & 1) && (r >> p.sub_bits) >= p.n_buckets) {
       ok &= ~(1ull << j);
@@ -421,7 +440,7 @@ __device__ __forceinline__ void partition_relative(const PartitionParams &p, con
 }
 
 // 1024 threads x 32 keys, one workgroup per CU (152 KiB of LDS); any alignment, ragged last tile.
-template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16>
+template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
     PartitionParams p, unsigned long long *counters) {
   constexpr int kTile = THREADS * KPT;
@@ -434,6 +453,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
   uint32_t rel[KPT];
+  KeyStats ks;
+  ks.mn = INT64_MAX;
+  ks.mx = INT64_MIN;
+  ks.lo = 0;
+  ks.hi = 0;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint64_t ok;
     {
@@ -441,12 +465,125 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
       uint32_t ok32 = 0;
       partition_load_tile<THREADS, KPT, VALIDITY>(p, tile, wide, key, ok32);
       ok = ok32;
-      partition_relative<KPT>(p, key, rel, ok, n_out);
+      n_valid += __builtin_popcountll(ok);  // every non-NULL row, whether its key lies inside the range or not
+      partition_relative<KPT, STATS>(p, key, rel, ok, n_out, ks);
     }
-    n_valid += __builtin_popcountll(ok);
     partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16>(p, sorted, hist, toff, gbase, wave_sums, rel, ok, [] {}, [] {});
   }
+  if (STATS) {
+    // one ScanPartial per workgroup: wave shuffle, then LDS (the tile buffers are free now)
+    unsigned long long cnt = n_valid;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int64_t omn = __shfl_down(ks.mn, d, 64), omx = __shfl_down(ks.mx, d, 64);
+      const uint64_t olo = (uint64_t)__shfl_down((long long)ks.lo, d, 64);
+      const int64_t ohi = __shfl_down(ks.hi, d, 64);
+      ks.mn = omn < ks.mn ? omn : ks.mn;
+      ks.mx = omx > ks.mx ? omx : ks.mx;
+      const uint64_t lo = ks.lo + olo;
+      ks.hi += ohi + (lo < ks.lo ? 1 : 0);
+      ks.lo = lo;
+      cnt += __shfl_down(cnt, d, 64);
+    }
+    __syncthreads();
+    long long *red = (long long *)sorted;  // [wave][5]
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      red[wave * 5 + 0] = ks.mn;
+      red[wave * 5 + 1] = ks.mx;
+      red[wave * 5 + 2] = (long long)ks.lo;
+      red[wave * 5 + 3] = ks.hi;
+      red[wave * 5 + 4] = (long long)cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ScanPartial out;
+      out.min_k = INT64_MAX;
+      out.max_k = INT64_MIN;
+      out.sum_lo = 0;
+      out.sum_hi = 0;
+      out.non_null = 0;
+      out.sum = out.comp = out.s1 = out.s2 = 0.0;
+      for (uint32_t w = 0; w < THREADS / 64; w++) {
+        out.min_k = red[w * 5 + 0] < out.min_k ? red[w * 5 + 0] : out.min_k;
+        out.max_k = red[w * 5 + 1] > out.max_k ? red[w * 5 + 1] : out.max_k;
+        const uint64_t lo = out.sum_lo + (uint64_t)red[w * 5 + 2];
+        out.sum_hi += red[w * 5 + 3] + (lo < out.sum_lo ? 1 : 0);
+        out.sum_lo = lo;
+        out.non_null += red[w * 5 + 4];
+      }
+      p.stats[blockIdx.x] = out;
+    }
+    __syncthreads();
+  }
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
+}
+
+// A strided sample of the column (at most 2^16 rows, evenly spread): where its keys lie, before anything has read
+// it.  The DISTINCT pass lays its range bitmap out from this estimate (with slack) and takes the column's range
+// aggregates along; keys that fall outside after all are counted and repaired later (tgx_api.cpp, distinct_resolve).
+__global__ __launch_bounds__(256) void distinct_sample_kernel(DistinctColDesc d, DistinctSample *out) {
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  const int64_t want = d.length < 65536 ? d.length : 65536;
+  const int64_t step = d.length / want;
+  int64_t mn = INT64_MAX, mx = INT64_MIN;
+  unsigned long long cnt = 0;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < want; k += (int64_t)gridDim.x * 256) {
+    const int64_t i = k * step + ((k * 40503) & 15 ? 0 : (step > 1 ? step / 2 : 0));  // (not a pure stride)
+    bool valid = true;
+    if (vbits) {
+      const int64_t b = d.offset + i;
+      valid = (vbits[b >> 3] >> (b & 7)) & 1;
+    }
+    if (!valid) continue;
+    const int64_t v = vals[i];
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+    cnt++;
+  }
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    const int64_t omn = __shfl_down(mn, dlt, 64), omx = __shfl_down(mx, dlt, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+    cnt += __shfl_down(cnt, dlt, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicMin((long long *)&out->min_v, (long long)mn);
+    atomicMax((long long *)&out->max_v, (long long)mx);
+    atomicAdd(&out->count, cnt);
+  }
+}
+
+// The repair of a speculated range: the batch's keys OUTSIDE [base, base + range) -- never inserted into the bitmap
+// -- go into the hash set (the bitmap's keys have been moved there first).  Row counters are not touched.
+__global__ __launch_bounds__(256) void distinct_outlier_kernel(DistinctColDesc d, int64_t base, uint64_t range,
+                                                                HashSetView t, unsigned long long *counters) {
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  unsigned long long n_new = 0, n_dup = 0, n_empty = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
+    bool valid = true;
+    if (vbits) {
+      int64_t b = d.offset + i;
+      valid = (vbits[b >> 3] >> (b & 7)) & 1;
+    }
+    if (!valid) continue;
+    const uint64_t key = (uint64_t)vals[i];
+    if (key - (uint64_t)base < range) continue;  // the bitmap had it
+    if (key == kEmptyKey) {
+      n_empty++;
+      continue;
+    }
+    int became_dup = 0;
+    n_new += hash_insert(t, key, d.want_multiplicity, 0, &became_dup);
+    n_dup += became_dup;
+  }
+  block_add2(n_new, n_dup, &counters[0], &counters[1]);
+  __syncthreads();
+  block_add2(n_empty, 0ull, &counters[2], &counters[kCntSpare]);
 }
 
 // Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of
@@ -754,13 +891,19 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   // (software-pipelined variants -- next tile requested before this tile's stores -- were measured three times:
   //  with spills 3.3 ms, as 512 threads x 64 keys with 256 registers 6.0 ms, and spill-free 2.9 ms against
   //  2.7 ms without: the load and store phases already run at HBM rate and the other CUs fill the gaps)
-#define TGX_PART(VAL, K16)                                                                                          \
-  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16>), \
+#define TGX_PART(VAL, K16, ST)                                                                                      \
+  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16, ST>), \
                      dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters)
-  if (p.key16) {
-    if (p.validity) TGX_PART(true, true); else TGX_PART(false, true);
+  if (p.stats) {
+    if (p.key16) {
+      if (p.validity) TGX_PART(true, true, true); else TGX_PART(false, true, true);
+    } else {
+      if (p.validity) TGX_PART(true, false, true); else TGX_PART(false, false, true);
+    }
+  } else if (p.key16) {
+    if (p.validity) TGX_PART(true, true, false); else TGX_PART(false, true, false);
   } else {
-    if (p.validity) TGX_PART(true, false); else TGX_PART(false, false);
+    if (p.validity) TGX_PART(true, false, false); else TGX_PART(false, false, false);
   }
 #undef TGX_PART
 }
@@ -868,6 +1011,22 @@ void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slic
                          unsigned long long *d_counters, hipStream_t stream) {
   hipLaunchKernelGGL(bitmap_adopt_kernel, dim3(grid_for(slice_words)), dim3(256), 0, stream, seen_slices,
                      twice_slices, n_slices, slice_words, stride_words, out_seen, out_twice, d_counters);
+}
+
+int partition_grid(int64_t length, int n_cu) {
+  int64_t n_tiles = (length + kPartitionTile - 1) / kPartitionTile;
+  int grid = (int)(n_tiles < (int64_t)n_cu ? n_tiles : (int64_t)n_cu);
+  return grid < 1 ? 1 : grid;
+}
+
+void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream) {
+  hipLaunchKernelGGL(distinct_sample_kernel, dim3(64), dim3(256), 0, stream, d, out);
+}
+
+void launch_distinct_outliers(const DistinctColDesc &d, int64_t base, uint64_t range, const HashSetView &t,
+                              unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(distinct_outlier_kernel, dim3(grid_for((uint64_t)d.length)), dim3(256), 0, stream, d, base, range,
+                     t, d_counters);
 }
 
 }  // namespace tgx

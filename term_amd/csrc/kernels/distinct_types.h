@@ -54,6 +54,17 @@ struct PartitionParams {
   uint32_t *twice;     // or nullptr
   int32_t want_multiplicity;
   int32_t key16;       // 1: sub_bits <= 16 and list entries are 2 bytes (never with multiplicity)
+  // not nullptr: the pass also produces the column's COUNT / MIN / MAX / SUM (one ScanPartial per workgroup, folded
+  // by scan_reduce_kernel) -- the numeric scan then skips the column: a unique-key column crosses HBM once for its
+  // range checks and its uniqueness check together
+  struct ScanPartial *stats;
+};
+
+// a strided sample of an Int64 column: the value range a DISTINCT pass can expect BEFORE the column has been scanned
+struct DistinctSample {
+  int64_t min_v, max_v;
+  unsigned long long count;  // valid values sampled
+  unsigned long long pad;
 };
 
 // 16-byte record used by merge / serialize / the cross-rank key exchange.

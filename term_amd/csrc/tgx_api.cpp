@@ -440,7 +440,10 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
 
 extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
   if (!st) return fail(err, TGX_INVALID_ARGUMENT, "state is NULL");
-  if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
+  if (st->device_ready) {
+    TGX_TRY(distinct_resolve_all(st, err));  // the caller may release its DEVICE batches after this call
+    HIP_TRY(hipStreamSynchronize(st->stream));
+  }
   return TGX_OK;
 } catch (...) {
   return tgx::abi_exception(err);
@@ -465,6 +468,8 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
     d.range = 0;
     d.wide = false;
     d.has_hint = false;
+    d.speculative = false;
+    d.retained.clear();
     d.bitmap_words = 0;
     d.capacity = 0;  // buffers stay allocated; hash_ensure / the bitmap path clear them before use
     d.rows_upper_bound = 0;
@@ -909,8 +914,23 @@ static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_co
   return TGX_OK;
 }
 
+namespace {
+struct NumericPrep {
+  bool prepared = false;
+  bool partitioned = false;  // the batch goes through partition_kernel / bucket_apply_kernel
+  uint32_t sub_bits = 0;
+  bool key16 = false;
+  uint64_t n_buckets = 0;
+};
+}  // namespace
+static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column &c, NumericPrep *prep,
+                                           tgx_error *err);
+static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c, const NumericPrep &prep,
+                                       int stats_slot, tgx_error *err);
+
 static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err,
-                                  const std::vector<DictGather> *gathers = nullptr) {
+                                  const std::vector<DictGather> *gathers = nullptr, const NumericPrep *ready = nullptr,
+                                  int stats_slot = -1) {
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
@@ -981,58 +1001,98 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
   ds.col_type = c.type;
   ds.total_rows += c.length;
   if (c.length == 0) return TGX_OK;
-  DistinctColDesc d;
-  d.values = c.values;
-  d.validity = c.validity;
-  d.offset = c.offset;
-  d.length = c.length;
-  d.want_multiplicity = mult ? 1 : 0;
-  d.pad = 0;
-  const uint64_t bytes = (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
+  NumericPrep prep;
+  if (ready && ready->prepared)
+    prep = *ready;  // decided before the scan of this batch was queued (tgx_update)
+  else
+    TGX_TRY(distinct_prepare_numeric(st, slot, c, &prep, err));
+  return distinct_run_numeric(st, slot, c, prep, stats_slot, err);
+}
 
-  // Int64: the scan of this batch has already folded the column's MIN/MAX into the running state
-  bool have_range = false;
-  int64_t lo = 0, hi = 0;
-  if (c.type == TGX_INT64 && ds.has_hint) {
-    have_range = true;  // the caller vouches for [lo, hi]; keys outside it are counted and reported
-    lo = ds.hint_lo;
-    hi = ds.hint_hi;
-  } else if (c.type == TGX_INT64 && ds.mode == DistinctMode::kUndecided && c.length < (1 << 16)) {
-    // a stream of small batches (DataFusion hands out 8192 rows at a time): reading the column's MIN/MAX back
-    // costs a stream synchronisation per batch (65 us vs 10 us per update); such a state goes straight to the
-    // hash set, whose inserts need no range and no synchronisation
-    ds.mode = DistinctMode::kHash;
-  } else if (c.type == TGX_INT64 && (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap)) {
-    ScanAcc acc;
-    if (st->scan_snapshot_valid) {
-      acc = st->scan_snapshot[task.scan_slot];  // read back once for all DISTINCT columns of this update
-    } else {
-      HIP_TRY(hipMemcpyAsync(&acc, st->d_scan_acc.as<ScanAcc>() + task.scan_slot, sizeof(ScanAcc),
-                             hipMemcpyDeviceToHost, st->stream));
-      HIP_TRY(hipStreamSynchronize(st->stream));
+// How the keys of one batch of an Int64 / Float64 column enter the set.
+//   * a set that is a range bitmap takes every batch as it is: keys outside its range are counted, never inserted,
+//     and repaired when the host next looks at the state (distinct_resolve) -- no batch waits for its own MIN / MAX;
+//   * an undecided Int64 set first SAMPLES the batch (<= 2^16 values, evenly spread; the whole batch when it is
+//     smaller): dense value range -> bitmap over the sampled range plus slack, else hash set.  A declared range
+//     (tgx_distinct_range_hint) replaces the sample, and then keys outside it are an error, not repaired.
+static void bitmap_shape(const DistinctState &ds, int64_t length, bool mult, uint32_t *sub_bits_out, bool *key16_out,
+                         uint64_t *n_buckets_out, bool *partitioned_out) {
+  // slices of 2^sub_bits keys: as many buckets as fit the phase-1 histogram (<= 2048 targeted) so every CU has lists
+  // to replay (<= 1024 targeted: longer runs per tile); one slice (two with multiplicity) must fit 128 KiB of LDS
+  uint32_t sub_bits = 14;
+  while (sub_bits < (mult ? 19u : 20u) && ((ds.range + (1ull << sub_bits) - 1) >> sub_bits) > 1024) sub_bits++;
+  // ranges up to 2048 x 2^16 values (134 M): buckets of <= 2^16 keys make a list entry 2 bytes instead of 4 --
+  // half the list traffic for more, shorter runs (not with multiplicity: run padding repeats keys)
+  bool key16 = false;
+  if (!mult && sub_bits > 16) {
+    uint32_t s16 = 14;
+    while (s16 < 16 && ((ds.range + (1ull << s16) - 1) >> s16) > kMaxPartitions) s16++;
+    if (((ds.range + (1ull << s16) - 1) >> s16) <= kMaxPartitions) {
+      key16 = true;
+      sub_bits = s16;
     }
-    if (acc.non_null > 0) {
-      have_range = true;
-      lo = acc.min_k;
-      hi = acc.max_k;
-    }
+  } else if (!mult) {
+    key16 = true;  // sub_bits <= 16 already
   }
+  const uint64_t n_buckets = (ds.range + (1ull << sub_bits) - 1) >> sub_bits;
+  uint64_t cap_slots = (uint64_t)length / std::max<uint64_t>(n_buckets, 1);
+  cap_slots = cap_slots + cap_slots / 4 + 16 * (((uint64_t)length >> 15) + 1) + 4096;
+  *sub_bits_out = sub_bits;
+  *key16_out = key16;
+  *n_buckets_out = n_buckets;
+  *partitioned_out = length >= (1 << 20) && n_buckets <= kMaxPartitions && (uint64_t)length * 64 >= ds.range &&
+                     cap_slots < (1ull << 32) - 64;
+}
+
+static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column &c, NumericPrep *prep,
+                                           tgx_error *err) {
+  const DistinctTask &task = st->plan->distinct[slot];
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = task.multiplicity;
+  prep->prepared = true;
+  prep->partitioned = false;
   if (ds.mode == DistinctMode::kUndecided) {
+    bool have_range = false;
+    int64_t lo = 0, hi = 0;
+    if (c.type == TGX_INT64 && ds.has_hint) {
+      have_range = true;  // the caller vouches for [lo, hi]; keys outside it are counted and reported
+      lo = ds.hint_lo;
+      hi = ds.hint_hi;
+    } else if (c.type == TGX_INT64 && c.length >= (1 << 16)) {
+      // (a stream of small batches -- DataFusion hands out 8192 rows at a time -- goes straight to the hash set:
+      // its inserts need no range, and the read-back below would cost one stream synchronisation per batch)
+      DistinctColDesc d;
+      d.values = c.values;
+      d.validity = c.validity;
+      d.offset = c.offset;
+      d.length = c.length;
+      d.want_multiplicity = 0;
+      d.pad = 0;
+      HIP_TRY(ds.sample.reserve(sizeof(DistinctSample)));
+      DistinctSample init{INT64_MAX, INT64_MIN, 0, 0}, got;
+      HIP_TRY(hipMemcpyAsync(ds.sample.p, &init, sizeof(init), hipMemcpyHostToDevice, st->stream));
+      launch_distinct_sample(d, ds.sample.as<DistinctSample>(), st->stream);
+      HIP_TRY(hipMemcpyAsync(&got, ds.sample.p, sizeof(got), hipMemcpyDeviceToHost, st->stream));
+      HIP_TRY(hipStreamSynchronize(st->stream));  // (the stream holds nothing but the sample when a step starts)
+      if (got.count == 0) return TGX_OK;          // nothing valid among the sampled rows: decide on a later batch
+      have_range = true;
+      lo = got.min_v;
+      hi = got.max_v;
+    }
     bool use_bitmap = false;
     if (c.type == TGX_INT64 && have_range) {
       // unsigned width of [lo, hi]; bitmap when it is at most 16 bits per expected row and <= 2^34
       uint64_t width = (uint64_t)hi - (uint64_t)lo;
       uint64_t expect = std::max<uint64_t>((uint64_t)c.length, g_ctx.distinct_hint);
       if (width < (1ull << 34) && width / 16 <= expect) {
-        uint64_t slack = ds.has_hint ? 0 : std::min<uint64_t>(width / 8 + 64, 1ull << 30);
+        // a sampled range is widened by a quarter on either side (the sample's extremes are not the column's)
+        uint64_t slack = ds.has_hint ? 0 : std::min<uint64_t>(width / 4 + 4096, 1ull << 30);
         int64_t base = (lo < INT64_MIN + (int64_t)slack) ? INT64_MIN : lo - (int64_t)slack;
         uint64_t top = (hi > INT64_MAX - (int64_t)slack) ? (uint64_t)INT64_MAX : (uint64_t)(hi + (int64_t)slack);
         ds.base = base;
         ds.range = top - (uint64_t)base + 1;
         use_bitmap = true;
       }
-    } else if (c.type == TGX_INT64 && !have_range) {
-      return TGX_OK;  // batch of NULLs only: nothing to insert, decide later
     }
     if (use_bitmap) {
       // whole 2^20-bit slices, so the partitioned path can move slices through LDS
@@ -1047,56 +1107,56 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
         HIP_TRY(hipMemsetAsync(ds.twice.p, 0, words * 4, st->stream));
       }
       ds.mode = DistinctMode::kBitmap;
+      ds.speculative = !ds.has_hint;
     } else {
       ds.mode = DistinctMode::kHash;
     }
   }
   if (ds.mode == DistinctMode::kBitmap) {
-    bool fits = have_range && lo >= ds.base && (uint64_t)hi - (uint64_t)ds.base < ds.range;
-    if (!fits) TGX_TRY(bitmap_to_hash(st, ds, mult, (uint64_t)c.length, err));
+    bitmap_shape(ds, c.length, mult, &prep->sub_bits, &prep->key16, &prep->n_buckets, &prep->partitioned);
+    if (ds.partitioned) prep->partitioned = false;  // an owned slice after tgx_allreduce: plain inserts only
   }
+  return TGX_OK;
+}
+
+// `stats_slot` >= 0: the partition pass also produces the column's COUNT / MIN / MAX / SUM into that scan slot (the
+// numeric scan has skipped the column)
+static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c, const NumericPrep &prep,
+                                       int stats_slot, tgx_error *err) {
+  const DistinctTask &task = st->plan->distinct[slot];
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = task.multiplicity;
+  DistinctColDesc d;
+  d.values = c.values;
+  d.validity = c.validity;
+  d.offset = c.offset;
+  d.length = c.length;
+  d.want_multiplicity = mult ? 1 : 0;
+  d.pad = 0;
+  const uint64_t bytes = (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
+  if (ds.mode == DistinctMode::kUndecided) return TGX_OK;  // nothing valid seen yet
   if (ds.mode == DistinctMode::kBitmap) {
-    // big batch over a dense range: bucket the keys and replay them against LDS-resident slices
-    // slices of 2^sub_bits keys: as many buckets as fit the phase-1 histogram (<= 2048 targeted) so
-    // every CU has lists to replay (<= 1024 targeted: longer runs per tile); one slice (two with multiplicity) must fit 128 KiB of LDS
-    uint32_t sub_bits = 14;
-    while (sub_bits < (mult ? 19u : 20u) && ((ds.range + (1ull << sub_bits) - 1) >> sub_bits) > 1024) sub_bits++;
-    // ranges up to 2048 x 2^16 values (134 M): buckets of <= 2^16 keys make a list entry 2 bytes instead of 4 --
-    // half the list traffic for more, shorter runs (not with multiplicity: run padding repeats keys)
-    bool key16 = false;
-    if (!mult && sub_bits > 16) {
-      uint32_t s16 = 14;
-      while (s16 < 16 && ((ds.range + (1ull << s16) - 1) >> s16) > kMaxPartitions) s16++;
-      if (((ds.range + (1ull << s16) - 1) >> s16) <= kMaxPartitions) {
-        key16 = true;
-        sub_bits = s16;
-      }
-    } else if (!mult) {
-      key16 = true;  // sub_bits <= 16 already
-    }
-    const uint64_t n_buckets = (ds.range + (1ull << sub_bits) - 1) >> sub_bits;
-    uint64_t cap_slots = (uint64_t)c.length / std::max<uint64_t>(n_buckets, 1);
-    cap_slots = cap_slots + cap_slots / 4 + 16 * (((uint64_t)c.length >> 15) + 1) + 4096;
-    const bool partitioned = c.length >= (1 << 20) && n_buckets <= kMaxPartitions &&
-                             (uint64_t)c.length * 64 >= ds.range && cap_slots < (1ull << 32) - 64;
-    if (partitioned) {
+    if (ds.speculative) ds.retained.push_back(c);  // (a DEVICE view, or a staged one resolved before the update returns)
+    if (prep.partitioned) {
+      // big batch over a dense range: bucket the keys and replay them against LDS-resident slices
       PartitionParams pp;
+      memset(&pp, 0, sizeof(pp));
       pp.values = c.values;
       pp.validity = c.validity;
       pp.offset = c.offset;
       pp.length = c.length;
       pp.base = ds.base;
       pp.range = ds.range;
-      pp.sub_bits = sub_bits;
-      pp.n_buckets = (uint32_t)n_buckets;
+      pp.sub_bits = prep.sub_bits;
+      pp.n_buckets = (uint32_t)prep.n_buckets;
       // runs are padded to 16 slots per (tile, bucket): budget the average load + 25 % + the padding
       const uint64_t tiles = ((uint64_t)c.length + kPartitionTile - 1) / kPartitionTile;
-      uint64_t cap = (uint64_t)c.length / n_buckets;
-      cap = cap + cap / 4 + (key16 ? 32 : 16) * tiles + 4096;
-      pp.cap = key16 ? (cap + 31) & ~31ull : (cap + 15) & ~15ull;
+      uint64_t cap = (uint64_t)c.length / prep.n_buckets;
+      cap = cap + cap / 4 + (prep.key16 ? 32 : 16) * tiles + 4096;
+      pp.cap = prep.key16 ? (cap + 31) & ~31ull : (cap + 15) & ~15ull;
       pp.want_multiplicity = mult ? 1 : 0;
-      pp.key16 = key16 ? 1 : 0;
-      HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * (key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
+      pp.key16 = prep.key16 ? 1 : 0;
+      HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * (prep.key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
       HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
       HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
       HIP_TRY(hipMemsetAsync(ds.cursors.as<unsigned long long>() + pp.n_buckets, 0xFF,
@@ -1105,12 +1165,27 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
       pp.cursors = ds.cursors.as<unsigned long long>();
       pp.seen = ds.seen.as<uint32_t>();
       pp.twice = mult ? ds.twice.as<uint32_t>() : nullptr;
+      const int grid = partition_grid(c.length, g_ctx.n_cu);
+      if (stats_slot >= 0) {
+        HIP_TRY(ds.stat_partials.reserve((size_t)grid * sizeof(ScanPartial)));
+        pp.stats = ds.stat_partials.as<ScanPartial>();
+      }
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
-      ProfScope ps(st, "distinct", bytes);
-      launch_partition(pp, cnt, g_ctx.n_cu, st->stream);
-      // phase 2 recomputes the totals from the slices
-      HIP_TRY(hipMemsetAsync(cnt + kCntDistinct, 0, 2 * sizeof(unsigned long long), st->stream));
-      HIP_TRY(launch_bucket_apply(pp, cnt, st->stream));
+      {
+        ProfScope ps(st, "distinct", bytes);
+        launch_partition(pp, cnt, g_ctx.n_cu, st->stream);
+        // phase 2 recomputes the totals from the slices
+        HIP_TRY(hipMemsetAsync(cnt + kCntDistinct, 0, 2 * sizeof(unsigned long long), st->stream));
+        HIP_TRY(launch_bucket_apply(pp, cnt, st->stream));
+      }
+      if (stats_slot >= 0) {
+        ScanLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.cols[0].length = c.length;
+        L.cols[0].is_float = 0;
+        L.acc_index[0] = stats_slot;
+        launch_scan_reduce_only(L, 1, grid, pp.stats, st->d_scan_acc.as<ScanAcc>(), st->stream);
+      }
     } else {
       ProfScope ps(st, "distinct", bytes);
       launch_distinct_bitmap(d, bitmap_view(ds), ds.counters.as<unsigned long long>(), st->stream);
@@ -1120,6 +1195,49 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     ProfScope ps(st, "distinct", bytes);
     launch_distinct_hash(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
   }
+  return TGX_OK;
+}
+
+// The host is about to look at the key set (counts, export, exchange, merge) or the caller may release the batches:
+// keys that fell outside a sampled range are brought in now.  The bitmap moves into a hash set and the retained
+// batches are walked once more for their outliers only (disjoint from the bitmap's keys, so multiplicities stay right).
+tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  if (!ds.speculative || ds.retained.empty() || !st->device_ready) {
+    ds.retained.clear();
+    return TGX_OK;
+  }
+  const bool mult = st->plan->distinct[slot].multiplicity;
+  unsigned long long c[kNumDistinctCounters];
+  TGX_TRY(distinct_read_counters(st, ds, c, err));
+  const uint64_t n_out = c[kCntOutOfRange];
+  if (n_out == 0 || ds.mode != DistinctMode::kBitmap) {
+    ds.retained.clear();
+    return TGX_OK;
+  }
+  const int64_t old_base = ds.base;
+  const uint64_t old_range = ds.range;
+  TGX_TRY(bitmap_to_hash(st, ds, mult, n_out, err));
+  TGX_TRY(hash_ensure(st, ds, mult, n_out, err));
+  for (const tgx_column &col : ds.retained) {
+    DistinctColDesc d;
+    d.values = col.values;
+    d.validity = col.validity;
+    d.offset = col.offset;
+    d.length = col.length;
+    d.want_multiplicity = mult ? 1 : 0;
+    d.pad = 0;
+    launch_distinct_outliers(d, old_base, old_range, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+  }
+  HIP_TRY(hipMemsetAsync(ds.counters.as<unsigned long long>() + kCntOutOfRange, 0, sizeof(unsigned long long), st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.retained.clear();
+  ds.speculative = false;
+  return TGX_OK;
+}
+
+tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
+  for (size_t k = 0; k < st->distinct.size(); k++) TGX_TRY(distinct_resolve(st, k, err));
   return TGX_OK;
 }
 
@@ -1280,6 +1398,19 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       if (d.n_tiles > 0) return (d.n_tiles + waves - 1) / waves * kTileRows;
       return ((d.length + 63) / 64 + waves - 1) / waves * 64;
     };
+    // ---- exact uniqueness over dense Int64 keys takes the column's range aggregates along (kernels/distinct.hip,
+    // partition_kernel<.., STATS>): such a column is not scanned at all -- it crosses HBM once for MIN / MAX / SUM /
+    // COUNT and COUNT(DISTINCT) together.  Decided here, before the scan is queued, from a sample of the batch.
+    std::vector<NumericPrep> dprep(plan->distinct.size());
+    std::vector<int> stats_by_partition(plan->scan.size(), -1);
+    for (size_t q = 0; q < plan->distinct.size(); q++) {
+      const DistinctTask &t = plan->distinct[q];
+      if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0) continue;
+      TGX_TRY(distinct_prepare_numeric(st, q, dev[t.column], &dprep[q], err));
+      if (dprep[q].partitioned && dev[t.column].type == TGX_INT64 && t.scan_slot >= 0 &&
+          !plan->scan[t.scan_slot].variance && pair_of_col[t.column] < 0 && kll_on_col[t.column] < 0)
+        stats_by_partition[t.scan_slot] = (int)q;
+    }
     // ---- numeric scan: all columns of the batch in launches of <= kMaxColsPerLaunch ----
     {
       std::vector<ScanColDesc> descs, kll_descs;
@@ -1298,6 +1429,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
           continue;
         }
         if (pair_of_col[plan->scan[s].column] >= 0) continue;  // scanned with its partner below
+        if (stats_by_partition[s] >= 0) continue;                // its DISTINCT pass brings the aggregates
         if (kll_on_col[plan->scan[s].column] < 0) {
           // a scan that only feeds DISTINCT's range decision is not needed once the range is declared
           bool bound = false, all_hinted = true, any_distinct = false;
@@ -1540,32 +1672,6 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       if (cap > 0 && !fuse.capacity.count(t.column)) fuse.capacity[t.column] = cap;
     }
     TGX_TRY(regex_update(st, dev.data(), err, &fuse));
-    {
-      // Int64 columns decide bitmap vs hash from the running MIN / MAX of the scan: with several such columns the
-      // accumulators come back in ONE copy and one stream synchronisation instead of one per column
-      int need = 0;
-      for (size_t s = 0; s < plan->distinct.size(); s++) {
-        const DistinctTask &t = plan->distinct[s];
-        if (!t.tuple.empty()) continue;
-        const tgx_column &c = dev[t.column];
-        const DistinctState &ds = st->distinct[s];
-        if (c.type != TGX_INT64 || c.length == 0 || ds.has_hint) continue;
-        if (ds.mode == DistinctMode::kUndecided && c.length < (1 << 16)) continue;
-        if (ds.mode == DistinctMode::kUndecided || ds.mode == DistinctMode::kBitmap) need++;
-      }
-      st->scan_snapshot_valid = false;
-      if (need >= 2 && !plan->scan.empty()) {
-        st->scan_snapshot.resize(plan->scan.size());
-        HIP_TRY(hipMemcpyAsync(st->scan_snapshot.data(), st->d_scan_acc.p, plan->scan.size() * sizeof(ScanAcc),
-                               hipMemcpyDeviceToHost, st->stream));
-        HIP_TRY(hipStreamSynchronize(st->stream));
-        st->scan_snapshot_valid = true;
-      }
-    }
-    struct SnapshotScope {
-      tgx_state *s;
-      ~SnapshotScope() { s->scan_snapshot_valid = false; }
-    } snapshot_scope{st};
     std::map<int, bool> fuse_done;
     for (size_t s = 0; s < plan->distinct.size(); s++)
       if (plan->distinct[s].tuple.empty()) {
@@ -1576,7 +1682,10 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
           g = &it->second;
           fuse_done[col] = true;
         }
-        TGX_TRY(distinct_update(st, s, dev[col], err, g));
+        const int stats_slot = (plan->distinct[s].scan_slot >= 0 && stats_by_partition[plan->distinct[s].scan_slot] == (int)s)
+                                   ? plan->distinct[s].scan_slot
+                                   : -1;
+        TGX_TRY(distinct_update(st, s, dev[col], err, g, &dprep[s], stats_slot));
       } else {
         TGX_TRY(distinct_tuple_update(st, s, dev.data(), err));
       }
@@ -1598,6 +1707,9 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   }
   // HOST buffers copied straight from the caller's memory are borrowed only until tgx_update returns
   if (any_host && st->host_direct) HIP_TRY(hipStreamSynchronize(st->stream));
+  // a sampled-range key set keeps views of its batches for a later repair: staged copies of HOST batches do not
+  // live that long
+  if (any_host) TGX_TRY(distinct_resolve_all(st, err));
   return TGX_OK;
 } catch (...) {
   return tgx::abi_exception(err);
@@ -1640,6 +1752,7 @@ static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t,
 
 static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   const tgx_plan *plan = st->plan;
+  TGX_TRY(distinct_resolve_all(st, err));
   g->scan = st->h_scan;
   g->count = st->h_count;
   g->como = st->h_como;
@@ -1813,6 +1926,7 @@ tgx_status tgx::distinct_export_impl(tgx_state *st, size_t slot, uint32_t world,
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;
   TGX_TRY(state_init_device(st, err));
+  TGX_TRY(distinct_resolve(st, slot, err));
   std::vector<unsigned long long> h_counts(world, 0);
   unsigned long long c[kNumDistinctCounters];
   TGX_TRY(distinct_read_counters(st, ds, c, err));
@@ -1897,6 +2011,7 @@ tgx_status tgx::distinct_import_records(tgx_state *st, size_t slot, const void *
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;
   TGX_TRY(state_init_device(st, err));
+  TGX_TRY(distinct_resolve(st, slot, err));
   if (ds.mode == DistinctMode::kBitmap) TGX_TRY(bitmap_to_hash(st, ds, mult, n, err));
   if (ds.mode == DistinctMode::kHash && ds.capacity > 0 && ds.wide != wide)
     return fail(err, TGX_INVALID_ARGUMENT, "distinct: cannot unite a Utf8 key set with a numeric one");
@@ -1977,6 +2092,7 @@ extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *
                                                tgx_error *err) try {
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
+  TGX_TRY(distinct_resolve(st, slot, err));
   DistinctState &ds = st->distinct[slot];
   if (ds.mode != DistinctMode::kBitmap)
     return fail(err, TGX_UNSUPPORTED, "the key set is not a range bitmap; use tgx_distinct_export / _import");

@@ -524,3 +524,78 @@ def test_several_distinct_columns_share_one_range_readback():
         if ci % 2:
             assert r.groups_once == d.groups_once, ci
         check_stats(res[2 * ci + 1], orc.stats(v, b))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The range bitmap of a dense Int64 key column is laid out from a SAMPLE of the first batch (so that no scan has to
+# finish first and the DISTINCT pass can take the column's MIN / MAX / SUM / COUNT along); keys the sample did not
+# announce are counted by the kernels and brought in when the host next looks at the state.
+def _dense_with_outliers(rng, n, n_out, dup_outliers):
+    vals = rng.permutation(n).astype(np.int64) + 1000
+    # rows the 2^16-row sample does not visit: it reads row k * step, every 16th one half a step later
+    step = n // 65536
+    rows = [r for r in rng.integers(0, n, 4 * n_out + 64).tolist() if r % step not in (0, step // 2)][:n_out]
+    far = np.array([10**15, -10**15, -1, 2**62, -2**62, 10**15 + 1], dtype=np.int64)  # -1: the all-ones pattern
+    for i, r in enumerate(rows):
+        vals[r] = far[i % len(far)] if dup_outliers else far[i % len(far)] + i // len(far) * 7
+    return vals
+
+
+@pytest.mark.parametrize("device", [True, False])
+@pytest.mark.parametrize("mult", [False, True])
+def test_keys_outside_the_sampled_range_are_repaired(device, mult):
+    rng = np.random.default_rng(41 + mult)
+    n = 3_000_000 + 17
+    vals = _dense_with_outliers(rng, n, 40, dup_outliers=mult)
+    mask = rng.random(n) >= 0.02
+    validity = orc.pack_validity(mask)
+    flags = T.FLAG_MULTIPLICITY if mult else 0
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=flags), spec(T.NUMERIC_STATS, 0), spec(T.COUNT, 0)])
+    st = T.State(plan)
+    st.profile_enable(True)
+    st.update([numeric_column(vals, validity, device)])
+    res = st.finalize()
+    d = orc.distinct_bits64(vals.view(np.uint64), validity)
+    o = orc.stats(vals, validity)
+    assert (res[0].total, res[0].non_null, res[0].distinct) == (d.total, d.non_null, d.distinct)
+    if mult:
+        assert res[0].groups_once == d.groups_once
+    # the aggregates came out of the DISTINCT pass (the scan did not read the column) and are exact all the same
+    assert st.profile_get("scan")["launches"] == 0
+    assert (res[1].non_null, res[1].min_i, res[1].max_i, res[1].sum_i) == (o.non_null, o.min_i, o.max_i, o.sum_i_wrapping)
+    assert (res[2].total, res[2].non_null) == (n, o.non_null)
+    # finalize is repeatable, and a later batch (outliers of its own) joins the repaired set
+    again = st.finalize()
+    assert (again[0].distinct, again[0].groups_once) == (res[0].distinct, res[0].groups_once)
+    more = _dense_with_outliers(rng, n, 25, dup_outliers=False) + 500_000
+    st.update([numeric_column(more, None, device)])
+    both = np.concatenate([vals, more])
+    both_valid = orc.pack_validity(np.concatenate([mask, np.ones(n, bool)]))
+    d2 = orc.distinct_bits64(both.view(np.uint64), both_valid)
+    r2 = st.finalize()
+    assert (r2[0].total, r2[0].non_null, r2[0].distinct) == (d2.total, d2.non_null, d2.distinct)
+    if mult:
+        assert r2[0].groups_once == d2.groups_once
+
+
+def test_outliers_in_a_later_batch_and_through_merge_and_serialize():
+    rng = np.random.default_rng(7)
+    n = 2_500_000
+    clean = rng.permutation(n).astype(np.int64)
+    dirty = _dense_with_outliers(rng, n, 30, False)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)])
+    a, b = T.State(plan), T.State(plan)
+    a.update([numeric_column(clean, None, True)])      # the bitmap is laid out from this batch ...
+    a.update([numeric_column(dirty, None, True)])      # ... and this one brings keys far outside it
+    b.update([numeric_column(dirty[::-1].copy(), None, True)])
+    blob = a.serialize()                               # a resolve point: the blob carries the repaired set
+    c = T.State.deserialize(plan, blob)
+    c.merge([b])
+    want = orc.distinct_bits64(np.concatenate([clean, dirty, dirty]).view(np.uint64), None)
+    got = c.finalize()[0]
+    assert (got.total, got.distinct, got.groups_once) == (want.total, want.distinct, want.groups_once)
+    one = orc.distinct_bits64(np.concatenate([clean, dirty]).view(np.uint64), None)
+    ra = a.finalize()[0]
+    assert (ra.distinct, ra.groups_once) == (one.distinct, one.groups_once)

@@ -18,3 +18,4 @@ for r in rows:
 for k, (n, v) in sorted(agg.items()):
     print("%-62s %-12s dispatches %4d  mean %14.1f KiB" % (k[0], k[1], n, v / n))
 PY
+rm -rf gpurun_out/pmc_$tag

@@ -18,3 +18,5 @@ for r in rows:
 for k, (n, v) in sorted(agg.items()):
     print(k[0], k[1], "dispatches", n, "mean", v / n)
 PY
+mkdir -p gpurun_out/pmc_keep_$tag && cp $f gpurun_out/pmc_keep_$tag/counter_collection.csv
+rm -rf gpurun_out/pmc_$tag && mv gpurun_out/pmc_keep_$tag gpurun_out/pmc_$tag

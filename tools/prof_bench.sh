@@ -6,3 +6,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- 
 tail -1 gpurun_out/prof_$tag.log | cut -c1-400
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 head -1 $f; grep "tgx::" $f
+# keep the summary (what profiles/ commits), drop the raw traces: gpurun_out/ travels back only while it stays small
+(head -1 $f; grep "tgx::" $f) > gpurun_out/${tag}_kernel_stats.csv
+rm -rf gpurun_out/prof_$tag
