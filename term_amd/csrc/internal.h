@@ -62,6 +62,7 @@ void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
+void launch_partition_outlier_stats(const OutlierStats *g, ScanPartial *partials, int at, hipStream_t stream);
 int partition_grid(int64_t length, int n_cu);  // workgroups of launch_partition (= ScanPartials it writes with stats)
 void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream);
 void launch_distinct_outliers(const DistinctColDesc &d, int64_t base, uint64_t range, const HashSetView &t,
@@ -265,7 +266,8 @@ struct DistinctState {
   bool speculative = false;
   std::vector<tgx_column> retained;
   DevBuf sample;         // DistinctSample
-  DevBuf stat_partials;  // ScanPartial per workgroup of the partition pass (PartitionParams::stats)
+  DevBuf stat_partials;  // ScanPartial per workgroup of the partition pass (PartitionParams::stats) + one for outliers
+  DevBuf outlier_stats;  // OutlierStats
   // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
   // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
   DevBuf spare_seen, spare_twice;

@@ -404,34 +404,23 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
 // key - base of one tile: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31).  Keys outside the declared
 // range (only possible with a caller-supplied range hint) are never inserted but counted, so that tgx_finalize
 // reports them instead of returning a wrong count.
-// the column's own aggregates, taken while the 64-bit keys are still in registers (PartitionParams::stats)
-struct KeyStats {
-  int64_t mn, mx;
-  uint64_t lo;
-  int64_t hi;
-};
-
 template <int KPT, bool STATS>
 __device__ __forceinline__ void partition_relative(const PartitionParams &p, const int64_t (&key)[KPT],
-                                                   uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out,
-                                                   KeyStats &ks) {
+                                                   uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out) {
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
-    if (STATS) {
-      const bool valid = (ok >> j) & 1;
-      const int64_t k = key[j];
-      ks.mn = (valid && k < ks.mn) ? k : ks.mn;
-      ks.mx = (valid && k > ks.mx) ? k : ks.mx;
-      const int64_t v = valid ? k : 0;
-      unsigned __int128 sum = ((unsigned __int128)ks.hi << 64) | (unsigned __int128)ks.lo;
-      sum += (unsigned __int128)(__int128)v;
-      ks.lo = (uint64_t)sum;
-      ks.hi = (int64_t)(uint64_t)(sum >> 64);
-    }
     const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
     if (((ok >> j) & 1) && (r >> p.sub_bits) >= p.n_buckets) {
       ok &= ~(1ull << j);
       n_out++;
+      if (STATS) {  // (rare: the range was sampled from the column) its share of the column's aggregates
+        const long long k = (long long)key[j];
+        atomicMin(&p.outliers->mn, k);
+        atomicMax(&p.outliers->mx, k);
+        atomicAdd(&p.outliers->lo32_sum, (unsigned long long)((uint64_t)k & 0xFFFFFFFFull));
+        atomicAdd((unsigned long long *)&p.outliers->hi32_sum, (unsigned long long)(k >> 32));
+        atomicAdd(&p.outliers->count, 1ull);
+      }
     }
     rel[j] = (uint32_t)r;  // the 64-bit keys die here
     asm volatile("" : "+v"(rel[j]));  // (keeps the compiler from re-deriving rel from the keys later)
@@ -453,11 +442,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
   uint32_t rel[KPT];
-  KeyStats ks;
-  ks.mn = INT64_MAX;
-  ks.mx = INT64_MIN;
-  ks.lo = 0;
-  ks.hi = 0;
+  // STATS: the column's COUNT / MIN / MAX / SUM over the keys inside the range, taken from the 32-bit offsets (the
+  // 64-bit keys are gone by then: no register is held across the tile for them) -- per tile a wave reduction and
+  // four LDS atomics
+  __shared__ uint32_t st_min, st_max;
+  __shared__ unsigned long long st_sum, st_cnt;
+  if (STATS && threadIdx.x == 0) {
+    st_min = 0xFFFFFFFFu;
+    st_max = 0;
+    st_sum = 0;
+    st_cnt = 0;
+  }
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint64_t ok;
     {
@@ -466,35 +461,37 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
       partition_load_tile<THREADS, KPT, VALIDITY>(p, tile, wide, key, ok32);
       ok = ok32;
       n_valid += __builtin_popcountll(ok);  // every non-NULL row, whether its key lies inside the range or not
-      partition_relative<KPT, STATS>(p, key, rel, ok, n_out, ks);
+      partition_relative<KPT, STATS>(p, key, rel, ok, n_out);
+    }
+    if (STATS) {
+      uint32_t tmin = 0xFFFFFFFFu, tmax = 0;
+      unsigned long long tsum = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const bool in = (ok >> j) & 1;
+        tmin = (in && rel[j] < tmin) ? rel[j] : tmin;
+        tmax = (in && rel[j] > tmax) ? rel[j] : tmax;
+        tsum += in ? rel[j] : 0u;
+      }
+      unsigned long long tcnt = __builtin_popcountll(ok);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t omin = __shfl_down(tmin, d, 64), omax = __shfl_down(tmax, d, 64);
+        tmin = omin < tmin ? omin : tmin;
+        tmax = omax > tmax ? omax : tmax;
+        tsum += __shfl_down(tsum, d, 64);
+        tcnt += __shfl_down(tcnt, d, 64);
+      }
+      if ((threadIdx.x & 63) == 0 && tcnt) {
+        atomicMin(&st_min, tmin);
+        atomicMax(&st_max, tmax);
+        atomicAdd(&st_sum, tsum);
+        atomicAdd(&st_cnt, tcnt);
+      }
     }
     partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16>(p, sorted, hist, toff, gbase, wave_sums, rel, ok, [] {}, [] {});
   }
   if (STATS) {
-    // one ScanPartial per workgroup: wave shuffle, then LDS (the tile buffers are free now)
-    unsigned long long cnt = n_valid;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const int64_t omn = __shfl_down(ks.mn, d, 64), omx = __shfl_down(ks.mx, d, 64);
-      const uint64_t olo = (uint64_t)__shfl_down((long long)ks.lo, d, 64);
-      const int64_t ohi = __shfl_down(ks.hi, d, 64);
-      ks.mn = omn < ks.mn ? omn : ks.mn;
-      ks.mx = omx > ks.mx ? omx : ks.mx;
-      const uint64_t lo = ks.lo + olo;
-      ks.hi += ohi + (lo < ks.lo ? 1 : 0);
-      ks.lo = lo;
-      cnt += __shfl_down(cnt, d, 64);
-    }
-    __syncthreads();
-    long long *red = (long long *)sorted;  // [wave][5]
-    const uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-      red[wave * 5 + 0] = ks.mn;
-      red[wave * 5 + 1] = ks.mx;
-      red[wave * 5 + 2] = (long long)ks.lo;
-      red[wave * 5 + 3] = ks.hi;
-      red[wave * 5 + 4] = (long long)cnt;
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
       ScanPartial out;
@@ -502,21 +499,39 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
       out.max_k = INT64_MIN;
       out.sum_lo = 0;
       out.sum_hi = 0;
-      out.non_null = 0;
+      out.non_null = (int64_t)st_cnt;
       out.sum = out.comp = out.s1 = out.s2 = 0.0;
-      for (uint32_t w = 0; w < THREADS / 64; w++) {
-        out.min_k = red[w * 5 + 0] < out.min_k ? red[w * 5 + 0] : out.min_k;
-        out.max_k = red[w * 5 + 1] > out.max_k ? red[w * 5 + 1] : out.max_k;
-        const uint64_t lo = out.sum_lo + (uint64_t)red[w * 5 + 2];
-        out.sum_hi += red[w * 5 + 3] + (lo < out.sum_lo ? 1 : 0);
-        out.sum_lo = lo;
-        out.non_null += red[w * 5 + 4];
+      if (st_cnt) {
+        out.min_k = (int64_t)((uint64_t)p.base + st_min);
+        out.max_k = (int64_t)((uint64_t)p.base + st_max);
+        const __int128 sum = (__int128)st_sum + (__int128)st_cnt * (__int128)p.base;
+        out.sum_lo = (uint64_t)sum;
+        out.sum_hi = (int64_t)(sum >> 64);
       }
       p.stats[blockIdx.x] = out;
     }
-    __syncthreads();
   }
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
+}
+
+// the outliers' share of the aggregates as one more partial (index `at`), once the partition pass is through
+__global__ void partition_outlier_stats_kernel(const OutlierStats *g, ScanPartial *partials, int at) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ScanPartial out;
+  out.min_k = INT64_MAX;
+  out.max_k = INT64_MIN;
+  out.sum_lo = 0;
+  out.sum_hi = 0;
+  out.non_null = (int64_t)g->count;
+  out.sum = out.comp = out.s1 = out.s2 = 0.0;
+  if (g->count) {
+    out.min_k = g->mn;
+    out.max_k = g->mx;
+    const __int128 sum = (__int128)(unsigned __int128)g->lo32_sum + (((__int128)g->hi32_sum) << 32);
+    out.sum_lo = (uint64_t)sum;
+    out.sum_hi = (int64_t)(sum >> 64);
+  }
+  partials[at] = out;
 }
 
 // A strided sample of the column (at most 2^16 rows, evenly spread): where its keys lie, before anything has read
@@ -1011,6 +1026,10 @@ void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slic
                          unsigned long long *d_counters, hipStream_t stream) {
   hipLaunchKernelGGL(bitmap_adopt_kernel, dim3(grid_for(slice_words)), dim3(256), 0, stream, seen_slices,
                      twice_slices, n_slices, slice_words, stride_words, out_seen, out_twice, d_counters);
+}
+
+void launch_partition_outlier_stats(const OutlierStats *g, ScanPartial *partials, int at, hipStream_t stream) {
+  hipLaunchKernelGGL(partition_outlier_stats_kernel, dim3(1), dim3(64), 0, stream, g, partials, at);
 }
 
 int partition_grid(int64_t length, int n_cu) {

@@ -58,6 +58,16 @@ struct PartitionParams {
   // by scan_reduce_kernel) -- the numeric scan then skips the column: a unique-key column crosses HBM once for its
   // range checks and its uniqueness check together
   struct ScanPartial *stats;
+  struct OutlierStats *outliers;  // with stats: the aggregates of the (rare) keys outside [base, base + range)
+};
+
+// keys outside the bitmap's range enter the column's aggregates through global atomics (they are rare: the range
+// was sampled from the column): SUM as the two halves sum(key & 0xFFFFFFFF) + 2^32 * sum(key >> 32)
+struct OutlierStats {
+  long long mn, mx;
+  unsigned long long lo32_sum;
+  long long hi32_sum;
+  unsigned long long count;
 };
 
 // a strided sample of an Int64 column: the value range a DISTINCT pass can expect BEFORE the column has been scanned

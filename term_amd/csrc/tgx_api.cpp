@@ -1167,8 +1167,13 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
       pp.twice = mult ? ds.twice.as<uint32_t>() : nullptr;
       const int grid = partition_grid(c.length, g_ctx.n_cu);
       if (stats_slot >= 0) {
-        HIP_TRY(ds.stat_partials.reserve((size_t)grid * sizeof(ScanPartial)));
+        HIP_TRY(ds.stat_partials.reserve((size_t)(grid + 1) * sizeof(ScanPartial)));
+        HIP_TRY(ds.outlier_stats.reserve(sizeof(OutlierStats)));
         pp.stats = ds.stat_partials.as<ScanPartial>();
+        pp.outliers = ds.outlier_stats.as<OutlierStats>();
+        const OutlierStats init{INT64_MAX, INT64_MIN, 0, 0, 0};
+        // (a pageable 40-byte source: the runtime copies it before the call returns)
+        HIP_TRY(hipMemcpyAsync(pp.outliers, &init, sizeof(init), hipMemcpyHostToDevice, st->stream));
       }
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
       {
@@ -1184,7 +1189,8 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
         L.cols[0].length = c.length;
         L.cols[0].is_float = 0;
         L.acc_index[0] = stats_slot;
-        launch_scan_reduce_only(L, 1, grid, pp.stats, st->d_scan_acc.as<ScanAcc>(), st->stream);
+        launch_partition_outlier_stats(pp.outliers, pp.stats, grid, st->stream);
+        launch_scan_reduce_only(L, 1, grid + 1, pp.stats, st->d_scan_acc.as<ScanAcc>(), st->stream);
       }
     } else {
       ProfScope ps(st, "distinct", bytes);
