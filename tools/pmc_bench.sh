@@ -2,7 +2,7 @@
 # usage: tools/pmc_bench.sh <tag> <counter> [bench args...]  -- one rocprofv3 --pmc pass (counters in their own run)
 tag=$1; shift; ctr=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py "$@" > gpurun_out/pmc_$tag.log 2>&1
+timeout -k 5 420 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py "$@" > gpurun_out/pmc_$tag.log 2>&1
 tail -1 gpurun_out/pmc_$tag.log | cut -c1-200
 f=$(find gpurun_out/pmc_$tag -name "*counter_collection.csv" | head -1)
 head -1 $f

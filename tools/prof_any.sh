@@ -3,7 +3,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 "$@" > gpurun_out/prof_$tag.log 2>&1
+timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 "$@" > gpurun_out/prof_$tag.log 2>&1
 grep -E "^\{|^rows|^col" gpurun_out/prof_$tag.log | cut -c1-300
 python3 tools/kstats.py gpurun_out/prof_$tag
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)

@@ -2,7 +2,7 @@
 # usage: tools/prof_bench.sh <tag> [bench args...]   -- rocprofv3 kernel stats of bench.py, tgx kernels only
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py "$@" > gpurun_out/prof_$tag.log 2>&1
+timeout -k 5 420 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py "$@" > gpurun_out/prof_$tag.log 2>&1
 tail -1 gpurun_out/prof_$tag.log | cut -c1-400
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 head -1 $f; grep "tgx::" $f
