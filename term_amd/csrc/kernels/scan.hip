@@ -725,9 +725,26 @@ __device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, La
   }
 }
 
+// The exact update of a whole tile, OUT OF LINE: it runs for a handful of tiles per wave, and inlined its code and
+// live ranges cost the hot loop a fifth of its vector instructions in scalar-register spills.  Everything travels
+// in registers (arguments and result by value).
+struct ExactState {
+  int64_t mn, mx;   // LaneAcc::mn / mx
+  double dmn, dmx;  // ColFast::dmn / dmx
+  int64_t lo, hi;   // the refreshed wave bounds
+};
+
 template <bool F>
-__device__ __forceinline__ void col_exact_tile(ColFast<F> &c, LaneAcc &a, i64x2 v0, i64x2 v1, i64x2 v2, i64x2 v3,
-                                               uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+__device__ __attribute__((noinline)) ExactState col_exact_tile(int64_t mn, int64_t mx, double dmn, double dmx, i64x2 v0,
+                                                               i64x2 v1, i64x2 v2, i64x2 v3, uint32_t b0, uint32_t b1,
+                                                               uint32_t b2, uint32_t b3) {
+  ColFast<F> c;
+  LaneAcc a;
+  a.mn = mn;
+  a.mx = mx;
+  c.dmn = dmn;
+  c.dmx = dmx;
+  c.lo = c.hi = 0;
   col_exact_value<F>(c, a, v0.x, (b0 & 1u) != 0);
   col_exact_value<F>(c, a, v0.y, (b0 & 2u) != 0);
   col_exact_value<F>(c, a, v1.x, (b1 & 1u) != 0);
@@ -737,6 +754,14 @@ __device__ __forceinline__ void col_exact_tile(ColFast<F> &c, LaneAcc &a, i64x2 
   col_exact_value<F>(c, a, v3.x, (b3 & 1u) != 0);
   col_exact_value<F>(c, a, v3.y, (b3 & 2u) != 0);
   col_refresh_bounds<F>(c, a);
+  ExactState o;
+  o.mn = a.mn;
+  o.mx = a.mx;
+  o.dmn = c.dmn;
+  o.dmx = c.dmx;
+  o.lo = c.lo;
+  o.hi = c.hi;
+  return o;
 }
 
 // one row per lane: ragged edges and pairs whose buffers do not allow tiles
@@ -820,6 +845,7 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
   const uint32_t wave_slot = (uint32_t)wave_global;
   const ScanColDesc &cx = P.x, &cy = P.y;
   int64_t cnt_x = 0, cnt_y = 0, n_both = 0;
+  uint32_t lane_cnt_x = 0, lane_cnt_y = 0, lane_both = 0;  // tile path: per-lane counts (a lane sees < 2^32 rows)
   ColFast<XF> fx;
   ColFast<YF> fy;
   col_fast_init<XF>(fx);
@@ -828,49 +854,72 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
     global_i64x2_ptr px = (global_i64x2_ptr)(uintptr_t)((const int64_t *)cx.values + cx.offset + cx.head);
     global_i64x2_ptr py = (global_i64x2_ptr)(uintptr_t)((const int64_t *)cy.values + cy.offset + cy.head);
     const bool hx = cx.validity != nullptr, hy = cy.validity != nullptr;
-    const_u64_ptr wx = (const_u64_ptr)(uintptr_t)(cx.validity + ((cx.offset + cx.head) >> 3));
-    const_u64_ptr wy = (const_u64_ptr)(uintptr_t)(cy.validity + ((cy.offset + cy.head) >> 3));
-    const uint32_t sh = 2u * (uint32_t)(lane & 31);
-    const bool upper = lane >= 32;
-    for (int64_t t = wave_global; t < cx.n_tiles; t += n_waves) {
-      const int64_t p = t * (kTileRows / 2) + lane;
+    global_u8_ptr vbx = (global_u8_ptr)(uintptr_t)(cx.validity + ((cx.offset + cx.head) >> 3));
+    global_u8_ptr vby = (global_u8_ptr)(uintptr_t)(cy.validity + ((cy.offset + cy.head) >> 3));
+    const int32_t n_tiles32 = (int32_t)cx.n_tiles, step32 = (int32_t)n_waves;  // (< 2^31 tiles: 10^12 rows)
+    for (int32_t t = (int32_t)wave_global; t < n_tiles32; t += step32) {
+      const int64_t p = (int64_t)t * (kTileRows / 2) + lane;
       const i64x2 x0 = __builtin_nontemporal_load(px + p), x1 = __builtin_nontemporal_load(px + p + 64);
       const i64x2 x2 = __builtin_nontemporal_load(px + p + 128), x3 = __builtin_nontemporal_load(px + p + 192);
       const i64x2 y0 = __builtin_nontemporal_load(py + p), y1 = __builtin_nontemporal_load(py + p + 64);
       const i64x2 y2 = __builtin_nontemporal_load(py + p + 128), y3 = __builtin_nontemporal_load(py + p + 192);
-      uint64_t a[8], b[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) a[k] = b[k] = ~0ull;
-      if (hx) {
-        const_u64_ptr q = wx + t * (kTileRows / 64);
-#pragma unroll
-        for (int k = 0; k < 8; k++) a[k] = q[k];
-      }
-      if (hy) {
-        const_u64_ptr q = wy + t * (kTileRows / 64);
-#pragma unroll
-        for (int k = 0; k < 8; k++) b[k] = q[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        cnt_x += __builtin_popcountll(a[k]);
-        cnt_y += __builtin_popcountll(b[k]);
-        n_both += __builtin_popcountll(a[k] & b[k]);
+      // the lane's validity bits: rows 2 lane, 2 lane + 1 of each 128-row slot share a byte -- one byte load per slot
+      // and column.  (The single-column scan fetches the tile's words through the scalar cache; here the wave's
+      // scalar registers are the scarce resource -- 16 words held next to the bounds, the samplers' state and two
+      // column descriptors were spilled to lanes, a fifth of the loop's vector instructions.)
+      uint32_t bx0 = 3, bx1 = 3, bx2 = 3, bx3 = 3, by0 = 3, by1 = 3, by2 = 3, by3 = 3;
+      {
+        const int64_t vbyte = (int64_t)t * (kTileRows / 8) + (lane >> 2);
+        const uint32_t sh2 = 2u * (uint32_t)(lane & 3);
+        if (hx) {
+          const uint32_t v0 = vbx[vbyte], v1 = vbx[vbyte + 16], v2 = vbx[vbyte + 32], v3 = vbx[vbyte + 48];
+          bx0 = (v0 >> sh2) & 3u;
+          bx1 = (v1 >> sh2) & 3u;
+          bx2 = (v2 >> sh2) & 3u;
+          bx3 = (v3 >> sh2) & 3u;
+        }
+        if (hy) {
+          const uint32_t v0 = vby[vbyte], v1 = vby[vbyte + 16], v2 = vby[vbyte + 32], v3 = vby[vbyte + 48];
+          by0 = (v0 >> sh2) & 3u;
+          by1 = (v1 >> sh2) & 3u;
+          by2 = (v2 >> sh2) & 3u;
+          by3 = (v3 >> sh2) & 3u;
+        }
       }
       ComoTile q;
 #pragma unroll
       for (int k = 0; k < 5; k++) q.t[k] = 0.0;
-      const uint32_t bx0 = (uint32_t)((upper ? a[1] : a[0]) >> sh) & 3u, bx1 = (uint32_t)((upper ? a[3] : a[2]) >> sh) & 3u;
-      const uint32_t bx2 = (uint32_t)((upper ? a[5] : a[4]) >> sh) & 3u, bx3 = (uint32_t)((upper ? a[7] : a[6]) >> sh) & 3u;
-      const uint32_t by0 = (uint32_t)((upper ? b[1] : b[0]) >> sh) & 3u, by1 = (uint32_t)((upper ? b[3] : b[2]) >> sh) & 3u;
-      const uint32_t by2 = (uint32_t)((upper ? b[5] : b[4]) >> sh) & 3u, by3 = (uint32_t)((upper ? b[7] : b[6]) >> sh) & 3u;
+      // COUNT(x), COUNT(y) and the rows both have: per lane from its own bits (the wave's scalar registers are the
+      // scarce resource of this kernel: three 64-bit counters and the a[k] & b[k] words were spilled to lanes)
+      lane_cnt_x += (bx0 & 1u) + (bx0 >> 1) + (bx1 & 1u) + (bx1 >> 1) + (bx2 & 1u) + (bx2 >> 1) + (bx3 & 1u) + (bx3 >> 1);
+      lane_cnt_y += (by0 & 1u) + (by0 >> 1) + (by1 & 1u) + (by1 >> 1) + (by2 & 1u) + (by2 >> 1) + (by3 & 1u) + (by3 >> 1);
+      {
+        const uint32_t c0 = bx0 & by0, c1 = bx1 & by1, c2 = bx2 & by2, c3 = bx3 & by3;
+        lane_both += (c0 & 1u) + (c0 >> 1) + (c1 & 1u) + (c1 >> 1) + (c2 & 1u) + (c2 >> 1) + (c3 & 1u) + (c3 >> 1);
+      }
       unsigned long long out_x = 0, out_y = 0;  // lanes holding a value outside the wave's bounds (uniform)
       pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x0, y0, bx0, by0, Kx, Ky, rx, ry);
       pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x1, y1, bx1, by1, Kx, Ky, rx, ry);
       pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x2, y2, bx2, by2, Kx, Ky, rx, ry);
       pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x3, y3, bx3, by3, Kx, Ky, rx, ry);
-      if (out_x) col_exact_tile<XF>(fx, ax, x0, x1, x2, x3, bx0, bx1, bx2, bx3);
-      if (out_y) col_exact_tile<YF>(fy, ay, y0, y1, y2, y3, by0, by1, by2, by3);
+      if (out_x) {
+        const ExactState e = col_exact_tile<XF>(ax.mn, ax.mx, fx.dmn, fx.dmx, x0, x1, x2, x3, bx0, bx1, bx2, bx3);
+        ax.mn = e.mn;
+        ax.mx = e.mx;
+        fx.dmn = e.dmn;
+        fx.dmx = e.dmx;
+        fx.lo = e.lo;
+        fx.hi = e.hi;
+      }
+      if (out_y) {
+        const ExactState e = col_exact_tile<YF>(ay.mn, ay.mx, fy.dmn, fy.dmx, y0, y1, y2, y3, by0, by1, by2, by3);
+        ay.mn = e.mn;
+        ay.mx = e.mx;
+        fy.dmn = e.dmn;
+        fy.dmx = e.dmx;
+        fy.lo = e.lo;
+        fy.hi = e.hi;
+      }
       como_tile_flush(m, q);
       if (XF) {
         two_sum_add(ax.s, ax.c, fx.tsum);
@@ -903,6 +952,14 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
     Ky.mx = __builtin_fmax(Ky.mx, fy.dmx);
     if (P.x.kll.picks) kll_finish_wave(Kx, rx, P.x.kll, wave_slot, lane);
     if (P.y.kll.picks) kll_finish_wave(Ky, ry, P.y.kll, wave_slot, lane);
+  }
+  ax.cnt += lane_cnt_x;
+  ay.cnt += lane_cnt_y;
+  {
+    int64_t both = lane_both;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) both += shfl_down_i64(both, d);
+    n_both += __shfl(both, 0, 64);
   }
   // wave reduce
 #pragma unroll
