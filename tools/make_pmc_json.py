@@ -35,7 +35,7 @@ def main():
         kernels[k] = {"dispatches": fetch.get(k, write.get(k))[0],
                       "FETCH_SIZE_KB_mean": fetch.get(k, (0, None))[1],
                       "WRITE_SIZE_KB_mean": write.get(k, (0, None))[1]}
-    scan = next(v for k, v in kernels.items() if "scan_kernel" in k)
+    scan = next(v for k, v in kernels.items() if "scan_kernel<" in k)
     sys.path.insert(0, ROOT)
     from term_amd import synth
     out = {
@@ -47,7 +47,13 @@ def main():
                 "global_load_dwordx4, so its HBM read bytes = 2 x FETCH_SIZE x 1024. WRITE_SIZE is exact for wide stores.",
         "kernels": kernels,
         "scan_kernel_traffic_bytes_per_launch": 2 * scan["FETCH_SIZE_KB_mean"] * 1024 + scan["WRITE_SIZE_KB_mean"] * 1024,
-        "scan_kernel_algorithmic_bytes_per_launch": synth.algorithmic_bytes(synth.COLUMNS_16, rows),
+        # the 14 columns scan_kernel reads: the two unique-key columns ride on their DISTINCT pass (partition_kernel)
+        "scan_kernel_algorithmic_bytes_per_launch": synth.algorithmic_bytes(
+            [c for i, c in enumerate(synth.COLUMNS_16) if i not in synth.UNIQUE_COLUMNS_16], rows),
+        "suite_algorithmic_bytes": synth.algorithmic_bytes(synth.COLUMNS_16, rows),
+        "suite_traffic_bytes_per_step": sum(
+            (2 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]) * 1024 * v["dispatches"] for v in kernels.values()
+            if v["FETCH_SIZE_KB_mean"] is not None and v["WRITE_SIZE_KB_mean"] is not None) / max(1, scan["dispatches"]),
     }
     path = os.path.join(ROOT, "profiles", "%s_pmc_1Brows_16cols.json" % tag)
     with open(path, "w") as f:
