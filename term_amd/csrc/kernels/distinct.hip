@@ -1038,6 +1038,29 @@ int partition_grid(int64_t length, int n_cu) {
   return grid < 1 ? 1 : grid;
 }
 
+// identities of the two small accumulators (a kernel, not two copies from pageable host memory: those stall the
+// caller for a staging round trip each)
+__global__ void distinct_init_kernel(DistinctSample *sample, OutlierStats *outliers) {
+  if (threadIdx.x != 0) return;
+  if (sample) {
+    sample->min_v = INT64_MAX;
+    sample->max_v = INT64_MIN;
+    sample->count = 0;
+    sample->pad = 0;
+  }
+  if (outliers) {
+    outliers->mn = INT64_MAX;
+    outliers->mx = INT64_MIN;
+    outliers->lo32_sum = 0;
+    outliers->hi32_sum = 0;
+    outliers->count = 0;
+  }
+}
+
+void launch_distinct_init(DistinctSample *sample, OutlierStats *outliers, hipStream_t stream) {
+  hipLaunchKernelGGL(distinct_init_kernel, dim3(1), dim3(64), 0, stream, sample, outliers);
+}
+
 void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream) {
   hipLaunchKernelGGL(distinct_sample_kernel, dim3(64), dim3(256), 0, stream, d, out);
 }

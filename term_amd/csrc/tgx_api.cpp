@@ -1069,8 +1069,8 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
       d.want_multiplicity = 0;
       d.pad = 0;
       HIP_TRY(ds.sample.reserve(sizeof(DistinctSample)));
-      DistinctSample init{INT64_MAX, INT64_MIN, 0, 0}, got;
-      HIP_TRY(hipMemcpyAsync(ds.sample.p, &init, sizeof(init), hipMemcpyHostToDevice, st->stream));
+      DistinctSample got;
+      launch_distinct_init(ds.sample.as<DistinctSample>(), nullptr, st->stream);
       launch_distinct_sample(d, ds.sample.as<DistinctSample>(), st->stream);
       HIP_TRY(hipMemcpyAsync(&got, ds.sample.p, sizeof(got), hipMemcpyDeviceToHost, st->stream));
       HIP_TRY(hipStreamSynchronize(st->stream));  // (the stream holds nothing but the sample when a step starts)
@@ -1174,9 +1174,7 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
         HIP_TRY(ds.outlier_stats.reserve(sizeof(OutlierStats)));
         pp.stats = ds.stat_partials.as<ScanPartial>();
         pp.outliers = ds.outlier_stats.as<OutlierStats>();
-        const OutlierStats init{INT64_MAX, INT64_MIN, 0, 0, 0};
-        // (a pageable 40-byte source: the runtime copies it before the call returns)
-        HIP_TRY(hipMemcpyAsync(pp.outliers, &init, sizeof(init), hipMemcpyHostToDevice, st->stream));
+        launch_distinct_init(nullptr, pp.outliers, st->stream);
       }
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
       {
