@@ -220,8 +220,16 @@ tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **
 void tgx_state_destroy(tgx_state *state);
 
 /* One call per RecordBatch: replaces DataFusion's accumulator `update_batch` for the plan's
- * aggregates (`Analyzer::compute_state_from_data`, TG/analyzers/traits.rs:98-111).  Asynchronous
- * on the state's stream. `columns[i]` is column i of the batch; unused columns may be zeroed. */
+ * aggregates (`Analyzer::compute_state_from_data`, TG/analyzers/traits.rs:98-111).  `columns[i]` is
+ * column i of the batch; unused columns may be zeroed.
+ * The batch's kernels are queued on the state's stream and the call returns without waiting for them, except:
+ *   - the FIRST batch (of 2^16 rows or more) an Int64 DISTINCT task sees waits for a sample of at most 2^16 of its
+ *     values (that is: for whatever the stream still holds, plus ~20 us) to lay out the key set; later batches of
+ *     the task never wait (keys outside the sampled range are counted and repaired at tgx_finalize /
+ *     tgx_state_sync / tgx_state_serialize / tgx_merge / tgx_allreduce);
+ *   - a hash key set that may have to grow reads its fill back first;
+ *   - HOST batches: buffers copied straight from the caller's memory are borrowed only until the call returns, so
+ *     it waits for the copies (small buffers travel through a pinned arena and do not). */
 tgx_status tgx_update(const tgx_plan *plan, tgx_state *state, const tgx_column *columns,
                       size_t n_columns, tgx_error *err);
 

@@ -1244,7 +1244,25 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
 }
 
 tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
-  for (size_t k = 0; k < st->distinct.size(); k++) TGX_TRY(distinct_resolve(st, k, err));
+  // one read-back for all tasks (a synchronisation each would cost a step with several uniqueness checks more than
+  // the checks themselves at small sizes); only a task that really has outliers goes through the repair
+  bool pending = false;
+  for (auto &ds : st->distinct) pending |= ds.speculative && !ds.retained.empty();
+  if (!pending || !st->device_ready || !st->d_distinct_counters.p) {
+    for (auto &ds : st->distinct) ds.retained.clear();
+    return TGX_OK;
+  }
+  std::vector<unsigned long long> all(st->distinct.size() * kNumDistinctCounters);
+  HIP_TRY(hipMemcpyAsync(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
+                         hipMemcpyDeviceToHost, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  for (size_t k = 0; k < st->distinct.size(); k++) {
+    DistinctState &ds = st->distinct[k];
+    if (ds.speculative && !ds.retained.empty() && all[k * kNumDistinctCounters + kCntOutOfRange] != 0)
+      TGX_TRY(distinct_resolve(st, k, err));
+    else
+      ds.retained.clear();
+  }
   return TGX_OK;
 }
 
@@ -1759,7 +1777,6 @@ static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t,
 
 static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   const tgx_plan *plan = st->plan;
-  TGX_TRY(distinct_resolve_all(st, err));
   g->scan = st->h_scan;
   g->count = st->h_count;
   g->como = st->h_como;
@@ -1787,6 +1804,24 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
     }
     HIP_TRY(hipStreamSynchronize(st->stream));
     st->ptr_tables.clear();
+    // keys that fell outside a sampled bitmap range (DistinctState::speculative): the counters just read say whether
+    // any task has some -- only then is there a repair to run and its counters to read again
+    bool repaired = false;
+    for (size_t k = 0; k < st->distinct.size(); k++) {
+      DistinctState &ds = st->distinct[k];
+      if (ds.speculative && !ds.retained.empty() && !all.empty() &&
+          all[k * kNumDistinctCounters + kCntOutOfRange] != 0) {
+        TGX_TRY(distinct_resolve(st, k, err));
+        repaired = true;
+      } else {
+        ds.retained.clear();
+      }
+    }
+    if (repaired) {
+      HIP_TRY(hipMemcpyAsync(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, st->stream));
+      HIP_TRY(hipStreamSynchronize(st->stream));
+    }
     for (size_t i = 0; i < d_scan.size(); i++) scan_acc_merge(g->scan[i], d_scan[i]);
     for (size_t i = 0; i < d_count.size(); i++) {
       g->count[i].total += d_count[i].total;
