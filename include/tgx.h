@@ -351,7 +351,8 @@ tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *state, tgx_comm *comm,
 
 /* ---- measurement ----------------------------------------------------------------------------
  * Per-kernel HIP-event timing on the state's stream (what bench.py's `roofline` uses).
- * Kernel names: "scan", "count", "distinct", "regex", "kll", "comoments". */
+ * Kernel names: "scan", "count", "distinct", "regex", "kll", "comoments"; "distinct_lists" is the share of
+ * "distinct" spent on big Utf8 batches that were deduplicated through partitioned fingerprint lists. */
 tgx_status tgx_profile_enable(tgx_state *state, int32_t on);
 tgx_status tgx_profile_get(tgx_state *state, const char *kernel, double *total_ms,
                            uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err);

@@ -105,6 +105,15 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
                         hipStream_t stream);
 void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
                            hipStream_t stream);
+// big Utf8 batches: fingerprints partitioned into lists, deduplicated list by list in LDS (distinct128.hip, fp_*)
+void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+                                 int64_t length, int large_offsets, const FpLists &level1,
+                                 unsigned long long *d_counters, hipStream_t stream);
+void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
+                               hipStream_t stream);
+void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
+                     unsigned long long *d_counters, hipStream_t stream);
+void launch_fp_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream);
 void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
@@ -269,6 +278,12 @@ struct DistinctState {
   DevBuf sample;         // DistinctSample
   DevBuf stat_partials;  // ScanPartial per workgroup of the partition pass (PartitionParams::stats) + one for outliers
   DevBuf outlier_stats;  // OutlierStats
+  // A big first Utf8 batch leaves its key set as partitioned fingerprint lists (kernels/distinct128.hip, fp_*): the
+  // counters are exact, the table is filled from the lists only when something needs it (distinct_resolve).  A list
+  // that overflowed (kCntOutOfRange) means the batch is redone through the table from the view retained above.
+  bool fp_staged = false;
+  uint64_t fp_cap1 = 0, fp_cap2 = 0;
+  DevBuf fp_level1, fp_level2, fp_offered, fp_per_list;
   // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
   // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
   DevBuf spare_seen, spare_twice;

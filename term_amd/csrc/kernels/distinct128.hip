@@ -8,6 +8,7 @@
 // 64-bit hashes agree: < 2^-64 per pair, ~1e-20 for 10^9 distinct values (DESIGN.md "Distinct").
 // The same table serves multi-batch updates, merges (records of 32 bytes) and the cross-rank exchange.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "distinct_types.h"
 
@@ -129,6 +130,31 @@ struct Utf8ColDesc {
   const uint8_t *const *buffers;  // Utf8View: device array of the data buffers' device pointers
 };
 
+// where the value of slot `slot` lies
+__device__ __forceinline__ void utf8_value(const Utf8ColDesc &d, int64_t slot, uintptr_t *p, uint64_t *len) {
+  if (d.views) {
+    global_i32_ptr vw = (global_i32_ptr)((uintptr_t)d.views + (uintptr_t)slot * 16);
+    const int32_t n = vw[0];
+    *len = (uint64_t)n;
+    if (n <= 12) {
+      *p = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
+    } else {
+      const int32_t bi = vw[2], bo = vw[3];
+      *p = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
+    }
+  } else if (d.large_offsets) {
+    global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
+    const int64_t b = off[slot];
+    *p = (uintptr_t)d.data + (uintptr_t)b;
+    *len = (uint64_t)(off[slot + 1] - b);
+  } else {
+    global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
+    const int32_t b = off[slot];
+    *p = (uintptr_t)d.data + (uintptr_t)b;
+    *len = (uint64_t)(off[slot + 1] - b);
+  }
+}
+
 __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashSetView t,
                                                              unsigned long long *counters) {
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
@@ -138,30 +164,10 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
     const int64_t slot = d.offset + i;
     if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) continue;
     n_valid++;
-    int64_t b, e;
-    uintptr_t base = (uintptr_t)d.data;
-    if (d.views) {
-      global_i32_ptr vw = (global_i32_ptr)((uintptr_t)d.views + (uintptr_t)slot * 16);
-      const int32_t len = vw[0];
-      b = 0;
-      e = len;
-      if (len <= 12) {
-        base = (uintptr_t)d.views + (uintptr_t)slot * 16 + 4;
-      } else {
-        const int32_t bi = vw[2], bo = vw[3];
-        base = (uintptr_t)d.buffers[bi] + (uintptr_t)(uint32_t)bo;
-      }
-    } else if (d.large_offsets) {
-      global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
-      b = off[slot];
-      e = off[slot + 1];
-    } else {
-      global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
-      b = off[slot];
-      e = off[slot + 1];
-    }
-    uint64_t fa, fb;
-    fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &fa, &fb);
+    uintptr_t p;
+    uint64_t len, fa, fb;
+    utf8_value(d, slot, &p, &len);
+    fingerprint(p, len, &fa, &fb);
     int became_dup = 0;
     n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
     n_dup += became_dup;
@@ -169,6 +175,214 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
   __syncthreads();
   block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+// ---- big batches: no global atomic per value ------------------------------------------------------------------
+// A global-table insert is a 64-byte read-modify-write at the memory side per VALUE (the chip does ~20 G of them a
+// second whatever the table's size: 5 ms per 100 M values before a byte of string is read).  A batch big enough to
+// care is instead reduced to its fingerprints, which are range-partitioned twice -- 8 bits of the first word each
+// time, a tile of kFpTile records grouped in LDS so that a list receives whole runs -- into kFpFan^2 lists of a few
+// thousand records; fp_count_kernel then deduplicates a list in an LDS table and the counts are summed.  The lists
+// ARE the key set until somebody needs the table (a second batch, a merge, an export): fp_insert_kernel then moves
+// them in.  A list that receives more records than it can hold (heavily repeated values) drops them and says so in
+// kCntOutOfRange: the host redoes the batch through the global table (tgx_api.cpp, fp_resolve).
+template <bool FROM_STRINGS>
+__global__ __launch_bounds__(256) void fp_partition_kernel(Utf8ColDesc d, FpLists in, uint32_t tiles_per_list,
+                                                           FpLists out, int shift, unsigned long long *counters) {
+  constexpr int PER = kFpTile / 256;
+  __shared__ ulonglong2 stage[kFpTile];
+  __shared__ uint32_t hist[kFpFan], lbase[kFpFan], gpos[kFpFan], lcur[kFpFan];
+  __shared__ uint32_t wsum[4], dropped;
+  const uint32_t tid = threadIdx.x;
+  int64_t first, count;
+  uint32_t in_list = 0;
+  if (FROM_STRINGS) {
+    first = (int64_t)blockIdx.x * kFpTile;
+    count = d.length - first;
+  } else {
+    in_list = blockIdx.x / tiles_per_list;
+    first = (int64_t)(blockIdx.x % tiles_per_list) * kFpTile;
+    const uint64_t have = in.offered[in_list];
+    count = (int64_t)(have < in.cap ? have : in.cap) - first;
+    if (count <= 0) return;
+  }
+  if (count > kFpTile) count = kFpTile;
+  hist[tid] = 0;
+  lcur[tid] = 0;
+  if (tid == 0) dropped = 0;
+  __syncthreads();
+  // ---- the tile's records into LDS (row order) + records per list ----
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  for (int k = 0; k < PER; k++) {
+    const int pos = k * 256 + (int)tid;
+    ulonglong2 r;
+    r.x = kEmptyKey;  // (no fingerprint's first word: fingerprint())
+    r.y = 0;
+    if (pos < count) {
+      if (FROM_STRINGS) {
+        const int64_t slot = d.offset + first + pos;
+        if (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1)) {
+          uintptr_t p;
+          uint64_t len, fa, fb;
+          utf8_value(d, slot, &p, &len);
+          fingerprint(p, len, &fa, &fb);
+          r.x = fa;
+          r.y = fb;
+        }
+      } else {
+        r = ((const ulonglong2 *)in.recs)[(uint64_t)in_list * in.cap + (uint64_t)(first + pos)];
+      }
+    }
+    if (r.x != kEmptyKey) atomicAdd(&hist[(r.x >> shift) & (kFpFan - 1)], 1u);
+    stage[pos] = r;
+  }
+  __syncthreads();
+  // ---- where each list's run starts in the tile, and ONE reservation per touched list ----
+  const uint32_t h = hist[tid];
+  uint32_t incl = h;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const uint32_t up = __shfl_up(incl, dlt, 64);
+    if ((tid & 63) >= (uint32_t)dlt) incl += up;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  ulonglong2 mine[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) mine[k] = stage[k * 256 + tid];
+  __syncthreads();  // wsum is there; everyone holds its records
+  uint32_t excl = incl - h;
+  for (uint32_t w = 0; w < (tid >> 6); w++) excl += wsum[w];
+  lbase[tid] = excl;
+  const uint32_t out_list0 = FROM_STRINGS ? 0u : in_list * kFpFan;
+  gpos[tid] = h ? atomicAdd(&out.offered[out_list0 + tid], h) : 0u;
+  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  // ---- grouped by list in LDS ----
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    if (mine[k].x == kEmptyKey) continue;
+    const uint32_t b = (uint32_t)(mine[k].x >> shift) & (kFpFan - 1);
+    stage[lbase[b] + atomicAdd(&lcur[b], 1u)] = mine[k];
+  }
+  __syncthreads();
+  // ---- runs out, 16 bytes per lane ----
+  bool lost = false;
+  for (uint32_t p = tid; p < total; p += 256) {
+    const ulonglong2 r = stage[p];
+    const uint32_t b = (uint32_t)(r.x >> shift) & (kFpFan - 1);
+    const uint64_t at = (uint64_t)gpos[b] + (p - lbase[b]);
+    if (at < out.cap)
+      ((ulonglong2 *)out.recs)[(uint64_t)(out_list0 + b) * out.cap + at] = r;
+    else
+      lost = true;
+  }
+  if (lost) dropped = 1;  // (same value from every writer)
+  __syncthreads();
+  if (tid == 0 && dropped) atomicAdd(&counters[kCntOutOfRange], 1ull);
+}
+
+// one workgroup per final list: distinct keys / keys seen twice of the list -> per_list[list]
+__global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list) {
+  // the table keeps first words only; the record that owns a slot is named beside it and its second word is read
+  // back from the list (it has just come through this CU's caches) in the one-in-2^48 case of equal first words
+  __shared__ unsigned long long ka[kFpSlots];
+  __shared__ uint32_t kown[kFpSlots];
+  __shared__ uint32_t dupw[kFpSlots / 32];
+  __shared__ uint32_t s_new[4], s_dup[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t offered = l.offered[blockIdx.x];
+  if (offered == 0 || offered > l.cap) {  // (an overflowed list was flagged by the kernel that filled it)
+    if (tid == 0) per_list[blockIdx.x] = make_uint2(0, 0);
+    return;
+  }
+  for (uint32_t s = tid; s < kFpSlots; s += 256) {
+    ka[s] = kEmptyKey;
+    kown[s] = 0xFFFFFFFFu;
+  }
+  if (tid < kFpSlots / 32) dupw[tid] = 0;
+  __syncthreads();
+  const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  uint32_t n_new = 0, n_dup = 0;
+  for (uint32_t i = tid; i < offered; i += 256) {
+    const ulonglong2 r = recs[i];
+    uint32_t hs = (uint32_t)(r.x >> 20) & (kFpSlots - 1);
+    for (;;) {
+      const unsigned long long old = atomicCAS(&ka[hs], (unsigned long long)kEmptyKey, (unsigned long long)r.x);
+      if (old == kEmptyKey) {
+        __hip_atomic_store(&kown[hs], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        n_new++;
+        break;
+      }
+      if (old == r.x) {
+        const uint32_t owner = __hip_atomic_load(&kown[hs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (owner == 0xFFFFFFFFu) continue;  // claimed, owner on its way: look at this slot again
+        if (recs[owner].y == r.y) {
+          if (want_mult) {
+            const uint32_t bit = 1u << (hs & 31);
+            const uint32_t prev = atomicOr(&dupw[hs >> 5], bit);
+            n_dup += (prev & bit) ? 0u : 1u;
+          }
+          break;
+        }
+      }
+      hs = (hs + 1) & (kFpSlots - 1);
+    }
+  }
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    n_new += __shfl_down(n_new, dlt, 64);
+    n_dup += __shfl_down(n_dup, dlt, 64);
+  }
+  if ((tid & 63) == 0) {
+    s_new[tid >> 6] = n_new;
+    s_dup[tid >> 6] = n_dup;
+  }
+  __syncthreads();
+  if (tid == 0)
+    per_list[blockIdx.x] = make_uint2(s_new[0] + s_new[1] + s_new[2] + s_new[3], s_dup[0] + s_dup[1] + s_dup[2] + s_dup[3]);
+}
+
+// one workgroup: the batch's counts into the task's counters (valid rows = records offered to the first level)
+__global__ __launch_bounds__(1024) void fp_totals_kernel(const uint2 *per_list, uint32_t n_lists, const uint32_t *offered1,
+                                                         unsigned long long *counters) {
+  __shared__ unsigned long long s[3][16];
+  unsigned long long a = 0, b = 0, v = 0;
+  for (uint32_t i = threadIdx.x; i < n_lists; i += 1024) {
+    const uint2 c = per_list[i];
+    a += c.x;
+    b += c.y;
+  }
+  if (threadIdx.x < kFpFan) v = offered1[threadIdx.x];
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    a += __shfl_down(a, dlt, 64);
+    b += __shfl_down(b, dlt, 64);
+    v += __shfl_down(v, dlt, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = a;
+    s[1][threadIdx.x >> 6] = b;
+    s[2][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 16; w++) t += s[threadIdx.x][w];
+    const int slot = threadIdx.x == 0 ? kCntDistinct : threadIdx.x == 1 ? kCntTwice : kCntValidRows;
+    counters[slot] += t;  // (the only writer of these slots while the lists hold the set)
+  }
+}
+
+// the lists' records into the global table (counted already: no counters)
+__global__ __launch_bounds__(256) void fp_insert_kernel(FpLists l, HashSetView t, int want_mult) {
+  const uint32_t offered = l.offered[blockIdx.x];
+  const uint32_t n = offered < l.cap ? offered : (uint32_t)l.cap;
+  const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const ulonglong2 r = recs[i];
+    int became_dup = 0;
+    (void)hash_insert128(t, r.x, r.y, want_mult, 0, &became_dup);
+  }
 }
 
 __global__ __launch_bounds__(256) void hash_rehash128_kernel(HashSetView src, HashSetView dst, int want_mult,
@@ -375,6 +589,43 @@ void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *
   d.want_multiplicity = want_mult;
   hipLaunchKernelGGL(distinct_utf8_kernel, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, t,
                      d_counters);
+}
+
+void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
+                                 int64_t length, int large_offsets, const FpLists &level1,
+                                 unsigned long long *d_counters, hipStream_t stream) {
+  Utf8ColDesc d;
+  memset(&d, 0, sizeof(d));
+  d.offsets = offsets;
+  d.data = data;
+  d.validity = validity;
+  d.offset = offset;
+  d.length = length;
+  d.large_offsets = large_offsets;
+  const int64_t tiles = (length + kFpTile - 1) / kFpTile;
+  FpLists none{nullptr, nullptr, 0};
+  hipLaunchKernelGGL(fp_partition_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, stream, d, none, 1u, level1, 56,
+                     d_counters);
+}
+
+void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
+                               hipStream_t stream) {
+  Utf8ColDesc d;
+  memset(&d, 0, sizeof(d));
+  const uint32_t tiles_per_list = (uint32_t)((level1.cap + kFpTile - 1) / kFpTile);
+  hipLaunchKernelGGL(fp_partition_kernel<false>, dim3(kFpFan * tiles_per_list), dim3(256), 0, stream, d, level1,
+                     tiles_per_list, level2, 48, d_counters);
+}
+
+void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
+                     unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(fp_count_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, want_mult, per_list);
+  hipLaunchKernelGGL(fp_totals_kernel, dim3(1), dim3(1024), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan), offered1,
+                     d_counters);
+}
+
+void launch_fp_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream) {
+  hipLaunchKernelGGL(fp_insert_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, t, want_mult);
 }
 
 void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,

@@ -90,13 +90,27 @@ struct KeyRecord128 {
   uint64_t pad;
 };
 
+// Big Utf8 batches (distinct128.hip, fp_* kernels): the fingerprints are partitioned twice, by 8 bits of their first
+// word each time, into kFpFan^2 lists short enough to be deduplicated in LDS -- no global atomic per value.
+constexpr int kFpFan = 256;              // lists per level
+constexpr int kFpTile = 2048;            // records a workgroup groups in LDS at a time
+constexpr uint32_t kFpSlots = 4096;      // LDS table of one final list
+constexpr uint32_t kFpListMax = 3072;    // records a final list may hold (load <= 3/4)
+constexpr int64_t kFpMinRows = 1 << 23;  // smaller batches go straight into the global table
+struct FpLists {
+  uint64_t *recs;     // [lists][cap] records of two words
+  uint32_t *offered;  // [lists] records offered to the list; those beyond cap were dropped (kCntOutOfRange counts
+                      // the workgroups that dropped some: the batch is then redone through the global table)
+  uint64_t cap;
+};
+
 // counters[] slots shared by the kernels of distinct.hip
 enum {
   kCntDistinct = 0,   // keys in the set (excluding the EMPTY stand-in)
   kCntTwice = 1,      // keys seen at least twice
   kCntEmptyRows = 2,  // rows (or record counts) carrying the all-ones key
   kCntValidRows = 3,  // non-null rows scanned
-  kCntOutOfRange = 4, // bitmap mode: keys outside [base, base+range) -- must stay 0
+  kCntOutOfRange = 4, // bitmap mode: keys outside [base, base+range); fingerprint lists: overflows -- must stay 0
   kCntSpare = 5,
   kNumDistinctCounters = 8
 };

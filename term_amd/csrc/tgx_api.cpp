@@ -469,6 +469,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
     d.wide = false;
     d.has_hint = false;
     d.speculative = false;
+    d.fp_staged = false;
     d.retained.clear();
     d.bitmap_words = 0;
     d.capacity = 0;  // buffers stay allocated; hash_ensure / the bitmap path clear them before use
@@ -928,6 +929,57 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
 static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c, const NumericPrep &prep,
                                        int stats_slot, tgx_error *err);
 
+// ---- big Utf8 batches: partitioned fingerprint lists (kernels/distinct128.hip, fp_*) ----
+// records a list is sized for when `rows` values are spread over `lists` lists: the mean, twelve standard deviations
+// (values that repeat widen the spread) and a floor
+static uint64_t fp_list_cap(int64_t rows, uint64_t lists) {
+  const double mean = (double)rows / (double)lists;
+  return ((uint64_t)(mean + 12.0 * std::sqrt(mean) + 64.0) + 15) & ~15ull;
+}
+static bool fp_lists_fit(const tgx_column &c) {
+  // TGX_FP_LISTS_MIN_ROWS: smallest batch that takes this path (tests lower it; a huge value turns the path off)
+  int64_t min_rows = kFpMinRows;
+  if (const char *e = getenv("TGX_FP_LISTS_MIN_ROWS")) min_rows = std::max<int64_t>(1, atoll(e));
+  // (Utf8View batches read their buffers through a pointer table staged per update: not retained)
+  return (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && c.length >= min_rows &&
+         fp_list_cap(c.length, (uint64_t)kFpFan * kFpFan) <= kFpListMax;
+}
+static void fp_views(const DistinctState &ds, FpLists *l1, FpLists *l2) {
+  l1->recs = ds.fp_level1.as<uint64_t>();
+  l1->offered = ds.fp_offered.as<uint32_t>();
+  l1->cap = ds.fp_cap1;
+  l2->recs = ds.fp_level2.as<uint64_t>();
+  l2->offered = ds.fp_offered.as<uint32_t>() + kFpFan;
+  l2->cap = ds.fp_cap2;
+}
+static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = st->plan->distinct[slot].multiplicity;
+  constexpr uint64_t kLists2 = (uint64_t)kFpFan * kFpFan;
+  ds.fp_cap1 = fp_list_cap(c.length, kFpFan);
+  ds.fp_cap2 = fp_list_cap(c.length, kLists2);
+  HIP_TRY(ds.fp_level1.reserve(kFpFan * ds.fp_cap1 * 16));
+  HIP_TRY(ds.fp_level2.reserve(kLists2 * ds.fp_cap2 * 16));
+  HIP_TRY(ds.fp_offered.reserve((kFpFan + kLists2) * sizeof(uint32_t)));
+  HIP_TRY(ds.fp_per_list.reserve(kLists2 * sizeof(uint2)));
+  HIP_TRY(hipMemsetAsync(ds.fp_offered.p, 0, (kFpFan + kLists2) * sizeof(uint32_t), st->stream));
+  FpLists l1, l2;
+  fp_views(ds, &l1, &l2);
+  ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
+  unsigned long long *counters = ds.counters.as<unsigned long long>();
+  launch_fp_partition_strings(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, l1, counters,
+                              st->stream);
+  launch_fp_partition_lists(l1, l2, counters, st->stream);
+  launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), l1.offered, counters, st->stream);
+  ds.mode = DistinctMode::kHash;
+  ds.wide = true;
+  ds.capacity = 0;  // no table yet
+  ds.rows_upper_bound = 0;
+  ds.fp_staged = true;
+  ds.retained.push_back(c);  // (a DEVICE view, or a staged one looked at before the update returns)
+  return TGX_OK;
+}
+
 static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err,
                                   const std::vector<DictGather> *gathers = nullptr, const NumericPrep *ready = nullptr,
                                   int stats_slot = -1) {
@@ -939,6 +991,8 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     ds.col_type = c.type;
     ds.total_rows += c.length;
     if (c.length == 0) return TGX_OK;
+    if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
+    if (ds.mode == DistinctMode::kUndecided && fp_lists_fit(c)) return fp_lists_update(st, slot, c, err);
     if (ds.mode == DistinctMode::kUndecided) {
       ds.mode = DistinctMode::kHash;
       ds.wide = true;
@@ -1210,6 +1264,32 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
 // batches are walked once more for their outliers only (disjoint from the bitmap's keys, so multiplicities stay right).
 tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
   DistinctState &ds = st->distinct[slot];
+  if (ds.fp_staged && st->device_ready) {
+    // Utf8 fingerprint lists: into the table -- or, if a list overflowed, the batch again, through the table
+    const bool mult = st->plan->distinct[slot].multiplicity;
+    unsigned long long c[kNumDistinctCounters];
+    TGX_TRY(distinct_read_counters(st, ds, c, err));
+    ds.fp_staged = false;
+    if (c[kCntOutOfRange] != 0) {
+      if (ds.retained.empty())
+        return fail(err, TGX_INTERNAL, "distinct: overflowed fingerprint lists and no batch to redo");
+      HIP_TRY(hipMemsetAsync(ds.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
+      for (const tgx_column &col : ds.retained) {
+        TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)col.length, err));
+        launch_distinct_utf8(col.offsets, col.data, nullptr, nullptr, col.validity, col.offset, col.length,
+                             col.type == TGX_LARGE_UTF8, mult ? 1 : 0, hash_view(ds),
+                             ds.counters.as<unsigned long long>(), st->stream);
+      }
+    } else {
+      FpLists l1, l2;
+      fp_views(ds, &l1, &l2);
+      TGX_TRY(hash_ensure(st, ds, mult, c[kCntDistinct], err));
+      launch_fp_insert(l2, hash_view(ds), mult ? 1 : 0, st->stream);
+    }
+    HIP_TRY(hipStreamSynchronize(st->stream));
+    ds.retained.clear();
+    return TGX_OK;
+  }
   if (!ds.speculative || ds.retained.empty() || !st->device_ready) {
     ds.retained.clear();
     return TGX_OK;
@@ -1247,7 +1327,7 @@ tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
   // one read-back for all tasks (a synchronisation each would cost a step with several uniqueness checks more than
   // the checks themselves at small sizes); only a task that really has outliers goes through the repair
   bool pending = false;
-  for (auto &ds : st->distinct) pending |= ds.speculative && !ds.retained.empty();
+  for (auto &ds : st->distinct) pending |= (ds.speculative || ds.fp_staged) && !ds.retained.empty();
   if (!pending || !st->device_ready || !st->d_distinct_counters.p) {
     for (auto &ds : st->distinct) ds.retained.clear();
     return TGX_OK;
@@ -1258,7 +1338,8 @@ tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
   HIP_TRY(hipStreamSynchronize(st->stream));
   for (size_t k = 0; k < st->distinct.size(); k++) {
     DistinctState &ds = st->distinct[k];
-    if (ds.speculative && !ds.retained.empty() && all[k * kNumDistinctCounters + kCntOutOfRange] != 0)
+    if ((ds.speculative || ds.fp_staged) && !ds.retained.empty() &&
+        all[k * kNumDistinctCounters + kCntOutOfRange] != 0)
       TGX_TRY(distinct_resolve(st, k, err));
     else
       ds.retained.clear();
@@ -1809,7 +1890,7 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
     bool repaired = false;
     for (size_t k = 0; k < st->distinct.size(); k++) {
       DistinctState &ds = st->distinct[k];
-      if (ds.speculative && !ds.retained.empty() && !all.empty() &&
+      if ((ds.speculative || ds.fp_staged) && !ds.retained.empty() && !all.empty() &&
           all[k * kNumDistinctCounters + kCntOutOfRange] != 0) {
         TGX_TRY(distinct_resolve(st, k, err));
         repaired = true;
