@@ -1,11 +1,12 @@
 // distinct128.hip -- exact-with-overwhelming-probability COUNT(DISTINCT) for Utf8 columns on gfx950.
 //
-// Variable-length values are reduced on the fly to 128-bit fingerprints (two independent 64-bit hashes
-// of the bytes and the length); the fingerprints are deduplicated in an open-addressing table of
-// 16-byte slots.  A slot is claimed with two 64-bit CASes (first word, then second word); a thread that
-// finds the first word equal but loses the second to a different fingerprint just keeps probing, so no
-// thread ever waits on another (no spinning inside a wave).  Two distinct strings collide only if both
-// 64-bit hashes agree: < 2^-64 per pair, ~1e-20 for 10^9 distinct values (DESIGN.md "Distinct").
+// Variable-length values are reduced on the fly to 128-bit fingerprints (fingerprint() below: four 32-bit lanes
+// over the bytes and the length).  Small batches deduplicate the fingerprints in an open-addressing table of
+// 16-byte slots: a slot is claimed with ONE 64-bit CAS on its first word and the owner publishes the second; a
+// thread that meets an equal first word and a different second just keeps probing, so no thread ever waits on
+// another.  Big batches never touch the table: the fingerprints are partitioned into lists that are deduplicated in
+// LDS (fp_* kernels).  Two distinct values collide only if all 128 bits agree: ~2^-128 per pair on data that was
+// not built against the (seedless) function, ~1e-21 for 10^9 distinct values (DESIGN.md "Distinct").
 // The same table serves multi-batch updates, merges (records of 32 bytes) and the cross-rank exchange.
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -30,14 +31,81 @@ __device__ __forceinline__ uint64_t mix64w(uint64_t x) {
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
-// two independent 64-bit hashes of bytes [p, p+len)
+// ---- the 128-bit fingerprint of a value ------------------------------------------------------------------------
+// Four 32-bit lanes in the manner of MurmurHash3's x86_128 variant: all arithmetic is 32-bit (a 64-bit multiply is
+// four quarter-rate instructions on this chip; the earlier chain of 64-bit mixers cost ~1800 cycles per wave of 28-byte
+// values, more than reading them).  The value is absorbed as LOGICAL little-endian 8-byte words (zero-padded last
+// word; the length goes in at the end), even words into lanes 0/1 and odd words into lanes 2/3; every step is a
+// bijection of the state for a given word and injective in the word for a given state, and the finish is a bijection
+// of the 128-bit state, so values of at most 8 bytes never collide and longer ones do with probability ~2^-128.
+struct Fp {
+  uint32_t h0, h1, h2, h3;
+};
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ void fp_init(Fp &s) {
+  s.h0 = 0x9e3779b9u;
+  s.h1 = 0x7f4a7c15u;
+  s.h2 = 0xc2b2ae3du;
+  s.h3 = 0x27d4eb4fu;
+}
+template <bool ODD>
+__device__ __forceinline__ void fp_absorb(Fp &s, uint64_t w) {
+  uint32_t k0 = (uint32_t)w, k1 = (uint32_t)(w >> 32);
+  k0 *= 0x239b961bu;
+  k0 = rotl32(k0, 15);
+  k0 *= 0xab0e9789u;
+  k1 *= 0x38b34ae5u;
+  k1 = rotl32(k1, 17);
+  k1 *= 0xa1e38b93u;
+  if (!ODD) {
+    s.h0 = (rotl32(s.h0 ^ k0, 19) + s.h1) * 5u + 0x561ccd1bu;
+    s.h1 = (rotl32(s.h1 ^ k1, 17) + s.h2) * 5u + 0x0bcaa747u;
+  } else {
+    s.h2 = (rotl32(s.h2 ^ k0, 15) + s.h3) * 5u + 0x96cd1c35u;
+    s.h3 = (rotl32(s.h3 ^ k1, 13) + s.h0) * 5u + 0x32ac3b17u;
+  }
+}
+__device__ __forceinline__ void fp_finish(Fp s, uint64_t len, uint64_t *fa, uint64_t *fb) {
+  const uint32_t n = (uint32_t)len;
+  s.h0 ^= n;
+  s.h1 ^= n;
+  s.h2 ^= n;
+  s.h3 ^= n ^ (uint32_t)(len >> 32);
+  s.h0 += s.h1 + s.h2 + s.h3;
+  s.h1 += s.h0;
+  s.h2 += s.h0;
+  s.h3 += s.h0;
+  s.h0 = fmix32(s.h0);
+  s.h1 = fmix32(s.h1);
+  s.h2 = fmix32(s.h2);
+  s.h3 = fmix32(s.h3);
+  s.h0 += s.h1 + s.h2 + s.h3;
+  s.h1 += s.h0;
+  s.h2 += s.h0;
+  s.h3 += s.h0;
+  uint64_t a = (uint64_t)s.h0 | ((uint64_t)s.h1 << 32), b = (uint64_t)s.h2 | ((uint64_t)s.h3 << 32);
+  if (a == kEmptyKey) a -= 1;  // (the table's free-slot marker)
+  if (b == kEmptyKey) b -= 1;
+  *fa = a;
+  *fb = b;
+}
+
+// fingerprint of bytes [p, p+len) in global memory
 __device__ __forceinline__ void fingerprint(uintptr_t p, uint64_t len, uint64_t *fa, uint64_t *fb) {
-  uint64_t a = 0x9e3779b97f4a7c15ULL ^ (len * 0xff51afd7ed558ccdULL);
-  uint64_t b = 0xc2b2ae3d27d4eb4fULL ^ (len * 0xc4ceb9fe1a85ec53ULL);
+  Fp s;
+  fp_init(s);
   // logical 8-byte words of the VALUE (independent of where it sits in memory), assembled from the one
   // or two aligned words that hold them; bytes outside the value are never part of w
   uint64_t remaining = len;
-  while (remaining > 0) {
+  auto next = [&]() -> uint64_t {
     const uint32_t nb = remaining < 8 ? (uint32_t)remaining : 8u;
     const uint32_t skip = (uint32_t)(p & 7);
     const uintptr_t base = p & ~(uintptr_t)7;
@@ -46,15 +114,14 @@ __device__ __forceinline__ void fingerprint(uintptr_t p, uint64_t len, uint64_t 
     if (nb < 8) w &= (1ull << (8 * nb)) - 1;
     p += nb;
     remaining -= nb;
-    a = rotl64(a ^ mix64w(w + 0x165667b19e3779f9ULL), 27) * 0x9fb21c651e98df25ULL + 0x2545f4914f6cdd1dULL;
-    b = rotl64(b ^ mix64w(w ^ 0x27d4eb2f165667c5ULL), 31) * 0xd6e8feb86659fd93ULL + 0x85ebca77c2b2ae63ULL;
+    return w;
+  };
+  while (remaining > 0) {
+    fp_absorb<false>(s, next());
+    if (remaining == 0) break;
+    fp_absorb<true>(s, next());
   }
-  a = mix64w(a);
-  b = mix64w(b ^ rotl64(a, 17));
-  if (a == kEmptyKey) a -= 1;
-  if (b == kEmptyKey) b -= 1;
-  *fa = a;
-  *fb = b;
+  fp_finish(s, len, fa, fb);
 }
 
 __device__ __forceinline__ void block_add2w(unsigned long long a, unsigned long long b,
@@ -186,99 +253,196 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
 // ARE the key set until somebody needs the table (a second batch, a merge, an export): fp_insert_kernel then moves
 // them in.  A list that receives more records than it can hold (heavily repeated values) drops them and says so in
 // kCntOutOfRange: the host redoes the batch through the global table (tgx_api.cpp, fp_resolve).
-template <bool FROM_STRINGS>
-__global__ __launch_bounds__(256) void fp_partition_kernel(Utf8ColDesc d, FpLists in, uint32_t tiles_per_list,
-                                                           FpLists out, int shift, unsigned long long *counters) {
+struct FpTileLds {
+  ulonglong2 stage[kFpTile];  // the tile's records: row order first, then grouped by list
+  uint32_t hist[kFpFan], lbase[kFpFan], gpos[kFpFan], lcur[kFpFan];
+  uint32_t wsum[4], dropped;
+};
+
+__device__ __forceinline__ void fp_tile_begin(FpTileLds &s) {
+  s.hist[threadIdx.x] = 0;
+  s.lcur[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s.dropped = 0;
+  __syncthreads();
+}
+
+// records of the tile are in s.stage (kEmptyKey in the first word: none) and counted per list in s.hist; a barrier
+// has passed since.  Groups them by list in LDS and appends every run to its list with ONE reservation per list.
+__device__ __forceinline__ void fp_tile_scatter(FpTileLds &s, uint32_t out_list0, const FpLists &out, int shift,
+                                                unsigned long long *counters) {
   constexpr int PER = kFpTile / 256;
-  __shared__ ulonglong2 stage[kFpTile];
-  __shared__ uint32_t hist[kFpFan], lbase[kFpFan], gpos[kFpFan], lcur[kFpFan];
-  __shared__ uint32_t wsum[4], dropped;
   const uint32_t tid = threadIdx.x;
-  int64_t first, count;
-  uint32_t in_list = 0;
-  if (FROM_STRINGS) {
-    first = (int64_t)blockIdx.x * kFpTile;
-    count = d.length - first;
-  } else {
-    in_list = blockIdx.x / tiles_per_list;
-    first = (int64_t)(blockIdx.x % tiles_per_list) * kFpTile;
-    const uint64_t have = in.offered[in_list];
-    count = (int64_t)(have < in.cap ? have : in.cap) - first;
-    if (count <= 0) return;
-  }
-  if (count > kFpTile) count = kFpTile;
-  hist[tid] = 0;
-  lcur[tid] = 0;
-  if (tid == 0) dropped = 0;
-  __syncthreads();
-  // ---- the tile's records into LDS (row order) + records per list ----
-  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
-  for (int k = 0; k < PER; k++) {
-    const int pos = k * 256 + (int)tid;
-    ulonglong2 r;
-    r.x = kEmptyKey;  // (no fingerprint's first word: fingerprint())
-    r.y = 0;
-    if (pos < count) {
-      if (FROM_STRINGS) {
-        const int64_t slot = d.offset + first + pos;
-        if (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1)) {
-          uintptr_t p;
-          uint64_t len, fa, fb;
-          utf8_value(d, slot, &p, &len);
-          fingerprint(p, len, &fa, &fb);
-          r.x = fa;
-          r.y = fb;
-        }
-      } else {
-        r = ((const ulonglong2 *)in.recs)[(uint64_t)in_list * in.cap + (uint64_t)(first + pos)];
-      }
-    }
-    if (r.x != kEmptyKey) atomicAdd(&hist[(r.x >> shift) & (kFpFan - 1)], 1u);
-    stage[pos] = r;
-  }
-  __syncthreads();
-  // ---- where each list's run starts in the tile, and ONE reservation per touched list ----
-  const uint32_t h = hist[tid];
+  const uint32_t h = s.hist[tid];
   uint32_t incl = h;
 #pragma unroll
   for (int dlt = 1; dlt < 64; dlt <<= 1) {
     const uint32_t up = __shfl_up(incl, dlt, 64);
     if ((tid & 63) >= (uint32_t)dlt) incl += up;
   }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  if ((tid & 63) == 63) s.wsum[tid >> 6] = incl;
   ulonglong2 mine[PER];
 #pragma unroll
-  for (int k = 0; k < PER; k++) mine[k] = stage[k * 256 + tid];
+  for (int k = 0; k < PER; k++) mine[k] = s.stage[k * 256 + tid];
   __syncthreads();  // wsum is there; everyone holds its records
   uint32_t excl = incl - h;
-  for (uint32_t w = 0; w < (tid >> 6); w++) excl += wsum[w];
-  lbase[tid] = excl;
-  const uint32_t out_list0 = FROM_STRINGS ? 0u : in_list * kFpFan;
-  gpos[tid] = h ? atomicAdd(&out.offered[out_list0 + tid], h) : 0u;
-  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  for (uint32_t w = 0; w < (tid >> 6); w++) excl += s.wsum[w];
+  s.lbase[tid] = excl;
+  s.gpos[tid] = h ? atomicAdd(&out.offered[out_list0 + tid], h) : 0u;
+  const uint32_t total = s.wsum[0] + s.wsum[1] + s.wsum[2] + s.wsum[3];
   __syncthreads();
-  // ---- grouped by list in LDS ----
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     if (mine[k].x == kEmptyKey) continue;
     const uint32_t b = (uint32_t)(mine[k].x >> shift) & (kFpFan - 1);
-    stage[lbase[b] + atomicAdd(&lcur[b], 1u)] = mine[k];
+    s.stage[s.lbase[b] + atomicAdd(&s.lcur[b], 1u)] = mine[k];
   }
   __syncthreads();
-  // ---- runs out, 16 bytes per lane ----
+  // runs out, 16 bytes per lane
   bool lost = false;
   for (uint32_t p = tid; p < total; p += 256) {
-    const ulonglong2 r = stage[p];
+    const ulonglong2 r = s.stage[p];
     const uint32_t b = (uint32_t)(r.x >> shift) & (kFpFan - 1);
-    const uint64_t at = (uint64_t)gpos[b] + (p - lbase[b]);
+    const uint64_t at = (uint64_t)s.gpos[b] + (p - s.lbase[b]);
     if (at < out.cap)
       ((ulonglong2 *)out.recs)[(uint64_t)(out_list0 + b) * out.cap + at] = r;
     else
       lost = true;
   }
-  if (lost) dropped = 1;  // (same value from every writer)
+  if (lost) s.dropped = 1;  // (same value from every writer)
   __syncthreads();
-  if (tid == 0 && dropped) atomicAdd(&counters[kCntOutOfRange], 1ull);
+  if (tid == 0 && s.dropped) atomicAdd(&counters[kCntOutOfRange], 1ull);
+}
+
+// fingerprint() of a value staged in LDS at byte `o` of `stage` (same words, same result)
+__device__ __forceinline__ void fingerprint_lds(const uint8_t *stage, uint32_t o, uint32_t len, uint64_t *fa,
+                                                uint64_t *fb) {
+  Fp s;
+  fp_init(s);
+  uint32_t remaining = len;
+  auto next = [&]() -> uint64_t {
+    const uint32_t nb = remaining < 8 ? remaining : 8u;
+    const uint32_t skip = o & 7, base = o & ~7u;
+    uint64_t w = *(const uint64_t *)(stage + base) >> (8 * skip);
+    if (skip + nb > 8) w |= *(const uint64_t *)(stage + base + 8) << (8 * (8 - skip));
+    if (nb < 8) w &= (1ull << (8 * nb)) - 1;
+    o += nb;
+    remaining -= nb;
+    return w;
+  };
+  while (remaining > 0) {
+    fp_absorb<false>(s, next());
+    if (remaining == 0) break;
+    fp_absorb<true>(s, next());
+  }
+  fp_finish(s, (uint64_t)len, fa, fb);
+}
+
+constexpr uint32_t kFpStageBytes = 4096;  // value bytes of 128 consecutive rows a wave stages at a time
+
+// level 1: a tile of rows -> fingerprints -> the kFpFan lists of bits [56, 64).  A wave takes 128 consecutive rows a
+// step, two per lane; their bytes are one span of the value buffer, copied into LDS with 16-byte loads and
+// fingerprinted from there (per-lane global loads at a ~28-byte stride read the column at 1.5 TB/s).  A span that
+// does not fit the stage is fingerprinted straight from global memory.
+__global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d, FpLists out,
+                                                                    unsigned long long *counters) {
+  constexpr int kRowsPerWave = kFpTile / 4, kSteps = kRowsPerWave / 128;
+  __shared__ FpTileLds s;
+  __shared__ __attribute__((aligned(16))) uint8_t bytes[4][kFpStageBytes + 32];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint8_t *stage = bytes[wave];
+  fp_tile_begin(s);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  const uintptr_t data0 = (uintptr_t)d.data;
+  const int64_t wave_first = (int64_t)blockIdx.x * kFpTile + (int64_t)wave * kRowsPerWave;
+  auto offset_at = [&](int64_t row) -> int64_t {  // rows past the end read the end offset: they come out empty
+    const int64_t slot = d.offset + (row < d.length ? row : d.length);
+    return d.large_offsets ? ((global_i64_ptr)(uintptr_t)d.offsets)[slot]
+                           : (int64_t)((global_i32_ptr)(uintptr_t)d.offsets)[slot];
+  };
+  auto valid_at = [&](int64_t row) -> bool {
+    if (row >= d.length) return false;
+    const int64_t slot = d.offset + row;
+    return !vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1);
+  };
+  struct Step {
+    int64_t b0, b1, tail;
+    bool v0, v1;
+  };
+  auto fetch = [&](int step) -> Step {
+    Step t;
+    const int64_t i0 = wave_first + step * 128 + lane;
+    t.b0 = offset_at(i0);
+    t.b1 = offset_at(i0 + 64);
+    t.tail = offset_at(wave_first + step * 128 + 128);
+    t.v0 = valid_at(i0);
+    t.v1 = valid_at(i0 + 64);
+    return t;
+  };
+  Step nxt = fetch(0);
+  for (int step = 0; step < kSteps; step++) {
+    const Step cur = nxt;
+    if (step + 1 < kSteps) nxt = fetch(step + 1);  // requested before this step's bytes are staged
+    // (every shuffle with all lanes active: a row's end is the next row's start)
+    const int64_t next0 = __shfl_down(cur.b0, 1, 64), next1 = __shfl_down(cur.b1, 1, 64);
+    const int64_t first1 = __shfl(cur.b1, 0, 64), b_first = __shfl(cur.b0, 0, 64);
+    const int64_t e0 = lane < 63 ? next0 : first1, e1 = lane < 63 ? next1 : cur.tail;
+    const int64_t base = b_first - (int64_t)((data0 + (uintptr_t)b_first) & 15);
+    ulonglong2 r0, r1;
+    r0.x = r1.x = kEmptyKey;
+    r0.y = r1.y = 0;
+    if (cur.tail - base <= (int64_t)kFpStageBytes) {  // wave-uniform
+      // 16-byte blocks by ABSOLUTE address: a block that holds a byte of the buffer lies in the buffer's pages
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
+      global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)base);
+      const int64_t n16 = (cur.tail - base + 15) >> 4;
+      for (int64_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + 16 * k) = src[k];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (cur.v0) fingerprint_lds(stage, (uint32_t)(cur.b0 - base), (uint32_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
+      if (cur.v1) fingerprint_lds(stage, (uint32_t)(cur.b1 - base), (uint32_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
+    } else {
+      if (cur.v0) fingerprint(data0 + (uintptr_t)cur.b0, (uint64_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
+      if (cur.v1) fingerprint(data0 + (uintptr_t)cur.b1, (uint64_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
+    }
+    const uint32_t pos = wave * kRowsPerWave + step * 128 + lane;
+    if (r0.x != kEmptyKey) atomicAdd(&s.hist[r0.x >> 56], 1u);
+    if (r1.x != kEmptyKey) atomicAdd(&s.hist[r1.x >> 56], 1u);
+    s.stage[pos] = r0;
+    s.stage[pos + 64] = r1;
+  }
+  __syncthreads();
+  fp_tile_scatter(s, 0u, out, 56, counters);
+}
+
+// level 2: a tile of one level-1 list -> the kFpFan lists of bits [48, 56) under it
+__global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uint32_t tiles_per_list, FpLists out,
+                                                                  unsigned long long *counters) {
+  constexpr int PER = kFpTile / 256;
+  __shared__ FpTileLds s;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t in_list = blockIdx.x / tiles_per_list;
+  const int64_t first = (int64_t)(blockIdx.x % tiles_per_list) * kFpTile;
+  const uint64_t have = in.offered[in_list];
+  int64_t count = (int64_t)(have < in.cap ? have : in.cap) - first;
+  if (count <= 0) return;
+  if (count > kFpTile) count = kFpTile;
+  fp_tile_begin(s);
+  const ulonglong2 *src = (const ulonglong2 *)in.recs + (uint64_t)in_list * in.cap + (uint64_t)first;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int pos = k * 256 + (int)tid;
+    ulonglong2 r;
+    r.x = kEmptyKey;
+    r.y = 0;
+    if (pos < count) r = src[pos];
+    if (r.x != kEmptyKey) atomicAdd(&s.hist[(r.x >> 48) & (kFpFan - 1)], 1u);
+    s.stage[pos] = r;
+  }
+  __syncthreads();
+  fp_tile_scatter(s, in_list * kFpFan, out, 48, counters);
 }
 
 // one workgroup per final list: distinct keys / keys seen twice of the list -> per_list[list]
@@ -603,18 +767,14 @@ void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const
   d.length = length;
   d.large_offsets = large_offsets;
   const int64_t tiles = (length + kFpTile - 1) / kFpTile;
-  FpLists none{nullptr, nullptr, 0};
-  hipLaunchKernelGGL(fp_partition_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, stream, d, none, 1u, level1, 56,
-                     d_counters);
+  hipLaunchKernelGGL(fp_partition_strings_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
 }
 
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
                                hipStream_t stream) {
-  Utf8ColDesc d;
-  memset(&d, 0, sizeof(d));
   const uint32_t tiles_per_list = (uint32_t)((level1.cap + kFpTile - 1) / kFpTile);
-  hipLaunchKernelGGL(fp_partition_kernel<false>, dim3(kFpFan * tiles_per_list), dim3(256), 0, stream, d, level1,
-                     tiles_per_list, level2, 48, d_counters);
+  hipLaunchKernelGGL(fp_partition_lists_kernel, dim3(kFpFan * tiles_per_list), dim3(256), 0, stream, level1,
+                     tiles_per_list, level2, d_counters);
 }
 
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,

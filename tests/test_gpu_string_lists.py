@@ -59,6 +59,26 @@ def test_without_multiplicity_and_without_validity(low_threshold):
     assert (res[0].total, res[0].non_null, res[0].distinct) == (want.total, want.non_null, want.distinct)
 
 
+def test_long_values_that_do_not_fit_the_stage(low_threshold):
+    """128 consecutive values of more than 4 KiB in all are fingerprinted from global memory, shorter stretches from
+    LDS: the two must agree (the same value appears in both kinds of stretch)"""
+    rng = np.random.default_rng(11)
+    vals = []
+    for block in range(300):
+        long_block = block % 3 == 0
+        for i in range(128):
+            k = int(rng.integers(0, 5000))
+            vals.append(("L%d-" % k) + "y" * ((k % 200) if long_block else (k % 9)) if k % 17 else None)
+        vals.append("q" * 5000 if block % 50 == 0 else "")  # (shifts the 128-row steps against the blocks)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.distinct_utf8(offs, data, validity)
+    for large in (False, True):
+        res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)],
+                         utf8_column(offs, data, validity, True, large=large))
+        assert took_lists(st) == 1
+        check(res[0], want)
+
+
 def test_sliced_column(low_threshold):
     rng = np.random.default_rng(6)
     vals = make_strings(rng, 90_000, 10**9)
