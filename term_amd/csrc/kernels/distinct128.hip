@@ -254,25 +254,29 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
 // them in.  A list that receives more records than it can hold (heavily repeated values) drops them and says so in
 // kCntOutOfRange: the host redoes the batch through the global table (tgx_api.cpp, fp_resolve).
 struct FpTileLds {
-  ulonglong2 stage[kFpTile];  // the tile's records: row order first, then grouped by list
-  uint32_t hist[kFpFan], lbase[kFpFan], gpos[kFpFan], lcur[kFpFan];
+  ulonglong2 stage[kFpTile];  // the tile's records grouped by list (level 1: first the waves' value bytes)
+  uint32_t hist[kFpFan];      // records per list, then the placement cursors
+  uint32_t lbase[kFpFan];     // where the list's run starts in `stage`
+  uint32_t delta[kFpFan];     // position in the global list - position in `stage`
   uint32_t wsum[4], dropped;
 };
 
 __device__ __forceinline__ void fp_tile_begin(FpTileLds &s) {
   s.hist[threadIdx.x] = 0;
-  s.lcur[threadIdx.x] = 0;
   if (threadIdx.x == 0) s.dropped = 0;
   __syncthreads();
 }
 
-// records of the tile are in s.stage (kEmptyKey in the first word: none) and counted per list in s.hist; a barrier
-// has passed since.  Groups them by list in LDS and appends every run to its list with ONE reservation per list.
-__device__ __forceinline__ void fp_tile_scatter(FpTileLds &s, uint32_t out_list0, const FpLists &out, int shift,
-                                                unsigned long long *counters) {
+// The tile's records are in registers (kEmptyKey in the first word: none) and counted per list in s.hist; a barrier
+// has passed since, and nobody reads s.stage any more.  Groups them by list in LDS and appends every run to its
+// list with ONE reservation per list.
+__device__ __forceinline__ void fp_tile_scatter(FpTileLds &s, const ulonglong2 (&mine)[kFpTile / 256], uint32_t out_list0,
+                                                const FpLists &out, int shift, unsigned long long *counters) {
   constexpr int PER = kFpTile / 256;
   const uint32_t tid = threadIdx.x;
   const uint32_t h = s.hist[tid];
+  // (the reservation's round trip runs under the scan and the regrouping: only the stores need its result)
+  const uint32_t reserved = h ? atomicAdd(&out.offered[out_list0 + tid], h) : 0u;
   uint32_t incl = h;
 #pragma unroll
   for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -280,29 +284,27 @@ __device__ __forceinline__ void fp_tile_scatter(FpTileLds &s, uint32_t out_list0
     if ((tid & 63) >= (uint32_t)dlt) incl += up;
   }
   if ((tid & 63) == 63) s.wsum[tid >> 6] = incl;
-  ulonglong2 mine[PER];
-#pragma unroll
-  for (int k = 0; k < PER; k++) mine[k] = s.stage[k * 256 + tid];
-  __syncthreads();  // wsum is there; everyone holds its records
+  __syncthreads();  // wsum is there; everyone has read its count
   uint32_t excl = incl - h;
   for (uint32_t w = 0; w < (tid >> 6); w++) excl += s.wsum[w];
   s.lbase[tid] = excl;
-  s.gpos[tid] = h ? atomicAdd(&out.offered[out_list0 + tid], h) : 0u;
+  s.hist[tid] = excl;  // becomes the placement cursor
   const uint32_t total = s.wsum[0] + s.wsum[1] + s.wsum[2] + s.wsum[3];
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     if (mine[k].x == kEmptyKey) continue;
     const uint32_t b = (uint32_t)(mine[k].x >> shift) & (kFpFan - 1);
-    s.stage[s.lbase[b] + atomicAdd(&s.lcur[b], 1u)] = mine[k];
+    s.stage[atomicAdd(&s.hist[b], 1u)] = mine[k];
   }
+  s.delta[tid] = reserved - excl;
   __syncthreads();
   // runs out, 16 bytes per lane
   bool lost = false;
   for (uint32_t p = tid; p < total; p += 256) {
     const ulonglong2 r = s.stage[p];
     const uint32_t b = (uint32_t)(r.x >> shift) & (kFpFan - 1);
-    const uint64_t at = (uint64_t)s.gpos[b] + (p - s.lbase[b]);
+    const uint64_t at = (uint64_t)(uint32_t)(p + s.delta[b]);
     if (at < out.cap)
       ((ulonglong2 *)out.recs)[(uint64_t)(out_list0 + b) * out.cap + at] = r;
     else
@@ -313,43 +315,73 @@ __device__ __forceinline__ void fp_tile_scatter(FpTileLds &s, uint32_t out_list0
   if (tid == 0 && s.dropped) atomicAdd(&counters[kCntOutOfRange], 1ull);
 }
 
-// fingerprint() of a value staged in LDS at byte `o` of `stage` (same words, same result)
-__device__ __forceinline__ void fingerprint_lds(const uint8_t *stage, uint32_t o, uint32_t len, uint64_t *fa,
-                                                uint64_t *fb) {
-  Fp s;
-  fp_init(s);
-  uint32_t remaining = len;
-  auto next = [&]() -> uint64_t {
-    const uint32_t nb = remaining < 8 ? remaining : 8u;
-    const uint32_t skip = o & 7, base = o & ~7u;
-    uint64_t w = *(const uint64_t *)(stage + base) >> (8 * skip);
-    if (skip + nb > 8) w |= *(const uint64_t *)(stage + base + 8) << (8 * (8 - skip));
+constexpr uint32_t kFpStageBytes = 4080;  // value bytes of 128 consecutive rows a wave stages at a time (255 blocks)
+constexpr uint32_t kFpStageAlloc = 4096 + 32;  // what the stage holds: 4 blocks per lane + slack for the read-ahead
+
+// fingerprint() of TWO values staged in LDS (same words, same results), walked in lockstep and without branches in
+// the loop body: both chains and all their LDS reads are in flight together.  A value that has ended keeps reading
+// (and discarding) what follows it; the addresses are kept inside the stage.
+__device__ __forceinline__ void fingerprint_lds2(const uint8_t *stage, uint32_t o0, uint32_t len0, uint32_t o1,
+                                                 uint32_t len1, ulonglong2 *f0, ulonglong2 *f1) {
+  Fp s0, s1;
+  fp_init(s0);
+  fp_init(s1);
+  uint32_t r0 = len0, r1 = len1;
+  auto word = [&](uint32_t &o, uint32_t &rem, bool *live) -> uint64_t {
+    *live = rem > 0;
+    const uint32_t nb = rem < 8 ? rem : 8u;
+    const uint32_t skip = o & 7;
+    uint32_t base = o & ~7u;
+    base = base < 4096u + 16u ? base : 4096u + 16u;
+    const uint64_t lo = *(const uint64_t *)(stage + base), hi = *(const uint64_t *)(stage + base + 8);
+    uint64_t w = lo >> (8 * skip);
+    if (skip) w |= hi << (8 * (8 - skip));  // (bytes past the value are masked off below)
     if (nb < 8) w &= (1ull << (8 * nb)) - 1;
     o += nb;
-    remaining -= nb;
+    rem -= nb;
     return w;
   };
-  while (remaining > 0) {
-    fp_absorb<false>(s, next());
-    if (remaining == 0) break;
-    fp_absorb<true>(s, next());
+  while ((r0 | r1) != 0) {
+    bool l0, l1;
+    uint64_t w0 = word(o0, r0, &l0), w1 = word(o1, r1, &l1);
+    Fp t0 = s0, t1 = s1;
+    fp_absorb<false>(t0, w0);
+    fp_absorb<false>(t1, w1);
+    s0.h0 = l0 ? t0.h0 : s0.h0;
+    s0.h1 = l0 ? t0.h1 : s0.h1;
+    s1.h0 = l1 ? t1.h0 : s1.h0;
+    s1.h1 = l1 ? t1.h1 : s1.h1;
+    w0 = word(o0, r0, &l0);
+    w1 = word(o1, r1, &l1);
+    t0 = s0;
+    t1 = s1;
+    fp_absorb<true>(t0, w0);
+    fp_absorb<true>(t1, w1);
+    s0.h2 = l0 ? t0.h2 : s0.h2;
+    s0.h3 = l0 ? t0.h3 : s0.h3;
+    s1.h2 = l1 ? t1.h2 : s1.h2;
+    s1.h3 = l1 ? t1.h3 : s1.h3;
   }
-  fp_finish(s, (uint64_t)len, fa, fb);
+  fp_finish(s0, (uint64_t)len0, (uint64_t *)&f0->x, (uint64_t *)&f0->y);
+  fp_finish(s1, (uint64_t)len1, (uint64_t *)&f1->x, (uint64_t *)&f1->y);
 }
-
-constexpr uint32_t kFpStageBytes = 4096;  // value bytes of 128 consecutive rows a wave stages at a time
 
 // level 1: a tile of rows -> fingerprints -> the kFpFan lists of bits [56, 64).  A wave takes 128 consecutive rows a
 // step, two per lane; their bytes are one span of the value buffer, copied into LDS with 16-byte loads and
-// fingerprinted from there (per-lane global loads at a ~28-byte stride read the column at 1.5 TB/s).  A span that
-// does not fit the stage is fingerprinted straight from global memory.
+// fingerprinted from there (per-lane global loads at a ~28-byte stride read the column at 1.5 TB/s).  The pipeline
+// is three steps deep: offsets of step s+2 and bytes of step s+1 (in registers) are in flight while step s is
+// fingerprinted.  A span that does not fit the stage is fingerprinted straight from global memory.
 __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d, FpLists out,
                                                                     unsigned long long *counters) {
   constexpr int kRowsPerWave = kFpTile / 4, kSteps = kRowsPerWave / 128;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
   __shared__ FpTileLds s;
-  __shared__ __attribute__((aligned(16))) uint8_t bytes[4][kFpStageBytes + 32];
+  static_assert(kFpStageAlloc <= kRowsPerWave * sizeof(ulonglong2), "a wave's value bytes fit its share of the tile");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint8_t *stage = bytes[wave];
+  // the records stay in registers until every wave is through its rows: until then the tile's LDS holds value bytes
+  uint8_t *stage = (uint8_t *)&s.stage[wave * kRowsPerWave];
+  ulonglong2 mine[kFpTile / 256];
   fp_tile_begin(s);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   const uintptr_t data0 = (uintptr_t)d.data;
@@ -378,43 +410,71 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
     t.v1 = valid_at(i0 + 64);
     return t;
   };
-  Step nxt = fetch(0);
+  // the span of a step's values: [base, tail), base rounded down to a 16-byte block by ABSOLUTE address (a block that
+  // holds a byte of the buffer lies in the buffer's pages)
+  auto span_of = [&](const Step &t, int64_t *base) -> bool {
+    const int64_t b_first = __shfl(t.b0, 0, 64);
+    *base = b_first - (int64_t)((data0 + (uintptr_t)b_first) & 15);
+    return t.tail - *base <= (int64_t)kFpStageBytes;  // wave-uniform
+  };
+  u32x4 pre[4];
+  auto load_bytes = [&](int64_t base, int64_t tail) {
+    global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)base);
+    const int64_t n16 = (tail - base + 15) >> 4;  // <= 255
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t k = lane + 64 * j;
+      pre[j] = k < n16 ? src[k] : (u32x4)0u;
+    }
+  };
+  Step cur = fetch(0), nxt = fetch(1);
+  int64_t base_cur = 0;
+  bool fit_cur = span_of(cur, &base_cur);
+  if (fit_cur) load_bytes(base_cur, cur.tail);
+#pragma unroll
   for (int step = 0; step < kSteps; step++) {
-    const Step cur = nxt;
-    if (step + 1 < kSteps) nxt = fetch(step + 1);  // requested before this step's bytes are staged
-    // (every shuffle with all lanes active: a row's end is the next row's start)
-    const int64_t next0 = __shfl_down(cur.b0, 1, 64), next1 = __shfl_down(cur.b1, 1, 64);
-    const int64_t first1 = __shfl(cur.b1, 0, 64), b_first = __shfl(cur.b0, 0, 64);
-    const int64_t e0 = lane < 63 ? next0 : first1, e1 = lane < 63 ? next1 : cur.tail;
-    const int64_t base = b_first - (int64_t)((data0 + (uintptr_t)b_first) & 15);
-    ulonglong2 r0, r1;
-    r0.x = r1.x = kEmptyKey;
-    r0.y = r1.y = 0;
-    if (cur.tail - base <= (int64_t)kFpStageBytes) {  // wave-uniform
-      // 16-byte blocks by ABSOLUTE address: a block that holds a byte of the buffer lies in the buffer's pages
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
-      global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)base);
-      const int64_t n16 = (cur.tail - base + 15) >> 4;
-      for (int64_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + 16 * k) = src[k];
+    if (fit_cur) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) *(u32x4 *)(stage + 16 * (lane + 64 * j)) = pre[j];
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (cur.v0) fingerprint_lds(stage, (uint32_t)(cur.b0 - base), (uint32_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
-      if (cur.v1) fingerprint_lds(stage, (uint32_t)(cur.b1 - base), (uint32_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
+    }
+    Step after = nxt;
+    if (step + 2 < kSteps) after = fetch(step + 2);
+    int64_t base_nxt = 0;
+    bool fit_nxt = false;
+    if (step + 1 < kSteps) {
+      fit_nxt = span_of(nxt, &base_nxt);
+      if (fit_nxt) load_bytes(base_nxt, nxt.tail);  // lands while this step is fingerprinted
+    }
+    // (every shuffle with all lanes active: a row's end is the next row's start)
+    const int64_t next0 = __shfl_down(cur.b0, 1, 64), next1 = __shfl_down(cur.b1, 1, 64);
+    const int64_t first1 = __shfl(cur.b1, 0, 64);
+    const int64_t e0 = lane < 63 ? next0 : first1, e1 = lane < 63 ? next1 : cur.tail;
+    ulonglong2 r0, r1;
+    if (fit_cur) {
+      fingerprint_lds2(stage, (uint32_t)(cur.b0 - base_cur), cur.v0 ? (uint32_t)(e0 - cur.b0) : 0u,
+                       (uint32_t)(cur.b1 - base_cur), cur.v1 ? (uint32_t)(e1 - cur.b1) : 0u, &r0, &r1);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
     } else {
+      r0.x = r1.x = kEmptyKey;
       if (cur.v0) fingerprint(data0 + (uintptr_t)cur.b0, (uint64_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
       if (cur.v1) fingerprint(data0 + (uintptr_t)cur.b1, (uint64_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
     }
-    const uint32_t pos = wave * kRowsPerWave + step * 128 + lane;
+    if (!cur.v0) r0.x = kEmptyKey;
+    if (!cur.v1) r1.x = kEmptyKey;
     if (r0.x != kEmptyKey) atomicAdd(&s.hist[r0.x >> 56], 1u);
     if (r1.x != kEmptyKey) atomicAdd(&s.hist[r1.x >> 56], 1u);
-    s.stage[pos] = r0;
-    s.stage[pos + 64] = r1;
+    mine[2 * step] = r0;
+    mine[2 * step + 1] = r1;
+    cur = nxt;
+    nxt = after;
+    base_cur = base_nxt;
+    fit_cur = fit_nxt;
   }
   __syncthreads();
-  fp_tile_scatter(s, 0u, out, 56, counters);
+  fp_tile_scatter(s, mine, 0u, out, 56, counters);
 }
 
 // level 2: a tile of one level-1 list -> the kFpFan lists of bits [48, 56) under it
@@ -431,56 +491,55 @@ __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uin
   if (count > kFpTile) count = kFpTile;
   fp_tile_begin(s);
   const ulonglong2 *src = (const ulonglong2 *)in.recs + (uint64_t)in_list * in.cap + (uint64_t)first;
+  ulonglong2 mine[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const int pos = k * 256 + (int)tid;
-    ulonglong2 r;
-    r.x = kEmptyKey;
-    r.y = 0;
-    if (pos < count) r = src[pos];
-    if (r.x != kEmptyKey) atomicAdd(&s.hist[(r.x >> 48) & (kFpFan - 1)], 1u);
-    s.stage[pos] = r;
+    mine[k].x = kEmptyKey;
+    mine[k].y = 0;
+    if (pos < count) mine[k] = src[pos];
   }
+#pragma unroll
+  for (int k = 0; k < PER; k++)
+    if (mine[k].x != kEmptyKey) atomicAdd(&s.hist[(mine[k].x >> 48) & (kFpFan - 1)], 1u);
   __syncthreads();
-  fp_tile_scatter(s, in_list * kFpFan, out, 48, counters);
+  fp_tile_scatter(s, mine, in_list * kFpFan, out, 48, counters);
 }
 
 // one workgroup per final list: distinct keys / keys seen twice of the list -> per_list[list]
 __global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list) {
-  // the table keeps first words only; the record that owns a slot is named beside it and its second word is read
-  // back from the list (it has just come through this CU's caches) in the one-in-2^48 case of equal first words
-  __shared__ unsigned long long ka[kFpSlots];
-  __shared__ uint32_t kown[kFpSlots];
+  // a slot is (32 bits of the first word) << 32 | index of the record that owns it: ONE compare-and-swap claims it and
+  // names the owner.  Equal tags are settled by reading the owner's record back from the list (it has just come
+  // through this CU's caches): the other 60-odd bits the tag, the slot and the list imply almost always differ.
+  __shared__ unsigned long long slot[kFpSlots];
   __shared__ uint32_t dupw[kFpSlots / 32];
   __shared__ uint32_t s_new[4], s_dup[4];
+  constexpr unsigned long long kFree = ~0ull;  // (no record has index 2^32 - 1)
   const uint32_t tid = threadIdx.x;
   const uint32_t offered = l.offered[blockIdx.x];
   if (offered == 0 || offered > l.cap) {  // (an overflowed list was flagged by the kernel that filled it)
     if (tid == 0) per_list[blockIdx.x] = make_uint2(0, 0);
     return;
   }
-  for (uint32_t s = tid; s < kFpSlots; s += 256) {
-    ka[s] = kEmptyKey;
-    kown[s] = 0xFFFFFFFFu;
-  }
+  for (uint32_t k = tid; k < kFpSlots; k += 256) slot[k] = kFree;
   if (tid < kFpSlots / 32) dupw[tid] = 0;
   __syncthreads();
   const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
   uint32_t n_new = 0, n_dup = 0;
   for (uint32_t i = tid; i < offered; i += 256) {
     const ulonglong2 r = recs[i];
-    uint32_t hs = (uint32_t)(r.x >> 20) & (kFpSlots - 1);
+    const uint32_t tag = (uint32_t)r.x;
+    const unsigned long long mine = ((unsigned long long)tag << 32) | i;
+    uint32_t hs = (uint32_t)(r.x >> 32) & (kFpSlots - 1);
     for (;;) {
-      const unsigned long long old = atomicCAS(&ka[hs], (unsigned long long)kEmptyKey, (unsigned long long)r.x);
-      if (old == kEmptyKey) {
-        __hip_atomic_store(&kown[hs], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long old = atomicCAS(&slot[hs], kFree, mine);
+      if (old == kFree) {
         n_new++;
         break;
       }
-      if (old == r.x) {
-        const uint32_t owner = __hip_atomic_load(&kown[hs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (owner == 0xFFFFFFFFu) continue;  // claimed, owner on its way: look at this slot again
-        if (recs[owner].y == r.y) {
+      if ((uint32_t)(old >> 32) == tag) {
+        const ulonglong2 o = recs[(uint32_t)old];
+        if (o.x == r.x && o.y == r.y) {
           if (want_mult) {
             const uint32_t bit = 1u << (hs & 31);
             const uint32_t prev = atomicOr(&dupw[hs >> 5], bit);
@@ -506,17 +565,17 @@ __global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult,
     per_list[blockIdx.x] = make_uint2(s_new[0] + s_new[1] + s_new[2] + s_new[3], s_dup[0] + s_dup[1] + s_dup[2] + s_dup[3]);
 }
 
-// one workgroup: the batch's counts into the task's counters (valid rows = records offered to the first level)
-__global__ __launch_bounds__(1024) void fp_totals_kernel(const uint2 *per_list, uint32_t n_lists, const uint32_t *offered1,
-                                                         unsigned long long *counters) {
-  __shared__ unsigned long long s[3][16];
+// the batch's counts into the task's counters (valid rows = records offered to the first level)
+__global__ __launch_bounds__(256) void fp_totals_kernel(const uint2 *per_list, uint32_t n_lists, const uint32_t *offered1,
+                                                        unsigned long long *counters) {
+  __shared__ unsigned long long s[3][4];
   unsigned long long a = 0, b = 0, v = 0;
-  for (uint32_t i = threadIdx.x; i < n_lists; i += 1024) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_lists; i += gridDim.x * 256) {
     const uint2 c = per_list[i];
     a += c.x;
     b += c.y;
   }
-  if (threadIdx.x < kFpFan) v = offered1[threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x < kFpFan) v = offered1[threadIdx.x];
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
     a += __shfl_down(a, dlt, 64);
@@ -530,10 +589,9 @@ __global__ __launch_bounds__(1024) void fp_totals_kernel(const uint2 *per_list, 
   }
   __syncthreads();
   if (threadIdx.x < 3) {
-    unsigned long long t = 0;
-    for (int w = 0; w < 16; w++) t += s[threadIdx.x][w];
-    const int slot = threadIdx.x == 0 ? kCntDistinct : threadIdx.x == 1 ? kCntTwice : kCntValidRows;
-    counters[slot] += t;  // (the only writer of these slots while the lists hold the set)
+    const unsigned long long t = s[threadIdx.x][0] + s[threadIdx.x][1] + s[threadIdx.x][2] + s[threadIdx.x][3];
+    const int at = threadIdx.x == 0 ? kCntDistinct : threadIdx.x == 1 ? kCntTwice : kCntValidRows;
+    if (t) atomicAdd(&counters[at], t);
   }
 }
 
@@ -780,7 +838,7 @@ void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, uns
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
                      unsigned long long *d_counters, hipStream_t stream) {
   hipLaunchKernelGGL(fp_count_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, want_mult, per_list);
-  hipLaunchKernelGGL(fp_totals_kernel, dim3(1), dim3(1024), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan), offered1,
+  hipLaunchKernelGGL(fp_totals_kernel, dim3(64), dim3(256), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan), offered1,
                      d_counters);
 }
 
