@@ -508,48 +508,67 @@ __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uin
 
 // one workgroup per final list: distinct keys / keys seen twice of the list -> per_list[list]
 __global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list) {
-  // a slot is (32 bits of the first word) << 32 | index of the record that owns it: ONE compare-and-swap claims it and
-  // names the owner.  Equal tags are settled by reading the owner's record back from the list (it has just come
-  // through this CU's caches): the other 60-odd bits the tag, the slot and the list imply almost always differ.
-  __shared__ unsigned long long slot[kFpSlots];
+  // a slot is (16 bits of the first word) << 16 | index of the record that owns it: ONE 32-bit compare-and-swap claims
+  // it and names the owner (16 KiB of table: eight workgroups a CU).  Equal tags are settled by reading the owner's
+  // record back from the list (it has just come through this CU's caches); tag, slot and list together fix 44 bits,
+  // so that read is rare unless the values really are equal.
+  static_assert(kFpListMax <= 0xFFFFu, "a record index fits 16 bits");
+  __shared__ uint32_t slot[kFpSlots];
   __shared__ uint32_t dupw[kFpSlots / 32];
   __shared__ uint32_t s_new[4], s_dup[4];
-  constexpr unsigned long long kFree = ~0ull;  // (no record has index 2^32 - 1)
+  constexpr uint32_t kFree = 0xFFFFFFFFu;  // (no record has index 0xFFFF)
   const uint32_t tid = threadIdx.x;
   const uint32_t offered = l.offered[blockIdx.x];
   if (offered == 0 || offered > l.cap) {  // (an overflowed list was flagged by the kernel that filled it)
     if (tid == 0) per_list[blockIdx.x] = make_uint2(0, 0);
     return;
   }
+  const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  constexpr int kAhead = 4;  // records a thread requests before it inserts the first
+  ulonglong2 r[kAhead];
+#pragma unroll
+  for (int j = 0; j < kAhead; j++)
+    if (tid + 256 * j < offered) r[j] = recs[tid + 256 * j];
   for (uint32_t k = tid; k < kFpSlots; k += 256) slot[k] = kFree;
   if (tid < kFpSlots / 32) dupw[tid] = 0;
   __syncthreads();
-  const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
   uint32_t n_new = 0, n_dup = 0;
-  for (uint32_t i = tid; i < offered; i += 256) {
-    const ulonglong2 r = recs[i];
-    const uint32_t tag = (uint32_t)r.x;
-    const unsigned long long mine = ((unsigned long long)tag << 32) | i;
-    uint32_t hs = (uint32_t)(r.x >> 32) & (kFpSlots - 1);
-    for (;;) {
-      const unsigned long long old = atomicCAS(&slot[hs], kFree, mine);
-      if (old == kFree) {
-        n_new++;
-        break;
-      }
-      if ((uint32_t)(old >> 32) == tag) {
-        const ulonglong2 o = recs[(uint32_t)old];
-        if (o.x == r.x && o.y == r.y) {
-          if (want_mult) {
-            const uint32_t bit = 1u << (hs & 31);
-            const uint32_t prev = atomicOr(&dupw[hs >> 5], bit);
-            n_dup += (prev & bit) ? 0u : 1u;
-          }
+  for (uint32_t i0 = tid; i0 < offered; i0 += 256 * kAhead) {
+    ulonglong2 nx[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) {
+      const uint32_t i = i0 + 256 * (kAhead + j);
+      if (i < offered) nx[j] = recs[i];
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) {
+      const uint32_t i = i0 + 256 * j;
+      if (i >= offered) break;
+      const uint32_t tag = (uint32_t)r[j].x & 0xFFFFu;
+      const uint32_t mine = (tag << 16) | i;
+      uint32_t hs = (uint32_t)(r[j].x >> 32) & (kFpSlots - 1);
+      for (;;) {
+        const uint32_t old = atomicCAS(&slot[hs], kFree, mine);
+        if (old == kFree) {
+          n_new++;
           break;
         }
+        if ((old >> 16) == tag) {
+          const ulonglong2 o = recs[old & 0xFFFFu];
+          if (o.x == r[j].x && o.y == r[j].y) {
+            if (want_mult) {
+              const uint32_t bit = 1u << (hs & 31);
+              const uint32_t prev = atomicOr(&dupw[hs >> 5], bit);
+              n_dup += (prev & bit) ? 0u : 1u;
+            }
+            break;
+          }
+        }
+        hs = (hs + 1) & (kFpSlots - 1);
       }
-      hs = (hs + 1) & (kFpSlots - 1);
     }
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) r[j] = nx[j];
   }
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
