@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
     fit_cur = fit_nxt;
   }
   __syncthreads();
-  fp_tile_scatter(s, mine, 0u, out, 56, counters);
+  fp_tile_scatter(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
 }
 
 // level 2: a tile of one level-1 list -> the kFpFan lists of bits [48, 56) under it
@@ -483,8 +483,14 @@ __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uin
   constexpr int PER = kFpTile / 256;
   __shared__ FpTileLds s;
   const uint32_t tid = threadIdx.x;
-  const uint32_t in_list = blockIdx.x / tiles_per_list;
-  const int64_t first = (int64_t)(blockIdx.x % tiles_per_list) * kFpTile;
+  // Workgroups go round the 8 XCDs.  XCD x takes the level-1 lists (all kFpXcds of them) of 32 values of the first
+  // byte, so everything that lands in one level-2 list comes out of ONE L2 (partial lines meet there before they
+  // leave: the pass took 0.80 ms with the plain order, 0.62 ms with this one).
+  constexpr uint32_t kPerXcd = kFpFan / kFpXcds;
+  const uint32_t xcd = blockIdx.x % kFpXcds, j = blockIdx.x / kFpXcds;
+  const uint32_t b1 = xcd * kPerXcd + j / (kFpXcds * tiles_per_list);
+  const uint32_t in_list = ((j / tiles_per_list) % kFpXcds) * kFpFan + b1;
+  const int64_t first = (int64_t)(j % tiles_per_list) * kFpTile;
   const uint64_t have = in.offered[in_list];
   int64_t count = (int64_t)(have < in.cap ? have : in.cap) - first;
   if (count <= 0) return;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uin
   for (int k = 0; k < PER; k++)
     if (mine[k].x != kEmptyKey) atomicAdd(&s.hist[(mine[k].x >> 48) & (kFpFan - 1)], 1u);
   __syncthreads();
-  fp_tile_scatter(s, mine, in_list * kFpFan, out, 48, counters);
+  fp_tile_scatter(s, mine, b1 * kFpFan, out, 48, counters);
 }
 
 // one workgroup per final list: distinct keys / keys seen twice of the list -> per_list[list]
@@ -594,7 +600,8 @@ __global__ __launch_bounds__(256) void fp_totals_kernel(const uint2 *per_list, u
     a += c.x;
     b += c.y;
   }
-  if (blockIdx.x == 0 && threadIdx.x < kFpFan) v = offered1[threadIdx.x];
+  if (blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(kFpXcds * kFpFan); i += 256) v += offered1[i];
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
     a += __shfl_down(a, dlt, 64);
@@ -850,7 +857,7 @@ void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
                                hipStream_t stream) {
   const uint32_t tiles_per_list = (uint32_t)((level1.cap + kFpTile - 1) / kFpTile);
-  hipLaunchKernelGGL(fp_partition_lists_kernel, dim3(kFpFan * tiles_per_list), dim3(256), 0, stream, level1,
+  hipLaunchKernelGGL(fp_partition_lists_kernel, dim3(kFpXcds * kFpFan * tiles_per_list), dim3(256), 0, stream, level1,
                      tiles_per_list, level2, d_counters);
 }
 

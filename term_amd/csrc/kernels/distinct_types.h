@@ -93,6 +93,8 @@ struct KeyRecord128 {
 // Big Utf8 batches (distinct128.hip, fp_* kernels): the fingerprints are partitioned twice, by 8 bits of their first
 // word each time, into kFpFan^2 lists short enough to be deduplicated in LDS -- no global atomic per value.
 constexpr int kFpFan = 256;              // lists per level
+constexpr int kFpXcds = 8;               // level 1 keeps a set of lists per XCD (workgroup w runs on XCD w % 8): runs that
+                                         // neighbour each other in a list then come out of ONE L2, where partial lines meet
 constexpr int kFpTile = 2048;            // records a workgroup groups in LDS at a time
 constexpr uint32_t kFpSlots = 4096;      // LDS table of one final list
 constexpr uint32_t kFpListMax = 3072;    // records a final list may hold (load <= 3/4)

@@ -949,20 +949,21 @@ static void fp_views(const DistinctState &ds, FpLists *l1, FpLists *l2) {
   l1->offered = ds.fp_offered.as<uint32_t>();
   l1->cap = ds.fp_cap1;
   l2->recs = ds.fp_level2.as<uint64_t>();
-  l2->offered = ds.fp_offered.as<uint32_t>() + kFpFan;
+  l2->offered = ds.fp_offered.as<uint32_t>() + kFpXcds * kFpFan;
   l2->cap = ds.fp_cap2;
 }
 static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;
   constexpr uint64_t kLists2 = (uint64_t)kFpFan * kFpFan;
-  ds.fp_cap1 = fp_list_cap(c.length, kFpFan);
+  constexpr uint64_t kLists1 = (uint64_t)kFpXcds * kFpFan;
+  ds.fp_cap1 = fp_list_cap(c.length, kLists1);
   ds.fp_cap2 = fp_list_cap(c.length, kLists2);
-  HIP_TRY(ds.fp_level1.reserve(kFpFan * ds.fp_cap1 * 16));
+  HIP_TRY(ds.fp_level1.reserve(kLists1 * ds.fp_cap1 * 16));
   HIP_TRY(ds.fp_level2.reserve(kLists2 * ds.fp_cap2 * 16));
-  HIP_TRY(ds.fp_offered.reserve((kFpFan + kLists2) * sizeof(uint32_t)));
+  HIP_TRY(ds.fp_offered.reserve((kLists1 + kLists2) * sizeof(uint32_t)));
   HIP_TRY(ds.fp_per_list.reserve(kLists2 * sizeof(uint2)));
-  HIP_TRY(hipMemsetAsync(ds.fp_offered.p, 0, (kFpFan + kLists2) * sizeof(uint32_t), st->stream));
+  HIP_TRY(hipMemsetAsync(ds.fp_offered.p, 0, (kLists1 + kLists2) * sizeof(uint32_t), st->stream));
   FpLists l1, l2;
   fp_views(ds, &l1, &l2);
   ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
