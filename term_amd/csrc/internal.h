@@ -109,6 +109,9 @@ void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned lo
 void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                                  int64_t length, int large_offsets, const FpLists &level1,
                                  unsigned long long *d_counters, hipStream_t stream);
+void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
+                               int64_t offset, int64_t length, const FpLists &level1, unsigned long long *d_counters,
+                               hipStream_t stream);
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
                                hipStream_t stream);
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
@@ -284,6 +287,7 @@ struct DistinctState {
   bool fp_staged = false;
   uint64_t fp_cap1 = 0, fp_cap2 = 0;
   DevBuf fp_level1, fp_level2, fp_offered, fp_per_list;
+  DevBuf fp_buffers;  // Utf8View batches: the retained view's table of data-buffer pointers (the update's own is staged)
   // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
   // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
   DevBuf spare_seen, spare_twice;

@@ -477,6 +477,37 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
   fp_tile_scatter(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
 }
 
+// level 1 for Utf8View columns: a value is wherever its view says (inline in the 16 view bytes up to 12 bytes, else
+// in one of the data buffers), so there is no common span to stage: every lane fingerprints its rows from global memory
+__global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, FpLists out,
+                                                                  unsigned long long *counters) {
+  constexpr int PER = kFpTile / 256;
+  __shared__ FpTileLds s;
+  const uint32_t tid = threadIdx.x;
+  fp_tile_begin(s);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  const int64_t first = (int64_t)blockIdx.x * kFpTile;
+  ulonglong2 mine[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int64_t row = first + k * 256 + (int64_t)tid;
+    mine[k].x = kEmptyKey;
+    mine[k].y = 0;
+    if (row < d.length) {
+      const int64_t slot = d.offset + row;
+      if (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1)) {
+        uintptr_t p;
+        uint64_t len;
+        utf8_value(d, slot, &p, &len);
+        fingerprint(p, len, (uint64_t *)&mine[k].x, (uint64_t *)&mine[k].y);
+      }
+    }
+    if (mine[k].x != kEmptyKey) atomicAdd(&s.hist[mine[k].x >> 56], 1u);
+  }
+  __syncthreads();
+  fp_tile_scatter(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
+}
+
 // level 2: a tile of one level-1 list -> the kFpFan lists of bits [48, 56) under it
 __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uint32_t tiles_per_list, FpLists out,
                                                                   unsigned long long *counters) {
@@ -852,6 +883,20 @@ void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const
   d.large_offsets = large_offsets;
   const int64_t tiles = (length + kFpTile - 1) / kFpTile;
   hipLaunchKernelGGL(fp_partition_strings_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
+}
+
+void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
+                               int64_t offset, int64_t length, const FpLists &level1, unsigned long long *d_counters,
+                               hipStream_t stream) {
+  Utf8ColDesc d;
+  memset(&d, 0, sizeof(d));
+  d.views = views;
+  d.buffers = buffers;
+  d.validity = validity;
+  d.offset = offset;
+  d.length = length;
+  const int64_t tiles = (length + kFpTile - 1) / kFpTile;
+  hipLaunchKernelGGL(fp_partition_views_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
 }
 
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,

@@ -940,8 +940,7 @@ static bool fp_lists_fit(const tgx_column &c) {
   // TGX_FP_LISTS_MIN_ROWS: smallest batch that takes this path (tests lower it; a huge value turns the path off)
   int64_t min_rows = kFpMinRows;
   if (const char *e = getenv("TGX_FP_LISTS_MIN_ROWS")) min_rows = std::max<int64_t>(1, atoll(e));
-  // (Utf8View batches read their buffers through a pointer table staged per update: not retained)
-  return (c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && c.length >= min_rows &&
+  return is_any_string(c.type) && c.length >= min_rows &&
          fp_list_cap(c.length, (uint64_t)kFpFan * kFpFan) <= kFpListMax;
 }
 static void fp_views(const DistinctState &ds, FpLists *l1, FpLists *l2) {
@@ -968,8 +967,20 @@ static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &
   fp_views(ds, &l1, &l2);
   ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
   unsigned long long *counters = ds.counters.as<unsigned long long>();
-  launch_fp_partition_strings(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, l1, counters,
-                              st->stream);
+  tgx_column kept = c;
+  if (c.type == TGX_UTF8_VIEW) {
+    // the table of data-buffer pointers the kernels read through is staged per update: the retained view gets a copy
+    const size_t bytes = (size_t)std::max(c.n_variadic, 1) * sizeof(void *);
+    HIP_TRY(ds.fp_buffers.reserve(bytes));
+    if (c.n_variadic > 0)
+      HIP_TRY(hipMemcpyAsync(ds.fp_buffers.p, c.variadic, (size_t)c.n_variadic * sizeof(void *), hipMemcpyDeviceToDevice,
+                             st->stream));
+    kept.variadic = (const uint8_t *const *)ds.fp_buffers.p;
+    launch_fp_partition_views(c.values, kept.variadic, c.validity, c.offset, c.length, l1, counters, st->stream);
+  } else {
+    launch_fp_partition_strings(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, l1,
+                                counters, st->stream);
+  }
   launch_fp_partition_lists(l1, l2, counters, st->stream);
   launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), l1.offered, counters, st->stream);
   ds.mode = DistinctMode::kHash;
@@ -977,7 +988,7 @@ static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &
   ds.capacity = 0;  // no table yet
   ds.rows_upper_bound = 0;
   ds.fp_staged = true;
-  ds.retained.push_back(c);  // (a DEVICE view, or a staged one looked at before the update returns)
+  ds.retained.push_back(kept);  // (a DEVICE view, or a staged one looked at before the update returns)
   return TGX_OK;
 }
 
@@ -1277,9 +1288,10 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       HIP_TRY(hipMemsetAsync(ds.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
       for (const tgx_column &col : ds.retained) {
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)col.length, err));
-        launch_distinct_utf8(col.offsets, col.data, nullptr, nullptr, col.validity, col.offset, col.length,
-                             col.type == TGX_LARGE_UTF8, mult ? 1 : 0, hash_view(ds),
-                             ds.counters.as<unsigned long long>(), st->stream);
+        const bool view = col.type == TGX_UTF8_VIEW;
+        launch_distinct_utf8(col.offsets, col.data, view ? col.values : nullptr, view ? col.variadic : nullptr,
+                             col.validity, col.offset, col.length, col.type == TGX_LARGE_UTF8, mult ? 1 : 0,
+                             hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
       }
     } else {
       FpLists l1, l2;

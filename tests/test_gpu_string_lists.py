@@ -79,6 +79,28 @@ def test_long_values_that_do_not_fit_the_stage(low_threshold):
         check(res[0], want)
 
 
+@pytest.mark.parametrize("device", [True, False])
+@pytest.mark.parametrize("n,card", [(120_000, 10**9), (100_000, 20_000), (50_000, 4)])
+def test_utf8view_batches(low_threshold, n, card, device):
+    """Utf8View: inline and out-of-line values, junk views under NULLs, several data buffers; card 4 overflows the
+    lists (the batch is redone through the table, for HOST batches before tgx_update returns)"""
+    from test_gpu_utf8view import view_column
+
+    rng = np.random.default_rng(n + card % 1000 + device)
+    vals = make_strings(rng, n, card)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.distinct_utf8(offs, data, validity)
+    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], view_column(vals, rng, device))
+    assert took_lists(st) == 1
+    check(res[0], want)
+    # a second batch (the table takes over from the lists), sliced with a lead of junk views
+    lead = 37
+    st.update([view_column([None] * lead + vals[: n // 3], rng, device, offset=lead, length=n // 3)])
+    check(st.finalize()[0], want.__class__(total=want.total + n // 3, non_null=want.non_null + orc.distinct_utf8(
+        offs, data, validity, n=n // 3).non_null, distinct=want.distinct, groups_once=orc.distinct_utf8(
+            *orc.utf8_from_list(vals + vals[: n // 3])).groups_once))
+
+
 def test_sliced_column(low_threshold):
     rng = np.random.default_rng(6)
     vals = make_strings(rng, 90_000, 10**9)

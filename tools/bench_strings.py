@@ -27,11 +27,20 @@ def main():
     offsets, data, validity, L, expect = make_column(torch, args.rows)
     col = T.Column(T.LARGE_UTF8, args.rows, offsets=offsets, data=data, validity=validity)
     alg_bytes = args.rows * (8 + L) + args.rows // 8
+    # the same values as a Utf8View column (16-byte views + one data buffer; 28-byte values are out of line)
+    views = torch.zeros(args.rows, 4, dtype=torch.int32, device="cuda")
+    views[:, 0] = L
+    views[:, 1] = data[: args.rows * L].view(args.rows, L)[:, :4].contiguous().view(torch.int32).view(args.rows)
+    views[:, 3] = (torch.arange(args.rows, dtype=torch.int64, device="cuda") * L).to(torch.int32)
+    view_col = T.Column.utf8_view(views.view(torch.uint8).view(-1), [data], validity=validity, length=args.rows)
     sets = {"COUNT(DISTINCT)": [spec(T.DISTINCT, 0)],
+            "COUNT(DISTINCT), column held as Utf8View": [spec(T.DISTINCT, 0)],
             "LENGTH between 5 and 40": [spec(T.LENGTH, 0, length_min=5, length_max=40)],
             "DISTINCT + LENGTH + '@'": [spec(T.DISTINCT, 0), spec(T.LENGTH, 0, length_min=5, length_max=40),
                                         spec(T.REGEX_MATCH, 0, pattern="@")]}
+    plain = col
     for name, specs in sets.items():
+        col = view_col if "Utf8View" in name else plain
         plan = T.Plan(specs)
         st = T.State(plan)
         st.update([col])
