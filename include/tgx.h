@@ -317,8 +317,13 @@ tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state *state, siz
  *   3. the packed partial states (a few KiB; KLL about 100 KiB) travel in one all-gather and are folded in rank
  *      order, so every rank ends with bit-identical results.
  * After the call tgx_finalize(state) returns the global results on every rank; the state keeps its device buffers
- * for the next tgx_state_reset / tgx_update round.  SPEARMAN states cannot be reduced (TG's are unmergeable too,
- * analyzers/advanced/correlation.rs:103-109): TGX_UNSUPPORTED.
+ * for the next tgx_state_reset / tgx_update round.
+ *   0. (before the above, for plans with SPEARMAN checks) RANK() over the union of the ranks' pairs: rank-based
+ *      states do not merge (TG's neither, analyzers/advanced/correlation.rs:103-109), so the call runs a distributed
+ *      sort per column -- local sort, world-1 splitters agreed from regular samples, every key to the rank that owns
+ *      its value range (equal keys meet there), ranked, the rank back to its row: two all-to-all-v of 8 bytes per pair
+ *      and column -- and adds up the five rank sums.  Every rank then answers with the sums of the whole table; such
+ *      a state takes no further batches until it is reset, and still neither merges nor serializes.
  *
  * A tgx_comm is the transport: RCCL over xGMI (tgx_comm_create_rccl: the library dlopens librccl.so.1, calls
  * ncclCommInitRank itself and owns the communicator; tgx_comm_adopt_rccl wraps a caller-owned ncclComm_t), or any

@@ -329,10 +329,6 @@ uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_comm *comm, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (!comm) return fail(err, TGX_INVALID_ARGUMENT, "comm is NULL");
-  if (plan->spearman && spearman_num_tasks(plan) > 0)
-    return fail(err, TGX_UNSUPPORTED,
-                "SPEARMAN states cannot be reduced across ranks (rank sums are not mergeable; the reference's are not "
-                "either, analyzers/advanced/correlation.rs:103-109)");
   const int32_t W = comm->ops.world, R = comm->ops.rank;
   const size_t nd = plan->distinct.size();
   if (comm->ops.device_buffers) {
@@ -340,6 +336,33 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     TGX_TRY(state_init_device(st, err));
   }
   hipStream_t s = st->device_ready ? st->stream : nullptr;
+
+  // ---- 0. SPEARMAN: ranks over the union of the ranks' pairs (a distributed sort, spearman_device.cpp) -----------
+  // Rank-based states do not merge (the reference's neither: analyzers/advanced/correlation.rs:103-109), so their
+  // results are computed here and carried past the reset + merge below by hand.
+  std::vector<SpearmanResolved> spearman_results;
+  const bool has_spearman = plan->spearman && spearman_num_tasks(plan) > 0;
+  if (has_spearman) {
+    SpearmanExchange X;
+    X.rank = R;
+    X.world = W;
+    X.allgather_host = [&](const void *h_send, void *h_recv, size_t bytes) {
+      return do_allgather_host(comm, st->device_ready ? st->stream : nullptr, h_send, h_recv, bytes, err);
+    };
+    X.alltoallv = [&](const void *d_send, const uint64_t *sc, void *d_recv, const uint64_t *rc, size_t elem) {
+      return do_alltoallv(comm, st->device_ready ? st->stream : nullptr, d_send, sc, d_recv, rc, elem, err);
+    };
+    TGX_TRY(spearman_allreduce(st, X, &spearman_results, err));
+    s = st->device_ready ? st->stream : nullptr;
+    spearman_set_reducing(st, true);  // (the state's own blob does not carry these tasks)
+  }
+  struct ReducingGuard {
+    tgx_state *st;
+    bool on;
+    ~ReducingGuard() {
+      if (on) spearman_set_reducing(st, false);
+    }
+  } reducing_guard{st, has_spearman};
 
   // ---- 1. facts --------------------------------------------------------------------------------------------
   TGX_TRY(distinct_resolve_all(st, err));  // keys outside a sampled bitmap range are brought in first
@@ -583,6 +606,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     tgx_state_destroy(part);
     if (ms != TGX_OK) return ms;
   }
+  if (has_spearman) spearman_install(st, spearman_results);
   return TGX_OK;
 } catch (...) {
   return abi_exception(err);

@@ -95,11 +95,40 @@ __global__ void run_heads_kernel(const uint64_t *sorted, uint64_t n, uint64_t *h
     heads[i] = (i > 0 && sorted[i] != sorted[i - 1]) ? i : 0;
 }
 
-// RANK(): 1 + first position of the tie run, scattered back to the original row order
-__global__ void scatter_ranks_kernel(const uint64_t *run_start, const uint32_t *idx_sorted, uint64_t n,
+// RANK(): 1 + first position of the tie run (+ `base`: the keys that sort before this rank's share when the ranking
+// is spread over several ranks), scattered back to the original row order
+__global__ void scatter_ranks_kernel(const uint64_t *run_start, const uint32_t *idx_sorted, uint64_t n, uint64_t base,
                                      uint64_t *rank) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    rank[idx_sorted[i]] = run_start[i] + 1;
+    rank[idx_sorted[i]] = base + run_start[i] + 1;
+}
+
+// ---- pieces of the cross-rank ranking (spearman_device.cpp, spearman_allreduce) ----
+// `count` regular samples of a sorted array
+__global__ void sample_sorted_kernel(const uint64_t *sorted, uint64_t n, uint32_t count, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = sorted[(uint64_t)i * n / count];
+}
+// out[j] = first position whose key is >= splitters[j]
+__global__ void lower_bounds_kernel(const uint64_t *sorted, uint64_t n, const uint64_t *splitters, uint32_t k,
+                                    uint64_t *out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const uint64_t v = splitters[j];
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (sorted[mid] < v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  out[j] = lo;
+}
+// out[perm[k]] = vals[k]
+__global__ void unsort_kernel(const uint64_t *vals, const uint32_t *perm, uint64_t n, uint64_t *out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[perm[i]] = vals[i];
 }
 
 struct RankSums {
@@ -174,7 +203,8 @@ size_t spearman_rank_sums_bytes() { return sizeof(RankSums); }
 // ranks `keys` (n sort keys, clobbered) into `rank` (original order). scratch buffers: n entries each.
 // Returns the rocPRIM temp bytes needed when temp == nullptr.
 hipError_t spearman_rank(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
-                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream) {
+                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream,
+                         uint64_t base) {
   size_t sort_bytes = 0, scan_bytes = 0;
   hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u,
                                            stream);
@@ -194,8 +224,35 @@ hipError_t spearman_rank(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint
   tb = *temp_bytes;
   e = rocprim::inclusive_scan(temp, tb, heads, heads, (size_t)n, rocprim::maximum<uint64_t>(), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(scatter_ranks_kernel, dim3(grid_of(n)), dim3(256), 0, stream, heads, idx_sorted, n, rank);
+  hipLaunchKernelGGL(scatter_ranks_kernel, dim3(grid_of(n)), dim3(256), 0, stream, heads, idx_sorted, n, base, rank);
   return hipGetLastError();
+}
+
+// (keys, position) sorted by key: keys_sorted and the permutation idx_sorted.  temp == nullptr: returns the bytes.
+hipError_t spearman_sort_pairs(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
+                               void *temp, size_t *temp_bytes, hipStream_t stream) {
+  size_t sort_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u,
+                                           stream);
+  if (e != hipSuccess) return e;
+  if (temp == nullptr) {
+    *temp_bytes = sort_bytes;
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_of(n)), dim3(256), 0, stream, idx, n);
+  size_t tb = *temp_bytes;
+  return rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u, stream);
+}
+
+void launch_sample_sorted(const uint64_t *sorted, uint64_t n, uint32_t count, uint64_t *out, hipStream_t stream) {
+  hipLaunchKernelGGL(sample_sorted_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, sorted, n, count, out);
+}
+void launch_lower_bounds(const uint64_t *sorted, uint64_t n, const uint64_t *splitters, uint32_t k, uint64_t *out,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(lower_bounds_kernel, dim3((k + 63) / 64), dim3(64), 0, stream, sorted, n, splitters, k, out);
+}
+void launch_unsort(const uint64_t *vals, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t stream) {
+  hipLaunchKernelGGL(unsort_kernel, dim3(grid_of(n)), dim3(256), 0, stream, vals, perm, n, out);
 }
 
 int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, void *partials, hipStream_t stream) {

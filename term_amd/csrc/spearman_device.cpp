@@ -13,7 +13,14 @@ void launch_spearman_compact(const ComomentColDesc &d, uint64_t *kx, uint64_t *k
                              hipStream_t stream);
 size_t spearman_rank_sums_bytes();
 hipError_t spearman_rank(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
-                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream);
+                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream,
+                         uint64_t base);
+hipError_t spearman_sort_pairs(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
+                               void *temp, size_t *temp_bytes, hipStream_t stream);
+void launch_sample_sorted(const uint64_t *sorted, uint64_t n, uint32_t count, uint64_t *out, hipStream_t stream);
+void launch_lower_bounds(const uint64_t *sorted, uint64_t n, const uint64_t *splitters, uint32_t k, uint64_t *out,
+                         hipStream_t stream);
+void launch_unsort(const uint64_t *vals, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t stream);
 int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, void *partials, hipStream_t stream);
 
 namespace {
@@ -25,6 +32,8 @@ struct SpearmanTaskState {
   uint64_t capacity = 0;     // pairs the buffers can hold
   uint64_t rows_upper = 0;   // host-side bound on pairs appended so far
   int64_t total_rows = 0;
+  bool resolved = false;     // reduced across ranks: `res` is the answer, the pairs are history
+  SpearmanResolved res;
 };
 struct SpearmanState {
   std::vector<SpearmanTaskState> tasks;
@@ -32,6 +41,10 @@ struct SpearmanState {
   // the tasks (they are ranked one after the other) and kept between calls -- allocating and freeing them inside
   // every fill_result was 160 ms of a 188 ms step at 100 M rows (hipMalloc / hipFree of 4.4 GB)
   DevBuf keys_sorted, idx, idx_sorted, heads, rx, ry, temp, partials;
+  // the cross-rank ranking: this rank's sorted keys and their permutation, the keys it owns, their ranks, the ranks
+  // that came back, samples / splitters / boundaries
+  DevBuf loc_sorted, loc_perm, recv, recv_ranks, back, small;
+  bool reducing = false;
 };
 
 tgx_status sfail(tgx_error *err, tgx_status code, const char *fmt, ...) {
@@ -50,6 +63,12 @@ tgx_status sfail(tgx_error *err, tgx_status code, const char *fmt, ...) {
     if (e_ != hipSuccess)                                                                                  \
       return sfail(err, e_ == hipErrorOutOfMemory ? TGX_OUT_OF_MEMORY : TGX_DEVICE_ERROR, "%s failed: %s", \
                    #expr, hipGetErrorString(e_));                                                          \
+  } while (0)
+
+#define STRY(expr)               \
+  do {                           \
+    tgx_status s_ = (expr);      \
+    if (s_ != TGX_OK) return s_; \
   } while (0)
 
 const SpearmanPlan *splan(const tgx_plan *p) { return (const SpearmanPlan *)p->spearman; }
@@ -106,6 +125,7 @@ void spearman_state_reset(tgx_state *st) {
   for (auto &t : s->tasks) {
     t.rows_upper = 0;
     t.total_rows = 0;
+    t.resolved = false;
     if (t.count.p) (void)hipMemsetAsync(t.count.p, 0, 8, st->stream);
   }
 }
@@ -120,6 +140,8 @@ tgx_status spearman_update(tgx_state *st, const tgx_column *dev, tgx_error *err)
     auto numeric = [](int t) { return t == TGX_INT64 || t == TGX_FLOAT64; };
     if (!numeric(x.type) || !numeric(y.type))
       return sfail(err, TGX_INVALID_ARGUMENT, "SPEARMAN needs numeric columns (%d, %d)", x.type, y.type);
+    if (ts.resolved)
+      return sfail(err, TGX_UNSUPPORTED, "SPEARMAN: the state holds the result of a cross-rank reduction; reset it first");
     ts.total_rows += x.length;
     if (x.length == 0) continue;
     if (!ts.count.p) {
@@ -160,6 +182,20 @@ tgx_status spearman_update(tgx_state *st, const tgx_column *dev, tgx_error *err)
 tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *err) {
   SpearmanTaskState &ts = sstate(st)->tasks[slot];
   const bool exact = splan(st->plan)->tasks[slot].exact_sums;
+  if (ts.resolved) {
+    r->total = ts.res.total_rows;
+    r->non_null = (int64_t)ts.res.pairs;
+    double out[5];
+    for (int k = 0; k < 5; k++)
+      out[k] = exact ? (double)(((unsigned __int128)ts.res.exact_hi[k] << 64) | ts.res.exact_lo[k])
+                     : (double)ts.res.wrapped[k];
+    r->sum_x = out[0];
+    r->sum_y = out[1];
+    r->sum_x2 = out[2];
+    r->sum_y2 = out[3];
+    r->sum_xy = out[4];
+    return TGX_OK;
+  }
   r->total = ts.total_rows;
   unsigned long long m = 0;
   if (ts.count.p) {
@@ -180,12 +216,12 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   SHIP(ry.reserve(m * 8));
   size_t temp_bytes = 0;
   SHIP(spearman_rank(ts.kx.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), idx.as<uint32_t>(), idx_sorted.as<uint32_t>(),
-                     heads.as<uint64_t>(), rx.as<uint64_t>(), nullptr, &temp_bytes, st->stream));
+                     heads.as<uint64_t>(), rx.as<uint64_t>(), nullptr, &temp_bytes, st->stream, 0));
   SHIP(temp.reserve(temp_bytes + 256));
   SHIP(spearman_rank(ts.kx.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), idx.as<uint32_t>(), idx_sorted.as<uint32_t>(),
-                     heads.as<uint64_t>(), rx.as<uint64_t>(), temp.p, &temp_bytes, st->stream));
+                     heads.as<uint64_t>(), rx.as<uint64_t>(), temp.p, &temp_bytes, st->stream, 0));
   SHIP(spearman_rank(ts.ky.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), idx.as<uint32_t>(), idx_sorted.as<uint32_t>(),
-                     heads.as<uint64_t>(), ry.as<uint64_t>(), temp.p, &temp_bytes, st->stream));
+                     heads.as<uint64_t>(), ry.as<uint64_t>(), temp.p, &temp_bytes, st->stream, 0));
   SHIP(partials.reserve(2048 * spearman_rank_sums_bytes()));
   const int blocks = launch_rank_sums(rx.as<uint64_t>(), ry.as<uint64_t>(), m, partials.p, st->stream);
   std::vector<RankSumsHost> h(blocks);
@@ -210,13 +246,196 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
 }
 
 tgx_status spearman_check_mergeable(tgx_state *st, tgx_error *err) {
-  if (!st->spearman) return TGX_OK;
+  if (!st->spearman || sstate(st)->reducing) return TGX_OK;
   for (auto &t : sstate(st)->tasks)
-    if (t.rows_upper > 0 || t.total_rows > 0)
+    if (t.rows_upper > 0 || t.total_rows > 0 || t.resolved)
       return sfail(err, TGX_UNSUPPORTED,
                    "Spearman states hold ranks of one data set and cannot be merged or serialized "
                    "(as in the reference, analyzers/advanced/correlation.rs:103-109)");
   return TGX_OK;
+}
+
+// ---- across ranks ---------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t kSamplesPerRank = 1024;
+
+// ranks of `keys` (m of them, this rank's) among ALL ranks' keys -> out[i] for keys[i]
+tgx_status rank_across(tgx_state *st, SpearmanState *ws, const SpearmanExchange &X, uint64_t *keys, uint64_t m,
+                       uint64_t *out, tgx_error *err) {
+  const int32_t W = X.world, R = X.rank;
+  hipStream_t s = st->device_ready ? st->stream : nullptr;
+  size_t tb = 0;
+  // (a) this rank's keys in order, with the permutation that leads back to the rows
+  if (m) {
+    SHIP(ws->loc_sorted.reserve(m * 8));
+    SHIP(ws->loc_perm.reserve(m * 4));
+    SHIP(ws->idx.reserve(m * 4));
+    SHIP(spearman_sort_pairs(keys, m, ws->loc_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(), ws->loc_perm.as<uint32_t>(),
+                             nullptr, &tb, s));
+    SHIP(ws->temp.reserve(tb + 256));
+    SHIP(spearman_sort_pairs(keys, m, ws->loc_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(), ws->loc_perm.as<uint32_t>(),
+                             ws->temp.p, &tb, s));
+  }
+  // (b) regular samples of every rank -> the same world-1 splitters everywhere
+  std::vector<uint64_t> mine(1 + kSamplesPerRank, 0), all((size_t)W * (1 + kSamplesPerRank), 0);
+  const uint32_t ns = (uint32_t)std::min<uint64_t>(m, kSamplesPerRank);
+  mine[0] = ns;
+  if (ns) {
+    SHIP(ws->small.reserve((2 * kSamplesPerRank + 512) * 8));
+    launch_sample_sorted(ws->loc_sorted.as<uint64_t>(), m, ns, ws->small.as<uint64_t>(), s);
+    SHIP(hipMemcpyAsync(&mine[1], ws->small.p, ns * 8, hipMemcpyDeviceToHost, s));
+    SHIP(hipStreamSynchronize(s));
+  }
+  STRY(X.allgather_host(mine.data(), all.data(), mine.size() * 8));
+  std::vector<uint64_t> pool;
+  for (int32_t r = 0; r < W; r++) {
+    const uint64_t *p = &all[(size_t)r * (1 + kSamplesPerRank)];
+    if (p[0] > kSamplesPerRank) return sfail(err, TGX_INTERNAL, "SPEARMAN exchange: bad sample header from rank %d", r);
+    pool.insert(pool.end(), p + 1, p + 1 + p[0]);
+  }
+  std::sort(pool.begin(), pool.end());
+  std::vector<uint64_t> split((size_t)std::max(W - 1, 0), 0);
+  for (int32_t j = 0; j + 1 < W; j++) split[j] = pool.empty() ? 0 : pool[(size_t)(j + 1) * pool.size() / W];
+  // (c) rank q owns the keys with exactly q splitters <= key: contiguous stretches of the sorted keys
+  std::vector<uint64_t> sc((size_t)W, 0);
+  if (m && W > 1) {
+    uint64_t *d_split = ws->small.as<uint64_t>() + kSamplesPerRank, *d_bound = d_split + 256;
+    if (W - 1 > 256) return sfail(err, TGX_UNSUPPORTED, "SPEARMAN across more than 257 ranks");
+    std::vector<uint64_t> bound((size_t)W - 1);
+    SHIP(hipMemcpyAsync(d_split, split.data(), split.size() * 8, hipMemcpyHostToDevice, s));
+    launch_lower_bounds(ws->loc_sorted.as<uint64_t>(), m, d_split, (uint32_t)(W - 1), d_bound, s);
+    SHIP(hipMemcpyAsync(bound.data(), d_bound, bound.size() * 8, hipMemcpyDeviceToHost, s));
+    SHIP(hipStreamSynchronize(s));
+    uint64_t prev = 0;
+    for (int32_t j = 0; j + 1 < W; j++) {
+      sc[j] = bound[j] - prev;
+      prev = bound[j];
+    }
+    sc[W - 1] = m - prev;
+  } else if (m) {
+    sc[0] = m;
+  }
+  std::vector<uint64_t> mat((size_t)W * W, 0), rc((size_t)W, 0);
+  STRY(X.allgather_host(sc.data(), mat.data(), (size_t)W * 8));  // mat[p * W + q]: p sends q
+  uint64_t M = 0, base = 0, everywhere = 0;
+  for (int32_t p = 0; p < W; p++) {
+    rc[p] = mat[(size_t)p * W + R];
+    M += rc[p];
+    for (int32_t q = 0; q < R; q++) base += mat[(size_t)p * W + q];
+    for (int32_t q = 0; q < W; q++) everywhere += mat[(size_t)p * W + q];
+  }
+  if (everywhere == 0) return TGX_OK;  // no rank holds a pair (every rank sees that): nothing to exchange
+  if (M > 0xFFFFFFF0ull)
+    return sfail(err, TGX_UNSUPPORTED, "SPEARMAN: more than 2^32 keys fall to one rank (heavily repeated values)");
+  if (M || m) {  // (a rank that saw no batch may still own a value range)
+    STRY(need_device(err));
+    STRY(state_init_device(st, err));
+    s = st->stream;
+  }
+  // (d) the keys to their owners, ranked there, the ranks back
+  SHIP(ws->recv.reserve(std::max<uint64_t>(M, 1) * 8));
+  SHIP(ws->loc_sorted.reserve(8));  // (a rank without keys still names a buffer)
+  STRY(X.alltoallv(ws->loc_sorted.p, sc.data(), ws->recv.p, rc.data(), 8));
+  SHIP(ws->recv_ranks.reserve(std::max<uint64_t>(M, 1) * 8));
+  if (M) {
+    SHIP(ws->keys_sorted.reserve(M * 8));
+    SHIP(ws->idx.reserve(M * 4));
+    SHIP(ws->idx_sorted.reserve(M * 4));
+    SHIP(ws->heads.reserve(M * 8));
+    SHIP(spearman_rank(ws->recv.as<uint64_t>(), M, ws->keys_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(),
+                       ws->idx_sorted.as<uint32_t>(), ws->heads.as<uint64_t>(), ws->recv_ranks.as<uint64_t>(), nullptr, &tb,
+                       s, base));
+    SHIP(ws->temp.reserve(tb + 256));
+    SHIP(spearman_rank(ws->recv.as<uint64_t>(), M, ws->keys_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(),
+                       ws->idx_sorted.as<uint32_t>(), ws->heads.as<uint64_t>(), ws->recv_ranks.as<uint64_t>(), ws->temp.p,
+                       &tb, s, base));
+  }
+  SHIP(ws->back.reserve(std::max<uint64_t>(m, 1) * 8));
+  STRY(X.alltoallv(ws->recv_ranks.p, rc.data(), ws->back.p, sc.data(), 8));
+  if (m) launch_unsort(ws->back.as<uint64_t>(), ws->loc_perm.as<uint32_t>(), m, out, s);
+  return TGX_OK;
+}
+}  // namespace
+
+tgx_status spearman_allreduce(tgx_state *st, const SpearmanExchange &X, std::vector<SpearmanResolved> *out,
+                              tgx_error *err) {
+  out->clear();
+  if (!st->plan->spearman) return TGX_OK;
+  const SpearmanPlan *sp = splan(st->plan);
+  SpearmanState *ws = sstate(st);
+  hipStream_t s = st->device_ready ? st->stream : nullptr;
+  struct Wire {
+    int64_t total_rows;
+    uint64_t pairs;
+    RankSumsHost sums;
+  };
+  for (size_t t = 0; t < sp->tasks.size(); t++) {
+    SpearmanTaskState &ts = ws->tasks[t];
+    if (ts.resolved)
+      return sfail(err, TGX_UNSUPPORTED, "SPEARMAN: the state already holds the result of a cross-rank reduction");
+    unsigned long long m = 0;
+    if (ts.count.p) {
+      SHIP(hipMemcpyAsync(&m, ts.count.p, 8, hipMemcpyDeviceToHost, s));
+      SHIP(hipStreamSynchronize(s));
+    }
+    if (m > 0xFFFFFFF0ull) return sfail(err, TGX_UNSUPPORTED, "SPEARMAN over more than 2^32 rows per rank is not supported");
+    if (m) {
+      SHIP(ws->rx.reserve(m * 8));
+      SHIP(ws->ry.reserve(m * 8));
+    }
+    STRY(rank_across(st, ws, X, ts.kx.as<uint64_t>(), m, ws->rx.as<uint64_t>(), err));
+    STRY(rank_across(st, ws, X, ts.ky.as<uint64_t>(), m, ws->ry.as<uint64_t>(), err));
+    Wire mine;
+    memset(&mine, 0, sizeof(mine));
+    mine.total_rows = ts.total_rows;
+    mine.pairs = m;
+    if (m) {
+      SHIP(ws->partials.reserve(2048 * spearman_rank_sums_bytes()));
+      const int blocks = launch_rank_sums(ws->rx.as<uint64_t>(), ws->ry.as<uint64_t>(), m, ws->partials.p, s);
+      std::vector<RankSumsHost> h(blocks);
+      SHIP(hipMemcpyAsync(h.data(), ws->partials.p, blocks * sizeof(RankSumsHost), hipMemcpyDeviceToHost, s));
+      SHIP(hipStreamSynchronize(s));
+      for (int k = 0; k < 5; k++) {
+        unsigned __int128 e = 0;
+        for (auto &p : h) {
+          mine.sums.wrapped[k] += p.wrapped[k];
+          e += ((unsigned __int128)p.exact_hi[k] << 64) | p.exact_lo[k];
+        }
+        mine.sums.exact_lo[k] = (unsigned long long)e;
+        mine.sums.exact_hi[k] = (unsigned long long)(e >> 64);
+      }
+    }
+    std::vector<Wire> all((size_t)X.world);
+    STRY(X.allgather_host(&mine, all.data(), sizeof(Wire)));
+    SpearmanResolved res;
+    memset(&res, 0, sizeof(res));
+    for (auto &w : all) {
+      res.total_rows += w.total_rows;
+      res.pairs += w.pairs;
+      for (int k = 0; k < 5; k++) {
+        res.wrapped[k] += w.sums.wrapped[k];
+        const unsigned __int128 e = (((unsigned __int128)res.exact_hi[k] << 64) | res.exact_lo[k]) +
+                                    (((unsigned __int128)w.sums.exact_hi[k] << 64) | w.sums.exact_lo[k]);
+        res.exact_lo[k] = (unsigned long long)e;
+        res.exact_hi[k] = (unsigned long long)(e >> 64);
+      }
+    }
+    out->push_back(res);
+  }
+  return TGX_OK;
+}
+
+void spearman_install(tgx_state *st, const std::vector<SpearmanResolved> &res) {
+  SpearmanState *ws = sstate(st);
+  if (!ws) return;
+  for (size_t t = 0; t < res.size() && t < ws->tasks.size(); t++) {
+    ws->tasks[t].resolved = true;
+    ws->tasks[t].res = res[t];
+  }
+}
+
+void spearman_set_reducing(tgx_state *st, bool on) {
+  if (sstate(st)) sstate(st)->reducing = on;
 }
 
 }  // namespace tgx

@@ -90,6 +90,13 @@ WORKER = textwrap.dedent('''
         part.allreduce(comm)
         r2 = part.finalize()
         assert r2[0].kll_n == 5000 * scale and (r2[1].total, r2[1].non_null) == (21, 14), (r2[0].kll_n, r2[1].total)
+    # a plan with a SPEARMAN task goes through the same call (no rank holds a pair here: the ranking has nothing to
+    # exchange, the other tasks are reduced as usual)
+    plan3 = T.Plan([spec(T.SPEARMAN, 0, column2=1), spec(T.COUNT, 0)])
+    sp = T.State.deserialize(plan3, wire.pack(count=[wire.count_acc(100 + rank, 90)]))
+    sp.allreduce(comm)
+    r3 = sp.finalize()
+    assert (r3[0].total, r3[0].non_null, r3[1].total, r3[1].non_null) == (0, 0, 200 + world * (world - 1) // 2, 90 * world)
     # an allreduce of an all-reduced state is the W-fold sum: the call is a plain cross-rank merge, nothing is cached
     again = T.State.deserialize(plan, merged.serialize())
     again.allreduce(comm)

@@ -160,3 +160,52 @@ def test_ranks_with_unequal_ranges_empty_shards_and_mixed_key_sets(world):
             (n, d.non_null, d.distinct, d.groups_once)
         assert (res[2].total, res[2].non_null) == (n, d.non_null)
         assert (res[3].total, res[3].distinct, res[3].groups_once) == (n, dm.distinct, dm.groups_once)
+
+
+@pytest.mark.parametrize("world,device_buffers", [(2, True), (3, False), (5, True)])
+def test_spearman_over_ranks(world, device_buffers):
+    """SQL RANK() over the union of the shards (tgx_allreduce: sort locally, agree on splitters, every key to the rank
+    that owns its value range, ranks back to their rows): the five UInt64 sums must equal the oracle's on the whole
+    table, bit for bit, on every rank -- heavy ties (equal keys meet on one rank), NULLs on either side, a sorted
+    column (each rank's keys are one value range: almost everything travels), unequal shards and an empty one; with
+    the suite's other checks in the same plan."""
+    from gpu_util import make_f64, make_i64
+
+    rng = np.random.default_rng(40 + world)
+    n = 400_000
+    xi, xv = make_i64(rng, n, -300, 300, null_frac=0.1)           # heavy ties
+    yf, yv = make_f64(rng, n, "normal", null_frac=0.05)
+    yf = np.round(yf, 2)
+    srt = np.sort(rng.standard_normal(n))                         # rank r's shard is one value range
+    bounds = [0, 1000]
+    for r in range(1, world - 1):
+        bounds.append(bounds[-1] + (n - 1000) // (world - 1) // 64 * 64)
+    bounds.append(n)
+    if world >= 3:
+        bounds[2] = bounds[1]                                     # rank 1 holds no rows at all
+    specs = [spec(T.SPEARMAN, 0, column2=1), spec(T.SPEARMAN, 2, column2=1, flags=T.FLAG_EXACT_RANK_SUMS),
+             spec(T.COMOMENTS, 0, column2=1), spec(T.COUNT, 0), spec(T.DISTINCT, 0)]
+    T.init()
+    plan = T.Plan(specs)
+
+    def shards_of(rank):
+        lo, hi = bounds[rank], bounds[rank + 1]
+        return [numeric_column(xi, xv, True, offset=lo, length=hi - lo),
+                numeric_column(yf, yv, True, offset=lo, length=hi - lo),
+                numeric_column(srt, None, True, offset=lo, length=hi - lo)]
+
+    want = orc.spearman_state(xi, yf, xv, yv)
+    want2 = orc.spearman_state(srt, yf, None, yv)
+    single, _, _ = __import__("gpu_util").run_plan(specs, [[numeric_column(xi, xv, True), numeric_column(yf, yv, True),
+                                                             numeric_column(srt, None, True)]])
+    for res, _ in _run_ranks(world, plan, shards_of, device_buffers=device_buffers, steps=2):
+        g = res[0]
+        assert (g.total, g.non_null) == (n, want.n)
+        assert (g.sum_x, g.sum_y, g.sum_x2, g.sum_y2, g.sum_xy) == \
+            (want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy)
+        e = res[1]
+        assert (e.total, e.non_null) == (n, want2.n)
+        assert (e.sum_x, e.sum_y, e.sum_x2, e.sum_y2, e.sum_xy) == \
+            (single[1].sum_x, single[1].sum_y, single[1].sum_x2, single[1].sum_y2, single[1].sum_xy)
+        assert res[2].non_null == want.n and res[3].non_null == single[3].non_null
+        assert res[4].distinct == single[4].distinct
