@@ -228,7 +228,7 @@ void tgx_state_destroy(tgx_state *state);
  *     the task never wait (keys outside the sampled range are counted and repaired at tgx_finalize /
  *     tgx_state_sync / tgx_state_serialize / tgx_merge / tgx_allreduce);
  *   - a hash key set that may have to grow reads its fill back first;
- *   (a Utf8 / LargeUtf8 DISTINCT task never waits: its first batch of 2^23 rows or more is deduplicated in
+ *   (a Utf8 / LargeUtf8 / Utf8View DISTINCT task never waits: its first batch of 2^21 rows or more is deduplicated in
  *    partitioned lists instead of the table, and should a list overflow -- heavily repeated values -- the batch is
  *    read once more at the next of the calls above: one more reason DEVICE buffers stay alive until then)
  *   - HOST batches: buffers copied straight from the caller's memory are borrowed only until the call returns, so

@@ -98,7 +98,7 @@ constexpr int kFpXcds = 8;               // level 1 keeps a set of lists per XCD
 constexpr int kFpTile = 2048;            // records a workgroup groups in LDS at a time
 constexpr uint32_t kFpSlots = 4096;      // LDS table of one final list
 constexpr uint32_t kFpListMax = 3072;    // records a final list may hold (load <= 3/4)
-constexpr int64_t kFpMinRows = 1 << 23;  // smaller batches go straight into the global table
+constexpr int64_t kFpMinRows = 1 << 21;  // smaller batches go straight into the global table (same time at 1-2 M rows)
 struct FpLists {
   uint64_t *recs;     // [lists][cap] records of two words
   uint32_t *offered;  // [lists] records offered to the list; those beyond cap were dropped (kCntOutOfRange counts

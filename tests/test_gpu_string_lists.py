@@ -1,5 +1,5 @@
 """-m gpu: COUNT(DISTINCT) of big Utf8 batches -- the fingerprints partitioned into lists and deduplicated list by list
-in LDS (kernels/distinct128.hip, fp_*) -- vs the oracle.  The path normally starts at 8 Mi rows; TGX_FP_LISTS_MIN_ROWS
+in LDS (kernels/distinct128.hip, fp_*) -- vs the oracle.  The path normally starts at 2 Mi rows; TGX_FP_LISTS_MIN_ROWS
 lowers that so the oracle still finishes in seconds, and the "distinct_lists" profile entry proves which path ran.
 One test runs at the real threshold on a generated column whose answer is known in closed form."""
 import numpy as np
