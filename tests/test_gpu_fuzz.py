@@ -137,11 +137,13 @@ def random_strings(rng, n):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TGX_FUZZ_STRING_SEEDS", "16"))))
-def test_random_string_plans_against_the_oracle(seed):
+def test_random_string_plans_against_the_oracle(seed, monkeypatch):
     from test_gpu_dictionary import encode
     from test_gpu_regex import utf8_column
     from test_gpu_utf8view import view_column
 
+    if seed % 2:  # odd seeds: the first batch of a Utf8 / Utf8View DISTINCT goes through the fingerprint lists
+        monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "50")
     rng = np.random.default_rng(5000 + seed)
     n = int(rng.choice([1, 64, 129, 5000, 60_000]))
     vals = random_strings(rng, n)
