@@ -46,7 +46,7 @@ __device__ __forceinline__ void dict_block_add(unsigned long long a, unsigned lo
 // Streams the index column once: f(e, valid) for every row.  Rows are taken four at a time with one
 // global_load_dwordx4 per lane (after a scalar head up to the first 16-byte aligned index), four loads in flight
 // per lane; the four validity bits of a quad come from a 16-bit window of the bitmap.
-template <class F>
+template <int kQ = 4, class F>  // kQ: quads per lane and batch (8 measured the same as 4)
 __device__ __forceinline__ void dict_for_each_row(const DictRowsDesc &d, F &&f) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   typedef const i32x4 __attribute__((address_space(1))) *global_i32x4_ptr;
@@ -68,7 +68,6 @@ __device__ __forceinline__ void dict_for_each_row(const DictRowsDesc &d, F &&f) 
   global_i32x4_ptr quads = (global_i32x4_ptr)(idx + head);
   // software pipeline: the loads of the NEXT four quads are requested before the current ones are handed to f (one
   // workgroup per CU and f's LDS work in between: waiting for each batch on its own left the kernel at 3.1-3.7 TB/s)
-  constexpr int kQ = 4;  // quads per lane and batch (8 measured the same)
   struct Batch {
     i32x4 v[kQ];
     uint32_t w[kQ];  // validity bytes covering the quad (low byte first), not shifted yet
@@ -112,6 +111,7 @@ __device__ __forceinline__ void dict_for_each_row(const DictRowsDesc &d, F &&f) 
 }
 
 constexpr int kDictLdsWords = 32768;  // 128 KiB of LDS bitmaps: 1 Mi entries (one bitmap) or 512 Ki (two)
+constexpr int kDictLdsWordsSmall = 16384;  // dictionaries that fit half of that: two workgroups a CU
 constexpr int kDictThreads = 1024;    // one workgroup per CU, 16 waves
 constexpr int kDictMaxFused = 4;      // pattern checks that can ride on the DISTINCT pass of a column
 
@@ -145,11 +145,12 @@ __device__ __forceinline__ uint32_t dict_pack_hits(const uint8_t *hits, uint32_t
 // matches += hits[index] for valid rows (hit byte: 1 = entry matches, 2 = entry is NULL), null_is_valid for NULL
 // rows.  LDS: the per-entry verdicts as a bitmap in LDS (dictionaries without NULL values, <= 1 Mi entries), so
 // the per-row lookup is an LDS read instead of a scattered global byte load.
-template <bool LDS>
+template <int LDSW>  // words of LDS bitmap: 0 = none (verdict bytes from global memory), kDictLdsWordsSmall, kDictLdsWords
 __global__ __launch_bounds__(kDictThreads) void dict_count_hits_kernel(DictRowsDesc d, const uint8_t *hits,
                                                                         int null_is_valid,
                                                                         unsigned long long *counters) {
-  __shared__ uint32_t match_bits[LDS ? kDictLdsWords : 1];
+  constexpr bool LDS = LDSW > 0;
+  __shared__ uint32_t match_bits[LDS ? LDSW : 1];
   global_u8_ptr h = (global_u8_ptr)(uintptr_t)hits;
   if (LDS) {
     const int64_t words = (d.dict_length + 31) >> 5;
@@ -180,10 +181,11 @@ __global__ __launch_bounds__(kDictThreads) void dict_count_hits_kernel(DictRowsD
 //              (two workgroups that each saw an entry once make it "twice") into `seen` / `twice`.
 // LDS = false: dictionaries beyond the LDS budget -- test-before-set atomicOr straight into `seen` / `twice`.
 // counters[kCntValidRows] += valid rows.
-template <bool LDS, bool MULT>
+template <int LDSW, bool MULT>
 __global__ __launch_bounds__(kDictThreads) void dict_usage_kernel(DictRowsDesc d, uint32_t *seen, uint32_t *twice,
                                                                    uint32_t *slices, unsigned long long *counters) {
-  __shared__ uint32_t bits[LDS ? kDictLdsWords : 1];
+  constexpr bool LDS = LDSW > 0;
+  __shared__ uint32_t bits[LDS ? LDSW : 1];
   const uint32_t words = (uint32_t)((d.dict_length + 31) >> 5);
   uint32_t *l_seen = bits, *l_twice = bits + words;
   if (LDS) {
@@ -243,10 +245,10 @@ struct DictFuseParams {
   int32_t k;
 };
 
-template <bool MULT>
-__global__ __launch_bounds__(kDictThreads) void dict_fused_kernel(DictRowsDesc d, DictFuseParams f, uint32_t *slices,
-                                                                   unsigned long long *counters) {
-  __shared__ uint32_t bits[kDictLdsWords];
+template <bool MULT, int LDSW>  // LDSW = kDictLdsWordsSmall: two workgroups a CU (the compiler keeps to 64 registers)
+__global__ __launch_bounds__(kDictThreads) __attribute__((amdgpu_waves_per_eu(LDSW <= kDictLdsWordsSmall ? 8 : 4, LDSW <= kDictLdsWordsSmall ? 8 : 4))) void dict_fused_kernel(
+    DictRowsDesc d, DictFuseParams f, uint32_t *slices, unsigned long long *counters) {
+  __shared__ uint32_t bits[LDSW];
   const uint32_t words = (uint32_t)((d.dict_length + 31) >> 5);
   const uint32_t usage_words = (MULT ? 2u : 1u) * words;
   uint32_t *l_seen = bits, *l_twice = bits + words, *l_hits = bits + usage_words;
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(kDictThreads) void dict_fused_kernel(DictRowsDesc d
       l_hits[(uint32_t)k * words + w] = dict_pack_hits(f.hits[k], w, d.dict_length);
   }
   __syncthreads();
-  unsigned long long n_valid = 0, matches[kDictMaxFused] = {0, 0, 0, 0};
-  dict_for_each_row(d, [&](int32_t e, bool valid) {
+  uint32_t n_valid = 0, matches[kDictMaxFused] = {0, 0, 0, 0};  // (a lane sees far fewer than 2^32 rows)
+  dict_for_each_row<(LDSW <= kDictLdsWordsSmall ? 2 : 4)>(d, [&](int32_t e, bool valid) {
     if (!valid) {
 #pragma unroll
       for (int k = 0; k < kDictMaxFused; k++) matches[k] += (k < f.k && f.null_is_valid[k]) ? 1 : 0;
@@ -325,10 +327,11 @@ __global__ __launch_bounds__(kReduceThreads) void dict_usage_reduce_kernel(const
     if (mult) twice[w] = acc_twice;
   }
 }
-static int dict_grid(int64_t n, int n_cu) {
+static int dict_grid(int64_t n, int n_cu, size_t lds_words = kDictLdsWords) {
   int64_t b = (n / 16 + kDictThreads - 1) / kDictThreads;  // 16 rows per thread per trip
   if (b < 1) b = 1;
-  if (b > n_cu) b = n_cu;  // 128 KiB of LDS: one workgroup per CU
+  const int64_t resident = lds_words <= (size_t)kDictLdsWordsSmall ? 2 * (int64_t)n_cu : n_cu;  // 64 / 128 KiB of LDS
+  if (b > resident) b = resident;
   return (int)b;
 }
 
@@ -336,12 +339,16 @@ void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int
                             int64_t dict_length, int dict_has_nulls, const uint8_t *hits, int null_is_valid,
                             unsigned long long *d_counters, int n_cu, hipStream_t stream) {
   DictRowsDesc d{indices, validity, offset, length, nullptr, 0, dict_length};
-  const int grid = dict_grid(length, n_cu);
-  if (!dict_has_nulls && dict_length <= (int64_t)kDictLdsWords * 32)
-    hipLaunchKernelGGL(dict_count_hits_kernel<true>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
+  const size_t words = (size_t)((dict_length + 31) >> 5);
+  const int grid = dict_grid(length, n_cu, words);
+  if (!dict_has_nulls && words <= (size_t)kDictLdsWordsSmall)
+    hipLaunchKernelGGL(dict_count_hits_kernel<kDictLdsWordsSmall>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
+                       null_is_valid, d_counters);
+  else if (!dict_has_nulls && words <= (size_t)kDictLdsWords)
+    hipLaunchKernelGGL(dict_count_hits_kernel<kDictLdsWords>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
                        null_is_valid, d_counters);
   else
-    hipLaunchKernelGGL(dict_count_hits_kernel<false>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
+    hipLaunchKernelGGL(dict_count_hits_kernel<0>, dim3(grid), dim3(kDictThreads), 0, stream, d, hits,
                        null_is_valid, d_counters);
 }
 
@@ -376,13 +383,25 @@ void launch_dict_usage_fused(const int32_t *indices, const uint8_t *validity, in
     f.counters[k] = pattern_counters[k];
     f.null_is_valid[k] = null_is_valid[k];
   }
-  const int grid = dict_grid(length, n_cu);
-  if (want_mult)
-    hipLaunchKernelGGL(dict_fused_kernel<true>, dim3(grid), dim3(kDictThreads), 0, stream, d, f, scratch, d_counters);
-  else
-    hipLaunchKernelGGL(dict_fused_kernel<false>, dim3(grid), dim3(kDictThreads), 0, stream, d, f, scratch, d_counters);
   const uint32_t words = (uint32_t)((dict_length + 31) >> 5);
-  hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 63) / 64), dim3(kReduceThreads), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
+  const size_t lds_words = (size_t)words * ((want_mult ? 2 : 1) + n_patterns);
+  const bool small = lds_words <= (size_t)kDictLdsWordsSmall;
+  // (the slices were sized by dict_usage_scratch_bytes from the usage words alone: never fewer workgroups than here)
+  const int grid = dict_grid(length, n_cu, small ? (size_t)words * (want_mult ? 2 : 1) : (size_t)kDictLdsWords);
+  const int grid_used = small ? grid : dict_grid(length, n_cu);
+  const dim3 g(grid_used), b(kDictThreads);
+  if (small) {
+    if (want_mult)
+      hipLaunchKernelGGL((dict_fused_kernel<true, kDictLdsWordsSmall>), g, b, 0, stream, d, f, scratch, d_counters);
+    else
+      hipLaunchKernelGGL((dict_fused_kernel<false, kDictLdsWordsSmall>), g, b, 0, stream, d, f, scratch, d_counters);
+  } else {
+    if (want_mult)
+      hipLaunchKernelGGL((dict_fused_kernel<true, kDictLdsWords>), g, b, 0, stream, d, f, scratch, d_counters);
+    else
+      hipLaunchKernelGGL((dict_fused_kernel<false, kDictLdsWords>), g, b, 0, stream, d, f, scratch, d_counters);
+  }
+  hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 63) / 64), dim3(kReduceThreads), 0, stream, scratch, (uint32_t)grid_used, words, want_mult, seen, twice);
 }
 
 size_t dict_usage_words(int64_t dict_length) { return (size_t)((dict_length + 31) >> 5); }
@@ -391,7 +410,7 @@ size_t dict_usage_words(int64_t dict_length) { return (size_t)((dict_length + 31
 size_t dict_usage_scratch_bytes(int64_t length, int64_t dict_length, int want_mult, int n_cu) {
   const size_t words = dict_usage_words(dict_length) * (want_mult ? 2 : 1);
   if (words > (size_t)kDictLdsWords) return 0;
-  return (size_t)dict_grid(length, n_cu) * words * sizeof(uint32_t);
+  return (size_t)dict_grid(length, n_cu, words) * words * sizeof(uint32_t);
 }
 
 // seen / twice: bitmaps of dict_usage_words(dict_length) words each (twice only written with want_mult);
@@ -401,21 +420,29 @@ void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t 
                        uint32_t *seen, uint32_t *twice, uint32_t *scratch, unsigned long long *d_counters, int n_cu,
                        hipStream_t stream) {
   DictRowsDesc d{indices, validity, offset, length, dict_validity, dict_offset, dict_length};
-  const int grid = dict_grid(length, n_cu);
+  const size_t lds_words = dict_usage_words(dict_length) * (want_mult ? 2 : 1);
   const bool lds = dict_usage_scratch_bytes(length, dict_length, want_mult, n_cu) != 0;
+  const int grid = dict_grid(length, n_cu, lds ? lds_words : (size_t)kDictLdsWords);
   const dim3 g(grid), b(kDictThreads);
-  if (lds) {
+  if (lds && lds_words <= (size_t)kDictLdsWordsSmall) {
     if (want_mult)
-      hipLaunchKernelGGL((dict_usage_kernel<true, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+      hipLaunchKernelGGL((dict_usage_kernel<kDictLdsWordsSmall, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
     else
-      hipLaunchKernelGGL((dict_usage_kernel<true, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+      hipLaunchKernelGGL((dict_usage_kernel<kDictLdsWordsSmall, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+    const uint32_t words = (uint32_t)dict_usage_words(dict_length);
+    hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 63) / 64), dim3(kReduceThreads), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
+  } else if (lds) {
+    if (want_mult)
+      hipLaunchKernelGGL((dict_usage_kernel<kDictLdsWords, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+    else
+      hipLaunchKernelGGL((dict_usage_kernel<kDictLdsWords, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
     const uint32_t words = (uint32_t)dict_usage_words(dict_length);
     hipLaunchKernelGGL(dict_usage_reduce_kernel, dim3((words + 63) / 64), dim3(kReduceThreads), 0, stream, scratch, (uint32_t)grid, words, want_mult, seen, twice);
   } else {
     if (want_mult)
-      hipLaunchKernelGGL((dict_usage_kernel<false, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+      hipLaunchKernelGGL((dict_usage_kernel<0, true>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
     else
-      hipLaunchKernelGGL((dict_usage_kernel<false, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
+      hipLaunchKernelGGL((dict_usage_kernel<0, false>), g, b, 0, stream, d, seen, twice, scratch, d_counters);
   }
 }
 
