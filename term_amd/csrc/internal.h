@@ -65,6 +65,8 @@ void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
 void launch_partition_outlier_stats(const OutlierStats *g, ScanPartial *partials, int at, hipStream_t stream);
 int partition_grid(int64_t length, int n_cu);  // workgroups of launch_partition (= ScanPartials it writes with stats)
 void launch_distinct_init(DistinctSample *sample, OutlierStats *outliers, hipStream_t stream);
+void launch_partition_init(unsigned long long *cursors, uint32_t n_buckets, OutlierStats *outliers,
+                           unsigned long long *totals, hipStream_t stream);
 void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream);
 void launch_distinct_outliers(const DistinctColDesc &d, int64_t base, uint64_t range, const HashSetView &t,
                               unsigned long long *d_counters, hipStream_t stream);
@@ -279,6 +281,8 @@ struct DistinctState {
   bool speculative = false;
   std::vector<tgx_column> retained;
   DevBuf sample;         // DistinctSample
+  bool sample_ready = false;  // `sample_host` holds this batch's sample (tgx_update reads all tasks' samples at once)
+  DistinctSample sample_host;
   DevBuf stat_partials;  // ScanPartial per workgroup of the partition pass (PartitionParams::stats) + one for outliers
   DevBuf outlier_stats;  // OutlierStats
   // A big first Utf8 batch leaves its key set as partitioned fingerprint lists (kernels/distinct128.hip, fp_*): the
@@ -347,6 +351,11 @@ struct tgx_state {
   bool arena_busy[2] = {false, false};
   int arena_cur = 0;
   size_t arena_used = 0;
+  // small read-backs (the samples of the key columns, the accumulators at finalize) land in pinned memory: copies
+  // into pageable memory are staged one by one (each waits for the one before), pinned ones are queued together and
+  // cost ONE wait
+  void *h_pinned = nullptr;
+  size_t h_pinned_cap = 0;
   bool host_direct = false;  // this update copied a HOST buffer straight from the caller's memory
   std::deque<tgx_column> dict_views;  // device views of the dictionaries of the batch being updated
   // host copies of Utf8View buffer-pointer tables whose asynchronous upload may still be pending; dropped

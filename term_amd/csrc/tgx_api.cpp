@@ -434,6 +434,7 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
     if (st->arena_event[k]) (void)hipEventDestroy(st->arena_event[k]);
     if (st->arena_host[k]) (void)hipHostFree(st->arena_host[k]);
   }
+  if (st->h_pinned) (void)hipHostFree(st->h_pinned);
   if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
   delete st;
 }
@@ -1110,6 +1111,60 @@ static void bitmap_shape(const DistinctState &ds, int64_t length, bool mult, uin
                      cap_slots < (1ull << 32) - 64;
 }
 
+static tgx_status pinned_readback(tgx_state *st, size_t bytes, tgx_error *err) {
+  if (bytes <= st->h_pinned_cap) return TGX_OK;
+  if (st->h_pinned) (void)hipHostFree(st->h_pinned);
+  st->h_pinned = nullptr;
+  st->h_pinned_cap = 0;
+  const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+  HIP_TRY(hipHostMalloc(&st->h_pinned, want, hipHostMallocDefault));
+  st->h_pinned_cap = want;
+  return TGX_OK;
+}
+
+// does this batch of an undecided Int64 key set get its range from a sample? (see distinct_prepare_numeric)
+static bool distinct_wants_sample(const DistinctState &ds, const tgx_column &c) {
+  return ds.mode == DistinctMode::kUndecided && c.type == TGX_INT64 && !ds.has_hint && c.length >= (1 << 16);
+}
+
+// The samples of ALL key columns of the batch, queued together and read back with ONE wait: a read-back costs the
+// stream's latency (~50 us) whatever its size -- two key columns sampled one after the other were 6 % of a
+// 100 M-row step.
+static tgx_status distinct_sample_all(tgx_state *st, const tgx_column *dev, tgx_error *err) {
+  const tgx_plan *plan = st->plan;
+  std::vector<size_t> who;
+  for (size_t q = 0; q < plan->distinct.size(); q++) {
+    const DistinctTask &t = plan->distinct[q];
+    st->distinct[q].sample_ready = false;
+    if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0) continue;
+    if (distinct_wants_sample(st->distinct[q], dev[t.column])) who.push_back(q);
+  }
+  if (who.empty()) return TGX_OK;
+  TGX_TRY(pinned_readback(st, who.size() * sizeof(DistinctSample), err));
+  DistinctSample *got = (DistinctSample *)st->h_pinned;
+  for (size_t k = 0; k < who.size(); k++) {
+    DistinctState &ds = st->distinct[who[k]];
+    const tgx_column &c = dev[plan->distinct[who[k]].column];
+    DistinctColDesc d;
+    d.values = c.values;
+    d.validity = c.validity;
+    d.offset = c.offset;
+    d.length = c.length;
+    d.want_multiplicity = 0;
+    d.pad = 0;
+    HIP_TRY(ds.sample.reserve(sizeof(DistinctSample)));
+    launch_distinct_init(ds.sample.as<DistinctSample>(), nullptr, st->stream);
+    launch_distinct_sample(d, ds.sample.as<DistinctSample>(), st->stream);
+    HIP_TRY(hipMemcpyAsync(&got[k], ds.sample.p, sizeof(DistinctSample), hipMemcpyDeviceToHost, st->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(st->stream));  // (the stream holds nothing but the samples when a step starts)
+  for (size_t k = 0; k < who.size(); k++) {
+    st->distinct[who[k]].sample_host = got[k];
+    st->distinct[who[k]].sample_ready = true;
+  }
+  return TGX_OK;
+}
+
 static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column &c, NumericPrep *prep,
                                            tgx_error *err) {
   const DistinctTask &task = st->plan->distinct[slot];
@@ -1124,22 +1179,27 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
       have_range = true;  // the caller vouches for [lo, hi]; keys outside it are counted and reported
       lo = ds.hint_lo;
       hi = ds.hint_hi;
-    } else if (c.type == TGX_INT64 && c.length >= (1 << 16)) {
+    } else if (distinct_wants_sample(ds, c)) {
       // (a stream of small batches -- DataFusion hands out 8192 rows at a time -- goes straight to the hash set:
-      // its inserts need no range, and the read-back below would cost one stream synchronisation per batch)
-      DistinctColDesc d;
-      d.values = c.values;
-      d.validity = c.validity;
-      d.offset = c.offset;
-      d.length = c.length;
-      d.want_multiplicity = 0;
-      d.pad = 0;
-      HIP_TRY(ds.sample.reserve(sizeof(DistinctSample)));
+      // its inserts need no range, and the read-back of a sample would cost one stream synchronisation per batch)
       DistinctSample got;
-      launch_distinct_init(ds.sample.as<DistinctSample>(), nullptr, st->stream);
-      launch_distinct_sample(d, ds.sample.as<DistinctSample>(), st->stream);
-      HIP_TRY(hipMemcpyAsync(&got, ds.sample.p, sizeof(got), hipMemcpyDeviceToHost, st->stream));
-      HIP_TRY(hipStreamSynchronize(st->stream));  // (the stream holds nothing but the sample when a step starts)
+      if (ds.sample_ready) {  // tgx_update has read the samples of all key columns at once
+        got = ds.sample_host;
+        ds.sample_ready = false;
+      } else {
+        DistinctColDesc d;
+        d.values = c.values;
+        d.validity = c.validity;
+        d.offset = c.offset;
+        d.length = c.length;
+        d.want_multiplicity = 0;
+        d.pad = 0;
+        HIP_TRY(ds.sample.reserve(sizeof(DistinctSample)));
+        launch_distinct_init(ds.sample.as<DistinctSample>(), nullptr, st->stream);
+        launch_distinct_sample(d, ds.sample.as<DistinctSample>(), st->stream);
+        HIP_TRY(hipMemcpyAsync(&got, ds.sample.p, sizeof(got), hipMemcpyDeviceToHost, st->stream));
+        HIP_TRY(hipStreamSynchronize(st->stream));
+      }
       if (got.count == 0) return TGX_OK;          // nothing valid among the sampled rows: decide on a later batch
       have_range = true;
       lo = got.min_v;
@@ -1227,9 +1287,6 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
       pp.key16 = prep.key16 ? 1 : 0;
       HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * (prep.key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
       HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
-      HIP_TRY(hipMemsetAsync(ds.cursors.p, 0, pp.n_buckets * sizeof(unsigned long long), st->stream));
-      HIP_TRY(hipMemsetAsync(ds.cursors.as<unsigned long long>() + pp.n_buckets, 0xFF,
-                             pp.n_buckets * sizeof(unsigned long long), st->stream));
       pp.lists = ds.lists.as<uint32_t>();
       pp.cursors = ds.cursors.as<unsigned long long>();
       pp.seen = ds.seen.as<uint32_t>();
@@ -1240,14 +1297,14 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
         HIP_TRY(ds.outlier_stats.reserve(sizeof(OutlierStats)));
         pp.stats = ds.stat_partials.as<ScanPartial>();
         pp.outliers = ds.outlier_stats.as<OutlierStats>();
-        launch_distinct_init(nullptr, pp.outliers, st->stream);
       }
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
+      static_assert(kCntDistinct == 0 && kCntTwice == 1, "partition_init_kernel clears the two totals together");
+      // cursors, limits, the outliers' aggregates and the totals phase 2 recomputes from the slices: one launch
+      launch_partition_init(pp.cursors, pp.n_buckets, pp.outliers, cnt + kCntDistinct, st->stream);
       {
         ProfScope ps(st, "distinct", bytes);
         launch_partition(pp, cnt, g_ctx.n_cu, st->stream);
-        // phase 2 recomputes the totals from the slices
-        HIP_TRY(hipMemsetAsync(cnt + kCntDistinct, 0, 2 * sizeof(unsigned long long), st->stream));
         HIP_TRY(launch_bucket_apply(pp, cnt, st->stream));
       }
       if (stats_slot >= 0) {
@@ -1522,6 +1579,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     // COUNT and COUNT(DISTINCT) together.  Decided here, before the scan is queued, from a sample of the batch.
     std::vector<NumericPrep> dprep(plan->distinct.size());
     std::vector<int> stats_by_partition(plan->scan.size(), -1);
+    TGX_TRY(distinct_sample_all(st, dev.data(), err));
     for (size_t q = 0; q < plan->distinct.size(); q++) {
       const DistinctTask &t = plan->distinct[q];
       if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0) continue;
@@ -1879,24 +1937,28 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   if (st->device_ready) {
     // every accumulator comes back with copies ordered on the state's OWN stream and one synchronisation of it: a
     // synchronous hipMemcpy (null stream) also waits for the other streams of the device, e.g. another state's scan
+    // ... and into PINNED memory: the four copies are queued together (into pageable memory each is staged and
+    // waited for before the next is issued: 25 us between two of them)
     std::vector<ScanAcc> d_scan(plan->scan.size());
     std::vector<CountAcc> d_count(plan->count.size());
     std::vector<ComomentAcc> d_como(plan->como.size());
-    if (!d_scan.empty())
-      HIP_TRY(hipMemcpyAsync(d_scan.data(), st->d_scan_acc.p, d_scan.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost,
+    if (st->d_distinct_counters.p) all.resize(plan->distinct.size() * kNumDistinctCounters);
+    const size_t b_scan = d_scan.size() * sizeof(ScanAcc), b_count = d_count.size() * sizeof(CountAcc),
+                 b_como = d_como.size() * sizeof(ComomentAcc), b_all = all.size() * sizeof(unsigned long long);
+    TGX_TRY(pinned_readback(st, b_scan + b_count + b_como + b_all + 64, err));
+    char *h = (char *)st->h_pinned;
+    if (b_scan) HIP_TRY(hipMemcpyAsync(h, st->d_scan_acc.p, b_scan, hipMemcpyDeviceToHost, st->stream));
+    if (b_count) HIP_TRY(hipMemcpyAsync(h + b_scan, st->d_count_acc.p, b_count, hipMemcpyDeviceToHost, st->stream));
+    if (b_como)
+      HIP_TRY(hipMemcpyAsync(h + b_scan + b_count, st->d_como_acc.p, b_como, hipMemcpyDeviceToHost, st->stream));
+    if (b_all)
+      HIP_TRY(hipMemcpyAsync(h + b_scan + b_count + b_como, st->d_distinct_counters.p, b_all, hipMemcpyDeviceToHost,
                              st->stream));
-    if (!d_count.empty())
-      HIP_TRY(hipMemcpyAsync(d_count.data(), st->d_count_acc.p, d_count.size() * sizeof(CountAcc),
-                             hipMemcpyDeviceToHost, st->stream));
-    if (!d_como.empty())
-      HIP_TRY(hipMemcpyAsync(d_como.data(), st->d_como_acc.p, d_como.size() * sizeof(ComomentAcc),
-                             hipMemcpyDeviceToHost, st->stream));
-    if (st->d_distinct_counters.p) {
-      all.resize(plan->distinct.size() * kNumDistinctCounters);
-      HIP_TRY(hipMemcpyAsync(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
-                             hipMemcpyDeviceToHost, st->stream));
-    }
     HIP_TRY(hipStreamSynchronize(st->stream));
+    if (b_scan) memcpy(d_scan.data(), h, b_scan);
+    if (b_count) memcpy(d_count.data(), h + b_scan, b_count);
+    if (b_como) memcpy(d_como.data(), h + b_scan + b_count, b_como);
+    if (b_all) memcpy(all.data(), h + b_scan + b_count + b_como, b_all);
     st->ptr_tables.clear();
     // keys that fell outside a sampled bitmap range (DistinctState::speculative): the counters just read say whether
     // any task has some -- only then is there a repair to run and its counters to read again
