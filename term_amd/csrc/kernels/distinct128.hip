@@ -477,32 +477,127 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
   fp_tile_scatter(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
 }
 
-// level 1 for Utf8View columns: a value is wherever its view says (inline in the 16 view bytes up to 12 bytes, else
-// in one of the data buffers), so there is no common span to stage: every lane fingerprints its rows from global memory
+// fingerprint() of a value of at most 16 bytes held in two registers (the logical words w0 = bytes 0..7, w1 = 8..15)
+__device__ __forceinline__ void fingerprint_words(uint64_t w0, uint64_t w1, uint32_t len, uint64_t *fa, uint64_t *fb) {
+  Fp s;
+  fp_init(s);
+  if (len > 0) {
+    if (len < 8) w0 &= (1ull << (8 * len)) - 1;
+    fp_absorb<false>(s, w0);
+  }
+  if (len > 8) {
+    if (len < 16) w1 &= (1ull << (8 * (len - 8))) - 1;
+    fp_absorb<true>(s, w1);
+  }
+  fp_finish(s, (uint64_t)len, fa, fb);
+}
+
+// level 1 for Utf8View columns.  A value is wherever its view says: inline in the 16 view bytes up to 12 bytes (those
+// are fingerprinted from the registers that hold the view), else at an offset of one of the data buffers.  Arrow's
+// builders append the long values of consecutive rows one after the other, so a wave first looks whether the long
+// values of its 128 rows lie in ONE buffer within a span that fits the stage: then the span is copied into LDS with
+// 16-byte loads and fingerprinted there like a plain Utf8 column; otherwise every lane reads its own from global
+// memory (3.1 -> 2.6 ms per 100 M x 28 B with the span staged).
 __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, FpLists out,
                                                                   unsigned long long *counters) {
-  constexpr int PER = kFpTile / 256;
+  constexpr int kRowsPerWave = kFpTile / 4, kSteps = kRowsPerWave / 128;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
   __shared__ FpTileLds s;
-  const uint32_t tid = threadIdx.x;
+  static_assert(kFpStageAlloc <= kRowsPerWave * sizeof(ulonglong2), "a wave's value bytes fit its share of the tile");
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint8_t *stage = (uint8_t *)&s.stage[wave * kRowsPerWave];  // (the records stay in registers: fp_partition_strings_kernel)
+  ulonglong2 mine[kFpTile / 256];
   fp_tile_begin(s);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
-  const int64_t first = (int64_t)blockIdx.x * kFpTile;
-  ulonglong2 mine[PER];
+  const int64_t wave_first = (int64_t)blockIdx.x * kFpTile + (int64_t)wave * kRowsPerWave;
+  struct Row {
+    u32x4 v;     // the view
+    bool valid;  // in range and not NULL (the view of a NULL slot is arbitrary: never interpreted)
+  };
+  auto row_at = [&](int64_t row) -> Row {
+    Row r;
+    const bool in = row < d.length;
+    const int64_t slot = d.offset + (in ? row : d.length - 1);
+    r.valid = in && (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1));
+    r.v = *(global_u4_ptr)((uintptr_t)d.views + (uintptr_t)slot * 16);
+    return r;
+  };
+  auto wave_min = [](uint32_t x) {
 #pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const int64_t row = first + k * 256 + (int64_t)tid;
-    mine[k].x = kEmptyKey;
-    mine[k].y = 0;
-    if (row < d.length) {
-      const int64_t slot = d.offset + row;
-      if (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1)) {
-        uintptr_t p;
-        uint64_t len;
-        utf8_value(d, slot, &p, &len);
-        fingerprint(p, len, (uint64_t *)&mine[k].x, (uint64_t *)&mine[k].y);
-      }
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      const uint32_t o = __shfl_xor(x, dlt, 64);
+      x = o < x ? o : x;
     }
-    if (mine[k].x != kEmptyKey) atomicAdd(&s.hist[mine[k].x >> 56], 1u);
+    return x;
+  };
+  auto wave_max = [](uint32_t x) {
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      const uint32_t o = __shfl_xor(x, dlt, 64);
+      x = o > x ? o : x;
+    }
+    return x;
+  };
+  Row n0 = row_at(wave_first + lane), n1 = row_at(wave_first + 64 + lane);
+#pragma unroll
+  for (int step = 0; step < kSteps; step++) {
+    const Row r0 = n0, r1 = n1;
+    if (step + 1 < kSteps) {  // the next step's views are requested before this step's bytes are staged
+      n0 = row_at(wave_first + (step + 1) * 128 + lane);
+      n1 = row_at(wave_first + (step + 1) * 128 + 64 + lane);
+    }
+    const uint32_t len0 = r0.valid ? r0.v.x : 0u, len1 = r1.valid ? r1.v.x : 0u;
+    const bool long0 = len0 > 12, long1 = len1 > 12;
+    // one buffer, one short span?  (wave-uniform; a step without long values stages nothing)
+    const unsigned long long any_long = __builtin_amdgcn_ballot_w64(long0 || long1);
+    bool staged = false;
+    int64_t base = 0;  // of the staged span, relative to the buffer (up to 15 bytes in front of the first value)
+    uint32_t n16 = 0;
+    uintptr_t buf = 0;
+    if (any_long) {
+      const int first_lane = __builtin_ctzll(any_long);
+      const uint32_t bi = (uint32_t)__shfl(long0 ? r0.v.z : r1.v.z, first_lane, 64);
+      const bool same = (!long0 || r0.v.z == bi) && (!long1 || r1.v.z == bi);
+      const uint32_t lo0 = long0 ? r0.v.w : 0xFFFFFFFFu, lo1 = long1 ? r1.v.w : 0xFFFFFFFFu;
+      const uint32_t hi0 = long0 ? r0.v.w + len0 : 0u, hi1 = long1 ? r1.v.w + len1 : 0u;  // (< 2^32: both < 2^31)
+      const uint32_t lo = wave_min(lo0 < lo1 ? lo0 : lo1), hi = wave_max(hi0 > hi1 ? hi0 : hi1);
+      buf = (uintptr_t)d.buffers[bi];
+      base = (int64_t)lo - (int64_t)((buf + lo) & 15);  // 16-byte blocks by ABSOLUTE address, as in the plain kernel
+      staged = __builtin_amdgcn_ballot_w64(!same) == 0 && (int64_t)hi - base <= (int64_t)kFpStageBytes;
+      n16 = (uint32_t)(((int64_t)hi - base + 15) >> 4);  // <= 255 when staged
+    }
+    ulonglong2 f0, f1;
+    f0.x = f1.x = kEmptyKey;
+    f0.y = f1.y = 0;
+    if (staged) {
+      global_u4_ptr src = (global_u4_ptr)(buf + (uintptr_t)base);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t k = lane + 64 * j;
+        if (k < n16) *(u32x4 *)(stage + 16 * k) = src[k];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      fingerprint_lds2(stage, long0 ? (uint32_t)((int64_t)r0.v.w - base) : 0u, long0 ? len0 : 0u,
+                       long1 ? (uint32_t)((int64_t)r1.v.w - base) : 0u, long1 ? len1 : 0u, &f0, &f1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
+    } else {
+      if (long0) fingerprint((uintptr_t)d.buffers[r0.v.z] + (uintptr_t)r0.v.w, len0, (uint64_t *)&f0.x, (uint64_t *)&f0.y);
+      if (long1) fingerprint((uintptr_t)d.buffers[r1.v.z] + (uintptr_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
+    }
+    // inline values: bytes 4..15 of the view
+    if (r0.valid && !long0)
+      fingerprint_words((uint64_t)r0.v.y | ((uint64_t)r0.v.z << 32), (uint64_t)r0.v.w, len0, (uint64_t *)&f0.x, (uint64_t *)&f0.y);
+    if (r1.valid && !long1)
+      fingerprint_words((uint64_t)r1.v.y | ((uint64_t)r1.v.z << 32), (uint64_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
+    if (!r0.valid) f0.x = kEmptyKey;
+    if (!r1.valid) f1.x = kEmptyKey;
+    if (f0.x != kEmptyKey) atomicAdd(&s.hist[f0.x >> 56], 1u);
+    if (f1.x != kEmptyKey) atomicAdd(&s.hist[f1.x >> 56], 1u);
+    mine[2 * step] = f0;
+    mine[2 * step + 1] = f1;
   }
   __syncthreads();
   fp_tile_scatter(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);

@@ -80,17 +80,21 @@ def test_long_values_that_do_not_fit_the_stage(low_threshold):
 
 
 @pytest.mark.parametrize("device", [True, False])
-@pytest.mark.parametrize("n,card", [(120_000, 10**9), (100_000, 20_000), (50_000, 4)])
-def test_utf8view_batches(low_threshold, n, card, device):
-    """Utf8View: inline and out-of-line values, junk views under NULLs, several data buffers; card 4 overflows the
+@pytest.mark.parametrize("n,card,n_buffers", [(120_000, 10**9, 3), (120_000, 10**9, 1), (100_000, 20_000, 1),
+                                              (100_000, 20_000, 2), (50_000, 4, 3)])
+def test_utf8view_batches(low_threshold, n, card, n_buffers, device):
+    """Utf8View: inline and out-of-line values, junk views under NULLs; with ONE data buffer the long values of
+    consecutive rows lie one after the other (what Arrow's builders produce: the kernel stages their span in LDS),
+    with several they are scattered (read from global memory, as are the rare 5000-byte values); card 4 overflows the
     lists (the batch is redone through the table, for HOST batches before tgx_update returns)"""
     from test_gpu_utf8view import view_column
 
-    rng = np.random.default_rng(n + card % 1000 + device)
+    rng = np.random.default_rng(n + card % 1000 + device + 7 * n_buffers)
     vals = make_strings(rng, n, card)
+    vals[1000] = "z" * 5000  # (longer than the stage: that step falls back to global memory)
     offs, data, validity = orc.utf8_from_list(vals)
     want = orc.distinct_utf8(offs, data, validity)
-    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], view_column(vals, rng, device))
+    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], view_column(vals, rng, device, n_buffers=n_buffers))
     assert took_lists(st) == 1
     check(res[0], want)
     # a second batch (the table takes over from the lists), sliced with a lead of junk views
