@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     int64_t b, e;
     uintptr_t data;
     bool valid, in;
+    uint32_t vy, vz, vw;  // VIEW: words 1..3 of the view (inline bytes, or prefix / buffer / offset)
   };
   // What a step requests up front.  Offsets: ONE load per row -- a row's end is the next row's start, fetched from
   // the neighbouring lane when the step is used (rows past the end of the column read the end offset, so they
@@ -319,6 +320,9 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     const i32x4 vw = *(gi32x4)((uintptr_t)d.views + (uintptr_t)slot * 16);
     r.valid = r.in && ((vbyte >> (slot & 7)) & 1);
     const int32_t len = r.valid ? vw.x : 0;
+    r.vy = (uint32_t)vw.y;
+    r.vz = (uint32_t)vw.z;
+    r.vw = (uint32_t)vw.w;
     r.b = 0;
     r.e = len;
     if (len <= 12)
@@ -438,9 +442,71 @@ __global__ __launch_bounds__(256) void regex_match_kernel(RegexColDesc d, DfaVie
     uint32_t st0 = 0, st1 = 0;
     int64_t wb0, we0, wb1, we1;
     if (is_view) {
-      bounds(r0, false, 0, &wb0, &we0);
-      bounds(r1, false, 0, &wb1, &we1);
-      walk2<LDS_TABLE, DIRECT>(tbl, r0.data, wb0, we0, r1.data, wb1, we1, &st0, &st1);
+      // A view says where its value is: inline (<= 12 bytes, in the view itself) or at an offset of a data buffer.
+      // Arrow's builders append the long values of consecutive rows one after the other, so the wave looks whether
+      // the long values of its 128 rows lie in ONE buffer within a span that fits the stage (next to 16-byte slots for
+      // the inline values, when there are any): then everything is walked from LDS like a plain column (1.27 -> 1.06 ms
+      // per 100 M e-mail rows held as views, 2.37 -> 1.89 ms for three patterns); otherwise every lane walks its own
+      // bytes from global memory.
+      const uint32_t len0 = (uint32_t)(r0.e - r0.b), len1 = (uint32_t)(r1.e - r1.b);  // 0 for NULL rows
+      const bool long0 = len0 > 12, long1 = len1 > 12;
+      const bool inl0 = r0.valid && !long0, inl1 = r1.valid && !long1;
+      const unsigned long long any_long = __builtin_amdgcn_ballot_w64(long0 || long1);
+      const uint32_t area = __builtin_amdgcn_ballot_w64(inl0 || inl1) ? 2048u : 0u;  // the inline slots, 16 B a row
+      bool staged = true;
+      int64_t sbase = 0;
+      uint32_t n16 = 0;
+      uintptr_t buf = 0;
+      if (any_long) {
+        const int first_lane = __builtin_ctzll(any_long);
+        const uint32_t bi = (uint32_t)__shfl(long0 ? r0.vz : r1.vz, first_lane, 64);
+        const bool same = (!long0 || r0.vz == bi) && (!long1 || r1.vz == bi);
+        const uint32_t lo0 = long0 ? r0.vw : 0xFFFFFFFFu, lo1 = long1 ? r1.vw : 0xFFFFFFFFu;
+        const uint32_t hi0 = long0 ? r0.vw + len0 : 0u, hi1 = long1 ? r1.vw + len1 : 0u;  // (both < 2^31: no wrap)
+        uint32_t lo = lo0 < lo1 ? lo0 : lo1, hi = hi0 > hi1 ? hi0 : hi1;
+#pragma unroll
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+          const uint32_t ol = __shfl_xor(lo, dlt, 64), oh = __shfl_xor(hi, dlt, 64);
+          lo = ol < lo ? ol : lo;
+          hi = oh > hi ? oh : hi;
+        }
+        buf = (uintptr_t)d.buffers[bi];
+        sbase = (int64_t)lo - (int64_t)((buf + lo) & 15);  // 16-byte blocks by ABSOLUTE address (see stage_in)
+        staged = __builtin_amdgcn_ballot_w64(!same) == 0 && (int64_t)hi - sbase <= (int64_t)(kStageBytes - area);
+        n16 = (uint32_t)(((int64_t)hi - sbase + 15) >> 4);
+      }
+      if (staged) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
+        if (inl0) *(u32x4 *)(stage + 16 * lane) = u32x4{r0.vy, r0.vz, r0.vw, 0u};
+        if (inl1) *(u32x4 *)(stage + 1024 + 16 * lane) = u32x4{r1.vy, r1.vz, r1.vw, 0u};
+        if (any_long) {
+          global_u4_ptr src = (global_u4_ptr)(buf + (uintptr_t)sbase);
+          for (uint32_t k = lane; k < n16; k += 64) *(u32x4 *)(stage + area + 16 * k) = src[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t o0 = long0 ? area + (uint32_t)((int64_t)r0.vw - sbase) : 16u * lane;
+        uint32_t o1 = long1 ? area + (uint32_t)((int64_t)r1.vw - sbase) : 1024u + 16u * lane;
+        uint32_t n0 = len0, n1 = len1;
+        if (d.trim) {  // SQL TRIM(col) = btrim(col, ' '): U+0020 only
+          while (n0 && stage[o0] == 0x20) o0++, n0--;
+          while (n0 && stage[o0 + n0 - 1] == 0x20) n0--;
+          while (n1 && stage[o1] == 0x20) o1++, n1--;
+          while (n1 && stage[o1 + n1 - 1] == 0x20) n1--;
+        }
+        if constexpr (LDS_TABLE) {
+          walk2_staged<DIRECT>(tbl, stage, o0, n0, o1, n1, &st0, &st1);
+        } else {
+          st0 = walk<LDS_TABLE, true, DIRECT>(tbl, 0, (int64_t)o0, (int64_t)(o0 + n0), stage, 0);
+          st1 = walk<LDS_TABLE, true, DIRECT>(tbl, 0, (int64_t)o1, (int64_t)(o1 + n1), stage, 0);
+        }
+        stage_done();
+      } else {
+        bounds(r0, false, 0, &wb0, &we0);
+        bounds(r1, false, 0, &wb1, &we1);
+        walk2<LDS_TABLE, DIRECT>(tbl, r0.data, wb0, we0, r1.data, wb1, we1, &st0, &st1);
+      }
     } else {
       // the step's values are contiguous: [b of its first row, e of its last)
       const int64_t b_first = __shfl(r0.b, 0, 64), e_half = __shfl(r0.e, 63, 64), e_last = __shfl(r1.e, 63, 64);
