@@ -1403,9 +1403,11 @@ tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
     return TGX_OK;
   }
   std::vector<unsigned long long> all(st->distinct.size() * kNumDistinctCounters);
-  HIP_TRY(hipMemcpyAsync(all.data(), st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
+  TGX_TRY(pinned_readback(st, all.size() * sizeof(unsigned long long), err));
+  HIP_TRY(hipMemcpyAsync(st->h_pinned, st->d_distinct_counters.p, all.size() * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost, st->stream));
   HIP_TRY(hipStreamSynchronize(st->stream));
+  memcpy(all.data(), st->h_pinned, all.size() * sizeof(unsigned long long));
   for (size_t k = 0; k < st->distinct.size(); k++) {
     DistinctState &ds = st->distinct[k];
     if ((ds.speculative || ds.fp_staged) && !ds.retained.empty() &&
