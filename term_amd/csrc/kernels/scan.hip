@@ -141,19 +141,30 @@ __device__ void scan_ragged(const ScanColDesc &c, int64_t r0, int64_t r1, int la
 // ---------------------------------------------------------------------------------------------
 // The KLL sampler riding on the scan (kll_types.h, ScanKll): every wave keeps the values of its own row stream that
 // have not been grouped yet in a private LDS ring -- at most 2^top - 1 pending ones plus the 512 a tile brings --
-// and, whenever 2^top of them are complete, keeps one member of the group chosen by a counter hash.  Per value this
+// (the ring wraps: nothing is ever moved) and, whenever 2^top of them are complete, keeps one member of the group
+// chosen by a counter hash.  Per value this
 // costs a ballot, an mbcnt and one LDS store next to the column's other accumulators; the column crosses HBM once.
 struct KllLane {
   double mn, mx;           // NaN-ignoring MIN / MAX (KllSketch::update drops NaN, kll_sketch.rs:197-199)
+  uint32_t head;           // ring slot of the oldest pending value, wave-uniform
   uint32_t pending;        // values in the ring, wave-uniform
   uint32_t groups;         // groups emitted so far, wave-uniform
+  uint32_t rsize;          // slots of the ring: 2^top + kTileRows (pending < 2^top before a tile, < rsize after it)
 };
 
-__device__ __forceinline__ void kll_lane_init(KllLane &K) {
+__device__ __forceinline__ void kll_lane_init(KllLane &K, int top = 0) {
   K.mn = __longlong_as_double(0x7FF0000000000000LL);
   K.mx = -K.mn;
+  K.head = 0;
   K.pending = 0;
   K.groups = 0;
+  K.rsize = (1u << top) + (uint32_t)kTileRows;
+}
+
+// the ring wraps: slot of the i-th pending value (i < rsize, head < rsize: one conditional subtraction)
+__device__ __forceinline__ uint32_t kll_slot(const KllLane &K, uint32_t i) {
+  const uint32_t p = K.head + i;
+  return p >= K.rsize ? p - K.rsize : p;
 }
 
 __device__ __forceinline__ uint64_t scan_mix(uint64_t x) {
@@ -177,7 +188,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <bool TRACK = true>
 __device__ __forceinline__ void kll_push(KllLane &K, double *ring, double x, bool ok) {
   const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-  const uint32_t pos = K.pending + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  const uint32_t pos = kll_slot(K, K.pending + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)));
   if (ok) ring[pos] = x;
   K.pending += (uint32_t)__builtin_popcountll(m);
   if (TRACK) {
@@ -187,7 +198,7 @@ __device__ __forceinline__ void kll_push(KllLane &K, double *ring, double x, boo
   }
 }
 
-// emits the complete groups of the ring and moves the rest to its front
+// emits the complete groups of the ring; the rest stays where it is (the ring wraps: nothing is moved)
 __device__ __forceinline__ void kll_drain(KllLane &K, double *ring, const ScanKll &q, uint32_t wave_slot, int lane) {
   const uint32_t top = (uint32_t)q.top;
   const uint32_t ng = K.pending >> top;
@@ -198,15 +209,13 @@ __device__ __forceinline__ void kll_drain(KllLane &K, double *ring, const ScanKl
     const uint32_t g = g0 + (uint32_t)lane;
     if (g < ng && K.groups + g < (uint32_t)q.cap) {
       const uint64_t h = scan_mix(q.salt ^ ((uint64_t)wave_slot << 36) ^ (uint64_t)(K.groups + g));
-      out[K.groups + g] = ring[(g << top) + ((uint32_t)(h >> 20) & ((1u << top) - 1u))];
+      out[K.groups + g] = ring[kll_slot(K, (g << top) + ((uint32_t)(h >> 20) & ((1u << top) - 1u)))];
     }
   }
-  const uint32_t rem = K.pending & ((1u << top) - 1u), src = ng << top;  // src >= 2^top > rem: no overlap
-  wave_lds_fence();
-  for (uint32_t r = (uint32_t)lane; r < rem; r += 64) ring[r] = ring[src + r];
-  wave_lds_fence();
+  wave_lds_fence();  // (the slots of the emitted groups are free for the next tile's values from here on)
+  K.head = kll_slot(K, ng << top);
   K.groups += ng;
-  K.pending = rem;
+  K.pending &= (1u << top) - 1u;
 }
 
 // end of the wave's stream: the pending values leave as weight-1 leftovers, unused slots as NaN
@@ -215,7 +224,7 @@ __device__ __forceinline__ void kll_finish_wave(KllLane &K, double *ring, const 
   wave_lds_fence();
   const double nan = __longlong_as_double(0x7FF8000000000000LL);
   double *left = q.left + ((size_t)wave_slot << q.top);
-  for (uint32_t i = (uint32_t)lane; i < (1u << q.top); i += 64) left[i] = i < K.pending ? ring[i] : nan;
+  for (uint32_t i = (uint32_t)lane; i < (1u << q.top); i += 64) left[i] = i < K.pending ? ring[kll_slot(K, i)] : nan;
   double *out = q.picks + (size_t)wave_slot * (size_t)q.cap;
   for (uint32_t g = K.groups + (uint32_t)lane; g < (uint32_t)q.cap; g += 64) out[g] = nan;
   double mn = K.mn, mx = K.mx;
@@ -446,7 +455,7 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
   KllLane K;
   double *ring = nullptr;
   if (KLL) {
-    kll_lane_init(K);
+    kll_lane_init(K, c.kll.top);
     ring = scan_dyn_lds + (size_t)wave * ((1u << c.kll.top) + kTileRows);
   }
   const uint32_t wave_slot = (uint32_t)wave_global;
@@ -807,8 +816,8 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
 #pragma unroll
   for (int k = 0; k < 5; k++) m.s[k] = m.c[k] = 0.0;
   KllLane Kx, Ky;
-  kll_lane_init(Kx);
-  kll_lane_init(Ky);
+  kll_lane_init(Kx, P.x.kll.top);
+  kll_lane_init(Ky, P.y.kll.top);
   double *rx = nullptr, *ry = nullptr;
   if (KLL) {
     // rings of the sampled columns of this wave, x first
