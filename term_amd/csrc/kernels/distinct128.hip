@@ -639,15 +639,17 @@ __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uin
 }
 
 // one workgroup per final list: distinct keys / keys seen twice of the list -> per_list[list]
-__global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list) {
+template <uint32_t SLOTS, uint32_t THREADS>  // THREADS: 256 for the small table, 1024 for the big ones (one or two
+                                             // workgroups fit a CU then: the waves have to come from inside)
+__global__ __launch_bounds__(THREADS) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list) {
   // a slot is (16 bits of the first word) << 16 | index of the record that owns it: ONE 32-bit compare-and-swap claims
   // it and names the owner (16 KiB of table: eight workgroups a CU).  Equal tags are settled by reading the owner's
   // record back from the list (it has just come through this CU's caches); tag, slot and list together fix 44 bits,
   // so that read is rare unless the values really are equal.
-  static_assert(kFpListMax <= 0xFFFFu, "a record index fits 16 bits");
-  __shared__ uint32_t slot[kFpSlots];
-  __shared__ uint32_t dupw[kFpSlots / 32];
-  __shared__ uint32_t s_new[4], s_dup[4];
+  static_assert(kFpListMax <= 0xFFFFu && SLOTS >= 4096 && (SLOTS & (SLOTS - 1)) == 0, "a record index fits 16 bits");
+  __shared__ uint32_t slot[SLOTS];
+  __shared__ uint32_t dupw[SLOTS / 32];
+  __shared__ uint32_t s_new[THREADS / 64], s_dup[THREADS / 64];
   constexpr uint32_t kFree = 0xFFFFFFFFu;  // (no record has index 0xFFFF)
   const uint32_t tid = threadIdx.x;
   const uint32_t offered = l.offered[blockIdx.x];
@@ -660,25 +662,25 @@ __global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult,
   ulonglong2 r[kAhead];
 #pragma unroll
   for (int j = 0; j < kAhead; j++)
-    if (tid + 256 * j < offered) r[j] = recs[tid + 256 * j];
-  for (uint32_t k = tid; k < kFpSlots; k += 256) slot[k] = kFree;
-  if (tid < kFpSlots / 32) dupw[tid] = 0;
+    if (tid + THREADS * j < offered) r[j] = recs[tid + THREADS * j];
+  for (uint32_t k = tid; k < SLOTS; k += THREADS) slot[k] = kFree;
+  if (tid < SLOTS / 32) dupw[tid] = 0;
   __syncthreads();
   uint32_t n_new = 0, n_dup = 0;
-  for (uint32_t i0 = tid; i0 < offered; i0 += 256 * kAhead) {
+  for (uint32_t i0 = tid; i0 < offered; i0 += THREADS * kAhead) {
     ulonglong2 nx[kAhead];
 #pragma unroll
     for (int j = 0; j < kAhead; j++) {
-      const uint32_t i = i0 + 256 * (kAhead + j);
+      const uint32_t i = i0 + THREADS * (kAhead + j);
       if (i < offered) nx[j] = recs[i];
     }
 #pragma unroll
     for (int j = 0; j < kAhead; j++) {
-      const uint32_t i = i0 + 256 * j;
+      const uint32_t i = i0 + THREADS * j;
       if (i >= offered) break;
       const uint32_t tag = (uint32_t)r[j].x & 0xFFFFu;
       const uint32_t mine = (tag << 16) | i;
-      uint32_t hs = (uint32_t)(r[j].x >> 32) & (kFpSlots - 1);
+      uint32_t hs = (uint32_t)(r[j].x >> 32) & (SLOTS - 1);
       for (;;) {
         const uint32_t old = atomicCAS(&slot[hs], kFree, mine);
         if (old == kFree) {
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult,
             break;
           }
         }
-        hs = (hs + 1) & (kFpSlots - 1);
+        hs = (hs + 1) & (SLOTS - 1);
       }
     }
 #pragma unroll
@@ -712,8 +714,14 @@ __global__ __launch_bounds__(256) void fp_count_kernel(FpLists l, int want_mult,
     s_dup[tid >> 6] = n_dup;
   }
   __syncthreads();
-  if (tid == 0)
-    per_list[blockIdx.x] = make_uint2(s_new[0] + s_new[1] + s_new[2] + s_new[3], s_dup[0] + s_dup[1] + s_dup[2] + s_dup[3]);
+  if (tid == 0) {
+    uint32_t a = 0, b = 0;
+    for (uint32_t w = 0; w < THREADS / 64; w++) {
+      a += s_new[w];
+      b += s_dup[w];
+    }
+    per_list[blockIdx.x] = make_uint2(a, b);
+  }
 }
 
 // the batch's counts into the task's counters (valid rows = records offered to the first level)
@@ -1003,7 +1011,15 @@ void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, uns
 
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
                      unsigned long long *d_counters, hipStream_t stream) {
-  hipLaunchKernelGGL(fp_count_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, want_mult, per_list);
+  // the table holds a list at load <= 3/4: 16 KiB of LDS (eight workgroups a CU) up to 3072 records a list, i.e.
+  // batches up to ~157 M rows; 64 / 128 KiB for batches up to ~0.6 / ~1.4 G rows
+  const dim3 grid(kFpFan * kFpFan);
+  if (level2.cap <= 3072)
+    hipLaunchKernelGGL((fp_count_kernel<4096, 256>), grid, dim3(256), 0, stream, level2, want_mult, per_list);
+  else if (level2.cap <= 12288)
+    hipLaunchKernelGGL((fp_count_kernel<16384, 1024>), grid, dim3(1024), 0, stream, level2, want_mult, per_list);
+  else
+    hipLaunchKernelGGL((fp_count_kernel<32768, 1024>), grid, dim3(1024), 0, stream, level2, want_mult, per_list);
   hipLaunchKernelGGL(fp_totals_kernel, dim3(64), dim3(256), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan), offered1,
                      d_counters);
 }

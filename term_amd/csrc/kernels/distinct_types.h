@@ -96,8 +96,9 @@ constexpr int kFpFan = 256;              // lists per level
 constexpr int kFpXcds = 8;               // level 1 keeps a set of lists per XCD (workgroup w runs on XCD w % 8): runs that
                                          // neighbour each other in a list then come out of ONE L2, where partial lines meet
 constexpr int kFpTile = 2048;            // records a workgroup groups in LDS at a time
-constexpr uint32_t kFpSlots = 4096;      // LDS table of one final list
-constexpr uint32_t kFpListMax = 3072;    // records a final list may hold (load <= 3/4)
+constexpr uint32_t kFpSlots = 4096;      // LDS table of one final list (16 KiB: eight workgroups a CU); lists of bigger
+                                         // batches get 16384 or 32768 slots (fp_count_kernel<SLOTS>), load <= 3/4
+constexpr uint32_t kFpListMax = 24576;   // records a final list may hold at most (3/4 of 32768; a 16-bit record index)
 constexpr int64_t kFpMinRows = 1 << 21;  // smaller batches go straight into the global table (same time at 1-2 M rows)
 struct FpLists {
   uint64_t *recs;     // [lists][cap] records of two words

@@ -222,3 +222,20 @@ def test_real_threshold_closed_form():
     st.update([col.sliced(half, n - half)])
     r2 = st.finalize()[0]
     assert (r2.total, r2.non_null, r2.distinct, r2.groups_once) == (r.total, r.non_null, r.distinct, r.groups_once)
+
+
+def test_batch_beyond_the_small_table_closed_form():
+    """170 M generated e-mail rows: a final list holds more than the 3072 records the 16 KiB table takes, so the count
+    pass runs with its 64 KiB table (the 128 KiB one, past ~0.6 G rows, is exercised by tools/bench_strings.py
+    --rows 900000000, which asserts the same closed form)"""
+    import torch
+    from test_gpu_configs import _email_column
+
+    n = 170_000_000
+    offsets, data, validity, L, expect = _email_column(torch, n)
+    col = T.Column(T.LARGE_UTF8, n, offsets=offsets, data=data, validity=validity)
+    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], col)
+    assert took_lists(st) == 1
+    r = res[0]
+    assert (r.total, r.non_null, r.distinct, r.groups_once) == (n, n - expect["nulls"], n - expect["nulls"],
+                                                               n - expect["nulls"])
