@@ -119,6 +119,10 @@ void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, uns
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
                      unsigned long long *d_counters, hipStream_t stream);
 void launch_fp_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream);
+// the same for big batches of keys without a dense range (distinct.hip, key_*): 8-byte records (the mixed key)
+void launch_key_lists(const DistinctColDesc &d, const FpLists &level1, const FpLists &level2, int want_mult,
+                      uint2 *per_list, unsigned long long *d_counters, hipStream_t stream);
+void launch_key_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream);
 void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream);
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,

@@ -18,6 +18,7 @@
 
 #include "device_types.h"
 #include "distinct_types.h"
+#include "lists.h"
 
 namespace tgx {
 
@@ -950,6 +951,99 @@ static inline int grid_for(uint64_t items) {
   if (blocks < 1) blocks = 1;
   if (blocks > 256 * 8) blocks = 256 * 8;
   return (int)blocks;
+}
+
+// ---- big batches of keys that have no dense range (sparse Int64 ids, Float64): no global atomic per key -----------
+// The hash set takes one 64-byte read-modify-write at the memory side per KEY (~27 G keys/s whatever the table's
+// size).  A batch big enough to care goes the way of the big Utf8 batches instead (lists.h, distinct128.hip): every
+// key is replaced by its splitmix64 mix -- a bijection, so equal records mean equal keys: the count is EXACT -- and
+// the mixes are partitioned twice by 8 bits into kFpFan^2 lists that are deduplicated one by one in LDS.  The lists
+// are the key set until something needs the table (key_insert_kernel un-mixes them into it); a list that overflows
+// (heavily repeated keys) flags the batch for a redo through the table.
+__device__ __forceinline__ uint64_t unmix64(uint64_t x) {  // inverse of mix64
+  x ^= (x >> 31) ^ (x >> 62);
+  x *= 0x319642b2d24d8ec3ULL;
+  x ^= (x >> 27) ^ (x >> 54);
+  x *= 0x96de1b173f119089ULL;
+  x ^= (x >> 30) ^ (x >> 60);
+  return x;
+}
+
+// level 1: a tile of the column's keys -> per-XCD lists by the top byte of their mix
+__global__ __launch_bounds__(256) void key_partition_values_kernel(DistinctColDesc d, FpLists out,
+                                                                    unsigned long long *counters) {
+  constexpr int PER = kFpTile / 256;
+  __shared__ FpTileLdsT<KeyRec> s;
+  const uint32_t tid = threadIdx.x;
+  fp_tile_begin(s);
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  const int64_t first = (int64_t)blockIdx.x * kFpTile;
+  KeyRec mine[PER];
+  uint32_t present = 0, n_empty = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int64_t row = first + k * 256 + (int64_t)tid;
+    mine[k] = 0;
+    if (row < d.length) {
+      bool valid = true;
+      if (vbits) {
+        const int64_t b = d.offset + row;
+        valid = (vbits[b >> 3] >> (b & 7)) & 1;
+      }
+      if (valid) {
+        const uint64_t key = (uint64_t)vals[row];
+        if (key == kEmptyKey) {
+          n_empty++;  // the table's free-slot marker: counted on the side, as everywhere
+        } else {
+          mine[k] = mix64(key);
+          present |= 1u << k;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PER; k++)
+    if ((present >> k) & 1u) atomicAdd(&s.hist[mine[k] >> 56], 1u);
+  if (n_empty) {  // (rare)
+    atomicAdd(&counters[kCntEmptyRows], (unsigned long long)n_empty);
+    atomicAdd(&counters[kCntValidRows], (unsigned long long)n_empty);
+  }
+  __syncthreads();
+  fp_tile_scatter(s, mine, present, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
+}
+
+// the lists' records back to keys and into the global table (counted already: no counters)
+__global__ __launch_bounds__(256) void key_insert_kernel(FpLists l, HashSetView t, int want_mult) {
+  const uint32_t offered = l.offered[blockIdx.x];
+  const uint32_t n = offered < l.cap ? offered : (uint32_t)l.cap;
+  const KeyRec *recs = (const KeyRec *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    int became_dup = 0;
+    (void)hash_insert(t, unmix64(recs[i]), want_mult, 0, &became_dup);
+  }
+}
+
+void launch_key_lists(const DistinctColDesc &d, const FpLists &level1, const FpLists &level2, int want_mult,
+                      uint2 *per_list, unsigned long long *d_counters, hipStream_t stream) {
+  const int64_t tiles = (d.length + kFpTile - 1) / kFpTile;
+  hipLaunchKernelGGL(key_partition_values_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
+  const uint32_t tiles_per_list = (uint32_t)((level1.cap + kFpTile - 1) / kFpTile);
+  hipLaunchKernelGGL(fp_partition_lists_kernel<KeyRec>, dim3(kFpXcds * kFpFan * tiles_per_list), dim3(256), 0, stream,
+                     level1, tiles_per_list, level2, d_counters);
+  const dim3 grid(kFpFan * kFpFan);
+  if (level2.cap <= 3072)
+    hipLaunchKernelGGL((fp_count_kernel<4096, 256, KeyRec>), grid, dim3(256), 0, stream, level2, want_mult, per_list);
+  else if (level2.cap <= 12288)
+    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, KeyRec>), grid, dim3(1024), 0, stream, level2, want_mult, per_list);
+  else
+    hipLaunchKernelGGL((fp_count_kernel<32768, 1024, KeyRec>), grid, dim3(1024), 0, stream, level2, want_mult, per_list);
+  hipLaunchKernelGGL(fp_totals_kernel<KeyRec>, dim3(64), dim3(256), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan),
+                     level1.offered, d_counters);
+}
+
+void launch_key_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream) {
+  hipLaunchKernelGGL(key_insert_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, t, want_mult);
 }
 
 void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,

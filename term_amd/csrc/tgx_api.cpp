@@ -941,7 +941,7 @@ static bool fp_lists_fit(const tgx_column &c) {
   // TGX_FP_LISTS_MIN_ROWS: smallest batch that takes this path (tests lower it; a huge value turns the path off)
   int64_t min_rows = kFpMinRows;
   if (const char *e = getenv("TGX_FP_LISTS_MIN_ROWS")) min_rows = std::max<int64_t>(1, atoll(e));
-  return is_any_string(c.type) && c.length >= min_rows &&
+  return (is_any_string(c.type) || c.type == TGX_INT64 || c.type == TGX_FLOAT64) && c.length >= min_rows &&
          fp_list_cap(c.length, (uint64_t)kFpFan * kFpFan) <= kFpListMax;
 }
 static void fp_views(const DistinctState &ds, FpLists *l1, FpLists *l2) {
@@ -952,18 +952,24 @@ static void fp_views(const DistinctState &ds, FpLists *l1, FpLists *l2) {
   l2->offered = ds.fp_offered.as<uint32_t>() + kFpXcds * kFpFan;
   l2->cap = ds.fp_cap2;
 }
-static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
-  DistinctState &ds = st->distinct[slot];
-  const bool mult = st->plan->distinct[slot].multiplicity;
+// sizes and clears the two levels of lists for a batch of `rows` records of `rec_bytes` bytes
+static tgx_status fp_lists_prepare(tgx_state *st, DistinctState &ds, int64_t rows, size_t rec_bytes, tgx_error *err) {
   constexpr uint64_t kLists2 = (uint64_t)kFpFan * kFpFan;
   constexpr uint64_t kLists1 = (uint64_t)kFpXcds * kFpFan;
-  ds.fp_cap1 = fp_list_cap(c.length, kLists1);
-  ds.fp_cap2 = fp_list_cap(c.length, kLists2);
-  HIP_TRY(ds.fp_level1.reserve(kLists1 * ds.fp_cap1 * 16));
-  HIP_TRY(ds.fp_level2.reserve(kLists2 * ds.fp_cap2 * 16));
+  ds.fp_cap1 = fp_list_cap(rows, kLists1);
+  ds.fp_cap2 = fp_list_cap(rows, kLists2);
+  HIP_TRY(ds.fp_level1.reserve(kLists1 * ds.fp_cap1 * rec_bytes));
+  HIP_TRY(ds.fp_level2.reserve(kLists2 * ds.fp_cap2 * rec_bytes));
   HIP_TRY(ds.fp_offered.reserve((kLists1 + kLists2) * sizeof(uint32_t)));
   HIP_TRY(ds.fp_per_list.reserve(kLists2 * sizeof(uint2)));
   HIP_TRY(hipMemsetAsync(ds.fp_offered.p, 0, (kLists1 + kLists2) * sizeof(uint32_t), st->stream));
+  return TGX_OK;
+}
+
+static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = st->plan->distinct[slot].multiplicity;
+  TGX_TRY(fp_lists_prepare(st, ds, c.length, 16, err));
   FpLists l1, l2;
   fp_views(ds, &l1, &l2);
   ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
@@ -1321,6 +1327,20 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
       launch_distinct_bitmap(d, bitmap_view(ds), ds.counters.as<unsigned long long>(), st->stream);
     }
   } else {
+    if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
+    if (ds.capacity == 0 && fp_lists_fit(c)) {
+      // the first big batch of a key set without a dense range: mixed keys through partitioned lists, deduplicated
+      // in LDS (kernels/distinct.hip, key_*) -- no global atomic per key; the lists are the set until the table is needed
+      TGX_TRY(fp_lists_prepare(st, ds, c.length, 8, err));
+      FpLists l1, l2;
+      fp_views(ds, &l1, &l2);
+      ProfScope ps(st, "distinct", bytes), ps_lists(st, "distinct_lists", 0);
+      launch_key_lists(d, l1, l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), ds.counters.as<unsigned long long>(),
+                       st->stream);
+      ds.fp_staged = true;
+      ds.retained.push_back(c);  // (a DEVICE view, or a staged one looked at before the update returns)
+      return TGX_OK;
+    }
     TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
     ProfScope ps(st, "distinct", bytes);
     launch_distinct_hash(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
@@ -1345,6 +1365,17 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       HIP_TRY(hipMemsetAsync(ds.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
       for (const tgx_column &col : ds.retained) {
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)col.length, err));
+        if (!ds.wide) {  // a numeric key column
+          DistinctColDesc d;
+          d.values = col.values;
+          d.validity = col.validity;
+          d.offset = col.offset;
+          d.length = col.length;
+          d.want_multiplicity = mult ? 1 : 0;
+          d.pad = 0;
+          launch_distinct_hash(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+          continue;
+        }
         const bool view = col.type == TGX_UTF8_VIEW;
         launch_distinct_utf8(col.offsets, col.data, view ? col.values : nullptr, view ? col.variadic : nullptr,
                              col.validity, col.offset, col.length, col.type == TGX_LARGE_UTF8, mult ? 1 : 0,
@@ -1354,7 +1385,10 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       FpLists l1, l2;
       fp_views(ds, &l1, &l2);
       TGX_TRY(hash_ensure(st, ds, mult, c[kCntDistinct], err));
-      launch_fp_insert(l2, hash_view(ds), mult ? 1 : 0, st->stream);
+      if (ds.wide)
+        launch_fp_insert(l2, hash_view(ds), mult ? 1 : 0, st->stream);
+      else
+        launch_key_insert(l2, hash_view(ds), mult ? 1 : 0, st->stream);
     }
     HIP_TRY(hipStreamSynchronize(st->stream));
     ds.retained.clear();

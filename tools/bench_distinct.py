@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Times the exact COUNT(DISTINCT) path alone (range-partitioned bitmap) on the bench table's two unique columns.
+"""Times the exact COUNT(DISTINCT) paths alone.
 
-    python tools/bench_distinct.py [--rows N] [--steps K]
-The value range is declared up front (tgx_distinct_range_hint), so no scan runs: the numbers are the partition +
-bucket-apply kernels only (tgx_profile_get("distinct"))."""
+    python tools/bench_distinct.py [--rows N] [--steps K] [--sparse-rows M]
+(1) the range-partitioned bitmap on the bench table's two unique columns: the value range is declared up front
+    (tgx_distinct_range_hint), so no scan runs -- the numbers are the partition + bucket-apply kernels only
+    (tgx_profile_get("distinct"));
+(2) keys WITHOUT a dense range (sparse Int64 ids, Float64 values), M rows: through the key lists (mixed keys
+    partitioned twice, deduplicated in LDS) and, with TGX_FP_LISTS_MIN_ROWS raised out of reach, through the hash
+    table (one memory-side atomic per key)."""
 import argparse
 import os
 import sys
@@ -16,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--sparse-rows", type=int, default=1_000_000_000)
     args = ap.parse_args()
     import torch
     import term_amd as T
@@ -47,6 +52,34 @@ def main():
         prof = st.profile_get("distinct")
         print("col %d (%s, validity=%s): distinct=%d  wall %.2f ms/step, kernels %.2f ms/step" %
               (ci, layout[ci][0], validity is not None, res[0].distinct, dt, prof["total_ms"] / args.steps))
+    del table
+    # ---- (2) sparse keys ----
+    m = (args.sparse_rows // 64) * 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ids = torch.randint(-2**62, 2**62, (m,), dtype=torch.int64, device="cuda", generator=g)
+    vals = torch.randn(m, dtype=torch.float64, device="cuda", generator=g)
+    for name, col in (("sparse Int64 ids", T.Column.int64(ids, None, length=m)),
+                      ("Float64 values", T.Column.float64(vals, None, length=m))):
+        for path, env in (("key lists", None), ("hash table", str(1 << 62))):
+            if env is None:
+                os.environ.pop("TGX_FP_LISTS_MIN_ROWS", None)
+            else:
+                os.environ["TGX_FP_LISTS_MIN_ROWS"] = env
+            plan = T.Plan([spec(T.DISTINCT, 0)])
+            st = T.State(plan)
+            for it in range(args.steps + 2):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                st.reset()
+                st.update([col])
+                res = st.finalize()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps * 1e3
+            print("%s, %d rows, %s: distinct=%d  wall %.2f ms/step = %.1f G rows/s" %
+                  (name, m, path, res[0].distinct, dt, m / dt / 1e6))
+            del st
+    os.environ.pop("TGX_FP_LISTS_MIN_ROWS", None)
 
 
 if __name__ == "__main__":
