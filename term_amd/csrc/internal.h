@@ -114,6 +114,8 @@ void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const
 void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
                                int64_t offset, int64_t length, const FpLists &level1, unsigned long long *d_counters,
                                hipStream_t stream);
+void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, unsigned long long *d_counters,
+                                hipStream_t stream);
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
                                hipStream_t stream);
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,

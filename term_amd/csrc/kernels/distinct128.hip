@@ -633,57 +633,67 @@ __global__ __launch_bounds__(256) void hash_export_scatter128_kernel(HashSetView
 // ---- tuples of columns: COUNT(DISTINCT (a, b, ...)) / GROUP BY a, b, ... ------------------------------------
 // Every component is reduced to 128 bits (numeric: its bit pattern; string: the fingerprint above; NULL: a
 // marker no value maps to) and the components are chained position by position into the tuple's fingerprint.
+__device__ __forceinline__ void tuple_fingerprint(const TupleDesc &d, int64_t i, uint64_t *out_a, uint64_t *out_b,
+                                                  bool *all_valid_out) {
+  uint64_t fa = 0x6a09e667f3bcc908ULL, fb = 0xbb67ae8584caa73bULL;
+  bool all_valid = true;
+  for (int c = 0; c < d.n_cols; c++) {
+    const TupleCol &col = d.cols[c];
+    const int64_t slot = col.offset + i;
+    global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)col.validity;
+    uint64_t ca, cb;
+    if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) {
+      all_valid = false;
+      ca = 0x4e554c4c4e554c4cULL;  // "NULLNULL": tagged below so that no value of any type collides with it
+      cb = 0;
+    } else if (col.kind == 0) {  // Int64 / Float64: the 64 bits themselves
+      ca = (uint64_t)((global_i64_ptr)(uintptr_t)col.values)[slot];
+      cb = 1;
+    } else {
+      int64_t b, e;
+      uintptr_t base = (uintptr_t)col.data;
+      if (col.kind == 3) {
+        global_i32_ptr vw = (global_i32_ptr)((uintptr_t)col.values + (uintptr_t)slot * 16);
+        const int32_t len = vw[0];
+        b = 0;
+        e = len;
+        if (len <= 12) {
+          base = (uintptr_t)col.values + (uintptr_t)slot * 16 + 4;
+        } else {
+          const int32_t bi = vw[2], bo = vw[3];
+          base = (uintptr_t)col.buffers[bi] + (uintptr_t)(uint32_t)bo;
+        }
+      } else if (col.kind == 2) {
+        global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
+        b = off[slot];
+        e = off[slot + 1];
+      } else {
+        global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
+        b = off[slot];
+        e = off[slot + 1];
+      }
+      fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &ca, &cb);
+      cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
+    }
+    fa = rotl64(fa ^ mix64w(ca + 0x165667b19e3779f9ULL * (uint64_t)(c + 1)), 27) * 0x9fb21c651e98df25ULL + cb;
+    fb = rotl64(fb ^ mix64w(cb ^ rotl64(ca, 32) ^ 0x27d4eb2f165667c5ULL), 31) * 0xd6e8feb86659fd93ULL + ca;
+  }
+  fa = mix64w(fa);
+  fb = mix64w(fb ^ rotl64(fa, 17));
+  if (fa == kEmptyKey) fa -= 1;
+  if (fb == kEmptyKey) fb -= 1;
+  *out_a = fa;
+  *out_b = fb;
+  *all_valid_out = all_valid;
+}
+
 __global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSetView t, unsigned long long *counters) {
   unsigned long long n_new = 0, n_dup = 0, n_valid = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
-    uint64_t fa = 0x6a09e667f3bcc908ULL, fb = 0xbb67ae8584caa73bULL;
-    bool all_valid = true;
-    for (int c = 0; c < d.n_cols; c++) {
-      const TupleCol &col = d.cols[c];
-      const int64_t slot = col.offset + i;
-      global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)col.validity;
-      uint64_t ca, cb;
-      if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) {
-        all_valid = false;
-        ca = 0x4e554c4c4e554c4cULL;  // "NULLNULL": tagged below so that no value of any type collides with it
-        cb = 0;
-      } else if (col.kind == 0) {  // Int64 / Float64: the 64 bits themselves
-        ca = (uint64_t)((global_i64_ptr)(uintptr_t)col.values)[slot];
-        cb = 1;
-      } else {
-        int64_t b, e;
-        uintptr_t base = (uintptr_t)col.data;
-        if (col.kind == 3) {
-          global_i32_ptr vw = (global_i32_ptr)((uintptr_t)col.values + (uintptr_t)slot * 16);
-          const int32_t len = vw[0];
-          b = 0;
-          e = len;
-          if (len <= 12) {
-            base = (uintptr_t)col.values + (uintptr_t)slot * 16 + 4;
-          } else {
-            const int32_t bi = vw[2], bo = vw[3];
-            base = (uintptr_t)col.buffers[bi] + (uintptr_t)(uint32_t)bo;
-          }
-        } else if (col.kind == 2) {
-          global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
-          b = off[slot];
-          e = off[slot + 1];
-        } else {
-          global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
-          b = off[slot];
-          e = off[slot + 1];
-        }
-        fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &ca, &cb);
-        cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
-      }
-      fa = rotl64(fa ^ mix64w(ca + 0x165667b19e3779f9ULL * (uint64_t)(c + 1)), 27) * 0x9fb21c651e98df25ULL + cb;
-      fb = rotl64(fb ^ mix64w(cb ^ rotl64(ca, 32) ^ 0x27d4eb2f165667c5ULL), 31) * 0xd6e8feb86659fd93ULL + ca;
-    }
-    fa = mix64w(fa);
-    fb = mix64w(fb ^ rotl64(fa, 17));
-    if (fa == kEmptyKey) fa -= 1;
-    if (fb == kEmptyKey) fb -= 1;
+    uint64_t fa, fb;
+    bool all_valid;
+    tuple_fingerprint(d, i, &fa, &fb, &all_valid);
     n_valid += all_valid ? 1 : 0;
     int became_dup = 0;
     n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
@@ -692,6 +702,42 @@ __global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSe
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
   __syncthreads();
   block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+// level 1 of the lists for tuples: EVERY row is a record (a tuple with NULL components is a value of its own); the
+// rows whose components are all non-NULL are counted on the side (one add per workgroup)
+__global__ __launch_bounds__(256) void fp_partition_tuples_kernel(TupleDesc d, FpLists out, unsigned long long *counters) {
+  constexpr int PER = kFpTile / 256;
+  __shared__ FpTileLds s;
+  __shared__ uint32_t s_valid;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_valid = 0;
+  fp_tile_begin(s);
+  const int64_t first = (int64_t)blockIdx.x * kFpTile;
+  uint32_t n_valid = 0;
+#pragma unroll 1  // (the fingerprint code once: the records wait in the tile's LDS, row order)
+  for (int k = 0; k < PER; k++) {
+    const int64_t row = first + k * 256 + (int64_t)tid;
+    ulonglong2 r;
+    r.x = kEmptyKey;
+    r.y = 0;
+    if (row < d.length) {
+      bool all_valid;
+      tuple_fingerprint(d, row, (uint64_t *)&r.x, (uint64_t *)&r.y, &all_valid);
+      n_valid += all_valid ? 1u : 0u;
+      atomicAdd(&s.hist[r.x >> 56], 1u);
+    }
+    s.stage[k * 256 + tid] = r;
+  }
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) n_valid += __shfl_down(n_valid, dlt, 64);
+  if ((tid & 63) == 0 && n_valid) atomicAdd(&s_valid, n_valid);
+  ulonglong2 mine[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) mine[k] = s.stage[k * 256 + tid];  // (its own records: no barrier needed to read them)
+  __syncthreads();  // everyone holds its records and has counted them: the tile's LDS is free
+  if (tid == 0 && s_valid) atomicAdd(&counters[kCntValidRows], (unsigned long long)s_valid);
+  fp_tile_scatter16(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
 }
 
 // ---- Dictionary<Int32, Utf8> columns (see dict.hip): fingerprints per dictionary entry, inserted with the
@@ -798,6 +844,12 @@ void launch_fp_partition_views(const void *views, const uint8_t *const *buffers,
   d.length = length;
   const int64_t tiles = (length + kFpTile - 1) / kFpTile;
   hipLaunchKernelGGL(fp_partition_views_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
+}
+
+void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, unsigned long long *d_counters,
+                                hipStream_t stream) {
+  const int64_t tiles = (d.length + kFpTile - 1) / kFpTile;
+  hipLaunchKernelGGL(fp_partition_tuples_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
 }
 
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void fp_totals_kernel(const uint2 *per_list, u
     a += c.x;
     b += c.y;
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0 && offered1)  // (nullptr: the valid rows were counted elsewhere -- tuples)
     for (uint32_t i = threadIdx.x; i < (uint32_t)(kFpXcds * kFpFan); i += 256) v += offered1[i];
 #pragma unroll
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {

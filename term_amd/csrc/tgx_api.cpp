@@ -875,17 +875,15 @@ static tgx_status bitmap_to_hash(tgx_state *st, DistinctState &ds, bool mult, ui
 }
 
 // COUNT(DISTINCT (a, b, ...)): every row's tuple goes into the 128-bit fingerprint set (kernels/distinct128.hip)
-static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *dev, tgx_error *err) {
-  const DistinctTask &task = st->plan->distinct[slot];
-  DistinctState &ds = st->distinct[slot];
-  TupleDesc d;
-  memset(&d, 0, sizeof(d));
-  d.n_cols = (int32_t)task.tuple.size();
-  d.want_multiplicity = task.multiplicity ? 1 : 0;
-  d.length = dev[task.tuple[0]].length;
-  for (size_t k = 0; k < task.tuple.size(); k++) {
-    const tgx_column &c = dev[task.tuple[k]];
-    TupleCol &tc = d.cols[k];
+// the kernels' view of a tuple of columns; cols[k] = the k-th component
+static tgx_status tuple_desc_of(const std::vector<const tgx_column *> &cols, bool mult, TupleDesc *d, tgx_error *err) {
+  memset(d, 0, sizeof(*d));
+  d->n_cols = (int32_t)cols.size();
+  d->want_multiplicity = mult ? 1 : 0;
+  d->length = cols[0]->length;
+  for (size_t k = 0; k < cols.size(); k++) {
+    const tgx_column &c = *cols[k];
+    TupleCol &tc = d->cols[k];
     tc.validity = c.validity;
     tc.offset = c.offset;
     if (is_numeric(c.type)) {
@@ -903,9 +901,32 @@ static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_co
       return fail(err, TGX_UNSUPPORTED, "DISTINCT over a tuple: column type %d is not supported", c.type);
     }
   }
+  return TGX_OK;
+}
+
+static bool fp_lists_fit_rows(int64_t rows);
+static tgx_status fp_lists_tuple_update(tgx_state *st, size_t slot, const TupleDesc &d,
+                                        const std::vector<const tgx_column *> &cols, tgx_error *err);
+
+// COUNT(DISTINCT (a, b, ...)): every row's tuple goes into the 128-bit fingerprint set (kernels/distinct128.hip)
+static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *dev, tgx_error *err) {
+  const DistinctTask &task = st->plan->distinct[slot];
+  DistinctState &ds = st->distinct[slot];
+  std::vector<const tgx_column *> cols;
+  bool any_view = false;
+  for (int c2 : task.tuple) {
+    cols.push_back(&dev[c2]);
+    any_view |= dev[c2].type == TGX_UTF8_VIEW;
+  }
+  TupleDesc d;
+  TGX_TRY(tuple_desc_of(cols, task.multiplicity, &d, err));
   ds.col_type = TGX_UTF8;  // a 128-bit fingerprint set, like a string column's
   ds.total_rows += d.length;
   if (d.length == 0) return TGX_OK;
+  if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
+  // the first big batch: through the partitioned lists (views read their buffers through a table staged per update)
+  if (ds.mode == DistinctMode::kUndecided && !any_view && fp_lists_fit_rows(d.length))
+    return fp_lists_tuple_update(st, slot, d, cols, err);
   if (ds.mode == DistinctMode::kUndecided) {
     ds.mode = DistinctMode::kHash;
     ds.wide = true;
@@ -937,12 +958,14 @@ static uint64_t fp_list_cap(int64_t rows, uint64_t lists) {
   const double mean = (double)rows / (double)lists;
   return ((uint64_t)(mean + 12.0 * std::sqrt(mean) + 64.0) + 15) & ~15ull;
 }
-static bool fp_lists_fit(const tgx_column &c) {
+static bool fp_lists_fit_rows(int64_t rows) {
   // TGX_FP_LISTS_MIN_ROWS: smallest batch that takes this path (tests lower it; a huge value turns the path off)
   int64_t min_rows = kFpMinRows;
   if (const char *e = getenv("TGX_FP_LISTS_MIN_ROWS")) min_rows = std::max<int64_t>(1, atoll(e));
-  return (is_any_string(c.type) || c.type == TGX_INT64 || c.type == TGX_FLOAT64) && c.length >= min_rows &&
-         fp_list_cap(c.length, (uint64_t)kFpFan * kFpFan) <= kFpListMax;
+  return rows >= min_rows && fp_list_cap(rows, (uint64_t)kFpFan * kFpFan) <= kFpListMax;
+}
+static bool fp_lists_fit(const tgx_column &c) {
+  return (is_any_string(c.type) || c.type == TGX_INT64 || c.type == TGX_FLOAT64) && fp_lists_fit_rows(c.length);
 }
 static void fp_views(const DistinctState &ds, FpLists *l1, FpLists *l2) {
   l1->recs = ds.fp_level1.as<uint64_t>();
@@ -996,6 +1019,28 @@ static tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &
   ds.rows_upper_bound = 0;
   ds.fp_staged = true;
   ds.retained.push_back(kept);  // (a DEVICE view, or a staged one looked at before the update returns)
+  return TGX_OK;
+}
+
+// the same for the first big batch of a tuple task: its components are retained in tuple order
+static tgx_status fp_lists_tuple_update(tgx_state *st, size_t slot, const TupleDesc &d,
+                                        const std::vector<const tgx_column *> &cols, tgx_error *err) {
+  DistinctState &ds = st->distinct[slot];
+  const bool mult = st->plan->distinct[slot].multiplicity;
+  TGX_TRY(fp_lists_prepare(st, ds, d.length, 16, err));
+  FpLists l1, l2;
+  fp_views(ds, &l1, &l2);
+  ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
+  unsigned long long *counters = ds.counters.as<unsigned long long>();
+  launch_fp_partition_tuples(d, l1, counters, st->stream);
+  launch_fp_partition_lists(l1, l2, counters, st->stream);
+  launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), nullptr, counters, st->stream);  // (valid rows: level 1)
+  ds.mode = DistinctMode::kHash;
+  ds.wide = true;
+  ds.capacity = 0;  // no table yet
+  ds.rows_upper_bound = 0;
+  ds.fp_staged = true;
+  for (const tgx_column *c : cols) ds.retained.push_back(*c);
   return TGX_OK;
 }
 
@@ -1363,6 +1408,15 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       if (ds.retained.empty())
         return fail(err, TGX_INTERNAL, "distinct: overflowed fingerprint lists and no batch to redo");
       HIP_TRY(hipMemsetAsync(ds.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
+      const DistinctTask &task = st->plan->distinct[slot];
+      if (!task.tuple.empty()) {  // the retained columns are the tuple's components, in order
+        std::vector<const tgx_column *> cols;
+        for (const tgx_column &col : ds.retained) cols.push_back(&col);
+        TupleDesc d;
+        TGX_TRY(tuple_desc_of(cols, mult, &d, err));
+        TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)d.length, err));
+        launch_distinct_tuple(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+      } else
       for (const tgx_column &col : ds.retained) {
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)col.length, err));
         if (!ds.wide) {  // a numeric key column

@@ -24,7 +24,7 @@ def run(specs, col):
     plan = T.Plan(specs)
     st = T.State(plan)
     st.profile_enable()
-    st.update([col])
+    st.update(col if isinstance(col, list) else [col])
     res = st.finalize()
     return res, st, plan
 
@@ -239,3 +239,29 @@ def test_batch_beyond_the_small_table_closed_form():
     r = res[0]
     assert (r.total, r.non_null, r.distinct, r.groups_once) == (n, n - expect["nulls"], n - expect["nulls"],
                                                                n - expect["nulls"])
+
+
+def test_tuples_through_the_lists(low_threshold):
+    """COUNT(DISTINCT (a, b, ...)): the first big batch of a tuple task takes the lists too (every row is a record;
+    rows whose components are all non-NULL are counted on the side).  The tuple test of test_gpu_strings.py, run with
+    the low threshold: (string, int) tuples fit the lists, (int, float) tuples repeat hundreds of times (overflow:
+    redone through the table), batches / serialize / merge after the lists."""
+    from collections import Counter
+
+    from gpu_util import numeric_column
+    import test_gpu_strings
+
+    test_gpu_strings.test_distinct_over_column_tuples()
+    rng = np.random.default_rng(31)
+    n = 80_000
+    a = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    b = rng.integers(0, 3, size=n, dtype=np.int64)
+    amask = rng.random(n) >= 0.1
+    av = orc.pack_validity(amask)
+    cnt = Counter((int(a[i]) if amask[i] else None, int(b[i])) for i in range(n))
+    res, st, _ = run([spec(T.DISTINCT, 0, columns=[0, 1], flags=T.FLAG_MULTIPLICITY)],
+                     [numeric_column(a, av, True), numeric_column(b, None, True)])
+    assert took_lists(st) == 1
+    r = res[0]
+    assert (r.total, r.non_null, r.distinct, r.groups_once) == \
+        (n, int(amask.sum()), len(cnt), sum(1 for v in cnt.values() if v == 1))
