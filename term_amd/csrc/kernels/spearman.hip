@@ -138,11 +138,11 @@ struct RankSums {
 };
 
 __global__ __launch_bounds__(256) void rank_sums_kernel(const uint64_t *rx, const uint64_t *ry, uint64_t n,
-                                                         RankSums *partials) {
+                                                         uint64_t plus, RankSums *partials) {
   unsigned long long w[5] = {0, 0, 0, 0, 0};
   unsigned __int128 e[5] = {0, 0, 0, 0, 0};
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long a = rx[i], b = ry[i];
+    const unsigned long long a = rx[i] + plus, b = ry[i] + plus;  // (plus = 1: the arrays hold run starts)
     w[0] += a;
     w[1] += b;
     w[2] += a * a;
@@ -255,10 +255,46 @@ void launch_unsort(const uint64_t *vals, const uint32_t *perm, uint64_t n, uint6
   hipLaunchKernelGGL(unsort_kernel, dim3(grid_of(n)), dim3(256), 0, stream, vals, perm, n, out);
 }
 
-int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, void *partials, hipStream_t stream) {
+int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, uint64_t plus, void *partials,
+                     hipStream_t stream) {
   const int g = grid_of(n);
-  hipLaunchKernelGGL(rank_sums_kernel, dim3(g), dim3(256), 0, stream, rx, ry, n, (RankSums *)partials);
+  hipLaunchKernelGGL(rank_sums_kernel, dim3(g), dim3(256), 0, stream, rx, ry, n, plus, (RankSums *)partials);
   return g;
+}
+
+// ---- one state, all pairs on this device: no rank ever has to find its way back to a row -------------------------
+// The five sums need the two ranks of a ROW side by side only in sum(rank_x * rank_y).  Sorting the pairs by x with y
+// as the payload gives every pair its rank_x in sorted order; sorting THOSE (y, rank_x) by y gives rank_y next to the
+// rank_x that travelled along: the sums are taken in y order.  Two sorts of (8 + 8)-byte pairs -- the scatter of
+// 1 G ranks back to their rows, twice, was 84 of the 228 ms of a 1 G-pair Spearman.
+hipError_t spearman_sort_kv64(uint64_t *keys, uint64_t *vals, uint64_t n, uint64_t *keys_sorted, uint64_t *vals_sorted,
+                              void *temp, size_t *temp_bytes, hipStream_t stream) {
+  size_t sort_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, vals_sorted, (size_t)n, 0u,
+                                           64u, stream);
+  if (e != hipSuccess) return e;
+  if (temp == nullptr) {
+    *temp_bytes = sort_bytes;
+    return hipSuccess;
+  }
+  size_t tb = *temp_bytes;
+  return rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, vals, vals_sorted, (size_t)n, 0u, 64u, stream);
+}
+
+// run_start[i] = first position of the tie run of sorted[i]  (RANK() - 1, in sorted order)
+hipError_t spearman_run_starts(const uint64_t *sorted, uint64_t n, uint64_t *run_start, void *temp, size_t *temp_bytes,
+                               hipStream_t stream) {
+  size_t scan_bytes = 0;
+  hipError_t e = rocprim::inclusive_scan(nullptr, scan_bytes, run_start, run_start, (size_t)n,
+                                         rocprim::maximum<uint64_t>(), stream);
+  if (e != hipSuccess) return e;
+  if (temp == nullptr) {
+    *temp_bytes = scan_bytes;
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(run_heads_kernel, dim3(grid_of(n)), dim3(256), 0, stream, sorted, n, run_start);
+  size_t tb = *temp_bytes;
+  return rocprim::inclusive_scan(temp, tb, run_start, run_start, (size_t)n, rocprim::maximum<uint64_t>(), stream);
 }
 
 }  // namespace tgx

@@ -21,7 +21,12 @@ void launch_sample_sorted(const uint64_t *sorted, uint64_t n, uint32_t count, ui
 void launch_lower_bounds(const uint64_t *sorted, uint64_t n, const uint64_t *splitters, uint32_t k, uint64_t *out,
                          hipStream_t stream);
 void launch_unsort(const uint64_t *vals, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t stream);
-int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, void *partials, hipStream_t stream);
+int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, uint64_t plus, void *partials,
+                     hipStream_t stream);
+hipError_t spearman_sort_kv64(uint64_t *keys, uint64_t *vals, uint64_t n, uint64_t *keys_sorted, uint64_t *vals_sorted,
+                              void *temp, size_t *temp_bytes, hipStream_t stream);
+hipError_t spearman_run_starts(const uint64_t *sorted, uint64_t n, uint64_t *run_start, void *temp, size_t *temp_bytes,
+                               hipStream_t stream);
 
 namespace {
 struct SpearmanPlan {
@@ -206,24 +211,30 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   if (m == 0) return TGX_OK;
   if (m > 0xFFFFFFF0ull) return sfail(err, TGX_UNSUPPORTED, "SPEARMAN over more than 2^32 rows is not supported");
   SpearmanState *ws = sstate(st);
-  DevBuf &keys_sorted = ws->keys_sorted, &idx = ws->idx, &idx_sorted = ws->idx_sorted, &heads = ws->heads,
-         &rx = ws->rx, &ry = ws->ry, &temp = ws->temp, &partials = ws->partials;
+  // pairs sorted by x (y travels along) -> rank_x in that order -> (y, rank_x) sorted by y -> rank_y beside rank_x:
+  // no rank is ever scattered back to its row (kernels/spearman.hip).  32 bytes of work buffers per pair.
+  DevBuf &keys_sorted = ws->keys_sorted, &heads = ws->heads, &rx = ws->rx, &ry = ws->ry, &temp = ws->temp,
+         &partials = ws->partials;
   SHIP(keys_sorted.reserve(m * 8));
-  SHIP(idx.reserve(m * 4));
-  SHIP(idx_sorted.reserve(m * 4));
   SHIP(heads.reserve(m * 8));
   SHIP(rx.reserve(m * 8));
   SHIP(ry.reserve(m * 8));
-  size_t temp_bytes = 0;
-  SHIP(spearman_rank(ts.kx.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), idx.as<uint32_t>(), idx_sorted.as<uint32_t>(),
-                     heads.as<uint64_t>(), rx.as<uint64_t>(), nullptr, &temp_bytes, st->stream, 0));
+  size_t sort_bytes = 0, scan_bytes = 0;
+  SHIP(spearman_sort_kv64(ts.kx.as<uint64_t>(), ts.ky.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), ry.as<uint64_t>(),
+                          nullptr, &sort_bytes, st->stream));
+  SHIP(spearman_run_starts(keys_sorted.as<uint64_t>(), m, heads.as<uint64_t>(), nullptr, &scan_bytes, st->stream));
+  size_t temp_bytes = std::max(sort_bytes, scan_bytes);
   SHIP(temp.reserve(temp_bytes + 256));
-  SHIP(spearman_rank(ts.kx.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), idx.as<uint32_t>(), idx_sorted.as<uint32_t>(),
-                     heads.as<uint64_t>(), rx.as<uint64_t>(), temp.p, &temp_bytes, st->stream, 0));
-  SHIP(spearman_rank(ts.ky.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), idx.as<uint32_t>(), idx_sorted.as<uint32_t>(),
-                     heads.as<uint64_t>(), ry.as<uint64_t>(), temp.p, &temp_bytes, st->stream, 0));
+  // by x: keys_sorted = x in order, ry = the y of those pairs, heads = RANK(x) - 1
+  SHIP(spearman_sort_kv64(ts.kx.as<uint64_t>(), ts.ky.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), ry.as<uint64_t>(),
+                          temp.p, &temp_bytes, st->stream));
+  SHIP(spearman_run_starts(keys_sorted.as<uint64_t>(), m, heads.as<uint64_t>(), temp.p, &temp_bytes, st->stream));
+  // by y: keys_sorted = y in order, rx = the RANK(x) - 1 of those pairs, heads = RANK(y) - 1
+  SHIP(spearman_sort_kv64(ry.as<uint64_t>(), heads.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), rx.as<uint64_t>(), temp.p,
+                          &temp_bytes, st->stream));
+  SHIP(spearman_run_starts(keys_sorted.as<uint64_t>(), m, heads.as<uint64_t>(), temp.p, &temp_bytes, st->stream));
   SHIP(partials.reserve(2048 * spearman_rank_sums_bytes()));
-  const int blocks = launch_rank_sums(rx.as<uint64_t>(), ry.as<uint64_t>(), m, partials.p, st->stream);
+  const int blocks = launch_rank_sums(rx.as<uint64_t>(), heads.as<uint64_t>(), m, 1, partials.p, st->stream);
   std::vector<RankSumsHost> h(blocks);
   SHIP(hipMemcpyAsync(h.data(), partials.p, blocks * sizeof(RankSumsHost), hipMemcpyDeviceToHost, st->stream));
   SHIP(hipStreamSynchronize(st->stream));
@@ -391,7 +402,7 @@ tgx_status spearman_allreduce(tgx_state *st, const SpearmanExchange &X, std::vec
     mine.pairs = m;
     if (m) {
       SHIP(ws->partials.reserve(2048 * spearman_rank_sums_bytes()));
-      const int blocks = launch_rank_sums(ws->rx.as<uint64_t>(), ws->ry.as<uint64_t>(), m, ws->partials.p, s);
+      const int blocks = launch_rank_sums(ws->rx.as<uint64_t>(), ws->ry.as<uint64_t>(), m, 0, ws->partials.p, s);
       std::vector<RankSumsHost> h(blocks);
       SHIP(hipMemcpyAsync(h.data(), ws->partials.p, blocks * sizeof(RankSumsHost), hipMemcpyDeviceToHost, s));
       SHIP(hipStreamSynchronize(s));
