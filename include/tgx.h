@@ -37,7 +37,8 @@ extern "C" {
 /* 2: tgx_column grew the Utf8View fields, tgx_check_spec the column list and LENGTH bounds,
  *    tgx_distinct_adopt_slices a slice stride */
 /* 3: tgx_comm / tgx_allreduce (the cross-rank step behind the C ABI) */
-#define TGX_ABI_VERSION 3
+/* 4: tgx_result grew the centred co-moments (co_*) at its end; state blobs are version 2 */
+#define TGX_ABI_VERSION 4
 
 typedef enum tgx_status {
   TGX_OK = 0,
@@ -118,7 +119,8 @@ typedef enum tgx_check_kind {
    *                                            TG/analyzers/advanced/kll_sketch.rs:195-229 */
   TGX_CHECK_KLL = 5,
   /* n, Sx, Sy, Sxx, Syy, Sxy over rows with both columns non-NULL (CAST AS DOUBLE)
-   *                                            TG/analyzers/advanced/correlation.rs:239-249 */
+   *                                            TG/analyzers/advanced/correlation.rs:239-249
+   * and the centred moments behind CORR / COVAR_SAMP   TG/constraints/correlation.rs:260-275 */
   TGX_CHECK_COMOMENTS = 6,
   /* n and the sums of SQL RANK() ranks (min-rank ties) of both columns over rows with both non-NULL
    * (CAST AS DOUBLE), reported in sum_x .. sum_xy          TG/analyzers/advanced/correlation.rs:334-350 */
@@ -186,6 +188,13 @@ typedef struct tgx_result {
   double sum_x, sum_y, sum_x2, sum_y2, sum_xy;
   /* KLL: read through tgx_kll_* below */
   uint64_t kll_n;
+  /* COMOMENTS, centred: means, M2x = SUM((x - mean_x)^2), M2y, Cxy = SUM((x - mean_x)(y - mean_y)) over the rows
+   * with both sides non-NULL.  CORR(x, y) = Cxy / sqrt(M2x M2y) (0 when either M2 is 0), COVAR_SAMP = Cxy / (n - 1),
+   * COVAR_POP = Cxy / n -- what DataFusion's online accumulators arrive at (TG/constraints/correlation.rs:260-275).
+   * The library sums about a pivot near the data, so these hold their precision on offset columns (timestamps,
+   * ids around 1e9) where n * sum_xy - sum_x * sum_y has cancelled; sum_x .. sum_xy above are the raw sums of
+   * TG/analyzers/advanced/correlation.rs:239-249 and carry that analyzer's own cancellation. */
+  double co_mean_x, co_mean_y, co_m2_x, co_m2_y, co_c_xy;
 } tgx_result;
 
 typedef struct tgx_options {

@@ -10,7 +10,7 @@ _ROOT = os.path.dirname(_HERE)
 COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 1, 2, 3, 4, 5, 6, 7, 8
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
-ABI_VERSION = 3  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
+ABI_VERSION = 4  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
@@ -58,6 +58,8 @@ class Result(C.Structure):
         ("distinct", C.c_int64), ("groups_once", C.c_int64), ("matches", C.c_int64),
         ("sum_x", C.c_double), ("sum_y", C.c_double), ("sum_x2", C.c_double), ("sum_y2", C.c_double),
         ("sum_xy", C.c_double), ("kll_n", C.c_uint64),
+        ("co_mean_x", C.c_double), ("co_mean_y", C.c_double), ("co_m2_x", C.c_double), ("co_m2_y", C.c_double),
+        ("co_c_xy", C.c_double),
     ]
 
 
@@ -469,9 +471,13 @@ class State:
         # DEVICE buffers must outlive the asynchronous kernels of EVERY batch queued since the last finalize / sync
         # (include/tgx.h): a streamed `update(b1); del b1; update(b2)` would otherwise hand b1's memory back to the
         # allocator while the scan of b1 is still reading it
-        if getattr(self, "_keep", None) is None:
-            self._keep = []
-        self._keep.append(cols)
+        # HOST buffers are borrowed only until tgx_update returns: holding them would pin a whole streamed table in
+        # host memory until finalize
+        held = [c for c in cols if c is not None and (c.c.mem == 1 or (c.c.dictionary and c.c.dictionary.contents.mem == 1))]
+        if held:
+            if getattr(self, "_keep", None) is None:
+                self._keep = []
+            self._keep.append(held)
 
     def finalize(self):
         res = (Result * max(1, self.plan.n))()

@@ -1,4 +1,5 @@
 // host_abi.cpp -- the C bridge of include/tgx_host.h over host/term_guard.{h,cpp}.
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -150,6 +151,20 @@ extern "C" tgx_status tgx_host_constraint_verdict_json(const char *constraint_js
       r.sum_x2 = o.get_num("sum_x2");
       r.sum_y2 = o.get_num("sum_y2");
       r.sum_xy = o.get_num("sum_xy");
+      if (o.get("co_m2_x")) {
+        r.co_mean_x = o.get_num("co_mean_x");
+        r.co_mean_y = o.get_num("co_mean_y");
+        r.co_m2_x = o.get_num("co_m2_x");
+        r.co_m2_y = o.get_num("co_m2_y");
+        r.co_c_xy = o.get_num("co_c_xy");
+      } else if (r.non_null > 0) {  // results that carry the raw sums only: centred from them
+        const double n = (double)r.non_null;
+        r.co_mean_x = r.sum_x / n;
+        r.co_mean_y = r.sum_y / n;
+        r.co_m2_x = std::max(0.0, r.sum_x2 - r.sum_x * r.sum_x / n);
+        r.co_m2_y = std::max(0.0, r.sum_y2 - r.sum_y * r.sum_y / n);
+        r.co_c_xy = r.sum_xy - r.sum_x * r.sum_y / n;
+      }
       r.kll_n = (uint64_t)o.get_num("kll_n");
       if (const json::Value *q = o.get("quantiles"))
         for (auto &kv : q->obj) fq.per_request[i].emplace_back(atof(kv.first.c_str()), kv.second.num);

@@ -927,22 +927,22 @@ class CorrelationConstraint : public Constraint {
     return lower.find(';') != std::string::npos || lower.find("drop") != std::string::npos;
   }
   // DataFusion's CORR: population covariance over the population standard deviations, 0 when either deviation is
-  // 0 (restated from the raw moments the kernel returns)
+  // 0 (constraints/correlation.rs:260-275 emits `CORR(a, b)`; its accumulators are online -- Welford variances and
+  // a co-moment -- so what they hold at the end are the CENTRED moments, which is what the library returns in
+  // co_m2_x / co_m2_y / co_c_xy: on offset data the raw-sum form n Sxy - Sx Sy has lost its digits)
   static double pearson(const tgx_result *r) {
     const double n = (double)r->non_null;
     if (n < 1) return 0.0;
-    const double cov = r->sum_xy / n - (r->sum_x / n) * (r->sum_y / n);
-    const double vx = r->sum_x2 / n - (r->sum_x / n) * (r->sum_x / n);
-    const double vy = r->sum_y2 / n - (r->sum_y / n) * (r->sum_y / n);
-    const double sx = vx > 0 ? sqrt(vx) : 0.0, sy = vy > 0 ? sqrt(vy) : 0.0;
+    const double cov = r->co_c_xy / n;
+    const double sx = r->co_m2_x > 0 ? sqrt(r->co_m2_x / n) : 0.0, sy = r->co_m2_y > 0 ? sqrt(r->co_m2_y / n) : 0.0;
     return (sx == 0.0 || sy == 0.0) ? 0.0 : cov / sx / sy;
   }
-  // COVAR_SAMP = (Sxy - Sx Sy / n) / (n - 1); SQL NULL below two rows, which the reference reads as the raw slot
-  // value (`value(0)` without a null check, :355-362 -- unpinned): 0.0 here
+  // COVAR_SAMP = Cxy / (n - 1); SQL NULL below two rows, which the reference reads as the raw slot value
+  // (`value(0)` without a null check, :355-362 -- unpinned): 0.0 here
   static double covar_samp(const tgx_result *r) {
     const double n = (double)r->non_null;
     if (n < 2) return 0.0;
-    return (r->sum_xy - r->sum_x * r->sum_y / n) / (n - 1.0);
+    return r->co_c_xy / (n - 1.0);
   }
   CorrelationValidation v_;
 };

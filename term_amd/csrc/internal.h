@@ -47,7 +47,9 @@ void launch_scan_main_only(const ScanLaunch &L, int n_cols, int blocks_per_col, 
 void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t lds_bytes, ScanPartial *d_partials,
                      hipStream_t stream);
 void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,
-                       ScanPartial *d_partials, void *d_como_partials, hipStream_t stream);
+                       ScanPartial *d_partials, void *d_como_partials, const ComomentAcc *d_como_accs,
+                       hipStream_t stream);
+void launch_como_pivot(const ComomentLaunch &L, int n_pairs, ComomentAcc *d_accs, hipStream_t stream);
 void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, const void *d_partials,
                              ComomentAcc *d_accs, hipStream_t stream);
 void launch_widen32(const void *src, void *dst, int64_t n, int is_float, int n_cu, hipStream_t stream);
@@ -341,6 +343,7 @@ struct tgx_state {
     int64_t n;
     int is_float;
   };
+  std::vector<int> como_pivot_tries;  // per COMOMENTS task: batches that offered the pivot kernel a look (<= 4)
   std::vector<Widen> pending_widen;  // TGX_INT32 / TGX_FLOAT32 windows of the current update (stage_column)
   tgx::DevBuf d_distinct_counters;  // [distinct task][kNumDistinctCounters]: every DistinctState::counters is a slice
   // per-update scratch

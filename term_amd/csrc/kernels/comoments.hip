@@ -1,7 +1,9 @@
-// comoments.hip -- raw co-moments of two numeric columns for gfx950.
+// comoments.hip -- co-moments of two numeric columns for gfx950.
 //
-//   n, SUM(x), SUM(y), SUM(x*x), SUM(y*y), SUM(x*y)  over rows where both are non-NULL,
-//   every value CAST AS DOUBLE                 (TG/analyzers/advanced/correlation.rs:239-249)
+//   n, SUM(x'), SUM(y'), SUM(x'*x'), SUM(y'*y'), SUM(x'*y')  over rows where both are non-NULL,
+//   every value CAST AS DOUBLE, x' = x - px, y' = y - py for a per-pair pivot (px, py) picked near the data
+//   (como_pivot_kernel).  The host rebuilds the raw sums of TG/analyzers/advanced/correlation.rs:239-249 and the
+//   centred moments behind CORR / COVAR_SAMP (TG/constraints/correlation.rs:260-275) from them (tgx_finalize).
 //
 // HBM-bound (16 B + 2 validity bits per row).  One row per lane per load, 4 loads in flight per
 // column per lane; sums are two-sum compensated per lane so the result does not depend on the
@@ -27,8 +29,10 @@ __device__ __forceinline__ bool cm_valid(global_u8_ptr v, int64_t bit) {
 }
 
 __global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
-                                                         ComomentPartial *__restrict__ partials) {
+                                                         ComomentPartial *__restrict__ partials,
+                                                         const ComomentAcc *__restrict__ accs) {
   const ComomentColDesc d = L.pairs[blockIdx.y];
+  const double px = accs[L.acc_index[blockIdx.y]].px, py = accs[L.acc_index[blockIdx.y]].py;
   global_i64_ptr x = (global_i64_ptr)(uintptr_t)((const int64_t *)d.x + d.xoff);
   global_i64_ptr y = (global_i64_ptr)(uintptr_t)((const int64_t *)d.y + d.yoff);
   global_u8_ptr xv = (global_u8_ptr)(uintptr_t)d.xv;
@@ -39,8 +43,8 @@ __global__ __launch_bounds__(256) void comoments_kernel(const ComomentLaunch L,
   auto fold = [&](int64_t xb, int64_t yb, bool ok) {
     double a = d.x_is_float ? __longlong_as_double(xb) : (double)xb;
     double b = d.y_is_float ? __longlong_as_double(yb) : (double)yb;
-    a = ok ? a : 0.0;
-    b = ok ? b : 0.0;
+    a = ok ? a - px : 0.0;
+    b = ok ? b - py : 0.0;
     n += ok ? 1 : 0;
     cm_two_sum(s[0], c[0], a);
     cm_two_sum(s[1], c[1], b);
@@ -174,6 +178,58 @@ __global__ __launch_bounds__(64) void comoments_reduce_kernel(
   }
 }
 
+// Picks the pivots of a pair: the means of (up to) 4096 evenly spread rows of the batch that have both values, finite.
+// Any finite pivot gives the right answer; one near the data keeps S(x'x') - S(x')^2 / n well conditioned.  Pivots are
+// fixed once rows have been folded in (acc.n > 0): every batch of a state is summed about the same pair.
+__global__ __launch_bounds__(256) void como_pivot_kernel(const ComomentLaunch L, ComomentAcc *__restrict__ accs) {
+  const ComomentColDesc d = L.pairs[blockIdx.x];
+  ComomentAcc &acc = accs[L.acc_index[blockIdx.x]];
+  if (acc.n > 0 || d.length <= 0) return;
+  global_i64_ptr x = (global_i64_ptr)(uintptr_t)((const int64_t *)d.x + d.xoff);
+  global_i64_ptr y = (global_i64_ptr)(uintptr_t)((const int64_t *)d.y + d.yoff);
+  global_u8_ptr xv = (global_u8_ptr)(uintptr_t)d.xv;
+  global_u8_ptr yv = (global_u8_ptr)(uintptr_t)d.yv;
+  const int64_t samples = d.length < 4096 ? d.length : 4096;
+  const int64_t step = d.length / samples;
+  double sx = 0.0, sy = 0.0;
+  int cnt = 0;
+  for (int64_t k = threadIdx.x; k < samples; k += 256) {
+    const int64_t i = k * step;
+    if (!cm_valid(xv, d.xoff + i) || !cm_valid(yv, d.yoff + i)) continue;
+    const double a = d.x_is_float ? __longlong_as_double(x[i]) : (double)x[i];
+    const double b = d.y_is_float ? __longlong_as_double(y[i]) : (double)y[i];
+    if (a - a != 0.0 || b - b != 0.0) continue;  // inf / NaN
+    sx += a;
+    sy += b;
+    cnt++;
+  }
+  __shared__ double s_x[256], s_y[256];
+  __shared__ int s_n[256];
+  s_x[threadIdx.x] = sx;
+  s_y[threadIdx.x] = sy;
+  s_n[threadIdx.x] = cnt;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double tx = 0.0, ty = 0.0;
+  int k = 0;
+  for (int i = 0; i < 256; i++) {
+    tx += s_x[i];
+    ty += s_y[i];
+    k += s_n[i];
+  }
+  if (k == 0) return;
+  tx /= (double)k;
+  ty /= (double)k;
+  if (tx - tx != 0.0 || ty - ty != 0.0) return;  // the sample's sum overflowed: stay with what is there
+  acc.px = tx;
+  acc.py = ty;
+  acc.pivot_set = 1;
+}
+
+void launch_como_pivot(const ComomentLaunch &L, int n_pairs, ComomentAcc *d_accs, hipStream_t stream) {
+  hipLaunchKernelGGL(como_pivot_kernel, dim3(n_pairs), dim3(256), 0, stream, L, d_accs);
+}
+
 size_t comoments_partial_bytes() { return sizeof(ComomentPartial); }
 
 // the fold alone: scan_pair_kernel leaves the same per-block partials
@@ -186,7 +242,7 @@ void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_pe
 void launch_comoments(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, void *d_partials,
                       ComomentAcc *d_accs, hipStream_t stream) {
   hipLaunchKernelGGL(comoments_kernel, dim3(blocks_per_pair, n_pairs), dim3(256), 0, stream, L,
-                     (ComomentPartial *)d_partials);
+                     (ComomentPartial *)d_partials, (const ComomentAcc *)d_accs);
   hipLaunchKernelGGL(comoments_reduce_kernel, dim3(n_pairs), dim3(64), 0, stream, L,
                      (const ComomentPartial *)d_partials, blocks_per_pair, d_accs);
 }

@@ -93,7 +93,12 @@ struct CountAcc {
   int64_t non_null;
 };
 
-// Two-column raw co-moments.
+// Two-column co-moments, accumulated about a per-pair PIVOT (px, py) that the first batch picks near the data
+// (como_pivot_kernel): sums of (x - px), (y - py) and their products.  DataFusion's CORR / COVAR_SAMP are online
+// (Welford) accumulators (TG/constraints/correlation.rs:260-275): on offset data -- timestamps, ids around 1e9 -- the
+// raw sums SUM(x*x), SUM(x*y) cancel catastrophically in n*Sxy - Sx*Sy, the shifted ones do not.  The raw sums the
+// CorrelationAnalyzer reports (TG/analyzers/advanced/correlation.rs:239-249) are rebuilt from the shifted ones on the
+// host (tgx_finalize).
 struct ComomentColDesc {
   const void *x, *y;
   const uint8_t *xv, *yv;
@@ -107,7 +112,7 @@ struct ComomentLaunch {
   int32_t acc_index[kMaxColsPerLaunch];
 };
 
-// per (pair, block) partial of the co-moment kernels (comoments.hip, scan_pair_kernel)
+// per (pair, block) partial of the co-moment kernels (comoments.hip, scan_pair_kernel): sums about the pair's pivot
 struct ComomentPartial {
   int64_t n;
   double s[5], c[5];
@@ -116,7 +121,11 @@ struct ComomentPartial {
 struct ComomentAcc {
   int64_t total;
   int64_t n;
-  double s[5], c[5];  // sum_x, sum_y, sum_x2, sum_y2, sum_xy as (sum, compensation)
+  // sums of x', y', x'x', y'y', x'y' with x' = x - px, y' = y - py, as (sum, compensation)
+  double s[5], c[5];
+  double px, py;       // the pivots: fixed once rows have been folded in (n > 0); (0, 0) = the raw sums
+  int32_t pivot_set;
+  int32_t pad;
 };
 
 __host__ __device__ inline int64_t f64_total_key(int64_t bits) {

@@ -567,9 +567,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_kll_kernel(const ScanLaunch L
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two columns per workgroup (ScanPairDesc): each column's own aggregates exactly as scan_body computes them, the raw
-// co-moments of the pair over the rows where both are non-NULL (TG/analyzers/advanced/correlation.rs:239-249: every
-// value CAST AS DOUBLE), and either column's KLL sampler -- a correlation check next to range / quantile checks on
+// Two columns per workgroup (ScanPairDesc): each column's own aggregates exactly as scan_body computes them, the
+// co-moments of the pair about its pivots over the rows where both are non-NULL (device_types.h, ComomentAcc;
+// TG/analyzers/advanced/correlation.rs:239-249: every value CAST AS DOUBLE), and either column's KLL sampler -- a correlation check next to range / quantile checks on
 // the same columns reads them once.
 struct ComoLane {
   double s[5], c[5];
@@ -713,15 +713,15 @@ template <bool XF, bool YF, bool KLL>
 __device__ __forceinline__ void pair_rows(const ScanPairDesc &P, LaneAcc &ax, LaneAcc &ay, ColFast<XF> &fx,
                                           ColFast<YF> &fy, unsigned long long &out_x, unsigned long long &out_y,
                                           ComoTile &m, i64x2 vx, i64x2 vy, uint32_t bx, uint32_t by, KllLane &Kx,
-                                          KllLane &Ky, double *rx, double *ry) {
+                                          KllLane &Ky, double *rx, double *ry, double pvx, double pvy) {
   out_x |= col_fast_value<XF>(fx, ax, vx.x, (bx & 1u) != 0);
   out_x |= col_fast_value<XF>(fx, ax, vx.y, (bx & 2u) != 0);
   out_y |= col_fast_value<YF>(fy, ay, vy.x, (by & 1u) != 0);
   out_y |= col_fast_value<YF>(fy, ay, vy.y, (by & 2u) != 0);
   const double x0 = kll_value<XF>(vx.x), x1 = kll_value<XF>(vx.y);
   const double y0 = kll_value<YF>(vy.x), y1 = kll_value<YF>(vy.y);
-  como_tile_add(m, x0, y0, (bx & by & 1u) != 0);
-  como_tile_add(m, x1, y1, (bx & by & 2u) != 0);
+  como_tile_add(m, x0 - pvx, y0 - pvy, (bx & by & 1u) != 0);  // about the pair's pivot (device_types.h, ComomentAcc)
+  como_tile_add(m, x1 - pvx, y1 - pvy, (bx & by & 2u) != 0);
   if (KLL) {
     if (P.x.kll.picks) {  // uniform
       kll_push<false>(Kx, rx, x0, (bx & 1u) != 0 && x0 == x0);
@@ -754,7 +754,7 @@ __device__ __forceinline__ void col_exact_tile(ColFast<F> &c, LaneAcc &a, i64x2 
 template <bool XF, bool YF, bool KLL>
 __device__ void pair_ragged(const ScanPairDesc &P, int64_t r0, int64_t r1, int lane, int stride, LaneAcc &ax,
                             LaneAcc &ay, ComoLane &m, int64_t &n_both, KllLane &Kx, KllLane &Ky, double *rx, double *ry,
-                            uint32_t wave_slot) {
+                            uint32_t wave_slot, double pvx, double pvy) {
   global_i64_ptr xs = (global_i64_ptr)(uintptr_t)((const int64_t *)P.x.values + P.x.offset);
   global_i64_ptr ys = (global_i64_ptr)(uintptr_t)((const int64_t *)P.y.values + P.y.offset);
   global_u8_ptr xv = (global_u8_ptr)(uintptr_t)P.x.validity, yv = (global_u8_ptr)(uintptr_t)P.y.validity;
@@ -776,7 +776,7 @@ __device__ void pair_ragged(const ScanPairDesc &P, int64_t r0, int64_t r1, int l
     ax.cnt += vx ? 1 : 0;
     ay.cnt += vy ? 1 : 0;
     const double a = kll_value<XF>(xb), b = kll_value<YF>(yb);
-    como_fold(m, a, b, vx && vy);
+    como_fold(m, a - pvx, b - pvy, vx && vy);
     n_both += (int64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vx && vy));  // wave-uniform, like the tiles'
 
     if (KLL) {
@@ -808,7 +808,7 @@ __device__ __forceinline__ void write_partial(ScanPartial *out, const LaneAcc &r
 
 template <bool XF, bool YF, bool KLL>
 __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *out_x, ScanPartial *out_y,
-                                          ComomentPartial *out_c, int wave, int lane) {
+                                          ComomentPartial *out_c, int wave, int lane, double pvx, double pvy) {
   LaneAcc ax, ay;
   acc_init(ax);
   acc_init(ay);
@@ -884,10 +884,10 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
         lane_both += (c0 & 1u) + (c0 >> 1) + (c1 & 1u) + (c1 >> 1) + (c2 & 1u) + (c2 >> 1) + (c3 & 1u) + (c3 >> 1);
       }
       unsigned long long out_x = 0, out_y = 0;  // lanes holding a value outside the wave's bounds (uniform)
-      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x0, y0, bx0, by0, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x1, y1, bx1, by1, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x2, y2, bx2, by2, Kx, Ky, rx, ry);
-      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x3, y3, bx3, by3, Kx, Ky, rx, ry);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x0, y0, bx0, by0, Kx, Ky, rx, ry, pvx, pvy);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x1, y1, bx1, by1, Kx, Ky, rx, ry, pvx, pvy);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x2, y2, bx2, by2, Kx, Ky, rx, ry, pvx, pvy);
+      pair_rows<XF, YF, KLL>(P, ax, ay, fx, fy, out_x, out_y, q, x3, y3, bx3, by3, Kx, Ky, rx, ry, pvx, pvy);
       if (out_x) col_exact_tile<XF>(fx, ax, x0, x1, x2, x3, bx0, bx1, bx2, bx3);
       if (out_y) col_exact_tile<YF>(fy, ay, y0, y1, y2, y3, by0, by1, by2, by3);
       como_tile_flush(m, q);
@@ -906,13 +906,14 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
     }
     if (blockIdx.x == gridDim.x - 1) {
       const int64_t tail0 = cx.head + cx.n_tiles * kTileRows;
-      if (wave == 0) pair_ragged<XF, YF, KLL>(P, 0, cx.head, lane, 64, ax, ay, m, n_both, Kx, Ky, rx, ry, wave_slot);
+      if (wave == 0)
+        pair_ragged<XF, YF, KLL>(P, 0, cx.head, lane, 64, ax, ay, m, n_both, Kx, Ky, rx, ry, wave_slot, pvx, pvy);
       if (wave == 1)
-        pair_ragged<XF, YF, KLL>(P, tail0, cx.length, lane, 64, ax, ay, m, n_both, Kx, Ky, rx, ry, wave_slot);
+        pair_ragged<XF, YF, KLL>(P, tail0, cx.length, lane, 64, ax, ay, m, n_both, Kx, Ky, rx, ry, wave_slot, pvx, pvy);
     }
   } else {
     pair_ragged<XF, YF, KLL>(P, wave_global * 64, cx.length, lane, (int)(n_waves * 64), ax, ay, m, n_both, Kx, Ky,
-                             rx, ry, wave_slot);
+                             rx, ry, wave_slot, pvx, pvy);
   }
   if (KLL) {
     // the samplers' MIN / MAX: what the exact tiles saw, and what the ragged rows added to K.mn / K.mx themselves
@@ -986,8 +987,10 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
 // grid = (blocks per pair, pairs); partials: [2 * pair + {0, 1}][block] for the columns, como: [pair][block]
 template <bool KLL>
 __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(const ScanPairLaunch L, ScanPartial *__restrict__ partials,
-                                                                ComomentPartial *__restrict__ como) {
+                                                                ComomentPartial *__restrict__ como,
+                                                                const ComomentAcc *__restrict__ como_accs) {
   const ScanPairDesc &P = L.pairs[blockIdx.y];
+  const double pvx = como_accs[P.como_acc].px, pvy = como_accs[P.como_acc].py;  // the pair's pivots (uniform)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   ScanPartial *ox = partials + ((size_t)2 * blockIdx.y) * gridDim.x + blockIdx.x;
@@ -995,13 +998,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(const ScanPairLau
   ComomentPartial *oc = como + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   const bool xf = P.x.is_float != 0, yf = P.y.is_float != 0;
   if (xf && yf)
-    pair_body<true, true, KLL>(P, ox, oy, oc, wave, lane);
+    pair_body<true, true, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
   else if (xf)
-    pair_body<true, false, KLL>(P, ox, oy, oc, wave, lane);
+    pair_body<true, false, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
   else if (yf)
-    pair_body<false, true, KLL>(P, ox, oy, oc, wave, lane);
+    pair_body<false, true, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
   else
-    pair_body<false, false, KLL>(P, ox, oy, oc, wave, lane);
+    pair_body<false, false, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
 }
 
 // Folds the per-block partials of each column (fixed order => bitwise reproducible) and merges
@@ -1206,13 +1209,14 @@ void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t
 }
 
 void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,
-                       ScanPartial *d_partials, void *d_como_partials, hipStream_t stream) {
+                       ScanPartial *d_partials, void *d_como_partials, const ComomentAcc *d_como_accs,
+                       hipStream_t stream) {
   if (lds_bytes)
     hipLaunchKernelGGL(scan_pair_kernel<true>, dim3(blocks_per_pair, n_pairs), dim3(kScanBlock), lds_bytes, stream, L,
-                       d_partials, (ComomentPartial *)d_como_partials);
+                       d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
   else
     hipLaunchKernelGGL(scan_pair_kernel<false>, dim3(blocks_per_pair, n_pairs), dim3(kScanBlock), 0, stream, L,
-                       d_partials, (ComomentPartial *)d_como_partials);
+                       d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
 }
 
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,

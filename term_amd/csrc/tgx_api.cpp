@@ -335,13 +335,45 @@ static void scan_acc_merge(ScanAcc &a, const ScanAcc &b) {
   }
 }
 
-static void como_acc_merge(ComomentAcc &a, const ComomentAcc &b) {
-  a.total += b.total;
-  a.n += b.n;
-  for (int k = 0; k < 5; k++) {
-    a.c[k] += b.c[k];
-    host_two_sum(a.s[k], a.c[k], b.s[k]);
+// ---- co-moments: sums about a pivot (kernels/device_types.h, ComomentAcc) -------------------------------------
+// Host-side arithmetic on them runs in x87 extended precision (64-bit mantissa): re-basing and centring are a
+// handful of operations per state, and a sum travels as the (double, remainder) pair the kernels keep anyway.
+typedef long double xdouble;
+static xdouble como_sum(const ComomentAcc &a, int k) {
+  return std::isfinite(a.s[k]) ? (xdouble)a.s[k] + (xdouble)a.c[k] : (xdouble)a.s[k];
+}
+static void como_store(ComomentAcc &a, int k, xdouble v) {
+  a.s[k] = (double)v;
+  a.c[k] = std::isfinite(a.s[k]) ? (double)(v - (xdouble)a.s[k]) : 0.0;
+}
+// the same sums about (px, py): x - px = (x - b.px) + dx
+static void como_rebase(ComomentAcc &b, double px, double py) {
+  if (b.px == px && b.py == py) return;
+  const xdouble n = (xdouble)b.n, dx = (xdouble)b.px - (xdouble)px, dy = (xdouble)b.py - (xdouble)py;
+  const xdouble s0 = como_sum(b, 0), s1 = como_sum(b, 1), s2 = como_sum(b, 2), s3 = como_sum(b, 3), s4 = como_sum(b, 4);
+  como_store(b, 0, s0 + n * dx);
+  como_store(b, 1, s1 + n * dy);
+  como_store(b, 2, s2 + 2 * dx * s0 + n * dx * dx);
+  como_store(b, 3, s3 + 2 * dy * s1 + n * dy * dy);
+  como_store(b, 4, s4 + dx * s1 + dy * s0 + n * dx * dy);
+  b.px = px;
+  b.py = py;
+}
+// AnalyzerState::merge for the pair (TG/analyzers/advanced/correlation.rs:64-101 adds the raw sums): the right-hand
+// side is re-based onto the left one's pivots first; an empty left side takes the other's pivots as they are
+static void como_acc_merge(ComomentAcc &a, const ComomentAcc &b_in) {
+  a.total += b_in.total;
+  if (b_in.n == 0) return;
+  if (a.n == 0) {
+    const int64_t total = a.total;
+    a = b_in;
+    a.total = total;
+    return;
   }
+  ComomentAcc b = b_in;
+  como_rebase(b, a.px, a.py);
+  a.n += b.n;
+  for (int k = 0; k < 5; k++) como_store(a, k, como_sum(a, k) + como_sum(b, k));
 }
 
 static void state_init_host(tgx_state *st, const tgx_plan *plan) {
@@ -486,6 +518,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   kll_state_reset(st);
   regex_state_reset(st);
   spearman_state_reset(st);
+  st->como_pivot_tries.clear();
   if (st->device_ready) {
     if (!plan->scan.empty()) {
       HIP_TRY(hipMemcpyAsync(st->d_scan_acc.p, st->d_scan_identity.p, plan->scan.size() * sizeof(ScanAcc),
@@ -909,14 +942,15 @@ static tgx_status fp_lists_tuple_update(tgx_state *st, size_t slot, const TupleD
                                         const std::vector<const tgx_column *> &cols, tgx_error *err);
 
 // COUNT(DISTINCT (a, b, ...)): every row's tuple goes into the 128-bit fingerprint set (kernels/distinct128.hip)
-static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *dev, tgx_error *err) {
+static tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *dev, tgx_error *err,
+                                        const tgx_column *orig = nullptr) {
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
   std::vector<const tgx_column *> cols;
-  bool any_view = false;
+  bool any_view = false;  // a component whose device view lives in per-update scratch: never retained (no lists)
   for (int c2 : task.tuple) {
     cols.push_back(&dev[c2]);
-    any_view |= dev[c2].type == TGX_UTF8_VIEW;
+    any_view |= dev[c2].type == TGX_UTF8_VIEW || (orig && is_numeric32(orig[c2].type));
   }
   TupleDesc d;
   TGX_TRY(tuple_desc_of(cols, task.multiplicity, &d, err));
@@ -949,7 +983,7 @@ struct NumericPrep {
 static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column &c, NumericPrep *prep,
                                            tgx_error *err);
 static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c, const NumericPrep &prep,
-                                       int stats_slot, tgx_error *err);
+                                       int stats_slot, tgx_error *err, const tgx_column *orig = nullptr);
 
 // ---- big Utf8 batches: partitioned fingerprint lists (kernels/distinct128.hip, fp_*) ----
 // records a list is sized for when `rows` values are spread over `lists` lists: the mean, twelve standard deviations
@@ -1044,9 +1078,11 @@ static tgx_status fp_lists_tuple_update(tgx_state *st, size_t slot, const TupleD
   return TGX_OK;
 }
 
+// `orig`: the caller's own view of the column when `c` is a per-update staging copy of a DEVICE column (a 4-byte
+// numeric column widened for this pass): what a key set retains for a later repair must outlive the update
 static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_error *err,
                                   const std::vector<DictGather> *gathers = nullptr, const NumericPrep *ready = nullptr,
-                                  int stats_slot = -1) {
+                                  int stats_slot = -1, const tgx_column *orig = nullptr) {
   const DistinctTask &task = st->plan->distinct[slot];
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
@@ -1124,7 +1160,7 @@ static tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &
     prep = *ready;  // decided before the scan of this batch was queued (tgx_update)
   else
     TGX_TRY(distinct_prepare_numeric(st, slot, c, &prep, err));
-  return distinct_run_numeric(st, slot, c, prep, stats_slot, err);
+  return distinct_run_numeric(st, slot, c, prep, stats_slot, err, orig);
 }
 
 // How the keys of one batch of an Int64 / Float64 column enter the set.
@@ -1302,8 +1338,12 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
 // `stats_slot` >= 0: the partition pass also produces the column's COUNT / MIN / MAX / SUM into that scan slot (the
 // numeric scan has skipped the column)
 static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c, const NumericPrep &prep,
-                                       int stats_slot, tgx_error *err) {
+                                       int stats_slot, tgx_error *err, const tgx_column *orig) {
   const DistinctTask &task = st->plan->distinct[slot];
+  // what a later repair walks again: never a view into the update's staging scratch (the next update reuses it) --
+  // a widened DEVICE Int32 / Float32 column is retained as the caller's 4-byte column and widened again at the
+  // repair (retained_numeric_view); staged copies of HOST batches are resolved before tgx_update returns
+  const tgx_column &keep = (orig && orig->mem == TGX_MEM_DEVICE && is_numeric32(orig->type)) ? *orig : c;
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
   DistinctColDesc d;
@@ -1316,7 +1356,7 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
   const uint64_t bytes = (uint64_t)c.length * 8 + (c.validity ? (uint64_t)(c.length + 7) / 8 : 0);
   if (ds.mode == DistinctMode::kUndecided) return TGX_OK;  // nothing valid seen yet
   if (ds.mode == DistinctMode::kBitmap) {
-    if (ds.speculative) ds.retained.push_back(c);  // (a DEVICE view, or a staged one resolved before the update returns)
+    if (ds.speculative) ds.retained.push_back(keep);  // (a DEVICE view, or a staged one resolved before the update returns)
     if (prep.partitioned) {
       // big batch over a dense range: bucket the keys and replay them against LDS-resident slices
       PartitionParams pp;
@@ -1383,7 +1423,7 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
       launch_key_lists(d, l1, l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), ds.counters.as<unsigned long long>(),
                        st->stream);
       ds.fp_staged = true;
-      ds.retained.push_back(c);  // (a DEVICE view, or a staged one looked at before the update returns)
+      ds.retained.push_back(keep);  // (a DEVICE view, or a staged one looked at before the update returns)
       return TGX_OK;
     }
     TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
@@ -1393,11 +1433,33 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
   return TGX_OK;
 }
 
+// A retained DEVICE Int32 / Float32 column (distinct_run_numeric keeps the caller's 4-byte view, not the update's
+// widened scratch) as the Int64 / Float64 view the repair kernels read: widened again into `tmp`, exactly as
+// stage_column did for the update (window from slot offset & ~63, validity re-based by bytes).
+static tgx_status retained_numeric_view(tgx_state *st, const tgx_column &col, std::vector<std::unique_ptr<DevBuf>> &tmp,
+                                        tgx_column *out, tgx_error *err) {
+  *out = col;
+  if (!is_numeric32(col.type)) return TGX_OK;
+  const int64_t e0 = col.offset & ~(int64_t)63;
+  const int64_t slots = col.offset - e0 + col.length;
+  tmp.emplace_back(new DevBuf());
+  DevBuf *w = tmp.back().get();
+  HIP_TRY(w->reserve((size_t)slots * 8 + 16));
+  launch_widen32((const uint8_t *)col.values + (size_t)e0 * 4, w->p, slots, col.type == TGX_FLOAT32 ? 1 : 0, g_ctx.n_cu,
+                 st->stream);
+  out->type = col.type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
+  out->values = w->p;
+  out->validity = col.validity ? col.validity + (e0 >> 3) : nullptr;
+  out->offset = col.offset - e0;
+  return TGX_OK;
+}
+
 // The host is about to look at the key set (counts, export, exchange, merge) or the caller may release the batches:
 // keys that fell outside a sampled range are brought in now.  The bitmap moves into a hash set and the retained
 // batches are walked once more for their outliers only (disjoint from the bitmap's keys, so multiplicities stay right).
 tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
   DistinctState &ds = st->distinct[slot];
+  std::vector<std::unique_ptr<DevBuf>> widened;  // freed on the way out: every path below drains the stream first
   if (ds.fp_staged && st->device_ready) {
     // Utf8 fingerprint lists: into the table -- or, if a list overflowed, the batch again, through the table
     const bool mult = st->plan->distinct[slot].multiplicity;
@@ -1417,7 +1479,9 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)d.length, err));
         launch_distinct_tuple(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
       } else
-      for (const tgx_column &col : ds.retained) {
+      for (const tgx_column &kept : ds.retained) {
+        tgx_column col;
+        TGX_TRY(retained_numeric_view(st, kept, widened, &col, err));
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)col.length, err));
         if (!ds.wide) {  // a numeric key column
           DistinctColDesc d;
@@ -1464,7 +1528,9 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
   const uint64_t old_range = ds.range;
   TGX_TRY(bitmap_to_hash(st, ds, mult, n_out, err));
   TGX_TRY(hash_ensure(st, ds, mult, n_out, err));
-  for (const tgx_column &col : ds.retained) {
+  for (const tgx_column &kept : ds.retained) {
+    tgx_column col;
+    TGX_TRY(retained_numeric_view(st, kept, widened, &col, err));
     DistinctColDesc d;
     d.values = col.values;
     d.validity = col.validity;
@@ -1504,6 +1570,22 @@ tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
     else
       ds.retained.clear();
   }
+  return TGX_OK;
+}
+
+// The pivots of the pairs of one launch (kernels/comoments.hip, como_pivot_kernel): picked from the first batches that
+// bring rows -- the kernel leaves a pair alone once rows have been folded into it; after a few batches nothing is
+// launched any more (a stream of 8192-row batches must not pay a launch per batch for a decision long taken).
+static tgx_status como_pivots(tgx_state *st, const ComomentLaunch &L, int n_pairs, tgx_error *err) {
+  (void)err;
+  bool want = false;
+  if (st->como_pivot_tries.size() < st->plan->como.size()) st->como_pivot_tries.assign(st->plan->como.size(), 0);
+  for (int k = 0; k < n_pairs; k++)
+    if (L.pairs[k].length > 0 && st->como_pivot_tries[L.acc_index[k]] < 4) {
+      st->como_pivot_tries[L.acc_index[k]]++;
+      want = true;
+    }
+  if (want) launch_como_pivot(L, n_pairs, st->d_como_acc.as<ComomentAcc>(), st->stream);
   return TGX_OK;
 }
 
@@ -1828,14 +1910,25 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
           RL.cols[2 * k + 1] = P.y;
           RL.acc_index[2 * k] = P.x_acc;
           RL.acc_index[2 * k + 1] = P.y_acc;
+          const tgx_column &xc = dev[fp.x], &yc = dev[fp.y];
+          CL.pairs[k].x = xc.values;
+          CL.pairs[k].y = yc.values;
+          CL.pairs[k].xv = xc.validity;
+          CL.pairs[k].yv = yc.validity;
+          CL.pairs[k].xoff = xc.offset;
+          CL.pairs[k].yoff = yc.offset;
           CL.pairs[k].length = P.x.length;
+          CL.pairs[k].x_is_float = xc.type == TGX_FLOAT64;
+          CL.pairs[k].y_is_float = yc.type == TGX_FLOAT64;
           CL.acc_index[k] = fp.como;
         }
+        TGX_TRY(como_pivots(st, CL, n, err));
         HIP_TRY(st->d_scan_partials.reserve((size_t)2 * n * blocks * sizeof(ScanPartial)));
         HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
         {
           ProfScope ps(st, "scan", chunk_bytes);
-          launch_scan_pairs(PL, n, blocks, lds, st->d_scan_partials.as<ScanPartial>(), st->d_como_partials.p, st->stream);
+          launch_scan_pairs(PL, n, blocks, lds, st->d_scan_partials.as<ScanPartial>(), st->d_como_partials.p,
+                            st->d_como_acc.as<ComomentAcc>(), st->stream);
         }
         launch_scan_reduce_only(RL, 2 * n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
                                 st->stream);
@@ -1921,6 +2014,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         int blocks = (int)std::min<int64_t>(std::max<int64_t>(1, (nrows + 256 * 16 - 1) / (256 * 16)),
                                             std::max(32, (g_ctx.n_cu * 12) / n));  // 4/5/6/8/12 per CU: 6.8/6.4/6.2/6.5/6.0 ms (2 pairs, 1 G rows)
         HIP_TRY(st->d_como_partials.reserve((size_t)n * blocks * comoments_partial_bytes()));
+        TGX_TRY(como_pivots(st, L, n, err));
         ProfScope ps(st, "comoments", bytes * n / std::max<size_t>(descs.size(), 1));
         launch_comoments(L, n, blocks, st->d_como_partials.p, st->d_como_acc.as<ComomentAcc>(), st->stream);
       }
@@ -1952,9 +2046,9 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         const int stats_slot = (plan->distinct[s].scan_slot >= 0 && stats_by_partition[plan->distinct[s].scan_slot] == (int)s)
                                    ? plan->distinct[s].scan_slot
                                    : -1;
-        TGX_TRY(distinct_update(st, s, dev[col], err, g, &dprep[s], stats_slot));
+        TGX_TRY(distinct_update(st, s, dev[col], err, g, &dprep[s], stats_slot, &columns[col]));
       } else {
-        TGX_TRY(distinct_tuple_update(st, s, dev.data(), err));
+        TGX_TRY(distinct_tuple_update(st, s, dev.data(), err, columns));
       }
     // (gathers handed out but not consumed -- cannot happen: every fusable column has exactly one DISTINCT task)
     // ---- KLL ----
@@ -2179,13 +2273,25 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
         const ComomentAcc &a = g.como[b.slot];
         r->total = a.total;
         r->non_null = a.n;
-        double v[5];
-        for (int k = 0; k < 5; k++) v[k] = isfinite(a.s[k]) ? a.s[k] + a.c[k] : a.s[k];
-        r->sum_x = v[0];
-        r->sum_y = v[1];
-        r->sum_x2 = v[2];
-        r->sum_y2 = v[3];
-        r->sum_xy = v[4];
+        // the raw sums the analyzer reports (TG/analyzers/advanced/correlation.rs:239-249): the sums about (0, 0)
+        ComomentAcc raw = a;
+        como_rebase(raw, 0.0, 0.0);
+        r->sum_x = (double)como_sum(raw, 0);
+        r->sum_y = (double)como_sum(raw, 1);
+        r->sum_x2 = (double)como_sum(raw, 2);
+        r->sum_y2 = (double)como_sum(raw, 3);
+        r->sum_xy = (double)como_sum(raw, 4);
+        // the centred moments CORR / COVAR_SAMP are made of (TG/constraints/correlation.rs:260-275: DataFusion's
+        // online accumulators arrive at these, not at the raw sums): taken about the pivots, which lie near the data
+        if (a.n > 0) {
+          const xdouble n = (xdouble)a.n, s0 = como_sum(a, 0), s1 = como_sum(a, 1);
+          const xdouble m2x = como_sum(a, 2) - s0 * s0 / n, m2y = como_sum(a, 3) - s1 * s1 / n;
+          r->co_mean_x = (double)((xdouble)a.px + s0 / n);
+          r->co_mean_y = (double)((xdouble)a.py + s1 / n);
+          r->co_m2_x = m2x > 0 ? (double)m2x : (m2x == m2x ? 0.0 : (double)m2x);
+          r->co_m2_y = m2y > 0 ? (double)m2y : (m2y == m2y ? 0.0 : (double)m2y);
+          r->co_c_xy = (double)(como_sum(a, 4) - s0 * s1 / n);
+        }
         break;
       }
       case TGX_CHECK_KLL:
@@ -2532,7 +2638,7 @@ struct Reader {
   }
 };
 constexpr uint32_t kWireMagic = 0x53584754;  // "TGXS"
-constexpr uint32_t kWireVersion = 1;
+constexpr uint32_t kWireVersion = 2;  // 2: ComomentAcc carries its pivots
 }  // namespace
 
 extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, uint8_t *buf, size_t cap,

@@ -1,4 +1,4 @@
-"""Wire form of a tgx state (tgx_state_serialize / tgx_state_deserialize), version 1.
+"""Wire form of a tgx state (tgx_state_serialize / tgx_state_deserialize), version 2.
 
 The blob is what ranks exchange (one all-gather of a few KiB) and what a checkpoint stores; it is the
 counterpart of the serde_json analyzer states of the reference's IncrementalAnalysisRunner
@@ -8,7 +8,9 @@ counterpart of the serde_json analyzer states of the reference's IncrementalAnal
     n_scan      x ScanAcc      i64 total, non_null, min_key, max_key; u64 sum_lo; i64 sum_hi; f64 sum, comp;
                                i64 var_n; f64 var_mean, var_m2; i32 is_float, pad                    (96 B)
     n_count     x CountAcc     i64 total, non_null                                                      (16 B)
-    n_comoments x ComomentAcc  i64 total, n; f64 s[5]; f64 c[5]   (sum_x, sum_y, sum_x2, sum_y2, sum_xy) (96 B)
+    n_comoments x ComomentAcc  i64 total, n; f64 s[5]; f64 c[5]; f64 px, py; i32 pivot_set, pad          (120 B)
+                               s + c = sums of x', y', x'x', y'y', x'y' with x' = x - px, y' = y - py: about the
+                               pivots (px, py); (0, 0) makes them the raw sum_x, sum_y, sum_x2, sum_y2, sum_xy
     n_distinct  x { u32 owner_partitioned, u32 wide_keys; u64 total, non_null, distinct, twice, empty_rows;
                     u64 n_records; records (16 B {key, count} or 32 B {hash_a, hash_b, count, 0}) }
     n_kll       x { u32 k, u32 n_levels; u64 n; f64 min, max; n_levels x { u32 count; f64 items[count] } }
@@ -19,7 +21,7 @@ min_key / max_key are the Int64 values themselves, or the IEEE totalOrder keys o
 """
 import struct
 
-MAGIC, VERSION = 0x53584754, 1
+MAGIC, VERSION = 0x53584754, 2
 I64_MAX, I64_MIN = (1 << 63) - 1, -(1 << 63)
 
 
@@ -52,8 +54,10 @@ def count_acc(total, non_null):
     return struct.pack("<qq", total, non_null)
 
 
-def comoment_acc(total, n, sum_x, sum_y, sum_x2, sum_y2, sum_xy):
-    return struct.pack("<qq5d5d", total, n, sum_x, sum_y, sum_x2, sum_y2, sum_xy, 0.0, 0.0, 0.0, 0.0, 0.0)
+def comoment_acc(total, n, sum_x, sum_y, sum_x2, sum_y2, sum_xy, px=0.0, py=0.0):
+    """the five sums are taken about the pivots (px, py); the default (0, 0) means raw sums"""
+    return struct.pack("<qq5d5dddii", total, n, sum_x, sum_y, sum_x2, sum_y2, sum_xy, 0.0, 0.0, 0.0, 0.0, 0.0,
+                       px, py, 1, 0)
 
 
 def distinct_counts(total, non_null, distinct, twice=0):

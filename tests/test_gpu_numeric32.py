@@ -159,3 +159,41 @@ def test_suite_over_32_bit_columns():
     assert [i.message for i in narrow.report.issues] == [i.message for i in wide.report.issues]
     assert narrow.report.metrics.passed_checks == wide.report.metrics.passed_checks
     assert len(narrow.report.issues) == 1 and "Uniqueness ratio" in narrow.report.issues[0].message  # qty repeats
+
+
+@pytest.mark.parametrize("kind", ["growing_ids", "sparse_keys", "tuple"])
+def test_retained_views_of_widened_device_columns_survive_later_batches(kind, monkeypatch):
+    """A DEVICE Int32 key column is widened into per-update scratch; what a key set keeps for a later repair (keys
+    outside the sampled range, overflowed lists) must not point there: the next update reuses the scratch
+    (tgx_api.cpp: distinct_run_numeric `keep`, retained_numeric_view).  Three batches of growing ids: every batch
+    after the first lies outside the range the first one's sample laid the bitmap out for."""
+    if kind != "growing_ids":
+        monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "1000")
+    rng = np.random.default_rng(5)
+    n = 100_000
+    batches, arrays = [], []
+    for b in range(3):
+        if kind == "growing_ids":
+            ids = (np.arange(n, dtype=np.int64) + b * 3 * n)
+            ids[rng.random(n) < 0.01] = b * 3 * n + 7     # some repeats inside every batch
+        else:
+            ids = rng.integers(0, 2**31 - 1, size=n, dtype=np.int64)
+            ids[: n // 2] = ids[0]                         # one heavy key: its list overflows
+        arrays.append(ids.astype(np.int32))
+    if kind == "tuple":
+        specs = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY, columns=[0, 1])]
+        second = [(a // 3).astype(np.int32) for a in arrays]
+        batches = [[col32(a, None, True), col32(s2, None, True)] for a, s2 in zip(arrays, second)]
+    else:
+        specs = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)]
+        batches = [[col32(a, None, True)] for a in arrays]
+    res, _, _ = run_plan(specs, batches)
+    if kind == "tuple":
+        import collections
+        keys = collections.Counter(zip(np.concatenate(arrays).tolist(), np.concatenate(second).tolist()))
+        want = (3 * n, len(keys), sum(1 for v in keys.values() if v == 1))
+        assert (res[0].total, res[0].distinct, res[0].groups_once) == want
+    else:
+        wide = np.concatenate(arrays).astype(np.int64)
+        d = orc.distinct_bits64(wide.view(np.uint64), None, n=3 * n)
+        assert (res[0].total, res[0].distinct, res[0].groups_once) == (d.total, d.distinct, d.groups_once)
