@@ -16,6 +16,8 @@ and merged in rank order on every rank.
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (bare: starts the N ranks itself, as children, and relays rank 0's line;
+                                         refuses -- non-zero exit -- when the machine has fewer than N GPUs)
 """
 import argparse
 import json
@@ -78,6 +80,69 @@ def cpu_baseline(torch, layout, unique_cols, table, sample_rows):
                       % (sample_rows, len(layout), cores, runs, best, one_rows, dt1)}
 
 
+def launcher_command(n_gpus, port, script_args):
+    """argv of the one-rank-per-GPU launch the driver's contract names (torch.distributed.run, one node)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(script_args)
+
+
+def launcher_env(base=None):
+    """environment of the launched ranks: rendezvous on 127.0.0.1 (the container's hostname may not resolve) and
+    dmabuf IPC (the host driver supports nothing else: RCCL fails with hipIpcGetMemHandle otherwise)"""
+    env = dict(os.environ if base is None else base)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, script_args):
+    """`python bench.py --gpus N` without a launcher around it: N fresh worker processes, one per GPU, started as
+    CHILDREN (never an exec: this process stays the parent and only relays) before anything here has touched the GPU.
+    Rank 0's JSON line is passed on as this process's own single line; any worker failing fails the run."""
+    import subprocess
+
+    import torch  # importing torch and counting devices initialises no GPU on this image
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print("bench.py: --gpus %d but this machine exposes %d GPU(s): refusing to run fewer ranks than asked for "
+              "(a 1-GPU number must never be recorded as an %d-GPU one)" % (args.gpus, have, args.gpus),
+              file=sys.stderr, flush=True)
+        return 2
+    cmd = launcher_command(args.gpus, free_port(), script_args)
+    proc = subprocess.run(cmd, env=launcher_env(), stdout=subprocess.PIPE, stderr=None, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    json_line = None
+    for ln in reversed(lines):
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            json_line = ln
+            break
+    for ln in lines:
+        if ln is not json_line:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or json_line is None:
+        print("bench.py: the %d-rank launch failed (exit code %d%s)" %
+              (args.gpus, proc.returncode, "" if json_line else ", no result line"), file=sys.stderr, flush=True)
+        return proc.returncode or 3
+    if json.loads(json_line).get("n_gpus") != args.gpus:
+        print("bench.py: the result line reports n_gpus=%r for --gpus %d" % (json.loads(json_line).get("n_gpus"), args.gpus),
+              file=sys.stderr, flush=True)
+        return 4
+    sys.stdout.flush()
+    print(json_line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,11 +158,23 @@ def main():
                          "with one rank: a self-test of the multi-GPU step on a 1-GPU box")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # invoked bare with --gpus N: start the N ranks ourselves (before anything here touches the GPU)
+            raise SystemExit(launch_ranks(args, sys.argv[1:]))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # never a line whose n_gpus disagrees with --gpus
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d), or run "
+                         "`python bench.py --gpus %d` bare and let it start the ranks" %
+                         (args.gpus, world, args.gpus, args.gpus, args.gpus))
 
     import torch
     import term_amd as T

@@ -326,6 +326,11 @@ struct Header {
   uint64_t magic;
   uint64_t blob_len;   // payload bytes that follow the header in the blob round (0: it did not fit)
   uint64_t blob_need;  // capacity this rank needs
+  // tgx_status of what this rank did on its own since the last header (resolving its key sets, exporting records,
+  // packing its state): a rank that fails locally must not simply return -- its peers would wait in the next
+  // collective for ever -- so it keeps taking part (with empty contributions) until the next header carries the
+  // failure to everybody, and ALL ranks return an error from the same point
+  uint64_t status;
 };
 constexpr uint64_t kFactsMagic = 0x5447584641435453ull;  // "TGXFACTS"
 
@@ -335,6 +340,7 @@ uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_comm *comm, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (!comm) return fail(err, TGX_INVALID_ARGUMENT, "comm is NULL");
+  bind_thread();  // (a tokio worker / any thread: HIP's current device is per thread)
   const int32_t W = comm->ops.world, R = comm->ops.rank;
   const size_t nd = plan->distinct.size();
   if (comm->ops.device_buffers) {
@@ -372,27 +378,49 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
 
   // ---- 1. facts --------------------------------------------------------------------------------------------
   std::vector<ScanAcc> scan(plan->scan.size());
-  if (st->device_ready && !scan.empty()) {
-    // (queued in front of the resolve's own read-back, into pinned memory: the two come back with one wait)
-    TGX_TRY(pinned_reserve(&comm->h_a, &comm->h_a_cap, scan.size() * sizeof(ScanAcc), err));
-    HIP_TRY(hipMemcpyAsync(comm->h_a, st->d_scan_acc.p, scan.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost, s));
-  }
-  TGX_TRY(distinct_resolve_all(st, err));  // keys outside a sampled bitmap range are brought in first
-  if (st->device_ready) {
-    HIP_TRY(hipStreamSynchronize(s));
-    if (!scan.empty()) memcpy(scan.data(), comm->h_a, scan.size() * sizeof(ScanAcc));
-  } else {
+  tgx_error local_err;
+  memset(&local_err, 0, sizeof(local_err));
+  auto local_prep = [&](tgx_error *err) -> tgx_status {
+    if (st->device_ready && !scan.empty()) {
+      // (queued in front of the resolve's own read-back, into pinned memory: the two come back with one wait)
+      TGX_TRY(pinned_reserve(&comm->h_a, &comm->h_a_cap, scan.size() * sizeof(ScanAcc), err));
+      HIP_TRY(hipMemcpyAsync(comm->h_a, st->d_scan_acc.p, scan.size() * sizeof(ScanAcc), hipMemcpyDeviceToHost, s));
+    }
+    TGX_TRY(distinct_resolve_all(st, err));  // keys outside a sampled bitmap range are brought in first
+    if (st->device_ready) {
+      HIP_TRY(hipStreamSynchronize(s));
+      if (!scan.empty()) memcpy(scan.data(), comm->h_a, scan.size() * sizeof(ScanAcc));
+    }
+    return TGX_OK;
+  };
+  tgx_status local = local_prep(&local_err);
+  if (local != TGX_OK || !st->device_ready) {
     for (auto &a : scan) {
       memset(&a, 0, sizeof(a));
       a.min_k = INT64_MAX;
       a.max_k = INT64_MIN;
     }
   }
+  // every rank learns of a peer's local failure from the header it was about to receive anyway
+  auto peers_ok = [&](const uint8_t *blocks, size_t stride, const char *where) -> tgx_status {
+    for (int32_t r = 0; r < W; r++) {
+      const Header *hr = (const Header *)(blocks + (size_t)r * stride);
+      if (hr->status == 0) continue;
+      if (r == R && local != TGX_OK) {
+        if (err) *err = local_err;
+        return local;
+      }
+      return fail(err, (tgx_status)hr->status, "tgx_allreduce: rank %d failed %s (%s); no rank went on", r, where,
+                  tgx_status_name((int32_t)hr->status));
+    }
+    return TGX_OK;
+  };
   const size_t facts_bytes = sizeof(Header) + nd * sizeof(TaskFacts);
   std::vector<uint8_t> mine(facts_bytes), all(facts_bytes * (size_t)W);
   Header *hd = (Header *)mine.data();
   hd->magic = kFactsMagic ^ (uint64_t)nd;
   hd->blob_len = hd->blob_need = 0;
+  hd->status = (uint64_t)local;
   TaskFacts *tf = (TaskFacts *)(mine.data() + sizeof(Header));
   for (size_t k = 0; k < nd; k++) {
     const DistinctTask &task = plan->distinct[k];
@@ -434,6 +462,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   for (int32_t r = 0; r < W; r++)
     if (((const Header *)(all.data() + (size_t)r * facts_bytes))->magic != hd->magic)
       return fail(err, TGX_INVALID_ARGUMENT, "rank %d runs a different plan (or the transport mixed up the blocks)", r);
+  TGX_TRY(peers_ok(all.data(), facts_bytes, "while preparing its key sets"));
   auto facts_of = [&](int32_t r, size_t k) -> const TaskFacts & {
     return ((const TaskFacts *)(all.data() + (size_t)r * facts_bytes + sizeof(Header)))[k];
   };
@@ -536,7 +565,13 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     if (ds.mode == DistinctMode::kUndecided) ds.wide = wide;  // a rank that saw no rows still receives keys
     const void *recs = nullptr;
     std::vector<uint64_t> sc((size_t)W, 0), rc((size_t)W, 0);
-    if (!ds.partitioned) TGX_TRY(distinct_export_impl(st, k, (uint32_t)W, &recs, sc.data(), err));
+    if (!ds.partitioned && local == TGX_OK) {
+      local = distinct_export_impl(st, k, (uint32_t)W, &recs, sc.data(), &local_err);
+      if (local != TGX_OK) {  // keep taking part with nothing to send; the blob round's header tells everybody
+        recs = nullptr;
+        std::fill(sc.begin(), sc.end(), 0);
+      }
+    }
     // counts first (8 bytes per peer), then the records themselves
     HIP_TRY(comm->d_small_send.reserve((size_t)W * 8 + 16));
     HIP_TRY(comm->d_small_recv.reserve((size_t)W * 8 + 16));
@@ -564,12 +599,13 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   // ---- 3. the packed partial states: one all-gather, folded in rank order ----------------------------------------
   size_t len = 0;
   std::vector<uint8_t> blob;
-  {
-    tgx_status ss = tgx_state_serialize(plan, st, nullptr, 0, &len, err);
-    if (ss != TGX_OK) return ss;
-    blob.resize(len);
-    ss = tgx_state_serialize(plan, st, blob.data(), blob.size(), &len, err);
-    if (ss != TGX_OK) return ss;
+  if (local == TGX_OK) {
+    local = tgx_state_serialize(plan, st, nullptr, 0, &len, &local_err);
+    if (local == TGX_OK) {
+      blob.resize(len);
+      local = tgx_state_serialize(plan, st, blob.data(), blob.size(), &len, &local_err);
+    }
+    if (local != TGX_OK) len = 0;
   }
   if (comm->blob_plan != plan) {
     comm->blob_plan = plan;
@@ -587,6 +623,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     h.magic = kFactsMagic;
     h.blob_len = fits ? len : 0;
     h.blob_need = len;
+    h.status = (uint64_t)local;
     memcpy(sendbuf.data(), &h, sizeof(h));
     if (fits) memcpy(sendbuf.data() + sizeof(Header), blob.data(), len);
     recvbuf.resize(sendbuf.size() * (size_t)W);
@@ -599,6 +636,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
       need = std::max<size_t>(need, hr->blob_need);
       all_fit &= hr->blob_need <= cap;
     }
+    TGX_TRY(peers_ok(recvbuf.data(), sendbuf.size(), "while exchanging its key sets or packing its state"));
     if (all_fit) break;
     if (round >= 3) return fail(err, TGX_INTERNAL, "state gather: the ranks cannot agree on a capacity");
     comm->blob_cap = round_up(need + need / 2 + 64, 256);  // the same on every rank: all saw the same headers

@@ -403,5 +403,6 @@ tgx_status distinct_resolve(tgx_state *st, size_t slot, tgx_error *err);
 tgx_status distinct_resolve_all(tgx_state *st, tgx_error *err);
 int num_cus();
 int device_id();
+void bind_thread();  // hipSetDevice(the device tgx_init selected) for the calling thread
 }  // namespace tgx
 

@@ -359,6 +359,7 @@ using namespace tgx;
 
 extern "C" tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *st, size_t spec_index, double phi,
                                        double *out, tgx_error *err) try {
+  bind_thread();
   int slot = 0;
   tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
   if (s != TGX_OK) return s;
@@ -375,6 +376,7 @@ extern "C" tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *st, size
 extern "C" tgx_status tgx_kll_summary(const tgx_plan *plan, tgx_state *st, size_t spec_index, uint64_t *n,
                                       double *min_value, double *max_value, uint64_t *num_levels,
                                       uint64_t *num_retained, tgx_error *err) try {
+  bind_thread();
   int slot = 0;
   tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
   if (s != TGX_OK) return s;
@@ -392,6 +394,7 @@ extern "C" tgx_status tgx_kll_summary(const tgx_plan *plan, tgx_state *st, size_
 extern "C" tgx_status tgx_kll_level_items(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                           uint64_t level, double *out, uint64_t cap, uint64_t *count,
                                           tgx_error *err) try {
+  bind_thread();
   int slot = 0;
   tgx_status s = kll_slot(plan, st, spec_index, &slot, err);
   if (s != TGX_OK) return s;

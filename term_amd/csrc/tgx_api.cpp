@@ -116,6 +116,13 @@ extern "C" tgx_status tgx_shutdown(void) try {
   return tgx::abi_exception(nullptr);
 }
 
+// HIP's current device is per THREAD: the caller's evaluate() may run on any tokio worker ("callable
+// from arbitrary threads"), and a thread that never called hipSetDevice launches on device 0 against streams and
+// buffers of device k.  Every entry point that touches HIP binds its thread to the device tgx_init selected first.
+void tgx::bind_thread() {
+  if (g_ctx.inited) (void)hipSetDevice(g_ctx.device);
+}
+
 tgx_status tgx::need_device(tgx_error *err) {
   if (!g_ctx.inited)
     return fail(err, TGX_NO_DEVICE, "tgx_init has not succeeded: no gfx950 device, and libtgx has no CPU path");
@@ -453,6 +460,7 @@ extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, t
 
 extern "C" void tgx_state_destroy(tgx_state *st) {
   if (!st) return;
+  bind_thread();
   if (st->device_ready && st->stream) (void)hipStreamSynchronize(st->stream);
   for (auto &kv : st->profile)
     for (auto &ev : kv.second.pending) {
@@ -472,6 +480,7 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
 }
 
 extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
+  bind_thread();
   if (!st) return fail(err, TGX_INVALID_ARGUMENT, "state is NULL");
   if (st->device_ready) {
     TGX_TRY(distinct_resolve_all(st, err));  // the caller may release its DEVICE batches after this call
@@ -483,6 +492,7 @@ extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
 }
 
 extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) try {
+  bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   st->ptr_tables.clear();
@@ -593,6 +603,7 @@ static void prof_resolve(tgx_state *st) {
 
 extern "C" tgx_status tgx_profile_get(tgx_state *st, const char *kernel, double *total_ms,
                                       uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err) try {
+  bind_thread();
   if (!st || !kernel) return fail(err, TGX_INVALID_ARGUMENT, "state/kernel is NULL");
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   prof_resolve(st);
@@ -606,6 +617,7 @@ extern "C" tgx_status tgx_profile_get(tgx_state *st, const char *kernel, double 
 }
 
 extern "C" tgx_status tgx_profile_reset(tgx_state *st) try {
+  bind_thread();
   if (!st) return TGX_INVALID_ARGUMENT;
   if (st->device_ready) (void)hipStreamSynchronize(st->stream);
   prof_resolve(st);
@@ -1591,6 +1603,7 @@ static tgx_status como_pivots(tgx_state *st, const ComomentLaunch &L, int n_pair
 
 extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_column *columns,
                                  size_t n_columns, tgx_error *err) try {
+  bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if ((int)n_columns < plan->n_columns_needed)
     return fail(err, TGX_INVALID_ARGUMENT, "plan reads column %d but only %zu columns were passed",
@@ -2220,6 +2233,7 @@ static void fill_stats(const ScanAcc &a, bool variance, tgx_result *r) {
 
 extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_result *results,
                                    size_t n_results, tgx_error *err) try {
+  bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (n_results < plan->specs.size() || (!results && !plan->specs.empty()))
     return fail(err, TGX_INVALID_ARGUMENT, "results has room for %zu of %zu specs", n_results, plan->specs.size());
@@ -2388,6 +2402,7 @@ extern "C" size_t tgx_distinct_record_bytes(const tgx_plan *plan, const tgx_stat
 extern "C" tgx_status tgx_distinct_export(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                           uint32_t world, const void **device_records, uint64_t *counts,
                                           tgx_error *err) try {
+  bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
@@ -2424,6 +2439,7 @@ tgx_status tgx::distinct_import_records(tgx_state *st, size_t slot, const void *
 
 extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, size_t spec_index,
                                           const void *device_records, uint64_t n_records, tgx_error *err) try {
+  bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
@@ -2484,6 +2500,7 @@ extern "C" tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *s
 extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *st, size_t spec_index, int64_t *base,
                                                uint64_t *n_words, const void **seen, const void **twice,
                                                tgx_error *err) try {
+  bind_thread();
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   TGX_TRY(distinct_resolve(st, slot, err));
@@ -2504,6 +2521,7 @@ extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state 
                                                 int64_t slice_base, const void *seen_slices,
                                                 const void *twice_slices, uint32_t n_slices, uint64_t slice_words,
                                                 uint64_t slice_stride_words, tgx_error *err) try {
+  bind_thread();
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   TGX_TRY(need_device(err));
@@ -2544,6 +2562,7 @@ extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state 
 
 extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state *const *srcs, size_t n_srcs,
                                 tgx_error *err) try {
+  bind_thread();
   if (!plan || !dst || dst->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "dst does not belong to plan");
   for (size_t i = 0; i < n_srcs; i++) {
     tgx_state *src = srcs ? srcs[i] : nullptr;
@@ -2643,6 +2662,7 @@ constexpr uint32_t kWireVersion = 2;  // 2: ComomentAcc carries its pivots
 
 extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, uint8_t *buf, size_t cap,
                                           size_t *len, tgx_error *err) try {
+  bind_thread();
   if (!plan || !st || st->plan != plan || !len) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
   TGX_TRY(spearman_check_mergeable(st, err));
   Gathered g;
@@ -2692,6 +2712,7 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
 
 extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t *buf, size_t len,
                                             tgx_state **out, tgx_error *err) try {
+  bind_thread();
   if (!plan || !buf || !out) return fail(err, TGX_INVALID_ARGUMENT, "bad arguments");
   *out = nullptr;
   Reader r{buf, len};
