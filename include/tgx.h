@@ -197,9 +197,14 @@ typedef struct tgx_result {
   double co_mean_x, co_mean_y, co_m2_x, co_m2_y, co_c_xy;
 } tgx_result;
 
+enum {
+  /* every batch is launched as it arrives: no library-side coalescing of small batches (see tgx_update) */
+  TGX_OPT_NO_COALESCE = 1u << 0
+};
+
 typedef struct tgx_options {
   int32_t device_id;       /* -1 = current HIP device */
-  int32_t reserved;
+  uint32_t flags;          /* TGX_OPT_* */
   uint64_t distinct_capacity_hint; /* expected rows per DISTINCT column (0 = grow on demand) */
 } tgx_options;
 

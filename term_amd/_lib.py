@@ -64,7 +64,7 @@ class Result(C.Structure):
 
 
 class _Options(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("reserved", C.c_int32), ("distinct_capacity_hint", C.c_uint64)]
+    _fields_ = [("device_id", C.c_int32), ("flags", C.c_uint32), ("distinct_capacity_hint", C.c_uint64)]
 
 
 def lib_path():
@@ -176,11 +176,15 @@ def _check(status, err):
 _INITED = False
 
 
-def init(device_id=-1, distinct_capacity_hint=0):
-    """tgx_init: selects the gfx950 device. Raises TgxError(TGX_NO_DEVICE) when there is none."""
+OPT_NO_COALESCE = 1
+
+
+def init(device_id=-1, distinct_capacity_hint=0, flags=0):
+    """tgx_init: selects the gfx950 device. Raises TgxError(TGX_NO_DEVICE) when there is none.
+    flags: OPT_NO_COALESCE = every batch is launched as it arrives"""
     global _INITED
     err = _Error()
-    opts = _Options(device_id, 0, distinct_capacity_hint)
+    opts = _Options(device_id, flags, distinct_capacity_hint)
     _check(lib().tgx_init(C.byref(opts), C.byref(err)), err)
     _INITED = True
 

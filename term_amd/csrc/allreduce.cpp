@@ -341,6 +341,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (!comm) return fail(err, TGX_INVALID_ARGUMENT, "comm is NULL");
   bind_thread();  // (a tokio worker / any thread: HIP's current device is per thread)
+  TGX_TRY(coalesce_flush(st, err));  // batches tgx_update has only noted so far
   const int32_t W = comm->ops.world, R = comm->ops.rank;
   const size_t nd = plan->distinct.size();
   if (comm->ops.device_buffers) {

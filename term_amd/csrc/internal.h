@@ -84,6 +84,7 @@ void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *
                           const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
+void launch_gather_segments(const GatherSeg *d_segs, int n_segs, hipStream_t stream);
 int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
 void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
                             int64_t dict_length, int dict_has_nulls, const uint8_t *hits, int null_is_valid,
@@ -192,6 +193,8 @@ struct tgx_plan {
   std::vector<tgx::ComomentTask> como;
   std::vector<tgx::KllTask> kll;
   int n_columns_needed = 0;  // 1 + max column index
+  // per plan column, fixed at tgx_plan_create (tgx_update runs once per 8192-row batch: nothing is allocated there)
+  std::vector<char> used, reads_values, needs_wide;
   void *regex = nullptr;     // tgx::RegexPlan (regex_device.cpp)
   void *spearman = nullptr;  // tgx::SpearmanPlan (spearman_device.cpp)
 };
@@ -287,7 +290,24 @@ struct DistinctState {
   // batches retained here -- DEVICE views, which the caller keeps alive until tgx_finalize / tgx_state_sync
   // (include/tgx.h); HOST batches are resolved before tgx_update returns.
   bool speculative = false;
-  std::vector<tgx_column> retained;
+  // the views, and for each the coalescing region set it points into (-1: the caller's own memory)
+  struct Retained {
+    std::vector<tgx_column> cols;
+    std::vector<int8_t> region_set;
+    void push_back(const tgx_column &c) {
+      cols.push_back(c);
+      region_set.push_back(-1);
+    }
+    void clear() {
+      cols.clear();
+      region_set.clear();
+    }
+    bool empty() const { return cols.empty(); }
+    size_t size() const { return cols.size(); }
+    std::vector<tgx_column>::const_iterator begin() const { return cols.begin(); }
+    std::vector<tgx_column>::const_iterator end() const { return cols.end(); }
+    const tgx_column &operator[](size_t i) const { return cols[i]; }
+  } retained;
   DevBuf sample;         // DistinctSample
   bool sample_ready = false;  // `sample_host` holds this batch's sample (tgx_update reads all tasks' samples at once)
   DistinctSample sample_host;
@@ -314,6 +334,59 @@ struct DictGather {
 struct DictFuse {
   std::map<int, int> capacity;                         // column -> pattern checks the fused pass can take
   std::map<int, std::vector<DictGather>> by_column;    // filled by regex_update
+};
+
+// ---- library-side coalescing of small batches (tgx_api.cpp "coalescing", kernels/gather.hip) ----
+// DataFusion streams 8192-row RecordBatches (TG/core/context.rs:28-38).  tgx_update only notes a small batch: one
+// segment per used column (a HOST batch's windows are first copied into a pinned arena -- its buffers are borrowed only
+// until the call returns); a flush uploads the arena, gathers every column's segments into one contiguous device
+// column and runs the ordinary fused pass on that.  Two arenas and two sets of device regions take turns, so the host
+// keeps copying batch k+1 while the device still works on flush k; nothing is synchronised per batch.
+struct CoalesceSegment {
+  const void *values;       // window start (device address: the caller's buffer or the arena's device twin)
+  const uint8_t *validity;  // byte of the first validity bit, or nullptr
+  const uint8_t *data;      // strings: first value byte of the window
+  int64_t bit0;             // first validity bit within *validity
+  int64_t length;
+  int64_t data_first, data_len;
+};
+struct CoalesceColumn {
+  int type = 0;             // tgx_type of the pending segments
+  bool any_validity = false;
+  int64_t data_bytes = 0;   // strings: value bytes pending
+  std::vector<CoalesceSegment> segs;
+  DevBuf values[2], validity[2], data[2];  // the coalesced column, per region set
+};
+struct Coalescer {
+  bool disabled = false;
+  int64_t flush_rows = 0;   // 0: the default threshold (TGX_COALESCE_FLUSH_ROWS overrides it, for tests)
+  int64_t rows = 0;         // rows pending
+  size_t batches = 0;       // batches pending
+  std::vector<int64_t> batch_rows;  // rows of each pending batch
+  std::vector<CoalesceColumn> cols;  // per plan column
+  // HOST batches: pinned arenas (and their device twins), guarded by an event recorded after the flush that used them
+  void *arena_host[2] = {nullptr, nullptr};
+  DevBuf arena_dev[2];
+  size_t arena_cap[2] = {0, 0};
+  size_t arena_want = 8u << 20;  // grows (to kCoalesceArenaMax) when flushes are forced by a full arena
+  hipEvent_t arena_event[2] = {nullptr, nullptr};
+  bool arena_busy[2] = {false, false};
+  int arena_cur = 0;
+  size_t arena_used = 0;
+  // the segment table of a flush: pinned, uploaded, one per arena turn
+  void *desc_host[2] = {nullptr, nullptr};
+  size_t desc_cap[2] = {0, 0};
+  DevBuf desc_dev[2];
+  // device region set of the next flush, and what is known about the flush that last used each set: a snapshot of the
+  // DISTINCT counters taken right after it (views retained into the set can be dropped without a wait when the
+  // snapshot shows no key outside its bitmap and no overflowed list)
+  int set_cur = 0;
+  void *snap_host[2] = {nullptr, nullptr};
+  size_t snap_cap[2] = {0, 0};
+  hipEvent_t snap_event[2] = {nullptr, nullptr};
+  bool snap_pending[2] = {false, false};
+  bool flushing = false;
+  uint64_t flushes = 0, coalesced_batches = 0;  // statistics (tgx_profile_get "coalesce_flushes" / "coalesced_batches")
 };
 
 struct ProfileEntry {
@@ -381,7 +454,7 @@ struct tgx_state {
   void *regex = nullptr;  // tgx::RegexState (regex_device.cpp)
   void *spearman = nullptr;  // tgx::SpearmanState (spearman_device.cpp)
 
-  // rows handled by host-answered COUNT tasks (columns without a validity buffer)
+  tgx::Coalescer coalesce;
   bool profiling = false;
   std::map<std::string, tgx::ProfileEntry> profile;
 };
@@ -401,6 +474,9 @@ tgx_status distinct_import_records(tgx_state *st, size_t slot, const void *d_rec
 // brings in the keys that fell outside a sampled bitmap range (see DistinctState::speculative); a no-op otherwise
 tgx_status distinct_resolve(tgx_state *st, size_t slot, tgx_error *err);
 tgx_status distinct_resolve_all(tgx_state *st, tgx_error *err);
+// runs the small batches tgx_update has only noted so far (no-op when none are pending); called by every entry point
+// that looks at the state
+tgx_status coalesce_flush(tgx_state *st, tgx_error *err);
 int num_cus();
 int device_id();
 void bind_thread();  // hipSetDevice(the device tgx_init selected) for the calling thread

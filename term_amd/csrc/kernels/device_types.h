@@ -128,6 +128,23 @@ struct ComomentAcc {
   int32_t pad;
 };
 
+// One (column, batch) window of the library-side batch coalescing (kernels/gather.hip): where the window lives and
+// where it lands in the coalesced column.  A table of these is uploaded per flush; one workgroup per entry.
+struct GatherSeg {
+  const void *src_values;       // kind 0: first value of the window; kinds 1 / 2: its first offset (length + 1 offsets)
+  const uint8_t *src_validity;  // byte holding the window's first validity bit, or nullptr (no nulls)
+  const uint8_t *src_data;      // strings: the window's first value byte (offset value data_first)
+  void *dst_values;             // the coalesced column's values / offsets buffer (element 0)
+  uint8_t *dst_validity;        // the coalesced bitmap (zeroed before the gather), or nullptr (no segment has nulls)
+  uint8_t *dst_data;            // strings: the coalesced value bytes
+  int64_t src_bit0;             // bit of row 0 within *src_validity (0..7)
+  int64_t length;               // rows
+  int64_t dst_row;              // first row in the coalesced column
+  int64_t data_first, data_base, data_len;  // strings: first source offset value, destination byte position, bytes
+  int32_t elem_bytes;           // kind 0: 8 or 4
+  int32_t kind;                 // 0 fixed width, 1 Utf8 (int32 offsets), 2 LargeUtf8 (int64 offsets)
+};
+
 __host__ __device__ inline int64_t f64_total_key(int64_t bits) {
   return bits ^ (int64_t)(((uint64_t)(bits >> 63)) >> 1);
 }

@@ -350,6 +350,8 @@ static tgx_status kll_slot(const tgx_plan *plan, tgx_state *st, size_t spec_inde
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_KLL)
     return kfail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a KLL check", spec_index);
   *slot = plan->bind[spec_index].slot;
+  tgx_status cs = coalesce_flush(st, err);  // batches tgx_update has only noted so far
+  if (cs != TGX_OK) return cs;
   return kll_flush(st, err);
 }
 

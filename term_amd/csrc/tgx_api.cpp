@@ -70,6 +70,7 @@ struct Context {
   int device = -1;
   int n_cu = 256;
   uint64_t distinct_hint = 0;
+  bool no_coalesce = false;
   char arch[64] = {0};
 } g_ctx;
 }  // namespace
@@ -102,6 +103,7 @@ extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) try {
   g_ctx.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   snprintf(g_ctx.arch, sizeof(g_ctx.arch), "%s", prop.gcnArchName);
   g_ctx.distinct_hint = opts ? opts->distinct_capacity_hint : 0;
+  g_ctx.no_coalesce = opts && (opts->flags & TGX_OPT_NO_COALESCE) != 0;
   g_ctx.inited = true;
   return TGX_OK;
 } catch (...) {
@@ -278,6 +280,31 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
   }
   plan->n_columns_needed = max_col + 1;
   regex_plan_finish(plan.get());
+  // which columns the plan touches, whose values it reads, and which 4-byte numeric columns a pass needs widened
+  {
+    tgx_plan *P = plan.get();
+    P->used.assign(P->n_columns_needed, 0);
+    P->reads_values.assign(P->n_columns_needed, 0);
+    P->needs_wide.assign(P->n_columns_needed, 0);
+    for (auto &t : P->scan) P->used[t.column] = P->reads_values[t.column] = 1;
+    for (auto &t : P->count) P->used[t.column] = 1;
+    for (auto &t : P->distinct) {
+      P->used[t.column] = P->reads_values[t.column] = P->needs_wide[t.column] = 1;
+      for (int c : t.tuple) P->used[c] = P->reads_values[c] = P->needs_wide[c] = 1;
+    }
+    for (auto &t : P->como)
+      P->used[t.col_x] = P->used[t.col_y] = P->reads_values[t.col_x] = P->reads_values[t.col_y] =
+          P->needs_wide[t.col_x] = P->needs_wide[t.col_y] = 1;
+    for (auto &t : P->kll) P->used[t.column] = P->reads_values[t.column] = P->needs_wide[t.column] = 1;
+    regex_mark_used(P, P->used);
+    std::vector<char> sp_used(P->n_columns_needed, 0), sp_vals(P->n_columns_needed, 0);
+    spearman_mark_used(P, sp_used, sp_vals);
+    for (int i = 0; i < P->n_columns_needed; i++) {
+      P->used[i] |= sp_used[i];
+      P->reads_values[i] |= sp_vals[i];
+      P->needs_wide[i] |= sp_used[i];
+    }
+  }
   // re-point pattern pointers at the plan-owned copies
   for (size_t i = 0; i < n_specs; i++) {
     plan->specs[i].pattern = plan->patterns[i].empty() ? nullptr : plan->patterns[i].data();
@@ -299,6 +326,7 @@ extern "C" size_t tgx_plan_num_specs(const tgx_plan *plan) { return plan ? plan-
 
 // ------------------------------------------------------------------------------------------------
 // state
+static void coalesce_drop(tgx_state *st);
 static ScanAcc scan_acc_identity() {
   ScanAcc a;
   memset(&a, 0, sizeof(a));
@@ -452,6 +480,11 @@ extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, t
   state_init_host(st, plan);
   st->stream = (hipStream_t)hip_stream;
   st->own_stream = false;
+  // TGX_COALESCE=0 (or tgx_options.flags & TGX_OPT_NO_COALESCE): every batch is launched as it arrives
+  const char *ce = getenv("TGX_COALESCE");
+  st->coalesce.disabled = g_ctx.no_coalesce || (ce && ce[0] == '0');
+  if (const char *fe = getenv("TGX_COALESCE_FLUSH_ROWS"))  // (tests: many flushes from little data)
+    st->coalesce.flush_rows = std::max<int64_t>(1, atoll(fe));
   *out = st;
   return TGX_OK;
 } catch (...) {
@@ -473,6 +506,12 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   for (int k = 0; k < 2; k++) {
     if (st->arena_event[k]) (void)hipEventDestroy(st->arena_event[k]);
     if (st->arena_host[k]) (void)hipHostFree(st->arena_host[k]);
+    tgx::Coalescer &co = st->coalesce;
+    if (co.arena_event[k]) (void)hipEventDestroy(co.arena_event[k]);
+    if (co.snap_event[k]) (void)hipEventDestroy(co.snap_event[k]);
+    if (co.arena_host[k]) (void)hipHostFree(co.arena_host[k]);
+    if (co.desc_host[k]) (void)hipHostFree(co.desc_host[k]);
+    if (co.snap_host[k]) (void)hipHostFree(co.snap_host[k]);
   }
   if (st->h_pinned) (void)hipHostFree(st->h_pinned);
   if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
@@ -482,6 +521,7 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
 extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
   bind_thread();
   if (!st) return fail(err, TGX_INVALID_ARGUMENT, "state is NULL");
+  TGX_TRY(coalesce_flush(st, err));  // batches tgx_update has only noted so far
   if (st->device_ready) {
     TGX_TRY(distinct_resolve_all(st, err));  // the caller may release its DEVICE batches after this call
     HIP_TRY(hipStreamSynchronize(st->stream));
@@ -494,6 +534,7 @@ extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
 extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_error *err) try {
   bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  coalesce_drop(st);
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   st->ptr_tables.clear();
   // host side back to the identity; device buffers are kept and re-zeroed (no hipFree / hipMalloc)
@@ -605,6 +646,13 @@ extern "C" tgx_status tgx_profile_get(tgx_state *st, const char *kernel, double 
                                       uint64_t *launches, uint64_t *algorithmic_bytes, tgx_error *err) try {
   bind_thread();
   if (!st || !kernel) return fail(err, TGX_INVALID_ARGUMENT, "state/kernel is NULL");
+  if (strcmp(kernel, "coalesce") == 0) {  // flushes so far / batches that were coalesced into them (no timing)
+    if (total_ms) *total_ms = 0.0;
+    if (launches) *launches = st->coalesce.flushes;
+    if (algorithmic_bytes) *algorithmic_bytes = st->coalesce.coalesced_batches;
+    return TGX_OK;
+  }
+  TGX_TRY(coalesce_flush(st, err));
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   prof_resolve(st);
   auto it = st->profile.find(kernel);
@@ -912,8 +960,8 @@ static tgx_status bitmap_to_hash(tgx_state *st, DistinctState &ds, bool mult, ui
   launch_bitmap_to_hash(bitmap_view(ds), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
                         st->stream);
   HIP_TRY(hipStreamSynchronize(st->stream));
-  ds.seen.release();
-  ds.twice.release();
+  // (the bitmap's buffers stay with the state: a step that is reset and repeated would free and allocate them each
+  //  time, and hipFree waits for the whole device)
   ds.mode = DistinctMode::kHash;
   ds.rows_upper_bound = actual;
   return TGX_OK;
@@ -1601,29 +1649,19 @@ static tgx_status como_pivots(tgx_state *st, const ComomentLaunch &L, int n_pair
   return TGX_OK;
 }
 
-extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_column *columns,
-                                 size_t n_columns, tgx_error *err) try {
-  bind_thread();
-  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
-  if ((int)n_columns < plan->n_columns_needed)
-    return fail(err, TGX_INVALID_ARGUMENT, "plan reads column %d but only %zu columns were passed",
-                plan->n_columns_needed - 1, n_columns);
-  if (n_columns > 0 && !columns) return fail(err, TGX_INVALID_ARGUMENT, "columns is NULL");
-  TGX_TRY(need_device(err));
-  TGX_TRY(state_init_device(st, err));
+// checks one batch's column views against the plan and the state (types, row counts, required buffers); *nrows_out =
+// the batch's rows.  Nothing is allocated here: it runs once per 8192-row batch.
+namespace {
+struct BatchTraits {
+  bool any_host = false, any_utf8 = false;
+  bool coalescible = true;  // every used column is of a kind the segment gather takes (kernels/gather.hip)
+};
+}  // namespace
 
-  // which columns does the plan touch, and do they agree on the row count
-  std::vector<char> used(plan->n_columns_needed, 0), reads_values(plan->n_columns_needed, 0);
-  for (auto &t : plan->scan) used[t.column] = reads_values[t.column] = 1;
-  for (auto &t : plan->count) used[t.column] = 1;
-  for (auto &t : plan->distinct) {
-    used[t.column] = reads_values[t.column] = 1;
-    for (int c : t.tuple) used[c] = reads_values[c] = 1;
-  }
-  for (auto &t : plan->como) used[t.col_x] = used[t.col_y] = reads_values[t.col_x] = reads_values[t.col_y] = 1;
-  for (auto &t : plan->kll) used[t.column] = reads_values[t.column] = 1;
-  regex_mark_used(plan, used);
-  spearman_mark_used(plan, used, reads_values);
+static tgx_status update_validate(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, size_t n_columns,
+                                  int64_t *nrows_out, BatchTraits *traits, tgx_error *err) {
+  (void)n_columns;
+  const std::vector<char> &used = plan->used, &reads_values = plan->reads_values;
   int64_t nrows = -1;
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!used[i]) continue;
@@ -1634,10 +1672,18 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
       return fail(err, TGX_INVALID_ARGUMENT, "column %d has %lld rows, expected %lld", i, (long long)c.length,
                   (long long)nrows);
     if (c.type < TGX_INT64 || c.type > TGX_FLOAT32) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
+    if (c.mem != TGX_MEM_HOST && c.mem != TGX_MEM_DEVICE)
+      return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown memory space %d", i, c.mem);
     if (st->col_types[i] == 0) st->col_types[i] = c.type;
     if (st->col_types[i] != c.type)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d changed type between batches (%d -> %d)", i,
                   st->col_types[i], c.type);
+    const bool host = c.mem == TGX_MEM_HOST;
+    traits->any_host |= host;
+    traits->any_utf8 |= c.type == TGX_UTF8;
+    // string windows need their first / last offsets on the host: HOST batches only (what DataFusion streams);
+    // Utf8View and dictionary batches keep the immediate path
+    traits->coalescible &= is_numeric(c.type) || is_numeric32(c.type) || (is_string(c.type) && host);
     if (c.length > 0) {
       if ((is_numeric(c.type) || is_numeric32(c.type)) && reads_values[i] && !c.values)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
@@ -1661,7 +1707,46 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: indices (values) is NULL", i);
     }
   }
-  if (nrows < 0) nrows = 0;
+  *nrows_out = nrows < 0 ? 0 : nrows;
+  return TGX_OK;
+}
+
+static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, int64_t nrows,
+                              tgx_error *err);
+static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, int64_t nrows,
+                                  const BatchTraits &traits, bool *taken, tgx_error *err);
+constexpr int64_t kCoalesceMaxRows = 1 << 16;        // batches up to this many rows are coalesced
+
+extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_column *columns,
+                                 size_t n_columns, tgx_error *err) try {
+  if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
+  if ((int)n_columns < plan->n_columns_needed)
+    return fail(err, TGX_INVALID_ARGUMENT, "plan reads column %d but only %zu columns were passed",
+                plan->n_columns_needed - 1, n_columns);
+  if (n_columns > 0 && !columns) return fail(err, TGX_INVALID_ARGUMENT, "columns is NULL");
+  TGX_TRY(need_device(err));
+  bind_thread();
+  int64_t nrows = 0;
+  BatchTraits traits;
+  TGX_TRY(update_validate(plan, st, columns, n_columns, &nrows, &traits, err));
+  // a small batch is only noted (kernels/gather.hip): no launch, no synchronisation per 8192-row batch
+  const Coalescer &co = st->coalesce;
+  if (traits.coalescible && nrows > 0 && nrows <= kCoalesceMaxRows && !co.disabled && !co.flushing) {
+    bool taken = false;
+    TGX_TRY(coalesce_append(plan, st, columns, nrows, traits, &taken, err));
+    if (taken) return TGX_OK;
+  }
+  TGX_TRY(coalesce_flush(st, err));  // batches stay in order
+  return update_impl(plan, st, columns, nrows, err);
+} catch (...) {
+  return tgx::abi_exception(err);
+}
+
+// one batch through the fused pass: device views of its columns, then every kernel of the plan
+static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, int64_t nrows,
+                              tgx_error *err) {
+  TGX_TRY(state_init_device(st, err));
+  const std::vector<char> &used = plan->used;
 
   // device views of every used column
   st->staging_used = 0;
@@ -1672,18 +1757,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   st->pending_widen.clear();
   std::vector<tgx_column> dev(plan->n_columns_needed);
   // 4-byte numeric columns are widened to 8-byte values only for the passes that need them so
-  std::vector<char> needs_wide(plan->n_columns_needed, 0);
-  for (auto &t : plan->distinct) {
-    needs_wide[t.column] = 1;
-    for (int c2 : t.tuple) needs_wide[c2] = 1;
-  }
-  for (auto &t : plan->como) needs_wide[t.col_x] = needs_wide[t.col_y] = 1;
-  for (auto &t : plan->kll) needs_wide[t.column] = 1;
-  {
-    std::vector<char> sp_used(plan->n_columns_needed, 0), sp_vals(plan->n_columns_needed, 0);
-    spearman_mark_used(plan, sp_used, sp_vals);
-    for (int i = 0; i < plan->n_columns_needed; i++) needs_wide[i] |= sp_used[i];
-  }
+  const std::vector<char> &needs_wide = plan->needs_wide;
   bool any_host = false;
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!used[i]) continue;
@@ -2085,8 +2159,343 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   // live that long
   if (any_host) TGX_TRY(distinct_resolve_all(st, err));
   return TGX_OK;
-} catch (...) {
-  return tgx::abi_exception(err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// coalescing: small batches are noted, gathered into one column per flush, then take the ordinary pass
+// (internal.h, Coalescer; kernels/gather.hip).  Reference shape: DataFusion's `batch_size: 8192`
+// (TG/core/context.rs:28-38) -- what `execute_stream()` hands a drop-in.
+constexpr int64_t kCoalesceFlushRows = 4 << 20;      // pending rows that trigger a flush
+constexpr size_t kCoalesceFlushBatches = 4096;       // pending batches that trigger a flush
+constexpr size_t kCoalesceArenaMax = 128u << 20;     // pinned staging per arena turn (HOST batches)
+
+// a copy that does not pull the destination into the cache first (the arena is written once and read by the DMA
+// engine): glibc's memcpy takes its streaming path only for copies of several MiB
+static void stream_copy(void *dst, const void *src, size_t bytes) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)  // (this file also passes through the device compiler)
+  if (bytes >= 4096 && ((uintptr_t)dst & 31) == 0) {
+    typedef long long v4 __attribute__((vector_size(32), aligned(1)));
+    typedef long long v4a __attribute__((vector_size(32)));
+    const size_t n32 = bytes / 32;
+    const v4 *s = (const v4 *)src;
+    v4a *d = (v4a *)dst;
+    for (size_t i = 0; i < n32; i++) __builtin_nontemporal_store((v4a)s[i], d + i);
+    __builtin_ia32_sfence();
+    const size_t done = n32 * 32;
+    if (done < bytes) memcpy((char *)dst + done, (const char *)src + done, bytes - done);
+    return;
+  }
+#endif
+  memcpy(dst, src, bytes);
+}
+
+static tgx_status coalesce_arena_ready(tgx_state *st, tgx_error *err) {
+  Coalescer &co = st->coalesce;
+  const int k = co.arena_cur;
+  if (co.arena_busy[k]) {  // the flush that used this arena two turns ago (long done)
+    HIP_TRY(hipEventSynchronize(co.arena_event[k]));
+    co.arena_busy[k] = false;
+  }
+  if (co.arena_cap[k] < co.arena_want) {
+    if (co.arena_host[k]) (void)hipHostFree(co.arena_host[k]);
+    co.arena_host[k] = nullptr;
+    co.arena_cap[k] = 0;
+    HIP_TRY(hipHostMalloc(&co.arena_host[k], co.arena_want, hipHostMallocDefault));
+    HIP_TRY(co.arena_dev[k].reserve(co.arena_want));
+    co.arena_cap[k] = co.arena_want;
+  }
+  if (!co.arena_event[k]) HIP_TRY(hipEventCreateWithFlags(&co.arena_event[k], hipEventDisableTiming));
+  return TGX_OK;
+}
+
+// bytes one batch's HOST windows take in the arena (each buffer padded to 64 bytes)
+static size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int64_t nrows) {
+  size_t total = 0;
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!plan->used[i] || columns[i].mem != TGX_MEM_HOST) continue;
+    const tgx_column &c = columns[i];
+    if (c.validity) total += (size_t)(((c.offset & 7) + nrows + 7) >> 3) + 64;
+    if (is_string(c.type)) {
+      const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
+      const int64_t first = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[c.offset] : ((const int64_t *)c.offsets)[c.offset];
+      const int64_t end = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[c.offset + nrows]
+                                  : ((const int64_t *)c.offsets)[c.offset + nrows];
+      total += (size_t)(nrows + 1) * ow + 64 + (size_t)std::max<int64_t>(end - first, 0) + 64;
+    } else if (plan->reads_values[i] || c.values) {
+      total += (size_t)nrows * (is_numeric32(c.type) ? 4 : 8) + 64;
+    }
+  }
+  return total;
+}
+
+static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, int64_t nrows,
+                                  const BatchTraits &traits, bool *taken, tgx_error *err) {
+  Coalescer &co = st->coalesce;
+  *taken = false;
+  if (co.cols.size() != (size_t)plan->n_columns_needed) co.cols.resize(plan->n_columns_needed);
+  const bool any_host = traits.any_host;
+  if (any_host) {
+    const size_t need = coalesce_host_bytes(plan, columns, nrows);
+    if (need > kCoalesceArenaMax) return TGX_OK;  // (64 Ki rows of very long strings): the immediate path
+    if (co.arena_used > 0 && co.arena_used + need > co.arena_cap[co.arena_cur]) {
+      // the arena is full: flush, and ask for a bigger one next time (fewer, larger flushes)
+      co.arena_want = std::min(kCoalesceArenaMax, std::max(co.arena_want * 2, need));
+      TGX_TRY(coalesce_flush(st, err));
+    }
+    if (need > co.arena_want) co.arena_want = std::min(kCoalesceArenaMax, need + need / 2);
+    if (co.arena_used == 0) TGX_TRY(coalesce_arena_ready(st, err));  // this arena turn's first HOST window
+    if (co.arena_used + need > co.arena_cap[co.arena_cur]) return TGX_OK;  // (cannot happen after the above)
+  }
+  // a string column whose coalesced int32 offsets would pass 2^31: flush first
+  for (int i = 0; traits.any_utf8 && i < plan->n_columns_needed; i++) {
+    if (!plan->used[i] || columns[i].type != TGX_UTF8) continue;
+    const tgx_column &c = columns[i];
+    const int64_t bytes = (int64_t)((const int32_t *)c.offsets)[c.offset + nrows] - (int64_t)((const int32_t *)c.offsets)[c.offset];
+    if (co.cols[i].data_bytes + bytes > 0x7FFFFF00LL) {
+      TGX_TRY(coalesce_flush(st, err));
+      if (any_host) TGX_TRY(coalesce_arena_ready(st, err));  // (strings are HOST windows: the arena has just turned)
+      break;
+    }
+  }
+  char *ah = any_host ? (char *)co.arena_host[co.arena_cur] : nullptr;
+  const char *ad = any_host ? (const char *)co.arena_dev[co.arena_cur].p : nullptr;
+  auto to_arena = [&](const void *src, size_t bytes) -> const void * {  // returns the DEVICE twin's address
+    const size_t at = (co.arena_used + 63) & ~(size_t)63;
+    stream_copy(ah + at, src, bytes);
+    co.arena_used = at + bytes;
+    return ad + at;
+  };
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!plan->used[i]) continue;
+    const tgx_column &c = columns[i];
+    CoalesceColumn &cc = co.cols[i];
+    cc.type = c.type;
+    CoalesceSegment sg;
+    memset(&sg, 0, sizeof(sg));
+    sg.length = nrows;
+    const bool host = c.mem == TGX_MEM_HOST;
+    if (c.validity) {
+      const uint8_t *v0 = c.validity + (c.offset >> 3);
+      sg.bit0 = c.offset & 7;
+      sg.validity = host ? (const uint8_t *)to_arena(v0, (size_t)((sg.bit0 + nrows + 7) >> 3)) : v0;
+      cc.any_validity = true;
+    }
+    if (is_string(c.type)) {
+      const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
+      const uint8_t *o0 = (const uint8_t *)c.offsets + (size_t)c.offset * ow;
+      const int64_t first = ow == 4 ? (int64_t)((const int32_t *)o0)[0] : ((const int64_t *)o0)[0];
+      const int64_t end = ow == 4 ? (int64_t)((const int32_t *)o0)[nrows] : ((const int64_t *)o0)[nrows];
+      if (end < first) return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets decrease", i);
+      sg.data_first = first;
+      sg.data_len = end - first;
+      sg.values = to_arena(o0, (size_t)(nrows + 1) * ow);
+      sg.data = (sg.data_len > 0 && c.data) ? (const uint8_t *)to_arena(c.data + first, (size_t)sg.data_len) : nullptr;
+      cc.data_bytes += sg.data_len;
+    } else if (c.values) {
+      const size_t ew = is_numeric32(c.type) ? 4 : 8;
+      const uint8_t *v0 = (const uint8_t *)c.values + (size_t)c.offset * ew;
+      sg.values = host ? to_arena(v0, (size_t)nrows * ew) : (const void *)v0;
+    }
+    cc.segs.push_back(sg);
+  }
+  co.rows += nrows;
+  co.batches += 1;
+  co.coalesced_batches += 1;
+  st->batches++;
+  *taken = true;
+  if (co.rows >= (co.flush_rows > 0 ? co.flush_rows : kCoalesceFlushRows) || co.batches >= kCoalesceFlushBatches)
+    return coalesce_flush(st, err);
+  return TGX_OK;
+}
+
+// Region set `set` is about to be overwritten: views retained into it (a sampled-range key set keeps its batches for
+// a later repair) are dropped when the counters snapshot taken after the flush that filled it shows nothing to repair;
+// otherwise the repair runs now.
+static tgx_status coalesce_release_set(tgx_state *st, int set, tgx_error *err) {
+  Coalescer &co = st->coalesce;
+  bool any = false;
+  for (auto &ds : st->distinct)
+    for (size_t k = 0; k < ds.retained.size(); k++) any |= ds.retained.region_set[k] == set;
+  if (!any) {
+    co.snap_pending[set] = false;
+    return TGX_OK;
+  }
+  bool repair = !co.snap_pending[set];
+  if (co.snap_pending[set]) {
+    HIP_TRY(hipEventSynchronize(co.snap_event[set]));  // (recorded two flushes ago)
+    co.snap_pending[set] = false;
+    const unsigned long long *snap = (const unsigned long long *)co.snap_host[set];
+    for (size_t q = 0; q < st->distinct.size(); q++) {
+      DistinctState &ds = st->distinct[q];
+      bool tagged = false;
+      for (size_t k = 0; k < ds.retained.size(); k++) tagged |= ds.retained.region_set[k] == set;
+      if (!tagged) continue;
+      if (snap[q * kNumDistinctCounters + kCntOutOfRange] != 0) {
+        repair = true;
+        continue;
+      }
+      // nothing outside the bitmap / no overflowed list as of the end of that flush: its batches hold nothing to repair
+      size_t w = 0;
+      for (size_t k = 0; k < ds.retained.size(); k++)
+        if (ds.retained.region_set[k] != set) {
+          ds.retained.cols[w] = ds.retained.cols[k];
+          ds.retained.region_set[w++] = ds.retained.region_set[k];
+        }
+      ds.retained.cols.resize(w);
+      ds.retained.region_set.resize(w);
+    }
+  }
+  if (repair) TGX_TRY(distinct_resolve_all(st, err));
+  return TGX_OK;
+}
+
+tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
+  Coalescer &co = st->coalesce;
+  if (co.rows == 0 || co.flushing) return TGX_OK;
+  const tgx_plan *plan = st->plan;
+  TGX_TRY(state_init_device(st, err));
+  struct Guard {
+    Coalescer &c;
+    ~Guard() { c.flushing = false; }
+  } guard{co};
+  co.flushing = true;
+  const int set = co.set_cur, ar = co.arena_cur;
+  const int64_t rows = co.rows;
+  TGX_TRY(coalesce_release_set(st, set, err));
+  // the segment table: pinned, one turn per arena
+  size_t n_segs = 0;
+  for (int i = 0; i < plan->n_columns_needed; i++)
+    if (plan->used[i]) n_segs += co.cols[i].segs.size();
+  if (!co.arena_event[ar]) HIP_TRY(hipEventCreateWithFlags(&co.arena_event[ar], hipEventDisableTiming));
+  if (co.arena_busy[ar]) {  // (DEVICE-only batches never went through coalesce_arena_ready)
+    HIP_TRY(hipEventSynchronize(co.arena_event[ar]));
+    co.arena_busy[ar] = false;
+  }
+  if (co.desc_cap[ar] < n_segs * sizeof(GatherSeg)) {
+    if (co.desc_host[ar]) (void)hipHostFree(co.desc_host[ar]);
+    co.desc_host[ar] = nullptr;
+    co.desc_cap[ar] = 0;
+    const size_t want = std::max<size_t>(2 * n_segs * sizeof(GatherSeg), 64u << 10);
+    HIP_TRY(hipHostMalloc(&co.desc_host[ar], want, hipHostMallocDefault));
+    co.desc_cap[ar] = want;
+  }
+  HIP_TRY(co.desc_dev[ar].reserve(co.desc_cap[ar]));
+  GatherSeg *gs = (GatherSeg *)co.desc_host[ar];
+  size_t g = 0;
+  std::vector<tgx_column> views(plan->n_columns_needed);
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    tgx_column &v = views[i];
+    memset(&v, 0, sizeof(v));
+    if (!plan->used[i]) continue;
+    CoalesceColumn &cc = co.cols[i];
+    const bool str = is_string(cc.type);
+    const size_t ew = str ? (cc.type == TGX_UTF8 ? 4 : 8) : (is_numeric32(cc.type) ? 4 : 8);
+    bool has_values = false;
+    for (const CoalesceSegment &sg : cc.segs) has_values |= sg.values != nullptr;
+    if (has_values) HIP_TRY(cc.values[set].reserve((size_t)(rows + 1) * ew + 64));
+    if (cc.any_validity) {
+      const size_t vb = ((size_t)rows + 31) / 32 * 4 + 64;
+      HIP_TRY(cc.validity[set].reserve(vb));
+      HIP_TRY(hipMemsetAsync(cc.validity[set].p, 0, vb, st->stream));
+    }
+    if (str) HIP_TRY(cc.data[set].reserve((size_t)cc.data_bytes + 64));
+    int64_t row = 0, data_at = 0;
+    for (const CoalesceSegment &sg : cc.segs) {
+      GatherSeg &d = gs[g++];
+      memset(&d, 0, sizeof(d));
+      d.src_values = sg.values;
+      d.src_validity = sg.validity;
+      d.src_data = sg.data;
+      d.dst_values = has_values ? cc.values[set].p : nullptr;
+      d.dst_validity = cc.any_validity ? cc.validity[set].as<uint8_t>() : nullptr;
+      d.dst_data = str ? cc.data[set].as<uint8_t>() : nullptr;
+      d.src_bit0 = sg.bit0;
+      d.length = sg.length;
+      d.dst_row = row;
+      d.data_first = sg.data_first;
+      d.data_base = data_at;
+      d.data_len = sg.data ? sg.data_len : 0;
+      d.elem_bytes = (int32_t)ew;
+      d.kind = str ? (cc.type == TGX_UTF8 ? 1 : 2) : 0;
+      row += sg.length;
+      data_at += sg.data_len;
+    }
+    v.type = cc.type;
+    v.mem = TGX_MEM_DEVICE;
+    v.length = rows;
+    v.offset = 0;
+    v.null_count = -1;
+    v.validity = cc.any_validity ? cc.validity[set].as<uint8_t>() : nullptr;
+    if (str) {
+      v.offsets = cc.values[set].p;
+      v.data = cc.data[set].as<uint8_t>();
+    } else {
+      v.values = has_values ? cc.values[set].p : nullptr;
+    }
+  }
+  if (co.arena_used)
+    HIP_TRY(hipMemcpyAsync(co.arena_dev[ar].p, co.arena_host[ar], co.arena_used, hipMemcpyHostToDevice, st->stream));
+  HIP_TRY(hipMemcpyAsync(co.desc_dev[ar].p, gs, g * sizeof(GatherSeg), hipMemcpyHostToDevice, st->stream));
+  {
+    ProfScope ps(st, "gather", 0);
+    launch_gather_segments(co.desc_dev[ar].as<GatherSeg>(), (int)g, st->stream);
+  }
+  // the arena and the table are free again once the gather has run
+  HIP_TRY(hipEventRecord(co.arena_event[ar], st->stream));
+  co.arena_busy[ar] = true;
+  co.arena_cur ^= 1;
+  co.arena_used = 0;
+  // the pending list is empty from here on (update_impl may come back to tgx::coalesce_flush through a resolve)
+  for (auto &cc : co.cols) {
+    cc.segs.clear();
+    cc.any_validity = false;
+    cc.data_bytes = 0;
+  }
+  const int64_t batches_of_flush = (int64_t)co.batches;
+  co.rows = 0;
+  co.batches = 0;
+  co.set_cur ^= 1;
+  co.flushes++;
+  std::vector<size_t> kept_before(st->distinct.size());
+  for (size_t q = 0; q < st->distinct.size(); q++) kept_before[q] = st->distinct[q].retained.size();
+  st->batches -= batches_of_flush;  // update_impl counts the flush as one batch: keep the caller's count
+  tgx_status rc = update_impl(plan, st, views.data(), rows, err);
+  st->batches += batches_of_flush - 1;
+  if (rc != TGX_OK) return rc;
+  // views the key sets kept of this flush point into region set `set`
+  for (size_t q = 0; q < st->distinct.size(); q++) {
+    DistinctState::Retained &r = st->distinct[q].retained;
+    for (size_t k = std::min(kept_before[q], r.size()); k < r.size(); k++) r.region_set[k] = (int8_t)set;
+  }
+  bool any_kept = false;
+  for (auto &ds : st->distinct) any_kept |= !ds.retained.empty();
+  if (any_kept && st->d_distinct_counters.p) {
+    const size_t bytes = st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long);
+    if (co.snap_cap[set] < bytes) {
+      if (co.snap_host[set]) (void)hipHostFree(co.snap_host[set]);
+      co.snap_host[set] = nullptr;
+      HIP_TRY(hipHostMalloc(&co.snap_host[set], bytes + 256, hipHostMallocDefault));
+      co.snap_cap[set] = bytes + 256;
+    }
+    if (!co.snap_event[set]) HIP_TRY(hipEventCreateWithFlags(&co.snap_event[set], hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(co.snap_host[set], st->d_distinct_counters.p, bytes, hipMemcpyDeviceToHost, st->stream));
+    HIP_TRY(hipEventRecord(co.snap_event[set], st->stream));
+    co.snap_pending[set] = true;
+  }
+  return TGX_OK;
+}
+
+static void coalesce_drop(tgx_state *st) {  // reset / destroy: pending batches are forgotten
+  Coalescer &co = st->coalesce;
+  for (auto &cc : co.cols) {
+    cc.segs.clear();
+    cc.any_validity = false;
+    cc.data_bytes = 0;
+  }
+  co.rows = 0;
+  co.batches = 0;
+  co.arena_used = 0;
+  co.snap_pending[0] = co.snap_pending[1] = false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2126,6 +2535,7 @@ static tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t,
 
 static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   const tgx_plan *plan = st->plan;
+  TGX_TRY(coalesce_flush(st, err));  // batches tgx_update has only noted so far
   g->scan = st->h_scan;
   g->count = st->h_count;
   g->como = st->h_como;
@@ -2331,6 +2741,7 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
 // distinct: export / import / merge
 tgx_status tgx::distinct_export_impl(tgx_state *st, size_t slot, uint32_t world,
                                        const void **device_records, uint64_t *counts, tgx_error *err) {
+  TGX_TRY(coalesce_flush(st, err));
   DistinctState &ds = st->distinct[slot];
   const bool mult = st->plan->distinct[slot].multiplicity;
   TGX_TRY(state_init_device(st, err));
@@ -2444,6 +2855,7 @@ extern "C" tgx_status tgx_distinct_import(const tgx_plan *plan, tgx_state *st, s
   if (spec_index >= plan->specs.size() || plan->specs[spec_index].kind != TGX_CHECK_DISTINCT)
     return fail(err, TGX_INVALID_ARGUMENT, "spec %zu is not a DISTINCT check", spec_index);
   TGX_TRY(need_device(err));
+  TGX_TRY(coalesce_flush(st, err));
   const size_t slot = plan->bind[spec_index].slot;
   DistinctState &ds = st->distinct[slot];
   TGX_TRY(state_init_device(st, err));
@@ -2485,6 +2897,7 @@ extern "C" tgx_status tgx_distinct_range_hint(const tgx_plan *plan, tgx_state *s
                                               int64_t hi, tgx_error *err) try {
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
+  TGX_TRY(coalesce_flush(st, err));
   DistinctState &ds = st->distinct[slot];
   if (ds.mode != DistinctMode::kUndecided)
     return fail(err, TGX_INVALID_ARGUMENT, "range hint must be given before the first batch (after tgx_state_reset)");
@@ -2503,6 +2916,7 @@ extern "C" tgx_status tgx_distinct_bitmap_view(const tgx_plan *plan, tgx_state *
   bind_thread();
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
+  TGX_TRY(coalesce_flush(st, err));
   TGX_TRY(distinct_resolve(st, slot, err));
   DistinctState &ds = st->distinct[slot];
   if (ds.mode != DistinctMode::kBitmap)
@@ -2525,6 +2939,7 @@ extern "C" tgx_status tgx_distinct_adopt_slices(const tgx_plan *plan, tgx_state 
   size_t slot = 0;
   TGX_TRY(distinct_slot_of(plan, st, spec_index, &slot, err));
   TGX_TRY(need_device(err));
+  TGX_TRY(coalesce_flush(st, err));
   TGX_TRY(state_init_device(st, err));
   DistinctState &ds = st->distinct[slot];
   const bool mult = plan->distinct[slot].multiplicity;
@@ -2564,6 +2979,7 @@ extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state 
                                 tgx_error *err) try {
   bind_thread();
   if (!plan || !dst || dst->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "dst does not belong to plan");
+  TGX_TRY(coalesce_flush(dst, err));
   for (size_t i = 0; i < n_srcs; i++) {
     tgx_state *src = srcs ? srcs[i] : nullptr;
     if (!src || src->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "src %zu does not belong to plan", i);

@@ -1,0 +1,240 @@
+"""-m gpu: library-side coalescing of small batches (tgx_api.cpp "coalescing", kernels/gather.hip).  DataFusion hands a
+drop-in 8192-row RecordBatches (TG/core/context.rs:28-38); tgx_update only notes them and a flush runs the pending
+ones as ONE batch.  Whatever the batching, the results must be those of the table: integers / counts / key sets /
+pattern hits bit-exact against the oracle and against the same table fed as one batch with coalescing off, float
+aggregates to 1e-12 (the association of a compensated sum moves its last digits, nothing else)."""
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+import term_amd as T
+from _lib_spec import spec
+from gpu_util import numeric_column, pad_validity, rel_err, to_device
+from test_gpu_parity import check_stats
+
+pytestmark = pytest.mark.gpu
+
+
+def ragged_cuts(n, rng, sizes=(8192, 8192, 1000, 7, 65536, 8192, 64, 1, 4099)):
+    cuts, at, k = [0], 0, 0
+    while at < n:
+        at = min(n, at + sizes[k % len(sizes)])
+        cuts.append(at)
+        k += 1
+    return cuts
+
+
+def feed(plan, cols_np, cuts, device, env=None, monkeypatch=None):
+    if monkeypatch is not None:
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+    st = T.State(plan)
+    if monkeypatch is not None:
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        st.update([numeric_column(v, m, device, offset=a, length=b - a) for v, m in cols_np])
+    return st
+
+
+def exact_key(r):
+    return (r.kind, r.total, r.non_null, r.has_value, r.min_i, r.max_i, r.sum_i, r.distinct, r.groups_once, r.matches,
+            r.kll_n, r.min_f, r.max_f)
+
+
+def compare(got, want):
+    assert [exact_key(r) for r in got] == [exact_key(r) for r in want]
+    for g, w in zip(got, want):
+        for f in ("sum_f", "mean", "var_samp", "sum_x", "sum_y", "sum_x2", "sum_y2", "sum_xy", "co_c_xy", "co_m2_x"):
+            a, b = getattr(g, f), getattr(w, f)
+            assert (np.isnan(a) and np.isnan(b)) or rel_err(a, b) <= 1e-12, (f, a, b)
+
+
+@pytest.mark.parametrize("device", [True, False])
+@pytest.mark.parametrize("flush_rows", [None, "20000"])  # one flush at finalize / a flush every few batches
+def test_numeric_suite_equals_one_batch(device, flush_rows, monkeypatch):
+    rng = np.random.default_rng(7)
+    n = 300_000 + 37
+    ids = rng.permutation(n).astype(np.int64)
+    keys = rng.integers(0, n // 10, size=n, dtype=np.int64)
+    sparse = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    sparse[: n // 3] = sparse[n // 3: 2 * (n // 3)]
+    f1 = rng.standard_normal(n) * 1e3
+    f2 = 0.25 * f1 + rng.standard_normal(n)
+    f2[rng.random(n) < 0.001] = -0.0
+    masks = [None, rng.random(n) >= 0.05, rng.random(n) >= 0.5, rng.random(n) >= 0.05, None]
+    cols_np = [(v, None if m is None else orc.pack_validity(m)) for v, m in zip([ids, keys, sparse, f1, f2], masks)]
+    specs = []
+    for ci in range(5):
+        specs += [spec(T.COUNT, ci), spec(T.NUMERIC_STATS, ci, flags=T.FLAG_VARIANCE if ci == 3 else 0)]
+    specs += [spec(T.DISTINCT, 0), spec(T.DISTINCT, 1, flags=T.FLAG_MULTIPLICITY), spec(T.DISTINCT, 2, flags=T.FLAG_MULTIPLICITY),
+              spec(T.DISTINCT, 4), spec(T.COMOMENTS, 3, column2=4), spec(T.KLL, 3, kll_k=200)]
+    T.init()
+    plan = T.Plan(specs)
+    whole = feed(plan, cols_np, [0, n], True, {"TGX_COALESCE": "0"}, monkeypatch)
+    want = whole.finalize()
+    assert whole.profile_get("coalesce")["launches"] == 0
+    env = {} if flush_rows is None else {"TGX_COALESCE_FLUSH_ROWS": flush_rows}
+    st = feed(plan, cols_np, ragged_cuts(n, rng), device, env, monkeypatch)
+    got = st.finalize()
+    stats = st.profile_get("coalesce")
+    assert stats["launches"] >= (1 if flush_rows is None else 5) and stats["bytes"] >= 20  # flushes, batches coalesced
+    compare(got, want)
+    # and against the oracle
+    for ci, (v, b) in enumerate(cols_np):
+        c = orc.count(b, n)
+        assert (got[2 * ci].total, got[2 * ci].non_null) == (c.total, c.non_null)
+        check_stats(got[2 * ci + 1], orc.stats(v, b), variance=ci == 3)
+    for k, ci in ((10, 0), (11, 1), (12, 2), (13, 4)):
+        v, b = cols_np[ci]
+        d = orc.distinct_bits64(v.view(np.uint64), b, n=n)
+        assert (got[k].distinct, got[k].non_null) == (d.distinct, d.non_null)
+        if specs[k].flags & T.FLAG_MULTIPLICITY:
+            assert got[k].groups_once == d.groups_once
+    assert got[15].kll_n == int(masks[3].sum())
+    # quantiles of a sketch built from flushes stay inside the stated rank error
+    vals = np.sort(f1[masks[3]])
+    for phi in (0.05, 0.5, 0.95):
+        q = st.kll_quantile(15, phi)
+        assert abs(np.searchsorted(vals, q) / len(vals) - phi) < 1.65 / np.sqrt(200)
+
+
+@pytest.mark.parametrize("device", [True, False])
+def test_growing_ids_are_repaired_across_flushes(device, monkeypatch):
+    """a sampled-range key set keeps views of its batches -- here views into the coalescing regions, which take turns:
+    ids that grow past the first flush's range arrive many flushes later and must still be counted exactly"""
+    n = 400_000
+    ids = np.arange(n, dtype=np.int64) * 3
+    ids[n // 2:] += 10_000_000            # far outside the range the first flush's sample laid out
+    rng = np.random.default_rng(1)
+    ids[rng.random(n) < 0.01] = 5          # repeats everywhere
+    cols_np = [(ids, None)]
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.NUMERIC_STATS, 0)])
+    st = feed(plan, cols_np, list(range(0, n, 8192)) + [n], device, {"TGX_COALESCE_FLUSH_ROWS": "70000"}, monkeypatch)
+    res = st.finalize()
+    assert st.profile_get("coalesce")["launches"] >= 5
+    d = orc.distinct_bits64(ids.view(np.uint64), None, n=n)
+    assert (res[0].total, res[0].distinct, res[0].groups_once) == (d.total, d.distinct, d.groups_once)
+    assert (res[1].min_i, res[1].max_i, res[1].sum_i) == (int(ids.min()), int(ids.max()), int(ids.sum()))
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_host_string_batches(large, monkeypatch):
+    """Utf8 / LargeUtf8 HOST batches (what DataFusion streams): offsets re-based, bytes concatenated; the pattern,
+    length and DISTINCT checks of the coalesced column equal those of the table"""
+    import pyarrow as pa
+
+    rng = np.random.default_rng(3)
+    n = 120_000
+    vals = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.02:
+            vals.append(None)
+        elif r < 0.8:
+            vals.append("user%d@example%d.com" % (i % 50_000, i % 1000))
+        elif r < 0.9:
+            vals.append("")
+        else:
+            vals.append("not an e-mail é中 %d" % (i % 97))
+    arr = pa.array(vals, type=pa.large_string() if large else pa.string())
+    specs = [spec(T.REGEX_MATCH, 0, pattern=r"^[^@]+@[^@]+\.[^@]+$", flags=T.FLAG_NULL_IS_VALID),
+             spec(T.REGEX_MATCH, 0, pattern="@"), spec(T.LENGTH, 0, length_min=1, length_max=24),
+             spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.COUNT, 0)]
+    T.init()
+    plan = T.Plan(specs)
+
+    def column(a, lo, hi):
+        sl = a.slice(lo, hi - lo)  # a sliced array: Arrow offset != 0, shared buffers
+        bufs = sl.buffers()
+        validity = None if bufs[0] is None else np.frombuffer(bufs[0], dtype=np.uint8)
+        offsets = np.frombuffer(bufs[1], dtype=np.int64 if large else np.int32)
+        data = np.frombuffer(bufs[2], dtype=np.uint8) if bufs[2] is not None else np.zeros(1, np.uint8)
+        ctor = T.Column.large_utf8 if large else T.Column.utf8
+        return ctor(offsets, data, pad_validity(validity) if validity is not None else None, length=len(sl), offset=sl.offset)
+
+    monkeypatch.setenv("TGX_COALESCE", "0")
+    whole = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE")
+    whole.update([column(arr, 0, n)])
+    want = whole.finalize()
+    monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", "30000")
+    st = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS")
+    cuts = ragged_cuts(n, rng, sizes=(8192, 1000, 3, 8192, 1, 5000))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        st.update([column(arr, a, b)])
+    got = st.finalize()
+    assert st.profile_get("coalesce")["launches"] >= 3
+    compare(got, want)
+    import re
+
+    pat = re.compile(r"^[^@]+@[^@]+\.[^@]+\Z")
+    assert got[0].matches == sum(1 for v in vals if v is None or pat.search(v))
+    assert got[1].matches == sum(1 for v in vals if v is not None and "@" in v)
+    assert got[2].matches == sum(1 for v in vals if v is None or 1 <= len(v) <= 24)
+    assert got[3].distinct == len({v for v in vals if v is not None})
+    assert (got[4].total, got[4].non_null) == (n, sum(v is not None for v in vals))
+
+
+def test_int32_float32_and_count_only_columns(monkeypatch):
+    from test_gpu_numeric32 import col32
+
+    rng = np.random.default_rng(9)
+    n = 150_000
+    i32 = rng.integers(0, 40_000, size=n, dtype=np.int64).astype(np.int32)
+    f32 = (rng.standard_normal(n) * 100).astype(np.float32)
+    mask = rng.random(n) >= 0.1
+    vb = orc.pack_validity(mask)
+    specs = [spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY),
+             spec(T.NUMERIC_STATS, 1, flags=T.FLAG_VARIANCE), spec(T.COUNT, 2)]
+    T.init()
+    plan = T.Plan(specs)
+    for device in (True, False):
+        monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", "50000")
+        st = T.State(plan)
+        monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS")
+        cuts = ragged_cuts(n, rng)
+        vpad = pad_validity(vb)
+        vdev = to_device(vpad) if device else vpad
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            # column 2 is validity-only (COUNT): no values buffer at all
+            count_only = T.Column.int64(None, vdev, length=b - a, offset=a)
+            st.update([col32(i32, vb, device, offset=a, length=b - a), col32(f32, None, device, offset=a, length=b - a),
+                       count_only])
+        res = st.finalize()
+        assert st.profile_get("coalesce")["launches"] >= 2
+        wide = i32.astype(np.int64)
+        c = orc.count(vb, n)
+        assert (res[0].total, res[0].non_null) == (c.total, c.non_null) == (res[4].total, res[4].non_null)
+        check_stats(res[1], orc.stats(wide, vb))
+        d = orc.distinct_bits64(wide.view(np.uint64), vb, n=n)
+        assert (res[2].distinct, res[2].groups_once) == (d.distinct, d.groups_once)
+        check_stats(res[3], orc.stats(f32.astype(np.float64), None), variance=True)
+
+
+def test_pending_batches_are_seen_by_every_reader():
+    """merge, serialize, sync and reset with batches still pending"""
+    rng = np.random.default_rng(4)
+    n = 50_000
+    v = rng.integers(0, 1000, size=n, dtype=np.int64)
+    specs = [spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 0)]
+    T.init()
+    plan = T.Plan(specs)
+    a, b = T.State(plan), T.State(plan)
+    a.update([numeric_column(v, None, True, length=8192)])
+    b.update([numeric_column(v, None, False, offset=8192, length=n - 8192)])
+    blob = b.serialize()                       # flushes b
+    a.merge([T.State.deserialize(plan, blob)])  # flushes a first
+    r = a.finalize()
+    assert (r[0].total, r[0].sum_i, r[1].distinct) == (n, int(v.sum()), len(np.unique(v)))
+    c = T.State(plan)
+    c.update([numeric_column(v, None, True, length=100)])
+    c.reset()                                  # pending batches are dropped with the rest
+    c.update([numeric_column(v, None, True, offset=100, length=50)])
+    c.sync()
+    r = c.finalize()
+    assert (r[0].total, r[0].sum_i) == (50, int(v[100:150].sum()))
+    e = T.State(plan)
+    assert e.finalize()[0].total == 0

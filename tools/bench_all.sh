@@ -14,5 +14,6 @@ run python tools/bench_distinct.py --rows 100000000 --steps 3 --sparse-rows 1000
 run python tools/bench_kll.py
 run python tools/bench_numeric32.py                   # Int32 / Float32 columns next to Int64 / Float64
 run python tools/bench_spearman.py --ranks 8       # + the distributed ranking over 8 threaded ranks on this one GPU
-run python tools/bench_batches.py                     # per-update cost of small batches (device / host buffers)
+run build/feed_batches                                # 8192-row batches through the C ABI from plain C (make -C tools): the coalescing rates
+run python tools/bench_batches.py                     # the same through the Python binding (a ctypes call costs 2-4 us)
 run python tools/bench_host_batches.py                # PCIe-inclusive rate
