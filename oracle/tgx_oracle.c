@@ -162,6 +162,72 @@ int orc_distinct_bits64(const uint64_t *bits, const uint8_t *validity, int64_t o
   return 0;
 }
 
+/* TG/constraints/approx_count_distinct.rs:56-66 `APPROX_DISTINCT(col)`: a HyperLogLog sketch.  DataFusion's
+ * (datafusion-functions-aggregate 50.3.0, src/hyperloglog.rs -- absent from /root/reference, a Cargo.lock dependency)
+ * has 2^14 one-byte registers over ahash values; its `count()` is Ertl's improved estimator ("New cardinality
+ * estimation algorithms for HyperLogLog sketches", 2017, algorithm 6).  The hash is third-party and seeded inside the
+ * crate; the product's lane mixes a value's 64 bits with the bijection restated here (index = low 14 bits of `a`, rank =
+ * leading zeros of `b` + 1, 1..33), so the REGISTERS are a pure function of the set of values: the device must
+ * reproduce them byte for byte, and the estimate with them.  NULL rows are skipped (:229-255). */
+#define ORC_HLL_REGISTERS 16384
+static uint32_t orc_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+void orc_hll_registers(const uint64_t *bits, const uint8_t *validity, int64_t offset, int64_t n, uint8_t *registers) {
+  for (int64_t i = 0; i < n; i++) {
+    if (!bit_is_set(validity, offset + i)) continue;
+    const uint64_t v = bits[offset + i];
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    uint32_t a = lo ^ orc_rotl32(hi * 0x9E3779B1u, 15);
+    a ^= a >> 16;
+    a *= 0x85EBCA6Bu;
+    a ^= a >> 13;
+    a *= 0xC2B2AE35u;
+    a ^= a >> 16;
+    uint32_t b = (hi ^ orc_rotl32(a, 16)) * 0x27D4EB2Fu;
+    b ^= b >> 15;
+    uint32_t rank = 1;
+    while (rank <= 32 && !(b & 0x80000000u)) {
+      b <<= 1;
+      rank++;
+    }
+    uint8_t *r = &registers[a & (ORC_HLL_REGISTERS - 1)];
+    if (*r < rank) *r = (uint8_t)rank;
+  }
+}
+static double orc_hll_sigma(double x) {
+  if (x == 1.0) return INFINITY;
+  double y = 1.0, z = x;
+  for (;;) {
+    x *= x;
+    double z0 = z;
+    z += x * y;
+    y += y;
+    if (z0 == z) return z;
+  }
+}
+static double orc_hll_tau(double x) {
+  if (x == 0.0 || x == 1.0) return 0.0;
+  double y = 1.0, z = 1.0 - x;
+  for (;;) {
+    x = sqrt(x);
+    double z0 = z;
+    y *= 0.5;
+    z -= (1.0 - x) * (1.0 - x) * y;
+    if (z0 == z) return z / 3.0;
+  }
+}
+/* q = 32: ranks 0 .. 33 (DataFusion: q = 50 with a 64-bit hash; the formula is the same) */
+uint64_t orc_hll_estimate(const uint8_t *registers) {
+  enum { Q = 32 };
+  double hist[Q + 2] = {0};
+  for (int i = 0; i < ORC_HLL_REGISTERS; i++) hist[registers[i] > Q + 1 ? Q + 1 : registers[i]] += 1.0;
+  const double m = (double)ORC_HLL_REGISTERS;
+  double z = m * orc_hll_tau((m - hist[Q + 1]) / m);
+  for (int k = Q; k >= 1; k--) z = 0.5 * (z + hist[k]);
+  z += m * orc_hll_sigma(hist[0] / m);
+  const double e = 0.5 / log(2.0) * m * m / z;
+  return isfinite(e) ? (uint64_t)llround(e) : 0;
+}
+
 typedef struct {
   const uint8_t *p;
   int32_t len;

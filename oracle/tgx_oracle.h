@@ -144,6 +144,10 @@ uint64_t orc_kll_level_capacity(uint64_t k, uint64_t level);
 uint64_t orc_siphash(int c_rounds, int d_rounds, uint64_t k0, uint64_t k1, const uint8_t *msg,
                      size_t len);
 
+/* ---- APPROX_DISTINCT (TG/constraints/approx_count_distinct.rs:56-66): HyperLogLog, 2^14 one-byte registers ---- */
+void orc_hll_registers(const uint64_t *bits, const uint8_t *validity, int64_t offset, int64_t n, uint8_t *registers);
+uint64_t orc_hll_estimate(const uint8_t *registers);
+
 /* ---- K7: pattern checks (TG/constraints/format.rs:750-776) ---- */
 typedef struct orc_regex orc_regex;
 /* compile with Rust-regex syntax; case_insensitive = the SQL `~*` operator.

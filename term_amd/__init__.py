@@ -24,6 +24,8 @@ from ._lib import (  # noqa: F401
     COMOMENTS,
     SPEARMAN,
     LENGTH,
+    APPROX_DISTINCT,
+    OPT_NO_COALESCE,
     FLAG_EXACT_RANK_SUMS,
     FLAG_VARIANCE,
     FLAG_MULTIPLICITY,

@@ -8,6 +8,7 @@ _ROOT = os.path.dirname(_HERE)
 
 # enums of include/tgx.h
 COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 1, 2, 3, 4, 5, 6, 7, 8
+APPROX_DISTINCT = 9
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
 ABI_VERSION = 4  # include/tgx.h TGX_ABI_VERSION: the struct layouts below

@@ -184,13 +184,14 @@ class DistinctnessAnalyzer : public ColumnAnalyzer {  // basic/distinctness.rs
 };
 
 // advanced/approx_count_distinct.rs: APPROX_DISTINCT(col) (DataFusion's HyperLogLog, a third-party estimate whose
-// value is unpinned by the reference's tests) and COUNT(col).  The device path counts EXACTLY (kernels/distinct*.hip),
-// which is the value the estimate approximates; state fields, the max-merge and the metric type are the reference's.
+// value is unpinned by the reference's tests) and COUNT(col).  The device path keeps a HyperLogLog of the same shape on
+// the column's scan (TGX_CHECK_APPROX_DISTINCT; the exact count on string columns); state fields, the max-merge and the
+// metric type are the reference's.
 class ApproxCountDistinctAnalyzer : public ColumnAnalyzer {
  public:
   using ColumnAnalyzer::ColumnAnalyzer;
   std::string name() const override { return "approx_count_distinct"; }
-  std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_DISTINCT, column_)}; }
+  std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_APPROX_DISTINCT, column_)}; }
   json::Value state_from_results(const std::vector<const tgx_result *> &r, const std::vector<int> &) const override {
     return jobj({{"approx_distinct_count", jnum((double)r[0]->distinct)}, {"total_count", jnum((double)r[0]->non_null)}});
   }

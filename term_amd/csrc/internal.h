@@ -49,6 +49,7 @@ void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t
 void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,
                        ScanPartial *d_partials, void *d_como_partials, const ComomentAcc *d_como_accs,
                        hipStream_t stream);
+void launch_scan_hll(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials, hipStream_t stream);
 void launch_como_pivot(const ComomentLaunch &L, int n_pairs, ComomentAcc *d_accs, hipStream_t stream);
 void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, const void *d_partials,
                              ComomentAcc *d_accs, hipStream_t stream);
@@ -155,6 +156,7 @@ void launch_bitmap_export_scatter(const BitmapView &bm, uint32_t world, int want
 struct ScanTask {
   int column;
   bool variance;
+  bool stats_needed = false;  // a NUMERIC_STATS spec or a key set's range reads its MIN / MAX / SUM (else COUNT only)
 };
 struct CountTask {
   int column;
@@ -164,6 +166,17 @@ struct DistinctTask {
   bool multiplicity;
   int scan_slot;  // scan task that provides MIN/MAX for the bitmap decision
   std::vector<int> tuple;  // >= 2 columns: COUNT(DISTINCT (a, b, ...)); `column` is then tuple[0]
+  // only APPROX_DISTINCT specs point here: the task runs for the column kinds the HyperLogLog lane does not take
+  // (strings, dictionaries) and stays idle on numeric columns
+  bool approx_only = false;
+};
+// APPROX_DISTINCT: the HyperLogLog lane of the numeric scan (kernels/scan.hip, scan_hll_kernel).  When the plan also
+// holds an exact DISTINCT check of the column -- or the column turns out to be a string column -- the exact key set
+// answers instead (`distinct_slot`).
+struct HllTask {
+  int column;
+  int scan_slot;
+  int distinct_slot;
 };
 struct ComomentTask {
   int col_x, col_y;
@@ -192,6 +205,7 @@ struct tgx_plan {
   std::vector<tgx::DistinctTask> distinct;
   std::vector<tgx::ComomentTask> como;
   std::vector<tgx::KllTask> kll;
+  std::vector<tgx::HllTask> hll;
   int n_columns_needed = 0;  // 1 + max column index
   // per plan column, fixed at tgx_plan_create (tgx_update runs once per 8192-row batch: nothing is allocated there)
   std::vector<char> used, reads_values, needs_wide;
@@ -450,6 +464,12 @@ struct tgx_state {
   std::vector<tgx::ComomentAcc> h_como;
   std::vector<tgx::DistinctState> distinct;
   std::vector<tgx::KllHost> h_kll;
+  // HyperLogLog tasks: running registers on the device ([task][kHllRegisters] bytes), the per-launch rows of the
+  // workgroups, and what was merged in on the host (byte-wise max); which side answers each task: 0 undecided,
+  // 1 the registers, 2 the exact key set of `distinct_slot`
+  tgx::DevBuf d_hll, d_hll_rows;
+  std::vector<std::vector<uint8_t>> h_hll;
+  std::vector<int> hll_mode;
   void *kll = nullptr;    // tgx::KllDeviceState (kll_device.cpp)
   void *regex = nullptr;  // tgx::RegexState (regex_device.cpp)
   void *spearman = nullptr;  // tgx::SpearmanState (spearman_device.cpp)

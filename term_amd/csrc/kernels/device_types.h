@@ -24,9 +24,32 @@ struct ScanColDesc {
   int32_t want_variance;
   const double *pivot;      // device scalar: shift for the variance lanes (may be nullptr)
   int32_t elem32;           // 1: `values` holds 4-byte elements (Int32 / Float32), widened as they are loaded
-  int32_t pad32;
+  int32_t skip_stats;       // scan_hll_kernel: nobody asked for MIN / MAX / SUM of this column -- COUNT and registers only
   ScanKll kll;              // kll.picks != nullptr: the column's KLL sampler rides on this scan (kll_types.h)
+  uint8_t *hll;             // scan_hll_kernel: [workgroup][kHllRegisters] register bytes of this launch (else nullptr)
+  uint8_t *hll_regs;        // ... and the task's running registers the launch is folded into (hll_reduce_kernel)
 };
+
+// HyperLogLog lane of the scan (APPROX_DISTINCT, TG/constraints/approx_count_distinct.rs:56-66): 2^14 registers like
+// DataFusion's sketch (datafusion-functions-aggregate 50.3.0, hyperloglog.rs: HLL_P = 14).  A value's 64 bits are
+// mixed by a bijection into (a, b): register = low 14 bits of a, rank = leading zeros of b + 1 (1 .. 33).
+constexpr int kHllBits = 14;
+constexpr int kHllRegisters = 1 << kHllBits;
+constexpr int kHllMaxRank = 33;
+__host__ __device__ inline uint32_t hll_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ inline void hll_hash(uint64_t bits, uint32_t *a_out, uint32_t *b_out) {
+  const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+  uint32_t a = lo ^ hll_rotl32(hi * 0x9E3779B1u, 15);
+  a ^= a >> 16;  // Murmur3's 32-bit finaliser
+  a *= 0x85EBCA6Bu;
+  a ^= a >> 13;
+  a *= 0xC2B2AE35u;
+  a ^= a >> 16;
+  uint32_t b = (hi ^ hll_rotl32(a, 16)) * 0x27D4EB2Fu;
+  b ^= b >> 15;
+  *a_out = a;
+  *b_out = b;
+}
 
 // Per (column, block) partial written by scan_kernel; reduced in fixed order by scan_reduce_kernel.
 struct ScanPartial {

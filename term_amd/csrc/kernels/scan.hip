@@ -61,6 +61,29 @@ __device__ __forceinline__ void two_sum_add(double &s, double &c, double x) {
   c += e;
 }
 
+// ---------------------------------------------------------------------------------------------
+// HyperLogLog lane (scan_hll_kernel): the workgroup's 2^14 one-byte registers live in 16 KiB of LDS.  A register only
+// ever grows, and after the first few thousand values of a workgroup almost no value raises its register any more: a
+// value READS its register (ds_read_u8) and only a value that would raise it enters the compare-and-swap on the word
+// that holds it -- LDS has no byte atomics, and a 32-bit max over packed bytes is not a byte-wise max.
+__device__ __forceinline__ void hll_update(uint32_t *regs, int64_t bits, bool valid) {
+  uint32_t a, b;
+  hll_hash((uint64_t)bits, &a, &b);
+  const uint32_t idx = a & (uint32_t)(kHllRegisters - 1);
+  const uint32_t rho = (uint32_t)__builtin_clz(b | 1u) + (b ? 1u : 2u);  // clz(b) + 1; b == 0 -> 33
+  const uint32_t sh = (idx & 3u) * 8u;
+  uint32_t *word = regs + (idx >> 2);
+  if (valid && ((const uint8_t *)regs)[idx] < rho) {
+    uint32_t old = *word;
+    while (((old >> sh) & 0xFFu) < rho) {
+      const uint32_t want = (old & ~(0xFFu << sh)) | (rho << sh);
+      const uint32_t seen = atomicCAS(word, old, want);
+      if (seen == old) break;
+      old = seen;
+    }
+  }
+}
+
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef const i32x2 __attribute__((address_space(1))) *global_i32x2_ptr;
 typedef const int32_t __attribute__((address_space(1))) *global_i32_ptr;
@@ -120,9 +143,9 @@ __device__ __forceinline__ void acc_pair(LaneAcc &a, i64x2 v, uint32_t two_bits,
 
 // rows [r0, r1) one row per lane per step: ragged head / tail and columns whose buffers are not
 // 16-byte / 64-bit aligned for the tile path.
-template <bool IS_FLOAT, bool VAR>
+template <bool IS_FLOAT, bool VAR, bool HLL = false>
 __device__ void scan_ragged(const ScanColDesc &c, int64_t r0, int64_t r1, int lane, int stride,
-                            LaneAcc &a, double pivot) {
+                            LaneAcc &a, double pivot, uint32_t *hll = nullptr) {
   global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)c.values + c.offset);
   global_i32_ptr vals32 = (global_i32_ptr)(uintptr_t)((const int32_t *)c.values + c.offset);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)c.validity;
@@ -133,8 +156,9 @@ __device__ void scan_ragged(const ScanColDesc &c, int64_t r0, int64_t r1, int la
       valid = (vbits[b >> 3] >> (b & 7)) & 1;
     }
     const int64_t bits = c.elem32 ? widen32<IS_FLOAT>(vals32[i]) : vals[i];
-    acc_value<IS_FLOAT, VAR>(a, bits, valid, pivot);
+    if (!HLL || !c.skip_stats) acc_value<IS_FLOAT, VAR>(a, bits, valid, pivot);
     a.cnt += valid ? 1 : 0;
+    if (HLL) hll_update(hll, bits, valid);
   }
 }
 
@@ -297,11 +321,11 @@ __device__ __forceinline__ i64x2 tile_load32(global_i32x2_ptr p) {
   return r;
 }
 
-template <bool IS_FLOAT, bool VAR, int VARIANT, bool KLL = false>
+template <bool IS_FLOAT, bool VAR, int VARIANT, bool KLL = false, bool HLL = false>
 __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_global,
                                            int64_t n_waves, int lane, LaneAcc &a,
                                            int64_t &tile_count, double pivot, KllLane *K = nullptr,
-                                           double *ring = nullptr, uint32_t wave_slot = 0) {
+                                           double *ring = nullptr, uint32_t wave_slot = 0, uint32_t *hll = nullptr) {
   global_i64x2_ptr vp =
       (global_i64x2_ptr)(uintptr_t)((const int64_t *)c.values + c.offset + c.head);
   global_i32x2_ptr vp32 =
@@ -358,10 +382,22 @@ __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_gl
     }
     const uint32_t b0 = (uint32_t)((upper ? w1 : w0) >> sh) & 3u, b1 = (uint32_t)((upper ? w3 : w2) >> sh) & 3u;
     const uint32_t b2 = (uint32_t)((upper ? w5 : w4) >> sh) & 3u, b3 = (uint32_t)((upper ? w7 : w6) >> sh) & 3u;
-    acc_pair<IS_FLOAT, VAR>(a, v0, b0, pivot);
-    acc_pair<IS_FLOAT, VAR>(a, v1, b1, pivot);
-    acc_pair<IS_FLOAT, VAR>(a, v2, b2, pivot);
-    acc_pair<IS_FLOAT, VAR>(a, v3, b3, pivot);
+    if (!HLL || !c.skip_stats) {  // (uniform)
+      acc_pair<IS_FLOAT, VAR>(a, v0, b0, pivot);
+      acc_pair<IS_FLOAT, VAR>(a, v1, b1, pivot);
+      acc_pair<IS_FLOAT, VAR>(a, v2, b2, pivot);
+      acc_pair<IS_FLOAT, VAR>(a, v3, b3, pivot);
+    }
+    if (HLL) {
+      hll_update(hll, v0.x, (b0 & 1u) != 0);
+      hll_update(hll, v0.y, (b0 & 2u) != 0);
+      hll_update(hll, v1.x, (b1 & 1u) != 0);
+      hll_update(hll, v1.y, (b1 & 2u) != 0);
+      hll_update(hll, v2.x, (b2 & 1u) != 0);
+      hll_update(hll, v2.y, (b2 & 2u) != 0);
+      hll_update(hll, v3.x, (b3 & 1u) != 0);
+      hll_update(hll, v3.y, (b3 & 2u) != 0);
+    }
     if (KLL) {
       kll_push_pair<IS_FLOAT>(*K, ring, v0, b0);
       kll_push_pair<IS_FLOAT>(*K, ring, v1, b1);
@@ -443,9 +479,9 @@ __device__ __forceinline__ void scan_fold(ScanAcc &s, const LaneAcc &a, const Sc
 
 extern __shared__ double scan_dyn_lds[];  // KLL rings: one per (wave, sampled column) of the workgroup
 
-template <bool IS_FLOAT, bool VAR, int VARIANT, bool KLL = false>
+template <bool IS_FLOAT, bool VAR, int VARIANT, bool KLL = false, bool HLL = false>
 __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out, ScanAcc *direct, int wave,
-                                          int lane) {
+                                          int lane, uint32_t *hll = nullptr) {
   LaneAcc a;
   acc_init(a);
   const double pivot = (VAR && c.pivot) ? *c.pivot : 0.0;
@@ -460,7 +496,8 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
   }
   const uint32_t wave_slot = (uint32_t)wave_global;
   if (c.n_tiles > 0) {
-    scan_tiles<IS_FLOAT, VAR, VARIANT, KLL>(c, wave_global, n_waves, lane, a, tile_count, pivot, &K, ring, wave_slot);
+    scan_tiles<IS_FLOAT, VAR, VARIANT, KLL, HLL>(c, wave_global, n_waves, lane, a, tile_count, pivot, &K, ring, wave_slot,
+                                                 hll);
     // ragged edges belong to the last block (it has the least tile work when tiles % grid != 0)
     if (blockIdx.x == gridDim.x - 1) {
       const int64_t tail0 = c.head + c.n_tiles * kTileRows;
@@ -468,8 +505,8 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
         if (wave == 0) scan_ragged_kll<IS_FLOAT, VAR>(c, 0, c.head, lane, 64, a, pivot, K, ring, wave_slot);
         if (wave == 1) scan_ragged_kll<IS_FLOAT, VAR>(c, tail0, c.length, lane, 64, a, pivot, K, ring, wave_slot);
       } else {
-        if (wave == 0) scan_ragged<IS_FLOAT, VAR>(c, 0, c.head, lane, 64, a, pivot);
-        if (wave == 1) scan_ragged<IS_FLOAT, VAR>(c, tail0, c.length, lane, 64, a, pivot);
+        if (wave == 0) scan_ragged<IS_FLOAT, VAR, HLL>(c, 0, c.head, lane, 64, a, pivot, hll);
+        if (wave == 1) scan_ragged<IS_FLOAT, VAR, HLL>(c, tail0, c.length, lane, 64, a, pivot, hll);
       }
     }
   } else if (KLL) {
@@ -477,8 +514,7 @@ __device__ __forceinline__ void scan_body(const ScanColDesc &c, ScanPartial *out
                                    wave_slot);
   } else {
     // unaligned or short column: every wave strides over rows
-    scan_ragged<IS_FLOAT, VAR>(c, wave_global * 64, c.length, lane, (int)(n_waves * 64), a,
-                               pivot);
+    scan_ragged<IS_FLOAT, VAR, HLL>(c, wave_global * 64, c.length, lane, (int)(n_waves * 64), a, pivot, hll);
   }
   if (KLL) kll_finish_wave(K, ring, c.kll, wave_slot, lane);
   // wave reduce
@@ -564,6 +600,55 @@ __global__ __launch_bounds__(kScanBlock) void scan_kll_kernel(const ScanLaunch L
     else
       scan_body<false, false, VARIANT, true>(c, out, nullptr, wave, lane);
   }
+}
+
+// the same columns with the HyperLogLog lane on (APPROX_DISTINCT): the workgroup's registers in 16 KiB of LDS, written
+// out as one row of the column's [workgroup][register] bytes; hll_reduce_kernel folds the rows into the running
+// registers with a byte-wise max (a HyperLogLog merge).  skip_stats: the column's MIN / MAX / SUM were not asked for.
+template <int VARIANT>
+__global__ __launch_bounds__(kScanBlock) void scan_hll_kernel(const ScanLaunch L, ScanPartial *__restrict__ partials) {
+  __shared__ uint32_t s_regs[kHllRegisters / 4];
+  const ScanColDesc c = L.cols[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < kHllRegisters / 4; i += kScanBlock) s_regs[i] = 0;
+  __syncthreads();
+  ScanPartial *out = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (c.is_float)
+    scan_body<true, false, VARIANT, false, true>(c, out, nullptr, wave, lane, s_regs);
+  else
+    scan_body<false, false, VARIANT, false, true>(c, out, nullptr, wave, lane, s_regs);
+  __syncthreads();
+  uint4 *row = (uint4 *)(c.hll + (size_t)blockIdx.x * kHllRegisters);
+  for (int i = threadIdx.x; i < kHllRegisters / 16; i += kScanBlock) row[i] = ((const uint4 *)s_regs)[i];
+}
+
+// grid = (kHllRegisters / 4 / 256, columns): thread t owns four registers of its column
+__global__ __launch_bounds__(256) void hll_reduce_kernel(const ScanLaunch L, int blocks_per_col) {
+  const ScanColDesc c = L.cols[blockIdx.y];
+  const int w = blockIdx.x * 256 + threadIdx.x;  // word of four registers
+  const uint32_t *rows = (const uint32_t *)c.hll;
+  uint32_t m = 0;
+  for (int b = 0; b < blocks_per_col; b++) {
+    const uint32_t v = rows[(size_t)b * (kHllRegisters / 4) + w];
+    // byte-wise max of two packed words
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t x = (m >> (8 * k)) & 0xFFu, y = (v >> (8 * k)) & 0xFFu;
+      r |= (x > y ? x : y) << (8 * k);
+    }
+    m = r;
+  }
+  uint32_t *dst = (uint32_t *)c.hll_regs + w;
+  const uint32_t v = *dst;
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t x = (m >> (8 * k)) & 0xFFu, y = (v >> (8 * k)) & 0xFFu;
+    r |= (x > y ? x : y) << (8 * k);
+  }
+  *dst = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1206,6 +1291,13 @@ void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t
                      hipStream_t stream) {
   hipLaunchKernelGGL(scan_kll_kernel<1>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), lds_bytes, stream, L,
                      d_partials);
+}
+
+// columns with a HyperLogLog lane: d.hll = the launch's [workgroup][register] rows of each, d.hll_regs = the running
+// registers of its task
+void launch_scan_hll(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_hll_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, L, d_partials);
+  hipLaunchKernelGGL(hll_reduce_kernel, dim3(kHllRegisters / 4 / 256, n_cols), dim3(256), 0, stream, L, blocks_per_col);
 }
 
 void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,

@@ -199,6 +199,28 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
         } else if (mult) {
           plan->distinct[slot].multiplicity = true;
         }
+        plan->distinct[slot].approx_only = false;  // (an APPROX_DISTINCT spec may have created it)
+        plan->bind[i].slot = slot;
+        break;
+      }
+      case TGX_CHECK_APPROX_DISTINCT: {
+        int slot = -1;
+        for (size_t h = 0; h < plan->hll.size(); h++)
+          if (plan->hll[h].column == sp.column) slot = (int)h;
+        if (slot < 0) {
+          // the exact key set that answers where the lane does not apply: shared with a DISTINCT check of the column
+          int ds = -1;
+          for (size_t d = 0; d < plan->distinct.size(); d++)
+            if (plan->distinct[d].column == sp.column && plan->distinct[d].tuple.empty()) ds = (int)d;
+          if (ds < 0) {
+            DistinctTask t{sp.column, false, -1, {}};
+            t.approx_only = true;
+            plan->distinct.push_back(t);
+            ds = (int)plan->distinct.size() - 1;
+          }
+          plan->hll.push_back({sp.column, -1, ds});
+          slot = (int)plan->hll.size() - 1;
+        }
         plan->bind[i].slot = slot;
         break;
       }
@@ -258,6 +280,11 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
   // Int64 DISTINCT columns want the running MIN/MAX for the range-bitmap decision
   for (auto &d : plan->distinct)
     if (d.tuple.empty()) d.scan_slot = need_scan(d.column, false);
+  for (auto &h : plan->hll) h.scan_slot = need_scan(h.column, false);
+  for (size_t i = 0; i < n_specs; i++)
+    if (plan->specs[i].kind == TGX_CHECK_NUMERIC_STATS) plan->scan[plan->bind[i].slot].stats_needed = true;
+  for (auto &d : plan->distinct)
+    if (d.tuple.empty() && !d.approx_only && d.scan_slot >= 0) plan->scan[d.scan_slot].stats_needed = true;
   // pass 2: COUNT rides on a scan of the same column when there is one
   for (size_t i = 0; i < n_specs; i++) {
     tgx_check_spec &sp = plan->specs[i];
@@ -289,7 +316,9 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
     for (auto &t : P->scan) P->used[t.column] = P->reads_values[t.column] = 1;
     for (auto &t : P->count) P->used[t.column] = 1;
     for (auto &t : P->distinct) {
-      P->used[t.column] = P->reads_values[t.column] = P->needs_wide[t.column] = 1;
+      P->used[t.column] = P->reads_values[t.column] = 1;
+      // (an approx_only key set of a numeric column only runs when the column's scan carries variance lanes)
+      if (!t.approx_only || (t.scan_slot >= 0 && P->scan[t.scan_slot].variance)) P->needs_wide[t.column] = 1;
       for (int c : t.tuple) P->used[c] = P->reads_values[c] = P->needs_wide[c] = 1;
     }
     for (auto &t : P->como)
@@ -424,6 +453,8 @@ static void state_init_host(tgx_state *st, const tgx_plan *plan) {
   st->h_kll.clear();
   st->h_kll.resize(plan->kll.size());
   for (size_t i = 0; i < plan->kll.size(); i++) st->h_kll[i].k = plan->kll[i].k;
+  st->h_hll.assign(plan->hll.size(), std::vector<uint8_t>());
+  st->hll_mode.assign(plan->hll.size(), 0);
   regex_state_init(st);
   kll_state_init(st);
   spearman_state_init(st);
@@ -460,6 +491,10 @@ tgx_status tgx::state_init_device(tgx_state *st, tgx_error *err) {
   if (!plan->como.empty()) {
     HIP_TRY(st->d_como_acc.reserve(plan->como.size() * sizeof(ComomentAcc)));
     HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
+  }
+  if (!plan->hll.empty()) {
+    HIP_TRY(st->d_hll.reserve(plan->hll.size() * (size_t)kHllRegisters));
+    HIP_TRY(hipMemsetAsync(st->d_hll.p, 0, plan->hll.size() * (size_t)kHllRegisters, st->stream));
   }
   if (!st->distinct.empty()) {
     const size_t each = kNumDistinctCounters * sizeof(unsigned long long);
@@ -570,6 +605,10 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   regex_state_reset(st);
   spearman_state_reset(st);
   st->como_pivot_tries.clear();
+  st->h_hll.assign(plan->hll.size(), std::vector<uint8_t>());
+  st->hll_mode.assign(plan->hll.size(), 0);
+  if (st->device_ready && st->d_hll.p)
+    HIP_TRY(hipMemsetAsync(st->d_hll.p, 0, plan->hll.size() * (size_t)kHllRegisters, st->stream));
   if (st->device_ready) {
     if (!plan->scan.empty()) {
       HIP_TRY(hipMemcpyAsync(st->d_scan_acc.p, st->d_scan_identity.p, plan->scan.size() * sizeof(ScanAcc),
@@ -834,7 +873,9 @@ static void fill_scan_desc(const tgx_column &c, bool variance, const double *piv
   d->want_variance = variance ? 1 : 0;
   d->pivot = pivot;
   d->elem32 = is_numeric32(c.type) ? 1 : 0;
-  d->pad32 = 0;
+  d->skip_stats = 0;
+  d->hll = nullptr;
+  d->hll_regs = nullptr;
   const uintptr_t width = d->elem32 ? 4 : 8;  // a lane's pair of rows is one 2 x width load
   int64_t head = (64 - (c.offset & 63)) & 63;
   if (head > c.length) head = c.length;
@@ -1284,6 +1325,10 @@ static tgx_status distinct_sample_all(tgx_state *st, const tgx_column *dev, tgx_
     const DistinctTask &t = plan->distinct[q];
     st->distinct[q].sample_ready = false;
     if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0) continue;
+    bool lane = false;  // (the HyperLogLog lane has the column: its approx_only key set stays idle)
+    for (size_t h = 0; h < plan->hll.size(); h++)
+      lane |= plan->hll[h].distinct_slot == (int)q && st->hll_mode[h] == 1;
+    if (lane) continue;
     if (distinct_wants_sample(st->distinct[q], dev[t.column])) who.push_back(q);
   }
   if (who.empty()) return TGX_OK;
@@ -1796,10 +1841,27 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
       ScanColDesc dx, dy;
     };
     std::vector<FusedPair> fused_pairs;
+    // ---- APPROX_DISTINCT: the HyperLogLog lane of the scan for numeric columns; the exact key set elsewhere ----
+    // (decided by the first batch's column type; a column whose scan also carries variance lanes keeps the exact set)
+    std::vector<int> hll_on_col(n_plan_cols, -1);
+    std::vector<char> distinct_is_idle(plan->distinct.size(), 0);
+    for (size_t q = 0; q < plan->hll.size(); q++) {
+      const HllTask &t = plan->hll[q];
+      const int type = dev[t.column].type;
+      const bool numeric = is_numeric(type) || is_numeric32(type);
+      const bool lane = numeric && plan->distinct[t.distinct_slot].approx_only && !plan->scan[t.scan_slot].variance;
+      if (st->hll_mode[q] == 0) st->hll_mode[q] = lane ? 1 : 2;
+      if (st->hll_mode[q] == 1) {
+        if (dev[t.column].values) hll_on_col[t.column] = (int)q;
+        distinct_is_idle[t.distinct_slot] = 1;  // (its approx_only key set has nothing to do)
+      }
+    }
+    auto distinct_idle = [&](size_t q) { return distinct_is_idle[q] != 0; };
+    auto has_hll = [&](int col) { return hll_on_col[col] >= 0; };  // its own scan launch: fuses with nothing else
     if (nrows >= (1 << 20)) {
       for (size_t q = 0; q < plan->kll.size(); q++) {
         const int col = plan->kll[q].column;
-        if (plain8(col) && kll_on_col[col] < 0 && kll_scan_eligible(nrows)) {
+        if (plain8(col) && !has_hll(col) && kll_on_col[col] < 0 && kll_scan_eligible(nrows)) {
           kll_on_col[col] = (int)q;
           kll_fused[q] = 1;
         }
@@ -1807,6 +1869,7 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
       for (size_t q = 0; q < plan->como.size() && fused_pairs.size() < (size_t)kMaxPairsPerLaunch; q++) {
         const int x = plan->como[q].col_x, y = plan->como[q].col_y;
         if (x == y || !plain8(x) || !plain8(y) || pair_of_col[x] >= 0 || pair_of_col[y] >= 0) continue;
+        if (has_hll(x) || has_hll(y)) continue;
         const int sx = scan_slot_of(x), sy = scan_slot_of(y);
         if ((sx >= 0 && plan->scan[sx].variance) || (sy >= 0 && plan->scan[sy].variance)) continue;
         FusedPair fp;
@@ -1841,7 +1904,7 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
     TGX_TRY(distinct_sample_all(st, dev.data(), err));
     for (size_t q = 0; q < plan->distinct.size(); q++) {
       const DistinctTask &t = plan->distinct[q];
-      if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0) continue;
+      if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0 || distinct_idle(q)) continue;
       TGX_TRY(distinct_prepare_numeric(st, q, dev[t.column], &dprep[q], err));
       if (dprep[q].partitioned && dev[t.column].type == TGX_INT64 && t.scan_slot >= 0 &&
           !plan->scan[t.scan_slot].variance && pair_of_col[t.column] < 0 && kll_on_col[t.column] < 0)
@@ -1849,8 +1912,8 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
     }
     // ---- numeric scan: all columns of the batch in launches of <= kMaxColsPerLaunch ----
     {
-      std::vector<ScanColDesc> descs, kll_descs;
-      std::vector<int32_t> index, kll_index;
+      std::vector<ScanColDesc> descs, kll_descs, hll_descs;
+      std::vector<int32_t> index, kll_index, hll_index;
       std::vector<int> kll_slots;
       for (size_t s = 0; s < plan->scan.size(); s++) {
         const tgx_column &c = dev[plan->scan[s].column];
@@ -1866,7 +1929,7 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
         }
         if (pair_of_col[plan->scan[s].column] >= 0) continue;  // scanned with its partner below
         if (stats_by_partition[s] >= 0) continue;                // its DISTINCT pass brings the aggregates
-        if (kll_on_col[plan->scan[s].column] < 0) {
+        if (kll_on_col[plan->scan[s].column] < 0 && hll_on_col[plan->scan[s].column] < 0) {
           // a scan that only feeds DISTINCT's range decision is not needed once the range is declared
           bool bound = false, all_hinted = true, any_distinct = false;
           for (size_t i = 0; i < plan->specs.size(); i++) {
@@ -1883,6 +1946,14 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
         }
         ScanColDesc d;
         fill_scan_desc(c, plan->scan[s].variance, st->d_pivots.as<double>() + s, &d);
+        if (hll_on_col[plan->scan[s].column] >= 0 && !plan->scan[s].variance) {
+          d.skip_stats = plan->scan[s].stats_needed ? 0 : 1;
+          d.hll_regs = st->d_hll.as<uint8_t>() + (size_t)hll_on_col[plan->scan[s].column] * kHllRegisters;
+          hll_descs.push_back(d);
+          hll_index.push_back((int32_t)s);
+          hll_on_col[plan->scan[s].column] = -2;  // taken
+          continue;
+        }
         if (kll_on_col[plan->scan[s].column] >= 0) {
           kll_descs.push_back(d);
           kll_index.push_back((int32_t)s);
@@ -1956,6 +2027,30 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
         {
           ProfScope ps(st, "scan", chunk_bytes);
           launch_scan_kll(L, n, blocks, lds, st->d_scan_partials.as<ScanPartial>(), st->stream);
+        }
+        launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
+                                st->stream);
+      }
+      // columns with the HyperLogLog lane on (APPROX_DISTINCT)
+      for (size_t c0 = 0; c0 < hll_descs.size(); c0 += kMaxColsPerLaunch) {
+        const int n = (int)std::min<size_t>(kMaxColsPerLaunch, hll_descs.size() - c0);
+        ScanLaunch L;
+        memset(&L, 0, sizeof(L));
+        int blocks = 1;
+        uint64_t chunk_bytes = 0;
+        for (int k = 0; k < n; k++) {
+          L.cols[k] = hll_descs[c0 + k];
+          L.acc_index[k] = hll_index[c0 + k];
+          blocks = std::max(blocks, scan_blocks_for(L.cols[k], n));
+          chunk_bytes += (uint64_t)L.cols[k].length * (L.cols[k].elem32 ? 4 : 8) +
+                         (L.cols[k].validity ? (uint64_t)(L.cols[k].length + 7) / 8 : 0);
+        }
+        HIP_TRY(st->d_scan_partials.reserve((size_t)n * blocks * sizeof(ScanPartial)));
+        HIP_TRY(st->d_hll_rows.reserve((size_t)n * blocks * kHllRegisters));
+        for (int k = 0; k < n; k++) L.cols[k].hll = st->d_hll_rows.as<uint8_t>() + (size_t)k * blocks * kHllRegisters;
+        {
+          ProfScope ps(st, "scan", chunk_bytes), ps_hll(st, "scan_hll", chunk_bytes);
+          launch_scan_hll(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->stream);
         }
         launch_scan_reduce_only(L, n, blocks, st->d_scan_partials.as<ScanPartial>(), st->d_scan_acc.as<ScanAcc>(),
                                 st->stream);
@@ -2122,7 +2217,9 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
     TGX_TRY(regex_update(st, dev.data(), err, &fuse));
     std::map<int, bool> fuse_done;
     for (size_t s = 0; s < plan->distinct.size(); s++)
-      if (plan->distinct[s].tuple.empty()) {
+      if (distinct_idle(s)) {
+        continue;
+      } else if (plan->distinct[s].tuple.empty()) {
         const int col = plan->distinct[s].column;
         const std::vector<DictGather> *g = nullptr;
         auto it = fuse.by_column.find(col);
@@ -2509,6 +2606,7 @@ struct Gathered {
   std::vector<CountAcc> count;
   std::vector<ComomentAcc> como;
   std::vector<DistinctTotals> distinct;
+  std::vector<std::vector<uint8_t>> hll;  // per task: kHllRegisters bytes, or empty (nothing seen)
 };
 }  // namespace
 
@@ -2539,6 +2637,7 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
   g->scan = st->h_scan;
   g->count = st->h_count;
   g->como = st->h_como;
+  g->hll = st->h_hll;
   g->distinct.resize(plan->distinct.size());
   std::vector<unsigned long long> all;
   if (st->device_ready) {
@@ -2552,7 +2651,8 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
     if (st->d_distinct_counters.p) all.resize(plan->distinct.size() * kNumDistinctCounters);
     const size_t b_scan = d_scan.size() * sizeof(ScanAcc), b_count = d_count.size() * sizeof(CountAcc),
                  b_como = d_como.size() * sizeof(ComomentAcc), b_all = all.size() * sizeof(unsigned long long);
-    TGX_TRY(pinned_readback(st, b_scan + b_count + b_como + b_all + 64, err));
+    const size_t b_hll = st->d_hll.p ? plan->hll.size() * (size_t)kHllRegisters : 0;
+    TGX_TRY(pinned_readback(st, b_scan + b_count + b_como + b_all + b_hll + 64, err));
     char *h = (char *)st->h_pinned;
     if (b_scan) HIP_TRY(hipMemcpyAsync(h, st->d_scan_acc.p, b_scan, hipMemcpyDeviceToHost, st->stream));
     if (b_count) HIP_TRY(hipMemcpyAsync(h + b_scan, st->d_count_acc.p, b_count, hipMemcpyDeviceToHost, st->stream));
@@ -2561,7 +2661,19 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
     if (b_all)
       HIP_TRY(hipMemcpyAsync(h + b_scan + b_count + b_como, st->d_distinct_counters.p, b_all, hipMemcpyDeviceToHost,
                              st->stream));
+    if (b_hll)
+      HIP_TRY(hipMemcpyAsync(h + b_scan + b_count + b_como + b_all, st->d_hll.p, b_hll, hipMemcpyDeviceToHost, st->stream));
     HIP_TRY(hipStreamSynchronize(st->stream));
+    for (size_t q = 0; b_hll && q < plan->hll.size(); q++) {
+      if (st->hll_mode[q] != 1) continue;
+      const uint8_t *regs = (const uint8_t *)h + b_scan + b_count + b_como + b_all + q * (size_t)kHllRegisters;
+      std::vector<uint8_t> &out = g->hll[q];
+      if (out.empty()) {
+        out.assign(regs, regs + kHllRegisters);
+      } else {
+        for (int r = 0; r < kHllRegisters; r++) out[r] = std::max(out[r], regs[r]);
+      }
+    }
     if (b_scan) memcpy(d_scan.data(), h, b_scan);
     if (b_count) memcpy(d_count.data(), h + b_scan, b_count);
     if (b_como) memcpy(d_como.data(), h + b_scan + b_count, b_como);
@@ -2641,6 +2753,45 @@ static void fill_stats(const ScanAcc &a, bool variance, tgx_result *r) {
   }
 }
 
+// The cardinality estimate of a HyperLogLog sketch of 2^p registers whose ranks run 0 .. q + 1: Ertl, "New
+// cardinality estimation algorithms for HyperLogLog sketches" (2017), algorithm 6 -- the estimator of DataFusion's
+// APPROX_DISTINCT (datafusion-functions-aggregate 50.3.0, hyperloglog.rs `count`, there with p = 14, q = 50; here
+// q = 32: the rank comes from a 32-bit word).
+static double hll_sigma(double x) {
+  if (x == 1.0) return INFINITY;
+  double y = 1.0, z = x;
+  for (;;) {
+    x *= x;
+    const double z0 = z;
+    z += x * y;
+    y += y;
+    if (z0 == z) return z;
+  }
+}
+static double hll_tau(double x) {
+  if (x == 0.0 || x == 1.0) return 0.0;
+  double y = 1.0, z = 1.0 - x;
+  for (;;) {
+    x = sqrt(x);
+    const double z0 = z;
+    y *= 0.5;
+    z -= (1.0 - x) * (1.0 - x) * y;
+    if (z0 == z) return z / 3.0;
+  }
+}
+static uint64_t hll_estimate(const std::vector<uint8_t> &regs) {
+  if (regs.empty()) return 0;
+  constexpr int q = kHllMaxRank - 1;
+  uint32_t hist[kHllMaxRank + 1] = {0};
+  for (int r = 0; r < kHllRegisters; r++) hist[std::min<int>(regs[r], kHllMaxRank)]++;
+  const double m = (double)kHllRegisters;
+  double z = m * hll_tau((m - (double)hist[q + 1]) / m);
+  for (int k = q; k >= 1; k--) z = 0.5 * (z + (double)hist[k]);
+  z += m * hll_sigma((double)hist[0] / m);
+  const double e = 0.5 / log(2.0) * m * m / z;
+  return std::isfinite(e) ? (uint64_t)llround(e) : 0;
+}
+
 extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_result *results,
                                    size_t n_results, tgx_error *err) try {
   bind_thread();
@@ -2715,6 +2866,20 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
           r->co_m2_x = m2x > 0 ? (double)m2x : (m2x == m2x ? 0.0 : (double)m2x);
           r->co_m2_y = m2y > 0 ? (double)m2y : (m2y == m2y ? 0.0 : (double)m2y);
           r->co_c_xy = (double)(como_sum(a, 4) - s0 * s1 / n);
+        }
+        break;
+      }
+      case TGX_CHECK_APPROX_DISTINCT: {
+        const HllTask &t = plan->hll[b.slot];
+        if (st->hll_mode[b.slot] == 1) {  // the HyperLogLog lane of the column's scan
+          r->total = g.scan[t.scan_slot].total;
+          r->non_null = g.scan[t.scan_slot].non_null;
+          r->distinct = (int64_t)hll_estimate(g.hll[b.slot]);
+        } else {  // the exact key set (string / dictionary columns, or a DISTINCT check of the same column)
+          const DistinctTotals &d = g.distinct[t.distinct_slot];
+          r->total = (int64_t)d.total;
+          r->non_null = (int64_t)d.non_null;
+          r->distinct = (int64_t)d.distinct;
         }
         break;
       }
@@ -2997,6 +3162,19 @@ extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state 
       dst->h_count[k].non_null += g.count[k].non_null;
     }
     for (size_t k = 0; k < g.como.size(); k++) como_acc_merge(dst->h_como[k], g.como[k]);
+    for (size_t k = 0; k < plan->hll.size(); k++) {
+      if (src->hll_mode[k] == 0) continue;
+      if (dst->hll_mode[k] == 0) dst->hll_mode[k] = src->hll_mode[k];
+      if (dst->hll_mode[k] != src->hll_mode[k])
+        return fail(err, TGX_INVALID_ARGUMENT, "APPROX_DISTINCT task %zu: one state holds registers, the other a key set", k);
+      if (g.hll[k].empty()) continue;
+      std::vector<uint8_t> &out = dst->h_hll[k];
+      if (out.empty()) {
+        out = g.hll[k];
+      } else {
+        for (int r = 0; r < kHllRegisters; r++) out[r] = std::max(out[r], g.hll[k][r]);
+      }
+    }
     for (size_t k = 0; k < plan->distinct.size(); k++) {
       DistinctState &s = src->distinct[k];
       DistinctState &d = dst->distinct[k];
@@ -3092,6 +3270,7 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
   w.pod((uint32_t)g.distinct.size());
   w.pod((uint32_t)plan->kll.size());
   w.pod((uint32_t)regex_num_tasks(plan));
+  w.pod((uint32_t)plan->hll.size());
   for (auto &a : g.scan) w.pod(a);
   for (auto &a : g.count) w.pod(a);
   for (auto &a : g.como) w.pod(a);
@@ -3119,6 +3298,11 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
   }
   TGX_TRY(kll_serialize(st, &w.len, w.buf, w.cap, err));
   TGX_TRY(regex_serialize(st, &w.len, w.buf, w.cap, err));
+  for (size_t k = 0; k < plan->hll.size(); k++) {  // { u32 mode, u32 has_registers; registers }
+    w.pod((uint32_t)st->hll_mode[k]);
+    w.pod((uint32_t)(g.hll[k].empty() ? 0 : 1));
+    if (!g.hll[k].empty()) w.put(g.hll[k].data(), kHllRegisters);
+  }
   *len = w.len;
   if (buf && w.len > cap) return fail(err, TGX_INVALID_ARGUMENT, "buffer too small: need %zu bytes", w.len);
   return TGX_OK;
@@ -3135,9 +3319,10 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
   if (r.pod<uint32_t>() != kWireMagic) return fail(err, TGX_INVALID_ARGUMENT, "not a tgx state blob");
   if (r.pod<uint32_t>() != kWireVersion) return fail(err, TGX_INVALID_ARGUMENT, "state blob version mismatch");
   uint32_t n_scan = r.pod<uint32_t>(), n_count = r.pod<uint32_t>(), n_como = r.pod<uint32_t>(),
-           n_dist = r.pod<uint32_t>(), n_kll = r.pod<uint32_t>(), n_regex = r.pod<uint32_t>();
+           n_dist = r.pod<uint32_t>(), n_kll = r.pod<uint32_t>(), n_regex = r.pod<uint32_t>(), n_hll = r.pod<uint32_t>();
   if (n_scan != plan->scan.size() || n_count != plan->count.size() || n_como != plan->como.size() ||
-      n_dist != plan->distinct.size() || n_kll != plan->kll.size() || n_regex != regex_num_tasks(plan))
+      n_dist != plan->distinct.size() || n_kll != plan->kll.size() || n_regex != regex_num_tasks(plan) ||
+      n_hll != plan->hll.size())
     return fail(err, TGX_INVALID_ARGUMENT, "state blob was produced by a different plan");
   std::unique_ptr<tgx_state, void (*)(tgx_state *)> st(new tgx_state(), tgx_state_destroy);
   state_init_host(st.get(), plan);
@@ -3187,6 +3372,15 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
     if (s != TGX_OK) return s;
     s = regex_deserialize(st.get(), r.buf, r.len, &r.pos, err);
     if (s != TGX_OK) return s;
+    for (size_t k = 0; k < plan->hll.size() && r.ok; k++) {
+      const uint32_t mode = r.pod<uint32_t>(), has = r.pod<uint32_t>();
+      if (mode > 2 || has > 1) return fail(err, TGX_INVALID_ARGUMENT, "malformed state blob (APPROX_DISTINCT task)");
+      st->hll_mode[k] = (int)mode;
+      if (has) {
+        st->h_hll[k].resize(kHllRegisters);
+        r.get(st->h_hll[k].data(), kHllRegisters);
+      }
+    }
   }
   if (!r.ok) return fail(err, TGX_INVALID_ARGUMENT, "truncated state blob");
   *out = st.release();

@@ -4,7 +4,7 @@ The blob is what ranks exchange (one all-gather of a few KiB) and what a checkpo
 counterpart of the serde_json analyzer states of the reference's IncrementalAnalysisRunner
 (analyzers/incremental/runner.rs:71-111).  Layout, little-endian, in plan-task order:
 
-    u32 magic 'TGXS', u32 version, u32 n_scan, n_count, n_comoments, n_distinct, n_kll, n_regex
+    u32 magic 'TGXS', u32 version, u32 n_scan, n_count, n_comoments, n_distinct, n_kll, n_regex, n_hll
     n_scan      x ScanAcc      i64 total, non_null, min_key, max_key; u64 sum_lo; i64 sum_hi; f64 sum, comp;
                                i64 var_n; f64 var_mean, var_m2; i32 is_float, pad                    (96 B)
     n_count     x CountAcc     i64 total, non_null                                                      (16 B)
@@ -15,6 +15,8 @@ counterpart of the serde_json analyzer states of the reference's IncrementalAnal
                     u64 n_records; records (16 B {key, count} or 32 B {hash_a, hash_b, count, 0}) }
     n_kll       x { u32 k, u32 n_levels; u64 n; f64 min, max; n_levels x { u32 count; f64 items[count] } }
     n_regex     x { u64 total, u64 matches }
+    n_hll       x { u32 mode (0 nothing seen, 1 registers, 2 the exact key set answers), u32 has_registers;
+                    has_registers x 16384 u8 HyperLogLog registers (rank 0 .. 33) }
 
 min_key / max_key are the Int64 values themselves, or the IEEE totalOrder keys of Float64 values
 (bits ^ ((bits >> 63) >>> 1)).  This module packs partial states from plain numbers; libtgx does the parsing.
@@ -76,6 +78,16 @@ def regex_counts(total, matches):
     return struct.pack("<QQ", total, matches)
 
 
-def pack(scan=(), count=(), comoments=(), distinct=(), kll=(), regex=()):
-    head = struct.pack("<8I", MAGIC, VERSION, len(scan), len(count), len(comoments), len(distinct), len(kll), len(regex))
-    return head + b"".join(scan) + b"".join(count) + b"".join(comoments) + b"".join(distinct) + b"".join(kll) + b"".join(regex)
+def hll_state(registers=None, mode=1):
+    """registers: 16384 bytes (or None: nothing seen yet)"""
+    if registers is None:
+        return struct.pack("<II", mode, 0)
+    assert len(registers) == 16384
+    return struct.pack("<II", mode, 1) + bytes(registers)
+
+
+def pack(scan=(), count=(), comoments=(), distinct=(), kll=(), regex=(), hll=()):
+    head = struct.pack("<9I", MAGIC, VERSION, len(scan), len(count), len(comoments), len(distinct), len(kll), len(regex),
+                       len(hll))
+    return (head + b"".join(scan) + b"".join(count) + b"".join(comoments) + b"".join(distinct) + b"".join(kll) +
+            b"".join(regex) + b"".join(hll))

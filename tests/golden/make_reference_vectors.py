@@ -138,6 +138,9 @@ approx_count_distinct = [
          assertion=["equals", 0.0], status="success", bounds=[0.0, 0.0], exact=0.0),
     dict(ref="constraints/approx_count_distinct.rs:314-326", dtype="int64", values=[N, N, N, N, N],
          assertion=["equals", 0.0], status="success", bounds=[0.0, 0.0], exact=0.0),
+    # "Should be within 3% of 1000": 10 000 rows, i % 1000
+    dict(ref="constraints/approx_count_distinct.rs:329-348", dtype="int64", values=[i % 1000 for i in range(10000)],
+         assertion=["between", 970.0, 1030.0], status="success", bounds=[970.0, 1030.0], exact=1000.0),
 ]
 
 EMAIL = "email"

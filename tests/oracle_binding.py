@@ -71,6 +71,10 @@ def _declare(L):
     L.orc_stats_f64.argtypes = [vp, vp, i64, i64, C.POINTER(Stats)]
     L.orc_distinct_bits64.argtypes = [vp, vp, i64, i64, C.POINTER(Distinct)]
     L.orc_distinct_utf8.argtypes = [vp, vp, vp, i64, i64, C.POINTER(Distinct)]
+    L.orc_hll_registers.argtypes = [vp, vp, i64, i64, vp]
+    L.orc_hll_registers.restype = None
+    L.orc_hll_estimate.argtypes = [vp]
+    L.orc_hll_estimate.restype = C.c_uint64
     L.orc_comoments.argtypes = [vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, i64, C.POINTER(Comoments)]
     L.orc_pearson_from_state.argtypes = [C.POINTER(Comoments)]
     L.orc_pearson_from_state.restype = dbl
@@ -169,6 +173,21 @@ def distinct_bits64(values, validity=None, n=None, offset=0):
     rc = lib().orc_distinct_bits64(_p(values), _p(validity), offset, n, C.byref(out))
     assert rc == 0
     return out
+
+
+def hll_registers(values, validity=None, n=None, offset=0, registers=None):
+    """HyperLogLog registers (16384 bytes) of the 8-byte values' bit patterns; `registers` continues a sketch"""
+    import numpy as np
+
+    n = len(values) - offset if n is None else n
+    assert values.dtype.itemsize == 8
+    regs = np.zeros(16384, np.uint8) if registers is None else registers
+    lib().orc_hll_registers(_p(values), _p(validity), offset, n, _p(regs))
+    return regs
+
+
+def hll_estimate(registers):
+    return int(lib().orc_hll_estimate(_p(registers)))
 
 
 def distinct_utf8(offsets, data, validity=None, n=None, offset=0):

@@ -235,6 +235,36 @@ def test_distinct_semantics():
     assert orc.distinct_bits64(f.view(np.uint64)).distinct == 3  # by bit pattern
 
 
+def test_approx_count_distinct_vectors(golden):
+    """constraints/approx_count_distinct.rs:186-347: the reference's tests BOUND DataFusion's HyperLogLog estimate (its
+    hash is third-party); the oracle's sketch of the same shape (2^14 registers, Ertl's estimator) must land inside
+    every one of those bounds, be exact at small cardinalities, and merge by max (advanced/approx_count_distinct.rs:45-61)"""
+    for case in golden["approx_count_distinct"]:
+        if case["dtype"] != "int64":
+            continue  # (string columns are answered by the exact key set)
+        vals = np.array([0 if v is None else v for v in case["values"]], dtype=np.int64)
+        mask = np.array([v is not None for v in case["values"]], dtype=bool)
+        regs = orc.hll_registers(vals, orc.pack_validity(mask) if len(vals) else None, n=len(vals))
+        est = orc.hll_estimate(regs)
+        assert case["bounds"][0] <= est <= case["bounds"][1], (case["ref"], est)
+        if case["exact"] <= 100:
+            assert est == case["exact"], case["ref"]
+    # registers are a function of the SET of values: order, repetition and the split into batches do not matter
+    rng = np.random.default_rng(0)
+    v = rng.integers(-10**12, 10**12, size=200_000, dtype=np.int64)
+    whole = orc.hll_registers(v)
+    parts = np.maximum(orc.hll_registers(v[:70_001].copy()), orc.hll_registers(np.concatenate([v[70_001:], v[:500]])))
+    assert np.array_equal(whole, parts) and np.array_equal(whole, orc.hll_registers(rng.permutation(np.concatenate([v, v]))))
+    true = len(np.unique(v))
+    assert abs(orc.hll_estimate(whole) / true - 1) < 0.03
+    # the standard error of 2^14 registers is 0.8 %: sequential ids, strided ids, epoch milliseconds, doubles
+    for vals in (np.arange(1_000_000, dtype=np.int64), np.arange(1_000_000, dtype=np.int64) * 3 - 1_000_000,
+                 1_700_000_000_000 + np.arange(1_000_000, dtype=np.int64) * 1000,
+                 (np.arange(1_000_000) * 0.01).view(np.int64), (rng.random(1_000_000) * 1000).view(np.int64)):
+        assert abs(orc.hll_estimate(orc.hll_registers(vals)) / len(np.unique(vals)) - 1) < 0.03
+    assert orc.hll_estimate(np.zeros(16384, np.uint8)) == 0
+
+
 def test_length_vectors(golden):
     """constraints/length.rs:246-438: ratio = rows with LENGTH(c) inside the bounds OR NULL, over all rows"""
     for case in golden["length"]:

@@ -80,6 +80,27 @@ def main():
                   (name, m, path, res[0].distinct, dt, m / dt / 1e6))
             del st
     os.environ.pop("TGX_FP_LISTS_MIN_ROWS", None)
+    # ---- (3) APPROX_DISTINCT: the HyperLogLog lane of the scan (2^14 registers), alone and next to min / max / mean ----
+    for name, col in (("sparse Int64 ids", T.Column.int64(ids, None, length=m)),
+                      ("Float64 values", T.Column.float64(vals, None, length=m))):
+        for what, specs in (("lane alone", [spec(T.APPROX_DISTINCT, 0), spec(T.COUNT, 0)]),
+                            ("lane + min/max/mean", [spec(T.APPROX_DISTINCT, 0), spec(T.NUMERIC_STATS, 0)])):
+            st = T.State(T.Plan(specs))
+            for it in range(args.steps + 2):
+                if it == 2:
+                    st.profile_enable(True)
+                    st.profile_reset()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                st.reset()
+                st.update([col])
+                res = st.finalize()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps * 1e3
+            k = st.profile_get("scan_hll")["total_ms"] / args.steps
+            print("%s, %d rows, APPROX_DISTINCT (%s): estimate=%d  wall %.2f ms/step, kernels %.2f ms = %.2f TB/s" %
+                  (name, m, what, res[0].distinct, dt, k, m * 8 / (k * 1e-3) / 1e12))
+            del st
 
 
 if __name__ == "__main__":
