@@ -183,7 +183,6 @@ void orc_hll_registers(const uint64_t *bits, const uint8_t *validity, int64_t of
     a *= 0xC2B2AE35u;
     a ^= a >> 16;
     uint32_t b = (hi ^ orc_rotl32(a, 16)) * 0x27D4EB2Fu;
-    b ^= b >> 15;
     uint32_t rank = 1;
     while (rank <= 32 && !(b & 0x80000000u)) {
       b <<= 1;

@@ -45,8 +45,7 @@ __host__ __device__ inline void hll_hash(uint64_t bits, uint32_t *a_out, uint32_
   a ^= a >> 13;
   a *= 0xC2B2AE35u;
   a ^= a >> 16;
-  uint32_t b = (hi ^ hll_rotl32(a, 16)) * 0x27D4EB2Fu;
-  b ^= b >> 15;
+  const uint32_t b = (hi ^ hll_rotl32(a, 16)) * 0x27D4EB2Fu;  // (only its leading zeros are used)
   *a_out = a;
   *b_out = b;
 }

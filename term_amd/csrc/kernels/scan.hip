@@ -66,21 +66,46 @@ __device__ __forceinline__ void two_sum_add(double &s, double &c, double x) {
 // ever grows, and after the first few thousand values of a workgroup almost no value raises its register any more: a
 // value READS its register (ds_read_u8) and only a value that would raise it enters the compare-and-swap on the word
 // that holds it -- LDS has no byte atomics, and a 32-bit max over packed bytes is not a byte-wise max.
-__device__ __forceinline__ void hll_update(uint32_t *regs, int64_t bits, bool valid) {
+__device__ __forceinline__ void hll_rank(int64_t bits, bool valid, uint32_t &idx, uint32_t &rho) {
   uint32_t a, b;
   hll_hash((uint64_t)bits, &a, &b);
-  const uint32_t idx = a & (uint32_t)(kHllRegisters - 1);
-  const uint32_t rho = (uint32_t)__builtin_clz(b | 1u) + (b ? 1u : 2u);  // clz(b) + 1; b == 0 -> 33
+  idx = a & (uint32_t)(kHllRegisters - 1);
+  rho = (uint32_t)__builtin_clz(b | 1u) + (b ? 1u : 2u);  // clz(b) + 1; b == 0 -> 33
+  rho = valid ? rho : 0u;                                  // a NULL raises nothing
+}
+__device__ __forceinline__ void hll_raise(uint32_t *regs, uint32_t idx, uint32_t rho) {
   const uint32_t sh = (idx & 3u) * 8u;
   uint32_t *word = regs + (idx >> 2);
-  if (valid && ((const uint8_t *)regs)[idx] < rho) {
-    uint32_t old = *word;
-    while (((old >> sh) & 0xFFu) < rho) {
-      const uint32_t want = (old & ~(0xFFu << sh)) | (rho << sh);
-      const uint32_t seen = atomicCAS(word, old, want);
-      if (seen == old) break;
-      old = seen;
-    }
+  uint32_t old = *word;
+  while (((old >> sh) & 0xFFu) < rho) {
+    const uint32_t want = (old & ~(0xFFu << sh)) | (rho << sh);
+    const uint32_t seen = atomicCAS(word, old, want);
+    if (seen == old) break;
+    old = seen;
+  }
+}
+__device__ __forceinline__ void hll_update(uint32_t *regs, int64_t bits, bool valid) {
+  uint32_t idx, rho;
+  hll_rank(bits, valid, idx, rho);
+  if (((const uint8_t *)regs)[idx] < rho) hll_raise(regs, idx, rho);
+}
+// a tile's eight values of a lane together: the eight hash chains interleave (a 32-bit multiply is a quarter-rate
+// instruction with a long latency), the eight register reads are in flight at once and waited for once, and the
+// compare-and-swap path is entered only by a wave in which some value does raise its register -- value by value,
+// each behind its own read and its own branch, the lane ran at LDS latency: 2.0 ms per 1 G-row column
+__device__ __forceinline__ void hll_update8(uint32_t *regs, const int64_t (&bits)[8], const bool (&valid)[8]) {
+  uint32_t idx[8], rho[8], cur[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) hll_rank(bits[k], valid[k], idx[k], rho[k]);
+#pragma unroll
+  for (int k = 0; k < 8; k++) cur[k] = ((const uint8_t *)regs)[idx[k]];
+  bool need = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) need |= cur[k] < rho[k];
+  if (__builtin_amdgcn_ballot_w64(need) != 0) {  // (uniform)
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (cur[k] < rho[k]) hll_raise(regs, idx[k], rho[k]);
   }
 }
 
@@ -389,14 +414,10 @@ __device__ __forceinline__ void scan_tiles(const ScanColDesc &c, int64_t wave_gl
       acc_pair<IS_FLOAT, VAR>(a, v3, b3, pivot);
     }
     if (HLL) {
-      hll_update(hll, v0.x, (b0 & 1u) != 0);
-      hll_update(hll, v0.y, (b0 & 2u) != 0);
-      hll_update(hll, v1.x, (b1 & 1u) != 0);
-      hll_update(hll, v1.y, (b1 & 2u) != 0);
-      hll_update(hll, v2.x, (b2 & 1u) != 0);
-      hll_update(hll, v2.y, (b2 & 2u) != 0);
-      hll_update(hll, v3.x, (b3 & 1u) != 0);
-      hll_update(hll, v3.y, (b3 & 2u) != 0);
+      const int64_t hb[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+      const bool hv[8] = {(b0 & 1u) != 0, (b0 & 2u) != 0, (b1 & 1u) != 0, (b1 & 2u) != 0,
+                          (b2 & 1u) != 0, (b2 & 2u) != 0, (b3 & 1u) != 0, (b3 & 2u) != 0};
+      hll_update8(hll, hb, hv);
     }
     if (KLL) {
       kll_push_pair<IS_FLOAT>(*K, ring, v0, b0);
