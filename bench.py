@@ -41,6 +41,45 @@ def build_suite(T, spec, layout, unique_cols):
     return specs
 
 
+def reference_cpu_baseline(sample_rows, seed):
+    """term-guard itself on the host cores: baselines/term_guard_cpu is a Rust main that puts the
+    same synthetic table into a DataFusion MemTable (target_partitions = nproc) and runs the same suite through
+    ValidationSuite::run.  It needs cargo, the reference's sources and an OFFLINE crate registry (datafusion 50.3,
+    arrow 56.2, ...): probed here, absent in the builder's image and on its GPU boxes -- then (None, why) comes back
+    and the caller reports the oracle's restatement instead (`kind: "port"`)."""
+    import shutil
+    import subprocess
+
+    crate = os.path.join(ROOT, "baselines", "term_guard_cpu")
+    cargo = shutil.which("cargo")
+    if not cargo:
+        return None, "no cargo on PATH"
+    ref = os.environ.get("TGX_TERM_GUARD_PATH", "/root/reference/term-guard")
+    if not os.path.exists(os.path.join(ref, "Cargo.toml")):
+        return None, "term-guard sources not found (TGX_TERM_GUARD_PATH)"
+    home = os.environ.get("TGX_CARGO_HOME", os.environ.get("CARGO_HOME", os.path.expanduser("~/.cargo")))
+    if not (os.path.isdir(os.path.join(crate, "vendor")) or os.path.isdir(os.path.join(home, "registry", "cache"))):
+        return None, "no offline crate registry (vendor/ or $CARGO_HOME/registry)"
+    env = dict(os.environ, CARGO_HOME=home)
+    cmd = [cargo, "build", "--release", "--offline", "--manifest-path", os.path.join(crate, "Cargo.toml")]
+    if ref != "/root/reference/term-guard":
+        cmd += ["--config", 'patch.crates-io.term-guard.path="%s"' % ref]
+    try:
+        b = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+        if b.returncode != 0:
+            return None, "cargo build failed: " + b.stderr.strip().splitlines()[-1][:200]
+        exe = os.path.join(crate, "target", "release", "term_guard_cpu")
+        r = subprocess.run([exe, str(sample_rows), str(seed)], capture_output=True, text=True, timeout=1800)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        got = json.loads(line)
+    except (OSError, subprocess.TimeoutExpired, IndexError, ValueError) as e:
+        return None, "term_guard_cpu did not run: %r" % (e,)
+    return {"value": got["rows_per_s"], "unit": "rows/s", "cores": got["cores"], "kind": "reference",
+            "verified": bool(got.get("total_checks")),
+            "sample": "term-guard's ValidationSuite::run over a MemTable of the first %d rows of the same table "
+                      "(%d checks, %.2f s), baselines/term_guard_cpu" % (got["rows"], got["total_checks"], got["seconds"])}, None
+
+
 def cpu_baseline(torch, layout, unique_cols, table, sample_rows):
     """The proxy CPU baseline of SURVEY.md section 8d: the oracle's restatement of the reference semantics (NOT
     term-guard itself, which cannot be built here: no cargo / crates) on ALL host cores -- row-range partitions,
@@ -308,8 +347,11 @@ def main():
                                                "aggregates come out of their DISTINCT pass (partition_kernel)"},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(torch, layout, unique_cols, table,
-                                               min(args.cpu_sample_rows, n_local))
+            sample = min(args.cpu_sample_rows, n_local)
+            ref_line, why_not = reference_cpu_baseline(sample, args.seed)  # term-guard itself, where it can be built
+            out["cpu_baseline"] = ref_line or cpu_baseline(torch, layout, unique_cols, table, sample)
+            if ref_line is None:
+                out["cpu_baseline"]["reference_probe"] = why_not
         line = json.dumps(out)
     else:
         line = None

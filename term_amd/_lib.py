@@ -69,7 +69,8 @@ class _Options(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libtgx.so")
+    # TGX_LIB: another build of the same library (the host-side sanitizer build, tools/run_host_asan.sh)
+    return os.environ.get("TGX_LIB") or os.path.join(_HERE, "libtgx.so")
 
 
 def abi_symbols():
