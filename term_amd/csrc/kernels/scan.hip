@@ -708,9 +708,11 @@ __device__ __forceinline__ void como_tile_add(ComoTile &q, double a, double b, b
   b = ok ? b : 0.0;
   q.t[0] += a;
   q.t[1] += b;
-  q.t[2] += a * a;
-  q.t[3] += b * b;
-  q.t[4] += a * b;
+  // (the file is built with -ffp-contract=off: the fused form is asked for by name -- three instructions fewer per
+  //  row in an issue-bound loop, and the product enters the sum unrounded)
+  q.t[2] = __builtin_fma(a, a, q.t[2]);
+  q.t[3] = __builtin_fma(b, b, q.t[3]);
+  q.t[4] = __builtin_fma(a, b, q.t[4]);
 }
 __device__ __forceinline__ void como_tile_flush(ComoLane &m, ComoTile &q) {
 #pragma unroll
@@ -1090,27 +1092,24 @@ __device__ __forceinline__ void pair_body(const ScanPairDesc &P, ScanPartial *ou
   }
 }
 
-// grid = (blocks per pair, pairs); partials: [2 * pair + {0, 1}][block] for the columns, como: [pair][block]
-template <bool KLL>
-__global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(const ScanPairLaunch L, ScanPartial *__restrict__ partials,
+// grid = (blocks per pair, pairs); partials: [2 * pair + {0, 1}][block] for the columns, como: [pair][block].
+// One kernel per (x type, y type, samplers on / off): inside ONE kernel the four type combinations shared a register
+// allocation sized for the worst of them (the Int64 paths convert every value to a double) and spilled scalars to
+// lanes in every loop; a launch takes the pairs of one combination (`first`: its first pair in the launch's table).
+template <bool XF, bool YF, bool KLL>
+__global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(const ScanPairLaunch L, int first,
+                                                                ScanPartial *__restrict__ partials,
                                                                 ComomentPartial *__restrict__ como,
                                                                 const ComomentAcc *__restrict__ como_accs) {
-  const ScanPairDesc &P = L.pairs[blockIdx.y];
+  const int pair = first + (int)blockIdx.y;
+  const ScanPairDesc &P = L.pairs[pair];
   const double pvx = como_accs[P.como_acc].px, pvy = como_accs[P.como_acc].py;  // the pair's pivots (uniform)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  ScanPartial *ox = partials + ((size_t)2 * blockIdx.y) * gridDim.x + blockIdx.x;
-  ScanPartial *oy = partials + ((size_t)2 * blockIdx.y + 1) * gridDim.x + blockIdx.x;
-  ComomentPartial *oc = como + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const bool xf = P.x.is_float != 0, yf = P.y.is_float != 0;
-  if (xf && yf)
-    pair_body<true, true, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
-  else if (xf)
-    pair_body<true, false, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
-  else if (yf)
-    pair_body<false, true, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
-  else
-    pair_body<false, false, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
+  ScanPartial *ox = partials + ((size_t)2 * pair) * gridDim.x + blockIdx.x;
+  ScanPartial *oy = partials + ((size_t)2 * pair + 1) * gridDim.x + blockIdx.x;
+  ComomentPartial *oc = como + (size_t)pair * gridDim.x + blockIdx.x;
+  pair_body<XF, YF, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
 }
 
 // Folds the per-block partials of each column (fixed order => bitwise reproducible) and merges
@@ -1321,15 +1320,65 @@ void launch_scan_hll(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPa
   hipLaunchKernelGGL(hll_reduce_kernel, dim3(kHllRegisters / 4 / 256, n_cols), dim3(256), 0, stream, L, blocks_per_col);
 }
 
+// two Float64 columns: the instance needs 129 registers as the compiler allocates it freely -- one too many for four
+// waves per SIMD; held to 128 it runs at 4 instead of 3
+template <bool KLL>
+__global__ __launch_bounds__(kScanBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_pair_ff_kernel(
+    const ScanPairLaunch L, int first, ScanPartial *__restrict__ partials, ComomentPartial *__restrict__ como,
+    const ComomentAcc *__restrict__ como_accs) {
+  const int pair = first + (int)blockIdx.y;
+  const ScanPairDesc &P = L.pairs[pair];
+  const double pvx = como_accs[P.como_acc].px, pvy = como_accs[P.como_acc].py;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  ScanPartial *ox = partials + ((size_t)2 * pair) * gridDim.x + blockIdx.x;
+  ScanPartial *oy = partials + ((size_t)2 * pair + 1) * gridDim.x + blockIdx.x;
+  ComomentPartial *oc = como + (size_t)pair * gridDim.x + blockIdx.x;
+  pair_body<true, true, KLL>(P, ox, oy, oc, wave, lane, pvx, pvy);
+}
+
+template <bool XF, bool YF>
+static void launch_scan_pairs_of(const ScanPairLaunch &L, int first, int count, int blocks_per_pair, size_t lds_bytes,
+                                 ScanPartial *d_partials, void *d_como_partials, const ComomentAcc *d_como_accs,
+                                 hipStream_t stream) {
+  if (XF && YF) {
+    if (lds_bytes)
+      hipLaunchKernelGGL(scan_pair_ff_kernel<true>, dim3(blocks_per_pair, count), dim3(kScanBlock), lds_bytes, stream, L,
+                         first, d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
+    else
+      hipLaunchKernelGGL(scan_pair_ff_kernel<false>, dim3(blocks_per_pair, count), dim3(kScanBlock), 0, stream, L, first,
+                         d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
+    return;
+  }
+  if (lds_bytes)
+    hipLaunchKernelGGL((scan_pair_kernel<XF, YF, true>), dim3(blocks_per_pair, count), dim3(kScanBlock), lds_bytes, stream,
+                       L, first, d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
+  else
+    hipLaunchKernelGGL((scan_pair_kernel<XF, YF, false>), dim3(blocks_per_pair, count), dim3(kScanBlock), 0, stream, L,
+                       first, d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
+}
+
+// the pairs arrive grouped by type combination (tgx_update sorts them): one launch per run of equal combinations
 void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair, size_t lds_bytes,
                        ScanPartial *d_partials, void *d_como_partials, const ComomentAcc *d_como_accs,
                        hipStream_t stream) {
-  if (lds_bytes)
-    hipLaunchKernelGGL(scan_pair_kernel<true>, dim3(blocks_per_pair, n_pairs), dim3(kScanBlock), lds_bytes, stream, L,
-                       d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
-  else
-    hipLaunchKernelGGL(scan_pair_kernel<false>, dim3(blocks_per_pair, n_pairs), dim3(kScanBlock), 0, stream, L,
-                       d_partials, (ComomentPartial *)d_como_partials, d_como_accs);
+  int first = 0;
+  while (first < n_pairs) {
+    const bool xf = L.pairs[first].x.is_float != 0, yf = L.pairs[first].y.is_float != 0;
+    int count = 1;
+    while (first + count < n_pairs && (L.pairs[first + count].x.is_float != 0) == xf &&
+           (L.pairs[first + count].y.is_float != 0) == yf)
+      count++;
+    if (xf && yf)
+      launch_scan_pairs_of<true, true>(L, first, count, blocks_per_pair, lds_bytes, d_partials, d_como_partials, d_como_accs, stream);
+    else if (xf)
+      launch_scan_pairs_of<true, false>(L, first, count, blocks_per_pair, lds_bytes, d_partials, d_como_partials, d_como_accs, stream);
+    else if (yf)
+      launch_scan_pairs_of<false, true>(L, first, count, blocks_per_pair, lds_bytes, d_partials, d_como_partials, d_como_accs, stream);
+    else
+      launch_scan_pairs_of<false, false>(L, first, count, blocks_per_pair, lds_bytes, d_partials, d_como_partials, d_como_accs, stream);
+    first += count;
+  }
 }
 
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,

@@ -2058,6 +2058,10 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
       // COMOMENTS pairs: both columns and their co-moments from one read
       if (!fused_pairs.empty()) {
         const int n = (int)fused_pairs.size();
+        // grouped by (x type, y type): one launch of the kernel instance of each combination (kernels/scan.hip)
+        std::stable_sort(fused_pairs.begin(), fused_pairs.end(), [](const FusedPair &a, const FusedPair &b) {
+          return 2 * a.dx.is_float + a.dy.is_float > 2 * b.dx.is_float + b.dy.is_float;
+        });
         ScanPairLaunch PL;
         ScanLaunch RL;  // the same columns as the reduce kernel wants them: [2 k] = x, [2 k + 1] = y
         ComomentLaunch CL;
