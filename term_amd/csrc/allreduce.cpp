@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -349,12 +350,41 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     TGX_TRY(state_init_device(st, err));
   }
   hipStream_t s = st->device_ready ? st->stream : nullptr;
+  // Facts and key sets travel on a SECOND stream that waits only for the key columns' uniqueness passes
+  // (tgx_update records `keys_ready` right after them and queues the scan of the other columns behind): the exchange
+  // -- range / 8 bytes per rank and dense key column over xGMI, three collective latencies -- then runs while the
+  // state's own stream is still scanning.  Every helper below works on `st->stream`, so the state borrows the second
+  // stream for the two phases (StreamLoan) and the two are joined by an event before the states are packed.
+  const bool has_spearman_tasks = plan->spearman && spearman_num_tasks(plan) > 0;
+  const bool overlap = comm->ops.device_buffers && st->device_ready && st->keys_ready_recorded && nd > 0 &&
+                       !has_spearman_tasks && getenv("TGX_NO_EXCHANGE_OVERLAP") == nullptr;
+  st->exchange_expected = comm->ops.device_buffers != 0 && nd > 0;
+  struct StreamLoan {
+    tgx_state *st;
+    hipStream_t own;
+    bool on = false;
+    ~StreamLoan() {
+      if (on) st->stream = own;
+    }
+  } loan{st, st->stream};
+  if (overlap) {
+    if (!st->aux_stream) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (hi is the numerically lowest = most urgent)
+      HIP_TRY(hipStreamCreateWithPriority(&st->aux_stream, hipStreamNonBlocking, hi));
+      HIP_TRY(hipEventCreateWithFlags(&st->aux_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamWaitEvent(st->aux_stream, st->keys_ready, 0));
+    st->stream = st->aux_stream;
+    loan.on = true;
+    s = st->aux_stream;
+  }
 
   // ---- 0. SPEARMAN: ranks over the union of the ranks' pairs (a distributed sort, spearman_device.cpp) -----------
   // Rank-based states do not merge (the reference's neither: analyzers/advanced/correlation.rs:103-109), so their
   // results are computed here and carried past the reset + merge below by hand.
   std::vector<SpearmanResolved> spearman_results;
-  const bool has_spearman = plan->spearman && spearman_num_tasks(plan) > 0;
+  const bool has_spearman = has_spearman_tasks;
   if (has_spearman) {
     SpearmanExchange X;
     X.rank = R;
@@ -597,6 +627,13 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     ds.partitioned = true;
   }
 
+  if (loan.on) {  // the state's own stream goes on only after the exchange; the host has not waited for either
+    HIP_TRY(hipEventRecord(st->aux_done, st->aux_stream));
+    st->stream = loan.own;
+    loan.on = false;
+    s = st->stream;
+    HIP_TRY(hipStreamWaitEvent(st->stream, st->aux_done, 0));
+  }
   // ---- 3. the packed partial states: one all-gather, folded in rank order ----------------------------------------
   size_t len = 0;
   std::vector<uint8_t> blob;

@@ -475,6 +475,14 @@ struct tgx_state {
   void *spearman = nullptr;  // tgx::SpearmanState (spearman_device.cpp)
 
   tgx::Coalescer coalesce;
+  // cross-rank overlap (allreduce.cpp): `keys_ready` is recorded right after the key columns' uniqueness passes of an
+  // update; tgx_allreduce runs its facts round and the key-set exchange on `aux_stream` behind that event while the
+  // state's own stream is still scanning, and joins the two with `aux_done`
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t keys_ready = nullptr, aux_done = nullptr;
+  bool keys_ready_recorded = false;  // since the last reset, and standing for EVERY key set of the plan
+  int64_t passes = 0;                // fused passes (batches or flushes) with rows since the last reset
+  bool exchange_expected = false;    // the state has been through tgx_allreduce: its scans leave room for the exchange
   bool profiling = false;
   std::map<std::string, tgx::ProfileEntry> profile;
 };

@@ -549,6 +549,9 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
     if (co.snap_host[k]) (void)hipHostFree(co.snap_host[k]);
   }
   if (st->h_pinned) (void)hipHostFree(st->h_pinned);
+  if (st->keys_ready) (void)hipEventDestroy(st->keys_ready);
+  if (st->aux_done) (void)hipEventDestroy(st->aux_done);
+  if (st->aux_stream) (void)hipStreamDestroy(st->aux_stream);
   if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
   delete st;
 }
@@ -570,6 +573,8 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   bind_thread();
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   coalesce_drop(st);
+  st->keys_ready_recorded = false;
+  st->passes = 0;
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
   st->ptr_tables.clear();
   // host side back to the identity; device buffers are kept and re-zeroed (no hipFree / hipMalloc)
@@ -887,14 +892,14 @@ static void fill_scan_desc(const tgx_column &c, bool variance, const double *piv
   d->n_tiles = n_tiles;
 }
 
-static int scan_blocks_for(const ScanColDesc &d, int n_cols_in_launch) {
+static int scan_blocks_for(const ScanColDesc &d, int n_cols_in_launch, int per_cu = 8) {
   int64_t want;
   if (d.n_tiles > 0)
     want = (d.n_tiles + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);  // >= 4 tiles per wave
   else
     want = (d.length + kScanBlock * 8 - 1) / (kScanBlock * 8);
   // (4 .. 12 workgroups per CU all measured 20.7-22.5 ms on the 1 G x 16 scan: HBM-bound, not occupancy-bound)
-  int cap = std::max(32, (g_ctx.n_cu * 8) / std::max(1, n_cols_in_launch));
+  int cap = std::max(32, (g_ctx.n_cu * per_cu) / std::max(1, n_cols_in_launch));
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (int)want;
@@ -1910,6 +1915,28 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
           !plan->scan[t.scan_slot].variance && pair_of_col[t.column] < 0 && kll_on_col[t.column] < 0)
         stats_by_partition[t.scan_slot] = (int)q;
     }
+    // ---- the key columns' uniqueness passes go FIRST (numeric keys: everything they need is decided) and an event
+    // marks their end: across ranks the exchange of the key sets (tgx_allreduce) can then run on a second stream
+    // while the scan of the other columns below is still running (the >= 6x target is set by the exchange)
+    std::vector<char> distinct_done(plan->distinct.size(), 0);
+    for (size_t q = 0; q < plan->distinct.size(); q++) {
+      const DistinctTask &t = plan->distinct[q];
+      if (!t.tuple.empty() || distinct_idle(q) || !is_numeric(dev[t.column].type) || dev[t.column].length == 0) continue;
+      const int stats_slot = (t.scan_slot >= 0 && stats_by_partition[t.scan_slot] == (int)q) ? t.scan_slot : -1;
+      TGX_TRY(distinct_update(st, q, dev[t.column], err, nullptr, &dprep[q], stats_slot, &columns[t.column]));
+      distinct_done[q] = 1;
+    }
+    if (!st->keys_ready) HIP_TRY(hipEventCreateWithFlags(&st->keys_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(st->keys_ready, st->stream));
+    // (the event stands for the key sets only when every key set of the plan was touched before it: string,
+    //  dictionary and tuple sets are updated further down, behind the scan)
+    bool all_early = true;
+    for (size_t q = 0; q < plan->distinct.size(); q++) all_early &= distinct_done[q] || distinct_idle(q);
+    st->keys_ready_recorded = all_early && (st->passes == 0 || st->keys_ready_recorded);
+    st->passes++;
+    // (a state that takes part in exchanges leaves two workgroup slots per CU to the second stream's kernels: the
+    //  scan is HBM-bound from 4 workgroups per CU upwards)
+    const int scan_per_cu = st->exchange_expected ? 6 : 8;
     // ---- numeric scan: all columns of the batch in launches of <= kMaxColsPerLaunch ----
     {
       std::vector<ScanColDesc> descs, kll_descs, hll_descs;
@@ -1985,7 +2012,7 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
         for (int k = 0; k < n; k++) {
           L.cols[k] = descs[c0 + k];
           L.acc_index[k] = index[c0 + k];
-          blocks = std::max(blocks, scan_blocks_for(L.cols[k], n));
+          blocks = std::max(blocks, scan_blocks_for(L.cols[k], n, scan_per_cu));
           chunk_bytes += (uint64_t)L.cols[k].length * (L.cols[k].elem32 ? 4 : 8) +
                          (L.cols[k].validity ? (uint64_t)(L.cols[k].length + 7) / 8 : 0);
           chunk_var |= L.cols[k].want_variance != 0;
@@ -2221,7 +2248,7 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
     TGX_TRY(regex_update(st, dev.data(), err, &fuse));
     std::map<int, bool> fuse_done;
     for (size_t s = 0; s < plan->distinct.size(); s++)
-      if (distinct_idle(s)) {
+      if (distinct_idle(s) || distinct_done[s]) {
         continue;
       } else if (plan->distinct[s].tuple.empty()) {
         const int col = plan->distinct[s].column;
