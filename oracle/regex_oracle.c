@@ -99,7 +99,7 @@ static int cls_table(cls_t *c, const char *name) {
 }
 
 /* ---------------------------------------------------------------- AST */
-enum { N_EMPTY, N_CLASS, N_START, N_END, N_CAT, N_ALT, N_REP };
+enum { N_EMPTY, N_CLASS, N_START, N_END, N_BOL, N_EOL, N_WORDB, N_NWORDB, N_CAT, N_ALT, N_REP };
 typedef struct node {
   int kind;
   cls_t cls;
@@ -130,6 +130,8 @@ static void node_free(node_t *n) {
 
 typedef struct {
   int i, s, x;
+  int m;      /* (?m): ^ / $ also match after / before a line feed */
+  int ascii;  /* (?-u): \w \d \s \b \B are the ASCII ones */
 } flags_t;
 
 typedef struct {
@@ -138,6 +140,7 @@ typedef struct {
   int failed;
   char msg[200];
   int depth;
+  int ascii; /* the (?-u) flag of the group being parsed (class_escape has no flags argument) */
 } parser_t;
 
 static int p_fail(parser_t *ps, const char *m) {
@@ -264,6 +267,15 @@ static int unicode_prop(parser_t *ps, const char *name, cls_t *out) {
 /* handles \d \D \s \S \w \W \p \P after the backslash char `c` has been consumed; 1 = was a class */
 static int class_escape(parser_t *ps, uint32_t c, cls_t *out, int *is_class) {
   *is_class = 1;
+  if (ps->ascii) { /* (?-u): ASCII Perl classes; the negated ones could match invalid UTF-8 (regex-syntax rejects them) */
+    switch (c) {
+      case 'd': cls_add(out, '0', '9'); return 1;
+      case 's': cls_add(out, '\t', '\r'); cls_add(out, ' ', ' '); cls_norm(out); return 1;
+      case 'w': cls_add(out, '0', '9'); cls_add(out, 'A', 'Z'); cls_add(out, '_', '_'); cls_add(out, 'a', 'z'); cls_norm(out); return 1;
+      case 'D': case 'S': case 'W': case 'p': case 'P': return p_fail(ps, "negated / Unicode classes under (?-u)");
+      default: break;
+    }
+  }
   switch (c) {
     case 'd': cls_table(out, "perl_digit"); return 1;
     case 'D': cls_table(out, "perl_digit"); cls_negate(out); return 1;
@@ -360,10 +372,62 @@ static int class_item(parser_t *ps, uint32_t *cp, cls_t *cs, int *is_class) {
   return 1;
 }
 
+/* a && b as the complement of (not a) union (not b) */
+static void cls_intersect(cls_t *a, const cls_t *b) {
+  cls_t nb = {0, 0, 0};
+  cls_union(&nb, b);
+  cls_norm(&nb);
+  cls_negate(&nb);
+  cls_negate(a);
+  cls_union(a, &nb);
+  cls_norm(a);
+  cls_negate(a);
+  free(nb.r);
+}
+/* regex-syntax's class set operations: && -- ~~ bind weaker than the union of adjacent items, left to right */
+static void cls_apply(cls_t *result, int op, cls_t *acc, const flags_t *f) {
+  cls_norm(acc);
+  if (f->i) cls_fold(acc);
+  if (op == 0) {
+    free(result->r);
+    *result = *acc;
+    acc->r = NULL;
+    acc->n = acc->cap = 0;
+    return;
+  }
+  if (op == '&') {
+    cls_intersect(result, acc);
+  } else if (op == '-') {
+    cls_t nb = {0, 0, 0};
+    cls_union(&nb, acc);
+    cls_norm(&nb);
+    cls_negate(&nb);
+    cls_intersect(result, &nb);
+    free(nb.r);
+  } else { /* ~~ : (a or b) minus (a and b) */
+    cls_t both = {0, 0, 0}, any = {0, 0, 0};
+    cls_union(&both, result);
+    cls_norm(&both);
+    cls_intersect(&both, acc);
+    cls_union(&any, result);
+    cls_union(&any, acc);
+    cls_norm(&any);
+    cls_negate(&both);
+    cls_intersect(&any, &both);
+    free(result->r);
+    *result = any;
+    free(both.r);
+  }
+  free(acc->r);
+  acc->r = NULL;
+  acc->n = acc->cap = 0;
+}
+
 static int parse_class(parser_t *ps, const flags_t *f, cls_t *out) {
+  ps->ascii = f->ascii;
   ps->pos++; /* [ */
-  int neg = p_eat(ps, '^'), first = 1;
-  cls_t acc = {0, 0, 0};
+  int neg = p_eat(ps, '^'), first = 1, pending_op = 0;
+  cls_t acc = {0, 0, 0}, result = {0, 0, 0};
   for (;;) {
     if (p_eof(ps)) {
       free(acc.r);
@@ -406,8 +470,10 @@ static int parse_class(parser_t *ps, const flags_t *f, cls_t *out) {
     }
     if ((c == '&' && p_peek(ps, 1) == '&') || (c == '-' && p_peek(ps, 1) == '-') ||
         (c == '~' && p_peek(ps, 1) == '~')) {
-      free(acc.r);
-      return p_fail(ps, "class set operations are not supported");
+      cls_apply(&result, pending_op, &acc, f);
+      pending_op = (int)c;
+      ps->pos += 2;
+      continue;
     }
     uint32_t lo = 0;
     int is_class = 0;
@@ -422,11 +488,7 @@ static int parse_class(parser_t *ps, const flags_t *f, cls_t *out) {
       free(cs.r);
       continue;
     }
-    if (p_peek(ps, 0) == '-' && p_peek(ps, 1) != ']' && !p_eof(ps)) {
-      if (p_peek(ps, 1) == '-') {
-        free(acc.r);
-        return p_fail(ps, "class set operations are not supported");
-      }
+    if (p_peek(ps, 0) == '-' && p_peek(ps, 1) != ']' && p_peek(ps, 1) != '-' && !p_eof(ps)) {
       ps->pos++;
       uint32_t hi = 0;
       int hic = 0;
@@ -446,10 +508,9 @@ static int parse_class(parser_t *ps, const flags_t *f, cls_t *out) {
       cls_add(&acc, lo, lo);
     }
   }
-  cls_norm(&acc);
-  if (f->i) cls_fold(&acc);
-  if (neg) cls_negate(&acc);
-  *out = acc;
+  cls_apply(&result, pending_op, &acc, f);
+  if (neg) cls_negate(&result);
+  *out = result;
   return 1;
 }
 
@@ -527,8 +588,8 @@ static node_t *parse_group(parser_t *ps, flags_t *f) {
         else if (c == 's') inner.s = on;
         else if (c == 'x') inner.x = on;
         else if (c == 'U' || c == 'R') { /* greediness / CRLF: no effect on is_match without (?m) */ }
-        else if (c == 'm') { if (on) { p_fail(ps, "multi-line mode is not covered by the oracle"); return NULL; } }
-        else if (c == 'u') { if (!on) { p_fail(ps, "(?-u) is not covered by the oracle"); return NULL; } }
+        else if (c == 'm') inner.m = on;
+        else if (c == 'u') inner.ascii = !on;
         else { p_fail(ps, "unrecognized flag"); return NULL; }
         ps->pos++;
       }
@@ -558,6 +619,7 @@ static node_t *parse_group(parser_t *ps, flags_t *f) {
 
 static node_t *parse_atom(parser_t *ps, flags_t *f) {
   uint32_t c = p_peek(ps, 0);
+  ps->ascii = f->ascii;
   if (c == '(') return parse_group(ps, f);
   if (c == '[') {
     node_t *n = node_new(N_CLASS);
@@ -566,6 +628,10 @@ static node_t *parse_atom(parser_t *ps, flags_t *f) {
       return NULL;
     }
     return n;
+  }
+  if (c == '.' && f->ascii) {
+    p_fail(ps, "`.` under (?-u) can match invalid UTF-8");
+    return NULL;
   }
   if (c == '.') {
     ps->pos++;
@@ -580,11 +646,11 @@ static node_t *parse_atom(parser_t *ps, flags_t *f) {
   }
   if (c == '^') {
     ps->pos++;
-    return node_new(N_START);
+    return node_new(f->m ? N_BOL : N_START);
   }
   if (c == '$') {
     ps->pos++;
-    return node_new(N_END);
+    return node_new(f->m ? N_EOL : N_END);
   }
   if (c == '*' || c == '+' || c == '?' || c == '{') {
     p_fail(ps, "repetition operator missing expression");
@@ -600,8 +666,11 @@ static node_t *parse_atom(parser_t *ps, flags_t *f) {
     if (e == 'A') return node_new(N_START);
     if (e == 'z') return node_new(N_END);
     if (e == 'b' || e == 'B') {
-      p_fail(ps, "word boundaries are not covered by the oracle");
-      return NULL;
+      if (!f->ascii) { /* Unicode word boundaries: not covered (the product does not take them either) */
+        p_fail(ps, "Unicode word boundaries are not covered by the oracle");
+        return NULL;
+      }
+      return node_new(e == 'b' ? N_WORDB : N_NWORDB);
     }
     if (e >= '1' && e <= '9') {
       p_fail(ps, "backreferences are not supported");
@@ -717,7 +786,7 @@ static node_t *parse_alt(parser_t *ps, flags_t *f_in) {
 }
 
 /* ---------------------------------------------------------------- program (Pike VM) */
-enum { I_CLASS, I_SPLIT, I_JMP, I_START, I_END, I_MATCH };
+enum { I_CLASS, I_SPLIT, I_JMP, I_START, I_END, I_BOL, I_EOL, I_WORDB, I_NWORDB, I_MATCH };
 typedef struct {
   int op;
   int x, y;         /* targets / class index */
@@ -764,6 +833,10 @@ static void gen(orc_regex *re, const node_t *n) {
     case N_CLASS: emit(re, I_CLASS, add_class(re, &n->cls), 0); break;
     case N_START: emit(re, I_START, 0, 0); break;
     case N_END: emit(re, I_END, 0, 0); break;
+    case N_BOL: emit(re, I_BOL, 0, 0); break;
+    case N_EOL: emit(re, I_EOL, 0, 0); break;
+    case N_WORDB: emit(re, I_WORDB, 0, 0); break;
+    case N_NWORDB: emit(re, I_NWORDB, 0, 0); break;
     case N_CAT:
       for (int i = 0; i < n->nkid; i++) gen(re, n->kid[i]);
       break;
@@ -878,7 +951,12 @@ typedef struct {
 } tlist_t;
 
 /* follow empty-width instructions from pc; mark[] prevents revisits within one step */
-static int add_thread(const orc_regex *re, tlist_t *l, int *mark, int gen_id, int pc, int at_start, int at_end) {
+static int ascii_word(long cp) {
+  return (cp >= '0' && cp <= '9') || (cp >= 'A' && cp <= 'Z') || cp == '_' || (cp >= 'a' && cp <= 'z');
+}
+/* prev / next: the code points on either side of the position, -1 at the ends of the haystack */
+static int add_thread(const orc_regex *re, tlist_t *l, int *mark, int gen_id, int pc, long prev, long next) {
+  const int at_start = prev < 0, at_end = next < 0;
   /* iterative DFS; a pc is marked when pushed, so the stack never holds more than re->n entries */
   int *stack = (int *)malloc((size_t)(re->n + 1) * sizeof(int));
   int sp = 0, matched = 0;
@@ -905,6 +983,18 @@ static int add_thread(const orc_regex *re, tlist_t *l, int *mark, int gen_id, in
       case I_END:
         if (at_end) PUSH(p + 1);
         break;
+      case I_BOL: /* (?m)^ : at the start or after a line feed */
+        if (at_start || prev == '\n') PUSH(p + 1);
+        break;
+      case I_EOL: /* (?m)$ : at the end or before a line feed */
+        if (at_end || next == '\n') PUSH(p + 1);
+        break;
+      case I_WORDB: /* (?-u:\b) */
+        if (ascii_word(prev) != ascii_word(next)) PUSH(p + 1);
+        break;
+      case I_NWORDB:
+        if (ascii_word(prev) == ascii_word(next)) PUSH(p + 1);
+        break;
       case I_MATCH: matched = 1; break;
       default: l->pc[l->n++] = p; break;
     }
@@ -928,7 +1018,8 @@ int orc_regex_is_match(const orc_regex *re, const uint8_t *s, size_t len) {
     /* re-close survivors is unnecessary: they were closed when added; but a fresh thread must not
        duplicate them, so mark the survivors first */
     for (int k = 0; k < cur.n; k++) mark[cur.pc[k]] = gen_id;
-    if (add_thread(re, &cur, mark, gen_id, 0, i == 0, i == n)) matched = 1;
+    const long prev = i > 0 ? (long)cp[i - 1] : -1, next = i < n ? (long)cp[i] : -1;
+    if (add_thread(re, &cur, mark, gen_id, 0, prev, next)) matched = 1;
     if (matched || i == n) break;
     /* step over cp[i] */
     nxt.n = 0;
@@ -936,7 +1027,7 @@ int orc_regex_is_match(const orc_regex *re, const uint8_t *s, size_t len) {
     for (int k = 0; k < cur.n && !matched; k++) {
       const inst_t *in = &re->prog[cur.pc[k]];
       if (in->op == I_CLASS && cls_has(&re->classes[in->x], cp[i]))
-        if (add_thread(re, &nxt, mark, gen_id, cur.pc[k] + 1, 0, i + 1 == n)) matched = 1;
+        if (add_thread(re, &nxt, mark, gen_id, cur.pc[k] + 1, (long)cp[i], i + 1 < n ? (long)cp[i + 1] : -1)) matched = 1;
     }
     tlist_t t = cur;
     cur = nxt;

@@ -50,6 +50,28 @@ ClassSet negate(ClassSet c) {
   return out;
 }
 
+// class set operations of regex-syntax: [a&&b] [a--b] [a~~b] (operands are normalised)
+ClassSet intersect(const ClassSet &a, const ClassSet &b) {
+  ClassSet out;
+  size_t i = 0, j = 0;
+  while (i < a.size() && j < b.size()) {
+    const uint32_t lo = std::max(a[i].lo, b[j].lo), hi = std::min(a[i].hi, b[j].hi);
+    if (lo <= hi) out.push_back({lo, hi});
+    if (a[i].hi < b[j].hi)
+      i++;
+    else
+      j++;
+  }
+  return out;
+}
+ClassSet difference(const ClassSet &a, const ClassSet &b) { return intersect(a, negate(b)); }
+ClassSet symmetric_difference(const ClassSet &a, const ClassSet &b) {
+  ClassSet u = a;
+  u.insert(u.end(), b.begin(), b.end());
+  normalize(u);
+  return difference(u, intersect(a, b));
+}
+
 bool contains(const ClassSet &c, uint32_t cp) {
   size_t lo = 0, hi = c.size();
   while (lo < hi) {
@@ -86,7 +108,8 @@ bool table_lookup(const std::string &name, ClassSet *out) {
 
 // ------------------------------------------------------------------------------------------- AST
 struct Node {
-  enum Kind { kEmpty, kClass, kStart, kEnd, kConcat, kAlt, kRepeat } kind = kEmpty;
+  // kLineStart / kLineEnd: `^` / `$` under (?m); kWordB / kNotWordB: ASCII word boundaries (`\b` / `\B` under (?-u))
+  enum Kind { kEmpty, kClass, kStart, kEnd, kLineStart, kLineEnd, kWordB, kNotWordB, kConcat, kAlt, kRepeat } kind = kEmpty;
   ClassSet cls;
   std::vector<std::unique_ptr<Node>> kids;
   int min = 0, max = 0;  // kRepeat; max < 0 = unbounded
@@ -101,6 +124,9 @@ NodeP mk(Node::Kind k) {
 
 struct Flags {
   bool i = false, s = false, x = false, swap_greed = false;
+  bool m = false;   // multi-line: ^ / $ also match after / before a line feed
+  bool u = true;    // Unicode mode; (?-u) makes \w \d \s \b ASCII (only forms that cannot match invalid UTF-8 are taken)
+  bool crlf = false;
 };
 
 struct Parser {
@@ -312,6 +338,10 @@ struct Parser {
     }
     if (c == '.') {
       pos++;
+      if (!f.u) {
+        fail(kUnsupported, "`.` under (?-u) can match invalid UTF-8; not supported by the GPU engine");
+        return nullptr;
+      }
       NodeP n = mk(Node::kClass);
       if (f.s)
         n->cls.push_back({0, kMaxCp});
@@ -321,11 +351,11 @@ struct Parser {
     }
     if (c == '^') {
       pos++;
-      return mk(Node::kStart);
+      return mk(f.m ? Node::kLineStart : Node::kStart);
     }
     if (c == '$') {
       pos++;
-      return mk(Node::kEnd);
+      return mk(f.m ? Node::kLineEnd : Node::kEnd);
     }
     if (c == '*' || c == '+' || c == '?') {
       fail(kInvalid, "repetition operator missing expression");
@@ -379,19 +409,9 @@ struct Parser {
             case 's': inner.s = on; break;
             case 'x': inner.x = on; break;
             case 'U': inner.swap_greed = on; break;
-            case 'R': break;  // CRLF mode only changes multi-line anchors
-            case 'm':
-              if (on) {
-                fail(kUnsupported, "multi-line mode (?m) is not supported by the GPU engine");
-                return nullptr;
-              }
-              break;
-            case 'u':
-              if (!on) {
-                fail(kUnsupported, "(?-u) byte-oriented mode is not supported by the GPU engine");
-                return nullptr;
-              }
-              break;
+            case 'R': inner.crlf = on; break;  // CRLF mode only changes multi-line anchors
+            case 'm': inner.m = on; break;
+            case 'u': inner.u = on; break;
             default:
               fail(kInvalid, "unrecognized flag");
               return nullptr;
@@ -400,6 +420,10 @@ struct Parser {
         }
         if (!any && !neg && peek() == ')') {
           fail(kInvalid, "missing flags");  // "(?)"
+          return nullptr;
+        }
+        if (inner.m && inner.crlf) {
+          fail(kUnsupported, "CRLF multi-line mode (?mR) is not supported by the GPU engine");
           return nullptr;
         }
         if (eat(')')) {
@@ -470,6 +494,16 @@ struct Parser {
   // \d \w \s \p{..} and negations; returns false (without error) when `c` is not a class escape
   bool class_escape(uint32_t c, const Flags &f, ClassSet *out, bool *is_class) {
     *is_class = true;
+    if (!f.u) {  // (?-u): the ASCII Perl classes; their negations could match invalid UTF-8
+      switch (c) {
+        case 'd': out->assign(1, Range{'0', '9'}); return true;
+        case 's': *out = {{'\t', '\r'}, {' ', ' '}}; return true;
+        case 'w': *out = {{'0', '9'}, {'A', 'Z'}, {'_', '_'}, {'a', 'z'}}; return true;
+        case 'D': case 'S': case 'W': case 'p': case 'P':
+          return fail(kUnsupported, "negated / Unicode classes under (?-u) are not supported by the GPU engine");
+        default: break;
+      }
+    }
     switch (c) {
       case 'd': table_lookup("perl_digit", out); return true;
       case 'D': table_lookup("perl_digit", out); *out = negate(*out); return true;
@@ -598,8 +632,17 @@ struct Parser {
     if (c == 'A') return mk(Node::kStart);
     if (c == 'z') return mk(Node::kEnd);
     if (c == 'b' || c == 'B') {
-      fail(kUnsupported, "word boundary assertions are not supported by the GPU engine");
-      return nullptr;
+      // Unicode word boundaries look at whole characters on both sides (up to four bytes each way): not built.  The
+      // ASCII ones of (?-u) look at one byte each way and are part of the automaton (a one-byte context per state).
+      if (f.u) {
+        fail(kUnsupported, "Unicode word boundaries are not supported by the GPU engine (the ASCII ones are: (?-u:\\b))");
+        return nullptr;
+      }
+      if (peek() == '{') {
+        fail(kUnsupported, "word boundary variants \\b{...} are not supported by the GPU engine");
+        return nullptr;
+      }
+      return mk(c == 'b' ? Node::kWordB : Node::kNotWordB);
     }
     if (c >= '1' && c <= '9') {
       fail(kInvalid, "backreferences are not supported");
@@ -653,11 +696,28 @@ struct Parser {
     return false;
   }
 
+  // [items] with regex-syntax's set operations: `&&` (intersection), `--` (difference), `~~` (symmetric difference)
+  // bind weaker than the union of adjacent items and associate to the left: [a-z&&[^m]--x] = (([a-z] && [^m]) -- [x])
   bool parse_class(const Flags &f, ClassSet *out) {
     pos++;  // [
     bool neg = eat('^');
-    ClassSet acc;
+    if (neg && !f.u) return fail(kUnsupported, "negated classes under (?-u) are not supported by the GPU engine");
+    ClassSet acc, result;
+    int pending_op = 0;  // 0 none yet, '&', '-', '~'
     bool first = true;
+    auto finish_operand = [&]() {
+      normalize(acc);
+      if (f.i) case_fold(acc);
+      if (pending_op == 0)
+        result = acc;
+      else if (pending_op == '&')
+        result = intersect(result, acc);
+      else if (pending_op == '-')
+        result = difference(result, acc);
+      else
+        result = symmetric_difference(result, acc);
+      acc.clear();
+    };
     for (;;) {
       if (eof()) return fail(kInvalid, "unclosed character class");
       uint32_t c = peek();
@@ -680,7 +740,10 @@ struct Parser {
           ClassSet pc;
           if (peek() == ':' && peek(1) == ']' && posix_class(name, &pc)) {
             pos += 2;
-            if (pneg) pc = negate(pc);
+            if (pneg) {
+              if (!f.u) return fail(kUnsupported, "negated classes under (?-u) are not supported by the GPU engine");
+              pc = negate(pc);
+            }
             acc.insert(acc.end(), pc.begin(), pc.end());
             continue;
           }
@@ -691,8 +754,12 @@ struct Parser {
         acc.insert(acc.end(), nested.begin(), nested.end());
         continue;
       }
-      if ((c == '&' && peek(1) == '&') || (c == '-' && peek(1) == '-') || (c == '~' && peek(1) == '~'))
-        return fail(kUnsupported, "character class set operations are not supported by the GPU engine");
+      if ((c == '&' && peek(1) == '&') || (c == '-' && peek(1) == '-') || (c == '~' && peek(1) == '~')) {
+        finish_operand();
+        pending_op = (int)c;
+        pos += 2;
+        continue;
+      }
       uint32_t lo;
       bool lo_is_class = false;
       ClassSet cs;
@@ -701,8 +768,7 @@ struct Parser {
         acc.insert(acc.end(), cs.begin(), cs.end());
         continue;
       }
-      if (peek() == '-' && peek(1) != ']' && !eof()) {
-        if (peek(1) == '-') return fail(kUnsupported, "character class set operations are not supported by the GPU engine");
+      if (peek() == '-' && peek(1) != ']' && peek(1) != '-' && !eof()) {
         pos++;  // -
         uint32_t hi;
         bool hi_is_class = false;
@@ -715,10 +781,9 @@ struct Parser {
         acc.push_back({lo, lo});
       }
     }
-    normalize(acc);
-    if (f.i) case_fold(acc);
-    if (neg) acc = negate(acc);
-    *out = acc;
+    finish_operand();
+    if (neg) result = negate(result);
+    *out = result;
     return true;
   }
 
@@ -748,7 +813,8 @@ struct Parser {
 
 // ------------------------------------------------------------------------------------------- NFA
 struct NState {
-  enum Type { kByte, kSplit, kEmpty, kAssertStart, kAssertEnd, kMatch } type;
+  enum Type { kByte, kSplit, kEmpty, kAssertStart, kAssertEnd, kAssertLineStart, kAssertLineEnd, kAssertWordB,
+              kAssertNotWordB, kMatch } type;
   uint8_t lo = 0, hi = 0;
   int out = -1, out1 = -1;
 };
@@ -875,6 +941,14 @@ struct Nfa {
         return add(NState::kAssertStart, next);
       case Node::kEnd:
         return add(NState::kAssertEnd, next);
+      case Node::kLineStart:
+        return add(NState::kAssertLineStart, next);
+      case Node::kLineEnd:
+        return add(NState::kAssertLineEnd, next);
+      case Node::kWordB:
+        return add(NState::kAssertWordB, next);
+      case Node::kNotWordB:
+        return add(NState::kAssertNotWordB, next);
       case Node::kClass: {
         std::vector<ByteSeq> seqs;
         utf8_sequences(n->cls, &seqs);
@@ -932,8 +1006,20 @@ struct Builder {
   std::vector<uint32_t> mark;
   uint32_t epoch = 0;
 
-  // epsilon closure of `seeds`; keeps byte / match / assert-end states
-  void closure(const std::vector<int> &seeds, bool at_start, bool at_end, std::vector<int> *out) {
+  // What a position knows about its neighbourhood.  `prev`: the byte before it -- kCtxStart (none: start of the
+  // haystack), kCtxNewline, kCtxWord ([0-9A-Za-z_]) or kCtxOther, as finely as the pattern's assertions need
+  // (ctx_of).  `next`: the byte after it when known (>= 0), kNextUnknown while the automaton has not consumed it yet,
+  // kNextEnd at the end of the haystack.
+  enum { kCtxStart = 0, kCtxNewline = 1, kCtxWord = 2, kCtxOther = 3 };
+  enum { kNextUnknown = -1, kNextEnd = -2 };
+  static bool is_word_byte(int b) {
+    return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || b == '_' || (b >= 'a' && b <= 'z');
+  }
+
+  // epsilon closure of `seeds`.  Assertions that look BEHIND (\A, (?m)^) are decided from `prev`; those that look
+  // AHEAD ($, (?m)$, \b, \B) are decided when `next` is known and otherwise stay in the set as pending states -- the
+  // transition on the next byte (or the end of the haystack) runs the closure over the set once more with it.
+  void closure(const std::vector<int> &seeds, int prev, int next, std::vector<int> *out) {
     if (mark.size() != nfa.st.size()) mark.assign(nfa.st.size(), 0);
     epoch++;
     stack.assign(seeds.begin(), seeds.end());
@@ -952,13 +1038,31 @@ struct Builder {
           stack.push_back(n.out1);
           break;
         case NState::kAssertStart:
-          if (at_start) stack.push_back(n.out);
+          if (prev == kCtxStart) stack.push_back(n.out);
+          break;
+        case NState::kAssertLineStart:
+          if (prev == kCtxStart || prev == kCtxNewline) stack.push_back(n.out);
           break;
         case NState::kAssertEnd:
-          if (at_end)
+          if (next == kNextEnd)
             stack.push_back(n.out);
-          else
+          else if (next == kNextUnknown)
             out->push_back(s);
+          break;
+        case NState::kAssertLineEnd:
+          if (next == kNextEnd || next == '\n')
+            stack.push_back(n.out);
+          else if (next == kNextUnknown)
+            out->push_back(s);
+          break;
+        case NState::kAssertWordB:
+        case NState::kAssertNotWordB:
+          if (next == kNextUnknown) {
+            out->push_back(s);
+          } else {
+            const bool boundary = (prev == kCtxWord) != (next >= 0 && is_word_byte(next));
+            if (boundary == (n.type == NState::kAssertWordB)) stack.push_back(n.out);
+          }
           break;
         case NState::kByte:
         case NState::kMatch:
@@ -1026,7 +1130,13 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
     return kUnsupported;
   }
 
-  // byte classes from every byte-range boundary
+  // which neighbourhood the pattern's assertions look at
+  bool uses_line = false, uses_word = false;
+  for (const NState &s : nfa.st) {
+    uses_line |= s.type == NState::kAssertLineStart || s.type == NState::kAssertLineEnd;
+    uses_word |= s.type == NState::kAssertWordB || s.type == NState::kAssertNotWordB;
+  }
+  // byte classes from every byte-range boundary (and from the bytes the assertions tell apart)
   bool boundary[257];
   memset(boundary, 0, sizeof(boundary));
   boundary[0] = true;
@@ -1035,6 +1145,10 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
       boundary[s.lo] = true;
       boundary[(int)s.hi + 1] = true;
     }
+  if (uses_line) boundary['\n'] = boundary['\n' + 1] = true;
+  if (uses_word)
+    for (int b = 1; b < 256; b++)
+      if (Builder::is_word_byte(b) != Builder::is_word_byte(b - 1)) boundary[b] = true;
   int ncls = 0;
   uint8_t rep[256];
   for (int b = 0; b < 256; b++) {
@@ -1046,29 +1160,45 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
   }
 
   Builder bld(nfa);
-  std::vector<int> init_unanchored, init_start;
-  bld.closure({start}, false, false, &init_unanchored);
-  bld.closure({start}, true, false, &init_start);
+  // the context a consumed byte leaves behind, no finer than the assertions need (a pattern without look-behind
+  // assertions keeps ONE context, and its automaton is the one it always was)
+  auto ctx_of = [&](int byte) -> int {
+    if (uses_line && byte == '\n') return Builder::kCtxNewline;
+    if (uses_word && Builder::is_word_byte(byte)) return Builder::kCtxWord;
+    return Builder::kCtxOther;
+  };
+  // an unanchored search may begin a match at every position: the start state's closure under each context
+  std::vector<int> init_unanchored[4];
+  for (int c = 0; c < 4; c++) bld.closure({start}, c, Builder::kNextUnknown, &init_unanchored[c]);
 
+  bool can_restart = false;
+  for (int c = 1; c < 4; c++) can_restart |= !init_unanchored[c].empty();
+  // a DFA state = (context of the byte before, set of NFA states); the context rides in front of the set as -(10 + c)
   std::map<std::vector<int>, int> ids;
   std::vector<std::vector<int>> sets;
   // ids: 0 = DEAD (empty set), 1 = MATCHED
   sets.push_back({});
   ids[{}] = 0;
   sets.push_back({-1});
-  auto intern = [&](const std::vector<int> &set) -> int {
+  auto intern = [&](int ctx, const std::vector<int> &set) -> int {
     if (bld.has_match(set)) return 1;
-    auto it = ids.find(set);
+    // an empty set is DEAD only if no later context can start a match (after a line feed (?m)^ can): states that
+    // never reach an accept are folded into DEAD by the reachability pass below either way
+    if (set.empty() && !can_restart) return 0;
+    std::vector<int> key;
+    key.reserve(set.size() + 1);
+    key.push_back(-(10 + ctx));
+    key.insert(key.end(), set.begin(), set.end());
+    auto it = ids.find(key);
     if (it != ids.end()) return it->second;
     int id = (int)sets.size();
-    ids[set] = id;
-    sets.push_back(set);
+    ids[key] = id;
+    sets.push_back(key);
     return id;
   };
-  int start_id = intern(init_start);
+  int start_id = intern(Builder::kCtxStart, init_unanchored[Builder::kCtxStart]);
   std::vector<uint16_t> table;
   std::vector<uint8_t> acc_end;
-  // accept-at-end of the start state uses both assertions at once (empty haystack)
   for (size_t cur = 0; cur < sets.size(); cur++) {
     if (sets.size() > kMaxDfaStates) {
       *msg = "pattern needs more than 20000 DFA states; not supported by the GPU engine";
@@ -1086,33 +1216,37 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
       acc_end[1] = 1;
       continue;
     }
-    const std::vector<int> set = sets[cur];
+    const int ctx = -sets[cur][0] - 10;
+    const std::vector<int> set(sets[cur].begin() + 1, sets[cur].end());
     {
+      // the haystack ends here: the pending look-ahead assertions are decided with "no next byte"
       std::vector<int> endc;
-      if ((int)cur == start_id) {
-        bld.closure({start}, true, true, &endc);
-      } else {
-        std::vector<int> seeds;
-        for (int s : set)
-          if (nfa.st[s].type == NState::kAssertEnd) seeds.push_back(nfa.st[s].out);
-        bld.closure(seeds, false, true, &endc);
-      }
+      bld.closure(set, ctx, Builder::kNextEnd, &endc);
       acc_end[cur] = bld.has_match(endc) ? 1 : 0;
     }
     for (int c = 0; c < ncls; c++) {
       const uint8_t byte = rep[c];
-      std::vector<int> seeds;
-      for (int s : set) {
-        const NState &n = nfa.st[s];
-        if (n.type == NState::kByte && n.lo <= byte && byte <= n.hi) seeds.push_back(n.out);
+      // 1. the pending look-ahead assertions of this position, now that the next byte is known
+      std::vector<int> here;
+      bld.closure(set, ctx, (int)byte, &here);
+      int id;
+      if (bld.has_match(here)) {
+        id = 1;  // matched before this byte
+      } else {
+        // 2. the byte itself, then the closure behind it (context = this byte), plus a fresh start
+        std::vector<int> seeds;
+        for (int s : here) {
+          const NState &n = nfa.st[s];
+          if (n.type == NState::kByte && n.lo <= byte && byte <= n.hi) seeds.push_back(n.out);
+        }
+        const int nctx = ctx_of(byte);
+        std::vector<int> next;
+        bld.closure(seeds, nctx, Builder::kNextUnknown, &next);
+        next.insert(next.end(), init_unanchored[nctx].begin(), init_unanchored[nctx].end());
+        std::sort(next.begin(), next.end());
+        next.erase(std::unique(next.begin(), next.end()), next.end());
+        id = intern(nctx, next);
       }
-      std::vector<int> next;
-      bld.closure(seeds, false, false, &next);
-      // unanchored search: a match may also begin at the next position
-      next.insert(next.end(), init_unanchored.begin(), init_unanchored.end());
-      std::sort(next.begin(), next.end());
-      next.erase(std::unique(next.begin(), next.end()), next.end());
-      int id = intern(next);
       table.resize(std::max(table.size(), (cur + 1) * (size_t)ncls));
       table[cur * ncls + c] = (uint16_t)id;
     }

@@ -76,7 +76,7 @@ def test_plan_validation_needs_no_device():
     with pytest.raises(T.TgxError):
         T.Plan([spec(T.COMOMENTS, 0)])  # needs column2
     with pytest.raises(T.TgxError) as e:
-        T.Plan([spec(T.REGEX_MATCH, 0, pattern="(?m)^a$")])
+        T.Plan([spec(T.REGEX_MATCH, 0, pattern=r"\bword\b")])  # Unicode word boundaries: outside the engine
     assert e.value.status == "TGX_UNSUPPORTED"  # the shim falls back to the stock SQL constraint
     p = T.Plan([spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 0), spec(T.NUMERIC_STATS, 0, flags=T.FLAG_VARIANCE)])
     assert T.lib().tgx_plan_num_specs(p.h) == 3

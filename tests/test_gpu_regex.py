@@ -177,3 +177,24 @@ def test_chunk_walk_boundaries():
                     offs, data, validity, n=len(vals) - lead, offset=lead, trim=bool(f & T.FLAG_TRIM),
                     null_is_valid=bool(f & T.FLAG_NULL_IS_VALID))
                 assert (r.total, r.matches) == (want.total, want.matches), (p, large, lead)
+
+
+@pytest.mark.parametrize("device", [True, False])
+def test_multiline_word_boundary_and_set_operation_patterns_on_gpu(device):
+    """(?m) anchors, (?-u) ASCII word boundaries / classes and class set operations (round 3): the match kernel walks
+    the automaton whose states carry the context of the byte before -- counts equal the oracle's VM on a column of
+    multi-line values, alone and as one product automaton of all patterns of the column"""
+    rng = np.random.default_rng(11)
+    words = ["foo", "food", "a foo b", "afoo", "foo_", "é foo", "fooé", "select 1", "SELECTED", "x\nfoo\ny", "abc\n123",
+             "123", "a123", "12\n345", "\n", "", "abc\n", "m", "amz", "bcx", "x\nabc", "abc", " ", "tab\there"]
+    vals = [None if rng.random() < 0.03 else rng.choice(words) + ("" if rng.random() < 0.5 else "\n" + rng.choice(words))
+            for _ in range(60_000)]
+    offs, data, validity = orc.utf8_from_list(vals)
+    pats = [r"(?m)^foo$", r"(?m)^\d+$", r"(?-u:\b)foo(?-u:\b)", r"(?i)(?-u:\b)select(?-u:\b)", r"(?m)^[a-z--m]+$",
+            r"^[a-z&&[^m]]+$", r"(?-u:\B)oo", r"(?m)^$"]
+    specs = [spec(T.REGEX_MATCH, 0, pattern=p, flags=T.FLAG_NULL_IS_VALID if k % 2 else 0) for k, p in enumerate(pats)]
+    res, _, _ = run_plan(specs, [[utf8_column(offs, data, validity, device)]])
+    for k, p in enumerate(pats):
+        want = orc.Regex(p).count_utf8(offs, data, validity, null_is_valid=bool(k % 2))
+        assert (res[k].total, res[k].matches) == (want.total, want.matches), p
+        assert 0 < res[k].matches < res[k].total, p  # (the column exercises both verdicts of every pattern)

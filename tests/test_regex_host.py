@@ -175,3 +175,45 @@ def test_product_automaton_of_several_patterns_decides_each_of_them(crosscheck, 
         assert product_group_mask(trio, [0, 0, 0], s) == (want, True), s
     with pytest.raises(T.TgxError):
         product_group_mask(["(unclosed", "a"], [0, 0], "a")
+
+
+@pytest.fixture(scope="module")
+def crosscheck_r3():
+    with open(os.path.join(ROOT, "tests", "golden", "regex_crosscheck_r3.json")) as f:
+        return json.load(f)
+
+
+def test_multiline_word_boundary_and_set_operation_vectors(crosscheck_r3):
+    """(?m) anchors, the ASCII word boundaries and Perl classes of (?-u), class set operations (&& -- ~~): the PyPI
+    `regex` truth of tests/golden/regex_crosscheck_r3.json through the oracle's VM, the product's automaton, and the
+    product automaton of groups of these patterns (the form in which a column's patterns share one walk)."""
+    by_pattern = {}
+    for c in crosscheck_r3["cases"]:
+        by_pattern.setdefault(c["pattern"], []).append(c)
+    for pat, cases in by_pattern.items():
+        rx = orc.Regex(pat)
+        assert product_validate(pat)[0] == 0, pat
+        for c in cases:
+            assert rx.is_match(c["input"]) == c["match"], ("oracle", pat, c["input"])
+            assert product_is_match(pat, c["input"]) == c["match"], ("product", pat, c["input"])
+    T.lib().tgx_regex_match_group.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                                              C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_int32), C.POINTER(_Error)]
+    pats = sorted(by_pattern)
+    grouped_any = 0
+    for g0 in range(0, len(pats) - 2, 3):
+        group = pats[g0:g0 + 3]
+        truth = {(c["pattern"], c["input"]): c["match"] for p in group for c in by_pattern[p]}
+        for s in sorted({c["input"] for p in group for c in by_pattern[p]})[::7]:
+            mask, grouped = product_group_mask(group, [0, 0, 0], s)
+            grouped_any += grouped
+            for bit, p in enumerate(group):
+                want = truth.get((p, s))
+                if want is None:  # (no vector for this pair: the oracle decides)
+                    want = orc.Regex(p).is_match(s)
+                assert bool((mask >> bit) & 1) == want, (group, s, bit)
+    assert grouped_any > 0
+    # what stays outside the engine is refused, not mis-evaluated
+    for p in crosscheck_r3["unsupported"]:
+        rc, msg = product_validate(p)
+        assert rc == 2, (p, rc, msg)
