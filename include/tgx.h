@@ -260,6 +260,17 @@ void tgx_state_destroy(tgx_state *state);
  *
  * A batch that is NOT coalesced (more than 2^16 rows, Utf8View / dictionary columns, DEVICE strings) has its kernels
  * queued on the state's stream at once, and the call returns without waiting for them, except:
+ *   - the FIRST batch (of 2^16 rows or more) an Int64 DISTINCT task sees waits for a sample of at most 2^16 of its
+ *     values (that is: for whatever the stream still holds, plus ~20 us) to lay out the key set; later batches of
+ *     the task never wait (keys outside the sampled range are counted and repaired at tgx_finalize /
+ *     tgx_state_sync / tgx_state_serialize / tgx_merge / tgx_allreduce);
+ *   - a hash key set that may have to grow reads its fill back first;
+ *   (a Utf8 / LargeUtf8 / Utf8View DISTINCT task never waits: its first batch of 2^21 rows or more -- like that of
+ *    a numeric task whose keys have no dense range -- is deduplicated in partitioned lists instead of the table, and
+ *    should a list overflow -- heavily repeated values -- the batch is read once more at the next of the calls
+ *    above: one more reason DEVICE buffers stay alive until then)
+ *   - HOST batches: buffers copied straight from the caller's memory are borrowed only until the call returns, so
+ *     it waits for the copies (small buffers travel through a pinned arena and do not). */
 tgx_status tgx_update(const tgx_plan *plan, tgx_state *state, const tgx_column *columns,
                       size_t n_columns, tgx_error *err);
 

@@ -209,6 +209,7 @@ struct tgx_plan {
   int n_columns_needed = 0;  // 1 + max column index
   // per plan column, fixed at tgx_plan_create (tgx_update runs once per 8192-row batch: nothing is allocated there)
   std::vector<char> used, reads_values, needs_wide;
+  std::vector<char> key_column;  // a single-column DISTINCT check reads it (range tracking of coalesced HOST batches)
   void *regex = nullptr;     // tgx::RegexPlan (regex_device.cpp)
   void *spearman = nullptr;  // tgx::SpearmanPlan (spearman_device.cpp)
 };
@@ -304,6 +305,9 @@ struct DistinctState {
   // batches retained here -- DEVICE views, which the caller keeps alive until tgx_finalize / tgx_state_sync
   // (include/tgx.h); HOST batches are resolved before tgx_update returns.
   bool speculative = false;
+  // the value range of the batch about to be run, when the host knows it (a coalesced flush of HOST windows)
+  bool batch_range_known = false;
+  int64_t batch_lo = 0, batch_hi = 0;
   // the views, and for each the coalescing region set it points into (-1: the caller's own memory)
   struct Retained {
     std::vector<tgx_column> cols;
@@ -370,6 +374,16 @@ struct CoalesceColumn {
   int64_t data_bytes = 0;   // strings: value bytes pending
   std::vector<CoalesceSegment> segs;
   DevBuf values[2], validity[2], data[2];  // the coalesced column, per region set
+  // Int64 key columns (a numeric DISTINCT check reads them): MIN / MAX of the pending HOST windows' non-NULL values,
+  // taken while the windows are copied -- the flush then lays the range bitmap out (or grows it) for what it is about
+  // to see instead of sampling the device copy and waiting for the answer.  Unknown once a DEVICE window is pending.
+  bool range_known = true;
+  int64_t range_lo = INT64_MAX, range_hi = INT64_MIN;
+};
+struct CoalesceCopy {
+  void *dst;
+  const void *src;
+  size_t bytes;
 };
 struct Coalescer {
   bool disabled = false;
@@ -400,6 +414,7 @@ struct Coalescer {
   hipEvent_t snap_event[2] = {nullptr, nullptr};
   bool snap_pending[2] = {false, false};
   bool flushing = false;
+  std::vector<CoalesceCopy> copy_jobs, copy_tail;  // the HOST windows of the batch being noted (scratch)
   uint64_t flushes = 0, coalesced_batches = 0;  // statistics (tgx_profile_get "coalesce_flushes" / "coalesced_batches")
 };
 
@@ -475,6 +490,7 @@ struct tgx_state {
   void *spearman = nullptr;  // tgx::SpearmanState (spearman_device.cpp)
 
   tgx::Coalescer coalesce;
+  std::vector<tgx::DevBuf> parked;  // buffers replaced while the stream may still read them; freed once it has drained
   // cross-rank overlap (allreduce.cpp): `keys_ready` is recorded right after the key columns' uniqueness passes of an
   // update; tgx_allreduce runs its facts round and the key-set exchange on `aux_stream` behind that event while the
   // state's own stream is still scanning, and joins the two with `aux_done`

@@ -10,7 +10,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include "internal.h"
 #include "kll_device.h"
@@ -313,6 +316,9 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
     P->used.assign(P->n_columns_needed, 0);
     P->reads_values.assign(P->n_columns_needed, 0);
     P->needs_wide.assign(P->n_columns_needed, 0);
+    P->key_column.assign(P->n_columns_needed, 0);
+    for (auto &t : P->distinct)
+      if (t.tuple.empty() && !t.approx_only) P->key_column[t.column] = 1;
     for (auto &t : P->scan) P->used[t.column] = P->reads_values[t.column] = 1;
     for (auto &t : P->count) P->used[t.column] = 1;
     for (auto &t : P->distinct) {
@@ -576,6 +582,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   st->keys_ready_recorded = false;
   st->passes = 0;
   if (st->device_ready) HIP_TRY(hipStreamSynchronize(st->stream));
+  st->parked.clear();
   st->ptr_tables.clear();
   // host side back to the identity; device buffers are kept and re-zeroed (no hipFree / hipMalloc)
   st->batches = 0;
@@ -1317,7 +1324,8 @@ static tgx_status pinned_readback(tgx_state *st, size_t bytes, tgx_error *err) {
 
 // does this batch of an undecided Int64 key set get its range from a sample? (see distinct_prepare_numeric)
 static bool distinct_wants_sample(const DistinctState &ds, const tgx_column &c) {
-  return ds.mode == DistinctMode::kUndecided && c.type == TGX_INT64 && !ds.has_hint && c.length >= (1 << 16);
+  return ds.mode == DistinctMode::kUndecided && c.type == TGX_INT64 && !ds.has_hint && !ds.batch_range_known &&
+         c.length >= (1 << 16);
 }
 
 // The samples of ALL key columns of the batch, queued together and read back with ONE wait: a read-back costs the
@@ -1362,6 +1370,63 @@ static tgx_status distinct_sample_all(tgx_state *st, const tgx_column *dev, tgx_
   return TGX_OK;
 }
 
+// Extends a sampled-range bitmap so that it covers [lo, hi] as well: whole 2^20-bit slices are added below and / or
+// above (the old words move by whole slices, a device copy), generously in the direction of growth -- at least the
+// old range again -- so that a key column that keeps growing costs O(log) extensions.  Only while the range stays as
+// dense as a bitmap must be (16 bits per row seen, below 2^34 values); otherwise the keys stay outliers for the repair.
+static tgx_status bitmap_grow(tgx_state *st, DistinctState &ds, bool mult, int64_t lo, int64_t hi, int64_t incoming,
+                              tgx_error *err) {
+  const uint64_t old_top = (uint64_t)ds.base + (ds.range - 1);  // (as unsigned offsets from INT64_MIN they are ordered)
+  auto u = [](int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; };
+  const bool below = u(lo) < u(ds.base), above = u(hi) > u((int64_t)old_top);
+  if (!below && !above) return TGX_OK;
+  constexpr uint64_t kSlice = 1ull << 20;
+  uint64_t add_below = 0, add_above = 0;
+  if (below) {
+    const uint64_t need = u(ds.base) - u(lo);
+    add_below = (std::max(need, ds.range) + kSlice - 1) / kSlice * kSlice;
+    if (add_below > u(ds.base)) add_below = u(ds.base) / kSlice * kSlice;  // (not below INT64_MIN)
+    if (add_below < need) return TGX_OK;
+  }
+  if (above) {
+    const uint64_t need = u(hi) - u((int64_t)old_top);
+    add_above = std::max(need, ds.range);
+    const uint64_t room = 0xFFFFFFFFFFFFFFFFull - u((int64_t)old_top);
+    if (add_above > room) add_above = room;
+    if (add_above < need) return TGX_OK;
+  }
+  const uint64_t new_range = ds.range + add_below + add_above;
+  const uint64_t rows_seen = (uint64_t)std::max<int64_t>(ds.total_rows + incoming, 1);
+  if (new_range >= (1ull << 34) || new_range / 16 > std::max<uint64_t>(rows_seen, g_ctx.distinct_hint)) {
+    // too sparse for a bitmap once extended that far: take what the batch needs and no more, if that is dense enough
+    add_below = below ? ((u(ds.base) - u(lo)) + kSlice - 1) / kSlice * kSlice : 0;
+    add_above = above ? u(hi) - u((int64_t)old_top) : 0;
+    const uint64_t tight = ds.range + add_below + add_above;
+    if (tight >= (1ull << 34) || tight / 16 > std::max<uint64_t>(rows_seen, g_ctx.distinct_hint)) return TGX_OK;
+  }
+  const uint64_t range = ds.range + add_below + add_above;
+  const size_t old_words = (size_t)ds.bitmap_words;
+  const size_t words = (size_t)(((range + kSlice - 1) >> 20) << 15) + 4;
+  const size_t shift_words = (size_t)(add_below >> 5);
+  auto regrow = [&](DevBuf &buf) -> tgx_status {
+    DevBuf bigger;
+    HIP_TRY(bigger.reserve(words * 4));
+    HIP_TRY(hipMemsetAsync(bigger.p, 0, words * 4, st->stream));
+    HIP_TRY(hipMemcpyAsync((uint32_t *)bigger.p + shift_words, buf.p, old_words * 4, hipMemcpyDeviceToDevice, st->stream));
+    // the old words are still being copied: the old buffer is parked until the stream is next drained (freeing it
+    // here would mean waiting for the flush's upload, and hipFree waits for the whole device)
+    st->parked.emplace_back(std::move(buf));
+    buf = std::move(bigger);
+    return TGX_OK;
+  };
+  TGX_TRY(regrow(ds.seen));
+  if (mult) TGX_TRY(regrow(ds.twice));
+  ds.base = (int64_t)((uint64_t)ds.base - add_below);
+  ds.range = range;
+  ds.bitmap_words = words - 4;
+  return TGX_OK;
+}
+
 static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column &c, NumericPrep *prep,
                                            tgx_error *err) {
   const DistinctTask &task = st->plan->distinct[slot];
@@ -1376,6 +1441,10 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
       have_range = true;  // the caller vouches for [lo, hi]; keys outside it are counted and reported
       lo = ds.hint_lo;
       hi = ds.hint_hi;
+    } else if (c.type == TGX_INT64 && ds.batch_range_known) {
+      have_range = true;  // a coalesced flush of HOST windows: the host saw every value on its way into the arena
+      lo = ds.batch_lo;
+      hi = ds.batch_hi;
     } else if (distinct_wants_sample(ds, c)) {
       // (a stream of small batches -- DataFusion hands out 8192 rows at a time -- goes straight to the hash set:
       // its inserts need no range, and the read-back of a sample would cost one stream synchronisation per batch)
@@ -1438,6 +1507,10 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
       ds.mode = DistinctMode::kHash;
     }
   }
+  // a later batch whose range the host knows and the bitmap does not cover (ids that grow from batch to batch): the
+  // bitmap grows instead of counting the batch's keys as outliers and repairing them through the hash set afterwards
+  if (ds.mode == DistinctMode::kBitmap && ds.speculative && !ds.partitioned && ds.batch_range_known)
+    TGX_TRY(bitmap_grow(st, ds, mult, ds.batch_lo, ds.batch_hi, c.length, err));
   if (ds.mode == DistinctMode::kBitmap) {
     bitmap_shape(ds, c.length, mult, &prep->sub_bits, &prep->key16, &prep->n_buckets, &prep->partitioned);
     if (ds.partitioned) prep->partitioned = false;  // an owned slice after tgx_allreduce: plain inserts only
@@ -2297,6 +2370,77 @@ constexpr int64_t kCoalesceFlushRows = 4 << 20;      // pending rows that trigge
 constexpr size_t kCoalesceFlushBatches = 4096;       // pending batches that trigger a flush
 constexpr size_t kCoalesceArenaMax = 128u << 20;     // pinned staging per arena turn (HOST batches)
 
+// The copy of a HOST batch's windows into the pinned arena is the only per-row work tgx_update does for a coalesced
+// batch, and one core moves about 27 GB/s: a helper thread takes half of every batch's bytes (the calling thread the
+// other half), which is what brings a stream of 8192-row batches near the PCIe rate.  The helper spins for a short
+// while after a job -- batches of a stream arrive every few microseconds, a condition-variable wake-up costs more
+// than a batch -- and then sleeps.  TGX_COPY_THREADS=0 keeps every copy on the calling thread.
+static void stream_copy(void *dst, const void *src, size_t bytes);
+namespace {
+typedef tgx::CoalesceCopy CopyJob;
+class CopyHelper {
+ public:
+  static CopyHelper *get() {
+    static CopyHelper *h = [] {
+      const char *e = getenv("TGX_COPY_THREADS");
+      if (e && e[0] == '0') return (CopyHelper *)nullptr;
+      return new CopyHelper();  // (lives as long as the process: a detached worker must not outlive its state)
+    }();
+    return h;
+  }
+  void post(const CopyJob *jobs, size_t n) {
+    jobs_ = jobs;
+    n_ = n;
+    const uint64_t ticket = posted_.load(std::memory_order_relaxed) + 1;
+    posted_.store(ticket, std::memory_order_release);
+    if (sleeping_.load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> lock(mu_);
+      cv_.notify_one();
+    }
+  }
+  void wait() {
+    const uint64_t ticket = posted_.load(std::memory_order_relaxed);
+    while (done_.load(std::memory_order_acquire) != ticket) __builtin_ia32_pause_or_nop();
+  }
+
+ private:
+  static void __builtin_ia32_pause_or_nop() {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  CopyHelper() {
+    std::thread([this] { run(); }).detach();
+  }
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      // spin for about 200 us, then sleep until the next post
+      int spins = 0;
+      while (posted_.load(std::memory_order_acquire) == seen) {
+        __builtin_ia32_pause_or_nop();
+        if (++spins > 20000) {
+          std::unique_lock<std::mutex> lock(mu_);
+          sleeping_.store(true, std::memory_order_release);
+          cv_.wait(lock, [&] { return posted_.load(std::memory_order_acquire) != seen; });
+          sleeping_.store(false, std::memory_order_release);
+          spins = 0;
+        }
+      }
+      seen = posted_.load(std::memory_order_acquire);
+      for (size_t k = 0; k < n_; k++) stream_copy(jobs_[k].dst, jobs_[k].src, jobs_[k].bytes);
+      done_.store(seen, std::memory_order_release);
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> posted_{0}, done_{0};
+  std::atomic<bool> sleeping_{false};
+  const CopyJob *jobs_ = nullptr;
+  size_t n_ = 0;
+};
+}  // namespace
+
 // a copy that does not pull the destination into the cache first (the arena is written once and read by the DMA
 // engine): glibc's memcpy takes its streaming path only for copies of several MiB
 static void stream_copy(void *dst, const void *src, size_t bytes) {
@@ -2315,6 +2459,68 @@ static void stream_copy(void *dst, const void *src, size_t bytes) {
   }
 #endif
   memcpy(dst, src, bytes);
+}
+
+// MIN / MAX of the non-NULL values of an Int64 window (row 0 = bit `bit0` of *validity).  Runs on the thread that
+// notes the batch, once per key column and batch: the plain loop is compiled a second time for AVX2 (64-bit
+// compares), taken when the CPU has it.
+#define TGX_MINMAX_BODY                                                        \
+  int64_t mn = *lo, mx = *hi;                                                  \
+  if (!validity) {                                                             \
+    for (int64_t i = 0; i < n; i++) {                                          \
+      mn = v[i] < mn ? v[i] : mn;                                              \
+      mx = v[i] > mx ? v[i] : mx;                                              \
+    }                                                                          \
+  } else {                                                                     \
+    int64_t i = 0;                                                             \
+    for (; i < n && ((bit0 + i) & 7); i++) {                                   \
+      const int64_t b = bit0 + i;                                              \
+      if ((validity[b >> 3] >> (b & 7)) & 1) {                                 \
+        mn = v[i] < mn ? v[i] : mn;                                            \
+        mx = v[i] > mx ? v[i] : mx;                                            \
+      }                                                                        \
+    }                                                                          \
+    for (; i + 8 <= n; i += 8) { /* a validity byte at a time: all-valid bytes take the branch-free loop */ \
+      const uint8_t m = validity[(bit0 + i) >> 3];                             \
+      if (m == 0xFF) {                                                         \
+        for (int k = 0; k < 8; k++) {                                          \
+          mn = v[i + k] < mn ? v[i + k] : mn;                                  \
+          mx = v[i + k] > mx ? v[i + k] : mx;                                  \
+        }                                                                      \
+      } else {                                                                 \
+        for (int k = 0; k < 8; k++)                                            \
+          if ((m >> k) & 1) {                                                  \
+            mn = v[i + k] < mn ? v[i + k] : mn;                                \
+            mx = v[i + k] > mx ? v[i + k] : mx;                                \
+          }                                                                    \
+      }                                                                        \
+    }                                                                          \
+    for (; i < n; i++) {                                                       \
+      const int64_t b = bit0 + i;                                              \
+      if ((validity[b >> 3] >> (b & 7)) & 1) {                                 \
+        mn = v[i] < mn ? v[i] : mn;                                            \
+        mx = v[i] > mx ? v[i] : mx;                                            \
+      }                                                                        \
+    }                                                                          \
+  }                                                                            \
+  *lo = mn;                                                                    \
+  *hi = mx;
+static void host_minmax_i64_plain(const int64_t *v, const uint8_t *validity, int64_t bit0, int64_t n, int64_t *lo,
+                                  int64_t *hi) {
+  TGX_MINMAX_BODY
+}
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target("avx2"))) static void host_minmax_i64_avx2(const int64_t *v, const uint8_t *validity, int64_t bit0,
+                                                                 int64_t n, int64_t *lo, int64_t *hi) {
+  TGX_MINMAX_BODY
+}
+#endif
+static void host_minmax_i64(const int64_t *v, const uint8_t *validity, int64_t bit0, int64_t n, int64_t *lo, int64_t *hi) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return host_minmax_i64_avx2(v, validity, bit0, n, lo, hi);
+#endif
+  host_minmax_i64_plain(v, validity, bit0, n, lo, hi);
 }
 
 static tgx_status coalesce_arena_ready(tgx_state *st, tgx_error *err) {
@@ -2387,9 +2593,11 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
   }
   char *ah = any_host ? (char *)co.arena_host[co.arena_cur] : nullptr;
   const char *ad = any_host ? (const char *)co.arena_dev[co.arena_cur].p : nullptr;
+  std::vector<CopyJob> &jobs = co.copy_jobs;
+  jobs.clear();
   auto to_arena = [&](const void *src, size_t bytes) -> const void * {  // returns the DEVICE twin's address
     const size_t at = (co.arena_used + 63) & ~(size_t)63;
-    stream_copy(ah + at, src, bytes);
+    jobs.push_back({ah + at, src, bytes});  // (copied below, half of the bytes by the helper thread)
     co.arena_used = at + bytes;
     return ad + at;
   };
@@ -2423,8 +2631,40 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
       const size_t ew = is_numeric32(c.type) ? 4 : 8;
       const uint8_t *v0 = (const uint8_t *)c.values + (size_t)c.offset * ew;
       sg.values = host ? to_arena(v0, (size_t)nrows * ew) : (const void *)v0;
+      if (plan->key_column[i] && c.type == TGX_INT64) {
+        if (host && cc.range_known)
+          host_minmax_i64((const int64_t *)v0, c.validity ? c.validity + (c.offset >> 3) : nullptr, c.offset & 7, nrows,
+                          &cc.range_lo, &cc.range_hi);
+        else
+          cc.range_known = false;
+      }
     }
     cc.segs.push_back(sg);
+  }
+  if (!jobs.empty()) {
+    size_t total = 0;
+    for (const CopyJob &j : jobs) total += j.bytes;
+    CopyHelper *helper = total >= (64u << 10) ? CopyHelper::get() : nullptr;
+    if (!helper) {
+      for (const CopyJob &j : jobs) stream_copy(j.dst, j.src, j.bytes);
+    } else {
+      // split at the byte midpoint (the job that straddles it is cut at a 64-byte boundary): the tail to the helper
+      size_t acc = 0, k = 0;
+      while (k < jobs.size() && acc + jobs[k].bytes <= total / 2) acc += jobs[k++].bytes;
+      std::vector<CopyJob> &tail = co.copy_tail;
+      tail.clear();
+      size_t mine_of_k = 0;
+      if (k < jobs.size()) {
+        mine_of_k = std::min(jobs[k].bytes, ((total / 2 - acc) + 63) & ~(size_t)63);
+        if (mine_of_k < jobs[k].bytes)
+          tail.push_back({(char *)jobs[k].dst + mine_of_k, (const char *)jobs[k].src + mine_of_k, jobs[k].bytes - mine_of_k});
+        for (size_t q = k + 1; q < jobs.size(); q++) tail.push_back(jobs[q]);
+      }
+      helper->post(tail.data(), tail.size());
+      for (size_t q = 0; q < k; q++) stream_copy(jobs[q].dst, jobs[q].src, jobs[q].bytes);
+      if (k < jobs.size() && mine_of_k) stream_copy(jobs[k].dst, jobs[k].src, mine_of_k);
+      helper->wait();
+    }
   }
   co.rows += nrows;
   co.batches += 1;
@@ -2573,11 +2813,27 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   co.arena_busy[ar] = true;
   co.arena_cur ^= 1;
   co.arena_used = 0;
+  // Int64 key columns whose pending windows were all HOST: the flush's value range is known exactly
+  for (size_t q = 0; q < plan->distinct.size(); q++) {
+    const DistinctTask &t = plan->distinct[q];
+    DistinctState &ds = st->distinct[q];
+    ds.batch_range_known = false;
+    if (!t.tuple.empty() || t.approx_only) continue;
+    const CoalesceColumn &cc = co.cols[t.column];
+    if (cc.type == TGX_INT64 && cc.range_known && cc.range_lo <= cc.range_hi && !cc.segs.empty()) {
+      ds.batch_range_known = true;
+      ds.batch_lo = cc.range_lo;
+      ds.batch_hi = cc.range_hi;
+    }
+  }
   // the pending list is empty from here on (update_impl may come back to tgx::coalesce_flush through a resolve)
   for (auto &cc : co.cols) {
     cc.segs.clear();
     cc.any_validity = false;
     cc.data_bytes = 0;
+    cc.range_known = true;
+    cc.range_lo = INT64_MAX;
+    cc.range_hi = INT64_MIN;
   }
   const int64_t batches_of_flush = (int64_t)co.batches;
   co.rows = 0;
@@ -2589,6 +2845,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   st->batches -= batches_of_flush;  // update_impl counts the flush as one batch: keep the caller's count
   tgx_status rc = update_impl(plan, st, views.data(), rows, err);
   st->batches += batches_of_flush - 1;
+  for (auto &ds : st->distinct) ds.batch_range_known = false;
   if (rc != TGX_OK) return rc;
   // views the key sets kept of this flush point into region set `set`
   for (size_t q = 0; q < st->distinct.size(); q++) {
@@ -2619,6 +2876,9 @@ static void coalesce_drop(tgx_state *st) {  // reset / destroy: pending batches 
     cc.segs.clear();
     cc.any_validity = false;
     cc.data_bytes = 0;
+    cc.range_known = true;
+    cc.range_lo = INT64_MAX;
+    cc.range_hi = INT64_MIN;
   }
   co.rows = 0;
   co.batches = 0;
@@ -2710,6 +2970,7 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
     if (b_como) memcpy(d_como.data(), h + b_scan + b_count, b_como);
     if (b_all) memcpy(all.data(), h + b_scan + b_count + b_como, b_all);
     st->ptr_tables.clear();
+    st->parked.clear();  // (the stream has just been drained)
     // keys that fell outside a sampled bitmap range (DistinctState::speculative): the counters just read say whether
     // any task has some -- only then is there a repair to run and its counters to read again
     bool repaired = false;

@@ -238,3 +238,35 @@ def test_pending_batches_are_seen_by_every_reader():
     assert (r[0].total, r[0].sum_i) == (50, int(v[100:150].sum()))
     e = T.State(plan)
     assert e.finalize()[0].total == 0
+
+
+@pytest.mark.parametrize("shape", ["up", "down", "both", "jump_too_far"])
+def test_host_streams_of_growing_ids_grow_the_bitmap(shape, monkeypatch):
+    """HOST batches: the host sees every key on its way into the arena, so a flush knows its value range -- the first
+    flush lays the bitmap out without sampling, later flushes whose ids lie outside it GROW it (whole slices, old
+    words moved) instead of leaving their keys to the repair; a jump that would make the bitmap too sparse stays with
+    the repair.  Exact either way."""
+    n = 600_000
+    base = np.arange(n, dtype=np.int64)
+    if shape == "up":
+        ids = base * 2 + 7_000_000
+    elif shape == "down":
+        ids = 50_000_000 - base * 3
+    elif shape == "both":
+        ids = np.where(base % 2 == 0, 10_000_000 + base, 10_000_000 - base)
+    else:
+        ids = base.copy()
+        ids[n // 2:] += 1 << 40  # the second half far away: too sparse for one bitmap
+    rng = np.random.default_rng(8)
+    ids[rng.random(n) < 0.02] = ids[3]
+    mask = rng.random(n) >= 0.03
+    vb = orc.pack_validity(mask)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.NUMERIC_STATS, 0), spec(T.COUNT, 0)])
+    st = feed(plan, [(ids, vb)], list(range(0, n, 8192)) + [n], False, {"TGX_COALESCE_FLUSH_ROWS": "70000"}, monkeypatch)
+    res = st.finalize()
+    assert st.profile_get("coalesce")["launches"] >= 5
+    d = orc.distinct_bits64(ids.view(np.uint64), vb, n=n)
+    assert (res[0].total, res[0].non_null, res[0].distinct, res[0].groups_once) == (d.total, d.non_null, d.distinct, d.groups_once)
+    o = orc.stats(ids, vb)
+    assert (res[1].min_i, res[1].max_i, res[1].sum_i) == (o.min_i, o.max_i, o.sum_i_wrapping)
