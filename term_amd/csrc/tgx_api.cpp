@@ -1848,7 +1848,6 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
                 plan->n_columns_needed - 1, n_columns);
   if (n_columns > 0 && !columns) return fail(err, TGX_INVALID_ARGUMENT, "columns is NULL");
   TGX_TRY(need_device(err));
-  bind_thread();
   int64_t nrows = 0;
   BatchTraits traits;
   TGX_TRY(update_validate(plan, st, columns, n_columns, &nrows, &traits, err));
@@ -1859,6 +1858,7 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     TGX_TRY(coalesce_append(plan, st, columns, nrows, traits, &taken, err));
     if (taken) return TGX_OK;
   }
+  bind_thread();  // (the noted-only path above makes no HIP call: it binds where it does, in the arena set-up and the flush)
   TGX_TRY(coalesce_flush(st, err));  // batches stay in order
   return update_impl(plan, st, columns, nrows, err);
 } catch (...) {
@@ -2525,6 +2525,7 @@ static void host_minmax_i64(const int64_t *v, const uint8_t *validity, int64_t b
 
 static tgx_status coalesce_arena_ready(tgx_state *st, tgx_error *err) {
   Coalescer &co = st->coalesce;
+  bind_thread();
   const int k = co.arena_cur;
   if (co.arena_busy[k]) {  // the flush that used this arena two turns ago (long done)
     HIP_TRY(hipEventSynchronize(co.arena_event[k]));
@@ -2566,7 +2567,10 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
                                   const BatchTraits &traits, bool *taken, tgx_error *err) {
   Coalescer &co = st->coalesce;
   *taken = false;
-  if (co.cols.size() != (size_t)plan->n_columns_needed) co.cols.resize(plan->n_columns_needed);
+  if (co.cols.size() != (size_t)plan->n_columns_needed) {
+    co.cols.resize(plan->n_columns_needed);
+    for (auto &cc : co.cols) cc.segs.reserve(kCoalesceFlushBatches);
+  }
   const bool any_host = traits.any_host;
   if (any_host) {
     const size_t need = coalesce_host_bytes(plan, columns, nrows);
@@ -2721,6 +2725,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   Coalescer &co = st->coalesce;
   if (co.rows == 0 || co.flushing) return TGX_OK;
   const tgx_plan *plan = st->plan;
+  bind_thread();
   TGX_TRY(state_init_device(st, err));
   struct Guard {
     Coalescer &c;
