@@ -206,6 +206,40 @@ def test_c4_plan_vs_oracle_and_over_8_ranks():
     assert len(blobs) == 1
 
 
+def test_c4_plan_with_its_spearman_pair_vs_oracle_and_over_8_ranks():
+    """SURVEY.md 8d lists a Spearman pair in C4 (timed separately in the bench): the whole plan of C4 PLUS the rank
+    correlation of its first pair in ONE plan -- one state, and row shards over 8 ranks, where the ranking is a
+    distributed sort inside tgx_allreduce; the rank sums bit-exact against the oracle (UInt64 wrapping as the reference)"""
+    n = 1_200_000 + 64
+    T.init(distinct_capacity_hint=n)
+    table = synth.make_table(LAYOUT16, 0, n, n, 0x7E570004, "cuda")
+    host = _host_table(table, n)
+    specs = c4_specs() + [spec(T.SPEARMAN, PAIRS[0][0], column2=PAIRS[0][1])]
+    plan = T.Plan(specs)
+    (a, c) = PAIRS[0]
+    want = orc.spearman_state(host[a][0], host[c][0], host[a][1], host[c][1], n=n)
+
+    def check(res, st):
+        check_c4_against_oracle(specs[:-1], res[:-1], st, host, n)
+        r = res[-1]
+        assert (r.total, r.non_null) == (n, want.n)
+        assert (r.sum_x, r.sum_y, r.sum_x2, r.sum_y2, r.sum_xy) == (want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy)
+
+    one = T.State(plan)
+    one.update(columns16(table, 0, n))
+    check(one.finalize(), one)
+    world = 8
+
+    def shards_of(rank):
+        from term_amd.distributed import shard_rows
+
+        lo, hi = shard_rows(n, world, rank)
+        return columns16(table, lo, hi - lo)
+
+    for res, st in _run_ranks(world, plan, shards_of):
+        check(res, st)
+
+
 def test_c4_full_size_properties():
     import torch
 
