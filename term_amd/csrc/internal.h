@@ -68,8 +68,7 @@ void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
 void launch_partition_outlier_stats(const OutlierStats *g, ScanPartial *partials, int at, hipStream_t stream);
 int partition_grid(int64_t length, int n_cu);  // workgroups of launch_partition (= ScanPartials it writes with stats)
 void launch_distinct_init(DistinctSample *sample, OutlierStats *outliers, hipStream_t stream);
-void launch_partition_init(unsigned long long *cursors, uint32_t n_buckets, OutlierStats *outliers,
-                           unsigned long long *totals, hipStream_t stream);
+void launch_partition_init(const PartitionParams &p, unsigned long long *totals, hipStream_t stream);
 void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream);
 void launch_distinct_outliers(const DistinctColDesc &d, int64_t base, uint64_t range, const HashSetView &t,
                               unsigned long long *d_counters, hipStream_t stream);

@@ -14,6 +14,8 @@
 // (MI355X_MICROARCH.md "Global float atomics" / SURVEY.md section 7 notes).  Counters are
 // block-reduced first: one atomicAdd per block, not per row.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdlib.h>
 
 #include "device_types.h"
@@ -250,10 +252,11 @@ __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, in
 //   pass 2   counting sort of the 20-bit sub-keys into LDS      (hook `mid` runs just before it)
 //   stores   each wave streams whole runs out, 16 bytes per lane (hook `before_stores` runs just before)
 // (the hooks are where a software-pipelined caller would request the next tile; unused today)
-template <int THREADS, int KPT, int MAXP, int PAD, bool KEY16, class MidFn, class StoreFn>
+template <int THREADS, int KPT, int MAXP, int PAD, bool KEY16, bool CLUSTERED, class MidFn, class StoreFn>
 __device__ __forceinline__ void partition_process_tile(const PartitionParams &p, uint32_t *sorted, uint32_t *hist,
                                                        uint32_t *toff, uint32_t *gbase, uint32_t *wave_sums,
-                                                       const uint32_t (&rel)[KPT], uint64_t ok, MidFn &&mid,
+                                                       uint32_t *long_runs, const uint32_t (&rel)[KPT], uint64_t ok,
+                                                       MidFn &&mid,
                                                        StoreFn &&before_stores) {
   constexpr uint32_t NW = THREADS / 64;       // waves per workgroup
   constexpr int BPT = MAXP / THREADS;         // buckets per thread in the scan
@@ -267,11 +270,46 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
   for (uint32_t b = tid; b < (uint32_t)MAXP; b += THREADS) hist[b] = 0;
+  // CLUSTERED: runs of kLongRun keys and more (a tile of keys in order is one or two runs) are streamed out by the
+  // whole workgroup, not by the one wave that owns the bucket: long_runs[0 .. n) are their buckets, [kMaxLongRuns] = n
+  constexpr uint32_t kLongRun = 1024, kMaxLongRuns = THREADS * KPT / kLongRun;
+  if (CLUSTERED && tid == 0) long_runs[kMaxLongRuns] = 0;
   __syncthreads();  // hist is zero
   // ---- pass 1: count keys per bucket ----
+  // Keys that arrive in order (ids that grow with the row number, timestamps) put the 128 consecutive rows a wave
+  // holds for one j into ONE bucket: 64 LDS atomics on one address take their turns (a tile of sorted keys cost
+  // 180 us instead of 24).  CLUSTERED (the batch looked like that to partition_init_kernel's probe): wherever a wave's
+  // valid lanes agree on the bucket it sends one add of the lane count.  `uni` remembers those j for pass 2; every
+  // term is wave-uniform, so the branches are scalar.  (A template parameter and a copy of the tile loop, not a
+  // question per tile: next to the plain passes in one loop the extra state spilled ~200 bytes per lane and cost
+  // shuffled keys 0.5 - 1.3 ms per 1 G-row column.)
+  auto wave_agrees = [&](int j, uint64_t &act, uint32_t &first, uint32_t &b0) {
+    const bool okj = (ok >> j) & 1;
+    const uint32_t b = rel[j] >> p.sub_bits;
+    act = __ballot(okj);
+    if (act == 0) return false;
+    first = (uint32_t)__builtin_ctzll(act);
+    b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)first);
+    return __ballot(okj && b != b0) == 0;
+  };
+  uint32_t uni = 0;
+  if (CLUSTERED) {
 #pragma unroll
-  for (int j = 0; j < KPT; j++)
-    if ((ok >> j) & 1) atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+    for (int j = 0; j < KPT; j++) {
+      uint64_t act;
+      uint32_t first = 0, b0 = 0;
+      if (wave_agrees(j, act, first, b0)) {
+        uni |= 1u << j;
+        if (lane == first) atomicAdd(&hist[b0], (uint32_t)__builtin_popcountll(act));
+      } else if ((ok >> j) & 1) {
+        atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KPT; j++)
+      if ((ok >> j) & 1) atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+  }
   __syncthreads();
   // ---- exclusive scan of the counts (BPT entries per thread) + one global reservation per touched bucket ----
   {
@@ -297,7 +335,9 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
       toff[b] = excl;
       hist[b] = excl;  // becomes the placement cursor of pass 2
       uint32_t g = 0;
-      if (h[k]) {
+      if (h[k] && b - p.bucket0 >= p.n_lists) {
+        g = 0xFFFFFFFFu;  // no list for this bucket: the run goes straight to the bitmap
+      } else if (h[k]) {
         const unsigned long long padded = (h[k] + (RPAD - 1u)) & ~(RPAD - 1u);
         const unsigned long long at = atomicAdd(&p.cursors[b], padded);
         // cap < 2^32 (checked on the host); a run that does not fit spills as a whole
@@ -307,6 +347,7 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
           g = 0xFFFFFFFFu;
         } else {
           g = (uint32_t)at;
+          if (CLUSTERED && h[k] >= kLongRun) long_runs[atomicAdd(&long_runs[kMaxLongRuns], 1u)] = b;
         }
       }
       gbase[b] = g;
@@ -319,11 +360,31 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   mid();
   __builtin_amdgcn_sched_barrier(0);
   // ---- pass 2: counting sort into LDS ----
+  if (CLUSTERED) {
 #pragma unroll
-  for (int j = 0; j < KPT; j++) {
-    if (!((ok >> j) & 1)) continue;
-    const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
-    sorted[pos] = rel[j] & sub_mask;
+    for (int j = 0; j < KPT; j++) {
+      const bool okj = (ok >> j) & 1;
+      if ((uni >> j) & 1) {  // one bucket for the whole wave: one cursor bump, the lanes line up behind it
+        const uint64_t act = __ballot(okj);
+        const uint32_t first = (uint32_t)__builtin_ctzll(act);
+        uint32_t at = 0;
+        if (lane == first) at = atomicAdd(&hist[rel[j] >> p.sub_bits], (uint32_t)__builtin_popcountll(act));
+        at = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)first);
+        const uint32_t before =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        if (okj) sorted[at + before] = rel[j] & sub_mask;
+      } else if (okj) {
+        const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+        sorted[pos] = rel[j] & sub_mask;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if (!((ok >> j) & 1)) continue;
+      const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+      sorted[pos] = rel[j] & sub_mask;
+    }
   }
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
@@ -358,13 +419,14 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
         const uint32_t o = __shfl(m_o[s2], src, 64), g = __shfl(m_g[s2], src, 64);
         uint32_t h = __shfl(m_h[s2], src, 64);
         if (m >= m_end) h = 0;
+        if (CLUSTERED && h >= kLongRun && g != 0xFFFFFFFFu) h = 0;  // (everybody's job, below)
         if (h == 0) continue;
         const uint32_t b = (m + 64 * s2) * NW + wave;
         if (g != 0xFFFFFFFFu) {
           const uint32_t padded = (h + (RPAD - 1u)) & ~(RPAD - 1u);
           if (KEY16) {
             // 16-byte aligned: cap and g are multiples of 32 two-byte slots
-            uint16_t *dst = (uint16_t *)p.lists + (uint64_t)b * p.cap + g;
+            uint16_t *dst = (uint16_t *)p.lists + (uint64_t)(b - p.bucket0) * p.cap + g;
             for (uint32_t i = KPL * sub; i < padded; i += KPL * LPB) {
               uint32_t k8[8];
 #pragma unroll
@@ -377,7 +439,7 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
               *(uint4 *)&dst[i] = v;
             }
           } else {
-            uint32_t *dst = p.lists + (uint64_t)b * p.cap + g;  // 16-byte aligned: cap and g are multiples of PAD
+            uint32_t *dst = p.lists + (uint64_t)(b - p.bucket0) * p.cap + g;  // 16-byte aligned: cap, g multiples of PAD
             for (uint32_t i = KPL * sub; i < padded; i += KPL * LPB) {
               uint4 v;
               v.x = i < h ? sorted[o + i] : kListPad;
@@ -399,22 +461,73 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
       }
     }
   }
+  if (CLUSTERED) {
+    const uint32_t n_long = long_runs[kMaxLongRuns];
+    for (uint32_t q = 0; q < n_long; q++) {
+      const uint32_t b = long_runs[q];
+      const uint32_t o = toff[b], h = toff[b + 1] - o, g = gbase[b];
+      const uint32_t padded = (h + (RPAD - 1u)) & ~(RPAD - 1u);
+      if (KEY16) {
+        uint16_t *dst = (uint16_t *)p.lists + (uint64_t)(b - p.bucket0) * p.cap + g;
+        for (uint32_t i = 8u * tid; i < padded; i += 8u * THREADS) {
+          uint32_t k8[8];
+#pragma unroll
+          for (uint32_t j = 0; j < 8; j++) k8[j] = sorted[o + (i + j < h ? i + j : h - 1)];
+          uint4 v;
+          v.x = k8[0] | (k8[1] << 16);
+          v.y = k8[2] | (k8[3] << 16);
+          v.z = k8[4] | (k8[5] << 16);
+          v.w = k8[6] | (k8[7] << 16);
+          *(uint4 *)&dst[i] = v;
+        }
+      } else {
+        uint32_t *dst = p.lists + (uint64_t)(b - p.bucket0) * p.cap + g;
+        for (uint32_t i = 4u * tid; i < padded; i += 4u * THREADS) {
+          uint4 v;
+          v.x = i < h ? sorted[o + i] : kListPad;
+          v.y = i + 1 < h ? sorted[o + i + 1] : kListPad;
+          v.z = i + 2 < h ? sorted[o + i + 2] : kListPad;
+          v.w = i + 3 < h ? sorted[o + i + 3] : kListPad;
+          *(uint4 *)&dst[i] = v;
+        }
+      }
+    }
+  }
   __syncthreads();
 }
 
-// key - base of one tile: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31).  Keys outside the declared
-// range (only possible with a caller-supplied range hint) are never inserted but counted, so that tgx_finalize
-// reports them instead of returning a wrong count.
-template <int KPT, bool STATS>
+// key - base of one tile: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31).  "In range" is key - base < range,
+// the test every other kernel of the key set applies (distinct_bitmap_kernel, distinct_outlier_kernel, the exports): NOT
+// "inside the last slice" -- a key between the range's end and the slice's would be in the bitmap for this pass and
+// an outlier for the repair, i.e. counted twice (groups_once came out short).  Keys outside the range (a
+// sampled range that missed them, a later batch of keys that grow, a caller-supplied hint that does not hold) are never
+// inserted but counted, so that the repair (distinct_resolve) or tgx_finalize knows; `outm` gets their positions.
+template <int KPT>
 __device__ __forceinline__ void partition_relative(const PartitionParams &p, const int64_t (&key)[KPT],
-                                                   uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out) {
+                                                   uint32_t (&rel)[KPT], uint32_t &outm) {
+  outm = 0;
 #pragma unroll
   for (int j = 0; j < KPT; j++) {
     const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
-    if (((ok >> j) & 1) && (r >> p.sub_bits) >= p.n_buckets) {
+    outm |= (r >= p.range ? 1u : 0u) << j;
+    rel[j] = (uint32_t)r;  // the 64-bit keys die here
+    asm volatile("" : "+v"(rel[j]));  // (keeps the compiler from re-deriving rel from the keys later)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// The same for a batch of keys in no particular order (the plain passes): the few keys outside a sampled range add
+// their share of the aggregates through global atomics where they are met.
+template <int KPT, bool STATS>
+__device__ __forceinline__ void partition_relative_plain(const PartitionParams &p, const int64_t (&key)[KPT],
+                                                         uint32_t (&rel)[KPT], uint64_t &ok, unsigned long long &n_out) {
+#pragma unroll
+  for (int j = 0; j < KPT; j++) {
+    const uint64_t r = (uint64_t)key[j] - (uint64_t)p.base;
+    if (((ok >> j) & 1) && r >= p.range) {
       ok &= ~(1ull << j);
       n_out++;
-      if (STATS) {  // (rare: the range was sampled from the column) its share of the column's aggregates
+      if (STATS) {
         const long long k = (long long)key[j];
         atomicMin(&p.outliers->mn, k);
         atomicMax(&p.outliers->mx, k);
@@ -429,6 +542,33 @@ __device__ __forceinline__ void partition_relative(const PartitionParams &p, con
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// The outliers' share of the column's aggregates (STATS), collected in LDS and handed on once by partition_kernel: a
+// batch that lies outside the range altogether would otherwise queue five device-wide atomics per key on the same
+// five addresses (3.9 ms per 4 Mi keys).  Their keys are read AGAIN here (from L2: the tile has just been loaded) --
+// keeping the 64-bit keys until now, or reducing inside partition_relative, spills the tile's registers on every tile
+// for the sake of a case that is rare.  MIN / MAX only bother the LDS when they would change it.
+template <int THREADS, int KPT>
+__device__ __forceinline__ void partition_outlier_stats(const PartitionParams &p, int64_t tile, bool wide, uint32_t outm,
+                                                     OutlierStats *lds_out) {
+  constexpr int kTile = THREADS * KPT;
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)p.values + p.offset);
+  const int64_t row0 = tile * kTile;
+  const bool paired = row0 + kTile <= p.length && wide;  // (the layout partition_load_tile chose)
+  unsigned long long cnt = 0;
+  for (int j = 0; j < KPT; j++) {
+    if (!((outm >> j) & 1)) continue;
+    const int64_t i = paired ? row0 + (int64_t)(j / 2) * 2 * THREADS + 2 * threadIdx.x + (j & 1)
+                             : row0 + (int64_t)j * THREADS + threadIdx.x;
+    const long long k = vals[i];
+    if (k < *(volatile long long *)&lds_out->mn) atomicMin(&lds_out->mn, k);
+    if (k > *(volatile long long *)&lds_out->mx) atomicMax(&lds_out->mx, k);
+    atomicAdd(&lds_out->lo32_sum, (unsigned long long)((uint64_t)k & 0xFFFFFFFFull));
+    atomicAdd((unsigned long long *)&lds_out->hi32_sum, (unsigned long long)(k >> 32));
+    cnt++;
+  }
+  atomicAdd(&lds_out->count, cnt);
+}
+
 // 1024 threads x 32 keys, one workgroup per CU (152 KiB of LDS); any alignment, ragged last tile.
 template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
@@ -439,6 +579,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   __shared__ uint32_t toff[MAXP + 1];    // exclusive prefix of the counts (toff[P] = tile total)
   __shared__ uint32_t gbase[MAXP];       // start of the run in the bucket's global list
   __shared__ uint32_t wave_sums[16];
+  __shared__ uint32_t long_runs[kTile / 1024 + 1];
   const bool wide = (((uintptr_t)p.values + (uintptr_t)p.offset * 8) & 15) == 0;  // 16-byte loads legal
   unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
@@ -448,12 +589,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // four LDS atomics
   __shared__ uint32_t st_min, st_max;
   __shared__ unsigned long long st_sum, st_cnt;
+  __shared__ OutlierStats st_out;  // (STATS) the keys outside the range: their aggregates go out once, at the end
   if (STATS && threadIdx.x == 0) {
     st_min = 0xFFFFFFFFu;
     st_max = 0;
     st_sum = 0;
     st_cnt = 0;
+    st_out.mn = INT64_MAX;
+    st_out.mx = INT64_MIN;
+    st_out.lo32_sum = 0;
+    st_out.hi32_sum = 0;
+    st_out.count = 0;
   }
+  if (STATS) __syncthreads();
+  auto tile_loop = [&](auto clustered_tag) __attribute__((always_inline)) {
+  constexpr bool CLUSTERED = decltype(clustered_tag)::value;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint64_t ok;
     {
@@ -462,7 +612,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
       partition_load_tile<THREADS, KPT, VALIDITY>(p, tile, wide, key, ok32);
       ok = ok32;
       n_valid += __builtin_popcountll(ok);  // every non-NULL row, whether its key lies inside the range or not
-      partition_relative<KPT, STATS>(p, key, rel, ok, n_out);
+      if (CLUSTERED) {
+        // (keys in order: a later batch of a column that grows lies outside the range as a whole)
+        uint32_t outm;
+        partition_relative<KPT>(p, key, rel, outm);
+        outm &= ok32;
+        ok = ok32 & ~outm;
+        if (__ballot(outm != 0)) {
+          n_out += __builtin_popcount(outm);
+          if (STATS && outm) partition_outlier_stats<THREADS, KPT>(p, tile, wide, outm, &st_out);
+        }
+      } else {
+        partition_relative_plain<KPT, STATS>(p, key, rel, ok, n_out);
+      }
     }
     if (STATS) {
       uint32_t tmin = 0xFFFFFFFFu, tmax = 0;
@@ -490,8 +652,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         atomicAdd(&st_cnt, tcnt);
       }
     }
-    partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16>(p, sorted, hist, toff, gbase, wave_sums, rel, ok, [] {}, [] {});
+    partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16, CLUSTERED>(p, sorted, hist, toff, gbase, wave_sums, long_runs, rel, ok,
+                                                                      [] {}, [] {});
   }
+  };
+  // the probe's verdict (partition_init_kernel): two copies of the loop, the flag picks one for the whole launch
+  if (__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]))
+    tile_loop(std::true_type{});
+  else
+    tile_loop(std::false_type{});
   if (STATS) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -510,6 +679,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         out.sum_hi = (int64_t)(sum >> 64);
       }
       p.stats[blockIdx.x] = out;
+      if (st_out.count) {
+        atomicMin(&p.outliers->mn, st_out.mn);
+        atomicMax(&p.outliers->mx, st_out.mx);
+        atomicAdd(&p.outliers->lo32_sum, st_out.lo32_sum);
+        atomicAdd((unsigned long long *)&p.outliers->hi32_sum, (unsigned long long)st_out.hi32_sum);
+        atomicAdd(&p.outliers->count, st_out.count);
+      }
     }
   }
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
@@ -602,6 +778,24 @@ __global__ __launch_bounds__(256) void distinct_outlier_kernel(DistinctColDesc d
   block_add2(n_empty, 0ull, &counters[2], &counters[kCntSpare]);
 }
 
+// Keys in order replayed against a slice: G neighbouring lanes hold the 32 keys of ONE bitmap word, and G atomics on one
+// LDS address take their turns.  The lanes of such a group merge their bits (a butterfly over the group; merging only
+// ever adds bits of the same word, so it is harmless when the group does not agree) and, when the whole group names
+// the same word, only its first lane sends the OR.  Returns whether this lane still has to send its own.
+template <int G>
+__device__ __forceinline__ bool merge_word_group(uint32_t cw, uint32_t &cb) {
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) {
+    const uint32_t ow = __shfl_xor(cw, d, 64), ob = __shfl_xor(cb, d, 64);
+    if (ow == cw) cb |= ob;
+  }
+  const uint32_t lead = lane & ~(uint32_t)(G - 1);
+  const uint64_t agree = __ballot(cw == (uint32_t)__shfl(cw, (int)lead, 64));
+  const bool whole = ((agree >> lead) & ((1ull << G) - 1)) == ((1ull << G) - 1);
+  return !whole || lane == lead;
+}
+
 // Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of
 // earlier batches and this batch's spills), replay list b with LDS atomics, store it back, and add the
 // slice's popcounts to the totals (counters[kCntDistinct] / [kCntTwice] are zeroed before the launch).
@@ -625,11 +819,17 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
   unsigned long long cnt = p.cursors[b];
   const unsigned long long limit = p.cursors[p.n_buckets + b];  // start of the first run that spilled
   if (cnt > limit) cnt = limit;
+  const bool clustered = p.cursors[2 * p.n_buckets] != 0;  // (partition_init_kernel's probe)
+  const uint32_t li = b - p.bucket0;  // (a bucket without a list has cnt == 0: its runs spilled)
+  if (li >= p.n_lists) cnt = 0;
   if (KEY16) {
     // 2-byte entries, eight per 16-byte load; runs are padded with repeats of real keys, so every entry counts
-    const uint16_t *list16 = (const uint16_t *)p.lists + (uint64_t)b * p.cap;
+    const uint16_t *list16 = (const uint16_t *)p.lists + (uint64_t)li * p.cap;
     constexpr uint64_t kStep16 = (uint64_t)kPartitionThreads * 8;
-    for (uint64_t i0 = (uint64_t)tid * 8; i0 < cnt; i0 += 4 * kStep16) {
+    // (a wave's lanes leave the loop together -- the loop bound is the wave's first entry -- so that the merge of
+    //  neighbouring lanes below always finds the whole wave)
+    for (uint64_t w0 = (uint64_t)(tid & ~63u) * 8; w0 < cnt; w0 += 4 * kStep16) {
+      const uint64_t i0 = w0 + (uint64_t)(tid & 63u) * 8;
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       u32x4 k4[4];
 #pragma unroll
@@ -638,6 +838,28 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
         k4[q] = u32x4{0, 0, 0, 0};
         if (i < cnt) k4[q] = __builtin_nontemporal_load((const u32x4 *)&list16[i]);
       }
+      if (clustered) {
+        // (the probe saw keys in order: a lane's eight keys mostly share a bitmap word, four lanes share it too)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const bool in = i0 + q * kStep16 < cnt;
+          const uint32_t w4[4] = {k4[q].x, k4[q].y, k4[q].z, k4[q].w};
+          uint32_t cw = 0xFFFFFFFFu, cb = 0;
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const uint32_t k = (u & 1) ? w4[u / 2] >> 16 : w4[u / 2] & 0xFFFFu;
+            if (!in) continue;
+            if ((k >> 5) != cw) {
+              if (cb) atomicOr(&l_seen[cw], cb);
+              cw = k >> 5;
+              cb = 0;
+            }
+            cb |= 1u << (k & 31);
+          }
+          const bool send = merge_word_group<4>(cw, cb);
+          if (send && cb) atomicOr(&l_seen[cw], cb);
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if (i0 + q * kStep16 >= cnt) continue;
@@ -649,14 +871,16 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
           atomicOr(&l_seen[kb >> 5], 1u << (kb & 31));
         }
       }
+      }
     }
   } else {
-  const uint32_t *list = p.lists + (uint64_t)b * p.cap;
+  const uint32_t *list = p.lists + (uint64_t)li * p.cap;
   // lists are made of 16-slot aligned runs, so cnt is a multiple of 4; kListPad slots are filler
   // four 16-byte loads in flight per lane before the first LDS atomic (requesting the NEXT four before the atomics
   // of the current ones -- the pipeline that pays in dict.hip / kll.hip -- measured 1.01 ms instead of 0.93 here)
   constexpr uint64_t kStep = (uint64_t)kPartitionThreads * 4;
-  for (uint64_t i0 = (uint64_t)tid * 4; i0 < cnt; i0 += 4 * kStep) {
+  for (uint64_t w0 = (uint64_t)(tid & ~63u) * 4; w0 < cnt; w0 += 4 * kStep) {  // (whole waves, as above)
+    const uint64_t i0 = w0 + (uint64_t)(tid & 63u) * 4;
     uint4 k4[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -665,6 +889,26 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
       u32x4 v = {kListPad, kListPad, kListPad, kListPad};
       if (i < cnt) v = __builtin_nontemporal_load((const u32x4 *)&list[i]);
       k4[q] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    if (clustered && !g_twice) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t ks[4] = {k4[q].x, k4[q].y, k4[q].z, k4[q].w};
+        uint32_t cw = 0xFFFFFFFFu, cb = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (ks[u] == kListPad) continue;
+          if ((ks[u] >> 5) != cw) {
+            if (cb) atomicOr(&l_seen[cw], cb);
+            cw = ks[u] >> 5;
+            cb = 0;
+          }
+          cb |= 1u << (ks[u] & 31);
+        }
+        const bool send = merge_word_group<8>(cw, cb);
+        if (send && cb) atomicOr(&l_seen[cw], cb);
+      }
+      continue;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -1154,8 +1398,10 @@ __global__ void distinct_init_kernel(DistinctSample *sample, OutlierStats *outli
 // everything a partition pass wants cleared, in ONE launch (four small fills / kernels in a row were 20 us of a
 // 100 M-row step per key column): the lists' cursors (zero) and valid-length limits (all-ones), the outliers'
 // aggregates, and the two totals the replay recomputes
-__global__ __launch_bounds__(1024) void partition_init_kernel(unsigned long long *cursors, uint32_t n_buckets,
-                                                              OutlierStats *outliers, unsigned long long *totals) {
+__global__ __launch_bounds__(1024) void partition_init_kernel(PartitionParams p, unsigned long long *totals) {
+  unsigned long long *cursors = p.cursors;
+  const uint32_t n_buckets = p.n_buckets;
+  OutlierStats *outliers = p.outliers;
   for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
     cursors[b] = 0;
     cursors[n_buckets + b] = ~0ull;
@@ -1171,11 +1417,44 @@ __global__ __launch_bounds__(1024) void partition_init_kernel(unsigned long long
     totals[0] = 0;
     totals[1] = 0;
   }
+  // The probe: do keys that sit next to each other in the column fall into the same bucket?  64 groups of 128
+  // consecutive rows, evenly spread (what a wave of partition_kernel holds for one j): a group agrees when every valid
+  // key inside the range names one bucket.  Three quarters agreeing -> cursors[2 P] = 1 and partition_kernel runs its
+  // CLUSTERED passes; shuffled keys never agree, keys in order always do (but for the groups that straddle a boundary).
+  __shared__ uint32_t agree, asked;
+  if (threadIdx.x == 0) agree = asked = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_groups = p.length / 128;
+  global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)p.values + p.offset);
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)p.validity;
+  for (uint32_t g = wave; g < 64 && (int64_t)g < n_groups; g += 16) {
+    const int64_t group = n_groups <= 64 ? (int64_t)g : (int64_t)g * (n_groups / 64);
+    bool same = true;
+    uint32_t b0 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int64_t i = group * 128 + h * 64 + lane;
+      const uint64_t r = (uint64_t)vals[i] - (uint64_t)p.base;
+      bool okr = r < p.range;
+      if (vbits) okr = okr && ((vbits[(p.offset + i) >> 3] >> ((p.offset + i) & 7)) & 1);
+      const uint64_t act = __ballot(okr);
+      if (act == 0) continue;  // (nothing inside the range: a group of outliers agrees -- CLUSTERED is their path too)
+      const uint32_t b = (uint32_t)(r >> p.sub_bits);
+      if (b0 == 0xFFFFFFFFu) b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(act));
+      same = same && __ballot(okr && b != b0) == 0;
+    }
+    if (lane == 0) {
+      atomicAdd(&asked, 1u);
+      if (same) atomicAdd(&agree, 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cursors[2 * n_buckets] = (p.probe && asked >= 4 && 4 * agree >= 3 * asked) ? 1ull : 0ull;
 }
 
-void launch_partition_init(unsigned long long *cursors, uint32_t n_buckets, OutlierStats *outliers,
-                           unsigned long long *totals, hipStream_t stream) {
-  hipLaunchKernelGGL(partition_init_kernel, dim3(1), dim3(1024), 0, stream, cursors, n_buckets, outliers, totals);
+void launch_partition_init(const PartitionParams &p, unsigned long long *totals, hipStream_t stream) {
+  hipLaunchKernelGGL(partition_init_kernel, dim3(1), dim3(1024), 0, stream, p, totals);
 }
 
 void launch_distinct_init(DistinctSample *sample, OutlierStats *outliers, hipStream_t stream) {

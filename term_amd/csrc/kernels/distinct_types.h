@@ -48,8 +48,10 @@ struct PartitionParams {
   uint32_t sub_bits;   // log2(keys per bucket)
   uint32_t n_buckets;  // P
   uint64_t cap;        // list capacity per bucket in slots (4-byte slots, multiple of 16; key16: 2-byte slots, of 32)
-  uint32_t *lists;     // P x cap slots
-  unsigned long long *cursors;  // [0,P): next free slot per list (zeroed per batch); [P,2P): valid-length limits (all-ones)
+  uint32_t *lists;     // n_lists x cap slots: the lists of buckets [bucket0, bucket0 + n_lists)
+  // [0,P): next free slot per list (zeroed per batch); [P,2P): valid-length limits (all-ones); [2P]: 1 when keys next
+  // to each other in the column share buckets (partition_init_kernel's probe): partition_kernel's CLUSTERED passes
+  unsigned long long *cursors;
   uint32_t *seen;      // global bitmap (rounded up to whole slices)
   uint32_t *twice;     // or nullptr
   int32_t want_multiplicity;
@@ -59,6 +61,12 @@ struct PartitionParams {
   // range checks and its uniqueness check together
   struct ScanPartial *stats;
   struct OutlierStats *outliers;  // with stats: the aggregates of the (rare) keys outside [base, base + range)
+  // the buckets this batch is expected to touch (all of them unless the batch's own value range is known -- a flush of
+  // a stream whose keys grow covers a few slices of a bitmap that has grown with the stream): lists are laid out and
+  // sized for these only; a key that lands in another bucket after all takes the spill path (exact, slow)
+  uint32_t bucket0, n_lists;
+  int32_t probe;  // 0: partition_init_kernel leaves the clustered flag at 0 (TGX_NO_CLUSTERED_PROBE=1: for A/B runs)
+  int32_t pad_;
 };
 
 // keys outside the bitmap's range enter the column's aggregates through global atomics (they are rare: the range

@@ -1554,13 +1554,32 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
       pp.n_buckets = (uint32_t)prep.n_buckets;
       // runs are padded to 16 slots per (tile, bucket): budget the average load + 25 % + the padding
       const uint64_t tiles = ((uint64_t)c.length + kPartitionTile - 1) / kPartitionTile;
-      uint64_t cap = (uint64_t)c.length / prep.n_buckets;
+      // the buckets the batch can touch: all of them, unless the host knows the batch's own value range (a coalesced
+      // flush of HOST windows) -- a flush of ids that grow lands in a few slices of a bitmap that has grown with the
+      // stream, and lists sized for an even spread over ALL slices would overflow into the spill path
+      pp.bucket0 = 0;
+      pp.n_lists = pp.n_buckets;
+      if (ds.batch_range_known) {
+        auto u = [](int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; };
+        const uint64_t ub = u(ds.base);
+        const uint64_t rlo = u(ds.batch_lo) > ub ? u(ds.batch_lo) - ub : 0;
+        uint64_t rhi = u(ds.batch_hi) > ub ? u(ds.batch_hi) - ub : 0;
+        rhi = std::min(rhi, ds.range - 1);
+        if (rlo <= rhi) {
+          pp.bucket0 = (uint32_t)(rlo >> pp.sub_bits);
+          pp.n_lists = (uint32_t)(rhi >> pp.sub_bits) - pp.bucket0 + 1;
+        }
+      }
+      uint64_t cap = (uint64_t)c.length / pp.n_lists;
       cap = cap + cap / 4 + (prep.key16 ? 32 : 16) * tiles + 4096;
       pp.cap = prep.key16 ? (cap + 31) & ~31ull : (cap + 15) & ~15ull;
+      if (pp.cap >= (1ull << 32) - 64) return fail(err, TGX_INTERNAL, "distinct: list capacity out of range");
       pp.want_multiplicity = mult ? 1 : 0;
       pp.key16 = prep.key16 ? 1 : 0;
-      HIP_TRY(ds.lists.reserve(pp.n_buckets * pp.cap * (prep.key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
-      HIP_TRY(ds.cursors.reserve(2 * pp.n_buckets * sizeof(unsigned long long)));
+      static const bool no_probe = getenv("TGX_NO_CLUSTERED_PROBE") && atoi(getenv("TGX_NO_CLUSTERED_PROBE")) != 0;
+      pp.probe = no_probe ? 0 : 1;
+      HIP_TRY(ds.lists.reserve((uint64_t)pp.n_lists * pp.cap * (prep.key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
+      HIP_TRY(ds.cursors.reserve((2 * pp.n_buckets + 1) * sizeof(unsigned long long)));  // (+ the probe's flag)
       pp.lists = ds.lists.as<uint32_t>();
       pp.cursors = ds.cursors.as<unsigned long long>();
       pp.seen = ds.seen.as<uint32_t>();
@@ -1575,7 +1594,7 @@ static tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_col
       unsigned long long *cnt = ds.counters.as<unsigned long long>();
       static_assert(kCntDistinct == 0 && kCntTwice == 1, "partition_init_kernel clears the two totals together");
       // cursors, limits, the outliers' aggregates and the totals phase 2 recomputes from the slices: one launch
-      launch_partition_init(pp.cursors, pp.n_buckets, pp.outliers, cnt + kCntDistinct, st->stream);
+      launch_partition_init(pp, cnt + kCntDistinct, st->stream);
       {
         ProfScope ps(st, "distinct", bytes);
         launch_partition(pp, cnt, g_ctx.n_cu, st->stream);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--sparse-rows", type=int, default=1_000_000_000)
+    ap.add_argument("--ordered-only", action="store_true", help="only (1b): the dense pass over keys in order")
     args = ap.parse_args()
     import torch
     import term_amd as T
@@ -29,6 +30,31 @@ def main():
 
     n = (args.rows // 64) * 64
     T.init(distinct_capacity_hint=n)
+    # ---- (1b) the dense pass over keys IN ORDER (ids that grow with the row number): a wave's rows share a bucket ----
+    ids = torch.arange(n, dtype=torch.int64, device="cuda") + 1000
+    for name, specs in (("uniqueness alone", [spec(T.DISTINCT, 0)]),
+                        ("uniqueness + min/max/mean", [spec(T.DISTINCT, 0), spec(T.NUMERIC_STATS, 0)])):
+        plan = T.Plan(specs)
+        st = T.State(plan)
+        col = T.Column.int64(ids, None, length=n)
+        for it in range(args.steps + 2):
+            if it == 2:
+                st.profile_enable(True)
+                st.profile_reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            st.reset()
+            st.update([col])
+            res = st.finalize()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps * 1e3
+        prof = st.profile_get("distinct")
+        ok = res[0].distinct == n and (len(specs) == 1 or (res[1].min_i, res[1].max_i) == (1000, n + 999))
+        print("ids in order, %d rows, %s: distinct=%d verified=%s  wall %.2f ms/step, kernels %.2f ms/step" %
+              (n, name, res[0].distinct, ok, dt, prof["total_ms"] / args.steps))
+    del ids
+    if args.ordered_only:
+        return
     layout = synth.COLUMNS_16[:2]
     table = synth.make_table(layout, 0, n, n, 0x7E570004, "cuda")
     for ci, (vals, validity) in enumerate(table):

@@ -5,7 +5,8 @@
  * through FFI is what this file does in C.
  *
  *   build:  make -C tools            (hipcc, links term_amd/libtgx.so and the HIP runtime)
- *   run:    build/feed_batches [rows] [cols]        (defaults: 8 Mi rows, 8 columns)
+ *   run:    build/feed_batches [rows] [cols] [only]   (defaults: 8 Mi rows, 8 columns; only = one case, e.g.
+ *           "u1-host-8192": with the uniqueness check, HOST buffers, 8192-row batches -- for a profiler)
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -51,6 +52,7 @@ static uint64_t mix64(uint64_t x) {
 int main(int argc, char **argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : (int64_t)8192 * 1024;
   const int n_cols = argc > 2 ? atoi(argv[2]) : 8;
+  const char *only = argc > 3 ? argv[3] : NULL;
   tgx_error err;
   memset(&err, 0, sizeof(err));
   tgx_options opts = {-1, 0, 0};
@@ -108,6 +110,9 @@ int main(int argc, char **argv) {
       const int64_t batch_sizes[3] = {n, 65536, 8192};
       for (int b = 0; b < 3; b++) {
         const int64_t rows = batch_sizes[b] < n ? batch_sizes[b] : n;
+        char tag[64];
+        snprintf(tag, sizeof(tag), "u%d-%s-%lld", with_unique, mem ? "device" : "host", (long long)rows);
+        if (only && strcmp(only, tag) != 0) continue;
         tgx_state *st = NULL;
         CHECK_TGX(tgx_state_create(plan, NULL, &st, &err));
         double best = 1e30;
