@@ -2407,7 +2407,13 @@ class CopyHelper {
     }();
     return h;
   }
-  void post(const CopyJob *jobs, size_t n) {
+  // ONE job slot: the helper serves one caller at a time.  States fed from several threads at once (a state per
+  // DataFusion partition stream) meet here; whoever finds the helper taken copies its whole batch itself.  (Without
+  // the claim two posts could overwrite each other's job list: copies skipped, or a caller waiting for a ticket
+  // that never comes -- the differential tester's threaded ranks hung once in ~150 runs.)
+  bool try_claim() { return busy_.try_lock(); }
+  void release() { busy_.unlock(); }
+  uint64_t post(const CopyJob *jobs, size_t n) {  // (claimed)
     jobs_ = jobs;
     n_ = n;
     const uint64_t ticket = posted_.load(std::memory_order_relaxed) + 1;
@@ -2416,9 +2422,9 @@ class CopyHelper {
       std::lock_guard<std::mutex> lock(mu_);
       cv_.notify_one();
     }
+    return ticket;
   }
-  void wait() {
-    const uint64_t ticket = posted_.load(std::memory_order_relaxed);
+  void wait(uint64_t ticket) {
     while (done_.load(std::memory_order_acquire) != ticket) __builtin_ia32_pause_or_nop();
   }
 
@@ -2451,7 +2457,7 @@ class CopyHelper {
       done_.store(seen, std::memory_order_release);
     }
   }
-  std::mutex mu_;
+  std::mutex mu_, busy_;
   std::condition_variable cv_;
   std::atomic<uint64_t> posted_{0}, done_{0};
   std::atomic<bool> sleeping_{false};
@@ -2668,6 +2674,7 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.bytes;
     CopyHelper *helper = total >= (64u << 10) ? CopyHelper::get() : nullptr;
+    if (helper && !helper->try_claim()) helper = nullptr;  // (serving another thread's state)
     if (!helper) {
       for (const CopyJob &j : jobs) stream_copy(j.dst, j.src, j.bytes);
     } else {
@@ -2683,10 +2690,11 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
           tail.push_back({(char *)jobs[k].dst + mine_of_k, (const char *)jobs[k].src + mine_of_k, jobs[k].bytes - mine_of_k});
         for (size_t q = k + 1; q < jobs.size(); q++) tail.push_back(jobs[q]);
       }
-      helper->post(tail.data(), tail.size());
+      const uint64_t ticket = helper->post(tail.data(), tail.size());
       for (size_t q = 0; q < k; q++) stream_copy(jobs[q].dst, jobs[q].src, jobs[q].bytes);
       if (k < jobs.size() && mine_of_k) stream_copy(jobs[k].dst, jobs[k].src, mine_of_k);
-      helper->wait();
+      helper->wait(ticket);
+      helper->release();
     }
   }
   co.rows += nrows;
@@ -3153,10 +3161,13 @@ extern "C" tgx_status tgx_finalize(const tgx_plan *plan, tgx_state *st, tgx_resu
         r->total = (int64_t)t.total;
         r->non_null = (int64_t)t.non_null;
         r->distinct = (int64_t)t.distinct;
-        // groups with cnt == 1: keys seen exactly once, plus the NULL group when it has one row
+        // groups with cnt == 1 (GROUP BY cols ... WHERE cnt = 1, uniqueness.rs:670-680): keys seen exactly once, plus --
+        // for a single column -- the NULL group when it has one row.  A tuple with NULL components is a key of its
+        // own and already among them (with one such row the group was counted twice).
         // (only tracked when the spec asks for TGX_FLAG_MULTIPLICITY; 0 otherwise)
+        const bool null_group = plan->distinct[b.slot].tuple.empty() && (t.total - t.non_null) == 1;
         r->groups_once = (plan->specs[i].flags & TGX_FLAG_MULTIPLICITY)
-                             ? (int64_t)(t.distinct - t.twice) + ((t.total - t.non_null) == 1 ? 1 : 0)
+                             ? (int64_t)(t.distinct - t.twice) + (null_group ? 1 : 0)
                              : 0;
         break;
       }

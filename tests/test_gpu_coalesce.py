@@ -270,3 +270,58 @@ def test_host_streams_of_growing_ids_grow_the_bitmap(shape, monkeypatch):
     assert (res[0].total, res[0].non_null, res[0].distinct, res[0].groups_once) == (d.total, d.non_null, d.distinct, d.groups_once)
     o = orc.stats(ids, vb)
     assert (res[1].min_i, res[1].max_i, res[1].sum_i) == (o.min_i, o.max_i, o.sum_i_wrapping)
+
+
+def test_states_fed_from_several_threads_at_once():
+    """A state per partition stream, every stream on its own thread (HOST 8192-row batches: the pinned-arena copies
+    share ONE helper thread process-wide).  Two callers used to overwrite each other's job list there -- copies
+    skipped or a caller waiting for ever; the differential tester's threaded ranks found it."""
+    import threading
+
+    n, n_threads, n_cols = 8192 * 40, 4, 8
+    plan_specs = []
+    for c in range(n_cols):
+        plan_specs += [spec(T.COUNT, c), spec(T.NUMERIC_STATS, c)]
+    plan_specs.append(spec(T.DISTINCT, 0))
+    T.init()
+    plan = T.Plan(plan_specs)
+    tables, results, errors = [], [None] * n_threads, []
+    for t in range(n_threads):
+        rng = np.random.default_rng(100 + t)
+        cols = [(rng.permutation(n).astype(np.int64) + t * n, None)]
+        cols += [(rng.integers(-2**40, 2**40, size=n, dtype=np.int64), orc.pack_validity(rng.random(n) >= 0.1))
+                 for _ in range(n_cols - 1)]
+        tables.append(cols)
+    start = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            import torch
+
+            torch.cuda.set_device(0)
+            st = T.State(plan)
+            start.wait()
+            for rep in range(3):
+                st.reset()
+                for a in range(0, n, 8192):
+                    st.update([numeric_column(v, m, False, offset=a, length=8192) for v, m in tables[t]])
+                results[t] = st.finalize()
+        except Exception:  # noqa: BLE001
+            import traceback
+
+            errors.append(traceback.format_exc())
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors, errors
+    assert not any(th.is_alive() for th in threads), "a feeding thread is stuck"
+    for t in range(n_threads):
+        res = results[t]
+        for c, (v, m) in enumerate(tables[t]):
+            cnt = orc.count(m, n)
+            assert (res[2 * c].total, res[2 * c].non_null) == (cnt.total, cnt.non_null)
+            check_stats(res[2 * c + 1], orc.stats(v, m))
+        assert res[2 * n_cols].distinct == n

@@ -1,188 +1,12 @@
-"""-m gpu: seeded differential runs -- random tables, random batch cuts and Arrow offsets, random mixes of checks in
-ONE plan, device and host buffers, states reused across tgx_state_reset -- against the oracle on the whole table.
-Integer results bit-exact; float aggregates within 1e-9 relative (north-star bar: 1e-6)."""
-import os
-
-import numpy as np
+"""-m gpu: a fixed set of seeds of the differential tester (tests/fuzz_plans.py): random plans x tables x batchings
+through the C ABI against the oracle.  tools/fuzz_device.py runs any other range of seeds."""
 import pytest
 
-import oracle_binding as orc
-import term_amd as T
-from _lib_spec import spec
-from gpu_util import numeric_column, rel_err
+from fuzz_plans import run_seed
 
 pytestmark = pytest.mark.gpu
 
 
-def random_column(rng, n, kind):
-    if kind == "i_dense":
-        v = rng.integers(-50, 5000, size=n, dtype=np.int64)
-    elif kind == "i_wide":
-        v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
-        if n > 3:
-            v[:3] = [np.iinfo(np.int64).min, np.iinfo(np.int64).max, -1]
-    elif kind == "i_const":
-        v = np.full(n, int(rng.integers(-5, 5)), dtype=np.int64)
-    elif kind == "f_normal":
-        v = rng.standard_normal(n) * 10.0 ** int(rng.integers(-3, 6))
-    else:  # f_special
-        v = rng.integers(0, 6, size=n).astype(np.float64)
-        pool = np.array([0.0, -0.0, np.inf, -np.inf, 5e-324, -5e-324, 1.7976931348623157e308, 1.0, -1.0])
-        sel = rng.random(n) < 0.2
-        v[sel] = rng.choice(pool, size=int(sel.sum()))
-    null_frac = float(rng.choice([0.0, 0.0, 0.01, 0.3, 1.0]))
-    mask = rng.random(n) >= null_frac if null_frac > 0 else None
-    return v, mask
-
-
-@pytest.mark.parametrize("seed", range(int(os.environ.get("TGX_FUZZ_SEEDS", "24"))))
-def test_random_plans_against_the_oracle(seed):
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([1, 63, 64, 65, 1000, 8191, 50_000, 300_000, 1_300_000]))
-    kinds = [str(rng.choice(["i_dense", "i_wide", "i_const", "f_normal", "f_special"])) for _ in range(3)]
-    cols = [random_column(rng, n, k) for k in kinds]
-    lead = int(rng.integers(0, 130))  # rows in front of the viewed window (Arrow offset)
-    device = bool(rng.integers(0, 2))
-    specs, expect = [], []
-    for ci, (v, m) in enumerate(cols):
-        specs.append(spec(T.COUNT, ci))
-        expect.append(("count", ci))
-        specs.append(spec(T.NUMERIC_STATS, ci, flags=T.FLAG_VARIANCE if rng.random() < 0.5 else 0))
-        expect.append(("stats", ci))
-        if rng.random() < 0.8:
-            specs.append(spec(T.DISTINCT, ci, flags=T.FLAG_MULTIPLICITY if rng.random() < 0.5 else 0))
-            expect.append(("distinct", ci))
-    specs.append(spec(T.COMOMENTS, 0, column2=1))
-    expect.append(("como", 0))
-    # batches: random cuts; every batch views [lead + lo, lead + hi) of buffers that start `lead` rows earlier
-    cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
-    full = []
-    for v, m in cols:
-        pv = np.concatenate([np.zeros(lead, dtype=v.dtype), v])
-        pm = None if m is None else np.concatenate([np.zeros(lead, dtype=bool), m])
-        full.append((pv, None if pm is None else orc.pack_validity(pm)))
-    T.init()
-    plan = T.Plan(specs)
-    st = T.State(plan)
-    for round_ in range(2):  # the second round reuses the state after a reset
-        st.reset()
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            st.update([numeric_column(pv, pb, device, offset=lead + lo, length=hi - lo) for pv, pb in full])
-        res = st.finalize()
-        for (what, ci), s_, r in zip(expect, specs, res):
-            v, m = cols[ci]
-            vb = None if m is None else orc.pack_validity(m)
-            if what == "count":
-                want = orc.count(vb, n)
-                assert (r.total, r.non_null) == (want.total, want.non_null)
-            elif what == "stats":
-                want = orc.stats(v.copy(), vb)
-                assert (r.total, r.non_null, bool(r.has_value)) == (want.total, want.non_null, bool(want.has_value))
-                if not want.has_value:
-                    continue
-                if v.dtype == np.int64:
-                    assert (r.min_i, r.max_i, r.sum_i) == (want.min_i, want.max_i, want.sum_i_wrapping)
-                    assert rel_err(r.mean, want.mean) < 1e-9
-                else:
-                    assert orc.nan_equal(r.min_f, want.min_f) and orc.nan_equal(r.max_f, want.max_f)
-                    assert np.signbit(r.min_f) == np.signbit(want.min_f) and np.signbit(r.max_f) == np.signbit(want.max_f)
-                    if np.isfinite(want.sum_hi):
-                        assert rel_err(r.sum_f, want.sum_hi) < 1e-9 and rel_err(r.mean, want.mean) < 1e-9
-                    else:
-                        # a Float64 SUM whose running value overflows is order dependent (DataFusion adds per-batch SIMD
-                        # partial sums, the oracle adds row by row, the GPU adds per-workgroup partials): +-inf in one
-                        # order can be -+inf or NaN (inf - inf) in another.  What is pinned: the sum is not finite.
-                        assert not np.isfinite(r.sum_f)
-                if (s_.flags & T.FLAG_VARIANCE) and want.has_variance and np.isfinite(want.var_samp):
-                    assert bool(r.has_variance)
-                    assert rel_err(r.var_samp, want.var_samp) < 1e-6 or abs(r.var_samp - want.var_samp) < 1e-300
-            elif what == "distinct":
-                want = orc.distinct_bits64(v.view(np.uint64), vb)
-                assert (r.total, r.non_null, r.distinct) == (want.total, want.non_null, want.distinct)
-                if s_.flags & T.FLAG_MULTIPLICITY:
-                    assert r.groups_once == want.groups_once
-            else:
-                (x, xm), (y, ym) = cols[0], cols[1]
-                want = orc.comoments(x.copy(), y.copy(), None if xm is None else orc.pack_validity(xm),
-                                     None if ym is None else orc.pack_validity(ym))
-                assert (r.total, r.non_null) == (n, want.n)
-                for got, w in ((r.sum_x, want.sum_x), (r.sum_y, want.sum_y), (r.sum_xy, want.sum_xy)):
-                    if np.isfinite(w):
-                        assert rel_err(got, w) < 1e-9 or abs(got - w) < 1e-290
-
-
-PATTERNS = [r"@", r"^[^@]+@[^@]+\.[^@]+$", r"^\d{3}-\d{2}-\d{4}$", r"(?i)^user", r"^\s*$", r"é|ß|你", r"^.{0,5}$",
-            r"[a-f0-9]{8}", r"^(?:foo|bar|baz)\d*$", r"\.com$"]
-
-
-def random_strings(rng, n):
-    alphabet = list("abcdefABC019 @.-_") + ["é", "ß", "你", "🦀", "\t", "\n"]
-    out = []
-    for i in range(n):
-        r = rng.random()
-        if r < 0.07:
-            out.append(None)
-        elif r < 0.35:
-            out.append("user%d@example%d.com" % (i % 977, i % 13))
-        elif r < 0.45:
-            out.append("%03d-%02d-%04d" % (i % 1000, i % 100, i % 10000))
-        elif r < 0.5:
-            out.append(" " * int(rng.integers(0, 4)))
-        elif r < 0.6:
-            out.append(str(rng.choice(["foo", "bar", "baz"])) + str(int(rng.integers(0, 50))))
-        else:
-            k = int(rng.integers(0, 24)) if r < 0.97 else int(rng.integers(100, 5000))
-            out.append("".join(alphabet[int(x)] for x in rng.integers(0, len(alphabet), size=k)))
-    return out
-
-
-@pytest.mark.parametrize("seed", range(int(os.environ.get("TGX_FUZZ_STRING_SEEDS", "16"))))
-def test_random_string_plans_against_the_oracle(seed, monkeypatch):
-    from test_gpu_dictionary import encode
-    from test_gpu_regex import utf8_column
-    from test_gpu_utf8view import view_column
-
-    if seed % 2:  # odd seeds: the first batch of a Utf8 / Utf8View DISTINCT goes through the fingerprint lists
-        monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "50")
-    rng = np.random.default_rng(5000 + seed)
-    n = int(rng.choice([1, 64, 129, 5000, 60_000]))
-    vals = random_strings(rng, n)
-    layout = str(rng.choice(["utf8", "large", "view", "dict"]))
-    device = bool(rng.integers(0, 2)) or layout in ("view", "dict")
-    specs, checks = [spec(T.COUNT, 0), spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], []
-    for _ in range(int(rng.integers(1, 4))):
-        pat = str(rng.choice(PATTERNS))
-        flags = (T.FLAG_TRIM if rng.random() < 0.4 else 0) | (T.FLAG_NULL_IS_VALID if rng.random() < 0.5 else 0) | \
-                (T.FLAG_CASE_INSENSITIVE if rng.random() < 0.3 else 0)
-        specs.append(spec(T.REGEX_MATCH, 0, pattern=pat, flags=flags))
-        checks.append(("regex", pat, flags))
-    lo_len, hi_len = int(rng.integers(0, 6)), int(rng.integers(6, 40))
-    specs.append(spec(T.LENGTH, 0, length_min=lo_len, length_max=hi_len))
-    checks.append(("length", lo_len, hi_len))
-    cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
-    offs, data, validity = orc.utf8_from_list(vals)
-    batches = []
-    for lo, hi in zip(cuts[:-1], cuts[1:]):
-        if layout == "view":
-            batches.append([view_column(vals[lo:hi], rng, True)])
-        elif layout == "dict":
-            batches.append([encode(vals[lo:hi], rng, repeat_entries=bool(rng.integers(0, 2)))])
-        else:
-            batches.append([utf8_column(offs, data, validity, device, offset=lo, length=hi - lo, large=(layout == "large"))])
-    T.init()
-    plan = T.Plan(specs)
-    st = T.State(plan)
-    for b in batches:
-        st.update(b)
-    res = st.finalize()
-    d = orc.distinct_utf8(offs, data, validity)
-    assert (res[0].total, res[0].non_null) == (n, d.non_null)
-    assert (res[1].distinct, res[1].groups_once) == (d.distinct, d.groups_once)
-    for (what, a, b), r in zip(checks, res[2:]):
-        if what == "regex":
-            want = orc.Regex(a, case_insensitive=bool(b & T.FLAG_CASE_INSENSITIVE)).count_utf8(
-                offs, data, validity, trim=bool(b & T.FLAG_TRIM), null_is_valid=bool(b & T.FLAG_NULL_IS_VALID)).matches
-            assert (r.total, r.matches) == (n, want), (layout, a, b)
-        else:
-            want = orc.length_count_utf8(offs, data, validity, min_chars=a, max_chars=b).matches
-            assert (r.total, r.matches) == (n, want), (layout, a, b)
+@pytest.mark.parametrize("seed", range(48))
+def test_seed(seed):
+    run_seed(seed)

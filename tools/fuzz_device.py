@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Runs the differential tester (tests/fuzz_plans.py) over a range of seeds on the GPU and prints every case whose
+device answers differ from the oracle's.
+
+    python tools/fuzz_device.py [--first S] [--count K] [--max-rows N]"""
+import argparse
+import os
+import sys
+import time
+
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=1000)
+    ap.add_argument("--count", type=int, default=200)
+    ap.add_argument("--max-rows", type=int, default=2_600_000)
+    ap.add_argument("--only-after", default=None, help="only cases that end this way (finalize / blob / merge / ranks)")
+    ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--seed-timeout", type=int, default=60, help="seconds before a case counts as stuck")
+    args = ap.parse_args()
+    from fuzz_plans import Case, run_seed
+
+    import faulthandler
+    import signal
+
+    def stuck(_sig, _frm):  # a case that hangs (threaded ranks waiting for each other) must not eat the GPU budget
+        print("STUCK seed %d: %s" % (seed, Case(seed, args.max_rows).describe()), flush=True)
+        faulthandler.dump_traceback(all_threads=True)
+        os._exit(3)
+
+    signal.signal(signal.SIGALRM, stuck)
+    bad = 0
+    t0 = time.time()
+    seeds = [sd for sd in range(args.first, args.first + args.count)
+             if args.only_after is None or Case(sd, args.max_rows).after == args.only_after] * args.repeat
+    for seed in seeds:
+        signal.alarm(args.seed_timeout)
+        try:
+            run_seed(seed, args.max_rows)
+        except AssertionError as err:
+            bad += 1
+            print("FAIL", str(err).replace("\n", "\n     "), flush=True)
+    signal.alarm(0)
+    print("%d cases (seeds from %d), %d failed, %.0f s" % (len(seeds), args.first, bad, time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
