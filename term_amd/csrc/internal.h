@@ -304,6 +304,11 @@ struct DistinctState {
   // batches retained here -- DEVICE views, which the caller keeps alive until tgx_finalize / tgx_state_sync
   // (include/tgx.h); HOST batches are resolved before tgx_update returns.
   bool speculative = false;
+  // some batch since the last look at the counters may have left keys outside the bitmap's range (its range was a
+  // sample's, or unknown: DEVICE buffers).  The range must then stay as it is until they have been repaired: the
+  // repair walks the retained batches for the keys outside the range, so a bitmap grown over them in the meantime
+  // would make it skip them (a stream of HOST and DEVICE batches of growing ids lost a whole batch that way).
+  bool outliers_possible = false;
   // the value range of the batch about to be run, when the host knows it (a coalesced flush of HOST windows)
   bool batch_range_known = false;
   int64_t batch_lo = 0, batch_hi = 0;

@@ -600,6 +600,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
     d.wide = false;
     d.has_hint = false;
     d.speculative = false;
+    d.outliers_possible = false;
     d.fp_staged = false;
     d.retained.clear();
     d.bitmap_words = 0;
@@ -1307,7 +1308,10 @@ static void bitmap_shape(const DistinctState &ds, int64_t length, bool mult, uin
   *sub_bits_out = sub_bits;
   *key16_out = key16;
   *n_buckets_out = n_buckets;
-  *partitioned_out = length >= (1 << 20) && n_buckets <= kMaxPartitions && (uint64_t)length * 64 >= ds.range &&
+  // (TGX_PARTITION_MIN_ROWS: the differential tester sends small batches through the partitioned pass as well)
+  const char *min_env = getenv("TGX_PARTITION_MIN_ROWS");
+  const int64_t min_rows = min_env ? std::max<int64_t>(1, atoll(min_env)) : (int64_t)1 << 20;
+  *partitioned_out = length >= min_rows && n_buckets <= kMaxPartitions && (uint64_t)length * 64 >= ds.range &&
                      cap_slots < (1ull << 32) - 64;
 }
 
@@ -1509,8 +1513,16 @@ static tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx
   }
   // a later batch whose range the host knows and the bitmap does not cover (ids that grow from batch to batch): the
   // bitmap grows instead of counting the batch's keys as outliers and repairing them through the hash set afterwards
-  if (ds.mode == DistinctMode::kBitmap && ds.speculative && !ds.partitioned && ds.batch_range_known)
+  if (ds.mode == DistinctMode::kBitmap && ds.speculative && !ds.partitioned && ds.batch_range_known &&
+      !ds.outliers_possible)
     TGX_TRY(bitmap_grow(st, ds, mult, ds.batch_lo, ds.batch_hi, c.length, err));
+  if (ds.mode == DistinctMode::kBitmap && ds.speculative) {
+    // can this batch leave keys outside the range?  Not when the host saw every value and the bitmap covers them.
+    auto u = [](int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; };
+    const bool covered = ds.batch_range_known && u(ds.batch_lo) >= u(ds.base) &&
+                         u(ds.batch_hi) - u(ds.base) < ds.range;
+    if (!covered) ds.outliers_possible = true;
+  }
   if (ds.mode == DistinctMode::kBitmap) {
     bitmap_shape(ds, c.length, mult, &prep->sub_bits, &prep->key16, &prep->n_buckets, &prep->partitioned);
     if (ds.partitioned) prep->partitioned = false;  // an owned slice after tgx_allreduce: plain inserts only
@@ -1724,6 +1736,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
   const uint64_t n_out = c[kCntOutOfRange];
   if (n_out == 0 || ds.mode != DistinctMode::kBitmap) {
     ds.retained.clear();
+    ds.outliers_possible = false;  // (the counters have just said so)
     return TGX_OK;
   }
   const int64_t old_base = ds.base;
@@ -1769,8 +1782,10 @@ tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
     if ((ds.speculative || ds.fp_staged) && !ds.retained.empty() &&
         all[k * kNumDistinctCounters + kCntOutOfRange] != 0)
       TGX_TRY(distinct_resolve(st, k, err));
-    else
+    else {
       ds.retained.clear();
+      ds.outliers_possible = false;  // (the counters have just said so)
+    }
   }
   return TGX_OK;
 }
@@ -3014,6 +3029,7 @@ static tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
         repaired = true;
       } else {
         ds.retained.clear();
+        if (!all.empty()) ds.outliers_possible = false;  // (the counters have just said so)
       }
     }
     if (repaired) {

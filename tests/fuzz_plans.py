@@ -100,21 +100,29 @@ def string_values(rng, n, vocab):
     return offsets, data
 
 
-def utf8_col(offsets, data, vb, device, offset, length, large):
-    validity = pad_validity(vb)
-    data = np.concatenate([data, np.zeros(16, np.uint8)])
-    offs = offsets if large else offsets.astype(np.int32)
-    if device:
-        offs, data, validity = to_device(offs), to_device(data), to_device(validity)
-    return T.Column(T.LARGE_UTF8 if large else T.UTF8, length, offsets=offs, data=data, validity=validity, offset=offset)
+class Buffers:
+    """the Arrow buffers of one column, on the host and (uploaded once, on first use) on the device"""
 
+    def __init__(self, kind, vals, vb, extra):
+        self.kind = kind
+        self.host = {"validity": pad_validity(vb)}
+        if kind == "s":
+            self.large = extra[1]
+            self.host["offsets"] = vals if self.large else vals.astype(np.int32)
+            self.host["data"] = np.concatenate([extra[0], np.zeros(16, np.uint8)])
+        else:
+            self.host["values"] = vals
+        self.dev = None
 
-def col32(vals, vb, device, offset, length):
-    validity = pad_validity(vb)
-    ctor = T.Column.int32 if vals.dtype == np.int32 else T.Column.float32
-    if device:
-        vals, validity = to_device(vals), to_device(validity)
-    return ctor(vals, validity, length=length, offset=offset)
+    def column(self, on_device, offset, length):
+        if on_device and self.dev is None:
+            self.dev = {k: to_device(v) for k, v in self.host.items()}
+        b = self.dev if on_device else self.host
+        if self.kind == "s":
+            return T.Column(T.LARGE_UTF8 if self.large else T.UTF8, length, offsets=b["offsets"], data=b["data"],
+                            validity=b["validity"], offset=offset)
+        ctor = {"i": T.Column.int64, "f": T.Column.float64, "i32": T.Column.int32, "f32": T.Column.float32}[self.kind]
+        return ctor(b["values"], b["validity"], length=length, offset=offset)
 
 
 def make_validity(rng, n, rate):
@@ -199,6 +207,17 @@ class Case:
             self.add(spec(T.DISTINCT, key_cols[0], columns=key_cols[:int(rng.integers(2, len(key_cols) + 1))],
                           flags=T.FLAG_MULTIPLICITY if mult else 0), ("tuple", tuple(key_cols), mult))
             self.expect[-1] = ("tuple", tuple(self.tuple_columns()), mult)
+        for ci, (kind, vals, vb, mask, extra) in enumerate(self.cols):
+            if kind in ("f", "i") and rng.random() < 0.15:
+                self.add(spec(T.KLL, ci, kll_k=int(rng.choice([200, 2048]))), ("kll", ci))
+        # thresholds that steer small batches into the big-batch paths (read per call / per state by the library)
+        self.env = {}
+        if rng.random() < 0.3:
+            self.env["TGX_FP_LISTS_MIN_ROWS"] = str(int(rng.choice([1, 3000, 50_000])))
+        if rng.random() < 0.3:
+            self.env["TGX_PARTITION_MIN_ROWS"] = str(int(rng.choice([1, 5000, 100_000])))
+        if rng.random() < 0.3:
+            self.env["TGX_COALESCE_FLUSH_ROWS"] = str(int(rng.choice([10_000, 20_000, 100_000])))
         # batching
         self.mode = str(rng.choice(["one", "cuts", "stream"], p=[0.35, 0.4, 0.25]))
         self.device = str(rng.choice(["device", "host", "mixed"], p=[0.5, 0.3, 0.2]))
@@ -229,22 +248,28 @@ class Case:
 
     def describe(self):
         cols = ", ".join("%s/nulls=%d" % (c[0], int((~c[3]).sum())) for c in self.cols)
-        return "seed %d: n=%d cols=[%s] checks=%s batching=%s(%d) buffers=%s after=%s" % (
-            self.seed, self.n, cols, [e[0] for e in self.expect], self.mode, len(self.cuts) - 1, self.device, self.after)
+        return "seed %d: n=%d cols=[%s] checks=%s batching=%s(%d) buffers=%s after=%s env=%s" % (
+            self.seed, self.n, cols, [e[0] for e in self.expect], self.mode, len(self.cuts) - 1, self.device, self.after,
+            self.env)
 
     # ---- the device side ----
     def columns_of(self, lo, hi, on_device):
-        out = []
-        for kind, vals, vb, _, extra in self.cols:
-            if kind in ("i", "f"):
-                out.append(numeric_column(vals, vb, on_device, offset=lo, length=hi - lo))
-            elif kind in ("i32", "f32"):
-                out.append(col32(vals, vb, on_device, lo, hi - lo))
-            else:
-                out.append(utf8_col(vals, extra[0], vb, on_device, lo, hi - lo, extra[1]))
-        return out
+        if not hasattr(self, "buffers"):
+            self.buffers = [Buffers(kind, vals, vb, extra) for kind, vals, vb, _, extra in self.cols]
+        return [b.column(on_device, lo, hi - lo) for b in self.buffers]
 
     def run_device(self):
+        import os
+
+        for k, v in self.env.items():
+            os.environ[k] = v
+        try:
+            return self.run_device_inner()
+        finally:
+            for k in self.env:
+                os.environ.pop(k, None)
+
+    def run_device_inner(self):
         T.init()
         plan = T.Plan(self.specs)
         if self.after == "ranks":
@@ -340,6 +365,9 @@ class Case:
                 want = rx.count_utf8(self.offsets32(vals), extra[0], vb, n=n, trim=bool(e[3] & T.FLAG_TRIM),
                                      null_is_valid=bool(e[3] & T.FLAG_NULL_IS_VALID))
                 assert (r.total, r.matches) == (n, want.matches), (e, r.matches, want.matches)
+            elif what == "kll":
+                x = vals[mask].astype(np.float64)
+                assert r.kll_n == int((~np.isnan(x)).sum()), (e, r.kll_n)
             elif what == "comoments":
                 _, y, yb, _, _ = self.cols[e[2]]
                 o = orc.comoments(vals, y, vb, yb, n=n)
@@ -400,12 +428,12 @@ class Case:
                 # The oracle restates DataFusion's online update, which loses digits on offset data (values near 6e11
                 # with a spread of 40: 143.50026 for a true 143.5); the device's pivot-shifted sums do not.  So: within
                 # 1e-6 of the reference's value, give or take the reference's own distance from the exact one -- and
-                # never further from the exact value than the reference is, beyond 1e-9 relative.
+                # never further from the exact value than the reference is, beyond 1e-7 relative.
                 slack = 0.0 if exact_var is None else 2 * abs(st.var_samp - exact_var)
                 assert abs(r.var_samp - st.var_samp) <= 1e-6 * abs(st.var_samp) + slack + 1e-12, (
                     e, r.var_samp, st.var_samp, exact_var)
                 if exact_var is not None:
-                    assert abs(r.var_samp - exact_var) <= abs(st.var_samp - exact_var) + 1e-9 * abs(exact_var) + 1e-12, (
+                    assert abs(r.var_samp - exact_var) <= abs(st.var_samp - exact_var) + 1e-7 * abs(exact_var) + 1e-12, (
                         e, r.var_samp, st.var_samp, exact_var)
 
 

@@ -325,3 +325,28 @@ def test_states_fed_from_several_threads_at_once():
             assert (res[2 * c].total, res[2 * c].non_null) == (cnt.total, cnt.non_null)
             check_stats(res[2 * c + 1], orc.stats(v, m))
         assert res[2 * n_cols].distinct == n
+
+
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+@pytest.mark.parametrize("pattern", ["HDHDH", "DHDHD", "DDHHH", "HHDDD"])
+def test_growing_ids_from_host_and_device_batches(order, pattern, monkeypatch):
+    """A stream of ids that keep growing (or falling), some batches HOST, some DEVICE.  A HOST flush tells the library
+    its value range and the bitmap grows to cover it; a DEVICE flush does not, and its keys wait outside the range for
+    the repair -- the bitmap must not grow over them meanwhile (the repair would take them for keys it already has:
+    the differential tester lost a whole batch of keys that way)."""
+    n = 293_798
+    vals = (1000 + np.arange(n, dtype=np.int64)) if order == "ascending" else (4_705_409_122 - np.arange(n, dtype=np.int64))
+    dv = to_device(vals)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.NUMERIC_STATS, 0)])
+    for flush_rows in ("20000", None):
+        if flush_rows:
+            monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", flush_rows)
+        st = T.State(plan)
+        monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS", raising=False)
+        for b, lo in enumerate(range(0, n, 65536)):
+            ln = min(65536, n - lo)
+            st.update([T.Column.int64(vals if pattern[b] == "H" else dv, None, length=ln, offset=lo)])
+        r = st.finalize()
+        assert (r[0].total, r[0].distinct, r[0].groups_once) == (n, n, n), (flush_rows, r[0].distinct)
+        check_stats(r[1], orc.stats(vals))
