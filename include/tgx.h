@@ -255,8 +255,9 @@ void tgx_state_destroy(tgx_state *state);
  * tgx_distinct_*).  Results do not depend on the batching: integers, key sets and pattern hits are those of the table;
  * float sums move in their last digits with the association, as they do between any two batchings.  Two arenas and two
  * sets of device regions take turns, so the host copies batch k+1 while the device works on flush k and nothing is
- * synchronised per batch: 8192-row batches of 8 columns run at 20 G rows/s from DEVICE buffers (0.4 us per call) and at
- * 0.43 G rows/s from HOST buffers (the copy into the arena: 27 GB/s on one core).  TGX_OPT_NO_COALESCE turns it off.
+ * synchronised per batch: 8192-row batches of 8 columns run at 21 G rows/s from DEVICE buffers (0.4 us per call) and at
+ * 0.55 G rows/s from HOST buffers (the copy into the arena, half of it on a helper thread).  TGX_OPT_NO_COALESCE turns
+ * it off.
  *
  * A batch that is NOT coalesced (more than 2^16 rows, Utf8View / dictionary columns, DEVICE strings) has its kernels
  * queued on the state's stream at once, and the call returns without waiting for them, except:
