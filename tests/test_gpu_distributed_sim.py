@@ -116,8 +116,9 @@ def _run_ranks(world, plan, shards_of, device_buffers=True, steps=1):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=600)
+        t.join(timeout=150)
     assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck"
     return results
 
 
