@@ -254,10 +254,23 @@ class Case:
         else:
             step = int(rng.choice([8192, 8192, 65536, 1000]))
             self.cuts = list(range(0, n, step)) + [n]
+        # what else happens to a state that is simply finalized: nothing / read half-way and fed on ("the state stays
+        # usable", include/tgx.h) / tgx_state_sync between batches / reset and fed the same table again, backwards
+        self.seq = str(rng.choice(["plain", "resume", "sync", "reuse"], p=[0.4, 0.25, 0.15, 0.2])) \
+            if self.after == "finalize" else "plain"
         if self.after == "ranks":
             self.world = int(rng.integers(2, 5))
             inner = sorted(int(x) // 64 * 64 for x in rng.integers(0, n + 1, size=self.world - 1))
             self.cuts = [0] + inner + [n]  # one shard per rank (validity bytes are shared: shards start on whole words)
+
+    def prefix_case(self, m):
+        """the same case over the table's first m rows (what a state read half-way must report)"""
+        import copy
+
+        c = copy.copy(self)
+        c.n = m
+        c.cols = [(k, (v[:m + 1] if k == "s" else v[:m]), vb, mask[:m], extra) for k, v, vb, mask, extra in self.cols]
+        return c
 
     def tuple_columns(self):
         s = self.specs[-1]
@@ -270,8 +283,8 @@ class Case:
     def describe(self):
         cols = ", ".join("%s/nulls=%d" % (c[0], int((~c[3]).sum())) for c in self.cols)
         return "seed %d: n=%d cols=[%s] checks=%s batching=%s(%d) buffers=%s after=%s env=%s" % (
-            self.seed, self.n, cols, [e[0] for e in self.expect], self.mode, len(self.cuts) - 1, self.device, self.after,
-            self.env)
+            self.seed, self.n, cols, [e[0] for e in self.expect], self.mode, len(self.cuts) - 1, self.device,
+            self.after + ("" if self.seq == "plain" else "/" + self.seq), self.env)
 
     # ---- the device side ----
     def columns_of(self, lo, hi, on_device):
@@ -304,12 +317,27 @@ class Case:
         n_states = int(self.rng.integers(2, 4)) if self.after == "merge" else 1
         states = [T.State(plan) for _ in range(n_states)]
         keep = []  # device tensors stay alive until the states have been read
-        for b in range(len(self.cuts) - 1):
+        n_batches = len(self.cuts) - 1
+        order = list(range(n_batches))
+        stop_at = int(self.rng.integers(0, n_batches + 1)) if self.seq == "resume" else -1
+        if self.seq == "reuse":  # a first round in the other order, read and thrown away
+            for b in reversed(order):
+                on_device = self.device == "device" or (self.device == "mixed" and bool(self.rng.integers(0, 2)))
+                cols = self.columns_of(self.cuts[b], self.cuts[b + 1], on_device)
+                keep.append(cols)
+                states[0].update(cols)
+            self.check_one(states[0].finalize())
+            states[0].reset()
+        for b in order:
+            if b == stop_at:  # the table so far
+                self.prefix_case(self.cuts[b]).check_one(states[0].finalize())
             lo, hi = self.cuts[b], self.cuts[b + 1]
             on_device = self.device == "device" or (self.device == "mixed" and bool(self.rng.integers(0, 2)))
             cols = self.columns_of(lo, hi, on_device)
             keep.append(cols)
-            states[b * n_states // max(1, len(self.cuts) - 1)].update(cols)
+            states[b * n_states // max(1, n_batches)].update(cols)
+            if self.seq == "sync" and self.rng.random() < 0.3:
+                states[0].sync()
         st = states[0]
         if self.after == "merge":
             order = list(self.rng.permutation(n_states))
