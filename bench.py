@@ -313,18 +313,21 @@ def main():
         scan_bytes = prof["bytes"] / max(1, prof["launches"])
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need their own rocprofv3 passes)
-        # but read from the committed passes of this same command on the builder's box -- profiles/r02_pmc_*.json:
-        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied; `traffic_source` says so
+        # but read from the committed passes of this same command on the builder's box -- profiles/rNN_pmc_*.json, the
+        # latest round's: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied;
+        # `traffic_source` says so
         traffic, traffic_source = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_1Brows_16cols.json")) as f:
-                pmc = json.load(f)
-            if pmc["rows_total"] == n_total and pmc["n_gpus"] == world and \
-                    pmc["scan_kernel_algorithmic_bytes_per_launch"] == int(scan_bytes):
-                traffic = pmc["scan_kernel_traffic_bytes_per_launch"]
-                traffic_source = "profiles/r02_pmc_1Brows_16cols.json (committed rocprofv3 --pmc passes of this command, not this run)"
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r03_pmc_1Brows_16cols.json", "r02_pmc_1Brows_16cols.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                if pmc["rows_total"] == n_total and pmc["n_gpus"] == world and \
+                        pmc["scan_kernel_algorithmic_bytes_per_launch"] == int(scan_bytes):
+                    traffic = pmc["scan_kernel_traffic_bytes_per_launch"]
+                    traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this command, not this run)" % name
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": "validated rows/sec, 16-col null+range+unique suite",
             "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
