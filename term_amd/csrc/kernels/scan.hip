@@ -644,32 +644,54 @@ __global__ __launch_bounds__(kScanBlock) void scan_hll_kernel(const ScanLaunch L
   for (int i = threadIdx.x; i < kHllRegisters / 16; i += kScanBlock) row[i] = ((const uint4 *)s_regs)[i];
 }
 
-// grid = (kHllRegisters / 4 / 256, columns): thread t owns four registers of its column
-__global__ __launch_bounds__(256) void hll_reduce_kernel(const ScanLaunch L, int blocks_per_col) {
+// byte-wise max of two words of four registers: the even and the odd bytes as two pairs of 16-bit lanes
+__device__ __forceinline__ uint32_t hll_max4(uint32_t a, uint32_t b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  union U {
+    uint32_t w;
+    u16x2 v;
+  };
+  U ae, be, ao, bo;
+  ae.w = a & 0x00FF00FFu;
+  be.w = b & 0x00FF00FFu;
+  ao.w = (a >> 8) & 0x00FF00FFu;
+  bo.w = (b >> 8) & 0x00FF00FFu;
+  U e, o;
+  e.v = __builtin_elementwise_max(ae.v, be.v);
+  o.v = __builtin_elementwise_max(ao.v, bo.v);
+  return e.w | (o.w << 8);
+}
+
+// grid = (16 word blocks x slices, columns): thread t owns four registers of its column over ONE slice of the
+// workgroups' rows (eight loads in flight), and folds its word into the running registers with a compare-and-swap.
+// (One thread per word walking all ~1500 rows one dependent load after the other took 0.52 ms of a 2.1 ms lane.)
+__global__ __launch_bounds__(256) void hll_reduce_kernel(const ScanLaunch L, int blocks_per_col, int rows_per_slice) {
   const ScanColDesc c = L.cols[blockIdx.y];
-  const int w = blockIdx.x * 256 + threadIdx.x;  // word of four registers
+  constexpr int kWordBlocks = kHllRegisters / 4 / 256;
+  const int w = (int)(blockIdx.x % kWordBlocks) * 256 + (int)threadIdx.x;  // word of four registers
+  const int b0 = (int)(blockIdx.x / kWordBlocks) * rows_per_slice;
+  const int b1 = b0 + rows_per_slice < blocks_per_col ? b0 + rows_per_slice : blocks_per_col;
   const uint32_t *rows = (const uint32_t *)c.hll;
   uint32_t m = 0;
-  for (int b = 0; b < blocks_per_col; b++) {
-    const uint32_t v = rows[(size_t)b * (kHllRegisters / 4) + w];
-    // byte-wise max of two packed words
-    uint32_t r = 0;
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t x = (m >> (8 * k)) & 0xFFu, y = (v >> (8 * k)) & 0xFFu;
-      r |= (x > y ? x : y) << (8 * k);
-    }
-    m = r;
+    for (int k = 0; k < 8; k++) v[k] = rows[(size_t)(b + k) * (kHllRegisters / 4) + w];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m = hll_max4(m, v[k]);
   }
+  for (; b < b1; b++) m = hll_max4(m, rows[(size_t)b * (kHllRegisters / 4) + w]);
+  if (m == 0) return;
   uint32_t *dst = (uint32_t *)c.hll_regs + w;
-  const uint32_t v = *dst;
-  uint32_t r = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t x = (m >> (8 * k)) & 0xFFu, y = (v >> (8 * k)) & 0xFFu;
-    r |= (x > y ? x : y) << (8 * k);
+  uint32_t old = *dst;
+  for (;;) {
+    const uint32_t want = hll_max4(old, m);
+    if (want == old) break;
+    const uint32_t got = atomicCAS(dst, old, want);
+    if (got == old) break;
+    old = got;
   }
-  *dst = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1317,7 +1339,10 @@ void launch_scan_kll(const ScanLaunch &L, int n_cols, int blocks_per_col, size_t
 // registers of its task
 void launch_scan_hll(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials, hipStream_t stream) {
   hipLaunchKernelGGL(scan_hll_kernel<3>, dim3(blocks_per_col, n_cols), dim3(kScanBlock), 0, stream, L, d_partials);
-  hipLaunchKernelGGL(hll_reduce_kernel, dim3(kHllRegisters / 4 / 256, n_cols), dim3(256), 0, stream, L, blocks_per_col);
+  const int slices = blocks_per_col >= 64 ? 32 : (blocks_per_col >= 8 ? 4 : 1);
+  const int rows_per_slice = (blocks_per_col + slices - 1) / slices;
+  hipLaunchKernelGGL(hll_reduce_kernel, dim3(kHllRegisters / 4 / 256 * slices, n_cols), dim3(256), 0, stream, L,
+                     blocks_per_col, rows_per_slice);
 }
 
 // two Float64 columns: the instance needs 129 registers as the compiler allocates it freely -- one too many for four

@@ -39,7 +39,7 @@ def main():
     sys.path.insert(0, ROOT)
     from term_amd import synth
     out = {
-        "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+        "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
                    "   (and a second pass with --pmc WRITE_SIZE); tools/pmc_bench.sh + tools/make_pmc_json.py",
         "rows_total": rows, "n_gpus": 1,
         "note": "FETCH_SIZE / WRITE_SIZE are in KiB per dispatch. On gfx950 FETCH_SIZE reports half the bytes of a "
