@@ -278,32 +278,32 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   // ---- pass 1: count keys per bucket ----
   // Keys that arrive in order (ids that grow with the row number, timestamps) put the 128 consecutive rows a wave
   // holds for one j into ONE bucket: 64 LDS atomics on one address take their turns (a tile of sorted keys cost
-  // 180 us instead of 24).  CLUSTERED (the batch looked like that to partition_init_kernel's probe): wherever a wave's
-  // valid lanes agree on the bucket it sends one add of the lane count.  `uni` remembers those j for pass 2; every
-  // term is wave-uniform, so the branches are scalar.  (A template parameter and a copy of the tile loop, not a
-  // question per tile: next to the plain passes in one loop the extra state spilled ~200 bytes per lane and cost
-  // shuffled keys 0.5 - 1.3 ms per 1 G-row column.)
-  auto wave_agrees = [&](int j, uint64_t &act, uint32_t &first, uint32_t &b0) {
-    const bool okj = (ok >> j) & 1;
-    const uint32_t b = rel[j] >> p.sub_bits;
-    act = __ballot(okj);
-    if (act == 0) return false;
-    first = (uint32_t)__builtin_ctzll(act);
-    b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)first);
-    return __ballot(okj && b != b0) == 0;
-  };
-  uint32_t uni = 0;
+  // 180 us instead of 24).  CLUSTERED (the batch looked like that to partition_init_kernel's probe): a wave whose
+  // valid lanes agree on the bucket for EVERY j of the tile (`whole`, a wave-uniform fact: one scalar branch picks a
+  // straight-line loop) sends one add of the lane count per j, and in pass 2 lines its lanes up behind one cursor
+  // bump.  A wave that straddles a bucket boundary takes the plain form for this tile.  (A template parameter and a
+  // copy of the tile loop, not a question per tile: next to the plain passes in one loop the extra state spilled
+  // ~200 bytes per lane and cost shuffled keys 0.5 - 1.3 ms per 1 G-row column.)
+  bool whole = false;
   if (CLUSTERED) {
+    uint32_t agreed = 0;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
-      uint64_t act;
-      uint32_t first = 0, b0 = 0;
-      if (wave_agrees(j, act, first, b0)) {
-        uni |= 1u << j;
-        if (lane == first) atomicAdd(&hist[b0], (uint32_t)__builtin_popcountll(act));
-      } else if ((ok >> j) & 1) {
-        atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
-      }
+      const bool okj = (ok >> j) & 1;
+      const uint32_t b = rel[j] >> p.sub_bits;
+      const uint64_t act = __ballot(okj);
+      const uint32_t first = act ? (uint32_t)__builtin_ctzll(act) : 0u;
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)first);
+      agreed |= (__ballot(okj && b != b0) == 0 ? 1u : 0u) << j;
+    }
+    whole = agreed == (uint32_t)((1ull << KPT) - 1ull);
+  }
+  if (CLUSTERED && whole) {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      const uint64_t act = __ballot((ok >> j) & 1);
+      const uint32_t first = act ? (uint32_t)__builtin_ctzll(act) : 64u;
+      if (lane == first) atomicAdd(&hist[rel[j] >> p.sub_bits], (uint32_t)__builtin_popcountll(act));
     }
   } else {
 #pragma unroll
@@ -360,23 +360,19 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   mid();
   __builtin_amdgcn_sched_barrier(0);
   // ---- pass 2: counting sort into LDS ----
-  if (CLUSTERED) {
+  if (CLUSTERED && whole) {
+    // one bucket per j for the whole wave: one cursor bump, the lanes line up behind it
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
       const bool okj = (ok >> j) & 1;
-      if ((uni >> j) & 1) {  // one bucket for the whole wave: one cursor bump, the lanes line up behind it
-        const uint64_t act = __ballot(okj);
-        const uint32_t first = (uint32_t)__builtin_ctzll(act);
-        uint32_t at = 0;
-        if (lane == first) at = atomicAdd(&hist[rel[j] >> p.sub_bits], (uint32_t)__builtin_popcountll(act));
-        at = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)first);
-        const uint32_t before =
-            __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-        if (okj) sorted[at + before] = rel[j] & sub_mask;
-      } else if (okj) {
-        const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
-        sorted[pos] = rel[j] & sub_mask;
-      }
+      const uint64_t act = __ballot(okj);
+      const uint32_t first = act ? (uint32_t)__builtin_ctzll(act) : 64u;
+      uint32_t at = 0;
+      if (lane == first) at = atomicAdd(&hist[rel[j] >> p.sub_bits], (uint32_t)__builtin_popcountll(act));
+      at = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)(first & 63u));
+      const uint32_t before =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+      if (okj) sorted[at + before] = rel[j] & sub_mask;
     }
   } else {
 #pragma unroll
