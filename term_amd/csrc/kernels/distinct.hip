@@ -492,6 +492,24 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   __syncthreads();
 }
 
+// Keys in order replayed against a slice: G neighbouring lanes hold the 32 keys of ONE bitmap word, and G atomics on one
+// LDS address take their turns.  The lanes of such a group merge their bits (a butterfly over the group; merging only
+// ever adds bits of the same word, so it is harmless when the group does not agree) and, when the whole group names
+// the same word, only its first lane sends the OR.  Returns whether this lane still has to send its own.
+template <int G>
+__device__ __forceinline__ bool merge_word_group(uint32_t cw, uint32_t &cb) {
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) {
+    const uint32_t ow = __shfl_xor(cw, d, 64), ob = __shfl_xor(cb, d, 64);
+    if (ow == cw) cb |= ob;
+  }
+  const uint32_t lead = lane & ~(uint32_t)(G - 1);
+  const uint64_t agree = __ballot(cw == (uint32_t)__shfl(cw, (int)lead, 64));
+  const bool whole = ((agree >> lead) & ((1ull << G) - 1)) == ((1ull << G) - 1);
+  return !whole || lane == lead;
+}
+
 // key - base of one tile: in-range keys fit 31 bits (n_buckets << sub_bits <= 2^31).  "In range" is key - base < range,
 // the test every other kernel of the key set applies (distinct_bitmap_kernel, distinct_outlier_kernel, the exports): NOT
 // "inside the last slice" -- a key between the range's end and the slice's would be in the bitmap for this pass and
@@ -576,6 +594,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   __shared__ uint32_t gbase[MAXP];       // start of the run in the bucket's global list
   __shared__ uint32_t wave_sums[16];
   __shared__ uint32_t long_runs[kTile / 1024 + 1];
+  __shared__ uint32_t t_lo, t_hi;  // (CLUSTERED) the span of the tile's keys
   const bool wide = (((uintptr_t)p.values + (uintptr_t)p.offset * 8) & 15) == 0;  // 16-byte loads legal
   unsigned long long n_valid = 0, n_out = 0;
   const int64_t n_tiles = (p.length + kTile - 1) / kTile;
@@ -646,6 +665,70 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         atomicMax(&st_max, tmax);
         atomicAdd(&st_sum, tsum);
         atomicAdd(&st_cnt, tcnt);
+      }
+    }
+    if (CLUSTERED && !p.want_multiplicity) {
+      // A tile of keys in order covers a short stretch of the range: when its keys span fewer bits than `sorted` has
+      // (2^20: 32 768 consecutive ids span 2^15) the tile is OR-ed into a bitmap of that stretch in LDS and the
+      // stretch's non-zero words into the global bitmap -- one device-wide atomic per 32 keys (ids in steps of one),
+      // no list written, nothing to replay.  (Not with multiplicity: the second sighting of a key is not seen here.)
+      if (threadIdx.x == 0) {
+        t_lo = 0xFFFFFFFFu;
+        t_hi = 0;
+      }
+      __syncthreads();
+      uint32_t lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const bool in = (ok >> j) & 1;
+        lo = (in && rel[j] < lo) ? rel[j] : lo;
+        hi = (in && rel[j] > hi) ? rel[j] : hi;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t olo = __shfl_xor(lo, d, 64), ohi = __shfl_xor(hi, d, 64);
+        lo = olo < lo ? olo : lo;
+        hi = ohi > hi ? ohi : hi;
+      }
+      if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&t_lo, lo);
+        atomicMax(&t_hi, hi);
+      }
+      __syncthreads();
+      const uint32_t tlo = t_lo, thi = t_hi;
+      if (tlo > thi) continue;  // (no valid key inside the range in this tile)
+      const uint32_t w0 = tlo >> 5, nw = (thi >> 5) - w0 + 1;
+      if (nw <= (uint32_t)kTile) {
+        for (uint32_t w = threadIdx.x; w < nw; w += THREADS) sorted[w] = 0;
+        __syncthreads();
+        // a lane's keys 2 j and 2 j + 1 are neighbouring rows; 16 lanes share a word when ids go in steps of one
+#pragma unroll
+        for (int j = 0; j < KPT; j += 2) {
+          uint32_t cw = 0xFFFFFFFFu, cb = 0;
+          if ((ok >> j) & 1) {
+            cw = (rel[j] >> 5) - w0;
+            cb = 1u << (rel[j] & 31);
+          }
+          if ((ok >> (j + 1)) & 1) {
+            const uint32_t w1 = (rel[j + 1] >> 5) - w0, b1 = 1u << (rel[j + 1] & 31);
+            if (w1 == cw) {
+              cb |= b1;
+            } else {
+              if (cb) atomicOr(&sorted[cw], cb);
+              cw = w1;
+              cb = b1;
+            }
+          }
+          const bool send = merge_word_group<16>(cw, cb);
+          if (send && cb) atomicOr(&sorted[cw], cb);
+        }
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < nw; w += THREADS) {
+          const uint32_t v = sorted[w];
+          if (v) atomicOr(&p.seen[w0 + w], v);
+        }
+        __syncthreads();
+        continue;
       }
     }
     partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16, CLUSTERED>(p, sorted, hist, toff, gbase, wave_sums, long_runs, rel, ok,
@@ -772,24 +855,6 @@ __global__ __launch_bounds__(256) void distinct_outlier_kernel(DistinctColDesc d
   block_add2(n_new, n_dup, &counters[0], &counters[1]);
   __syncthreads();
   block_add2(n_empty, 0ull, &counters[2], &counters[kCntSpare]);
-}
-
-// Keys in order replayed against a slice: G neighbouring lanes hold the 32 keys of ONE bitmap word, and G atomics on one
-// LDS address take their turns.  The lanes of such a group merge their bits (a butterfly over the group; merging only
-// ever adds bits of the same word, so it is harmless when the group does not agree) and, when the whole group names
-// the same word, only its first lane sends the OR.  Returns whether this lane still has to send its own.
-template <int G>
-__device__ __forceinline__ bool merge_word_group(uint32_t cw, uint32_t &cb) {
-  const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < G; d <<= 1) {
-    const uint32_t ow = __shfl_xor(cw, d, 64), ob = __shfl_xor(cb, d, 64);
-    if (ow == cw) cb |= ob;
-  }
-  const uint32_t lead = lane & ~(uint32_t)(G - 1);
-  const uint64_t agree = __ballot(cw == (uint32_t)__shfl(cw, (int)lead, 64));
-  const bool whole = ((agree >> lead) & ((1ull << G) - 1)) == ((1ull << G) - 1);
-  return !whole || lane == lead;
 }
 
 // Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of

@@ -1,8 +1,9 @@
 """-m gpu: the dense uniqueness pass over keys that arrive IN ORDER (ids that grow with the row number, timestamps).
 
-The rows a wave holds then share a bucket, so partition_kernel runs its CLUSTERED passes (kernels/distinct.hip: one
-LDS add per wave instead of 64 on one address, long runs streamed out by the whole workgroup, bucket_apply_kernel
-merging the bits of neighbouring lanes) once partition_init_kernel's probe has seen it.  Whatever the order of the
+The rows a wave holds then share a bucket, so partition_kernel runs its CLUSTERED form (kernels/distinct.hip: a tile
+whose keys span less than 2^20 values is OR-ed into a bitmap of that stretch in LDS and from there into the global
+bitmap -- no lists; otherwise one LDS add per wave instead of 64 on one address, long runs streamed out by the whole
+workgroup, bucket_apply_kernel merging the bits of neighbouring lanes) once partition_init_kernel's probe has seen it.  Whatever the order of the
 rows, the answers are the oracle's (TG/constraints/uniqueness.rs:568-700 counts; statistics.rs:259-299 aggregates):
 bit-exact."""
 import zlib
@@ -25,6 +26,10 @@ def shapes(rng, shape):
     validity = None
     if shape == "ascending":
         vals = np.arange(N, dtype=np.int64) * 1 + 10**12
+    elif shape == "ascending_step8":        # a tile spans 2^18 values: OR-ed into an LDS bitmap of the stretch
+        vals = np.arange(N, dtype=np.int64) * 8 - 12345
+    elif shape == "ascending_step64":       # a tile spans 2^21 values: too long for that, sorted into lists
+        vals = np.arange(N, dtype=np.int64) * 64
     elif shape == "descending":
         vals = (10**9 - np.arange(N, dtype=np.int64))
     elif shape == "runs_of_three":          # every key three times, in order
@@ -49,7 +54,7 @@ def shapes(rng, shape):
 
 
 @pytest.mark.parametrize("mult", [False, True])
-@pytest.mark.parametrize("shape", ["ascending", "descending", "runs_of_three", "ascending_with_nulls", "sorted_blocks",
+@pytest.mark.parametrize("shape", ["ascending", "ascending_step8", "ascending_step64", "descending", "runs_of_three", "ascending_with_nulls", "sorted_blocks",
                                    "half_ordered", "ordered_with_strays"])
 def test_keys_in_order(shape, mult):
     rng = np.random.default_rng(zlib.crc32(shape.encode()))

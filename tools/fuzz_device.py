@@ -32,6 +32,11 @@ def main():
         faulthandler.dump_traceback(all_threads=True)
         os._exit(3)
 
+    import torch  # noqa: F401  (the first import on a fresh box takes a minute or two: not a stuck case)
+    import term_amd as T
+
+    T.init()
+    torch.zeros(1, device="cuda")
     signal.signal(signal.SIGALRM, stuck)
     bad = 0
     t0 = time.time()
