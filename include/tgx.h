@@ -256,8 +256,8 @@ void tgx_state_destroy(tgx_state *state);
  * float sums move in their last digits with the association, as they do between any two batchings.  Two arenas and two
  * sets of device regions take turns, so the host copies batch k+1 while the device works on flush k and nothing is
  * synchronised per batch: 8192-row batches of 8 columns run at 21 G rows/s from DEVICE buffers (0.4 us per call) and at
- * 0.55 G rows/s from HOST buffers (the copy into the arena, half of it on a helper thread).  TGX_OPT_NO_COALESCE turns
- * it off.
+ * 0.70 G rows/s from HOST buffers (the copy into the arena, shared with three helper threads).  TGX_OPT_NO_COALESCE
+ * turns it off.
  *
  * A batch that is NOT coalesced (more than 2^16 rows, Utf8View / dictionary columns, DEVICE strings) has its kernels
  * queued on the state's stream at once, and the call returns without waiting for them, except:

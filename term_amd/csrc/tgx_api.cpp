@@ -2412,72 +2412,87 @@ constexpr size_t kCoalesceArenaMax = 128u << 20;     // pinned staging per arena
 static void stream_copy(void *dst, const void *src, size_t bytes);
 namespace {
 typedef tgx::CoalesceCopy CopyJob;
+// K workers (TGX_COPY_THREADS, default 3), each with its own job slot; the pool serves ONE caller at a time.  States
+// fed from several threads at once (a state per DataFusion partition stream) meet here; whoever finds the pool taken
+// copies its whole batch itself.  (Without the claim two posts could overwrite each other's job list: copies
+// skipped, or a caller waiting for a ticket that never comes -- the differential tester's threaded ranks hung once
+// in ~150 runs.)
 class CopyHelper {
  public:
   static CopyHelper *get() {
     static CopyHelper *h = [] {
       const char *e = getenv("TGX_COPY_THREADS");
-      if (e && e[0] == '0') return (CopyHelper *)nullptr;
-      return new CopyHelper();  // (lives as long as the process: a detached worker must not outlive its state)
+      int k = e ? atoi(e) : 3;
+      if (k <= 0) return (CopyHelper *)nullptr;
+      const unsigned hw = std::thread::hardware_concurrency();
+      if (hw && (unsigned)k + 1 > hw) k = hw > 1 ? (int)hw - 1 : 0;  // (the caller copies a share as well)
+      if (k <= 0) return (CopyHelper *)nullptr;
+      if (k > kMaxWorkers) k = kMaxWorkers;
+      return new CopyHelper(k);  // (lives as long as the process: a detached worker must not outlive its state)
     }();
     return h;
   }
-  // ONE job slot: the helper serves one caller at a time.  States fed from several threads at once (a state per
-  // DataFusion partition stream) meet here; whoever finds the helper taken copies its whole batch itself.  (Without
-  // the claim two posts could overwrite each other's job list: copies skipped, or a caller waiting for a ticket
-  // that never comes -- the differential tester's threaded ranks hung once in ~150 runs.)
+  static constexpr int kMaxWorkers = 8;
+  int workers() const { return n_workers_; }
   bool try_claim() { return busy_.try_lock(); }
   void release() { busy_.unlock(); }
-  uint64_t post(const CopyJob *jobs, size_t n) {  // (claimed)
-    jobs_ = jobs;
-    n_ = n;
-    const uint64_t ticket = posted_.load(std::memory_order_relaxed) + 1;
-    posted_.store(ticket, std::memory_order_release);
-    if (sleeping_.load(std::memory_order_acquire)) {
-      std::lock_guard<std::mutex> lock(mu_);
-      cv_.notify_one();
+  void post(int w, const CopyJob *jobs, size_t n) {  // (claimed)
+    Worker &k = w_[w];
+    k.jobs = jobs;
+    k.n = n;
+    k.ticket = k.posted.load(std::memory_order_relaxed) + 1;
+    k.posted.store(k.ticket, std::memory_order_release);
+    if (k.sleeping.load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> lock(k.mu);
+      k.cv.notify_one();
     }
-    return ticket;
   }
-  void wait(uint64_t ticket) {
-    while (done_.load(std::memory_order_acquire) != ticket) __builtin_ia32_pause_or_nop();
+  void wait(int w) {
+    Worker &k = w_[w];
+    while (k.done.load(std::memory_order_acquire) != k.ticket) pause_or_nop();
   }
 
  private:
-  static void __builtin_ia32_pause_or_nop() {
+  struct Worker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> posted{0}, done{0};
+    std::atomic<bool> sleeping{false};
+    const CopyJob *jobs = nullptr;
+    size_t n = 0;
+    uint64_t ticket = 0;
+  };
+  static void pause_or_nop() {
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
   }
-  CopyHelper() {
-    std::thread([this] { run(); }).detach();
+  explicit CopyHelper(int k) : n_workers_(k) {
+    for (int w = 0; w < k; w++) std::thread([this, w] { run(w_[w]); }).detach();
   }
-  void run() {
+  void run(Worker &k) {
     uint64_t seen = 0;
     for (;;) {
       // spin for about 200 us, then sleep until the next post
       int spins = 0;
-      while (posted_.load(std::memory_order_acquire) == seen) {
-        __builtin_ia32_pause_or_nop();
+      while (k.posted.load(std::memory_order_acquire) == seen) {
+        pause_or_nop();
         if (++spins > 20000) {
-          std::unique_lock<std::mutex> lock(mu_);
-          sleeping_.store(true, std::memory_order_release);
-          cv_.wait(lock, [&] { return posted_.load(std::memory_order_acquire) != seen; });
-          sleeping_.store(false, std::memory_order_release);
+          std::unique_lock<std::mutex> lock(k.mu);
+          k.sleeping.store(true, std::memory_order_release);
+          k.cv.wait(lock, [&] { return k.posted.load(std::memory_order_acquire) != seen; });
+          k.sleeping.store(false, std::memory_order_release);
           spins = 0;
         }
       }
-      seen = posted_.load(std::memory_order_acquire);
-      for (size_t k = 0; k < n_; k++) stream_copy(jobs_[k].dst, jobs_[k].src, jobs_[k].bytes);
-      done_.store(seen, std::memory_order_release);
+      seen = k.posted.load(std::memory_order_acquire);
+      for (size_t q = 0; q < k.n; q++) stream_copy(k.jobs[q].dst, k.jobs[q].src, k.jobs[q].bytes);
+      k.done.store(seen, std::memory_order_release);
     }
   }
-  std::mutex mu_, busy_;
-  std::condition_variable cv_;
-  std::atomic<uint64_t> posted_{0}, done_{0};
-  std::atomic<bool> sleeping_{false};
-  const CopyJob *jobs_ = nullptr;
-  size_t n_ = 0;
+  std::mutex busy_;
+  Worker w_[kMaxWorkers];
+  const int n_workers_;
 };
 }  // namespace
 
@@ -2693,22 +2708,36 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
     if (!helper) {
       for (const CopyJob &j : jobs) stream_copy(j.dst, j.src, j.bytes);
     } else {
-      // split at the byte midpoint (the job that straddles it is cut at a 64-byte boundary): the tail to the helper
-      size_t acc = 0, k = 0;
-      while (k < jobs.size() && acc + jobs[k].bytes <= total / 2) acc += jobs[k++].bytes;
-      std::vector<CopyJob> &tail = co.copy_tail;
-      tail.clear();
-      size_t mine_of_k = 0;
-      if (k < jobs.size()) {
-        mine_of_k = std::min(jobs[k].bytes, ((total / 2 - acc) + 63) & ~(size_t)63);
-        if (mine_of_k < jobs[k].bytes)
-          tail.push_back({(char *)jobs[k].dst + mine_of_k, (const char *)jobs[k].src + mine_of_k, jobs[k].bytes - mine_of_k});
-        for (size_t q = k + 1; q < jobs.size(); q++) tail.push_back(jobs[q]);
+      // equal shares of the bytes (a job that straddles a boundary is cut at a multiple of 64 bytes): the first to
+      // the caller, one to every worker
+      const int shares = helper->workers() + 1;
+      std::vector<CopyJob> &cut = co.copy_tail;  // all shares one behind the other; first[s] = where share s begins
+      cut.clear();
+      size_t first[CopyHelper::kMaxWorkers + 2];
+      const size_t per = (total / (size_t)shares + 63) & ~(size_t)63;
+      size_t room = per;
+      int share = 0;
+      first[0] = 0;
+      for (const CopyJob &j : jobs) {
+        size_t at = 0;
+        while (at < j.bytes) {
+          if (room == 0 && share + 1 < shares) {
+            first[++share] = cut.size();
+            room = per;
+          }
+          size_t take = share + 1 < shares ? std::min(room, j.bytes - at) : j.bytes - at;
+          if (take < j.bytes - at) take = std::min((take + 63) & ~(size_t)63, j.bytes - at);  // (cuts stay 64-byte aligned)
+          cut.push_back({(char *)j.dst + at, (const char *)j.src + at, take});
+          at += take;
+          room -= std::min(room, take);
+        }
       }
-      const uint64_t ticket = helper->post(tail.data(), tail.size());
-      for (size_t q = 0; q < k; q++) stream_copy(jobs[q].dst, jobs[q].src, jobs[q].bytes);
-      if (k < jobs.size() && mine_of_k) stream_copy(jobs[k].dst, jobs[k].src, mine_of_k);
-      helper->wait(ticket);
+      while (share + 1 < shares) first[++share] = cut.size();
+      first[shares] = cut.size();
+      for (int w = 0; w < helper->workers(); w++)
+        helper->post(w, cut.data() + first[w + 1], first[w + 2] - first[w + 1]);
+      for (size_t q = first[0]; q < first[1]; q++) stream_copy(cut[q].dst, cut[q].src, cut[q].bytes);
+      for (int w = 0; w < helper->workers(); w++) helper->wait(w);
       helper->release();
     }
   }
