@@ -865,11 +865,12 @@ void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, cons
   // batches up to ~157 M rows; 64 / 128 KiB for batches up to ~0.6 / ~1.4 G rows
   const dim3 grid(kFpFan * kFpFan);
   if (level2.cap <= 3072)
-    hipLaunchKernelGGL((fp_count_kernel<4096, 256, ulonglong2>), grid, dim3(256), 0, stream, level2, want_mult, per_list);
+    hipLaunchKernelGGL((fp_count_kernel<4096, 256, ulonglong2>), grid, dim3(256), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan));
   else if (level2.cap <= 12288)
-    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, ulonglong2>), grid, dim3(1024), 0, stream, level2, want_mult, per_list);
+    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, ulonglong2>), grid, dim3(1024), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan));
   else
-    hipLaunchKernelGGL((fp_count_kernel<32768, 1024, ulonglong2>), grid, dim3(1024), 0, stream, level2, want_mult, per_list);
+    hipLaunchKernelGGL((fp_count_kernel<32768, 1024, ulonglong2>), dim3(fp_resident_grid()), dim3(1024), 0, stream, level2, want_mult,
+                       per_list, (uint32_t)(kFpFan * kFpFan));  // one workgroup per CU, each walking its share of the lists
   hipLaunchKernelGGL(fp_totals_kernel<ulonglong2>, dim3(64), dim3(256), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan), offered1,
                      d_counters);
 }
