@@ -316,6 +316,17 @@ class Case:
             return [r for r, _st in out]  # every rank's view of the whole table
         n_states = int(self.rng.integers(2, 4)) if self.after == "merge" else 1
         states = [T.State(plan) for _ in range(n_states)]
+        # a declared value range (tgx_distinct_range_hint: what ranks agree on before a sharded run) for some of the
+        # single-column uniqueness checks over Int64 columns: the column's true MIN / MAX
+        hints = []
+        for k, e in enumerate(self.expect):
+            if e[0] == "distinct" and self.cols[e[1]][0] == "i" and self.cols[e[1]][3].any() and self.rng.random() < 0.2:
+                v = self.cols[e[1]][1][self.cols[e[1]][3]]
+                if int(v.max()) - int(v.min()) < 2**33:
+                    hints.append((k, int(v.min()), int(v.max())))
+        for st_k in states:
+            for k, lo, hi in hints:
+                st_k.distinct_range_hint(k, lo, hi)
         keep = []  # device tensors stay alive until the states have been read
         n_batches = len(self.cuts) - 1
         order = list(range(n_batches))
@@ -328,6 +339,8 @@ class Case:
                 states[0].update(cols)
             self.check_one(states[0].finalize())
             states[0].reset()
+            for k, lo, hi in hints:
+                states[0].distinct_range_hint(k, lo, hi)
         for b in order:
             if b == stop_at:  # the table so far
                 self.prefix_case(self.cuts[b]).check_one(states[0].finalize())
