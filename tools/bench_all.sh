@@ -17,3 +17,4 @@ run python tools/bench_spearman.py --ranks 8       # + the distributed ranking o
 run build/feed_batches                                # 8192-row batches through the C ABI from plain C (make -C tools): the coalescing rates
 run python tools/bench_batches.py                     # the same through the Python binding (a ctypes call costs 2-4 us)
 run python tools/bench_host_batches.py                # PCIe-inclusive rate
+run python tools/bench_host_strings.py                # a HOST Utf8 column streamed in 8192-row batches through a format check

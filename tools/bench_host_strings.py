@@ -22,7 +22,7 @@ def main():
     rng = np.random.default_rng(5)
     # "user<k>@example<k%1000>.com": built with numpy (offsets int32, data uint8)
     users = rng.integers(0, 10**9, size=n)
-    parts = [("user%d@example%d.com" % (int(u), int(u) % 1000)).encode() for u in users[:200_000]]
+    parts = [("user%d@example%d.com" % (int(u), int(u) % 1000)).encode() for u in users[:131_072]]
     reps = n // len(parts)
     lens = np.array([len(p) for p in parts], dtype=np.int64)
     data = np.frombuffer(b"".join(parts) * reps, dtype=np.uint8).copy()
