@@ -331,6 +331,10 @@ class Case:
         n_batches = len(self.cuts) - 1
         order = list(range(n_batches))
         stop_at = int(self.rng.integers(0, n_batches + 1)) if self.seq == "resume" else -1
+        # a blob taken half-way: the rest of the table is fed to the state rebuilt from it (what an incremental run does
+        # with a stored partial state); Spearman states hold their pairs on the device and stay as they are
+        blob_at = int(self.rng.integers(0, n_batches + 1)) if self.after == "blob" and not any(
+            e[0] == "spearman" for e in self.expect) else -1
         if self.seq == "reuse":  # a first round in the other order, read and thrown away
             for b in reversed(order):
                 on_device = self.device == "device" or (self.device == "mixed" and bool(self.rng.integers(0, 2)))
@@ -344,6 +348,8 @@ class Case:
         for b in order:
             if b == stop_at:  # the table so far
                 self.prefix_case(self.cuts[b]).check_one(states[0].finalize())
+            if b == blob_at:
+                states[0] = T.State.deserialize(plan, states[0].serialize())
             lo, hi = self.cuts[b], self.cuts[b + 1]
             on_device = self.device == "device" or (self.device == "mixed" and bool(self.rng.integers(0, 2)))
             cols = self.columns_of(lo, hi, on_device)
