@@ -302,7 +302,7 @@ tgx_status kll_serialize(tgx_state *st, size_t *len, uint8_t *buf, size_t cap, t
   tgx_status s = kll_flush(st, err);
   if (s != TGX_OK) return s;
   auto put = [&](const void *p, size_t n) {
-    if (buf && *len + n <= cap) memcpy(buf + *len, p, n);
+    if (n && buf && *len + n <= cap) memcpy(buf + *len, p, n);  // (an empty level has no items: p may be null)
     *len += n;
   };
   for (auto &h : st->h_kll) {
@@ -324,7 +324,7 @@ tgx_status kll_serialize(tgx_state *st, size_t *len, uint8_t *buf, size_t cap, t
 tgx_status kll_deserialize(tgx_state *st, const uint8_t *buf, size_t len, size_t *pos, tgx_error *err) {
   auto get = [&](void *p, size_t n) -> bool {
     if (*pos + n > len) return false;
-    memcpy(p, buf + *pos, n);
+    if (n) memcpy(p, buf + *pos, n);  // (an empty level: p may be null)
     *pos += n;
     return true;
   };

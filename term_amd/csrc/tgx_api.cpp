@@ -3086,7 +3086,7 @@ static double key_to_double(int64_t k) {
 }
 
 static double i128_to_double(uint64_t lo, int64_t hi) {
-  __int128 v = ((__int128)hi << 64) | (__int128)lo;
+  const __int128 v = (__int128)(((unsigned __int128)(uint64_t)hi << 64) | (unsigned __int128)lo);  // (no shift of a negative value)
   return (double)v;
 }
 

@@ -152,7 +152,7 @@ def make_validity(rng, n, rate):
 
 # ---- one case ---------------------------------------------------------------------------------------------------------
 class Case:
-    def __init__(self, seed, max_rows=2_600_000):
+    def __init__(self, seed, max_rows=2_600_000, host_only=False):
         rng = self.rng = np.random.default_rng(seed)
         self.seed = seed
         size_class = rng.choice(["tiny", "small", "medium", "big"], p=[0.15, 0.3, 0.3, 0.25])
@@ -244,6 +244,10 @@ class Case:
         self.device = str(rng.choice(["device", "host", "mixed"], p=[0.5, 0.3, 0.2]))
         has_spearman = any(e[0] == "spearman" for e in self.expect)
         self.after = str(rng.choice(["finalize", "blob", "merge", "ranks"], p=[0.4, 0.15, 0.25, 0.2]))
+        if host_only:  # (no torch in the process: HOST buffers only, no threaded ranks -- tools/run_gpu_host_asan.sh)
+            self.device = "host"
+            if self.after == "ranks":
+                self.after = "finalize"
         if has_spearman and self.after in ("blob", "merge"):
             self.after = "finalize"  # (not mergeable: TG/analyzers/advanced/correlation.rs:103-109)
         if self.mode == "one" or n == 0 or self.after == "ranks":
@@ -510,8 +514,8 @@ class Case:
                         merge_noise + 1e-12, (e, r.var_samp, st.var_samp, exact_var)
 
 
-def run_seed(seed, max_rows=2_600_000):
-    case = Case(seed, max_rows)
+def run_seed(seed, max_rows=2_600_000, host_only=False):
+    case = Case(seed, max_rows, host_only)
     try:
         case.check(case.run_device())
     except AssertionError as err:

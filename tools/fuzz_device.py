@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--max-rows", type=int, default=2_600_000)
     ap.add_argument("--only-after", default=None, help="only cases that end this way (finalize / blob / merge / ranks)")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--host-only", action="store_true", help="HOST buffers only, no threaded ranks, no torch")
     ap.add_argument("--seed-timeout", type=int, default=60, help="seconds before a case counts as stuck")
     args = ap.parse_args()
     from fuzz_plans import Case, run_seed
@@ -28,24 +29,26 @@ def main():
     import signal
 
     def stuck(_sig, _frm):  # a case that hangs (threaded ranks waiting for each other) must not eat the GPU budget
-        print("STUCK seed %d: %s" % (seed, Case(seed, args.max_rows).describe()), flush=True)
+        print("STUCK seed %d: %s" % (seed, Case(seed, args.max_rows, args.host_only).describe()), flush=True)
         faulthandler.dump_traceback(all_threads=True)
         os._exit(3)
 
-    import torch  # noqa: F401  (the first import on a fresh box takes a minute or two: not a stuck case)
     import term_amd as T
 
+    if not args.host_only:
+        import torch  # noqa: F401  (the first import on a fresh box takes a minute or two: not a stuck case)
+
+        torch.zeros(1, device="cuda")
     T.init()
-    torch.zeros(1, device="cuda")
     signal.signal(signal.SIGALRM, stuck)
     bad = 0
     t0 = time.time()
     seeds = [sd for sd in range(args.first, args.first + args.count)
-             if args.only_after is None or Case(sd, args.max_rows).after == args.only_after] * args.repeat
+             if args.only_after is None or Case(sd, args.max_rows, args.host_only).after == args.only_after] * args.repeat
     for seed in seeds:
         signal.alarm(args.seed_timeout)
         try:
-            run_seed(seed, args.max_rows)
+            run_seed(seed, args.max_rows, args.host_only)
         except AssertionError as err:
             bad += 1
             print("FAIL", str(err).replace("\n", "\n     "), flush=True)
