@@ -312,6 +312,10 @@ struct DistinctState {
   // the value range of the batch about to be run, when the host knows it (a coalesced flush of HOST windows)
   bool batch_range_known = false;
   int64_t batch_lo = 0, batch_hi = 0;
+  // the batch about to be run is a coalesced flush with DEVICE windows of this Int64 key column: the host has not seen
+  // its values, so -- while that can still keep the key set on the bitmap -- the device takes the flush's exact
+  // MIN / MAX before the pass (distinct_sample_all: one wait, the one a sample would cost)
+  bool flush_device_keys = false;
   // the views, and for each the coalescing region set it points into (-1: the caller's own memory)
   struct Retained {
     std::vector<tgx_column> cols;

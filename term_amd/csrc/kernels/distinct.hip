@@ -15,6 +15,7 @@
 // block-reduced first: one atomicAdd per block, not per row.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -796,7 +797,8 @@ __global__ void partition_outlier_stats_kernel(const OutlierStats *g, ScanPartia
 __global__ __launch_bounds__(256) void distinct_sample_kernel(DistinctColDesc d, DistinctSample *out) {
   global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)d.values + d.offset);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
-  const int64_t want = d.length < 65536 ? d.length : 65536;
+  // d.pad != 0: every row (the exact MIN / MAX of a coalesced flush of DEVICE windows), not a sample
+  const int64_t want = (d.pad || d.length < 65536) ? d.length : 65536;
   const int64_t step = d.length / want;
   int64_t mn = INT64_MAX, mx = INT64_MIN;
   unsigned long long cnt = 0;
@@ -1524,7 +1526,8 @@ void launch_distinct_init(DistinctSample *sample, OutlierStats *outliers, hipStr
 }
 
 void launch_distinct_sample(const DistinctColDesc &d, DistinctSample *out, hipStream_t stream) {
-  hipLaunchKernelGGL(distinct_sample_kernel, dim3(64), dim3(256), 0, stream, d, out);
+  const int grid = d.pad ? (int)std::min<int64_t>(1024, (d.length + 4095) / 4096) : 64;
+  hipLaunchKernelGGL(distinct_sample_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, stream, d, out);
 }
 
 void launch_distinct_outliers(const DistinctColDesc &d, int64_t base, uint64_t range, const HashSetView &t,

@@ -1331,6 +1331,15 @@ static bool distinct_wants_sample(const DistinctState &ds, const tgx_column &c) 
   return ds.mode == DistinctMode::kUndecided && c.type == TGX_INT64 && !ds.has_hint && !ds.batch_range_known &&
          c.length >= (1 << 16);
 }
+// ... or the exact MIN / MAX of a coalesced flush whose key windows were DEVICE memory?  While the key set is undecided,
+// or a bitmap no batch can have left outliers under: the flush then lays the bitmap out / grows it like a HOST flush
+// (a stream of DEVICE batches of growing ids stays on the bitmap instead of going through the repair, flush after flush)
+static bool distinct_wants_exact_range(const DistinctState &ds, const tgx_column &c) {
+  if (!ds.flush_device_keys || c.type != TGX_INT64 || ds.has_hint || ds.batch_range_known || c.length < (1 << 16))
+    return false;
+  return ds.mode == DistinctMode::kUndecided ||
+         (ds.mode == DistinctMode::kBitmap && ds.speculative && !ds.partitioned && !ds.outliers_possible);
+}
 
 // The samples of ALL key columns of the batch, queued together and read back with ONE wait: a read-back costs the
 // stream's latency (~50 us) whatever its size -- two key columns sampled one after the other were 6 % of a
@@ -1346,7 +1355,8 @@ static tgx_status distinct_sample_all(tgx_state *st, const tgx_column *dev, tgx_
     for (size_t h = 0; h < plan->hll.size(); h++)
       lane |= plan->hll[h].distinct_slot == (int)q && st->hll_mode[h] == 1;
     if (lane) continue;
-    if (distinct_wants_sample(st->distinct[q], dev[t.column])) who.push_back(q);
+    if (distinct_wants_sample(st->distinct[q], dev[t.column]) || distinct_wants_exact_range(st->distinct[q], dev[t.column]))
+      who.push_back(q);
   }
   if (who.empty()) return TGX_OK;
   TGX_TRY(pinned_readback(st, who.size() * sizeof(DistinctSample), err));
@@ -1360,7 +1370,7 @@ static tgx_status distinct_sample_all(tgx_state *st, const tgx_column *dev, tgx_
     d.offset = c.offset;
     d.length = c.length;
     d.want_multiplicity = 0;
-    d.pad = 0;
+    d.pad = distinct_wants_exact_range(ds, c) ? 1 : 0;  // every row, not a sample
     HIP_TRY(ds.sample.reserve(sizeof(DistinctSample)));
     launch_distinct_init(ds.sample.as<DistinctSample>(), nullptr, st->stream);
     launch_distinct_sample(d, ds.sample.as<DistinctSample>(), st->stream);
@@ -1368,8 +1378,17 @@ static tgx_status distinct_sample_all(tgx_state *st, const tgx_column *dev, tgx_
   }
   HIP_TRY(hipStreamSynchronize(st->stream));  // (the stream holds nothing but the samples when a step starts)
   for (size_t k = 0; k < who.size(); k++) {
-    st->distinct[who[k]].sample_host = got[k];
-    st->distinct[who[k]].sample_ready = true;
+    DistinctState &ds = st->distinct[who[k]];
+    if (distinct_wants_exact_range(ds, dev[plan->distinct[who[k]].column])) {
+      if (got[k].count) {  // the flush's range, as if the host had seen the values
+        ds.batch_range_known = true;
+        ds.batch_lo = got[k].min_v;
+        ds.batch_hi = got[k].max_v;
+      }
+      continue;
+    }
+    ds.sample_host = got[k];
+    ds.sample_ready = true;
   }
   return TGX_OK;
 }
@@ -2441,8 +2460,12 @@ class CopyHelper {
     k.jobs = jobs;
     k.n = n;
     k.ticket = k.posted.load(std::memory_order_relaxed) + 1;
-    k.posted.store(k.ticket, std::memory_order_release);
-    if (k.sleeping.load(std::memory_order_acquire)) {
+    // Sequentially consistent on both sides (this store / the load of `sleeping` here, the store of `sleeping` / the
+    // load of `posted` in the worker's wait): with release / acquire alone the load below may pass the store above,
+    // find the worker awake, and the worker -- about to sleep -- may still find nothing posted: nobody wakes it and
+    // the caller spins for ever (seen once in a few thousand HOST streams).
+    k.posted.store(k.ticket, std::memory_order_seq_cst);
+    if (k.sleeping.load(std::memory_order_seq_cst)) {
       std::lock_guard<std::mutex> lock(k.mu);
       k.cv.notify_one();
     }
@@ -2479,9 +2502,9 @@ class CopyHelper {
         pause_or_nop();
         if (++spins > 20000) {
           std::unique_lock<std::mutex> lock(k.mu);
-          k.sleeping.store(true, std::memory_order_release);
-          k.cv.wait(lock, [&] { return k.posted.load(std::memory_order_acquire) != seen; });
-          k.sleeping.store(false, std::memory_order_release);
+          k.sleeping.store(true, std::memory_order_seq_cst);
+          k.cv.wait(lock, [&] { return k.posted.load(std::memory_order_seq_cst) != seen; });
+          k.sleeping.store(false, std::memory_order_seq_cst);
           spins = 0;
         }
       }
@@ -2896,10 +2919,13 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     ds.batch_range_known = false;
     if (!t.tuple.empty() || t.approx_only) continue;
     const CoalesceColumn &cc = co.cols[t.column];
+    ds.flush_device_keys = false;
     if (cc.type == TGX_INT64 && cc.range_known && cc.range_lo <= cc.range_hi && !cc.segs.empty()) {
       ds.batch_range_known = true;
       ds.batch_lo = cc.range_lo;
       ds.batch_hi = cc.range_hi;
+    } else if (cc.type == TGX_INT64 && !cc.range_known && !cc.segs.empty()) {
+      ds.flush_device_keys = true;  // (DEVICE windows: the device will say, distinct_sample_all)
     }
   }
   // the pending list is empty from here on (update_impl may come back to tgx::coalesce_flush through a resolve)
@@ -2921,7 +2947,10 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   st->batches -= batches_of_flush;  // update_impl counts the flush as one batch: keep the caller's count
   tgx_status rc = update_impl(plan, st, views.data(), rows, err);
   st->batches += batches_of_flush - 1;
-  for (auto &ds : st->distinct) ds.batch_range_known = false;
+  for (auto &ds : st->distinct) {
+    ds.batch_range_known = false;
+    ds.flush_device_keys = false;
+  }
   if (rc != TGX_OK) return rc;
   // views the key sets kept of this flush point into region set `set`
   for (size_t q = 0; q < st->distinct.size(); q++) {

@@ -5,7 +5,7 @@
  * through FFI is what this file does in C.
  *
  *   build:  make -C tools            (hipcc, links term_amd/libtgx.so and the HIP runtime)
- *   run:    build/feed_batches [rows] [cols] [only]   (defaults: 8 Mi rows, 8 columns; only = one case, e.g.
+ *   run:    build/feed_batches [rows] [cols] [only] [gap_us]   (defaults: 8 Mi rows, 8 columns; only = one case, e.g.
  *           "u1-host-8192": with the uniqueness check, HOST buffers, 8192-row batches -- for a profiler)
  */
 #include <hip/hip_runtime_api.h>
@@ -53,6 +53,9 @@ int main(int argc, char **argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : (int64_t)8192 * 1024;
   const int n_cols = argc > 2 ? atoi(argv[2]) : 8;
   const char *only = argc > 3 ? argv[3] : NULL;
+  /* microseconds to idle between two updates, +- 50 %: the copy threads of the library spin ~200 us after a job and
+   * then sleep, so gaps of that size put every post on the edge of a worker falling asleep (a stress for that handshake) */
+  const long gap_us = argc > 4 ? atol(argv[4]) : 0;
   tgx_error err;
   memset(&err, 0, sizeof(err));
   tgx_options opts = {-1, 0, 0};
@@ -133,6 +136,11 @@ int main(int argc, char **argv) {
               k->validity = mem ? d_valid[c] : h_valid[c];
             }
             CHECK_TGX(tgx_update(plan, st, cols, (size_t)n_cols, &err));
+            if (gap_us > 0) {
+              const long us = gap_us / 2 + (long)(mix64((uint64_t)lo ^ (uint64_t)rep) % (uint64_t)gap_us);
+              struct timespec ts = {0, us * 1000};
+              nanosleep(&ts, NULL);
+            }
           }
           CHECK_TGX(tgx_finalize(plan, st, res, (size_t)n_specs, &err));
           const double dt = now() - t0;
