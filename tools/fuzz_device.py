@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--max-rows", type=int, default=2_600_000)
     ap.add_argument("--only-after", default=None, help="only cases that end this way (finalize / blob / merge / ranks)")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--native-stacks", action="store_true", help="on a stuck case, also print rocgdb's view of every thread")
     ap.add_argument("--host-only", action="store_true", help="HOST buffers only, no threaded ranks, no torch")
     ap.add_argument("--seed-timeout", type=int, default=60, help="seconds before a case counts as stuck")
     args = ap.parse_args()
@@ -31,6 +32,17 @@ def main():
     def stuck(_sig, _frm):  # a case that hangs (threaded ranks waiting for each other) must not eat the GPU budget
         print("STUCK seed %d: %s" % (seed, Case(seed, args.max_rows, args.host_only).describe()), flush=True)
         faulthandler.dump_traceback(all_threads=True)
+        if args.native_stacks:  # where the threads are inside libtgx / the HIP runtime (a debugger run by a helper
+            import subprocess   # process this one has allowed to attach)
+            import ctypes
+
+            try:
+                ctypes.CDLL(None).prctl(0x59616d61, -1, 0, 0, 0)  # PR_SET_PTRACER, PR_SET_PTRACER_ANY
+                out = subprocess.run(["rocgdb", "-p", str(os.getpid()), "-batch", "-ex", "thread apply all bt 14"],
+                                     capture_output=True, text=True, timeout=90)
+                print(out.stdout[-12000:], flush=True)
+            except Exception as e:  # noqa: BLE001
+                print("no native stacks: %r" % (e,), flush=True)
         os._exit(3)
 
     import term_amd as T
