@@ -1,0 +1,135 @@
+// sortrank.h -- the sample sort behind SQL RANK() (kernels/sortrank.hip): descriptors shared with the host code.
+//
+// RANK() OVER (ORDER BY c) of the reference's Spearman query (TG/analyzers/advanced/correlation.rs:334-350) is
+// "1 + the number of keys that sort before mine".  The keys (IEEE totalOrder keys of CAST(c AS DOUBLE), unsigned) are
+// partitioned by SPLITTERS drawn from a sorted random sample -- whatever the distribution, every bucket between two
+// neighbouring splitters holds about the same number of keys -- in up to three passes of at most 256 ways each, until
+// a bucket fits a small workgroup's LDS, where the rank inside the bucket is counted; a key EQUAL to a splitter goes
+// to a bucket of its own ("equality bucket": heavy ties never need sorting, every key there has the bucket's first
+// position as its rank).  No comparison sort, no radix passes over all 64 bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgx {
+
+constexpr int kSrTile = 2048;        // keys per tile of a partition pass
+constexpr int kSrPartThreads = 512;  // partition kernels: 8 waves, 4 keys per thread and tile
+constexpr int kSrPartPer = kSrTile / kSrPartThreads;
+constexpr int kSrMaxSplit = 255;     // splitters per part (an 8-step branch-free search in LDS)
+constexpr int kSrMaxNb = 2 * kSrMaxSplit + 1;
+constexpr int kSrXcds = 8;
+constexpr int kSrFirstParts = 64;    // the first pass cuts its input into this many stretches, eight per XCD
+// last pass, small buckets: 256 threads, 8 keys each
+constexpr int kSrFastThreads = 256;
+constexpr int kSrFastPer = 8;
+constexpr int kSrFastCap = kSrFastThreads * kSrFastPer;
+constexpr int kSrFastBinBits = 11;
+// last pass, buckets that outgrew the small one (and chunk against chunk beyond its own capacity)
+constexpr int kSrSlowThreads = 512;
+constexpr int kSrSlowPer = 8;
+constexpr int kSrSlowCap = kSrSlowThreads * kSrSlowPer;
+constexpr int kSrSlowBinBits = 12;
+constexpr uint32_t kSrEqPiece = 8192;  // an equality bucket is handed out in pieces of this many keys
+
+struct SrTileRef {  // one tile of a partition pass: keys [begin, min(begin + kSrTile, end of the part))
+  uint32_t part, begin;
+};
+struct SrItem {  // one unit of the last pass: a bucket (or a piece of an equality bucket)
+  uint32_t start, count;
+  uint32_t rank_base;  // keys that sort before the bucket
+  uint32_t flags;      // bit 0: every key of the item is the same
+  uint64_t lo, hi;     // the splitters the bucket lies between: lo < key < hi (small items only)
+};
+
+// what the last pass does with a key's rank
+enum SrSink : int {
+  kSrSorted = 0,       // keys (and payloads) written in order
+  kSrRank32 = 1,       // rank32[slot of the key in the partitioned arrays] = RANK() - 1
+  kSrSums = 2,         // payload = RANK(x) - 1 of the pair: the five rank sums
+  kSrRankScatter = 3,  // rank_out[payload] = ext_base + RANK()   (payload = where the key came from)
+};
+
+struct RankSums {
+  unsigned long long wrapped[5];   // UInt64 arithmetic of the reference: sums and products wrap modulo 2^64
+  unsigned long long exact_lo[5];  // the same sums without wrapping, 128 bits
+  unsigned long long exact_hi[5];
+};
+
+// One partition pass (tiles -> count -> offsets -> scatter), by value in the kernel-argument segment.
+// A pass cuts PARTS (pass 0: kSrFirstParts stretches of the input, all with the same splitters; later passes: the
+// buckets of the pass before, each with the splitters that lie between its bounds) into nb = 2 S + 1 buckets.
+struct SrLevel {
+  const uint64_t *keys_in;
+  const void *pay_in;  // nullptr with a 4-byte payload: the payload is the key's index (iota)
+  uint64_t *keys_out;
+  void *pay_out;
+  const uint64_t *fine;  // all splitters, in order
+  int32_t level;         // 0, 1, 2
+  uint32_t nbp;          // level 2: buckets per part of level 1 (a part is (d1, d2) = (p / nbp, p % nbp))
+  uint32_t w1, w2;       // first splitter of a part's range: (d1 >> 1) * w1 + (d2 >> 1) * w2
+  uint32_t stride;       // splitter k of a part: fine[first + (k + 1) * stride - 1]
+  uint32_t split_count;  // S
+  uint32_t nb;           // 2 S + 1
+  uint32_t *part_start;  // [nparts + 1]
+  uint32_t nparts;
+  SrTileRef *tiles;      // [kSrXcds][tile_cap]: the tiles each XCD's workgroups take
+  uint32_t tile_cap;
+  uint32_t *tile_count;  // [kSrXcds]
+  uint32_t *tot;         // [nparts][nb]: keys per bucket
+  uint32_t *cursor;      // [nparts][nb]: where the bucket's next run goes
+  uint32_t *bstart;      // pass 0: [nb + 1], later: [nparts * nb + 1]: where the buckets start (the next pass's parts)
+};
+
+struct SrFinal {
+  const uint64_t *keys;
+  const void *pay;
+  const SrItem *items;
+  const uint32_t *n_items;
+  uint64_t *out_keys;  // kSrSorted
+  void *out_pay;
+  uint32_t *rank32;    // kSrRank32
+  uint64_t *rank_out;  // kSrRankScatter
+  uint64_t ext_base;
+  RankSums *partials;  // kSrSums: one per workgroup
+  uint32_t cap;        // keys ranked in one go by the chunked kernel (<= kSrSlowCap)
+};
+
+// knobs (environment, read per call): tests shrink them so that small inputs take every path
+struct SrTuning {
+  uint32_t target;      // keys per bucket aimed at            TGX_SORT_TARGET   (1024)
+  uint32_t oversample;  // sample keys per bucket               TGX_SORT_SAMPLE   (16)
+  uint32_t cap;         // largest bucket of the small kernel   TGX_SORT_CAP      (2048)
+  uint32_t slow_cap;    // SrFinal::cap                         TGX_SORT_SLOWCAP  (4096)
+  uint32_t max_split;   // splitters per pass                   TGX_SORT_SPLIT    (255)
+  uint32_t wg_per_cu;   // workgroups per CU of a pass          TGX_SORT_WG       (3)
+};
+SrTuning sr_tuning();
+
+// A sort / ranking job.  Everything is queued on `stream`; nothing is waited for.
+struct SrJob {
+  const uint64_t *keys = nullptr;  // n keys (left as they are unless k[1] aliases them)
+  const void *pay = nullptr;       // payloads of pay_bytes each, or nullptr (iota with pay_bytes == 4)
+  uint64_t n = 0;
+  int pay_bytes = 0;               // 0, 4 or 8
+  // ping-pong space of the partition passes: pass i writes k[i & 1] / p[i & 1].  k[1] / p[1] may be the input arrays
+  // (they are read by pass 0 only): the keys then come back permuted, each with its payload
+  uint64_t *k[2] = {nullptr, nullptr};
+  void *p[2] = {nullptr, nullptr};
+  int sink = kSrSorted;
+  uint64_t *out_keys = nullptr;
+  void *out_pay = nullptr;
+  uint32_t *rank32 = nullptr;
+  uint64_t *rank_out = nullptr;
+  uint64_t ext_base = 0;
+  RankSums *partials = nullptr;  // kSrSums: sr_partials_count() entries
+};
+struct SrPlaced {  // where the job's keys / payloads lay when the last pass read them (kSrRank32 is aligned to it)
+  const uint64_t *keys;
+  const void *pay;
+};
+size_t sr_workspace_bytes(uint64_t n);
+int sr_partials_count();
+hipError_t sr_run(const SrJob &job, void *workspace, size_t workspace_bytes, hipStream_t stream, SrPlaced *placed);
+
+}  // namespace tgx

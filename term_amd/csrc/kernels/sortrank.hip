@@ -1,0 +1,1109 @@
+// sortrank.hip -- SQL RANK() over 64-bit keys on gfx950: a sample sort written for the chip, no library primitive.
+//
+// The reference ranks in SQL (TG/analyzers/advanced/correlation.rs:334-350: RANK() OVER (ORDER BY CAST(c AS DOUBLE)),
+// twice); DataFusion sorts the partition and numbers the tie runs.  Here (sortrank.h has the outline):
+//   sample     16 keys per aimed-at bucket, one from every stretch of n / ns keys at a hashed position; the sample is
+//              sorted by this very machinery (a 1 G-key job sorts 16 M, that one 256 K, that one 4 K, that one in a
+//              single workgroup) and every 16th sample key is a splitter
+//   partition  up to three passes of at most 256 ways (2 S + 1 buckets for S splitters: the odd ones hold the keys
+//              EQUAL to a splitter).  A pass is tiles -> count -> offsets -> scatter: buckets come out exactly sized
+//              and contiguous.  The scatter pass is the repo's list pass (kernels/lists.h) with exact reservations: a
+//              tile of 2048 keys is grouped by bucket in LDS, every (tile, bucket) run reserves its place in the bucket
+//              with ONE atomic and leaves in consecutive lanes.  A store of 8 scattered bytes per lane costs a memory
+//              transaction per lane AND leaves 56 bytes of every line for somebody else to fill -- from another
+//              XCD's L2 that means a partial write per key (the first version did exactly that: 1.2 TB/s) -- so all
+//              tiles of one part are taken by workgroups of ONE XCD: the runs that complete each other's lines meet in
+//              that L2.  (Pass 0 has one part, the input; it is cut into 64 stretches, eight per XCD, each with its own
+//              range in every bucket.)
+//   rank       one 256-thread workgroup per bucket of ~1024 keys: the keys are binned in LDS by the leading 11 bits
+//              of (key - min of the bucket) -- a counting sort; two keys meet in a bin only if they are equal or agree
+//              in those bits, and those few are compared -- so a key's rank is (keys before the bucket) + (keys in
+//              lower bins) + (smaller keys in its bin).  The next bucket's keys are requested before the current
+//              one's are looked at.  A bucket that outgrew that kernel (more than twice the aim: one in ~10^3 at 16
+//              samples a bucket) goes to a larger, chunk-against-chunk kernel; equality buckets are not looked at.
+// What the last pass does with a rank is the job's sink (SrSink): the Spearman state ranks x with y as the payload,
+// then y with RANK(x) as the payload, and sums -- no rank ever finds its way back to a row (spearman_device.cpp).
+#include "sortrank.h"
+
+#include <stdlib.h>
+
+#include <algorithm>
+#include <cmath>
+
+namespace tgx {
+int tgx_num_cus();
+
+namespace {
+
+__device__ __forceinline__ uint32_t sr_lane() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint32_t sr_below(uint64_t m) {  // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// cursor[b] += 1 for every lane with `valid`, returning the value before the lane's own increment.  Lanes that agree
+// on b are served by one LDS add of their count: the leader's group first, and on while the groups are worth it (keys
+// in order, few distinct values: an LDS atomic on ONE address retires every ~10 cycles, 64 lanes on it cost 600);
+// what is left (scattered keys: the first group is a lane or two) goes lane by lane.  Called by ALL lanes of the wave.
+__device__ __forceinline__ uint32_t sr_claim(uint32_t *cursor, uint32_t b, bool valid) {
+  const uint32_t lane = sr_lane();
+  uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+  uint32_t pos = 0;
+  while (todo) {  // (wave-uniform)
+    const int leader = (int)__builtin_ctzll(todo);
+    const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+    const uint64_t grp = __builtin_amdgcn_ballot_w64(valid && b == lb) & todo;
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(grp);
+    uint32_t base = 0;
+    if (lane == (uint32_t)leader) base = atomicAdd(&cursor[lb], cnt);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if ((grp >> lane) & 1ull) pos = base + sr_below(grp);
+    todo &= ~grp;
+    if (cnt < 8) break;
+  }
+  if ((todo >> lane) & 1ull) pos = atomicAdd(&cursor[b], 1u);
+  return pos;
+}
+
+// ---- parts and their splitters ------------------------------------------------------------------------------------
+struct SrPartInfo {
+  bool eq;         // an equality bucket of an earlier pass: one value, nothing to split
+  uint32_t owner;  // XCD whose workgroups take the part's tiles
+  uint64_t first;  // first splitter of the part's range in `fine`
+};
+__device__ __forceinline__ SrPartInfo sr_part_info(const SrLevel &L, uint32_t p) {
+  SrPartInfo r;
+  if (L.level == 0) {
+    r.eq = false;
+    r.owner = p & (kSrXcds - 1);
+    r.first = 0;
+  } else if (L.level == 1) {
+    r.eq = p & 1u;
+    r.owner = (p >> 1) & (kSrXcds - 1);
+    r.first = (uint64_t)(p >> 1) * L.w1;
+  } else {
+    const uint32_t d1 = p / L.nbp, d2 = p % L.nbp;
+    r.eq = (d1 | d2) & 1u;
+    r.owner = ((d1 >> 1) + (d2 >> 1)) & (kSrXcds - 1);
+    r.first = (uint64_t)(d1 >> 1) * L.w1 + (uint64_t)(d2 >> 1) * L.w2;
+  }
+  return r;
+}
+// the part's splitters into LDS, padded with the largest key so the search needs no bounds
+__device__ __forceinline__ void sr_load_splitters(const SrLevel &L, const SrPartInfo &pi, uint32_t S, uint64_t *sp) {
+  for (uint32_t k = threadIdx.x; k <= (uint32_t)kSrMaxSplit; k += blockDim.x)
+    sp[k] = k < S ? L.fine[pi.first + (uint64_t)(k + 1) * L.stride - 1] : ~0ull;
+}
+// bucket of a key: 2 * (splitters below it) + (it equals the next one)
+__device__ __forceinline__ uint32_t sr_bucket(const uint64_t *sp, uint32_t S, uint32_t first_step, uint64_t key) {
+  uint32_t pos = 0;
+  for (uint32_t step = first_step; step; step >>= 1)
+    if (sp[pos + step - 1] < key) pos += step;
+  return 2u * pos + ((pos < S && sp[pos] == key) ? 1u : 0u);
+}
+__device__ __forceinline__ uint32_t sr_first_step(uint32_t S) { return S ? 1u << (31 - __builtin_clz(S)) : 0u; }
+
+// exclusive scan of a[0 .. 8 * THREADS) in LDS (entries past n read as 0), `add` on top; a[n] = the total + add when
+// `sentinel`.  A barrier has passed since a[] was written; one passes before this returns.
+template <int THREADS>
+__device__ __forceinline__ void sr_block_scan8(uint32_t *a, uint32_t n, uint32_t add, bool sentinel, uint32_t *wsum) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t v[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = tid * 8 + k;
+    v[k] = i < n ? a[i] : 0u;
+    s += v[k];
+  }
+  uint32_t incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t run = add + incl - s;
+  for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = tid * 8 + k;
+    if (i < n) a[i] = run;
+    run += v[k];
+  }
+  if (sentinel && tid == THREADS - 1) a[n] = run;  // (the last thread's run has passed every entry)
+  __syncthreads();
+}
+
+// ---- sample / splitters -------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t sr_mix(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void sr_sample_kernel(const uint64_t *keys, uint64_t n, uint64_t ns, uint64_t stride, uint64_t *out) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ns) return;
+  uint64_t pos = k * stride + sr_mix(k + 0x9E3779B97F4A7C15ull) % stride;
+  if (pos >= n) pos = n - 1;
+  out[k] = keys[pos];
+}
+__global__ void sr_pick_kernel(const uint64_t *sorted, uint64_t count, uint32_t every, uint64_t *fine) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) fine[j] = sorted[(j + 1) * every];
+}
+
+// ---- a partition pass ---------------------------------------------------------------------------------------------
+// pass 0: the input as kSrFirstParts stretches of whole tiles
+__global__ void sr_first_parts_kernel(uint32_t *part_start, uint32_t nparts, uint32_t per_part, uint32_t n) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > nparts) return;
+  const uint64_t at = (uint64_t)p * per_part;
+  part_start[p] = (p == nparts || at > n) ? n : (uint32_t)at;
+}
+
+// the tiles of every part, listed per XCD: a part between two splitters belongs to ONE XCD (the runs that fill a
+// bucket's lines then meet in one L2); an equality part is only copied, its tiles go round all of them.  One wave per
+// part; the order of the lists does not matter.
+__global__ __launch_bounds__(256) void sr_tiles_kernel(SrLevel L) {
+  const uint32_t p = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (p >= L.nparts) return;
+  const uint32_t b = L.part_start[p], e = L.part_start[p + 1];
+  if (e <= b) return;
+  const uint32_t nt = (uint32_t)(((uint64_t)(e - b) + kSrTile - 1) / kSrTile);
+  const SrPartInfo pi = sr_part_info(L, p);
+  if (!pi.eq) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&L.tile_count[pi.owner], nt);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    SrTileRef *out = L.tiles + (size_t)pi.owner * L.tile_cap + base;
+    for (uint32_t k = lane; k < nt; k += 64) out[k] = SrTileRef{p, b + k * (uint32_t)kSrTile};
+  } else {
+    for (uint32_t x = 0; x < (uint32_t)kSrXcds; x++) {
+      if (nt <= x) break;
+      const uint32_t ntx = (nt - x + kSrXcds - 1) / kSrXcds;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&L.tile_count[x], ntx);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      SrTileRef *out = L.tiles + (size_t)x * L.tile_cap + base;
+      for (uint32_t k = lane; k < ntx; k += 64) out[k] = SrTileRef{p, b + (x + k * kSrXcds) * (uint32_t)kSrTile};
+    }
+  }
+}
+
+// keys per (part, bucket): a workgroup keeps counting in LDS while its tiles stay in one part; the next tile's keys
+// are requested before this tile's are searched
+__global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
+  __shared__ uint64_t sp[kSrMaxSplit + 1];
+  __shared__ uint32_t hist[kSrMaxNb + 1];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t x = blockIdx.x & (kSrXcds - 1), j0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+  const uint32_t nt = L.tile_count[x];
+  const SrTileRef *tiles = L.tiles + (size_t)x * L.tile_cap;
+  uint32_t cur = ~0u, S = 0, fs = 0;
+  // (a tile never crosses its part's end: begin + kSrTile is clipped by the start of the part behind)
+  auto tile_end = [&](const SrTileRef &r) {
+    const uint32_t pe = L.part_start[r.part + 1];
+    return pe - r.begin > (uint32_t)kSrTile ? r.begin + (uint32_t)kSrTile : pe;
+  };
+  auto fetch = [&](const SrTileRef &r, uint32_t end, uint64_t (&k)[kSrPartPer]) {
+#pragma unroll
+    for (int u = 0; u < kSrPartPer; u++) {
+      const uint64_t i = (uint64_t)r.begin + u * kSrPartThreads + tid;
+      k[u] = i < end ? __builtin_nontemporal_load(L.keys_in + i) : 0ull;
+    }
+  };
+  SrTileRef ref = j0 < nt ? tiles[j0] : SrTileRef{0, 0};
+  uint32_t end = j0 < nt ? tile_end(ref) : 0;
+  uint64_t key[kSrPartPer];
+  if (j0 < nt) fetch(ref, end, key);
+  for (uint32_t j = j0; j < nt; j += W) {
+    const bool more = j + W < nt;
+    const SrTileRef nref = more ? tiles[j + W] : SrTileRef{0, 0};
+    const uint32_t nend = more ? tile_end(nref) : 0;
+    uint64_t nkey[kSrPartPer];
+    if (more) fetch(nref, nend, nkey);
+    if (ref.part != cur) {
+      __syncthreads();
+      if (S) {
+        for (uint32_t v = tid; v < 2 * S + 1; v += kSrPartThreads) {
+          const uint32_t h = hist[v];
+          if (h) atomicAdd(&L.tot[(size_t)cur * L.nb + v], h);
+        }
+        __syncthreads();
+      }
+      cur = ref.part;
+      const SrPartInfo pi = sr_part_info(L, cur);
+      S = pi.eq ? 0u : L.split_count;
+      fs = sr_first_step(S);
+      sr_load_splitters(L, pi, S, sp);
+      for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb; v += kSrPartThreads) hist[v] = 0;
+      __syncthreads();
+    }
+    if (S) {  // (an equality part is one bucket: the offsets kernel knows its size)
+#pragma unroll
+      for (int u = 0; u < kSrPartPer; u++) {
+        const bool ok = (uint64_t)ref.begin + u * kSrPartThreads + tid < end;
+        (void)sr_claim(hist, ok ? sr_bucket(sp, S, fs, key[u]) : 0u, ok);
+      }
+    }
+    ref = nref;
+    end = nend;
+#pragma unroll
+    for (int u = 0; u < kSrPartPer; u++) key[u] = nkey[u];
+  }
+  __syncthreads();
+  if (S)
+    for (uint32_t v = tid; v < 2 * S + 1; v += kSrPartThreads) {
+      const uint32_t h = hist[v];
+      if (h) atomicAdd(&L.tot[(size_t)cur * L.nb + v], h);
+    }
+}
+
+// pass 0: bucket v starts at (keys of lower buckets); inside it the stretches follow one another
+__global__ __launch_bounds__(512) void sr_offsets_first_kernel(SrLevel L) {
+  __shared__ uint32_t start[kSrMaxNb + 9];
+  __shared__ uint32_t wsum[8];
+  const uint32_t tid = threadIdx.x;
+  uint32_t total = 0;
+  if (tid < L.nb)
+    for (uint32_t p = 0; p < L.nparts; p++) total += L.tot[(size_t)p * L.nb + tid];
+  for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb + 8; v += 512) start[v] = 0;
+  __syncthreads();
+  if (tid < L.nb) start[tid] = total;
+  __syncthreads();
+  sr_block_scan8<512>(start, L.nb, 0u, true, wsum);
+  if (tid < L.nb) {
+    uint32_t run = start[tid];
+    L.bstart[tid] = run;
+    for (uint32_t p = 0; p < L.nparts; p++) {
+      L.cursor[(size_t)p * L.nb + tid] = run;
+      run += L.tot[(size_t)p * L.nb + tid];
+    }
+    L.tot[tid] = total;  // (row 0 now holds the buckets' sizes: what the last pass's work list reads)
+  }
+  if (tid == 0) L.bstart[L.nb] = start[L.nb];
+}
+
+// later passes: the buckets of part p start at part_start[p] + (keys of the part's lower buckets).  One wave per part.
+__global__ __launch_bounds__(512) void sr_offsets_kernel(SrLevel L) {
+  const uint32_t p = (blockIdx.x * 512u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (p >= L.nparts) return;
+  const uint32_t b = L.part_start[p], e = L.part_start[p + 1];
+  const SrPartInfo pi = sr_part_info(L, p);
+  uint32_t *tot = L.tot + (size_t)p * L.nb, *cur = L.cursor + (size_t)p * L.nb, *bs = L.bstart + (size_t)p * L.nb;
+  uint32_t v[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = lane * 8 + k;
+    v[k] = (i < L.nb && !pi.eq) ? tot[i] : 0u;
+    if (pi.eq && i == 0) v[k] = e - b;
+    s += v[k];
+  }
+  uint32_t incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  uint32_t run = b + incl - s;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = lane * 8 + k;
+    if (i < L.nb) {
+      cur[i] = run;
+      bs[i] = run;
+      if (pi.eq) tot[i] = v[k];
+    }
+    run += v[k];
+  }
+  if (p == L.nparts - 1 && lane == 0) L.bstart[(size_t)L.nparts * L.nb] = e;
+}
+
+// the pass proper: a tile's keys (and payloads) grouped by bucket in LDS, every run placed with one reservation; the
+// next tile's keys are requested before this tile's are searched
+template <int PB>
+__global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
+  __shared__ uint64_t sp[kSrMaxSplit + 1];
+  __shared__ uint64_t stage_k[kSrTile];
+  __shared__ uint64_t stage_p8[PB == 8 ? kSrTile : 1];
+  __shared__ uint32_t stage_p4[PB == 4 ? kSrTile : 1];
+  __shared__ uint16_t ids[kSrTile];
+  __shared__ uint32_t hist[kSrMaxNb + 1];
+  __shared__ uint32_t delta[kSrMaxNb + 1];
+  __shared__ uint32_t wsum[kSrPartThreads / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t x = blockIdx.x & (kSrXcds - 1), j0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+  const uint32_t nt = L.tile_count[x];
+  const SrTileRef *tiles = L.tiles + (size_t)x * L.tile_cap;
+  const uint64_t *pin8 = (const uint64_t *)L.pay_in;
+  const uint32_t *pin4 = (const uint32_t *)L.pay_in;
+  uint64_t *pout8 = (uint64_t *)L.pay_out;
+  uint32_t *pout4 = (uint32_t *)L.pay_out;
+  uint32_t cur = ~0u, S = 0, fs = 0;
+  auto tile_end = [&](const SrTileRef &r) {
+    const uint32_t pe = L.part_start[r.part + 1];
+    return pe - r.begin > (uint32_t)kSrTile ? r.begin + (uint32_t)kSrTile : pe;
+  };
+  auto fetch = [&](const SrTileRef &r, uint32_t end, uint64_t (&k)[kSrPartPer], uint64_t (&q8)[PB == 8 ? kSrPartPer : 1],
+                   uint32_t (&q4)[PB == 4 ? kSrPartPer : 1]) {
+#pragma unroll
+    for (int u = 0; u < kSrPartPer; u++) {
+      const uint64_t i = (uint64_t)r.begin + u * kSrPartThreads + tid;
+      const bool ok = i < end;
+      k[u] = ok ? __builtin_nontemporal_load(L.keys_in + i) : 0ull;
+      if (PB == 8) q8[u] = ok ? __builtin_nontemporal_load(pin8 + i) : 0ull;
+      if (PB == 4) q4[u] = (ok && pin4) ? __builtin_nontemporal_load(pin4 + i) : (uint32_t)i;
+    }
+  };
+  SrTileRef ref = j0 < nt ? tiles[j0] : SrTileRef{0, 0};
+  uint32_t end = j0 < nt ? tile_end(ref) : 0;
+  uint64_t key[kSrPartPer];
+  uint64_t p8[PB == 8 ? kSrPartPer : 1];
+  uint32_t p4[PB == 4 ? kSrPartPer : 1];
+  if (j0 < nt) fetch(ref, end, key, p8, p4);
+  for (uint32_t j = j0; j < nt; j += W) {
+    const bool more = j + W < nt;
+    const SrTileRef nref = more ? tiles[j + W] : SrTileRef{0, 0};
+    const uint32_t nend = more ? tile_end(nref) : 0;
+    uint64_t nkey[kSrPartPer];
+    uint64_t np8[PB == 8 ? kSrPartPer : 1];
+    uint32_t np4[PB == 4 ? kSrPartPer : 1];
+    if (more) fetch(nref, nend, nkey, np8, np4);
+    if (ref.part != cur) {
+      __syncthreads();
+      cur = ref.part;
+      const SrPartInfo pi = sr_part_info(L, cur);
+      S = pi.eq ? 0u : L.split_count;
+      fs = sr_first_step(S);
+      sr_load_splitters(L, pi, S, sp);
+      for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb; v += kSrPartThreads) hist[v] = 0;
+      __syncthreads();
+    }
+    if (S == 0) {  // one bucket that starts where the part starts: the keys keep their places
+#pragma unroll
+      for (int u = 0; u < kSrPartPer; u++) {
+        const uint64_t i = (uint64_t)ref.begin + u * kSrPartThreads + tid;
+        if (i < end) {
+          L.keys_out[i] = key[u];
+          if (PB == 8) pout8[i] = p8[u];
+          if (PB == 4) pout4[i] = p4[u];
+        }
+      }
+    } else {
+      uint32_t bk[kSrPartPer], rk[kSrPartPer];
+#pragma unroll
+      for (int u = 0; u < kSrPartPer; u++) {
+        const bool ok = (uint64_t)ref.begin + u * kSrPartThreads + tid < end;
+        bk[u] = ok ? sr_bucket(sp, S, fs, key[u]) : 0u;
+        rk[u] = sr_claim(hist, bk[u], ok);  // (the key's place inside its run)
+      }
+      __syncthreads();
+      // one reservation per run -- its round trip runs under the scan and the regrouping: only the stores need it
+      const uint32_t h = tid < 2 * S + 1 ? hist[tid] : 0u;
+      const uint32_t reserved = h ? atomicAdd(&L.cursor[(size_t)cur * L.nb + tid], h) : 0u;
+      uint32_t incl = h;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t excl = incl - h;
+      for (uint32_t w = 0; w < wave; w++) excl += wsum[w];
+      hist[tid] = excl;  // (tid <= kSrMaxNb)
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kSrPartPer; u++) {
+        if ((uint64_t)ref.begin + u * kSrPartThreads + tid < end) {
+          const uint32_t at = hist[bk[u]] + rk[u];
+          stage_k[at] = key[u];
+          if (PB == 8) stage_p8[at] = p8[u];
+          if (PB == 4) stage_p4[at] = p4[u];
+          ids[at] = (uint16_t)bk[u];
+        }
+      }
+      delta[tid] = reserved - excl;
+      __syncthreads();
+      hist[tid] = 0;  // (nobody reads the counts any more; the barrier below stands before the next tile's)
+      const uint32_t count = end - ref.begin;
+      for (uint32_t q = tid; q < count; q += kSrPartThreads) {
+        const uint32_t at = q + delta[ids[q]];
+        L.keys_out[at] = stage_k[q];
+        if (PB == 8) pout8[at] = stage_p8[q];
+        if (PB == 4) pout4[at] = stage_p4[q];
+      }
+      __syncthreads();
+    }
+    ref = nref;
+    end = nend;
+#pragma unroll
+    for (int u = 0; u < kSrPartPer; u++) {
+      key[u] = nkey[u];
+      if (PB == 8) p8[u] = np8[u];
+      if (PB == 4) p4[u] = np4[u];
+    }
+  }
+}
+
+// ---- the last pass's work lists ------------------------------------------------------------------------------------
+// `small`: buckets the 256-thread kernel ranks (and the pieces of equality buckets), `large`: the others
+__global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buckets, uint32_t small_cap, SrItem *small,
+                                                        uint32_t *n_small, SrItem *large, uint32_t *n_large) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t block_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t rows = L.level == 0 ? 1ull : (uint64_t)L.nparts;  // (pass 0: row 0 holds the buckets' sizes)
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + tid, total = rows * L.nb;
+  uint32_t cnt = 0, st = 0;
+  bool eq = false;
+  if (e < total) {
+    const uint32_t p = (uint32_t)(e / L.nb), v = (uint32_t)(e % L.nb);
+    const bool part_eq = L.level == 0 ? false : sr_part_info(L, p).eq;
+    if (!(part_eq && v > 0)) cnt = L.tot[e];
+    eq = part_eq || (v & 1u);
+    st = L.bstart[e];
+  }
+  // a bucket between two splitters knows its key range (the small kernel bins by it); the first and the last bucket of
+  // all do not: they go with the large ones, whose kernel takes the range from the keys
+  uint64_t lo = 0, hi = 0;
+  bool edge = false;
+  if (cnt && !eq) {
+    const uint32_t p = (uint32_t)(e / L.nb), v = (uint32_t)(e % L.nb);
+    const uint64_t g = (L.level == 0 ? 0ull : sr_part_info(L, p).first) + (v >> 1);  // (the last pass: stride 1)
+    edge = g == 0 || g + 1 >= n_buckets;
+    if (!edge) {
+      lo = L.fine[g - 1];
+      hi = L.fine[g];
+    }
+  }
+  const bool big = (cnt > small_cap || edge) && !eq;
+  const uint32_t ni = (cnt == 0 || big) ? 0u : (eq ? (cnt + kSrEqPiece - 1) / kSrEqPiece : 1u);
+  uint32_t incl = ni;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t off = incl - ni;
+  for (uint32_t w = 0; w < wave; w++) off += wsum[w];
+  if (tid == 0) {
+    const uint32_t all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    block_base = all ? atomicAdd(n_small, all) : 0u;
+  }
+  __syncthreads();
+  if (big) large[atomicAdd(n_large, 1u)] = SrItem{st, cnt, st, 0u, 0ull, 0ull};
+  if (ni == 0) return;
+  SrItem *out = small + block_base + off;
+  if (!eq) {
+    out[0] = SrItem{st, cnt, st, 0u, lo, hi};
+  } else {
+    for (uint32_t k = 0; k < ni; k++) {
+      const uint32_t at = k * kSrEqPiece;
+      out[k] = SrItem{st + at, cnt - at < kSrEqPiece ? cnt - at : kSrEqPiece, st, 1u, 0ull, 0ull};
+    }
+  }
+}
+// (a job of one bucket: no splitters, hence no key range: the large kernel's)
+__global__ void sr_one_item_kernel(SrItem *large, uint32_t *n_small, uint32_t *n_large, uint32_t n) {
+  large[0] = SrItem{0u, n, 0u, 0u, 0ull, 0ull};
+  *n_small = 0;
+  *n_large = 1;
+}
+
+// ---- the last pass -------------------------------------------------------------------------------------------------
+struct SrSumAcc {
+  // sum(a), sum(b) stay below 2^64 (ranks <= n < 2^32: at most n (n + 1) / 2); the products need 128 bits
+  unsigned long long lo[5], hi[3];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int k = 0; k < 5; k++) lo[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) hi[k] = 0;
+  }
+  __device__ __forceinline__ void add(unsigned long long a, unsigned long long b) {
+    lo[0] += a;
+    lo[1] += b;
+    const unsigned __int128 t[3] = {(unsigned __int128)a * a, (unsigned __int128)b * b, (unsigned __int128)a * b};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const unsigned long long tl = (unsigned long long)t[k], th = (unsigned long long)(t[k] >> 64);
+      const unsigned long long s = lo[2 + k] + tl;
+      hi[k] += th + (s < tl ? 1ull : 0ull);
+      lo[2 + k] = s;
+    }
+  }
+};
+// the workgroup's sums: waves through shuffles, then LDS; every workgroup writes its slot
+template <int THREADS>
+__device__ __forceinline__ void sr_store_sums(const SrSumAcc &acc, RankSums *slot) {
+  __shared__ RankSums sh[THREADS / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    unsigned long long lo = acc.lo[k], hi = k >= 2 ? acc.hi[k - 2] : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long olo = __shfl_down(lo, d, 64), ohi = __shfl_down(hi, d, 64);
+      const unsigned long long s = lo + olo;
+      hi += ohi + (s < lo ? 1ull : 0ull);
+      lo = s;
+    }
+    if (lane == 0) {
+      sh[tid >> 6].exact_lo[k] = lo;
+      sh[tid >> 6].exact_hi[k] = hi;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    RankSums r = sh[0];
+    for (int wv = 1; wv < THREADS / 64; wv++)
+      for (int k = 0; k < 5; k++) {
+        const unsigned long long s = r.exact_lo[k] + sh[wv].exact_lo[k];
+        r.exact_hi[k] += sh[wv].exact_hi[k] + (s < r.exact_lo[k] ? 1ull : 0ull);
+        r.exact_lo[k] = s;
+      }
+    // UInt64 arithmetic that wraps (the reference's) is the exact sum modulo 2^64: ranks are below 2^33, and a
+    // product reduced modulo 2^64 before or after the summation is the same residue
+    for (int k = 0; k < 5; k++) r.wrapped[k] = r.exact_lo[k];
+    *slot = r;
+  }
+}
+
+// does the sink read the payload where the key lies?
+template <int PB, int SINK>
+struct SrWantsPay {
+  static constexpr bool k4 = (SINK == kSrSums || SINK == kSrRankScatter || (SINK == kSrSorted && PB == 4));
+  static constexpr bool k8 = SINK == kSrSorted && PB == 8;
+};
+
+template <int PB, int SINK>
+__device__ __forceinline__ void sr_emit(const SrFinal &F, const SrItem &it, uint64_t g, uint64_t key, uint32_t pay4,
+                                        uint64_t pay8, uint32_t lt, uint32_t eqb, SrSumAcc &acc) {
+  if (SINK == kSrSorted) {
+    const uint64_t at = (it.flags & 1u) ? g : (uint64_t)it.start + lt + eqb;
+    F.out_keys[at] = key;
+    if (PB == 8) ((uint64_t *)F.out_pay)[at] = pay8;
+    if (PB == 4) ((uint32_t *)F.out_pay)[at] = pay4;
+  } else if (SINK == kSrRank32) {
+    F.rank32[g] = it.rank_base + lt;
+  } else if (SINK == kSrSums) {
+    acc.add((unsigned long long)pay4 + 1ull, (unsigned long long)it.rank_base + lt + 1ull);
+  } else {
+    F.rank_out[pay4] = F.ext_base + it.rank_base + lt + 1ull;
+  }
+}
+template <int PB, int SINK>
+__device__ __forceinline__ uint32_t sr_pay4(const SrFinal &F, uint64_t g) {
+  if (!SrWantsPay<PB, SINK>::k4) return 0u;
+  const uint32_t *p = (const uint32_t *)F.pay;
+  return p ? __builtin_nontemporal_load(p + g) : (uint32_t)g;
+}
+template <int PB, int SINK>
+__device__ __forceinline__ uint64_t sr_pay8(const SrFinal &F, uint64_t g) {
+  if (!SrWantsPay<PB, SINK>::k8) return 0ull;
+  return __builtin_nontemporal_load((const uint64_t *)F.pay + g);
+}
+
+// buckets of up to kSrFastCap keys between two known splitters, one per workgroup and trip; the next bucket's keys are
+// on their way while this one's are ranked.  Five barriers a bucket: the bins of the NEXT bucket are cleared while this
+// one's keys are compared (two sets of bins take turns).
+template <int PB, int SINK>
+__global__ __launch_bounds__(kSrFastThreads) void sr_rank_small_kernel(SrFinal F) {
+  constexpr bool kWantOrder = SINK == kSrSorted;  // positions among EQUAL keys matter only when the keys are laid out
+  constexpr int kBins = 1 << kSrFastBinBits;
+  constexpr bool kPay8 = SrWantsPay<PB, SINK>::k8;
+  __shared__ uint64_t skey[kSrFastCap];
+  __shared__ uint32_t bins2[2][kBins + 8];
+  __shared__ uint32_t wsum[kSrFastThreads / 64];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_items = *F.n_items, G = gridDim.x;
+  SrSumAcc acc;
+  acc.clear();
+  for (uint32_t v = tid; v < 2u * (kBins + 8); v += kSrFastThreads) (&bins2[0][0])[v] = 0;
+  __syncthreads();
+
+  uint32_t w = blockIdx.x, par = 0;
+  const SrItem none = SrItem{0, 0, 0, 1, 0, 0};
+  SrItem it = w < n_items ? F.items[w] : none;
+  SrItem it_next = w + G < n_items ? F.items[w + G] : none;
+  uint64_t key[kSrFastPer];
+  uint32_t pay4[kSrFastPer];
+  uint64_t pay8[kPay8 ? kSrFastPer : 1];
+  auto fetch = [&](const SrItem &t, uint64_t (&k)[kSrFastPer], uint32_t (&p4)[kSrFastPer],
+                   uint64_t (&p8)[kPay8 ? kSrFastPer : 1]) {
+    if (t.flags & 1u) return;  // (equality pieces are walked where they lie)
+#pragma unroll
+    for (int u = 0; u < kSrFastPer; u++) {
+      const uint32_t e = tid + u * kSrFastThreads;
+      const uint64_t g = (uint64_t)t.start + e;
+      k[u] = 0;
+      p4[u] = 0;
+      if (e < t.count) {
+        k[u] = __builtin_nontemporal_load(F.keys + g);
+        p4[u] = sr_pay4<PB, SINK>(F, g);
+        if (kPay8) p8[u] = sr_pay8<PB, SINK>(F, g);
+      }
+    }
+  };
+  fetch(it, key, pay4, pay8);
+
+  for (; w < n_items; w += G) {
+    // the trip after this one: its descriptor was requested a trip ago, its keys are requested now
+    const SrItem it_next2 = w + 2 * G < n_items ? F.items[w + 2 * G] : none;
+    uint64_t nkey[kSrFastPer];
+    uint32_t npay4[kSrFastPer];
+    uint64_t npay8[kPay8 ? kSrFastPer : 1];
+    fetch(it_next, nkey, npay4, npay8);
+
+    if (it.flags & 1u) {  // every key the same: RANK() is the bucket's first position for all of them
+      for (uint32_t e = tid; e < it.count; e += kSrFastThreads) {
+        const uint64_t g = (uint64_t)it.start + e;
+        sr_emit<PB, SINK>(F, it, g, SINK == kSrSorted ? F.keys[g] : 0ull, sr_pay4<PB, SINK>(F, g), sr_pay8<PB, SINK>(F, g),
+                          0u, 0u, acc);
+      }
+    } else {
+      uint32_t *bins = bins2[par], *other = bins2[par ^ 1u];
+      par ^= 1u;
+      const uint32_t m = it.count;
+      const uint64_t kbase = it.lo + 1, span = it.hi - it.lo - 2;  // (lo < key < hi)
+      const int shift = span < (uint64_t)kBins ? 0 : (64 - (int)__builtin_clzll(span)) - kSrFastBinBits;
+      uint32_t slot[kSrFastPer];
+#pragma unroll
+      for (int u = 0; u < kSrFastPer; u++)
+        if (tid + u * kSrFastThreads < m) slot[u] = atomicAdd(&bins[(uint32_t)((key[u] - kbase) >> shift)], 1u);
+      __syncthreads();
+      sr_block_scan8<kSrFastThreads>(bins, kBins, 0u, true, wsum);
+#pragma unroll
+      for (int u = 0; u < kSrFastPer; u++)
+        if (tid + u * kSrFastThreads < m) {
+          slot[u] += bins[(uint32_t)((key[u] - kbase) >> shift)];
+          skey[slot[u]] = key[u];
+        }
+      __syncthreads();
+      for (uint32_t v = tid; v < (uint32_t)kBins + 1; v += kSrFastThreads) other[v] = 0;  // (the next bucket's bins)
+#pragma unroll
+      for (int u = 0; u < kSrFastPer; u++) {
+        if (tid + u * kSrFastThreads >= m) continue;
+        const uint32_t d = (uint32_t)((key[u] - kbase) >> shift);
+        const uint32_t b0 = bins[d], b1 = bins[d + 1];
+        uint32_t lt = b0, eqb = 0;  // everything in a lower bin is smaller
+        if (shift == 0) {          // a bin is one value
+          if (kWantOrder) eqb = slot[u] - b0;
+        } else {
+          for (uint32_t j = b0; j < b1; j++) {
+            const uint64_t kk = skey[j];
+            lt += kk < key[u] ? 1u : 0u;
+            if (kWantOrder) eqb += (kk == key[u] && j < slot[u]) ? 1u : 0u;
+          }
+        }
+        sr_emit<PB, SINK>(F, it, (uint64_t)it.start + tid + u * kSrFastThreads, key[u], pay4[u], kPay8 ? pay8[u] : 0ull,
+                          lt, eqb, acc);
+      }
+      __syncthreads();
+    }
+    it = it_next;
+    it_next = it_next2;
+#pragma unroll
+    for (int u = 0; u < kSrFastPer; u++) {
+      key[u] = nkey[u];
+      pay4[u] = npay4[u];
+      if (kPay8) pay8[u] = npay8[u];
+    }
+  }
+  if (SINK == kSrSums) sr_store_sums<kSrFastThreads>(acc, F.partials + blockIdx.x);
+}
+
+// buckets of any size: F.cap keys at a time, every chunk ranked against every chunk
+template <int PB, int SINK>
+__global__ __launch_bounds__(kSrSlowThreads) void sr_rank_large_kernel(SrFinal F) {
+  constexpr bool kWantOrder = SINK == kSrSorted;
+  constexpr int kBins = 1 << kSrSlowBinBits;
+  __shared__ uint64_t skey[kSrSlowCap];
+  __shared__ uint32_t bins[kBins + 8];
+  __shared__ unsigned long long s_mn, s_mx;
+  __shared__ uint32_t wsum[kSrSlowThreads / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t n_items = *F.n_items;
+  SrSumAcc acc;
+  acc.clear();
+
+  for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+    const SrItem it = F.items[w];
+    const uint32_t C = F.cap, m = it.count, nch = (m + C - 1) / C;
+    if (tid == 0) {
+      s_mn = ~0ull;
+      s_mx = 0ull;
+    }
+    __syncthreads();
+    {
+      unsigned long long mn = ~0ull, mx = 0ull;
+      for (uint32_t e = tid; e < m; e += kSrSlowThreads) {
+        const unsigned long long k = F.keys[(uint64_t)it.start + e];
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+      }
+      if (lane == 0) {
+        atomicMin(&s_mn, mn);
+        atomicMax(&s_mx, mx);
+      }
+    }
+    __syncthreads();
+    const uint64_t kbase = s_mn, span = s_mx - s_mn;
+    const int shift = span < (uint64_t)kBins ? 0 : (64 - (int)__builtin_clzll(span)) - kSrSlowBinBits;
+
+    for (uint32_t ci = 0; ci < nch; ci++) {
+      const uint32_t ilen = m - ci * C < C ? m - ci * C : C;
+      uint64_t key[kSrSlowPer];
+      uint32_t okm = 0;
+#pragma unroll
+      for (int u = 0; u < kSrSlowPer; u++) {
+        const uint32_t e = tid + u * kSrSlowThreads;
+        key[u] = 0;
+        if (e < ilen) {
+          key[u] = F.keys[(uint64_t)it.start + (uint64_t)ci * C + e];
+          okm |= 1u << u;
+        }
+      }
+      uint32_t lt[kSrSlowPer], eqb[kSrSlowPer];
+#pragma unroll
+      for (int u = 0; u < kSrSlowPer; u++) lt[u] = eqb[u] = 0;
+
+      for (uint32_t cj = 0; cj < nch; cj++) {
+        const bool own = cj == ci;
+        const uint32_t jlen = m - cj * C < C ? m - cj * C : C;
+        uint64_t kj[kSrSlowPer];
+        uint32_t okj = 0;
+        if (own) {
+#pragma unroll
+          for (int u = 0; u < kSrSlowPer; u++) kj[u] = key[u];
+          okj = okm;
+        } else {
+#pragma unroll
+          for (int u = 0; u < kSrSlowPer; u++) {
+            const uint32_t e = tid + u * kSrSlowThreads;
+            kj[u] = 0;
+            if (e < jlen) {
+              kj[u] = F.keys[(uint64_t)it.start + (uint64_t)cj * C + e];
+              okj |= 1u << u;
+            }
+          }
+        }
+        for (uint32_t v = tid; v < (uint32_t)kBins + 1; v += kSrSlowThreads) bins[v] = 0;
+        __syncthreads();
+        uint32_t slot[kSrSlowPer];
+#pragma unroll
+        for (int u = 0; u < kSrSlowPer; u++) {
+          const bool ok = (okj >> u) & 1u;
+          const uint32_t d = ok ? (uint32_t)((kj[u] - kbase) >> shift) : 0u;
+          slot[u] = sr_claim(bins, d, ok);  // (arrival order inside the bin)
+        }
+        __syncthreads();
+        sr_block_scan8<kSrSlowThreads>(bins, kBins, 0u, true, wsum);
+#pragma unroll
+        for (int u = 0; u < kSrSlowPer; u++)
+          if ((okj >> u) & 1u) {
+            slot[u] += bins[(uint32_t)((kj[u] - kbase) >> shift)];
+            skey[slot[u]] = kj[u];
+          }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kSrSlowPer; u++) {
+          if (!((okm >> u) & 1u)) continue;
+          const uint32_t d = (uint32_t)((key[u] - kbase) >> shift);
+          const uint32_t b0 = bins[d], b1 = bins[d + 1];
+          lt[u] += b0;  // everything in a lower bin is smaller
+          if (shift == 0) {  // a bin is one value
+            if (kWantOrder) eqb[u] += cj < ci ? b1 - b0 : (own ? slot[u] - b0 : 0u);
+          } else {
+            for (uint32_t j = b0; j < b1; j++) {
+              const uint64_t kk = skey[j];
+              lt[u] += kk < key[u] ? 1u : 0u;
+              if (kWantOrder) eqb[u] += (kk == key[u] && (cj < ci || (own && j < slot[u]))) ? 1u : 0u;
+            }
+          }
+        }
+        __syncthreads();  // bins / skey are rebuilt by the next chunk (or item)
+      }
+#pragma unroll
+      for (int u = 0; u < kSrSlowPer; u++)
+        if ((okm >> u) & 1u) {
+          const uint64_t g = (uint64_t)it.start + (uint64_t)ci * C + tid + u * kSrSlowThreads;
+          sr_emit<PB, SINK>(F, it, g, key[u], sr_pay4<PB, SINK>(F, g), sr_pay8<PB, SINK>(F, g), lt[u], eqb[u], acc);
+        }
+    }
+  }
+  if (SINK == kSrSums) sr_store_sums<kSrSlowThreads>(acc, F.partials + blockIdx.x);
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+  const char *e = getenv(name);
+  if (!e || !*e) return dflt;
+  const long long v = atoll(e);
+  if (v < (long long)lo) return lo;
+  if (v > (long long)hi) return hi;
+  return (uint32_t)v;
+}
+
+struct SrShape {
+  int levels = 0;
+  uint32_t f[3] = {1, 1, 1};
+  uint32_t every = 1;
+  uint64_t buckets = 1, ns = 0, sample_stride = 1;
+  uint32_t nparts[3] = {1, 1, 1}, nb[3] = {1, 1, 1}, tile_cap[3] = {1, 1, 1};
+  uint32_t per_part = kSrTile;
+  uint64_t max_small = 1, max_large = 1;
+};
+
+SrShape sr_shape(uint64_t n, const SrTuning &t) {
+  SrShape s;
+  if (n <= t.cap) return s;
+  const uint64_t max_f = (uint64_t)t.max_split + 1;
+  uint64_t b = (n + t.target - 1) / t.target;
+  if (b < 2) b = 2;
+  s.levels = b <= max_f ? 1 : (b <= max_f * max_f ? 2 : 3);
+  uint64_t f = (uint64_t)std::ceil(std::pow((double)b, 1.0 / s.levels));
+  while (s.levels == 2 && f * f < b) f++;
+  while (s.levels == 3 && f * f * f < b) f++;
+  f = std::min(std::max<uint64_t>(f, 2), max_f);
+  uint64_t below = 1;
+  for (int l = 0; l + 1 < s.levels; l++) {
+    s.f[l] = (uint32_t)f;
+    below *= f;
+  }
+  uint64_t last = (b + below - 1) / below;
+  last = std::min(std::max<uint64_t>(last, 2), max_f);
+  s.f[s.levels - 1] = (uint32_t)last;
+  s.buckets = below * last;
+  // (the sample is sorted by the same machinery: it has to be a fraction of the job)
+  uint64_t every = std::min<uint64_t>(t.oversample, n / (4 * s.buckets));
+  if (every < 1) every = 1;
+  s.every = (uint32_t)every;
+  s.ns = s.buckets * every;  // <= n when buckets <= n
+  if (s.ns > n) s.ns = n;    // (cannot happen: buckets <= ceil(n / target) * (rounding of three roots); kept honest)
+  s.sample_stride = std::max<uint64_t>(1, n / s.ns);
+  uint64_t per = (n + kSrFirstParts - 1) / kSrFirstParts;
+  per = (per + kSrTile - 1) / kSrTile * kSrTile;
+  s.per_part = (uint32_t)std::min<uint64_t>(per, 0x80000000ull);
+  uint64_t parts = kSrFirstParts;
+  for (int l = 0; l < s.levels; l++) {
+    s.nparts[l] = (uint32_t)parts;
+    s.nb[l] = 2 * (s.f[l] - 1) + 1;
+    s.tile_cap[l] = (uint32_t)std::min<uint64_t>(n / kSrTile + std::min<uint64_t>(parts, n) + 16, 0xFFFFFFF0ull);
+    parts = (l == 0 ? 1 : parts) * s.nb[l];
+  }
+  s.max_small = parts + n / kSrEqPiece + 2;  // (`parts` is now the number of buckets of the last pass)
+  s.max_large = n / (t.cap + 1) + 4;  // (+ the two buckets at the ends of the key range)
+  return s;
+}
+
+struct Carver {  // hands out pieces of the workspace; with base == nullptr it only adds up
+  char *base;
+  size_t off = 0;
+  template <class T>
+  T *take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T *p = base ? (T *)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+int sr_small_grid() { return std::max(1, tgx_num_cus()) * 6; }
+int sr_large_grid() { return std::max(1, tgx_num_cus()); }
+
+template <int PB, int SINK>
+void launch_rank(const SrFinal &small, const SrFinal &large, hipStream_t stream) {
+  hipLaunchKernelGGL((sr_rank_small_kernel<PB, SINK>), dim3(sr_small_grid()), dim3(kSrFastThreads), 0, stream, small);
+  hipLaunchKernelGGL((sr_rank_large_kernel<PB, SINK>), dim3(sr_large_grid()), dim3(kSrSlowThreads), 0, stream, large);
+}
+
+// queues the whole job; `dry`: only walks the workspace (sizes)
+hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const SrTuning &tune, bool dry, SrPlaced *placed,
+                       int depth) {
+  const uint64_t n = job.n;
+  if (placed) *placed = SrPlaced{job.keys, job.pay};
+  if (n == 0) return hipSuccess;
+  if (depth > 40) return hipErrorUnknown;
+  const SrShape sh = sr_shape(n, tune);
+  SrItem *small = ws.take<SrItem>(sh.max_small), *large = ws.take<SrItem>(sh.max_large);
+  uint32_t *counters = ws.take<uint32_t>(8);  // [0] small items, [1] large items
+  const uint64_t *keys = job.keys;
+  const void *pay = job.pay;
+  if (sh.levels == 0) {
+    if (!dry)
+      hipLaunchKernelGGL(sr_one_item_kernel, dim3(1), dim3(1), 0, stream, large, counters, counters + 1, (uint32_t)n);
+  } else {
+    // ---- splitters: a sorted sample
+    uint64_t *samp = ws.take<uint64_t>(sh.ns), *sorted = ws.take<uint64_t>(sh.ns);
+    uint64_t *fine = ws.take<uint64_t>(sh.buckets);
+    SrJob sj;
+    sj.keys = samp;
+    sj.n = sh.ns;
+    sj.pay_bytes = 0;
+    sj.k[0] = ws.take<uint64_t>(sh.ns);
+    sj.k[1] = ws.take<uint64_t>(sh.ns);
+    sj.sink = kSrSorted;
+    sj.out_keys = sorted;
+    if (!dry)
+      hipLaunchKernelGGL(sr_sample_kernel, dim3((unsigned)((sh.ns + 255) / 256)), dim3(256), 0, stream, job.keys, n, sh.ns,
+                         sh.sample_stride, samp);
+    hipError_t e = sr_run_impl(sj, ws, stream, tune, dry, nullptr, depth + 1);
+    if (e != hipSuccess) return e;
+    if (!dry)
+      hipLaunchKernelGGL(sr_pick_kernel, dim3((unsigned)((sh.buckets - 1 + 255) / 256)), dim3(256), 0, stream, sorted,
+                         sh.buckets - 1, sh.every, fine);
+    // ---- the partition passes
+    const int grid = kSrXcds * std::max<int>(1, (std::max(1, tgx_num_cus()) / kSrXcds) * (int)tune.wg_per_cu);
+    uint32_t *next_parts = nullptr;
+    SrLevel L;
+    for (int lv = 0; lv < sh.levels; lv++) {
+      L.keys_in = keys;
+      L.pay_in = pay;
+      L.keys_out = job.k[lv & 1];
+      L.pay_out = job.p[lv & 1];
+      L.fine = fine;
+      L.level = lv;
+      L.nbp = lv == 2 ? sh.nb[1] : 1;
+      // splitter k of a part: fine[first + (k + 1) * stride - 1], stride = the ways of the passes below
+      uint32_t below[3] = {1, 1, 1};
+      for (int l = sh.levels - 2; l >= 0; l--) below[l] = below[l + 1] * sh.f[l + 1];
+      L.stride = below[lv];
+      L.w1 = below[0];
+      L.w2 = sh.levels > 1 ? below[1] : 1;
+      L.split_count = sh.f[lv] - 1;
+      L.nb = sh.nb[lv];
+      L.nparts = sh.nparts[lv];
+      L.tile_cap = sh.tile_cap[lv];
+      L.tiles = ws.take<SrTileRef>((size_t)kSrXcds * L.tile_cap);
+      L.tile_count = ws.take<uint32_t>(kSrXcds);
+      const size_t table = (size_t)L.nparts * L.nb;
+      L.tot = ws.take<uint32_t>(table);
+      L.cursor = ws.take<uint32_t>(table);
+      L.bstart = ws.take<uint32_t>(table + 2);
+      if (lv == 0) {
+        L.part_start = ws.take<uint32_t>((size_t)L.nparts + 2);
+        if (!dry)
+          hipLaunchKernelGGL(sr_first_parts_kernel, dim3(1), dim3(128), 0, stream, L.part_start, L.nparts, sh.per_part,
+                             (uint32_t)n);
+      } else {
+        L.part_start = next_parts;
+      }
+      if (!dry) {
+        hipError_t e2 = hipMemsetAsync(L.tot, 0, table * sizeof(uint32_t), stream);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(L.tile_count, 0, kSrXcds * sizeof(uint32_t), stream);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(sr_tiles_kernel, dim3((L.nparts + 3) / 4), dim3(256), 0, stream, L);
+        hipLaunchKernelGGL(sr_count_kernel, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        if (lv == 0)
+          hipLaunchKernelGGL(sr_offsets_first_kernel, dim3(1), dim3(512), 0, stream, L);
+        else
+          hipLaunchKernelGGL(sr_offsets_kernel, dim3((L.nparts + 7) / 8), dim3(512), 0, stream, L);
+        if (job.pay_bytes == 8)
+          hipLaunchKernelGGL(sr_scatter_kernel<8>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        else if (job.pay_bytes == 4)
+          hipLaunchKernelGGL(sr_scatter_kernel<4>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        else
+          hipLaunchKernelGGL(sr_scatter_kernel<0>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+      }
+      keys = L.keys_out;
+      pay = L.pay_out;
+      next_parts = L.bstart;
+    }
+    if (!dry) {
+      hipError_t e2 = hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), stream);
+      if (e2 != hipSuccess) return e2;
+      const uint64_t entries = (uint64_t)(L.level == 0 ? 1 : L.nparts) * L.nb;
+      hipLaunchKernelGGL(sr_items_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, stream, L, sh.buckets,
+                         tune.cap, small, counters, large, counters + 1);
+    }
+  }
+  if (placed) *placed = SrPlaced{keys, pay};
+  if (dry) return hipSuccess;
+  SrFinal F;
+  F.keys = keys;
+  F.pay = pay;
+  F.items = small;
+  F.n_items = counters;
+  F.out_keys = job.out_keys;
+  F.out_pay = job.out_pay;
+  F.rank32 = job.rank32;
+  F.rank_out = job.rank_out;
+  F.ext_base = job.ext_base;
+  F.partials = job.partials;
+  F.cap = tune.slow_cap;
+  SrFinal FL = F;
+  FL.items = large;
+  FL.n_items = counters + 1;
+  FL.partials = job.partials ? job.partials + sr_small_grid() : nullptr;
+  switch (job.sink) {
+    case kSrSorted:
+      if (job.pay_bytes == 8)
+        launch_rank<8, kSrSorted>(F, FL, stream);
+      else if (job.pay_bytes == 4)
+        launch_rank<4, kSrSorted>(F, FL, stream);
+      else
+        launch_rank<0, kSrSorted>(F, FL, stream);
+      break;
+    case kSrRank32:
+      launch_rank<0, kSrRank32>(F, FL, stream);
+      break;
+    case kSrSums:
+      launch_rank<4, kSrSums>(F, FL, stream);
+      break;
+    default:
+      launch_rank<4, kSrRankScatter>(F, FL, stream);
+      break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+SrTuning sr_tuning() {
+  SrTuning t;
+  t.target = env_u32("TGX_SORT_TARGET", 1024, 2, 1u << 20);
+  t.oversample = env_u32("TGX_SORT_SAMPLE", 16, 1, 256);
+  t.cap = env_u32("TGX_SORT_CAP", kSrFastCap, 8, kSrFastCap);
+  t.slow_cap = env_u32("TGX_SORT_SLOWCAP", kSrSlowCap, 8, kSrSlowCap);
+  t.max_split = env_u32("TGX_SORT_SPLIT", kSrMaxSplit, 1, kSrMaxSplit);
+  t.wg_per_cu = env_u32("TGX_SORT_WG", 3, 1, 16);
+  return t;
+}
+
+int sr_partials_count() { return sr_small_grid() + sr_large_grid(); }
+
+size_t sr_workspace_bytes(uint64_t n) {
+  Carver c{nullptr};
+  SrJob j;
+  j.n = n;
+  (void)sr_run_impl(j, c, nullptr, sr_tuning(), true, nullptr, 0);
+  return c.off + 256;
+}
+
+hipError_t sr_run(const SrJob &job, void *workspace, size_t workspace_bytes, hipStream_t stream, SrPlaced *placed) {
+  if (job.n > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+  const SrTuning tune = sr_tuning();
+  Carver dry{nullptr};
+  hipError_t e = sr_run_impl(job, dry, stream, tune, true, nullptr, 0);
+  if (e != hipSuccess) return e;
+  if (dry.off + 256 > workspace_bytes) return hipErrorOutOfMemory;
+  Carver c{(char *)workspace};
+  return sr_run_impl(job, c, stream, tune, false, placed, 0);
+}
+
+}  // namespace tgx

@@ -6,16 +6,15 @@
 //   SELECT COUNT(*), SUM(rank_x), SUM(rank_y), SUM(rank_x*rank_x), SUM(rank_y*rank_y), SUM(rank_x*rank_y)
 // i.e. two global sorts with min-rank ties and UInt64 arithmetic that wraps (the sums of squares overflow past
 // ~3.8 M rows).  Not mergeable (`:103-109`), so the state keeps the (x, y) pairs of every batch and ranks them at
-// finalize.  Off the hot path (SURVEY.md section 8d times it separately): the two device sorts and the max-scan use
-// rocPRIM's radix_sort_pairs / inclusive_scan (a plain library primitive); compaction, tie ranking and the
-// sums are kernels of this file.
+// finalize.  Off the hot path (SURVEY.md section 8d times it separately).  The ranking itself is kernels/sortrank.hip
+// (a sample sort that counts ranks bucket by bucket in LDS); this file holds the pair compaction and the pieces of
+// the cross-rank ranking.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include "device_types.h"
+#include "sortrank.h"
 
 namespace tgx {
 
@@ -29,8 +28,10 @@ __device__ __forceinline__ uint64_t sort_key(int64_t bits, int is_float) {
 }
 
 // appends the (x, y) sort keys of rows where both sides are non-NULL; *count is the running pair count.
-// A workgroup takes 2048 consecutive rows per trip, eight per thread: one global atomic (and three barriers) per 2048
-// rows -- with 256 rows per trip the kernel ran at 0.7 TB/s, bound by the latency of that atomic.
+// A workgroup takes 2048 consecutive rows per trip, eight per thread: one global atomic (and two barriers) per 2048
+// rows -- with 256 rows per trip the kernel ran at 0.7 TB/s, bound by that atomic.  The pairs of a trip are placed by
+// ballot: per step the valid lanes of a wave write NEIGHBOURING slots (a thread that placed its own eight pairs one
+// behind the other made every store instruction touch 64 lines).
 constexpr int kCompactRows = 8;
 __global__ __launch_bounds__(256) void spearman_compact_kernel(ComomentColDesc d, uint64_t *kx, uint64_t *ky,
                                                                 unsigned long long *count) {
@@ -40,13 +41,14 @@ __global__ __launch_bounds__(256) void spearman_compact_kernel(ComomentColDesc d
   global_u8_ptr yv = (global_u8_ptr)(uintptr_t)d.yv;
   __shared__ unsigned long long block_base;
   __shared__ uint32_t wave_cnt[4];
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wave = threadIdx.x >> 6;
   constexpr int64_t kTrip = 256 * kCompactRows;
   const int64_t step = (int64_t)gridDim.x * kTrip;
   const int64_t rounded = (d.length + step - 1) / step * step;
   for (int64_t base = (int64_t)blockIdx.x * kTrip; base < rounded; base += step) {
-    uint32_t okm = 0;
     int64_t vx[kCompactRows], vy[kCompactRows];
+    unsigned long long m[kCompactRows];
+    uint32_t mine = 0;
 #pragma unroll
     for (int u = 0; u < kCompactRows; u++) {
       const int64_t i = base + u * 256 + threadIdx.x;  // coalesced; the order of the pairs does not matter
@@ -55,53 +57,45 @@ __global__ __launch_bounds__(256) void spearman_compact_kernel(ComomentColDesc d
       if (ok && yv) ok = (yv[(d.yoff + i) >> 3] >> ((d.yoff + i) & 7)) & 1;
       vx[u] = i < d.length ? x[i] : 0;
       vy[u] = i < d.length ? y[i] : 0;
-      okm |= (uint32_t)ok << u;
+      m[u] = __builtin_amdgcn_ballot_w64(ok);
+      mine += (uint32_t)__builtin_popcountll(m[u]);  // (the wave's count: the same in every lane)
     }
-    const uint32_t mine = __builtin_popcount(okm);
-    uint32_t incl = mine;
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const uint32_t up = __shfl_up(incl, dlt, 64);
-      if (lane >= (uint32_t)dlt) incl += up;
-    }
-    if (lane == 63) wave_cnt[wave] = incl;
+    if ((threadIdx.x & 63) == 0) wave_cnt[wave] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
       block_base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
     }
     __syncthreads();
-    uint64_t off = block_base + incl - mine;
+    uint64_t off = block_base;
     for (uint32_t w = 0; w < wave; w++) off += wave_cnt[w];
+    const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
     for (int u = 0; u < kCompactRows; u++) {
-      if (!((okm >> u) & 1)) continue;
-      kx[off] = sort_key(vx[u], d.x_is_float);
-      ky[off] = sort_key(vy[u], d.y_is_float);
-      off++;
+      if ((m[u] >> lane) & 1ull) {
+        const uint64_t at = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+        kx[at] = sort_key(vx[u], d.x_is_float);
+        ky[at] = sort_key(vy[u], d.y_is_float);
+      }
+      off += (uint32_t)__builtin_popcountll(m[u]);
     }
     __syncthreads();
   }
 }
 
-__global__ void iota_kernel(uint32_t *idx, uint64_t n) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    idx[i] = (uint32_t)i;
+// neither column has NULLs: every row is a pair, placed behind the pairs the state already holds (*count is bumped
+// by the launch that follows: nobody changes it while this one reads it)
+__global__ __launch_bounds__(256) void spearman_convert_kernel(ComomentColDesc d, uint64_t *kx, uint64_t *ky,
+                                                                const unsigned long long *count) {
+  const int64_t *x = (const int64_t *)d.x + d.xoff, *y = (const int64_t *)d.y + d.yoff;
+  const unsigned long long base = *count;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.length; i += (int64_t)gridDim.x * 256) {
+    kx[base + i] = sort_key(__builtin_nontemporal_load(x + i), d.x_is_float);
+    ky[base + i] = sort_key(__builtin_nontemporal_load(y + i), d.y_is_float);
+  }
 }
-
-// start position of each tie run (0 elsewhere); an inclusive max-scan turns it into "first position of my run"
-__global__ void run_heads_kernel(const uint64_t *sorted, uint64_t n, uint64_t *heads) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    heads[i] = (i > 0 && sorted[i] != sorted[i - 1]) ? i : 0;
-}
-
-// RANK(): 1 + first position of the tie run (+ `base`: the keys that sort before this rank's share when the ranking
-// is spread over several ranks), scattered back to the original row order
-__global__ void scatter_ranks_kernel(const uint64_t *run_start, const uint32_t *idx_sorted, uint64_t n, uint64_t base,
-                                     uint64_t *rank) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    rank[idx_sorted[i]] = base + run_start[i] + 1;
-}
+__global__ void spearman_bump_kernel(unsigned long long *count, unsigned long long by) { *count += by; }
 
 // ---- pieces of the cross-rank ranking (spearman_device.cpp, spearman_allreduce) ----
 // `count` regular samples of a sorted array
@@ -130,12 +124,6 @@ __global__ void unsort_kernel(const uint64_t *vals, const uint32_t *perm, uint64
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     out[perm[i]] = vals[i];
 }
-
-struct RankSums {
-  unsigned long long wrapped[5];   // UInt64 arithmetic of the reference: sums and products wrap modulo 2^64
-  unsigned long long exact_lo[5];  // the same sums without wrapping, 128 bits
-  unsigned long long exact_hi[5];
-};
 
 __global__ __launch_bounds__(256) void rank_sums_kernel(const uint64_t *rx, const uint64_t *ry, uint64_t n,
                                                          uint64_t plus, RankSums *partials) {
@@ -195,54 +183,15 @@ static int grid_of(uint64_t n) {
 
 void launch_spearman_compact(const ComomentColDesc &d, uint64_t *kx, uint64_t *ky, unsigned long long *count,
                              hipStream_t stream) {
+  if (!d.xv && !d.yv) {
+    hipLaunchKernelGGL(spearman_convert_kernel, dim3(grid_of((uint64_t)d.length)), dim3(256), 0, stream, d, kx, ky, count);
+    hipLaunchKernelGGL(spearman_bump_kernel, dim3(1), dim3(1), 0, stream, count, (unsigned long long)d.length);
+    return;
+  }
   hipLaunchKernelGGL(spearman_compact_kernel, dim3(grid_of((uint64_t)d.length)), dim3(256), 0, stream, d, kx, ky, count);
 }
 
 size_t spearman_rank_sums_bytes() { return sizeof(RankSums); }
-
-// ranks `keys` (n sort keys, clobbered) into `rank` (original order). scratch buffers: n entries each.
-// Returns the rocPRIM temp bytes needed when temp == nullptr.
-hipError_t spearman_rank(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
-                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream,
-                         uint64_t base) {
-  size_t sort_bytes = 0, scan_bytes = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u,
-                                           stream);
-  if (e != hipSuccess) return e;
-  e = rocprim::inclusive_scan(nullptr, scan_bytes, heads, heads, (size_t)n, rocprim::maximum<uint64_t>(), stream);
-  if (e != hipSuccess) return e;
-  const size_t need = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
-  if (temp == nullptr) {
-    *temp_bytes = need;
-    return hipSuccess;
-  }
-  hipLaunchKernelGGL(iota_kernel, dim3(grid_of(n)), dim3(256), 0, stream, idx, n);
-  size_t tb = *temp_bytes;
-  e = rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u, stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(run_heads_kernel, dim3(grid_of(n)), dim3(256), 0, stream, keys_sorted, n, heads);
-  tb = *temp_bytes;
-  e = rocprim::inclusive_scan(temp, tb, heads, heads, (size_t)n, rocprim::maximum<uint64_t>(), stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(scatter_ranks_kernel, dim3(grid_of(n)), dim3(256), 0, stream, heads, idx_sorted, n, base, rank);
-  return hipGetLastError();
-}
-
-// (keys, position) sorted by key: keys_sorted and the permutation idx_sorted.  temp == nullptr: returns the bytes.
-hipError_t spearman_sort_pairs(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
-                               void *temp, size_t *temp_bytes, hipStream_t stream) {
-  size_t sort_bytes = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u,
-                                           stream);
-  if (e != hipSuccess) return e;
-  if (temp == nullptr) {
-    *temp_bytes = sort_bytes;
-    return hipSuccess;
-  }
-  hipLaunchKernelGGL(iota_kernel, dim3(grid_of(n)), dim3(256), 0, stream, idx, n);
-  size_t tb = *temp_bytes;
-  return rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, idx, idx_sorted, (size_t)n, 0u, 64u, stream);
-}
 
 void launch_sample_sorted(const uint64_t *sorted, uint64_t n, uint32_t count, uint64_t *out, hipStream_t stream) {
   hipLaunchKernelGGL(sample_sorted_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, sorted, n, count, out);
@@ -260,41 +209,6 @@ int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, uint64_
   const int g = grid_of(n);
   hipLaunchKernelGGL(rank_sums_kernel, dim3(g), dim3(256), 0, stream, rx, ry, n, plus, (RankSums *)partials);
   return g;
-}
-
-// ---- one state, all pairs on this device: no rank ever has to find its way back to a row -------------------------
-// The five sums need the two ranks of a ROW side by side only in sum(rank_x * rank_y).  Sorting the pairs by x with y
-// as the payload gives every pair its rank_x in sorted order; sorting THOSE (y, rank_x) by y gives rank_y next to the
-// rank_x that travelled along: the sums are taken in y order.  Two sorts of (8 + 8)-byte pairs -- the scatter of
-// 1 G ranks back to their rows, twice, was 84 of the 228 ms of a 1 G-pair Spearman.
-hipError_t spearman_sort_kv64(uint64_t *keys, uint64_t *vals, uint64_t n, uint64_t *keys_sorted, uint64_t *vals_sorted,
-                              void *temp, size_t *temp_bytes, hipStream_t stream) {
-  size_t sort_bytes = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, vals_sorted, (size_t)n, 0u,
-                                           64u, stream);
-  if (e != hipSuccess) return e;
-  if (temp == nullptr) {
-    *temp_bytes = sort_bytes;
-    return hipSuccess;
-  }
-  size_t tb = *temp_bytes;
-  return rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, vals, vals_sorted, (size_t)n, 0u, 64u, stream);
-}
-
-// run_start[i] = first position of the tie run of sorted[i]  (RANK() - 1, in sorted order)
-hipError_t spearman_run_starts(const uint64_t *sorted, uint64_t n, uint64_t *run_start, void *temp, size_t *temp_bytes,
-                               hipStream_t stream) {
-  size_t scan_bytes = 0;
-  hipError_t e = rocprim::inclusive_scan(nullptr, scan_bytes, run_start, run_start, (size_t)n,
-                                         rocprim::maximum<uint64_t>(), stream);
-  if (e != hipSuccess) return e;
-  if (temp == nullptr) {
-    *temp_bytes = scan_bytes;
-    return hipSuccess;
-  }
-  hipLaunchKernelGGL(run_heads_kernel, dim3(grid_of(n)), dim3(256), 0, stream, sorted, n, run_start);
-  size_t tb = *temp_bytes;
-  return rocprim::inclusive_scan(temp, tb, run_start, run_start, (size_t)n, rocprim::maximum<uint64_t>(), stream);
 }
 
 }  // namespace tgx

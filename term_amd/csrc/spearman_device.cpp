@@ -1,6 +1,8 @@
 // spearman_device.cpp -- keeps the (x, y) pairs of every batch on the device and ranks them at finalize.
 #include "spearman_device.h"
 
+#include "kernels/sortrank.h"
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -12,21 +14,12 @@ namespace tgx {
 void launch_spearman_compact(const ComomentColDesc &d, uint64_t *kx, uint64_t *ky, unsigned long long *count,
                              hipStream_t stream);
 size_t spearman_rank_sums_bytes();
-hipError_t spearman_rank(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
-                         uint64_t *heads, uint64_t *rank, void *temp, size_t *temp_bytes, hipStream_t stream,
-                         uint64_t base);
-hipError_t spearman_sort_pairs(uint64_t *keys, uint64_t n, uint64_t *keys_sorted, uint32_t *idx, uint32_t *idx_sorted,
-                               void *temp, size_t *temp_bytes, hipStream_t stream);
 void launch_sample_sorted(const uint64_t *sorted, uint64_t n, uint32_t count, uint64_t *out, hipStream_t stream);
 void launch_lower_bounds(const uint64_t *sorted, uint64_t n, const uint64_t *splitters, uint32_t k, uint64_t *out,
                          hipStream_t stream);
 void launch_unsort(const uint64_t *vals, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t stream);
 int launch_rank_sums(const uint64_t *rx, const uint64_t *ry, uint64_t n, uint64_t plus, void *partials,
                      hipStream_t stream);
-hipError_t spearman_sort_kv64(uint64_t *keys, uint64_t *vals, uint64_t n, uint64_t *keys_sorted, uint64_t *vals_sorted,
-                              void *temp, size_t *temp_bytes, hipStream_t stream);
-hipError_t spearman_run_starts(const uint64_t *sorted, uint64_t n, uint64_t *run_start, void *temp, size_t *temp_bytes,
-                               hipStream_t stream);
 
 namespace {
 struct SpearmanPlan {
@@ -42,10 +35,10 @@ struct SpearmanTaskState {
 };
 struct SpearmanState {
   std::vector<SpearmanTaskState> tasks;
-  // work buffers of the ranking (sorted keys, permutation, run heads, ranks, sort scratch): 40 bytes per pair, shared by
-  // the tasks (they are ranked one after the other) and kept between calls -- allocating and freeing them inside
-  // every fill_result was 160 ms of a 188 ms step at 100 M rows (hipMalloc / hipFree of 4.4 GB)
-  DevBuf keys_sorted, idx, idx_sorted, heads, rx, ry, temp, partials;
+  // work buffers of the ranking (the two partition passes' ping-pong space, ranks, the sorter's tables): 28 bytes per
+  // pair, shared by the tasks (they are ranked one after the other) and kept between calls -- allocating and freeing
+  // them inside every fill_result was 160 ms of a 188 ms step at 100 M rows (hipMalloc / hipFree of 4.4 GB)
+  DevBuf keys_sorted, idx, idx_sorted, heads, rx, ry, temp, partials, rank32;
   // the cross-rank ranking: this rank's sorted keys and their permutation, the keys it owns, their ranks, the ranks
   // that came back, samples / splitters / boundaries
   DevBuf loc_sorted, loc_perm, recv, recv_ranks, back, small;
@@ -211,30 +204,46 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   if (m == 0) return TGX_OK;
   if (m > 0xFFFFFFF0ull) return sfail(err, TGX_UNSUPPORTED, "SPEARMAN over more than 2^32 rows is not supported");
   SpearmanState *ws = sstate(st);
-  // pairs sorted by x (y travels along) -> rank_x in that order -> (y, rank_x) sorted by y -> rank_y beside rank_x:
-  // no rank is ever scattered back to its row (kernels/spearman.hip).  32 bytes of work buffers per pair.
-  DevBuf &keys_sorted = ws->keys_sorted, &heads = ws->heads, &rx = ws->rx, &ry = ws->ry, &temp = ws->temp,
-         &partials = ws->partials;
-  SHIP(keys_sorted.reserve(m * 8));
-  SHIP(heads.reserve(m * 8));
-  SHIP(rx.reserve(m * 8));
-  SHIP(ry.reserve(m * 8));
-  size_t sort_bytes = 0, scan_bytes = 0;
-  SHIP(spearman_sort_kv64(ts.kx.as<uint64_t>(), ts.ky.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), ry.as<uint64_t>(),
-                          nullptr, &sort_bytes, st->stream));
-  SHIP(spearman_run_starts(keys_sorted.as<uint64_t>(), m, heads.as<uint64_t>(), nullptr, &scan_bytes, st->stream));
-  size_t temp_bytes = std::max(sort_bytes, scan_bytes);
-  SHIP(temp.reserve(temp_bytes + 256));
-  // by x: keys_sorted = x in order, ry = the y of those pairs, heads = RANK(x) - 1
-  SHIP(spearman_sort_kv64(ts.kx.as<uint64_t>(), ts.ky.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), ry.as<uint64_t>(),
-                          temp.p, &temp_bytes, st->stream));
-  SHIP(spearman_run_starts(keys_sorted.as<uint64_t>(), m, heads.as<uint64_t>(), temp.p, &temp_bytes, st->stream));
-  // by y: keys_sorted = y in order, rx = the RANK(x) - 1 of those pairs, heads = RANK(y) - 1
-  SHIP(spearman_sort_kv64(ry.as<uint64_t>(), heads.as<uint64_t>(), m, keys_sorted.as<uint64_t>(), rx.as<uint64_t>(), temp.p,
-                          &temp_bytes, st->stream));
-  SHIP(spearman_run_starts(keys_sorted.as<uint64_t>(), m, heads.as<uint64_t>(), temp.p, &temp_bytes, st->stream));
-  SHIP(partials.reserve(2048 * spearman_rank_sums_bytes()));
-  const int blocks = launch_rank_sums(rx.as<uint64_t>(), heads.as<uint64_t>(), m, 1, partials.p, st->stream);
+  // RANK(x) with y as the payload, then RANK(y) with RANK(x) as the payload, the five sums taken where the second
+  // ranking ends: no rank is ever scattered back to its row and nothing is laid out in order (kernels/sortrank.hip).
+  // The first ranking's second partition pass writes back into the state's own arrays: the pairs come back permuted,
+  // every x still beside its y.  28 bytes of work buffers per pair.
+  DevBuf &ka = ws->keys_sorted, &pa = ws->heads, &ra = ws->idx, &rb = ws->idx_sorted, &rank32 = ws->rank32,
+         &temp = ws->temp, &partials = ws->partials;
+  SHIP(ka.reserve(m * 8));
+  SHIP(pa.reserve(m * 8));
+  SHIP(ra.reserve(m * 4));
+  SHIP(rb.reserve(m * 4));
+  SHIP(rank32.reserve(m * 4));
+  const size_t temp_bytes = sr_workspace_bytes(m);
+  SHIP(temp.reserve(temp_bytes));
+  const int blocks = sr_partials_count();
+  SHIP(partials.reserve((size_t)blocks * spearman_rank_sums_bytes()));
+  SrJob jx;
+  jx.keys = ts.kx.as<uint64_t>();
+  jx.pay = ts.ky.p;
+  jx.n = m;
+  jx.pay_bytes = 8;
+  jx.k[0] = ka.as<uint64_t>();
+  jx.p[0] = pa.p;
+  jx.k[1] = ts.kx.as<uint64_t>();
+  jx.p[1] = ts.ky.p;
+  jx.sink = kSrRank32;
+  jx.rank32 = rank32.as<uint32_t>();
+  SrPlaced at;
+  SHIP(sr_run(jx, temp.p, temp_bytes, st->stream, &at));
+  SrJob jy;
+  jy.keys = (const uint64_t *)at.pay;  // the y keys, slot for slot beside rank32
+  jy.pay = rank32.p;
+  jy.n = m;
+  jy.pay_bytes = 4;
+  jy.k[0] = ka.as<uint64_t>();  // (free again: the first ranking is through)
+  jy.p[0] = ra.p;
+  jy.k[1] = pa.as<uint64_t>();  // (may be where the y keys lie now: they are read by the first pass only)
+  jy.p[1] = rb.p;
+  jy.sink = kSrSums;
+  jy.partials = (RankSums *)partials.p;
+  SHIP(sr_run(jy, temp.p, temp_bytes, st->stream, nullptr));
   std::vector<RankSumsHost> h(blocks);
   SHIP(hipMemcpyAsync(h.data(), partials.p, blocks * sizeof(RankSumsHost), hipMemcpyDeviceToHost, st->stream));
   SHIP(hipStreamSynchronize(st->stream));
@@ -276,16 +285,29 @@ tgx_status rank_across(tgx_state *st, SpearmanState *ws, const SpearmanExchange 
   const int32_t W = X.world, R = X.rank;
   hipStream_t s = st->device_ready ? st->stream : nullptr;
   size_t tb = 0;
-  // (a) this rank's keys in order, with the permutation that leads back to the rows
+  // (a) this rank's keys in order, with the permutation that leads back to the rows (the keys' positions travel as the
+  //     payload; the state's own arrays are only read: x and y must stay side by side)
   if (m) {
     SHIP(ws->loc_sorted.reserve(m * 8));
     SHIP(ws->loc_perm.reserve(m * 4));
+    SHIP(ws->keys_sorted.reserve(m * 8));
+    SHIP(ws->heads.reserve(m * 8));
     SHIP(ws->idx.reserve(m * 4));
-    SHIP(spearman_sort_pairs(keys, m, ws->loc_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(), ws->loc_perm.as<uint32_t>(),
-                             nullptr, &tb, s));
-    SHIP(ws->temp.reserve(tb + 256));
-    SHIP(spearman_sort_pairs(keys, m, ws->loc_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(), ws->loc_perm.as<uint32_t>(),
-                             ws->temp.p, &tb, s));
+    SHIP(ws->idx_sorted.reserve(m * 4));
+    tb = sr_workspace_bytes(m);
+    SHIP(ws->temp.reserve(tb));
+    SrJob j;
+    j.keys = keys;
+    j.n = m;
+    j.pay_bytes = 4;  // (no payload array: the index)
+    j.k[0] = ws->keys_sorted.as<uint64_t>();
+    j.p[0] = ws->idx.p;
+    j.k[1] = ws->heads.as<uint64_t>();
+    j.p[1] = ws->idx_sorted.p;
+    j.sink = kSrSorted;
+    j.out_keys = ws->loc_sorted.as<uint64_t>();
+    j.out_pay = ws->loc_perm.p;
+    SHIP(sr_run(j, ws->temp.p, tb, s, nullptr));
   }
   // (b) regular samples of every rank -> the same world-1 splitters everywhere
   std::vector<uint64_t> mine(1 + kSamplesPerRank, 0), all((size_t)W * (1 + kSamplesPerRank), 0);
@@ -349,17 +371,26 @@ tgx_status rank_across(tgx_state *st, SpearmanState *ws, const SpearmanExchange 
   STRY(X.alltoallv(ws->loc_sorted.p, sc.data(), ws->recv.p, rc.data(), 8));
   SHIP(ws->recv_ranks.reserve(std::max<uint64_t>(M, 1) * 8));
   if (M) {
+    // RANK() of a received key = the keys lower ranks own + its rank among the keys owned here, written to the slot
+    // the key arrived in
     SHIP(ws->keys_sorted.reserve(M * 8));
+    SHIP(ws->heads.reserve(M * 8));
     SHIP(ws->idx.reserve(M * 4));
     SHIP(ws->idx_sorted.reserve(M * 4));
-    SHIP(ws->heads.reserve(M * 8));
-    SHIP(spearman_rank(ws->recv.as<uint64_t>(), M, ws->keys_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(),
-                       ws->idx_sorted.as<uint32_t>(), ws->heads.as<uint64_t>(), ws->recv_ranks.as<uint64_t>(), nullptr, &tb,
-                       s, base));
-    SHIP(ws->temp.reserve(tb + 256));
-    SHIP(spearman_rank(ws->recv.as<uint64_t>(), M, ws->keys_sorted.as<uint64_t>(), ws->idx.as<uint32_t>(),
-                       ws->idx_sorted.as<uint32_t>(), ws->heads.as<uint64_t>(), ws->recv_ranks.as<uint64_t>(), ws->temp.p,
-                       &tb, s, base));
+    tb = sr_workspace_bytes(M);
+    SHIP(ws->temp.reserve(tb));
+    SrJob j;
+    j.keys = ws->recv.as<uint64_t>();
+    j.n = M;
+    j.pay_bytes = 4;
+    j.k[0] = ws->keys_sorted.as<uint64_t>();
+    j.p[0] = ws->idx.p;
+    j.k[1] = ws->heads.as<uint64_t>();
+    j.p[1] = ws->idx_sorted.p;
+    j.sink = kSrRankScatter;
+    j.rank_out = ws->recv_ranks.as<uint64_t>();
+    j.ext_base = base;
+    SHIP(sr_run(j, ws->temp.p, tb, s, nullptr));
   }
   SHIP(ws->back.reserve(std::max<uint64_t>(m, 1) * 8));
   STRY(X.alltoallv(ws->recv_ranks.p, rc.data(), ws->back.p, sc.data(), 8));

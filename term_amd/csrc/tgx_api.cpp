@@ -2058,6 +2058,15 @@ static tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_col
     //  dictionary and tuple sets are updated further down, behind the scan)
     bool all_early = true;
     for (size_t q = 0; q < plan->distinct.size(); q++) all_early &= distinct_done[q] || distinct_idle(q);
+    // ... and for the running MIN / MAX the facts round reads (allreduce.cpp tightens a bitmap's range with them) only
+    // when they, too, were produced before it: a key column whose aggregates come from the scan below -- a pass that is
+    // not partitioned, variance / pair / KLL / HLL lanes on the key column -- would have its ScanAcc read on the second
+    // stream while the scan is still writing it
+    for (size_t q = 0; q < plan->distinct.size(); q++) {
+      const DistinctTask &t = plan->distinct[q];
+      if (!distinct_done[q] || t.scan_slot < 0 || st->distinct[q].has_hint) continue;
+      all_early &= stats_by_partition[t.scan_slot] == (int)q;
+    }
     st->keys_ready_recorded = all_early && (st->passes == 0 || st->keys_ready_recorded);
     st->passes++;
     // (a state that takes part in exchanges leaves two workgroup slots per CU to the second stream's kernels: the

@@ -109,3 +109,116 @@ def test_state_reuse_across_sizes_and_pairs():
             assert (r.total, r.non_null) == (n, want.n)
             assert (r.sum_x, r.sum_y, r.sum_x2, r.sum_y2, r.sum_xy) == \
                 (want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy), n
+
+
+# ---- the ranking machinery itself (kernels/sortrank.hip): distributions x shapes of the partition -------------------
+def _sort_data(kind, n, rng):
+    if kind == "uniform":
+        return rng.random(n) * 1000.0
+    if kind == "normal":
+        return rng.standard_normal(n)
+    if kind == "sorted_ids":
+        return np.arange(n, dtype=np.int64) * 3 - 17
+    if kind == "reversed":
+        return np.arange(n, 0, -1, dtype=np.int64)
+    if kind == "two_values":
+        return rng.integers(0, 2, size=n, dtype=np.int64) * 1000 - 500
+    if kind == "five_values":
+        return rng.integers(0, 5, size=n, dtype=np.int64).astype(np.float64) * 0.25
+    if kind == "all_equal":
+        return np.full(n, 42.5)
+    if kind == "one_heavy":  # half the rows one value, the rest spread
+        v = rng.random(n)
+        v[rng.random(n) < 0.5] = 0.5
+        return v
+    if kind == "clusters":  # cluster centres with jitter far below the gaps: bins of the last pass collide
+        return rng.integers(0, 50, size=n).astype(np.float64) + rng.random(n) * 1e-9
+    if kind == "exponents":  # spread over the whole exponent range, both signs
+        return np.sign(rng.standard_normal(n)) * 10.0 ** rng.uniform(-300, 300, size=n)
+    if kind == "specials":
+        v = rng.standard_normal(n)
+        pick = rng.random(n)
+        v[pick < 0.05] = np.nan
+        v[(pick >= 0.05) & (pick < 0.10)] = np.inf
+        v[(pick >= 0.10) & (pick < 0.15)] = -np.inf
+        v[(pick >= 0.15) & (pick < 0.20)] = 0.0
+        v[(pick >= 0.20) & (pick < 0.25)] = -0.0
+        return v
+    if kind == "big_ints":  # beyond 2^53: CAST(.. AS DOUBLE) makes neighbours equal
+        return (2**62 + rng.integers(0, 4096, size=n, dtype=np.int64)).astype(np.int64)
+    if kind == "outlier":  # one far key stretches the first bucket's span
+        v = rng.random(n) * 1e-6
+        v[n // 2] = 1e300
+        return v
+    raise ValueError(kind)
+
+
+SORT_KINDS = ["uniform", "normal", "sorted_ids", "reversed", "two_values", "five_values", "all_equal", "one_heavy",
+              "clusters", "exponents", "specials", "big_ints", "outlier"]
+# knobs of kernels/sortrank.hip (sr_tuning): None = the shipped shape.  20 000 rows each.
+SORT_SHAPES = {
+    "shipped": None,
+    "three_passes": dict(TGX_SORT_TARGET="16", TGX_SORT_CAP="64", TGX_SORT_SPLIT="15"),
+    "two_passes": dict(TGX_SORT_TARGET="32", TGX_SORT_CAP="128", TGX_SORT_SPLIT="31", TGX_SORT_SAMPLE="8"),
+    "one_pass": dict(TGX_SORT_TARGET="512", TGX_SORT_CAP="1024"),
+    "chunked_last_pass": dict(TGX_SORT_TARGET="300", TGX_SORT_CAP="64", TGX_SORT_SLOWCAP="128", TGX_SORT_SPLIT="31",
+                              TGX_SORT_SAMPLE="2"),
+    "coarse": dict(TGX_SORT_TARGET="64", TGX_SORT_SPLIT="3", TGX_SORT_SAMPLE="1"),
+}
+
+
+def _check_spearman(x, y, xv=None, yv=None):
+    res, _, st = run_plan([spec(T.SPEARMAN, 0, column2=1)], [[numeric_column(x, xv, True), numeric_column(y, yv, True)]])
+    want = orc.spearman_state(x, y, xv, yv)
+    got = res[0]
+    assert got.non_null == want.n
+    assert (got.sum_x, got.sum_y, got.sum_x2, got.sum_y2, got.sum_xy) == \
+        (want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy)
+    again = st.finalize()[0]  # the pairs came back permuted, each x beside its y: the same answer again
+    assert (again.sum_x, again.sum_x2, again.sum_xy) == (want.sum_x, want.sum_x2, want.sum_xy)
+
+
+@pytest.mark.parametrize("shape", list(SORT_SHAPES))
+@pytest.mark.parametrize("kind", SORT_KINDS)
+def test_ranking_distributions_and_partition_shapes(kind, shape, monkeypatch):
+    env = SORT_SHAPES[shape]
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    n = 20_000 if env else 150_000
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("%s/%s" % (kind, shape)).encode()))
+    x = _sort_data(kind, n, rng)
+    other = SORT_KINDS[(SORT_KINDS.index(kind) + 5) % len(SORT_KINDS)]
+    y = _sort_data(other, n, rng)
+    xv = orc.pack_validity(rng.random(n) >= 0.07)
+    _check_spearman(x, y, xv, None)
+
+
+@pytest.mark.parametrize("n", [2047, 2048, 2049, 4097, 262_144, 262_145, 3_000_001])
+def test_ranking_sizes_around_the_pass_boundaries(n):
+    """2048 keys are ranked by one workgroup, up to 256 * 1024 take one partition pass, up to 65 536 * 1024 two"""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    y = np.round(x * 3 + rng.standard_normal(n), 2)  # ties
+    _check_spearman(x, y)
+
+
+def test_ranking_three_passes_at_size(monkeypatch):
+    """64 keys a bucket: 5 M rows are 78 K buckets, i.e. three passes of 43 ways"""
+    monkeypatch.setenv("TGX_SORT_TARGET", "64")
+    rng = np.random.default_rng(5)
+    n = 5_000_000
+    x = rng.standard_normal(n)
+    y = rng.integers(0, 1000, size=n).astype(np.float64)
+    _check_spearman(x, y)
+
+
+def test_ranking_oversized_bucket_default_shape(monkeypatch):
+    """one sample key per bucket: bucket sizes vary like an exponential distribution, many exceed the 2048 keys the
+    small kernel ranks and go to the large one, some exceed its 4096 and are ranked chunk against chunk"""
+    monkeypatch.setenv("TGX_SORT_SAMPLE", "1")
+    rng = np.random.default_rng(99)
+    n = 1_500_000
+    x = rng.standard_normal(n)
+    y = rng.random(n)
+    _check_spearman(x, y)
