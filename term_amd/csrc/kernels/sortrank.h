@@ -31,6 +31,7 @@ constexpr int kSrSlowPer = 8;
 constexpr int kSrSlowCap = kSrSlowThreads * kSrSlowPer;
 constexpr int kSrSlowBinBits = 12;
 constexpr uint32_t kSrEqPiece = 8192;  // an equality bucket is handed out in pieces of this many keys
+constexpr uint32_t kSrEqTiny = 32;     // ... unless it holds at most this many: then one thread walks it
 
 struct SrTileRef {  // one tile of a partition pass: keys [begin, min(begin + kSrTile, end of the part))
   uint32_t part, begin;
@@ -78,6 +79,7 @@ struct SrLevel {
   uint32_t *tile_count;  // [kSrXcds]
   uint32_t *tot;         // [nparts][nb]: keys per bucket
   uint32_t *cursor;      // [nparts][nb]: where the bucket's next run goes
+  uint32_t group;        // workgroups of an XCD that walk a stretch of its tile list side by side (0: all of them)
   uint32_t *bstart;      // pass 0: [nb + 1], later: [nparts * nb + 1]: where the buckets start (the next pass's parts)
 };
 
@@ -86,6 +88,8 @@ struct SrFinal {
   const void *pay;
   const SrItem *items;
   const uint32_t *n_items;
+  const SrItem *tiny;  // equality buckets of a few keys (every splitter is a key of the input: at least its own bucket
+  const uint32_t *n_tiny;  // holds one), a thread each
   uint64_t *out_keys;  // kSrSorted
   void *out_pay;
   uint32_t *rank32;    // kSrRank32

@@ -25,6 +25,7 @@
 // then y with RANK(x) as the payload, and sums -- no rank ever finds its way back to a row (spearman_device.cpp).
 #include "sortrank.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -95,14 +96,85 @@ __device__ __forceinline__ void sr_load_splitters(const SrLevel &L, const SrPart
   for (uint32_t k = threadIdx.x; k <= (uint32_t)kSrMaxSplit; k += blockDim.x)
     sp[k] = k < S ? L.fine[pi.first + (uint64_t)(k + 1) * L.stride - 1] : ~0ull;
 }
-// bucket of a key: 2 * (splitters below it) + (it equals the next one)
-__device__ __forceinline__ uint32_t sr_bucket(const uint64_t *sp, uint32_t S, uint32_t first_step, uint64_t key) {
+// lower bound by halving steps over the padded splitters (first_step: the largest power of two <= S)
+__device__ __forceinline__ uint32_t sr_lower_bound(const uint64_t *sp, uint32_t first_step, uint64_t key) {
   uint32_t pos = 0;
   for (uint32_t step = first_step; step; step >>= 1)
     if (sp[pos + step - 1] < key) pos += step;
-  return 2u * pos + ((pos < S && sp[pos] == key) ? 1u : 0u);
+  return pos;
 }
 __device__ __forceinline__ uint32_t sr_first_step(uint32_t S) { return S ? 1u << (31 - __builtin_clz(S)) : 0u; }
+
+// The search of a part: a table over the key range the splitters span, kSrLutCells cells of equal width, says between
+// which two splitter indices the lower bound of a cell's keys lies (splitters are quantiles: for most data a cell holds
+// one or none, and the 8 dependent LDS reads of a plain binary search -- the partition kernels were bound by their
+// instruction count, ~90 a key -- become one table read and a step or two).
+constexpr int kSrLutCells = 256;
+struct SrSearch {
+  uint64_t dom_lo, dom_hi;  // the table's key range: splitters `edge` and S - 1 - edge
+  uint32_t S, edge;
+  int shift;
+};
+// sp[] holds the part's splitters (a barrier has passed); builds lut[] and passes a barrier.  The table spans the
+// splitters without the outermost sixteenth on either side: quantiles of doubles are anything but evenly spread over
+// the KEY range where the values cross many exponents (uniform [0, 1): half of all splitters lie in the top 1 / 1022 of
+// it), between the 6th and the 94th percentile a few exponents remain; keys outside search the few splitters there.
+__device__ __forceinline__ SrSearch sr_build_search(const uint64_t *sp, uint32_t S, uint32_t *lut) {
+  SrSearch q;
+  q.S = S;
+  q.edge = 0;
+  q.dom_lo = q.dom_hi = 0;
+  q.shift = 0;
+  if (S) {
+    q.edge = S / 16;
+    q.dom_lo = sp[q.edge];
+    q.dom_hi = sp[S - 1 - q.edge];
+    const uint64_t width = q.dom_hi - q.dom_lo;
+    q.shift = width < (uint64_t)kSrLutCells ? 0 : (64 - (int)__builtin_clzll(width)) - 8;
+    const uint32_t fs = sr_first_step(S);
+    for (uint32_t c = threadIdx.x; c < (uint32_t)kSrLutCells; c += blockDim.x) {
+      const uint64_t start = q.dom_lo + ((uint64_t)c << q.shift);
+      const uint64_t next = start + (1ull << q.shift);
+      const bool wraps = next < start || start < q.dom_lo;
+      const uint32_t lb0 = start < q.dom_lo ? S : sr_lower_bound(sp, fs, start);
+      const uint32_t lb1 = wraps ? S : sr_lower_bound(sp, fs, next);
+      lut[c] = lb0 | (lb1 << 16);
+    }
+  }
+  __syncthreads();
+  return q;
+}
+// buckets of N keys at once (their LDS reads in flight together): 2 * (splitters below the key) + (it equals the next)
+template <int N>
+__device__ __forceinline__ void sr_buckets(const uint64_t *sp, const uint32_t *lut, const SrSearch &q,
+                                           const uint64_t (&key)[N], uint32_t (&b)[N]) {
+  uint32_t lo[N], hi[N];
+#pragma unroll
+  for (int u = 0; u < N; u++) {
+    const bool in = key[u] >= q.dom_lo && key[u] <= q.dom_hi;
+    const uint32_t e = lut[in ? (uint32_t)((key[u] - q.dom_lo) >> q.shift) : 0u];
+    // (below the table: at most `edge` splitters are smaller; above it: all but the last `edge` are)
+    lo[u] = in ? (e & 0xFFFFu) : (key[u] < q.dom_lo ? 0u : q.S - q.edge);
+    hi[u] = in ? (e >> 16) : (key[u] < q.dom_lo ? q.edge : q.S);
+  }
+  for (;;) {
+    bool open = false;
+#pragma unroll
+    for (int u = 0; u < N; u++) open = open || lo[u] < hi[u];
+    if (__builtin_amdgcn_ballot_w64(open) == 0) break;
+#pragma unroll
+    for (int u = 0; u < N; u++)
+      if (lo[u] < hi[u]) {
+        const uint32_t mid = (lo[u] + hi[u]) >> 1;
+        if (sp[mid] < key[u])
+          lo[u] = mid + 1;
+        else
+          hi[u] = mid;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < N; u++) b[u] = 2u * lo[u] + ((lo[u] < q.S && sp[lo[u]] == key[u]) ? 1u : 0u);
+}
 
 // exclusive scan of a[0 .. 8 * THREADS) in LDS (entries past n read as 0), `add` on top; a[n] = the total + add when
 // `sentinel`.  A barrier has passed since a[] was written; one passes before this returns.
@@ -144,10 +216,16 @@ __device__ __forceinline__ uint64_t sr_mix(uint64_t x) {
   x *= 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-__global__ void sr_sample_kernel(const uint64_t *keys, uint64_t n, uint64_t ns, uint64_t stride, uint64_t *out) {
+// one key from each of ns stretches that together cover ALL n positions (an input in order -- the second ranking of a
+// correlated pair reads its keys grouped by the first -- has its largest keys at the end: a sample that stops short of
+// it leaves them to one huge last bucket)
+__global__ void sr_sample_kernel(const uint64_t *keys, uint64_t n, uint64_t ns, uint64_t *out) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= ns) return;
-  uint64_t pos = k * stride + sr_mix(k + 0x9E3779B97F4A7C15ull) % stride;
+  // n = ns * q + r: the first r stretches hold q + 1 keys, the others q
+  const uint64_t q = n / ns, r = n - q * ns;  // (wave-uniform: scalar divisions)
+  const uint64_t b = k * q + (k < r ? k : r), len = q + (k < r ? 1 : 0);
+  uint64_t pos = b + (len > 1 ? sr_mix(k + 0x9E3779B97F4A7C15ull) % len : 0);
   if (pos >= n) pos = n - 1;
   out[k] = keys[pos];
 }
@@ -198,12 +276,19 @@ __global__ __launch_bounds__(256) void sr_tiles_kernel(SrLevel L) {
 // are requested before this tile's are searched
 __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
   __shared__ uint64_t sp[kSrMaxSplit + 1];
+  __shared__ uint32_t lut[kSrLutCells];
   __shared__ uint32_t hist[kSrMaxNb + 1];
   const uint32_t tid = threadIdx.x;
-  const uint32_t x = blockIdx.x & (kSrXcds - 1), j0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+  const uint32_t x = blockIdx.x & (kSrXcds - 1), W = gridDim.x >> 3;
   const uint32_t nt = L.tile_count[x];
+  // `group` workgroups walk a stretch of their XCD's list side by side
+  const uint32_t jstep = (L.group == 0 || L.group > W) ? W : L.group, groups = (W + jstep - 1) / jstep;
+  const uint32_t len = (nt + groups - 1) / groups, g0 = ((blockIdx.x >> 3) / jstep) * len;
+  const uint32_t j0 = g0 + (blockIdx.x >> 3) % jstep, j1 = g0 + len < nt ? g0 + len : nt;
   const SrTileRef *tiles = L.tiles + (size_t)x * L.tile_cap;
-  uint32_t cur = ~0u, S = 0, fs = 0;
+  uint32_t cur = ~0u;
+  SrSearch q;
+  q.S = 0;
   // (a tile never crosses its part's end: begin + kSrTile is clipped by the start of the part behind)
   auto tile_end = [&](const SrTileRef &r) {
     const uint32_t pe = L.part_start[r.part + 1];
@@ -216,51 +301,49 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
       k[u] = i < end ? __builtin_nontemporal_load(L.keys_in + i) : 0ull;
     }
   };
-  SrTileRef ref = j0 < nt ? tiles[j0] : SrTileRef{0, 0};
-  uint32_t end = j0 < nt ? tile_end(ref) : 0;
+  auto flush = [&]() {
+    __syncthreads();
+    if (q.S) {
+      for (uint32_t v = tid; v < 2 * q.S + 1; v += kSrPartThreads) {
+        const uint32_t h = hist[v];
+        if (h) atomicAdd(&L.tot[(size_t)cur * L.nb + v], h);
+      }
+      __syncthreads();
+    }
+  };
+  SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0};
+  uint32_t end = j0 < j1 ? tile_end(ref) : 0;
   uint64_t key[kSrPartPer];
-  if (j0 < nt) fetch(ref, end, key);
-  for (uint32_t j = j0; j < nt; j += W) {
-    const bool more = j + W < nt;
-    const SrTileRef nref = more ? tiles[j + W] : SrTileRef{0, 0};
+  if (j0 < j1) fetch(ref, end, key);
+  for (uint32_t j = j0; j < j1; j += jstep) {
+    const bool more = j + jstep < j1;
+    const SrTileRef nref = more ? tiles[j + jstep] : SrTileRef{0, 0};
     const uint32_t nend = more ? tile_end(nref) : 0;
     uint64_t nkey[kSrPartPer];
     if (more) fetch(nref, nend, nkey);
     if (ref.part != cur) {
-      __syncthreads();
-      if (S) {
-        for (uint32_t v = tid; v < 2 * S + 1; v += kSrPartThreads) {
-          const uint32_t h = hist[v];
-          if (h) atomicAdd(&L.tot[(size_t)cur * L.nb + v], h);
-        }
-        __syncthreads();
-      }
+      flush();
       cur = ref.part;
       const SrPartInfo pi = sr_part_info(L, cur);
-      S = pi.eq ? 0u : L.split_count;
-      fs = sr_first_step(S);
+      const uint32_t S = pi.eq ? 0u : L.split_count;
       sr_load_splitters(L, pi, S, sp);
       for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb; v += kSrPartThreads) hist[v] = 0;
       __syncthreads();
+      q = sr_build_search(sp, S, lut);
     }
-    if (S) {  // (an equality part is one bucket: the offsets kernel knows its size)
+    if (q.S) {  // (an equality part is one bucket: the offsets kernel knows its size)
+      uint32_t bk[kSrPartPer];
+      sr_buckets<kSrPartPer>(sp, lut, q, key, bk);
 #pragma unroll
-      for (int u = 0; u < kSrPartPer; u++) {
-        const bool ok = (uint64_t)ref.begin + u * kSrPartThreads + tid < end;
-        (void)sr_claim(hist, ok ? sr_bucket(sp, S, fs, key[u]) : 0u, ok);
-      }
+      for (int u = 0; u < kSrPartPer; u++)
+        (void)sr_claim(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end);
     }
     ref = nref;
     end = nend;
 #pragma unroll
     for (int u = 0; u < kSrPartPer; u++) key[u] = nkey[u];
   }
-  __syncthreads();
-  if (S)
-    for (uint32_t v = tid; v < 2 * S + 1; v += kSrPartThreads) {
-      const uint32_t h = hist[v];
-      if (h) atomicAdd(&L.tot[(size_t)cur * L.nb + v], h);
-    }
+  flush();
 }
 
 // pass 0: bucket v starts at (keys of lower buckets); inside it the stretches follow one another
@@ -332,18 +415,26 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
   __shared__ uint64_t stage_p8[PB == 8 ? kSrTile : 1];
   __shared__ uint32_t stage_p4[PB == 4 ? kSrTile : 1];
   __shared__ uint16_t ids[kSrTile];
+  __shared__ uint32_t lut[kSrLutCells];
   __shared__ uint32_t hist[kSrMaxNb + 1];
   __shared__ uint32_t delta[kSrMaxNb + 1];
   __shared__ uint32_t wsum[kSrPartThreads / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t x = blockIdx.x & (kSrXcds - 1), j0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+  const uint32_t x = blockIdx.x & (kSrXcds - 1), W = gridDim.x >> 3;
   const uint32_t nt = L.tile_count[x];
+  // `group` workgroups walk a stretch of their XCD's list side by side: the runs that complete a bucket's lines follow
+  // one another closely, and few buckets are open per L2 at a time
+  const uint32_t jstep = (L.group == 0 || L.group > W) ? W : L.group, groups = (W + jstep - 1) / jstep;
+  const uint32_t len = (nt + groups - 1) / groups, g0 = ((blockIdx.x >> 3) / jstep) * len;
+  const uint32_t j0 = g0 + (blockIdx.x >> 3) % jstep, j1 = g0 + len < nt ? g0 + len : nt;
   const SrTileRef *tiles = L.tiles + (size_t)x * L.tile_cap;
   const uint64_t *pin8 = (const uint64_t *)L.pay_in;
   const uint32_t *pin4 = (const uint32_t *)L.pay_in;
   uint64_t *pout8 = (uint64_t *)L.pay_out;
   uint32_t *pout4 = (uint32_t *)L.pay_out;
-  uint32_t cur = ~0u, S = 0, fs = 0;
+  uint32_t cur = ~0u, S = 0;
+  SrSearch q;
+  q.S = 0;
   auto tile_end = [&](const SrTileRef &r) {
     const uint32_t pe = L.part_start[r.part + 1];
     return pe - r.begin > (uint32_t)kSrTile ? r.begin + (uint32_t)kSrTile : pe;
@@ -359,15 +450,15 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       if (PB == 4) q4[u] = (ok && pin4) ? __builtin_nontemporal_load(pin4 + i) : (uint32_t)i;
     }
   };
-  SrTileRef ref = j0 < nt ? tiles[j0] : SrTileRef{0, 0};
-  uint32_t end = j0 < nt ? tile_end(ref) : 0;
+  SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0};
+  uint32_t end = j0 < j1 ? tile_end(ref) : 0;
   uint64_t key[kSrPartPer];
   uint64_t p8[PB == 8 ? kSrPartPer : 1];
   uint32_t p4[PB == 4 ? kSrPartPer : 1];
-  if (j0 < nt) fetch(ref, end, key, p8, p4);
-  for (uint32_t j = j0; j < nt; j += W) {
-    const bool more = j + W < nt;
-    const SrTileRef nref = more ? tiles[j + W] : SrTileRef{0, 0};
+  if (j0 < j1) fetch(ref, end, key, p8, p4);
+  for (uint32_t j = j0; j < j1; j += jstep) {
+    const bool more = j + jstep < j1;
+    const SrTileRef nref = more ? tiles[j + jstep] : SrTileRef{0, 0};
     const uint32_t nend = more ? tile_end(nref) : 0;
     uint64_t nkey[kSrPartPer];
     uint64_t np8[PB == 8 ? kSrPartPer : 1];
@@ -378,10 +469,10 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       cur = ref.part;
       const SrPartInfo pi = sr_part_info(L, cur);
       S = pi.eq ? 0u : L.split_count;
-      fs = sr_first_step(S);
       sr_load_splitters(L, pi, S, sp);
       for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb; v += kSrPartThreads) hist[v] = 0;
       __syncthreads();
+      q = sr_build_search(sp, S, lut);
     }
     if (S == 0) {  // one bucket that starts where the part starts: the keys keep their places
 #pragma unroll
@@ -395,12 +486,10 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       }
     } else {
       uint32_t bk[kSrPartPer], rk[kSrPartPer];
+      sr_buckets<kSrPartPer>(sp, lut, q, key, bk);
 #pragma unroll
-      for (int u = 0; u < kSrPartPer; u++) {
-        const bool ok = (uint64_t)ref.begin + u * kSrPartThreads + tid < end;
-        bk[u] = ok ? sr_bucket(sp, S, fs, key[u]) : 0u;
-        rk[u] = sr_claim(hist, bk[u], ok);  // (the key's place inside its run)
-      }
+      for (int u = 0; u < kSrPartPer; u++)  // (the key's place inside its run)
+        rk[u] = sr_claim(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end);
       __syncthreads();
       // one reservation per run -- its round trip runs under the scan and the regrouping: only the stores need it
       const uint32_t h = tid < 2 * S + 1 ? hist[tid] : 0u;
@@ -453,7 +542,10 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
 // ---- the last pass's work lists ------------------------------------------------------------------------------------
 // `small`: buckets the 256-thread kernel ranks (and the pieces of equality buckets), `large`: the others
 __global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buckets, uint32_t small_cap, SrItem *small,
-                                                        uint32_t *n_small, SrItem *large, uint32_t *n_large) {
+                                                        uint32_t *n_small, SrItem *large, uint32_t *n_large, SrItem *tiny,
+                                                        uint32_t *n_tiny) {
+  __shared__ uint32_t wsum_t[4];
+  __shared__ uint32_t block_base_t;
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t block_base;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -482,23 +574,36 @@ __global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buc
     }
   }
   const bool big = (cnt > small_cap || edge) && !eq;
-  const uint32_t ni = (cnt == 0 || big) ? 0u : (eq ? (cnt + kSrEqPiece - 1) / kSrEqPiece : 1u);
-  uint32_t incl = ni;
+  const bool is_tiny = eq && cnt > 0 && cnt <= kSrEqTiny;
+  const uint32_t ni = (cnt == 0 || big || is_tiny) ? 0u : (eq ? (cnt + kSrEqPiece - 1) / kSrEqPiece : 1u);
+  uint32_t incl = ni, incl_t = is_tiny ? 1u : 0u;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(incl, d, 64);
-    if (lane >= (uint32_t)d) incl += up;
+    const uint32_t up = __shfl_up(incl, d, 64), up_t = __shfl_up(incl_t, d, 64);
+    if (lane >= (uint32_t)d) {
+      incl += up;
+      incl_t += up_t;
+    }
   }
-  if (lane == 63) wsum[wave] = incl;
+  if (lane == 63) {
+    wsum[wave] = incl;
+    wsum_t[wave] = incl_t;
+  }
   __syncthreads();
-  uint32_t off = incl - ni;
-  for (uint32_t w = 0; w < wave; w++) off += wsum[w];
+  uint32_t off = incl - ni, off_t = incl_t - (is_tiny ? 1u : 0u);
+  for (uint32_t w = 0; w < wave; w++) {
+    off += wsum[w];
+    off_t += wsum_t[w];
+  }
   if (tid == 0) {
     const uint32_t all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     block_base = all ? atomicAdd(n_small, all) : 0u;
+    const uint32_t all_t = wsum_t[0] + wsum_t[1] + wsum_t[2] + wsum_t[3];
+    block_base_t = all_t ? atomicAdd(n_tiny, all_t) : 0u;
   }
   __syncthreads();
   if (big) large[atomicAdd(n_large, 1u)] = SrItem{st, cnt, st, 0u, 0ull, 0ull};
+  if (is_tiny) tiny[block_base_t + off_t] = SrItem{st, cnt, st, 1u, 0ull, 0ull};
   if (ni == 0) return;
   SrItem *out = small + block_base + off;
   if (!eq) {
@@ -511,10 +616,11 @@ __global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buc
   }
 }
 // (a job of one bucket: no splitters, hence no key range: the large kernel's)
-__global__ void sr_one_item_kernel(SrItem *large, uint32_t *n_small, uint32_t *n_large, uint32_t n) {
+__global__ void sr_one_item_kernel(SrItem *large, uint32_t *counters, uint32_t n) {
   large[0] = SrItem{0u, n, 0u, 0u, 0ull, 0ull};
-  *n_small = 0;
-  *n_large = 1;
+  counters[0] = 0;
+  counters[1] = 1;
+  counters[2] = 0;
 }
 
 // ---- the last pass -------------------------------------------------------------------------------------------------
@@ -630,6 +736,17 @@ __global__ __launch_bounds__(kSrFastThreads) void sr_rank_small_kernel(SrFinal F
   for (uint32_t v = tid; v < 2u * (kBins + 8); v += kSrFastThreads) (&bins2[0][0])[v] = 0;
   __syncthreads();
 
+  {  // equality buckets of a few keys: RANK() is the bucket's first position for all of them; a thread per bucket
+    const uint32_t n_tiny = *F.n_tiny;
+    for (uint32_t i = blockIdx.x * kSrFastThreads + tid; i < n_tiny; i += G * kSrFastThreads) {
+      const SrItem t = F.tiny[i];
+      for (uint32_t e = 0; e < t.count; e++) {
+        const uint64_t g = (uint64_t)t.start + e;
+        sr_emit<PB, SINK>(F, t, g, SINK == kSrSorted ? F.keys[g] : 0ull, sr_pay4<PB, SINK>(F, g), sr_pay8<PB, SINK>(F, g),
+                          0u, 0u, acc);
+      }
+    }
+  }
   uint32_t w = blockIdx.x, par = 0;
   const SrItem none = SrItem{0, 0, 0, 1, 0, 0};
   SrItem it = w < n_items ? F.items[w] : none;
@@ -941,12 +1058,13 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
   if (depth > 40) return hipErrorUnknown;
   const SrShape sh = sr_shape(n, tune);
   SrItem *small = ws.take<SrItem>(sh.max_small), *large = ws.take<SrItem>(sh.max_large);
-  uint32_t *counters = ws.take<uint32_t>(8);  // [0] small items, [1] large items
+  SrItem *tiny = ws.take<SrItem>(sh.max_small);
+  uint32_t *counters = ws.take<uint32_t>(8);  // [0] small items, [1] large items, [2] tiny items
   const uint64_t *keys = job.keys;
   const void *pay = job.pay;
   if (sh.levels == 0) {
     if (!dry)
-      hipLaunchKernelGGL(sr_one_item_kernel, dim3(1), dim3(1), 0, stream, large, counters, counters + 1, (uint32_t)n);
+      hipLaunchKernelGGL(sr_one_item_kernel, dim3(1), dim3(1), 0, stream, large, counters, (uint32_t)n);
   } else {
     // ---- splitters: a sorted sample
     uint64_t *samp = ws.take<uint64_t>(sh.ns), *sorted = ws.take<uint64_t>(sh.ns);
@@ -961,14 +1079,16 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
     sj.out_keys = sorted;
     if (!dry)
       hipLaunchKernelGGL(sr_sample_kernel, dim3((unsigned)((sh.ns + 255) / 256)), dim3(256), 0, stream, job.keys, n, sh.ns,
-                         sh.sample_stride, samp);
+                         samp);
     hipError_t e = sr_run_impl(sj, ws, stream, tune, dry, nullptr, depth + 1);
     if (e != hipSuccess) return e;
     if (!dry)
       hipLaunchKernelGGL(sr_pick_kernel, dim3((unsigned)((sh.buckets - 1 + 255) / 256)), dim3(256), 0, stream, sorted,
                          sh.buckets - 1, sh.every, fine);
     // ---- the partition passes
-    const int grid = kSrXcds * std::max<int>(1, (std::max(1, tgx_num_cus()) / kSrXcds) * (int)tune.wg_per_cu);
+    const int per_xcd = std::max(1, tgx_num_cus() / kSrXcds);
+    const int grid = kSrXcds * per_xcd * (int)tune.wg_per_cu;
+    const int count_grid = kSrXcds * per_xcd * 4;  // (little LDS, few registers: four 512-thread workgroups fill a CU)
     uint32_t *next_parts = nullptr;
     SrLevel L;
     for (int lv = 0; lv < sh.levels; lv++) {
@@ -989,6 +1109,14 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
       L.nb = sh.nb[lv];
       L.nparts = sh.nparts[lv];
       L.tile_cap = sh.tile_cap[lv];
+      // long parts (the first passes): all workgroups of an XCD walk a part side by side -- one part's buckets open per
+      // L2 (a workgroup on a part of its own: 96 x 199 x 2 open lines per L2, and the last pass of three took 10.3
+      // instead of 6.1 ms); short parts (that pass: ~50 tiles each): eight together, or every tile would bring its own
+      // splitters and table
+      {
+        const uint64_t tiles_per_part = (n / kSrTile) / std::max<uint64_t>(1, L.nparts / 2 + 1);
+        L.group = tiles_per_part < 4ull * (uint64_t)(grid / kSrXcds) ? 8u : 0u;
+      }
       L.tiles = ws.take<SrTileRef>((size_t)kSrXcds * L.tile_cap);
       L.tile_count = ws.take<uint32_t>(kSrXcds);
       const size_t table = (size_t)L.nparts * L.nb;
@@ -1008,7 +1136,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
         if (e2 == hipSuccess) e2 = hipMemsetAsync(L.tile_count, 0, kSrXcds * sizeof(uint32_t), stream);
         if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(sr_tiles_kernel, dim3((L.nparts + 3) / 4), dim3(256), 0, stream, L);
-        hipLaunchKernelGGL(sr_count_kernel, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        hipLaunchKernelGGL(sr_count_kernel, dim3(count_grid), dim3(kSrPartThreads), 0, stream, L);
         if (lv == 0)
           hipLaunchKernelGGL(sr_offsets_first_kernel, dim3(1), dim3(512), 0, stream, L);
         else
@@ -1029,7 +1157,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
       if (e2 != hipSuccess) return e2;
       const uint64_t entries = (uint64_t)(L.level == 0 ? 1 : L.nparts) * L.nb;
       hipLaunchKernelGGL(sr_items_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, stream, L, sh.buckets,
-                         tune.cap, small, counters, large, counters + 1);
+                         tune.cap, small, counters, large, counters + 1, tiny, counters + 2);
     }
   }
   if (placed) *placed = SrPlaced{keys, pay};
@@ -1039,6 +1167,8 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
   F.pay = pay;
   F.items = small;
   F.n_items = counters;
+  F.tiny = tiny;
+  F.n_tiny = counters + 2;
   F.out_keys = job.out_keys;
   F.out_pay = job.out_pay;
   F.rank32 = job.rank32;
@@ -1068,6 +1198,14 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
     default:
       launch_rank<4, kSrRankScatter>(F, FL, stream);
       break;
+  }
+  if (depth == 0 && getenv("TGX_SORT_DEBUG")) {  // (diagnostics: waits for the job)
+    uint32_t c[3] = {0, 0, 0};
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost);
+    fprintf(stderr, "tgx sort: n %llu, %d passes of %u x %u x %u ways, %llu splitters from %llu sample keys, %u small + %u "
+                    "large + %u tiny items\n", (unsigned long long)n, sh.levels, sh.f[0], sh.f[1], sh.f[2],
+            (unsigned long long)sh.buckets - 1, (unsigned long long)sh.ns, c[0], c[1], c[2]);
   }
   return hipGetLastError();
 }
