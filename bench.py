@@ -144,15 +144,38 @@ def free_port():
         return s.getsockname()[1]
 
 
+def count_gpus(base="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs of this machine WITHOUT touching any of them: the KFD topology (nodes with SIMDs are GPUs; the CPUs' nodes
+    have none), narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when they list devices; torch's own count only
+    where /sys has no topology (it does not initialise a device on this image either)"""
+    have = None
+    try:
+        have = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                have += 1
+    except (OSError, ValueError):
+        have = None
+    if have is None:
+        import torch
+
+        return torch.cuda.device_count()
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(args, script_args):
     """`python bench.py --gpus N` without a launcher around it: N fresh worker processes, one per GPU, started as
     CHILDREN (never an exec: this process stays the parent and only relays) before anything here has touched the GPU.
     Rank 0's JSON line is passed on as this process's own single line; any worker failing fails the run."""
     import subprocess
 
-    import torch  # importing torch and counting devices initialises no GPU on this image
-
-    have = torch.cuda.device_count()
+    have = count_gpus()
     if have < args.gpus:
         print("bench.py: --gpus %d but this machine exposes %d GPU(s): refusing to run fewer ranks than asked for "
               "(a 1-GPU number must never be recorded as an %d-GPU one)" % (args.gpus, have, args.gpus),
@@ -199,6 +222,11 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    # Every rank, however it was launched (by launch_ranks below or by `python -m torch.distributed.run ... bench.py`),
+    # before its first GPU call: the host driver of this pool only supports dmabuf IPC, and with the legacy mode RCCL /
+    # device-memory sharing across processes fails with `hipIpcGetMemHandle: invalid argument` (stated by the pool's
+    # environment notes; the value in force is reported in the result line's config)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             # invoked bare with --gpus N: start the N ranks ourselves (before anything here touches the GPU)
@@ -271,9 +299,12 @@ def main():
     st.profile_enable(True)
     st.profile_reset()
     fence()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        t1 = time.perf_counter()
+        res = step()  # (returns the step's results: the device is through with it)
+        step_ms.append((time.perf_counter() - t1) * 1e3)
     fence()
     dt = time.perf_counter() - t0
     if distributed:
@@ -317,7 +348,7 @@ def main():
         # latest round's: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied;
         # `traffic_source` says so
         traffic, traffic_source = None, None
-        for name in ("r03_pmc_1Brows_16cols.json", "r02_pmc_1Brows_16cols.json"):
+        for name in ("r04_pmc_1Brows_16cols.json", "r03_pmc_1Brows_16cols.json", "r02_pmc_1Brows_16cols.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -331,12 +362,14 @@ def main():
         out = {
             "metric": "validated rows/sec, 16-col null+range+unique suite",
             "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_median": sorted(step_ms)[len(step_ms) // 2],
+            "ms_min": min(step_ms), "ms_mean": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": "16-col (8 int64 + 8 float64, 12 nullable) null+range+unique suite: "
                                    "completeness x16, min/max/mean x16, uniqueness x2",
                        "rows_total": n_total, "rows_per_gpu": n_local, "cols": len(layout),
                        "parallelism": "row-range shards x%d" % world,
+                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "suite_algorithmic_bytes": alg_suite,
                        "suite_hbm_gbs": alg_suite / (dt / args.steps) / 1e9,
                        "suite_frac_of_8TBs": alg_suite / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world,  # per GPU

@@ -15,7 +15,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -105,6 +107,12 @@ struct tgx_comm {
   // the blob capacity the ranks agreed on for a plan (one collective per step once it has settled)
   const tgx_plan *blob_plan = nullptr;
   size_t blob_cap = 0;
+  // every host wait behind a collective has a deadline (TGX_COLLECTIVE_TIMEOUT_MS, default two minutes): a peer that
+  // died or left the step must surface as an error on the ranks that are still there, not as a process that hangs
+  hipEvent_t wait_event = nullptr;
+  ~tgx_comm() {
+    if (wait_event) (void)hipEventDestroy(wait_event);
+  }
 };
 
 namespace {
@@ -146,6 +154,34 @@ tgx_status comm_fail(tgx_comm *c, tgx_error *err, const char *what) {
   if (c->api && c->nccl && c->last_nccl_error)
     return fail(err, TGX_DEVICE_ERROR, "%s failed: %s", what, c->api->GetErrorString((ncclResult_t)c->last_nccl_error));
   return fail(err, TGX_DEVICE_ERROR, "%s failed in the transport", what);
+}
+
+int64_t collective_timeout_ms() {
+  const char *e = getenv("TGX_COLLECTIVE_TIMEOUT_MS");
+  const long long v = e && *e ? atoll(e) : 120000;
+  return v > 0 ? v : 120000;
+}
+
+// waits until everything queued on `s` so far is through -- at most the collective deadline
+tgx_status deadline_sync(tgx_comm *c, hipStream_t s, const char *what, tgx_error *err) {
+  if (!c->wait_event) HIP_TRY(hipEventCreateWithFlags(&c->wait_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->wait_event, s));
+  const auto t0 = std::chrono::steady_clock::now();
+  const int64_t limit = collective_timeout_ms();
+  for (uint64_t spins = 0;; spins++) {
+    const hipError_t q = hipEventQuery(c->wait_event);
+    if (q == hipSuccess) return TGX_OK;
+    if (q != hipErrorNotReady)
+      return fail(err, TGX_DEVICE_ERROR, "tgx_allreduce: waiting for %s failed: %s", what, hipGetErrorString(q));
+    if (spins < 4096) continue;  // (the usual wait is tens of microseconds: poll; then back off)
+    const int64_t ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > limit)
+      return fail(err, TGX_DEVICE_ERROR,
+                  "tgx_allreduce: %s did not complete within %lld ms on rank %d of %d (a peer has failed or left the "
+                  "step, or the transport is stuck); the state and the communicator are unusable",
+                  what, (long long)limit, c->ops.rank, c->ops.world);
+    std::this_thread::sleep_for(std::chrono::microseconds(ms < 2 ? 20 : 200));
+  }
 }
 
 tgx_status pinned_reserve(void **p, size_t *cap, size_t bytes, tgx_error *err) {
@@ -216,7 +252,7 @@ tgx_status do_allgather_host(tgx_comm *c, hipStream_t s, const void *h_send, voi
   if (c->ops.allgather(c->ops.ctx, c->d_small_send.p, c->d_small_recv.p, bytes, s) != 0)
     return comm_fail(c, err, "all-gather");
   HIP_TRY(hipMemcpyAsync(c->h_b, c->d_small_recv.p, total, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  TGX_TRY(deadline_sync(c, s, "an all-gather", err));
   memcpy(h_recv, c->h_b, total);
   return TGX_OK;
 }
@@ -321,6 +357,7 @@ struct TaskFacts {
   int64_t kind;     // kKind*
   int64_t wide;     // 128-bit fingerprint set (Utf8 / tuple keys)
   int64_t rows;     // rows it has seen
+  uint64_t spare_cap;  // bytes its spare bitmaps can take without an allocation (min of the two for a multiplicity set)
 };
 
 struct Header {
@@ -332,6 +369,10 @@ struct Header {
   // collective for ever -- so it keeps taking part (with empty contributions) until the next header carries the
   // failure to everybody, and ALL ranks return an error from the same point
   uint64_t status;
+  // bytes the rank's exchange buffers hold already: if every rank's buffers (and spare bitmaps, TaskFacts) are large
+  // enough for what the facts call for, nobody can fail between here and the blob round's header and the step needs
+  // no further status round; otherwise all ranks allocate, tell each other how that went, and only then exchange
+  uint64_t xchg_cap;
 };
 constexpr uint64_t kFactsMagic = 0x5447584641435453ull;  // "TGXFACTS"
 
@@ -408,10 +449,33 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   } reducing_guard{st, has_spearman};
 
   // ---- 1. facts --------------------------------------------------------------------------------------------
-  std::vector<ScanAcc> scan(plan->scan.size());
+  // A rank that fails ON ITS OWN between two collectives must not return: its peers would wait in the next one for
+  // ever.  It notes the failure in `local`, keeps taking part with what it has, and the next status word the ranks
+  // exchange anyway (facts header, the "ready" rounds below, the blob header) makes ALL ranks return an error from the
+  // same point.  TGX_FAULT_INJECT="rank:site" makes that rank fail at site 1..7 (tests/test_gpu_distributed_sim.py).
+  int fault_rank = -1, fault_site = 0;
+  if (const char *fi = getenv("TGX_FAULT_INJECT")) (void)sscanf(fi, "%d:%d", &fault_rank, &fault_site);
+  tgx_status local = TGX_OK;
   tgx_error local_err;
   memset(&local_err, 0, sizeof(local_err));
+  auto note = [&](tgx_status sdone, const tgx_error &e) {
+    if (local == TGX_OK && sdone != TGX_OK) {
+      local = sdone;
+      local_err = e;
+    }
+  };
+  auto injected = [&](int site, tgx_error *e) -> tgx_status {
+    if (fault_rank == R && fault_site == site) return fail(e, TGX_OUT_OF_MEMORY, "injected failure at site %d", site);
+    return TGX_OK;
+  };
+  std::vector<ScanAcc> scan(plan->scan.size());
   auto local_prep = [&](tgx_error *err) -> tgx_status {
+    TGX_TRY(injected(1, err));
+    // (the small staging buffers of the record exchange: allocated here, where a failure still travels in the facts)
+    if (st->device_ready || comm->ops.device_buffers) {
+      HIP_TRY(comm->d_small_send.reserve((size_t)W * 16 + 16));
+      HIP_TRY(comm->d_small_recv.reserve((size_t)W * 16 + 16));
+    }
     if (st->device_ready && !scan.empty()) {
       // (queued in front of the resolve's own read-back, into pinned memory: the two come back with one wait)
       TGX_TRY(pinned_reserve(&comm->h_a, &comm->h_a_cap, scan.size() * sizeof(ScanAcc), err));
@@ -424,7 +488,11 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     }
     return TGX_OK;
   };
-  tgx_status local = local_prep(&local_err);
+  {
+    tgx_error e;
+    memset(&e, 0, sizeof(e));
+    note(local_prep(&e), e);
+  }
   if (local != TGX_OK || !st->device_ready) {
     for (auto &a : scan) {
       memset(&a, 0, sizeof(a));
@@ -432,18 +500,28 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
       a.max_k = INT64_MIN;
     }
   }
-  // every rank learns of a peer's local failure from the header it was about to receive anyway
+  // every rank learns of a peer's local failure from a status word it was about to receive anyway
+  auto report = [&](int32_t r, uint64_t status, const char *where) -> tgx_status {
+    if (r == R && local != TGX_OK) {
+      if (err) *err = local_err;
+      return local;
+    }
+    return fail(err, (tgx_status)status, "tgx_allreduce: rank %d failed %s (%s); no rank went on", r, where,
+                tgx_status_name((int32_t)status));
+  };
   auto peers_ok = [&](const uint8_t *blocks, size_t stride, const char *where) -> tgx_status {
     for (int32_t r = 0; r < W; r++) {
       const Header *hr = (const Header *)(blocks + (size_t)r * stride);
-      if (hr->status == 0) continue;
-      if (r == R && local != TGX_OK) {
-        if (err) *err = local_err;
-        return local;
-      }
-      return fail(err, (tgx_status)hr->status, "tgx_allreduce: rank %d failed %s (%s); no rank went on", r, where,
-                  tgx_status_name((int32_t)hr->status));
+      if (hr->status != 0) return report(r, hr->status, where);
     }
+    return TGX_OK;
+  };
+  // one word per rank, all-gathered: "did what you just did on your own succeed?"
+  auto status_round = [&](const char *where) -> tgx_status {
+    std::vector<uint64_t> mine_w(1, (uint64_t)local), all_w((size_t)W, 0);
+    TGX_TRY(do_allgather_host(comm, s, mine_w.data(), all_w.data(), sizeof(uint64_t), err));
+    for (int32_t r = 0; r < W; r++)
+      if (all_w[r] != 0) return report(r, all_w[r], where);
     return TGX_OK;
   };
   const size_t facts_bytes = sizeof(Header) + nd * sizeof(TaskFacts);
@@ -452,6 +530,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   hd->magic = kFactsMagic ^ (uint64_t)nd;
   hd->blob_len = hd->blob_need = 0;
   hd->status = (uint64_t)local;
+  hd->xchg_cap = st->device_ready ? std::min(comm->d_send.cap, comm->d_recv.cap) : 0;  // (0: "I will have to allocate")
   TaskFacts *tf = (TaskFacts *)(mine.data() + sizeof(Header));
   for (size_t k = 0; k < nd; k++) {
     const DistinctTask &task = plan->distinct[k];
@@ -462,6 +541,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     f.kind = kKindNone;
     f.wide = (ds.wide || !task.tuple.empty()) ? 1 : 0;
     f.rows = ds.total_rows;
+    f.spare_cap = task.multiplicity ? std::min(ds.spare_seen.cap, ds.spare_twice.cap) : ds.spare_seen.cap;
     if (!ds.partitioned && st->device_ready) {
       if (ds.mode == DistinctMode::kBitmap) f.kind = kKindBitmap;
       if (ds.mode == DistinctMode::kHash) f.kind = kKindHash;
@@ -522,11 +602,6 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
       rows += (uint64_t)f.rows;
     }
     if (!any_set) continue;  // nobody holds keys on a device (already partitioned, host-only or empty states)
-    if (!st->device_ready) {
-      TGX_TRY(need_device(err));
-      TGX_TRY(state_init_device(st, err));
-      s = st->stream;
-    }
     // a pure function of agreed values, so every rank takes the same branch: range bitmaps everywhere, and a global
     // range that is still dense (at most 16 bits per row of the whole table, below 2^34 values)
     bool use_bitmap = all_bitmap && !wide && glo <= ghi;
@@ -548,10 +623,50 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
       by_records.push_back(k);
     }
   }
+  if ((!parts.empty() || !by_records.empty()) && !st->device_ready) {
+    // (a rank that saw no batch still owns a slice / a share of the keys: it needs its device state now; whether a
+    //  rank gets here is a function of the facts, and a failure travels in the next status word)
+    tgx_error e;
+    memset(&e, 0, sizeof(e));
+    tgx_status sd = need_device(&e);
+    if (sd == TGX_OK) sd = state_init_device(st, &e);
+    if (sd == TGX_OK) {
+      hipError_t he = comm->d_small_send.reserve((size_t)W * 16 + 16);
+      if (he == hipSuccess) he = comm->d_small_recv.reserve((size_t)W * 16 + 16);
+      if (he != hipSuccess) sd = fail(&e, TGX_OUT_OF_MEMORY, "exchange staging: %s", hipGetErrorString(he));
+    }
+    note(sd, e);
+    if (st->device_ready) s = st->stream;
+  }
   if (!parts.empty()) {
     const size_t total_bytes = (size_t)W * row_words * 4;
-    HIP_TRY(comm->d_send.reserve(total_bytes + 16));
-    HIP_TRY(comm->d_recv.reserve(total_bytes + 16));
+    // does ANY rank have to allocate for this exchange?  (a function of the facts: every rank answers alike)
+    bool any_alloc = false;
+    for (int32_t r = 0; r < W; r++) {
+      any_alloc |= ((const Header *)(all.data() + (size_t)r * facts_bytes))->xchg_cap < total_bytes + 16;
+      for (const BitmapPart &p : parts) any_alloc |= facts_of(r, p.task).spare_cap < p.slice_words * 4 + 16;
+    }
+    if (fault_site == 2 || fault_site == 3) any_alloc = true;  // (every rank reads the same environment)
+    auto alloc = [&](tgx_error *err) -> tgx_status {
+      TGX_TRY(injected(2, err));
+      HIP_TRY(comm->d_send.reserve(total_bytes + 16));
+      HIP_TRY(comm->d_recv.reserve(total_bytes + 16));
+      for (const BitmapPart &p : parts) {
+        DistinctState &ds = st->distinct[p.task];
+        TGX_TRY(injected(3, err));
+        HIP_TRY(ds.spare_seen.reserve(p.slice_words * 4 + 16));
+        if (p.mult) HIP_TRY(ds.spare_twice.reserve(p.slice_words * 4 + 16));
+      }
+      return TGX_OK;
+    };
+    if (local == TGX_OK) {
+      tgx_error e;
+      memset(&e, 0, sizeof(e));
+      note(alloc(&e), e);
+    }
+    if (any_alloc) TGX_TRY(status_round("while allocating the buffers of the key-set exchange"));
+    // (from here to the blob round nothing of this branch can fail on its own but a queueing call of the runtime: it is
+    //  noted and the blob header carries it)
     uint32_t *send = comm->d_send.as<uint32_t>();
     for (const BitmapPart &p : parts) {
       DistinctState &ds = st->distinct[p.task];
@@ -572,9 +687,13 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
       // the owned slice: OR of what every rank sent for it; the key counters are recounted from it, the row counters
       // stay (the old bitmap becomes the spare of the next round, so a state that is reset and refilled every step
       // neither frees nor allocates)
-      HIP_TRY(ds.spare_seen.reserve(p.slice_words * 4 + 16));
-      if (p.mult) HIP_TRY(ds.spare_twice.reserve(p.slice_words * 4 + 16));
-      HIP_TRY(hipMemsetAsync(ds.counters.as<unsigned long long>() + kCntDistinct, 0, 2 * sizeof(unsigned long long), s));
+      const hipError_t me = hipMemsetAsync(ds.counters.as<unsigned long long>() + kCntDistinct, 0,
+                                           2 * sizeof(unsigned long long), s);
+      if (me != hipSuccess) {
+        tgx_error e;
+        note(fail(&e, TGX_DEVICE_ERROR, "hipMemsetAsync failed: %s", hipGetErrorString(me)), e);
+        continue;
+      }
       launch_bitmap_adopt(recv + p.col_words, p.mult ? recv + p.col_words + p.slice_words : nullptr, (uint32_t)W,
                           p.slice_words, row_words, ds.spare_seen.as<uint32_t>(),
                           p.mult ? ds.spare_twice.as<uint32_t>() : nullptr, ds.counters.as<unsigned long long>(), s);
@@ -597,33 +716,71 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     const void *recs = nullptr;
     std::vector<uint64_t> sc((size_t)W, 0), rc((size_t)W, 0);
     if (!ds.partitioned && local == TGX_OK) {
-      local = distinct_export_impl(st, k, (uint32_t)W, &recs, sc.data(), &local_err);
-      if (local != TGX_OK) {  // keep taking part with nothing to send; the blob round's header tells everybody
+      tgx_error e;
+      memset(&e, 0, sizeof(e));
+      tgx_status se = injected(4, &e);
+      if (se == TGX_OK) se = distinct_export_impl(st, k, (uint32_t)W, &recs, sc.data(), &e);
+      note(se, e);
+      if (local != TGX_OK) {  // keep taking part with nothing to send; the status beside the counts tells everybody
         recs = nullptr;
         std::fill(sc.begin(), sc.end(), 0);
       }
     }
-    // counts first (8 bytes per peer), then the records themselves
-    HIP_TRY(comm->d_small_send.reserve((size_t)W * 8 + 16));
-    HIP_TRY(comm->d_small_recv.reserve((size_t)W * 8 + 16));
-    HIP_TRY(hipMemcpyAsync(comm->d_small_send.p, sc.data(), (size_t)W * 8, hipMemcpyHostToDevice, s));
-    TGX_TRY(do_alltoall(comm, s, comm->d_small_send.p, comm->d_small_recv.p, 8, err));
-    HIP_TRY(hipMemcpyAsync(rc.data(), comm->d_small_recv.p, (size_t)W * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // counts first -- 16 bytes per peer: how many records, and whether this rank is still well -- then the records
+    std::vector<uint64_t> cs((size_t)W * 2, 0), cr((size_t)W * 2, 0);
+    for (int32_t r = 0; r < W; r++) {
+      cs[2 * r] = sc[r];
+      cs[2 * r + 1] = (uint64_t)local;
+    }
+    HIP_TRY(hipMemcpyAsync(comm->d_small_send.p, cs.data(), (size_t)W * 16, hipMemcpyHostToDevice, s));
+    TGX_TRY(do_alltoall(comm, s, comm->d_small_send.p, comm->d_small_recv.p, 16, err));
+    HIP_TRY(hipMemcpyAsync(cr.data(), comm->d_small_recv.p, (size_t)W * 16, hipMemcpyDeviceToHost, s));
+    TGX_TRY(deadline_sync(comm, s, "the all-to-all of record counts", err));
+    for (int32_t r = 0; r < W; r++) {
+      rc[r] = cr[2 * r];
+      if (cr[2 * r + 1] != 0) return report(r, cr[2 * r + 1], "while exporting its keys");
+    }
     const size_t rec_bytes = wide ? sizeof(KeyRecord128) : sizeof(KeyRecord);
     uint64_t n_recv = 0;
     for (int32_t r = 0; r < W; r++) n_recv += rc[r];
-    HIP_TRY(comm->d_recv.reserve(std::max<size_t>((size_t)n_recv * rec_bytes, 16)));
+    {  // the receive buffer: sized by what the peers announced, so its allocation is this rank's own business --
+       // and the ranks tell each other how it went before anybody sends
+      tgx_error e;
+      memset(&e, 0, sizeof(e));
+      tgx_status sa = injected(5, &e);
+      if (sa == TGX_OK) {
+        const hipError_t he = comm->d_recv.reserve(std::max<size_t>((size_t)n_recv * rec_bytes, 16));
+        if (he != hipSuccess)
+          sa = fail(&e, he == hipErrorOutOfMemory ? TGX_OUT_OF_MEMORY : TGX_DEVICE_ERROR,
+                    "receive buffer of %llu key records: %s", (unsigned long long)n_recv, hipGetErrorString(he));
+      }
+      note(sa, e);
+    }
+    TGX_TRY(status_round("while allocating the receive buffer of its keys"));
     static const uint64_t nothing = 0;
     TGX_TRY(do_alltoallv(comm, s, recs ? recs : (const void *)&nothing, sc.data(), comm->d_recv.p, rc.data(), rec_bytes, err));
-    // keep the row counters, replace the key set by the owned keys of all ranks
-    HIP_TRY(hipMemsetAsync(ds.counters.as<unsigned long long>() + kCntDistinct, 0, 3 * sizeof(unsigned long long), s));
-    ds.capacity = 0;
-    ds.rows_upper_bound = 0;
-    ds.mode = DistinctMode::kHash;
-    ds.wide = wide;
-    TGX_TRY(distinct_import_records(st, k, comm->d_recv.p, n_recv, wide, err));
-    HIP_TRY(hipStreamSynchronize(s));  // d_recv is reused by the next column
+    // keep the row counters, replace the key set by the owned keys of all ranks (what fails from here on is noted: the
+    // blob round's header carries it, and nothing below needs a peer)
+    {
+      tgx_error e;
+      memset(&e, 0, sizeof(e));
+      tgx_status si = injected(6, &e);
+      if (si == TGX_OK) {
+        const hipError_t me = hipMemsetAsync(ds.counters.as<unsigned long long>() + kCntDistinct, 0,
+                                             3 * sizeof(unsigned long long), s);
+        if (me != hipSuccess) si = fail(&e, TGX_DEVICE_ERROR, "hipMemsetAsync failed: %s", hipGetErrorString(me));
+      }
+      if (si == TGX_OK) {
+        ds.capacity = 0;
+        ds.rows_upper_bound = 0;
+        ds.mode = DistinctMode::kHash;
+        ds.wide = wide;
+        si = distinct_import_records(st, k, comm->d_recv.p, n_recv, wide, &e);
+      }
+      note(si, e);
+    }
+    // (d_recv is reused by the next column's exchange: queued behind the import on the same stream -- the host does
+    //  not wait here; a transport that takes HOST buffers has waited in do_alltoallv)
     ds.partitioned = true;
   }
 
@@ -638,11 +795,19 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   size_t len = 0;
   std::vector<uint8_t> blob;
   if (local == TGX_OK) {
-    local = tgx_state_serialize(plan, st, nullptr, 0, &len, &local_err);
-    if (local == TGX_OK) {
+    tgx_error e;
+    memset(&e, 0, sizeof(e));
+    tgx_status ss = injected(7, &e);
+    // (packing reads the state back: it waits for the exchange queued above -- with a deadline, like every wait
+    //  behind a collective)
+    if (ss == TGX_OK && comm->ops.device_buffers && st->device_ready && (!parts.empty() || !by_records.empty()))
+      ss = deadline_sync(comm, s, "the exchange of the key sets", &e);
+    if (ss == TGX_OK) ss = tgx_state_serialize(plan, st, nullptr, 0, &len, &e);
+    if (ss == TGX_OK) {
       blob.resize(len);
-      local = tgx_state_serialize(plan, st, blob.data(), blob.size(), &len, &local_err);
+      ss = tgx_state_serialize(plan, st, blob.data(), blob.size(), &len, &e);
     }
+    note(ss, e);
     if (local != TGX_OK) len = 0;
   }
   if (comm->blob_plan != plan) {

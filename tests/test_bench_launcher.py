@@ -23,6 +23,21 @@ def test_launcher_builds_the_contract_command_and_environment():
     assert 1024 < bench.free_port() < 65536
 
 
+def test_gpus_are_counted_from_the_kfd_topology_without_touching_one(tmp_path, monkeypatch):
+    import bench
+
+    for i, simds in enumerate([0, 0, 1024, 1024, 1024]):  # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (96 if simds == 0 else 0, simds))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.count_gpus(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus(str(tmp_path)) == 2
+    assert bench.count_gpus(str(tmp_path / "absent")) >= 0  # (no topology: torch's count)
+
+
 def _run(args, env_extra=None):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -33,9 +48,9 @@ def _run(args, env_extra=None):
 
 
 def test_more_ranks_than_gpus_fails_loudly():
-    import torch
+    import bench
 
-    n = torch.cuda.device_count() + 1  # one more than the machine has (here: no GPU at all)
+    n = bench.count_gpus() + 1  # one more than the machine has (here: no GPU at all)
     if n < 2:
         n = 2
     p = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0"])

@@ -210,3 +210,104 @@ def test_spearman_over_ranks(world, device_buffers):
             (single[1].sum_x, single[1].sum_y, single[1].sum_x2, single[1].sum_y2, single[1].sum_xy)
         assert res[2].non_null == want.n and res[3].non_null == single[3].non_null
         assert res[4].distinct == single[4].distinct
+
+
+# ---- a rank that fails on its own between two collectives (allreduce.cpp: `local`, the status words, the deadline) ----
+@pytest.mark.parametrize("site", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("device_buffers", [True, False])
+def test_a_local_failure_fails_every_rank_at_the_same_point(site, device_buffers, monkeypatch):
+    """TGX_FAULT_INJECT="rank:site" makes one rank fail where only IT can (preparing its key sets, allocating the
+    exchange's buffers / its spare bitmaps, exporting its keys, allocating the receive buffer of the records, importing
+    them, packing its state).  It must not simply return -- its peers would sit in the next collective for ever --:
+    every rank returns an error, the same status, within the collective deadline, and none is left behind."""
+    import torch
+
+    world, bad = 4, 2
+    monkeypatch.setenv("TGX_FAULT_INJECT", "%d:%d" % (bad, site))
+    monkeypatch.setenv("TGX_COLLECTIVE_TIMEOUT_MS", "20000")
+    rng = np.random.default_rng(site)
+    n = 600_000
+    ids = rng.permutation(n).astype(np.int64)                      # dense: bitmap slices (sites 2, 3)
+    keys = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)     # sparse: key records (sites 4, 5, 6)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0), spec(T.DISTINCT, 1, flags=T.FLAG_MULTIPLICITY), spec(T.NUMERIC_STATS, 0)])
+    group = ThreadGroup(world)
+    outcome = [None] * world
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = shard_rows(n, world, rank)
+            shard = [numeric_column(c, None, True, offset=lo, length=hi - lo) for c in (ids, keys)]
+            st = T.State(plan)
+            comm = thread_comm(group, rank, device_buffers=device_buffers)
+            sharded_suite_step(plan, st, shard, comm)
+            outcome[rank] = ("ok", "")
+        except T.TgxError as e:
+            outcome[rank] = (e.status, str(e))
+        except Exception as e:  # noqa: BLE001  (a broken barrier: somebody was left behind)
+            outcome[rank] = ("other", repr(e))
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective: %r" % (outcome,)
+    statuses = {o[0] for o in outcome}
+    assert statuses == {"TGX_OUT_OF_MEMORY"}, outcome
+    assert "injected failure at site %d" % site in outcome[bad][1]
+    for r in range(world):
+        if r != bad:
+            assert "rank %d failed" % bad in outcome[r][1], outcome[r]
+
+
+def test_growing_ids_over_several_flushes_without_partition_passes(monkeypatch):
+    """with the exchange on its second stream, the facts round read the key column's running MIN / MAX
+    while the scan that produces them (a pass that is NOT partitioned: TGX_PARTITION_MIN_ROWS set high) could still be
+    running, narrowed the agreed range with stale values and dropped the last pass's keys from the re-based bitmaps.
+    `keys_ready` now stands only when the aggregates were produced before it."""
+    monkeypatch.setenv("TGX_PARTITION_MIN_ROWS", str(1 << 40))
+    world, n, batches = 4, 4_000_000, 5
+    rng = np.random.default_rng(77)
+    ids = np.arange(n, dtype=np.int64) + 1_000_000  # growing: every flush extends the range
+    other = rng.standard_normal(n)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0), spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 1)])
+
+    import torch
+
+    group = ThreadGroup(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = shard_rows(n, world, rank)
+            st = T.State(plan)
+            comm = thread_comm(group, rank, device_buffers=True)
+            for _ in range(3):
+                st.reset()
+                cut = np.linspace(lo, hi, batches + 1).astype(np.int64) // 64 * 64
+                cut[0], cut[-1] = lo, hi
+                for a, b in zip(cut[:-1], cut[1:]):
+                    st.update([numeric_column(ids, None, True, offset=int(a), length=int(b - a)),
+                               numeric_column(other, None, True, offset=int(a), length=int(b - a))])
+                st.allreduce(comm)
+                results[rank] = st.finalize()
+                assert results[rank][0].distinct == n, (rank, results[rank][0].distinct)
+        except Exception:  # noqa: BLE001
+            import traceback
+
+            errors.append((rank, traceback.format_exc()))
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=150)
+    assert not errors, errors
+    for r in results:
+        assert (r[0].distinct, r[1].total) == (n, n)
