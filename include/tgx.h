@@ -248,7 +248,10 @@ void tgx_state_destroy(tgx_state *state);
  * SMALL BATCHES ARE COALESCED.  DataFusion streams 8192-row RecordBatches (TG/core/context.rs:28-38): a batch of up to
  * 2^16 rows whose used columns are Int64 / Float64 / Int32 / Float32 (HOST or DEVICE) or HOST Utf8 / LargeUtf8 is only
  * NOTED by this call -- HOST windows are copied into a pinned arena first, so HOST buffers may still be released when
- * the call returns; DEVICE buffers must stay alive until the next tgx_finalize / tgx_state_sync as always.  The pending
+ * the call returns; DEVICE buffers must stay alive AND UNMODIFIED until the next tgx_finalize / tgx_state_sync (a noted
+ * DEVICE window is read by a later flush, not by this call: a producer that recycles its device buffers in stream order
+ * behind tgx_update -- fine for the kernels this call queues -- would have the flush read the next batch's bytes; such a
+ * producer sets TGX_OPT_NO_COALESCE, or calls tgx_state_sync before it overwrites a buffer).  The pending
  * batches of every column are gathered into ONE contiguous device column and run as one batch when 4 Mi rows (or
  * 4096 batches, or a full arena) are pending, when a batch arrives that is not coalesced, and by every call that looks
  * at the state (tgx_finalize, tgx_state_sync, tgx_merge, tgx_state_serialize, tgx_allreduce, tgx_kll_*,

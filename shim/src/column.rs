@@ -1,0 +1,123 @@
+//! An Arrow array as the `tgx_column` view the kernels read in place (include/tgx.h, "column views").
+//!
+//! The view borrows the array's buffers: keep the `ColumnView` (and through it the array) alive until `State::update`
+//! has returned.  DataFusion reads Parquet strings as `Utf8View` and streams 8192-row batches
+//! (term-guard/src/core/context.rs:28-38): both are taken as they come, small batches are coalesced by the library.
+use crate::sys::*;
+use arrow::array::{make_array, Array, ArrayRef};
+use arrow::buffer::Buffer;
+use arrow::datatypes::DataType;
+use std::ptr;
+
+/// A `tgx_column` together with what it points into.
+pub struct ColumnView {
+    pub raw: tgx_column,
+    _array: ArrayRef,
+    _dictionary: Option<Box<ColumnView>>,
+    _variadic: Vec<*const u8>,
+    _variadic_sizes: Vec<i64>,
+    _realigned_validity: Option<Buffer>,
+}
+
+/// `None`: a type outside the path (Decimal, Boolean, nested ..) -- evaluate the constraint with the stock SQL.
+pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
+    let d = arr.to_data();
+    let mut view = ColumnView {
+        raw: tgx_column {
+            type_: 0,
+            mem: TGX_MEM_HOST,
+            length: d.len() as i64,
+            offset: d.offset() as i64,
+            null_count: d.null_count() as i64,
+            validity: ptr::null(),
+            values: ptr::null(),
+            offsets: ptr::null(),
+            data: ptr::null(),
+            dictionary: ptr::null(),
+            variadic: ptr::null(),
+            variadic_sizes: ptr::null(),
+            n_variadic: 0,
+            reserved: 0,
+        },
+        _array: arr.clone(),
+        _dictionary: None,
+        _variadic: Vec::new(),
+        _variadic_sizes: Vec::new(),
+        _realigned_validity: None,
+    };
+    // tgx applies ONE offset to validity bits and value slots alike; a NullBuffer carries its own bit offset
+    if let Some(nulls) = d.nulls() {
+        if nulls.offset() == d.offset() {
+            view.raw.validity = nulls.validity().as_ptr();
+        } else {
+            // re-align: bit `offset + i` of the new bitmap is the validity of slot i
+            let bits = nulls.inner().sliced();
+            let mut aligned = arrow::buffer::MutableBuffer::new_null(d.offset() + d.len());
+            for i in 0..d.len() {
+                if arrow::util::bit_util::get_bit(bits.as_slice(), i) {
+                    arrow::util::bit_util::set_bit(aligned.as_slice_mut(), d.offset() + i);
+                }
+            }
+            let buf: Buffer = aligned.into();
+            view.raw.validity = buf.as_ptr();
+            view._realigned_validity = Some(buf);
+        }
+    }
+    let first = |i: usize| d.buffers()[i].as_ptr();
+    match d.data_type() {
+        DataType::Int64 | DataType::Timestamp(_, _) | DataType::Date64 | DataType::Time64(_) | DataType::Duration(_) => {
+            view.raw.type_ = TGX_INT64;
+            view.raw.values = first(0) as _;
+        }
+        DataType::Float64 => {
+            view.raw.type_ = TGX_FLOAT64;
+            view.raw.values = first(0) as _;
+        }
+        // 4-byte numerics: read in place by COUNT / NUMERIC_STATS, widened on the device for the other checks
+        DataType::Int32 | DataType::Date32 | DataType::Time32(_) => {
+            view.raw.type_ = TGX_INT32;
+            view.raw.values = first(0) as _;
+        }
+        DataType::Float32 => {
+            view.raw.type_ = TGX_FLOAT32;
+            view.raw.values = first(0) as _;
+        }
+        DataType::Utf8 => {
+            view.raw.type_ = TGX_UTF8;
+            view.raw.offsets = first(0) as _;
+            view.raw.data = first(1);
+        }
+        DataType::LargeUtf8 => {
+            view.raw.type_ = TGX_LARGE_UTF8;
+            view.raw.offsets = first(0) as _;
+            view.raw.data = first(1);
+        }
+        DataType::Utf8View => {
+            view.raw.type_ = TGX_UTF8_VIEW;
+            view.raw.values = first(0) as _;
+            for b in &d.buffers()[1..] {
+                view._variadic.push(b.as_ptr());
+                view._variadic_sizes.push(b.len() as i64);
+            }
+            view.raw.n_variadic = view._variadic.len() as i32;
+            view.raw.variadic = view._variadic.as_ptr();
+            view.raw.variadic_sizes = view._variadic_sizes.as_ptr();
+        }
+        DataType::Dictionary(k, v)
+            if **k == DataType::Int32 && matches!(**v, DataType::Utf8 | DataType::LargeUtf8) =>
+        {
+            view.raw.type_ = TGX_DICT32_UTF8;
+            view.raw.values = first(0) as _;
+            let dict = Box::new(column_view(&make_array(d.child_data()[0].clone()))?);
+            view.raw.dictionary = &dict.raw as *const tgx_column;
+            view._dictionary = Some(dict);
+        }
+        _ => return None,
+    }
+    Some(view)
+}
+
+/// A column the plan does not read: zeroed (include/tgx.h, tgx_update).
+pub fn unused_column() -> tgx_column {
+    unsafe { std::mem::zeroed() }
+}

@@ -1418,13 +1418,21 @@ static tgx_status bitmap_grow(tgx_state *st, DistinctState &ds, bool mult, int64
     if (add_above > room) add_above = room;
     if (add_above < need) return TGX_OK;
   }
-  const uint64_t new_range = ds.range + add_below + add_above;
+  // (the three terms can add up to exactly 2^64 -- a flush from INT64_MIN to INT64_MAX -- and wrap to a "range" of 0
+  //  that passes every density test: sum them with the carry)
+  auto sum3 = [](uint64_t a, uint64_t b, uint64_t c, uint64_t *out) {
+    uint64_t t = 0;
+    return !__builtin_add_overflow(a, b, &t) && !__builtin_add_overflow(t, c, out);
+  };
+  uint64_t new_range = 0;
+  const bool fits = sum3(ds.range, add_below, add_above, &new_range);
   const uint64_t rows_seen = (uint64_t)std::max<int64_t>(ds.total_rows + incoming, 1);
-  if (new_range >= (1ull << 34) || new_range / 16 > std::max<uint64_t>(rows_seen, g_ctx.distinct_hint)) {
+  if (!fits || new_range >= (1ull << 34) || new_range / 16 > std::max<uint64_t>(rows_seen, g_ctx.distinct_hint)) {
     // too sparse for a bitmap once extended that far: take what the batch needs and no more, if that is dense enough
     add_below = below ? ((u(ds.base) - u(lo)) + kSlice - 1) / kSlice * kSlice : 0;
     add_above = above ? u(hi) - u((int64_t)old_top) : 0;
-    const uint64_t tight = ds.range + add_below + add_above;
+    uint64_t tight = 0;
+    if (!sum3(ds.range, add_below, add_above, &tight)) return TGX_OK;
     if (tight >= (1ull << 34) || tight / 16 > std::max<uint64_t>(rows_seen, g_ctx.distinct_hint)) return TGX_OK;
   }
   const uint64_t range = ds.range + add_below + add_above;
@@ -1904,6 +1912,10 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
   int64_t nrows = 0;
   BatchTraits traits;
   TGX_TRY(update_validate(plan, st, columns, n_columns, &nrows, &traits, err));
+  if (nrows == 0) {  // an empty RecordBatch (streams interleave them): nothing to note, nothing to flush for
+    st->batches++;
+    return TGX_OK;
+  }
   // a small batch is only noted (kernels/gather.hip): no launch, no synchronisation per 8192-row batch
   const Coalescer &co = st->coalesce;
   if (traits.coalescible && nrows > 0 && nrows <= kCoalesceMaxRows && !co.disabled && !co.flushing) {
@@ -2682,6 +2694,40 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
       break;
     }
   }
+  // everything that can refuse the batch is checked BEFORE the first column notes its window: a batch is noted for all
+  // columns or for none (a column with one segment more than its neighbours would make the next flush's gather write
+  // past the coalesced buffers)
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!plan->used[i] || !is_string(columns[i].type)) continue;
+    const tgx_column &c = columns[i];
+    const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
+    const uint8_t *o0 = (const uint8_t *)c.offsets + (size_t)c.offset * ow;
+    const int64_t first = ow == 4 ? (int64_t)((const int32_t *)o0)[0] : ((const int64_t *)o0)[0];
+    const int64_t end = ow == 4 ? (int64_t)((const int32_t *)o0)[nrows] : ((const int64_t *)o0)[nrows];
+    if (end < first) return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets decrease", i);
+  }
+  struct Rollback {  // (a host allocation that throws while the windows are noted)
+    Coalescer &co;
+    std::vector<size_t> segs;
+    std::vector<int64_t> data_bytes;
+    size_t arena_used;
+    bool armed = true;
+    explicit Rollback(Coalescer &c) : co(c), arena_used(c.arena_used) {
+      for (auto &cc : co.cols) {
+        segs.push_back(cc.segs.size());
+        data_bytes.push_back(cc.data_bytes);
+      }
+    }
+    ~Rollback() {
+      if (!armed) return;
+      for (size_t i = 0; i < co.cols.size(); i++) {
+        co.cols[i].segs.resize(segs[i]);
+        co.cols[i].data_bytes = data_bytes[i];
+        co.cols[i].range_known = false;  // (a MIN / MAX of rows that are not pending after all is only too wide)
+      }
+      co.arena_used = arena_used;
+    }
+  } rollback(co);
   char *ah = any_host ? (char *)co.arena_host[co.arena_cur] : nullptr;
   const char *ad = any_host ? (const char *)co.arena_dev[co.arena_cur].p : nullptr;
   std::vector<CopyJob> &jobs = co.copy_jobs;
@@ -2712,7 +2758,6 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
       const uint8_t *o0 = (const uint8_t *)c.offsets + (size_t)c.offset * ow;
       const int64_t first = ow == 4 ? (int64_t)((const int32_t *)o0)[0] : ((const int64_t *)o0)[0];
       const int64_t end = ow == 4 ? (int64_t)((const int32_t *)o0)[nrows] : ((const int64_t *)o0)[nrows];
-      if (end < first) return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets decrease", i);
       sg.data_first = first;
       sg.data_len = end - first;
       sg.values = to_arena(o0, (size_t)(nrows + 1) * ow);
@@ -2773,6 +2818,7 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
       helper->release();
     }
   }
+  rollback.armed = false;
   co.rows += nrows;
   co.batches += 1;
   co.coalesced_batches += 1;
@@ -2960,12 +3006,13 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     ds.batch_range_known = false;
     ds.flush_device_keys = false;
   }
-  if (rc != TGX_OK) return rc;
-  // views the key sets kept of this flush point into region set `set`
+  // views the key sets kept of this flush point into region set `set` -- also when the pass failed half-way: a view
+  // that kept the tag of "the caller's memory" would dangle once the set is used again
   for (size_t q = 0; q < st->distinct.size(); q++) {
     DistinctState::Retained &r = st->distinct[q].retained;
     for (size_t k = std::min(kept_before[q], r.size()); k < r.size(); k++) r.region_set[k] = (int8_t)set;
   }
+  if (rc != TGX_OK) return rc;
   bool any_kept = false;
   for (auto &ds : st->distinct) any_kept |= !ds.retained.empty();
   if (any_kept && st->d_distinct_counters.p) {
@@ -3555,11 +3602,26 @@ extern "C" tgx_status tgx_merge(const tgx_plan *plan, tgx_state *dst, tgx_state 
   bind_thread();
   if (!plan || !dst || dst->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "dst does not belong to plan");
   TGX_TRY(coalesce_flush(dst, err));
+  {  // what can refuse a source is checked for ALL sources before dst takes anything of any of them
+    std::vector<int> mode(dst->hll_mode.begin(), dst->hll_mode.end());
+    for (size_t i = 0; i < n_srcs; i++) {
+      tgx_state *src = srcs ? srcs[i] : nullptr;
+      if (!src || src->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "src %zu does not belong to plan", i);
+      if (src == dst) return fail(err, TGX_INVALID_ARGUMENT, "src %zu is dst", i);
+      TGX_TRY(spearman_check_mergeable(src, err));
+      TGX_TRY(coalesce_flush(src, err));  // (its noted batches decide which form an APPROX_DISTINCT task takes)
+      for (size_t k = 0; k < plan->hll.size(); k++) {
+        if (src->hll_mode[k] == 0) continue;
+        if (mode[k] == 0) mode[k] = src->hll_mode[k];
+        if (mode[k] != src->hll_mode[k])
+          return fail(err, TGX_INVALID_ARGUMENT,
+                      "APPROX_DISTINCT task %zu: one state holds registers, the other a key set (src %zu); nothing was merged",
+                      k, i);
+      }
+    }
+  }
   for (size_t i = 0; i < n_srcs; i++) {
-    tgx_state *src = srcs ? srcs[i] : nullptr;
-    if (!src || src->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "src %zu does not belong to plan", i);
-    if (src == dst) return fail(err, TGX_INVALID_ARGUMENT, "src %zu is dst", i);
-    TGX_TRY(spearman_check_mergeable(src, err));
+    tgx_state *src = srcs[i];
     Gathered g;
     // distinct totals are handled set-wise below; gather the fixed-size parts
     {

@@ -350,3 +350,50 @@ def test_growing_ids_from_host_and_device_batches(order, pattern, monkeypatch):
         r = st.finalize()
         assert (r[0].total, r[0].distinct, r[0].groups_once) == (n, n, n), (flush_rows, r[0].distinct)
         check_stats(r[1], orc.stats(vals))
+
+
+def test_a_refused_batch_is_noted_for_no_column(monkeypatch):
+    """a batch whose SECOND column is refused (offsets that decrease) had already left a segment in the
+    first column's pending list -- the next flush sized the coalesced buffers for `rows` and gathered rows + nrows.  A
+    batch is noted for all columns or for none: the state goes on as if the call had not been made."""
+    rng = np.random.default_rng(3)
+    n = 40_000
+    ids = rng.permutation(n).astype(np.int64)
+    words = ["w%d" % (i % 1000) for i in range(n)]
+    offsets = np.zeros(n + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum([len(w) for w in words])
+    data = np.frombuffer("".join(words).encode(), dtype=np.uint8)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0), spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 1), spec(T.COUNT, 1)])
+    st = T.State(plan)
+
+    def batch(a, b, offs=offsets):
+        return [numeric_column(ids, None, False, offset=a, length=b - a), T.Column.utf8(offs, data, None, length=b - a, offset=a)]
+
+    st.update(batch(0, 8192))
+    bad = offsets.copy()
+    bad[8192 + 100:] -= 50_000  # the window's last offset lies before its first
+    with pytest.raises(T.TgxError) as e:
+        st.update(batch(8192, 16384, bad))
+    assert e.value.status == "TGX_INVALID_ARGUMENT"
+    for a in range(8192, n, 8192):
+        st.update(batch(a, min(n, a + 8192)))
+    res = st.finalize()
+    assert (res[0].distinct, res[1].total, res[1].min_i, res[1].max_i) == (n, n, 0, n - 1)
+    assert (res[2].distinct, res[3].total, res[3].non_null) == (1000, n, n)
+
+
+def test_empty_batches_do_not_flush():
+    """an empty RecordBatch between the others (streams interleave them) is nothing to flush for"""
+    rng = np.random.default_rng(4)
+    n = 64_000
+    v = rng.integers(0, 1000, size=n, dtype=np.int64)
+    T.init()
+    plan = T.Plan([spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 0)])
+    st = T.State(plan)
+    for a in range(0, n, 8000):
+        st.update([numeric_column(v, None, False, offset=a, length=8000)])
+        st.update([numeric_column(v, None, False, offset=a, length=0)])
+    assert st.profile_get("coalesce")["launches"] == 0  # eight noted batches, no flush yet
+    res = st.finalize()
+    assert (res[0].total, res[0].sum_i, res[1].distinct) == (n, int(v.sum()), len(np.unique(v)))

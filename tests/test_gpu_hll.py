@@ -124,3 +124,29 @@ def test_exact_key_set_answers_where_the_lane_does_not_apply():
     res = st.finalize()
     assert (res[0].distinct, res[0].total, res[0].non_null) == (777, 20_005, 20_000)
     assert (res[1].total, res[1].non_null) == (20_005, 20_000)
+
+
+def test_merge_refuses_mixed_forms_before_it_takes_anything():
+    """tgx_merge found out that one source holds HyperLogLog registers and another a key set AFTER it had
+    folded the first sources' accumulators into dst.  All sources are checked first: a refused merge leaves dst as it
+    was."""
+    import pyarrow as pa
+
+    rng = np.random.default_rng(6)
+    n = 50_000
+    nums = rng.integers(0, 5000, size=n, dtype=np.int64)
+    T.init()
+    plan = T.Plan([spec(T.APPROX_DISTINCT, 0), spec(T.COUNT, 0)])
+    a, b, c, dst = T.State(plan), T.State(plan), T.State(plan), T.State(plan)
+    a.update([numeric_column(nums, None, True)])
+    b.update([numeric_column(nums, None, True)])
+    c.update([T.Column.from_arrow(pa.array(["s%d" % (i % 77) for i in range(1000)]))])  # a string column: the key set
+    dst.update([numeric_column(nums[:1000], None, True)])
+    before = dst.finalize()
+    with pytest.raises(T.TgxError) as e:
+        dst.merge([a, b, c])
+    assert e.value.status == "TGX_INVALID_ARGUMENT" and "nothing was merged" in str(e.value)
+    after = dst.finalize()
+    assert (after[1].total, after[0].distinct) == (before[1].total, before[0].distinct) and after[1].total == 1000
+    dst.merge([a, b])
+    assert dst.finalize()[1].total == 1000 + 2 * n
