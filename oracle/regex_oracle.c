@@ -99,7 +99,7 @@ static int cls_table(cls_t *c, const char *name) {
 }
 
 /* ---------------------------------------------------------------- AST */
-enum { N_EMPTY, N_CLASS, N_START, N_END, N_BOL, N_EOL, N_WORDB, N_NWORDB, N_CAT, N_ALT, N_REP };
+enum { N_EMPTY, N_CLASS, N_START, N_END, N_BOL, N_EOL, N_WORDB, N_NWORDB, N_UWORDB, N_UNWORDB, N_CAT, N_ALT, N_REP };
 typedef struct node {
   int kind;
   cls_t cls;
@@ -666,10 +666,7 @@ static node_t *parse_atom(parser_t *ps, flags_t *f) {
     if (e == 'A') return node_new(N_START);
     if (e == 'z') return node_new(N_END);
     if (e == 'b' || e == 'B') {
-      if (!f->ascii) { /* Unicode word boundaries: not covered (the product does not take them either) */
-        p_fail(ps, "Unicode word boundaries are not covered by the oracle");
-        return NULL;
-      }
+      if (!f->ascii) return node_new(e == 'b' ? N_UWORDB : N_UNWORDB); /* \w of the characters on either side */
       return node_new(e == 'b' ? N_WORDB : N_NWORDB);
     }
     if (e >= '1' && e <= '9') {
@@ -786,7 +783,7 @@ static node_t *parse_alt(parser_t *ps, flags_t *f_in) {
 }
 
 /* ---------------------------------------------------------------- program (Pike VM) */
-enum { I_CLASS, I_SPLIT, I_JMP, I_START, I_END, I_BOL, I_EOL, I_WORDB, I_NWORDB, I_MATCH };
+enum { I_CLASS, I_SPLIT, I_JMP, I_START, I_END, I_BOL, I_EOL, I_WORDB, I_NWORDB, I_UWORDB, I_UNWORDB, I_MATCH };
 typedef struct {
   int op;
   int x, y;         /* targets / class index */
@@ -837,6 +834,8 @@ static void gen(orc_regex *re, const node_t *n) {
     case N_EOL: emit(re, I_EOL, 0, 0); break;
     case N_WORDB: emit(re, I_WORDB, 0, 0); break;
     case N_NWORDB: emit(re, I_NWORDB, 0, 0); break;
+    case N_UWORDB: emit(re, I_UWORDB, 0, 0); break;
+    case N_UNWORDB: emit(re, I_UNWORDB, 0, 0); break;
     case N_CAT:
       for (int i = 0; i < n->nkid; i++) gen(re, n->kid[i]);
       break;
@@ -954,6 +953,16 @@ typedef struct {
 static int ascii_word(long cp) {
   return (cp >= '0' && cp <= '9') || (cp >= 'A' && cp <= 'Z') || cp == '_' || (cp >= 'a' && cp <= 'z');
 }
+static int uni_word(long cp) { /* \w under Unicode: the same table the class escape uses */
+  static cls_t word;
+  static int built = 0;
+  if (!built) {
+    memset(&word, 0, sizeof(word));
+    cls_table(&word, "perl_word");
+    built = 1;
+  }
+  return cp >= 0 && cls_has(&word, (uint32_t)cp);
+}
 /* prev / next: the code points on either side of the position, -1 at the ends of the haystack */
 static int add_thread(const orc_regex *re, tlist_t *l, int *mark, int gen_id, int pc, long prev, long next) {
   const int at_start = prev < 0, at_end = next < 0;
@@ -994,6 +1003,12 @@ static int add_thread(const orc_regex *re, tlist_t *l, int *mark, int gen_id, in
         break;
       case I_NWORDB:
         if (ascii_word(prev) == ascii_word(next)) PUSH(p + 1);
+        break;
+      case I_UWORDB: /* \b: exactly one of the two neighbours is a \w character (the ends of the haystack are not) */
+        if (uni_word(prev) != uni_word(next)) PUSH(p + 1);
+        break;
+      case I_UNWORDB:
+        if (uni_word(prev) == uni_word(next)) PUSH(p + 1);
         break;
       case I_MATCH: matched = 1; break;
       default: l->pc[l->n++] = p; break;

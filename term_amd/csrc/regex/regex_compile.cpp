@@ -4,8 +4,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 
 #include "unicode_tables.h"
@@ -108,8 +110,10 @@ bool table_lookup(const std::string &name, ClassSet *out) {
 
 // ------------------------------------------------------------------------------------------- AST
 struct Node {
-  // kLineStart / kLineEnd: `^` / `$` under (?m); kWordB / kNotWordB: ASCII word boundaries (`\b` / `\B` under (?-u))
-  enum Kind { kEmpty, kClass, kStart, kEnd, kLineStart, kLineEnd, kWordB, kNotWordB, kConcat, kAlt, kRepeat } kind = kEmpty;
+  // kLineStart / kLineEnd: `^` / `$` under (?m); kWordB / kNotWordB: ASCII word boundaries (`\b` / `\B` under (?-u));
+  // kUWordB / kUNotWordB: the Unicode ones (whole characters on either side, \w as in the tables)
+  enum Kind { kEmpty, kClass, kStart, kEnd, kLineStart, kLineEnd, kWordB, kNotWordB, kUWordB, kUNotWordB, kConcat, kAlt,
+              kRepeat } kind = kEmpty;
   ClassSet cls;
   std::vector<std::unique_ptr<Node>> kids;
   int min = 0, max = 0;  // kRepeat; max < 0 = unbounded
@@ -632,16 +636,14 @@ struct Parser {
     if (c == 'A') return mk(Node::kStart);
     if (c == 'z') return mk(Node::kEnd);
     if (c == 'b' || c == 'B') {
-      // Unicode word boundaries look at whole characters on both sides (up to four bytes each way): not built.  The
-      // ASCII ones of (?-u) look at one byte each way and are part of the automaton (a one-byte context per state).
-      if (f.u) {
-        fail(kUnsupported, "Unicode word boundaries are not supported by the GPU engine (the ASCII ones are: (?-u:\\b))");
-        return nullptr;
-      }
+      // The ASCII ones of (?-u) look at one byte each way (a one-byte context per state); the Unicode ones at whole
+      // characters: the automaton's context then follows the bytes of a character through a classifier of \w, and a
+      // thread that passed the assertion carries what the NEXT character has to be until that character is through.
       if (peek() == '{') {
         fail(kUnsupported, "word boundary variants \\b{...} are not supported by the GPU engine");
         return nullptr;
       }
+      if (f.u) return mk(c == 'b' ? Node::kUWordB : Node::kUNotWordB);
       return mk(c == 'b' ? Node::kWordB : Node::kNotWordB);
     }
     if (c >= '1' && c <= '9') {
@@ -814,7 +816,7 @@ struct Parser {
 // ------------------------------------------------------------------------------------------- NFA
 struct NState {
   enum Type { kByte, kSplit, kEmpty, kAssertStart, kAssertEnd, kAssertLineStart, kAssertLineEnd, kAssertWordB,
-              kAssertNotWordB, kMatch } type;
+              kAssertNotWordB, kAssertUWordB, kAssertUNotWordB, kMatch } type;
   uint8_t lo = 0, hi = 0;
   int out = -1, out1 = -1;
 };
@@ -949,6 +951,10 @@ struct Nfa {
         return add(NState::kAssertWordB, next);
       case Node::kNotWordB:
         return add(NState::kAssertNotWordB, next);
+      case Node::kUWordB:
+        return add(NState::kAssertUWordB, next);
+      case Node::kUNotWordB:
+        return add(NState::kAssertUNotWordB, next);
       case Node::kClass: {
         std::vector<ByteSeq> seqs;
         utf8_sequences(n->cls, &seqs);
@@ -1016,57 +1022,93 @@ struct Builder {
     return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || b == '_' || (b >= 'a' && b <= 'z');
   }
 
+  // A set element is (NFA state, obligation): e = state + obligation * nfa.st.size().  A thread that has passed a
+  // Unicode word boundary carries what the character that FOLLOWS the assertion has to be -- kNeedWord / kNeedOther --
+  // while it goes on consuming that very character; the transition that completes the character (the classifier says
+  // which kind it was) drops the threads whose obligation fails and clears the others'.  Patterns without such
+  // assertions never leave obligation 0, and their elements are the state numbers they always were.
+  enum { kNoObligation = 0, kNeedWord = 1, kNeedOther = 2 };
+  int enc(int state, int obligation) const { return state + obligation * (int)nfa.st.size(); }
+  int state_of(int e) const { return e % (int)nfa.st.size(); }
+  int obligation_of(int e) const { return e / (int)nfa.st.size(); }
+
   // epsilon closure of `seeds`.  Assertions that look BEHIND (\A, (?m)^) are decided from `prev`; those that look
   // AHEAD ($, (?m)$, \b, \B) are decided when `next` is known and otherwise stay in the set as pending states -- the
   // transition on the next byte (or the end of the haystack) runs the closure over the set once more with it.
+  // `prev` >= 4: the position lies inside a character (Unicode word boundaries only): no assertion holds there.
   void closure(const std::vector<int> &seeds, int prev, int next, std::vector<int> *out) {
-    if (mark.size() != nfa.st.size()) mark.assign(nfa.st.size(), 0);
+    if (mark.size() != 3 * nfa.st.size()) mark.assign(3 * nfa.st.size(), 0);
     epoch++;
     stack.assign(seeds.begin(), seeds.end());
     while (!stack.empty()) {
-      int s = stack.back();
+      int e = stack.back();
       stack.pop_back();
-      if (s < 0 || mark[s] == epoch) continue;
-      mark[s] = epoch;
+      if (e < 0) continue;
+      int s = state_of(e), ob = obligation_of(e);
+      if (next == kNextEnd && ob != kNoObligation) {  // nothing follows: "not a word character"
+        if (ob == kNeedWord) continue;
+        ob = kNoObligation;
+        e = enc(s, ob);
+      }
+      if (mark[e] == epoch) continue;
+      mark[e] = epoch;
       const NState &n = nfa.st[s];
+      auto push = [&](int to) {
+        if (to >= 0) stack.push_back(enc(to, ob));
+      };
       switch (n.type) {
         case NState::kEmpty:
-          stack.push_back(n.out);
+          push(n.out);
           break;
         case NState::kSplit:
-          stack.push_back(n.out);
-          stack.push_back(n.out1);
+          push(n.out);
+          push(n.out1);
           break;
         case NState::kAssertStart:
-          if (prev == kCtxStart) stack.push_back(n.out);
+          if (prev == kCtxStart) push(n.out);
           break;
         case NState::kAssertLineStart:
-          if (prev == kCtxStart || prev == kCtxNewline) stack.push_back(n.out);
+          if (prev == kCtxStart || prev == kCtxNewline) push(n.out);
           break;
         case NState::kAssertEnd:
           if (next == kNextEnd)
-            stack.push_back(n.out);
+            push(n.out);
           else if (next == kNextUnknown)
-            out->push_back(s);
+            out->push_back(e);
           break;
         case NState::kAssertLineEnd:
           if (next == kNextEnd || next == '\n')
-            stack.push_back(n.out);
+            push(n.out);
           else if (next == kNextUnknown)
-            out->push_back(s);
+            out->push_back(e);
           break;
         case NState::kAssertWordB:
         case NState::kAssertNotWordB:
           if (next == kNextUnknown) {
-            out->push_back(s);
+            out->push_back(e);
           } else {
             const bool boundary = (prev == kCtxWord) != (next >= 0 && is_word_byte(next));
-            if (boundary == (n.type == NState::kAssertWordB)) stack.push_back(n.out);
+            if (boundary == (n.type == NState::kAssertWordB)) push(n.out);
           }
           break;
+        case NState::kAssertUWordB:
+        case NState::kAssertUNotWordB: {
+          if (prev >= 4) break;  // (inside a character: cannot be reached on valid UTF-8)
+          const bool prev_word = prev == kCtxWord;
+          const bool next_must_be_word = (n.type == NState::kAssertUWordB) ? !prev_word : prev_word;
+          if (next == kNextEnd) {
+            if (!next_must_be_word) push(n.out);
+          } else {
+            const int need = next_must_be_word ? kNeedWord : kNeedOther;
+            if (ob == kNoObligation || ob == need) {
+              if (n.out >= 0) stack.push_back(enc(n.out, need));
+            }  // (else: two assertions at one position that contradict each other)
+          }
+          break;
+        }
         case NState::kByte:
         case NState::kMatch:
-          out->push_back(s);
+          out->push_back(e);
           break;
       }
     }
@@ -1075,9 +1117,98 @@ struct Builder {
   }
 
   bool has_match(const std::vector<int> &set) const {
-    for (int s : set)
-      if (nfa.st[s].type == NState::kMatch) return true;
+    for (int e : set)
+      if (e >= 0 && nfa.st[state_of(e)].type == NState::kMatch && obligation_of(e) == kNoObligation) return true;
     return false;
+  }
+};
+
+// What kind of character the bytes since the last character boundary make: a deterministic walk over the UTF-8 forms of
+// \w (tables: perl_word) and of everything else, from 0x80 up (ASCII bytes are told apart directly).
+// next[k][byte]: >= 1 the walk's next state, kWord / kOther: the character is complete; state 0 = a character begins.
+struct WordClassifier {
+  enum { kWord = -1, kOther = -2 };
+  std::vector<std::array<int, 256>> next;
+  std::vector<std::pair<uint8_t, uint8_t>> byte_ranges;  // what the walk tells apart (for the byte classes)
+  bool build() {
+    ClassSet word;
+    if (!table_lookup("perl_word", &word)) return false;
+    ClassSet w, o, not_word = negate(word);
+    for (const Range &r : word)
+      if (r.hi >= 0x80) w.push_back({std::max<uint32_t>(r.lo, 0x80), r.hi});
+    for (const Range &r : not_word)
+      if (r.hi >= 0x80) o.push_back({std::max<uint32_t>(r.lo, 0x80), r.hi});
+    Nfa cn;
+    const int tw = cn.add(NState::kMatch), to = cn.add(NState::kMatch);
+    auto head = [&](const ClassSet &cs, int term) -> int {
+      std::vector<ByteSeq> seqs;
+      utf8_sequences(cs, &seqs);
+      if (seqs.empty()) return -1;
+      std::sort(seqs.begin(), seqs.end(), [](const ByteSeq &x, const ByteSeq &y) {
+        if (x.n != y.n) return x.n < y.n;
+        for (int i = 0; i < x.n; i++) {
+          if (x.lo[i] != y.lo[i]) return x.lo[i] < y.lo[i];
+          if (x.hi[i] != y.hi[i]) return x.hi[i] < y.hi[i];
+        }
+        return false;
+      });
+      return cn.build_class(seqs, 0, seqs.size(), 0, term);
+    };
+    const int hw = head(w, tw), ho = head(o, to);
+    if (cn.overflow) return false;
+    for (const NState &st : cn.st)
+      if (st.type == NState::kByte && st.lo <= st.hi) byte_ranges.push_back({st.lo, st.hi});
+    auto close = [&](std::vector<int> seeds) {
+      std::vector<int> out, stack = std::move(seeds);
+      std::vector<char> seen(cn.st.size(), 0);
+      while (!stack.empty()) {
+        const int s = stack.back();
+        stack.pop_back();
+        if (s < 0 || seen[s]) continue;
+        seen[s] = 1;
+        const NState &n = cn.st[s];
+        if (n.type == NState::kSplit) {
+          stack.push_back(n.out);
+          stack.push_back(n.out1);
+        } else {
+          out.push_back(s);
+        }
+      }
+      std::sort(out.begin(), out.end());
+      return out;
+    };
+    std::map<std::vector<int>, int> ids;
+    std::vector<std::vector<int>> sets;
+    sets.push_back(close({hw, ho}));
+    ids[sets[0]] = 0;
+    for (size_t cur = 0; cur < sets.size(); cur++) {
+      std::array<int, 256> row;
+      for (int b = 0; b < 256; b++) {
+        std::vector<int> seeds;
+        for (int s : sets[cur]) {
+          const NState &n = cn.st[s];
+          if (n.type == NState::kByte && n.lo <= b && b <= n.hi) seeds.push_back(n.out);
+        }
+        const std::vector<int> nx = close(seeds);
+        if (nx.empty()) {
+          row[b] = kOther;  // (not UTF-8: an Arrow string never holds it; ends the character)
+        } else if (std::find(nx.begin(), nx.end(), tw) != nx.end()) {
+          row[b] = kWord;
+        } else if (std::find(nx.begin(), nx.end(), to) != nx.end()) {
+          row[b] = kOther;
+        } else {
+          auto it = ids.find(nx);
+          if (it == ids.end()) {
+            it = ids.emplace(nx, (int)sets.size()).first;
+            sets.push_back(nx);
+          }
+          row[b] = it->second;
+        }
+      }
+      next.push_back(row);
+      if (sets.size() > 4096) return false;
+    }
+    return true;
   }
 };
 
@@ -1131,11 +1262,26 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
   }
 
   // which neighbourhood the pattern's assertions look at
-  bool uses_line = false, uses_word = false;
+  bool uses_line = false, uses_word = false, uses_uword = false;
   for (const NState &s : nfa.st) {
     uses_line |= s.type == NState::kAssertLineStart || s.type == NState::kAssertLineEnd;
     uses_word |= s.type == NState::kAssertWordB || s.type == NState::kAssertNotWordB;
+    uses_uword |= s.type == NState::kAssertUWordB || s.type == NState::kAssertUNotWordB;
   }
+  if (uses_word && uses_uword) {
+    *msg = "ASCII and Unicode word boundaries in one pattern are not supported by the GPU engine";
+    return kUnsupported;
+  }
+  // (the classifier does not depend on the pattern: built once per process)
+  static WordClassifier wc_shared;
+  static bool wc_ok = false;
+  static std::once_flag wc_once;
+  if (uses_uword) std::call_once(wc_once, [] { wc_ok = wc_shared.build(); });
+  if (uses_uword && !wc_ok) {
+    *msg = "Unicode word boundaries: the classifier of \\w could not be built";
+    return kUnsupported;
+  }
+  const WordClassifier &wc = wc_shared;
   // byte classes from every byte-range boundary (and from the bytes the assertions tell apart)
   bool boundary[257];
   memset(boundary, 0, sizeof(boundary));
@@ -1146,9 +1292,16 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
       boundary[(int)s.hi + 1] = true;
     }
   if (uses_line) boundary['\n'] = boundary['\n' + 1] = true;
-  if (uses_word)
+  if (uses_word || uses_uword)
     for (int b = 1; b < 256; b++)
       if (Builder::is_word_byte(b) != Builder::is_word_byte(b - 1)) boundary[b] = true;
+  if (uses_uword) {
+    boundary[0x80] = true;
+    for (const auto &r : wc.byte_ranges) {
+      boundary[r.first] = true;
+      boundary[(int)r.second + 1] = true;
+    }
+  }
   int ncls = 0;
   uint8_t rep[256];
   for (int b = 0; b < 256; b++) {
@@ -1164,8 +1317,19 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
   // assertions keeps ONE context, and its automaton is the one it always was)
   auto ctx_of = [&](int byte) -> int {
     if (uses_line && byte == '\n') return Builder::kCtxNewline;
-    if (uses_word && Builder::is_word_byte(byte)) return Builder::kCtxWord;
+    if ((uses_word || uses_uword) && Builder::is_word_byte(byte)) return Builder::kCtxWord;
     return Builder::kCtxOther;
+  };
+  // ... and, with Unicode word boundaries, the walk through a character's bytes: contexts 0..3 are character
+  // boundaries, 4 + k is state k of the classifier (inside a character)
+  auto ctx_step = [&](int ctx, int byte) -> int {
+    if (!uses_uword) return ctx_of(byte);
+    const int k = ctx >= 4 ? ctx - 4 : 0;
+    if (k == 0 && byte < 0x80) return ctx_of(byte);
+    const int r = wc.next[(size_t)k][(size_t)byte];
+    if (r == WordClassifier::kWord) return Builder::kCtxWord;
+    if (r == WordClassifier::kOther) return Builder::kCtxOther;
+    return 4 + r;
   };
   // an unanchored search may begin a match at every position: the start state's closure under each context
   std::vector<int> init_unanchored[4];
@@ -1235,14 +1399,30 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
       } else {
         // 2. the byte itself, then the closure behind it (context = this byte), plus a fresh start
         std::vector<int> seeds;
-        for (int s : here) {
-          const NState &n = nfa.st[s];
-          if (n.type == NState::kByte && n.lo <= byte && byte <= n.hi) seeds.push_back(n.out);
+        for (int e : here) {
+          const NState &n = nfa.st[bld.state_of(e)];
+          const int ob = bld.obligation_of(e);
+          if (n.type == NState::kByte && n.lo <= byte && byte <= n.hi && n.out >= 0) seeds.push_back(bld.enc(n.out, ob));
+          // (a match that still waits for the character behind it to turn out right stays until that is known)
+          if (n.type == NState::kMatch && ob != Builder::kNoObligation) seeds.push_back(e);
         }
-        const int nctx = ctx_of(byte);
+        const int nctx = ctx_step(ctx, byte);
+        if (uses_uword && nctx < 4) {  // a character is complete: what the threads required of it is settled
+          const bool was_word = nctx == Builder::kCtxWord;
+          std::vector<int> kept;
+          for (int e : seeds) {
+            const int ob = bld.obligation_of(e);
+            if (ob == Builder::kNoObligation)
+              kept.push_back(e);
+            else if ((ob == Builder::kNeedWord) == was_word)
+              kept.push_back(bld.enc(bld.state_of(e), Builder::kNoObligation));
+          }
+          seeds.swap(kept);
+        }
         std::vector<int> next;
         bld.closure(seeds, nctx, Builder::kNextUnknown, &next);
-        next.insert(next.end(), init_unanchored[nctx].begin(), init_unanchored[nctx].end());
+        // (a match may begin at every CHARACTER: inside one -- contexts from 4 up -- none does)
+        if (nctx < 4) next.insert(next.end(), init_unanchored[nctx].begin(), init_unanchored[nctx].end());
         std::sort(next.begin(), next.end());
         next.erase(std::unique(next.begin(), next.end()), next.end());
         id = intern(nctx, next);

@@ -86,9 +86,25 @@ tgx_status compile_checked(const char *pattern, size_t len, uint32_t flags, rx::
   std::string msg;
   rx::CompileStatus rs = rx::validate_pattern_rules(pattern, len, &msg);
   if (rs != rx::kOk) return rfail(err, TGX_INVALID_ARGUMENT, "%s", msg.c_str());
-  rs = rx::compile(pattern, len, (flags & TGX_FLAG_CASE_INSENSITIVE) != 0, dfa, &msg);
+  // a pattern is compiled by validate, by plan_create and by every is_match / match_group of a host-side check: the
+  // last few automata of the thread are kept (a pattern with Unicode word boundaries takes 15-100 ms to build)
+  struct Cached {
+    std::string pattern;
+    bool fold;
+    rx::Dfa dfa;
+  };
+  static thread_local std::vector<Cached> cache;
+  const bool fold = (flags & TGX_FLAG_CASE_INSENSITIVE) != 0;
+  for (size_t i = 0; i < cache.size(); i++)
+    if (cache[i].fold == fold && cache[i].pattern.size() == len && memcmp(cache[i].pattern.data(), pattern, len) == 0) {
+      *dfa = cache[i].dfa;
+      return TGX_OK;
+    }
+  rs = rx::compile(pattern, len, fold, dfa, &msg);
   if (rs == rx::kInvalid) return rfail(err, TGX_INVALID_ARGUMENT, "%s", msg.c_str());
   if (rs != rx::kOk) return rfail(err, TGX_UNSUPPORTED, "%s", msg.c_str());
+  if (cache.size() >= 8) cache.erase(cache.begin());
+  cache.push_back({std::string(pattern, len), fold, *dfa});
   return TGX_OK;
 }
 }  // namespace

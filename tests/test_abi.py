@@ -76,8 +76,16 @@ def test_plan_validation_needs_no_device():
     with pytest.raises(T.TgxError):
         T.Plan([spec(T.COMOMENTS, 0)])  # needs column2
     with pytest.raises(T.TgxError) as e:
-        T.Plan([spec(T.REGEX_MATCH, 0, pattern=r"\bword\b")])  # Unicode word boundaries: outside the engine
+        T.Plan([spec(T.REGEX_MATCH, 0, pattern=r"\b{start}word")])  # the \b{..} variants: outside the engine
     assert e.value.status == "TGX_UNSUPPORTED"  # the shim falls back to the stock SQL constraint
+    # Unicode word boundaries are part of the engine since round 4 (whole characters on either side, \w as in the tables)
+    T.Plan([spec(T.REGEX_MATCH, 0, pattern=r"\bword\b")])
+    import ctypes as C
+
+    for value, want in (("a word here", 1), ("swordfish", 0), ("wörd", 0), ("éword", 0), ("word é", 1), ("日本 word。", 1)):
+        m, err, v, pat = C.c_int32(-1), T._lib._Error(), value.encode(), rb"\bword\b"
+        assert T.lib().tgx_regex_is_match(pat, len(pat), 0, v, len(v), C.byref(m), C.byref(err)) == 0
+        assert m.value == want, value
     p = T.Plan([spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 0), spec(T.NUMERIC_STATS, 0, flags=T.FLAG_VARIANCE)])
     assert T.lib().tgx_plan_num_specs(p.h) == 3
 

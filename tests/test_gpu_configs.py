@@ -57,7 +57,7 @@ def test_c3_patterns_on_a_column_crossing_2_31_value_bytes():
     import torch
 
     T.init()
-    n = 80_000_000  # x 28 B = 2.24e9 value bytes > 2^31: int64 offsets, 64-bit byte addressing in the kernel
+    n = 100_000_000  # C3's size; x 28 B = 2.8e9 value bytes > 2^31: int64 offsets, 64-bit byte addressing in the kernel
     offsets, data, validity, L, expect = _email_column(torch, n)
     assert n * L > 2**31
     col = T.Column(T.LARGE_UTF8, n, offsets=offsets, data=data, validity=validity)
@@ -89,7 +89,7 @@ def test_c3_patterns_on_a_column_crossing_2_31_value_bytes():
                                        null_is_valid=bool(f & T.FLAG_NULL_IS_VALID))
         assert (r.total, r.matches) == (want.total, want.matches), p
     # additivity at full size: two ragged halves merged == the whole
-    cut = 41_234_560
+    cut = 51_234_560
     a, b = T.State(plan), T.State(plan)
     a.update([T.Column(T.LARGE_UTF8, cut, offsets=offsets, data=data, validity=validity)])
     b.update([T.Column(T.LARGE_UTF8, n - cut, offsets=offsets, data=data, validity=validity, offset=cut)])

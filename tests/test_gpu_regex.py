@@ -198,3 +198,32 @@ def test_multiline_word_boundary_and_set_operation_patterns_on_gpu(device):
         want = orc.Regex(p).count_utf8(offs, data, validity, null_is_valid=bool(k % 2))
         assert (res[k].total, res[k].matches) == (want.total, want.matches), p
         assert 0 < res[k].matches < res[k].total, p  # (the column exercises both verdicts of every pattern)
+
+
+@pytest.mark.parametrize("device", [True, False])
+@pytest.mark.parametrize("view", [False, True])
+def test_unicode_word_boundaries_on_gpu(device, view):
+    """`\\b` / `\\B` as Rust's `regex` takes them by default (round 4): the automaton's context follows a character's
+    bytes through a classifier of \\w and a thread past the assertion carries what the next character has to be -- ~650
+    states x ~100 byte classes, so the kernel walks a table in global memory.  Counts equal the oracle's VM (code points
+    on either side) on a column of words in several scripts, Utf8 and Utf8View."""
+    rng = np.random.default_rng(12)
+    words = ["word", "a word here", "swordfish", "wörd", "éword", "word é", "日本 word。", "naïve", "naïvely", "12", "a12",
+             "x 12 y", "١٢", "x١٢", "αβγ δ", "xαβγ", "select", "xselect", "drop x", "", " ", "é", "日本", "a_b", "éx",
+             "a‍b", "😀a", "on", "upon", "bonbon", "word, word", "WORD"]
+    vals = [None if rng.random() < 0.03 else rng.choice(words) + ("" if rng.random() < 0.6 else " " + rng.choice(words))
+            for _ in range(40_000)]
+    offs, data, validity = orc.utf8_from_list(vals)
+    pats = [r"\bword\b", r"\b\d+\b", r"\bé", r"\Bon\b", r"(?i)\bWORD\b", r"\b\p{Greek}+\b", r"\b(?:select|drop)\b", r"\w\b\W"]
+    specs = [spec(T.REGEX_MATCH, 0, pattern=p, flags=T.FLAG_NULL_IS_VALID if k % 2 else 0) for k, p in enumerate(pats)]
+    if view:
+        from test_gpu_utf8view import view_column
+
+        col = view_column(vals, rng, device)
+    else:
+        col = utf8_column(offs, data, validity, device)
+    res, _, _ = run_plan(specs, [[col]])
+    for k, p in enumerate(pats):
+        want = orc.Regex(p).count_utf8(offs, data, validity, null_is_valid=bool(k % 2))
+        assert (res[k].total, res[k].matches) == (want.total, want.matches), p
+        assert 0 < res[k].matches < res[k].total, p

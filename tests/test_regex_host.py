@@ -217,3 +217,42 @@ def test_multiline_word_boundary_and_set_operation_vectors(crosscheck_r3):
     for p in crosscheck_r3["unsupported"]:
         rc, msg = product_validate(p)
         assert rc == 2, (p, rc, msg)
+
+
+@pytest.fixture(scope="module")
+def crosscheck_r4():
+    with open(os.path.join(ROOT, "tests", "golden", "regex_crosscheck_r4.json")) as f:
+        return json.load(f)
+
+
+def test_unicode_word_boundary_vectors(crosscheck_r4):
+    """`\\b` / `\\B` as Rust's `regex` takes them by default (security.rs:152-183 accepts whatever that crate compiles):
+    the PyPI `regex` truth of tests/golden/regex_crosscheck_r4.json through the oracle's VM (code points on either
+    side), the product's automaton (a context that follows a character's bytes, an obligation carried until the
+    character behind the assertion is complete) and the product automaton of groups of these patterns."""
+    by_pattern = {}
+    for c in crosscheck_r4["cases"]:
+        by_pattern.setdefault(c["pattern"], []).append(c)
+    assert len(by_pattern) >= 25
+    for pat, cases in by_pattern.items():
+        rx = orc.Regex(pat)
+        assert product_validate(pat)[0] == 0, pat
+        for c in cases:
+            assert rx.is_match(c["input"]) == c["match"], ("oracle", pat, c["input"])
+            assert product_is_match(pat, c["input"]) == c["match"], ("product", pat, c["input"])
+    pats = sorted(by_pattern)
+    grouped_any = 0
+    for g0 in range(0, len(pats) - 2, 3):
+        group = pats[g0:g0 + 3]
+        truth = {(c["pattern"], c["input"]): c["match"] for p in group for c in by_pattern[p]}
+        for s in sorted({c["input"] for p in group for c in by_pattern[p]})[::5]:
+            mask, grouped = product_group_mask(group, [0, 0, 0], s)
+            grouped_any += grouped
+            for bit, p in enumerate(group):
+                want = truth.get((p, s))
+                if want is None:  # (no vector for this pair: the oracle decides)
+                    want = orc.Regex(p).is_match(s)
+                assert bool((mask >> bit) & 1) == want, (group, s, bit)
+    # (an automaton with Unicode word boundaries carries the walk through \w's UTF-8 forms: ~650 states x ~100 byte
+    #  classes, four times the LDS table -- these patterns run from a table in global memory and are not grouped)
+    assert grouped_any == 0
