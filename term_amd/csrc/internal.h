@@ -375,6 +375,25 @@ struct CoalesceSegment {
   int64_t bit0;             // first validity bit within *validity
   int64_t length;
   int64_t data_first, data_len;
+  // Utf8View windows: the stretches of the variadic buffers the long views point into (GatherSeg, kind 3)
+  int32_t vb_count = 0;
+  int32_t vb_index[kGatherViewBufs] = {0, 0, 0, 0};
+  int64_t vb_min[kGatherViewBufs] = {0, 0, 0, 0}, vb_len[kGatherViewBufs] = {0, 0, 0, 0};
+  const uint8_t *vb_src[kGatherViewBufs] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t index_shift = 0;  // dictionary index windows: first entry of the window's dictionary in the coalesced one
+};
+// the dictionaries of a Dictionary<Int32, Utf8> column's pending windows, coalesced like a Utf8 column of their own
+struct CoalesceDict {
+  int type = 0;             // TGX_UTF8 / TGX_LARGE_UTF8
+  bool any_validity = false;
+  int64_t data_bytes = 0, entries = 0;
+  std::vector<CoalesceSegment> segs;
+  DevBuf values[2], validity[2], data[2];
+  tgx_column view[2];       // what the coalesced column's `dictionary` points at (per region set)
+  // the dictionary of the last noted window: batches of one file share theirs, it is taken once per flush
+  const void *last_offsets = nullptr;
+  const uint8_t *last_data = nullptr, *last_validity = nullptr;
+  int64_t last_offset = 0, last_length = -1, last_base = 0;
 };
 struct CoalesceColumn {
   int type = 0;             // tgx_type of the pending segments
@@ -382,6 +401,8 @@ struct CoalesceColumn {
   int64_t data_bytes = 0;   // strings: value bytes pending
   std::vector<CoalesceSegment> segs;
   DevBuf values[2], validity[2], data[2];  // the coalesced column, per region set
+  const uint8_t *view_buf[2] = {nullptr, nullptr};  // Utf8View: the coalesced column's one data buffer (`variadic`)
+  std::unique_ptr<CoalesceDict> dict;               // Dictionary<Int32, Utf8>
   // Int64 key columns (a numeric DISTINCT check reads them): MIN / MAX of the pending HOST windows' non-NULL values,
   // taken while the windows are copied -- the flush then lays the range bitmap out (or grows it) for what it is about
   // to see instead of sampling the device copy and waiting for the answer.  Unknown once a DEVICE window is pending.

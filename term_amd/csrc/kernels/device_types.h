@@ -164,8 +164,18 @@ struct GatherSeg {
   int64_t dst_row;              // first row in the coalesced column
   int64_t data_first, data_base, data_len;  // strings: first source offset value, destination byte position, bytes
   int32_t elem_bytes;           // kind 0: 8 or 4
-  int32_t kind;                 // 0 fixed width, 1 Utf8 (int32 offsets), 2 LargeUtf8 (int64 offsets)
+  int32_t kind;                 // 0 fixed width, 1 Utf8 (int32 offsets), 2 LargeUtf8 (int64 offsets),
+                                // 3 Utf8View (16-byte views), 4 dictionary indices (int32, shifted)
+  // kind 3: the stretches of the window's data buffers its long views point into (at most kGatherViewBufs buffers per
+  // window): stretch k is bytes [vb_min, vb_min + vb_len) of source buffer vb_index, copied from vb_src to
+  // dst_data + vb_base; a long view (buffer, offset) becomes (0, vb_base + offset - vb_min)
+  int32_t vb_count;
+  int32_t index_shift;          // kind 4: added to every index (where the window's dictionary starts in the coalesced one)
+  int32_t vb_index[4];
+  int64_t vb_min[4], vb_len[4], vb_base[4];
+  const uint8_t *vb_src[4];
 };
+constexpr int kGatherViewBufs = 4;
 
 __host__ __device__ inline int64_t f64_total_key(int64_t bits) {
   return bits ^ (int64_t)(((uint64_t)(bits >> 63)) >> 1);

@@ -9,7 +9,11 @@
 //   * validity bitmaps: concatenated bit-exactly -- a segment may start at any Arrow offset and land at any row, so
 //     every destination word is assembled from the source bits it covers; words shared by two segments are merged
 //     with an atomic OR into the zeroed destination; a segment without a bitmap contributes ones,
-//   * Utf8 / LargeUtf8: offsets re-based onto the running byte position of the coalesced data buffer, bytes copied.
+//   * Utf8 / LargeUtf8: offsets re-based onto the running byte position of the coalesced data buffer, bytes copied,
+//   * Utf8View (what DataFusion reads Parquet strings as): the stretches of the data buffers a window's long views
+//     point into are laid one behind the other in ONE data buffer and the views re-pointed at them,
+//   * Dictionary<Int32, Utf8>: the windows' dictionaries (one per run of batches that share theirs) are gathered like
+//     a Utf8 column of their own and every window's indices shifted to where its dictionary starts.
 // One workgroup per (column, segment).  HBM traffic: the windows are read once and written once (then read by the
 // checks): a stream of 8192-row batches costs 3x the bytes of one big batch -- against one launch per ~500 batches.
 #include <hip/hip_runtime.h>
@@ -103,6 +107,35 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherSeg *_
     if (g.src_values)
       gather_bytes((uint8_t *)g.dst_values + g.dst_row * g.elem_bytes, (const uint8_t *)g.src_values,
                    g.length * g.elem_bytes);
+    return;
+  }
+  if (g.kind == 4) {  // dictionary indices: the window's dictionary starts at index_shift of the coalesced one
+    const int32_t *si = (const int32_t *)g.src_values;
+    int32_t *d = (int32_t *)g.dst_values + g.dst_row;
+    for (int64_t i = tid; i < g.length; i += blockDim.x) d[i] = si[i] + g.index_shift;
+    return;
+  }
+  if (g.kind == 3) {  // Utf8View: the stretches of the data buffers, then the views re-pointed at them
+    for (int k = 0; k < g.vb_count; k++)
+      if (g.vb_len[k] > 0) gather_bytes(g.dst_data + g.vb_base[k], g.vb_src[k], g.vb_len[k]);
+    const uint4 *sv = (const uint4 *)g.src_values;
+    uint4 *d = (uint4 *)g.dst_values + g.dst_row;
+    for (int64_t i = tid; i < g.length; i += blockDim.x) {
+      uint4 v = sv[i];
+      if ((int32_t)v.x > 12) {
+        int k = 0;
+        while (k < g.vb_count && g.vb_index[k] != (int32_t)v.z) k++;
+        if (k < g.vb_count) {
+          v.w = (uint32_t)(g.vb_base[k] + ((int64_t)(int32_t)v.w - g.vb_min[k]));
+          v.z = 0;
+        } else {
+          v = make_uint4(0, 0, 0, 0);  // (a NULL row's view may hold anything: it becomes an empty value)
+        }
+      } else if ((int32_t)v.x < 0) {
+        v = make_uint4(0, 0, 0, 0);
+      }
+      d[i] = v;
+    }
     return;
   }
   // ---- strings: offsets re-based, bytes copied ----

@@ -113,7 +113,9 @@ extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) try {
   return tgx::abi_exception(err);
 }
 
+static void copy_pool_shutdown();
 extern "C" tgx_status tgx_shutdown(void) try {
+  copy_pool_shutdown();  // (the helper threads of the coalescing arenas' copies: stopped and joined)
   std::lock_guard<std::mutex> lock(g_ctx.mu);
   g_ctx.inited = false;
   return TGX_OK;
@@ -1865,9 +1867,11 @@ static tgx_status update_validate(const tgx_plan *plan, tgx_state *st, const tgx
     const bool host = c.mem == TGX_MEM_HOST;
     traits->any_host |= host;
     traits->any_utf8 |= c.type == TGX_UTF8;
-    // string windows need their first / last offsets on the host: HOST batches only (what DataFusion streams);
-    // Utf8View and dictionary batches keep the immediate path
-    traits->coalescible &= is_numeric(c.type) || is_numeric32(c.type) || (is_string(c.type) && host);
+    // string windows need their first / last offsets (Utf8View: the stretches its views point into; dictionaries:
+    // theirs) on the host: HOST batches only (what DataFusion streams); DEVICE strings keep the immediate path
+    traits->coalescible &= is_numeric(c.type) || is_numeric32(c.type) || (is_string(c.type) && host) ||
+                           (c.type == TGX_UTF8_VIEW && host) ||
+                           (c.type == TGX_DICT32_UTF8 && host && c.dictionary && c.dictionary->mem == TGX_MEM_HOST);
     if (c.length > 0) {
       if ((is_numeric(c.type) || is_numeric32(c.type)) && reads_values[i] && !c.values)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
@@ -2452,30 +2456,52 @@ constexpr size_t kCoalesceArenaMax = 128u << 20;     // pinned staging per arena
 static void stream_copy(void *dst, const void *src, size_t bytes);
 namespace {
 typedef tgx::CoalesceCopy CopyJob;
-// K workers (TGX_COPY_THREADS, default 3), each with its own job slot; the pool serves ONE caller at a time.  States
-// fed from several threads at once (a state per DataFusion partition stream) meet here; whoever finds the pool taken
-// copies its whole batch itself.  (Without the claim two posts could overwrite each other's job list: copies
-// skipped, or a caller waiting for a ticket that never comes -- the differential tester's threaded ranks hung once
-// in ~150 runs.)
-class CopyHelper {
+// K workers (TGX_COPY_THREADS, default 3), each with its own job slot.  A caller CLAIMS the workers that are idle at
+// that moment (states fed from several threads at once -- a state per DataFusion partition stream -- share the pool:
+// the first version gave the whole pool to one caller at a time and let the others copy alone at a core's 27 GB/s),
+// cuts its batch's copies into (claimed + 1) shares, posts one to every claimed worker through its slot (no queue, no
+// lock: a worker spins on its own ticket for ~200 us after its last job, then sleeps), copies its own share and waits
+// for the others.  tgx_shutdown stops and joins the workers.
+class CopyPool {
  public:
-  static CopyHelper *get() {
-    static CopyHelper *h = [] {
+  static constexpr int kMaxWorkers = 8;
+  static CopyPool *get() {
+    if (CopyPool *fast = fast_instance().load(std::memory_order_acquire)) return fast->n_workers_ > 0 ? fast : nullptr;
+    std::lock_guard<std::mutex> lock(instance_mu());
+    CopyPool *h = fast_instance().load(std::memory_order_acquire);
+    if (!h) {
       const char *e = getenv("TGX_COPY_THREADS");
       int k = e ? atoi(e) : 3;
-      if (k <= 0) return (CopyHelper *)nullptr;
       const unsigned hw = std::thread::hardware_concurrency();
       if (hw && (unsigned)k + 1 > hw) k = hw > 1 ? (int)hw - 1 : 0;  // (the caller copies a share as well)
-      if (k <= 0) return (CopyHelper *)nullptr;
       if (k > kMaxWorkers) k = kMaxWorkers;
-      return new CopyHelper(k);  // (lives as long as the process: a detached worker must not outlive its state)
-    }();
-    return h;
+      h = new CopyPool(k < 0 ? 0 : k);
+      fast_instance().store(h, std::memory_order_release);
+    }
+    return h->n_workers_ > 0 ? h : nullptr;
   }
-  static constexpr int kMaxWorkers = 8;
-  int workers() const { return n_workers_; }
-  bool try_claim() { return busy_.try_lock(); }
-  void release() { busy_.unlock(); }
+  static void shutdown() {  // tgx_shutdown: no state is being fed any more
+    CopyPool *h = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(instance_mu());
+      h = fast_instance().exchange(nullptr, std::memory_order_acq_rel);
+    }
+    if (!h) return;
+    h->stop_.store(true, std::memory_order_seq_cst);
+    for (int w = 0; w < h->n_workers_; w++) {
+      std::lock_guard<std::mutex> lock(h->w_[w].mu);
+      h->w_[w].cv.notify_all();
+    }
+    for (auto &t : h->threads_) t.join();
+    delete h;
+  }
+  // the idle workers, now this caller's until release(): ids[0 .. return value)
+  int claim(int *ids) {
+    int n = 0;
+    for (int w = 0; w < n_workers_; w++)
+      if (!w_[w].busy.exchange(true, std::memory_order_acquire)) ids[n++] = w;
+    return n;
+  }
   void post(int w, const CopyJob *jobs, size_t n) {  // (claimed)
     Worker &k = w_[w];
     k.jobs = jobs;
@@ -2491,40 +2517,51 @@ class CopyHelper {
       k.cv.notify_one();
     }
   }
-  void wait(int w) {
+  void wait_and_release(int w) {
     Worker &k = w_[w];
     while (k.done.load(std::memory_order_acquire) != k.ticket) pause_or_nop();
+    k.busy.store(false, std::memory_order_release);
   }
+  void release(int w) { w_[w].busy.store(false, std::memory_order_release); }
 
  private:
   struct Worker {
     std::mutex mu;
     std::condition_variable cv;
     std::atomic<uint64_t> posted{0}, done{0};
-    std::atomic<bool> sleeping{false};
+    std::atomic<bool> sleeping{false}, busy{false};
     const CopyJob *jobs = nullptr;
     size_t n = 0;
     uint64_t ticket = 0;
   };
+  static std::mutex &instance_mu() {
+    static std::mutex m;
+    return m;
+  }
+  static std::atomic<CopyPool *> &fast_instance() {
+    static std::atomic<CopyPool *> h{nullptr};
+    return h;
+  }
   static void pause_or_nop() {
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
   }
-  explicit CopyHelper(int k) : n_workers_(k) {
-    for (int w = 0; w < k; w++) std::thread([this, w] { run(w_[w]); }).detach();
+  explicit CopyPool(int k) : n_workers_(k) {
+    for (int w = 0; w < k; w++) threads_.emplace_back([this, w] { run(w_[w]); });
   }
   void run(Worker &k) {
     uint64_t seen = 0;
     for (;;) {
-      // spin for about 200 us, then sleep until the next post
+      // spin for about 200 us, then sleep until the next post (or the end)
       int spins = 0;
       while (k.posted.load(std::memory_order_acquire) == seen) {
+        if (stop_.load(std::memory_order_relaxed)) return;
         pause_or_nop();
         if (++spins > 20000) {
           std::unique_lock<std::mutex> lock(k.mu);
           k.sleeping.store(true, std::memory_order_seq_cst);
-          k.cv.wait(lock, [&] { return k.posted.load(std::memory_order_seq_cst) != seen; });
+          k.cv.wait(lock, [&] { return k.posted.load(std::memory_order_seq_cst) != seen || stop_.load(std::memory_order_seq_cst); });
           k.sleeping.store(false, std::memory_order_seq_cst);
           spins = 0;
         }
@@ -2534,11 +2571,13 @@ class CopyHelper {
       k.done.store(seen, std::memory_order_release);
     }
   }
-  std::mutex busy_;
+  std::atomic<bool> stop_{false};
   Worker w_[kMaxWorkers];
+  std::vector<std::thread> threads_;
   const int n_workers_;
 };
 }  // namespace
+static void copy_pool_shutdown() { CopyPool::shutdown(); }
 
 // a copy that does not pull the destination into the cache first (the arena is written once and read by the DMA
 // engine): glibc's memcpy takes its streaming path only for copies of several MiB
@@ -2642,13 +2681,88 @@ static tgx_status coalesce_arena_ready(tgx_state *st, tgx_error *err) {
   return TGX_OK;
 }
 
+// What a Utf8View / dictionary window needs beyond its fixed-width part, found before anything is noted:
+//   views:        the stretches of the variadic buffers the window's long views point into (a Parquet page's buffer is
+//                 shared by the batches cut from it: only what THIS window references is copied) -- one walk over the
+//                 window's views, NULL rows skipped (their views may hold anything);
+//   dictionaries: whether the window brings a dictionary the column has not noted yet (batches of one file share
+//                 theirs: it is taken once per flush).
+struct WindowPrep {
+  bool ok = true;  // false: more than kGatherViewBufs buffers referenced -- the batch takes the immediate path
+  int32_t vb_count = 0;
+  int32_t vb_index[kGatherViewBufs];
+  int64_t vb_min[kGatherViewBufs], vb_end[kGatherViewBufs];
+  bool new_dict = false;
+  int64_t dict_first = 0, dict_end = 0;  // value bytes of the new dictionary's window
+};
+static tgx_status coalesce_prepare_window(const tgx_column &c, int64_t nrows, const CoalesceColumn &cc, int col,
+                                          WindowPrep *w, tgx_error *err) {
+  if (c.type == TGX_UTF8_VIEW) {
+    const int32_t *v = (const int32_t *)c.values + (size_t)c.offset * 4;
+    for (int64_t i = 0; i < nrows; i++, v += 4) {
+      const int32_t len = v[0];
+      if (len <= 12) continue;
+      if (c.validity && !((c.validity[(c.offset + i) >> 3] >> ((c.offset + i) & 7)) & 1)) continue;
+      const int32_t b = v[2];
+      const int64_t off = v[3], end = off + len;
+      if (b < 0 || b >= c.n_variadic || off < 0 || end > c.variadic_sizes[b])
+        return fail(err, TGX_INVALID_ARGUMENT, "column %d: a view of row %lld points outside its data buffers", col, (long long)i);
+      int k = 0;
+      while (k < w->vb_count && w->vb_index[k] != b) k++;
+      if (k == w->vb_count) {
+        if (k == kGatherViewBufs) {
+          w->ok = false;
+          return TGX_OK;
+        }
+        w->vb_index[k] = b;
+        w->vb_min[k] = off;
+        w->vb_end[k] = end;
+        w->vb_count++;
+      } else {
+        w->vb_min[k] = std::min(w->vb_min[k], off);
+        w->vb_end[k] = std::max(w->vb_end[k], end);
+      }
+    }
+  } else if (c.type == TGX_DICT32_UTF8) {
+    const tgx_column &d = *c.dictionary;
+    const CoalesceDict *cd = cc.dict.get();
+    w->new_dict = !cd || cd->segs.empty() || cd->last_offsets != d.offsets || cd->last_data != d.data ||
+                  cd->last_validity != d.validity || cd->last_offset != d.offset || cd->last_length != d.length ||
+                  cd->type != d.type;
+    if (w->new_dict && d.length > 0) {
+      const size_t ow = d.type == TGX_UTF8 ? 4 : 8;
+      const uint8_t *o0 = (const uint8_t *)d.offsets + (size_t)d.offset * ow;
+      w->dict_first = ow == 4 ? (int64_t)((const int32_t *)o0)[0] : ((const int64_t *)o0)[0];
+      w->dict_end = ow == 4 ? (int64_t)((const int32_t *)o0)[d.length] : ((const int64_t *)o0)[d.length];
+      if (w->dict_end < w->dict_first) return fail(err, TGX_INVALID_ARGUMENT, "column %d: dictionary offsets decrease", col);
+    }
+    if (cd && !cd->segs.empty() && cd->type != d.type) w->ok = false;  // (Utf8 and LargeUtf8 dictionaries in one flush)
+  }
+  return TGX_OK;
+}
+
 // bytes one batch's HOST windows take in the arena (each buffer padded to 64 bytes)
-static size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int64_t nrows) {
+static size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int64_t nrows,
+                                  const std::vector<WindowPrep> &prep) {
   size_t total = 0;
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!plan->used[i] || columns[i].mem != TGX_MEM_HOST) continue;
     const tgx_column &c = columns[i];
     if (c.validity) total += (size_t)(((c.offset & 7) + nrows + 7) >> 3) + 64;
+    if (c.type == TGX_UTF8_VIEW) {
+      total += (size_t)nrows * 16 + 64;
+      for (int k = 0; k < prep[i].vb_count; k++) total += (size_t)(prep[i].vb_end[k] - prep[i].vb_min[k]) + 64;
+      continue;
+    }
+    if (c.type == TGX_DICT32_UTF8) {
+      total += (size_t)nrows * 4 + 64;
+      if (prep[i].new_dict) {
+        const tgx_column &d = *c.dictionary;
+        total += (size_t)(d.length + 1) * (d.type == TGX_UTF8 ? 4 : 8) + 64 + (size_t)(prep[i].dict_end - prep[i].dict_first) + 64;
+        if (d.validity) total += (size_t)(((d.offset & 7) + d.length + 7) >> 3) + 64;
+      }
+      continue;
+    }
     if (is_string(c.type)) {
       const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
       const int64_t first = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[c.offset] : ((const int64_t *)c.offsets)[c.offset];
@@ -2671,28 +2785,52 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
     for (auto &cc : co.cols) cc.segs.reserve(kCoalesceFlushBatches);
   }
   const bool any_host = traits.any_host;
-  if (any_host) {
-    const size_t need = coalesce_host_bytes(plan, columns, nrows);
-    if (need > kCoalesceArenaMax) return TGX_OK;  // (64 Ki rows of very long strings): the immediate path
-    if (co.arena_used > 0 && co.arena_used + need > co.arena_cap[co.arena_cur]) {
-      // the arena is full: flush, and ask for a bigger one next time (fewer, larger flushes)
-      co.arena_want = std::min(kCoalesceArenaMax, std::max(co.arena_want * 2, need));
-      TGX_TRY(coalesce_flush(st, err));
+  // (a flush in here empties the pending lists -- the dictionaries' too: what the windows bring is then looked at again)
+  std::vector<WindowPrep> prep(plan->n_columns_needed);
+  for (int attempt = 0;; attempt++) {
+    const uint64_t flushes_before = co.flushes;
+    for (int i = 0; i < plan->n_columns_needed; i++) {
+      prep[i] = WindowPrep();
+      if (!plan->used[i] || (columns[i].type != TGX_UTF8_VIEW && columns[i].type != TGX_DICT32_UTF8)) continue;
+      TGX_TRY(coalesce_prepare_window(columns[i], nrows, co.cols[i], i, &prep[i], err));
+      if (!prep[i].ok) return TGX_OK;  // (not taken: the immediate path)
     }
-    if (need > co.arena_want) co.arena_want = std::min(kCoalesceArenaMax, need + need / 2);
-    if (co.arena_used == 0) TGX_TRY(coalesce_arena_ready(st, err));  // this arena turn's first HOST window
-    if (co.arena_used + need > co.arena_cap[co.arena_cur]) return TGX_OK;  // (cannot happen after the above)
-  }
-  // a string column whose coalesced int32 offsets would pass 2^31: flush first
-  for (int i = 0; traits.any_utf8 && i < plan->n_columns_needed; i++) {
-    if (!plan->used[i] || columns[i].type != TGX_UTF8) continue;
-    const tgx_column &c = columns[i];
-    const int64_t bytes = (int64_t)((const int32_t *)c.offsets)[c.offset + nrows] - (int64_t)((const int32_t *)c.offsets)[c.offset];
-    if (co.cols[i].data_bytes + bytes > 0x7FFFFF00LL) {
-      TGX_TRY(coalesce_flush(st, err));
-      if (any_host) TGX_TRY(coalesce_arena_ready(st, err));  // (strings are HOST windows: the arena has just turned)
-      break;
+    if (any_host) {
+      const size_t need = coalesce_host_bytes(plan, columns, nrows, prep);
+      if (need > kCoalesceArenaMax) return TGX_OK;  // (64 Ki rows of very long strings): the immediate path
+      if (co.arena_used > 0 && co.arena_used + need > co.arena_cap[co.arena_cur]) {
+        // the arena is full: flush, and ask for a bigger one next time (fewer, larger flushes)
+        co.arena_want = std::min(kCoalesceArenaMax, std::max(co.arena_want * 2, need));
+        TGX_TRY(coalesce_flush(st, err));
+      }
+      if (need > co.arena_want) co.arena_want = std::min(kCoalesceArenaMax, need + need / 2);
+      if (co.arena_used == 0) TGX_TRY(coalesce_arena_ready(st, err));  // this arena turn's first HOST window
+      if (co.arena_used + need > co.arena_cap[co.arena_cur]) return TGX_OK;  // (cannot happen after the above)
     }
+    // a string column whose coalesced int32 offsets would pass 2^31: flush first
+    for (int i = 0; traits.any_utf8 && i < plan->n_columns_needed; i++) {
+      if (!plan->used[i] || columns[i].type != TGX_UTF8) continue;
+      const tgx_column &c = columns[i];
+      const int64_t bytes = (int64_t)((const int32_t *)c.offsets)[c.offset + nrows] - (int64_t)((const int32_t *)c.offsets)[c.offset];
+      if (co.cols[i].data_bytes + bytes > 0x7FFFFF00LL) {
+        TGX_TRY(coalesce_flush(st, err));
+        if (any_host) TGX_TRY(coalesce_arena_ready(st, err));  // (strings are HOST windows: the arena has just turned)
+        break;
+      }
+    }
+    // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
+    for (int i = 0; i < plan->n_columns_needed; i++) {
+      if (!plan->used[i] || columns[i].type != TGX_UTF8_VIEW) continue;
+      int64_t bytes = 0;
+      for (int k = 0; k < prep[i].vb_count; k++) bytes += prep[i].vb_end[k] - prep[i].vb_min[k] + 16;
+      if (co.cols[i].data_bytes + bytes > 0x7FFFFF00LL) {
+        TGX_TRY(coalesce_flush(st, err));
+        if (any_host) TGX_TRY(coalesce_arena_ready(st, err));
+        break;
+      }
+    }
+    if (co.flushes == flushes_before) break;  // nothing was flushed: `prep` describes what is pending
+    if (attempt >= 2) return TGX_OK;          // (cannot happen: after a flush nothing is pending)
   }
   // everything that can refuse the batch is checked BEFORE the first column notes its window: a batch is noted for all
   // columns or for none (a column with one segment more than its neighbours would make the next flush's gather write
@@ -2708,13 +2846,14 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
   }
   struct Rollback {  // (a host allocation that throws while the windows are noted)
     Coalescer &co;
-    std::vector<size_t> segs;
+    std::vector<size_t> segs, dict_segs;
     std::vector<int64_t> data_bytes;
     size_t arena_used;
     bool armed = true;
     explicit Rollback(Coalescer &c) : co(c), arena_used(c.arena_used) {
       for (auto &cc : co.cols) {
         segs.push_back(cc.segs.size());
+        dict_segs.push_back(cc.dict ? cc.dict->segs.size() : 0);
         data_bytes.push_back(cc.data_bytes);
       }
     }
@@ -2724,10 +2863,33 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
         co.cols[i].segs.resize(segs[i]);
         co.cols[i].data_bytes = data_bytes[i];
         co.cols[i].range_known = false;  // (a MIN / MAX of rows that are not pending after all is only too wide)
+        if (co.cols[i].dict && co.cols[i].dict->segs.size() > dict_segs[i]) {
+          // (entries / data_bytes of the dropped dictionary stay counted: the buffers are only sized too generously;
+          //  forgetting "the last dictionary" makes the next window bring its own again)
+          co.cols[i].dict->segs.resize(dict_segs[i]);
+          co.cols[i].dict->last_length = -1;
+        }
       }
       co.arena_used = arena_used;
     }
   } rollback(co);
+  // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!plan->used[i] || columns[i].type != TGX_UTF8_VIEW) continue;
+    int64_t bytes = 0;
+    for (int k = 0; k < prep[i].vb_count; k++) bytes += prep[i].vb_end[k] - prep[i].vb_min[k] + 16;
+    if (co.cols[i].data_bytes + bytes > 0x7FFFFF00LL) {
+      TGX_TRY(coalesce_flush(st, err));
+      if (any_host) TGX_TRY(coalesce_arena_ready(st, err));
+      // (the flush has emptied every column's dictionary list: what the windows bring is new again)
+      for (int j = 0; j < plan->n_columns_needed; j++)
+        if (plan->used[j] && columns[j].type == TGX_DICT32_UTF8) {
+          prep[j] = WindowPrep();
+          TGX_TRY(coalesce_prepare_window(columns[j], nrows, co.cols[j], j, &prep[j], err));
+        }
+      break;
+    }
+  }
   char *ah = any_host ? (char *)co.arena_host[co.arena_cur] : nullptr;
   const char *ad = any_host ? (const char *)co.arena_dev[co.arena_cur].p : nullptr;
   std::vector<CopyJob> &jobs = co.copy_jobs;
@@ -2753,7 +2915,52 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
       sg.validity = host ? (const uint8_t *)to_arena(v0, (size_t)((sg.bit0 + nrows + 7) >> 3)) : v0;
       cc.any_validity = true;
     }
-    if (is_string(c.type)) {
+    if (c.type == TGX_UTF8_VIEW) {
+      // the views as they are, and the stretches of the data buffers they point into (host is true: update_validate)
+      sg.values = to_arena((const uint8_t *)c.values + (size_t)c.offset * 16, (size_t)nrows * 16);
+      sg.vb_count = prep[i].vb_count;
+      for (int k = 0; k < prep[i].vb_count; k++) {
+        sg.vb_index[k] = prep[i].vb_index[k];
+        sg.vb_min[k] = prep[i].vb_min[k];
+        sg.vb_len[k] = prep[i].vb_end[k] - prep[i].vb_min[k];
+        sg.vb_src[k] = (const uint8_t *)to_arena(c.variadic[prep[i].vb_index[k]] + prep[i].vb_min[k], (size_t)sg.vb_len[k]);
+        sg.data_len += (sg.vb_len[k] + 15) & ~(int64_t)15;  // (every stretch lands 16-byte aligned)
+      }
+      cc.data_bytes += sg.data_len;
+    } else if (c.type == TGX_DICT32_UTF8) {
+      if (!cc.dict) cc.dict.reset(new CoalesceDict());
+      CoalesceDict &cd = *cc.dict;
+      const tgx_column &d = *c.dictionary;
+      if (prep[i].new_dict) {
+        CoalesceSegment ds;
+        memset(&ds, 0, sizeof(ds));
+        ds.length = d.length;
+        cd.type = d.type;
+        if (d.validity && d.length > 0) {
+          ds.bit0 = d.offset & 7;
+          ds.validity = (const uint8_t *)to_arena(d.validity + (d.offset >> 3), (size_t)((ds.bit0 + d.length + 7) >> 3));
+          cd.any_validity = true;
+        }
+        if (d.length > 0) {
+          const size_t ow = d.type == TGX_UTF8 ? 4 : 8;
+          ds.data_first = prep[i].dict_first;
+          ds.data_len = prep[i].dict_end - prep[i].dict_first;
+          ds.values = to_arena((const uint8_t *)d.offsets + (size_t)d.offset * ow, (size_t)(d.length + 1) * ow);
+          ds.data = (ds.data_len > 0 && d.data) ? (const uint8_t *)to_arena(d.data + ds.data_first, (size_t)ds.data_len) : nullptr;
+        }
+        cd.last_base = cd.entries;
+        cd.entries += d.length;
+        cd.data_bytes += ds.data_len;
+        cd.last_offsets = d.offsets;
+        cd.last_data = d.data;
+        cd.last_validity = d.validity;
+        cd.last_offset = d.offset;
+        cd.last_length = d.length;
+        cd.segs.push_back(ds);
+      }
+      sg.values = to_arena((const uint8_t *)c.values + (size_t)c.offset * 4, (size_t)nrows * 4);
+      sg.index_shift = (int32_t)cd.last_base;
+    } else if (is_string(c.type)) {
       const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
       const uint8_t *o0 = (const uint8_t *)c.offsets + (size_t)c.offset * ow;
       const int64_t first = ow == 4 ? (int64_t)((const int32_t *)o0)[0] : ((const int64_t *)o0)[0];
@@ -2780,17 +2987,18 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
   if (!jobs.empty()) {
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.bytes;
-    CopyHelper *helper = total >= (64u << 10) ? CopyHelper::get() : nullptr;
-    if (helper && !helper->try_claim()) helper = nullptr;  // (serving another thread's state)
-    if (!helper) {
+    CopyPool *pool = total >= (64u << 10) ? CopyPool::get() : nullptr;
+    int ids[CopyPool::kMaxWorkers];
+    const int helpers = pool ? pool->claim(ids) : 0;  // (whoever is idle right now: other states may hold the rest)
+    if (helpers == 0) {
       for (const CopyJob &j : jobs) stream_copy(j.dst, j.src, j.bytes);
     } else {
-      // equal shares of the bytes (a job that straddles a boundary is cut at a multiple of 64 bytes): the first to
-      // the caller, one to every worker
-      const int shares = helper->workers() + 1;
+      // equal shares of the bytes (a job that straddles a boundary is cut at a multiple of 64 bytes): the first for
+      // the caller, one for every claimed worker
+      const int shares = helpers + 1;
       std::vector<CopyJob> &cut = co.copy_tail;  // all shares one behind the other; first[s] = where share s begins
       cut.clear();
-      size_t first[CopyHelper::kMaxWorkers + 2];
+      size_t first[CopyPool::kMaxWorkers + 2];
       const size_t per = (total / (size_t)shares + 63) & ~(size_t)63;
       size_t room = per;
       int share = 0;
@@ -2811,11 +3019,9 @@ static tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx
       }
       while (share + 1 < shares) first[++share] = cut.size();
       first[shares] = cut.size();
-      for (int w = 0; w < helper->workers(); w++)
-        helper->post(w, cut.data() + first[w + 1], first[w + 2] - first[w + 1]);
+      for (int w = 0; w < helpers; w++) pool->post(ids[w], cut.data() + first[w + 1], first[w + 2] - first[w + 1]);
       for (size_t q = first[0]; q < first[1]; q++) stream_copy(cut[q].dst, cut[q].src, cut[q].bytes);
-      for (int w = 0; w < helper->workers(); w++) helper->wait(w);
-      helper->release();
+      for (int w = 0; w < helpers; w++) pool->wait_and_release(ids[w]);
     }
   }
   rollback.armed = false;
@@ -2887,7 +3093,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   // the segment table: pinned, one turn per arena
   size_t n_segs = 0;
   for (int i = 0; i < plan->n_columns_needed; i++)
-    if (plan->used[i]) n_segs += co.cols[i].segs.size();
+    if (plan->used[i]) n_segs += co.cols[i].segs.size() + (co.cols[i].dict ? co.cols[i].dict->segs.size() : 0);
   if (!co.arena_event[ar]) HIP_TRY(hipEventCreateWithFlags(&co.arena_event[ar], hipEventDisableTiming));
   if (co.arena_busy[ar]) {  // (DEVICE-only batches never went through coalesce_arena_ready)
     HIP_TRY(hipEventSynchronize(co.arena_event[ar]));
@@ -2910,8 +3116,8 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     memset(&v, 0, sizeof(v));
     if (!plan->used[i]) continue;
     CoalesceColumn &cc = co.cols[i];
-    const bool str = is_string(cc.type);
-    const size_t ew = str ? (cc.type == TGX_UTF8 ? 4 : 8) : (is_numeric32(cc.type) ? 4 : 8);
+    const bool str = is_string(cc.type), vw = cc.type == TGX_UTF8_VIEW, dct = cc.type == TGX_DICT32_UTF8;
+    const size_t ew = str ? (cc.type == TGX_UTF8 ? 4 : 8) : vw ? 16 : (dct || is_numeric32(cc.type)) ? 4 : 8;
     bool has_values = false;
     for (const CoalesceSegment &sg : cc.segs) has_values |= sg.values != nullptr;
     if (has_values) HIP_TRY(cc.values[set].reserve((size_t)(rows + 1) * ew + 64));
@@ -2920,7 +3126,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
       HIP_TRY(cc.validity[set].reserve(vb));
       HIP_TRY(hipMemsetAsync(cc.validity[set].p, 0, vb, st->stream));
     }
-    if (str) HIP_TRY(cc.data[set].reserve((size_t)cc.data_bytes + 64));
+    if (str || vw) HIP_TRY(cc.data[set].reserve((size_t)cc.data_bytes + 64));
     int64_t row = 0, data_at = 0;
     for (const CoalesceSegment &sg : cc.segs) {
       GatherSeg &d = gs[g++];
@@ -2930,7 +3136,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
       d.src_data = sg.data;
       d.dst_values = has_values ? cc.values[set].p : nullptr;
       d.dst_validity = cc.any_validity ? cc.validity[set].as<uint8_t>() : nullptr;
-      d.dst_data = str ? cc.data[set].as<uint8_t>() : nullptr;
+      d.dst_data = (str || vw) ? cc.data[set].as<uint8_t>() : nullptr;
       d.src_bit0 = sg.bit0;
       d.length = sg.length;
       d.dst_row = row;
@@ -2938,7 +3144,20 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
       d.data_base = data_at;
       d.data_len = sg.data ? sg.data_len : 0;
       d.elem_bytes = (int32_t)ew;
-      d.kind = str ? (cc.type == TGX_UTF8 ? 1 : 2) : 0;
+      d.kind = str ? (cc.type == TGX_UTF8 ? 1 : 2) : vw ? 3 : dct ? 4 : 0;
+      if (vw) {  // the window's stretches one behind the other, each 16-byte aligned
+        d.vb_count = sg.vb_count;
+        int64_t at = data_at;
+        for (int k = 0; k < sg.vb_count; k++) {
+          d.vb_index[k] = sg.vb_index[k];
+          d.vb_min[k] = sg.vb_min[k];
+          d.vb_len[k] = sg.vb_len[k];
+          d.vb_src[k] = sg.vb_src[k];
+          d.vb_base[k] = at;
+          at += (sg.vb_len[k] + 15) & ~(int64_t)15;
+        }
+      }
+      d.index_shift = sg.index_shift;
       row += sg.length;
       data_at += sg.data_len;
     }
@@ -2951,8 +3170,56 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     if (str) {
       v.offsets = cc.values[set].p;
       v.data = cc.data[set].as<uint8_t>();
+    } else if (vw) {  // a Utf8View column with ONE data buffer
+      v.values = cc.values[set].p;
+      cc.view_buf[set] = cc.data[set].as<uint8_t>();
+      v.variadic = &cc.view_buf[set];
+      v.n_variadic = 1;
     } else {
       v.values = has_values ? cc.values[set].p : nullptr;
+    }
+    if (dct) {  // the windows' dictionaries, gathered like a Utf8 column of their own
+      CoalesceDict &cd = *cc.dict;
+      const size_t dw = cd.type == TGX_UTF8 ? 4 : 8;
+      HIP_TRY(cd.values[set].reserve((size_t)(cd.entries + 1) * dw + 64));
+      HIP_TRY(hipMemsetAsync(cd.values[set].p, 0, (size_t)(cd.entries + 1) * dw, st->stream));  // (an empty dictionary: offset 0)
+      if (cd.any_validity) {
+        const size_t vb = ((size_t)cd.entries + 31) / 32 * 4 + 64;
+        HIP_TRY(cd.validity[set].reserve(vb));
+        HIP_TRY(hipMemsetAsync(cd.validity[set].p, 0, vb, st->stream));
+      }
+      HIP_TRY(cd.data[set].reserve((size_t)cd.data_bytes + 64));
+      int64_t drow = 0, dat = 0;
+      for (const CoalesceSegment &sg : cd.segs) {
+        GatherSeg &d = gs[g++];
+        memset(&d, 0, sizeof(d));
+        d.src_values = sg.values;
+        d.src_validity = sg.validity;
+        d.src_data = sg.data;
+        d.dst_values = cd.values[set].p;
+        d.dst_validity = cd.any_validity ? cd.validity[set].as<uint8_t>() : nullptr;
+        d.dst_data = cd.data[set].as<uint8_t>();
+        d.src_bit0 = sg.bit0;
+        d.length = sg.length;
+        d.dst_row = drow;
+        d.data_first = sg.data_first;
+        d.data_base = dat;
+        d.data_len = sg.data ? sg.data_len : 0;
+        d.elem_bytes = (int32_t)dw;
+        d.kind = cd.type == TGX_UTF8 ? 1 : 2;
+        drow += sg.length;
+        dat += sg.data_len;
+      }
+      tgx_column &dv = cd.view[set];
+      memset(&dv, 0, sizeof(dv));
+      dv.type = cd.type;
+      dv.mem = TGX_MEM_DEVICE;
+      dv.length = cd.entries;
+      dv.null_count = -1;
+      dv.validity = cd.any_validity ? cd.validity[set].as<uint8_t>() : nullptr;
+      dv.offsets = cd.values[set].p;
+      dv.data = cd.data[set].as<uint8_t>();
+      v.dictionary = &dv;
     }
   }
   if (co.arena_used)
@@ -2991,6 +3258,12 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     cc.range_known = true;
     cc.range_lo = INT64_MAX;
     cc.range_hi = INT64_MIN;
+    if (cc.dict) {
+      cc.dict->segs.clear();
+      cc.dict->any_validity = false;
+      cc.dict->data_bytes = cc.dict->entries = 0;
+      cc.dict->last_length = -1;
+    }
   }
   const int64_t batches_of_flush = (int64_t)co.batches;
   co.rows = 0;
@@ -3040,6 +3313,12 @@ static void coalesce_drop(tgx_state *st) {  // reset / destroy: pending batches 
     cc.range_known = true;
     cc.range_lo = INT64_MAX;
     cc.range_hi = INT64_MIN;
+    if (cc.dict) {
+      cc.dict->segs.clear();
+      cc.dict->any_validity = false;
+      cc.dict->data_bytes = cc.dict->entries = 0;
+      cc.dict->last_length = -1;
+    }
   }
   co.rows = 0;
   co.batches = 0;

@@ -397,3 +397,118 @@ def test_empty_batches_do_not_flush():
     assert st.profile_get("coalesce")["launches"] == 0  # eight noted batches, no flush yet
     res = st.finalize()
     assert (res[0].total, res[0].sum_i, res[1].distinct) == (n, int(v.sum()), len(np.unique(v)))
+
+
+# ---- Utf8View and Dictionary<Int32, Utf8> batches (what DataFusion reads Parquet strings as), HOST buffers -----------
+def _string_specs():
+    return [spec(T.REGEX_MATCH, 0, pattern=r"^[^@]+@[^@]+\.[^@]+$", flags=T.FLAG_NULL_IS_VALID),
+            spec(T.REGEX_MATCH, 0, pattern="@"), spec(T.LENGTH, 0, length_min=1, length_max=24),
+            spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY), spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 1)]
+
+
+def _string_values(rng, n):
+    vals = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.05:
+            vals.append(None)
+        elif r < 0.55:
+            vals.append("user%d@example%d.com" % (i % 5000, i % 7))  # long values: 13+ bytes, in the data buffers
+        elif r < 0.75:
+            vals.append("s%d" % (i % 300))                            # short values: inline in the view
+        elif r < 0.8:
+            vals.append("")
+        else:
+            vals.append("not an e-mail é中 %d" % (i % 97))
+    return vals
+
+
+@pytest.mark.parametrize("flush_rows", [None, "30000"])
+def test_host_utf8view_batches(flush_rows, monkeypatch):
+    """views copied as they are, the stretches of the data buffers a window's long views point into laid one behind the
+    other, views re-pointed on the device (kernels/gather.hip, kind 3): results of the same values as one batch"""
+    from test_gpu_utf8view import encode_views
+
+    rng = np.random.default_rng(21)
+    n = 120_000 + 11
+    vals = _string_values(rng, n)
+    nums = rng.integers(-1000, 1000, size=n, dtype=np.int64)
+    views, bufs, validity = encode_views(vals, rng, n_buffers=3)
+    v = pad_validity(validity) if validity is not None else None
+    T.init()
+    plan = T.Plan(_string_specs())
+
+    def batch(lo, hi):
+        return [T.Column.utf8_view(views, bufs, validity=v, length=hi - lo, offset=lo), numeric_column(nums, None, False, offset=lo, length=hi - lo)]
+
+    monkeypatch.setenv("TGX_COALESCE", "0")
+    whole = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE")
+    whole.update(batch(0, n))
+    want = whole.finalize()
+    if flush_rows:
+        monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", flush_rows)
+    st = T.State(plan)
+    if flush_rows:
+        monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS")
+    cuts = ragged_cuts(n, rng, sizes=(8192, 1000, 3, 8192, 1, 5000, 8192))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        st.update(batch(a, b))
+    assert st.profile_get("coalesce")["bytes"] == len(cuts) - 1  # ("bytes": batches that were only noted -- all of them)
+    got = st.finalize()
+    assert st.profile_get("coalesce")["launches"] >= (3 if flush_rows else 1)
+    compare(got, want)
+    assert got[3].distinct == len({x for x in vals if x is not None})
+    assert (got[4].total, got[4].non_null) == (n, sum(x is not None for x in vals))
+
+
+def test_host_dictionary_batches(monkeypatch):
+    """index windows shifted to where their dictionary starts in the coalesced one; a dictionary shared by the batches
+    of a file is taken once per flush, a different one (the next file) appended behind it -- unused and repeated entries
+    allowed, NULL dictionary values are NULL rows"""
+    import pyarrow as pa
+
+    rng = np.random.default_rng(22)
+    n = 90_000
+    words_a = ["user%d@example%d.com" % (i, i % 7) for i in range(4000)] + [None, "", "plain"]
+    words_b = ["other%d@x.org" % i for i in range(1500)] + ["plain", "é中"]
+    nums = rng.integers(0, 50, size=n, dtype=np.int64)
+    T.init()
+    plan = T.Plan(_string_specs())
+
+    def dict_column(words, idx, mask):
+        d = pa.array(words, type=pa.string())
+        arr = pa.DictionaryArray.from_arrays(pa.array(idx, type=pa.int32(), mask=~mask), d)
+        return arr
+
+    half = n // 2
+    idx_a = rng.integers(0, len(words_a), size=half)
+    idx_b = rng.integers(0, len(words_b), size=n - half)
+    mask = rng.random(n) >= 0.04
+    arr_a, arr_b = dict_column(words_a, idx_a, mask[:half]), dict_column(words_b, idx_b, mask[half:])
+
+    def batches(step):
+        out = []
+        for arr, base in ((arr_a, 0), (arr_b, half)):
+            for lo in range(0, len(arr), step):
+                hi = min(len(arr), lo + step)
+                out.append([T.Column.from_arrow(arr.slice(lo, hi - lo)), numeric_column(nums, None, False, offset=base + lo, length=hi - lo)])
+        return out
+
+    monkeypatch.setenv("TGX_COALESCE", "0")
+    whole = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE")
+    for cols in batches(1 << 20):
+        whole.update(cols)
+    want = whole.finalize()
+    monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", "40000")
+    st = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS")
+    for cols in batches(8192):
+        st.update(cols)
+    got = st.finalize()
+    assert st.profile_get("coalesce")["launches"] >= 2
+    compare(got, want)
+    truth = [words_a[i] if m else None for i, m in zip(idx_a, mask[:half])] + [words_b[i] if m else None for i, m in zip(idx_b, mask[half:])]
+    assert got[3].distinct == len({x for x in truth if x is not None})
+    assert (got[4].total, got[4].non_null) == (n, sum(x is not None for x in truth))
