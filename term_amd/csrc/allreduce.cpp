@@ -802,10 +802,17 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     //  behind a collective)
     if (ss == TGX_OK && comm->ops.device_buffers && st->device_ready && (!parts.empty() || !by_records.empty()))
       ss = deadline_sync(comm, s, "the exchange of the key sets", &e);
-    if (ss == TGX_OK) ss = tgx_state_serialize(plan, st, nullptr, 0, &len, &e);
+    // (packing reads every accumulator back: once -- into a buffer of the capacity the ranks last agreed on -- and a
+    //  second time only if the state has outgrown that)
     if (ss == TGX_OK) {
-      blob.resize(len);
+      blob.resize(std::max<size_t>(comm->blob_plan == plan ? comm->blob_cap : 0, 4096));
       ss = tgx_state_serialize(plan, st, blob.data(), blob.size(), &len, &e);
+      if (ss == TGX_INVALID_ARGUMENT && len > blob.size()) {  // ("buffer too small": len says how much it takes)
+        blob.resize(len);
+        memset(&e, 0, sizeof(e));
+        ss = tgx_state_serialize(plan, st, blob.data(), blob.size(), &len, &e);
+      }
+      if (ss == TGX_OK) blob.resize(len);
     }
     note(ss, e);
     if (local != TGX_OK) len = 0;
