@@ -7,6 +7,12 @@
 // a bucket fits a small workgroup's LDS, where the rank inside the bucket is counted; a key EQUAL to a splitter goes
 // to a bucket of its own ("equality bucket": heavy ties never need sorting, every key there has the bucket's first
 // position as its rank).  No comparison sort, no radix passes over all 64 bits.
+//
+// A pass needs to know where every bucket starts before it moves a key.  Counting the keys first (a read of all keys
+// per pass) is one way; the sample is the other: the share of the sample that falls into a bucket, plus 6.5 standard
+// deviations, is room enough but once in ~10^6 jobs, and a pass that finds a bucket full says so in the job's status
+// word -- the caller then runs the job again with counted buckets (SrJob::optimistic).  Only the last pass counts: its
+// buckets are the work items of the ranking kernels and lie one behind the other.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,7 +25,7 @@ constexpr int kSrPartPer = kSrTile / kSrPartThreads;
 constexpr int kSrMaxSplit = 255;     // splitters per part (an 8-step branch-free search in LDS)
 constexpr int kSrMaxNb = 2 * kSrMaxSplit + 1;
 constexpr int kSrXcds = 8;
-constexpr int kSrFirstParts = 64;    // the first pass cuts its input into this many stretches, eight per XCD
+constexpr int kSrFirstParts = 8;     // the first pass cuts its input into this many stretches, one per XCD
 // last pass, small buckets: 256 threads, 8 keys each
 constexpr int kSrFastThreads = 256;
 constexpr int kSrFastPer = 8;
@@ -33,8 +39,8 @@ constexpr int kSrSlowBinBits = 12;
 constexpr uint32_t kSrEqPiece = 8192;  // an equality bucket is handed out in pieces of this many keys
 constexpr uint32_t kSrEqTiny = 32;     // ... unless it holds at most this many: then one thread walks it
 
-struct SrTileRef {  // one tile of a partition pass: keys [begin, min(begin + kSrTile, end of the part))
-  uint32_t part, begin;
+struct SrTileRef {  // one tile of a partition pass: keys [begin, begin + len) of a piece of `part`, len <= kSrTile
+  uint32_t part, begin, len;
 };
 struct SrItem {  // one unit of the last pass: a bucket (or a piece of an equality bucket)
   uint32_t start, count;
@@ -57,9 +63,11 @@ struct RankSums {
   unsigned long long exact_hi[5];
 };
 
-// One partition pass (tiles -> count -> offsets -> scatter), by value in the kernel-argument segment.
+// One partition pass (tiles -> count or estimate -> offsets -> scatter), by value in the kernel-argument segment.
 // A pass cuts PARTS (pass 0: kSrFirstParts stretches of the input, all with the same splitters; later passes: the
-// buckets of the pass before, each with the splitters that lie between its bounds) into nb = 2 S + 1 buckets.
+// buckets of the pass before, each with the splitters that lie between its bounds) into nb = 2 S + 1 buckets.  A part
+// lies in PIECES: piece s of part p is [pbeg[s * pstride + p], pend[s * pstride + p]) -- one piece, but for the parts
+// of pass 1, which are what the stretches of pass 0 each wrote of a bucket.
 struct SrLevel {
   const uint64_t *keys_in;
   const void *pay_in;  // nullptr with a 4-byte payload: the payload is the key's index (iota)
@@ -72,15 +80,24 @@ struct SrLevel {
   uint32_t stride;       // splitter k of a part: fine[first + (k + 1) * stride - 1]
   uint32_t split_count;  // S
   uint32_t nb;           // 2 S + 1
-  uint32_t *part_start;  // [nparts + 1]
+  const uint32_t *pbeg, *pend;  // the pieces of the parts
+  uint32_t npieces, pstride;
   uint32_t nparts;
+  uint32_t *part_size;   // [nparts]: keys of the part (the tiles kernel adds the pieces up)
+  uint32_t *part_total;  // [nparts]: room the part's buckets take in the output (counted: the same)
+  uint32_t *out_base;    // [nparts + 1]: where the part's first bucket starts in the output
+  uint32_t *limit;       // [nparts][nb]: where the bucket's room ends
+  uint32_t *pbegin;      // pass 0: [nparts][nb]: where each stretch's range of a bucket starts (the next pass's pieces)
+  uint32_t out_cap;      // keys the output arrays hold
+  uint32_t *status;      // the job's status word: != 0 -- every kernel returns.  Bit 4 * pass: the buckets' room
+                         // together exceeds the output arrays; bit 4 * pass + 1: a bucket was full
   SrTileRef *tiles;      // [kSrXcds][tile_cap]: the tiles each XCD's workgroups take
   uint32_t tile_cap;
   uint32_t *tile_count;  // [kSrXcds]
   uint32_t *tot;         // [nparts][nb]: keys per bucket
   uint32_t *cursor;      // [nparts][nb]: where the bucket's next run goes
   uint32_t group;        // workgroups of an XCD that walk a stretch of its tile list side by side (0: all of them)
-  uint32_t *bstart;      // pass 0: [nb + 1], later: [nparts * nb + 1]: where the buckets start (the next pass's parts)
+  uint32_t *bstart;      // pass 0: [nb + 1], later: [nparts * nb + 1]: where the buckets start
 };
 
 struct SrFinal {
@@ -97,6 +114,7 @@ struct SrFinal {
   uint64_t ext_base;
   RankSums *partials;  // kSrSums: one per workgroup
   uint32_t cap;        // keys ranked in one go by the chunked kernel (<= kSrSlowCap)
+  const uint32_t *status;
 };
 
 // knobs (environment, read per call): tests shrink them so that small inputs take every path
@@ -107,6 +125,10 @@ struct SrTuning {
   uint32_t slow_cap;    // SrFinal::cap                         TGX_SORT_SLOWCAP  (4096)
   uint32_t max_split;   // splitters per pass                   TGX_SORT_SPLIT    (255)
   uint32_t wg_per_cu;   // workgroups per CU of a pass          TGX_SORT_WG       (3)
+  uint32_t first_parts; // stretches of pass 0                  TGX_SORT_PARTS    (8)
+  uint32_t optimistic;  // 0: every pass counts                 TGX_SORT_OPTIMISTIC (1)
+  uint32_t sigmas_x2;   // twice the standard deviations of room TGX_SORT_SIGMAS_X2 (13; tests shrink it to see a job fail)
+  uint32_t optimistic_min;  // callers ask for it from this many keys on  TGX_SORT_OPTIMISTIC_MIN (1 Mi)
 };
 SrTuning sr_tuning();
 
@@ -127,12 +149,19 @@ struct SrJob {
   uint64_t *rank_out = nullptr;
   uint64_t ext_base = 0;
   RankSums *partials = nullptr;  // kSrSums: sr_partials_count() entries
+  // bucket sizes taken from the sample in all passes but the last: k[i] / p[i] then hold cap[i] >= sr_roomy_elems(n)
+  // keys (the buckets lie apart), the input arrays are not among them, and *status (a device word, written by the job)
+  // != 0 once the job is through means: nothing of its output is valid, run it again with optimistic = false
+  bool optimistic = false;
+  uint64_t cap[2] = {0, 0};
+  uint32_t *status = nullptr;
 };
 struct SrPlaced {  // where the job's keys / payloads lay when the last pass read them (kSrRank32 is aligned to it)
   const uint64_t *keys;
   const void *pay;
 };
 size_t sr_workspace_bytes(uint64_t n);
+uint64_t sr_roomy_elems(uint64_t n);  // elements of k[i] / p[i] an optimistic job wants
 int sr_partials_count();
 hipError_t sr_run(const SrJob &job, void *workspace, size_t workspace_bytes, hipStream_t stream, SrPlaced *placed);
 

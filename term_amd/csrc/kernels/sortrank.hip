@@ -67,6 +67,22 @@ __device__ __forceinline__ uint32_t sr_claim(uint32_t *cursor, uint32_t b, bool 
   return pos;
 }
 
+// the same without the positions (the counting pass): the lanes left over after the groups send adds that return nothing
+__device__ __forceinline__ void sr_tally(uint32_t *hist, uint32_t b, bool valid) {
+  const uint32_t lane = sr_lane();
+  uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+  while (todo) {  // (wave-uniform)
+    const int leader = (int)__builtin_ctzll(todo);
+    const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+    const uint64_t grp = __builtin_amdgcn_ballot_w64(valid && b == lb) & todo;
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(grp);
+    if (cnt < 8) break;
+    if (lane == (uint32_t)leader) __hip_atomic_fetch_add(&hist[lb], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    todo &= ~grp;
+  }
+  if ((todo >> lane) & 1ull) __hip_atomic_fetch_add(&hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- parts and their splitters ------------------------------------------------------------------------------------
 struct SrPartInfo {
   bool eq;         // an equality bucket of an earlier pass: one value, nothing to split
@@ -235,30 +251,48 @@ __global__ void sr_pick_kernel(const uint64_t *sorted, uint64_t count, uint32_t 
 }
 
 // ---- a partition pass ---------------------------------------------------------------------------------------------
-// pass 0: the input as kSrFirstParts stretches of whole tiles
-__global__ void sr_first_parts_kernel(uint32_t *part_start, uint32_t nparts, uint32_t per_part, uint32_t n) {
+// pass 0: the input as stretches of whole tiles; and the stretches of the sample that were drawn from them (`ns` sample
+// keys, in the order of the positions they came from; a stretch's share of the sample starts with the first sample key
+// drawn at or behind its first position -- sharp to one sample key, the room of a bucket is generous by more)
+__global__ void sr_first_parts_kernel(uint32_t *part_start, uint32_t nparts, uint32_t per_part, uint32_t n,
+                                      uint32_t *sample_start, uint32_t ns) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > nparts) return;
   const uint64_t at = (uint64_t)p * per_part;
-  part_start[p] = (p == nparts || at > n) ? n : (uint32_t)at;
+  const uint32_t v = (p == nparts || at > n) ? n : (uint32_t)at;
+  part_start[p] = v;
+  if (sample_start) {
+    // sr_sample_kernel: n = ns * q + r, the first r sample keys come from q + 1 positions each, the others from q
+    const uint64_t q = ns ? n / ns : 0, r = ns ? n - q * ns : 0, edge = r * (q + 1);
+    uint64_t k = ns;
+    if (v < n && q) k = v < edge ? v / (q + 1) : r + (v - edge) / q;
+    sample_start[p] = k > ns ? ns : (uint32_t)k;
+  }
 }
 
 // the tiles of every part, listed per XCD: a part between two splitters belongs to ONE XCD (the runs that fill a
 // bucket's lines then meet in one L2); an equality part is only copied, its tiles go round all of them.  One wave per
-// part; the order of the lists does not matter.
+// piece of a part; the order of the lists does not matter.
 __global__ __launch_bounds__(256) void sr_tiles_kernel(SrLevel L) {
-  const uint32_t p = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-  if (p >= L.nparts) return;
-  const uint32_t b = L.part_start[p], e = L.part_start[p + 1];
+  if (*(volatile const uint32_t *)L.status) return;
+  const uint32_t w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (w >= L.nparts * L.npieces) return;
+  const uint32_t p = w % L.nparts, piece = w / L.nparts;
+  const uint32_t b = L.pbeg[(size_t)piece * L.pstride + p], e = L.pend[(size_t)piece * L.pstride + p];
   if (e <= b) return;
+  if (lane == 0) atomicAdd(&L.part_size[p], e - b);
   const uint32_t nt = (uint32_t)(((uint64_t)(e - b) + kSrTile - 1) / kSrTile);
   const SrPartInfo pi = sr_part_info(L, p);
+  auto ref = [&](uint32_t k) {
+    const uint32_t at = b + k * (uint32_t)kSrTile;
+    return SrTileRef{p, at, e - at > (uint32_t)kSrTile ? (uint32_t)kSrTile : e - at};
+  };
   if (!pi.eq) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&L.tile_count[pi.owner], nt);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     SrTileRef *out = L.tiles + (size_t)pi.owner * L.tile_cap + base;
-    for (uint32_t k = lane; k < nt; k += 64) out[k] = SrTileRef{p, b + k * (uint32_t)kSrTile};
+    for (uint32_t k = lane; k < nt; k += 64) out[k] = ref(k);
   } else {
     for (uint32_t x = 0; x < (uint32_t)kSrXcds; x++) {
       if (nt <= x) break;
@@ -267,7 +301,7 @@ __global__ __launch_bounds__(256) void sr_tiles_kernel(SrLevel L) {
       if (lane == 0) base = atomicAdd(&L.tile_count[x], ntx);
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
       SrTileRef *out = L.tiles + (size_t)x * L.tile_cap + base;
-      for (uint32_t k = lane; k < ntx; k += 64) out[k] = SrTileRef{p, b + (x + k * kSrXcds) * (uint32_t)kSrTile};
+      for (uint32_t k = lane; k < ntx; k += 64) out[k] = ref(x + k * kSrXcds);
     }
   }
 }
@@ -278,6 +312,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
   __shared__ uint64_t sp[kSrMaxSplit + 1];
   __shared__ uint32_t lut[kSrLutCells];
   __shared__ uint32_t hist[kSrMaxNb + 1];
+  if (*(volatile const uint32_t *)L.status) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t x = blockIdx.x & (kSrXcds - 1), W = gridDim.x >> 3;
   const uint32_t nt = L.tile_count[x];
@@ -289,11 +324,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
   uint32_t cur = ~0u;
   SrSearch q;
   q.S = 0;
-  // (a tile never crosses its part's end: begin + kSrTile is clipped by the start of the part behind)
-  auto tile_end = [&](const SrTileRef &r) {
-    const uint32_t pe = L.part_start[r.part + 1];
-    return pe - r.begin > (uint32_t)kSrTile ? r.begin + (uint32_t)kSrTile : pe;
-  };
+  auto tile_end = [&](const SrTileRef &r) { return r.begin + r.len; };
   auto fetch = [&](const SrTileRef &r, uint32_t end, uint64_t (&k)[kSrPartPer]) {
 #pragma unroll
     for (int u = 0; u < kSrPartPer; u++) {
@@ -311,13 +342,13 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
       __syncthreads();
     }
   };
-  SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0};
+  SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0, 0};
   uint32_t end = j0 < j1 ? tile_end(ref) : 0;
   uint64_t key[kSrPartPer];
   if (j0 < j1) fetch(ref, end, key);
   for (uint32_t j = j0; j < j1; j += jstep) {
     const bool more = j + jstep < j1;
-    const SrTileRef nref = more ? tiles[j + jstep] : SrTileRef{0, 0};
+    const SrTileRef nref = more ? tiles[j + jstep] : SrTileRef{0, 0, 0};
     const uint32_t nend = more ? tile_end(nref) : 0;
     uint64_t nkey[kSrPartPer];
     if (more) fetch(nref, nend, nkey);
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
       sr_buckets<kSrPartPer>(sp, lut, q, key, bk);
 #pragma unroll
       for (int u = 0; u < kSrPartPer; u++)
-        (void)sr_claim(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end);
+        sr_tally(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end);
     }
     ref = nref;
     end = nend;
@@ -346,44 +377,193 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
   flush();
 }
 
-// pass 0: bucket v starts at (keys of lower buckets); inside it the stretches follow one another
+// ---- room from the sample instead of a count ----------------------------------------------------------------------
+// m sample keys fell into a bucket out of `of` drawn from `size` keys: the bucket holds about size * m / of keys; the
+// room is that plus sigmas_x2 / 2 standard deviations of m (a Poisson count: sqrt(m)) plus a few keys' worth for the
+// buckets no sample key fell into -- and never more than the keys there are
+__device__ __forceinline__ uint32_t sr_room(uint32_t m, uint32_t of, uint32_t size, uint32_t sigmas_x2) {
+  if (of == 0) return size;
+  const double mm = (double)m;
+  const double want = (mm + 0.5 * (double)sigmas_x2 * sqrt(mm) + 2.0 * (double)sigmas_x2) * ((double)size / (double)of);
+  return want >= (double)size ? size : (uint32_t)want + 1u;
+}
+// pass 0: tot[s][v] holds the sample keys of stretch s that fall into bucket v (the counting kernel, run over the
+// sample): the room of the stretch's range in the bucket
+__global__ void sr_room_first_kernel(SrLevel L, const uint32_t *sample_start, uint32_t sigmas_x2) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= L.nparts * L.nb) return;
+  const uint32_t sidx = e / L.nb;
+  const uint32_t size = L.pend[sidx] - L.pbeg[sidx], of = sample_start[sidx + 1] - sample_start[sidx];
+  L.tot[e] = sr_room(L.tot[e], of, size, sigmas_x2);
+}
+__device__ __forceinline__ uint32_t sr_sample_lower(const uint64_t *sorted, uint32_t ns, uint64_t v) {  // keys < v
+  uint32_t lo = 0, hi = ns;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (sorted[mid] < v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t sr_sample_upper(const uint64_t *sorted, uint32_t ns, uint64_t v) {  // keys <= v
+  uint32_t lo = 0, hi = ns;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (sorted[mid] <= v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+// later passes: a part is the keys between two splitters whatever order they came in, so the sorted sample's share
+// between a bucket's bounds is the bucket's share of the part.  One thread per (part, bucket).
+__global__ void sr_room_kernel(SrLevel L, const uint64_t *sorted, uint32_t ns, uint64_t n_fine, uint32_t sigmas_x2) {
+  if (*(volatile const uint32_t *)L.status) return;
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (uint64_t)L.nparts * L.nb) return;
+  const uint32_t p = (uint32_t)(e / L.nb), v = (uint32_t)(e % L.nb);
+  const SrPartInfo pi = sr_part_info(L, p);
+  const uint32_t size = L.part_size[p];
+  if (pi.eq || size == 0) {
+    L.tot[e] = (pi.eq && v == 0) ? size : 0u;
+    return;
+  }
+  const uint32_t S = L.split_count;
+  if (v > 2 * S) {
+    L.tot[e] = 0;
+    return;
+  }
+  const uint64_t width = (uint64_t)(S + 1) * L.stride;
+  // sample keys strictly inside the part
+  const bool has_lo = pi.first > 0, has_hi = pi.first + width - 1 < n_fine;
+  const uint32_t part_a = has_lo ? sr_sample_upper(sorted, ns, L.fine[pi.first - 1]) : 0u;
+  const uint32_t part_b = has_hi ? sr_sample_lower(sorted, ns, L.fine[pi.first + width - 1]) : ns;
+  const uint32_t of = part_b > part_a ? part_b - part_a : 0u;
+  const uint32_t k = v >> 1;
+  uint32_t a, b;
+  if (v & 1u) {  // the keys equal to splitter k
+    const uint64_t val = L.fine[pi.first + (uint64_t)(k + 1) * L.stride - 1];
+    a = sr_sample_lower(sorted, ns, val);
+    b = sr_sample_upper(sorted, ns, val);
+  } else {
+    a = k == 0 ? part_a : sr_sample_upper(sorted, ns, L.fine[pi.first + (uint64_t)k * L.stride - 1]);
+    b = k == S ? part_b : sr_sample_lower(sorted, ns, L.fine[pi.first + (uint64_t)(k + 1) * L.stride - 1]);
+  }
+  L.tot[e] = sr_room(b > a ? b - a : 0u, of, size, sigmas_x2);
+}
+
+// ---- where the buckets start ----------------------------------------------------------------------------------------
+// pass 0: bucket v starts at (room of the lower buckets); inside it the stretches' ranges follow one another
 __global__ __launch_bounds__(512) void sr_offsets_first_kernel(SrLevel L) {
   __shared__ uint32_t start[kSrMaxNb + 9];
   __shared__ uint32_t wsum[8];
+  __shared__ unsigned long long all;
   const uint32_t tid = threadIdx.x;
+  if (tid == 0) all = 0;
   uint32_t total = 0;
   if (tid < L.nb)
     for (uint32_t p = 0; p < L.nparts; p++) total += L.tot[(size_t)p * L.nb + tid];
   for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb + 8; v += 512) start[v] = 0;
   __syncthreads();
-  if (tid < L.nb) start[tid] = total;
+  if (tid < L.nb) {
+    start[tid] = total;
+    atomicAdd(&all, (unsigned long long)total);
+  }
   __syncthreads();
+  if (all > (unsigned long long)L.out_cap) {  // (the sum in 64 bits: the scan below would wrap)
+    if (tid == 0) atomicOr(L.status, 1u << (4 * L.level));
+    return;
+  }
   sr_block_scan8<512>(start, L.nb, 0u, true, wsum);
   if (tid < L.nb) {
     uint32_t run = start[tid];
     L.bstart[tid] = run;
     for (uint32_t p = 0; p < L.nparts; p++) {
-      L.cursor[(size_t)p * L.nb + tid] = run;
-      run += L.tot[(size_t)p * L.nb + tid];
+      const size_t at = (size_t)p * L.nb + tid;
+      const uint32_t room = L.tot[at];
+      L.cursor[at] = run;
+      L.pbegin[at] = run;
+      run += room;
+      L.limit[at] = run;
     }
     L.tot[tid] = total;  // (row 0 now holds the buckets' sizes: what the last pass's work list reads)
   }
   if (tid == 0) L.bstart[L.nb] = start[L.nb];
 }
 
-// later passes: the buckets of part p start at part_start[p] + (keys of the part's lower buckets).  One wave per part.
-__global__ __launch_bounds__(512) void sr_offsets_kernel(SrLevel L) {
+// later passes, one wave per part: the room its buckets take (an equality part is one bucket: its keys)
+__global__ __launch_bounds__(512) void sr_part_totals_kernel(SrLevel L) {
+  if (*(volatile const uint32_t *)L.status) return;
   const uint32_t p = (blockIdx.x * 512u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
   if (p >= L.nparts) return;
-  const uint32_t b = L.part_start[p], e = L.part_start[p + 1];
   const SrPartInfo pi = sr_part_info(L, p);
-  uint32_t *tot = L.tot + (size_t)p * L.nb, *cur = L.cursor + (size_t)p * L.nb, *bs = L.bstart + (size_t)p * L.nb;
+  uint32_t *tot = L.tot + (size_t)p * L.nb;
+  unsigned long long s = 0;
+  if (pi.eq) {
+    for (uint32_t i = lane; i < L.nb; i += 64) tot[i] = i == 0 ? L.part_size[p] : 0u;
+    s = lane == 0 ? L.part_size[p] : 0;
+  } else {
+    for (uint32_t i = lane; i < L.nb; i += 64) s += tot[i];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) {
+    if (s > 0xFFFFFFFFull) {
+      atomicOr(L.status, 1u << (4 * L.level));
+      s = 0;
+    }
+    L.part_total[p] = (uint32_t)s;
+  }
+}
+// ... one after the other in the output (a single workgroup: a few ten thousand parts at most)
+__global__ __launch_bounds__(1024) void sr_scan_parts_kernel(SrLevel L) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry;
+  if (*(volatile const uint32_t *)L.status) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < L.nparts; base += 1024) {
+    const uint32_t p = base + tid;
+    const unsigned long long v = p < L.nparts ? L.part_total[p] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long up = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long before = carry;
+    for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+    const unsigned long long mine = before + incl - v;
+    if (p < L.nparts) L.out_base[p] = mine > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mine;
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    L.out_base[L.nparts] = carry > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)carry;
+    if (carry > (unsigned long long)L.out_cap) atomicOr(L.status, 1u << (4 * L.level));
+  }
+}
+// ... and the part's buckets from there on.  One wave per part.
+__global__ __launch_bounds__(512) void sr_offsets_kernel(SrLevel L) {
+  if (*(volatile const uint32_t *)L.status) return;
+  const uint32_t p = (blockIdx.x * 512u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (p >= L.nparts) return;
+  const uint32_t b = L.out_base[p];
+  const size_t row = (size_t)p * L.nb;
+  const uint32_t *tot = L.tot + row;
+  uint32_t *cur = L.cursor + row, *bs = L.bstart + row, *lim = L.limit + row;
   uint32_t v[8], s = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const uint32_t i = lane * 8 + k;
-    v[k] = (i < L.nb && !pi.eq) ? tot[i] : 0u;
-    if (pi.eq && i == 0) v[k] = e - b;
+    v[k] = i < L.nb ? tot[i] : 0u;
     s += v[k];
   }
   uint32_t incl = s;
@@ -399,17 +579,18 @@ __global__ __launch_bounds__(512) void sr_offsets_kernel(SrLevel L) {
     if (i < L.nb) {
       cur[i] = run;
       bs[i] = run;
-      if (pi.eq) tot[i] = v[k];
+      lim[i] = run + v[k];
     }
     run += v[k];
   }
-  if (p == L.nparts - 1 && lane == 0) L.bstart[(size_t)L.nparts * L.nb] = e;
 }
 
 // the pass proper: a tile's keys (and payloads) grouped by bucket in LDS, every run placed with one reservation; the
 // next tile's keys are requested before this tile's are searched
+// (three workgroups a CU are six waves a SIMD: 80 registers each -- at 82 the third workgroup does not fit and the
+// pass takes 10.5 instead of 7 ms)
 template <int PB>
-__global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
+__global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void sr_scatter_kernel(SrLevel L) {
   __shared__ uint64_t sp[kSrMaxSplit + 1];
   __shared__ uint64_t stage_k[kSrTile];
   __shared__ uint64_t stage_p8[PB == 8 ? kSrTile : 1];
@@ -418,8 +599,12 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
   __shared__ uint32_t lut[kSrLutCells];
   __shared__ uint32_t hist[kSrMaxNb + 1];
   __shared__ uint32_t delta[kSrMaxNb + 1];
+  __shared__ uint32_t room_end[kSrMaxNb + 1];  // where the buckets of the part at hand end
   __shared__ uint32_t wsum[kSrPartThreads / 64];
+  __shared__ uint32_t s_full, s_base;
+  if (*(volatile const uint32_t *)L.status) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) s_full = 0;
   const uint32_t x = blockIdx.x & (kSrXcds - 1), W = gridDim.x >> 3;
   const uint32_t nt = L.tile_count[x];
   // `group` workgroups walk a stretch of their XCD's list side by side: the runs that complete a bucket's lines follow
@@ -435,10 +620,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
   uint32_t cur = ~0u, S = 0;
   SrSearch q;
   q.S = 0;
-  auto tile_end = [&](const SrTileRef &r) {
-    const uint32_t pe = L.part_start[r.part + 1];
-    return pe - r.begin > (uint32_t)kSrTile ? r.begin + (uint32_t)kSrTile : pe;
-  };
+  auto tile_end = [&](const SrTileRef &r) { return r.begin + r.len; };
   auto fetch = [&](const SrTileRef &r, uint32_t end, uint64_t (&k)[kSrPartPer], uint64_t (&q8)[PB == 8 ? kSrPartPer : 1],
                    uint32_t (&q4)[PB == 4 ? kSrPartPer : 1]) {
 #pragma unroll
@@ -450,7 +632,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       if (PB == 4) q4[u] = (ok && pin4) ? __builtin_nontemporal_load(pin4 + i) : (uint32_t)i;
     }
   };
-  SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0};
+  SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0, 0};
   uint32_t end = j0 < j1 ? tile_end(ref) : 0;
   uint64_t key[kSrPartPer];
   uint64_t p8[PB == 8 ? kSrPartPer : 1];
@@ -458,7 +640,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
   if (j0 < j1) fetch(ref, end, key, p8, p4);
   for (uint32_t j = j0; j < j1; j += jstep) {
     const bool more = j + jstep < j1;
-    const SrTileRef nref = more ? tiles[j + jstep] : SrTileRef{0, 0};
+    const SrTileRef nref = more ? tiles[j + jstep] : SrTileRef{0, 0, 0};
     const uint32_t nend = more ? tile_end(nref) : 0;
     uint64_t nkey[kSrPartPer];
     uint64_t np8[PB == 8 ? kSrPartPer : 1];
@@ -470,18 +652,32 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       const SrPartInfo pi = sr_part_info(L, cur);
       S = pi.eq ? 0u : L.split_count;
       sr_load_splitters(L, pi, S, sp);
-      for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb; v += kSrPartThreads) hist[v] = 0;
+      for (uint32_t v = tid; v <= (uint32_t)kSrMaxNb; v += kSrPartThreads) {
+        hist[v] = 0;
+        room_end[v] = v < L.nb ? L.limit[(size_t)cur * L.nb + v] : 0u;
+      }
       __syncthreads();
       q = sr_build_search(sp, S, lut);
     }
-    if (S == 0) {  // one bucket that starts where the part starts: the keys keep their places
+    if (S == 0) {  // one bucket: the tile is one run
+      __syncthreads();
+      if (tid == 0) {
+        const size_t at = (size_t)cur * L.nb;
+        const uint32_t base = atomicAdd(&L.cursor[at], ref.len);
+        s_base = base;
+        if (base + ref.len > L.limit[at] || base + ref.len < base) s_full = 1;
+      }
+      __syncthreads();
+      if (s_full) break;
+      const uint32_t shift = s_base - ref.begin;
 #pragma unroll
       for (int u = 0; u < kSrPartPer; u++) {
         const uint64_t i = (uint64_t)ref.begin + u * kSrPartThreads + tid;
         if (i < end) {
-          L.keys_out[i] = key[u];
-          if (PB == 8) pout8[i] = p8[u];
-          if (PB == 4) pout4[i] = p4[u];
+          const uint32_t at = (uint32_t)i + shift;
+          L.keys_out[at] = key[u];
+          if (PB == 8) pout8[at] = p8[u];
+          if (PB == 4) pout4[at] = p4[u];
         }
       }
     } else {
@@ -493,7 +689,12 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       __syncthreads();
       // one reservation per run -- its round trip runs under the scan and the regrouping: only the stores need it
       const uint32_t h = tid < 2 * S + 1 ? hist[tid] : 0u;
-      const uint32_t reserved = h ? atomicAdd(&L.cursor[(size_t)cur * L.nb + tid], h) : 0u;
+      uint32_t reserved = 0;
+      if (h) {
+        const size_t cell = (size_t)cur * L.nb + tid;
+        reserved = atomicAdd(&L.cursor[cell], h);
+        if (reserved + h > room_end[tid] || reserved + h < reserved) s_full = 1;  // (the barrier below publishes it)
+      }
       uint32_t incl = h;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -502,6 +703,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       }
       if (lane == 63) wsum[wave] = incl;
       __syncthreads();
+      if (s_full) break;  // a bucket had less room than keys: nothing of this job counts any more
       uint32_t excl = incl - h;
       for (uint32_t w = 0; w < wave; w++) excl += wsum[w];
       hist[tid] = excl;  // (tid <= kSrMaxNb)
@@ -537,6 +739,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_scatter_kernel(SrLevel L) {
       if (PB == 4) p4[u] = np4[u];
     }
   }
+  if (s_full && tid == 0) atomicOr(L.status, 2u << (4 * L.level));  // (sortrank.h: the status word's bits)
 }
 
 // ---- the last pass's work lists ------------------------------------------------------------------------------------
@@ -548,6 +751,7 @@ __global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buc
   __shared__ uint32_t block_base_t;
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t block_base;
+  if (*(volatile const uint32_t *)L.status) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t rows = L.level == 0 ? 1ull : (uint64_t)L.nparts;  // (pass 0: row 0 holds the buckets' sizes)
   const uint64_t e = (uint64_t)blockIdx.x * 256 + tid, total = rows * L.nb;
@@ -730,14 +934,15 @@ __global__ __launch_bounds__(kSrFastThreads) void sr_rank_small_kernel(SrFinal F
   __shared__ uint32_t bins2[2][kBins + 8];
   __shared__ uint32_t wsum[kSrFastThreads / 64];
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_items = *F.n_items, G = gridDim.x;
+  const bool off = *(volatile const uint32_t *)F.status != 0;  // (a failed job: the sums' slots are still written)
+  const uint32_t n_items = off ? 0u : *F.n_items, G = gridDim.x;
   SrSumAcc acc;
   acc.clear();
   for (uint32_t v = tid; v < 2u * (kBins + 8); v += kSrFastThreads) (&bins2[0][0])[v] = 0;
   __syncthreads();
 
   {  // equality buckets of a few keys: RANK() is the bucket's first position for all of them; a thread per bucket
-    const uint32_t n_tiny = *F.n_tiny;
+    const uint32_t n_tiny = off ? 0u : *F.n_tiny;
     for (uint32_t i = blockIdx.x * kSrFastThreads + tid; i < n_tiny; i += G * kSrFastThreads) {
       const SrItem t = F.tiny[i];
       for (uint32_t e = 0; e < t.count; e++) {
@@ -848,7 +1053,7 @@ __global__ __launch_bounds__(kSrSlowThreads) void sr_rank_large_kernel(SrFinal F
   __shared__ unsigned long long s_mn, s_mx;
   __shared__ uint32_t wsum[kSrSlowThreads / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t n_items = *F.n_items;
+  const uint32_t n_items = *(volatile const uint32_t *)F.status ? 0u : *F.n_items;
   SrSumAcc acc;
   acc.clear();
 
@@ -1013,14 +1218,17 @@ SrShape sr_shape(uint64_t n, const SrTuning &t) {
   s.ns = s.buckets * every;  // <= n when buckets <= n
   if (s.ns > n) s.ns = n;    // (cannot happen: buckets <= ceil(n / target) * (rounding of three roots); kept honest)
   s.sample_stride = std::max<uint64_t>(1, n / s.ns);
-  uint64_t per = (n + kSrFirstParts - 1) / kSrFirstParts;
+  const uint64_t first_parts = t.first_parts;
+  uint64_t per = (n + first_parts - 1) / first_parts;
   per = (per + kSrTile - 1) / kSrTile * kSrTile;
   s.per_part = (uint32_t)std::min<uint64_t>(per, 0x80000000ull);
-  uint64_t parts = kSrFirstParts;
+  uint64_t parts = first_parts;
   for (int l = 0; l < s.levels; l++) {
     s.nparts[l] = (uint32_t)parts;
     s.nb[l] = 2 * (s.f[l] - 1) + 1;
-    s.tile_cap[l] = (uint32_t)std::min<uint64_t>(n / kSrTile + std::min<uint64_t>(parts, n) + 16, 0xFFFFFFF0ull);
+    // (a part of pass 1 lies in as many pieces as pass 0 has stretches, each with a last, short tile)
+    const uint64_t pieces = std::min<uint64_t>(parts, n) * (l == 1 ? first_parts : 1);
+    s.tile_cap[l] = (uint32_t)std::min<uint64_t>(n / kSrTile + pieces + 16, 0xFFFFFFF0ull);
     parts = (l == 0 ? 1 : parts) * s.nb[l];
   }
   s.max_small = parts + n / kSrEqPiece + 2;  // (`parts` is now the number of buckets of the last pass)
@@ -1060,6 +1268,16 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
   SrItem *small = ws.take<SrItem>(sh.max_small), *large = ws.take<SrItem>(sh.max_large);
   SrItem *tiny = ws.take<SrItem>(sh.max_small);
   uint32_t *counters = ws.take<uint32_t>(8);  // [0] small items, [1] large items, [2] tiny items
+  uint32_t *own_status = ws.take<uint32_t>(1);
+  uint32_t *status = job.status ? job.status : own_status;
+  if (!dry) {
+    hipError_t e0 = hipMemsetAsync(status, 0, sizeof(uint32_t), stream);
+    if (e0 != hipSuccess) return e0;
+  }
+  // bucket sizes from the sample in all passes but the last, if the caller gave the room
+  const uint64_t roomy = sr_roomy_elems(n);
+  const bool optimistic = job.optimistic && tune.optimistic && sh.levels >= 2 && job.cap[0] >= roomy &&
+                          job.cap[1] >= roomy && roomy <= 0xFFFFFFF0ull;
   const uint64_t *keys = job.keys;
   const void *pay = job.pay;
   if (sh.levels == 0) {
@@ -1089,13 +1307,16 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
     const int per_xcd = std::max(1, tgx_num_cus() / kSrXcds);
     const int grid = kSrXcds * per_xcd * (int)tune.wg_per_cu;
     const int count_grid = kSrXcds * per_xcd * 4;  // (little LDS, few registers: four 512-thread workgroups fill a CU)
-    uint32_t *next_parts = nullptr;
-    SrLevel L;
+    SrLevel L{}, prev{};
     for (int lv = 0; lv < sh.levels; lv++) {
+      prev = L;
+      const bool guess = optimistic && lv + 1 < sh.levels;  // this pass takes its buckets' room from the sample
       L.keys_in = keys;
       L.pay_in = pay;
       L.keys_out = job.k[lv & 1];
       L.pay_out = job.p[lv & 1];
+      L.out_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(job.cap[lv & 1], n), 0xFFFFFFF0ull);
+      L.status = status;
       L.fine = fine;
       L.level = lv;
       L.nbp = lv == 2 ? sh.nb[1] : 1;
@@ -1122,25 +1343,75 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
       const size_t table = (size_t)L.nparts * L.nb;
       L.tot = ws.take<uint32_t>(table);
       L.cursor = ws.take<uint32_t>(table);
+      L.limit = ws.take<uint32_t>(table);
       L.bstart = ws.take<uint32_t>(table + 2);
+      L.part_size = ws.take<uint32_t>(L.nparts);
+      L.part_total = ws.take<uint32_t>(L.nparts);
+      L.out_base = ws.take<uint32_t>((size_t)L.nparts + 1);
+      L.pbegin = lv == 0 ? ws.take<uint32_t>(table) : nullptr;
+      uint32_t *sample_start = nullptr;
       if (lv == 0) {
-        L.part_start = ws.take<uint32_t>((size_t)L.nparts + 2);
+        uint32_t *part_start = ws.take<uint32_t>((size_t)L.nparts + 2);
+        sample_start = ws.take<uint32_t>((size_t)L.nparts + 2);
+        L.pbeg = part_start;
+        L.pend = part_start + 1;
+        L.npieces = 1;
+        L.pstride = 0;
         if (!dry)
-          hipLaunchKernelGGL(sr_first_parts_kernel, dim3(1), dim3(128), 0, stream, L.part_start, L.nparts, sh.per_part,
-                             (uint32_t)n);
+          hipLaunchKernelGGL(sr_first_parts_kernel, dim3(1), dim3(128), 0, stream, part_start, L.nparts, sh.per_part,
+                             (uint32_t)n, sample_start, (uint32_t)sh.ns);
+      } else if (lv == 1) {  // what each stretch of pass 0 wrote of a bucket
+        L.pbeg = prev.pbegin;
+        L.pend = prev.cursor;
+        L.npieces = prev.nparts;
+        L.pstride = prev.nb;
       } else {
-        L.part_start = next_parts;
+        L.pbeg = prev.bstart;
+        L.pend = prev.cursor;
+        L.npieces = 1;
+        L.pstride = 0;
+      }
+      // (pass 0 with room from the sample: the counting kernel runs over the sample's stretches)
+      SrLevel LS = L;
+      uint32_t *sample_size = nullptr;
+      if (lv == 0) {
+        LS.keys_in = samp;
+        LS.pbeg = sample_start;
+        LS.pend = sample_start + 1;
+        LS.tile_cap = (uint32_t)(sh.ns / kSrTile + L.nparts + 16);
+        LS.tiles = ws.take<SrTileRef>((size_t)kSrXcds * LS.tile_cap);
+        LS.tile_count = ws.take<uint32_t>(kSrXcds);
+        sample_size = ws.take<uint32_t>(L.nparts);
+        LS.part_size = sample_size;
       }
       if (!dry) {
         hipError_t e2 = hipMemsetAsync(L.tot, 0, table * sizeof(uint32_t), stream);
         if (e2 == hipSuccess) e2 = hipMemsetAsync(L.tile_count, 0, kSrXcds * sizeof(uint32_t), stream);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(L.part_size, 0, L.nparts * sizeof(uint32_t), stream);
         if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(sr_tiles_kernel, dim3((L.nparts + 3) / 4), dim3(256), 0, stream, L);
-        hipLaunchKernelGGL(sr_count_kernel, dim3(count_grid), dim3(kSrPartThreads), 0, stream, L);
-        if (lv == 0)
+        const unsigned tile_waves = L.nparts * L.npieces;
+        hipLaunchKernelGGL(sr_tiles_kernel, dim3((tile_waves + 3) / 4), dim3(256), 0, stream, L);
+        if (!guess) {
+          hipLaunchKernelGGL(sr_count_kernel, dim3(count_grid), dim3(kSrPartThreads), 0, stream, L);
+        } else if (lv == 0) {
+          e2 = hipMemsetAsync(LS.tile_count, 0, kSrXcds * sizeof(uint32_t), stream);
+          if (e2 == hipSuccess) e2 = hipMemsetAsync(sample_size, 0, L.nparts * sizeof(uint32_t), stream);
+          if (e2 != hipSuccess) return e2;
+          hipLaunchKernelGGL(sr_tiles_kernel, dim3((L.nparts + 3) / 4), dim3(256), 0, stream, LS);
+          hipLaunchKernelGGL(sr_count_kernel, dim3(count_grid), dim3(kSrPartThreads), 0, stream, LS);
+          hipLaunchKernelGGL(sr_room_first_kernel, dim3((unsigned)((table + 255) / 256)), dim3(256), 0, stream, L,
+                             sample_start, tune.sigmas_x2);
+        } else {
+          hipLaunchKernelGGL(sr_room_kernel, dim3((unsigned)((table + 255) / 256)), dim3(256), 0, stream, L, sorted,
+                             (uint32_t)sh.ns, sh.buckets - 1, tune.sigmas_x2);
+        }
+        if (lv == 0) {
           hipLaunchKernelGGL(sr_offsets_first_kernel, dim3(1), dim3(512), 0, stream, L);
-        else
+        } else {
+          hipLaunchKernelGGL(sr_part_totals_kernel, dim3((L.nparts + 7) / 8), dim3(512), 0, stream, L);
+          hipLaunchKernelGGL(sr_scan_parts_kernel, dim3(1), dim3(1024), 0, stream, L);
           hipLaunchKernelGGL(sr_offsets_kernel, dim3((L.nparts + 7) / 8), dim3(512), 0, stream, L);
+        }
         if (job.pay_bytes == 8)
           hipLaunchKernelGGL(sr_scatter_kernel<8>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
         else if (job.pay_bytes == 4)
@@ -1150,7 +1421,6 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
       }
       keys = L.keys_out;
       pay = L.pay_out;
-      next_parts = L.bstart;
     }
     if (!dry) {
       hipError_t e2 = hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), stream);
@@ -1176,6 +1446,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
   F.ext_base = job.ext_base;
   F.partials = job.partials;
   F.cap = tune.slow_cap;
+  F.status = status;
   SrFinal FL = F;
   FL.items = large;
   FL.n_items = counters + 1;
@@ -1203,9 +1474,12 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
     uint32_t c[3] = {0, 0, 0};
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost);
-    fprintf(stderr, "tgx sort: n %llu, %d passes of %u x %u x %u ways, %llu splitters from %llu sample keys, %u small + %u "
-                    "large + %u tiny items\n", (unsigned long long)n, sh.levels, sh.f[0], sh.f[1], sh.f[2],
-            (unsigned long long)sh.buckets - 1, (unsigned long long)sh.ns, c[0], c[1], c[2]);
+    uint32_t stw = 0;
+    (void)hipMemcpy(&stw, status, sizeof(stw), hipMemcpyDeviceToHost);
+    fprintf(stderr, "tgx sort: n %llu, %d passes of %u x %u x %u ways (%s), %llu splitters from %llu sample keys, %u small "
+                    "+ %u large + %u tiny items, status %u\n", (unsigned long long)n, sh.levels, sh.f[0], sh.f[1], sh.f[2],
+            optimistic ? "room from the sample" : "counted", (unsigned long long)sh.buckets - 1,
+            (unsigned long long)sh.ns, c[0], c[1], c[2], stw);
   }
   return hipGetLastError();
 }
@@ -1220,10 +1494,17 @@ SrTuning sr_tuning() {
   t.slow_cap = env_u32("TGX_SORT_SLOWCAP", kSrSlowCap, 8, kSrSlowCap);
   t.max_split = env_u32("TGX_SORT_SPLIT", kSrMaxSplit, 1, kSrMaxSplit);
   t.wg_per_cu = env_u32("TGX_SORT_WG", 3, 1, 16);
+  t.first_parts = env_u32("TGX_SORT_PARTS", kSrFirstParts, 8, 64) & ~7u;
+  t.optimistic = env_u32("TGX_SORT_OPTIMISTIC", 1, 0, 1);
+  t.sigmas_x2 = env_u32("TGX_SORT_SIGMAS_X2", 13, 0, 64);
+  t.optimistic_min = env_u32("TGX_SORT_OPTIMISTIC_MIN", 1u << 20, 1, 0xFFFFFFFFu);
   return t;
 }
 
 int sr_partials_count() { return sr_small_grid() + sr_large_grid(); }
+
+// the buckets of a pass that takes their room from the sample lie apart: about a quarter more than the keys
+uint64_t sr_roomy_elems(uint64_t n) { return n + n / 3 + (8u << 20); }
 
 size_t sr_workspace_bytes(uint64_t n) {
   Carver c{nullptr};

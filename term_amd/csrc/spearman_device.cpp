@@ -209,44 +209,86 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   // The first ranking's second partition pass writes back into the state's own arrays: the pairs come back permuted,
   // every x still beside its y.  28 bytes of work buffers per pair.
   DevBuf &ka = ws->keys_sorted, &pa = ws->heads, &ra = ws->idx, &rb = ws->idx_sorted, &rank32 = ws->rank32,
-         &temp = ws->temp, &partials = ws->partials;
-  SHIP(ka.reserve(m * 8));
-  SHIP(pa.reserve(m * 8));
-  SHIP(ra.reserve(m * 4));
-  SHIP(rb.reserve(m * 4));
-  SHIP(rank32.reserve(m * 4));
+         &temp = ws->temp, &partials = ws->partials, &kc = ws->rx, &pc = ws->ry;
+  const int blocks = sr_partials_count();
+  const size_t sums_bytes = (size_t)blocks * spearman_rank_sums_bytes();
+  SHIP(partials.reserve(sums_bytes + 64));
+  uint32_t *d_status = (uint32_t *)((char *)partials.p + sums_bytes);  // [0] the first ranking's, [1] the second's
   const size_t temp_bytes = sr_workspace_bytes(m);
   SHIP(temp.reserve(temp_bytes));
-  const int blocks = sr_partials_count();
-  SHIP(partials.reserve((size_t)blocks * spearman_rank_sums_bytes()));
-  SrJob jx;
-  jx.keys = ts.kx.as<uint64_t>();
-  jx.pay = ts.ky.p;
-  jx.n = m;
-  jx.pay_bytes = 8;
-  jx.k[0] = ka.as<uint64_t>();
-  jx.p[0] = pa.p;
-  jx.k[1] = ts.kx.as<uint64_t>();
-  jx.p[1] = ts.ky.p;
-  jx.sink = kSrRank32;
-  jx.rank32 = rank32.as<uint32_t>();
-  SrPlaced at;
-  SHIP(sr_run(jx, temp.p, temp_bytes, st->stream, &at));
-  SrJob jy;
-  jy.keys = (const uint64_t *)at.pay;  // the y keys, slot for slot beside rank32
-  jy.pay = rank32.p;
-  jy.n = m;
-  jy.pay_bytes = 4;
-  jy.k[0] = ka.as<uint64_t>();  // (free again: the first ranking is through)
-  jy.p[0] = ra.p;
-  jy.k[1] = pa.as<uint64_t>();  // (may be where the y keys lie now: they are read by the first pass only)
-  jy.p[1] = rb.p;
-  jy.sink = kSrSums;
-  jy.partials = (RankSums *)partials.p;
-  SHIP(sr_run(jy, temp.p, temp_bytes, st->stream, nullptr));
+  SHIP(rank32.reserve(m * 4));
+  // Bucket sizes from the sample instead of a counting read per pass (kernels/sortrank.h): the passes' buckets then lie
+  // apart, in arrays a third larger, none of them the state's own (a pass that finds a bucket full leaves nothing
+  // valid behind: the pairs have to be intact for the second try, with counted buckets).  Taken when the device has
+  // the room: 72 instead of 28 bytes of work buffers per pair.
+  const uint64_t roomy = sr_roomy_elems(m);
+  bool optimistic = m >= sr_tuning().optimistic_min;
+  if (optimistic) {
+    size_t free_b = 0, total_b = 0;
+    const size_t have = ka.cap + pa.cap + kc.cap + pc.cap + ra.cap + rb.cap;
+    const size_t want = (size_t)roomy * 40;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (want > have && free_b < want - have + (2ull << 30)))
+      optimistic = false;
+  }
   std::vector<RankSumsHost> h(blocks);
-  SHIP(hipMemcpyAsync(h.data(), partials.p, blocks * sizeof(RankSumsHost), hipMemcpyDeviceToHost, st->stream));
-  SHIP(hipStreamSynchronize(st->stream));
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const uint64_t elems = optimistic ? roomy : m;
+    SHIP(ka.reserve(elems * 8));
+    SHIP(pa.reserve(elems * 8));
+    SHIP(ra.reserve(elems * 4));
+    SHIP(rb.reserve(elems * 4));
+    if (optimistic) {
+      SHIP(kc.reserve(elems * 8));
+      SHIP(pc.reserve(elems * 8));
+    }
+    SrJob jx;
+    jx.keys = ts.kx.as<uint64_t>();
+    jx.pay = ts.ky.p;
+    jx.n = m;
+    jx.pay_bytes = 8;
+    jx.k[0] = ka.as<uint64_t>();
+    jx.p[0] = pa.p;
+    // (counted buckets: the second pass writes back into the state's own arrays, the pairs come back permuted, every
+    // x still beside its y)
+    jx.k[1] = optimistic ? kc.as<uint64_t>() : ts.kx.as<uint64_t>();
+    jx.p[1] = optimistic ? pc.p : ts.ky.p;
+    jx.optimistic = optimistic;
+    jx.cap[0] = jx.cap[1] = elems;
+    jx.status = d_status;
+    jx.sink = kSrRank32;
+    jx.rank32 = rank32.as<uint32_t>();
+    SrPlaced at;
+    SHIP(sr_run(jx, temp.p, temp_bytes, st->stream, &at));
+    SrJob jy;
+    jy.keys = (const uint64_t *)at.pay;  // the y keys, slot for slot beside rank32
+    jy.pay = rank32.p;
+    jy.n = m;
+    jy.pay_bytes = 4;
+    // the first ranking is through: its arrays are free again, but (with room from the sample) the one the y keys lie in
+    uint64_t *spare[4] = {ka.as<uint64_t>(), pa.as<uint64_t>(), optimistic ? kc.as<uint64_t>() : nullptr,
+                          optimistic ? pc.as<uint64_t>() : nullptr};
+    int took = 0;
+    for (int c = 0; c < 4 && took < 2; c++)
+      if (spare[c] && (!optimistic || (const void *)spare[c] != at.pay)) jy.k[took++] = spare[c];
+    // (counted buckets: k[1] may be where the y keys lie now -- they are read by the first pass only)
+    jy.p[0] = ra.p;
+    jy.p[1] = rb.p;
+    jy.optimistic = optimistic;
+    jy.cap[0] = jy.cap[1] = elems;
+    jy.status = d_status + 1;
+    jy.sink = kSrSums;
+    jy.partials = (RankSums *)partials.p;
+    SHIP(sr_run(jy, temp.p, temp_bytes, st->stream, nullptr));
+    uint32_t status[2] = {0, 0};
+    SHIP(hipMemcpyAsync(h.data(), partials.p, blocks * sizeof(RankSumsHost), hipMemcpyDeviceToHost, st->stream));
+    SHIP(hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, st->stream));
+    SHIP(hipStreamSynchronize(st->stream));
+    if ((status[0] | status[1]) == 0) break;
+    if (!optimistic) return sfail(err, TGX_INTERNAL, "SPEARMAN: the ranking failed with counted buckets (status %u, %u)",
+                                  status[0], status[1]);
+    optimistic = false;  // a bucket outgrew the room its share of the sample gave it: once more, counting
+    if (getenv("TGX_SORT_DEBUG")) fprintf(stderr, "tgx sort: a bucket was full (status %u, %u): again with counted buckets\n", status[0], status[1]);
+  }
   double out[5];
   for (int k = 0; k < 5; k++) {
     unsigned long long w = 0;

@@ -222,3 +222,58 @@ def test_ranking_oversized_bucket_default_shape(monkeypatch):
     x = rng.standard_normal(n)
     y = rng.random(n)
     _check_spearman(x, y)
+
+
+# ---- room from the sample instead of a counting read (all passes but the last; kernels/sortrank.h) --------------------
+ROOMY_SHAPES = {
+    "three_passes": dict(TGX_SORT_TARGET="16", TGX_SORT_CAP="64", TGX_SORT_SPLIT="15"),
+    "two_passes": dict(TGX_SORT_TARGET="32", TGX_SORT_CAP="128", TGX_SORT_SPLIT="31", TGX_SORT_SAMPLE="8"),
+    "coarse": dict(TGX_SORT_TARGET="64", TGX_SORT_SPLIT="3", TGX_SORT_SAMPLE="1"),
+    "many_stretches": dict(TGX_SORT_TARGET="16", TGX_SORT_CAP="64", TGX_SORT_SPLIT="15", TGX_SORT_PARTS="64"),
+}
+
+
+@pytest.mark.parametrize("shape", list(ROOMY_SHAPES))
+@pytest.mark.parametrize("kind", SORT_KINDS)
+def test_ranking_with_room_from_the_sample(kind, shape, monkeypatch, capfd):
+    for k, v in ROOMY_SHAPES[shape].items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("TGX_SORT_OPTIMISTIC_MIN", "1")
+    monkeypatch.setenv("TGX_SORT_DEBUG", "1")
+    n = 60_000
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("roomy/%s/%s" % (kind, shape)).encode()))
+    x = _sort_data(kind, n, rng)
+    other = SORT_KINDS[(SORT_KINDS.index(kind) + 3) % len(SORT_KINDS)]
+    y = _sort_data(other, n, rng)
+    yv = orc.pack_validity(rng.random(n) >= 0.05)
+    _check_spearman(x, y, None, yv)
+    assert "room from the sample" in capfd.readouterr().err  # (whether or not a bucket then was full)
+
+
+@pytest.mark.parametrize("sigmas_x2", ["0", "2"])
+def test_ranking_full_bucket_is_counted_again(sigmas_x2, monkeypatch, capfd):
+    """no slack on the sample's estimate: some bucket is full, the job says so, the ranking runs again with counted
+    buckets -- from the untouched pairs -- and the sums are the oracle's"""
+    monkeypatch.setenv("TGX_SORT_OPTIMISTIC_MIN", "1")
+    monkeypatch.setenv("TGX_SORT_SIGMAS_X2", sigmas_x2)
+    monkeypatch.setenv("TGX_SORT_DEBUG", "1")
+    rng = np.random.default_rng(int(sigmas_x2) + 11)
+    n = 2_000_000
+    x = rng.standard_normal(n)
+    y = np.round(x + rng.standard_normal(n), 3)
+    _check_spearman(x, y)
+    err = capfd.readouterr().err
+    if sigmas_x2 == "0":
+        assert "again with counted buckets" in err
+
+
+def test_ranking_room_from_the_sample_at_size():
+    """the shipped shape from 1 Mi pairs on: keys in order on one side (every stretch of pass 0 sees other buckets),
+    heavy ties on the other"""
+    rng = np.random.default_rng(21)
+    n = 6_000_000
+    x = np.arange(n, dtype=np.float64) * 0.5
+    y = rng.integers(0, 300, size=n).astype(np.float64) + (np.arange(n) % 7 == 0) * rng.random(n)
+    _check_spearman(x, y)
+    _check_spearman(y, x)
