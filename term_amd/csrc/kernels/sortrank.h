@@ -39,6 +39,24 @@ constexpr int kSrSlowBinBits = 12;
 constexpr uint32_t kSrEqPiece = 8192;  // an equality bucket is handed out in pieces of this many keys
 constexpr uint32_t kSrEqTiny = 32;     // ... unless it holds at most this many: then one thread walks it
 
+// what a job's keys (and 8-byte payloads) are when pass 0 reads them: sort keys already, or column values that become
+// sort keys as they are read -- CAST(c AS DOUBLE), then the IEEE total order as an unsigned number (the Spearman state
+// ranks a lent batch straight from the caller's columns: no converted copy is written first)
+enum SrSource : int { kSrKeys = 0, kSrInt64 = 1, kSrFloat64 = 2 };
+__host__ __device__ inline uint64_t sr_source_key(uint64_t bits, int source) {
+  if (source == kSrKeys) return bits;
+  double d;
+  if (source == kSrFloat64) {
+    __builtin_memcpy(&d, &bits, 8);
+  } else {
+    d = (double)(int64_t)bits;
+  }
+  int64_t k;
+  __builtin_memcpy(&k, &d, 8);
+  k ^= (int64_t)(((uint64_t)(k >> 63)) >> 1);  // (f64_total_key, device_types.h)
+  return (uint64_t)k ^ 0x8000000000000000ULL;  // signed total order -> unsigned order
+}
+
 struct SrTileRef {  // one tile of a partition pass: keys [begin, begin + len) of a piece of `part`, len <= kSrTile
   uint32_t part, begin, len;
 };
@@ -74,6 +92,7 @@ struct SrLevel {
   uint64_t *keys_out;
   void *pay_out;
   const uint64_t *fine;  // all splitters, in order
+  int32_t key_source, pay_source;  // SrSource of keys_in / an 8-byte pay_in (pass 0 of a job over column values)
   int32_t level;         // 0, 1, 2
   uint32_t nbp;          // level 2: buckets per part of level 1 (a part is (d1, d2) = (p / nbp, p % nbp))
   uint32_t w1, w2;       // first splitter of a part's range: (d1 >> 1) * w1 + (d2 >> 1) * w2
@@ -138,6 +157,7 @@ struct SrJob {
   const void *pay = nullptr;       // payloads of pay_bytes each, or nullptr (iota with pay_bytes == 4)
   uint64_t n = 0;
   int pay_bytes = 0;               // 0, 4 or 8
+  int key_source = kSrKeys, pay_source = kSrKeys;  // SrSource (pay_source: 8-byte payloads only)
   // ping-pong space of the partition passes: pass i writes k[i & 1] / p[i & 1].  k[1] / p[1] may be the input arrays
   // (they are read by pass 0 only): the keys then come back permuted, each with its payload
   uint64_t *k[2] = {nullptr, nullptr};
@@ -162,6 +182,7 @@ struct SrPlaced {  // where the job's keys / payloads lay when the last pass rea
 };
 size_t sr_workspace_bytes(uint64_t n);
 uint64_t sr_roomy_elems(uint64_t n);  // elements of k[i] / p[i] an optimistic job wants
+bool sr_optimistic_applies(uint64_t n);  // would a job of n keys with optimistic = true and that room take it?
 int sr_partials_count();
 hipError_t sr_run(const SrJob &job, void *workspace, size_t workspace_bytes, hipStream_t stream, SrPlaced *placed);
 

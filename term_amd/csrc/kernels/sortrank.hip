@@ -235,7 +235,7 @@ __device__ __forceinline__ uint64_t sr_mix(uint64_t x) {
 // one key from each of ns stretches that together cover ALL n positions (an input in order -- the second ranking of a
 // correlated pair reads its keys grouped by the first -- has its largest keys at the end: a sample that stops short of
 // it leaves them to one huge last bucket)
-__global__ void sr_sample_kernel(const uint64_t *keys, uint64_t n, uint64_t ns, uint64_t *out) {
+__global__ void sr_sample_kernel(const uint64_t *keys, uint64_t n, uint64_t ns, uint64_t *out, int source) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= ns) return;
   // n = ns * q + r: the first r stretches hold q + 1 keys, the others q
@@ -243,7 +243,7 @@ __global__ void sr_sample_kernel(const uint64_t *keys, uint64_t n, uint64_t ns, 
   const uint64_t b = k * q + (k < r ? k : r), len = q + (k < r ? 1 : 0);
   uint64_t pos = b + (len > 1 ? sr_mix(k + 0x9E3779B97F4A7C15ull) % len : 0);
   if (pos >= n) pos = n - 1;
-  out[k] = keys[pos];
+  out[k] = sr_source_key(keys[pos], source);
 }
 __global__ void sr_pick_kernel(const uint64_t *sorted, uint64_t count, uint32_t every, uint64_t *fine) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
 #pragma unroll
     for (int u = 0; u < kSrPartPer; u++) {
       const uint64_t i = (uint64_t)r.begin + u * kSrPartThreads + tid;
-      k[u] = i < end ? __builtin_nontemporal_load(L.keys_in + i) : 0ull;
+      k[u] = i < end ? sr_source_key(__builtin_nontemporal_load(L.keys_in + i), L.key_source) : 0ull;
     }
   };
   auto flush = [&]() {
@@ -589,7 +589,8 @@ __global__ __launch_bounds__(512) void sr_offsets_kernel(SrLevel L) {
 // next tile's keys are requested before this tile's are searched
 // (three workgroups a CU are six waves a SIMD: 80 registers each -- at 82 the third workgroup does not fit and the
 // pass takes 10.5 instead of 7 ms)
-template <int PB>
+// SRC: the keys (and 8-byte payloads) are column values (SrLevel::key_source; pass 0 of a job over a lent batch)
+template <int PB, bool SRC>
 __global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void sr_scatter_kernel(SrLevel L) {
   __shared__ uint64_t sp[kSrMaxSplit + 1];
   __shared__ uint64_t stage_k[kSrTile];
@@ -629,6 +630,10 @@ __global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(
       const bool ok = i < end;
       k[u] = ok ? __builtin_nontemporal_load(L.keys_in + i) : 0ull;
       if (PB == 8) q8[u] = ok ? __builtin_nontemporal_load(pin8 + i) : 0ull;
+      if (SRC) {
+        k[u] = sr_source_key(k[u], L.key_source);
+        if (PB == 8) q8[u] = sr_source_key(q8[u], L.pay_source);
+      }
       if (PB == 4) q4[u] = (ok && pin4) ? __builtin_nontemporal_load(pin4 + i) : (uint32_t)i;
     }
   };
@@ -754,11 +759,11 @@ __global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buc
   if (*(volatile const uint32_t *)L.status) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t rows = L.level == 0 ? 1ull : (uint64_t)L.nparts;  // (pass 0: row 0 holds the buckets' sizes)
-  const uint64_t e = (uint64_t)blockIdx.x * 256 + tid, total = rows * L.nb;
+  const uint32_t e = blockIdx.x * 256u + tid, total = (uint32_t)(rows * L.nb);  // (at most 511^3 entries)
   uint32_t cnt = 0, st = 0;
   bool eq = false;
   if (e < total) {
-    const uint32_t p = (uint32_t)(e / L.nb), v = (uint32_t)(e % L.nb);
+    const uint32_t p = e / L.nb, v = e - p * L.nb;
     const bool part_eq = L.level == 0 ? false : sr_part_info(L, p).eq;
     if (!(part_eq && v > 0)) cnt = L.tot[e];
     eq = part_eq || (v & 1u);
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(256) void sr_items_kernel(SrLevel L, uint64_t n_buc
   uint64_t lo = 0, hi = 0;
   bool edge = false;
   if (cnt && !eq) {
-    const uint32_t p = (uint32_t)(e / L.nb), v = (uint32_t)(e % L.nb);
+    const uint32_t p = e / L.nb, v = e - p * L.nb;
     const uint64_t g = (L.level == 0 ? 0ull : sr_part_info(L, p).first) + (v >> 1);  // (the last pass: stride 1)
     edge = g == 0 || g + 1 >= n_buckets;
     if (!edge) {
@@ -953,6 +958,7 @@ __global__ __launch_bounds__(kSrFastThreads) void sr_rank_small_kernel(SrFinal F
     }
   }
   uint32_t w = blockIdx.x, par = 0;
+  uint32_t dirty[2] = {0, 0};  // entries of each set of bins that are not zero
   const SrItem none = SrItem{0, 0, 0, 1, 0, 0};
   SrItem it = w < n_items ? F.items[w] : none;
   SrItem it_next = w + G < n_items ? F.items[w + G] : none;
@@ -993,16 +999,23 @@ __global__ __launch_bounds__(kSrFastThreads) void sr_rank_small_kernel(SrFinal F
       }
     } else {
       uint32_t *bins = bins2[par], *other = bins2[par ^ 1u];
+      const uint32_t dirty_other = dirty[par ^ 1u];
       par ^= 1u;
       const uint32_t m = it.count;
       const uint64_t kbase = it.lo + 1, span = it.hi - it.lo - 2;  // (lo < key < hi)
-      const int shift = span < (uint64_t)kBins ? 0 : (64 - (int)__builtin_clzll(span)) - kSrFastBinBits;
+      // as many bins as the bucket may hold keys, but no fewer than 512: scanning and clearing 2048 bins costs what
+      // ranking a thousand keys does, and a bucket of the aimed-at size has a thousand
+      const int bits = m > 1024u ? kSrFastBinBits : (m > 512u ? kSrFastBinBits - 1 : kSrFastBinBits - 2);
+      const uint32_t nbins = 1u << bits;
+      dirty[par] = 0;           // (par now names the other set: cleared below)
+      dirty[par ^ 1u] = nbins + 1;
+      const int shift = span < (uint64_t)nbins ? 0 : (64 - (int)__builtin_clzll(span)) - bits;
       uint32_t slot[kSrFastPer];
 #pragma unroll
       for (int u = 0; u < kSrFastPer; u++)
         if (tid + u * kSrFastThreads < m) slot[u] = atomicAdd(&bins[(uint32_t)((key[u] - kbase) >> shift)], 1u);
       __syncthreads();
-      sr_block_scan8<kSrFastThreads>(bins, kBins, 0u, true, wsum);
+      sr_block_scan8<kSrFastThreads>(bins, nbins, 0u, true, wsum);
 #pragma unroll
       for (int u = 0; u < kSrFastPer; u++)
         if (tid + u * kSrFastThreads < m) {
@@ -1010,7 +1023,8 @@ __global__ __launch_bounds__(kSrFastThreads) void sr_rank_small_kernel(SrFinal F
           skey[slot[u]] = key[u];
         }
       __syncthreads();
-      for (uint32_t v = tid; v < (uint32_t)kBins + 1; v += kSrFastThreads) other[v] = 0;  // (the next bucket's bins)
+      // (the next bucket's bins, as far as the bucket before this one wrote them)
+      for (uint32_t v = tid; v < dirty_other; v += kSrFastThreads) other[v] = 0;
 #pragma unroll
       for (int u = 0; u < kSrFastPer; u++) {
         if (tid + u * kSrFastThreads >= m) continue;
@@ -1278,6 +1292,8 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
   const uint64_t roomy = sr_roomy_elems(n);
   const bool optimistic = job.optimistic && tune.optimistic && sh.levels >= 2 && job.cap[0] >= roomy &&
                           job.cap[1] >= roomy && roomy <= 0xFFFFFFF0ull;
+  // (column values as keys: only pass 0 reads them, and only a job that never writes where it reads may be given any)
+  if ((job.key_source != kSrKeys || job.pay_source != kSrKeys) && !optimistic) return hipErrorInvalidValue;
   const uint64_t *keys = job.keys;
   const void *pay = job.pay;
   if (sh.levels == 0) {
@@ -1297,7 +1313,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
     sj.out_keys = sorted;
     if (!dry)
       hipLaunchKernelGGL(sr_sample_kernel, dim3((unsigned)((sh.ns + 255) / 256)), dim3(256), 0, stream, job.keys, n, sh.ns,
-                         samp);
+                         samp, job.key_source);
     hipError_t e = sr_run_impl(sj, ws, stream, tune, dry, nullptr, depth + 1);
     if (e != hipSuccess) return e;
     if (!dry)
@@ -1313,6 +1329,8 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
       const bool guess = optimistic && lv + 1 < sh.levels;  // this pass takes its buckets' room from the sample
       L.keys_in = keys;
       L.pay_in = pay;
+      L.key_source = lv == 0 ? job.key_source : (int)kSrKeys;
+      L.pay_source = lv == 0 ? job.pay_source : (int)kSrKeys;
       L.keys_out = job.k[lv & 1];
       L.pay_out = job.p[lv & 1];
       L.out_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(job.cap[lv & 1], n), 0xFFFFFFF0ull);
@@ -1376,6 +1394,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
       uint32_t *sample_size = nullptr;
       if (lv == 0) {
         LS.keys_in = samp;
+        LS.key_source = kSrKeys;  // (the sample holds sort keys)
         LS.pbeg = sample_start;
         LS.pend = sample_start + 1;
         LS.tile_cap = (uint32_t)(sh.ns / kSrTile + L.nparts + 16);
@@ -1412,12 +1431,19 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
           hipLaunchKernelGGL(sr_scan_parts_kernel, dim3(1), dim3(1024), 0, stream, L);
           hipLaunchKernelGGL(sr_offsets_kernel, dim3((L.nparts + 7) / 8), dim3(512), 0, stream, L);
         }
-        if (job.pay_bytes == 8)
-          hipLaunchKernelGGL(sr_scatter_kernel<8>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        const bool src = L.key_source != kSrKeys || L.pay_source != kSrKeys;
+        if (job.pay_bytes == 8 && src)
+          hipLaunchKernelGGL((sr_scatter_kernel<8, true>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        else if (job.pay_bytes == 8)
+          hipLaunchKernelGGL((sr_scatter_kernel<8, false>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        else if (job.pay_bytes == 4 && src)
+          hipLaunchKernelGGL((sr_scatter_kernel<4, true>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
         else if (job.pay_bytes == 4)
-          hipLaunchKernelGGL(sr_scatter_kernel<4>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+          hipLaunchKernelGGL((sr_scatter_kernel<4, false>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        else if (src)
+          hipLaunchKernelGGL((sr_scatter_kernel<0, true>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
         else
-          hipLaunchKernelGGL(sr_scatter_kernel<0>, dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+          hipLaunchKernelGGL((sr_scatter_kernel<0, false>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
       }
       keys = L.keys_out;
       pay = L.pay_out;
@@ -1505,6 +1531,10 @@ int sr_partials_count() { return sr_small_grid() + sr_large_grid(); }
 
 // the buckets of a pass that takes their room from the sample lie apart: about a quarter more than the keys
 uint64_t sr_roomy_elems(uint64_t n) { return n + n / 3 + (8u << 20); }
+bool sr_optimistic_applies(uint64_t n) {
+  const SrTuning t = sr_tuning();
+  return t.optimistic && n <= 0xFFFFFFF0ull && sr_roomy_elems(n) <= 0xFFFFFFF0ull && sr_shape(n, t).levels >= 2;
+}
 
 size_t sr_workspace_bytes(uint64_t n) {
   Carver c{nullptr};

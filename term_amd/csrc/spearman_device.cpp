@@ -25,7 +25,26 @@ namespace {
 struct SpearmanPlan {
   std::vector<SpearmanTask> tasks;
 };
+// A first batch without NULLs whose columns lie in the caller's DEVICE memory is not copied: the state keeps a view, and
+// the first ranking's first pass reads the columns themselves (kernels/sortrank.h, SrSource) -- the pass that used to
+// write the converted pairs (32 GB moved per 1 G pairs) is gone, and the pairs the state owns afterwards are the first
+// ranking's output.  Another batch, a synchronisation or a reduction across ranks first turns the view into pairs.
+struct LentBatch {
+  const void *x = nullptr, *y = nullptr;  // element 0 of the batch's rows
+  int64_t length = 0;
+  bool x_is_float = false, y_is_float = false;
+};
 struct SpearmanTaskState {
+  LentBatch lent;
+  unsigned long long count_seed[2] = {0, 0};  // (source of a copy to `count`: lives as long as the state)
+  // after the ranking of a lent batch: the pairs lie in two of the state's work arrays (and stay there while this is
+  // the only task and nothing else wants the arrays: a state that is reset next never pays for a change of owners)
+  DevBuf *work_x = nullptr, *work_y = nullptr;
+  uint64_t work_pairs = 0;
+  // the last result, until a batch arrives or the state is reset
+  bool cached = false;
+  uint64_t cached_pairs = 0;
+  double cached_out[5];
   DevBuf kx, ky, count;
   uint64_t capacity = 0;     // pairs the buffers can hold
   uint64_t rows_upper = 0;   // host-side bound on pairs appended so far
@@ -124,16 +143,84 @@ void spearman_state_reset(tgx_state *st) {
     t.rows_upper = 0;
     t.total_rows = 0;
     t.resolved = false;
+    t.lent = LentBatch();
+    t.work_x = t.work_y = nullptr;
+    t.cached = false;
     if (t.count.p) (void)hipMemsetAsync(t.count.p, 0, 8, st->stream);
   }
 }
 
-tgx_status spearman_update(tgx_state *st, const tgx_column *dev, tgx_error *err) {
+namespace {
+// the pairs of `length` rows without NULLs behind the pairs the task holds
+tgx_status append_rows(tgx_state *st, SpearmanTaskState &ts, const void *xv, const void *yv, const uint8_t *xval,
+                       const uint8_t *yval, int64_t xoff, int64_t yoff, int64_t length, bool x_is_float, bool y_is_float,
+                       tgx_error *err) {
+  if (!ts.count.p) {
+    SHIP(ts.count.reserve(16));
+    SHIP(hipMemsetAsync(ts.count.p, 0, 16, st->stream));
+  }
+  const uint64_t need = ts.rows_upper + (uint64_t)length;
+  if (need > ts.capacity) {
+    const uint64_t cap = std::max<uint64_t>(need, ts.capacity * 2);
+    DevBuf nx, ny;
+    SHIP(nx.reserve(cap * 8));
+    SHIP(ny.reserve(cap * 8));
+    if (ts.capacity && ts.rows_upper) {
+      SHIP(hipMemcpyAsync(nx.p, ts.kx.p, ts.rows_upper * 8, hipMemcpyDeviceToDevice, st->stream));
+      SHIP(hipMemcpyAsync(ny.p, ts.ky.p, ts.rows_upper * 8, hipMemcpyDeviceToDevice, st->stream));
+      SHIP(hipStreamSynchronize(st->stream));
+    }
+    ts.kx = std::move(nx);
+    ts.ky = std::move(ny);
+    ts.capacity = cap;
+  }
+  ComomentColDesc d;
+  d.x = xv;
+  d.y = yv;
+  d.xv = xval;
+  d.yv = yval;
+  d.xoff = xoff;
+  d.yoff = yoff;
+  d.length = length;
+  d.x_is_float = x_is_float;
+  d.y_is_float = y_is_float;
+  launch_spearman_compact(d, ts.kx.as<uint64_t>(), ts.ky.as<uint64_t>(), ts.count.as<unsigned long long>(), st->stream);
+  ts.rows_upper = need;
+  return TGX_OK;
+}
+tgx_status resolve_lent(tgx_state *st, SpearmanTaskState &ts, tgx_error *err) {
+  if (ts.work_x) {  // the pairs a ranking left in the work arrays become the state's (the arrays change owners)
+    std::swap(*ts.work_x, ts.kx);
+    std::swap(*ts.work_y, ts.ky);
+    ts.capacity = std::min(ts.kx.cap, ts.ky.cap) / 8;
+    ts.rows_upper = ts.work_pairs;
+    ts.work_x = ts.work_y = nullptr;
+    if (!ts.count.p) SHIP(ts.count.reserve(16));
+    ts.count_seed[0] = ts.work_pairs;
+    ts.count_seed[1] = 0;
+    SHIP(hipMemcpyAsync(ts.count.p, ts.count_seed, 16, hipMemcpyHostToDevice, st->stream));
+  }
+  if (!ts.lent.length) return TGX_OK;
+  const LentBatch b = ts.lent;
+  ts.lent = LentBatch();
+  return append_rows(st, ts, b.x, b.y, nullptr, nullptr, 0, 0, b.length, b.x_is_float, b.y_is_float, err);
+}
+}  // namespace
+
+tgx_status spearman_resolve_all(tgx_state *st, tgx_error *err) {
+  if (!st->spearman) return TGX_OK;
+  for (auto &ts : sstate(st)->tasks) STRY(resolve_lent(st, ts, err));
+  return TGX_OK;
+}
+
+tgx_status spearman_update(tgx_state *st, const tgx_column *dev, const tgx_column *columns, bool lendable,
+                           tgx_error *err) {
   if (!st->plan->spearman) return TGX_OK;
   const SpearmanPlan *sp = splan(st->plan);
   SpearmanState *ss = sstate(st);
   for (size_t i = 0; i < sp->tasks.size(); i++) {
     const tgx_column &x = dev[sp->tasks[i].col_x], &y = dev[sp->tasks[i].col_y];
+    const tgx_column &ox = columns[sp->tasks[i].col_x], &oy = columns[sp->tasks[i].col_y];
     SpearmanTaskState &ts = ss->tasks[i];
     auto numeric = [](int t) { return t == TGX_INT64 || t == TGX_FLOAT64; };
     if (!numeric(x.type) || !numeric(y.type))
@@ -142,37 +229,22 @@ tgx_status spearman_update(tgx_state *st, const tgx_column *dev, tgx_error *err)
       return sfail(err, TGX_UNSUPPORTED, "SPEARMAN: the state holds the result of a cross-rank reduction; reset it first");
     ts.total_rows += x.length;
     if (x.length == 0) continue;
-    if (!ts.count.p) {
-      SHIP(ts.count.reserve(16));
-      SHIP(hipMemsetAsync(ts.count.p, 0, 16, st->stream));
+    ts.cached = false;
+    STRY(resolve_lent(st, ts, err));  // (a second batch: the first becomes pairs of the state's own)
+    // the first batch, in the caller's own DEVICE buffers, without NULLs, large enough for the ranking to take it
+    const bool lend = lendable && ts.rows_upper == 0 && !x.validity && !y.validity && ox.mem == TGX_MEM_DEVICE &&
+                      oy.mem == TGX_MEM_DEVICE && x.values == ox.values && y.values == oy.values &&
+                      (uint64_t)x.length >= sr_tuning().optimistic_min && sr_optimistic_applies((uint64_t)x.length);
+    if (lend) {
+      ts.lent.x = (const int64_t *)x.values + x.offset;
+      ts.lent.y = (const int64_t *)y.values + y.offset;
+      ts.lent.length = x.length;
+      ts.lent.x_is_float = x.type == TGX_FLOAT64;
+      ts.lent.y_is_float = y.type == TGX_FLOAT64;
+      continue;
     }
-    const uint64_t need = ts.rows_upper + (uint64_t)x.length;
-    if (need > ts.capacity) {
-      const uint64_t cap = std::max<uint64_t>(need, ts.capacity * 2);
-      DevBuf nx, ny;
-      SHIP(nx.reserve(cap * 8));
-      SHIP(ny.reserve(cap * 8));
-      if (ts.capacity) {
-        SHIP(hipMemcpyAsync(nx.p, ts.kx.p, ts.rows_upper * 8, hipMemcpyDeviceToDevice, st->stream));
-        SHIP(hipMemcpyAsync(ny.p, ts.ky.p, ts.rows_upper * 8, hipMemcpyDeviceToDevice, st->stream));
-        SHIP(hipStreamSynchronize(st->stream));
-      }
-      ts.kx = std::move(nx);
-      ts.ky = std::move(ny);
-      ts.capacity = cap;
-    }
-    ComomentColDesc d;
-    d.x = x.values;
-    d.y = y.values;
-    d.xv = x.validity;
-    d.yv = y.validity;
-    d.xoff = x.offset;
-    d.yoff = y.offset;
-    d.length = x.length;
-    d.x_is_float = x.type == TGX_FLOAT64;
-    d.y_is_float = y.type == TGX_FLOAT64;
-    launch_spearman_compact(d, ts.kx.as<uint64_t>(), ts.ky.as<uint64_t>(), ts.count.as<unsigned long long>(), st->stream);
-    ts.rows_upper = need;
+    STRY(append_rows(st, ts, x.values, y.values, x.validity, y.validity, x.offset, y.offset, x.length,
+                     x.type == TGX_FLOAT64, y.type == TGX_FLOAT64, err));
   }
   return TGX_OK;
 }
@@ -195,8 +267,21 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
     return TGX_OK;
   }
   r->total = ts.total_rows;
+  if (ts.cached) {  // (nothing arrived since the last ranking)
+    r->non_null = (int64_t)ts.cached_pairs;
+    const double *c = ts.cached_out;
+    r->sum_x = c[0];
+    r->sum_y = c[1];
+    r->sum_x2 = c[2];
+    r->sum_y2 = c[3];
+    r->sum_xy = c[4];
+    return TGX_OK;
+  }
   unsigned long long m = 0;
-  if (ts.count.p) {
+  bool lent = ts.lent.length > 0;
+  if (lent) {
+    m = (unsigned long long)ts.lent.length;  // (no NULLs: every row is a pair)
+  } else if (ts.count.p) {
     SHIP(hipMemcpyAsync(&m, ts.count.p, 8, hipMemcpyDeviceToHost, st->stream));
     SHIP(hipStreamSynchronize(st->stream));
   }
@@ -230,7 +315,12 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (want > have && free_b < want - have + (2ull << 30)))
       optimistic = false;
   }
+  if (lent && !optimistic) {  // (no room for a ranking that leaves its input alone: pairs of the state's own first)
+    STRY(resolve_lent(st, ts, err));
+    lent = false;
+  }
   std::vector<RankSumsHost> h(blocks);
+  SrPlaced at;
   for (int attempt = 0; attempt < 2; attempt++) {
     const uint64_t elems = optimistic ? roomy : m;
     SHIP(ka.reserve(elems * 8));
@@ -242,8 +332,12 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
       SHIP(pc.reserve(elems * 8));
     }
     SrJob jx;
-    jx.keys = ts.kx.as<uint64_t>();
-    jx.pay = ts.ky.p;
+    jx.keys = lent ? (const uint64_t *)ts.lent.x : ts.kx.as<uint64_t>();
+    jx.pay = lent ? ts.lent.y : ts.ky.p;
+    if (lent) {  // the caller's columns, made sort keys as the first pass reads them
+      jx.key_source = ts.lent.x_is_float ? kSrFloat64 : kSrInt64;
+      jx.pay_source = ts.lent.y_is_float ? kSrFloat64 : kSrInt64;
+    }
     jx.n = m;
     jx.pay_bytes = 8;
     jx.k[0] = ka.as<uint64_t>();
@@ -257,7 +351,6 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
     jx.status = d_status;
     jx.sink = kSrRank32;
     jx.rank32 = rank32.as<uint32_t>();
-    SrPlaced at;
     SHIP(sr_run(jx, temp.p, temp_bytes, st->stream, &at));
     SrJob jy;
     jy.keys = (const uint64_t *)at.pay;  // the y keys, slot for slot beside rank32
@@ -269,7 +362,8 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
                           optimistic ? pc.as<uint64_t>() : nullptr};
     int took = 0;
     for (int c = 0; c < 4 && took < 2; c++)
-      if (spare[c] && (!optimistic || (const void *)spare[c] != at.pay)) jy.k[took++] = spare[c];
+      if (spare[c] && (!optimistic || (const void *)spare[c] != at.pay) && (!lent || spare[c] != at.keys))
+        jy.k[took++] = spare[c];  // (a lent batch: the x keys are kept too -- the state's pairs from now on)
     // (counted buckets: k[1] may be where the y keys lie now -- they are read by the first pass only)
     jy.p[0] = ra.p;
     jy.p[1] = rb.p;
@@ -287,7 +381,28 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
     if (!optimistic) return sfail(err, TGX_INTERNAL, "SPEARMAN: the ranking failed with counted buckets (status %u, %u)",
                                   status[0], status[1]);
     optimistic = false;  // a bucket outgrew the room its share of the sample gave it: once more, counting
+    if (lent) {
+      STRY(resolve_lent(st, ts, err));
+      lent = false;
+    }
     if (getenv("TGX_SORT_DEBUG")) fprintf(stderr, "tgx sort: a bucket was full (status %u, %u): again with counted buckets\n", status[0], status[1]);
+  }
+  if (lent) {
+    // the first ranking left every x beside its y, as sort keys, in two of the work arrays: the state's pairs from now
+    // on, the view of the caller's batch is dropped
+    DevBuf *work[4] = {&ka, &pa, &kc, &pc}, *bx = nullptr, *by = nullptr;
+    for (DevBuf *b : work) {
+      if (b->p == (const void *)at.keys) bx = b;
+      if (b->p == at.pay) by = b;
+    }
+    if (!bx || !by || bx == by) return sfail(err, TGX_INTERNAL, "SPEARMAN: the ranking's output is not where it was expected");
+    ts.work_x = bx;
+    ts.work_y = by;
+    ts.work_pairs = m;
+    ts.rows_upper = m;
+    ts.lent = LentBatch();
+    // (another task ranks in the same arrays next)
+    if (sstate(st)->tasks.size() > 1) STRY(resolve_lent(st, ts, err));
   }
   double out[5];
   for (int k = 0; k < 5; k++) {
@@ -298,7 +413,10 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
       e += ((unsigned __int128)p.exact_hi[k] << 64) | p.exact_lo[k];
     }
     out[k] = exact ? (double)e : (double)w;
+    ts.cached_out[k] = out[k];
   }
+  ts.cached = true;
+  ts.cached_pairs = m;
   r->sum_x = out[0];
   r->sum_y = out[1];
   r->sum_x2 = out[2];
@@ -445,6 +563,7 @@ tgx_status spearman_allreduce(tgx_state *st, const SpearmanExchange &X, std::vec
                               tgx_error *err) {
   out->clear();
   if (!st->plan->spearman) return TGX_OK;
+  STRY(spearman_resolve_all(st, err));  // (the exchange reads the state's own pairs)
   const SpearmanPlan *sp = splan(st->plan);
   SpearmanState *ws = sstate(st);
   hipStream_t s = st->device_ready ? st->stream : nullptr;

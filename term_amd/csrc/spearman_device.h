@@ -17,7 +17,12 @@ void spearman_mark_used(const tgx_plan *plan, std::vector<char> &used, std::vect
 void spearman_state_init(tgx_state *st);
 void spearman_state_free(tgx_state *st);
 void spearman_state_reset(tgx_state *st);
-tgx_status spearman_update(tgx_state *st, const tgx_column *dev_columns, tgx_error *err);
+// `columns`: the batch as the caller handed it over; lendable: its DEVICE buffers stay as they are until the next
+// tgx_finalize / tgx_state_sync (include/tgx.h) -- not a flush's gathered columns, not a producer that recycles buffers
+tgx_status spearman_update(tgx_state *st, const tgx_column *dev_columns, const tgx_column *columns, bool lendable,
+                           tgx_error *err);
+// a batch the state only holds a view of becomes pairs of its own (the caller may release the batch after this)
+tgx_status spearman_resolve_all(tgx_state *st, tgx_error *err);
 tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_error *err);
 // rank-based states are not mergeable (TG/analyzers/advanced/correlation.rs:103-109): TGX_UNSUPPORTED when non-empty
 tgx_status spearman_check_mergeable(tgx_state *st, tgx_error *err);

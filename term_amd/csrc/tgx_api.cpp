@@ -528,6 +528,7 @@ extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
   TGX_TRY(coalesce_flush(st, err));  // batches tgx_update has only noted so far
   if (st->device_ready) {
     TGX_TRY(distinct_resolve_all(st, err));  // the caller may release its DEVICE batches after this call
+    TGX_TRY(spearman_resolve_all(st, err));
     HIP_TRY(hipStreamSynchronize(st->stream));
   }
   return TGX_OK;

@@ -774,7 +774,7 @@ tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *co
     for (size_t s = 0; s < plan->kll.size(); s++)
       if (!kll_fused[s]) TGX_TRY(kll_update(st, s, dev[plan->kll[s].column], err));
     // ---- Spearman: keep the pairs, rank at finalize ----
-    TGX_TRY(spearman_update(st, dev.data(), err));
+    TGX_TRY(spearman_update(st, dev.data(), columns, !st->coalesce.flushing && !g_ctx.no_coalesce, err));
   }
   st->batches++;
   if (arena_in_use) {

@@ -277,3 +277,58 @@ def test_ranking_room_from_the_sample_at_size():
     y = rng.integers(0, 300, size=n).astype(np.float64) + (np.arange(n) % 7 == 0) * rng.random(n)
     _check_spearman(x, y)
     _check_spearman(y, x)
+
+
+# ---- a first DEVICE batch without NULLs is lent, not copied (spearman_device.cpp, LentBatch) ------------------------
+@pytest.mark.parametrize("kind", SORT_KINDS)
+def test_ranking_straight_from_the_callers_columns(kind, monkeypatch, capfd):
+    for k, v in ROOMY_SHAPES["three_passes"].items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("TGX_SORT_OPTIMISTIC_MIN", "1")
+    n = 40_000
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("lent/%s" % kind).encode()))
+    x = _sort_data(kind, n, rng)
+    y = _sort_data(SORT_KINDS[(SORT_KINDS.index(kind) + 4) % len(SORT_KINDS)], n, rng)
+    _check_spearman(x, y)  # (its second finalize ranks the pairs the state has adopted from the first ranking)
+    # the caller's columns are only read
+    cols = [numeric_column(x, None, True), numeric_column(y, None, True)]
+    res, _, _ = run_plan([spec(T.SPEARMAN, 0, column2=1)], [cols])
+    for col, host in zip(cols, (x, y)):
+        assert (col._keep[0].cpu().numpy().view(np.uint8) == host.view(np.uint8)).all()
+
+
+@pytest.mark.parametrize("between", ["nothing", "sync", "finalize"])
+def test_lent_batch_then_more_batches(between, monkeypatch):
+    """the view of the first batch becomes pairs of the state's own when another batch arrives, at a synchronisation
+    (the caller may free the batch then), or with the first result"""
+    monkeypatch.setenv("TGX_SORT_OPTIMISTIC_MIN", "1000")
+    rng = np.random.default_rng({"nothing": 1, "sync": 2, "finalize": 3}[between])
+    n, cut = 300_000, 200_000
+    x = rng.standard_normal(n)
+    y = np.round(rng.standard_normal(n) + x, 2)
+    yv = orc.pack_validity(np.concatenate([np.ones(cut, bool), rng.random(n - cut) >= 0.1]))
+    T.init()
+    plan = T.Plan([spec(T.SPEARMAN, 0, column2=1)])
+    st = T.State(plan)
+    first = [numeric_column(x, None, True, offset=0, length=cut), numeric_column(y, None, True, offset=0, length=cut)]
+    st.update(first)
+    if between == "sync":
+        st.sync()
+        first = None  # (the device copies may go)
+    elif between == "finalize":
+        want = orc.spearman_state(x[:cut], y[:cut], None, None)
+        got = st.finalize()[0]
+        assert (got.non_null, got.sum_x, got.sum_y2, got.sum_xy) == (want.n, want.sum_x, want.sum_y2, want.sum_xy)
+        first = None
+    st.update([numeric_column(x, None, True, offset=cut, length=n - cut),
+               numeric_column(y, yv, True, offset=cut, length=n - cut)])
+    want = orc.spearman_state(x, y, None, yv)
+    got = st.finalize()[0]
+    assert (got.total, got.non_null) == (n, want.n)
+    assert (got.sum_x, got.sum_y, got.sum_x2, got.sum_y2, got.sum_xy) == \
+        (want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy)
+    st.reset()
+    st.update([numeric_column(x, None, True, offset=0, length=cut), numeric_column(y, None, True, offset=0, length=cut)])
+    st.reset()  # (a view dropped unread)
+    assert st.finalize()[0].non_null == 0

@@ -12,7 +12,10 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "tgx::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last step starts at the last spearman_convert / compact kernel
-last = max(i for i, r in enumerate(rows) if "spearman_co" in r["Kernel_Name"])
+# the last step starts at its convert / compact kernel, or -- a lent batch -- at the first ranking's sample
+conv = [i for i, r in enumerate(rows) if "spearman_co" in r["Kernel_Name"]]
+big = [i for i, r in enumerate(rows) if "sr_sample_kernel" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 100000]
+last = max(conv) if conv and (not big or max(conv) > big[-2]) else big[-2]
 t0 = int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
