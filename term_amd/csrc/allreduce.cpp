@@ -173,14 +173,18 @@ tgx_status deadline_sync(tgx_comm *c, hipStream_t s, const char *what, tgx_error
     if (q == hipSuccess) return TGX_OK;
     if (q != hipErrorNotReady)
       return fail(err, TGX_DEVICE_ERROR, "tgx_allreduce: waiting for %s failed: %s", what, hipGetErrorString(q));
-    if (spins < 4096) continue;  // (the usual wait is tens of microseconds: poll; then back off)
-    const int64_t ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if ((spins & 63) != 63) continue;  // (polling costs a fraction of a microsecond: look at the clock now and then)
+    const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    // the usual wait is the rest of the step's scan, a few milliseconds at most: poll that long (a sleep of 20 us is
+    // 70 with the timer's slack, and the step's tail is a handful of such waits), then back off
+    if (us < 20000) continue;
+    const int64_t ms = us / 1000;
     if (ms > limit)
       return fail(err, TGX_DEVICE_ERROR,
                   "tgx_allreduce: %s did not complete within %lld ms on rank %d of %d (a peer has failed or left the "
                   "step, or the transport is stuck); the state and the communicator are unusable",
                   what, (long long)limit, c->ops.rank, c->ops.world);
-    std::this_thread::sleep_for(std::chrono::microseconds(ms < 2 ? 20 : 200));
+    std::this_thread::sleep_for(std::chrono::microseconds(ms < 100 ? 50 : 500));
   }
 }
 

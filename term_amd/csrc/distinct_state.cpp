@@ -402,7 +402,7 @@ tgx_status pinned_readback(tgx_state *st, size_t bytes, tgx_error *err) {
 // does this batch of an undecided Int64 key set get its range from a sample? (see distinct_prepare_numeric)
 bool distinct_wants_sample(const DistinctState &ds, const tgx_column &c) {
   return ds.mode == DistinctMode::kUndecided && c.type == TGX_INT64 && !ds.has_hint && !ds.batch_range_known &&
-         c.length >= (1 << 16);
+         !ds.remembered && c.length >= (1 << 16);
 }
 // ... or the exact MIN / MAX of a coalesced flush whose key windows were DEVICE memory?  While the key set is undecided,
 // or a bitmap no batch can have left outliers under: the flush then lays the bitmap out / grows it like a HOST flush
@@ -549,6 +549,10 @@ tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column
       have_range = true;  // a coalesced flush of HOST windows: the host saw every value on its way into the arena
       lo = ds.batch_lo;
       hi = ds.batch_hi;
+    } else if (c.type == TGX_INT64 && ds.remembered && c.length >= (1 << 16)) {
+      have_range = true;  // what the column's sample said before the state was reset; outliers are repaired as ever
+      lo = ds.remembered_lo;
+      hi = ds.remembered_hi;
     } else if (distinct_wants_sample(ds, c)) {
       // (a stream of small batches -- DataFusion hands out 8192 rows at a time -- goes straight to the hash set:
       // its inserts need no range, and the read-back of a sample would cost one stream synchronisation per batch)
@@ -607,8 +611,14 @@ tgx_status distinct_prepare_numeric(tgx_state *st, size_t slot, const tgx_column
       }
       ds.mode = DistinctMode::kBitmap;
       ds.speculative = !ds.has_hint;
+      if (ds.speculative && !ds.batch_range_known) {
+        ds.remembered = true;
+        ds.remembered_lo = lo;
+        ds.remembered_hi = hi;
+      }
     } else {
       ds.mode = DistinctMode::kHash;
+      ds.remembered = false;
     }
   }
   // a later batch whose range the host knows and the bitmap does not cover (ids that grow from batch to batch): the
@@ -841,6 +851,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
   }
   const int64_t old_base = ds.base;
   const uint64_t old_range = ds.range;
+  ds.remembered = false;  // (the range was not the column's)
   TGX_TRY(bitmap_to_hash(st, ds, mult, n_out, err));
   TGX_TRY(hash_ensure(st, ds, mult, n_out, err));
   for (const tgx_column &kept : ds.retained) {

@@ -304,6 +304,11 @@ struct DistinctState {
   // batches retained here -- DEVICE views, which the caller keeps alive until tgx_finalize / tgx_state_sync
   // (include/tgx.h); HOST batches are resolved before tgx_update returns.
   bool speculative = false;
+  // the sampled extremes the bitmap was last laid out over.  They outlive tgx_state_reset: the next first batch of the
+  // column takes them instead of a sample of its own (a read-back, i.e. the stream's latency, at the start of every
+  // step of a runner that checks table after table of one shape); forgotten as soon as a repair finds a key outside
+  bool remembered = false;
+  int64_t remembered_lo = 0, remembered_hi = 0;
   // some batch since the last look at the counters may have left keys outside the bitmap's range (its range was a
   // sample's, or unknown: DEVICE buffers).  The range must then stay as it is until they have been repaired: the
   // repair walks the retained batches for the keys outside the range, so a bitmap grown over them in the meantime

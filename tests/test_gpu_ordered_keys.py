@@ -83,3 +83,37 @@ def test_later_batches_of_keys_that_grow(stats):
     assert (res[0].total, res[0].distinct, res[0].groups_once) == (d.total, d.distinct, d.groups_once)
     if stats:
         check_stats(res[1], orc.stats(ids))
+
+
+@pytest.mark.parametrize("mult", [False, True])
+def test_a_reset_state_remembers_the_range_it_sampled(mult):
+    """A state that is reset keeps the extremes its key column's sample showed and lays the next table's bitmap out over
+    them without a sample (no read-back at the start of the step).  The next table may be anything: the same ids
+    shuffled, ids from elsewhere (every key an outlier: repaired, the range forgotten), a slightly wider range, sparse
+    keys -- the counts are the oracle's each time."""
+    rng = np.random.default_rng(77 + mult)
+    n = 1_500_000
+    tables = [
+        rng.permutation(n).astype(np.int64),                                 # the range is learned
+        rng.permutation(n).astype(np.int64),                                 # ... and fits
+        rng.permutation(n).astype(np.int64) + 10**9,                         # nothing fits
+        rng.permutation(n).astype(np.int64) + 10**9,                         # (learned anew)
+        np.concatenate([rng.permutation(n - 5).astype(np.int64) + 10**9,     # five keys far outside
+                        np.array([-3, 5, 2 * 10**9, 2 * 10**9, 7], dtype=np.int64)]),
+        rng.integers(-2**62, 2**62, size=n, dtype=np.int64),                 # no dense range at all
+        rng.integers(0, n // 10, size=n, dtype=np.int64),                    # dense again, heavy repeats
+    ]
+    flags = T.FLAG_MULTIPLICITY if mult else 0
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0, flags=flags), spec(T.NUMERIC_STATS, 0)])
+    st = T.State(plan)
+    for vals in tables:
+        st.reset()
+        cols = [numeric_column(vals, None, True)]
+        st.update(cols)
+        res = st.finalize()
+        d = orc.distinct_bits64(vals.view(np.uint64), None, n=len(vals))
+        assert (res[0].total, res[0].non_null, res[0].distinct) == (d.total, d.non_null, d.distinct)
+        if mult:
+            assert res[0].groups_once == d.groups_once
+        check_stats(res[1], orc.stats(vals, None))
