@@ -19,7 +19,9 @@
  *   - column buffers follow the Arrow C Data Interface layout (LSB-first validity bitmap, NULL
  *     when the array has no nulls; `offset` counts slots and applies to validity and values alike).
  *   - the caller owns column buffers; HOST buffers may be released when tgx_update returns, DEVICE
- *     buffers must stay alive until the next tgx_finalize / tgx_state_sync on that state.
+ *     buffers must stay alive AND UNMODIFIED until the next tgx_finalize / tgx_state_sync on that
+ *     state (work is queued, small batches are only noted, a key set may walk a batch a second
+ *     time, a SPEARMAN pair's first batch is ranked from the columns themselves: see tgx_update).
  *   - handles are not thread-safe; distinct handles are independent.  One HIP stream per state.
  *   - there is NO CPU fallback: without a usable gfx950 device tgx_init fails with TGX_NO_DEVICE
  *     and every compute entry point fails with it too.

@@ -13,8 +13,10 @@ run python tools/bench_tuples.py                      # multi-column uniqueness
 run python tools/bench_distinct.py --rows 100000000 --steps 3 --sparse-rows 100000000   # uniqueness passes alone; sparse keys
 run python tools/bench_kll.py
 run python tools/bench_numeric32.py                   # Int32 / Float32 columns next to Int64 / Float64
-run python tools/bench_spearman.py --ranks 8       # + the distributed ranking over 8 threaded ranks on this one GPU
+run python tools/bench_spearman.py --ranks 8       # 100 M pairs + the distributed ranking over 8 threaded ranks on this one GPU
+run python tools/bench_spearman.py --rows 1000000000 --steps 3   # 1 G pairs
 run build/feed_batches                                # 8192-row batches through the C ABI from plain C (make -C tools): the coalescing rates
 run python tools/bench_batches.py                     # the same through the Python binding (a ctypes call costs 2-4 us)
 run python tools/bench_host_batches.py                # PCIe-inclusive rate
-run python tools/bench_host_strings.py                # a HOST Utf8 column streamed in 8192-row batches through a format check
+run build/feed_strings                                # a HOST string column as Utf8 / Utf8View / Dictionary in 8192-row batches, plain C
+run python tools/bench_host_strings.py                # the same through the Python binding

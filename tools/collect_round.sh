@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/collect_round.sh rNN   -- everything profiles/ holds for a round, from the tree as it is (one MI355X, ~25 min):
-#   gpurun --timeout 2700 -- 'bash tools/collect_round.sh r03'
+#   gpurun --timeout 2700 -- 'bash tools/collect_round.sh r04'
 tag=$1
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
@@ -16,6 +16,9 @@ for c in C2 C4 C5; do
 done
 bash tools/prof_any.sh ${tag}_ordered tools/bench_distinct.py --rows 1000000000 --steps 3 --ordered-only > gpurun_out/${tag}_prof_ordered.txt 2>&1
 bash tools/prof_any.sh ${tag}_distinct tools/bench_distinct.py --rows 1000000000 --steps 3 --sparse-rows 1000000000 > gpurun_out/${tag}_prof_distinct.txt 2>&1
+bash tools/prof_any.sh ${tag}_spearman tools/bench_spearman.py --rows 1000000000 --steps 3 > gpurun_out/${tag}_prof_spearman.txt 2>&1
+bash tools/exp_sort_trace.sh 1000000000 TGX_SORT_DEBUG=1 > gpurun_out/${tag}_spearman_timeline.txt 2>&1
+bash tools/trace_step_api.sh --force-distributed --rows 125000000 --steps 6 --warmup 3 2>&1 | grep -v hipEventQuery > gpurun_out/${tag}_shard_step_tail.txt
 python tools/sim_bench_ranks.py > gpurun_out/${tag}_sim_ranks.txt 2>&1
 python bench.py > gpurun_out/${tag}_bench_1gpu.json 2> gpurun_out/${tag}_bench_1gpu.err
 tail -3 gpurun_out/${tag}_gpu_tests.txt; tail -c 600 gpurun_out/${tag}_bench_1gpu.json
