@@ -248,16 +248,30 @@ tgx_status coalesce_prepare_window(const tgx_column &c, int64_t nrows, const Coa
                                           WindowPrep *w, tgx_error *err) {
   if (c.type == TGX_UTF8_VIEW) {
     const int32_t *v = (const int32_t *)c.values + (size_t)c.offset * 4;
+    // (a window's long views point into one buffer, two where it crosses from one into the next: the buffer of the view
+    // before is looked at first, its size kept at hand)
+    int k = -1;
+    int32_t kb = -1;
+    int64_t ksize = 0;
     for (int64_t i = 0; i < nrows; i++, v += 4) {
       const int32_t len = v[0];
       if (len <= 12) continue;
       if (c.validity && !((c.validity[(c.offset + i) >> 3] >> ((c.offset + i) & 7)) & 1)) continue;
       const int32_t b = v[2];
       const int64_t off = v[3], end = off + len;
+      if (b == kb) {
+        if (off < 0 || end > ksize)
+          return fail(err, TGX_INVALID_ARGUMENT, "column %d: a view of row %lld points outside its data buffers", col, (long long)i);
+        if (off < w->vb_min[k]) w->vb_min[k] = off;
+        if (end > w->vb_end[k]) w->vb_end[k] = end;
+        continue;
+      }
       if (b < 0 || b >= c.n_variadic || off < 0 || end > c.variadic_sizes[b])
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: a view of row %lld points outside its data buffers", col, (long long)i);
-      int k = 0;
+      k = 0;
       while (k < w->vb_count && w->vb_index[k] != b) k++;
+      kb = b;
+      ksize = c.variadic_sizes[b];
       if (k == w->vb_count) {
         if (k == kGatherViewBufs) {
           w->ok = false;
