@@ -349,7 +349,13 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   }
   const bool any_host = traits.any_host;
   // (a flush in here empties the pending lists -- the dictionaries' too: what the windows bring is then looked at again)
-  std::vector<WindowPrep> prep(plan->n_columns_needed);
+  // (scratch that lives with the thread: tgx_update notes a DEVICE batch in half a microsecond, and three heap
+  // allocations per call were a third of that)
+  static thread_local std::vector<WindowPrep> prep_tls;
+  static thread_local std::vector<size_t> rb_segs, rb_dict_segs;
+  static thread_local std::vector<int64_t> rb_data_bytes;
+  if (prep_tls.size() < (size_t)plan->n_columns_needed) prep_tls.resize(plan->n_columns_needed);
+  std::vector<WindowPrep> &prep = prep_tls;
   for (int attempt = 0;; attempt++) {
     const uint64_t flushes_before = co.flushes;
     for (int i = 0; i < plan->n_columns_needed; i++) {
@@ -409,11 +415,15 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   }
   struct Rollback {  // (a host allocation that throws while the windows are noted)
     Coalescer &co;
-    std::vector<size_t> segs, dict_segs;
-    std::vector<int64_t> data_bytes;
+    std::vector<size_t> &segs, &dict_segs;
+    std::vector<int64_t> &data_bytes;
     size_t arena_used;
     bool armed = true;
-    explicit Rollback(Coalescer &c) : co(c), arena_used(c.arena_used) {
+    Rollback(Coalescer &c, std::vector<size_t> &s, std::vector<size_t> &d, std::vector<int64_t> &b)
+        : co(c), segs(s), dict_segs(d), data_bytes(b), arena_used(c.arena_used) {
+      segs.clear();
+      dict_segs.clear();
+      data_bytes.clear();
       for (auto &cc : co.cols) {
         segs.push_back(cc.segs.size());
         dict_segs.push_back(cc.dict ? cc.dict->segs.size() : 0);
@@ -424,6 +434,11 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       if (!armed) return;
       for (size_t i = 0; i < co.cols.size(); i++) {
         co.cols[i].segs.resize(segs[i]);
+        if (!co.cols[i].stretches.empty()) {  // (a Utf8View column: one entry per segment)
+          size_t keep = 0;
+          for (const CoalesceSegment &sg : co.cols[i].segs) keep = std::max(keep, (size_t)(sg.stretches + 1));
+          co.cols[i].stretches.resize(keep);
+        }
         co.cols[i].data_bytes = data_bytes[i];
         co.cols[i].range_known = false;  // (a MIN / MAX of rows that are not pending after all is only too wide)
         if (co.cols[i].dict && co.cols[i].dict->segs.size() > dict_segs[i]) {
@@ -435,7 +450,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       }
       co.arena_used = arena_used;
     }
-  } rollback(co);
+  } rollback(co, rb_segs, rb_dict_segs, rb_data_bytes);
   // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!plan->used[i] || columns[i].type != TGX_UTF8_VIEW) continue;
@@ -481,14 +496,17 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
     if (c.type == TGX_UTF8_VIEW) {
       // the views as they are, and the stretches of the data buffers they point into (host is true: update_validate)
       sg.values = to_arena((const uint8_t *)c.values + (size_t)c.offset * 16, (size_t)nrows * 16);
-      sg.vb_count = prep[i].vb_count;
+      CoalesceStretches vs;
+      vs.vb_count = prep[i].vb_count;
       for (int k = 0; k < prep[i].vb_count; k++) {
-        sg.vb_index[k] = prep[i].vb_index[k];
-        sg.vb_min[k] = prep[i].vb_min[k];
-        sg.vb_len[k] = prep[i].vb_end[k] - prep[i].vb_min[k];
-        sg.vb_src[k] = (const uint8_t *)to_arena(c.variadic[prep[i].vb_index[k]] + prep[i].vb_min[k], (size_t)sg.vb_len[k]);
-        sg.data_len += (sg.vb_len[k] + 15) & ~(int64_t)15;  // (every stretch lands 16-byte aligned)
+        vs.vb_index[k] = prep[i].vb_index[k];
+        vs.vb_min[k] = prep[i].vb_min[k];
+        vs.vb_len[k] = prep[i].vb_end[k] - prep[i].vb_min[k];
+        vs.vb_src[k] = (const uint8_t *)to_arena(c.variadic[prep[i].vb_index[k]] + prep[i].vb_min[k], (size_t)vs.vb_len[k]);
+        sg.data_len += (vs.vb_len[k] + 15) & ~(int64_t)15;  // (every stretch lands 16-byte aligned)
       }
+      sg.stretches = (int32_t)cc.stretches.size();
+      cc.stretches.push_back(vs);
       cc.data_bytes += sg.data_len;
     } else if (c.type == TGX_DICT32_UTF8) {
       if (!cc.dict) cc.dict.reset(new CoalesceDict());
@@ -709,15 +727,16 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
       d.elem_bytes = (int32_t)ew;
       d.kind = str ? (cc.type == TGX_UTF8 ? 1 : 2) : vw ? 3 : dct ? 4 : 0;
       if (vw) {  // the window's stretches one behind the other, each 16-byte aligned
-        d.vb_count = sg.vb_count;
+        const CoalesceStretches &vs = cc.stretches[(size_t)sg.stretches];
+        d.vb_count = vs.vb_count;
         int64_t at = data_at;
-        for (int k = 0; k < sg.vb_count; k++) {
-          d.vb_index[k] = sg.vb_index[k];
-          d.vb_min[k] = sg.vb_min[k];
-          d.vb_len[k] = sg.vb_len[k];
-          d.vb_src[k] = sg.vb_src[k];
+        for (int k = 0; k < vs.vb_count; k++) {
+          d.vb_index[k] = vs.vb_index[k];
+          d.vb_min[k] = vs.vb_min[k];
+          d.vb_len[k] = vs.vb_len[k];
+          d.vb_src[k] = vs.vb_src[k];
           d.vb_base[k] = at;
-          at += (sg.vb_len[k] + 15) & ~(int64_t)15;
+          at += (vs.vb_len[k] + 15) & ~(int64_t)15;
         }
       }
       d.index_shift = sg.index_shift;
@@ -816,6 +835,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   // the pending list is empty from here on (update_impl may come back to tgx::coalesce_flush through a resolve)
   for (auto &cc : co.cols) {
     cc.segs.clear();
+    cc.stretches.clear();
     cc.any_validity = false;
     cc.data_bytes = 0;
     cc.range_known = true;
@@ -871,6 +891,7 @@ void coalesce_drop(tgx_state *st) {  // reset / destroy: pending batches are for
   Coalescer &co = st->coalesce;
   for (auto &cc : co.cols) {
     cc.segs.clear();
+    cc.stretches.clear();
     cc.any_validity = false;
     cc.data_bytes = 0;
     cc.range_known = true;

@@ -380,12 +380,16 @@ struct CoalesceSegment {
   int64_t bit0;             // first validity bit within *validity
   int64_t length;
   int64_t data_first, data_len;
-  // Utf8View windows: the stretches of the variadic buffers the long views point into (GatherSeg, kind 3)
+  int32_t index_shift = 0;  // dictionary index windows: first entry of the window's dictionary in the coalesced one
+  int32_t stretches = -1;   // Utf8View windows: index into the column's `stretches`
+};
+// a Utf8View window's stretches of the variadic buffers its long views point into (GatherSeg, kind 3); kept beside the
+// segments, not in them: a segment is noted per (column, batch), half a microsecond a batch all told
+struct CoalesceStretches {
   int32_t vb_count = 0;
   int32_t vb_index[kGatherViewBufs] = {0, 0, 0, 0};
   int64_t vb_min[kGatherViewBufs] = {0, 0, 0, 0}, vb_len[kGatherViewBufs] = {0, 0, 0, 0};
   const uint8_t *vb_src[kGatherViewBufs] = {nullptr, nullptr, nullptr, nullptr};
-  int32_t index_shift = 0;  // dictionary index windows: first entry of the window's dictionary in the coalesced one
 };
 // the dictionaries of a Dictionary<Int32, Utf8> column's pending windows, coalesced like a Utf8 column of their own
 struct CoalesceDict {
@@ -405,6 +409,7 @@ struct CoalesceColumn {
   bool any_validity = false;
   int64_t data_bytes = 0;   // strings: value bytes pending
   std::vector<CoalesceSegment> segs;
+  std::vector<CoalesceStretches> stretches;  // (Utf8View columns)
   DevBuf values[2], validity[2], data[2];  // the coalesced column, per region set
   const uint8_t *view_buf[2] = {nullptr, nullptr};  // Utf8View: the coalesced column's one data buffer (`variadic`)
   std::unique_ptr<CoalesceDict> dict;               // Dictionary<Int32, Utf8>
