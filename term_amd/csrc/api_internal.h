@@ -70,6 +70,7 @@ struct NumericPrep {
 
 struct BatchTraits {
   bool any_host = false, any_utf8 = false;
+  bool any_strings = false;  // a used column is Utf8 / LargeUtf8 / Utf8View / a dictionary
   bool coalescible = true;  // every used column is of a kind the segment gather takes (kernels/gather.hip)
 };
 

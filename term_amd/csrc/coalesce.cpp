@@ -358,7 +358,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   std::vector<WindowPrep> &prep = prep_tls;
   for (int attempt = 0;; attempt++) {
     const uint64_t flushes_before = co.flushes;
-    for (int i = 0; i < plan->n_columns_needed; i++) {
+    for (int i = 0; traits.any_strings && i < plan->n_columns_needed; i++) {
       prep[i] = WindowPrep();
       if (!plan->used[i] || (columns[i].type != TGX_UTF8_VIEW && columns[i].type != TGX_DICT32_UTF8)) continue;
       TGX_TRY(coalesce_prepare_window(columns[i], nrows, co.cols[i], i, &prep[i], err));
@@ -388,7 +388,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       }
     }
     // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
-    for (int i = 0; i < plan->n_columns_needed; i++) {
+    for (int i = 0; traits.any_strings && i < plan->n_columns_needed; i++) {
       if (!plan->used[i] || columns[i].type != TGX_UTF8_VIEW) continue;
       int64_t bytes = 0;
       for (int k = 0; k < prep[i].vb_count; k++) bytes += prep[i].vb_end[k] - prep[i].vb_min[k] + 16;
@@ -404,7 +404,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   // everything that can refuse the batch is checked BEFORE the first column notes its window: a batch is noted for all
   // columns or for none (a column with one segment more than its neighbours would make the next flush's gather write
   // past the coalesced buffers)
-  for (int i = 0; i < plan->n_columns_needed; i++) {
+  for (int i = 0; traits.any_strings && i < plan->n_columns_needed; i++) {
     if (!plan->used[i] || !is_string(columns[i].type)) continue;
     const tgx_column &c = columns[i];
     const size_t ow = c.type == TGX_UTF8 ? 4 : 8;
@@ -418,9 +418,11 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
     std::vector<size_t> &segs, &dict_segs;
     std::vector<int64_t> &data_bytes;
     size_t arena_used;
-    bool armed = true;
-    Rollback(Coalescer &c, std::vector<size_t> &s, std::vector<size_t> &d, std::vector<int64_t> &b)
-        : co(c), segs(s), dict_segs(d), data_bytes(b), arena_used(c.arena_used) {
+    bool armed;
+    // (`needed` is false for a batch of DEVICE numeric windows: its segments go into reserved room, nothing can throw)
+    Rollback(Coalescer &c, std::vector<size_t> &s, std::vector<size_t> &d, std::vector<int64_t> &b, bool needed)
+        : co(c), segs(s), dict_segs(d), data_bytes(b), arena_used(c.arena_used), armed(needed) {
+      if (!needed) return;
       segs.clear();
       dict_segs.clear();
       data_bytes.clear();
@@ -450,7 +452,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       }
       co.arena_used = arena_used;
     }
-  } rollback(co, rb_segs, rb_dict_segs, rb_data_bytes);
+  } rollback(co, rb_segs, rb_dict_segs, rb_data_bytes, any_host || traits.any_strings);
   // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
   for (int i = 0; i < plan->n_columns_needed; i++) {
     if (!plan->used[i] || columns[i].type != TGX_UTF8_VIEW) continue;

@@ -224,6 +224,7 @@ tgx_status update_validate(const tgx_plan *plan, tgx_state *st, const tgx_column
     const bool host = c.mem == TGX_MEM_HOST;
     traits->any_host |= host;
     traits->any_utf8 |= c.type == TGX_UTF8;
+    traits->any_strings |= is_any_string(c.type) || c.type == TGX_DICT32_UTF8;
     // string windows need their first / last offsets (Utf8View: the stretches its views point into; dictionaries:
     // theirs) on the host: HOST batches only (what DataFusion streams); DEVICE strings keep the immediate path
     traits->coalescible &= is_numeric(c.type) || is_numeric32(c.type) || (is_string(c.type) && host) ||
