@@ -589,8 +589,9 @@ __global__ __launch_bounds__(512) void sr_offsets_kernel(SrLevel L) {
 // next tile's keys are requested before this tile's are searched
 // (three workgroups a CU are six waves a SIMD: 80 registers each -- at 82 the third workgroup does not fit and the
 // pass takes 10.5 instead of 7 ms)
-// SRC: the keys (and 8-byte payloads) are column values (SrLevel::key_source; pass 0 of a job over a lent batch)
-template <int PB, bool SRC>
+// KS / PS: what the keys / the 8-byte payloads are (SrSource; column values in pass 0 of a job over a lent batch) -- an
+// instance per kind: with the kind a run-time value the Int64 conversion's registers pushed the kernel over its 80
+template <int PB, int KS, int PS>
 __global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void sr_scatter_kernel(SrLevel L) {
   __shared__ uint64_t sp[kSrMaxSplit + 1];
   __shared__ uint64_t stage_k[kSrTile];
@@ -630,10 +631,8 @@ __global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(
       const bool ok = i < end;
       k[u] = ok ? __builtin_nontemporal_load(L.keys_in + i) : 0ull;
       if (PB == 8) q8[u] = ok ? __builtin_nontemporal_load(pin8 + i) : 0ull;
-      if (SRC) {
-        k[u] = sr_source_key(k[u], L.key_source);
-        if (PB == 8) q8[u] = sr_source_key(q8[u], L.pay_source);
-      }
+      if (KS != kSrKeys) k[u] = sr_source_key(k[u], KS);
+      if (PB == 8 && PS != kSrKeys) q8[u] = sr_source_key(q8[u], PS);
       if (PB == 4) q4[u] = (ok && pin4) ? __builtin_nontemporal_load(pin4 + i) : (uint32_t)i;
     }
   };
@@ -1431,19 +1430,27 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
           hipLaunchKernelGGL(sr_scan_parts_kernel, dim3(1), dim3(1024), 0, stream, L);
           hipLaunchKernelGGL(sr_offsets_kernel, dim3((L.nparts + 7) / 8), dim3(512), 0, stream, L);
         }
-        const bool src = L.key_source != kSrKeys || L.pay_source != kSrKeys;
-        if (job.pay_bytes == 8 && src)
-          hipLaunchKernelGGL((sr_scatter_kernel<8, true>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
-        else if (job.pay_bytes == 8)
-          hipLaunchKernelGGL((sr_scatter_kernel<8, false>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
-        else if (job.pay_bytes == 4 && src)
-          hipLaunchKernelGGL((sr_scatter_kernel<4, true>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
-        else if (job.pay_bytes == 4)
-          hipLaunchKernelGGL((sr_scatter_kernel<4, false>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
-        else if (src)
-          hipLaunchKernelGGL((sr_scatter_kernel<0, true>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
-        else
-          hipLaunchKernelGGL((sr_scatter_kernel<0, false>), dim3(grid), dim3(kSrPartThreads), 0, stream, L);
+        // (an instance per kind of source: see sr_scatter_kernel)
+#define TGX_SR_SCATTER(PB, KS, PS) \
+  hipLaunchKernelGGL((sr_scatter_kernel<PB, KS, PS>), dim3(grid), dim3(kSrPartThreads), 0, stream, L)
+        const int ks = L.key_source, ps = job.pay_bytes == 8 ? L.pay_source : (int)kSrKeys;
+        if (job.pay_bytes == 8) {
+          if (ks == kSrKeys && ps == kSrKeys) TGX_SR_SCATTER(8, kSrKeys, kSrKeys);
+          else if (ks == kSrFloat64 && ps == kSrFloat64) TGX_SR_SCATTER(8, kSrFloat64, kSrFloat64);
+          else if (ks == kSrFloat64 && ps == kSrInt64) TGX_SR_SCATTER(8, kSrFloat64, kSrInt64);
+          else if (ks == kSrInt64 && ps == kSrFloat64) TGX_SR_SCATTER(8, kSrInt64, kSrFloat64);
+          else if (ks == kSrInt64 && ps == kSrInt64) TGX_SR_SCATTER(8, kSrInt64, kSrInt64);
+          else return hipErrorInvalidValue;  // (keys that are sort keys beside payloads that are not: nobody asks)
+        } else if (job.pay_bytes == 4) {
+          if (ks == kSrKeys) TGX_SR_SCATTER(4, kSrKeys, kSrKeys);
+          else if (ks == kSrFloat64) TGX_SR_SCATTER(4, kSrFloat64, kSrKeys);
+          else TGX_SR_SCATTER(4, kSrInt64, kSrKeys);
+        } else {
+          if (ks == kSrKeys) TGX_SR_SCATTER(0, kSrKeys, kSrKeys);
+          else if (ks == kSrFloat64) TGX_SR_SCATTER(0, kSrFloat64, kSrKeys);
+          else TGX_SR_SCATTER(0, kSrInt64, kSrKeys);
+        }
+#undef TGX_SR_SCATTER
       }
       keys = L.keys_out;
       pay = L.pay_out;
