@@ -173,23 +173,27 @@ __device__ __forceinline__ void sr_buckets(const uint64_t *sp, const uint32_t *l
     lo[u] = in ? (e & 0xFFFFu) : (key[u] < q.dom_lo ? 0u : q.S - q.edge);
     hi[u] = in ? (e >> 16) : (key[u] < q.dom_lo ? q.edge : q.S);
   }
+  // (selects, not branches: a step is a read and four selects for every key of the lane, open or not -- with an `if`
+  // per key the loop was mostly exec-mask bookkeeping, and these kernels are bound by the instructions they issue)
   for (;;) {
     bool open = false;
 #pragma unroll
     for (int u = 0; u < N; u++) open = open || lo[u] < hi[u];
     if (__builtin_amdgcn_ballot_w64(open) == 0) break;
 #pragma unroll
-    for (int u = 0; u < N; u++)
-      if (lo[u] < hi[u]) {
-        const uint32_t mid = (lo[u] + hi[u]) >> 1;
-        if (sp[mid] < key[u])
-          lo[u] = mid + 1;
-        else
-          hi[u] = mid;
-      }
+    for (int u = 0; u < N; u++) {
+      const bool go = lo[u] < hi[u];
+      const uint32_t mid = (lo[u] + hi[u]) >> 1;  // (< S when go; <= S otherwise: sp[] is padded to kSrMaxSplit + 1)
+      const bool less = sp[mid] < key[u];
+      lo[u] = (go && less) ? mid + 1 : lo[u];
+      hi[u] = (go && !less) ? mid : hi[u];
+    }
   }
 #pragma unroll
-  for (int u = 0; u < N; u++) b[u] = 2u * lo[u] + ((lo[u] < q.S && sp[lo[u]] == key[u]) ? 1u : 0u);
+  for (int u = 0; u < N; u++) {
+    const uint32_t at = lo[u] < q.S ? lo[u] : q.S;  // (sp[S] is the padding: the largest key, never a real match below)
+    b[u] = 2u * lo[u] + ((lo[u] < q.S && sp[at] == key[u]) ? 1u : 0u);
+  }
 }
 
 // exclusive scan of a[0 .. 8 * THREADS) in LDS (entries past n read as 0), `add` on top; a[n] = the total + add when

@@ -450,6 +450,11 @@ class Case:
                                   (r.sum_xy, o.sum_xy)):
                     if math.isnan(want) or math.isinf(want):
                         assert math.isnan(got) or got == want, (e, got, want)
+                    elif abs(want) > 1e300 and math.isinf(got) and (got > 0) == (want > 0):
+                        # values next to DBL_MAX (the pool's 1e308, several times): the oracle adds in extended
+                        # precision, a sum in doubles -- the kernels', DataFusion's -- passes through infinity for
+                        # some orders of the same rows and stays there (seed 705910: -inf for -1.6e308)
+                        pass
                     else:
                         assert rel_err(got, want) < TOL or abs(got - want) < 1e-6, (e, got, want)
             elif what == "spearman":
