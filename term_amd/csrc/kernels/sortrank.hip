@@ -47,11 +47,15 @@ __device__ __forceinline__ uint32_t sr_below(uint64_t m) {  // set bits of m bel
 // on b are served by one LDS add of their count: the leader's group first, and on while the groups are worth it (keys
 // in order, few distinct values: an LDS atomic on ONE address retires every ~10 cycles, 64 lanes on it cost 600);
 // what is left (scattered keys: the first group is a lane or two) goes lane by lane.  Called by ALL lanes of the wave.
-__device__ __forceinline__ uint32_t sr_claim(uint32_t *cursor, uint32_t b, bool valid) {
+// `groups` (wave-uniform): look for lanes that agree at all; *paid: the first group was worth its add.  A partition
+// kernel looks on one tile in sixteen and goes on looking while it pays (keys in order, heavy ties); on scattered keys
+// the look costs a fifth of what the tile's keys cost otherwise.
+__device__ __forceinline__ uint32_t sr_claim(uint32_t *cursor, uint32_t b, bool valid, bool groups = true,
+                                             bool *paid = nullptr) {
   const uint32_t lane = sr_lane();
   uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
   uint32_t pos = 0;
-  while (todo) {  // (wave-uniform)
+  while (groups && todo) {  // (wave-uniform)
     const int leader = (int)__builtin_ctzll(todo);
     const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
     const uint64_t grp = __builtin_amdgcn_ballot_w64(valid && b == lb) & todo;
@@ -62,21 +66,23 @@ __device__ __forceinline__ uint32_t sr_claim(uint32_t *cursor, uint32_t b, bool 
     if ((grp >> lane) & 1ull) pos = base + sr_below(grp);
     todo &= ~grp;
     if (cnt < 8) break;
+    if (paid) *paid = true;
   }
   if ((todo >> lane) & 1ull) pos = atomicAdd(&cursor[b], 1u);
   return pos;
 }
 
 // the same without the positions (the counting pass): the lanes left over after the groups send adds that return nothing
-__device__ __forceinline__ void sr_tally(uint32_t *hist, uint32_t b, bool valid) {
+__device__ __forceinline__ void sr_tally(uint32_t *hist, uint32_t b, bool valid, bool groups, bool *paid) {
   const uint32_t lane = sr_lane();
   uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
-  while (todo) {  // (wave-uniform)
+  while (groups && todo) {  // (wave-uniform)
     const int leader = (int)__builtin_ctzll(todo);
     const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
     const uint64_t grp = __builtin_amdgcn_ballot_w64(valid && b == lb) & todo;
     const uint32_t cnt = (uint32_t)__builtin_popcountll(grp);
     if (cnt < 8) break;
+    *paid = true;
     if (lane == (uint32_t)leader) __hip_atomic_fetch_add(&hist[lb], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     todo &= ~grp;
   }
@@ -346,6 +352,8 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
       __syncthreads();
     }
   };
+  bool pays = true;   // (wave-uniform) lanes of this wave have lately agreed on buckets: sr_claim / sr_tally
+  uint32_t trip = 0;
   SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0, 0};
   uint32_t end = j0 < j1 ? tile_end(ref) : 0;
   uint64_t key[kSrPartPer];
@@ -369,9 +377,13 @@ __global__ __launch_bounds__(kSrPartThreads) void sr_count_kernel(SrLevel L) {
     if (q.S) {  // (an equality part is one bucket: the offsets kernel knows its size)
       uint32_t bk[kSrPartPer];
       sr_buckets<kSrPartPer>(sp, lut, q, key, bk);
+      const bool look = pays || (trip & 15u) == 0;
+      bool paid = false;
+      trip++;
 #pragma unroll
       for (int u = 0; u < kSrPartPer; u++)
-        sr_tally(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end);
+        sr_tally(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end, look, &paid);
+      if (look) pays = paid;
     }
     ref = nref;
     end = nend;
@@ -640,6 +652,8 @@ __global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(
       if (PB == 4) q4[u] = (ok && pin4) ? __builtin_nontemporal_load(pin4 + i) : (uint32_t)i;
     }
   };
+  bool pays = true;   // (wave-uniform) lanes of this wave have lately agreed on buckets: sr_claim / sr_tally
+  uint32_t trip = 0;
   SrTileRef ref = j0 < j1 ? tiles[j0] : SrTileRef{0, 0, 0};
   uint32_t end = j0 < j1 ? tile_end(ref) : 0;
   uint64_t key[kSrPartPer];
@@ -691,9 +705,14 @@ __global__ __launch_bounds__(kSrPartThreads) __attribute__((amdgpu_waves_per_eu(
     } else {
       uint32_t bk[kSrPartPer], rk[kSrPartPer];
       sr_buckets<kSrPartPer>(sp, lut, q, key, bk);
+      // (not with 8-byte payloads: that instance has no register to spare for the two words of state)
+      const bool look = PB == 8 || pays || (trip & 15u) == 0;
+      bool paid = false;
+      trip++;
 #pragma unroll
       for (int u = 0; u < kSrPartPer; u++)  // (the key's place inside its run)
-        rk[u] = sr_claim(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end);
+        rk[u] = sr_claim(hist, bk[u], (uint64_t)ref.begin + u * kSrPartThreads + tid < end, look, &paid);
+      if (look) pays = paid;
       __syncthreads();
       // one reservation per run -- its round trip runs under the scan and the regrouping: only the stores need it
       const uint32_t h = tid < 2 * S + 1 ? hist[tid] : 0u;
