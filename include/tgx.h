@@ -239,7 +239,10 @@ void tgx_plan_destroy(tgx_plan *plan);
 size_t tgx_plan_num_specs(const tgx_plan *plan);
 
 /* State = `Analyzer::State` for every spec of the plan (TG/analyzers/traits.rs:154-179).
- * `hip_stream` is a hipStream_t (NULL = a stream the library creates). */
+ * `hip_stream` is a hipStream_t (NULL = a stream the library creates).  Everything the state does on the device is
+ * queued on that stream and nowhere else: a DEVICE buffer handed to tgx_update has to be COMPLETE as far as that
+ * stream is concerned -- written by work on the same stream, or by work the caller has waited for (an event the stream
+ * waits on, or a synchronisation); the library's own stream does not wait for the legacy default stream. */
 tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **out, tgx_error *err);
 void tgx_state_destroy(tgx_state *state);
 

@@ -1306,7 +1306,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
   uint32_t *counters = ws.take<uint32_t>(8);  // [0] small items, [1] large items, [2] tiny items
   uint32_t *own_status = ws.take<uint32_t>(1);
   uint32_t *status = job.status ? job.status : own_status;
-  if (!dry) {
+  if (!dry && depth == 0) {  // (the sorts of the samples share the job's word: a failure anywhere is the job's)
     hipError_t e0 = hipMemsetAsync(status, 0, sizeof(uint32_t), stream);
     if (e0 != hipSuccess) return e0;
   }
@@ -1333,6 +1333,7 @@ hipError_t sr_run_impl(const SrJob &job, Carver &ws, hipStream_t stream, const S
     sj.k[1] = ws.take<uint64_t>(sh.ns);
     sj.sink = kSrSorted;
     sj.out_keys = sorted;
+    sj.status = status;
     if (!dry)
       hipLaunchKernelGGL(sr_sample_kernel, dim3((unsigned)((sh.ns + 255) / 256)), dim3(256), 0, stream, job.keys, n, sh.ns,
                          samp, job.key_source);

@@ -96,3 +96,60 @@ def test_c2_null_range_unique_suite_at_100m_rows():
     assert r2[16].total == N + 10_000_000 and r2[16].groups_once == N - 10_000_000
     del table
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [1_000_000_000, 300_000_017])
+def test_spearman_rank_sums_at_full_size_closed_forms(n):
+    """BASELINE's C4 carries a Spearman pair at 1 G rows: the oracle cannot rank that many, the domain can -- for
+    distinct x and y = -x, RANK(y) = n + 1 - RANK(x), so the five UInt64 sums (wrapping like the reference's,
+    correlation.rs:334-350) have closed forms; for y = x >> 8 (every y value 256 times, in x's order)
+    RANK(y) = 256 * (y's index) + 1.  The first call ranks straight from the columns (a lent batch), the second the
+    pairs the state has kept; the third pair arrives in three batches (nothing lent)."""
+    import torch
+
+    T.init()
+    M = 1 << 64
+    i = torch.arange(n, dtype=torch.int64, device="cuda")
+    x = (i * 0x9E3779B97F4A7) & ((1 << 52) - 1)  # an odd multiplier: a bijection of the residues modulo 2^52, exact as doubles
+    del i
+    s1, s2 = n * (n + 1) // 2, n * (n + 1) * (2 * n + 1) // 6
+    plan = T.Plan([spec(T.SPEARMAN, 0, column2=1)])
+
+    def sums(r):
+        return (r.non_null, r.sum_x, r.sum_y, r.sum_x2, r.sum_y2, r.sum_xy)
+
+    # ---- y = -x: ranks mirrored
+    y = -x
+    torch.cuda.synchronize()  # (the state works on a stream of its own: the columns have to be complete, include/tgx.h)
+    st = T.State(plan)
+    cols = [T.Column.int64(x, None, length=n), T.Column.int64(y, None, length=n)]
+    st.update(cols)
+    want = (n, float(s1 % M), float(s1 % M), float(s2 % M), float(s2 % M), float(((n + 1) * s1 - s2) % M))
+    assert sums(st.finalize()[0]) == want
+    assert sums(st.finalize()[0]) == want
+    del st, y, cols
+    # ---- y = x >> 8: tie runs of (up to) 256 -- min ranks: 1 + the number of pairs with a smaller y
+    xs = torch.sort(x).values
+    del x
+    ys = xs >> 8
+    uniq, counts = torch.unique_consecutive(ys, return_counts=True)
+    del uniq
+    starts = torch.cumsum(counts, 0) - counts  # pairs with a smaller y
+    ry = torch.repeat_interleave(starts + 1, counts)  # RANK(y) of the pairs in x's order
+    rx = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    del counts, starts
+
+    def msum(t):  # exact sum modulo 2^64 of a tensor of non-negative int64 values < 2^63 (int64 addition wraps)
+        return int(t.sum().item()) % M
+
+    want = (n, float(s1 % M), float(msum(ry)), float(s2 % M), float(msum(ry * ry)), float(msum(rx * ry)))
+    del rx, ry
+    torch.cuda.empty_cache()
+    st = T.State(plan)
+    cuts = [0, n // 3, n // 3 + 12345, n]
+    xf = xs.to(torch.float64)
+    del xs
+    torch.cuda.synchronize()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        st.update([T.Column.float64(xf, None, length=hi - lo, offset=lo), T.Column.int64(ys, None, length=hi - lo, offset=lo)])
+    assert sums(st.finalize()[0]) == want

@@ -33,6 +33,7 @@ def main():
     cols = [T.Column.float64(x, None, length=n), T.Column.float64(y, None, length=n)]
     plan = T.Plan([spec(T.SPEARMAN, 0, column2=1)])
     st = T.State(plan)
+    torch.cuda.synchronize()  # (the state works on a stream of its own: the columns have to be complete)
     st.update(cols)
     st.finalize()
     torch.cuda.synchronize()
