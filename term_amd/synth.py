@@ -137,6 +137,12 @@ def make_table(layout, row0, n, n_total, seed, device):
         vals = gen_column(kind, ci, row0, n, n_total, seed, device)
         validity = gen_validity(ci, row0, n, seed, device) if has_validity else None
         cols.append((vals, validity))
+    if str(device).startswith("cuda"):
+        # the columns are written by torch's stream; a tgx state works on a stream of its own and reads them as they
+        # are when its kernels run (include/tgx.h): hand them over complete
+        import torch
+
+        torch.cuda.synchronize()
     return cols
 
 
