@@ -332,3 +332,37 @@ def test_lent_batch_then_more_batches(between, monkeypatch):
     st.update([numeric_column(x, None, True, offset=0, length=cut), numeric_column(y, None, True, offset=0, length=cut)])
     st.reset()  # (a view dropped unread)
     assert st.finalize()[0].non_null == 0
+
+
+def test_two_lent_pairs_share_the_work_arrays(monkeypatch):
+    """two pairs of one plan, both lent: the second ranking runs in the arrays the first one's pairs were left in, so
+    the first pair's become the state's own before that; a third batch afterwards finds both sets of pairs intact"""
+    monkeypatch.setenv("TGX_SORT_OPTIMISTIC_MIN", "1000")
+    rng = np.random.default_rng(404)
+    n, more = 400_000, 50_000
+    a = rng.standard_normal(n + more)
+    b = np.round(a * 2 + rng.standard_normal(n + more), 1)
+    c = rng.integers(-1000, 1000, size=n + more).astype(np.int64)
+    T.init()
+    plan = T.Plan([spec(T.SPEARMAN, 0, column2=1), spec(T.SPEARMAN, 2, column2=0)])
+    st = T.State(plan)
+
+    def feed(lo, hi):
+        cols = [numeric_column(a, None, True, offset=lo, length=hi - lo), numeric_column(b, None, True, offset=lo, length=hi - lo),
+                numeric_column(c, None, True, offset=lo, length=hi - lo)]
+        st.update(cols)
+        return cols
+
+    def check(hi):
+        res = st.finalize()
+        for r, (x, y) in zip(res, ((a, b), (c, a))):
+            want = orc.spearman_state(x[:hi], y[:hi], None, None)
+            assert (r.non_null, r.sum_x, r.sum_y, r.sum_x2, r.sum_y2, r.sum_xy) == \
+                (want.n, want.sum_x, want.sum_y, want.sum_x2, want.sum_y2, want.sum_xy)
+
+    keep = feed(0, n)
+    check(n)
+    check(n)  # (the results kept)
+    keep = feed(n, n + more)
+    check(n + more)
+    del keep
