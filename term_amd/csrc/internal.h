@@ -85,6 +85,7 @@ void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_gather_segments(const GatherSeg *d_segs, int n_segs, hipStream_t stream);
+void launch_state_reset(const StateResetArgs &a, hipStream_t stream);
 int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
 void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
                             int64_t dict_length, int dict_has_nulls, const uint8_t *hits, int null_is_valid,

@@ -177,6 +177,18 @@ struct GatherSeg {
 };
 constexpr int kGatherViewBufs = 4;
 
+// tgx_state_reset: the small per-state accumulators back to their identities with ONE launch (a copy and five fills
+// were five trips through the runtime: 35 us of a 1.8 ms step)
+constexpr int kResetRegions = 8;
+struct StateResetArgs {
+  void *zero[kResetRegions];       // regions to clear (16-byte aligned allocations)
+  uint32_t zero_bytes[kResetRegions];
+  int32_t n_zero;
+  void *copy_dst;                  // the scan accumulators ...
+  const void *copy_src;            // ... and their identities
+  uint32_t copy_bytes;
+};
+
 __host__ __device__ inline int64_t f64_total_key(int64_t bits) {
   return bits ^ (int64_t)(((uint64_t)(bits >> 63)) >> 1);
 }

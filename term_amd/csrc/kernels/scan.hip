@@ -1421,4 +1421,23 @@ void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned
                        blocks_per_col, d_accs);
 }
 
+// ---- tgx_state_reset's device part (device_types.h, StateResetArgs) ----
+__global__ __launch_bounds__(256) void state_reset_kernel(StateResetArgs a) {
+  for (int r = 0; r < a.n_zero; r++) {
+    uint32_t *p = (uint32_t *)a.zero[r];
+    const uint32_t words = a.zero_bytes[r] >> 2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) p[i] = 0;
+  }
+  const uint32_t *src = (const uint32_t *)a.copy_src;
+  uint32_t *dst = (uint32_t *)a.copy_dst;
+  const uint32_t words = a.copy_bytes >> 2;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) dst[i] = src[i];
+}
+void launch_state_reset(const StateResetArgs &a, hipStream_t stream) {
+  uint32_t most = a.copy_bytes;
+  for (int r = 0; r < a.n_zero; r++) most = a.zero_bytes[r] > most ? a.zero_bytes[r] : most;
+  const unsigned blocks = most <= 4096u ? 1u : (most / 4096u > 64u ? 64u : most / 4096u);
+  hipLaunchKernelGGL(state_reset_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
 }  // namespace tgx

@@ -584,19 +584,26 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   if (st->device_ready && st->d_hll.p)
     HIP_TRY(hipMemsetAsync(st->d_hll.p, 0, plan->hll.size() * (size_t)kHllRegisters, st->stream));
   if (st->device_ready) {
+    // one launch for all the small accumulators (all sizes are multiples of four bytes)
+    StateResetArgs a;
+    memset(&a, 0, sizeof(a));
+    auto zero = [&](void *p, size_t bytes) {
+      if (!p || bytes == 0) return;
+      a.zero[a.n_zero] = p;
+      a.zero_bytes[a.n_zero] = (uint32_t)bytes;
+      a.n_zero++;
+    };
     if (!plan->scan.empty()) {
-      HIP_TRY(hipMemcpyAsync(st->d_scan_acc.p, st->d_scan_identity.p, plan->scan.size() * sizeof(ScanAcc),
-                             hipMemcpyDeviceToDevice, st->stream));
-      HIP_TRY(hipMemsetAsync(st->d_pivots.p, 0, plan->scan.size() * sizeof(double), st->stream));
-      HIP_TRY(hipMemsetAsync(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t), st->stream));
+      a.copy_dst = st->d_scan_acc.p;
+      a.copy_src = st->d_scan_identity.p;
+      a.copy_bytes = (uint32_t)(plan->scan.size() * sizeof(ScanAcc));
+      zero(st->d_pivots.p, plan->scan.size() * sizeof(double));
+      zero(st->d_pivot_set.p, plan->scan.size() * sizeof(int32_t));
     }
-    if (!plan->count.empty())
-      HIP_TRY(hipMemsetAsync(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc), st->stream));
-    if (!plan->como.empty())
-      HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
-    if (st->d_distinct_counters.p)
-      HIP_TRY(hipMemsetAsync(st->d_distinct_counters.p, 0,
-                             st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long), st->stream));
+    if (!plan->count.empty()) zero(st->d_count_acc.p, plan->count.size() * sizeof(CountAcc));
+    if (!plan->como.empty()) zero(st->d_como_acc.p, plan->como.size() * sizeof(ComomentAcc));
+    zero(st->d_distinct_counters.p, st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long));
+    if (a.n_zero || a.copy_bytes) launch_state_reset(a, st->stream);
   }
   return TGX_OK;
 } catch (...) {
