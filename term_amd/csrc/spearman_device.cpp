@@ -291,8 +291,6 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   SpearmanState *ws = sstate(st);
   // RANK(x) with y as the payload, then RANK(y) with RANK(x) as the payload, the five sums taken where the second
   // ranking ends: no rank is ever scattered back to its row and nothing is laid out in order (kernels/sortrank.hip).
-  // The first ranking's second partition pass writes back into the state's own arrays: the pairs come back permuted,
-  // every x still beside its y.  28 bytes of work buffers per pair.
   DevBuf &ka = ws->keys_sorted, &pa = ws->heads, &ra = ws->idx, &rb = ws->idx_sorted, &rank32 = ws->rank32,
          &temp = ws->temp, &partials = ws->partials, &kc = ws->rx, &pc = ws->ry;
   const int blocks = sr_partials_count();
@@ -305,7 +303,7 @@ tgx_status spearman_fill_result(tgx_state *st, int slot, tgx_result *r, tgx_erro
   // Bucket sizes from the sample instead of a counting read per pass (kernels/sortrank.h): the passes' buckets then lie
   // apart, in arrays a third larger, none of them the state's own (a pass that finds a bucket full leaves nothing
   // valid behind: the pairs have to be intact for the second try, with counted buckets).  Taken when the device has
-  // the room: 72 instead of 28 bytes of work buffers per pair.
+  // the room: ~57 instead of 28 bytes of work buffers per pair.
   const uint64_t roomy = sr_roomy_elems(m);
   bool optimistic = m >= sr_tuning().optimistic_min;
   if (optimistic) {
