@@ -13,14 +13,23 @@
 //              transaction per lane AND leaves 56 bytes of every line for somebody else to fill -- from another
 //              XCD's L2 that means a partial write per key (the first version did exactly that: 1.2 TB/s) -- so all
 //              tiles of one part are taken by workgroups of ONE XCD: the runs that complete each other's lines meet in
-//              that L2.  (Pass 0 has one part, the input; it is cut into 64 stretches, eight per XCD, each with its own
-//              range in every bucket.)
-//   rank       one 256-thread workgroup per bucket of ~1024 keys: the keys are binned in LDS by the leading 11 bits
-//              of (key - min of the bucket) -- a counting sort; two keys meet in a bin only if they are equal or agree
-//              in those bits, and those few are compared -- so a key's rank is (keys before the bucket) + (keys in
-//              lower bins) + (smaller keys in its bin).  The next bucket's keys are requested before the current
-//              one's are looked at.  A bucket that outgrew that kernel (more than twice the aim: one in ~10^3 at 16
-//              samples a bucket) goes to a larger, chunk-against-chunk kernel; equality buckets are not looked at.
+//              that L2.  (Pass 0 has one part, the input; it is cut into stretches, each with its own
+//              range in every bucket: one stretch per XCD.)
+//              Where a bucket starts has to be known before a key moves.  The last pass counts (a read of all keys:
+//              its buckets are the ranking kernels' work items and lie one behind the other); the passes before it
+//              take a bucket's size from its share of the SAMPLE plus 6.5 standard deviations (sr_room*): buckets
+//              then lie apart, a part is read in pieces, and a run that finds its bucket full raises the job's status
+//              word -- every later kernel returns at once and the caller runs the job again, counted (SrJob).
+//              These kernels are bound by the instructions they issue (~250 a key in a pass, ~110 in the count), not
+//              by bytes: the splitter search steps by selects, the look for lanes that agree on a bucket is taken on
+//              one tile in sixteen while it does not pay, the pass over column values (SrSource) is its own instance.
+//   rank       one 256-thread workgroup per bucket of ~1024 keys: the keys are binned in LDS by the leading bits of
+//              (key - lower splitter) -- a counting sort with as many bins as the bucket may hold keys; two keys meet
+//              in a bin only if they are equal or agree in those bits, and those few are compared -- so a key's rank
+//              is (keys before the bucket) + (keys in lower bins) + (smaller keys in its bin).  The next bucket's
+//              keys are requested before the current one's are looked at.  A bucket that outgrew that kernel (more
+//              than twice the aim: one in ~10^3 at 16 samples a bucket) goes to a larger, chunk-against-chunk kernel;
+//              equality buckets are not looked at.
 // What the last pass does with a rank is the job's sink (SrSink): the Spearman state ranks x with y as the payload,
 // then y with RANK(x) as the payload, and sums -- no rank ever finds its way back to a row (spearman_device.cpp).
 #include "sortrank.h"
