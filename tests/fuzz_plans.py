@@ -446,9 +446,18 @@ class Case:
                 _, y, yb, _, _ = self.cols[e[2]]
                 o = orc.comoments(vals, y, vb, yb, n=n)
                 assert int(r.non_null) == o.n, (e, r.non_null, o.n)
+                with np.errstate(all="ignore"):
+                    xa, ya = np.abs(np.asarray(vals, dtype=np.float64)), np.abs(np.asarray(y, dtype=np.float64))
+                    overflowing = bool(np.isinf(xa).any() or np.isinf(ya).any() or np.isinf(xa.max(initial=0.0) * ya.max(initial=0.0))
+                                       or np.isinf(xa.max(initial=0.0) ** 2) or np.isinf(ya.max(initial=0.0) ** 2))
                 for got, want in ((r.sum_x, o.sum_x), (r.sum_y, o.sum_y), (r.sum_x2, o.sum_x2), (r.sum_y2, o.sum_y2),
                                   (r.sum_xy, o.sum_xy)):
-                    if math.isnan(want) or math.isinf(want):
+                    if math.isnan(want) and math.isinf(got) and overflowing:
+                        # an infinity (or a product beyond DBL_MAX) among the pairs: the raw products the oracle -- and
+                        # DataFusion -- adds come out as +inf and -inf and cancel to NaN, the kernels' products about
+                        # the pair's pivot overflow with other signs and stay infinite (seed 2001332)
+                        pass
+                    elif math.isnan(want) or math.isinf(want):
                         assert math.isnan(got) or got == want, (e, got, want)
                     elif abs(want) > 1e300 and math.isinf(got) and (got > 0) == (want > 0):
                         # values next to DBL_MAX (the pool's 1e308, several times): the oracle adds in extended
