@@ -72,7 +72,9 @@ __device__ __forceinline__ void gather_bytes(uint8_t *__restrict__ dst, const ui
 }
 
 __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherSeg *__restrict__ segs) {
-  const GatherSeg g = segs[blockIdx.x];
+  // (by reference: the descriptor's arrays are indexed at run time in the Utf8View branch, and a copy of it would live
+  // in scratch memory -- 264 bytes written and read by every thread of every window, as much as a window's values)
+  const GatherSeg &g = segs[blockIdx.x];
   const int tid = threadIdx.x;
   if (g.length <= 0) return;
   // ---- validity: destination words [w0, w1] of this segment's rows ----
