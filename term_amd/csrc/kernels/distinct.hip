@@ -585,9 +585,13 @@ __device__ __forceinline__ void partition_outlier_stats(const PartitionParams &p
 }
 
 // 1024 threads x 32 keys, one workgroup per CU (152 KiB of LDS); any alignment, ragged last tile.
-template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS = false>
+// FORM: the probe's verdict (partition_init_kernel) picks one of two copies of the tile loop for the whole launch; they
+// are two KERNELS, launched one behind the other, the one whose form it is not leaving at once: in one kernel they
+// shared a register allocation and the form for keys in order paid for it (78 scratch loads per tile and thread)
+template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS, bool FORM_CLUSTERED>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
     PartitionParams p, unsigned long long *counters) {
+  if ((__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) != FORM_CLUSTERED) return;
   constexpr int kTile = THREADS * KPT;
   __shared__ uint32_t sorted[kTile];     // the tile, grouped by bucket
   __shared__ uint32_t hist[MAXP];        // pass 1: keys per bucket; pass 2: placement cursors
@@ -736,11 +740,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                                                       [] {}, [] {});
   }
   };
-  // the probe's verdict (partition_init_kernel): two copies of the loop, the flag picks one for the whole launch
-  if (__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]))
-    tile_loop(std::true_type{});
-  else
-    tile_loop(std::false_type{});
+  tile_loop(std::integral_constant<bool, FORM_CLUSTERED>{});
   if (STATS) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1215,8 +1215,12 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   //  with spills 3.3 ms, as 512 threads x 64 keys with 256 registers 6.0 ms, and spill-free 2.9 ms against
   //  2.7 ms without: the load and store phases already run at HBM rate and the other CUs fill the gaps)
 #define TGX_PART(VAL, K16, ST)                                                                                      \
-  hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16, ST>), \
-                     dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters)
+  do {                                                                                                              \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16, ST, false>), \
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16, ST, true>), \
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+  } while (0)
   if (p.stats) {
     if (p.key16) {
       if (p.validity) TGX_PART(true, true, true); else TGX_PART(false, true, true);
