@@ -18,7 +18,7 @@
 #include <string.h>
 
 #include "tgx_oracle.h"
-#include "unicode_tables.h"
+#include "unicode_oracle_tables.h"
 
 #define MAXCP 0x10FFFFu
 

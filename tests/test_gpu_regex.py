@@ -227,3 +227,44 @@ def test_unicode_word_boundaries_on_gpu(device, view):
         want = orc.Regex(p).count_utf8(offs, data, validity, null_is_valid=bool(k % 2))
         assert (res[k].total, res[k].matches) == (want.total, want.matches), p
         assert 0 < res[k].matches < res[k].total, p
+
+
+def test_case_insensitive_patterns_over_a_column_of_fold_edge_cases(golden):
+    """`~*` (format.rs:756-776; TGX_FLAG_CASE_INSENSITIVE) on the device over a column that holds the characters where
+    simple case folding, the Turkic lines and the Unicode version matter: counts bit-exact against the oracle (fold
+    table of another origin: tests/test_unicode_tables.py) AND against the PyPI-`regex` vectors of
+    tests/golden/regex_crosscheck_r5.json, summed per pattern."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "regex_crosscheck_r5.json")) as f:
+        cases = json.load(f)["cases"]
+    by_pattern = {}
+    for c in cases:
+        by_pattern.setdefault((c["pattern"], c["flags"]), {})[c["input"]] = c["match"]
+    # one column: every input any pattern has a vector for, repeated with a NULL and an empty value in between
+    inputs = sorted({c["input"] for c in cases})
+    vals = []
+    for rep in range(3):
+        for i, s in enumerate(inputs):
+            vals.append(s)
+            if (i + rep) % 97 == 0:
+                vals.append(None)
+    offs, data, validity = orc.utf8_from_list(vals)
+    keys = sorted(by_pattern)
+    for g0 in range(0, len(keys), 6):
+        group = keys[g0:g0 + 6]
+        specs = [spec(T.REGEX_MATCH, 0, flags=f, pattern=p) for p, f in group]
+        for device in (True, False):
+            res, _, _ = run_plan(specs, [[utf8_column(offs, data, validity, device)]])
+            for (p, f), r in zip(group, res):
+                want = orc.Regex(p, bool(f & T.FLAG_CASE_INSENSITIVE)).count_utf8(offs, data, validity, null_is_valid=False)
+                assert (r.total, r.matches) == (want.total, want.matches), (p, f)
+                known = by_pattern[(p, f)]
+                if all(s in known for s in inputs):   # (every pattern saw the seed inputs; mutated ones differ)
+                    assert r.matches == 3 * sum(known[s] for s in inputs), (p, f)
+    # the vectors themselves, pattern by pattern, each over exactly its own inputs
+    for (p, f), known in by_pattern.items():
+        ins = sorted(known)
+        o2, d2, v2 = orc.utf8_from_list(ins)
+        res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, flags=f, pattern=p)], [[utf8_column(o2, d2, v2, True)]])
+        assert res[0].matches == sum(known.values()), (p, f)

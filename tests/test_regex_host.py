@@ -256,3 +256,43 @@ def test_unicode_word_boundary_vectors(crosscheck_r4):
     # (an automaton with Unicode word boundaries carries the walk through \w's UTF-8 forms: ~650 states x ~100 byte
     #  classes, four times the LDS table -- these patterns run from a table in global memory and are not grouped)
     assert grouped_any == 0
+
+
+@pytest.fixture(scope="module")
+def crosscheck_r5():
+    with open(os.path.join(ROOT, "tests", "golden", "regex_crosscheck_r5.json")) as f:
+        return json.load(f)
+
+
+def test_case_insensitive_vectors_follow_simple_case_folding(crosscheck_r5):
+    """`~*` / `(?i)` (format.rs:756-776) is Rust's SIMPLE case folding -- CaseFolding.txt status C + S at Unicode 16.0, no
+    Turkic line, no full folding: tests/golden/regex_crosscheck_r5.json (the PyPI `regex` module asked about the
+    Turkic i's, the Kelvin / long-s / Angstrom signs, capital sharp s, 15.1's status-S lines and cased pairs of
+    Unicode 14 / 16 / 17, corrected where the module is not Rust -- make_regex_crosscheck_r5.py) through the oracle's
+    VM and the product's automaton, whose fold tables have different origins (tests/test_unicode_tables.py).  The
+    tables both engines shared up to round 4 fail 95 of these vectors."""
+    by_pattern = {}
+    for c in crosscheck_r5["cases"]:
+        by_pattern.setdefault((c["pattern"], c["flags"]), []).append(c)
+    assert len(by_pattern) >= 40
+    hit = set()
+    for (pat, flags), cases in by_pattern.items():
+        rx = orc.Regex(pat, bool(flags & T.FLAG_CASE_INSENSITIVE))
+        assert product_validate(pat, flags)[0] == 0, pat
+        for c in cases:
+            assert rx.is_match(c["input"]) == c["match"], ("oracle", pat, flags, c["input"])
+            assert product_is_match(pat, c["input"], flags) == c["match"], ("product", pat, flags, c["input"])
+            hit.update(c["input"])
+    for ch in "ıİKſẞⰯꟁ\U00010597ﬅΐɤ\U00010d70ᲊ꟏\U00016ebb":
+        assert ch in hit, hex(ord(ch))
+    # the verdict's probes, spelled out
+    ci = T.FLAG_CASE_INSENSITIVE
+    for engine in (lambda p, v, f=0: product_is_match(p, v, f), lambda p, v, f=0: orc.Regex(p, bool(f & 8)).is_match(v)):
+        assert not engine(r"(?i)^i$", "ı") and not engine(r"^[a-z]+$", "ı", ci) and not engine(r"^I$", "ı", ci)
+        assert not engine(r"^i$", "İ", ci) and not engine("^İ$", "i", ci) and engine("^İ$", "İ", ci)
+        for a, b in (("Ⱟ", "ⱟ"), ("Ꟁ", "ꟁ"), ("\U00010570", "\U00010597"), ("Ɤ", "ɤ"),
+                     ("\U00010d50", "\U00010d70"), ("Ᲊ", "ᲊ"), ("k", "K"), ("s", "ſ"), ("ß", "ẞ")):
+            assert engine("^%s$" % a, b, ci) and engine("(?i)^%s$" % b, a), (a, b)
+            assert not engine("^%s$" % a, b)
+        for a, b in (("꟎", "꟏"), ("\U00016ea0", "\U00016ebb")):   # Unicode 17.0: not in regex-syntax 0.8.8
+            assert not engine("^%s$" % a, b, ci)
