@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--secondary", action="store_true", help="measure the secondary configs at any --rows")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other BASELINE.json configs (C2, C3, C4 on one GPU, C5) and the cold-step measurement "
+                         "that follow the headline's timed region at N = 1")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N>1 code path (range agreement, bitmap-slice exchange, all-gather merge) even "
                          "with one rank: a self-test of the multi-GPU step on a 1-GPU box")
@@ -294,8 +298,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    first_step_ms = None
+    for w in range(args.warmup):
+        t1 = time.perf_counter()
         res = step()
+        if w == 0:  # the process's first state: its buffers come from hipMalloc, the kernels' code objects are loaded
+            first_step_ms = (time.perf_counter() - t1) * 1e3
     st.profile_enable(True)
     st.profile_reset()
     fence()
@@ -391,6 +399,19 @@ def main():
             out["cpu_baseline"] = ref_line or cpu_baseline(torch, layout, unique_cols, table, sample)
             if ref_line is None:
                 out["cpu_baseline"]["reference_probe"] = why_not
+        if world == 1 and not distributed and not args.no_secondary and (n_total == 1_000_000_000 or args.secondary):
+            # the other BASELINE.json configs and the cold step, after the headline's timed region (tools/secondary_bench.py);
+            # the headline's own keys above are what they always were
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import secondary_bench
+
+            warm_ms = out["ms_per_step"]
+            st.close()  # (its blocks go to the library's cache: the cold states below start from there)
+            out["secondary"] = secondary_bench.measure(
+                T, torch, synth, spec, layout, unique_cols, plan, table, columns, n_total, args.seed,
+                steps=5, warmup=2, warm_headline_ms=warm_ms,
+                log=lambda m: print(m, file=sys.stderr, flush=True))
+            out["secondary"]["cold"]["headline_first_state_step_ms"] = first_step_ms
         line = json.dumps(out)
     else:
         line = None

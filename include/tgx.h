@@ -82,7 +82,25 @@ typedef enum tgx_type {
    * staging buffer on the device first (one extra pass over those columns).  Int64-shaped Arrow types (Timestamp, Date64, Time64, Duration) are passed as
    * TGX_INT64 as they are. */
   TGX_INT32 = 7,
-  TGX_FLOAT32 = 8
+  TGX_FLOAT32 = 8,
+  /* Narrow and unsigned integers (round 5): the reference's completeness / uniqueness SQL takes any column type
+   * (TG/constraints/completeness.rs:158-163, uniqueness.rs:612-617) and Parquet tables are full of these.  `values`
+   * holds 1 / 2 / 4 bytes per row; the batch's window is widened to Int64 on the device (value-preserving: every check
+   * then sees the Int64 column the values stand for -- SUM in Int64 as DataFusion's for signed inputs; its UInt64 sum
+   * of unsigned inputs has the same value while it fits).  Not coalesced: every batch is launched as it arrives. */
+  TGX_INT8 = 9,
+  TGX_INT16 = 10,
+  TGX_UINT8 = 11,
+  TGX_UINT16 = 12,
+  TGX_UINT32 = 13,
+  /* UInt64: 8 bytes per row read in place.  COUNT and DISTINCT only (a key is its bit pattern: COUNT(DISTINCT) is exact);
+   * a plan that asks a statistic, a sketch or a correlation of such a column gets TGX_UNSUPPORTED from tgx_update --
+   * the reference itself cannot read MIN / MAX / SUM of a UInt64 column (statistics.rs:277-308). */
+  TGX_UINT64 = 14,
+  /* Boolean: `values` is a bit-packed buffer like `validity` (bit `offset + i` = row i).  COUNT and DISTINCT only
+   * (false and true are the keys 0 and 1); anything else is TGX_UNSUPPORTED (MIN / MAX of a Boolean column come back
+   * Boolean in DataFusion: "Failed to extract statistic value" in the reference). */
+  TGX_BOOL = 15
 } tgx_type;
 
 typedef enum tgx_memspace { TGX_MEM_HOST = 0, TGX_MEM_DEVICE = 1 } tgx_memspace;
@@ -228,6 +246,24 @@ uint32_t tgx_abi_version(void);
 tgx_status tgx_init(const tgx_options *opts, tgx_error *err);
 tgx_status tgx_shutdown(void);
 const char *tgx_status_name(int32_t status);
+
+/* Device memory between runs.  `ValidationSuite::run` (TG/core/suite.rs:399) is called once per table: a state is
+ * created, fed, read and dropped.  The device (and pinned host) blocks of a destroyed state are kept by the library, by
+ * size class, and handed to the next state -- from the second state of a process on, tgx_state_create .. tgx_finalize
+ * performs no hipMalloc (a GB-sized hipMalloc costs milliseconds, hipFree waits for the whole device).  Bounded by
+ * TGX_DEVICE_CACHE_MAX_BYTES (default: a quarter of the device's memory, at most 64 GiB); TGX_DEVICE_CACHE=0 turns it
+ * off.  tgx_trim() returns everything cached to the driver (tgx_shutdown does too); no reference counterpart. */
+typedef struct tgx_cache_stats {
+  uint64_t device_cached_bytes;  /* held by the cache right now (not by live states) */
+  uint64_t device_cached_blocks;
+  uint64_t device_hits;          /* allocations served from the cache since the process started */
+  uint64_t device_misses;        /* allocations that went to hipMalloc */
+  uint64_t pinned_cached_bytes;
+  uint64_t pinned_hits;
+  uint64_t pinned_misses;
+} tgx_cache_stats;
+tgx_status tgx_trim(void);
+tgx_status tgx_cache_stats_get(tgx_cache_stats *out);
 
 /* Plan = the fused set of aggregates a ValidationSuite needs, grouped so each column buffer is
  * read once.  Replaces the per-constraint `format!("SELECT ...")` + `ctx.sql()` planning in

@@ -5,7 +5,14 @@
  * (`serde_json::to_string_pretty(ValidationResult)`, TG/formatters.rs:222-245, TG/core/result.rs:123-136).
  *
  * Suite JSON:
- *   {"name": "...", "table_name": "data", "checks": [{"name": "...", "level": "error|warning|info",
+ *   {"name": "...", "table_name": "data",
+ *    "column_types": {"c": "Int32", "d": "Timestamp(Nanosecond, None)"},   (optional: Arrow DataTypes as the caller holds
+ *                     them; a column without an entry is what its tgx_type says)
+ *    "strict_reference_types": true,    (default.  StatisticalConstraint reads its aggregate as Int64Array or Float64Array
+ *                     and fails with "Failed to extract statistic value" otherwise (TG/constraints/statistics.rs:277-308):
+ *                     MIN / MAX / quantiles of an Int32, Date32, Float32, Timestamp or UInt column, SUM of a UInt column
+ *                     are ERRORS there, and here.  false: the value of the widened column answers -- a deviation)
+ *    "checks": [{"name": "...", "level": "error|warning|info",
  *     "constraints": [
  *       {"type": "size", "assertion": A},
  *       {"type": "approx_count_distinct", "column": "c", "assertion": A},   (metric: the exact distinct count)
@@ -48,7 +55,8 @@ tgx_status tgx_host_constraint_plan_json(const char *constraint_json, char **out
 
 /* `Constraint::evaluate`'s verdict half on given aggregates: results_json is an array of objects with
  * tgx_result's field names (answering the plan in order; a KLL entry may carry {"quantiles": {"0.5": v}}).
- * Returns {"status": "success|failure|skipped", "metric": x|null, "message": s|null}.  Needs no device. */
+ * Returns {"status": "success|failure|skipped", "metric": x|null, "message": s|null}.  Needs no device.
+ * The constraint JSON may carry "column_type" (the column's Arrow DataType) and "strict_reference_types" as above. */
 tgx_status tgx_host_constraint_verdict_json(const char *constraint_json, const char *results_json, char **out_json,
                                             tgx_error *err);
 

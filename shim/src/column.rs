@@ -19,7 +19,7 @@ pub struct ColumnView {
     _realigned_validity: Option<Buffer>,
 }
 
-/// `None`: a type outside the path (Decimal, Boolean, nested ..) -- evaluate the constraint with the stock SQL.
+/// `None`: a type outside the path (Decimal, Binary, nested ..) -- evaluate the constraint with the stock SQL.
 pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
     let d = arr.to_data();
     let mut view = ColumnView {
@@ -80,6 +80,29 @@ pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
         }
         DataType::Float32 => {
             view.raw.type_ = TGX_FLOAT32;
+            view.raw.values = first(0) as _;
+        }
+        // narrow and unsigned integers: widened to Int64 on the device (completeness / uniqueness take any column type:
+        // completeness.rs:158-163, uniqueness.rs:612-617; what statistics the stock constraint can read off such a
+        // column is the planner's `reference_extracts`)
+        DataType::Int8 | DataType::Int16 | DataType::UInt8 | DataType::UInt16 | DataType::UInt32 => {
+            view.raw.type_ = match d.data_type() {
+                DataType::Int8 => TGX_INT8,
+                DataType::Int16 => TGX_INT16,
+                DataType::UInt8 => TGX_UINT8,
+                DataType::UInt16 => TGX_UINT16,
+                _ => TGX_UINT32,
+            };
+            view.raw.values = first(0) as _;
+        }
+        // COUNT / DISTINCT only (the library answers TGX_UNSUPPORTED to anything else: the binding stays unplanned)
+        DataType::UInt64 => {
+            view.raw.type_ = TGX_UINT64;
+            view.raw.values = first(0) as _;
+        }
+        DataType::Boolean => {
+            // the values buffer is bit-packed; ArrayData's offset applies to it as to the validity bitmap
+            view.raw.type_ = TGX_BOOL;
             view.raw.values = first(0) as _;
         }
         DataType::Utf8 => {

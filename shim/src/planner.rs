@@ -25,6 +25,7 @@
 use crate::column::{column_view, unused_column, ColumnView};
 use crate::handles::{Error, Plan, Spec, State};
 use crate::sys::*;
+use arrow::datatypes::DataType;
 use async_trait::async_trait;
 use datafusion::prelude::SessionContext;
 use futures::StreamExt;
@@ -88,6 +89,32 @@ struct RunOutput {
 struct Shared {
     bindings: Mutex<Vec<Binding>>,
     output: RwLock<Option<RunOutput>>,
+    /// see [`GpuPlanner::strict_reference_types`]
+    strict_types: std::sync::atomic::AtomicBool,
+}
+
+/// Can the stock constraint read its aggregate off a column of this type?  `StatisticalConstraint::evaluate` downcasts
+/// the result to `Int64Array`, then `Float64Array`, else `Err("Failed to extract statistic value")`
+/// (constraints/statistics.rs:277-308); DataFusion's MIN / MAX / APPROX_PERCENTILE_CONT keep the input type, SUM gives
+/// Int64 for signed integers, UInt64 for unsigned ones, Float64 for floats, AVG / STDDEV / VARIANCE give Float64.
+/// `QuantileConstraint` also reads `Int32Array` (constraints/quantile.rs:308-324).
+fn reference_extracts(v: &Verdict, t: &DataType) -> bool {
+    use DataType::*;
+    let sint = matches!(t, Int8 | Int16 | Int32);
+    let uint = matches!(t, UInt8 | UInt16 | UInt32 | UInt64);
+    let flt = matches!(t, Float16 | Float32);
+    if matches!(t, Int64 | Float64) {
+        return true;
+    }
+    match v {
+        Verdict::Statistic { stat, .. } => match stat {
+            StatisticType::Min | StatisticType::Max | StatisticType::Median | StatisticType::Percentile(_) => false,
+            StatisticType::Sum => sint || flt,
+            StatisticType::Mean | StatisticType::StandardDeviation | StatisticType::Variance => sint || uint || flt,
+        },
+        Verdict::Quantile { .. } => matches!(t, Int32),
+        _ => true, // counts: COUNT / COUNT(DISTINCT) / pattern and length matches come back as Int64 whatever the column
+    }
 }
 
 /// Factory of GPU-answered constraints, registry of what they need, and the runner of the fused pass.
@@ -151,7 +178,23 @@ impl Default for GpuPlanner {
 
 impl GpuPlanner {
     pub fn new() -> Self {
-        GpuPlanner { shared: Arc::new(Shared { bindings: Mutex::new(Vec::new()), output: RwLock::new(None) }) }
+        GpuPlanner {
+            shared: Arc::new(Shared {
+                bindings: Mutex::new(Vec::new()),
+                output: RwLock::new(None),
+                strict_types: std::sync::atomic::AtomicBool::new(true),
+            }),
+        }
+    }
+
+    /// `true` (the default): a statistic or quantile whose aggregate the stock constraint could not read off the
+    /// column's type -- MIN / MAX of an Int32, Date32, Float32 or Timestamp column, SUM of a UInt column, ... -- is NOT
+    /// answered from the device: the binding stays unplanned and the stock constraint returns the reference's own
+    /// `Err("Failed to extract statistic value")` (a failed check, "Error evaluating constraint: ..").  `false`: the
+    /// kernels' value for the widened column answers -- a deviation from the reference, listed in INTEGRATION.md.
+    pub fn strict_reference_types(&self, on: bool) -> &Self {
+        self.shared.strict_types.store(on, std::sync::atomic::Ordering::Relaxed);
+        self
     }
 
     fn bind(&self, stock: Arc<dyn Constraint>, requests: Vec<Request>, verdict: Verdict) -> GpuConstraint {
@@ -338,9 +381,18 @@ impl GpuPlanner {
         let mut planned: Vec<bool> = Vec::new();
         {
             let bindings = self.shared.bindings.lock().unwrap();
+            let strict = self.shared.strict_types.load(std::sync::atomic::Ordering::Relaxed);
             for (id, b) in bindings.iter().enumerate() {
                 let mut mine = Vec::new();
                 for r in &b.requests {
+                    // the reference's result-type rule: what it would fail to read is left to it
+                    if strict {
+                        if let Some(c) = index(&r.column) {
+                            if !reference_extracts(&b.verdict, schema.field(c as usize).data_type()) {
+                                break;
+                            }
+                        }
+                    }
                     let (Some(c), c2) = (index(&r.column), r.column2.as_deref().map(index)) else { break };
                     if matches!(c2, Some(None)) {
                         break;

@@ -16,6 +16,8 @@ from ._lib import (  # noqa: F401
     lib,
     lib_path,
     abi_symbols,
+    cache_stats,
+    trim,
     COUNT,
     NUMERIC_STATS,
     DISTINCT,
@@ -32,6 +34,13 @@ from ._lib import (  # noqa: F401
     FLAG_TRIM,
     FLAG_CASE_INSENSITIVE,
     FLAG_NULL_IS_VALID,
+    INT8,
+    INT16,
+    UINT8,
+    UINT16,
+    UINT32,
+    UINT64,
+    BOOL,
     INT32,
     INT64,
     FLOAT32,

@@ -13,6 +13,7 @@ FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS
 FLAG_EXACT_RANK_SUMS = 32
 ABI_VERSION = 4  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
+INT8, INT16, UINT8, UINT16, UINT32, UINT64, BOOL = 9, 10, 11, 12, 13, 14, 15  # (include/tgx.h: narrow / unsigned / Boolean)
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
                 4: "TGX_OUT_OF_MEMORY", 5: "TGX_INTERNAL", 6: "TGX_NO_DEVICE"}
@@ -166,8 +167,32 @@ def lib():
         L.tgx_profile_reset.argtypes = [vp]
         L.tgx_regex_validate.argtypes = [C.c_char_p, sz, C.c_uint32, E]
         L.tgx_regex_is_match.argtypes = [C.c_char_p, sz, C.c_uint32, C.c_char_p, sz, C.POINTER(C.c_int32), E]
+        L.tgx_cache_stats_get.argtypes = [C.POINTER(CacheStats)]
         _LIB = L
     return _LIB
+
+
+class CacheStats(C.Structure):
+    """tgx_cache_stats (include/tgx.h)"""
+    _fields_ = [("device_cached_bytes", C.c_uint64), ("device_cached_blocks", C.c_uint64), ("device_hits", C.c_uint64),
+                ("device_misses", C.c_uint64), ("pinned_cached_bytes", C.c_uint64), ("pinned_hits", C.c_uint64),
+                ("pinned_misses", C.c_uint64)]
+
+
+def cache_stats():
+    """tgx_cache_stats_get: what the library's cache of device / pinned blocks holds and has served"""
+    out = CacheStats()
+    rc = lib().tgx_cache_stats_get(C.byref(out))
+    if rc != 0:
+        raise TgxError(rc, "tgx_cache_stats_get")
+    return out
+
+
+def trim():
+    """tgx_trim: the cached blocks of destroyed states go back to the driver"""
+    rc = lib().tgx_trim()
+    if rc != 0:
+        raise TgxError(rc, "tgx_trim")
 
 
 def _check(status, err):
@@ -282,6 +307,18 @@ class Column:
         return Column(FLOAT32, n, values=values, validity=validity, offset=offset)
 
     @staticmethod
+    def narrow(type_id, values, validity=None, length=None, offset=0):
+        """Int8 / Int16 / UInt8 / UInt16 / UInt32 (widened to Int64 on the device) and UInt64 (read in place, COUNT /
+        DISTINCT only): `values` holds one element per row"""
+        n = (len(values) - offset) if length is None else length
+        return Column(type_id, n, values=values, validity=validity, offset=offset)
+
+    @staticmethod
+    def boolean(bits, length, validity=None, offset=0):
+        """Boolean: `bits` is the bit-packed values buffer (uint8, bit `offset + i` = row i); COUNT / DISTINCT only"""
+        return Column(BOOL, length, values=bits, validity=validity, offset=offset)
+
+    @staticmethod
     def utf8(offsets, data, validity=None, length=None, offset=0):
         n = (len(offsets) - 1 - offset) if length is None else length
         return Column(UTF8, n, offsets=offsets, data=data, validity=validity, offset=offset)
@@ -328,6 +365,15 @@ class Column:
                           null_count=arr.null_count)
         if pa.types.is_float32(t):
             return Column(FLOAT32, len(arr), values=view(bufs[1], np.float32), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count)
+        for is_t, type_id, dtype in ((pa.types.is_int8, INT8, np.int8), (pa.types.is_int16, INT16, np.int16),
+                                     (pa.types.is_uint8, UINT8, np.uint8), (pa.types.is_uint16, UINT16, np.uint16),
+                                     (pa.types.is_uint32, UINT32, np.uint32), (pa.types.is_uint64, UINT64, np.uint64)):
+            if is_t(t):
+                return Column(type_id, len(arr), values=view(bufs[1], dtype), validity=validity, offset=arr.offset,
+                              null_count=arr.null_count)
+        if pa.types.is_boolean(t):
+            return Column(BOOL, len(arr), values=view(bufs[1], np.uint8), validity=validity, offset=arr.offset,
                           null_count=arr.null_count)
         if pa.types.is_timestamp(t) or pa.types.is_date64(t) or pa.types.is_time64(t) or pa.types.is_duration(t):
             # Int64-shaped: the checks see the stored integer (microseconds, milliseconds, ...)
@@ -464,10 +510,15 @@ class State:
         _check(lib().tgx_state_create(plan.h, stream, C.byref(h), C.byref(err)), err)
         self.h = h
 
-    def __del__(self):
+    def close(self):
+        """tgx_state_destroy now (not when the garbage collector gets to it)"""
         if getattr(self, "h", None):
             lib().tgx_state_destroy(self.h)
             self.h = None
+        self._keep = None
+
+    def __del__(self):
+        self.close()
 
     def update(self, columns):
         cols = list(columns)

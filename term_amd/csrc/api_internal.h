@@ -96,6 +96,35 @@ struct WindowPrep {
 
 static inline bool is_numeric(int t) { return t == TGX_INT64 || t == TGX_FLOAT64; }
 static inline bool is_numeric32(int t) { return t == TGX_INT32 || t == TGX_FLOAT32; }
+// the narrow types of round 5: no kernel reads them in place, every pass sees them widened to Int64
+static inline bool is_narrow_int(int t) { return (t >= TGX_INT8 && t <= TGX_UINT32) || t == TGX_BOOL; }
+// everything stage_column widens into a staging buffer (4-byte numerics only for the passes that need 8-byte values)
+static inline bool is_widened(int t) { return is_numeric32(t) || is_narrow_int(t); }
+// COUNT and DISTINCT only (include/tgx.h)
+static inline bool is_keys_only(int t) { return t == TGX_UINT64 || t == TGX_BOOL; }
+// bytes the first `slots` slots of a values buffer of type `t` take (Boolean: bits)
+static inline size_t narrow_bytes(int t, int64_t slots) {
+  switch (t) {
+    case TGX_INT8: case TGX_UINT8: return (size_t)slots;
+    case TGX_INT16: case TGX_UINT16: return (size_t)slots * 2;
+    case TGX_BOOL: return (size_t)((slots + 7) / 8);
+    default: return (size_t)slots * 4;  // Int32, Float32, UInt32
+  }
+}
+// the type a widened column is seen as, and the widen kernel's mode (kernels/scan.hip, widen_kernel)
+static inline int widened_type(int t) { return t == TGX_FLOAT32 ? TGX_FLOAT64 : TGX_INT64; }
+static inline int widen_mode(int t) {
+  switch (t) {
+    case TGX_FLOAT32: return 1;
+    case TGX_INT8: return 2;
+    case TGX_INT16: return 3;
+    case TGX_UINT8: return 4;
+    case TGX_UINT16: return 5;
+    case TGX_UINT32: return 6;
+    case TGX_BOOL: return 7;
+    default: return 0;  // Int32
+  }
+}
 static inline bool is_string(int t) { return t == TGX_UTF8 || t == TGX_LARGE_UTF8; }
 static inline bool is_any_string(int t) { return is_string(t) || t == TGX_UTF8_VIEW; }
 

@@ -227,10 +227,10 @@ tgx_status coalesce_arena_ready(tgx_state *st, tgx_error *err) {
     co.arena_busy[k] = false;
   }
   if (co.arena_cap[k] < co.arena_want) {
-    if (co.arena_host[k]) (void)hipHostFree(co.arena_host[k]);
+    pinned_free(co.arena_host[k], co.arena_cap[k]);
     co.arena_host[k] = nullptr;
     co.arena_cap[k] = 0;
-    HIP_TRY(hipHostMalloc(&co.arena_host[k], co.arena_want, hipHostMallocDefault));
+    HIP_TRY(pinned_alloc(&co.arena_host[k], co.arena_want));
     HIP_TRY(co.arena_dev[k].reserve(co.arena_want));
     co.arena_cap[k] = co.arena_want;
   }
@@ -683,11 +683,11 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     co.arena_busy[ar] = false;
   }
   if (co.desc_cap[ar] < n_segs * sizeof(GatherSeg)) {
-    if (co.desc_host[ar]) (void)hipHostFree(co.desc_host[ar]);
+    pinned_free(co.desc_host[ar], co.desc_cap[ar]);
     co.desc_host[ar] = nullptr;
     co.desc_cap[ar] = 0;
     const size_t want = std::max<size_t>(2 * n_segs * sizeof(GatherSeg), 64u << 10);
-    HIP_TRY(hipHostMalloc(&co.desc_host[ar], want, hipHostMallocDefault));
+    HIP_TRY(pinned_alloc(&co.desc_host[ar], want));
     co.desc_cap[ar] = want;
   }
   HIP_TRY(co.desc_dev[ar].reserve(co.desc_cap[ar]));
@@ -876,9 +876,10 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   if (any_kept && st->d_distinct_counters.p) {
     const size_t bytes = st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long);
     if (co.snap_cap[set] < bytes) {
-      if (co.snap_host[set]) (void)hipHostFree(co.snap_host[set]);
+      pinned_free(co.snap_host[set], co.snap_cap[set]);
       co.snap_host[set] = nullptr;
-      HIP_TRY(hipHostMalloc(&co.snap_host[set], bytes + 256, hipHostMallocDefault));
+      co.snap_cap[set] = 0;
+      HIP_TRY(pinned_alloc(&co.snap_host[set], bytes + 256));
       co.snap_cap[set] = bytes + 256;
     }
     if (!co.snap_event[set]) HIP_TRY(hipEventCreateWithFlags(&co.snap_event[set], hipEventDisableTiming));

@@ -150,7 +150,7 @@ tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *d
   bool any_view = false;  // a component whose device view lives in per-update scratch: never retained (no lists)
   for (int c2 : task.tuple) {
     cols.push_back(&dev[c2]);
-    any_view |= dev[c2].type == TGX_UTF8_VIEW || (orig && is_numeric32(orig[c2].type));
+    any_view |= dev[c2].type == TGX_UTF8_VIEW || (orig && is_widened(orig[c2].type));
   }
   TupleDesc d;
   TGX_TRY(tuple_desc_of(cols, task.multiplicity, &d, err));
@@ -390,11 +390,11 @@ void bitmap_shape(const DistinctState &ds, int64_t length, bool mult, uint32_t *
 
 tgx_status pinned_readback(tgx_state *st, size_t bytes, tgx_error *err) {
   if (bytes <= st->h_pinned_cap) return TGX_OK;
-  if (st->h_pinned) (void)hipHostFree(st->h_pinned);
+  pinned_free(st->h_pinned, st->h_pinned_cap);
   st->h_pinned = nullptr;
   st->h_pinned_cap = 0;
   const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
-  HIP_TRY(hipHostMalloc(&st->h_pinned, want, hipHostMallocDefault));
+  HIP_TRY(pinned_alloc(&st->h_pinned, want));
   st->h_pinned_cap = want;
   return TGX_OK;
 }
@@ -648,7 +648,7 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
   // what a later repair walks again: never a view into the update's staging scratch (the next update reuses it) --
   // a widened DEVICE Int32 / Float32 column is retained as the caller's 4-byte column and widened again at the
   // repair (retained_numeric_view); staged copies of HOST batches are resolved before tgx_update returns
-  const tgx_column &keep = (orig && orig->mem == TGX_MEM_DEVICE && is_numeric32(orig->type)) ? *orig : c;
+  const tgx_column &keep = (orig && orig->mem == TGX_MEM_DEVICE && is_widened(orig->type)) ? *orig : c;
   DistinctState &ds = st->distinct[slot];
   const bool mult = task.multiplicity;
   DistinctColDesc d;
@@ -763,15 +763,15 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
 tgx_status retained_numeric_view(tgx_state *st, const tgx_column &col, std::vector<std::unique_ptr<DevBuf>> &tmp,
                                         tgx_column *out, tgx_error *err) {
   *out = col;
-  if (!is_numeric32(col.type)) return TGX_OK;
+  if (!is_widened(col.type)) return TGX_OK;
   const int64_t e0 = col.offset & ~(int64_t)63;
   const int64_t slots = col.offset - e0 + col.length;
   tmp.emplace_back(new DevBuf());
   DevBuf *w = tmp.back().get();
   HIP_TRY(w->reserve((size_t)slots * 8 + 16));
-  launch_widen32((const uint8_t *)col.values + (size_t)e0 * 4, w->p, slots, col.type == TGX_FLOAT32 ? 1 : 0, g_ctx.n_cu,
+  launch_widen32((const uint8_t *)col.values + narrow_bytes(col.type, e0), w->p, slots, widen_mode(col.type), g_ctx.n_cu,
                  st->stream);
-  out->type = col.type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
+  out->type = widened_type(col.type);
   out->values = w->p;
   out->validity = col.validity ? col.validity + (e0 >> 3) : nullptr;
   out->offset = col.offset - e0;

@@ -177,6 +177,14 @@ extern "C" tgx_status tgx_host_constraint_verdict_json(const char *constraint_js
     for (auto &r : results) in.results.push_back(&r);
     in.ctx = &fq;
     in.quantile = fake_quantile;
+    {  // the reference's result-type rule (term_guard.h reference_extracts): "column_type" = the column's Arrow DataType
+      json::Value cv;
+      std::string cerr;
+      if (json::parse(constraint_json, &cv, &cerr) && cv.is(json::Value::Object)) {
+        if (cv.get("column_type")) in.arrow_types.assign(results.size(), cv.get_str("column_type"));
+        in.strict_reference_types = cv.get_bool("strict_reference_types", true);
+      }
+    }
     ConstraintResult cr = c->evaluate(in);
     const char *st = cr.status == ConstraintStatus::Success ? "success" : cr.status == ConstraintStatus::Failure ? "failure" : "skipped";
     std::string o = std::string("{\"status\": \"") + st + "\", \"metric\": ";

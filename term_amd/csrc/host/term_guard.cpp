@@ -30,6 +30,7 @@ std::string TermError::display() const {
     case DataFusion: return "DataFusion error: " + message;
     case NotSupported: return "Operation not supported: " + message;
     case Configuration: return "Configuration error: " + message;
+    case TypeMismatch: return "Type mismatch: " + message;  // error.rs:81 ("expected {expected}, found {found}")
     default: return "Internal error: " + message;
   }
 }
@@ -324,6 +325,35 @@ static void require_threshold(double t) {
 }
 
 // ------------------------------------------------------------------------------------------------ constraints
+// ---- the reference's result-type rule (term_guard.h) ----
+static bool is_one_of(const std::string &t, std::initializer_list<const char *> names) {
+  for (const char *n : names)
+    if (t == n) return true;
+  return false;
+}
+bool reference_extracts(StatisticResultKind stat, const std::string &t) {
+  if (t.empty() || t == "Int64" || t == "Float64") return true;
+  const bool sint = is_one_of(t, {"Int8", "Int16", "Int32"});
+  const bool uint = is_one_of(t, {"UInt8", "UInt16", "UInt32", "UInt64"});
+  const bool flt = is_one_of(t, {"Float16", "Float32"});
+  switch (stat) {
+    case StatisticResultKind::Min:
+    case StatisticResultKind::Max:
+    case StatisticResultKind::Quantile:
+      return false;  // the aggregate keeps the column's type: neither Int64Array nor Float64Array
+    case StatisticResultKind::Sum:
+      return sint || flt;  // Int64 / Float64; unsigned sums are UInt64
+    case StatisticResultKind::Mean:
+    case StatisticResultKind::StandardDeviation:
+    case StatisticResultKind::Variance:
+      return sint || uint || flt;  // Float64
+  }
+  return false;
+}
+bool reference_extracts_quantile(const std::string &t) {
+  return t.empty() || t == "Int64" || t == "Float64" || t == "Int32";
+}
+
 namespace {
 
 // constraints/size.rs:60-120
@@ -425,6 +455,22 @@ constexpr uint32_t kDefaultKllK = 200;
 // the value one statistic reads out of its aggregate (statistics.rs:278-308: Float64, else Int64 cast to f64);
 // false = SQL NULL.  `request` indexes the constraint's plan(): a NUMERIC_STATS request, or a KLL request for
 // Median / Percentile (APPROX_PERCENTILE_CONT in the reference, the KLL sketch here)
+static StatisticResultKind result_kind_of(const StatisticType &st) {
+  switch (st.kind) {
+    case StatisticType::Min: return StatisticResultKind::Min;
+    case StatisticType::Max: return StatisticResultKind::Max;
+    case StatisticType::Mean: return StatisticResultKind::Mean;
+    case StatisticType::Sum: return StatisticResultKind::Sum;
+    case StatisticType::StandardDeviation: return StatisticResultKind::StandardDeviation;
+    case StatisticType::Variance: return StatisticResultKind::Variance;
+    default: return StatisticResultKind::Quantile;
+  }
+}
+static bool extractable(const StatisticType &st, const Constraint::Inputs &in, size_t request) {
+  if (!in.strict_reference_types || request >= in.arrow_types.size()) return true;
+  return reference_extracts(result_kind_of(st), in.arrow_types[request]);
+}
+
 static bool statistic_value(const StatisticType &st, const Constraint::Inputs &in, size_t request, double *value) {
   const tgx_result *r = in.results[request];
   switch (st.kind) {
@@ -468,6 +514,8 @@ class StatisticalConstraint : public Constraint {
     return {r};
   }
   ConstraintResult evaluate(const Inputs &in) const override {
+    // statistics.rs:277-308: a result column that is neither Int64Array nor Float64Array
+    if (!extractable(st_, in, 0)) throw TermError{TermError::Internal, "Failed to extract statistic value"};
     double value = 0;
     const bool null = !statistic_value(st_, in, 0, &value);
     if (null) return ConstraintResult::failure(st_.name() + " is null (no non-null values)");  // statistics.rs:284-301
@@ -524,6 +572,10 @@ class MultiStatisticalConstraint : public Constraint {
     for (auto &sa : stats_) {
       const bool q = sa.first.kind == StatisticType::Median || sa.first.kind == StatisticType::Percentile;
       double value = 0;
+      if (!extractable(sa.first, in, q && any_plain_ ? 1 : 0)) {
+        failures.push_back("Failed to compute " + sa.first.name());  // statistics.rs:478-482
+        continue;
+      }
       if (!statistic_value(sa.first, in, q && any_plain_ ? 1 : 0, &value)) {
         failures.push_back(sa.first.name() + " is null");  // :466-470
         continue;
@@ -813,6 +865,10 @@ class QuantileConstraint : public Constraint {
     if (v_.kind == QuantileValidation::Distribution || v_.kind == QuantileValidation::Custom)
       return ConstraintResult::skipped("Validation type not yet implemented");  // :481-486
     if (in.results[0]->kll_n == 0) return ConstraintResult::skipped("No data to validate");
+    // quantile.rs:308-324 (and :369-385, :433-449): APPROX_PERCENTILE_CONT keeps the column's type; what is not
+    // Float64 / Int64 / Int32 is a TypeMismatch error whose `found` is the DataType's Debug form
+    if (in.strict_reference_types && !in.arrow_types.empty() && !reference_extracts_quantile(in.arrow_types[0]))
+      throw TermError{TermError::TypeMismatch, "expected Float64, Int64, or Int32, found " + in.arrow_types[0]};
     switch (v_.kind) {
       case QuantileValidation::Single: {  // :287-345
         const QuantileCheck &c = v_.checks[0];
@@ -1201,6 +1257,23 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
       if (table->column_names[i] == name) return (int)i;
     return -1;
   };
+  // the Arrow DataType of a column: what the caller declared, else what its tgx_type says
+  auto arrow_type_of = [&](const std::string &name) -> std::string {
+    auto declared = declared_types_.find(name);
+    if (declared != declared_types_.end()) return declared->second;
+    const int ci = column_index(name);
+    if (ci < 0) return std::string();
+    if ((size_t)ci < table->arrow_types.size() && !table->arrow_types[ci].empty()) return table->arrow_types[ci];
+    for (const Batch &b : table->batches)
+      if ((size_t)ci < b.columns.size()) switch (b.columns[ci].type) {
+          case TGX_INT64: return "Int64";
+          case TGX_FLOAT64: return "Float64";
+          case TGX_INT32: return "Int32";
+          case TGX_FLOAT32: return "Float32";
+          default: return std::string();
+        }
+    return std::string();
+  };
   for (const Check &check : checks_) {
     for (const auto &c : check.constraints()) {
       Planned p;
@@ -1298,6 +1371,8 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
       Constraint::Inputs in;
       QuantileCtx qctx{h.plan, h.state, p.spec_index};
       for (size_t si : p.spec_index) in.results.push_back(&results[si]);
+      for (const SpecRequest &r : p.requests) in.arrow_types.push_back(arrow_type_of(r.column));
+      in.strict_reference_types = strict_types_;
       in.ctx = &qctx;
       in.quantile = quantile_cb;
       try {
@@ -1587,6 +1662,11 @@ ValidationSuite suite_from_json(const std::string &text) {
     throw TermError{TermError::Internal, "suite JSON: " + (err.empty() ? std::string("not an object") : err)};
   ValidationSuite::Builder sb = ValidationSuite::builder(root.get_str("name", "suite"));
   if (root.get("table_name")) sb.table_name(root.get_str("table_name", "data"));
+  if (root.get("strict_reference_types")) sb.strict_reference_types(root.get_bool("strict_reference_types"));
+  if (const json::Value *ct = root.get("column_types"))
+    if (ct->is(json::Value::Object))
+      for (const auto &kv : ct->obj)
+        if (kv.second.is(json::Value::String)) sb.column_type(kv.first, kv.second.str);
   if (root.get("description")) sb.description(root.get_str("description"));
   if (const json::Value *checks = root.get("checks")) {
     for (const json::Value &cv : checks->arr) {

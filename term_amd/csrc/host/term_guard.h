@@ -46,7 +46,7 @@ struct ConstraintResult {
 
 // TermError (error.rs:14-145): only the variants this path produces
 struct TermError {
-  enum Kind { Internal, SecurityError, DataFusion, NotSupported, Configuration } kind = Internal;
+  enum Kind { Internal, SecurityError, DataFusion, NotSupported, Configuration, TypeMismatch } kind = Internal;
   std::string message;
   std::string display() const;  // thiserror Display strings, e.g. "Security error: ..."
 };
@@ -170,9 +170,27 @@ class Constraint {
     std::vector<const tgx_result *> results;
     const void *ctx = nullptr;
     double (*quantile)(const void *ctx, size_t request_index, double phi) = nullptr;
+    // the Arrow DataType of the column request i reads, as the caller holds it ("Int64", "Int32", "Date32",
+    // "Timestamp", "Float32", "UInt16", ...; empty = unknown, taken for Int64 / Float64), and whether the verdict
+    // follows the reference's own extraction rule for it (reference_extracts below)
+    std::vector<std::string> arrow_types;
+    bool strict_reference_types = true;
   };
   virtual ConstraintResult evaluate(const Inputs &in) const = 0;
 };
+
+// What DataFusion 50's aggregate hands back for a column of Arrow type `arrow_type`, and whether the reference can
+// read it: StatisticalConstraint::evaluate downcasts the result column to Int64Array, then Float64Array, else
+// Err("Failed to extract statistic value") (constraints/statistics.rs:277-308; MultiStatisticalConstraint pushes
+// "Failed to compute {name}", :466-483).  MIN / MAX / APPROX_PERCENTILE_CONT keep the input type, SUM widens signed
+// integers to Int64 and floats to Float64 (unsigned: UInt64), AVG / STDDEV / VARIANCE are Float64.  So on an Int32,
+// Date32, Float32, Timestamp or UInt column the reference's has_min is an ERROR, not a verdict -- and with
+// `strict_reference_types` (the default) so is this library's, although the kernels could answer (the widening
+// behaviour is opt-in and listed as a deviation in INTEGRATION.md).
+enum class StatisticResultKind { Min, Max, Mean, Sum, StandardDeviation, Variance, Quantile };
+bool reference_extracts(StatisticResultKind stat, const std::string &arrow_type);
+// QuantileConstraint reads Float64, Int64 or Int32 (constraints/quantile.rs:308-324), else TypeMismatch
+bool reference_extracts_quantile(const std::string &arrow_type);
 
 // ---- core/check.rs
 class Check {
@@ -292,6 +310,10 @@ struct Batch {
 struct Table {
   std::vector<std::string> column_names;
   std::vector<Batch> batches;
+  // Arrow DataType names parallel to column_names (optional: a column without one is what its tgx_type says --
+  // TGX_INT64 "Int64", TGX_INT32 "Int32", TGX_FLOAT32 "Float32", ...; a Timestamp / Date32 column handed over as
+  // TGX_INT64 / TGX_INT32 needs its name here for the reference's result-type rule to apply)
+  std::vector<std::string> arrow_types;
 };
 class Context {
  public:
@@ -350,6 +372,8 @@ class ValidationSuite {
   std::optional<std::string> description_;
   std::string table_name_ = "data";  // suite.rs:549
   std::vector<Check> checks_;
+  bool strict_types_ = true;
+  std::map<std::string, std::string> declared_types_;
 };
 class ValidationSuite::Builder {
  public:
@@ -358,6 +382,15 @@ class ValidationSuite::Builder {
   Builder &table_name(std::string t) { suite_.table_name_ = std::move(t); return *this; }
   Builder &check(Check c) { suite_.checks_.push_back(std::move(c)); return *this; }
   Builder &with_optimizer(bool) { return *this; }  // suite.rs:457-469: the reference ignores it too
+  // true (default): MIN / MAX / SUM / quantiles on columns whose aggregate the reference cannot read are errors, as
+  // there (reference_extracts); false: the widened value answers (a deviation)
+  Builder &strict_reference_types(bool on) { suite_.strict_types_ = on; return *this; }
+  // the Arrow DataType (its Debug form: "Int32", "Date32", "Timestamp(Nanosecond, None)", "UInt8", ...) of a column of
+  // the table the suite will run on; takes precedence over Table::arrow_types
+  Builder &column_type(std::string column, std::string arrow_type) {
+    suite_.declared_types_[std::move(column)] = std::move(arrow_type);
+    return *this;
+  }
   ValidationSuite build() { return suite_; }
 
  private:

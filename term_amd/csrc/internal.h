@@ -53,7 +53,8 @@ void launch_scan_hll(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPa
 void launch_como_pivot(const ComomentLaunch &L, int n_pairs, ComomentAcc *d_accs, hipStream_t stream);
 void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_per_pair, const void *d_partials,
                              ComomentAcc *d_accs, hipStream_t stream);
-void launch_widen32(const void *src, void *dst, int64_t n, int is_float, int n_cu, hipStream_t stream);
+// mode: 0 Int32, 1 Float32, 2 Int8, 3 Int16, 4 UInt8, 5 UInt16, 6 UInt32, 7 Boolean (bits) -> Int64 / Float64
+void launch_widen32(const void *src, void *dst, int64_t n, int mode, int n_cu, hipStream_t stream);
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
                              ScanAcc *d_accs, hipStream_t stream);
 void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,
@@ -210,13 +211,31 @@ struct tgx_plan {
   // per plan column, fixed at tgx_plan_create (tgx_update runs once per 8192-row batch: nothing is allocated there)
   std::vector<char> used, reads_values, needs_wide;
   std::vector<char> key_column;  // a single-column DISTINCT check reads it (range tracking of coalesced HOST batches)
+  std::vector<char> stats_on;    // a statistic, sketch, correlation or ranking reads it (TGX_UINT64 / TGX_BOOL columns may not)
   void *regex = nullptr;     // tgx::RegexPlan (regex_device.cpp)
   void *spearman = nullptr;  // tgx::SpearmanPlan (spearman_device.cpp)
 };
 
 namespace tgx {
 
-// device buffer that grows on demand
+// devcache.cpp: the process-wide cache of device / pinned allocations
+size_t cache_size_class(size_t bytes);
+hipError_t dev_alloc(void **p, size_t *cap, size_t bytes);  // `*cap` = the block's size class (>= bytes)
+void dev_free(void *p, size_t cap);                          // waits for the device unless inside a QuiescedScope
+hipError_t pinned_alloc(void **p, size_t bytes);
+void pinned_free(void *p, size_t bytes);                     // `bytes` as asked for
+void dev_cache_trim();
+void dev_cache_stats(tgx_cache_stats *out);
+// "the device has been waited for and this thread queues nothing until the scope ends": releases inside it skip the
+// wait that keeps a cached block away from work still in flight (tgx_state_destroy)
+struct QuiescedScope {
+  QuiescedScope();
+  ~QuiescedScope();
+  QuiescedScope(const QuiescedScope &) = delete;
+  QuiescedScope &operator=(const QuiescedScope &) = delete;
+};
+
+// device buffer that grows on demand (its memory comes from and returns to the cache)
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -243,7 +262,7 @@ struct DevBuf {
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p && owned) (void)hipFree(p);
+    if (p && owned) dev_free(p, cap);
     p = nullptr;
     cap = 0;
     owned = true;
@@ -259,9 +278,7 @@ struct DevBuf {
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
     release();
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) cap = bytes;
-    return e;
+    return dev_alloc(&p, &cap, bytes);
   }
   template <class T>
   T *as() const {
@@ -483,7 +500,7 @@ struct tgx_state {
     const void *src;
     void *dst;
     int64_t n;
-    int is_float;
+    int mode;  // widen_mode()
   };
   std::vector<int> como_pivot_tries;  // per COMOMENTS task: batches that offered the pivot kernel a look (<= 4)
   std::vector<Widen> pending_widen;  // TGX_INT32 / TGX_FLOAT32 windows of the current update (stage_column)
@@ -496,7 +513,7 @@ struct tgx_state {
   // is 8192 rows: a dozen 64-KiB buffers, 12 us of call overhead each when copied one by one)
   // two arenas take turns, each guarded by an event recorded after the update that used it, so an update whose
   // HOST buffers all fitted returns without synchronising the stream
-  void *arena_host[2] = {nullptr, nullptr};  // hipHostMalloc
+  void *arena_host[2] = {nullptr, nullptr};  // pinned_alloc(kArenaBytes)
   tgx::DevBuf arena_dev[2];
   hipEvent_t arena_event[2] = {nullptr, nullptr};
   bool arena_busy[2] = {false, false};

@@ -1278,6 +1278,25 @@ __global__ __launch_bounds__(64) void count_reduce_kernel(const CountLaunch L,
 // ---------------------------------------------------------------------------------------------
 // Int32 -> Int64 / Float32 -> Float64 over the rows a batch views (TGX_INT32 / TGX_FLOAT32 columns): four values per
 // lane and trip (one 16-byte load when the source is 16-byte aligned, two 16-byte stores).
+// The narrow types of round 5 (Int8, Int16, UInt8, UInt16, UInt32 -> Int64; Boolean bits -> 0 / 1) take the plain
+// loop: one value per lane and trip, an 8-byte store each (these are the rare columns of a table, not its bulk).
+__global__ __launch_bounds__(256) void widen_narrow_kernel(const void *__restrict__ src, long long *__restrict__ dst,
+                                                           int64_t n, int mode) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long long v;
+    switch (mode) {
+      case 2: v = (long long)((const int8_t *)src)[i]; break;
+      case 3: v = (long long)((const int16_t *)src)[i]; break;
+      case 4: v = (long long)((const uint8_t *)src)[i]; break;
+      case 5: v = (long long)((const uint16_t *)src)[i]; break;
+      case 6: v = (long long)((const uint32_t *)src)[i]; break;
+      default: v = (long long)((((const uint8_t *)src)[i >> 3] >> (i & 7)) & 1); break;  // 7: Boolean
+    }
+    dst[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void widen32_kernel(const void *__restrict__ src, void *__restrict__ dst, int64_t n,
                                                       int is_float) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1304,12 +1323,16 @@ __global__ __launch_bounds__(256) void widen32_kernel(const void *__restrict__ s
   }
 }
 
-void launch_widen32(const void *src, void *dst, int64_t n, int is_float, int n_cu, hipStream_t stream) {
+void launch_widen32(const void *src, void *dst, int64_t n, int mode, int n_cu, hipStream_t stream) {
   if (n <= 0) return;
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(widen32_kernel, dim3((int)blocks), dim3(256), 0, stream, src, dst, n, is_float);
+  if (mode >= 2) {
+    hipLaunchKernelGGL(widen_narrow_kernel, dim3((int)blocks), dim3(256), 0, stream, src, (long long *)dst, n, mode);
+    return;
+  }
+  hipLaunchKernelGGL(widen32_kernel, dim3((int)blocks), dim3(256), 0, stream, src, dst, n, mode);
 }
 
 // ---------------------------------------------------------------------------------------------

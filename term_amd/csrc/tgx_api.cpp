@@ -77,7 +77,27 @@ extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) try {
 extern "C" tgx_status tgx_shutdown(void) try {
   copy_pool_shutdown();  // (the helper threads of the coalescing arenas' copies: stopped and joined)
   std::lock_guard<std::mutex> lock(g_ctx.mu);
+  if (g_ctx.inited) {
+    (void)hipSetDevice(g_ctx.device);
+    tgx::dev_cache_trim();  // (blocks of destroyed states; live states keep theirs)
+  }
   g_ctx.inited = false;
+  return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(nullptr);
+}
+
+extern "C" tgx_status tgx_trim(void) try {
+  bind_thread();
+  tgx::dev_cache_trim();
+  return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(nullptr);
+}
+
+extern "C" tgx_status tgx_cache_stats_get(tgx_cache_stats *out) try {
+  if (!out) return TGX_INVALID_ARGUMENT;
+  tgx::dev_cache_stats(out);
   return TGX_OK;
 } catch (...) {
   return tgx::abi_exception(nullptr);
@@ -279,8 +299,12 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
     P->reads_values.assign(P->n_columns_needed, 0);
     P->needs_wide.assign(P->n_columns_needed, 0);
     P->key_column.assign(P->n_columns_needed, 0);
+    P->stats_on.assign(P->n_columns_needed, 0);
     for (auto &t : P->distinct)
       if (t.tuple.empty() && !t.approx_only) P->key_column[t.column] = 1;
+    for (auto &t : P->scan) P->stats_on[t.column] = 1;
+    for (auto &t : P->como) P->stats_on[t.col_x] = P->stats_on[t.col_y] = 1;
+    for (auto &t : P->kll) P->stats_on[t.column] = 1;
     for (auto &t : P->scan) P->used[t.column] = P->reads_values[t.column] = 1;
     for (auto &t : P->count) P->used[t.column] = 1;
     for (auto &t : P->distinct) {
@@ -300,6 +324,7 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
       P->used[i] |= sp_used[i];
       P->reads_values[i] |= sp_vals[i];
       P->needs_wide[i] |= sp_used[i];
+      P->stats_on[i] |= sp_used[i];
     }
   }
   // re-point pattern pointers at the plan-owned copies
@@ -495,7 +520,10 @@ extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, t
 extern "C" void tgx_state_destroy(tgx_state *st) {
   if (!st) return;
   bind_thread();
-  if (st->device_ready && st->stream) (void)hipStreamSynchronize(st->stream);
+  // one wait for the whole device -- what the first hipFree of the state's buffers used to do implicitly (and every
+  // further one again) -- then its device and pinned blocks go back to the cache without waiting (devcache.cpp)
+  if (g_ctx.inited) (void)hipDeviceSynchronize();
+  tgx::QuiescedScope quiesced;
   for (auto &kv : st->profile)
     for (auto &ev : kv.second.pending) {
       (void)hipEventDestroy(ev.first);
@@ -506,15 +534,15 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   spearman_state_free(st);
   for (int k = 0; k < 2; k++) {
     if (st->arena_event[k]) (void)hipEventDestroy(st->arena_event[k]);
-    if (st->arena_host[k]) (void)hipHostFree(st->arena_host[k]);
+    pinned_free(st->arena_host[k], kArenaBytes);
     tgx::Coalescer &co = st->coalesce;
     if (co.arena_event[k]) (void)hipEventDestroy(co.arena_event[k]);
     if (co.snap_event[k]) (void)hipEventDestroy(co.snap_event[k]);
-    if (co.arena_host[k]) (void)hipHostFree(co.arena_host[k]);
-    if (co.desc_host[k]) (void)hipHostFree(co.desc_host[k]);
-    if (co.snap_host[k]) (void)hipHostFree(co.snap_host[k]);
+    pinned_free(co.arena_host[k], co.arena_cap[k]);
+    pinned_free(co.desc_host[k], co.desc_cap[k]);
+    pinned_free(co.snap_host[k], co.snap_cap[k]);
   }
-  if (st->h_pinned) (void)hipHostFree(st->h_pinned);
+  pinned_free(st->h_pinned, st->h_pinned_cap);
   if (st->keys_ready) (void)hipEventDestroy(st->keys_ready);
   if (st->aux_done) (void)hipEventDestroy(st->aux_done);
   if (st->aux_stream) (void)hipStreamDestroy(st->aux_stream);

@@ -32,7 +32,7 @@ tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx
     if (c.mem == TGX_MEM_HOST && bytes <= kArenaMaxBuffer) {
       const int k = st->arena_cur;
       if (!st->arena_host[k]) {
-        HIP_TRY(hipHostMalloc(&st->arena_host[k], kArenaBytes, hipHostMallocDefault));
+        HIP_TRY(pinned_alloc(&st->arena_host[k], kArenaBytes));
         HIP_TRY(st->arena_dev[k].reserve(kArenaBytes));
         HIP_TRY(hipEventCreateWithFlags(&st->arena_event[k], hipEventDisableTiming));
       }
@@ -72,24 +72,32 @@ tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx
     TGX_TRY(stage(table.data(), table.size() * sizeof(void *), &dt));
     out->variadic = (const uint8_t *const *)dt;
   }
-  if (c.mem == TGX_MEM_DEVICE && !(is_numeric32(c.type) && widen32)) return TGX_OK;
+  if (c.type == TGX_UINT64) {
+    // 8-byte values read in place: a key is its bit pattern (COUNT / DISTINCT only: update_validate)
+    tgx_column as_i64 = c;
+    as_i64.type = TGX_INT64;
+    TGX_TRY(stage_column(st, as_i64, out, err, false));
+    return TGX_OK;
+  }
+  if (c.mem == TGX_MEM_DEVICE && !(is_widened(c.type) && widen32)) return TGX_OK;
   // Only the window the batch views is copied: a sliced array (offset > 0 into big buffers) costs its own rows,
   // not everything before them.  The window starts at slot e0 = offset rounded down to 64 (keeps the validity
   // byte / word alignment the kernels like); the device view gets offset - e0 as its Arrow offset.
   const int64_t e0 = c.offset & ~(int64_t)63;
   const int64_t slots = c.offset - e0 + c.length;  // slots of the window
   const void *p = nullptr;
-  if (is_numeric32(c.type)) {
-    // 4-byte numerics (include/tgx.h): the window is widened to 8-byte values in a staging buffer on the device; the
+  if (is_widened(c.type)) {
+    // 4-byte numerics, narrow integers, Booleans (include/tgx.h): the window is widened to 8-byte values in a staging buffer on the device; the
     // kernels then see an Int64 / Float64 column.  DEVICE columns keep their validity bitmap and Arrow offset as they
     // are (only the values move: slot e0 of the source becomes slot 0 of the widened buffer, so the bitmap of a device
     // column is re-based by staging nothing and pointing at byte e0 / 8).
     const bool host = c.mem == TGX_MEM_HOST;
-    const void *src = c.values ? (const uint8_t *)c.values + (size_t)e0 * 4 : nullptr;
+    // (e0 is a multiple of 64: a whole number of bytes of a Boolean column's bits too)
+    const void *src = c.values ? (const uint8_t *)c.values + narrow_bytes(c.type, e0) : nullptr;
     if (host) {
       TGX_TRY(stage(c.validity ? c.validity + (e0 >> 3) : nullptr, c.validity ? (size_t)((slots + 7) / 8) : 0, &p));
       out->validity = (const uint8_t *)p;
-      TGX_TRY(stage(src, (size_t)slots * 4, &p));
+      TGX_TRY(stage(src, narrow_bytes(c.type, slots), &p));
       src = p;
     } else {
       out->validity = c.validity ? c.validity + (e0 >> 3) : nullptr;
@@ -100,14 +108,14 @@ tgx_status stage_column(tgx_state *st, const tgx_column &c, tgx_column *out, tgx
       out->mem = TGX_MEM_DEVICE;
       return TGX_OK;
     }
-    out->type = c.type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
+    out->type = widened_type(c.type);
     out->values = nullptr;
     if (src) {
       if (st->staging_used == st->staging.size()) st->staging.emplace_back(new DevBuf());
       DevBuf *w = st->staging[st->staging_used++].get();
       HIP_TRY(w->reserve((size_t)slots * 8 + 16));
       // launched by tgx_update once the pinned arena (small HOST buffers travel in it) has been uploaded
-      st->pending_widen.push_back({src, w->p, slots, c.type == TGX_FLOAT32 ? 1 : 0});
+      st->pending_widen.push_back({src, w->p, slots, widen_mode(c.type)});
       out->values = w->p;
     }
     return TGX_OK;
@@ -214,7 +222,10 @@ tgx_status update_validate(const tgx_plan *plan, tgx_state *st, const tgx_column
     if (c.length != nrows)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d has %lld rows, expected %lld", i, (long long)c.length,
                   (long long)nrows);
-    if (c.type < TGX_INT64 || c.type > TGX_FLOAT32) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
+    if (c.type < TGX_INT64 || c.type > TGX_BOOL) return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown type %d", i, c.type);
+    if (is_keys_only(c.type) && plan->stats_on[i])
+      return fail(err, TGX_UNSUPPORTED, "column %d: a %s column takes COUNT and DISTINCT checks only", i,
+                  c.type == TGX_BOOL ? "Boolean" : "UInt64");
     if (c.mem != TGX_MEM_HOST && c.mem != TGX_MEM_DEVICE)
       return fail(err, TGX_INVALID_ARGUMENT, "column %d: unknown memory space %d", i, c.mem);
     if (st->col_types[i] == 0) st->col_types[i] = c.type;
@@ -231,7 +242,7 @@ tgx_status update_validate(const tgx_plan *plan, tgx_state *st, const tgx_column
                            (c.type == TGX_UTF8_VIEW && host) ||
                            (c.type == TGX_DICT32_UTF8 && host && c.dictionary && c.dictionary->mem == TGX_MEM_HOST);
     if (c.length > 0) {
-      if ((is_numeric(c.type) || is_numeric32(c.type)) && reads_values[i] && !c.values)
+      if ((is_numeric(c.type) || is_widened(c.type) || c.type == TGX_UINT64) && reads_values[i] && !c.values)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: values is NULL", i);
       if ((c.type == TGX_UTF8 || c.type == TGX_LARGE_UTF8) && !c.offsets)
         return fail(err, TGX_INVALID_ARGUMENT, "column %d: offsets is NULL", i);
@@ -309,16 +320,27 @@ tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *co
     if (columns[i].mem == TGX_MEM_HOST && columns[i].length > 0) any_host = true;
     if (columns[i].length == 0) {
       dev[i] = columns[i];
-      if (is_numeric32(dev[i].type) && needs_wide[i]) dev[i].type = dev[i].type == TGX_INT32 ? TGX_INT64 : TGX_FLOAT64;
+      if ((is_numeric32(dev[i].type) && needs_wide[i]) || is_narrow_int(dev[i].type)) dev[i].type = widened_type(dev[i].type);
+      if (dev[i].type == TGX_UINT64) dev[i].type = TGX_INT64;
       continue;
     }
-    TGX_TRY(stage_column(st, columns[i], &dev[i], err, needs_wide[i] != 0));
+    // (narrow integers and Booleans are always widened: no kernel reads them in place -- unless no check reads the
+    //  column's values at all: a completeness check needs the validity bitmap only)
+    const bool widen = needs_wide[i] != 0 || (is_narrow_int(columns[i].type) && plan->reads_values[i]);
+    if (is_narrow_int(columns[i].type) && !widen) {
+      tgx_column bare = columns[i];
+      bare.type = TGX_INT64;
+      bare.values = nullptr;
+      TGX_TRY(stage_column(st, bare, &dev[i], err, false));
+      continue;
+    }
+    TGX_TRY(stage_column(st, columns[i], &dev[i], err, widen));
   }
   const bool arena_in_use = st->arena_used != 0;
   if (arena_in_use)
     HIP_TRY(hipMemcpyAsync(st->arena_dev[st->arena_cur].p, st->arena_host[st->arena_cur], st->arena_used,
                            hipMemcpyHostToDevice, st->stream));
-  for (const auto &w : st->pending_widen) launch_widen32(w.src, w.dst, w.n, w.is_float, g_ctx.n_cu, st->stream);
+  for (const auto &w : st->pending_widen) launch_widen32(w.src, w.dst, w.n, w.mode, g_ctx.n_cu, st->stream);
   st->pending_widen.clear();
 
   if (nrows > 0) {

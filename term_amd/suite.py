@@ -444,6 +444,19 @@ class ValidationSuiteBuilder:
     def with_optimizer(self, _enabled):
         return self
 
+    def strict_reference_types(self, on):
+        """True (default): statistics the reference cannot read off a column's type are errors, as there
+        (constraints/statistics.rs:277-308: the aggregate must come back Int64 or Float64 -- MIN / MAX of an Int32,
+        Date32, Float32 or Timestamp column does not); False: the widened column's value answers (a deviation)"""
+        self._s["strict_reference_types"] = bool(on)
+        return self
+
+    def column_type(self, column, arrow_type):
+        """the Arrow DataType of a column of the table ("Int32", "Date32", "Timestamp(Nanosecond, None)", ...); a
+        pyarrow table handed to run() declares its own"""
+        self._s.setdefault("column_types", {})[column] = arrow_type
+        return self
+
     def build(self):
         return ValidationSuite(self._s)
 
@@ -487,9 +500,39 @@ class ValidationSuite:
         name_arr, n_cols, col_arr, n_batches, _keep = _flatten_table(table)
         out = C.c_char_p()
         err = _Error()
-        _host_check(_host().tgx_host_run_suite_json(json.dumps(self.spec).encode(), name_arr, n_cols, col_arr,
+        spec = self.spec
+        declared = _arrow_type_names(table)
+        if declared:  # (what the builder declared wins)
+            spec = dict(spec, column_types=dict(declared, **spec.get("column_types", {})))
+        _host_check(_host().tgx_host_run_suite_json(json.dumps(spec).encode(), name_arr, n_cols, col_arr,
                                                     n_batches, C.byref(out), C.byref(err)), err)
         return ValidationResult(_take(out))
+
+
+def _arrow_type_names(table):
+    """{column: DataType in arrow-rs's Debug spelling} of a pyarrow table (the reference's result-type rule needs the
+    type the caller holds, not the 4- / 8-byte layout it is handed over as); {} for anything else"""
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return {}
+    if not isinstance(table, (pa.Table, pa.RecordBatch)):
+        return {}
+    simple = {pa.int8(): "Int8", pa.int16(): "Int16", pa.int32(): "Int32", pa.int64(): "Int64", pa.uint8(): "UInt8",
+              pa.uint16(): "UInt16", pa.uint32(): "UInt32", pa.uint64(): "UInt64", pa.float16(): "Float16",
+              pa.float32(): "Float32", pa.float64(): "Float64", pa.date32(): "Date32", pa.date64(): "Date64",
+              pa.bool_(): "Boolean"}
+    out = {}
+    for f in table.schema:
+        t = f.type
+        if t in simple:
+            out[f.name] = simple[t]
+        elif pa.types.is_timestamp(t):
+            unit = {"s": "Second", "ms": "Millisecond", "us": "Microsecond", "ns": "Nanosecond"}[t.unit]
+            out[f.name] = "Timestamp(%s, %s)" % (unit, "None" if t.tz is None else 'Some("%s")' % t.tz)
+        elif pa.types.is_time(t) or pa.types.is_duration(t) or pa.types.is_decimal(t):
+            out[f.name] = str(t)
+    return out
 
 
 def _flatten_table(table):

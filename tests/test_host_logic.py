@@ -344,3 +344,54 @@ def test_suite_without_table_reports_errors_and_json_shape():
     r = suite.run(None)
     assert r.is_success() and r.report.has_warnings() and r.metrics().failed_checks == 1
     assert '"status": "success"' in r.to_json()
+
+
+def test_statistics_follow_the_reference_result_type_rule():
+    """constraints/statistics.rs:277-308: the aggregate's column is read as Int64Array, then Float64Array, else
+    Err("Failed to extract statistic value") -- DataFusion's MIN / MAX / APPROX_PERCENTILE_CONT keep the input type, SUM
+    widens signed integers to Int64 and floats to Float64 (unsigned: UInt64), AVG / STDDEV / VARIANCE are Float64.
+    `strict_reference_types` (default) mirrors that; off, the widened column's value answers.  MultiStatistical pushes
+    "Failed to compute {name}" (:478-482); QuantileConstraint also reads Int32 and fails with TypeMismatch (quantile.rs:
+    308-324)."""
+    vals, validity = orc.column_from_list([3, 1, 2, None], np.int64)
+    res = stats_result(vals, validity)
+    gt0 = Assertion.GreaterThan(0.0)
+    ok = {  # statistic -> the Arrow types the reference reads a value for
+        "min": ["Int64", "Float64"], "max": ["Int64", "Float64"],
+        "sum": ["Int64", "Float64", "Int8", "Int16", "Int32", "Float32"],
+        "mean": ["Int64", "Float64", "Int8", "Int16", "Int32", "Float32", "UInt8", "UInt16", "UInt32", "UInt64"],
+        "standard_deviation": ["Int64", "Float64", "Int8", "Int16", "Int32", "Float32", "UInt8", "UInt16", "UInt32", "UInt64"],
+    }
+    every = ["Int64", "Float64", "Int8", "Int16", "Int32", "Float32", "UInt8", "UInt16", "UInt32", "UInt64", "Date32",
+             "Timestamp(Nanosecond, None)"]
+    for stat, good in ok.items():
+        for t in every:
+            if stat in ("sum", "mean", "standard_deviation") and (t.startswith("Date") or t.startswith("Timestamp")):
+                continue  # (DataFusion refuses to plan these: the shim falls back to the stock constraint)
+            c = dict(only(Check.builder("c").statistic("value", stat, gt0)), column_type=t)
+            if t in good:
+                assert S.constraint_verdict(c, [res])["status"] == "success", (stat, t)
+            else:
+                with pytest.raises(T.TgxError) as e:
+                    S.constraint_verdict(c, [res])
+                assert "Internal error: Failed to extract statistic value" in str(e.value), (stat, t)
+                loose = dict(c, strict_reference_types=False)
+                assert S.constraint_verdict(loose, [res])["status"] == "success", (stat, t)
+    # no declared type: the column is what its tgx_type says (Int64 / Float64 here)
+    assert S.constraint_verdict(only(Check.builder("c").statistic("value", "min", gt0)), [res])["status"] == "success"
+    # MultiStatisticalConstraint: a failure entry per unreadable statistic, no error
+    multi = dict(S.MultiStatisticalConstraint("value", [("min", gt0), ("mean", gt0), ("max", gt0)]).spec,
+                 column_type="Int32")
+    v = S.constraint_verdict(multi, [res])
+    assert v["status"] == "failure" and v["message"] == "Failed to compute minimum; Failed to compute maximum"
+    v = S.constraint_verdict(dict(multi, column_type="Int64"), [res])
+    assert v["status"] == "success" and v["metric"] == 1.0
+    # QuantileConstraint: Float64 / Int64 / Int32 are read, the rest is a TypeMismatch
+    q = only(Check.builder("c").has_approx_quantile("value", 0.5, gt0))
+    kll = [{"kll_n": 3, "quantiles": {"0.5": 2.0}}]
+    for t in ("Int32", "Int64", "Float64"):
+        assert S.constraint_verdict(dict(q, column_type=t), kll)["status"] == "success"
+    with pytest.raises(T.TgxError) as e:
+        S.constraint_verdict(dict(q, column_type="Float32"), kll)
+    assert "Type mismatch: expected Float64, Int64, or Int32, found Float32" in str(e.value)
+    assert S.constraint_verdict(dict(q, column_type="Float32", strict_reference_types=False), kll)["status"] == "success"
