@@ -414,9 +414,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   } loan{st, st->stream};
   if (overlap) {
     if (!st->aux_stream) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (hi is the numerically lowest = most urgent)
-      HIP_TRY(hipStreamCreateWithPriority(&st->aux_stream, hipStreamNonBlocking, hi));
+      HIP_TRY(stream_acquire(&st->aux_stream, true));  // (the most urgent priority; from the library's pool)
       HIP_TRY(hipEventCreateWithFlags(&st->aux_done, hipEventDisableTiming));
     }
     HIP_TRY(hipStreamWaitEvent(st->aux_stream, st->keys_ready, 0));

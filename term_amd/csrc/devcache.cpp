@@ -51,6 +51,19 @@ bool poison() {
   }();
   return on;
 }
+// (on a stream of its own that does not synchronise with the others: a null-stream hipMemset waits for every blocking
+//  stream of the device -- with ranks as threads of one process, one of them inside a collective's barrier, for ever)
+void poison_block(void *p, size_t bytes) {
+  static hipStream_t s = [] {
+    hipStream_t q = nullptr;
+    (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+    return q;
+  }();
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  (void)hipMemsetAsync(p, 0xA5, bytes, s);
+  (void)hipStreamSynchronize(s);
+}
 uint64_t dev_limit() {
   static const uint64_t lim = [] {
     if (const char *e = getenv("TGX_DEVICE_CACHE_MAX_BYTES")) return (uint64_t)strtoull(e, nullptr, 10);
@@ -77,18 +90,25 @@ QuiescedScope::~QuiescedScope() { tl_quiesced--; }
 hipError_t dev_alloc(void **p, size_t *cap, size_t bytes) {
   const size_t cls = cache_enabled() ? cache_size_class(bytes) : bytes;
   if (cache_enabled()) {
-    std::lock_guard<std::mutex> lock(g_dev.mu);
-    auto it = g_dev.free_blocks.find(cls);
-    if (it != g_dev.free_blocks.end() && !it->second.empty()) {
-      *p = it->second.back();
-      it->second.pop_back();
-      g_dev.cached_bytes -= cls;
-      g_dev.hits++;
+    bool hit = false;
+    {
+      std::lock_guard<std::mutex> lock(g_dev.mu);
+      auto it = g_dev.free_blocks.find(cls);
+      if (it != g_dev.free_blocks.end() && !it->second.empty()) {
+        *p = it->second.back();
+        it->second.pop_back();
+        g_dev.cached_bytes -= cls;
+        g_dev.hits++;
+        hit = true;
+      } else {
+        g_dev.misses++;
+      }
+    }
+    if (hit) {
       *cap = cls;
-      if (poison()) (void)hipMemset(*p, 0xA5, cls);
+      if (poison()) poison_block(*p, cls);
       return hipSuccess;
     }
-    g_dev.misses++;
   }
   hipError_t e = hipMalloc(p, cls);
   if (e != hipSuccess && cache_enabled()) {
@@ -101,7 +121,7 @@ hipError_t dev_alloc(void **p, size_t *cap, size_t bytes) {
     return e;
   }
   *cap = cls;
-  if (poison()) (void)hipMemset(*p, 0xA5, cls);
+  if (poison()) poison_block(*p, cls);
   return hipSuccess;
 }
 
@@ -161,7 +181,56 @@ void pinned_free(void *p, size_t bytes) {
   (void)hipHostFree(p);
 }
 
+// ---- streams ----------------------------------------------------------------------------------------------------
+// hipStreamCreate / hipStreamDestroy cost 0.4 - 0.5 ms each on this runtime (tools/trace_cold_step.sh): more than the
+// whole device side of a 100 M-row x 8-column suite's key passes.  A destroyed state's own streams (idle: the device
+// has been waited for) are kept and handed to the next state.
+namespace {
+std::mutex g_stream_mu;
+std::vector<hipStream_t> g_streams[2];  // [0] default priority, [1] the highest
+}  // namespace
+
+hipError_t stream_acquire(hipStream_t *out, bool high_priority) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    auto &pool = g_streams[high_priority ? 1 : 0];
+    if (cache_enabled() && !pool.empty()) {
+      *out = pool.back();
+      pool.pop_back();
+      return hipSuccess;
+    }
+  }
+  if (!high_priority) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi);
+}
+
+void stream_release(hipStream_t s, bool high_priority) {
+  if (!s) return;
+  if (cache_enabled()) {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    auto &pool = g_streams[high_priority ? 1 : 0];
+    if (pool.size() < 64) {
+      pool.push_back(s);
+      return;
+    }
+  }
+  (void)hipStreamDestroy(s);
+}
+
 void dev_cache_trim() {
+  {
+    std::vector<hipStream_t> streams;
+    {
+      std::lock_guard<std::mutex> lock(g_stream_mu);
+      for (auto &pool : g_streams) {
+        streams.insert(streams.end(), pool.begin(), pool.end());
+        pool.clear();
+      }
+    }
+    for (hipStream_t s : streams) (void)hipStreamDestroy(s);
+  }
   std::map<size_t, std::vector<void *>> dev, host;
   {
     std::lock_guard<std::mutex> lock(g_dev.mu);

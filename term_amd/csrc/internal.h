@@ -224,6 +224,9 @@ hipError_t dev_alloc(void **p, size_t *cap, size_t bytes);  // `*cap` = the bloc
 void dev_free(void *p, size_t cap);                          // waits for the device unless inside a QuiescedScope
 hipError_t pinned_alloc(void **p, size_t bytes);
 void pinned_free(void *p, size_t bytes);                     // `bytes` as asked for
+// a non-blocking stream from / back to the library's pool (the caller has waited for everything queued on it)
+hipError_t stream_acquire(hipStream_t *out, bool high_priority);
+void stream_release(hipStream_t s, bool high_priority);
 void dev_cache_trim();
 void dev_cache_stats(tgx_cache_stats *out);
 // "the device has been waited for and this thread queues nothing until the scope ends": releases inside it skip the
@@ -495,7 +498,7 @@ struct tgx_state {
 
   // device accumulators
   tgx::DevBuf d_scan_acc, d_count_acc, d_como_acc, d_pivots, d_pivot_set;
-  tgx::DevBuf d_scan_identity;  // the accumulators' identities, copied over d_scan_acc by reset
+  tgx::DevBuf d_scan_identity;  // (unused since round 5: state_reset_kernel writes the identities itself)
   struct Widen {
     const void *src;
     void *dst;

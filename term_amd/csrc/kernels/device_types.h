@@ -184,9 +184,8 @@ struct StateResetArgs {
   void *zero[kResetRegions];       // regions to clear (16-byte aligned allocations)
   uint32_t zero_bytes[kResetRegions];
   int32_t n_zero;
-  void *copy_dst;                  // the scan accumulators ...
-  const void *copy_src;            // ... and their identities
-  uint32_t copy_bytes;
+  ScanAcc *ident;                  // the scan accumulators: set to their identity (MIN = INT64_MAX, MAX = INT64_MIN, else 0)
+  uint32_t n_ident;
 };
 
 __host__ __device__ inline int64_t f64_total_key(int64_t bits) {

@@ -1451,13 +1451,17 @@ __global__ __launch_bounds__(256) void state_reset_kernel(StateResetArgs a) {
     const uint32_t words = a.zero_bytes[r] >> 2;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) p[i] = 0;
   }
-  const uint32_t *src = (const uint32_t *)a.copy_src;
-  uint32_t *dst = (uint32_t *)a.copy_dst;
-  const uint32_t words = a.copy_bytes >> 2;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) dst[i] = src[i];
+  // the accumulators' identities, two 8-byte words at a time (ScanAcc is 12 of them: words 2 and 3 are MIN and MAX)
+  constexpr uint32_t W = sizeof(ScanAcc) / 8;
+  static_assert(sizeof(ScanAcc) % 8 == 0 && offsetof(ScanAcc, min_k) == 16 && offsetof(ScanAcc, max_k) == 24, "layout");
+  long long *dst = (long long *)a.ident;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n_ident * W; i += gridDim.x * 256u) {
+    const uint32_t w = i % W;
+    dst[i] = w == 2 ? INT64_MAX : w == 3 ? INT64_MIN : 0;
+  }
 }
 void launch_state_reset(const StateResetArgs &a, hipStream_t stream) {
-  uint32_t most = a.copy_bytes;
+  uint32_t most = a.n_ident * (uint32_t)sizeof(ScanAcc);
   for (int r = 0; r < a.n_zero; r++) most = a.zero_bytes[r] > most ? a.zero_bytes[r] : most;
   const unsigned blocks = most <= 4096u ? 1u : (most / 4096u > 64u ? 64u : most / 4096u);
   hipLaunchKernelGGL(state_reset_kernel, dim3(blocks), dim3(256), 0, stream, a);

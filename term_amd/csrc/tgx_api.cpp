@@ -302,9 +302,13 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
     P->stats_on.assign(P->n_columns_needed, 0);
     for (auto &t : P->distinct)
       if (t.tuple.empty() && !t.approx_only) P->key_column[t.column] = 1;
-    for (auto &t : P->scan) P->stats_on[t.column] = 1;
-    for (auto &t : P->como) P->stats_on[t.col_x] = P->stats_on[t.col_y] = 1;
-    for (auto &t : P->kll) P->stats_on[t.column] = 1;
+    // (by what was ASKED: a key column has a scan task of its own for the range decisions of its key set)
+    for (size_t i = 0; i < n_specs; i++) {
+      const tgx_check_spec &sp = P->specs[i];
+      if (sp.kind == TGX_CHECK_NUMERIC_STATS || sp.kind == TGX_CHECK_KLL || sp.kind == TGX_CHECK_APPROX_DISTINCT)
+        P->stats_on[sp.column] = 1;
+      if (sp.kind == TGX_CHECK_COMOMENTS) P->stats_on[sp.column] = P->stats_on[sp.column2] = 1;
+    }
     for (auto &t : P->scan) P->used[t.column] = P->reads_values[t.column] = 1;
     for (auto &t : P->count) P->used[t.column] = 1;
     for (auto &t : P->distinct) {
@@ -451,38 +455,47 @@ void state_init_host(tgx_state *st, const tgx_plan *plan) {
   spearman_state_init(st);
 }
 
+// one launch for all the small accumulators of a state (fresh, or reset): the scan accumulators to their identities,
+// everything else to zero (all sizes are multiples of four bytes)
+static void state_reset_small(tgx_state *st) {
+  const tgx_plan *plan = st->plan;
+  StateResetArgs a;
+  memset(&a, 0, sizeof(a));
+  auto zero = [&](void *p, size_t bytes) {
+    if (!p || bytes == 0) return;
+    a.zero[a.n_zero] = p;
+    a.zero_bytes[a.n_zero] = (uint32_t)bytes;
+    a.n_zero++;
+  };
+  if (!plan->scan.empty()) {
+    a.ident = st->d_scan_acc.as<ScanAcc>();
+    a.n_ident = (uint32_t)plan->scan.size();
+    zero(st->d_pivots.p, plan->scan.size() * sizeof(double));
+    zero(st->d_pivot_set.p, plan->scan.size() * sizeof(int32_t));
+  }
+  if (!plan->count.empty()) zero(st->d_count_acc.p, plan->count.size() * sizeof(CountAcc));
+  if (!plan->como.empty()) zero(st->d_como_acc.p, plan->como.size() * sizeof(ComomentAcc));
+  zero(st->d_distinct_counters.p, st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long));
+  if (a.n_zero || a.n_ident) launch_state_reset(a, st->stream);
+}
+
 tgx_status tgx::state_init_device(tgx_state *st, tgx_error *err) {
   if (st->device_ready) return TGX_OK;
   TGX_TRY(need_device(err));
   const tgx_plan *plan = st->plan;
   if (!st->stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    HIP_TRY(stream_acquire(&st->stream, false));  // (from the library's pool: creating one costs ~0.4 ms)
     st->own_stream = true;
   }
-  // (zero-fills go through the state's own stream: it is non-blocking, so a null-stream hipMemset could still be
-  //  in flight when the first kernel on it starts)
+  // the small accumulators: allocated, then brought to their identities by ONE launch on the state's own stream (a
+  // synchronous copy of the identities, a device copy and five fills cost a fresh state ~0.1 ms of host time)
   if (!plan->scan.empty()) {
-    std::vector<ScanAcc> init(plan->scan.size(), scan_acc_identity());
-    HIP_TRY(st->d_scan_acc.reserve(init.size() * sizeof(ScanAcc)));
-    // the identities are kept on the device: tgx_state_reset then restores them with a copy ordered on the state's
-    // stream (a synchronous hipMemcpy in reset held the caller until every stream of the device had drained)
-    HIP_TRY(st->d_scan_identity.reserve(init.size() * sizeof(ScanAcc)));
-    HIP_TRY(hipMemcpy(st->d_scan_identity.p, init.data(), init.size() * sizeof(ScanAcc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpyAsync(st->d_scan_acc.p, st->d_scan_identity.p, init.size() * sizeof(ScanAcc),
-                           hipMemcpyDeviceToDevice, st->stream));
+    HIP_TRY(st->d_scan_acc.reserve(plan->scan.size() * sizeof(ScanAcc)));
     HIP_TRY(st->d_pivots.reserve(plan->scan.size() * sizeof(double)));
     HIP_TRY(st->d_pivot_set.reserve(plan->scan.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(st->d_pivots.p, 0, plan->scan.size() * sizeof(double), st->stream));
-    HIP_TRY(hipMemsetAsync(st->d_pivot_set.p, 0, plan->scan.size() * sizeof(int32_t), st->stream));
   }
-  if (!plan->count.empty()) {
-    HIP_TRY(st->d_count_acc.reserve(plan->count.size() * sizeof(CountAcc)));
-    HIP_TRY(hipMemsetAsync(st->d_count_acc.p, 0, plan->count.size() * sizeof(CountAcc), st->stream));
-  }
-  if (!plan->como.empty()) {
-    HIP_TRY(st->d_como_acc.reserve(plan->como.size() * sizeof(ComomentAcc)));
-    HIP_TRY(hipMemsetAsync(st->d_como_acc.p, 0, plan->como.size() * sizeof(ComomentAcc), st->stream));
-  }
+  if (!plan->count.empty()) HIP_TRY(st->d_count_acc.reserve(plan->count.size() * sizeof(CountAcc)));
+  if (!plan->como.empty()) HIP_TRY(st->d_como_acc.reserve(plan->como.size() * sizeof(ComomentAcc)));
   if (!plan->hll.empty()) {
     HIP_TRY(st->d_hll.reserve(plan->hll.size() * (size_t)kHllRegisters));
     HIP_TRY(hipMemsetAsync(st->d_hll.p, 0, plan->hll.size() * (size_t)kHllRegisters, st->stream));
@@ -490,10 +503,10 @@ tgx_status tgx::state_init_device(tgx_state *st, tgx_error *err) {
   if (!st->distinct.empty()) {
     const size_t each = kNumDistinctCounters * sizeof(unsigned long long);
     HIP_TRY(st->d_distinct_counters.reserve(st->distinct.size() * each));
-    HIP_TRY(hipMemsetAsync(st->d_distinct_counters.p, 0, st->distinct.size() * each, st->stream));
     for (size_t i = 0; i < st->distinct.size(); i++)
       st->distinct[i].counters.borrow((char *)st->d_distinct_counters.p + i * each, each);
   }
+  state_reset_small(st);
   st->device_ready = true;
   return TGX_OK;
 }
@@ -545,8 +558,9 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   pinned_free(st->h_pinned, st->h_pinned_cap);
   if (st->keys_ready) (void)hipEventDestroy(st->keys_ready);
   if (st->aux_done) (void)hipEventDestroy(st->aux_done);
-  if (st->aux_stream) (void)hipStreamDestroy(st->aux_stream);
-  if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
+  // (idle: the device has been waited for above) back to the pool -- hipStreamDestroy costs ~0.5 ms
+  if (st->aux_stream) stream_release(st->aux_stream, true);
+  if (st->own_stream && st->stream) stream_release(st->stream, false);
   delete st;
 }
 
@@ -611,28 +625,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
   st->hll_mode.assign(plan->hll.size(), 0);
   if (st->device_ready && st->d_hll.p)
     HIP_TRY(hipMemsetAsync(st->d_hll.p, 0, plan->hll.size() * (size_t)kHllRegisters, st->stream));
-  if (st->device_ready) {
-    // one launch for all the small accumulators (all sizes are multiples of four bytes)
-    StateResetArgs a;
-    memset(&a, 0, sizeof(a));
-    auto zero = [&](void *p, size_t bytes) {
-      if (!p || bytes == 0) return;
-      a.zero[a.n_zero] = p;
-      a.zero_bytes[a.n_zero] = (uint32_t)bytes;
-      a.n_zero++;
-    };
-    if (!plan->scan.empty()) {
-      a.copy_dst = st->d_scan_acc.p;
-      a.copy_src = st->d_scan_identity.p;
-      a.copy_bytes = (uint32_t)(plan->scan.size() * sizeof(ScanAcc));
-      zero(st->d_pivots.p, plan->scan.size() * sizeof(double));
-      zero(st->d_pivot_set.p, plan->scan.size() * sizeof(int32_t));
-    }
-    if (!plan->count.empty()) zero(st->d_count_acc.p, plan->count.size() * sizeof(CountAcc));
-    if (!plan->como.empty()) zero(st->d_como_acc.p, plan->como.size() * sizeof(ComomentAcc));
-    zero(st->d_distinct_counters.p, st->distinct.size() * kNumDistinctCounters * sizeof(unsigned long long));
-    if (a.n_zero || a.copy_bytes) launch_state_reset(a, st->stream);
-  }
+  if (st->device_ready) state_reset_small(st);
   return TGX_OK;
 } catch (...) {
   return tgx::abi_exception(err);

@@ -26,7 +26,7 @@ def result_tuple(T, s, r):
     if k == T.DISTINCT:
         return ["distinct", r.total, r.non_null, r.distinct, r.groups_once]
     if k == T.COMOMENTS:
-        return ["como", r.non_null, r.sum_x.hex(), r.sum_y.hex(), r.sum_xx.hex(), r.sum_yy.hex(), r.sum_xy.hex()]
+        return ["como", r.non_null, r.sum_x.hex(), r.sum_y.hex(), r.sum_x2.hex(), r.sum_y2.hex(), r.sum_xy.hex()]
     if k == T.KLL:
         return ["kll", r.kll_n]
     if k == T.REGEX_MATCH:

@@ -104,6 +104,6 @@ def test_blocks_handed_out_with_stale_contents_change_nothing():
     tester's plans -- every kind of check, HOST and DEVICE batches, merges, blobs -- against the oracle in a child."""
     env = dict(os.environ, TGX_DEVICE_CACHE_POISON="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_device.py"), "--first", "5150", "--count", "40",
-                        "--max-rows", "1200000"], env=env, capture_output=True, text=True, timeout=1200)
+                        "--max-rows", "1200000", "--seed-timeout", "90"], env=env, capture_output=True, text=True, timeout=540)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "40 cases of 40 selected" in p.stdout and ", 0 failed" in p.stdout, p.stdout[-800:]

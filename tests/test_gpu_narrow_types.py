@@ -128,7 +128,7 @@ def test_uint64_and_boolean_columns_count_and_distinct(device):
             run_plan([bad], [cols(0, 1000)])
         assert e.value.status == "TGX_UNSUPPORTED" and "COUNT and DISTINCT checks only" in str(e.value)
     # completeness alone reads no values at all
-    res, _, _ = run_plan([spec(T.COUNT, 1)], [[T.Column(T.BOOL, n, values=None, validity=(to_device(pad_validity(bval)) if device else pad_validity(bval)))]])
+    res, _, _ = run_plan([spec(T.COUNT, 0)], [[T.Column(T.BOOL, n, values=None, validity=(to_device(pad_validity(bval)) if device else pad_validity(bval)))]])
     assert (res[0].total, res[0].non_null) == (n, ob.non_null)
 
 

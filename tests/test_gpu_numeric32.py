@@ -126,7 +126,10 @@ def test_from_arrow_32_bit_and_int64_shaped_types():
 
 def test_suite_over_32_bit_columns():
     """the suite front end (term_amd/suite.py -> host layer -> tgx) on a table of Int32 / Float32 / Date32 /
-    Timestamp columns: verdicts and metrics as on the Int64 / Float64 twin of the table"""
+    Timestamp columns.  With `strict_reference_types(False)`: verdicts and metrics as on the Int64 / Float64 twin of the
+    table (the widening deviation).  By default: what the reference does -- MIN / MAX of such a column come back in the
+    column's own type, which StatisticalConstraint cannot read: "Failed to extract statistic value"
+    (constraints/statistics.rs:277-308), a failed check; SUM (Int64) and AVG (Float64) of them are read."""
     import pyarrow as pa
 
     from term_amd.suite import Assertion, Check, Level, ValidationSuite
@@ -153,7 +156,16 @@ def test_suite_over_32_bit_columns():
              .has_mean("price", Assertion.Between(45.0, 55.0)).has_sum("qty", Assertion.GreaterThan(0.0))
              .has_min("day", Assertion.GreaterThanOrEqual(8000.0)).has_max("ts", Assertion.LessThan(2.0e15))
              .validates_uniqueness(["key"], 1.0).validates_uniqueness(["qty"], 0.5).build())
-    suite = ValidationSuite.builder("s").check(check).build()
+    strict = ValidationSuite.builder("s").check(check).build()
+    suite = ValidationSuite.builder("s").check(check).strict_reference_types(False).build()
+    as_reference, twin = strict.run(table(True)), strict.run(table(False))
+    errors = [i for i in as_reference.report.issues if i.message.startswith("Error evaluating constraint")]
+    assert [(i.constraint_name, i.message) for i in errors] == [
+        (name, "Error evaluating constraint: Internal error: Failed to extract statistic value")
+        for name in ("min", "max", "min", "max")]   # qty Int32, qty Int32, day Date32, ts Timestamp
+    assert as_reference.is_failure() and as_reference.report.metrics.failed_checks == 5
+    kept = {k: v for k, v in twin.report.metrics.custom_metrics.items() if k not in ("chk.min", "chk.max")}
+    assert as_reference.report.metrics.custom_metrics == kept   # mean(price Float32), sum(qty Int32), the uniqueness ratios
     narrow, wide = suite.run(table(True)), suite.run(table(False))
     assert narrow.report.metrics.custom_metrics == wide.report.metrics.custom_metrics
     assert [i.message for i in narrow.report.issues] == [i.message for i in wide.report.issues]

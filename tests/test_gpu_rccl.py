@@ -40,7 +40,11 @@ def test_world1_step_over_rccl_equals_the_plain_state(suite, rows):
     id_distinct = [r for r in got["sharded"] if r[0] == "distinct"][0]
     assert id_distinct[3] == got["rows"]   # the id column is a permutation of 0 .. n-1
     if suite == "full":
-        assert got["kll_sharded"] == got["kll_plain"]
+        # (the sharded state's sketch has been packed, gathered and merged into an emptied state: another sketch of the
+        #  same stream -- equal weight, quantiles within the stated rank error of each other; kll_sketch.rs:397-399)
+        eps = 1.65 / 200 ** 0.5
+        for a, b in zip(got["kll_sharded"], got["kll_plain"]):
+            assert abs(a - b) < eps * max(1.0, abs(b)), (a, b)
 
 
 def test_bench_force_distributed_line():

@@ -282,6 +282,7 @@ def measure(T, torch, synth, spec, layout, unique_cols, headline_plan, table, co
     del columns[:]
     del table[:]
     torch.cuda.empty_cache()
+    T.init(distinct_capacity_hint=100_000_000)  # (the hint is per process: each config states its own rows)
     out["C2"] = run_c2(T, torch, synth, spec, max(steps, 10), warmup, seed)
     out["cold"]["C2_cold_step_ms"] = out["C2"].pop("cold_step_ms")
     out["cold"]["C2_cold_first_state_ms"] = out["C2"].pop("cold_first_state_ms")
@@ -292,6 +293,8 @@ def measure(T, torch, synth, spec, layout, unique_cols, headline_plan, table, co
     out.update(run_c3(T, torch, spec, max(steps, 10), warmup))
     note("C3")
     torch.cuda.empty_cache()
+    T.init(distinct_capacity_hint=1 << 20)  # (dictionaries of at most 1 M entries)
+    T.trim()
     out["C5"] = run_c5(T, torch, synth, spec, steps, warmup)
     note("C5")
     torch.cuda.empty_cache()
