@@ -103,7 +103,19 @@ typedef enum tgx_type {
   TGX_BOOL = 15
 } tgx_type;
 
-typedef enum tgx_memspace { TGX_MEM_HOST = 0, TGX_MEM_DEVICE = 1 } tgx_memspace;
+typedef enum tgx_memspace {
+  TGX_MEM_HOST = 0,
+  TGX_MEM_DEVICE = 1,
+  /* HOST buffers the caller keeps alive AND unmodified until the next flushing call (tgx_finalize, tgx_state_sync,
+   * tgx_state_serialize, tgx_merge, tgx_allreduce, tgx_state_reset) -- the contract DEVICE buffers have.  What it
+   * buys: a small batch (coalesced, below) is only NOTED -- its windows are copied into the pinned arena when the
+   * flush runs, all of a flush's windows together by the library's copy threads, instead of window by window on the
+   * calling thread inside tgx_update (one core moves ~27 GB/s: the cap of a stream of 8192-row batches).  A consumer of
+   * DataFusion's `execute_stream()` holds the RecordBatches (Arc'd buffers) until it syncs.  Batches that are not
+   * coalesced are read before tgx_update returns, as TGX_MEM_HOST ones are.  All HOST columns of a batch should be
+   * given the same way (a batch that mixes the two is taken as TGX_MEM_HOST). */
+  TGX_MEM_HOST_RETAINED = 2
+} tgx_memspace;
 
 typedef struct tgx_column {
   int32_t type;            /* tgx_type */
@@ -281,6 +293,12 @@ size_t tgx_plan_num_specs(const tgx_plan *plan);
  * waits on, or a synchronisation); the library's own stream does not wait for the legacy default stream. */
 tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **out, tgx_error *err);
 void tgx_state_destroy(tgx_state *state);
+/* How many of the batches handed to tgx_update so far are only NOTED (coalesced, not yet run): the LAST `*batches` ones.
+ * A caller that feeds TGX_MEM_HOST_RETAINED (or DEVICE) buffers of a long stream may release every batch before those
+ * -- the library flushes by itself every few tens of MB -- instead of holding the whole table until tgx_finalize.
+ * (DEVICE batches a sampled-range key set retains for a repair are the exception stated at tgx_update.)  Makes no
+ * device call. */
+tgx_status tgx_state_pending(const tgx_state *state, uint64_t *batches, uint64_t *rows);
 
 /* One call per RecordBatch: replaces DataFusion's accumulator `update_batch` for the plan's
  * aggregates (`Analyzer::compute_state_from_data`, TG/analyzers/traits.rs:98-111).  `columns[i]` is

@@ -19,6 +19,16 @@ pub struct ColumnView {
     _realigned_validity: Option<Buffer>,
 }
 
+impl ColumnView {
+    /// The view as `TGX_MEM_HOST_RETAINED`: the caller promises to keep the array (this `ColumnView`) alive and
+    /// unmodified until the library has run the batch (`State::pending`), and the library may copy it at the flush.
+    pub fn retained(&self) -> tgx_column {
+        let mut c = self.raw;
+        c.mem = TGX_MEM_HOST_RETAINED;
+        c
+    }
+}
+
 /// `None`: a type outside the path (Decimal, Binary, nested ..) -- evaluate the constraint with the stock SQL.
 pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
     let d = arr.to_data();
@@ -131,7 +141,10 @@ pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
         {
             view.raw.type_ = TGX_DICT32_UTF8;
             view.raw.values = first(0) as _;
-            let dict = Box::new(column_view(&make_array(d.child_data()[0].clone()))?);
+            let mut dict = Box::new(column_view(&make_array(d.child_data()[0].clone()))?);
+            // (the dictionary lives as long as this view does: with `retained()` indices the whole column is kept; with
+            //  the plain `raw` the library sees a batch that mixes the two and copies it before `update` returns)
+            dict.raw.mem = TGX_MEM_HOST_RETAINED;
             view.raw.dictionary = &dict.raw as *const tgx_column;
             view._dictionary = Some(dict);
         }

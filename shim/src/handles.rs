@@ -133,6 +133,13 @@ impl<'p> State<'p> {
         let mut err = new_err();
         check(unsafe { tgx_update(self.plan.raw(), self.raw, columns.as_ptr(), columns.len(), &mut err) }, &err)
     }
+    /// How many of the batches fed so far are only noted (coalesced, not yet run): the last `.0` ones (`.1` rows).
+    /// Whoever feeds `TGX_MEM_HOST_RETAINED` buffers keeps exactly those alive.
+    pub fn pending(&self) -> (u64, u64) {
+        let (mut b, mut r) = (0u64, 0u64);
+        unsafe { tgx_state_pending(self.raw, &mut b, &mut r) };
+        (b, r)
+    }
     /// `AnalyzerState::merge` (traits.rs:160-170): exact, DISTINCT included (set union).
     pub fn merge(&mut self, others: &mut [State<'p>]) -> Result<(), Error> {
         let raws: Vec<*mut tgx_state> = others.iter().map(|s| s.raw).collect();

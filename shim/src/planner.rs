@@ -443,6 +443,12 @@ impl GpuPlanner {
             .collect();
         // 2. one scan of the table instead of one per constraint; batches as DataFusion makes them (8192 rows,
         //    core/context.rs:28-38): the library coalesces them
+        //    The batches are handed over as TGX_MEM_HOST_RETAINED: a RecordBatch is a set of Arc'd buffers, so holding
+        //    the ones the library has only NOTED (`State::pending`: the last few hundred at most -- it flushes every few
+        //    tens of MB) costs nothing, and their copy into pinned memory then happens at the flush, on the library's
+        //    copy threads, instead of window by window inside `update` on this thread.
+        let mut held: std::collections::VecDeque<(datafusion::arrow::record_batch::RecordBatch, Vec<Option<ColumnView>>)> =
+            std::collections::VecDeque::new();
         let mut stream = df.execute_stream().await?;
         while let Some(batch) = stream.next().await {
             let batch = batch?;
@@ -455,8 +461,16 @@ impl GpuPlanner {
                 *self.shared.output.write().unwrap() = None;
                 return Ok(());
             }
-            let raw: Vec<tgx_column> = views.iter().map(|v| v.as_ref().map(|v| v.raw).unwrap_or_else(unused_column)).collect();
+            let raw: Vec<tgx_column> = views
+                .iter()
+                .map(|v| v.as_ref().map(|v| v.retained()).unwrap_or_else(unused_column))
+                .collect();
             state.update(&raw).map_err(internal)?;
+            held.push_back((batch, views)); // (the views own what `raw` pointed into: re-aligned bitmaps, buffer tables)
+            let (pending, _) = state.pending();
+            while held.len() as u64 > pending {
+                held.pop_front();
+            }
         }
         // 3. finalize; the quantiles are read while the sketches exist
         let results = state.finalize().map_err(internal)?;

@@ -51,6 +51,7 @@ from ._lib import (  # noqa: F401
     UTF8_VIEW,
     MEM_HOST,
     MEM_DEVICE,
+    MEM_HOST_RETAINED,
 )
 
 __version__ = "0.1.0"

@@ -14,7 +14,7 @@ FLAG_EXACT_RANK_SUMS = 32
 ABI_VERSION = 4  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
 INT8, INT16, UINT8, UINT16, UINT32, UINT64, BOOL = 9, 10, 11, 12, 13, 14, 15  # (include/tgx.h: narrow / unsigned / Boolean)
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_RETAINED = 0, 1, 2
 STATUS_NAMES = {0: "TGX_OK", 1: "TGX_INVALID_ARGUMENT", 2: "TGX_UNSUPPORTED", 3: "TGX_DEVICE_ERROR",
                 4: "TGX_OUT_OF_MEMORY", 5: "TGX_INTERNAL", 6: "TGX_NO_DEVICE"}
 
@@ -168,6 +168,7 @@ def lib():
         L.tgx_regex_validate.argtypes = [C.c_char_p, sz, C.c_uint32, E]
         L.tgx_regex_is_match.argtypes = [C.c_char_p, sz, C.c_uint32, C.c_char_p, sz, C.POINTER(C.c_int32), E]
         L.tgx_cache_stats_get.argtypes = [C.POINTER(CacheStats)]
+        L.tgx_state_pending.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -530,11 +531,18 @@ class State:
         # allocator while the scan of b1 is still reading it
         # HOST buffers are borrowed only until tgx_update returns: holding them would pin a whole streamed table in
         # host memory until finalize
-        held = [c for c in cols if c is not None and (c.c.mem == 1 or (c.c.dictionary and c.c.dictionary.contents.mem == 1))]
+        # (TGX_MEM_HOST_RETAINED buffers are promised to stay as they are until the next flushing call: held likewise)
+        held = [c for c in cols if c is not None and (c.c.mem != 0 or (c.c.dictionary and c.c.dictionary.contents.mem != 0))]
         if held:
             if getattr(self, "_keep", None) is None:
                 self._keep = []
             self._keep.append(held)
+
+    def pending(self):
+        """(batches, rows) that tgx_update has only noted so far: the last ones fed"""
+        b, r = C.c_uint64(), C.c_uint64()
+        lib().tgx_state_pending(self.h, C.byref(b), C.byref(r))
+        return b.value, r.value
 
     def finalize(self):
         res = (Result * max(1, self.plan.n))()

@@ -72,6 +72,7 @@ struct BatchTraits {
   bool any_host = false, any_utf8 = false;
   bool any_strings = false;  // a used column is Utf8 / LargeUtf8 / Utf8View / a dictionary
   bool coalescible = true;  // every used column is of a kind the segment gather takes (kernels/gather.hip)
+  bool retained = false;    // the batch's HOST columns were all given as TGX_MEM_HOST_RETAINED: their copies may wait for the flush
 };
 
 struct DistinctTotals {

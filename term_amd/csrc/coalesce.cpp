@@ -14,6 +14,7 @@
 // than a batch -- and then sleeps.  TGX_COPY_THREADS=0 keeps every copy on the calling thread.
 namespace {
 typedef tgx::CoalesceCopy CopyJob;
+void copy_piece(CopyJob &j);  // (below: the copy, and the MIN / MAX of a key column's piece)
 // K workers (TGX_COPY_THREADS, default 3), each with its own job slot.  A caller CLAIMS the workers that are idle at
 // that moment (states fed from several threads at once -- a state per DataFusion partition stream -- share the pool:
 // the first version gave the whole pool to one caller at a time and let the others copy alone at a core's 27 GB/s),
@@ -125,7 +126,7 @@ class CopyPool {
         }
       }
       seen = k.posted.load(std::memory_order_acquire);
-      for (size_t q = 0; q < k.n; q++) stream_copy(k.jobs[q].dst, k.jobs[q].src, k.jobs[q].bytes);
+      for (size_t q = 0; q < k.n; q++) copy_piece(const_cast<CopyJob &>(k.jobs[q]));
       k.done.store(seen, std::memory_order_release);
     }
   }
@@ -155,6 +156,14 @@ void stream_copy(void *dst, const void *src, size_t bytes) {
 #endif
   memcpy(dst, src, bytes);
 }
+
+namespace {
+void copy_piece(CopyJob &j) {
+  stream_copy(j.dst, j.src, j.bytes);
+  if (j.mm_col >= 0)
+    host_minmax_i64((const int64_t *)j.src, j.mm_validity, j.mm_bit0, (int64_t)(j.bytes / 8), &j.lo, &j.hi);
+}
+}  // namespace
 
 // MIN / MAX of the non-NULL values of an Int64 window (row 0 = bit `bit0` of *validity).  Runs on the thread that
 // notes the batch, once per key column and batch: the plain loop is compiled a second time for AVX2 (64-bit
@@ -339,6 +348,8 @@ size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int6
   return total;
 }
 
+void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs);
+
 tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, int64_t nrows,
                                   const BatchTraits &traits, bool *taken, tgx_error *err) {
   Coalescer &co = st->coalesce;
@@ -417,11 +428,11 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
     Coalescer &co;
     std::vector<size_t> &segs, &dict_segs;
     std::vector<int64_t> &data_bytes;
-    size_t arena_used;
+    size_t arena_used, deferred;
     bool armed;
     // (`needed` is false for a batch of DEVICE numeric windows: its segments go into reserved room, nothing can throw)
     Rollback(Coalescer &c, std::vector<size_t> &s, std::vector<size_t> &d, std::vector<int64_t> &b, bool needed)
-        : co(c), segs(s), dict_segs(d), data_bytes(b), arena_used(c.arena_used), armed(needed) {
+        : co(c), segs(s), dict_segs(d), data_bytes(b), arena_used(c.arena_used), deferred(c.deferred.size()), armed(needed) {
       if (!needed) return;
       segs.clear();
       dict_segs.clear();
@@ -451,6 +462,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
         }
       }
       co.arena_used = arena_used;
+      co.deferred.resize(deferred);
     }
   } rollback(co, rb_segs, rb_dict_segs, rb_data_bytes, any_host || traits.any_strings);
   // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
@@ -474,9 +486,12 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   const char *ad = any_host ? (const char *)co.arena_dev[co.arena_cur].p : nullptr;
   std::vector<CopyJob> &jobs = co.copy_jobs;
   jobs.clear();
+  // TGX_MEM_HOST_RETAINED: the caller keeps the windows as they are until the next flushing call -- their copies (and
+  // the key columns' MIN / MAX) wait for the flush, which runs all of them together on every copy thread
+  const bool defer = traits.retained;
   auto to_arena = [&](const void *src, size_t bytes) -> const void * {  // returns the DEVICE twin's address
     const size_t at = (co.arena_used + 63) & ~(size_t)63;
-    jobs.push_back({ah + at, src, bytes});  // (copied below, half of the bytes by the helper thread)
+    (defer ? co.deferred : jobs).push_back({ah + at, src, bytes});  // (jobs: copied below, shared with the helper threads)
     co.arena_used = at + bytes;
     return ad + at;
   };
@@ -558,7 +573,12 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       const uint8_t *v0 = (const uint8_t *)c.values + (size_t)c.offset * ew;
       sg.values = host ? to_arena(v0, (size_t)nrows * ew) : (const void *)v0;
       if (plan->key_column[i] && c.type == TGX_INT64) {
-        if (host && cc.range_known)
+        if (host && cc.range_known && defer) {
+          CopyJob &j = co.deferred.back();  // (this window's copy, noted just above: its copier takes the MIN / MAX)
+          j.mm_col = i;
+          j.mm_validity = c.validity ? c.validity + (c.offset >> 3) : nullptr;
+          j.mm_bit0 = c.offset & 7;
+        } else if (host && cc.range_known)
           host_minmax_i64((const int64_t *)v0, c.validity ? c.validity + (c.offset >> 3) : nullptr, c.offset & 7, nrows,
                           &cc.range_lo, &cc.range_hi);
         else
@@ -567,14 +587,46 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
     }
     cc.segs.push_back(sg);
   }
+  run_copy_jobs(co, jobs);
+  rollback.armed = false;
+  co.rows += nrows;
+  co.batches += 1;
+  co.coalesced_batches += 1;
+  st->batches++;
+  *taken = true;
+  if (co.rows >= (co.flush_rows > 0 ? co.flush_rows : kCoalesceFlushRows) || co.batches >= kCoalesceFlushBatches)
+    return coalesce_flush(st, err);
+  // a HOST stream is flushed in pieces of a few tens of MB: the upload of one piece then runs beside the noting and
+  // copying of the next (with 4 Mi-row flushes an 8 Mi-row table was two flushes: nothing overlapped; a piece of 32 MB
+  // is 0.6 ms of PCIe time, against ~0.1 ms of launches per flush)
+  static const size_t flush_host_bytes = [] {
+    const char *e = getenv("TGX_COALESCE_FLUSH_HOST_BYTES");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32 << 20;
+  }();
+  if (any_host && co.flush_rows == 0 && co.arena_used >= flush_host_bytes) return coalesce_flush(st, err);
+  return TGX_OK;
+}
+
+// the copies of `jobs` shared between the calling thread and the copy threads that are idle right now
+void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs) {
   if (!jobs.empty()) {
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.bytes;
     CopyPool *pool = total >= (64u << 10) ? CopyPool::get() : nullptr;
     int ids[CopyPool::kMaxWorkers];
     const int helpers = pool ? pool->claim(ids) : 0;  // (whoever is idle right now: other states may hold the rest)
+    auto fold = [&](const CopyJob &j) {  // a key column's piece: its MIN / MAX into the column's pending range
+      if (j.mm_col < 0) return;
+      CoalesceColumn &cc = co.cols[j.mm_col];
+      cc.range_lo = std::min(cc.range_lo, j.lo);
+      cc.range_hi = std::max(cc.range_hi, j.hi);
+    };
     if (helpers == 0) {
-      for (const CopyJob &j : jobs) stream_copy(j.dst, j.src, j.bytes);
+      for (const CopyJob &j0 : jobs) {
+        CopyJob j = j0;
+        copy_piece(j);
+        fold(j);
+      }
     } else {
       // equal shares of the bytes (a job that straddles a boundary is cut at a multiple of 64 bytes): the first for
       // the caller, one for every claimed worker
@@ -595,7 +647,14 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
           }
           size_t take = share + 1 < shares ? std::min(room, j.bytes - at) : j.bytes - at;
           if (take < j.bytes - at) take = std::min((take + 63) & ~(size_t)63, j.bytes - at);  // (cuts stay 64-byte aligned)
-          cut.push_back({(char *)j.dst + at, (const char *)j.src + at, take});
+          cut.push_back(CopyJob((char *)j.dst + at, (const char *)j.src + at, take));
+          if (j.mm_col >= 0) {  // (cuts are multiples of 64 bytes = 8 values: whole validity bytes further on)
+            CopyJob &piece = cut.back();
+            piece.mm_col = j.mm_col;
+            const int64_t bit = j.mm_bit0 + (int64_t)(at / 8);
+            piece.mm_validity = j.mm_validity ? j.mm_validity + (bit >> 3) : nullptr;
+            piece.mm_bit0 = bit & 7;
+          }
           at += take;
           room -= std::min(room, take);
         }
@@ -603,19 +662,11 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       while (share + 1 < shares) first[++share] = cut.size();
       first[shares] = cut.size();
       for (int w = 0; w < helpers; w++) pool->post(ids[w], cut.data() + first[w + 1], first[w + 2] - first[w + 1]);
-      for (size_t q = first[0]; q < first[1]; q++) stream_copy(cut[q].dst, cut[q].src, cut[q].bytes);
+      for (size_t q = first[0]; q < first[1]; q++) copy_piece(cut[q]);
       for (int w = 0; w < helpers; w++) pool->wait_and_release(ids[w]);
+      for (const CopyJob &piece : cut) fold(piece);
     }
   }
-  rollback.armed = false;
-  co.rows += nrows;
-  co.batches += 1;
-  co.coalesced_batches += 1;
-  st->batches++;
-  *taken = true;
-  if (co.rows >= (co.flush_rows > 0 ? co.flush_rows : kCoalesceFlushRows) || co.batches >= kCoalesceFlushBatches)
-    return coalesce_flush(st, err);
-  return TGX_OK;
 }
 
 // Region set `set` is about to be overwritten: views retained into it (a sampled-range key set keeps its batches for
@@ -703,13 +754,13 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     const size_t ew = str ? (cc.type == TGX_UTF8 ? 4 : 8) : vw ? 16 : (dct || is_numeric32(cc.type)) ? 4 : 8;
     bool has_values = false;
     for (const CoalesceSegment &sg : cc.segs) has_values |= sg.values != nullptr;
-    if (has_values) HIP_TRY(cc.values[set].reserve((size_t)(rows + 1) * ew + 64));
+    if (has_values) HIP_TRY(cc.values[set].reserve_roomy((size_t)(rows + 1) * ew + 64));
     if (cc.any_validity) {
       const size_t vb = ((size_t)rows + 31) / 32 * 4 + 64;
-      HIP_TRY(cc.validity[set].reserve(vb));
+      HIP_TRY(cc.validity[set].reserve_roomy(vb));
       HIP_TRY(hipMemsetAsync(cc.validity[set].p, 0, vb, st->stream));
     }
-    if (str || vw) HIP_TRY(cc.data[set].reserve((size_t)cc.data_bytes + 64));
+    if (str || vw) HIP_TRY(cc.data[set].reserve_roomy((size_t)cc.data_bytes + 64));
     int64_t row = 0, data_at = 0;
     for (const CoalesceSegment &sg : cc.segs) {
       GatherSeg &d = gs[g++];
@@ -765,14 +816,14 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     if (dct) {  // the windows' dictionaries, gathered like a Utf8 column of their own
       CoalesceDict &cd = *cc.dict;
       const size_t dw = cd.type == TGX_UTF8 ? 4 : 8;
-      HIP_TRY(cd.values[set].reserve((size_t)(cd.entries + 1) * dw + 64));
+      HIP_TRY(cd.values[set].reserve_roomy((size_t)(cd.entries + 1) * dw + 64));
       HIP_TRY(hipMemsetAsync(cd.values[set].p, 0, (size_t)(cd.entries + 1) * dw, st->stream));  // (an empty dictionary: offset 0)
       if (cd.any_validity) {
         const size_t vb = ((size_t)cd.entries + 31) / 32 * 4 + 64;
-        HIP_TRY(cd.validity[set].reserve(vb));
+        HIP_TRY(cd.validity[set].reserve_roomy(vb));
         HIP_TRY(hipMemsetAsync(cd.validity[set].p, 0, vb, st->stream));
       }
-      HIP_TRY(cd.data[set].reserve((size_t)cd.data_bytes + 64));
+      HIP_TRY(cd.data[set].reserve_roomy((size_t)cd.data_bytes + 64));
       int64_t drow = 0, dat = 0;
       for (const CoalesceSegment &sg : cd.segs) {
         GatherSeg &d = gs[g++];
@@ -806,12 +857,21 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
       v.dictionary = &dv;
     }
   }
+  if (!co.deferred.empty()) {
+    // TGX_MEM_HOST_RETAINED windows: into the arena now, all of them together; the key columns' MIN / MAX beside them
+    run_copy_jobs(co, co.deferred);
+    co.deferred.clear();
+  }
   if (co.arena_used)
     HIP_TRY(hipMemcpyAsync(co.arena_dev[ar].p, co.arena_host[ar], co.arena_used, hipMemcpyHostToDevice, st->stream));
   HIP_TRY(hipMemcpyAsync(co.desc_dev[ar].p, gs, g * sizeof(GatherSeg), hipMemcpyHostToDevice, st->stream));
   {
     ProfScope ps(st, "gather", 0);
-    launch_gather_segments(co.desc_dev[ar].as<GatherSeg>(), (int)g, st->stream);
+    // workgroups per segment: one per ~8192 rows of the longest window (64 KB of 8-byte values), at most 32
+    int64_t longest = 0;
+    for (size_t q = 0; q < g; q++) longest = std::max<int64_t>(longest, gs[q].length);
+    const int parts = (int)std::min<int64_t>(32, std::max<int64_t>(1, (longest + 8191) / 8192));
+    launch_gather_segments(co.desc_dev[ar].as<GatherSeg>(), (int)g, parts, st->stream);
   }
   // the arena and the table are free again once the gather has run
   HIP_TRY(hipEventRecord(co.arena_event[ar], st->stream));
@@ -910,6 +970,7 @@ void coalesce_drop(tgx_state *st) {  // reset / destroy: pending batches are for
   co.rows = 0;
   co.batches = 0;
   co.arena_used = 0;
+  co.deferred.clear();
   co.snap_pending[0] = co.snap_pending[1] = false;
 }
 

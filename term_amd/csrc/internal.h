@@ -85,7 +85,7 @@ void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *
                           const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
                           int64_t length, int large_offsets, int want_mult, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
-void launch_gather_segments(const GatherSeg *d_segs, int n_segs, hipStream_t stream);
+void launch_gather_segments(const GatherSeg *d_segs, int n_segs, int parts, hipStream_t stream);
 void launch_state_reset(const StateResetArgs &a, hipStream_t stream);
 int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
 void launch_dict_count_hits(const int32_t *indices, const uint8_t *validity, int64_t offset, int64_t length,
@@ -283,6 +283,12 @@ struct DevBuf {
     release();
     return dev_alloc(&p, &cap, bytes);
   }
+  // for buffers that are re-sized flush after flush (a growth frees the old block: a wait for the whole device): ask
+  // for a quarter more than is needed, so that sizes that creep upwards settle after a few flushes
+  hipError_t reserve_roomy(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    return reserve(bytes + bytes / 4);
+  }
   template <class T>
   T *as() const {
     return (T *)p;
@@ -444,6 +450,14 @@ struct CoalesceCopy {
   void *dst;
   const void *src;
   size_t bytes;
+  // mm_col >= 0: `src` is a window of Int64 key column mm_col; whoever copies the piece also takes the MIN / MAX of its
+  // non-NULL values (row 0 of the piece = bit mm_bit0 of *mm_validity) into lo / hi
+  int32_t mm_col = -1;
+  const uint8_t *mm_validity = nullptr;
+  int64_t mm_bit0 = 0;
+  int64_t lo = INT64_MAX, hi = INT64_MIN;
+  CoalesceCopy() = default;
+  CoalesceCopy(void *d, const void *s, size_t b) : dst(d), src(s), bytes(b) {}
 };
 struct Coalescer {
   bool disabled = false;
@@ -475,6 +489,9 @@ struct Coalescer {
   bool snap_pending[2] = {false, false};
   bool flushing = false;
   std::vector<CoalesceCopy> copy_jobs, copy_tail;  // the HOST windows of the batch being noted (scratch)
+  // TGX_MEM_HOST_RETAINED batches: the copies into the arena being filled, and the key columns' windows whose MIN / MAX
+  // the host takes, both left for the flush (all of them at once, on every copy thread)
+  std::vector<CoalesceCopy> deferred;
   uint64_t flushes = 0, coalesced_batches = 0;  // statistics (tgx_profile_get "coalesce_flushes" / "coalesced_batches")
 };
 

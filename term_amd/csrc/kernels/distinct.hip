@@ -266,7 +266,7 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   // KEY16: buckets of <= 2^16 keys, so a list entry is 2 bytes: half the list traffic.  Runs are padded to 32 slots
   // (64 bytes) by REPEATING their last key (a set union is idempotent; not used with multiplicity), since no
   // 16-bit value is left over as a filler.
-  constexpr uint32_t RPAD = KEY16 ? 32u : (uint32_t)PAD;
+  constexpr uint32_t RPAD = KEY16 ? (uint32_t)kRunPad2 : (uint32_t)PAD;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
@@ -1216,9 +1216,9 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   //  2.7 ms without: the load and store phases already run at HBM rate and the other CUs fill the gaps)
 #define TGX_PART(VAL, K16, ST)                                                                                      \
   do {                                                                                                              \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16, ST, false>), \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, false>), \
                        dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, 16, VAL, K16, ST, true>), \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, true>), \
                        dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
   } while (0)
   if (p.stats) {

@@ -32,7 +32,15 @@ struct BitmapView {
 // phase 1 scatters (key - base) into P = ceil(range / 2^sub_bits) bucket lists of 32-bit in-bucket
 // offsets; phase 2 replays each list against its 2^sub_bits-bit slice of the bitmap held in LDS.
 constexpr uint32_t kMaxPartitions = 2048;
-constexpr uint32_t kListPad = 0xFFFFFFFFu;  // filler of the 16-slot aligned runs in the bucket lists
+constexpr uint32_t kListPad = 0xFFFFFFFFu;  // filler of the padded runs in the bucket lists
+// a (tile, bucket) run is padded to a whole number of these many slots: 4-byte entries / 2-byte entries
+#ifndef TGX_RUN_PAD4
+#define TGX_RUN_PAD4 16
+#endif
+#ifndef TGX_RUN_PAD2
+#define TGX_RUN_PAD2 32
+#endif
+constexpr int kRunPad4 = TGX_RUN_PAD4, kRunPad2 = TGX_RUN_PAD2;
 constexpr int kPartitionThreads = 1024;
 constexpr int kPartitionKeysPerThread = 32;
 constexpr int kPartitionTile = kPartitionThreads * kPartitionKeysPerThread;  // 32768 keys

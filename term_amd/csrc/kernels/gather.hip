@@ -14,7 +14,7 @@
 //     point into are laid one behind the other in ONE data buffer and the views re-pointed at them,
 //   * Dictionary<Int32, Utf8>: the windows' dictionaries (one per run of batches that share theirs) are gathered like
 //     a Utf8 column of their own and every window's indices shifted to where its dictionary starts.
-// One workgroup per (column, segment).  HBM traffic: the windows are read once and written once (then read by the
+// One workgroup per (column, segment) -- several for windows of more than ~8192 rows.  HBM traffic: the windows are read once and written once (then read by the
 // checks): a stream of 8192-row batches costs 3x the bytes of one big batch -- against one launch per ~500 batches.
 #include <hip/hip_runtime.h>
 
@@ -24,8 +24,10 @@ namespace tgx {
 
 typedef const uint8_t __attribute__((address_space(1))) *g_u8;
 
-__device__ __forceinline__ void gather_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t bytes) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+// (tid, nt): this thread's index among the nt threads that share the move -- the workgroups blockIdx.y = 0 .. gridDim.y - 1
+// of a segment (a 64 Ki-row window moved by ONE workgroup took 0.8 ms: a flush of fifteen such windows kept 15 CUs busy)
+__device__ __forceinline__ void gather_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t bytes,
+                                             const int tid, const int nt) {
   const uintptr_t mis = ((uintptr_t)dst | (uintptr_t)src);
   if ((mis & 15) == 0) {
     const int64_t n16 = bytes >> 4;
@@ -75,14 +77,14 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherSeg *_
   // (by reference: the descriptor's arrays are indexed at run time in the Utf8View branch, and a copy of it would live
   // in scratch memory -- 264 bytes written and read by every thread of every window, as much as a window's values)
   const GatherSeg &g = segs[blockIdx.x];
-  const int tid = threadIdx.x;
+  const int tid = (int)(blockIdx.y * blockDim.x + threadIdx.x), nt = (int)(gridDim.y * blockDim.x);
   if (g.length <= 0) return;
   // ---- validity: destination words [w0, w1] of this segment's rows ----
   if (g.dst_validity) {
     uint32_t *dv = (uint32_t *)g.dst_validity;
     const int64_t r0 = g.dst_row, r1 = g.dst_row + g.length;
     const int64_t w0 = r0 >> 5, w1 = (r1 - 1) >> 5;
-    for (int64_t w = w0 + tid; w <= w1; w += blockDim.x) {
+    for (int64_t w = w0 + tid; w <= w1; w += nt) {
       const int64_t lo = (w << 5) > r0 ? (w << 5) : r0;
       const int64_t hi = ((w + 1) << 5) < r1 ? ((w + 1) << 5) : r1;
       const uint32_t nb = (uint32_t)(hi - lo);
@@ -108,21 +110,21 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherSeg *_
   if (g.kind == 0) {
     if (g.src_values)
       gather_bytes((uint8_t *)g.dst_values + g.dst_row * g.elem_bytes, (const uint8_t *)g.src_values,
-                   g.length * g.elem_bytes);
+                   g.length * g.elem_bytes, tid, nt);
     return;
   }
   if (g.kind == 4) {  // dictionary indices: the window's dictionary starts at index_shift of the coalesced one
     const int32_t *si = (const int32_t *)g.src_values;
     int32_t *d = (int32_t *)g.dst_values + g.dst_row;
-    for (int64_t i = tid; i < g.length; i += blockDim.x) d[i] = si[i] + g.index_shift;
+    for (int64_t i = tid; i < g.length; i += nt) d[i] = si[i] + g.index_shift;
     return;
   }
   if (g.kind == 3) {  // Utf8View: the stretches of the data buffers, then the views re-pointed at them
     for (int k = 0; k < g.vb_count; k++)
-      if (g.vb_len[k] > 0) gather_bytes(g.dst_data + g.vb_base[k], g.vb_src[k], g.vb_len[k]);
+      if (g.vb_len[k] > 0) gather_bytes(g.dst_data + g.vb_base[k], g.vb_src[k], g.vb_len[k], tid, nt);
     const uint4 *sv = (const uint4 *)g.src_values;
     uint4 *d = (uint4 *)g.dst_values + g.dst_row;
-    for (int64_t i = tid; i < g.length; i += blockDim.x) {
+    for (int64_t i = tid; i < g.length; i += nt) {
       uint4 v = sv[i];
       if ((int32_t)v.x > 12) {
         int k = 0;
@@ -145,18 +147,20 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherSeg *_
   if (g.kind == 1) {
     const int32_t *so = (const int32_t *)g.src_values;
     int32_t *d = (int32_t *)g.dst_values + g.dst_row;
-    for (int64_t i = tid; i <= g.length; i += blockDim.x) d[i] = (int32_t)((int64_t)so[i] + shift);
+    for (int64_t i = tid; i <= g.length; i += nt) d[i] = (int32_t)((int64_t)so[i] + shift);
   } else {
     const int64_t *so = (const int64_t *)g.src_values;
     int64_t *d = (int64_t *)g.dst_values + g.dst_row;
-    for (int64_t i = tid; i <= g.length; i += blockDim.x) d[i] = so[i] + shift;
+    for (int64_t i = tid; i <= g.length; i += nt) d[i] = so[i] + shift;
   }
-  if (g.data_len > 0) gather_bytes(g.dst_data + g.data_base, g.src_data, g.data_len);
+  if (g.data_len > 0) gather_bytes(g.dst_data + g.data_base, g.src_data, g.data_len, tid, nt);
 }
 
-void launch_gather_segments(const GatherSeg *d_segs, int n_segs, hipStream_t stream) {
+// `parts`: workgroups per segment (1 for DataFusion's 8192-row windows; a 64 Ki-row window is shared by eight)
+void launch_gather_segments(const GatherSeg *d_segs, int n_segs, int parts, hipStream_t stream) {
   if (n_segs <= 0) return;
-  hipLaunchKernelGGL(gather_segments_kernel, dim3(n_segs), dim3(256), 0, stream, d_segs);
+  if (parts < 1) parts = 1;
+  hipLaunchKernelGGL(gather_segments_kernel, dim3(n_segs, parts), dim3(256), 0, stream, d_segs);
 }
 
 }  // namespace tgx

@@ -564,6 +564,13 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   delete st;
 }
 
+extern "C" tgx_status tgx_state_pending(const tgx_state *st, uint64_t *batches, uint64_t *rows) {
+  if (!st) return TGX_INVALID_ARGUMENT;
+  if (batches) *batches = (uint64_t)st->coalesce.batches;
+  if (rows) *rows = (uint64_t)st->coalesce.rows;
+  return TGX_OK;
+}
+
 extern "C" tgx_status tgx_state_sync(tgx_state *st, tgx_error *err) try {
   bind_thread();
   if (!st) return fail(err, TGX_INVALID_ARGUMENT, "state is NULL");

@@ -277,8 +277,35 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
                 plan->n_columns_needed - 1, n_columns);
   if (n_columns > 0 && !columns) return fail(err, TGX_INVALID_ARGUMENT, "columns is NULL");
   TGX_TRY(need_device(err));
+  // TGX_MEM_HOST_RETAINED (include/tgx.h): HOST columns whose copy may wait for the flush.  Below this point such a
+  // column is a HOST column; `retained` (all of the batch's HOST columns were given so) travels in the traits.
+  bool any_retained = false, any_plain_host = false;
+  for (int i = 0; i < plan->n_columns_needed; i++) {
+    if (!plan->used[i]) continue;
+    const tgx_column &c = columns[i];
+    any_retained |= c.mem == TGX_MEM_HOST_RETAINED || (c.dictionary && c.dictionary->mem == TGX_MEM_HOST_RETAINED);
+    any_plain_host |= c.mem == TGX_MEM_HOST || (c.dictionary && c.dictionary->mem == TGX_MEM_HOST);
+  }
+  static thread_local std::vector<tgx_column> as_host, as_host_dicts;
+  if (any_retained) {
+    as_host.assign(columns, columns + n_columns);
+    as_host_dicts.clear();
+    as_host_dicts.reserve(n_columns);  // (no reallocation: the columns point into it)
+    for (size_t i = 0; i < n_columns; i++) {
+      if ((int)i >= plan->n_columns_needed || !plan->used[i]) continue;
+      tgx_column &c = as_host[i];
+      if (c.mem == TGX_MEM_HOST_RETAINED) c.mem = TGX_MEM_HOST;
+      if (c.dictionary && c.dictionary->mem == TGX_MEM_HOST_RETAINED) {
+        as_host_dicts.push_back(*c.dictionary);
+        as_host_dicts.back().mem = TGX_MEM_HOST;
+        c.dictionary = &as_host_dicts.back();
+      }
+    }
+    columns = as_host.data();
+  }
   int64_t nrows = 0;
   BatchTraits traits;
+  traits.retained = any_retained && !any_plain_host;
   TGX_TRY(update_validate(plan, st, columns, n_columns, &nrows, &traits, err));
   if (nrows == 0) {  // an empty RecordBatch (streams interleave them): nothing to note, nothing to flush for
     st->batches++;

@@ -512,3 +512,80 @@ def test_host_dictionary_batches(monkeypatch):
     truth = [words_a[i] if m else None for i, m in zip(idx_a, mask[:half])] + [words_b[i] if m else None for i, m in zip(idx_b, mask[half:])]
     assert got[3].distinct == len({x for x in truth if x is not None})
     assert (got[4].total, got[4].non_null) == (n, sum(x is not None for x in truth))
+
+
+def _retained(col):
+    """the same view, promised to stay as it is until the next flushing call (TGX_MEM_HOST_RETAINED)"""
+    col.c.mem = T.MEM_HOST_RETAINED
+    if col.c.dictionary:
+        col.c.dictionary.contents.mem = T.MEM_HOST_RETAINED
+    return col
+
+
+@pytest.mark.parametrize("flush_rows", [None, "30000"])
+def test_host_buffers_kept_until_the_flush(flush_rows, monkeypatch):
+    """TGX_MEM_HOST_RETAINED (include/tgx.h): the windows of a noted batch are copied when the flush runs -- all of them
+    together, on the copy threads, the key column's MIN / MAX taken by whoever copies the piece -- instead of inside
+    tgx_update.  Same results as the plain HOST stream and as one batch: numeric suite with a growing key column, a Utf8
+    column, a Utf8View column and a dictionary column; a batch that mixes plain and kept HOST columns is a plain one."""
+    import pyarrow as pa
+    from test_gpu_utf8view import encode_views
+
+    rng = np.random.default_rng(23)
+    n = 150_000 + 5
+    ids = np.arange(n, dtype=np.int64) * 3 + 1_000_000   # a growing key: the flush's range comes from the copiers
+    ids[rng.random(n) < 0.01] = 1_000_000
+    kval = orc.pack_validity(rng.random(n) >= 0.05)
+    f = rng.standard_normal(n)
+    vals = _string_values(rng, n)
+    offs, data, sval = orc.utf8_from_list(vals)
+    views, bufs, vval = encode_views(vals, rng, n_buffers=2)
+    words = ["w%d@x.org" % i for i in range(3000)] + [None, ""]
+    idx = rng.integers(0, len(words), size=n)
+    darr = pa.DictionaryArray.from_arrays(pa.array(idx, type=pa.int32()), pa.array(words, type=pa.string()))
+    T.init()
+    from term_amd.csrc_patterns import EMAIL
+    plan = T.Plan([spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY),
+                   spec(T.NUMERIC_STATS, 1, flags=T.FLAG_VARIANCE), spec(T.REGEX_MATCH, 2, pattern=EMAIL), spec(T.DISTINCT, 2),
+                   spec(T.REGEX_MATCH, 3, pattern=r"@"), spec(T.DISTINCT, 3), spec(T.DISTINCT, 4), spec(T.LENGTH, 4, length_min=2, length_max=9)])
+    sv = np.concatenate([data, np.zeros(16, np.uint8)])
+
+    def batch(lo, hi, kept, mixed=False):
+        cols = [numeric_column(ids, kval, False, offset=lo, length=hi - lo), numeric_column(f, None, False, offset=lo, length=hi - lo),
+                T.Column(T.UTF8, hi - lo, offsets=offs, data=sv, validity=pad_validity(sval), offset=lo),
+                T.Column.utf8_view(views, bufs, validity=pad_validity(vval) if vval is not None else None, length=hi - lo, offset=lo),
+                T.Column.from_arrow(darr.slice(lo, hi - lo))]
+        if kept:
+            cols = [_retained(c) if not (mixed and k == 1) else c for k, c in enumerate(cols)]
+        return cols
+
+    monkeypatch.setenv("TGX_COALESCE", "0")
+    whole = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE")
+    whole.update(batch(0, n, False))
+    want = whole.finalize()
+    cuts = ragged_cuts(n, rng, sizes=(8192, 8192, 1000, 3, 8192, 1, 5000, 8192, 65536))
+    results = {}
+    for mode in ("plain", "kept", "mixed"):
+        if flush_rows:
+            monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", flush_rows)
+        st = T.State(plan)
+        if flush_rows:
+            monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS")
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            st.update(batch(a, b, mode != "plain", mixed=(mode == "mixed")))
+        assert st.profile_get("coalesce")["bytes"] == len(cuts) - 1   # every batch was only noted
+        results[mode] = st.finalize()
+        compare(results[mode], want)
+    od = orc.distinct_bits64(ids, kval)
+    assert (results["kept"][2].distinct, results["kept"][2].groups_once) == (od.distinct, od.groups_once)
+    # a big batch of kept buffers is read before tgx_update returns, like a plain HOST one
+    st = T.State(plan)
+    st.update(batch(0, n, True))
+    compare(st.finalize(), want)
+    # and a reset forgets copies that were still waiting
+    st = T.State(plan)
+    st.update(batch(0, 8192, True))
+    st.reset()
+    st.update(batch(0, n, True))
+    compare(st.finalize(), want)

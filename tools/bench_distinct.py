@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--sparse-rows", type=int, default=1_000_000_000)
     ap.add_argument("--ordered-only", action="store_true", help="only (1b): the dense pass over keys in order")
+    ap.add_argument("--dense-only", action="store_true", help="only (1): the bench table's two unique columns")
     args = ap.parse_args()
     import torch
     import term_amd as T
@@ -31,9 +32,9 @@ def main():
     n = (args.rows // 64) * 64
     T.init(distinct_capacity_hint=n)
     # ---- (1b) the dense pass over keys IN ORDER (ids that grow with the row number): a wave's rows share a bucket ----
-    ids = torch.arange(n, dtype=torch.int64, device="cuda") + 1000
-    for name, specs in (("uniqueness alone", [spec(T.DISTINCT, 0)]),
-                        ("uniqueness + min/max/mean", [spec(T.DISTINCT, 0), spec(T.NUMERIC_STATS, 0)])):
+    ids = torch.arange(n if not args.dense_only else 64, dtype=torch.int64, device="cuda") + 1000
+    for name, specs in (() if args.dense_only else (("uniqueness alone", [spec(T.DISTINCT, 0)]),
+                        ("uniqueness + min/max/mean", [spec(T.DISTINCT, 0), spec(T.NUMERIC_STATS, 0)]))):
         plan = T.Plan(specs)
         st = T.State(plan)
         col = T.Column.int64(ids, None, length=n)
@@ -79,6 +80,8 @@ def main():
         print("col %d (%s, validity=%s): distinct=%d  wall %.2f ms/step, kernels %.2f ms/step" %
               (ci, layout[ci][0], validity is not None, res[0].distinct, dt, prof["total_ms"] / args.steps))
     del table
+    if args.dense_only:
+        return
     # ---- (2) sparse keys ----
     m = (args.sparse_rows // 64) * 64
     g = torch.Generator(device="cuda").manual_seed(3)

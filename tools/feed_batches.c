@@ -109,12 +109,14 @@ int main(int argc, char **argv) {
     CHECK_TGX(tgx_plan_create(specs, n_specs, &plan, &err));
     tgx_result *res = calloc(n_specs, sizeof(tgx_result));
     tgx_column *cols = calloc(n_cols, sizeof(tgx_column));
-    for (int mem = 1; mem >= 0; mem--) {
+    /* mem: 1 DEVICE buffers, 0 HOST buffers (read before tgx_update returns), 2 HOST buffers the caller keeps as they
+     * are until tgx_finalize (TGX_MEM_HOST_RETAINED: their copies wait for the flush) */
+    for (int mem = 2; mem >= 0; mem--) {
       const int64_t batch_sizes[3] = {n, 65536, 8192};
       for (int b = 0; b < 3; b++) {
         const int64_t rows = batch_sizes[b] < n ? batch_sizes[b] : n;
         char tag[64];
-        snprintf(tag, sizeof(tag), "u%d-%s-%lld", with_unique, mem ? "device" : "host", (long long)rows);
+        snprintf(tag, sizeof(tag), "u%d-%s-%lld", with_unique, mem == 1 ? "device" : mem == 2 ? "hostkept" : "host", (long long)rows);
         if (only && strcmp(only, tag) != 0) continue;
         tgx_state *st = NULL;
         CHECK_TGX(tgx_state_create(plan, NULL, &st, &err));
@@ -128,12 +130,12 @@ int main(int argc, char **argv) {
             for (int c = 0; c < n_cols; c++) {
               tgx_column *k = &cols[c];
               k->type = (c == 0 || !(c & 1)) ? TGX_INT64 : TGX_FLOAT64;
-              k->mem = mem ? TGX_MEM_DEVICE : TGX_MEM_HOST;
+              k->mem = mem == 1 ? TGX_MEM_DEVICE : mem == 2 ? TGX_MEM_HOST_RETAINED : TGX_MEM_HOST;
               k->length = len;
               k->offset = lo; /* a slice of the table's buffers, as Arrow hands them out */
               k->null_count = -1;
-              k->values = mem ? d_vals[c] : h_vals[c];
-              k->validity = mem ? d_valid[c] : h_valid[c];
+              k->values = mem == 1 ? d_vals[c] : h_vals[c];
+              k->validity = mem == 1 ? d_valid[c] : h_valid[c];
             }
             CHECK_TGX(tgx_update(plan, st, cols, (size_t)n_cols, &err));
             if (gap_us > 0) {
@@ -151,7 +153,7 @@ int main(int argc, char **argv) {
         const int64_t updates = (n + rows - 1) / rows;
         printf("{\"suite\": \"null+range x%d%s\", \"buffers\": \"%s\", \"rows\": %lld, \"batch_rows\": %lld, "
                "\"updates\": %lld, \"total_ms\": %.3f, \"us_per_update\": %.3f, \"rows_per_s\": %.4g, \"verified\": %s}\n",
-               n_cols, with_unique ? " + unique x1" : "", mem ? "device" : "host", (long long)n, (long long)rows,
+               n_cols, with_unique ? " + unique x1" : "", mem == 1 ? "device" : mem == 2 ? "host, kept until finalize" : "host", (long long)n, (long long)rows,
                (long long)updates, best * 1e3, best * 1e6 / (double)updates, (double)n / best, ok ? "true" : "false");
         fflush(stdout);
         tgx_state_destroy(st);
