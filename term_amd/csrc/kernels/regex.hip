@@ -15,8 +15,9 @@
 //     (SQ_LDS_UNALIGNED_STALL = 60 % of SQ_LDS_IDX_ACTIVE)                                  1.37 ms
 //   * chunks cut from aligned words (ChunkFeed)                                             1.02 ms
 //   * LDS sized per launch, grid = exactly the resident workgroups (7 per CU)              0.86-0.93 ms
-// VALU (~55 %), LDS (~45 %) and HBM (~65 % of the achievable rate) are now about equally loaded.  Evaluating
-// several patterns of one column in the same pass was tried earlier and was slower than one pass each.  Match
+// VALU (~55 %), LDS (~45 %) and HBM (~65 % of the achievable rate) are now about equally loaded.  Several patterns of
+// one column share ONE walk (MULTI, the product automaton); round 5 measured workgroups of 8 / 12 / 14 waves sharing
+// one table for big automata: never better than four-wave workgroups at the right count per CU.  Match
 // counts are block-reduced: one atomic per block.
 #include <hip/hip_runtime.h>
 
@@ -673,6 +674,15 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
     // the occupancy API answers one workgroup too many for 256-thread kernels with 81..96 SGPRs (these instances
     // have 88..91; 800 SGPRs per SIMD / (96 + 16) = 7 waves): MI355X_MICROARCH.md, "Correctness boundaries"
     if (occ > 7) occ = 7;
+    // ... and one too many when the workgroups' LDS only just fits: six workgroups of 27 136 bytes (three patterns in
+    // one walk) are 162 816 of the CU's 163 840 bytes, but only FIVE were resident and the sixth ran as a second round
+    // -- 1.40 ms per 100 M rows instead of 0.97 (sweep of 3 .. 7 workgroups per CU, round 5; the same second-round cliff
+    // the eighth workgroup showed).  LDS is handed out in granules: 512 bytes did not explain the measurement, 1280
+    // (1/128 of the CU's LDS) does; counting one workgroup too few costs ~5 %, one too many 45 %.
+    constexpr uint32_t kLdsGranule = 1280;
+    const int by_lds = (int)((160u << 10) / ((lds.total + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
+    if (by_lds >= 1 && occ > by_lds) occ = by_lds;
+    if (const char *e = getenv("TGX_REGEX_RESIDENT")) occ = std::max(1, atoi(e));  // (experiments: workgroups per CU)
     cache[{id, lds.total}] = occ;
     return occ;
   };
