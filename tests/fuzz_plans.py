@@ -103,8 +103,9 @@ def string_values(rng, n, vocab):
 class Buffers:
     """the Arrow buffers of one column, on the host and (uploaded once, on first use) on the device"""
 
-    def __init__(self, kind, vals, vb, extra, mask, seed):
+    def __init__(self, kind, vals, vb, extra, mask, seed, present=None):
         self.kind = kind
+        self.present = present  # (round 5) an Int64 column handed over as a narrower / unsigned / Boolean Arrow type
         self.host = {"validity": pad_validity(vb)}
         self.layout = "plain"
         if kind == "s" and extra[2] != "plain":
@@ -117,6 +118,12 @@ class Buffers:
             self.large = extra[1]
             self.host["offsets"] = vals if self.large else vals.astype(np.int32)
             self.host["data"] = np.concatenate([extra[0], np.zeros(16, np.uint8)])
+        elif present == "bool":
+            self.host["values"] = np.concatenate([orc.pack_validity(vals != 0), np.zeros(64, np.uint8)])
+        elif present is not None:
+            narrow = vals.astype(present)
+            assert (narrow.astype(np.int64) == vals).all() or present == np.uint64
+            self.host["values"] = np.concatenate([narrow, np.zeros(64, narrow.dtype)]).view(np.uint8)
         else:
             self.host["values"] = vals
         self.dev = None
@@ -139,6 +146,10 @@ class Buffers:
         if self.kind == "s":
             return T.Column(T.LARGE_UTF8 if self.large else T.UTF8, length, offsets=b["offsets"], data=b["data"],
                             validity=b["validity"], offset=offset)
+        if self.present is not None:
+            type_id = {"bool": T.BOOL, np.int8: T.INT8, np.int16: T.INT16, np.uint8: T.UINT8, np.uint16: T.UINT16,
+                       np.uint32: T.UINT32, np.uint64: T.UINT64}[self.present]
+            return T.Column(type_id, length, values=b["values"], validity=b["validity"], offset=offset)
         ctor = {"i": T.Column.int64, "f": T.Column.float64, "i32": T.Column.int32, "f32": T.Column.float32}[self.kind]
         return ctor(b["values"], b["validity"], length=length, offset=offset)
 
@@ -267,6 +278,34 @@ class Case:
             self.world = int(rng.integers(2, 5))
             inner = sorted(int(x) // 64 * 64 for x in rng.integers(0, n + 1, size=self.world - 1))
             self.cuts = [0] + inner + [n]  # one shard per rank (validity bytes are shared: shards start on whole words)
+        # ---- round 5, drawn from a stream of their own (the cases of earlier seeds stay what they were) ----
+        rng5 = np.random.default_rng([seed, 5])
+        # HOST batches handed over as TGX_MEM_HOST_RETAINED (kept until the flush): nothing about the results may change
+        self.retain = bool(rng5.random() < 0.4)
+        # an Int64 column presented as the narrowest Arrow type that holds its values (Int8 .. UInt32: widened on the
+        # device; UInt64 / Boolean: COUNT and DISTINCT only) -- the oracle keeps seeing the Int64 values
+        self.present = [None] * len(self.cols)
+        for ci, (kind, vals, vb, mask, extra) in enumerate(self.cols):
+            if kind != "i" or rng5.random() >= 0.3:
+                continue
+            lo, hi = (int(vals.min()), int(vals.max())) if n else (0, 0)
+            keys_only = all(e[0] in ("count", "distinct", "tuple") for e in self.expect if ci in self.columns_of_expect(e))
+            fits = [t for t in (np.int8, np.uint8, np.int16, np.uint16, np.uint32)
+                    if np.iinfo(t).min <= lo and hi <= np.iinfo(t).max]
+            if keys_only and lo >= 0 and hi <= 1 and rng5.random() < 0.5:
+                self.present[ci] = "bool"
+            elif keys_only and lo >= 0 and rng5.random() < 0.5:
+                self.present[ci] = np.uint64
+            elif fits:
+                self.present[ci] = fits[int(rng5.integers(0, len(fits)))]
+
+    @staticmethod
+    def columns_of_expect(e):
+        if e[0] == "tuple":
+            return tuple(e[1])
+        if e[0] in ("comoments", "spearman"):
+            return (e[1], e[2])
+        return (e[1],)
 
     def prefix_case(self, m):
         """the same case over the table's first m rows (what a state read half-way must report)"""
@@ -286,17 +325,25 @@ class Case:
         self.expect.append(e)
 
     def describe(self):
-        cols = ", ".join("%s/nulls=%d" % (c[0], int((~c[3]).sum())) for c in self.cols)
+        cols = ", ".join("%s%s/nulls=%d" % (c[0], "" if p is None else "as" + (p if isinstance(p, str) else p.__name__),
+                                            int((~c[3]).sum())) for c, p in zip(self.cols, self.present))
         return "seed %d: n=%d cols=[%s] checks=%s batching=%s(%d) buffers=%s after=%s env=%s" % (
             self.seed, self.n, cols, [e[0] for e in self.expect], self.mode, len(self.cuts) - 1, self.device,
-            self.after + ("" if self.seq == "plain" else "/" + self.seq), self.env)
+            self.after + ("" if self.seq == "plain" else "/" + self.seq) + (" kept" if self.retain else ""), self.env)
 
     # ---- the device side ----
     def columns_of(self, lo, hi, on_device):
         if not hasattr(self, "buffers"):
-            self.buffers = [Buffers(kind, vals, vb, extra, mask, self.seed + k)
+            self.buffers = [Buffers(kind, vals, vb, extra, mask, self.seed + k, self.present[k])
                             for k, (kind, vals, vb, mask, extra) in enumerate(self.cols)]
-        return [b.column(on_device, lo, hi - lo) for b in self.buffers]
+        cols = [b.column(on_device, lo, hi - lo) for b in self.buffers]
+        if self.retain and not on_device:
+            for c in cols:
+                if c.c.mem == T.MEM_HOST:
+                    c.c.mem = T.MEM_HOST_RETAINED
+                if c.c.dictionary and c.c.dictionary.contents.mem == T.MEM_HOST:
+                    c.c.dictionary.contents.mem = T.MEM_HOST_RETAINED
+        return cols
 
     def run_device(self):
         import os
