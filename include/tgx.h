@@ -40,7 +40,9 @@ extern "C" {
  *    tgx_distinct_adopt_slices a slice stride */
 /* 3: tgx_comm / tgx_allreduce (the cross-rank step behind the C ABI) */
 /* 4: tgx_result grew the centred co-moments (co_*) at its end; state blobs are version 2 */
-#define TGX_ABI_VERSION 4
+/* 5: tgx_type grew Int8 .. UInt64 / Boolean, tgx_memspace TGX_MEM_HOST_RETAINED; tgx_trim, tgx_cache_stats_get,
+ *    tgx_state_pending (no struct changed its layout) */
+#define TGX_ABI_VERSION 5
 
 typedef enum tgx_status {
   TGX_OK = 0,

@@ -11,7 +11,7 @@ COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 
 APPROX_DISTINCT = 9
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
-ABI_VERSION = 4  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
+ABI_VERSION = 5  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
 INT8, INT16, UINT8, UINT16, UINT32, UINT64, BOOL = 9, 10, 11, 12, 13, 14, 15  # (include/tgx.h: narrow / unsigned / Boolean)
 MEM_HOST, MEM_DEVICE, MEM_HOST_RETAINED = 0, 1, 2
