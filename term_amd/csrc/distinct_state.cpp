@@ -358,23 +358,20 @@ tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
 //     (tgx_distinct_range_hint) replaces the sample, and then keys outside it are an error, not repaired.
 void bitmap_shape(const DistinctState &ds, int64_t length, bool mult, uint32_t *sub_bits_out, bool *key16_out,
                          uint64_t *n_buckets_out, bool *partitioned_out) {
-  // slices of 2^sub_bits keys: as many buckets as fit the phase-1 histogram (<= 2048 targeted) so every CU has lists
-  // to replay (<= 1024 targeted: longer runs per tile); one slice (two with multiplicity) must fit 128 KiB of LDS
+  // slices of 2^sub_bits keys; one slice (two with multiplicity) must fit 128 KiB of LDS.  How many buckets: every
+  // (tile, bucket) run is padded to a 64-byte line, so FEWER buckets mean longer runs and less padding -- and fewer
+  // workgroups for the replay, one per bucket.  With multiplicity (4-byte entries, padded with a filler): <= 1024
+  // buckets, as ever.  Without (round 5): <= 256 -- a list entry is then 2 bytes where a bucket holds <= 2^16 keys, else
+  // 20 bits (three to an 8-byte word: distinct_run_numeric, `pack20`).  Measured at 1 G keys over 10^8 values: 1526
+  // buckets of 2-byte entries 3.26 ms, 763 / 382 / 191 / 96 buckets of 20-bit entries 3.09 / 3.07 / 2.93 / 3.36 ms.
+  // (TGX_BUCKET_TARGET overrides the aim, TGX_KEY16=0 forbids 2-byte entries: experiments)
+  const char *bt = getenv("TGX_BUCKET_TARGET");
+  const uint64_t bucket_target = bt ? std::max<uint64_t>(1, strtoull(bt, nullptr, 10)) : (mult ? 1024 : 256);
+  const char *k16 = getenv("TGX_KEY16");
+  const bool allow_key16 = !(k16 && atoi(k16) == 0);
   uint32_t sub_bits = 14;
-  while (sub_bits < (mult ? 19u : 20u) && ((ds.range + (1ull << sub_bits) - 1) >> sub_bits) > 1024) sub_bits++;
-  // ranges up to 2048 x 2^16 values (134 M): buckets of <= 2^16 keys make a list entry 2 bytes instead of 4 --
-  // half the list traffic for more, shorter runs (not with multiplicity: run padding repeats keys)
-  bool key16 = false;
-  if (!mult && sub_bits > 16) {
-    uint32_t s16 = 14;
-    while (s16 < 16 && ((ds.range + (1ull << s16) - 1) >> s16) > kMaxPartitions) s16++;
-    if (((ds.range + (1ull << s16) - 1) >> s16) <= kMaxPartitions) {
-      key16 = true;
-      sub_bits = s16;
-    }
-  } else if (!mult) {
-    key16 = true;  // sub_bits <= 16 already
-  }
+  while (sub_bits < (mult ? 19u : 20u) && ((ds.range + (1ull << sub_bits) - 1) >> sub_bits) > bucket_target) sub_bits++;
+  const bool key16 = allow_key16 && !mult && sub_bits <= 16;
   const uint64_t n_buckets = (ds.range + (1ull << sub_bits) - 1) >> sub_bits;
   uint64_t cap_slots = (uint64_t)length / std::max<uint64_t>(n_buckets, 1);
   cap_slots = cap_slots + cap_slots / 4 + 16 * (((uint64_t)length >> 15) + 1) + 4096;
@@ -692,15 +689,23 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
           pp.n_lists = (uint32_t)(rhi >> pp.sub_bits) - pp.bucket0 + 1;
         }
       }
+      // list entries: 2 bytes (buckets of <= 2^16 keys), else -- without multiplicity: run padding repeats keys -- 20 bits,
+      // three to an 8-byte word, 24 to a 64-byte line (round 5: 2.67 instead of 4 bytes per key written and read back),
+      // else 4 bytes
+      const char *p20 = getenv("TGX_PACK20");  // (per batch: tests compare the two forms in one process)
+      const bool no_pack20 = p20 && atoi(p20) == 0;
+      const bool pack20 = !prep.key16 && !mult && prep.sub_bits <= 20 && !no_pack20;
       uint64_t cap = (uint64_t)c.length / pp.n_lists;
-      cap = cap + cap / 4 + (prep.key16 ? 32 : 16) * tiles + 4096;
-      pp.cap = prep.key16 ? (cap + 31) & ~31ull : (cap + 15) & ~15ull;
+      cap = cap + cap / 4 + (prep.key16 ? 32 : pack20 ? 24 : 16) * tiles + 4096;
+      pp.cap = prep.key16 ? (cap + 31) & ~31ull : pack20 ? (cap + 23) / 24 * 24 : (cap + 15) & ~15ull;
       if (pp.cap >= (1ull << 32) - 64) return fail(err, TGX_INTERNAL, "distinct: list capacity out of range");
       pp.want_multiplicity = mult ? 1 : 0;
-      pp.key16 = prep.key16 ? 1 : 0;
+      pp.key16 = prep.key16 ? 1 : pack20 ? 2 : 0;
       static const bool no_probe = getenv("TGX_NO_CLUSTERED_PROBE") && atoi(getenv("TGX_NO_CLUSTERED_PROBE")) != 0;
       pp.probe = no_probe ? 0 : 1;
-      HIP_TRY(ds.lists.reserve((uint64_t)pp.n_lists * pp.cap * (prep.key16 ? sizeof(uint16_t) : sizeof(uint32_t))));
+      HIP_TRY(ds.lists.reserve(prep.key16 ? (uint64_t)pp.n_lists * pp.cap * sizeof(uint16_t)
+                               : pack20   ? (uint64_t)pp.n_lists * pp.cap / 3 * 8
+                                          : (uint64_t)pp.n_lists * pp.cap * sizeof(uint32_t)));
       HIP_TRY(ds.cursors.reserve((2 * pp.n_buckets + 1) * sizeof(unsigned long long)));  // (+ the probe's flag)
       pp.lists = ds.lists.as<uint32_t>();
       pp.cursors = ds.cursors.as<unsigned long long>();

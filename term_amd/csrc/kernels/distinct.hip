@@ -253,7 +253,7 @@ __device__ __forceinline__ void partition_load_tile(const PartitionParams &p, in
 //   pass 2   counting sort of the 20-bit sub-keys into LDS      (hook `mid` runs just before it)
 //   stores   each wave streams whole runs out, 16 bytes per lane (hook `before_stores` runs just before)
 // (the hooks are where a software-pipelined caller would request the next tile; unused today)
-template <int THREADS, int KPT, int MAXP, int PAD, bool KEY16, bool CLUSTERED, class MidFn, class StoreFn>
+template <int THREADS, int KPT, int MAXP, int PAD, bool KEY16, bool PACK20, bool CLUSTERED, class MidFn, class StoreFn>
 __device__ __forceinline__ void partition_process_tile(const PartitionParams &p, uint32_t *sorted, uint32_t *hist,
                                                        uint32_t *toff, uint32_t *gbase, uint32_t *wave_sums,
                                                        uint32_t *long_runs, const uint32_t (&rel)[KPT], uint64_t ok,
@@ -266,7 +266,22 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   // KEY16: buckets of <= 2^16 keys, so a list entry is 2 bytes: half the list traffic.  Runs are padded to 32 slots
   // (64 bytes) by REPEATING their last key (a set union is idempotent; not used with multiplicity), since no
   // 16-bit value is left over as a filler.
-  constexpr uint32_t RPAD = KEY16 ? (uint32_t)kRunPad2 : (uint32_t)PAD;
+  // PACK20 (round 5): 20-bit entries, three to an 8-byte word: a 64-byte line holds 24 of them (2.67 B per key instead
+  // of 4); runs are padded to 24 entries, again by repeating their last key
+  constexpr uint32_t RPAD = PACK20 ? 24u : KEY16 ? (uint32_t)kRunPad2 : (uint32_t)PAD;
+  auto pad_up = [](uint32_t h) -> uint32_t { return PACK20 ? (h + 23u) / 24u * 24u : (h + (RPAD - 1u)) & ~(RPAD - 1u); };
+  // six consecutive entries of a run (the last one repeated past its end) as two words of three
+  auto pack6 = [&](uint32_t o, uint32_t h, uint32_t i) -> uint4 {
+    uint64_t w[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t i0 = i + 3u * q;
+      const uint64_t a = sorted[o + (i0 < h ? i0 : h - 1)], b = sorted[o + (i0 + 1 < h ? i0 + 1 : h - 1)],
+                     c = sorted[o + (i0 + 2 < h ? i0 + 2 : h - 1)];
+      w[q] = a | (b << 20) | (c << 40);
+    }
+    return make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+  };
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
@@ -339,7 +354,7 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
       if (h[k] && b - p.bucket0 >= p.n_lists) {
         g = 0xFFFFFFFFu;  // no list for this bucket: the run goes straight to the bitmap
       } else if (h[k]) {
-        const unsigned long long padded = (h[k] + (RPAD - 1u)) & ~(RPAD - 1u);
+        const unsigned long long padded = pad_up(h[k]);
         const unsigned long long at = atomicAdd(&p.cursors[b], padded);
         // cap < 2^32 (checked on the host); a run that does not fit spills as a whole
         if (at + padded > p.cap) {
@@ -406,7 +421,7 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
     const uint32_t n_meta = (p.n_buckets > wave) ? (p.n_buckets - wave + NW - 1) / NW : 0;
     // lanes per bucket and buckets per step: 16 x 4 with 4-byte entries, 4 x 16 with 2-byte entries (a lane always
     // stores 16 bytes; runs average kTile / P keys)
-    constexpr uint32_t LPB = KEY16 ? 4u : 16u, BPS = 64u / LPB, KPL = KEY16 ? 8u : 4u;
+    constexpr uint32_t LPB = (KEY16 || PACK20) ? 4u : 16u, BPS = 64u / LPB, KPL = PACK20 ? 6u : KEY16 ? 8u : 4u;
     const uint32_t grp = lane / LPB, sub = lane % LPB;
 #pragma unroll
     for (int s2 = 0; s2 < NS; s2++) {
@@ -420,8 +435,12 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
         if (h == 0) continue;
         const uint32_t b = (m + 64 * s2) * NW + wave;
         if (g != 0xFFFFFFFFu) {
-          const uint32_t padded = (h + (RPAD - 1u)) & ~(RPAD - 1u);
-          if (KEY16) {
+          const uint32_t padded = pad_up(h);
+          if (PACK20) {
+            // cap and g are multiples of 24 entries: the run starts on a 64-byte line
+            uint8_t *dst = (uint8_t *)p.lists + ((uint64_t)(b - p.bucket0) * p.cap + g) / 3 * 8;
+            for (uint32_t i = KPL * sub; i < padded; i += KPL * LPB) *(uint4 *)(dst + (uint64_t)(i / 3) * 8) = pack6(o, h, i);
+          } else if (KEY16) {
             // 16-byte aligned: cap and g are multiples of 32 two-byte slots
             uint16_t *dst = (uint16_t *)p.lists + (uint64_t)(b - p.bucket0) * p.cap + g;
             for (uint32_t i = KPL * sub; i < padded; i += KPL * LPB) {
@@ -463,8 +482,11 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
     for (uint32_t q = 0; q < n_long; q++) {
       const uint32_t b = long_runs[q];
       const uint32_t o = toff[b], h = toff[b + 1] - o, g = gbase[b];
-      const uint32_t padded = (h + (RPAD - 1u)) & ~(RPAD - 1u);
-      if (KEY16) {
+      const uint32_t padded = pad_up(h);
+      if (PACK20) {
+        uint8_t *dst = (uint8_t *)p.lists + ((uint64_t)(b - p.bucket0) * p.cap + g) / 3 * 8;
+        for (uint32_t i = 6u * tid; i < padded; i += 6u * THREADS) *(uint4 *)(dst + (uint64_t)(i / 3) * 8) = pack6(o, h, i);
+      } else if (KEY16) {
         uint16_t *dst = (uint16_t *)p.lists + (uint64_t)(b - p.bucket0) * p.cap + g;
         for (uint32_t i = 8u * tid; i < padded; i += 8u * THREADS) {
           uint32_t k8[8];
@@ -588,7 +610,7 @@ __device__ __forceinline__ void partition_outlier_stats(const PartitionParams &p
 // FORM: the probe's verdict (partition_init_kernel) picks one of two copies of the tile loop for the whole launch; they
 // are two KERNELS, launched one behind the other, the one whose form it is not leaving at once: in one kernel they
 // shared a register allocation and the form for keys in order paid for it (78 scratch loads per tile and thread)
-template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS, bool FORM_CLUSTERED>
+template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS, bool FORM_CLUSTERED, bool PACK20 = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
     PartitionParams p, unsigned long long *counters) {
   if ((__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) != FORM_CLUSTERED) return;
@@ -736,7 +758,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         continue;
       }
     }
-    partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16, CLUSTERED>(p, sorted, hist, toff, gbase, wave_sums, long_runs, rel, ok,
+    partition_process_tile<THREADS, KPT, MAXP, PAD, KEY16, PACK20, CLUSTERED>(p, sorted, hist, toff, gbase, wave_sums, long_runs, rel, ok,
                                                                       [] {}, [] {});
   }
   };
@@ -862,7 +884,7 @@ __global__ __launch_bounds__(256) void distinct_outlier_kernel(DistinctColDesc d
 // Phase 2.  Workgroup b owns slice b of the bitmap: load it into LDS (it already holds the keys of
 // earlier batches and this batch's spills), replay list b with LDS atomics, store it back, and add the
 // slice's popcounts to the totals (counters[kCntDistinct] / [kCntTwice] are zeroed before the launch).
-template <int LDS_WORDS, bool KEY16 = false>
+template <int LDS_WORDS, bool KEY16 = false, bool PACK20 = false>
 __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(PartitionParams p,
                                                                          unsigned long long *counters) {
   // static LDS: gfx950 lets one workgroup declare up to 160 KiB statically (dynamic LDS is capped lower)
@@ -885,7 +907,34 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
   const bool clustered = p.cursors[2 * p.n_buckets] != 0;  // (partition_init_kernel's probe)
   const uint32_t li = b - p.bucket0;  // (a bucket without a list has cnt == 0: its runs spilled)
   if (li >= p.n_lists) cnt = 0;
-  if (KEY16) {
+  if (PACK20) {
+    // 20-bit entries, three to an 8-byte word, six per 16-byte load; cnt is a multiple of 24 and runs are padded with
+    // repeats of real keys, so every entry counts (the keys-in-order form of the pass takes this plain loop as well: a
+    // column that reaches the lists in order has wide steps, and its tiles' words rarely repeat)
+    const uint8_t *list = (const uint8_t *)p.lists + (uint64_t)li * p.cap / 3 * 8;
+    constexpr uint64_t kStepP = (uint64_t)kPartitionThreads * 6;
+    for (uint64_t w0 = (uint64_t)(tid & ~63u) * 6; w0 < cnt; w0 += 4 * kStepP) {
+      const uint64_t i0 = w0 + (uint64_t)(tid & 63u) * 6;
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 k4[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint64_t i = i0 + q * kStepP;
+        k4[q] = u32x4{0, 0, 0, 0};
+        if (i < cnt) k4[q] = __builtin_nontemporal_load((const u32x4 *)(list + i / 3 * 8));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (i0 + q * kStepP >= cnt) continue;
+        const uint64_t w[2] = {(uint64_t)k4[q].x | ((uint64_t)k4[q].y << 32), (uint64_t)k4[q].z | ((uint64_t)k4[q].w << 32)};
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const uint32_t k = (uint32_t)(w[u / 3] >> (20 * (u % 3))) & 0xFFFFFu;
+          atomicOr(&l_seen[k >> 5], 1u << (k & 31));
+        }
+      }
+    }
+  } else if (KEY16) {
     // 2-byte entries, eight per 16-byte load; runs are padded with repeats of real keys, so every entry counts
     const uint16_t *list16 = (const uint16_t *)p.lists + (uint64_t)li * p.cap;
     constexpr uint64_t kStep16 = (uint64_t)kPartitionThreads * 8;
@@ -1221,6 +1270,21 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
     hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, true>), \
                        dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
   } while (0)
+#define TGX_PART20(VAL, ST)                                                                                         \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, false, true>), \
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+  } while (0)
+  if (p.key16 == 2) {  // 20-bit packed entries
+    if (p.stats) {
+      if (p.validity) TGX_PART20(true, true); else TGX_PART20(false, true);
+    } else {
+      if (p.validity) TGX_PART20(true, false); else TGX_PART20(false, false);
+    }
+    return;
+  }
   if (p.stats) {
     if (p.key16) {
       if (p.validity) TGX_PART(true, true, true); else TGX_PART(false, true, true);
@@ -1233,6 +1297,7 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
     if (p.validity) TGX_PART(true, false, false); else TGX_PART(false, false, false);
   }
 #undef TGX_PART
+#undef TGX_PART20
 }
 
 hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_counters,
@@ -1241,7 +1306,9 @@ hipError_t launch_bucket_apply(const PartitionParams &p, unsigned long long *d_c
   const dim3 grid(p.n_buckets), block(kPartitionThreads);
 #define TGX_APPLY(W)                                                                                  \
   if (words <= W) {                                                                                   \
-    if (p.key16)                                                                                      \
+    if (p.key16 == 2)                                                                                 \
+      hipLaunchKernelGGL((bucket_apply_kernel<W, false, true>), grid, block, 0, stream, p, d_counters); \
+    else if (p.key16)                                                                                 \
       hipLaunchKernelGGL((bucket_apply_kernel<W, true>), grid, block, 0, stream, p, d_counters);      \
     else                                                                                              \
       hipLaunchKernelGGL((bucket_apply_kernel<W, false>), grid, block, 0, stream, p, d_counters);     \

@@ -63,7 +63,8 @@ struct PartitionParams {
   uint32_t *seen;      // global bitmap (rounded up to whole slices)
   uint32_t *twice;     // or nullptr
   int32_t want_multiplicity;
-  int32_t key16;       // 1: sub_bits <= 16 and list entries are 2 bytes (never with multiplicity)
+  int32_t key16;       // 1: sub_bits <= 16 and list entries are 2 bytes; 2: 20-bit entries, three to an 8-byte word, cap
+                       //    and every run a multiple of 24 (64 bytes) -- both never with multiplicity; 0: 4-byte entries
   // not nullptr: the pass also produces the column's COUNT / MIN / MAX / SUM (one ScanPartial per workgroup, folded
   // by scan_reduce_kernel) -- the numeric scan then skips the column: a unique-key column crosses HBM once for its
   // range checks and its uniqueness check together

@@ -2,6 +2,7 @@
 inputs. Counts / min / max / distinct are bit-exact; float aggregates within 1e-6 relative (north star),
 in practice ~1e-15 because the device sums are compensated."""
 import math
+import zlib
 
 import numpy as np
 import pytest
@@ -599,3 +600,38 @@ def test_outliers_in_a_later_batch_and_through_merge_and_serialize():
     one = orc.distinct_bits64(np.concatenate([clean, dirty]).view(np.uint64), None)
     ra = a.finalize()[0]
     assert (ra.distinct, ra.groups_once) == (one.distinct, one.groups_once)
+
+
+@pytest.mark.parametrize("with_stats", [True, False])
+@pytest.mark.parametrize("shape", ["shuffled", "two_batches_nulls", "skewed"])
+def test_distinct_partitioned_bitmap_20_bit_entries(shape, with_stats, monkeypatch):
+    """A dense range of more than 2048 x 2^16 values (no 2-byte entries) without multiplicity: the bucket lists hold 20-bit
+    entries, three to an 8-byte word, runs padded to 24 entries by repeating their last key (kernels/distinct.hip, PACK20;
+    the keys-in-order form of the same lists: tests/test_gpu_ordered_keys.py `ascending_step64`).  Bit-exact against the
+    oracle, and equal to the 4-byte lists (TGX_PACK20=0)."""
+    rng = np.random.default_rng(zlib.crc32(shape.encode()) + int(with_stats))
+    n = 3_200_011
+    validity = None
+    vals = rng.permutation(n).astype(np.int64) * 61 - 7_000_000_000   # 195 M values wide, all distinct
+    if shape == "two_batches_nulls":
+        vals[rng.random(n) < 0.02] = vals[5]                            # repeats
+        validity = orc.pack_validity(rng.random(n) >= 0.07)
+    elif shape == "skewed":                                             # 70 % of the rows in two buckets: lists overflow, runs spill
+        hot = rng.random(n) < 0.7
+        vals[hot] = -7_000_000_000 + rng.integers(50_000_000, 50_000_000 + (1 << 21), size=int(hot.sum()), dtype=np.int64)
+    specs = [spec(T.DISTINCT, 0)] + ([spec(T.NUMERIC_STATS, 0)] if with_stats else [spec(T.COUNT, 0)])
+    if shape == "two_batches_nulls":
+        cut = 1_700_003
+        batches = [[numeric_column(vals, validity, True, offset=0, length=cut)],
+                   [numeric_column(vals, validity, True, offset=cut, length=n - cut)]]
+    else:
+        batches = [[numeric_column(vals, validity, True)]]
+    res, _, st = run_plan(specs, batches, hint=n)
+    assert st.profile_get("distinct")["launches"] >= 0
+    d = orc.distinct_bits64(vals.view(np.uint64), validity, n=n)
+    assert (res[0].total, res[0].non_null, res[0].distinct) == (d.total, d.non_null, d.distinct)
+    if with_stats:
+        check_stats(res[1], orc.stats(vals, validity))
+    monkeypatch.setenv("TGX_PACK20", "0")   # the same batches through 4-byte entries
+    again, _, _ = run_plan(specs, batches, hint=n)
+    assert (again[0].distinct, again[0].non_null) == (res[0].distinct, res[0].non_null)
