@@ -689,12 +689,12 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
           pp.n_lists = (uint32_t)(rhi >> pp.sub_bits) - pp.bucket0 + 1;
         }
       }
-      // list entries: 2 bytes (buckets of <= 2^16 keys), else -- without multiplicity: run padding repeats keys -- 20 bits,
-      // three to an 8-byte word, 24 to a 64-byte line (round 5: 2.67 instead of 4 bytes per key written and read back),
-      // else 4 bytes
+      // list entries: 2 bytes (buckets of <= 2^16 keys, without multiplicity), else 20 bits, three to an 8-byte word, 24
+      // to a 64-byte line (round 5: 2.67 instead of 4 bytes per key written and read back); 4 bytes only with TGX_PACK20=0
       const char *p20 = getenv("TGX_PACK20");  // (per batch: tests compare the two forms in one process)
       const bool no_pack20 = p20 && atoi(p20) == 0;
-      const bool pack20 = !prep.key16 && !mult && prep.sub_bits <= 20 && !no_pack20;
+      // (with multiplicity the padding is a filler, 0xFFFFF: no sub-key of <= 19 bits)
+      const bool pack20 = !prep.key16 && prep.sub_bits <= (mult ? 19u : 20u) && !no_pack20;
       uint64_t cap = (uint64_t)c.length / pp.n_lists;
       cap = cap + cap / 4 + (prep.key16 ? 32 : pack20 ? 24 : 16) * tiles + 4096;
       pp.cap = prep.key16 ? (cap + 31) & ~31ull : pack20 ? (cap + 23) / 24 * 24 : (cap + 15) & ~15ull;

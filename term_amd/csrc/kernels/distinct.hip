@@ -270,15 +270,32 @@ __device__ __forceinline__ void partition_process_tile(const PartitionParams &p,
   // of 4); runs are padded to 24 entries, again by repeating their last key
   constexpr uint32_t RPAD = PACK20 ? 24u : KEY16 ? (uint32_t)kRunPad2 : (uint32_t)PAD;
   auto pad_up = [](uint32_t h) -> uint32_t { return PACK20 ? (h + 23u) / 24u * 24u : (h + (RPAD - 1u)) & ~(RPAD - 1u); };
-  // six consecutive entries of a run (the last one repeated past its end) as two words of three
+  // six consecutive entries of a run as two words of three.  Past the run's end: its last key again -- or, with
+  // multiplicity (a second sighting of a key counts), the filler 0xFFFFF, which no sub-key equals there (two bitmap
+  // slices share the LDS: sub_bits <= 19).  Two copies of the loop, picked by a wave-uniform branch per run: the
+  // selects of the filler form cost the plain form 8 % of the pass when both shared one body
+  const bool fill = p.want_multiplicity != 0;
   auto pack6 = [&](uint32_t o, uint32_t h, uint32_t i) -> uint4 {
     uint64_t w[2];
+    if (!fill) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const uint32_t i0 = i + 3u * q;
-      const uint64_t a = sorted[o + (i0 < h ? i0 : h - 1)], b = sorted[o + (i0 + 1 < h ? i0 + 1 : h - 1)],
-                     c = sorted[o + (i0 + 2 < h ? i0 + 2 : h - 1)];
-      w[q] = a | (b << 20) | (c << 40);
+      for (int q = 0; q < 2; q++) {
+        const uint32_t i0 = i + 3u * q;
+        const uint64_t a = sorted[o + (i0 < h ? i0 : h - 1)], b = sorted[o + (i0 + 1 < h ? i0 + 1 : h - 1)],
+                       c = sorted[o + (i0 + 2 < h ? i0 + 2 : h - 1)];
+        w[q] = a | (b << 20) | (c << 40);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        uint64_t e[3];
+#pragma unroll
+        for (uint32_t j = 0; j < 3; j++) {
+          const uint32_t at = i + 3u * q + j;
+          e[j] = at < h ? (uint64_t)sorted[o + at] : 0xFFFFFull;
+        }
+        w[q] = e[0] | (e[1] << 20) | (e[2] << 40);
+      }
     }
     return make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
   };
@@ -909,7 +926,7 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
   if (li >= p.n_lists) cnt = 0;
   if (PACK20) {
     // 20-bit entries, three to an 8-byte word, six per 16-byte load; cnt is a multiple of 24 and runs are padded with
-    // repeats of real keys, so every entry counts (the keys-in-order form of the pass takes this plain loop as well: a
+    // repeats of real keys -- every entry counts -- or, with multiplicity, with a filler (the keys-in-order form of the pass takes this plain loop as well: a
     // column that reaches the lists in order has wide steps, and its tiles' words rarely repeat)
     const uint8_t *list = (const uint8_t *)p.lists + (uint64_t)li * p.cap / 3 * 8;
     constexpr uint64_t kStepP = (uint64_t)kPartitionThreads * 6;
@@ -930,7 +947,14 @@ __global__ __launch_bounds__(kPartitionThreads) void bucket_apply_kernel(Partiti
 #pragma unroll
         for (int u = 0; u < 6; u++) {
           const uint32_t k = (uint32_t)(w[u / 3] >> (20 * (u % 3))) & 0xFFFFFu;
-          atomicOr(&l_seen[k >> 5], 1u << (k & 31));
+          const uint32_t bit = 1u << (k & 31);
+          if (g_twice) {  // (multiplicity: runs are padded with the filler, never with a key)
+            if (k == 0xFFFFFu) continue;
+            const uint32_t prev = atomicOr(&l_seen[k >> 5], bit);
+            if (prev & bit) atomicOr(&l_twice[k >> 5], bit);
+          } else {
+            atomicOr(&l_seen[k >> 5], bit);
+          }
         }
       }
     }

@@ -535,8 +535,11 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   bind_thread();
   // one wait for the whole device -- what the first hipFree of the state's buffers used to do implicitly (and every
   // further one again) -- then its device and pinned blocks go back to the cache without waiting (devcache.cpp)
-  if (g_ctx.inited) (void)hipDeviceSynchronize();
-  tgx::QuiescedScope quiesced;
+  // (a state that never touched the device -- the blobs tgx_allreduce unpacks and merges -- owns nothing to wait for)
+  // (without the wait no scope: should such a state own a block after all, its release waits by itself)
+  const bool waited = g_ctx.inited && (st->device_ready || st->stream);
+  if (waited) (void)hipDeviceSynchronize();
+  std::unique_ptr<tgx::QuiescedScope> quiesced(waited ? new tgx::QuiescedScope() : nullptr);
   for (auto &kv : st->profile)
     for (auto &ev : kv.second.pending) {
       (void)hipEventDestroy(ev.first);
