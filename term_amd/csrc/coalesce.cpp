@@ -158,10 +158,30 @@ void stream_copy(void *dst, const void *src, size_t bytes) {
 }
 
 namespace {
+// narrow integers / Boolean bits as the Int64 values they stand for (a HOST window on its way into the arena)
+void widen_copy(int64_t *dst, const void *src, int64_t n, int mode, int bit0) {
+  switch (mode) {
+    case 2: { const int8_t *s = (const int8_t *)src; for (int64_t i = 0; i < n; i++) dst[i] = s[i]; break; }
+    case 3: { const int16_t *s = (const int16_t *)src; for (int64_t i = 0; i < n; i++) dst[i] = s[i]; break; }
+    case 4: { const uint8_t *s = (const uint8_t *)src; for (int64_t i = 0; i < n; i++) dst[i] = s[i]; break; }
+    case 5: { const uint16_t *s = (const uint16_t *)src; for (int64_t i = 0; i < n; i++) dst[i] = s[i]; break; }
+    case 6: { const uint32_t *s = (const uint32_t *)src; for (int64_t i = 0; i < n; i++) dst[i] = s[i]; break; }
+    default: {  // 7: bits
+      const uint8_t *s = (const uint8_t *)src;
+      for (int64_t i = 0; i < n; i++) {
+        const int64_t b = bit0 + i;
+        dst[i] = (s[b >> 3] >> (b & 7)) & 1;
+      }
+    }
+  }
+}
 void copy_piece(CopyJob &j) {
-  stream_copy(j.dst, j.src, j.bytes);
-  if (j.mm_col >= 0)
-    host_minmax_i64((const int64_t *)j.src, j.mm_validity, j.mm_bit0, (int64_t)(j.bytes / 8), &j.lo, &j.hi);
+  if (j.widen)
+    widen_copy((int64_t *)j.dst, j.src, (int64_t)(j.bytes / 8), j.widen, j.src_bit0);
+  else
+    stream_copy(j.dst, j.src, j.bytes);
+  if (j.mm_col >= 0)  // (of the Int64 values: a widened window's are in `dst`)
+    host_minmax_i64((const int64_t *)(j.widen ? j.dst : j.src), j.mm_validity, j.mm_bit0, (int64_t)(j.bytes / 8), &j.lo, &j.hi);
 }
 }  // namespace
 
@@ -342,7 +362,7 @@ size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int6
                                   : ((const int64_t *)c.offsets)[c.offset + nrows];
       total += (size_t)(nrows + 1) * ow + 64 + (size_t)std::max<int64_t>(end - first, 0) + 64;
     } else if (plan->reads_values[i] || c.values) {
-      total += (size_t)nrows * (is_numeric32(c.type) ? 4 : 8) + 64;
+      total += (size_t)nrows * (is_numeric32(c.type) ? 4 : 8) + 64;  // (narrow integers / Booleans arrive widened: 8)
     }
   }
   return total;
@@ -568,6 +588,22 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       sg.values = to_arena(o0, (size_t)(nrows + 1) * ow);
       sg.data = (sg.data_len > 0 && c.data) ? (const uint8_t *)to_arena(c.data + first, (size_t)sg.data_len) : nullptr;
       cc.data_bytes += sg.data_len;
+    } else if (c.values && is_narrow_int(c.type)) {
+      // (HOST: update_validate) widened on the way into the arena: the flush sees an Int64 column
+      cc.type = TGX_INT64;
+      const bool bits = c.type == TGX_BOOL;
+      sg.values = to_arena(bits ? (const uint8_t *)c.values + (c.offset >> 3)
+                                : (const uint8_t *)c.values + narrow_bytes(c.type, c.offset), (size_t)nrows * 8);
+      CopyJob &j = (defer ? co.deferred : jobs).back();
+      j.widen = widen_mode(c.type);
+      j.src_bit0 = bits ? (int32_t)(c.offset & 7) : 0;
+      if (plan->key_column[i]) {
+        if (cc.range_known) {  // (whoever widens the piece takes its MIN / MAX: the Int64 values are in the arena)
+          j.mm_col = i;
+          j.mm_validity = c.validity ? c.validity + (c.offset >> 3) : nullptr;
+          j.mm_bit0 = c.offset & 7;
+        }
+      }
     } else if (c.values) {
       const size_t ew = is_numeric32(c.type) ? 4 : 8;
       const uint8_t *v0 = (const uint8_t *)c.values + (size_t)c.offset * ew;
@@ -648,6 +684,13 @@ void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs) {
           size_t take = share + 1 < shares ? std::min(room, j.bytes - at) : j.bytes - at;
           if (take < j.bytes - at) take = std::min((take + 63) & ~(size_t)63, j.bytes - at);  // (cuts stay 64-byte aligned)
           cut.push_back(CopyJob((char *)j.dst + at, (const char *)j.src + at, take));
+          if (j.widen) {  // (`at` counts destination bytes, a multiple of 64: 8 values, one byte of Boolean bits)
+            CopyJob &piece = cut.back();
+            piece.widen = j.widen;
+            piece.src_bit0 = j.src_bit0;
+            const size_t e = at / 8;
+            piece.src = (const char *)j.src + (j.widen == 7 ? e / 8 : j.widen == 6 ? e * 4 : (j.widen == 3 || j.widen == 5) ? e * 2 : e);
+          }
           if (j.mm_col >= 0) {  // (cuts are multiples of 64 bytes = 8 values: whole validity bytes further on)
             CopyJob &piece = cut.back();
             piece.mm_col = j.mm_col;

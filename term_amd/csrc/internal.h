@@ -456,6 +456,9 @@ struct CoalesceCopy {
   const uint8_t *mm_validity = nullptr;
   int64_t mm_bit0 = 0;
   int64_t lo = INT64_MAX, hi = INT64_MIN;
+  // widen != 0: not a byte copy -- `src` holds narrow integers (widen_mode(): Int8 .. UInt32) or Boolean bits (row 0 = bit
+  // src_bit0 of *src) and `dst` takes the Int64 values they stand for; `bytes` counts the DESTINATION
+  int32_t widen = 0, src_bit0 = 0;
   CoalesceCopy() = default;
   CoalesceCopy(void *d, const void *s, size_t b) : dst(d), src(s), bytes(b) {}
 };

@@ -238,7 +238,9 @@ tgx_status update_validate(const tgx_plan *plan, tgx_state *st, const tgx_column
     traits->any_strings |= is_any_string(c.type) || c.type == TGX_DICT32_UTF8;
     // string windows need their first / last offsets (Utf8View: the stretches its views point into; dictionaries:
     // theirs) on the host: HOST batches only (what DataFusion streams); DEVICE strings keep the immediate path
-    traits->coalescible &= is_numeric(c.type) || is_numeric32(c.type) || (is_string(c.type) && host) ||
+    traits->coalescible &= is_numeric(c.type) || is_numeric32(c.type) || c.type == TGX_UINT64 ||
+                           (is_narrow_int(c.type) && host) ||  // (widened on the way into the arena; DEVICE: immediate)
+                           (is_string(c.type) && host) ||
                            (c.type == TGX_UTF8_VIEW && host) ||
                            (c.type == TGX_DICT32_UTF8 && host && c.dictionary && c.dictionary->mem == TGX_MEM_HOST);
     if (c.length > 0) {
