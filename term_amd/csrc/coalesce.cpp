@@ -370,6 +370,15 @@ size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int6
 
 void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs);
 
+// pending HOST bytes that trigger a flush (below); TGX_COALESCE_FLUSH_HOST_BYTES overrides
+static size_t coalesce_flush_host_bytes() {
+  static const size_t v = [] {
+    const char *e = getenv("TGX_COALESCE_FLUSH_HOST_BYTES");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32 << 20;
+  }();
+  return v;
+}
+
 tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column *columns, int64_t nrows,
                                   const BatchTraits &traits, bool *taken, tgx_error *err) {
   Coalescer &co = st->coalesce;
@@ -400,7 +409,10 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       if (need > kCoalesceArenaMax) return TGX_OK;  // (64 Ki rows of very long strings): the immediate path
       if (co.arena_used > 0 && co.arena_used + need > co.arena_cap[co.arena_cur]) {
         // the arena is full: flush, and ask for a bigger one next time (fewer, larger flushes)
-        co.arena_want = std::min(kCoalesceArenaMax, std::max(co.arena_want * 2, need));
+        // (straight to the size a stream settles at -- a flush's worth plus a batch -- instead of doubling its way
+        //  there: every growth pins a new arena, and 8 + 16 + 32 + 64 MB cost a first stream 10 - 20 ms)
+        co.arena_want = std::min(kCoalesceArenaMax,
+                                 std::max({co.arena_want * 2, need, coalesce_flush_host_bytes() + need + ((size_t)1 << 20)}));
         TGX_TRY(coalesce_flush(st, err));
       }
       if (need > co.arena_want) co.arena_want = std::min(kCoalesceArenaMax, need + need / 2);
@@ -635,11 +647,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   // a HOST stream is flushed in pieces of a few tens of MB: the upload of one piece then runs beside the noting and
   // copying of the next (with 4 Mi-row flushes an 8 Mi-row table was two flushes: nothing overlapped; a piece of 32 MB
   // is 0.6 ms of PCIe time, against ~0.1 ms of launches per flush)
-  static const size_t flush_host_bytes = [] {
-    const char *e = getenv("TGX_COALESCE_FLUSH_HOST_BYTES");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32 << 20;
-  }();
-  if (any_host && co.flush_rows == 0 && co.arena_used >= flush_host_bytes) return coalesce_flush(st, err);
+  if (any_host && co.flush_rows == 0 && co.arena_used >= coalesce_flush_host_bytes()) return coalesce_flush(st, err);
   return TGX_OK;
 }
 

@@ -41,15 +41,20 @@ def main():
             for cols in cols_per_batch[:4]:
                 st.update(cols)
             st.finalize()
-            st.reset()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for cols in cols_per_batch:
-                st.update(cols)
-            res = st.finalize()
-            dt = time.perf_counter() - t0
+            # the first pass over a batch size may still grow the state's pinned arenas (a one-time cost per process:
+            # round 4's "64 Ki cliff" from Python was this pass, timed); the steady figure is the best of the next three
+            times = []
+            for rep in range(4):
+                st.reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for cols in cols_per_batch:
+                    st.update(cols)
+                res = st.finalize()
+                times.append(time.perf_counter() - t0)
+            dt = min(times[1:])
             print(json.dumps({"suite": name, "buffers": where, "rows": n, "batch_rows": batch_rows, "updates": len(cols_per_batch),
-                              "total_ms": dt * 1e3, "us_per_update": dt * 1e6 / len(cols_per_batch),
+                              "total_ms": dt * 1e3, "first_pass_ms": times[0] * 1e3, "us_per_update": dt * 1e6 / len(cols_per_batch),
                               "rows_per_s": n / dt, "distinct0": res[-2].distinct if len(sp) > 16 else None}))
 
 
