@@ -89,7 +89,8 @@ typedef enum tgx_type {
    * (TG/constraints/completeness.rs:158-163, uniqueness.rs:612-617) and Parquet tables are full of these.  `values`
    * holds 1 / 2 / 4 bytes per row; the batch's window is widened to Int64 on the device (value-preserving: every check
    * then sees the Int64 column the values stand for -- SUM in Int64 as DataFusion's for signed inputs; its UInt64 sum
-   * of unsigned inputs has the same value while it fits).  Not coalesced: every batch is launched as it arrives. */
+   * of unsigned inputs has the same value while it fits).  Small HOST batches are coalesced like Int64 ones (widened
+   * on their way into the pinned arena); DEVICE batches of these types are launched as they arrive. */
   TGX_INT8 = 9,
   TGX_INT16 = 10,
   TGX_UINT8 = 11,

@@ -17,6 +17,7 @@ pub struct ColumnView {
     _variadic: Vec<*const u8>,
     _variadic_sizes: Vec<i64>,
     _realigned_validity: Option<Buffer>,
+    _offsets: Vec<i32>, // fixed-width values presented as w-byte strings: the offsets 0, w, 2 w, ..
 }
 
 impl ColumnView {
@@ -29,7 +30,8 @@ impl ColumnView {
     }
 }
 
-/// `None`: a type outside the path (Decimal, Binary, nested ..) -- evaluate the constraint with the stock SQL.
+/// `None`: a type outside the path (nested types, intervals, Float16 ..) -- evaluate the constraint with the stock SQL
+/// (or, for a column only completeness / size look at, hand over `validity_only_view`).
 pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
     let d = arr.to_data();
     let mut view = ColumnView {
@@ -54,6 +56,7 @@ pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
         _variadic: Vec::new(),
         _variadic_sizes: Vec::new(),
         _realigned_validity: None,
+        _offsets: Vec::new(),
     };
     // tgx applies ONE offset to validity bits and value slots alike; a NullBuffer carries its own bit offset
     if let Some(nulls) = d.nulls() {
@@ -125,7 +128,7 @@ pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
             view.raw.offsets = first(0) as _;
             view.raw.data = first(1);
         }
-        DataType::Utf8View => {
+        DataType::Utf8View | DataType::BinaryView => {
             view.raw.type_ = TGX_UTF8_VIEW;
             view.raw.values = first(0) as _;
             for b in &d.buffers()[1..] {
@@ -148,9 +151,88 @@ pub fn column_view(arr: &ArrayRef) -> Option<ColumnView> {
             view.raw.dictionary = &dict.raw as *const tgx_column;
             view._dictionary = Some(dict);
         }
+        // Binary / LargeBinary / BinaryView have the string layouts: COUNT and COUNT(DISTINCT) compare bytes, as the
+        // reference's SQL does (the planner plans no pattern or LENGTH check on them: `string_typed`)
+        DataType::Binary => {
+            view.raw.type_ = TGX_UTF8;
+            view.raw.offsets = first(0) as _;
+            view.raw.data = first(1);
+        }
+        DataType::LargeBinary => {
+            view.raw.type_ = TGX_LARGE_UTF8;
+            view.raw.offsets = first(0) as _;
+            view.raw.data = first(1);
+        }
+        // fixed-width values of w bytes (FixedSizeBinary(w), Decimal128 = 16, Decimal256 = 32): one precision / scale per
+        // column, so equal values are equal bytes and COUNT(DISTINCT) sees them as w-byte strings; the offsets are made
+        // here (4 bytes per row), the values are not copied.  The validity bitmap keeps the array's offset, so the
+        // offsets start at slot `offset` too.
+        DataType::FixedSizeBinary(_) | DataType::Decimal128(_, _) | DataType::Decimal256(_, _) => {
+            let w = match d.data_type() {
+                DataType::FixedSizeBinary(w) => *w as i64,
+                DataType::Decimal128(_, _) => 16,
+                _ => 32,
+            };
+            let slots = (d.offset() + d.len() + 1) as i64;
+            if slots * w >= i32::MAX as i64 {
+                return None;
+            }
+            view._offsets = (0..slots).map(|i| (i * w) as i32).collect();
+            view.raw.type_ = TGX_UTF8;
+            view.raw.offsets = view._offsets.as_ptr() as _;
+            view.raw.data = first(0);
+        }
         _ => return None,
     }
     Some(view)
+}
+
+/// ANY array for the checks that read no values -- completeness and size need the validity bitmap and the length only
+/// (`SELECT COUNT(*), COUNT(c)` takes every column type: constraints/completeness.rs:158-163): lists, structs, maps,
+/// intervals .. no longer send a whole run back to SQL because one of them has an `is_complete` check.
+pub fn validity_only_view(arr: &ArrayRef) -> ColumnView {
+    let d = arr.to_data();
+    let mut raw: tgx_column = unsafe { std::mem::zeroed() };
+    raw.type_ = TGX_INT64;
+    raw.mem = TGX_MEM_HOST;
+    raw.length = d.len() as i64;
+    raw.offset = d.offset() as i64;
+    raw.null_count = d.null_count() as i64;
+    let mut realigned = None;
+    if let Some(nulls) = d.nulls() {
+        if nulls.offset() == d.offset() {
+            raw.validity = nulls.validity().as_ptr();
+        } else {
+            let bits = nulls.inner().sliced();
+            let mut aligned = arrow::buffer::MutableBuffer::new_null(d.offset() + d.len());
+            for i in 0..d.len() {
+                if arrow::util::bit_util::get_bit(bits.as_slice(), i) {
+                    arrow::util::bit_util::set_bit(aligned.as_slice_mut(), d.offset() + i);
+                }
+            }
+            let buf: Buffer = aligned.into();
+            raw.validity = buf.as_ptr();
+            realigned = Some(buf);
+        }
+    }
+    ColumnView {
+        raw,
+        _array: arr.clone(),
+        _dictionary: None,
+        _variadic: Vec::new(),
+        _variadic_sizes: Vec::new(),
+        _realigned_validity: realigned,
+        _offsets: Vec::new(),
+    }
+}
+
+/// Do pattern / length / containment checks apply to this type?  (The reference's `~` and `LENGTH` take strings.)
+pub fn string_typed(t: &DataType) -> bool {
+    match t {
+        DataType::Utf8 | DataType::LargeUtf8 | DataType::Utf8View => true,
+        DataType::Dictionary(_, v) => matches!(**v, DataType::Utf8 | DataType::LargeUtf8),
+        _ => false,
+    }
 }
 
 /// A column the plan does not read: zeroed (include/tgx.h, tgx_update).

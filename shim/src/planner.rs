@@ -22,7 +22,7 @@
 //! | containment (`ContainmentConstraint::new`)          | COUNT(c) + REGEX_MATCH(c, `^(?:a|b|..)$`) | constraints/values.rs:245-291 |
 //! | `has_approx_count_distinct`                         | APPROX_DISTINCT(c)                        | constraints/approx_count_distinct.rs:53-120 |
 //! | `has_correlation` (Pearson), covariance, independence | COMOMENTS(a, b)                         | constraints/correlation.rs:299-444 |
-use crate::column::{column_view, unused_column, ColumnView};
+use crate::column::{column_view, string_typed, unused_column, validity_only_view, ColumnView};
 use crate::handles::{Error, Plan, Spec, State};
 use crate::sys::*;
 use arrow::datatypes::DataType;
@@ -113,7 +113,10 @@ fn reference_extracts(v: &Verdict, t: &DataType) -> bool {
             StatisticType::Mean | StatisticType::StandardDeviation | StatisticType::Variance => sint || uint || flt,
         },
         Verdict::Quantile { .. } => matches!(t, Int32),
-        _ => true, // counts: COUNT / COUNT(DISTINCT) / pattern and length matches come back as Int64 whatever the column
+        // pattern / length / containment checks are for string columns (a Binary column has the string LAYOUT here, but
+        // `~` and LENGTH on it are the reference's to refuse)
+        Verdict::Format { .. } | Verdict::Length(_) | Verdict::Containment => string_typed(t),
+        _ => true, // counts: COUNT / COUNT(DISTINCT) come back as Int64 whatever the column
     }
 }
 
@@ -441,6 +444,10 @@ impl GpuPlanner {
         let used: Vec<bool> = (0..names.len() as i32)
             .map(|i| specs.iter().any(|s| s.column == i || s.column2 == i || s.columns.contains(&i)))
             .collect();
+        // columns only completeness / size look at: any Arrow type will do (validity + length)
+        let reads_values: Vec<bool> = (0..names.len() as i32)
+            .map(|i| specs.iter().any(|s| s.kind != TGX_CHECK_COUNT && (s.column == i || s.column2 == i || s.columns.contains(&i))))
+            .collect();
         // 2. one scan of the table instead of one per constraint; batches as DataFusion makes them (8192 rows,
         //    core/context.rs:28-38): the library coalesces them
         //    The batches are handed over as TGX_MEM_HOST_RETAINED: a RecordBatch is a set of Arc'd buffers, so holding
@@ -454,7 +461,13 @@ impl GpuPlanner {
             let batch = batch?;
             let mut views: Vec<Option<ColumnView>> = Vec::with_capacity(names.len());
             for (i, col) in batch.columns().iter().enumerate() {
-                views.push(if used[i] { column_view(col) } else { None });
+                views.push(if !used[i] {
+                    None
+                } else if reads_values[i] {
+                    column_view(col)
+                } else {
+                    Some(column_view(col).unwrap_or_else(|| validity_only_view(col)))
+                });
             }
             if views.iter().zip(&used).any(|(v, u)| *u && v.is_none()) {
                 // a column type outside the path appeared: nothing of this run is answered from the device

@@ -396,7 +396,48 @@ class Column:
             return Column(DICT32_UTF8, len(arr), values=view(bufs[1], np.int32), validity=validity,
                           offset=arr.offset, null_count=arr.null_count,
                           dictionary=Column.from_arrow(arr.dictionary))
+        # Binary / LargeBinary / BinaryView have the string layouts: COUNT and COUNT(DISTINCT) compare bytes, which is what
+        # the reference's SQL does with them (a pattern or LENGTH check on such a column is the caller's to refuse)
+        if pa.types.is_binary(t) or pa.types.is_large_binary(t):
+            data = view(bufs[2], np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
+            return Column(LARGE_UTF8 if pa.types.is_large_binary(t) else UTF8, len(arr),
+                          offsets=view(bufs[1], np.int64 if pa.types.is_large_binary(t) else np.int32), data=data,
+                          validity=validity, offset=arr.offset, null_count=arr.null_count)
+        if hasattr(pa.types, "is_binary_view") and pa.types.is_binary_view(t):
+            return Column(UTF8_VIEW, len(arr), values=view(bufs[1], np.uint8), validity=validity, offset=arr.offset,
+                          null_count=arr.null_count, variadic=[view(b, np.uint8) for b in bufs[2:]])
+        # fixed-width values of w bytes (FixedSizeBinary(w), Decimal128 = 16, Decimal256 = 32): equality of values is
+        # equality of bytes (one precision / scale per column), so COUNT(DISTINCT) sees them as w-byte strings -- the
+        # offsets 0, w, 2 w, ... are made here (4 bytes per row of host work; the values are not copied)
+        width = t.byte_width if (pa.types.is_fixed_size_binary(t) or pa.types.is_decimal(t)) else 0
+        if width:
+            n = len(arr)
+            offs = (np.arange(n + 1, dtype=np.int64) + arr.offset) * width
+            if offs[-1] < 2**31:
+                col = Column(UTF8, n, offsets=offs.astype(np.int32), data=view(bufs[1], np.uint8), validity=None, offset=0,
+                             null_count=arr.null_count)
+            else:
+                col = Column(LARGE_UTF8, n, offsets=offs, data=view(bufs[1], np.uint8), validity=None, offset=0,
+                             null_count=arr.null_count)
+            if validity is not None:  # (the validity bitmap keeps the array's own offset: re-aligned to row 0)
+                mask = np.unpackbits(validity, bitorder="little")[arr.offset:arr.offset + n]
+                v = np.concatenate([np.packbits(mask, bitorder="little"), np.zeros(8, np.uint8)])
+                col = Column(col.c.type, n, offsets=col._keep[2], data=col._keep[3], validity=v, offset=0,
+                             null_count=arr.null_count)
+            return col
         raise TgxError(2, "unsupported Arrow type %s" % arr.type)
+
+    @staticmethod
+    def validity_only(arr):
+        """ANY pyarrow Array as a column for checks that read no values (completeness / COUNT: the validity bitmap and
+        the length are all they need -- `SELECT COUNT(*), COUNT(c)` takes every column type, completeness.rs:158-163)"""
+        import numpy as np
+
+        bufs = arr.buffers()
+        validity = np.frombuffer(bufs[0], dtype=np.uint8) if (arr.null_count and bufs and bufs[0] is not None) else None
+        if validity is None and arr.null_count:  # NullArray: no bitmap, every row NULL
+            return Column(INT64, len(arr), values=None, validity=np.zeros((len(arr) + 7) // 8 + 8, np.uint8), null_count=len(arr))
+        return Column(INT64, len(arr), values=None, validity=validity, offset=arr.offset, null_count=arr.null_count)
 
 
 def spec(kind, column, column2=-1, flags=0, pattern=None, kll_k=0, columns=None, length_min=0, length_max=None):

@@ -473,9 +473,10 @@ def _arrow_batches(table):
         try:
             return Column.from_arrow(arr)
         except TgxError:
-            # a type outside the path (dates, decimals, ...): carried as a placeholder; only a check that
-            # actually reads the column fails, with the library's own error
-            return Column(0, len(arr))
+            # a type outside the path (lists, structs, ...): its validity bitmap and length travel all the same --
+            # completeness / size checks need nothing else -- and a check that reads its values fails with the library's
+            # own error ("values is NULL")
+            return Column.validity_only(arr)
 
     for rb in table.to_batches():
         batches.append([view(rb.column(i)) for i in range(rb.num_columns)])

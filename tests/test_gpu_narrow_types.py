@@ -160,3 +160,72 @@ def test_arrow_arrays_of_the_new_types():
     assert [r.non_null for r in res[:5]] == [3, 3, 3, 3, 3]
     assert [r.distinct for r in res[5:10]] == [3, 2, 2, 2, 2]
     assert (res[10].min_i, res[10].max_i, res[10].sum_i) == (0, 1, 2)
+
+
+def test_binary_decimal_and_fixed_width_columns_as_byte_strings():
+    """Binary / LargeBinary / BinaryView have the string layouts; FixedSizeBinary(w), Decimal128 and Decimal256 are w-byte
+    values under synthetic offsets (no copy of the values): COUNT and COUNT(DISTINCT) on them against Python sets, on
+    SLICED arrays with NULLs (the offsets, the validity bits and the value slots all start mid-buffer)."""
+    import decimal
+
+    import pyarrow as pa
+
+    rng = np.random.default_rng(77)
+    n, cut = 50_000, 1_237
+    pool = [bytes(rng.integers(0, 256, size=int(k), dtype=np.uint8)) for k in rng.integers(0, 40, size=300)]
+    blobs = [None if rng.random() < 0.1 else pool[int(i)] for i in rng.integers(0, len(pool), size=n)]
+    fixed = [None if b is None else (b + b"\0" * 12)[:12] for b in blobs]
+    cents = [None if rng.random() < 0.2 else decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-400, 400, size=n)]
+    big = [None if c is None else c * 10**30 for c in cents]
+    arrays = [pa.array(blobs, pa.binary()), pa.array(blobs, pa.large_binary()), pa.array(blobs, pa.binary_view()),
+              pa.array(fixed, pa.binary(12)), pa.array(cents, pa.decimal128(12, 2)), pa.array(big, pa.decimal256(50, 2))]
+    pylists = [blobs, blobs, blobs, fixed, cents, big]
+    cols = [T.Column.from_arrow(a.slice(cut, n - 2 * cut)) for a in arrays]
+    specs = [spec(T.COUNT, i) for i in range(6)] + [spec(T.DISTINCT, i, flags=T.WANT_MULTIPLICITY) for i in range(6)]
+    res, _, _ = run_plan(specs, [cols])
+    for i, vals in enumerate(pylists):
+        part = vals[cut:n - cut]
+        live = [v for v in part if v is not None]
+        assert (res[i].total, res[i].non_null) == (len(part), len(live)), arrays[i].type
+        counts = {}
+        for v in live:
+            counts[v] = counts.get(v, 0) + 1
+        assert res[6 + i].distinct == len(counts), arrays[i].type
+        assert res[6 + i].unique == sum(1 for c in counts.values() if c == 1), arrays[i].type
+    # the same column in several batches cut at odd rows (each cut a slice with its own offset)
+    bounds = [0, 1, 8191, 8192, 30_001, n]
+    batches = [[T.Column.from_arrow(a.slice(lo, hi - lo)) for a in arrays] for lo, hi in zip(bounds, bounds[1:])]
+    res2, _, _ = run_plan(specs, batches)
+    for i, vals in enumerate(pylists):
+        live = [v for v in vals if v is not None]
+        assert (res2[i].total, res2[i].non_null, res2[6 + i].distinct) == (n, len(live), len(set(live))), arrays[i].type
+
+
+def test_completeness_of_any_arrow_type():
+    """COUNT reads the validity bitmap and the length: lists, structs, maps, intervals, NullArrays .. go through
+    Column.validity_only (what ValidationSuite.run falls back to for a column only completeness / size look at)"""
+    import pyarrow as pa
+
+    from term_amd.suite import Assertion, Check, CompletenessOptions, Level, ValidationSuite
+
+    n = 20_000
+    rng = np.random.default_rng(3)
+    keep = rng.random(n) > 0.25
+    lists = pa.array([[1, 2] if k else None for k in keep], pa.list_(pa.int32()))
+    structs = pa.array([{"a": 1, "b": "x"} if k else None for k in keep[::-1]], pa.struct([("a", pa.int8()), ("b", pa.string())]))
+    nulls = pa.nulls(n)
+    months = pa.array([3 if k else None for k in keep], pa.month_day_nano_interval()) if hasattr(pa, "month_day_nano_interval") else lists
+    arrays = [lists, structs, nulls, months]
+    cols = [T.Column.validity_only(a.slice(77, n - 100)) for a in arrays]
+    res, _, _ = run_plan([spec(T.COUNT, i) for i in range(4)], [cols])
+    want = [int(keep[77:n - 23].sum()), int(keep[::-1][77:n - 23].sum()), 0, int(keep[77:n - 23].sum())]
+    assert [(r.total, r.non_null) for r in res] == [(n - 100, w) for w in want]
+    # through the suite: a table with a list column beside the checked ones no longer needs the list column dropped
+    ids = pa.array(np.arange(n, dtype=np.int64))
+    table = pa.table({"id": ids, "tags": lists, "rec": structs})
+    check = (Check.builder("c").level(Level.ERROR).validates_uniqueness(["id"], 1.0)
+             .completeness("tags", CompletenessOptions.threshold(0.9)).completeness("rec", CompletenessOptions.threshold(0.7))
+             .has_size(Assertion.Equals(float(n))).build())
+    out = ValidationSuite.builder("s").check(check).build().run(table)
+    assert (out.report.metrics.total_checks, out.report.metrics.failed_checks) == (4, 1)
+    assert [i.constraint_name for i in out.report.issues] == ["completeness"] and "tags" in out.report.issues[0].message
