@@ -181,7 +181,7 @@ def test_binary_decimal_and_fixed_width_columns_as_byte_strings():
               pa.array(fixed, pa.binary(12)), pa.array(cents, pa.decimal128(12, 2)), pa.array(big, pa.decimal256(50, 2))]
     pylists = [blobs, blobs, blobs, fixed, cents, big]
     cols = [T.Column.from_arrow(a.slice(cut, n - 2 * cut)) for a in arrays]
-    specs = [spec(T.COUNT, i) for i in range(6)] + [spec(T.DISTINCT, i, flags=T.WANT_MULTIPLICITY) for i in range(6)]
+    specs = [spec(T.COUNT, i) for i in range(6)] + [spec(T.DISTINCT, i, flags=T.FLAG_MULTIPLICITY) for i in range(6)]
     res, _, _ = run_plan(specs, [cols])
     for i, vals in enumerate(pylists):
         part = vals[cut:n - cut]
@@ -191,7 +191,7 @@ def test_binary_decimal_and_fixed_width_columns_as_byte_strings():
         for v in live:
             counts[v] = counts.get(v, 0) + 1
         assert res[6 + i].distinct == len(counts), arrays[i].type
-        assert res[6 + i].unique == sum(1 for c in counts.values() if c == 1), arrays[i].type
+        assert res[6 + i].groups_once == sum(1 for c in counts.values() if c == 1), arrays[i].type
     # the same column in several batches cut at odd rows (each cut a slice with its own offset)
     bounds = [0, 1, 8191, 8192, 30_001, n]
     batches = [[T.Column.from_arrow(a.slice(lo, hi - lo)) for a in arrays] for lo, hi in zip(bounds, bounds[1:])]
@@ -214,7 +214,7 @@ def test_completeness_of_any_arrow_type():
     lists = pa.array([[1, 2] if k else None for k in keep], pa.list_(pa.int32()))
     structs = pa.array([{"a": 1, "b": "x"} if k else None for k in keep[::-1]], pa.struct([("a", pa.int8()), ("b", pa.string())]))
     nulls = pa.nulls(n)
-    months = pa.array([3 if k else None for k in keep], pa.month_day_nano_interval()) if hasattr(pa, "month_day_nano_interval") else lists
+    months = pa.array([pa.MonthDayNano([3, 0, 0]) if k else None for k in keep], pa.month_day_nano_interval())
     arrays = [lists, structs, nulls, months]
     cols = [T.Column.validity_only(a.slice(77, n - 100)) for a in arrays]
     res, _, _ = run_plan([spec(T.COUNT, i) for i in range(4)], [cols])
