@@ -202,6 +202,15 @@ tgx_status fp_lists_prepare(tgx_state *st, DistinctState &ds, int64_t rows, size
   constexpr uint64_t kLists1 = (uint64_t)kFpXcds * kFpFan;
   ds.fp_cap1 = fp_list_cap(rows, kLists1);
   ds.fp_cap2 = fp_list_cap(rows, kLists2);
+  // TGX_FP_LIST_CAPS="cap1:cap2" (tests): room for longer lists than the batch's size asks for, so that a batch of a
+  // few hundred thousand keys chosen to fall into a dozen lists runs the kernels that otherwise need 800 M rows
+  if (const char *e = getenv("TGX_FP_LIST_CAPS")) {
+    unsigned long long c1 = 0, c2 = 0;
+    if (sscanf(e, "%llu:%llu", &c1, &c2) == 2 && c2 <= kFpListMax) {
+      ds.fp_cap1 = std::max<uint64_t>(ds.fp_cap1, (c1 + 15) & ~15ull);
+      ds.fp_cap2 = std::max<uint64_t>(ds.fp_cap2, (c2 + 15) & ~15ull);
+    }
+  }
   HIP_TRY(ds.fp_level1.reserve(kLists1 * ds.fp_cap1 * rec_bytes));
   HIP_TRY(ds.fp_level2.reserve(kLists2 * ds.fp_cap2 * rec_bytes));
   HIP_TRY(ds.fp_offered.reserve((kLists1 + kLists2) * sizeof(uint32_t)));

@@ -131,3 +131,58 @@ def test_real_threshold_sparse_ids():
     st.update([col.sliced(n // 2, n - n // 2)])
     r2 = st.finalize()[0]
     assert (r2.total, r2.non_null, r2.distinct, r2.groups_once) == (r.total, r.non_null, r.distinct, r.groups_once)
+
+
+_M64 = (1 << 64) - 1
+
+
+def _unmix64(x):
+    """inverse of the splitmix64 finaliser the key lists partition by (kernels/distinct.hip, unmix64)"""
+    x = np.asarray(x, dtype=np.uint64).copy()
+    x ^= (x >> np.uint64(31)) ^ (x >> np.uint64(62))
+    x *= np.uint64(0x319642B2D24D8EC3)
+    x ^= (x >> np.uint64(27)) ^ (x >> np.uint64(54))
+    x *= np.uint64(0x96DE1B173F119089)
+    x ^= (x >> np.uint64(30)) ^ (x >> np.uint64(60))
+    return x
+
+
+@pytest.mark.parametrize("cap2", [17_000, 24_000])
+@pytest.mark.parametrize("shape", ["distinct", "repeats", "crowded"])
+def test_long_lists_counted_in_lds(monkeypatch, cap2, shape):
+    """The count of LONG lists (more than 12 288 records: what 800 M+ keys produce) on a few hundred thousand keys
+    chosen -- through the inverse of the mix -- to fall into a dozen of the 65 536 lists, with room made by
+    TGX_FP_LIST_CAPS (the 32 Ki-slot table at one workgroup a CU: before round 5 only runs of that size reached it).
+    distinct: every key once; repeats: every key 1-6 times, some a thousand times; crowded: a third of a list's records
+    start at the SAME slot, another third share a tag with different keys (probe chains thousands of slots long)."""
+    monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "1000")
+    monkeypatch.setenv("TGX_FP_LIST_CAPS", "%d:%d" % (cap2 + 2_000, cap2))
+    rng = np.random.default_rng([cap2, len(shape)])
+    lists = rng.choice(65536, size=12, replace=False).astype(np.uint64)
+    per = cap2 - 900
+    mixed = []
+    for li in lists:
+        low = rng.integers(0, 1 << 48, size=per, dtype=np.uint64)
+        if shape == "repeats":
+            pool = low[: per // 3]
+            low = pool[rng.integers(0, len(pool), size=per)]
+            low[: 1000] = pool[0]
+        elif shape == "crowded":
+            third = per // 3
+            low[:third] = (low[:third] & np.uint64(0xFFFF_8000_FFFF_FFFF)) | (np.uint64(12345) << np.uint64(32))  # one slot
+            low[third:2 * third] = (low[third:2 * third] & np.uint64(0xFFFF_FFFF_FFFF_0000)) | np.uint64(0xBEEF)  # one tag
+            low[-50:] = low[:50]
+        mixed.append((li << np.uint64(48)) | low)
+    mixed = np.concatenate(mixed)
+    rng.shuffle(mixed)
+    keys = _unmix64(mixed).view(np.int64)
+    n = len(keys)
+    mask = rng.random(n) >= 0.03
+    valid = orc.pack_validity(mask)
+    want = orc.distinct_bits64(keys.view(np.uint64), valid)
+    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], [numeric_column(keys, valid, True)])
+    assert took_lists(st) == 1
+    check(res[0], want)
+    res, st, _ = run([spec(T.DISTINCT, 0)], [numeric_column(keys, None, True)])
+    want = orc.distinct_bits64(keys.view(np.uint64), None)
+    assert (res[0].non_null, res[0].distinct) == (want.non_null, want.distinct)
