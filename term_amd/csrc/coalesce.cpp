@@ -82,6 +82,7 @@ class CopyPool {
     k.busy.store(false, std::memory_order_release);
   }
   void release(int w) { w_[w].busy.store(false, std::memory_order_release); }
+  bool finished(int w) const { return w_[w].done.load(std::memory_order_acquire) == w_[w].ticket; }  // (claimed, posted)
 
  private:
   struct Worker {
@@ -369,6 +370,11 @@ size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int6
 }
 
 void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs);
+void coalesce_start_copies(Coalescer &co);
+void coalesce_finish_copies(Coalescer &co, bool fold);
+namespace {
+size_t coalesce_eager_bytes();
+}
 
 // pending HOST bytes that trigger a flush (below); TGX_COALESCE_FLUSH_HOST_BYTES overrides
 static size_t coalesce_flush_host_bytes() {
@@ -494,7 +500,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
         }
       }
       co.arena_used = arena_used;
-      co.deferred.resize(deferred);
+      co.deferred.resize(std::min(deferred, co.deferred.size()));  // (a flush on the way may have emptied it)
     }
   } rollback(co, rb_segs, rb_dict_segs, rb_data_bytes, any_host || traits.any_strings);
   // ... and a Utf8View column's one coalesced data buffer (int32 offsets in the views) likewise
@@ -514,6 +520,7 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       break;
     }
   }
+  const size_t deferred_from = co.deferred.size();  // (after any flush on the way)
   char *ah = any_host ? (char *)co.arena_host[co.arena_cur] : nullptr;
   const char *ad = any_host ? (const char *)co.arena_dev[co.arena_cur].p : nullptr;
   std::vector<CopyJob> &jobs = co.copy_jobs;
@@ -637,6 +644,10 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   }
   run_copy_jobs(co, jobs);
   rollback.armed = false;
+  if (defer) {
+    for (size_t q = deferred_from; q < co.deferred.size(); q++) co.deferred_bytes += co.deferred[q].bytes;
+    if (coalesce_eager_bytes() && co.deferred_bytes >= coalesce_eager_bytes()) coalesce_start_copies(co);
+  }
   co.rows += nrows;
   co.batches += 1;
   co.coalesced_batches += 1;
@@ -647,8 +658,114 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   // a HOST stream is flushed in pieces of a few tens of MB: the upload of one piece then runs beside the noting and
   // copying of the next (with 4 Mi-row flushes an 8 Mi-row table was two flushes: nothing overlapped; a piece of 32 MB
   // is 0.6 ms of PCIe time, against ~0.1 ms of launches per flush)
-  if (any_host && co.flush_rows == 0 && co.arena_used >= coalesce_flush_host_bytes()) return coalesce_flush(st, err);
+  // (the first piece of a stream is a short one: nothing is on the link until it goes)
+  if (any_host && co.flush_rows == 0 &&
+      co.arena_used >= (co.host_flushes == 0 ? std::min(coalesce_flush_host_bytes(), (size_t)8 << 20) : coalesce_flush_host_bytes()))
+    return coalesce_flush(st, err);
   return TGX_OK;
+}
+
+namespace {
+// `jobs` cut into `shares` equal shares of the bytes (a job that straddles a boundary is cut at a multiple of 64 bytes),
+// one behind the other in `cut`: share s is cut[first[s] .. first[s + 1])
+void cut_shares(const std::vector<CoalesceCopy> &jobs, size_t total, int shares, std::vector<CopyJob> &cut, size_t *first) {
+  cut.clear();
+  const size_t per = (total / (size_t)shares + 63) & ~(size_t)63;
+  size_t room = per;
+  int share = 0;
+  first[0] = 0;
+  for (const CopyJob &j : jobs) {
+    size_t at = 0;
+    while (at < j.bytes) {
+      if (room == 0 && share + 1 < shares) {
+        first[++share] = cut.size();
+        room = per;
+      }
+      size_t take = share + 1 < shares ? std::min(room, j.bytes - at) : j.bytes - at;
+      if (take < j.bytes - at) take = std::min((take + 63) & ~(size_t)63, j.bytes - at);  // (cuts stay 64-byte aligned)
+      cut.push_back(CopyJob((char *)j.dst + at, (const char *)j.src + at, take));
+      if (j.widen) {  // (`at` counts destination bytes, a multiple of 64: 8 values, one byte of Boolean bits)
+        CopyJob &piece = cut.back();
+        piece.widen = j.widen;
+        piece.src_bit0 = j.src_bit0;
+        const size_t e = at / 8;
+        piece.src = (const char *)j.src + (j.widen == 7 ? e / 8 : j.widen == 6 ? e * 4 : (j.widen == 3 || j.widen == 5) ? e * 2 : e);
+      }
+      if (j.mm_col >= 0) {  // (cuts are multiples of 64 bytes = 8 values: whole validity bytes further on)
+        CopyJob &piece = cut.back();
+        piece.mm_col = j.mm_col;
+        const int64_t bit = j.mm_bit0 + (int64_t)(at / 8);
+        piece.mm_validity = j.mm_validity ? j.mm_validity + (bit >> 3) : nullptr;
+        piece.mm_bit0 = bit & 7;
+      }
+      at += take;
+      room -= std::min(room, take);
+    }
+  }
+  while (share + 1 < shares) first[++share] = cut.size();
+  first[shares] = cut.size();
+}
+void fold_range(Coalescer &co, const CopyJob &j) {  // a key column's piece: its MIN / MAX into the column's pending range
+  if (j.mm_col < 0) return;
+  CoalesceColumn &cc = co.cols[j.mm_col];
+  cc.range_lo = std::min(cc.range_lo, j.lo);
+  cc.range_hi = std::max(cc.range_hi, j.hi);
+}
+// TGX_COALESCE_EAGER_BYTES: retained windows are handed to the copy threads every so many bytes (0: at the flush only)
+size_t coalesce_eager_bytes() {
+  static const size_t v = [] {
+    const char *e = getenv("TGX_COALESCE_EAGER_BYTES");
+    return e ? (size_t)atoll(e) : (size_t)4 << 20;
+  }();
+  return v;
+}
+}  // namespace
+
+// The retained windows noted so far go to the copy threads that are idle right now, and the caller goes on noting
+// batches: with the copies left to the flush the caller's thread stood still for a flush's worth of memcpy every 32 MB
+// and the stream ran at three quarters of what the link takes (its upload ran beside the NEXT piece's noting AND
+// copying); now a piece's copies run beside its own noting.  (The arena is not touched by anyone else until the flush:
+// it is sized when its first window is noted.)
+void coalesce_start_copies(Coalescer &co) {
+  // workers whose share is done go back to the pool (an earlier call's, or another state's, may want them)
+  for (Coalescer::Inflight &f : co.inflight) {
+    if (f.helpers < 0) continue;
+    CopyPool *pool = CopyPool::get();
+    bool all = pool != nullptr;
+    for (int w = 0; all && w < f.helpers; w++) all = pool->finished(f.ids[w]);
+    if (all) {
+      for (int w = 0; w < f.helpers; w++) pool->release(f.ids[w]);
+      f.helpers = -1;  // (its pieces wait for the flush: their MIN / MAX are folded there)
+    }
+  }
+  if (co.deferred.empty()) return;
+  CopyPool *pool = CopyPool::get();
+  if (!pool) return;
+  Coalescer::Inflight f;
+  f.helpers = pool->claim(f.ids);
+  if (f.helpers == 0) return;  // (all busy: the windows wait for the next call, or for the flush)
+  co.inflight.emplace_back();
+  Coalescer::Inflight &slot = co.inflight.back();
+  slot.helpers = f.helpers;
+  for (int w = 0; w < f.helpers; w++) slot.ids[w] = f.ids[w];
+  size_t first[CopyPool::kMaxWorkers + 2];
+  cut_shares(co.deferred, co.deferred_bytes, slot.helpers, slot.cut, first);
+  for (int w = 0; w < slot.helpers; w++) pool->post(slot.ids[w], slot.cut.data() + first[w], first[w + 1] - first[w]);
+  co.deferred.clear();
+  co.deferred_bytes = 0;
+}
+
+// the flush (or a reset): every started copy is through before anybody looks at the arena -- or lets go of it
+void coalesce_finish_copies(Coalescer &co, bool fold) {
+  for (Coalescer::Inflight &f : co.inflight) {
+    if (f.helpers > 0) {
+      CopyPool *pool = CopyPool::get();
+      for (int w = 0; pool && w < f.helpers; w++) pool->wait_and_release(f.ids[w]);
+    }
+    if (fold)
+      for (const CopyJob &piece : f.cut) fold_range(co, piece);
+  }
+  co.inflight.clear();
 }
 
 // the copies of `jobs` shared between the calling thread and the copy threads that are idle right now
@@ -659,12 +776,7 @@ void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs) {
     CopyPool *pool = total >= (64u << 10) ? CopyPool::get() : nullptr;
     int ids[CopyPool::kMaxWorkers];
     const int helpers = pool ? pool->claim(ids) : 0;  // (whoever is idle right now: other states may hold the rest)
-    auto fold = [&](const CopyJob &j) {  // a key column's piece: its MIN / MAX into the column's pending range
-      if (j.mm_col < 0) return;
-      CoalesceColumn &cc = co.cols[j.mm_col];
-      cc.range_lo = std::min(cc.range_lo, j.lo);
-      cc.range_hi = std::max(cc.range_hi, j.hi);
-    };
+    auto fold = [&](const CopyJob &j) { fold_range(co, j); };
     if (helpers == 0) {
       for (const CopyJob &j0 : jobs) {
         CopyJob j = j0;
@@ -672,46 +784,11 @@ void run_copy_jobs(Coalescer &co, const std::vector<CoalesceCopy> &jobs) {
         fold(j);
       }
     } else {
-      // equal shares of the bytes (a job that straddles a boundary is cut at a multiple of 64 bytes): the first for
-      // the caller, one for every claimed worker
+      // equal shares of the bytes: the first for the caller, one for every claimed worker
       const int shares = helpers + 1;
       std::vector<CopyJob> &cut = co.copy_tail;  // all shares one behind the other; first[s] = where share s begins
-      cut.clear();
       size_t first[CopyPool::kMaxWorkers + 2];
-      const size_t per = (total / (size_t)shares + 63) & ~(size_t)63;
-      size_t room = per;
-      int share = 0;
-      first[0] = 0;
-      for (const CopyJob &j : jobs) {
-        size_t at = 0;
-        while (at < j.bytes) {
-          if (room == 0 && share + 1 < shares) {
-            first[++share] = cut.size();
-            room = per;
-          }
-          size_t take = share + 1 < shares ? std::min(room, j.bytes - at) : j.bytes - at;
-          if (take < j.bytes - at) take = std::min((take + 63) & ~(size_t)63, j.bytes - at);  // (cuts stay 64-byte aligned)
-          cut.push_back(CopyJob((char *)j.dst + at, (const char *)j.src + at, take));
-          if (j.widen) {  // (`at` counts destination bytes, a multiple of 64: 8 values, one byte of Boolean bits)
-            CopyJob &piece = cut.back();
-            piece.widen = j.widen;
-            piece.src_bit0 = j.src_bit0;
-            const size_t e = at / 8;
-            piece.src = (const char *)j.src + (j.widen == 7 ? e / 8 : j.widen == 6 ? e * 4 : (j.widen == 3 || j.widen == 5) ? e * 2 : e);
-          }
-          if (j.mm_col >= 0) {  // (cuts are multiples of 64 bytes = 8 values: whole validity bytes further on)
-            CopyJob &piece = cut.back();
-            piece.mm_col = j.mm_col;
-            const int64_t bit = j.mm_bit0 + (int64_t)(at / 8);
-            piece.mm_validity = j.mm_validity ? j.mm_validity + (bit >> 3) : nullptr;
-            piece.mm_bit0 = bit & 7;
-          }
-          at += take;
-          room -= std::min(room, take);
-        }
-      }
-      while (share + 1 < shares) first[++share] = cut.size();
-      first[shares] = cut.size();
+      cut_shares(jobs, total, shares, cut, first);
       for (int w = 0; w < helpers; w++) pool->post(ids[w], cut.data() + first[w + 1], first[w + 2] - first[w + 1]);
       for (size_t q = first[0]; q < first[1]; q++) copy_piece(cut[q]);
       for (int w = 0; w < helpers; w++) pool->wait_and_release(ids[w]);
@@ -908,13 +985,27 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
       v.dictionary = &dv;
     }
   }
+  // TGX_MEM_HOST_RETAINED windows: what the copy threads have been given while the batches were noted is waited for,
+  // the rest goes into the arena now, all of it together; the key columns' MIN / MAX beside them
+  coalesce_finish_copies(co, true);
   if (!co.deferred.empty()) {
-    // TGX_MEM_HOST_RETAINED windows: into the arena now, all of them together; the key columns' MIN / MAX beside them
     run_copy_jobs(co, co.deferred);
     co.deferred.clear();
   }
-  if (co.arena_used)
-    HIP_TRY(hipMemcpyAsync(co.arena_dev[ar].p, co.arena_host[ar], co.arena_used, hipMemcpyHostToDevice, st->stream));
+  co.deferred_bytes = 0;
+  if (co.arena_used) {
+    // (the arena's device twin is free: whoever read it last was waited for when the arena's first window was noted)
+    static const bool own_stream = !(getenv("TGX_COALESCE_COPY_STREAM") && atoi(getenv("TGX_COALESCE_COPY_STREAM")) == 0);
+    if (own_stream && !co.copy_stream) HIP_TRY(stream_acquire(&co.copy_stream, false));
+    if (own_stream && !co.upload_done[ar]) HIP_TRY(hipEventCreateWithFlags(&co.upload_done[ar], hipEventDisableTiming));
+    hipStream_t up = own_stream ? co.copy_stream : st->stream;
+    HIP_TRY(hipMemcpyAsync(co.arena_dev[ar].p, co.arena_host[ar], co.arena_used, hipMemcpyHostToDevice, up));
+    if (own_stream) {
+      HIP_TRY(hipEventRecord(co.upload_done[ar], up));
+      HIP_TRY(hipStreamWaitEvent(st->stream, co.upload_done[ar], 0));
+    }
+    co.host_flushes++;
+  }
   HIP_TRY(hipMemcpyAsync(co.desc_dev[ar].p, gs, g * sizeof(GatherSeg), hipMemcpyHostToDevice, st->stream));
   {
     ProfScope ps(st, "gather", 0);
@@ -1021,7 +1112,10 @@ void coalesce_drop(tgx_state *st) {  // reset / destroy: pending batches are for
   co.rows = 0;
   co.batches = 0;
   co.arena_used = 0;
+  coalesce_finish_copies(co, false);  // (the copy threads let go of the arena before anybody else may have it)
+  co.host_flushes = 0;
   co.deferred.clear();
+  co.deferred_bytes = 0;
   co.snap_pending[0] = co.snap_pending[1] = false;
 }
 

@@ -478,6 +478,11 @@ struct Coalescer {
   bool arena_busy[2] = {false, false};
   int arena_cur = 0;
   size_t arena_used = 0;
+  // an arena goes up on a stream of its own (from the library's pool), the state's stream waits for it before the
+  // gather: the upload of one flush then runs beside the kernels of the flush before it instead of behind them
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t upload_done[2] = {nullptr, nullptr};
+  uint64_t host_flushes = 0;  // flushes that carried HOST windows since the last reset (the first is a short one)
   // the segment table of a flush: pinned, uploaded, one per arena turn
   void *desc_host[2] = {nullptr, nullptr};
   size_t desc_cap[2] = {0, 0};
@@ -495,6 +500,15 @@ struct Coalescer {
   // TGX_MEM_HOST_RETAINED batches: the copies into the arena being filled, and the key columns' windows whose MIN / MAX
   // the host takes, both left for the flush (all of them at once, on every copy thread)
   std::vector<CoalesceCopy> deferred;
+  // ... and the ones the copy threads are already working on while the caller goes on noting batches (started every
+  // few MB of retained windows, waited for at the flush): the pieces a worker was given stay where they are until then
+  struct Inflight {
+    std::vector<CoalesceCopy> cut;  // every worker's share, one behind the other
+    int ids[8];
+    int helpers = 0;
+  };
+  std::vector<Inflight> inflight;
+  size_t deferred_bytes = 0;  // bytes of `deferred`
   uint64_t flushes = 0, coalesced_batches = 0;  // statistics (tgx_profile_get "coalesce_flushes" / "coalesced_batches")
 };
 

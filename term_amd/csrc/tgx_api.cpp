@@ -548,11 +548,13 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   regex_state_free(st);
   kll_state_free(st);
   spearman_state_free(st);
+  coalesce_drop(st);  // (copy threads that are still filling an arena let go of it first)
   for (int k = 0; k < 2; k++) {
     if (st->arena_event[k]) (void)hipEventDestroy(st->arena_event[k]);
     pinned_free(st->arena_host[k], kArenaBytes);
     tgx::Coalescer &co = st->coalesce;
     if (co.arena_event[k]) (void)hipEventDestroy(co.arena_event[k]);
+    if (co.upload_done[k]) (void)hipEventDestroy(co.upload_done[k]);
     if (co.snap_event[k]) (void)hipEventDestroy(co.snap_event[k]);
     pinned_free(co.arena_host[k], co.arena_cap[k]);
     pinned_free(co.desc_host[k], co.desc_cap[k]);
@@ -563,6 +565,7 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   if (st->aux_done) (void)hipEventDestroy(st->aux_done);
   // (idle: the device has been waited for above) back to the pool -- hipStreamDestroy costs ~0.5 ms
   if (st->aux_stream) stream_release(st->aux_stream, true);
+  if (st->coalesce.copy_stream) stream_release(st->coalesce.copy_stream, false);
   if (st->own_stream && st->stream) stream_release(st->stream, false);
   delete st;
 }
