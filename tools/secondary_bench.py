@@ -258,6 +258,48 @@ def run_c5(T, torch, synth, spec, steps, warmup, n=250_000_000 // 64 * 64):
     return e
 
 
+def run_ingest(root):
+    """8192-row batches through the C ABI from plain C (build/feed_batches, build/feed_strings: child processes): HOST and
+    DEVICE buffers, numeric and string columns, beside the same rows as ONE batch.  rows/s; `of_one_batch` = the ratio."""
+    import json
+    import subprocess
+
+    out = {}
+
+    def lines(binary):
+        path = os.path.join(root, "build", binary)
+        if not os.path.exists(path):
+            return []
+        p = subprocess.run([path], capture_output=True, text=True, timeout=120)
+        got = []
+        for line in p.stdout.splitlines():
+            try:
+                got.append(json.loads(line))
+            except ValueError:
+                pass
+        return got
+
+    def fold(rows, key_of):
+        one = {}
+        for d in rows:  # (the one-batch line of a leg comes first)
+            k = key_of(d)
+            if d["updates"] == 1:
+                one[k.replace(" (kept until finalize)", "").replace(", kept until finalize", "")] = d["rows_per_s"]
+        for d in rows:
+            if d["batch_rows"] != 8192:
+                continue
+            k = key_of(d)
+            base = one.get(k.replace(" (kept until finalize)", "").replace(", kept until finalize", ""))
+            out[k] = {"rows_per_s_8192_row_batches": d["rows_per_s"], "rows_per_s_one_batch": base,
+                      "of_one_batch": (d["rows_per_s"] / base) if base else None, "verified": d.get("verified")}
+
+    fold(lines("feed_batches"), lambda d: "%s, %s buffers" % (d["suite"], d["buffers"]))
+    import re
+
+    fold(lines("feed_strings"), lambda d: re.sub(r", \d+ rows.*$", "", d["workload"]))
+    return out
+
+
 def measure(T, torch, synth, spec, layout, unique_cols, headline_plan, table, columns, n, seed, steps=5, warmup=2,
             warm_headline_ms=None, log=None):
     """Everything above, in an order that fits one GPU's memory: the headline table's legs first, then the table is
@@ -302,6 +344,12 @@ def measure(T, torch, synth, spec, layout, unique_cols, headline_plan, table, co
     out["cold"]["cache"] = {"device_hits": cs.device_hits, "device_misses": cs.device_misses,
                             "device_cached_bytes": cs.device_cached_bytes, "pinned_hits": cs.pinned_hits,
                             "pinned_misses": cs.pinned_misses}
+    T.trim()
+    try:
+        out["ingest"] = run_ingest(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    except Exception as e:  # (a feeder that is not built, or stuck: the rest of the line stands)
+        out["ingest"] = {"error": str(e)}
+    note("ingest")
     out["seconds"] = time.perf_counter() - t_start
     return out
 
