@@ -25,11 +25,14 @@ def table():
     words = ["alpha", "Beta", "gämma", "δelta", "user@example.com", "a@b.co", "日本語", "", "x" * 40, "bad@@mail"]
     text = [words[int(i)] + ("" if k % 4 else str(int(k))) for i, k in zip(rng.integers(0, len(words), size=N), rng.integers(0, 50, size=N))]
     codes = ["AA", "BB", "CC", "DD"]
+    text_arr = pa.array(text, pa.string(), mask=rng.random(N) < 0.07)
     return pa.table({
         "id": pa.array(ids),
         "qty": pa.array(qty, mask=rng.random(N) < 0.05),
         "price": pa.array(price, mask=rng.random(N) < 0.10),
-        "text": pa.array(text, pa.string(), mask=rng.random(N) < 0.07),
+        "text": text_arr,
+        "text_view": text_arr.cast(pa.string_view()),    # (what DataFusion reads Parquet strings as)
+        "text_large": text_arr.cast(pa.large_string()),
         "code": pa.array([codes[int(i)] for i in rng.integers(0, 4, size=N)], pa.string()).dictionary_encode(),
         "grp": pa.array(rng.integers(0, 1000, size=N, dtype=np.int64), mask=rng.random(N) < 0.02),
         "sp": pa.array(rng.integers(-10**12, 10**12, size=N, dtype=np.int64) // 3_000_000 * 7, mask=rng.random(N) < 0.03),
@@ -59,6 +62,11 @@ def suite():
     b = b.check(one("upper_first", lambda k: k.validates_regex("text", r"^\p{Lu}", 0.0)))
     b = b.check(one("code_fmt", lambda k: k.validates_regex("code", r"^[A-C]{2}$", 0.0)))
     b = b.check(one("len_text", lambda k: k.has_length_between("text", 2, 12)))
+    for c in ("text_view", "text_large"):  # the same values in the other two string layouts: the same metrics
+        b = b.check(one("dist_" + c, lambda k, c=c: k.validates_distinctness([c], any_)))
+        b = b.check(one("at_sign_" + c, lambda k, c=c: k.validates_regex(c, r"^[^@]+@[^@]+\.[a-z]+$", 0.0)))
+        b = b.check(one("upper_first_" + c, lambda k, c=c: k.validates_regex(c, r"^\p{Lu}", 0.0)))
+        b = b.check(one("complete_" + c, lambda k, c=c: k.completeness(c, CompletenessOptions.threshold(0.5))))
     b = b.check(one("size", lambda k: k.has_size(Assertion.Equals(float(N)))))
     b = b.check(one("corr", lambda k: k.has_correlation("qty", "price", any_)))
     return b.build()
@@ -101,6 +109,11 @@ def expected(t):
     ok = pc.and_(pc.greater_equal(lens, 2), pc.less_equal(lens, 12))
     m["len_text.length_between"] = (pc.sum(ok).as_py() + ok.null_count) / n
     m["size.size"] = float(n)
+    for c in ("text_view", "text_large"):
+        m["dist_%s.distinctness" % c] = m["dist_text.distinctness"]
+        m["at_sign_%s.regex" % c] = m["at_sign.regex"]
+        m["upper_first_%s.regex" % c] = m["upper_first.regex"]
+        m["complete_%s.completeness" % c] = m["complete_text.completeness"]
     both = pc.and_(pc.is_valid(t["qty"]), pc.is_valid(t["price"]))
     x = t["qty"].filter(both).to_numpy().astype(np.float64)
     y = t["price"].filter(both).to_numpy()
@@ -121,3 +134,4 @@ def test_suite_metrics_against_arrow_compute(batch_rows):
         assert got[k] == pytest.approx(v, rel=1e-9, abs=1e-9 if k.startswith("corr") else 1e-12), k
     # (the LENGTH constraint wants every row inside the bounds: it is the one that fails, with the ratio above as its metric)
     assert out.report.metrics.failed_checks == 1 and [i.check_name for i in out.report.issues] == ["len_text"]
+    assert out.report.metrics.total_checks == len(want)
