@@ -589,3 +589,56 @@ def test_host_buffers_kept_until_the_flush(flush_rows, monkeypatch):
     st.reset()
     st.update(batch(0, n, True))
     compare(st.finalize(), want)
+
+
+def test_kept_host_streams_of_several_threads_share_the_copy_threads():
+    """Four threads feed four states with kept 8192-row HOST batches at the same time: the copy threads are one pool, a
+    state takes whichever of them are idle when it has 4 MB of windows noted (coalesce_start_copies) and waits for its
+    own at the flush.  Every stream's answers equal the oracle's on its own data."""
+    import threading
+
+    T.init()
+    plan = T.Plan([spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY),
+                   spec(T.NUMERIC_STATS, 1, flags=T.FLAG_VARIANCE), spec(T.COUNT, 1)])
+    n = 1_200_000 + 11
+    data, want, errors = [], [], []
+    for t in range(4):
+        rng = np.random.default_rng(100 + t)
+        ids = (np.arange(n, dtype=np.int64) * (t + 2)) + 7_000_000 * t   # a growing key, a range per stream
+        ids[rng.random(n) < 0.02] = 7_000_000 * t
+        kval = orc.pack_validity(rng.random(n) >= 0.03)
+        f = rng.standard_normal(n) * (t + 1)
+        fval = orc.pack_validity(rng.random(n) >= 0.10)
+        data.append((ids, kval, f, fval))
+        want.append((orc.stats(ids, kval, n), orc.distinct_bits64(ids.view(np.uint64), kval, n), orc.stats(f, fval, n)))
+    got = [None] * 4
+
+    def stream(t):
+        try:
+            ids, kval, f, fval = data[t]
+            st = T.State(plan)
+            for rep in range(2):  # (the second pass over a reset state: arenas and workers change hands again)
+                st.reset()
+                for lo in range(0, n, 8192):
+                    hi = min(n, lo + 8192)
+                    st.update([_retained(numeric_column(ids, kval, False, offset=lo, length=hi - lo)),
+                               _retained(numeric_column(f, fval, False, offset=lo, length=hi - lo))])
+                got[t] = st.finalize()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=stream, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors and all(not th.is_alive() for th in threads), errors
+    for t in range(4):
+        si, di, sf = want[t]
+        r = got[t]
+        assert (r[0].total, r[0].non_null) == (n, si.non_null)
+        assert (r[1].min_i, r[1].max_i, r[1].sum_i) == (si.min_i, si.max_i, si.sum_i_wrapping)
+        assert (r[2].distinct, r[2].groups_once) == (di.distinct, di.groups_once)
+        assert (r[3].non_null, r[3].min_f, r[3].max_f) == (sf.non_null, sf.min_f, sf.max_f)
+        assert rel_err(r[3].sum_f, sf.sum_f) <= 1e-9 and rel_err(r[3].var_samp, sf.var_samp) <= 1e-9
+        assert r[4].non_null == sf.non_null
