@@ -111,8 +111,9 @@ typedef enum tgx_memspace {
   TGX_MEM_DEVICE = 1,
   /* HOST buffers the caller keeps alive AND unmodified until the next flushing call (tgx_finalize, tgx_state_sync,
    * tgx_state_serialize, tgx_merge, tgx_allreduce, tgx_state_reset) -- the contract DEVICE buffers have.  What it
-   * buys: a small batch (coalesced, below) is only NOTED -- its windows are copied into the pinned arena when the
-   * flush runs, all of a flush's windows together by the library's copy threads, instead of window by window on the
+   * buys: a small batch (coalesced, below) is only NOTED -- its windows are copied into the pinned arena by the
+   * library's copy threads at some point between this call and the flush (every few MB of noted windows are handed to
+   * the threads that are idle; the flush waits for them and copies the rest), instead of window by window on the
    * calling thread inside tgx_update (one core moves ~27 GB/s: the cap of a stream of 8192-row batches).  A consumer of
    * DataFusion's `execute_stream()` holds the RecordBatches (Arc'd buffers) until it syncs.  Batches that are not
    * coalesced are read before tgx_update returns, as TGX_MEM_HOST ones are.  All HOST columns of a batch should be
