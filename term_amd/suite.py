@@ -595,6 +595,12 @@ def _arrow_flat(table):
             slot.null_count = nulls
             if nulls and bufs[0] is not None:
                 slot.validity = bufs[0].address
+            if bufs[1] is None:  # (an array without rows may come without buffers)
+                if len(arr):
+                    col = long_way(arr)
+                    keep.append(col)
+                    C.memmove(C.byref(slot), C.byref(col.c), C.sizeof(_Column))
+                continue
             if how[0] == "fixed":
                 slot.values = bufs[1].address
             else:
