@@ -62,6 +62,9 @@ def suite():
     b = b.check(one("upper_first", lambda k: k.validates_regex("text", r"^\p{Lu}", 0.0)))
     b = b.check(one("code_fmt", lambda k: k.validates_regex("code", r"^[A-C]{2}$", 0.0)))
     b = b.check(one("len_text", lambda k: k.has_length_between("text", 2, 12)))
+    # tuples: a tuple is a value of its own, NULL components included (what GROUP BY makes of the same columns)
+    b = b.check(one("uniq_pair", lambda k: k.validates_uniqueness(["grp", "code"], 0.0)))
+    b = b.check(one("uniq_triple", lambda k: k.validates_uniqueness(["qty", "price", "text"], 0.0)))
     for c in ("text_view", "text_large"):  # the same values in the other two string layouts: the same metrics
         b = b.check(one("dist_" + c, lambda k, c=c: k.validates_distinctness([c], any_)))
         b = b.check(one("at_sign_" + c, lambda k, c=c: k.validates_regex(c, r"^[^@]+@[^@]+\.[a-z]+$", 0.0)))
@@ -109,6 +112,9 @@ def expected(t):
     ok = pc.and_(pc.greater_equal(lens, 2), pc.less_equal(lens, 12))
     m["len_text.length_between"] = (pc.sum(ok).as_py() + ok.null_count) / n
     m["size.size"] = float(n)
+    plain = t.set_column(t.schema.get_field_index("code"), "code", t["code"].cast(pa.string()))
+    m["uniq_pair.full_uniqueness"] = plain.group_by(["grp", "code"]).aggregate([]).num_rows / n
+    m["uniq_triple.full_uniqueness"] = plain.group_by(["qty", "price", "text"]).aggregate([]).num_rows / n
     for c in ("text_view", "text_large"):
         m["dist_%s.distinctness" % c] = m["dist_text.distinctness"]
         m["at_sign_%s.regex" % c] = m["at_sign.regex"]
