@@ -7,7 +7,7 @@ cp $g/${t}_bench_1gpu.json $p/${t}_bench_1gpu.json
 cp $g/${t}_bench_all.txt $p/${t}_bench_all.txt
 (cat $g/${t}_gpu_tests.txt; echo; echo "# tools/sim_bench_ranks.py"; cat $g/${t}_sim_ranks.txt) > $p/${t}_gpu_tests_and_sim_ranks.txt
 cp $g/${t}_kernel_stats.csv $p/${t}_kernel_stats_1Brows_16cols.csv
-head -1 $g/${t}_prof_bench.txt > $p/${t}_kernel_stats_1Brows_16cols.benchline.json
+grep "^{" $g/prof_${t}.log | tail -1 > $p/${t}_kernel_stats_1Brows_16cols.benchline.json
 cp $g/${t}_C2_kernel_stats.csv $p/${t}_kernel_stats_C2_100Mrows_8cols.csv
 cp $g/${t}_C4_kernel_stats.csv $p/${t}_kernel_stats_C4_1Brows_16cols.csv
 cp $g/${t}_C5_kernel_stats.csv $p/${t}_kernel_stats_C5_250Mrows_64cols.csv
