@@ -396,10 +396,16 @@ class CorrelationAnalyzer : public Analyzer {  // advanced/correlation.rs
 struct Handles {
   tgx_plan *plan = nullptr;
   tgx_state *state = nullptr;
-  ~Handles() {
+  Handles() = default;
+  Handles(const Handles &) = delete;
+  Handles &operator=(const Handles &) = delete;
+  void reset() {
     if (state) tgx_state_destroy(state);
     if (plan) tgx_plan_destroy(plan);
+    state = nullptr;
+    plan = nullptr;
   }
+  ~Handles() { reset(); }
 };
 
 }  // namespace
@@ -444,6 +450,7 @@ AnalyzerContext AnalysisRunner::run(const Context &ctx) const {
     return -1;
   };
   struct Planned {
+    std::vector<SpecRequest> reqs;
     std::vector<size_t> spec_index;
     std::vector<int> column_types;
     std::optional<std::string> error;
@@ -464,13 +471,7 @@ AnalyzerContext AnalysisRunner::run(const Context &ctx) const {
           p.error = AnalyzerError::query("Schema error: No field named " + *c + ".").text;
       }
       if (p.error) break;
-      size_t found = requests.size();
-      for (size_t i = 0; i < requests.size(); i++)
-        if (requests[i].kind == r.kind && requests[i].column == r.column && requests[i].column2 == r.column2 &&
-            requests[i].flags == r.flags)
-          found = i;
-      if (found == requests.size()) requests.push_back(r);
-      p.spec_index.push_back(found);
+      p.reqs.push_back(r);
     }
     for (const std::string &c : analyzers_[a]->columns()) {
       int ci = column_index(c);
@@ -481,30 +482,95 @@ AnalyzerContext AnalysisRunner::run(const Context &ctx) const {
       p.column_types.push_back(type);
     }
   }
-  // one pass over the table for every analyzer
+  // one pass over the table for every analyzer that is still in the run: their requests fused and de-duplicated
   std::vector<tgx_check_spec> specs;
-  for (const SpecRequest &r : requests) {
-    tgx_check_spec s;
-    memset(&s, 0, sizeof(s));
-    s.kind = r.kind;
-    s.column = column_index(r.column);
-    s.column2 = r.column2.empty() ? -1 : column_index(r.column2);
-    s.flags = r.flags;
-    specs.push_back(s);
-  }
+  auto fuse = [&]() {
+    requests.clear();
+    specs.clear();
+    for (Planned &p : planned) {
+      p.spec_index.clear();
+      if (p.error) continue;
+      for (const SpecRequest &r : p.reqs) {
+        size_t found = requests.size();
+        for (size_t i = 0; i < requests.size(); i++)
+          if (requests[i].kind == r.kind && requests[i].column == r.column && requests[i].column2 == r.column2 &&
+              requests[i].flags == r.flags)
+            found = i;
+        if (found == requests.size()) requests.push_back(r);
+        p.spec_index.push_back(found);
+      }
+    }
+    for (const SpecRequest &r : requests) {
+      tgx_check_spec s;
+      memset(&s, 0, sizeof(s));
+      s.kind = r.kind;
+      s.column = column_index(r.column);
+      s.column2 = r.column2.empty() ? -1 : column_index(r.column2);
+      s.flags = r.flags;
+      specs.push_back(s);
+    }
+  };
   Handles h;
-  std::vector<tgx_result> results(specs.size());
+  std::vector<tgx_result> results;
   std::optional<std::string> run_error;
-  if (!specs.empty()) {
+  auto pass = [&](Handles &hh, size_t max_rows, tgx_status *status) -> std::optional<std::string> {
     tgx_error err;
     memset(&err, 0, sizeof(err));
     tgx_status s = tgx_init(nullptr, &err);
-    if (s == TGX_OK) s = tgx_plan_create(specs.data(), specs.size(), &h.plan, &err);
-    if (s == TGX_OK) s = tgx_state_create(h.plan, nullptr, &h.state, &err);
-    for (size_t b = 0; s == TGX_OK && b < table->batches.size(); b++)
-      s = tgx_update(h.plan, h.state, table->batches[b].columns.data(), table->batches[b].columns.size(), &err);
-    if (s == TGX_OK) s = tgx_finalize(h.plan, h.state, results.data(), results.size(), &err);
-    if (s != TGX_OK) run_error = AnalyzerError::query(std::string(tgx_status_name(s)) + ": " + err.msg).text;
+    if (s == TGX_OK) s = tgx_plan_create(specs.data(), specs.size(), &hh.plan, &err);
+    if (s == TGX_OK) s = tgx_state_create(hh.plan, nullptr, &hh.state, &err);
+    std::vector<tgx_column> cut;
+    for (size_t b = 0; s == TGX_OK && b < table->batches.size(); b++) {
+      const std::vector<tgx_column> &cols = table->batches[b].columns;
+      if (max_rows == SIZE_MAX) {
+        s = tgx_update(hh.plan, hh.state, cols.data(), cols.size(), &err);
+      } else {  // (a probe: the first rows of the first batch)
+        cut = cols;
+        for (tgx_column &c : cut) c.length = std::min<int64_t>(c.length, (int64_t)max_rows);
+        s = tgx_update(hh.plan, hh.state, cut.data(), cut.size(), &err);
+        break;
+      }
+    }
+    if (s == TGX_OK) {
+      results.assign(specs.size(), tgx_result());
+      s = tgx_finalize(hh.plan, hh.state, results.data(), results.size(), &err);
+    }
+    *status = s;
+    if (s != TGX_OK) return AnalyzerError::query(std::string(tgx_status_name(s)) + ": " + err.msg).text;
+    return std::nullopt;
+  };
+  fuse();
+  if (!specs.empty()) {
+    tgx_status status = TGX_OK;
+    run_error = pass(h, SIZE_MAX, &status);
+    if (run_error && (status == TGX_UNSUPPORTED || status == TGX_INVALID_ARGUMENT)) {
+      // one analyzer the library refuses (a column type outside the path) keeps the refusal as ITS error -- the
+      // reference runs every analyzer as a query of its own (runner.rs:141-201) -- and the others run again as one pass:
+      // every analyzer's requests are tried alone on the table's first row (term_guard.cpp, ValidationSuite::run)
+      std::vector<std::optional<std::string>> saved;
+      for (const Planned &p : planned) saved.push_back(p.error);
+      size_t refused = 0;
+      for (size_t k = 0; k < planned.size(); k++) {
+        if (saved[k]) continue;
+        for (size_t j = 0; j < planned.size(); j++)
+          if (j != k && !planned[j].error) planned[j].error = std::string();  // (not part of this probe)
+        fuse();
+        Handles probe;
+        tgx_status ps = TGX_OK;
+        const std::optional<std::string> pe = specs.empty() ? std::nullopt : pass(probe, 1, &ps);
+        for (size_t j = 0; j < planned.size(); j++) planned[j].error = saved[j];
+        if (pe && (ps == TGX_UNSUPPORTED || ps == TGX_INVALID_ARGUMENT)) {
+          planned[k].error = saved[k] = pe;
+          refused++;
+        }
+      }
+      fuse();
+      if (refused) {
+        h.reset();
+        run_error.reset();
+        if (!specs.empty()) run_error = pass(h, SIZE_MAX, &status);
+      }
+    }
   }
   for (size_t a = 0; a < analyzers_.size(); a++) {
     const Analyzer &an = *analyzers_[a];

@@ -156,3 +156,20 @@ def test_incremental_runner_partitions_equal_the_whole_table(tmp_path):
         assert sa["count"] == sb["count"]
         for k in ("mean", "std_dev", "sample_variance"):
             assert abs(sa[k] - sb[k]) <= 1e-9 * abs(sb[k]), k
+
+
+def test_an_analyzer_the_library_refuses_does_not_cost_the_others_their_metrics():
+    """In the reference every analyzer is a query of its own (runner.rs:141-201): one that fails is recorded, the others
+    run.  Here all analyzers share ONE pass, and a request the library refuses (MIN of a Boolean column: COUNT and
+    DISTINCT checks only) used to fail that pass for everybody.  Now the refused analyzer keeps the refusal as its error
+    and the rest run again as one pass."""
+    n = 20_000
+    tbl = pa.table({"id": pa.array(range(n), pa.int64()),
+                    "flag": pa.array([i % 3 == 0 for i in range(n)], pa.bool_()),
+                    "value": pa.array([float(i % 100) for i in range(n)], pa.float64())})
+    ctx = (S.AnalysisRunner().add(S.SizeAnalyzer()).add(S.MinAnalyzer("flag")).add(S.MeanAnalyzer("value"))
+           .add(S.CompletenessAnalyzer("flag")).add(S.DistinctnessAnalyzer("id")).run(tbl))
+    assert [e["analyzer_name"] for e in ctx.errors()] == ["min"] and "TGX_UNSUPPORTED" in ctx.errors()[0]["error"]
+    assert ctx.get_metric("size")["value"] == n and ctx.get_metric("mean.value")["value"] == 49.5
+    assert ctx.get_metric("completeness.flag")["value"] == 1.0 and ctx.get_metric("distinctness.id")["value"] == 1.0
+    assert ctx.get_metric("min.flag") is None

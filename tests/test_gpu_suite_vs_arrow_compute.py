@@ -63,8 +63,11 @@ def suite():
     b = b.check(one("code_fmt", lambda k: k.validates_regex("code", r"^[A-C]{2}$", 0.0)))
     b = b.check(one("len_text", lambda k: k.has_length_between("text", 2, 12)))
     # tuples: a tuple is a value of its own, NULL components included (what GROUP BY makes of the same columns)
-    b = b.check(one("uniq_pair", lambda k: k.validates_uniqueness(["grp", "code"], 0.0)))
+    b = b.check(one("uniq_pair", lambda k: k.validates_uniqueness(["grp", "text_large"], 0.0)))
     b = b.check(one("uniq_triple", lambda k: k.validates_uniqueness(["qty", "price", "text"], 0.0)))
+    # ... and one binding the library refuses (a dictionary column inside a tuple): it keeps the refusal as its error,
+    # every other constraint of the suite is evaluated all the same
+    b = b.check(one("refused", lambda k: k.validates_uniqueness(["grp", "code"], 0.0)))
     for c in ("text_view", "text_large"):  # the same values in the other two string layouts: the same metrics
         b = b.check(one("dist_" + c, lambda k, c=c: k.validates_distinctness([c], any_)))
         b = b.check(one("at_sign_" + c, lambda k, c=c: k.validates_regex(c, r"^[^@]+@[^@]+\.[a-z]+$", 0.0)))
@@ -113,7 +116,7 @@ def expected(t):
     m["len_text.length_between"] = (pc.sum(ok).as_py() + ok.null_count) / n
     m["size.size"] = float(n)
     plain = t.set_column(t.schema.get_field_index("code"), "code", t["code"].cast(pa.string()))
-    m["uniq_pair.full_uniqueness"] = plain.group_by(["grp", "code"]).aggregate([]).num_rows / n
+    m["uniq_pair.full_uniqueness"] = plain.group_by(["grp", "text_large"]).aggregate([]).num_rows / n
     m["uniq_triple.full_uniqueness"] = plain.group_by(["qty", "price", "text"]).aggregate([]).num_rows / n
     for c in ("text_view", "text_large"):
         m["dist_%s.distinctness" % c] = m["dist_text.distinctness"]
@@ -139,5 +142,7 @@ def test_suite_metrics_against_arrow_compute(batch_rows):
     for k, v in want.items():
         assert got[k] == pytest.approx(v, rel=1e-9, abs=1e-9 if k.startswith("corr") else 1e-12), k
     # (the LENGTH constraint wants every row inside the bounds: it is the one that fails, with the ratio above as its metric)
-    assert out.report.metrics.failed_checks == 1 and [i.check_name for i in out.report.issues] == ["len_text"]
-    assert out.report.metrics.total_checks == len(want)
+    issues = {i.check_name: i.message for i in out.report.issues}
+    assert out.report.metrics.failed_checks == 2 and sorted(issues) == ["len_text", "refused"]
+    assert issues["refused"].startswith("Error evaluating constraint:") and "TGX_UNSUPPORTED" in issues["refused"]
+    assert out.report.metrics.total_checks == len(want) + 1 and "refused.full_uniqueness" not in got
