@@ -133,6 +133,17 @@ tgx_status tuple_desc_of(const std::vector<const tgx_column *> &cols, bool mult,
       tc.kind = 3;
       tc.values = c.values;
       tc.buffers = c.variadic;
+    } else if (c.type == TGX_DICT32_UTF8 && c.dictionary &&
+               (c.dictionary->type == TGX_UTF8 || c.dictionary->type == TGX_LARGE_UTF8)) {
+      // the component is the row's dictionary ENTRY (its string, or NULL): the same tuple as over the decoded column
+      const tgx_column &dc = *c.dictionary;
+      tc.kind = 4;
+      tc.dict_large = dc.type == TGX_LARGE_UTF8 ? 1 : 0;
+      tc.values = c.values;
+      tc.offsets = dc.offsets;
+      tc.data = dc.data;
+      tc.dict_validity = dc.validity;
+      tc.dict_offset = dc.offset;
     } else {
       return fail(err, TGX_UNSUPPORTED, "DISTINCT over a tuple: column type %d is not supported", c.type);
     }

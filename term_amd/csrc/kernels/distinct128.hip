@@ -650,9 +650,24 @@ __device__ __forceinline__ void tuple_fingerprint(const TupleDesc &d, int64_t i,
       ca = (uint64_t)((global_i64_ptr)(uintptr_t)col.values)[slot];
       cb = 1;
     } else {
-      int64_t b, e;
+      int64_t b = 0, e = 0;
       uintptr_t base = (uintptr_t)col.data;
-      if (col.kind == 3) {
+      bool null_entry = false;
+      if (col.kind == 4) {  // the row's dictionary entry: the component is the entry's string (or NULL), not the index
+        const int64_t ds = col.dict_offset + (int64_t)((global_i32_ptr)(uintptr_t)col.values)[slot];
+        global_u8_ptr dbits = (global_u8_ptr)(uintptr_t)col.dict_validity;
+        if (dbits && !((dbits[ds >> 3] >> (ds & 7)) & 1)) {
+          null_entry = true;
+        } else if (col.dict_large) {
+          global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
+          b = off[ds];
+          e = off[ds + 1];
+        } else {
+          global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
+          b = off[ds];
+          e = off[ds + 1];
+        }
+      } else if (col.kind == 3) {
         global_i32_ptr vw = (global_i32_ptr)((uintptr_t)col.values + (uintptr_t)slot * 16);
         const int32_t len = vw[0];
         b = 0;
@@ -672,8 +687,14 @@ __device__ __forceinline__ void tuple_fingerprint(const TupleDesc &d, int64_t i,
         b = off[slot];
         e = off[slot + 1];
       }
-      fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &ca, &cb);
-      cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
+      if (null_entry) {
+        all_valid = false;
+        ca = 0x4e554c4c4e554c4cULL;
+        cb = 0;
+      } else {
+        fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &ca, &cb);
+        cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
+      }
     }
     fa = rotl64(fa ^ mix64w(ca + 0x165667b19e3779f9ULL * (uint64_t)(c + 1)), 27) * 0x9fb21c651e98df25ULL + cb;
     fb = rotl64(fb ^ mix64w(cb ^ rotl64(ca, 32) ^ 0x27d4eb2f165667c5ULL), 31) * 0xd6e8feb86659fd93ULL + ca;

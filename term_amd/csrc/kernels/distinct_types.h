@@ -137,14 +137,16 @@ enum {
 
 // one component of a tuple key (distinct_tuple_kernel)
 struct TupleCol {
-  int32_t kind;  // 0 Int64 / Float64 (bit pattern), 1 Utf8, 2 LargeUtf8, 3 Utf8View
-  int32_t pad;
-  const void *values;             // numeric values / Utf8View views
-  const void *offsets;            // Utf8 / LargeUtf8
-  const uint8_t *data;
+  int32_t kind;  // 0 Int64 / Float64 (bit pattern), 1 Utf8, 2 LargeUtf8, 3 Utf8View, 4 Dictionary<Int32, Utf8 | LargeUtf8>
+  int32_t dict_large;             // kind 4: the dictionary's offsets are 64-bit
+  const void *values;             // numeric values / Utf8View views / dictionary indices
+  const void *offsets;            // Utf8 / LargeUtf8 (kind 4: the dictionary's)
+  const uint8_t *data;            // (kind 4: the dictionary's)
   const uint8_t *const *buffers;  // Utf8View
   const uint8_t *validity;
   int64_t offset;
+  const uint8_t *dict_validity;   // kind 4: a NULL entry makes the component NULL
+  int64_t dict_offset;            // kind 4: the dictionary's own Arrow offset
 };
 constexpr int kMaxTupleCols = 8;
 struct TupleDesc {

@@ -233,7 +233,7 @@ class Case:
             self.add(spec(T.COMOMENTS, numeric_cols[0], column2=numeric_cols[1]), ("comoments", numeric_cols[0], numeric_cols[1]))
         if len(numeric_cols) >= 2 and n <= 300_000 and rng.random() < 0.25:
             self.add(spec(T.SPEARMAN, numeric_cols[0], column2=numeric_cols[1]), ("spearman", numeric_cols[0], numeric_cols[1]))
-        # (tuples take Int64 / Float64 / Utf8 / LargeUtf8 components: a dictionary or view column is TGX_UNSUPPORTED there)
+        # (plain layouts here; tuples over Utf8View / dictionary columns are drawn further down, from a stream of their own)
         key_cols = [ci for ci, c in enumerate(self.cols) if c[0] in ("i", "f") or (c[0] == "s" and c[4][2] == "plain")]
         if len(key_cols) >= 2 and n <= 400_000 and rng.random() < 0.3:  # (the check counts tuples in a Python dict)
             mult = bool(rng.integers(0, 2))
@@ -243,6 +243,19 @@ class Case:
         for ci, (kind, vals, vb, mask, extra) in enumerate(self.cols):
             if kind in ("f", "i") and rng.random() < 0.15:
                 self.add(spec(T.KLL, ci, kll_k=int(rng.choice([200, 2048]))), ("kll", ci))
+        # (round 5, from a stream of its own -- earlier seeds keep their cases: tuples whose components are Utf8View or
+        #  dictionary columns: the component is the row's string whatever the layout)
+        rng6 = np.random.default_rng([seed, 6])
+        laid_out = [ci for ci, c in enumerate(self.cols) if c[0] == "s" and c[4][2] != "plain"]
+        if laid_out and len(self.cols) >= 2 and n <= 400_000 and not any(e[0] == "tuple" for e in self.expect) and rng6.random() < 0.35:
+            first = laid_out[int(rng6.integers(0, len(laid_out)))]
+            others = [ci for ci in range(len(self.cols)) if ci != first]
+            rng6.shuffle(others)
+            cols6 = [first] + others[:int(rng6.integers(1, min(3, len(others)) + 1))]
+            rng6.shuffle(cols6)
+            mult = bool(rng6.integers(0, 2))
+            self.add(spec(T.DISTINCT, cols6[0], columns=cols6, flags=T.FLAG_MULTIPLICITY if mult else 0), ("tuple", tuple(cols6), mult))
+            self.expect[-1] = ("tuple", tuple(self.tuple_columns()), mult)
         # thresholds that steer small batches into the big-batch paths (read per call / per state by the library)
         self.env = {}
         if rng.random() < 0.3:
