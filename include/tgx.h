@@ -198,7 +198,9 @@ typedef struct tgx_check_spec {
   /* DISTINCT over a tuple of 2..8 columns -- COUNT(DISTINCT (a, b)), GROUP BY a, b
    * (TG/constraints/uniqueness.rs:557-562, 687-699, 709-715): `columns` lists them (then `column` is ignored).
    * A tuple is a value of its own: NULL components take part like any other value (SQL struct / GROUP BY
-   * semantics), Float64 components compare by bit pattern.  Result: total = rows, non_null = rows whose every
+   * semantics), Float64 components compare by bit pattern, a string component is the row's string whatever the
+   * layout (Utf8 / LargeUtf8 / Utf8View / Dictionary<Int32, Utf8>: a NULL dictionary entry is a NULL component).
+   * Result: total = rows, non_null = rows whose every
    * component is non-NULL (the primary-key NULL check), distinct = tuples, groups_once with MULTIPLICITY.
    * n_columns == 0 or 1: the single-column check on `column`. */
   const int32_t *columns;
