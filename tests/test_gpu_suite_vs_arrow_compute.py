@@ -164,3 +164,17 @@ def test_a_constraint_the_library_refuses_does_not_cost_the_others_their_verdict
     (issue,) = out.report.issues
     assert issue.constraint_name == "min" and issue.message.startswith("Error evaluating constraint:") and "TGX_UNSUPPORTED" in issue.message
     assert m.custom_metrics["c.full_uniqueness"] == 1.0 and m.custom_metrics["c.mean"] == 49.5
+
+
+def test_tuples_over_boolean_narrow_and_unsigned_columns_against_group_by():
+    n = 100_000
+    rng = np.random.default_rng(5)
+    t = pa.table({"g": pa.array(rng.integers(0, 50, n)), "flag": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1),
+                  "u8": pa.array(rng.integers(0, 7, n).astype(np.uint8)), "u64": pa.array(rng.integers(0, 5, n).astype(np.uint64))})
+    c = Check.builder("c").level(Level.ERROR).validates_uniqueness(["g", "flag"], 0.0).build()
+    d = Check.builder("d").level(Level.ERROR).validates_uniqueness(["u8", "u64", "flag"], 0.0).build()
+    out = ValidationSuite.builder("s").check(c).check(d).build().run(pa.Table.from_batches(t.to_batches(max_chunksize=8192)))
+    m = out.report.metrics.custom_metrics
+    assert not out.report.issues
+    assert m["c.full_uniqueness"] == t.group_by(["g", "flag"]).aggregate([]).num_rows / n
+    assert m["d.full_uniqueness"] == t.group_by(["u8", "u64", "flag"]).aggregate([]).num_rows / n
