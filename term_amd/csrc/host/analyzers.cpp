@@ -525,6 +525,9 @@ AnalyzerContext AnalysisRunner::run(const Context &ctx) const {
       if (max_rows == SIZE_MAX) {
         s = tgx_update(hh.plan, hh.state, cols.data(), cols.size(), &err);
       } else {  // (a probe: the first rows of the first batch)
+        int64_t rows = 0;
+        for (const tgx_column &c : cols) rows = std::max(rows, c.length);
+        if (rows == 0 && b + 1 < table->batches.size()) continue;  // (an empty record batch says nothing)
         cut = cols;
         for (tgx_column &c : cut) c.length = std::min<int64_t>(c.length, (int64_t)max_rows);
         s = tgx_update(hh.plan, hh.state, cut.data(), cut.size(), &err);
