@@ -658,9 +658,11 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
   // a HOST stream is flushed in pieces of a few tens of MB: the upload of one piece then runs beside the noting and
   // copying of the next (with 4 Mi-row flushes an 8 Mi-row table was two flushes: nothing overlapped; a piece of 32 MB
   // is 0.6 ms of PCIe time, against ~0.1 ms of launches per flush)
-  // (the first piece of a stream is a short one: nothing is on the link until it goes)
+  // (a stream's first pieces are short ones -- 8, 16 MB, then the full size: nothing is on the link until the first
+  //  goes, and a stream of a few tens of MB should not end with most of itself still to upload)
   if (any_host && co.flush_rows == 0 &&
-      co.arena_used >= (co.host_flushes == 0 ? std::min(coalesce_flush_host_bytes(), (size_t)8 << 20) : coalesce_flush_host_bytes()))
+      co.arena_used >= (co.host_flushes < 2 ? std::min(coalesce_flush_host_bytes(), (size_t)8 << (20 + co.host_flushes))
+                                            : coalesce_flush_host_bytes()))
     return coalesce_flush(st, err);
   return TGX_OK;
 }
