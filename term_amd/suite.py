@@ -575,50 +575,52 @@ def _arrow_flat(table):
             lean.append(("string", first.c.type))
         else:
             lean.append(None)
-    at = 0
-    for rb in batches:
-        for ci in range(n_cols):
-            arr = rb.column(ci)
-            how = lean[ci]
-            slot = col_arr[at]
-            at += 1
-            if how is None:
-                col = long_way(arr)
-                keep.append(col)
-                C.memmove(C.byref(slot), C.byref(col.c), C.sizeof(_Column))
-                continue
-            bufs = arr.buffers()
-            slot.type = how[1]
-            slot.length = len(arr)
-            slot.offset = arr.offset
-            nulls = arr.null_count
-            slot.null_count = nulls
-            if nulls and bufs[0] is not None:
-                slot.validity = bufs[0].address
-            if bufs[1] is None:  # (an array without rows may come without buffers)
-                if len(arr):
+    import struct
+
+    fmt = struct.Struct("<iiqqqQQQQQQQii")  # tgx_column, field by field (its size is checked below)
+    assert fmt.size == C.sizeof(_Column)
+    pack, size = fmt.pack_into, fmt.size
+    # the columns' chunks are the record batches' columns when every column is cut alike (a table made of record
+    # batches is): reading them column by column spares a RecordBatch.column() call per (batch, column), 1 us each
+    chunked = [table.column(ci).chunks for ci in range(n_cols)]
+    if not all(len(ch) == n_batches and all(len(a) == len(rb) for a, rb in zip(ch, batches)) for ch in chunked):
+        chunked = [[rb.column(ci) for rb in batches] for ci in range(n_cols)]
+    slow = []  # the slots filled the long way: marked as retained afterwards (the packed ones already are)
+    for ci in range(n_cols):
+        how = lean[ci]
+        at = ci
+        for arr in chunked[ci]:
+            slot_at = at
+            at += n_cols
+            bufs = None if how is None else arr.buffers()
+            if how is None or bufs[1] is None:  # (an array without rows may come without buffers)
+                if how is None or len(arr):
                     col = long_way(arr)
                     keep.append(col)
-                    C.memmove(C.byref(slot), C.byref(col.c), C.sizeof(_Column))
+                    C.memmove(C.byref(col_arr[slot_at]), C.byref(col.c), C.sizeof(_Column))
+                else:
+                    col_arr[slot_at].type = how[1]
+                slow.append(slot_at)
                 continue
+            nulls = arr.null_count
+            validity = bufs[0].address if (nulls and bufs[0] is not None) else 0
             if how[0] == "fixed":
-                slot.values = bufs[1].address
+                pack(col_arr, slot_at * size, how[1], MEM_HOST_RETAINED, len(arr), arr.offset, nulls, validity, bufs[1].address, 0, 0, 0, 0, 0, 0, 0)
             else:
-                slot.offsets = bufs[1].address
-                if bufs[2] is not None:
-                    slot.data = bufs[2].address
+                pack(col_arr, slot_at * size, how[1], MEM_HOST_RETAINED, len(arr), arr.offset, nulls, validity, 0, bufs[1].address,
+                     bufs[2].address if bufs[2] is not None else 0, 0, 0, 0, 0, 0)
     name_arr = (C.c_char_p * max(1, n_cols))(*[n.encode() for n in names])
-    keep.append(_mark_retained(col_arr, n_cols * n_batches))
+    keep.append(_mark_retained(col_arr, slow))
     return name_arr, n_cols, col_arr, n_batches, keep
 
 
-def _mark_retained(col_arr, n):
+def _mark_retained(col_arr, which):
     """The host calls run the whole table and return: every buffer handed over is alive and unmodified until then, which
     is all TGX_MEM_HOST_RETAINED asks for -- a table that arrives as 8192-row record batches is then copied by the
     library's copy threads beside the noting of the next batches instead of inside every tgx_update.  (The structs in
     `col_arr` are copies: the caller's Column objects are not touched; a dictionary's struct is copied too.)"""
     dict_copies = []
-    for i in range(n):
+    for i in (range(which) if isinstance(which, int) else which):
         if col_arr[i].mem != MEM_HOST:
             continue
         if col_arr[i].dictionary:
