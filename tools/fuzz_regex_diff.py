@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Three-way differential fuzzer for the pattern engines, on the CPU: random VALID patterns from a grammar inside what
+Rust's regex and RE2 agree on (no \\d \\w \\s \\b over non-ASCII subjects, no look-around / back-references, Unicode
+classes and (?i) only over characters as old as Unicode 6) against random subjects, decided by
+  * the product's compiler + automaton (term_amd/csrc/regex, through tgx_regex_is_match),
+  * the oracle's backtracking-free VM (oracle/regex_oracle.c, through orc.Regex),
+  * RE2 (pyarrow.compute.match_substring_regex) -- an engine neither of the two shares a line with.
+Any disagreement is printed with the pattern and the subject.
+
+    python tools/fuzz_regex_diff.py [--seconds 60] [--seed 1] [--ascii]"""
+import argparse
+import ctypes as C
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+LITERALS_ASCII = list("abcxyzABZ019@.-_ /:")
+LITERALS_UNI = ["é", "ß", "ω", "Ω", "д", "Д", "日", "本", "ﬁ", "ı", "İ", "K", "ſ"]
+CLASSES_ASCII = ["[a-c]", "[^a-c]", "[0-9]", "[A-Za-z]", "[^@]", "[a-cx-z]", "[[:alpha:]]", "[[:digit:]]", "[^[:space:]]", ".", r"\.", r"\-"]
+CLASSES_PERL = [r"\d", r"\w", r"\s", r"\D", r"\W", r"\S"]           # ASCII subjects only
+CLASSES_UNI = [r"\p{L}", r"\p{Lu}", r"\p{Ll}", r"\p{N}", r"\PL", r"\p{Greek}", r"\p{Cyrillic}", r"\p{Han}", "[α-ω]", "[а-я]", "[^\\x00-\\x7F]"]
+QUANTS = ["", "", "", "", "*", "+", "?", "{2}", "{1,3}", "{0,2}", "{2,}", "*?", "+?", "??"]
+
+
+def atom(rng, ascii_only, depth):
+    r = rng.random()
+    if r < 0.45:
+        pool = LITERALS_ASCII if (ascii_only or rng.random() < 0.7) else LITERALS_UNI
+        c = rng.choice(pool)
+        return "\\" + c if c in ".-/" and rng.random() < 0.5 and c != "/" else ("\\." if c == "." else c)
+    if r < 0.75:
+        pool = list(CLASSES_ASCII)
+        if ascii_only:
+            pool += CLASSES_PERL
+        else:
+            pool += CLASSES_UNI
+        return rng.choice(pool)
+    if depth >= 2:
+        return rng.choice(LITERALS_ASCII[:9])
+    inner = alternation(rng, ascii_only, depth + 1)
+    return ("(?:%s)" if rng.random() < 0.6 else "(%s)") % inner
+
+
+def concat(rng, ascii_only, depth):
+    return "".join(atom(rng, ascii_only, depth) + rng.choice(QUANTS) for _ in range(rng.randint(1, 3 if depth else 4)))
+
+
+def alternation(rng, ascii_only, depth):
+    return "|".join(concat(rng, ascii_only, depth) for _ in range(1 if rng.random() < 0.7 else rng.randint(2, 3)))
+
+
+def pattern(rng, ascii_only):
+    p = alternation(rng, ascii_only, 0)
+    if rng.random() < 0.4:
+        p = "^" + p if "|" not in p else "^(?:" + p + ")"
+    if rng.random() < 0.4:
+        p = p + "$" if "|" not in p else "(?:" + p + ")$"
+    if rng.random() < 0.15:
+        p = "(?i)" + p
+    if rng.random() < 0.05:
+        p = "(?s)" + p
+    return p
+
+
+def subject(rng, ascii_only):
+    pool = LITERALS_ASCII + (["\t", "\n"] if rng.random() < 0.2 else []) + ([] if ascii_only else LITERALS_UNI + ["Ж", "漢", "😀"])
+    return "".join(rng.choice(pool) for _ in range(rng.randint(0, 10)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ascii", action="store_true", help="ASCII subjects, Perl classes in the grammar")
+    ap.add_argument("--subjects", type=int, default=40)
+    args = ap.parse_args()
+    import pyarrow as pa
+    import pyarrow.compute as pc
+
+    import oracle_binding as orc
+    import term_amd as T
+
+    rng = random.Random(args.seed)
+    t0 = time.time()
+    n_pat = n_cmp = bad = skipped = too_big = 0
+    while time.time() - t0 < args.seconds:
+        ascii_only = args.ascii or rng.random() < 0.5
+        pat = pattern(rng, ascii_only)
+        subs = [subject(rng, ascii_only) for _ in range(args.subjects)]
+        try:
+            want = pc.match_substring_regex(pa.array(subs, pa.large_string()), pat).to_pylist()
+        except Exception:  # (RE2 refuses it: outside the common subset after all)
+            skipped += 1
+            continue
+        pb = pat.encode()
+        err = T._lib._Error()
+        if T.lib().tgx_regex_validate(pb, len(pb), 0, C.byref(err)) != 0:
+            msg = err.msg.decode(errors="replace")
+            if "DFA states" in msg:  # (too big for the device's table: TGX_UNSUPPORTED, the caller's fall-back -- not a verdict)
+                too_big += 1
+                continue
+            print("PRODUCT REFUSES %r: %s" % (pat, msg))
+            bad += 1
+            continue
+        try:
+            rx = orc.Regex(pat)
+        except ValueError as e:
+            print("ORACLE REFUSES %r: %s" % (pat, e))
+            bad += 1
+            continue
+        n_pat += 1
+        for s, w in zip(subs, want):
+            sb = s.encode()
+            m = C.c_int32()
+            rc = T.lib().tgx_regex_is_match(pb, len(pb), 0, sb, len(sb), C.byref(m), C.byref(err))
+            got_p = None if rc != 0 else bool(m.value)
+            got_o = rx.is_match(s)
+            n_cmp += 1
+            if got_p != w or got_o != w:
+                bad += 1
+                print("DISAGREE pattern %r subject %r: product %s oracle %s RE2 %s" % (pat, s, got_p, got_o, w))
+    print("%d patterns, %d comparisons, %d disagreements, %d patterns RE2 refused, %d too big for the device table, %.0f s"
+          % (n_pat, n_cmp, bad, skipped, too_big, time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
