@@ -64,11 +64,15 @@ def pattern(rng, ascii_only):
         p = "(?i)" + p
     if rng.random() < 0.05:
         p = "(?s)" + p
+    if ascii_only and rng.random() < 0.15:  # word boundaries: Rust's are Unicode-aware, RE2's ASCII -- the same over ASCII subjects
+        p = rng.choice([r"\b", r"\B"]) + p if rng.random() < 0.5 else p + rng.choice([r"\b", r"\B"])
+    if rng.random() < 0.08:
+        p = "(?m)" + p  # ^ and $ at line feeds too
     return p
 
 
 def subject(rng, ascii_only):
-    pool = LITERALS_ASCII + (["\t", "\n"] if rng.random() < 0.2 else []) + ([] if ascii_only else LITERALS_UNI + ["Ж", "漢", "😀"])
+    pool = LITERALS_ASCII + (["\t", "\n", "\n"] if rng.random() < 0.3 else []) + ([] if ascii_only else LITERALS_UNI + ["Ж", "漢", "😀"])
     return "".join(rng.choice(pool) for _ in range(rng.randint(0, 10)))
 
 
