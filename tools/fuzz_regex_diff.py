@@ -128,6 +128,20 @@ def main():
             if got_p != w or got_o != w:
                 bad += 1
                 print("DISAGREE pattern %r subject %r: product %s oracle %s RE2 %s" % (pat, s, got_p, got_o, w))
+        # the case-insensitive FLAG (`~*`, FormatOptions::case_sensitive(false)) is the pattern under (?i)
+        if not pat.startswith("(?"):
+            want_ci = pc.match_substring_regex(pa.array(subs, pa.large_string()), "(?i)" + pat).to_pylist()
+            rx_ci = orc.Regex(pat, case_insensitive=True)
+            for s, w in zip(subs, want_ci):
+                sb = s.encode()
+                m = C.c_int32()
+                rc = T.lib().tgx_regex_is_match(pb, len(pb), T.FLAG_CASE_INSENSITIVE, sb, len(sb), C.byref(m), C.byref(err))
+                got_p = None if rc != 0 else bool(m.value)
+                got_o = rx_ci.is_match(s)
+                n_cmp += 1
+                if got_p != w or got_o != w:
+                    bad += 1
+                    print("DISAGREE (flag: case-insensitive) pattern %r subject %r: product %s oracle %s RE2 %s" % (pat, s, got_p, got_o, w))
     print("%d patterns, %d comparisons, %d disagreements, %d patterns RE2 refused, %d too big for the device table, %.0f s"
           % (n_pat, n_cmp, bad, skipped, too_big, time.time() - t0))
     return 1 if bad else 0
