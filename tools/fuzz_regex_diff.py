@@ -128,6 +128,17 @@ def main():
             if got_p != w or got_o != w:
                 bad += 1
                 print("DISAGREE pattern %r subject %r: product %s oracle %s RE2 %s" % (pat, s, got_p, got_o, w))
+        # FormatOptions::trim_before_check: the pattern sees TRIM(value) -- SQL TRIM takes the blanks (0x20) off both ends
+        want_trim = pc.match_substring_regex(pa.array([s.strip(" ") for s in subs], pa.large_string()), pat).to_pylist()
+        for s, w in zip(subs, want_trim):
+            sb = s.encode()
+            m = C.c_int32()
+            rc = T.lib().tgx_regex_is_match(pb, len(pb), T.FLAG_TRIM, sb, len(sb), C.byref(m), C.byref(err))
+            got_p = None if rc != 0 else bool(m.value)
+            n_cmp += 1
+            if got_p != w:
+                bad += 1
+                print("DISAGREE (flag: trim) pattern %r subject %r: product %s RE2 on the trimmed value %s" % (pat, s, got_p, w))
         # the case-insensitive FLAG (`~*`, FormatOptions::case_sensitive(false)) is the pattern under (?i)
         if not pat.startswith("(?"):
             want_ci = pc.match_substring_regex(pa.array(subs, pa.large_string()), "(?i)" + pat).to_pylist()
