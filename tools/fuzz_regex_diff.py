@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ascii", action="store_true", help="ASCII subjects, Perl classes in the grammar")
     ap.add_argument("--subjects", type=int, default=40)
+    ap.add_argument("--groups", type=float, default=0.0, help="after the single patterns: this fraction of --seconds on product automata of 2 - 4 patterns")
     args = ap.parse_args()
     import pyarrow as pa
     import pyarrow.compute as pc
@@ -153,6 +154,39 @@ def main():
                 if got_p != w or got_o != w:
                     bad += 1
                     print("DISAGREE (flag: case-insensitive) pattern %r subject %r: product %s oracle %s RE2 %s" % (pat, s, got_p, got_o, w))
+    # ---- the PRODUCT automaton of 2 - 4 patterns (what several pattern checks of one column share on the device): the
+    # mask it gives a value against RE2 pattern by pattern
+    L = T.lib()
+    L.tgx_regex_match_group.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_size_t,
+                                        C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p]
+    t1 = time.time()
+    n_groups = n_grouped = 0
+    while args.groups and time.time() - t1 < args.seconds * args.groups:
+        ascii_only = args.ascii or rng.random() < 0.5
+        k = rng.randint(2, 4)
+        pats = [pattern(rng, ascii_only) for _ in range(k)]
+        err = T._lib._Error()
+        if any(L.tgx_regex_validate(p.encode(), len(p.encode()), 0, C.byref(err)) != 0 for p in pats):
+            continue
+        subs = [subject(rng, ascii_only) for _ in range(args.subjects)]
+        want = [pc.match_substring_regex(pa.array(subs, pa.large_string()), p).to_pylist() for p in pats]
+        enc = [p.encode() for p in pats]
+        arr = (C.c_char_p * k)(*enc)
+        lens = (C.c_size_t * k)(*[len(e) for e in enc])
+        fl = (C.c_uint32 * k)(*([0] * k))
+        n_groups += 1
+        for si, s in enumerate(subs):
+            sb = s.encode()
+            mask, grouped = C.c_uint32(), C.c_int32()
+            rc = L.tgx_regex_match_group(arr, lens, fl, k, sb, len(sb), C.byref(mask), C.byref(grouped), C.byref(err))
+            n_grouped += 1 if (rc == 0 and grouped.value and si == 0) else 0
+            wmask = sum((1 << j) for j in range(k) if want[j][si])
+            n_cmp += 1
+            if rc != 0 or mask.value != wmask:
+                bad += 1
+                print("DISAGREE (product automaton) patterns %r subject %r: mask %s (rc %d) RE2 %s" % (pats, s, bin(mask.value), rc, bin(wmask)))
+    if args.groups:
+        print("%d groups of 2 - 4 patterns (%d walked as ONE automaton)" % (n_groups, n_grouped))
     print("%d patterns, %d comparisons, %d disagreements, %d patterns RE2 refused, %d too big for the device table, %.0f s"
           % (n_pat, n_cmp, bad, skipped, too_big, time.time() - t0))
     return 1 if bad else 0
