@@ -37,21 +37,33 @@ static json::Value jobj(std::vector<std::pair<std::string, json::Value>> kv) {
   x.obj = std::move(kv);
   return x;
 }
+static json::Value jcount(uint64_t v) { return json::Value::of_u64(v); }  // a `u64` field of a reference state struct
+// An f64 field: the shortest text that reads back to the same double, and always with a fraction or an exponent so the
+// token is a float to every reader (serde_json prints 30.0, 1e16, 0.1 the same way).
 static std::string num_text(double v) {
   if (isnan(v) || isinf(v)) return "null";  // serde_json writes non-finite f64 as null
   char buf[40];
   if (v == floor(v) && fabs(v) < 9.0e15) {
     snprintf(buf, sizeof(buf), "%.1f", v);
-  } else {
-    snprintf(buf, sizeof(buf), "%.17g", v);
+    return buf;
   }
+  for (int prec = 15; prec <= 17; prec++) {
+    snprintf(buf, sizeof(buf), "%.*g", prec, v);
+    if (strtod(buf, nullptr) == v) break;
+  }
+  if (!strpbrk(buf, ".eE")) strcat(buf, ".0");
   return buf;
+}
+static std::string value_text(const json::Value &v) {
+  if (v.int_kind == json::Value::Unsigned) return std::to_string((unsigned long long)v.u);
+  if (v.int_kind == json::Value::Signed) return std::to_string((long long)v.i);
+  return num_text(v.num);
 }
 std::string json_dump(const json::Value &v) {
   switch (v.type) {
     case json::Value::Null: return "null";
     case json::Value::Bool: return v.b ? "true" : "false";
-    case json::Value::Number: return num_text(v.num);
+    case json::Value::Number: return value_text(v);
     case json::Value::String: return json::quote(v.str);
     case json::Value::Array: {
       std::string o = "[";
@@ -68,7 +80,7 @@ std::string json_dump(const json::Value &v) {
   return "null";
 }
 static double f(const json::Value &s, const char *k) { return s.get_num(k, 0.0); }
-static uint64_t u(const json::Value &s, const char *k) { return (uint64_t)s.get_num(k, 0.0); }
+static uint64_t u(const json::Value &s, const char *k) { return s.get_u64(k, 0); }
 static std::optional<double> opt(const json::Value &s, const char *k) {
   const json::Value *v = s.get(k);
   if (!v || v->type != json::Value::Number) return std::nullopt;
@@ -118,12 +130,12 @@ class SizeAnalyzer : public Analyzer {  // basic/size.rs
   std::string name() const override { return "size"; }
   std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_COUNT, "")}; }  // COUNT(*): any column
   json::Value state_from_results(const std::vector<const tgx_result *> &r, const std::vector<int> &) const override {
-    return jobj({{"count", jnum((double)r[0]->total)}});
+    return jobj({{"count", jcount(r[0]->total)}});
   }
   json::Value merge_states(const std::vector<json::Value> &states) const override {  // size.rs:60-63
     uint64_t c = 0;
     for (auto &s : states) c += u(s, "count");
-    return jobj({{"count", jnum((double)c)}});
+    return jobj({{"count", jcount(c)}});
   }
   MetricValue metric_from_state(const json::Value &s) const override { return MetricValue::of_long((int64_t)u(s, "count")); }
 };
@@ -144,7 +156,7 @@ class CompletenessAnalyzer : public ColumnAnalyzer {  // basic/completeness.rs
   std::string name() const override { return "completeness"; }
   std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_COUNT, column_)}; }
   json::Value state_from_results(const std::vector<const tgx_result *> &r, const std::vector<int> &) const override {
-    return jobj({{"total_count", jnum((double)r[0]->total)}, {"non_null_count", jnum((double)r[0]->non_null)}});
+    return jobj({{"total_count", jcount(r[0]->total)}, {"non_null_count", jcount(r[0]->non_null)}});
   }
   json::Value merge_states(const std::vector<json::Value> &states) const override {  // :76-84
     uint64_t t = 0, n = 0;
@@ -152,7 +164,7 @@ class CompletenessAnalyzer : public ColumnAnalyzer {  // basic/completeness.rs
       t += u(s, "total_count");
       n += u(s, "non_null_count");
     }
-    return jobj({{"total_count", jnum((double)t)}, {"non_null_count", jnum((double)n)}});
+    return jobj({{"total_count", jcount(t)}, {"non_null_count", jcount(n)}});
   }
   MetricValue metric_from_state(const json::Value &s) const override {  // :62-68: empty dataset is complete
     const uint64_t t = u(s, "total_count");
@@ -167,7 +179,7 @@ class DistinctnessAnalyzer : public ColumnAnalyzer {  // basic/distinctness.rs
   std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_DISTINCT, column_)}; }
   json::Value state_from_results(const std::vector<const tgx_result *> &r, const std::vector<int> &) const override {
     // COUNT(col) is the denominator, not COUNT(*) (:113-116)
-    return jobj({{"total_count", jnum((double)r[0]->non_null)}, {"distinct_count", jnum((double)r[0]->distinct)}});
+    return jobj({{"total_count", jcount(r[0]->non_null)}, {"distinct_count", jcount(r[0]->distinct)}});
   }
   json::Value merge_states(const std::vector<json::Value> &states) const override {  // :77-92: clamped sum, an upper bound
     uint64_t t = 0, d = 0;
@@ -175,7 +187,7 @@ class DistinctnessAnalyzer : public ColumnAnalyzer {  // basic/distinctness.rs
       t += u(s, "total_count");
       d += u(s, "distinct_count");
     }
-    return jobj({{"total_count", jnum((double)t)}, {"distinct_count", jnum((double)std::min(d, t))}});
+    return jobj({{"total_count", jcount(t)}, {"distinct_count", jcount(std::min(d, t))}});
   }
   MetricValue metric_from_state(const json::Value &s) const override {  // :35-41
     const uint64_t t = u(s, "total_count");
@@ -193,7 +205,7 @@ class ApproxCountDistinctAnalyzer : public ColumnAnalyzer {
   std::string name() const override { return "approx_count_distinct"; }
   std::vector<SpecRequest> plan() const override { return {req(TGX_CHECK_APPROX_DISTINCT, column_)}; }
   json::Value state_from_results(const std::vector<const tgx_result *> &r, const std::vector<int> &) const override {
-    return jobj({{"approx_distinct_count", jnum((double)r[0]->distinct)}, {"total_count", jnum((double)r[0]->non_null)}});
+    return jobj({{"approx_distinct_count", jcount(r[0]->distinct)}, {"total_count", jcount(r[0]->non_null)}});
   }
   json::Value merge_states(const std::vector<json::Value> &states) const override {  // :45-61: max of the counts
     uint64_t d = 0, t = 0;
@@ -201,7 +213,7 @@ class ApproxCountDistinctAnalyzer : public ColumnAnalyzer {
       d = std::max(d, u(s, "approx_distinct_count"));
       t += u(s, "total_count");
     }
-    return jobj({{"approx_distinct_count", jnum((double)d)}, {"total_count", jnum((double)t)}});
+    return jobj({{"approx_distinct_count", jcount(d)}, {"total_count", jcount(t)}});
   }
   MetricValue metric_from_state(const json::Value &s) const override {  // :126-128
     return MetricValue::of_long((int64_t)u(s, "approx_distinct_count"));
@@ -220,7 +232,7 @@ class MeanAnalyzer : public ColumnAnalyzer {  // basic/mean.rs
     // the sum is read as Float64Array only (:117-126): an Int64 column's SUM is Int64 -> InvalidData, unless the
     // sum is NULL (no non-null value), which reads as 0.0
     if (r[0]->non_null > 0 && !r[0]->is_float) throw AnalyzerError::invalid_data("Expected Float64 array for sum");
-    return jobj({{"sum", jnum(r[0]->non_null > 0 ? r[0]->sum_f : 0.0)}, {"count", jnum((double)r[0]->non_null)}});
+    return jobj({{"sum", jnum(r[0]->non_null > 0 ? r[0]->sum_f : 0.0)}, {"count", jcount(r[0]->non_null)}});
   }
   json::Value merge_states(const std::vector<json::Value> &states) const override {
     double sum = 0;
@@ -229,7 +241,7 @@ class MeanAnalyzer : public ColumnAnalyzer {  // basic/mean.rs
       sum += f(s, "sum");
       c += u(s, "count");
     }
-    return jobj({{"sum", jnum(sum)}, {"count", jnum((double)c)}});
+    return jobj({{"sum", jnum(sum)}, {"count", jcount(c)}});
   }
   MetricValue metric_from_state(const json::Value &s) const override {  // :147-152
     const uint64_t c = u(s, "count");
@@ -338,7 +350,7 @@ class StandardDeviationAnalyzer : public ColumnAnalyzer {  // advanced/standard_
 
  private:
   static json::Value state(uint64_t c, double sum, double sq, double mean) {
-    return jobj({{"count", jnum((double)c)}, {"sum", jnum(sum)}, {"sum_squared", jnum(sq)}, {"mean", jnum(mean)}});
+    return jobj({{"count", jcount(c)}, {"sum", jnum(sum)}, {"sum_squared", jnum(sq)}, {"mean", jnum(mean)}});
   }
 };
 
@@ -385,7 +397,7 @@ class CorrelationAnalyzer : public Analyzer {  // advanced/correlation.rs
 
  private:
   json::Value state(uint64_t n, double sx, double sy, double sx2, double sy2, double sxy) const {
-    return jobj({{"n", jnum((double)n)}, {"sum_x", jnum(sx)}, {"sum_y", jnum(sy)}, {"sum_x2", jnum(sx2)},
+    return jobj({{"n", jcount(n)}, {"sum_x", jnum(sx)}, {"sum_y", jnum(sy)}, {"sum_x2", jnum(sx2)},
                  {"sum_y2", jnum(sy2)}, {"sum_xy", jnum(sxy)}, {"x_ranks", jnull()}, {"y_ranks", jnull()},
                  {"correlation_type", jstr(t_ == Pearson ? "Pearson" : t_ == Spearman ? "Spearman" : "Covariance")}});
   }

@@ -129,23 +129,23 @@ extern "C" tgx_status tgx_host_constraint_verdict_json(const char *constraint_js
       const json::Value &o = rv.arr[i];
       tgx_result &r = results[i];
       memset(&r, 0, sizeof(r));
-      r.is_float = (int32_t)o.get_num("is_float");
-      r.total = (int64_t)o.get_num("total");
-      r.non_null = (int64_t)o.get_num("non_null");
-      r.has_value = (int32_t)o.get_num("has_value");
-      r.has_variance = (int32_t)o.get_num("has_variance");
-      r.min_i = (int64_t)o.get_num("min_i");
-      r.max_i = (int64_t)o.get_num("max_i");
+      r.is_float = (int32_t)o.get_i64("is_float");
+      r.total = o.get_i64("total");
+      r.non_null = o.get_i64("non_null");
+      r.has_value = (int32_t)o.get_i64("has_value");
+      r.has_variance = (int32_t)o.get_i64("has_variance");
+      r.min_i = o.get_i64("min_i");
+      r.max_i = o.get_i64("max_i");
       r.min_f = o.get_num("min_f");
       r.max_f = o.get_num("max_f");
-      r.sum_i = (int64_t)o.get_num("sum_i");
+      r.sum_i = o.get_i64("sum_i");
       r.sum_f = o.get_num("sum_f");
       r.mean = o.get_num("mean");
       r.var_samp = o.get_num("var_samp");
       r.stddev_samp = o.get_num("stddev_samp");
-      r.distinct = (int64_t)o.get_num("distinct");
-      r.groups_once = (int64_t)o.get_num("groups_once");
-      r.matches = (int64_t)o.get_num("matches");
+      r.distinct = o.get_i64("distinct");
+      r.groups_once = o.get_i64("groups_once");
+      r.matches = o.get_i64("matches");
       r.sum_x = o.get_num("sum_x");
       r.sum_y = o.get_num("sum_y");
       r.sum_x2 = o.get_num("sum_x2");
@@ -165,7 +165,7 @@ extern "C" tgx_status tgx_host_constraint_verdict_json(const char *constraint_js
         r.co_m2_y = std::max(0.0, r.sum_y2 - r.sum_y * r.sum_y / n);
         r.co_c_xy = r.sum_xy - r.sum_x * r.sum_y / n;
       }
-      r.kll_n = (uint64_t)o.get_num("kll_n");
+      r.kll_n = o.get_u64("kll_n");
       if (const json::Value *q = o.get("quantiles"))
         for (auto &kv : q->obj) fq.per_request[i].emplace_back(atof(kv.first.c_str()), kv.second.num);
     }

@@ -1,6 +1,8 @@
 // json.h -- a small JSON value + parser + writer for the suite bridge (no external dependency).
 #pragma once
+#include <errno.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -16,6 +18,12 @@ struct Value {
   enum Type { Null, Bool, Number, String, Array, Object } type = Null;
   bool b = false;
   double num = 0;
+  // A Number whose token was an integer keeps it exactly: serde_json reads a `u64` / `i64` field only from an integer
+  // token (TG/analyzers/incremental/runner.rs:86,98), and a count above 2^53 does not fit a double.  `num` always holds
+  // the nearest double as well, so readers of f64 fields need not care.
+  enum IntKind { NotInt, Signed, Unsigned } int_kind = NotInt;
+  int64_t i = 0;    // int_kind == Signed (negative values)
+  uint64_t u = 0;   // int_kind == Unsigned (every non-negative integer token)
   std::string str;
   std::vector<Value> arr;
   std::vector<std::pair<std::string, Value>> obj;  // insertion ordered
@@ -34,6 +42,47 @@ struct Value {
   double get_num(const std::string &key, double dflt = 0) const {
     const Value *v = get(key);
     return v && v->type == Number ? v->num : dflt;
+  }
+  // an integer field: exact from an integer token; a float token (a state written by an older build or by a Python
+  // float) is accepted when it is integral and in range
+  uint64_t as_u64() const {
+    if (type != Number) return 0;
+    if (int_kind == Unsigned) return u;
+    if (int_kind == Signed) return i < 0 ? 0 : (uint64_t)i;
+    if (!(num >= 0)) return 0;
+    return num >= 18446744073709551615.0 ? UINT64_MAX : (uint64_t)num;
+  }
+  int64_t as_i64() const {
+    if (type != Number) return 0;
+    if (int_kind == Signed) return i;
+    if (int_kind == Unsigned) return u > (uint64_t)INT64_MAX ? INT64_MAX : (int64_t)u;
+    if (num != num) return 0;
+    return num >= 9223372036854775807.0 ? INT64_MAX : num <= -9223372036854775808.0 ? INT64_MIN : (int64_t)num;
+  }
+  uint64_t get_u64(const std::string &key, uint64_t dflt = 0) const {
+    const Value *v = get(key);
+    return v && v->type == Number ? v->as_u64() : dflt;
+  }
+  int64_t get_i64(const std::string &key, int64_t dflt = 0) const {
+    const Value *v = get(key);
+    return v && v->type == Number ? v->as_i64() : dflt;
+  }
+  static Value of_u64(uint64_t x) {
+    Value v;
+    v.type = Number;
+    v.int_kind = Unsigned;
+    v.u = x;
+    v.num = (double)x;
+    return v;
+  }
+  static Value of_i64(int64_t x) {
+    if (x >= 0) return of_u64((uint64_t)x);
+    Value v;
+    v.type = Number;
+    v.int_kind = Signed;
+    v.i = x;
+    v.num = (double)x;
+    return v;
   }
   bool get_bool(const std::string &key, bool dflt = false) const {
     const Value *v = get(key);
@@ -220,9 +269,33 @@ struct Parser {
     std::string tmp(p, (size_t)std::min<ptrdiff_t>(e - p, 64));
     double d = strtod(tmp.c_str(), &end);
     if (end == tmp.c_str()) return fail("unexpected token");
-    p += end - tmp.c_str();
+    const size_t len = (size_t)(end - tmp.c_str());
+    p += len;
     v->type = Value::Number;
     v->num = d;
+    // an integer token (no fraction, no exponent) that fits 64 bits is kept exactly
+    bool integral = true;
+    for (size_t k = 0; k < len; k++) {
+      const char ch = tmp[k];
+      if (!((ch >= '0' && ch <= '9') || (k == 0 && ch == '-'))) integral = false;
+    }
+    if (integral && len > (tmp[0] == '-' ? 1u : 0u)) {
+      errno = 0;
+      if (tmp[0] == '-') {
+        const long long sv = strtoll(tmp.c_str(), nullptr, 10);
+        if (errno == 0) {
+          if (sv == 0) {
+            *v = Value::of_u64(0);
+            v->num = d;  // "-0" stays -0.0 for an f64 reader
+          } else {
+            *v = Value::of_i64((int64_t)sv);
+          }
+        }
+      } else {
+        const unsigned long long uv = strtoull(tmp.c_str(), nullptr, 10);
+        if (errno == 0) *v = Value::of_u64((uint64_t)uv);
+      }
+    }
     return true;
   }
 };

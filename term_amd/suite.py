@@ -677,6 +677,14 @@ class _Analyzer:
                                                        C.byref(out), C.byref(err)), err)
         return json.loads(_take(out))
 
+    def merge_states_text(self, states):
+        """merge_states, but the bytes the library wrote (what serde_json would be handed)"""
+        out = C.c_char_p()
+        err = _Error()
+        _host_check(_host().tgx_host_merge_states_json(json.dumps(self.spec).encode(), json.dumps(states).encode(),
+                                                       C.byref(out), C.byref(err)), err)
+        return _take(out)
+
     def compute_metric_from_state(self, state):
         """-> MetricValue as {"type": "Double"|"Long"|"Map", "value": ...}; raises TgxError with the
         reference's AnalyzerError text (e.g. 'No data available for analysis')"""
@@ -707,6 +715,7 @@ class AnalyzerContext:
 
     def __init__(self, text):
         d = json.loads(text)
+        self.text = text  # as written by the library (integer / float token kinds matter to serde_json readers)
         self.metrics, self.states, self._errors = d["metrics"], d["states"], d["errors"]
 
     def get_metric(self, key):
