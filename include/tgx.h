@@ -299,7 +299,9 @@ size_t tgx_plan_num_specs(const tgx_plan *plan);
  * waits on, or a synchronisation); the library's own stream does not wait for the legacy default stream. */
 tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, tgx_state **out, tgx_error *err);
 void tgx_state_destroy(tgx_state *state);
-/* How many of the batches handed to tgx_update so far are only NOTED (coalesced, not yet run): the LAST `*batches` ones.
+/* How many of the batches handed to tgx_update so far are only NOTED (coalesced, not yet run): the LAST `*batches`
+ * NON-EMPTY ones -- a batch of zero rows is never noted (tgx_update returns at once for it) and is not counted, so a
+ * caller that keeps a window of retained batches must leave empty batches out of that window.
  * A caller that feeds TGX_MEM_HOST_RETAINED (or DEVICE) buffers of a long stream may release every batch before those
  * -- the library flushes by itself every few tens of MB -- instead of holding the whole table until tgx_finalize.
  * (DEVICE batches a sampled-range key set retains for a repair are the exception stated at tgx_update.)  Makes no

@@ -439,6 +439,12 @@ impl GpuPlanner {
             *self.shared.output.write().unwrap() = None;
             return Ok(());
         }
+        // `held` is declared BEFORE the state on purpose: locals drop in reverse order, so on every exit of this
+        // function (an error from the stream, a refused column, the future being cancelled at an `.await`) the state
+        // is destroyed first -- tgx_state_destroy waits for the library's copy threads -- and only then are the
+        // retained RecordBatches released.  The other order frees Arrow buffers the copy threads may still be reading.
+        let mut held: std::collections::VecDeque<(datafusion::arrow::record_batch::RecordBatch, Vec<Option<ColumnView>>)> =
+            std::collections::VecDeque::new();
         let plan = Plan::new(&specs).map_err(internal)?;
         let mut state = State::new(&plan).map_err(internal)?;
         let used: Vec<bool> = (0..names.len() as i32)
@@ -454,11 +460,15 @@ impl GpuPlanner {
         //    the ones the library has only NOTED (`State::pending`: the last few hundred at most -- it flushes every few
         //    tens of MB) costs nothing, and their copy into pinned memory then happens at the flush, on the library's
         //    copy threads, instead of window by window inside `update` on this thread.
-        let mut held: std::collections::VecDeque<(datafusion::arrow::record_batch::RecordBatch, Vec<Option<ColumnView>>)> =
-            std::collections::VecDeque::new();
         let mut stream = df.execute_stream().await?;
         while let Some(batch) = stream.next().await {
             let batch = batch?;
+            // DataFusion streams interleave empty batches (filters, repartitions).  tgx_update returns early for them
+            // and notes nothing, so they must not enter `held` either: `held` mirrors the library's NOTED batches one
+            // to one, and an extra entry would push the oldest still-pending batch out of the window below.
+            if batch.num_rows() == 0 {
+                continue;
+            }
             let mut views: Vec<Option<ColumnView>> = Vec::with_capacity(names.len());
             for (i, col) in batch.columns().iter().enumerate() {
                 views.push(if !used[i] {

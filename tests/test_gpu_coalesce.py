@@ -642,3 +642,52 @@ def test_kept_host_streams_of_several_threads_share_the_copy_threads():
         assert (r[3].non_null, r[3].min_f, r[3].max_f) == (sf.non_null, sf.min_f, sf.max_f)
         assert rel_err(r[3].sum_f, sf.sum_f) <= 1e-9 and rel_err(r[3].var_samp, sf.var_samp) <= 1e-9
         assert r[4].non_null == sf.non_null
+
+
+@pytest.mark.parametrize("flush_rows", [None, "20000"])
+def test_retained_window_with_empty_batches_interleaved(flush_rows, monkeypatch):
+    """The shim's protocol (shim/src/planner.rs): every non-empty batch is handed over as
+    TGX_MEM_HOST_RETAINED and kept in a window of `tgx_state_pending` batches; what falls out of the window is FREED
+    (here: overwritten with garbage).  Empty RecordBatches between them are never noted by the library, are not counted
+    by tgx_state_pending, and so must stay out of the window -- counting them would release the oldest batch the
+    library still has to copy.  Results equal the one-batch run."""
+    rng = np.random.default_rng(31)
+    n = 120_000
+    ids = rng.permutation(n).astype(np.int64)
+    f = rng.standard_normal(n)
+    mask = rng.random(n) >= 0.05
+    T.init()
+    plan = T.Plan([spec(T.COUNT, 0), spec(T.NUMERIC_STATS, 0), spec(T.DISTINCT, 0), spec(T.NUMERIC_STATS, 1, flags=T.FLAG_VARIANCE)])
+    monkeypatch.setenv("TGX_COALESCE", "0")
+    whole = T.State(plan)
+    monkeypatch.delenv("TGX_COALESCE")
+    whole.update([numeric_column(ids, orc.pack_validity(mask), False), numeric_column(f, None, False)])
+    want = whole.finalize()
+    if flush_rows:
+        monkeypatch.setenv("TGX_COALESCE_FLUSH_ROWS", flush_rows)
+    st = T.State(plan)
+    if flush_rows:
+        monkeypatch.delenv("TGX_COALESCE_FLUSH_ROWS")
+    held = []  # (arrays of the batch, its columns): what the shim keeps alive
+    cuts = ragged_cuts(n, rng, sizes=(8192, 8192, 1000, 3, 8192, 1, 5000))
+    noted = 0
+    for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        for _ in range(k % 3):  # zero, one or two empty batches before each real one
+            before = st.pending()
+            st.update([numeric_column(ids, None, False, offset=a, length=0), numeric_column(f, None, False, offset=a, length=0)])
+            assert st.pending() == before  # an empty batch is not noted and not counted
+        own_ids, own_f = ids[a:b].copy(), f[a:b].copy()
+        own_val = pad_validity(orc.pack_validity(mask[a:b]))
+        cols = [_retained(T.Column.int64(own_ids, own_val, length=b - a)), _retained(T.Column.float64(own_f, None, length=b - a))]
+        st.update(cols)
+        held.append((own_ids, own_f, own_val, cols))
+        noted += 1
+        pending, _rows = st.pending()
+        assert pending <= len(held)
+        while len(held) > pending:  # released = freed: the library must not look at these again
+            o_ids, o_f, o_val, _ = held.pop(0)
+            o_ids[:] = -7
+            o_f[:] = np.nan
+            o_val[:] = 0
+    compare(st.finalize(), want)
+    assert st.pending() == (0, 0)
