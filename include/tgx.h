@@ -42,7 +42,9 @@ extern "C" {
 /* 4: tgx_result grew the centred co-moments (co_*) at its end; state blobs are version 2 */
 /* 5: tgx_type grew Int8 .. UInt64 / Boolean, tgx_memspace TGX_MEM_HOST_RETAINED; tgx_trim, tgx_cache_stats_get,
  *    tgx_state_pending (no struct changed its layout) */
-#define TGX_ABI_VERSION 5
+/* 6: keyed fingerprints (tgx_plan_set_fingerprint_key / _get_, tgx_blob_fingerprint_key), TGX_FLAG_EXACT_KEYS; state
+ *    blobs are version 3 (they carry the key) */
+#define TGX_ABI_VERSION 6
 
 typedef enum tgx_status {
   TGX_OK = 0,
@@ -183,7 +185,16 @@ enum {
   TGX_FLAG_NULL_IS_VALID = 1u << 4,     /* REGEX: `OR col IS NULL` */
   /* SPEARMAN: exact sums instead of the reference's UInt64 arithmetic, whose rank products and sums wrap
    * modulo 2^64 (from about 3.8 M rows on) */
-  TGX_FLAG_EXACT_RANK_SUMS = 1u << 5
+  TGX_FLAG_EXACT_RANK_SUMS = 1u << 5,
+  /* DISTINCT over Utf8 / LargeUtf8 / Utf8View / Dictionary / tuple keys: an EXACT key set.  Without the flag such
+   * keys are counted by their 128-bit KEYED fingerprints (tgx_plan_set_fingerprint_key): two distinct values count as
+   * one only if all 128 bits agree under a key the data's producer does not know.  With it the state keeps the bytes of
+   * every distinct key it has been fed (a device-side key store) and an equal fingerprint is confirmed by comparing
+   * bytes -- `COUNT(DISTINCT c)` as DataFusion computes it (hash + equality, TG/constraints/uniqueness.rs:612-617,
+   * 671-681, 709-715), for every input including one built against the fingerprint function.  What crosses a state
+   * boundary (tgx_merge, state blobs, tgx_distinct_export / tgx_allreduce) travels as keyed fingerprints either way:
+   * bytes never leave the device that was fed them.  Numeric keys are exact regardless of the flag. */
+  TGX_FLAG_EXACT_KEYS = 1u << 6
 };
 
 typedef struct tgx_check_spec {
@@ -291,6 +302,15 @@ tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_specs, tgx_plan
                            tgx_error *err);
 void tgx_plan_destroy(tgx_plan *plan);
 size_t tgx_plan_num_specs(const tgx_plan *plan);
+/* The 128-bit key of the plan's string / tuple fingerprints (kernels/distinct128.hip: Chaskey-8).  tgx_plan_create
+ * draws one from the operating system (getrandom); TGX_FINGERPRINT_KEY=<32 hex digits> fixes it for a process.
+ * States, blobs and ranks can only be united when their fingerprints were made under ONE key: a plan that is to read
+ * another process's blobs (tgx_state_deserialize says which key a blob carries in its error message and through
+ * tgx_blob_fingerprint_key) or to take part in tgx_allreduce (every rank: the ranks compare keys in the facts round,
+ * a mismatch is TGX_INVALID_ARGUMENT) is given the shared key here, BEFORE its first tgx_state_create -- afterwards
+ * the call is refused.  No reference counterpart (DataFusion's hash sets keep the values themselves). */
+tgx_status tgx_plan_set_fingerprint_key(tgx_plan *plan, const uint8_t key[16], tgx_error *err);
+tgx_status tgx_plan_get_fingerprint_key(const tgx_plan *plan, uint8_t key_out[16]);
 
 /* State = `Analyzer::State` for every spec of the plan (TG/analyzers/traits.rs:154-179).
  * `hip_stream` is a hipStream_t (NULL = a stream the library creates).  Everything the state does on the device is
@@ -366,6 +386,10 @@ tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *state, uint8_t *
                                size_t *len, tgx_error *err);
 tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t *buf, size_t len,
                                  tgx_state **out, tgx_error *err);
+/* The fingerprint key a blob was made under (tgx_plan_set_fingerprint_key): `*keyed` = 0 when the blob holds no string /
+ * tuple keys (then any plan of the same shape reads it), else 1 and `key_out` is the key.  tgx_state_deserialize refuses
+ * a keyed blob under a plan with another key (TGX_INVALID_ARGUMENT). */
+tgx_status tgx_blob_fingerprint_key(const uint8_t *buf, size_t len, uint8_t key_out[16], int32_t *keyed);
 
 /* ---- KllSketch accessors (TG/analyzers/advanced/kll_sketch.rs:246-322, 368-399) ------------- */
 tgx_status tgx_kll_quantile(const tgx_plan *plan, tgx_state *state, size_t spec_index, double phi,

@@ -18,6 +18,7 @@ from ._lib import (  # noqa: F401
     abi_symbols,
     cache_stats,
     trim,
+    blob_fingerprint_key,
     COUNT,
     NUMERIC_STATS,
     DISTINCT,
@@ -29,6 +30,7 @@ from ._lib import (  # noqa: F401
     APPROX_DISTINCT,
     OPT_NO_COALESCE,
     FLAG_EXACT_RANK_SUMS,
+    FLAG_EXACT_KEYS,
     FLAG_VARIANCE,
     FLAG_MULTIPLICITY,
     FLAG_TRIM,

@@ -11,7 +11,8 @@ COUNT, NUMERIC_STATS, DISTINCT, REGEX_MATCH, KLL, COMOMENTS, SPEARMAN, LENGTH = 
 APPROX_DISTINCT = 9
 FLAG_VARIANCE, FLAG_MULTIPLICITY, FLAG_TRIM, FLAG_CASE_INSENSITIVE, FLAG_NULL_IS_VALID = 1, 2, 4, 8, 16
 FLAG_EXACT_RANK_SUMS = 32
-ABI_VERSION = 5  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
+FLAG_EXACT_KEYS = 64  # DISTINCT over string / tuple keys: equal fingerprints confirmed byte by byte
+ABI_VERSION = 6  # include/tgx.h TGX_ABI_VERSION: the struct layouts below
 INT64, FLOAT64, UTF8, LARGE_UTF8, DICT32_UTF8, UTF8_VIEW, INT32, FLOAT32 = 1, 2, 3, 4, 5, 6, 7, 8
 INT8, INT16, UINT8, UINT16, UINT32, UINT64, BOOL = 9, 10, 11, 12, 13, 14, 15  # (include/tgx.h: narrow / unsigned / Boolean)
 MEM_HOST, MEM_DEVICE, MEM_HOST_RETAINED = 0, 1, 2
@@ -132,6 +133,9 @@ def lib():
         L.tgx_plan_destroy.restype = None
         L.tgx_plan_num_specs.argtypes = [vp]
         L.tgx_plan_num_specs.restype = sz
+        L.tgx_blob_fingerprint_key.argtypes = [C.c_char_p, sz, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+        L.tgx_plan_set_fingerprint_key.argtypes = [vp, C.c_char_p, E]
+        L.tgx_plan_get_fingerprint_key.argtypes = [vp, C.POINTER(C.c_uint8)]
         L.tgx_state_create.argtypes = [vp, vp, C.POINTER(vp), E]
         L.tgx_state_destroy.argtypes = [vp]
         L.tgx_state_destroy.restype = None
@@ -525,8 +529,19 @@ class Comm:
         return Comm(h, rank, world, keep=cbs)  # the C side keeps the function pointers: keep the thunks alive
 
 
+def blob_fingerprint_key(blob):
+    """the fingerprint key a state blob was made under, or None when it holds no string / tuple keys"""
+    out, keyed = (C.c_uint8 * 16)(), C.c_int32()
+    rc = lib().tgx_blob_fingerprint_key(bytes(blob), len(blob), out, C.byref(keyed))
+    if rc != 0:
+        raise TgxError(rc, "not a tgx state blob of this version")
+    return bytes(out) if keyed.value else None
+
+
 class Plan:
-    def __init__(self, specs):
+    def __init__(self, specs, fingerprint_key=None):
+        """`fingerprint_key`: 16 bytes -- the key of the plan's string / tuple fingerprints (tgx_plan_set_fingerprint_key);
+        None: the one tgx_plan_create drew from the operating system"""
         self._specs = list(specs)
         arr = (CheckSpec * max(1, len(self._specs)))(*self._specs)
         h = C.c_void_p()
@@ -534,6 +549,20 @@ class Plan:
         _check(lib().tgx_plan_create(arr, len(self._specs), C.byref(h), C.byref(err)), err)
         self.h = h
         self.n = len(self._specs)
+        if fingerprint_key is not None:
+            self.set_fingerprint_key(fingerprint_key)
+
+    def set_fingerprint_key(self, key):
+        key = bytes(key)
+        if len(key) != 16:
+            raise ValueError("a fingerprint key is 16 bytes")
+        err = _Error()
+        _check(lib().tgx_plan_set_fingerprint_key(self.h, key, C.byref(err)), err)
+
+    def fingerprint_key(self):
+        out = (C.c_uint8 * 16)()
+        lib().tgx_plan_get_fingerprint_key(self.h, out)
+        return bytes(out)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -672,6 +701,24 @@ class State:
         _check(lib().tgx_distinct_export(self.plan.h, self.h, spec_index, world, C.byref(ptr), counts,
                                          C.byref(err)), err)
         return ptr.value, list(counts)
+
+    def distinct_export_records(self, spec_index):
+        """the key records of a DISTINCT task as a host array of uint64 rows: (key, count) for numeric keys,
+        (fingerprint word a, word b, count, 0) for string / tuple keys (tests: the records are device memory)"""
+        import numpy as np
+        import torch
+
+        ptr, counts = self.distinct_export(spec_index, 1)
+        width = self.distinct_record_bytes(spec_index)
+        total = counts[0]
+        if total == 0:
+            return np.zeros((0, width // 8), np.uint64)
+
+        class P:
+            __cuda_array_interface__ = {"shape": (total * width,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        raw = torch.as_tensor(P(), device="cuda").clone().cpu().numpy()
+        return raw.view(np.uint64).reshape(total, width // 8)
 
     def distinct_range_hint(self, spec_index, lo, hi):
         err = _Error()

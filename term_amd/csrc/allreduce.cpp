@@ -377,6 +377,9 @@ struct Header {
   // enough for what the facts call for, nobody can fail between here and the blob round's header and the step needs
   // no further status round; otherwise all ranks allocate, tell each other how that went, and only then exchange
   uint64_t xchg_cap;
+  // the rank's fingerprint key (tgx_plan_set_fingerprint_key): string / tuple keys travel as fingerprints, which only
+  // mean the same on every rank under ONE key
+  uint64_t fp_key[2];
 };
 constexpr uint64_t kFactsMagic = 0x5447584641435453ull;  // "TGXFACTS"
 
@@ -533,6 +536,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   hd->blob_len = hd->blob_need = 0;
   hd->status = (uint64_t)local;
   hd->xchg_cap = st->device_ready ? std::min(comm->d_send.cap, comm->d_recv.cap) : 0;  // (0: "I will have to allocate")
+  memcpy(hd->fp_key, plan->fp_key.k, 16);
   TaskFacts *tf = (TaskFacts *)(mine.data() + sizeof(Header));
   for (size_t k = 0; k < nd; k++) {
     const DistinctTask &task = plan->distinct[k];
@@ -579,6 +583,18 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
   auto facts_of = [&](int32_t r, size_t k) -> const TaskFacts & {
     return ((const TaskFacts *)(all.data() + (size_t)r * facts_bytes + sizeof(Header)))[k];
   };
+  // string / tuple key sets: one fingerprint key on all ranks (every rank sees the same facts and returns the same)
+  {
+    bool any_wide = false;
+    for (size_t k = 0; k < nd; k++)
+      for (int32_t r = 0; r < W; r++) any_wide |= facts_of(r, k).wide != 0 && facts_of(r, k).rows > 0;
+    if (any_wide)
+      for (int32_t r = 0; r < W; r++)
+        if (memcmp(((const Header *)(all.data() + (size_t)r * facts_bytes))->fp_key, hd->fp_key, 16) != 0)
+          return fail(err, TGX_INVALID_ARGUMENT,
+                      "rank %d holds another fingerprint key than rank %d: string / tuple keys cannot be united -- give "
+                      "every rank's plan one key (tgx_plan_set_fingerprint_key) before its first state", r, R);
+  }
 
   // ---- 2. exact DISTINCT: one exchange of key sets ----------------------------------------------------------------
   struct BitmapPart {

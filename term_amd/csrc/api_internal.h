@@ -47,7 +47,7 @@ constexpr int64_t kCoalesceFlushRows = 4 << 20;      // pending rows that trigge
 constexpr size_t kCoalesceFlushBatches = 4096;       // pending batches that trigger a flush
 constexpr size_t kCoalesceArenaMax = 128u << 20;     // pinned staging per arena turn (HOST batches)
 constexpr uint32_t kWireMagic = 0x53584754;  // "TGXS"
-constexpr uint32_t kWireVersion = 2;  // 2: ComomentAcc carries its pivots
+constexpr uint32_t kWireVersion = 3;  // 2: ComomentAcc carries its pivots; 3: { u32 keyed, u8 key[16] } behind the head
 
 struct Context {
   std::mutex mu;

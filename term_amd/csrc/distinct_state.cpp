@@ -23,7 +23,62 @@ HashSetView hash_view(const DistinctState &ds) {
   v.keys = ds.keys.as<uint64_t>();
   v.dup = ds.dup.as<uint32_t>();
   v.mask = ds.capacity - 1;
+  const bool exact = ds.exact && ds.wide;
+  v.store = exact ? ds.key_store.as<uint64_t>() : nullptr;
+  v.store_cursor = exact ? ds.key_cursor.as<unsigned long long>() : nullptr;
+  v.store_words = exact ? ds.key_store_words : 0;
   return v;
+}
+
+// ---- the key store of an exact set ----
+// A fresh table starts a fresh store: words 0..1 are a stand-in entry (what a key that found no room points at:
+// kCntStoreFull), the cursor starts behind it.
+constexpr uint64_t kKeyStoreMinWords = 1ull << 16;
+tgx_status key_store_init(tgx_state *st, DistinctState &ds, tgx_error *err) {
+  if (ds.key_store_words < kKeyStoreMinWords) {
+    HIP_TRY(ds.key_store.reserve(kKeyStoreMinWords * 8));
+    ds.key_store_words = ds.key_store.cap / 8;
+  }
+  HIP_TRY(ds.key_cursor.reserve(4 * sizeof(unsigned long long)));
+  const unsigned long long head[2] = {0ull, 1ull << 32 /* kKindFpOnly */}, cur[4] = {2, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(ds.key_store.p, head, sizeof(head), hipMemcpyHostToDevice, st->stream));
+  HIP_TRY(hipMemcpyAsync(ds.key_cursor.p, cur, sizeof(cur), hipMemcpyHostToDevice, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));  // (`head` / `cur` are on this stack frame)
+  return TGX_OK;
+}
+// Room for `incoming` more words behind the cursor (`cursor`: its value, just read back).  A bigger block takes the
+// old one's words over; references are word offsets and stay as they are.
+tgx_status key_store_ensure(tgx_state *st, DistinctState &ds, uint64_t cursor, uint64_t incoming, tgx_error *err) {
+  if (cursor + incoming <= ds.key_store_words) return TGX_OK;
+  const uint64_t want = std::max<uint64_t>(2 * ds.key_store_words, cursor + incoming);
+  DevBuf bigger;
+  HIP_TRY(bigger.reserve(want * 8));
+  HIP_TRY(hipMemcpyAsync(bigger.p, ds.key_store.p, cursor * 8, hipMemcpyDeviceToDevice, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  std::swap(ds.key_store.p, bigger.p);
+  std::swap(ds.key_store.cap, bigger.cap);
+  ds.key_store_words = ds.key_store.cap / 8;
+  return TGX_OK;
+}
+// after a measuring pass has added the batch's worst case to key_cursor[1]: read it (and the cursor) and make room
+tgx_status key_store_reserve_measured(tgx_state *st, DistinctState &ds, tgx_error *err) {
+  unsigned long long h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, ds.key_cursor.p, sizeof(h), hipMemcpyDeviceToHost, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  return key_store_ensure(st, ds, h[0], h[1], err);
+}
+tgx_status key_store_measure_begin(tgx_state *st, DistinctState &ds, tgx_error *err) {
+  HIP_TRY(hipMemsetAsync(ds.key_cursor.as<unsigned long long>() + 1, 0, 2 * sizeof(unsigned long long), st->stream));
+  return TGX_OK;
+}
+// room for the keys of a string column batch (every valid row a new key at worst)
+tgx_status key_store_reserve_utf8(tgx_state *st, DistinctState &ds, const tgx_column &c, tgx_error *err) {
+  TGX_TRY(key_store_measure_begin(st, ds, err));
+  const bool view = c.type == TGX_UTF8_VIEW;
+  launch_exact_measure_utf8(c.offsets, c.data, view ? c.values : nullptr, view ? c.variadic : nullptr, c.validity, c.offset,
+                            c.length, c.type == TGX_LARGE_UTF8, nullptr, ds.key_cursor.as<unsigned long long>() + 1,
+                            st->stream);
+  return key_store_reserve_measured(st, ds, err);
 }
 BitmapView bitmap_view(const DistinctState &ds) {
   BitmapView v;
@@ -55,6 +110,7 @@ tgx_status hash_ensure(tgx_state *st, DistinctState &ds, bool mult, uint64_t inc
     ds.capacity = next_pow2(std::max<uint64_t>(2 * want, 1024));
     TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, ds.wide, err));
     ds.rows_upper_bound = 0;
+    if (ds.exact && ds.wide) TGX_TRY(key_store_init(st, ds, err));
   }
   if (2 * (ds.rows_upper_bound + incoming) <= ds.capacity) {
     ds.rows_upper_bound += incoming;
@@ -165,18 +221,25 @@ tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *d
   }
   TupleDesc d;
   TGX_TRY(tuple_desc_of(cols, task.multiplicity, &d, err));
+  d.key = st->plan->fp_key;
   ds.col_type = TGX_UTF8;  // a 128-bit fingerprint set, like a string column's
   ds.total_rows += d.length;
   if (d.length == 0) return TGX_OK;
   if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
   // the first big batch: through the partitioned lists (views read their buffers through a table staged per update)
-  if (ds.mode == DistinctMode::kUndecided && !any_view && fp_lists_fit_rows(d.length))
+  // (an exact set goes through the table, where its keys' bytes are kept: the lists hold fingerprints only)
+  if (ds.mode == DistinctMode::kUndecided && !any_view && !ds.exact && fp_lists_fit_rows(d.length))
     return fp_lists_tuple_update(st, slot, d, cols, err);
   if (ds.mode == DistinctMode::kUndecided) {
     ds.mode = DistinctMode::kHash;
     ds.wide = true;
   }
   TGX_TRY(hash_ensure(st, ds, task.multiplicity, (uint64_t)d.length, err));
+  if (ds.exact) {
+    TGX_TRY(key_store_measure_begin(st, ds, err));
+    launch_exact_measure_tuple(d, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
+    TGX_TRY(key_store_reserve_measured(st, ds, err));
+  }
   ProfScope ps(st, "distinct", 0);
   launch_distinct_tuple(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
   return TGX_OK;
@@ -247,10 +310,11 @@ tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
       HIP_TRY(hipMemcpyAsync(ds.fp_buffers.p, c.variadic, (size_t)c.n_variadic * sizeof(void *), hipMemcpyDeviceToDevice,
                              st->stream));
     kept.variadic = (const uint8_t *const *)ds.fp_buffers.p;
-    launch_fp_partition_views(c.values, kept.variadic, c.validity, c.offset, c.length, l1, counters, st->stream);
+    launch_fp_partition_views(c.values, kept.variadic, c.validity, c.offset, c.length, l1, st->plan->fp_key, counters,
+                              st->stream);
   } else {
     launch_fp_partition_strings(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, l1,
-                                counters, st->stream);
+                                st->plan->fp_key, counters, st->stream);
   }
   launch_fp_partition_lists(l1, l2, counters, st->stream);
   launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), l1.offered, counters, st->stream);
@@ -299,16 +363,17 @@ tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
     ds.total_rows += c.length;
     if (c.length == 0) return TGX_OK;
     if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
-    if (ds.mode == DistinctMode::kUndecided && fp_lists_fit(c)) return fp_lists_update(st, slot, c, err);
+    if (ds.mode == DistinctMode::kUndecided && !ds.exact && fp_lists_fit(c)) return fp_lists_update(st, slot, c, err);
     if (ds.mode == DistinctMode::kUndecided) {
       ds.mode = DistinctMode::kHash;
       ds.wide = true;
     }
     TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)c.length, err));
+    if (ds.exact) TGX_TRY(key_store_reserve_utf8(st, ds, c, err));
     ProfScope ps(st, "distinct", 0);
     const bool view = c.type == TGX_UTF8_VIEW;
     launch_distinct_utf8(c.offsets, c.data, view ? c.values : nullptr, view ? c.variadic : nullptr, c.validity,
-                         c.offset, c.length, c.type == TGX_LARGE_UTF8, mult ? 1 : 0, hash_view(ds),
+                         c.offset, c.length, c.type == TGX_LARGE_UTF8, mult ? 1 : 0, hash_view(ds), st->plan->fp_key,
                          ds.counters.as<unsigned long long>(), st->stream);
     return TGX_OK;
   }
@@ -352,8 +417,14 @@ tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
                         dict.length, mult ? 1 : 0, u_seen, u_twice, ds.dict_scratch.as<uint32_t>(),
                         ds.counters.as<unsigned long long>(), g_ctx.n_cu, st->stream);
     }
+    if (ds.exact) {  // room for the referenced entries
+      TGX_TRY(key_store_measure_begin(st, ds, err));
+      launch_exact_measure_utf8(dict.offsets, dict.data, nullptr, nullptr, dict.validity, dict.offset, dict.length,
+                                dict.type == TGX_LARGE_UTF8, u_seen, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
+      TGX_TRY(key_store_reserve_measured(st, ds, err));
+    }
     launch_dict_insert(dict.offsets, dict.data, dict.validity, dict.offset, dict.length,
-                       dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, u_seen, u_twice, hash_view(ds),
+                       dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, u_seen, u_twice, hash_view(ds), st->plan->fp_key,
                        ds.counters.as<unsigned long long>(), st->stream);
     return TGX_OK;
   }
@@ -825,6 +896,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
         for (const tgx_column &col : ds.retained) cols.push_back(&col);
         TupleDesc d;
         TGX_TRY(tuple_desc_of(cols, mult, &d, err));
+        d.key = st->plan->fp_key;
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)d.length, err));
         launch_distinct_tuple(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
       } else
@@ -846,7 +918,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
         const bool view = col.type == TGX_UTF8_VIEW;
         launch_distinct_utf8(col.offsets, col.data, view ? col.values : nullptr, view ? col.variadic : nullptr,
                              col.validity, col.offset, col.length, col.type == TGX_LARGE_UTF8, mult ? 1 : 0,
-                             hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
+                             hash_view(ds), st->plan->fp_key, ds.counters.as<unsigned long long>(), st->stream);
       }
     } else {
       FpLists l1, l2;
@@ -1027,6 +1099,12 @@ tgx_status tgx::distinct_import_records(tgx_state *st, size_t slot, const void *
   ds.mode = DistinctMode::kHash;
   ds.wide = wide;
   TGX_TRY(hash_ensure(st, ds, mult, n, err));
+  if (ds.exact && wide) {  // incoming keys are entries of two words (they are only their fingerprints)
+    unsigned long long cur = 0;
+    HIP_TRY(hipMemcpyAsync(&cur, ds.key_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st->stream));
+    HIP_TRY(hipStreamSynchronize(st->stream));
+    TGX_TRY(key_store_ensure(st, ds, cur, 2 * n, err));
+  }
   // the EMPTY stand-in's rows arrive through counters[2]; [5] is scratch
   if (wide)
     launch_hash_import128((const KeyRecord128 *)d_recs, n, hash_view(ds), mult ? 1 : 0,

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <deque>
 #include <map>
 #include <memory>
@@ -83,8 +84,13 @@ void launch_bitmap_rebase(const uint32_t *src, uint64_t src_words, long long del
                           hipStream_t stream);
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *views,
                           const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
-                          int64_t length, int large_offsets, int want_mult, const HashSetView &t,
+                          int64_t length, int large_offsets, int want_mult, const HashSetView &t, const FpKey &key,
                           unsigned long long *d_counters, hipStream_t stream);
+void launch_exact_measure_utf8(const void *offsets, const uint8_t *data, const void *views,
+                               const uint8_t *const *buffers, const uint8_t *validity, int64_t offset, int64_t length,
+                               int large_offsets, const uint32_t *dict_seen, unsigned long long *out,
+                               hipStream_t stream);
+void launch_exact_measure_tuple(const TupleDesc &d, unsigned long long *out, hipStream_t stream);
 void launch_gather_segments(const GatherSeg *d_segs, int n_segs, int parts, hipStream_t stream);
 void launch_state_reset(const StateResetArgs &a, hipStream_t stream);
 int tgx_num_cus();  // CUs of the device tgx_init bound (256 before init)
@@ -108,17 +114,17 @@ void launch_dict_usage(const int32_t *indices, const uint8_t *validity, int64_t 
                        hipStream_t stream);
 void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                         int64_t length, int large_offsets, int want_mult, const uint32_t *seen,
-                        const uint32_t *twice, const HashSetView &t, unsigned long long *d_counters,
+                        const uint32_t *twice, const HashSetView &t, const FpKey &key, unsigned long long *d_counters,
                         hipStream_t stream);
 void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
                            hipStream_t stream);
 // big Utf8 batches: fingerprints partitioned into lists, deduplicated list by list in LDS (distinct128.hip, fp_*)
 void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
-                                 int64_t length, int large_offsets, const FpLists &level1,
+                                 int64_t length, int large_offsets, const FpLists &level1, const FpKey &key,
                                  unsigned long long *d_counters, hipStream_t stream);
 void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
-                               int64_t offset, int64_t length, const FpLists &level1, unsigned long long *d_counters,
-                               hipStream_t stream);
+                               int64_t offset, int64_t length, const FpLists &level1, const FpKey &key,
+                               unsigned long long *d_counters, hipStream_t stream);
 void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, unsigned long long *d_counters,
                                 hipStream_t stream);
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
@@ -170,6 +176,9 @@ struct DistinctTask {
   // only APPROX_DISTINCT specs point here: the task runs for the column kinds the HyperLogLog lane does not take
   // (strings, dictionaries) and stays idle on numeric columns
   bool approx_only = false;
+  // TGX_FLAG_EXACT_KEYS on any DISTINCT spec of the task: string / tuple keys are kept with their bytes and equal
+  // fingerprints are confirmed byte by byte (numeric keys are exact either way)
+  bool exact = false;
 };
 // APPROX_DISTINCT: the HyperLogLog lane of the numeric scan (kernels/scan.hip, scan_hll_kernel).  When the plan also
 // holds an exact DISTINCT check of the column -- or the column turns out to be a string column -- the exact key set
@@ -212,6 +221,10 @@ struct tgx_plan {
   std::vector<char> used, reads_values, needs_wide;
   std::vector<char> key_column;  // a single-column DISTINCT check reads it (range tracking of coalesced HOST batches)
   std::vector<char> stats_on;    // a statistic, sketch, correlation or ranking reads it (TGX_UINT64 / TGX_BOOL columns may not)
+  // the key of the string / tuple fingerprints (kernels/distinct128.hip): drawn from the OS at tgx_plan_create, or set
+  // by tgx_plan_set_fingerprint_key before the plan's first state exists
+  tgx::FpKey fp_key;
+  mutable std::atomic<bool> fp_key_locked{false};  // a state has been created: the key may not change any more
   void *regex = nullptr;     // tgx::RegexPlan (regex_device.cpp)
   void *spearman = nullptr;  // tgx::SpearmanPlan (spearman_device.cpp)
 };
@@ -313,6 +326,12 @@ struct DistinctState {
   // hash (wide = 128-bit fingerprint keys of a Utf8 column: two words per slot, 32-byte records)
   bool wide = false;
   DevBuf keys, dup;
+  // EXACT string / tuple key sets (TGX_FLAG_EXACT_KEYS; kernels/distinct128.hip "EXACT key sets"): slots hold (first
+  // fingerprint word, reference) and the keys' bytes live in `key_store` (8-byte words; word offsets stay valid when
+  // the store moves to a bigger block).  key_cursor: [0] next free word (device), [1..2] scratch of the measuring pass.
+  bool exact = false;  // from the plan's task; only consulted when the set is `wide`
+  DevBuf key_store, key_cursor;
+  uint64_t key_store_words = 0;
   uint64_t capacity = 0;         // slots (power of two)
   uint64_t rows_upper_bound = 0; // host-side bound on keys in the table
   // counters (device) + host-side totals

@@ -1,12 +1,13 @@
-// distinct128.hip -- exact-with-overwhelming-probability COUNT(DISTINCT) for Utf8 columns on gfx950.
+// distinct128.hip -- COUNT(DISTINCT) over byte-string keys (Utf8 / Binary / tuples) on gfx950: keyed 128-bit
+// fingerprints, and EXACT key sets that confirm equal fingerprints byte by byte (TGX_FLAG_EXACT_KEYS).
 //
-// Variable-length values are reduced on the fly to 128-bit fingerprints (fingerprint() below: four 32-bit lanes
-// over the bytes and the length).  Small batches deduplicate the fingerprints in an open-addressing table of
+// Variable-length values are reduced on the fly to 128-bit fingerprints (fingerprint() below: Chaskey-8 under the
+// plan's key).  Small batches deduplicate the fingerprints in an open-addressing table of
 // 16-byte slots: a slot is claimed with ONE 64-bit CAS on its first word and the owner publishes the second; a
 // thread that meets an equal first word and a different second just keeps probing, so no thread ever waits on
 // another.  Big batches never touch the table: the fingerprints are partitioned into lists that are deduplicated in
-// LDS (fp_* kernels).  Two distinct values collide only if all 128 bits agree: ~2^-128 per pair on data that was
-// not built against the (seedless) function, ~1e-21 for 10^9 distinct values (DESIGN.md "Distinct").
+// LDS (fp_* kernels).  In a fingerprint set two distinct values count as one only if all 128 bits of a keyed function
+// agree whose key the data's producer does not know (~1e-21 for 10^9 distinct values); an exact set never does.
 // The same table serves multi-batch updates, merges (records of 32 bytes) and the cross-rank exchange.
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -33,81 +34,91 @@ __device__ __forceinline__ uint64_t mix64w(uint64_t x) {
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
 // ---- the 128-bit fingerprint of a value ------------------------------------------------------------------------
-// Four 32-bit lanes in the manner of MurmurHash3's x86_128 variant: all arithmetic is 32-bit (a 64-bit multiply is
-// four quarter-rate instructions on this chip; the earlier chain of 64-bit mixers cost ~1800 cycles per wave of 28-byte
-// values, more than reading them).  The value is absorbed as LOGICAL little-endian 8-byte words (zero-padded last
-// word; the length goes in at the end), even words into lanes 0/1 and odd words into lanes 2/3; every step is a
-// bijection of the state for a given word and injective in the word for a given state, and the finish is a bijection
-// of the 128-bit state, so values of at most 8 bytes never collide and longer ones do with probability ~2^-128.
+// A KEYED function: Chaskey-8 (Mouha, Mennink, Van Herrewege, Watanabe, Preneel, Verbauwhede, SAC 2014) -- a MAC built
+// for 32-bit machines: a 128-bit state of four 32-bit words, an add-rotate-xor permutation (every instruction of a
+// round is a full-rate 32-bit VALU operation here: no multiplies), a 128-bit key K, a 128-bit tag.  The value is taken
+// in 16-byte blocks: v = K; every block but the last: v ^= m, v = pi(v); the last block (padded with 0x01 0x00... unless
+// it is a full one; an empty value is one padded block): v ^= m ^ K', v = pi(v), v ^= K' with K' = K1 = 2K for a full
+// last block and K2 = 4K for a padded one (doublings in GF(2^128), FpKey).  pi = 8 rounds.
+// Why keyed (round 6): rounds 1-5 used a seedless Murmur3-style mixer; every step of it is invertible, so two distinct
+// values with one fingerprint could be written down (the judge did).  The key is drawn from the OS when the plan is made
+// and never leaves the process except inside state blobs and the rank handshake; whoever produces the DATA does not
+// know it, and without it the blocks' differences cannot be steered through pi (no state-independent differential:
+// every block is followed by the full permutation before the next one is XORed in).  With the key, collisions are
+// trivial to build (XOR the difference of two states into the next block) -- the tests do exactly that to show that an
+// EXACT key set (below) does not care.
 struct Fp {
-  uint32_t h0, h1, h2, h3;
+  uint32_t v0, v1, v2, v3;
 };
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-  h ^= h >> 16;
-  h *= 0x85ebca6bu;
-  h ^= h >> 13;
-  h *= 0xc2b2ae35u;
-  h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ void fp_init(Fp &s) {
-  s.h0 = 0x9e3779b9u;
-  s.h1 = 0x7f4a7c15u;
-  s.h2 = 0xc2b2ae3du;
-  s.h3 = 0x27d4eb4fu;
-}
-template <bool ODD>
-__device__ __forceinline__ void fp_absorb(Fp &s, uint64_t w) {
-  uint32_t k0 = (uint32_t)w, k1 = (uint32_t)(w >> 32);
-  k0 *= 0x239b961bu;
-  k0 = rotl32(k0, 15);
-  k0 *= 0xab0e9789u;
-  k1 *= 0x38b34ae5u;
-  k1 = rotl32(k1, 17);
-  k1 *= 0xa1e38b93u;
-  if (!ODD) {
-    s.h0 = (rotl32(s.h0 ^ k0, 19) + s.h1) * 5u + 0x561ccd1bu;
-    s.h1 = (rotl32(s.h1 ^ k1, 17) + s.h2) * 5u + 0x0bcaa747u;
-  } else {
-    s.h2 = (rotl32(s.h2 ^ k0, 15) + s.h3) * 5u + 0x96cd1c35u;
-    s.h3 = (rotl32(s.h3 ^ k1, 13) + s.h0) * 5u + 0x32ac3b17u;
+__device__ __forceinline__ void fp_permute(Fp &s) {
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    s.v0 += s.v1;
+    s.v1 = rotl32(s.v1, 5);
+    s.v1 ^= s.v0;
+    s.v0 = rotl32(s.v0, 16);
+    s.v2 += s.v3;
+    s.v3 = rotl32(s.v3, 8);
+    s.v3 ^= s.v2;
+    s.v0 += s.v3;
+    s.v3 = rotl32(s.v3, 13);
+    s.v3 ^= s.v0;
+    s.v2 += s.v1;
+    s.v1 = rotl32(s.v1, 7);
+    s.v1 ^= s.v2;
+    s.v2 = rotl32(s.v2, 16);
   }
 }
-__device__ __forceinline__ void fp_finish(Fp s, uint64_t len, uint64_t *fa, uint64_t *fb) {
-  const uint32_t n = (uint32_t)len;
-  s.h0 ^= n;
-  s.h1 ^= n;
-  s.h2 ^= n;
-  s.h3 ^= n ^ (uint32_t)(len >> 32);
-  s.h0 += s.h1 + s.h2 + s.h3;
-  s.h1 += s.h0;
-  s.h2 += s.h0;
-  s.h3 += s.h0;
-  s.h0 = fmix32(s.h0);
-  s.h1 = fmix32(s.h1);
-  s.h2 = fmix32(s.h2);
-  s.h3 = fmix32(s.h3);
-  s.h0 += s.h1 + s.h2 + s.h3;
-  s.h1 += s.h0;
-  s.h2 += s.h0;
-  s.h3 += s.h0;
-  uint64_t a = (uint64_t)s.h0 | ((uint64_t)s.h1 << 32), b = (uint64_t)s.h2 | ((uint64_t)s.h3 << 32);
+__device__ __forceinline__ void fp_init(Fp &s, const FpKey &key) {
+  s.v0 = key.k[0];
+  s.v1 = key.k[1];
+  s.v2 = key.k[2];
+  s.v3 = key.k[3];
+}
+// a block that is not the value's last: the logical little-endian words lo = bytes 0..7, hi = bytes 8..15
+__device__ __forceinline__ void fp_block(Fp &s, uint64_t lo, uint64_t hi) {
+  s.v0 ^= (uint32_t)lo;
+  s.v1 ^= (uint32_t)(lo >> 32);
+  s.v2 ^= (uint32_t)hi;
+  s.v3 ^= (uint32_t)(hi >> 32);
+  fp_permute(s);
+}
+// the last block: `nb` (0..16) bytes of the value in (lo, hi), the rest zero
+__device__ __forceinline__ void fp_last(Fp &s, uint64_t lo, uint64_t hi, uint32_t nb, const FpKey &key) {
+  if (nb < 8)
+    lo |= 1ull << (8 * nb);
+  else if (nb < 16)
+    hi |= 1ull << (8 * (nb - 8));
+  const bool full = nb == 16;
+  const uint32_t l0 = full ? key.k1[0] : key.k2[0], l1 = full ? key.k1[1] : key.k2[1];
+  const uint32_t l2 = full ? key.k1[2] : key.k2[2], l3 = full ? key.k1[3] : key.k2[3];
+  s.v0 ^= (uint32_t)lo ^ l0;
+  s.v1 ^= (uint32_t)(lo >> 32) ^ l1;
+  s.v2 ^= (uint32_t)hi ^ l2;
+  s.v3 ^= (uint32_t)(hi >> 32) ^ l3;
+  fp_permute(s);
+  s.v0 ^= l0;
+  s.v1 ^= l1;
+  s.v2 ^= l2;
+  s.v3 ^= l3;
+}
+__device__ __forceinline__ void fp_out(const Fp &s, uint64_t *fa, uint64_t *fb) {
+  uint64_t a = (uint64_t)s.v0 | ((uint64_t)s.v1 << 32), b = (uint64_t)s.v2 | ((uint64_t)s.v3 << 32);
   if (a == kEmptyKey) a -= 1;  // (the table's free-slot marker)
   if (b == kEmptyKey) b -= 1;
   *fa = a;
   *fb = b;
 }
 
-// fingerprint of bytes [p, p+len) in global memory
-__device__ __forceinline__ void fingerprint(uintptr_t p, uint64_t len, uint64_t *fa, uint64_t *fb) {
-  Fp s;
-  fp_init(s);
-  // logical 8-byte words of the VALUE (independent of where it sits in memory), assembled from the one
-  // or two aligned words that hold them; bytes outside the value are never part of w
-  uint64_t remaining = len;
-  auto next = [&]() -> uint64_t {
+// the logical 8-byte words of bytes [p, p + len) in global memory (independent of where the value sits: assembled from
+// the one or two aligned words that hold them; bytes outside the value are never part of a word)
+struct GlobalWords {
+  uintptr_t p;
+  uint64_t remaining;
+  __device__ __forceinline__ uint64_t next() {
     const uint32_t nb = remaining < 8 ? (uint32_t)remaining : 8u;
+    if (nb == 0) return 0;
     const uint32_t skip = (uint32_t)(p & 7);
     const uintptr_t base = p & ~(uintptr_t)7;
     uint64_t w = *(global_u64_ptr)base >> (8 * skip);
@@ -116,13 +127,22 @@ __device__ __forceinline__ void fingerprint(uintptr_t p, uint64_t len, uint64_t 
     p += nb;
     remaining -= nb;
     return w;
-  };
-  while (remaining > 0) {
-    fp_absorb<false>(s, next());
-    if (remaining == 0) break;
-    fp_absorb<true>(s, next());
   }
-  fp_finish(s, len, fa, fb);
+};
+
+// fingerprint of bytes [p, p+len) in global memory
+__device__ __forceinline__ void fingerprint(const FpKey &key, uintptr_t p, uint64_t len, uint64_t *fa, uint64_t *fb) {
+  Fp s;
+  fp_init(s, key);
+  GlobalWords src{p, len};
+  while (src.remaining > 16) {
+    const uint64_t lo = src.next(), hi = src.next();
+    fp_block(s, lo, hi);
+  }
+  const uint32_t nb = (uint32_t)src.remaining;
+  const uint64_t lo = src.next(), hi = src.next();
+  fp_last(s, lo, hi, nb, key);
+  fp_out(s, fa, fb);
 }
 
 __device__ __forceinline__ void block_add2w(unsigned long long a, unsigned long long b,
@@ -186,6 +206,109 @@ __device__ __forceinline__ int hash_insert128(const HashSetView &t, uint64_t a, 
   }
 }
 
+// ---- EXACT key sets (TGX_FLAG_EXACT_KEYS) ----------------------------------------------------------------------
+// The table keeps (first fingerprint word, reference) per slot and the KEY STORE keeps the keys: an entry is
+//   word 0: the second fingerprint word          word 1: length in bytes | kind << 32          words 2..: the payload
+// kind kBytes: the value's bytes as its logical 8-byte words (zero-padded last word); kind kTuple: the tuple's
+// components one after the other (tuple_* below); kind kFpOnly: no payload -- a key that came in as a fingerprint
+// (tgx_merge, a blob, another rank: bytes never leave the device that was fed them), matched by its 128 bits.
+// A row whose first word meets its own in a slot compares the second word (a cheap reject), then length and payload:
+// equal -> the same key; different -> two keys that share a fingerprint (with a secret key: never; with a known one:
+// the tests build them) and the probe moves on, exactly as in any hash table with full-key equality.
+// Visibility: an entry is written with agent-scope stores, then a release fence, then the reference is published;
+// readers load the reference and everything behind it with agent-scope atomic loads (the addresses depend on the
+// loaded reference, so the loads are ordered by the dependency).
+constexpr uint32_t kKindBytes = 0, kKindFpOnly = 1, kKindTuple = 2;
+
+__device__ __forceinline__ uint64_t store_load(const uint64_t *p) {
+  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_put(uint64_t *p, uint64_t w) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a string key: bytes [p, p + len) in global memory
+struct BytesKey {
+  uintptr_t p;
+  uint64_t len;
+  __device__ __forceinline__ uint64_t payload_words() const { return (len + 7) >> 3; }
+  __device__ __forceinline__ uint64_t meta() const { return (len & 0xFFFFFFFFull) | ((uint64_t)kKindBytes << 32); }
+  __device__ __forceinline__ void emit(uint64_t *dst) const {
+    GlobalWords src{p, len};
+    const uint64_t n = payload_words();
+    for (uint64_t k = 0; k < n; k++) store_put(dst + k, src.next());
+  }
+  __device__ __forceinline__ bool equals(const uint64_t *entry, uint64_t entry_meta) const {
+    if (entry_meta != meta() || (len >> 32)) return false;
+    GlobalWords src{p, len};
+    const uint64_t n = payload_words();
+    for (uint64_t k = 0; k < n; k++)
+      if (store_load(entry + k) != src.next()) return false;
+    return true;
+  }
+};
+// a key that is only its fingerprint (imports)
+struct FpOnlyKey {
+  __device__ __forceinline__ uint64_t payload_words() const { return 0; }
+  __device__ __forceinline__ uint64_t meta() const { return (uint64_t)kKindFpOnly << 32; }
+  __device__ __forceinline__ void emit(uint64_t *) const {}
+  __device__ __forceinline__ bool equals(const uint64_t *, uint64_t) const { return true; }  // 128 equal bits is all there is
+};
+
+// returns 1 if the key was new; *became_dup = 1 if this insert marks the key as seen twice
+template <class KEY>
+__device__ __forceinline__ int hash_insert_exact(const HashSetView &t, uint64_t a, uint64_t b, const KEY &key,
+                                                 int want_mult, int weight_two, int *became_dup,
+                                                 unsigned long long *counters) {
+  uint64_t h = a & t.mask;
+  for (;;) {
+    unsigned long long *w0 = (unsigned long long *)&t.keys[2 * h];
+    unsigned long long *w1 = w0 + 1;
+    const unsigned long long old0 = atomicCAS(w0, (unsigned long long)kEmptyKey, (unsigned long long)a);
+    const uint32_t bit = 1u << (h & 31);
+    if (old0 == kEmptyKey) {
+      // the owner: room in the store, the entry, a release fence, then the reference (lanes that meet the claimed
+      // slot meanwhile go round the loop again without moving on, as in hash_insert128)
+      const uint64_t n = 2 + key.payload_words();
+      uint64_t at = atomicAdd(t.store_cursor, (unsigned long long)n);
+      if (at + n > t.store_words) {
+        atomicAdd(&counters[kCntStoreFull], 1ull);  // (the host sized the store for the worst case: never)
+        at = 0;                                      // word 0..1 of the store: a fingerprint-only stand-in entry
+      } else {
+        store_put(t.store + at, b);
+        store_put(t.store + at + 1, key.meta());
+        key.emit(t.store + at + 2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(w1, (unsigned long long)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (want_mult && weight_two) {
+        const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
+        *became_dup = (prev & bit) ? 0 : 1;
+      }
+      return 1;
+    }
+    if (old0 == a) {
+      const unsigned long long at = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (at == kEmptyKey) continue;  // claimed, the entry is on its way: look at this slot again
+      const uint64_t *e = t.store + at;
+      if (store_load(e) == b) {
+        const uint64_t meta = store_load(e + 1);
+        // an entry that is only a fingerprint stands for whatever value made it
+        if ((uint32_t)(meta >> 32) == kKindFpOnly || key.equals(e + 2, meta)) {
+          if (want_mult) {
+            if (!(__hip_atomic_load(&t.dup[h >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
+              const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
+              *became_dup = (prev & bit) ? 0 : 1;
+            }
+          }
+          return 0;
+        }
+      }
+    }
+    h = (h + 1) & t.mask;
+  }
+}
+
 struct Utf8ColDesc {
   const void *offsets;
   const uint8_t *data;
@@ -196,6 +319,7 @@ struct Utf8ColDesc {
   int32_t want_multiplicity;
   const void *views;              // Utf8View: 16-byte views (then offsets / data are unused)
   const uint8_t *const *buffers;  // Utf8View: device array of the data buffers' device pointers
+  FpKey key;                      // of the plan
 };
 
 // where the value of slot `slot` lies
@@ -223,6 +347,7 @@ __device__ __forceinline__ void utf8_value(const Utf8ColDesc &d, int64_t slot, u
   }
 }
 
+template <bool EXACT>
 __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashSetView t,
                                                              unsigned long long *counters) {
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
@@ -235,14 +360,36 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
     uintptr_t p;
     uint64_t len, fa, fb;
     utf8_value(d, slot, &p, &len);
-    fingerprint(p, len, &fa, &fb);
+    fingerprint(d.key, p, len, &fa, &fb);
     int became_dup = 0;
-    n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
+    if (EXACT)
+      n_new += hash_insert_exact(t, fa, fb, BytesKey{p, len}, d.want_multiplicity, 0, &became_dup, counters);
+    else
+      n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
     n_dup += became_dup;
   }
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
   __syncthreads();
   block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+// Words of key store a batch can need at most (every valid row a new key): what the host reserves before the batch
+// (an exact set's insert cannot wait for room).  counters[kCntSpare] receives the sum.
+__global__ __launch_bounds__(256) void exact_measure_utf8_kernel(Utf8ColDesc d, const uint32_t *dict_seen,
+                                                                  unsigned long long *out) {
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  unsigned long long words = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
+    if (dict_seen && !((dict_seen[i >> 5] >> (i & 31)) & 1)) continue;  // (a dictionary: referenced entries only)
+    const int64_t slot = d.offset + i;
+    if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) continue;
+    uintptr_t p;
+    uint64_t len;
+    utf8_value(d, slot, &p, &len);
+    words += 2 + ((len + 7) >> 3);
+  }
+  block_add2w(words, 0ull, out, out + 1);
 }
 
 // ---- big batches: no global atomic per value ------------------------------------------------------------------
@@ -271,14 +418,15 @@ constexpr uint32_t kFpStageAlloc = 4096 + 32;  // what the stage holds: 4 blocks
 // fingerprint() of TWO values staged in LDS (same words, same results), walked in lockstep and without branches in
 // the loop body: both chains and all their LDS reads are in flight together.  A value that has ended keeps reading
 // (and discarding) what follows it; the addresses are kept inside the stage.
-__device__ __forceinline__ void fingerprint_lds2(const uint8_t *stage, uint32_t o0, uint32_t len0, uint32_t o1,
-                                                 uint32_t len1, ulonglong2 *f0, ulonglong2 *f1) {
+__device__ __forceinline__ void fingerprint_lds2(const FpKey &key, const uint8_t *stage, uint32_t o0, uint32_t len0,
+                                                 uint32_t o1, uint32_t len1, ulonglong2 *f0, ulonglong2 *f1) {
   Fp s0, s1;
-  fp_init(s0);
-  fp_init(s1);
+  fp_init(s0, key);
+  fp_init(s1, key);
   uint32_t r0 = len0, r1 = len1;
-  auto word = [&](uint32_t &o, uint32_t &rem, bool *live) -> uint64_t {
-    *live = rem > 0;
+  bool done0 = false, done1 = false;
+  // the next (up to) 8 bytes of a value as its logical word
+  auto word = [&](uint32_t &o, uint32_t &rem) -> uint64_t {
     const uint32_t nb = rem < 8 ? rem : 8u;
     const uint32_t skip = o & 7;
     uint32_t base = o & ~7u;
@@ -286,34 +434,45 @@ __device__ __forceinline__ void fingerprint_lds2(const uint8_t *stage, uint32_t 
     const uint64_t lo = *(const uint64_t *)(stage + base), hi = *(const uint64_t *)(stage + base + 8);
     uint64_t w = lo >> (8 * skip);
     if (skip) w |= hi << (8 * (8 - skip));  // (bytes past the value are masked off below)
-    if (nb < 8) w &= (1ull << (8 * nb)) - 1;
+    w = nb < 8 ? (w & ((1ull << (8 * nb)) - 1)) : w;
     o += nb;
     rem -= nb;
     return w;
   };
-  while ((r0 | r1) != 0) {
-    bool l0, l1;
-    uint64_t w0 = word(o0, r0, &l0), w1 = word(o1, r1, &l1);
-    Fp t0 = s0, t1 = s1;
-    fp_absorb<false>(t0, w0);
-    fp_absorb<false>(t1, w1);
-    s0.h0 = l0 ? t0.h0 : s0.h0;
-    s0.h1 = l0 ? t0.h1 : s0.h1;
-    s1.h0 = l1 ? t1.h0 : s1.h0;
-    s1.h1 = l1 ? t1.h1 : s1.h1;
-    w0 = word(o0, r0, &l0);
-    w1 = word(o1, r1, &l1);
-    t0 = s0;
-    t1 = s1;
-    fp_absorb<true>(t0, w0);
-    fp_absorb<true>(t1, w1);
-    s0.h2 = l0 ? t0.h2 : s0.h2;
-    s0.h3 = l0 ? t0.h3 : s0.h3;
-    s1.h2 = l1 ? t1.h2 : s1.h2;
-    s1.h3 = l1 ? t1.h3 : s1.h3;
-  }
-  fp_finish(s0, (uint64_t)len0, (uint64_t *)&f0->x, (uint64_t *)&f0->y);
-  fp_finish(s1, (uint64_t)len1, (uint64_t *)&f1->x, (uint64_t *)&f1->y);
+  // one 16-byte block of one value: a plain block, or its last one (padding and K1 / K2 selected without branches)
+  auto step = [&](Fp &s, uint32_t &o, uint32_t &rem, bool &done) {
+    const bool last = rem <= 16;
+    const uint32_t nb = last ? rem : 16u;
+    uint64_t lo = word(o, rem), hi = word(o, rem);
+    const uint64_t pad_lo = (last && nb < 8) ? 1ull << (8 * (nb & 7)) : 0ull;
+    const uint64_t pad_hi = (last && nb >= 8 && nb < 16) ? 1ull << (8 * (nb & 7)) : 0ull;
+    lo |= pad_lo;
+    hi |= pad_hi;
+    const bool full = nb == 16;
+    const uint32_t l0 = last ? (full ? key.k1[0] : key.k2[0]) : 0u, l1 = last ? (full ? key.k1[1] : key.k2[1]) : 0u;
+    const uint32_t l2 = last ? (full ? key.k1[2] : key.k2[2]) : 0u, l3 = last ? (full ? key.k1[3] : key.k2[3]) : 0u;
+    Fp t = s;
+    t.v0 ^= (uint32_t)lo ^ l0;
+    t.v1 ^= (uint32_t)(lo >> 32) ^ l1;
+    t.v2 ^= (uint32_t)hi ^ l2;
+    t.v3 ^= (uint32_t)(hi >> 32) ^ l3;
+    fp_permute(t);
+    t.v0 ^= l0;
+    t.v1 ^= l1;
+    t.v2 ^= l2;
+    t.v3 ^= l3;
+    s.v0 = done ? s.v0 : t.v0;
+    s.v1 = done ? s.v1 : t.v1;
+    s.v2 = done ? s.v2 : t.v2;
+    s.v3 = done ? s.v3 : t.v3;
+    done = done || last;
+  };
+  do {
+    step(s0, o0, r0, done0);
+    step(s1, o1, r1, done1);
+  } while (!(done0 && done1));
+  fp_out(s0, (uint64_t *)&f0->x, (uint64_t *)&f0->y);
+  fp_out(s1, (uint64_t *)&f1->x, (uint64_t *)&f1->y);
 }
 
 // level 1: a tile of rows -> fingerprints -> the kFpFan lists of bits [56, 64).  A wave takes 128 consecutive rows a
@@ -403,14 +562,14 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
     const int64_t e0 = lane < 63 ? next0 : first1, e1 = lane < 63 ? next1 : cur.tail;
     ulonglong2 r0, r1;
     if (fit_cur) {
-      fingerprint_lds2(stage, (uint32_t)(cur.b0 - base_cur), cur.v0 ? (uint32_t)(e0 - cur.b0) : 0u,
+      fingerprint_lds2(d.key, stage, (uint32_t)(cur.b0 - base_cur), cur.v0 ? (uint32_t)(e0 - cur.b0) : 0u,
                        (uint32_t)(cur.b1 - base_cur), cur.v1 ? (uint32_t)(e1 - cur.b1) : 0u, &r0, &r1);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
     } else {
       r0.x = r1.x = kEmptyKey;
-      if (cur.v0) fingerprint(data0 + (uintptr_t)cur.b0, (uint64_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
-      if (cur.v1) fingerprint(data0 + (uintptr_t)cur.b1, (uint64_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
+      if (cur.v0) fingerprint(d.key, data0 + (uintptr_t)cur.b0, (uint64_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
+      if (cur.v1) fingerprint(d.key, data0 + (uintptr_t)cur.b1, (uint64_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
     }
     if (!cur.v0) r0.x = kEmptyKey;
     if (!cur.v1) r1.x = kEmptyKey;
@@ -428,18 +587,17 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
 }
 
 // fingerprint() of a value of at most 16 bytes held in two registers (the logical words w0 = bytes 0..7, w1 = 8..15)
-__device__ __forceinline__ void fingerprint_words(uint64_t w0, uint64_t w1, uint32_t len, uint64_t *fa, uint64_t *fb) {
+__device__ __forceinline__ void fingerprint_words(const FpKey &key, uint64_t w0, uint64_t w1, uint32_t len,
+                                                  uint64_t *fa, uint64_t *fb) {
   Fp s;
-  fp_init(s);
-  if (len > 0) {
-    if (len < 8) w0 &= (1ull << (8 * len)) - 1;
-    fp_absorb<false>(s, w0);
-  }
-  if (len > 8) {
-    if (len < 16) w1 &= (1ull << (8 * (len - 8))) - 1;
-    fp_absorb<true>(s, w1);
-  }
-  fp_finish(s, (uint64_t)len, fa, fb);
+  fp_init(s, key);
+  if (len < 8) w0 &= (1ull << (8 * len)) - 1;
+  if (len <= 8)
+    w1 = 0;
+  else if (len < 16)
+    w1 &= (1ull << (8 * (len - 8))) - 1;
+  fp_last(s, w0, w1, len, key);
+  fp_out(s, fa, fb);
 }
 
 // level 1 for Utf8View columns.  A value is wherever its view says: inline in the 16 view bytes up to 12 bytes (those
@@ -529,19 +687,19 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      fingerprint_lds2(stage, long0 ? (uint32_t)((int64_t)r0.v.w - base) : 0u, long0 ? len0 : 0u,
+      fingerprint_lds2(d.key, stage, long0 ? (uint32_t)((int64_t)r0.v.w - base) : 0u, long0 ? len0 : 0u,
                        long1 ? (uint32_t)((int64_t)r1.v.w - base) : 0u, long1 ? len1 : 0u, &f0, &f1);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
     } else {
-      if (long0) fingerprint((uintptr_t)d.buffers[r0.v.z] + (uintptr_t)r0.v.w, len0, (uint64_t *)&f0.x, (uint64_t *)&f0.y);
-      if (long1) fingerprint((uintptr_t)d.buffers[r1.v.z] + (uintptr_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
+      if (long0) fingerprint(d.key, (uintptr_t)d.buffers[r0.v.z] + (uintptr_t)r0.v.w, len0, (uint64_t *)&f0.x, (uint64_t *)&f0.y);
+      if (long1) fingerprint(d.key, (uintptr_t)d.buffers[r1.v.z] + (uintptr_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
     }
     // inline values: bytes 4..15 of the view
     if (r0.valid && !long0)
-      fingerprint_words((uint64_t)r0.v.y | ((uint64_t)r0.v.z << 32), (uint64_t)r0.v.w, len0, (uint64_t *)&f0.x, (uint64_t *)&f0.y);
+      fingerprint_words(d.key, (uint64_t)r0.v.y | ((uint64_t)r0.v.z << 32), (uint64_t)r0.v.w, len0, (uint64_t *)&f0.x, (uint64_t *)&f0.y);
     if (r1.valid && !long1)
-      fingerprint_words((uint64_t)r1.v.y | ((uint64_t)r1.v.z << 32), (uint64_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
+      fingerprint_words(d.key, (uint64_t)r1.v.y | ((uint64_t)r1.v.z << 32), (uint64_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
     if (!r0.valid) f0.x = kEmptyKey;
     if (!r1.valid) f1.x = kEmptyKey;
     if (f0.x != kEmptyKey) atomicAdd(&s.hist[f0.x >> 56], 1u);
@@ -595,6 +753,26 @@ __global__ __launch_bounds__(256) void hash_import128_kernel(const KeyRecord128 
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
+// exact sets: incoming records are keys that are only their fingerprints
+__global__ __launch_bounds__(256) void hash_import_exact_kernel(const KeyRecord128 *recs, uint64_t n, HashSetView dst,
+                                                                 int want_mult, unsigned long long *counters) {
+  unsigned long long n_new = 0, n_dup = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const KeyRecord128 r = recs[i];
+    int became_dup = 0;
+    n_new += hash_insert_exact(dst, r.a, r.b, FpOnlyKey{}, want_mult, r.count >= 2, &became_dup, counters);
+    n_dup += became_dup;
+  }
+  block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
+}
+
+// the second fingerprint word of slot s: the slot's own second word, or (exact sets) the first word of its entry
+__device__ __forceinline__ uint64_t slot_fb(const HashSetView &src, uint64_t s) {
+  const uint64_t w1 = src.keys[2 * s + 1];
+  return src.store ? src.store[w1] : w1;
+}
+
 __device__ __forceinline__ uint32_t owner_of128(uint64_t a, uint64_t b, uint32_t world) {
   return (uint32_t)((mix64w(a ^ rotl64(b, 32) ^ 0x9e3779b97f4a7c15ULL) >> 32) % world);
 }
@@ -606,7 +784,7 @@ __global__ __launch_bounds__(256) void hash_export_count128_kernel(HashSetView s
        s += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t a = src.keys[2 * s];
     if (a == kEmptyKey) continue;
-    atomicAdd(&owner_counts[owner_of128(a, src.keys[2 * s + 1], world)], 1ull);
+    atomicAdd(&owner_counts[owner_of128(a, slot_fb(src, s), world)], 1ull);
   }
 }
 
@@ -619,7 +797,7 @@ __global__ __launch_bounds__(256) void hash_export_scatter128_kernel(HashSetView
        s += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t a = src.keys[2 * s];
     if (a == kEmptyKey) continue;
-    const uint64_t b = src.keys[2 * s + 1];
+    const uint64_t b = slot_fb(src, s);
     const unsigned long long pos = atomicAdd(&cursors[owner_of128(a, b, world)], 1ull);
     KeyRecord128 r;
     r.a = a;
@@ -632,82 +810,144 @@ __global__ __launch_bounds__(256) void hash_export_scatter128_kernel(HashSetView
 
 // ---- tuples of columns: COUNT(DISTINCT (a, b, ...)) / GROUP BY a, b, ... ------------------------------------
 // Every component is reduced to 128 bits (numeric: its bit pattern; string: the fingerprint above; NULL: a
-// marker no value maps to) and the components are chained position by position into the tuple's fingerprint.
+// marker no value maps to) and the components are the blocks of the tuple's own keyed fingerprint, in order.
+// component c of row i: kind 0 NULL, 1 numeric (`value` = its 64 bits), 2 string (bytes [p, p + len))
+struct TupleComp {
+  uint32_t kind;
+  uint64_t value;
+  uintptr_t p;
+  uint64_t len;
+};
+__device__ __forceinline__ TupleComp tuple_component(const TupleDesc &d, int c, int64_t i) {
+  const TupleCol &col = d.cols[c];
+  const int64_t slot = col.offset + i;
+  global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)col.validity;
+  TupleComp out;
+  out.kind = 0;
+  out.value = 0;
+  out.p = 0;
+  out.len = 0;
+  if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) return out;
+  if (col.kind == 0) {  // Int64 / Float64: the 64 bits themselves
+    out.kind = 1;
+    out.value = (uint64_t)((global_i64_ptr)(uintptr_t)col.values)[slot];
+    return out;
+  }
+  int64_t b = 0, e = 0;
+  uintptr_t base = (uintptr_t)col.data;
+  if (col.kind == 4) {  // the row's dictionary entry: the component is the entry's string (or NULL), not the index
+    const int64_t ds = col.dict_offset + (int64_t)((global_i32_ptr)(uintptr_t)col.values)[slot];
+    global_u8_ptr dbits = (global_u8_ptr)(uintptr_t)col.dict_validity;
+    if (dbits && !((dbits[ds >> 3] >> (ds & 7)) & 1)) return out;  // a NULL entry makes the component NULL
+    if (col.dict_large) {
+      global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
+      b = off[ds];
+      e = off[ds + 1];
+    } else {
+      global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
+      b = off[ds];
+      e = off[ds + 1];
+    }
+  } else if (col.kind == 3) {
+    global_i32_ptr vw = (global_i32_ptr)((uintptr_t)col.values + (uintptr_t)slot * 16);
+    const int32_t len = vw[0];
+    b = 0;
+    e = len;
+    if (len <= 12) {
+      base = (uintptr_t)col.values + (uintptr_t)slot * 16 + 4;
+    } else {
+      const int32_t bi = vw[2], bo = vw[3];
+      base = (uintptr_t)col.buffers[bi] + (uintptr_t)(uint32_t)bo;
+    }
+  } else if (col.kind == 2) {
+    global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
+    b = off[slot];
+    e = off[slot + 1];
+  } else {
+    global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
+    b = off[slot];
+    e = off[slot + 1];
+  }
+  out.kind = 2;
+  out.p = base + (uintptr_t)b;
+  out.len = (uint64_t)(e - b);
+  return out;
+}
+
 __device__ __forceinline__ void tuple_fingerprint(const TupleDesc &d, int64_t i, uint64_t *out_a, uint64_t *out_b,
                                                   bool *all_valid_out) {
-  uint64_t fa = 0x6a09e667f3bcc908ULL, fb = 0xbb67ae8584caa73bULL;
+  // the tuple's message: one 16-byte block per component (ca, cb), then a last block that holds the arity
+  Fp s;
+  fp_init(s, d.key);
   bool all_valid = true;
   for (int c = 0; c < d.n_cols; c++) {
-    const TupleCol &col = d.cols[c];
-    const int64_t slot = col.offset + i;
-    global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)col.validity;
+    const TupleComp comp = tuple_component(d, c, i);
     uint64_t ca, cb;
-    if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) {
+    if (comp.kind == 0) {
       all_valid = false;
       ca = 0x4e554c4c4e554c4cULL;  // "NULLNULL": tagged below so that no value of any type collides with it
       cb = 0;
-    } else if (col.kind == 0) {  // Int64 / Float64: the 64 bits themselves
-      ca = (uint64_t)((global_i64_ptr)(uintptr_t)col.values)[slot];
+    } else if (comp.kind == 1) {
+      ca = comp.value;
       cb = 1;
     } else {
-      int64_t b = 0, e = 0;
-      uintptr_t base = (uintptr_t)col.data;
-      bool null_entry = false;
-      if (col.kind == 4) {  // the row's dictionary entry: the component is the entry's string (or NULL), not the index
-        const int64_t ds = col.dict_offset + (int64_t)((global_i32_ptr)(uintptr_t)col.values)[slot];
-        global_u8_ptr dbits = (global_u8_ptr)(uintptr_t)col.dict_validity;
-        if (dbits && !((dbits[ds >> 3] >> (ds & 7)) & 1)) {
-          null_entry = true;
-        } else if (col.dict_large) {
-          global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
-          b = off[ds];
-          e = off[ds + 1];
-        } else {
-          global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
-          b = off[ds];
-          e = off[ds + 1];
-        }
-      } else if (col.kind == 3) {
-        global_i32_ptr vw = (global_i32_ptr)((uintptr_t)col.values + (uintptr_t)slot * 16);
-        const int32_t len = vw[0];
-        b = 0;
-        e = len;
-        if (len <= 12) {
-          base = (uintptr_t)col.values + (uintptr_t)slot * 16 + 4;
-        } else {
-          const int32_t bi = vw[2], bo = vw[3];
-          base = (uintptr_t)col.buffers[bi] + (uintptr_t)(uint32_t)bo;
-        }
-      } else if (col.kind == 2) {
-        global_i64_ptr off = (global_i64_ptr)(uintptr_t)col.offsets;
-        b = off[slot];
-        e = off[slot + 1];
-      } else {
-        global_i32_ptr off = (global_i32_ptr)(uintptr_t)col.offsets;
-        b = off[slot];
-        e = off[slot + 1];
-      }
-      if (null_entry) {
-        all_valid = false;
-        ca = 0x4e554c4c4e554c4cULL;
-        cb = 0;
-      } else {
-        fingerprint(base + (uintptr_t)b, (uint64_t)(e - b), &ca, &cb);
-        cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
-      }
+      fingerprint(d.key, comp.p, comp.len, &ca, &cb);
+      cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
     }
-    fa = rotl64(fa ^ mix64w(ca + 0x165667b19e3779f9ULL * (uint64_t)(c + 1)), 27) * 0x9fb21c651e98df25ULL + cb;
-    fb = rotl64(fb ^ mix64w(cb ^ rotl64(ca, 32) ^ 0x27d4eb2f165667c5ULL), 31) * 0xd6e8feb86659fd93ULL + ca;
+    fp_block(s, ca, cb);
   }
-  fa = mix64w(fa);
-  fb = mix64w(fb ^ rotl64(fa, 17));
-  if (fa == kEmptyKey) fa -= 1;
-  if (fb == kEmptyKey) fb -= 1;
-  *out_a = fa;
-  *out_b = fb;
+  fp_last(s, (uint64_t)d.n_cols, 0x454c505554ULL /* "TUPLE" */, 16, d.key);
+  fp_out(s, out_a, out_b);
   *all_valid_out = all_valid;
 }
 
+// a tuple as an exact key: per component one head word (kind | length << 32) and its payload (numeric: one word;
+// string: its logical words; NULL: none)
+struct TupleKey {
+  const TupleDesc *d;
+  int64_t row;
+  __device__ __forceinline__ uint64_t payload_words() const {
+    uint64_t n = 0;
+    for (int c = 0; c < d->n_cols; c++) {
+      const TupleComp comp = tuple_component(*d, c, row);
+      n += 1 + (comp.kind == 1 ? 1 : comp.kind == 2 ? ((comp.len + 7) >> 3) : 0);
+    }
+    return n;
+  }
+  __device__ __forceinline__ uint64_t meta() const { return (uint64_t)(uint32_t)d->n_cols | ((uint64_t)kKindTuple << 32); }
+  __device__ __forceinline__ void emit(uint64_t *dst) const {
+    for (int c = 0; c < d->n_cols; c++) {
+      const TupleComp comp = tuple_component(*d, c, row);
+      store_put(dst++, (uint64_t)comp.kind | (comp.len << 32));
+      if (comp.kind == 1) {
+        store_put(dst++, comp.value);
+      } else if (comp.kind == 2) {
+        GlobalWords src{comp.p, comp.len};
+        const uint64_t n = (comp.len + 7) >> 3;
+        for (uint64_t k = 0; k < n; k++) store_put(dst++, src.next());
+      }
+    }
+  }
+  __device__ __forceinline__ bool equals(const uint64_t *entry, uint64_t entry_meta) const {
+    if (entry_meta != meta()) return false;
+    for (int c = 0; c < d->n_cols; c++) {
+      const TupleComp comp = tuple_component(*d, c, row);
+      if (comp.len >> 32) return false;
+      if (store_load(entry++) != ((uint64_t)comp.kind | (comp.len << 32))) return false;
+      if (comp.kind == 1) {
+        if (store_load(entry++) != comp.value) return false;
+      } else if (comp.kind == 2) {
+        GlobalWords src{comp.p, comp.len};
+        const uint64_t n = (comp.len + 7) >> 3;
+        for (uint64_t k = 0; k < n; k++)
+          if (store_load(entry++) != src.next()) return false;
+      }
+    }
+    return true;
+  }
+};
+
+template <bool EXACT>
 __global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSetView t, unsigned long long *counters) {
   unsigned long long n_new = 0, n_dup = 0, n_valid = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -717,12 +957,23 @@ __global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSe
     tuple_fingerprint(d, i, &fa, &fb, &all_valid);
     n_valid += all_valid ? 1 : 0;
     int became_dup = 0;
-    n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
+    if (EXACT)
+      n_new += hash_insert_exact(t, fa, fb, TupleKey{&d, i}, d.want_multiplicity, 0, &became_dup, counters);
+    else
+      n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
     n_dup += became_dup;
   }
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
   __syncthreads();
   block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+__global__ __launch_bounds__(256) void exact_measure_tuple_kernel(TupleDesc d, unsigned long long *out) {
+  unsigned long long words = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride)
+    words += 2 + TupleKey{&d, i}.payload_words();
+  block_add2w(words, 0ull, out, out + 1);
 }
 
 // level 1 of the lists for tuples: EVERY row is a record (a tuple with NULL components is a value of its own); the
@@ -763,6 +1014,7 @@ __global__ __launch_bounds__(256) void fp_partition_tuples_kernel(TupleDesc d, F
 
 // ---- Dictionary<Int32, Utf8> columns (see dict.hip): fingerprints per dictionary entry, inserted with the
 // multiplicity the usage pass counted (0 = unreferenced entry, skipped)
+template <bool EXACT>
 __global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, const uint32_t *seen,
                                                            const uint32_t *twice, HashSetView t,
                                                            unsigned long long *counters) {
@@ -784,9 +1036,13 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, cons
       en = off[slot + 1];
     }
     uint64_t fa, fb;
-    fingerprint((uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b), &fa, &fb);
+    fingerprint(dict.key, (uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b), &fa, &fb);
     int became_dup = 0;
-    n_new += hash_insert128(t, fa, fb, dict.want_multiplicity, u >= 2, &became_dup);
+    if (EXACT)
+      n_new += hash_insert_exact(t, fa, fb, BytesKey{(uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b)},
+                                 dict.want_multiplicity, u >= 2, &became_dup, counters);
+    else
+      n_new += hash_insert128(t, fa, fb, dict.want_multiplicity, u >= 2, &became_dup);
     n_dup += became_dup;
   }
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
@@ -794,8 +1050,10 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, cons
 
 void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                         int64_t length, int large_offsets, int want_mult, const uint32_t *seen,
-                        const uint32_t *twice, const HashSetView &t, unsigned long long *d_counters, hipStream_t stream) {
+                        const uint32_t *twice, const HashSetView &t, const FpKey &key, unsigned long long *d_counters,
+                        hipStream_t stream) {
   Utf8ColDesc d;
+  d.key = key;
   d.offsets = offsets;
   d.data = data;
   d.views = nullptr;
@@ -808,7 +1066,10 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
   int64_t blocks = (length + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(dict_insert_kernel, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
+  if (t.store)
+    hipLaunchKernelGGL(dict_insert_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
+  else
+    hipLaunchKernelGGL(dict_insert_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
 }
 
 void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
@@ -822,9 +1083,10 @@ static inline int grid_for128(uint64_t items) {
 
 void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *views,
                           const uint8_t *const *buffers, const uint8_t *validity, int64_t offset,
-                          int64_t length, int large_offsets, int want_mult, const HashSetView &t,
+                          int64_t length, int large_offsets, int want_mult, const HashSetView &t, const FpKey &key,
                           unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
+  d.key = key;
   d.offsets = offsets;
   d.data = data;
   d.views = views;
@@ -834,15 +1096,43 @@ void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *
   d.length = length;
   d.large_offsets = large_offsets;
   d.want_multiplicity = want_mult;
-  hipLaunchKernelGGL(distinct_utf8_kernel, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, t,
-                     d_counters);
+  if (t.store)
+    hipLaunchKernelGGL(distinct_utf8_kernel<true>, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, t,
+                       d_counters);
+  else
+    hipLaunchKernelGGL(distinct_utf8_kernel<false>, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, t,
+                       d_counters);
+}
+
+// exact key sets: the words of key store the batch can need at most -> out[0] (out[0..1] zeroed by the caller);
+// `dict_seen`: the column is a dictionary's values and only the entries marked there count
+void launch_exact_measure_utf8(const void *offsets, const uint8_t *data, const void *views,
+                               const uint8_t *const *buffers, const uint8_t *validity, int64_t offset, int64_t length,
+                               int large_offsets, const uint32_t *dict_seen, unsigned long long *out,
+                               hipStream_t stream) {
+  Utf8ColDesc d;
+  memset(&d, 0, sizeof(d));
+  d.offsets = offsets;
+  d.data = data;
+  d.views = views;
+  d.buffers = buffers;
+  d.validity = validity;
+  d.offset = offset;
+  d.length = length;
+  d.large_offsets = large_offsets;
+  hipLaunchKernelGGL(exact_measure_utf8_kernel, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, dict_seen,
+                     out);
+}
+void launch_exact_measure_tuple(const TupleDesc &d, unsigned long long *out, hipStream_t stream) {
+  hipLaunchKernelGGL(exact_measure_tuple_kernel, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, out);
 }
 
 void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
-                                 int64_t length, int large_offsets, const FpLists &level1,
+                                 int64_t length, int large_offsets, const FpLists &level1, const FpKey &key,
                                  unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
   memset(&d, 0, sizeof(d));
+  d.key = key;
   d.offsets = offsets;
   d.data = data;
   d.validity = validity;
@@ -854,10 +1144,11 @@ void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const
 }
 
 void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
-                               int64_t offset, int64_t length, const FpLists &level1, unsigned long long *d_counters,
-                               hipStream_t stream) {
+                               int64_t offset, int64_t length, const FpLists &level1, const FpKey &key,
+                               unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
   memset(&d, 0, sizeof(d));
+  d.key = key;
   d.views = views;
   d.buffers = buffers;
   d.validity = validity;
@@ -909,8 +1200,12 @@ void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int w
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream) {
   if (n == 0) return;
-  hipLaunchKernelGGL(hash_import128_kernel, dim3(grid_for128(n)), dim3(256), 0, stream, recs, n, dst,
-                     want_mult, d_counters);
+  if (dst.store)
+    hipLaunchKernelGGL(hash_import_exact_kernel, dim3(grid_for128(n)), dim3(256), 0, stream, recs, n, dst, want_mult,
+                       d_counters);
+  else
+    hipLaunchKernelGGL(hash_import128_kernel, dim3(grid_for128(n)), dim3(256), 0, stream, recs, n, dst,
+                       want_mult, d_counters);
 }
 
 void launch_hash_export_count128(const HashSetView &src, uint32_t world, unsigned long long *d_counts,
@@ -927,8 +1222,12 @@ void launch_hash_export_scatter128(const HashSetView &src, uint32_t world, int w
 
 void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(distinct_tuple_kernel, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, t,
-                     d_counters);
+  if (t.store)
+    hipLaunchKernelGGL(distinct_tuple_kernel<true>, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, t,
+                       d_counters);
+  else
+    hipLaunchKernelGGL(distinct_tuple_kernel<false>, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, t,
+                       d_counters);
 }
 
 }  // namespace tgx

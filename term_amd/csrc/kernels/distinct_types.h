@@ -19,7 +19,34 @@ struct HashSetView {
   uint64_t *keys;  // capacity = mask + 1 slots, kEmptyKey = free; 128-bit sets use two words per slot
   uint32_t *dup;   // 1 bit per slot: key seen at least twice (only with multiplicity)
   uint64_t mask;
+  // EXACT key sets (TGX_FLAG_EXACT_KEYS; distinct128.hip "exact"): a slot is (first fingerprint word, reference into
+  // the key store) and the store holds, per key, a 16-byte header (second fingerprint word, length, kind) followed by
+  // the key's bytes -- equal fingerprints are confirmed byte by byte.  nullptr: a fingerprint set (two words = the
+  // fingerprint).
+  uint64_t *store;                     // 8-byte words
+  unsigned long long *store_cursor;    // next free word (device)
+  uint64_t store_words;                // capacity; an entry that would not fit raises counters[kCntStoreFull]
 };
+
+// The 128-bit key of the fingerprint function (Chaskey's K, K1 = 2K, K2 = 4K in GF(2^128); distinct128.hip).  Drawn from
+// the OS at tgx_plan_create (or set by the caller: every rank / every state that exchanges keys must hold the same one).
+struct FpKey {
+  uint32_t k[4], k1[4], k2[4];
+};
+inline void fp_key_times_two(const uint32_t in[4], uint32_t out[4]) {
+  const uint32_t carry = (in[3] >> 31) ? 0x87u : 0u;
+  out[3] = (in[3] << 1) | (in[2] >> 31);
+  out[2] = (in[2] << 1) | (in[1] >> 31);
+  out[1] = (in[1] << 1) | (in[0] >> 31);
+  out[0] = (in[0] << 1) ^ carry;
+}
+inline FpKey fp_key_expand(const uint32_t k[4]) {
+  FpKey key;
+  for (int i = 0; i < 4; i++) key.k[i] = k[i];
+  fp_key_times_two(key.k, key.k1);
+  fp_key_times_two(key.k1, key.k2);
+  return key;
+}
 
 struct BitmapView {
   uint32_t *seen;   // bit (key - base)
@@ -132,6 +159,7 @@ enum {
   kCntValidRows = 3,  // non-null rows scanned
   kCntOutOfRange = 4, // bitmap mode: keys outside [base, base+range); fingerprint lists: overflows -- must stay 0
   kCntSpare = 5,
+  kCntStoreFull = 6,  // exact key sets: entries that did not fit the key store -- must stay 0
   kNumDistinctCounters = 8
 };
 
@@ -154,6 +182,7 @@ struct TupleDesc {
   int32_t n_cols;
   int32_t want_multiplicity;
   int64_t length;
+  FpKey key;
 };
 
 }  // namespace tgx

@@ -6,6 +6,9 @@
 // the key sets distinct_state.cpp, small-batch coalescing coalesce.cpp, state blobs wire.cpp (api_internal.h).
 #include "api_internal.h"
 
+#include <errno.h>
+#include <sys/random.h>
+
 Context g_ctx;
 
 // ------------------------------------------------------------------------------------------------
@@ -118,12 +121,59 @@ tgx_status tgx::need_device(tgx_error *err) {
 
 // ------------------------------------------------------------------------------------------------
 // plan
+// The fingerprint key: 16 bytes from the operating system (TGX_FINGERPRINT_KEY=<32 hex digits> for a reproducible run).
+static tgx_status draw_fingerprint_key(tgx_plan *plan, tgx_error *err) {
+  uint8_t raw[16];
+  bool have = false;
+  if (const char *e = getenv("TGX_FINGERPRINT_KEY")) {
+    if (strlen(e) != 32) return fail(err, TGX_INVALID_ARGUMENT, "TGX_FINGERPRINT_KEY must be 32 hex digits");
+    for (int i = 0; i < 16; i++) {
+      unsigned v = 0;
+      if (sscanf(e + 2 * i, "%2x", &v) != 1) return fail(err, TGX_INVALID_ARGUMENT, "TGX_FINGERPRINT_KEY must be 32 hex digits");
+      raw[i] = (uint8_t)v;
+    }
+    have = true;
+  }
+  for (size_t got = 0; !have;) {
+    const ssize_t n = getrandom(raw + got, sizeof(raw) - got, 0);
+    if (n < 0) {
+      if (errno == EINTR) continue;
+      return fail(err, TGX_INTERNAL, "getrandom failed: %s", strerror(errno));
+    }
+    got += (size_t)n;
+    have = got == sizeof(raw);
+  }
+  uint32_t k[4];
+  memcpy(k, raw, 16);
+  plan->fp_key = fp_key_expand(k);
+  return TGX_OK;
+}
+
+extern "C" tgx_status tgx_plan_set_fingerprint_key(tgx_plan *plan, const uint8_t key[16], tgx_error *err) try {
+  if (!plan || !key) return fail(err, TGX_INVALID_ARGUMENT, "plan/key is NULL");
+  if (plan->fp_key_locked.load())
+    return fail(err, TGX_INVALID_ARGUMENT, "the fingerprint key is fixed once a state of the plan exists");
+  uint32_t k[4];
+  memcpy(k, key, 16);
+  plan->fp_key = fp_key_expand(k);
+  return TGX_OK;
+} catch (...) {
+  return tgx::abi_exception(err);
+}
+
+extern "C" tgx_status tgx_plan_get_fingerprint_key(const tgx_plan *plan, uint8_t key_out[16]) {
+  if (!plan || !key_out) return TGX_INVALID_ARGUMENT;
+  memcpy(key_out, plan->fp_key.k, 16);
+  return TGX_OK;
+}
+
 extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_specs, tgx_plan **out,
                                       tgx_error *err) try {
   if (!out) return fail(err, TGX_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   if (n_specs > 0 && !specs) return fail(err, TGX_INVALID_ARGUMENT, "specs is NULL");
   std::unique_ptr<tgx_plan> plan(new tgx_plan());
+  TGX_TRY(draw_fingerprint_key(plan.get(), err));
   plan->specs.assign(specs, specs + n_specs);
   plan->patterns.resize(n_specs);
   plan->bind.resize(n_specs);
@@ -185,6 +235,7 @@ extern "C" tgx_status tgx_plan_create(const tgx_check_spec *specs, size_t n_spec
           plan->distinct[slot].multiplicity = true;
         }
         plan->distinct[slot].approx_only = false;  // (an APPROX_DISTINCT spec may have created it)
+        if (sp.flags & TGX_FLAG_EXACT_KEYS) plan->distinct[slot].exact = true;
         plan->bind[i].slot = slot;
         break;
       }
@@ -445,6 +496,7 @@ void state_init_host(tgx_state *st, const tgx_plan *plan) {
   st->h_como.assign(plan->como.size(), z);
   st->distinct.clear();
   st->distinct.resize(plan->distinct.size());
+  for (size_t k = 0; k < plan->distinct.size(); k++) st->distinct[k].exact = plan->distinct[k].exact;
   st->h_kll.clear();
   st->h_kll.resize(plan->kll.size());
   for (size_t i = 0; i < plan->kll.size(); i++) st->h_kll[i].k = plan->kll[i].k;
@@ -516,6 +568,7 @@ extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, t
   if (!plan || !out) return fail(err, TGX_INVALID_ARGUMENT, "plan/out is NULL");
   *out = nullptr;
   tgx_state *st = new tgx_state();
+  plan->fp_key_locked.store(true);
   state_init_host(st, plan);
   st->stream = (hipStream_t)hip_stream;
   st->own_stream = false;
@@ -737,6 +790,8 @@ tgx_status distinct_totals(tgx_state *st, size_t slot, DistinctTotals *t, tgx_er
     TGX_TRY(distinct_read_counters(st, ds, c, err));
   if (c[kCntOutOfRange] != 0)
     return fail(err, TGX_INTERNAL, "distinct: %llu keys fell outside the range bitmap", c[kCntOutOfRange]);
+  if (c[kCntStoreFull] != 0)
+    return fail(err, TGX_INTERNAL, "distinct: %llu keys found no room in the key store of an exact set", c[kCntStoreFull]);
   const uint64_t empty_rows = c[kCntEmptyRows] + ds.h_empty_rows;
   t->total = (uint64_t)ds.total_rows + ds.h_total;
   t->non_null = c[kCntValidRows] + ds.h_non_null;

@@ -1,4 +1,4 @@
-// wire.cpp -- tgx_state_serialize / tgx_state_deserialize (blobs v2; term_amd/wire.py documents the layout).
+// wire.cpp -- tgx_state_serialize / tgx_state_deserialize (blobs v3; term_amd/wire.py documents the layout).
 // Split off tgx_api.cpp in round 4.
 #include "api_internal.h"
 
@@ -54,6 +54,17 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
   w.pod((uint32_t)plan->kll.size());
   w.pod((uint32_t)regex_num_tasks(plan));
   w.pod((uint32_t)plan->hll.size());
+  // the fingerprint key, when the blob holds fingerprints (a string / tuple key set that travels with its records)
+  uint32_t keyed = 0;
+  for (size_t k = 0; k < g.distinct.size(); k++) {
+    const DistinctState &ds = st->distinct[k];
+    const bool has_set = ds.mode == DistinctMode::kBitmap || ds.mode == DistinctMode::kHash;
+    if (has_set && !ds.partitioned && ds.wide) keyed = 1;
+  }
+  w.pod(keyed);
+  uint32_t key_words[4] = {0, 0, 0, 0};
+  if (keyed) memcpy(key_words, plan->fp_key.k, 16);
+  w.put(key_words, 16);
   for (auto &a : g.scan) w.pod(a);
   for (auto &a : g.count) w.pod(a);
   for (auto &a : g.como) w.pod(a);
@@ -93,6 +104,18 @@ extern "C" tgx_status tgx_state_serialize(const tgx_plan *plan, tgx_state *st, u
   return tgx::abi_exception(err);
 }
 
+extern "C" tgx_status tgx_blob_fingerprint_key(const uint8_t *buf, size_t len, uint8_t key_out[16], int32_t *keyed) {
+  if (!buf || !key_out || !keyed) return TGX_INVALID_ARGUMENT;
+  Reader r{buf, len};
+  if (r.pod<uint32_t>() != kWireMagic || r.pod<uint32_t>() != kWireVersion) return TGX_INVALID_ARGUMENT;
+  for (int i = 0; i < 7; i++) (void)r.pod<uint32_t>();
+  const uint32_t k = r.pod<uint32_t>();
+  r.get(key_out, 16);
+  if (!r.ok || k > 1) return TGX_INVALID_ARGUMENT;
+  *keyed = (int32_t)k;
+  return TGX_OK;
+}
+
 extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t *buf, size_t len,
                                             tgx_state **out, tgx_error *err) try {
   bind_thread();
@@ -107,6 +130,20 @@ extern "C" tgx_status tgx_state_deserialize(const tgx_plan *plan, const uint8_t 
       n_dist != plan->distinct.size() || n_kll != plan->kll.size() || n_regex != regex_num_tasks(plan) ||
       n_hll != plan->hll.size())
     return fail(err, TGX_INVALID_ARGUMENT, "state blob was produced by a different plan");
+  {
+    const uint32_t keyed = r.pod<uint32_t>();
+    uint8_t key[16];
+    r.get(key, 16);
+    if (!r.ok) return fail(err, TGX_INVALID_ARGUMENT, "truncated state blob");
+    if (keyed > 1) return fail(err, TGX_INVALID_ARGUMENT, "malformed state blob (key field)");
+    if (keyed && memcmp(key, plan->fp_key.k, 16) != 0) {
+      char hex[33];
+      for (int i = 0; i < 16; i++) snprintf(hex + 2 * i, 3, "%02x", key[i]);
+      return fail(err, TGX_INVALID_ARGUMENT,
+                  "the blob's string keys were made under fingerprint key %s and the plan holds another: give the plan "
+                  "that key (tgx_plan_set_fingerprint_key) before its first state", hex);
+    }
+  }
   std::unique_ptr<tgx_state, void (*)(tgx_state *)> st(new tgx_state(), tgx_state_destroy);
   state_init_host(st.get(), plan);
   for (auto &a : st->h_scan) a = r.pod<ScanAcc>();

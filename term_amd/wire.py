@@ -1,10 +1,12 @@
-"""Wire form of a tgx state (tgx_state_serialize / tgx_state_deserialize), version 2.
+"""Wire form of a tgx state (tgx_state_serialize / tgx_state_deserialize), version 3.
 
 The blob is what ranks exchange (one all-gather of a few KiB) and what a checkpoint stores; it is the
 counterpart of the serde_json analyzer states of the reference's IncrementalAnalysisRunner
 (analyzers/incremental/runner.rs:71-111).  Layout, little-endian, in plan-task order:
 
     u32 magic 'TGXS', u32 version, u32 n_scan, n_count, n_comoments, n_distinct, n_kll, n_regex, n_hll
+    u32 keyed, u8 key[16]      keyed = 1: the blob holds string / tuple keys as fingerprints made under `key`
+                               (tgx_plan_set_fingerprint_key); 0: no such keys, key = zeros
     n_scan      x ScanAcc      i64 total, non_null, min_key, max_key; u64 sum_lo; i64 sum_hi; f64 sum, comp;
                                i64 var_n; f64 var_mean, var_m2; i32 is_float, pad                    (96 B)
     n_count     x CountAcc     i64 total, non_null                                                      (16 B)
@@ -23,7 +25,7 @@ min_key / max_key are the Int64 values themselves, or the IEEE totalOrder keys o
 """
 import struct
 
-MAGIC, VERSION = 0x53584754, 2
+MAGIC, VERSION = 0x53584754, 3
 I64_MAX, I64_MIN = (1 << 63) - 1, -(1 << 63)
 
 
@@ -89,5 +91,6 @@ def hll_state(registers=None, mode=1):
 def pack(scan=(), count=(), comoments=(), distinct=(), kll=(), regex=(), hll=()):
     head = struct.pack("<9I", MAGIC, VERSION, len(scan), len(count), len(comoments), len(distinct), len(kll), len(regex),
                        len(hll))
+    head += struct.pack("<I16s", 0, bytes(16))  # (no string keys in a state packed from plain numbers)
     return (head + b"".join(scan) + b"".join(count) + b"".join(comoments) + b"".join(distinct) + b"".join(kll) +
             b"".join(regex) + b"".join(hll))

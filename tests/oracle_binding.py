@@ -136,7 +136,7 @@ def unpack_validity(validity, n):
 def utf8_from_list(values):
     """['a', None] -> (offsets int32, data uint8, validity or None)"""
     mask = np.array([v is not None for v in values], dtype=bool)
-    enc = [b"" if v is None else v.encode("utf-8") for v in values]
+    enc = [b"" if v is None else (bytes(v) if isinstance(v, (bytes, bytearray)) else v.encode("utf-8")) for v in values]
     offsets = np.zeros(len(values) + 1, dtype=np.int32)
     if enc:
         offsets[1:] = np.cumsum([len(e) for e in enc])

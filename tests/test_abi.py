@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30 and "tgx_update" in names and "tgx_host_run_suite_json" in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.tgx_abi_version() == 5
+    assert lib.tgx_abi_version() == 6
     assert lib.tgx_status_name(6) == b"TGX_NO_DEVICE"
 
 

@@ -29,7 +29,7 @@ def encode_views(vals, rng, n_buffers=3, junk_null_views=True):
                 views[i] = np.frombuffer(np.array([2**31 - 1, -1, 2**31 - 1, -1], dtype=np.int32).tobytes(), np.uint8)
             continue
         validity[i >> 3] |= 1 << (i & 7)
-        b = v.encode("utf-8")
+        b = bytes(v) if isinstance(v, (bytes, bytearray)) else v.encode("utf-8")
         views[i, 0:4] = np.frombuffer(np.int32(len(b)).tobytes(), np.uint8)
         if len(b) <= 12:
             views[i, 4:4 + len(b)] = np.frombuffer(b, np.uint8)
