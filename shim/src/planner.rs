@@ -91,6 +91,7 @@ struct Shared {
     output: RwLock<Option<RunOutput>>,
     /// see [`GpuPlanner::strict_reference_types`]
     strict_types: std::sync::atomic::AtomicBool,
+    exact_keys: std::sync::atomic::AtomicBool,
 }
 
 /// Can the stock constraint read its aggregate off a column of this type?  `StatisticalConstraint::evaluate` downcasts
@@ -186,6 +187,7 @@ impl GpuPlanner {
                 bindings: Mutex::new(Vec::new()),
                 output: RwLock::new(None),
                 strict_types: std::sync::atomic::AtomicBool::new(true),
+                exact_keys: std::sync::atomic::AtomicBool::new(true),
             }),
         }
     }
@@ -197,6 +199,17 @@ impl GpuPlanner {
     /// kernels' value for the widened column answers -- a deviation from the reference, listed in INTEGRATION.md.
     pub fn strict_reference_types(&self, on: bool) -> &Self {
         self.shared.strict_types.store(on, std::sync::atomic::Ordering::Relaxed);
+        self
+    }
+
+    /// `true` (the default): uniqueness checks over string / binary / tuple keys count by VALUE -- the library keeps
+    /// the bytes of every distinct key and confirms equal fingerprints byte by byte (`TGX_FLAG_EXACT_KEYS`), which is
+    /// `COUNT(DISTINCT c)` as DataFusion's hash aggregation computes it (constraints/uniqueness.rs:612-617, 709-715).
+    /// `false`: by keyed 128-bit fingerprint alone -- faster on big batches; two distinct values count once only if all
+    /// 128 bits agree under a key the data's producer does not know (deviations).  Applies to
+    /// uniqueness constraints created after the call.
+    pub fn exact_string_keys(&self, on: bool) -> &Self {
+        self.shared.exact_keys.store(on, std::sync::atomic::Ordering::Relaxed);
         self
     }
 
@@ -261,6 +274,9 @@ impl GpuPlanner {
         }
         if matches!(kind, UniquenessType::UniqueValueRatio(_)) {
             req.flags = TGX_FLAG_MULTIPLICITY;
+        }
+        if self.shared.exact_keys.load(std::sync::atomic::Ordering::Relaxed) {
+            req.flags |= TGX_FLAG_EXACT_KEYS;
         }
         Ok(self.bind(Arc::new(stock), if planned { vec![req] } else { vec![] }, Verdict::Uniqueness { columns, kind }))
     }

@@ -519,6 +519,7 @@ AnalyzerContext AnalysisRunner::run(const Context &ctx) const {
       s.column = column_index(r.column);
       s.column2 = r.column2.empty() ? -1 : column_index(r.column2);
       s.flags = r.flags;
+      if (r.kind == TGX_CHECK_DISTINCT) s.flags |= TGX_FLAG_EXACT_KEYS;  // DistinctnessAnalyzer counts by value
       specs.push_back(s);
     }
   };

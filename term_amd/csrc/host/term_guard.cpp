@@ -1344,6 +1344,8 @@ ValidationResult ValidationSuite::run(const Context &ctx) const {
       s.column = column_index(r.column);
       s.column2 = r.kind == TGX_CHECK_COMOMENTS ? column_index(r.column2) : -1;
       s.flags = r.flags;
+      // COUNT(DISTINCT) by VALUE, as DataFusion groups (hash + equality): string / tuple keys are kept with their bytes
+      if (r.kind == TGX_CHECK_DISTINCT && exact_keys_) s.flags |= TGX_FLAG_EXACT_KEYS;
       s.pattern = r.pattern.empty() ? nullptr : r.pattern.data();
       s.pattern_len = r.pattern.size();
       s.kll_k = r.kll_k;
@@ -1732,6 +1734,7 @@ ValidationSuite suite_from_json(const std::string &text) {
   ValidationSuite::Builder sb = ValidationSuite::builder(root.get_str("name", "suite"));
   if (root.get("table_name")) sb.table_name(root.get_str("table_name", "data"));
   if (root.get("strict_reference_types")) sb.strict_reference_types(root.get_bool("strict_reference_types"));
+  if (root.get("exact_string_keys")) sb.exact_string_keys(root.get_bool("exact_string_keys"));
   if (const json::Value *ct = root.get("column_types"))
     if (ct->is(json::Value::Object))
       for (const auto &kv : ct->obj)

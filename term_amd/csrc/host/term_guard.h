@@ -373,6 +373,7 @@ class ValidationSuite {
   std::string table_name_ = "data";  // suite.rs:549
   std::vector<Check> checks_;
   bool strict_types_ = true;
+  bool exact_keys_ = true;
   std::map<std::string, std::string> declared_types_;
 };
 class ValidationSuite::Builder {
@@ -385,6 +386,11 @@ class ValidationSuite::Builder {
   // true (default): MIN / MAX / SUM / quantiles on columns whose aggregate the reference cannot read are errors, as
   // there (reference_extracts); false: the widened value answers (a deviation)
   Builder &strict_reference_types(bool on) { suite_.strict_types_ = on; return *this; }
+  // true (default): uniqueness checks over string / binary / tuple keys count by VALUE -- equal fingerprints are
+  // confirmed byte by byte (TGX_FLAG_EXACT_KEYS), `COUNT(DISTINCT c)` as the reference's DataFusion computes it
+  // (constraints/uniqueness.rs:612-617); false: by keyed 128-bit fingerprint alone (faster on big batches; two distinct
+  // values count once only if all 128 bits agree under a key the data's producer does not know: INTEGRATION.md)
+  Builder &exact_string_keys(bool on) { suite_.exact_keys_ = on; return *this; }
   // the Arrow DataType (its Debug form: "Int32", "Date32", "Timestamp(Nanosecond, None)", "UInt8", ...) of a column of
   // the table the suite will run on; takes precedence over Table::arrow_types
   Builder &column_type(std::string column, std::string arrow_type) {

@@ -451,6 +451,13 @@ class ValidationSuiteBuilder:
         self._s["strict_reference_types"] = bool(on)
         return self
 
+    def exact_string_keys(self, on):
+        """True (default): uniqueness checks over string / binary / tuple keys count by VALUE (equal fingerprints are
+        confirmed byte by byte, TGX_FLAG_EXACT_KEYS) -- COUNT(DISTINCT c) as the reference computes it
+        (constraints/uniqueness.rs:612-617); False: by keyed 128-bit fingerprint alone (deviations)"""
+        self._s["exact_string_keys"] = bool(on)
+        return self
+
     def column_type(self, column, arrow_type):
         """the Arrow DataType of a column of the table ("Int32", "Date32", "Timestamp(Nanosecond, None)", ...); a
         pyarrow table handed to run() declares its own"""
