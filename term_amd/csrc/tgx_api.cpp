@@ -488,6 +488,7 @@ void como_acc_merge(ComomentAcc &a, const ComomentAcc &b_in) {
 
 void state_init_host(tgx_state *st, const tgx_plan *plan) {
   st->plan = plan;
+  plan->fp_key_locked.store(true);  // (every state comes through here: created, deserialized, unpacked by a reduction)
   st->col_types.assign(plan->n_columns_needed, 0);
   st->h_scan.assign(plan->scan.size(), scan_acc_identity());
   st->h_count.assign(plan->count.size(), CountAcc{0, 0});
@@ -568,7 +569,6 @@ extern "C" tgx_status tgx_state_create(const tgx_plan *plan, void *hip_stream, t
   if (!plan || !out) return fail(err, TGX_INVALID_ARGUMENT, "plan/out is NULL");
   *out = nullptr;
   tgx_state *st = new tgx_state();
-  plan->fp_key_locked.store(true);
   state_init_host(st, plan);
   st->stream = (hipStream_t)hip_stream;
   st->own_stream = false;

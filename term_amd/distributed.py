@@ -34,6 +34,24 @@ def sharded_suite_step(plan, state, columns, comm):
     return state.finalize()
 
 
+def shared_fingerprint_key(dist, rank, device=None):
+    """One fingerprint key for all ranks (tgx_plan_set_fingerprint_key): string / tuple keys travel between ranks as
+    fingerprints, which mean the same everywhere only under one key -- tgx_allreduce refuses ranks whose keys differ.
+    Rank 0 draws 16 bytes from the operating system, torch.distributed broadcasts them; pass the result as
+    `T.Plan(specs, fingerprint_key=...)` on every rank.  (Plans without string / tuple DISTINCT checks need none.)"""
+    import os
+
+    import torch
+
+    key = torch.zeros(16, dtype=torch.uint8)
+    if rank == 0:
+        key = torch.frombuffer(bytearray(os.urandom(16)), dtype=torch.uint8).clone()
+    if device is not None:
+        key = key.to(device)
+    dist.broadcast(key, src=0)
+    return bytes(key.cpu().numpy())
+
+
 # ---------------------------------------------------------------------------------------------- RCCL
 def rccl_comm(dist, rank, world, device="cuda"):
     """tgx_comm over RCCL: rank 0 draws the unique id, torch.distributed broadcasts it, every rank joins"""

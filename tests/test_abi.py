@@ -117,3 +117,32 @@ def test_blob_roundtrip_without_device():
         T.State.deserialize(plan, blob[:-3])
     with pytest.raises(T.TgxError):
         T.State.deserialize(plan, b"nope" + blob[4:])
+
+
+def test_fingerprint_key_of_a_plan(monkeypatch):
+    """tgx_plan_create draws a key from the OS (two plans differ), TGX_FINGERPRINT_KEY fixes it, the setter replaces it
+    until the plan's first state exists; a blob packed from plain numbers carries none"""
+    from term_amd import wire
+
+    sp = [spec(T.DISTINCT, 0)]
+    a, b = T.Plan(sp), T.Plan(sp)
+    assert len(a.fingerprint_key()) == 16 and a.fingerprint_key() != b.fingerprint_key() and any(a.fingerprint_key())
+    monkeypatch.setenv("TGX_FINGERPRINT_KEY", "000102030405060708090a0b0c0d0e0f")
+    assert T.Plan(sp).fingerprint_key() == bytes(range(16))
+    monkeypatch.setenv("TGX_FINGERPRINT_KEY", "not-hex")
+    with pytest.raises(T.TgxError):
+        T.Plan(sp)
+    monkeypatch.delenv("TGX_FINGERPRINT_KEY")
+    a.set_fingerprint_key(bytes(range(16, 32)))
+    assert a.fingerprint_key() == bytes(range(16, 32))
+    with pytest.raises(ValueError):
+        a.set_fingerprint_key(b"short")
+    p = T.Plan([spec(T.COUNT, 0)])
+    blob = wire.pack(count=[wire.count_acc(10, 7)])
+    assert T.blob_fingerprint_key(blob) is None
+    st = T.State.deserialize(p, blob)  # (a host-only state: the key is fixed from here on)
+    with pytest.raises(T.TgxError, match="fixed once a state"):
+        p.set_fingerprint_key(bytes(16))
+    assert st.finalize()[0].total == 10
+    with pytest.raises(T.TgxError):
+        T.blob_fingerprint_key(b"garbage")

@@ -20,7 +20,7 @@ WORKER = textwrap.dedent('''
     import term_amd as T
     from term_amd import wire
     from term_amd._lib import spec
-    from term_amd.distributed import shard_rows, torch_dist_comm
+    from term_amd.distributed import shard_rows, shared_fingerprint_key, torch_dist_comm
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -101,6 +101,11 @@ WORKER = textwrap.dedent('''
     again = T.State.deserialize(plan, merged.serialize())
     again.allreduce(comm)
     assert again.finalize()[0].total == world * n
+    # one fingerprint key for all ranks (string / tuple keys travel as fingerprints): rank 0's, broadcast
+    key = shared_fingerprint_key(dist, rank)
+    keyed = T.Plan([spec(T.DISTINCT, 0)], fingerprint_key=key)
+    assert keyed.fingerprint_key() == key and T.Plan([spec(T.DISTINCT, 0)]).fingerprint_key() != key
+    out["fp_key"] = key.hex()
     print("RESULT " + json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
@@ -133,3 +138,4 @@ def test_world2_gloo_allgather_merge(tmp_path):
         assert r["regex"] == r["want_regex"]
     # rank-ordered merge: both ranks hold the identical merged state
     assert results[0]["blob"] == results[1]["blob"]
+    assert results[0]["fp_key"] == results[1]["fp_key"] and len(results[0]["fp_key"]) == 32

@@ -250,8 +250,9 @@ def test_what_travels_between_states_is_the_keyed_fingerprint(pairs):
     # 30 values of B meet fingerprints in A: 29 their partners' (a different value: the deviation), one its own
     want = len(set(a_vals) | set(b_vals)) - (len(some) - 1)
     assert a.finalize()[0].distinct == want
+    # ... and a blob holds fingerprints only: the pair that A kept apart by its bytes is one record's worth of key there
     u = T.State.deserialize(plan, a.serialize())
-    assert u.finalize()[0].distinct == want
+    assert u.finalize()[0].distinct == want - 1
 
 
 # ---- under a key nobody chose: every input counts right on every route, exact or not ----------------------------------

@@ -34,7 +34,9 @@ def main():
     views[:, 3] = (torch.arange(args.rows, dtype=torch.int64, device="cuda") * L).to(torch.int32)
     view_col = T.Column.utf8_view(views.view(torch.uint8).view(-1), [data], validity=validity, length=args.rows)
     sets = {"COUNT(DISTINCT)": [spec(T.DISTINCT, 0)],
+            "COUNT(DISTINCT), exact key set (TGX_FLAG_EXACT_KEYS)": [spec(T.DISTINCT, 0, flags=T.FLAG_EXACT_KEYS)],
             "COUNT(DISTINCT), column held as Utf8View": [spec(T.DISTINCT, 0)],
+            "COUNT(DISTINCT), exact key set, column held as Utf8View": [spec(T.DISTINCT, 0, flags=T.FLAG_EXACT_KEYS)],
             "LENGTH between 5 and 40": [spec(T.LENGTH, 0, length_min=5, length_max=40)],
             "DISTINCT + LENGTH + '@'": [spec(T.DISTINCT, 0), spec(T.LENGTH, 0, length_min=5, length_max=40),
                                         spec(T.REGEX_MATCH, 0, pattern="@")]}
