@@ -227,8 +227,12 @@ tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *d
   if (d.length == 0) return TGX_OK;
   if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
   // the first big batch: through the partitioned lists (views read their buffers through a table staged per update)
-  // (an exact set goes through the table, where its keys' bytes are kept: the lists hold fingerprints only)
-  if (ds.mode == DistinctMode::kUndecided && !any_view && !ds.exact && fp_lists_fit_rows(d.length))
+  // (an exact set takes the lists only over the caller's own DEVICE buffers, which outlive the update: its records refer
+  //  to rows, and what turns the lists into a table later needs the rows' bytes)
+  bool exact_lists_ok = orig != nullptr && d.length < (int64_t)1 << 32;
+  if (orig)
+    for (int c2 : task.tuple) exact_lists_ok &= orig[c2].mem == TGX_MEM_DEVICE && !is_widened(orig[c2].type);
+  if (ds.mode == DistinctMode::kUndecided && !any_view && (!ds.exact || exact_lists_ok) && fp_lists_fit_rows(d.length))
     return fp_lists_tuple_update(st, slot, d, cols, err);
   if (ds.mode == DistinctMode::kUndecided) {
     ds.mode = DistinctMode::kHash;
@@ -301,8 +305,15 @@ tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
   fp_views(ds, &l1, &l2);
   ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
   unsigned long long *counters = ds.counters.as<unsigned long long>();
+  // an exact set: records carry their row, the count settles equal fingerprints on the rows' bytes
+  uint32_t *fb_lo = nullptr;
+  if (ds.exact) {
+    HIP_TRY(ds.fp_fb_lo.reserve((size_t)c.length * sizeof(uint32_t) + 16));
+    fb_lo = ds.fp_fb_lo.as<uint32_t>();
+  }
   tgx_column kept = c;
-  if (c.type == TGX_UTF8_VIEW) {
+  const bool view = c.type == TGX_UTF8_VIEW;
+  if (view) {
     // the table of data-buffer pointers the kernels read through is staged per update: the retained view gets a copy
     const size_t bytes = (size_t)std::max(c.n_variadic, 1) * sizeof(void *);
     HIP_TRY(ds.fp_buffers.reserve(bytes));
@@ -310,19 +321,25 @@ tgx_status fp_lists_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
       HIP_TRY(hipMemcpyAsync(ds.fp_buffers.p, c.variadic, (size_t)c.n_variadic * sizeof(void *), hipMemcpyDeviceToDevice,
                              st->stream));
     kept.variadic = (const uint8_t *const *)ds.fp_buffers.p;
-    launch_fp_partition_views(c.values, kept.variadic, c.validity, c.offset, c.length, l1, st->plan->fp_key, counters,
+    launch_fp_partition_views(c.values, kept.variadic, c.validity, c.offset, c.length, l1, st->plan->fp_key, fb_lo, counters,
                               st->stream);
   } else {
     launch_fp_partition_strings(c.offsets, c.data, c.validity, c.offset, c.length, c.type == TGX_LARGE_UTF8, l1,
-                                st->plan->fp_key, counters, st->stream);
+                                st->plan->fp_key, fb_lo, counters, st->stream);
   }
   launch_fp_partition_lists(l1, l2, counters, st->stream);
-  launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), l1.offered, counters, st->stream);
+  if (ds.exact)
+    launch_fp_count_exact_utf8(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), l1.offered, c.offsets, c.data,
+                               view ? c.values : nullptr, view ? kept.variadic : nullptr, c.offset, c.length,
+                               c.type == TGX_LARGE_UTF8, counters, st->stream);
+  else
+    launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), l1.offered, counters, st->stream);
   ds.mode = DistinctMode::kHash;
   ds.wide = true;
   ds.capacity = 0;  // no table yet
   ds.rows_upper_bound = 0;
   ds.fp_staged = true;
+  ds.fp_exact_lists = ds.exact;
   ds.retained.push_back(kept);  // (a DEVICE view, or a staged one looked at before the update returns)
   return TGX_OK;
 }
@@ -337,14 +354,23 @@ tgx_status fp_lists_tuple_update(tgx_state *st, size_t slot, const TupleDesc &d,
   fp_views(ds, &l1, &l2);
   ProfScope ps(st, "distinct", 0), ps_lists(st, "distinct_lists", 0);
   unsigned long long *counters = ds.counters.as<unsigned long long>();
-  launch_fp_partition_tuples(d, l1, counters, st->stream);
+  uint32_t *fb_lo = nullptr;
+  if (ds.exact) {
+    HIP_TRY(ds.fp_fb_lo.reserve((size_t)d.length * sizeof(uint32_t) + 16));
+    fb_lo = ds.fp_fb_lo.as<uint32_t>();
+  }
+  launch_fp_partition_tuples(d, l1, fb_lo, counters, st->stream);
   launch_fp_partition_lists(l1, l2, counters, st->stream);
-  launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), nullptr, counters, st->stream);  // (valid rows: level 1)
+  if (ds.exact)
+    launch_fp_count_exact_tuple(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), d, counters, st->stream);
+  else
+    launch_fp_count(l2, mult ? 1 : 0, ds.fp_per_list.as<uint2>(), nullptr, counters, st->stream);  // (valid rows: level 1)
   ds.mode = DistinctMode::kHash;
   ds.wide = true;
   ds.capacity = 0;  // no table yet
   ds.rows_upper_bound = 0;
   ds.fp_staged = true;
+  ds.fp_exact_lists = ds.exact;
   for (const tgx_column *c : cols) ds.retained.push_back(*c);
   return TGX_OK;
 }
@@ -363,7 +389,11 @@ tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
     ds.total_rows += c.length;
     if (c.length == 0) return TGX_OK;
     if (ds.fp_staged) TGX_TRY(distinct_resolve(st, slot, err));  // a second batch: the table takes over
-    if (ds.mode == DistinctMode::kUndecided && !ds.exact && fp_lists_fit(c)) return fp_lists_update(st, slot, c, err);
+    // (an exact set takes the lists only over the caller's own DEVICE buffers, which outlive the update: its records
+    //  refer to rows, and what turns the lists into a table later needs the rows' bytes)
+    const bool exact_lists_ok = orig && orig->mem == TGX_MEM_DEVICE && c.length < (int64_t)1 << 32;
+    if (ds.mode == DistinctMode::kUndecided && (!ds.exact || exact_lists_ok) && fp_lists_fit(c))
+      return fp_lists_update(st, slot, c, err);
     if (ds.mode == DistinctMode::kUndecided) {
       ds.mode = DistinctMode::kHash;
       ds.wide = true;
@@ -886,7 +916,11 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
     unsigned long long c[kNumDistinctCounters];
     TGX_TRY(distinct_read_counters(st, ds, c, err));
     ds.fp_staged = false;
-    if (c[kCntOutOfRange] != 0) {
+    // an exact set's lists hold (part of the fingerprint, row): what makes a table of them is the batch itself, through
+    // the table path, while the batch is still there -- and the fingerprints alone once it has been released
+    const bool exact_lists = ds.fp_exact_lists;
+    ds.fp_exact_lists = false;
+    if (c[kCntOutOfRange] != 0 || (exact_lists && !ds.retained.empty())) {
       if (ds.retained.empty())
         return fail(err, TGX_INTERNAL, "distinct: overflowed fingerprint lists and no batch to redo");
       HIP_TRY(hipMemsetAsync(ds.counters.p, 0, kNumDistinctCounters * sizeof(unsigned long long), st->stream));
@@ -898,6 +932,11 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
         TGX_TRY(tuple_desc_of(cols, mult, &d, err));
         d.key = st->plan->fp_key;
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)d.length, err));
+        if (ds.exact) {
+          TGX_TRY(key_store_measure_begin(st, ds, err));
+          launch_exact_measure_tuple(d, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
+          TGX_TRY(key_store_reserve_measured(st, ds, err));
+        }
         launch_distinct_tuple(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
       } else
       for (const tgx_column &kept : ds.retained) {
@@ -915,11 +954,25 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
           launch_distinct_hash(d, hash_view(ds), ds.counters.as<unsigned long long>(), st->stream);
           continue;
         }
+        if (ds.exact) TGX_TRY(key_store_reserve_utf8(st, ds, col, err));
         const bool view = col.type == TGX_UTF8_VIEW;
         launch_distinct_utf8(col.offsets, col.data, view ? col.values : nullptr, view ? col.variadic : nullptr,
                              col.validity, col.offset, col.length, col.type == TGX_LARGE_UTF8, mult ? 1 : 0,
                              hash_view(ds), st->plan->fp_key, ds.counters.as<unsigned long long>(), st->stream);
       }
+    } else if (exact_lists) {
+      // the batch is gone (tgx_finalize handed it back): the keys go on as their 128-bit fingerprints
+      FpLists l1, l2;
+      fp_views(ds, &l1, &l2);
+      TGX_TRY(hash_ensure(st, ds, mult, c[kCntDistinct], err));
+      unsigned long long cur = 0;
+      HIP_TRY(hipMemcpyAsync(&cur, ds.key_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st->stream));
+      HIP_TRY(hipStreamSynchronize(st->stream));
+      // (one entry of two words per distinct fingerprint; values that shared one were told apart by the lists and
+      //  are one entry from here on)
+      TGX_TRY(key_store_ensure(st, ds, cur, 2 * (c[kCntDistinct] + 1), err));
+      launch_fp_demote(l2, ds.fp_fb_lo.as<uint32_t>(), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
+                       st->stream);
     } else {
       FpLists l1, l2;
       fp_views(ds, &l1, &l2);
@@ -987,8 +1040,9 @@ tgx_status tgx::distinct_resolve_all(tgx_state *st, tgx_error *err) {
   memcpy(all.data(), st->h_pinned, all.size() * sizeof(unsigned long long));
   for (size_t k = 0; k < st->distinct.size(); k++) {
     DistinctState &ds = st->distinct[k];
+    // (an exact set on the lists: the batch is about to be released -- its keys move into the table, bytes and all)
     if ((ds.speculative || ds.fp_staged) && !ds.retained.empty() &&
-        all[k * kNumDistinctCounters + kCntOutOfRange] != 0)
+        (all[k * kNumDistinctCounters + kCntOutOfRange] != 0 || (ds.fp_staged && ds.fp_exact_lists)))
       TGX_TRY(distinct_resolve(st, k, err));
     else {
       ds.retained.clear();

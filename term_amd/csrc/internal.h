@@ -121,12 +121,21 @@ void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned lo
 // big Utf8 batches: fingerprints partitioned into lists, deduplicated list by list in LDS (distinct128.hip, fp_*)
 void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                                  int64_t length, int large_offsets, const FpLists &level1, const FpKey &key,
-                                 unsigned long long *d_counters, hipStream_t stream);
+                                 uint32_t *exact_fb_lo, unsigned long long *d_counters, hipStream_t stream);
 void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
                                int64_t offset, int64_t length, const FpLists &level1, const FpKey &key,
-                               unsigned long long *d_counters, hipStream_t stream);
-void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, unsigned long long *d_counters,
+                               uint32_t *exact_fb_lo, unsigned long long *d_counters, hipStream_t stream);
+void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, uint32_t *exact_fb_lo,
+                                unsigned long long *d_counters, hipStream_t stream);
+// exact sets: the lists' records carry rows; equal fingerprints are settled on the rows' bytes
+void launch_fp_count_exact_utf8(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
+                                const void *offsets, const uint8_t *data, const void *views, const uint8_t *const *buffers,
+                                int64_t offset, int64_t length, int large_offsets, unsigned long long *d_counters,
                                 hipStream_t stream);
+void launch_fp_count_exact_tuple(const FpLists &level2, int want_mult, uint2 *per_list, const TupleDesc &d,
+                                 unsigned long long *d_counters, hipStream_t stream);
+void launch_fp_demote(const FpLists &level2, const uint32_t *fb_lo, const HashSetView &t, int want_mult,
+                      unsigned long long *d_counters, hipStream_t stream);
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
                                hipStream_t stream);
 void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
@@ -397,6 +406,10 @@ struct DistinctState {
   uint64_t fp_cap1 = 0, fp_cap2 = 0;
   DevBuf fp_level1, fp_level2, fp_offered, fp_per_list;
   DevBuf fp_buffers;  // Utf8View batches: the retained view's table of data-buffer pointers (the update's own is staged)
+  // exact sets on the lists: records carry (half of the second fingerprint word, row); the other half waits here, per
+  // row, for the day the batch is released while the lists are still the key set (fp_demote_kernel)
+  DevBuf fp_fb_lo;
+  bool fp_exact_lists = false;
   // second bitmap pair: tgx_distinct_adopt_slices builds the owned slice here and swaps, so a state that is
   // reset and refilled every step never frees or allocates (hipMalloc/hipFree of 125 MB cost ~0.3 ms a step)
   DevBuf spare_seen, spare_twice;

@@ -1435,12 +1435,12 @@ void launch_key_lists(const DistinctColDesc &d, const FpLists &level1, const FpL
                      level1, tiles_per_list, level2, d_counters);
   const dim3 grid(kFpFan * kFpFan);
   if (level2.cap <= 3072)
-    hipLaunchKernelGGL((fp_count_kernel<4096, 256, KeyRec>), grid, dim3(256), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan));
+    hipLaunchKernelGGL((fp_count_kernel<4096, 256, KeyRec>), grid, dim3(256), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan), PlainEq());
   else if (level2.cap <= 12288)
-    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, KeyRec>), grid, dim3(1024), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan));
+    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, KeyRec>), grid, dim3(1024), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan), PlainEq());
   else
     hipLaunchKernelGGL((fp_count_kernel<32768, 1024, KeyRec>), dim3(fp_resident_grid()), dim3(1024), 0, stream, level2, want_mult,
-                       per_list, (uint32_t)(kFpFan * kFpFan));  // one workgroup per CU, each walking its share of the lists
+                       per_list, (uint32_t)(kFpFan * kFpFan), PlainEq());  // one workgroup per CU, each walking its share of the lists
   hipLaunchKernelGGL(fp_totals_kernel<KeyRec>, dim3(64), dim3(256), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan),
                      level1.offered, d_counters);
 }

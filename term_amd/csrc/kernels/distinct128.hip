@@ -270,7 +270,24 @@ __device__ __forceinline__ int hash_insert_exact(const HashSetView &t, uint64_t 
       // the owner: room in the store, the entry, a release fence, then the reference (lanes that meet the claimed
       // slot meanwhile go round the loop again without moving on, as in hash_insert128)
       const uint64_t n = 2 + key.payload_words();
-      uint64_t at = atomicAdd(t.store_cursor, (unsigned long long)n);
+      // ONE reservation for all lanes of the wave that became owners in this trip round the loop (a cursor bumped
+      // by every new key is a single address: ~1 ns per key chip-wide, 100 ms per 100 M new keys)
+      uint64_t at;
+      {
+        const unsigned long long owners = __builtin_amdgcn_ballot_w64(true);  // the lanes in this branch
+        const int me = (int)(threadIdx.x & 63), first = __builtin_ctzll(owners);
+        uint64_t before = 0, total = 0;
+        for (unsigned long long m = owners; m; m &= m - 1) {
+          const int l = __builtin_ctzll(m);
+          const uint64_t nl = (uint64_t)__shfl((unsigned long long)n, l, 64);
+          before = l == me ? total : before;
+          total += nl;
+        }
+        unsigned long long base = 0;
+        if (me == first) base = atomicAdd(t.store_cursor, (unsigned long long)total);
+        base = __shfl(base, first, 64);
+        at = base + before;
+      }
       if (at + n > t.store_words) {
         atomicAdd(&counters[kCntStoreFull], 1ull);  // (the host sized the store for the worst case: never)
         at = 0;                                      // word 0..1 of the store: a fingerprint-only stand-in entry
@@ -480,7 +497,12 @@ __device__ __forceinline__ void fingerprint_lds2(const FpKey &key, const uint8_t
 // fingerprinted from there (per-lane global loads at a ~28-byte stride read the column at 1.5 TB/s).  The pipeline
 // is three steps deep: offsets of step s+2 and bytes of step s+1 (in registers) are in flight while step s is
 // fingerprinted.  A span that does not fit the stage is fingerprinted straight from global memory.
-__global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d, FpLists out,
+// EXACT (TGX_FLAG_EXACT_KEYS): a record's second word keeps the high half of the second fingerprint word and carries the
+// ROW in its low half (fp_count_kernel settles equal fingerprints by comparing the rows' bytes: ExactUtf8Eq); the low
+// half goes to fb_lo[row], from where a key set whose batch has been released can still be told as 128-bit
+// fingerprints (fp_demote_kernel).
+template <bool EXACT>
+__global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d, FpLists out, uint32_t *fb_lo,
                                                                     unsigned long long *counters) {
   constexpr int kRowsPerWave = kFpTile / 4, kSteps = kRowsPerWave / 128;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -573,6 +595,17 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
     }
     if (!cur.v0) r0.x = kEmptyKey;
     if (!cur.v1) r1.x = kEmptyKey;
+    if (EXACT) {
+      const int64_t i0 = wave_first + step * 128 + lane;
+      if (cur.v0) {
+        fb_lo[i0] = (uint32_t)r0.y;
+        r0.y = (r0.y & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)i0;
+      }
+      if (cur.v1) {
+        fb_lo[i0 + 64] = (uint32_t)r1.y;
+        r1.y = (r1.y & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)(i0 + 64);
+      }
+    }
     if (r0.x != kEmptyKey) atomicAdd(&s.hist[r0.x >> 56], 1u);
     if (r1.x != kEmptyKey) atomicAdd(&s.hist[r1.x >> 56], 1u);
     mine[2 * step] = r0;
@@ -606,7 +639,8 @@ __device__ __forceinline__ void fingerprint_words(const FpKey &key, uint64_t w0,
 // values of its 128 rows lie in ONE buffer within a span that fits the stage: then the span is copied into LDS with
 // 16-byte loads and fingerprinted there like a plain Utf8 column; otherwise every lane reads its own from global
 // memory (3.1 -> 2.6 ms per 100 M x 28 B with the span staged).
-__global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, FpLists out,
+template <bool EXACT>
+__global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, FpLists out, uint32_t *fb_lo,
                                                                   unsigned long long *counters) {
   constexpr int kRowsPerWave = kFpTile / 4, kSteps = kRowsPerWave / 128;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -702,6 +736,17 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
       fingerprint_words(d.key, (uint64_t)r1.v.y | ((uint64_t)r1.v.z << 32), (uint64_t)r1.v.w, len1, (uint64_t *)&f1.x, (uint64_t *)&f1.y);
     if (!r0.valid) f0.x = kEmptyKey;
     if (!r1.valid) f1.x = kEmptyKey;
+    if (EXACT) {
+      const int64_t i0 = wave_first + step * 128 + lane;
+      if (r0.valid) {
+        fb_lo[i0] = (uint32_t)f0.y;
+        f0.y = (f0.y & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)i0;
+      }
+      if (r1.valid) {
+        fb_lo[i0 + 64] = (uint32_t)f1.y;
+        f1.y = (f1.y & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)(i0 + 64);
+      }
+    }
     if (f0.x != kEmptyKey) atomicAdd(&s.hist[f0.x >> 56], 1u);
     if (f1.x != kEmptyKey) atomicAdd(&s.hist[f1.x >> 56], 1u);
     mine[2 * step] = f0;
@@ -709,6 +754,43 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
   }
   __syncthreads();
   fp_tile_scatter16(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
+}
+
+// ---- exact lists: when are two records one key? ------------------------------------------------------------------
+__device__ __forceinline__ bool utf8_rows_equal(const Utf8ColDesc &d, int64_t ra, int64_t rb) {
+  uintptr_t pa, pb;
+  uint64_t la, lb;
+  utf8_value(d, d.offset + ra, &pa, &la);
+  utf8_value(d, d.offset + rb, &pb, &lb);
+  if (la != lb) return false;
+  GlobalWords a{pa, la}, b{pb, lb};
+  while (a.remaining > 0)
+    if (a.next() != b.next()) return false;
+  return true;
+}
+struct ExactUtf8Eq {
+  Utf8ColDesc d;
+  __device__ __forceinline__ bool operator()(const ulonglong2 &a, const ulonglong2 &b) const {
+    if (a.x != b.x || (a.y >> 32) != (b.y >> 32)) return false;
+    const uint32_t ra = (uint32_t)a.y, rb = (uint32_t)b.y;
+    return ra == rb || utf8_rows_equal(d, (int64_t)ra, (int64_t)rb);
+  }
+};
+// An exact set's lists whose batch has been released (tgx_finalize hands the caller's buffers back): what is left of a
+// key is its 128-bit fingerprint -- the record's two words with the low half of the second restored from fb_lo[row] --
+// and that is what goes into the table, as an entry without bytes.  (The counters stay as the lists left them.)
+__global__ __launch_bounds__(256) void fp_demote_kernel(FpLists l, const uint32_t *fb_lo, HashSetView t, int want_mult,
+                                                         unsigned long long *counters) {
+  const uint32_t offered = l.offered[blockIdx.x];
+  const uint32_t n = offered < l.cap ? offered : (uint32_t)l.cap;
+  const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const ulonglong2 r = recs[i];
+    uint64_t fb = (r.y & 0xFFFFFFFF00000000ull) | (uint64_t)fb_lo[(uint32_t)r.y];
+    if (fb == kEmptyKey) fb -= 1;
+    int became_dup = 0;
+    (void)hash_insert_exact(t, r.x, fb, FpOnlyKey{}, want_mult, 0, &became_dup, counters);
+  }
 }
 
 // the lists' records into the global table (counted already: no counters)
@@ -947,6 +1029,27 @@ struct TupleKey {
   }
 };
 
+struct ExactTupleEq {
+  TupleDesc d;
+  __device__ __forceinline__ bool operator()(const ulonglong2 &a, const ulonglong2 &b) const {
+    if (a.x != b.x || (a.y >> 32) != (b.y >> 32)) return false;
+    const int64_t ra = (int64_t)(uint32_t)a.y, rb = (int64_t)(uint32_t)b.y;
+    if (ra == rb) return true;
+    for (int c = 0; c < d.n_cols; c++) {
+      const TupleComp x = tuple_component(d, c, ra), y = tuple_component(d, c, rb);
+      if (x.kind != y.kind) return false;
+      if (x.kind == 1 && x.value != y.value) return false;
+      if (x.kind == 2) {
+        if (x.len != y.len) return false;
+        GlobalWords wa{x.p, x.len}, wb{y.p, y.len};
+        while (wa.remaining > 0)
+          if (wa.next() != wb.next()) return false;
+      }
+    }
+    return true;
+  }
+};
+
 template <bool EXACT>
 __global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSetView t, unsigned long long *counters) {
   unsigned long long n_new = 0, n_dup = 0, n_valid = 0;
@@ -978,7 +1081,9 @@ __global__ __launch_bounds__(256) void exact_measure_tuple_kernel(TupleDesc d, u
 
 // level 1 of the lists for tuples: EVERY row is a record (a tuple with NULL components is a value of its own); the
 // rows whose components are all non-NULL are counted on the side (one add per workgroup)
-__global__ __launch_bounds__(256) void fp_partition_tuples_kernel(TupleDesc d, FpLists out, unsigned long long *counters) {
+template <bool EXACT>
+__global__ __launch_bounds__(256) void fp_partition_tuples_kernel(TupleDesc d, FpLists out, uint32_t *fb_lo,
+                                                                   unsigned long long *counters) {
   constexpr int PER = kFpTile / 256;
   __shared__ FpTileLds s;
   __shared__ uint32_t s_valid;
@@ -996,6 +1101,10 @@ __global__ __launch_bounds__(256) void fp_partition_tuples_kernel(TupleDesc d, F
     if (row < d.length) {
       bool all_valid;
       tuple_fingerprint(d, row, (uint64_t *)&r.x, (uint64_t *)&r.y, &all_valid);
+      if (EXACT) {
+        fb_lo[row] = (uint32_t)r.y;
+        r.y = (r.y & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)row;
+      }
       n_valid += all_valid ? 1u : 0u;
       atomicAdd(&s.hist[r.x >> 56], 1u);
     }
@@ -1129,7 +1238,7 @@ void launch_exact_measure_tuple(const TupleDesc &d, unsigned long long *out, hip
 
 void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset,
                                  int64_t length, int large_offsets, const FpLists &level1, const FpKey &key,
-                                 unsigned long long *d_counters, hipStream_t stream) {
+                                 uint32_t *exact_fb_lo, unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
   memset(&d, 0, sizeof(d));
   d.key = key;
@@ -1140,12 +1249,17 @@ void launch_fp_partition_strings(const void *offsets, const uint8_t *data, const
   d.length = length;
   d.large_offsets = large_offsets;
   const int64_t tiles = (length + kFpTile - 1) / kFpTile;
-  hipLaunchKernelGGL(fp_partition_strings_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
+  if (exact_fb_lo)
+    hipLaunchKernelGGL(fp_partition_strings_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, exact_fb_lo,
+                       d_counters);
+  else
+    hipLaunchKernelGGL(fp_partition_strings_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1,
+                       (uint32_t *)nullptr, d_counters);
 }
 
 void launch_fp_partition_views(const void *views, const uint8_t *const *buffers, const uint8_t *validity,
                                int64_t offset, int64_t length, const FpLists &level1, const FpKey &key,
-                               unsigned long long *d_counters, hipStream_t stream) {
+                               uint32_t *exact_fb_lo, unsigned long long *d_counters, hipStream_t stream) {
   Utf8ColDesc d;
   memset(&d, 0, sizeof(d));
   d.key = key;
@@ -1155,13 +1269,23 @@ void launch_fp_partition_views(const void *views, const uint8_t *const *buffers,
   d.offset = offset;
   d.length = length;
   const int64_t tiles = (length + kFpTile - 1) / kFpTile;
-  hipLaunchKernelGGL(fp_partition_views_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
+  if (exact_fb_lo)
+    hipLaunchKernelGGL(fp_partition_views_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, exact_fb_lo,
+                       d_counters);
+  else
+    hipLaunchKernelGGL(fp_partition_views_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1,
+                       (uint32_t *)nullptr, d_counters);
 }
 
-void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, unsigned long long *d_counters,
-                                hipStream_t stream) {
+void launch_fp_partition_tuples(const TupleDesc &d, const FpLists &level1, uint32_t *exact_fb_lo,
+                                unsigned long long *d_counters, hipStream_t stream) {
   const int64_t tiles = (d.length + kFpTile - 1) / kFpTile;
-  hipLaunchKernelGGL(fp_partition_tuples_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, d_counters);
+  if (exact_fb_lo)
+    hipLaunchKernelGGL(fp_partition_tuples_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1, exact_fb_lo,
+                       d_counters);
+  else
+    hipLaunchKernelGGL(fp_partition_tuples_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, stream, d, level1,
+                       (uint32_t *)nullptr, d_counters);
 }
 
 void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, unsigned long long *d_counters,
@@ -1171,20 +1295,53 @@ void launch_fp_partition_lists(const FpLists &level1, const FpLists &level2, uns
                      tiles_per_list, level2, d_counters);
 }
 
-void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
-                     unsigned long long *d_counters, hipStream_t stream) {
+template <class EQ>
+static void launch_fp_count_eq(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
+                               unsigned long long *d_counters, hipStream_t stream, const EQ &eq) {
   // the table holds a list at load <= 3/4: 16 KiB of LDS (eight workgroups a CU) up to 3072 records a list, i.e.
   // batches up to ~157 M rows; 64 / 128 KiB for batches up to ~0.6 / ~1.4 G rows
   const dim3 grid(kFpFan * kFpFan);
   if (level2.cap <= 3072)
-    hipLaunchKernelGGL((fp_count_kernel<4096, 256, ulonglong2>), grid, dim3(256), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan));
+    hipLaunchKernelGGL((fp_count_kernel<4096, 256, ulonglong2, EQ>), grid, dim3(256), 0, stream, level2, want_mult, per_list,
+                       (uint32_t)(kFpFan * kFpFan), eq);
   else if (level2.cap <= 12288)
-    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, ulonglong2>), grid, dim3(1024), 0, stream, level2, want_mult, per_list, (uint32_t)(kFpFan * kFpFan));
+    hipLaunchKernelGGL((fp_count_kernel<16384, 1024, ulonglong2, EQ>), grid, dim3(1024), 0, stream, level2, want_mult, per_list,
+                       (uint32_t)(kFpFan * kFpFan), eq);
   else
-    hipLaunchKernelGGL((fp_count_kernel<32768, 1024, ulonglong2>), dim3(fp_resident_grid()), dim3(1024), 0, stream, level2, want_mult,
-                       per_list, (uint32_t)(kFpFan * kFpFan));  // one workgroup per CU, each walking its share of the lists
+    hipLaunchKernelGGL((fp_count_kernel<32768, 1024, ulonglong2, EQ>), dim3(fp_resident_grid()), dim3(1024), 0, stream, level2,
+                       want_mult, per_list, (uint32_t)(kFpFan * kFpFan), eq);  // one workgroup per CU, each walking its share of the lists
   hipLaunchKernelGGL(fp_totals_kernel<ulonglong2>, dim3(64), dim3(256), 0, stream, per_list, (uint32_t)(kFpFan * kFpFan), offered1,
                      d_counters);
+}
+void launch_fp_count(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
+                     unsigned long long *d_counters, hipStream_t stream) {
+  launch_fp_count_eq(level2, want_mult, per_list, offered1, d_counters, stream, PlainEq());
+}
+// exact sets: equal fingerprints are settled on the rows' bytes (the batch the records were made from)
+void launch_fp_count_exact_utf8(const FpLists &level2, int want_mult, uint2 *per_list, const uint32_t *offered1,
+                                const void *offsets, const uint8_t *data, const void *views, const uint8_t *const *buffers,
+                                int64_t offset, int64_t length, int large_offsets, unsigned long long *d_counters,
+                                hipStream_t stream) {
+  ExactUtf8Eq eq;
+  memset(&eq, 0, sizeof(eq));
+  eq.d.offsets = offsets;
+  eq.d.data = data;
+  eq.d.views = views;
+  eq.d.buffers = buffers;
+  eq.d.offset = offset;
+  eq.d.length = length;
+  eq.d.large_offsets = large_offsets;
+  launch_fp_count_eq(level2, want_mult, per_list, offered1, d_counters, stream, eq);
+}
+void launch_fp_count_exact_tuple(const FpLists &level2, int want_mult, uint2 *per_list, const TupleDesc &d,
+                                 unsigned long long *d_counters, hipStream_t stream) {
+  ExactTupleEq eq;
+  eq.d = d;
+  launch_fp_count_eq(level2, want_mult, per_list, nullptr, d_counters, stream, eq);
+}
+void launch_fp_demote(const FpLists &level2, const uint32_t *fb_lo, const HashSetView &t, int want_mult,
+                      unsigned long long *d_counters, hipStream_t stream) {
+  hipLaunchKernelGGL(fp_demote_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, fb_lo, t, want_mult, d_counters);
 }
 
 void launch_fp_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream) {

@@ -124,9 +124,17 @@ __global__ __launch_bounds__(256) void fp_partition_lists_kernel(FpLists in, uin
 // gridDim.x < n_lists: a workgroup takes lists blockIdx.x, blockIdx.x + gridDim.x, ... (the 128 KiB table leaves room
 // for one workgroup a CU: one per CU that stays, instead of 65 536 that come and go, spares their set-up: 4.84 -> 4.52 ms
 // per 1 G keys.  Tried and dropped there: 16-byte loads of two 8-byte records, 4.72 ms; two walks with half the table, 7.2)
-template <uint32_t SLOTS, uint32_t THREADS, class REC>  // THREADS: 256 for the small table, 1024 for the big ones (one
-                                                        // or two workgroups fit a CU then: the waves come from inside)
-__global__ __launch_bounds__(THREADS) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list, uint32_t n_lists) {
+// EQ: when are two records the same key?  PlainEq: when they are equal (a record IS its key: a mixed 8-byte key, a
+// 128-bit fingerprint).  The exact string / tuple sets (distinct128.hip, ExactUtf8Eq / ExactTupleEq) carry a row number
+// in their records and settle equal fingerprints by comparing the rows' bytes.
+struct PlainEq {
+  template <class REC>
+  __device__ __forceinline__ bool operator()(const REC &a, const REC &b) const { return rec_equal(a, b); }
+};
+template <uint32_t SLOTS, uint32_t THREADS, class REC, class EQ = PlainEq>  // THREADS: 256 for the small table, 1024 for
+                                                        // the big ones (one or two workgroups fit a CU then: the waves come from inside)
+__global__ __launch_bounds__(THREADS) void fp_count_kernel(FpLists l, int want_mult, uint2 *per_list, uint32_t n_lists,
+                                                            EQ same) {
   // a slot is (16 bits of the first word) << 16 | index of the record that owns it: ONE 32-bit compare-and-swap claims
   // it and names the owner (16 KiB of table: eight workgroups a CU).  Equal tags are settled by reading the owner's
   // record back from the list (it has just come through this CU's caches); tag, slot and list together fix 44 bits,
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(THREADS) void fp_count_kernel(FpLists l, int want_m
         }
         if ((old >> 16) == tag) {
           const REC o = recs[old & 0xFFFFu];
-          if (rec_equal(o, r[j])) {
+          if (same(o, r[j])) {
             if (want_mult) {
               const uint32_t bit = 1u << (hs & 31);
               const uint32_t prev = atomicOr(&dupw[hs >> 5], bit);

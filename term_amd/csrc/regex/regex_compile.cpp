@@ -909,29 +909,95 @@ struct Nfa {
     return (int)st.size() - 1;
   }
 
-  // byte-range trie of a class's sequences, all leaves -> next
-  int build_class(const std::vector<ByteSeq> &seqs, size_t a, size_t b, int depth, int next) {
-    // seqs[a..b) share their first `depth` byte ranges; group by range at `depth`
-    int alt = -1;
+  // A class as a MINIMAL acyclic byte automaton: the trie of its UTF-8 sequences with equal sub-tries shared (nodes
+  // are hash-consed bottom-up; neighbouring byte ranges that lead to the same node are one edge).  \w is ~2 000
+  // trie states and a few dozen nodes.  A counted repeat instantiates the class once per copy: what the subset
+  // construction sees per copy is the NODES, which is what lets `^\w{1,64}$` or `^[\p{L}\p{M}\s'-]{1,100}$` through
+  // the state limit (round 6; before, every copy brought the whole trie).
+  struct DagEdge {
+    uint8_t lo, hi;
+    int child;  // node id; -1 = the class is complete
+    bool operator<(const DagEdge &o) const {
+      if (lo != o.lo) return lo < o.lo;
+      if (hi != o.hi) return hi < o.hi;
+      return child < o.child;
+    }
+  };
+  struct ClassDag {
+    std::vector<std::vector<DagEdge>> nodes;  // children before parents
+    int root = -1;                            // -1: the empty class
+  };
+  std::map<std::vector<std::pair<uint32_t, uint32_t>>, ClassDag> dag_cache;
+
+  static int dag_node(ClassDag &dag, std::map<std::vector<DagEdge>, int> &memo, std::vector<DagEdge> edges) {
+    std::sort(edges.begin(), edges.end());
+    std::vector<DagEdge> merged;
+    for (const DagEdge &e : edges) {
+      if (!merged.empty() && merged.back().child == e.child && (int)merged.back().hi + 1 == (int)e.lo)
+        merged.back().hi = e.hi;
+      else
+        merged.push_back(e);
+    }
+    auto it = memo.find(merged);
+    if (it != memo.end()) return it->second;
+    dag.nodes.push_back(merged);
+    memo[merged] = (int)dag.nodes.size() - 1;
+    return (int)dag.nodes.size() - 1;
+  }
+  // seqs[a..b) share their first `depth` byte ranges; group by the range at `depth`
+  static int dag_build(ClassDag &dag, std::map<std::vector<DagEdge>, int> &memo, const std::vector<ByteSeq> &seqs, size_t a,
+                       size_t b, int depth) {
+    std::vector<DagEdge> edges;
     size_t i = a;
-    std::vector<int> heads;
     while (i < b) {
       size_t j = i + 1;
       while (j < b && seqs[j].lo[depth] == seqs[i].lo[depth] && seqs[j].hi[depth] == seqs[i].hi[depth] &&
              seqs[j].n == seqs[i].n)
         j++;
-      int target;
-      if (seqs[i].n == depth + 1)
-        target = next;
-      else
-        target = build_class(seqs, i, j, depth + 1, next);
-      heads.push_back(add(NState::kByte, target, -1, seqs[i].lo[depth], seqs[i].hi[depth]));
+      const int child = seqs[i].n == depth + 1 ? -1 : dag_build(dag, memo, seqs, i, j, depth + 1);
+      edges.push_back({seqs[i].lo[depth], seqs[i].hi[depth], child});
       i = j;
     }
-    if (heads.empty()) return -1;
-    alt = heads.back();
-    for (size_t k = heads.size() - 1; k-- > 0;) alt = add(NState::kSplit, heads[k], alt);
-    return alt;
+    return dag_node(dag, memo, std::move(edges));
+  }
+  const ClassDag &class_dag(const ClassSet &cls) {
+    std::vector<std::pair<uint32_t, uint32_t>> key;
+    for (const Range &r : cls) key.emplace_back(r.lo, r.hi);
+    auto it = dag_cache.find(key);
+    if (it != dag_cache.end()) return it->second;
+    ClassDag dag;
+    std::vector<ByteSeq> seqs;
+    utf8_sequences(cls, &seqs);
+    if (!seqs.empty()) {
+      std::sort(seqs.begin(), seqs.end(), [](const ByteSeq &x, const ByteSeq &y) {
+        if (x.n != y.n) return x.n < y.n;
+        for (int i = 0; i < x.n; i++) {
+          if (x.lo[i] != y.lo[i]) return x.lo[i] < y.lo[i];
+          if (x.hi[i] != y.hi[i]) return x.hi[i] < y.hi[i];
+        }
+        return false;
+      });
+      std::map<std::vector<DagEdge>, int> memo;
+      // (sequences of different lengths never share a first byte range: one root over all of them)
+      dag.root = dag_build(dag, memo, seqs, 0, seqs.size(), 0);
+    }
+    return dag_cache.emplace(std::move(key), std::move(dag)).first->second;
+  }
+  // one copy of the class in front of `next`
+  int instantiate(const ClassDag &dag, int next) {
+    if (dag.root < 0) return add(NState::kByte, next, -1, 1, 0);  // empty class: matches nothing
+    std::vector<int> entry(dag.nodes.size(), -1);
+    for (size_t k = 0; k < dag.nodes.size(); k++) {  // children come first
+      const std::vector<DagEdge> &edges = dag.nodes[k];
+      int alt = -1;
+      for (size_t e = edges.size(); e-- > 0;) {
+        const int target = edges[e].child < 0 ? next : entry[(size_t)edges[e].child];
+        const int head = add(NState::kByte, target, -1, edges[e].lo, edges[e].hi);
+        alt = alt < 0 ? head : add(NState::kSplit, head, alt);
+      }
+      entry[k] = alt;
+    }
+    return entry[(size_t)dag.root];
   }
 
   int compile(const Node *n, int next) {
@@ -955,20 +1021,8 @@ struct Nfa {
         return add(NState::kAssertUWordB, next);
       case Node::kUNotWordB:
         return add(NState::kAssertUNotWordB, next);
-      case Node::kClass: {
-        std::vector<ByteSeq> seqs;
-        utf8_sequences(n->cls, &seqs);
-        if (seqs.empty()) return add(NState::kByte, next, -1, 1, 0);  // empty class: matches nothing
-        std::sort(seqs.begin(), seqs.end(), [](const ByteSeq &x, const ByteSeq &y) {
-          if (x.n != y.n) return x.n < y.n;
-          for (int i = 0; i < x.n; i++) {
-            if (x.lo[i] != y.lo[i]) return x.lo[i] < y.lo[i];
-            if (x.hi[i] != y.hi[i]) return x.hi[i] < y.hi[i];
-          }
-          return false;
-        });
-        return build_class(seqs, 0, seqs.size(), 0, next);
-      }
+      case Node::kClass:
+        return instantiate(class_dag(n->cls), next);
       case Node::kConcat: {
         int cur = next;
         for (size_t i = n->kids.size(); i-- > 0;) cur = compile(n->kids[i].get(), cur);
@@ -1141,18 +1195,8 @@ struct WordClassifier {
     Nfa cn;
     const int tw = cn.add(NState::kMatch), to = cn.add(NState::kMatch);
     auto head = [&](const ClassSet &cs, int term) -> int {
-      std::vector<ByteSeq> seqs;
-      utf8_sequences(cs, &seqs);
-      if (seqs.empty()) return -1;
-      std::sort(seqs.begin(), seqs.end(), [](const ByteSeq &x, const ByteSeq &y) {
-        if (x.n != y.n) return x.n < y.n;
-        for (int i = 0; i < x.n; i++) {
-          if (x.lo[i] != y.lo[i]) return x.lo[i] < y.lo[i];
-          if (x.hi[i] != y.hi[i]) return x.hi[i] < y.hi[i];
-        }
-        return false;
-      });
-      return cn.build_class(seqs, 0, seqs.size(), 0, term);
+      if (cs.empty()) return -1;
+      return cn.instantiate(cn.class_dag(cs), term);
     };
     const int hw = head(w, tw), ho = head(o, to);
     if (cn.overflow) return false;

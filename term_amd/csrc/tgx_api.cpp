@@ -671,6 +671,7 @@ extern "C" tgx_status tgx_state_reset(const tgx_plan *plan, tgx_state *st, tgx_e
     d.speculative = false;
     d.outliers_possible = false;
     d.fp_staged = false;
+    d.fp_exact_lists = false;
     d.retained.clear();
     d.bitmap_words = 0;
     d.capacity = 0;  // buffers stay allocated; hash_ensure / the bitmap path clear them before use

@@ -111,19 +111,109 @@ def test_small_batches_table_path(pairs, device, large):
     assert (res[0].total, res[0].non_null) == (want.total, want.non_null)
 
 
-def test_big_batch_keeps_exactness(pairs, monkeypatch):
-    """a batch big enough for the fingerprint lists (threshold lowered: the oracle has to finish): the exact set stays
-    on the table, where the keys' bytes are kept; the fingerprint set takes the lists and counts the pairs once"""
+def lists_ran(st):
+    return st.profile_get("distinct_lists")["launches"]
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_big_batch_on_the_lists(pairs, monkeypatch, large):
+    """a batch big enough for the fingerprint lists (threshold lowered: the oracle has to finish).  An exact set over the
+    caller's DEVICE buffers takes the lists too: its records carry rows, and fp_count_kernel settles equal fingerprints
+    on the rows' bytes (ExactUtf8Eq).  A HOST batch of an exact set goes to the table (its staged copy does not outlive
+    the update)."""
     monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "1000")
     rng = np.random.default_rng(8)
-    vals = plant(background(rng, 300_000, 10**9), pairs, rng)
-    col, (offs, data, validity) = column_of(vals)
+    vals = plant(background(rng, 300_000, 10**9), pairs, rng, times=(2, 1))
+    col, (offs, data, validity) = column_of(vals, large=large)
     want = orc.distinct_utf8(offs, data, validity)
-    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY | T.FLAG_EXACT_KEYS)], [[col]], profile=True)
+    sp = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY | T.FLAG_EXACT_KEYS)]
+    res, st, _ = run(sp, [[col]], profile=True)
+    assert lists_ran(st) == 1
+    check(res[0], want)
+    check(st.finalize()[0], want)  # (a second look)
+    res, st, _ = run(sp, [[column_of(vals, device=False, large=large)[0]]], profile=True)
+    assert lists_ran(st) == 0
     check(res[0], want)
     res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY)], [[col]], profile=True)
-    assert st.profile_get("distinct_lists")["launches"] == 1
+    assert lists_ran(st) == 1
     assert res[0].distinct == want.distinct - len(pairs)
+
+
+def test_lists_then_more(pairs, monkeypatch):
+    """what follows an exact set's lists: a second batch, tgx_state_sync, a blob or a merge BEFORE tgx_finalize find the
+    first batch still there and move its keys into the table with their bytes (partners that arrive later are told
+    apart); AFTER tgx_finalize the caller may have released the batch, and its keys go on as their 128-bit fingerprints
+    (include/tgx.h, TGX_FLAG_EXACT_KEYS)."""
+    monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "1000")
+    rng = np.random.default_rng(18)
+    n1, n2 = 120_000, 30_000
+    first = background(rng, n1, 10**9)
+    second = background(rng, n2, 10**9)
+    for j, (a, b) in enumerate(pairs):
+        first[100 + 13 * j] = a
+        (first if j % 2 else second)[50 + 11 * j] = b  # every other pair is split between the batches
+    split = sum(1 for j in range(len(pairs)) if j % 2 == 0)
+    col1, col2 = column_of(first)[0], column_of(second)[0]
+    offs, data, validity = orc.utf8_from_list(first + second)
+    want = orc.distinct_utf8(offs, data, validity)
+    sp = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY | T.FLAG_EXACT_KEYS)]
+    T.init()
+    plan = T.Plan(sp, fingerprint_key=KEY)
+    # (1) a second batch straight away
+    st = T.State(plan)
+    st.profile_enable()
+    st.update([col1])
+    st.update([col2])
+    assert lists_ran(st) == 1
+    check(st.finalize()[0], want)
+    # (2) tgx_state_sync in between (the caller may release the first batch after it)
+    st = T.State(plan)
+    st.update([col1])
+    st.sync()
+    st.update([col2])
+    check(st.finalize()[0], want)
+    # (3) merge of two states that are both on the lists: each converts with its bytes, the union is by fingerprint
+    a, b = T.State(plan), T.State(plan)
+    a.update([col1])
+    b.update([col2])
+    a.merge([b])
+    got = a.finalize()[0]
+    assert (got.total, got.non_null, got.distinct) == (want.total, want.non_null, want.distinct - split)
+    # (4) finalize first: the batch is the caller's again, the keys of the lists are fingerprints from here on
+    st = T.State(plan)
+    st.update([col1])
+    o1 = orc.utf8_from_list(first)
+    check(st.finalize()[0], orc.distinct_utf8(*o1))
+    st.update([col2])
+    got = st.finalize()[0]
+    assert (got.total, got.non_null, got.distinct) == (want.total, want.non_null, want.distinct - split)
+
+
+def test_views_and_tuples_on_the_exact_lists(pairs, monkeypatch):
+    from test_gpu_utf8view import view_column
+
+    monkeypatch.setenv("TGX_FP_LISTS_MIN_ROWS", "1000")
+    rng = np.random.default_rng(19)
+    vals = plant(background(rng, 100_000, 10**9) + [b"s%d" % (i % 300) for i in range(20_000)], pairs, rng)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.distinct_utf8(offs, data, validity)
+    res, st, _ = run([spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY | T.FLAG_EXACT_KEYS)], [[view_column(vals, rng, True)]],
+                     profile=True)
+    assert lists_ran(st) == 1
+    check(res[0], want)
+    # tuples (Int64, Utf8) through the lists
+    n = len(vals)
+    ints = rng.integers(0, 3, size=n).astype(np.int64)
+    where = {v: i for i, v in enumerate(vals)}
+    for a, b in pairs:
+        ints[where[b]] = ints[where[a]]
+    col_i = T.Column.int64(to_device(ints), None)
+    col_s, _ = column_of(vals)
+    want_t = len({(int(ints[i]), vals[i]) for i in range(n)})
+    res, st, _ = run([spec(T.DISTINCT, 0, columns=[0, 1], flags=T.FLAG_EXACT_KEYS)], [[col_i, col_s]], profile=True)
+    assert lists_ran(st) == 1 and res[0].distinct == want_t
+    res, st, _ = run([spec(T.DISTINCT, 0, columns=[0, 1])], [[col_i, col_s]], profile=True)
+    assert lists_ran(st) == 1 and res[0].distinct == want_t - len(pairs)
 
 
 def test_partners_in_different_batches_and_store_growth(pairs):
