@@ -971,6 +971,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       // (one entry of two words per distinct fingerprint; values that shared one were told apart by the lists and
       //  are one entry from here on)
       TGX_TRY(key_store_ensure(st, ds, cur, 2 * (c[kCntDistinct] + 1), err));
+      HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));  // (counted again as they go in)
       launch_fp_demote(l2, ds.fp_fb_lo.as<uint32_t>(), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
                        st->stream);
     } else {

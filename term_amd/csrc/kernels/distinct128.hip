@@ -778,19 +778,23 @@ struct ExactUtf8Eq {
 };
 // An exact set's lists whose batch has been released (tgx_finalize hands the caller's buffers back): what is left of a
 // key is its 128-bit fingerprint -- the record's two words with the low half of the second restored from fb_lo[row] --
-// and that is what goes into the table, as an entry without bytes.  (The counters stay as the lists left them.)
+// and that is what goes into the table, as an entry without bytes.  The keys are COUNTED AGAIN as they go in (the host
+// has zeroed the two counters): from here on the set is a set of fingerprints, and values the lists had told apart by
+// their bytes are one key if they share all 128 bits.
 __global__ __launch_bounds__(256) void fp_demote_kernel(FpLists l, const uint32_t *fb_lo, HashSetView t, int want_mult,
                                                          unsigned long long *counters) {
   const uint32_t offered = l.offered[blockIdx.x];
   const uint32_t n = offered < l.cap ? offered : (uint32_t)l.cap;
   const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  unsigned long long n_new = 0, n_dup = 0;
   for (uint32_t i = threadIdx.x; i < n; i += 256) {
     const ulonglong2 r = recs[i];
-    uint64_t fb = (r.y & 0xFFFFFFFF00000000ull) | (uint64_t)fb_lo[(uint32_t)r.y];
-    if (fb == kEmptyKey) fb -= 1;
+    const uint64_t fb = (r.y & 0xFFFFFFFF00000000ull) | (uint64_t)fb_lo[(uint32_t)r.y];
     int became_dup = 0;
-    (void)hash_insert_exact(t, r.x, fb, FpOnlyKey{}, want_mult, 0, &became_dup, counters);
+    n_new += hash_insert_exact(t, r.x, fb, FpOnlyKey{}, want_mult, 0, &became_dup, counters);
+    n_dup += became_dup;
   }
+  block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
 // the lists' records into the global table (counted already: no counters)

@@ -646,6 +646,89 @@ __global__ __launch_bounds__(256) void length_kernel(RegexColDesc d, LengthBound
   }
 }
 
+// ---- a pattern that is an automaton AND a character count (regex_compile.h, Dfa::len_min / len_max: `^C{m,n}$`) ---------
+// The walk has left one byte per row in d.hits (1 match, 0 no match, 2 NULL row); this pass takes the rows whose
+// [TRIM]med value has fewer than min or more than max characters out of the matches and counts what remains (NULL
+// rows by d.null_is_valid, as the walk counts them).  Most rows are decided by their byte length, like length_kernel's.
+__global__ __launch_bounds__(256) void length_filter_kernel(RegexColDesc d, LengthBounds lb, unsigned long long *counters) {
+  __shared__ unsigned long long s_part[4];
+  const bool is_view = d.views != nullptr;
+  unsigned long long matches = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.length; i += (int64_t)gridDim.x * 256) {
+    const uint8_t h = d.hits[i];
+    if (h != 1) {
+      matches += (h == 2 && d.null_is_valid) ? 1 : 0;
+      continue;
+    }
+    const int64_t slot = d.offset + i;
+    uintptr_t p;
+    uint64_t nbytes;
+    if (is_view) {
+      typedef const int32_t __attribute__((address_space(1))) *gi32;
+      gi32 vw = (gi32)((uintptr_t)d.views + (uintptr_t)slot * 16);
+      const int32_t len = vw[0];
+      nbytes = (uint64_t)len;
+      p = len <= 12 ? (uintptr_t)d.views + (uintptr_t)slot * 16 + 4
+                    : (uintptr_t)d.buffers[vw[2]] + (uintptr_t)(uint32_t)vw[3];
+    } else if (d.large_offsets) {
+      global_i64_ptr off = (global_i64_ptr)(uintptr_t)d.offsets;
+      const int64_t b = off[slot];
+      nbytes = (uint64_t)(off[slot + 1] - b);
+      p = (uintptr_t)d.data + (uintptr_t)b;
+    } else {
+      global_i32_ptr off = (global_i32_ptr)(uintptr_t)d.offsets;
+      const int32_t b = off[slot];
+      nbytes = (uint64_t)(off[slot + 1] - b);
+      p = (uintptr_t)d.data + (uintptr_t)b;
+    }
+    if (d.trim) {  // SQL TRIM(col) = btrim(col, ' '): U+0020 only
+      global_u8_ptr bytes = (global_u8_ptr)p;
+      while (nbytes && bytes[0] == 0x20) bytes++, p++, nbytes--;
+      while (nbytes && bytes[nbytes - 1] == 0x20) nbytes--;
+    }
+    bool ok;
+    if (nbytes < lb.min_chars || (nbytes + 3) / 4 > lb.max_chars) {
+      ok = false;  // chars <= bytes < min, or chars >= ceil(bytes / 4) > max
+    } else if (nbytes <= lb.max_chars && (nbytes + 3) / 4 >= lb.min_chars) {
+      ok = true;
+    } else {
+      uint64_t cont = 0, remaining = nbytes;
+      uintptr_t q = p;
+      while (remaining > 0) {
+        const uint32_t nb = remaining < 8 ? (uint32_t)remaining : 8u;
+        const uint32_t skip = (uint32_t)(q & 7);
+        const uintptr_t base = q & ~(uintptr_t)7;
+        uint64_t w = *(global_u64_ptr)base >> (8 * skip);
+        if (skip + nb > 8) w |= *(global_u64_ptr)(base + 8) << (8 * (8 - skip));
+        if (nb < 8) w &= (1ull << (8 * nb)) - 1;
+        cont += __builtin_popcountll(w & ~(w << 1) & 0x8080808080808080ULL);
+        q += nb;
+        remaining -= nb;
+      }
+      const uint64_t chars = nbytes - cont;
+      ok = chars >= lb.min_chars && chars <= lb.max_chars;
+    }
+    if (!ok) d.hits[i] = 0;
+    matches += ok ? 1 : 0;
+  }
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) matches += __shfl_down(matches, dlt, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = matches;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (t) atomicAdd(&counters[0], t);
+  }
+}
+
+void launch_length_filter(const RegexColDesc &d, const LengthBounds &lb, unsigned long long *d_counters, int n_cu,
+                          hipStream_t stream) {
+  int64_t blocks = (d.length + 255) / 256;
+  if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(length_filter_kernel, dim3((int)blocks), dim3(256), 0, stream, d, lb, d_counters);
+}
+
 void launch_length(const RegexColDesc &d, const LengthBounds &lb, unsigned long long *d_counters, int n_cu,
                    hipStream_t stream) {
   int64_t blocks = (d.length + 255) / 256;

@@ -1,7 +1,10 @@
 // regex_compile.cpp -- see regex_compile.h.
 #include "regex_compile.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <array>
@@ -1298,6 +1301,31 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
     return ps.status;
   }
   Nfa nfa;
+  out->len_min = out->len_max = -1;
+  {
+    // `^C{m,n}$` with a class whose copies would make a big automaton: `^C*$` and a character count (regex_compile.h)
+    auto strip = [](Node *n) -> Node * {
+      while ((n->kind == Node::kConcat || n->kind == Node::kAlt) && n->kids.size() == 1) n = n->kids[0].get();
+      return n;
+    };
+    Node *top = strip(ast.get());
+    if (top->kind == Node::kConcat) {
+      std::vector<Node *> parts;
+      for (auto &k : top->kids)
+        if (strip(k.get())->kind != Node::kEmpty) parts.push_back(strip(k.get()));
+      if (parts.size() == 3 && parts[0]->kind == Node::kStart && parts[2]->kind == Node::kEnd &&
+          parts[1]->kind == Node::kRepeat && parts[1]->max >= 0 && strip(parts[1]->kids[0].get())->kind == Node::kClass) {
+        Node *rep = parts[1];
+        const Nfa::ClassDag &dag = nfa.class_dag(strip(rep->kids[0].get())->cls);
+        if ((size_t)rep->max * std::max<size_t>(dag.nodes.size(), 1) > 1024) {
+          out->len_min = rep->min;
+          out->len_max = rep->max;
+          rep->min = 0;
+          rep->max = -1;
+        }
+      }
+    }
+  }
   int match = nfa.add(NState::kMatch);
   int start = nfa.compile(ast.get(), match);
   if (nfa.overflow) {
@@ -1476,6 +1504,7 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
     }
   }
   const int n_states = (int)sets.size();
+  if (getenv("TGX_RX_TIMING")) fprintf(stderr, "rx: nfa %zu states, subset construction -> %d states x %d classes (clock %.2f s)\n", nfa.st.size(), n_states, ncls, (double)clock() / CLOCKS_PER_SEC);
   // states from which neither MATCHED nor an accept-at-end state is reachable are DEAD
   std::vector<char> alive(n_states, 0);
   std::vector<std::vector<int>> rev(n_states);
@@ -1556,6 +1585,7 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
   for (int q = 0; q < m_states; q++)
     for (int c = 0; c < ncls; c++) ftable[(size_t)q * m_cls + cls_map[c]] = mtable[(size_t)q * ncls + c];
   for (int b = 0; b < 256; b++) out->byte_class[b] = (uint8_t)cls_map[out->byte_class[b]];
+  if (getenv("TGX_RX_TIMING")) fprintf(stderr, "rx: minimised -> %d states x %d classes (clock %.2f s)\n", m_states, m_cls, (double)clock() / CLOCKS_PER_SEC);
   out->n_states = (uint32_t)m_states;
   out->n_classes = (uint32_t)m_cls;
   out->start = alive[start_id] ? (uint32_t)remap[part[start_id]] : 0u;
@@ -1565,6 +1595,11 @@ CompileStatus compile(const char *pattern, size_t len, bool case_insensitive, Df
 }
 
 bool dfa_is_match(const Dfa &d, const uint8_t *s, size_t n) {
+  if (d.len_max >= 0) {  // characters = bytes that are not continuation bytes
+    int64_t chars = 0;
+    for (size_t i = 0; i < n; i++) chars += (s[i] & 0xC0) != 0x80;
+    if (chars < d.len_min || chars > d.len_max) return false;
+  }
   uint32_t st = d.start;
   for (size_t i = 0; i < n && st > 1; i++) st = d.table[(size_t)st * d.n_classes + d.byte_class[s[i]]];
   return st == 1 || d.accept_at_end[st] != 0;
@@ -1573,6 +1608,8 @@ bool dfa_is_match(const Dfa &d, const uint8_t *s, size_t n) {
 bool dfa_product(const std::vector<const Dfa *> &parts, uint32_t max_entries, ProductDfa *out) {
   const size_t k = parts.size();
   if (k == 0 || k > 8) return false;
+  for (const Dfa *p : parts)
+    if (p->len_max >= 0) return false;  // (an automaton with a character count is walked on its own)
   // common refinement of the byte classes: bytes with the same class in every part
   std::map<std::vector<uint8_t>, uint32_t> class_ids;
   std::vector<std::vector<uint8_t>> class_tuple;

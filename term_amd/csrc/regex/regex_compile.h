@@ -23,6 +23,11 @@ struct Dfa {
   uint8_t byte_class[256];
   std::vector<uint16_t> table;         // n_states * n_classes
   std::vector<uint8_t> accept_at_end;  // per state: the haystack may end here with a match
+  // A counted repeat of ONE class between anchors -- `^C{m,n}$`: "a user name of 1 to 64 word characters" -- is the
+  // automaton of `^C*$` and a count: every character of a matching value is one of C, so the value matches iff the
+  // automaton does AND its number of characters lies in [len_min, len_max].  The expanded automaton would hold a copy
+  // of the class's UTF-8 form per repetition (\w: ~300 states each).  -1: no bound (every other pattern).
+  int64_t len_min = -1, len_max = -1;
 };
 
 enum CompileStatus {

@@ -12,6 +12,8 @@
 
 namespace tgx {
 
+void launch_length_filter(const RegexColDesc &d, const LengthBounds &lb, unsigned long long *d_counters, int n_cu,
+                          hipStream_t stream);
 void launch_length(const RegexColDesc &d, const LengthBounds &lb, unsigned long long *d_counters, int n_cu,
                    hipStream_t stream);
 void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long *d_counters, int n_cu,
@@ -363,11 +365,21 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, Di
     v.n_final = 2;
     Timer timer(st);
     const LengthBounds lb{t.len_min, t.len_max};
+    // an automaton with a character count (`^C{m,n}$`, regex_compile.h): the walk leaves a byte per row, a second pass
+    // takes the rows whose length is outside the bounds out of the matches and counts
+    const bool bounded = !t.is_length && t.dfa.len_max >= 0;
+    const LengthBounds lbb{(uint64_t)std::max<int64_t>(t.dfa.len_min, 0), (uint64_t)std::max<int64_t>(t.dfa.len_max, 0)};
     if (!is_dict) {
-      if (t.is_length)
+      if (t.is_length) {
         launch_length(d, lb, ts.counters.as<unsigned long long>(), n_cu, st->stream);
-      else if (!walked[i])
+      } else if (!walked[i] && bounded) {
+        RHIP(ts.dict_hits.reserve((size_t)c.length + 32));
+        d.hits = ts.dict_hits.as<uint8_t>();
+        launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);  // (counters[1]: scratch)
+        launch_length_filter(d, lbb, ts.counters.as<unsigned long long>(), n_cu, st->stream);
+      } else if (!walked[i]) {
         launch_regex(d, v, ts.counters.as<unsigned long long>(), n_cu, st->stream);
+      }
     } else {
       // counters[1] soaks up the per-entry match count, counters[0] receives the per-row one
       if (sc.length > 0) {
@@ -375,6 +387,8 @@ tgx_status regex_update(tgx_state *st, const tgx_column *dev, tgx_error *err, Di
           launch_length(d, lb, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
         else if (!walked[i])
           launch_regex(d, v, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
+        if (!t.is_length && !walked[i] && bounded)  // (the entries' verdicts, before the rows gather them)
+          launch_length_filter(d, lbb, ts.counters.as<unsigned long long>() + 1, n_cu, st->stream);
       }
       bool fused = false;
       if (fuse) {
