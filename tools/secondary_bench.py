@@ -161,6 +161,22 @@ def run_c3(T, torch, spec, steps, warmup):
         ok = all(r.total == expect["n"] and r.matches == expect["with_at"] for r in res)
         out[name] = entry(ms, alg, n, ok, patterns=len(pats), value_bytes=L)
         st.close()
+    # uniqueness of the same string column (COUNT(DISTINCT), constraints/uniqueness.rs:612-617): by keyed 128-bit
+    # fingerprint, and as an EXACT key set (TGX_FLAG_EXACT_KEYS: equal fingerprints confirmed on the bytes) -- what the
+    # host layer and the shim ask for by default; a name of <= 64 word characters (`^[\w.@+-]{1,64}$`: the automaton of
+    # `^[\w.@+-]*$` and a character count) rides along as the pattern round 5 could not take
+    for name, flags in (("strings_distinct_fingerprint", 0), ("strings_distinct_exact", T.FLAG_EXACT_KEYS)):
+        plan = T.Plan([spec(T.DISTINCT, 0, flags=flags)])
+        st = T.State(plan)
+        ms, res = timed_steps(torch, st, [col], steps, warmup)
+        out[name] = entry(ms, alg, n, res[0].distinct == expect["n"] - expect["nulls"], value_bytes=L)
+        st.close()
+    plan = T.Plan([spec(T.REGEX_MATCH, 0, pattern=r"^[\w.@+-]{1,64}$")])
+    st = T.State(plan)
+    ms, res = timed_steps(torch, st, [col], steps, warmup)
+    out["C3_counted_class"] = entry(ms, alg, n, res[0].total == expect["n"] and res[0].matches == expect["with_at"],
+                                    pattern=r"^[\w.@+-]{1,64}$", value_bytes=L)
+    st.close()
     del col, offsets, data, validity
     return out
 
@@ -300,6 +316,37 @@ def run_ingest(root):
     return out
 
 
+def run_shard8_world1(root):
+    """One rank's step of the 8-way shard of the headline table -- 125 M rows x 16 columns -- through the N > 1 code path
+    (`bench.py --force-distributed`: facts round, bitmap-slice exchange over the library's RCCL communicator with the
+    rank as its own peer, state all-gather, rank-ordered merge) in a child process.  What a rank of `--gpus 8` runs,
+    minus what only exists with peers: the xGMI transfer and the other ranks' latencies.  8 x this step is the budget of
+    the 8-GPU run: 23.7 / 6 = 3.95 ms for >= 6x."""
+    import json
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-distributed", "--rows",
+                        "125000000", "--steps", "20", "--warmup", "5", "--no-secondary", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+    d = json.loads(lines[-1])
+    kernels = d["roofline"]["launch_ms"] + d["config"]["distinct_ms_per_step"]
+    return {"ms_per_step": d["ms_per_step"], "ms_min": d["ms_min"], "steps": d["steps"], "rows": d["config"]["rows_total"],
+            "kernels_ms": kernels, "tail_ms": d["ms_per_step"] - kernels, "verified": d["config"]["verified"],
+            "rank_breakdown": d["config"].get("rank_breakdown"),
+            "how": "child process: bench.py --gpus 1 --force-distributed --rows 125000000 --steps 20 --warmup 5"}
+
+
 def measure(T, torch, synth, spec, layout, unique_cols, headline_plan, table, columns, n, seed, steps=5, warmup=2,
             warm_headline_ms=None, log=None):
     """Everything above, in an order that fits one GPU's memory: the headline table's legs first, then the table is
@@ -345,6 +392,11 @@ def measure(T, torch, synth, spec, layout, unique_cols, headline_plan, table, co
                             "device_cached_bytes": cs.device_cached_bytes, "pinned_hits": cs.pinned_hits,
                             "pinned_misses": cs.pinned_misses}
     T.trim()
+    try:
+        out["shard8_world1"] = run_shard8_world1(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    except Exception as e:
+        out["shard8_world1"] = {"error": str(e)}
+    note("shard8_world1")
     try:
         out["ingest"] = run_ingest(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     except Exception as e:  # (a feeder that is not built, or stuck: the rest of the line stands)
