@@ -362,7 +362,7 @@ size_t coalesce_host_bytes(const tgx_plan *plan, const tgx_column *columns, int6
       const int64_t end = ow == 4 ? (int64_t)((const int32_t *)c.offsets)[c.offset + nrows]
                                   : ((const int64_t *)c.offsets)[c.offset + nrows];
       total += (size_t)(nrows + 1) * ow + 64 + (size_t)std::max<int64_t>(end - first, 0) + 64;
-    } else if (plan->reads_values[i] || c.values) {
+    } else if (plan->reads_values[i]) {  // (a column only completeness / size look at brings its validity alone)
       total += (size_t)nrows * (is_numeric32(c.type) ? 4 : 8) + 64;  // (narrow integers / Booleans arrive widened: 8)
     }
   }
@@ -607,6 +607,10 @@ tgx_status coalesce_append(const tgx_plan *plan, tgx_state *st, const tgx_column
       sg.values = to_arena(o0, (size_t)(nrows + 1) * ow);
       sg.data = (sg.data_len > 0 && c.data) ? (const uint8_t *)to_arena(c.data + first, (size_t)sg.data_len) : nullptr;
       cc.data_bytes += sg.data_len;
+    } else if (c.values && !plan->reads_values[i]) {
+      // the plan reads the column's validity only (completeness, size): no value crosses the bus -- an Int8 column
+      // widened here cost 8x its size in host copy, PCIe and gather traffic per flush; the flush's view has
+      // no values, like the `bare` column of the immediate path
     } else if (c.values && is_narrow_int(c.type)) {
       // (HOST: update_validate) widened on the way into the arena: the flush sees an Int64 column
       cc.type = TGX_INT64;

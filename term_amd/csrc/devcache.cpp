@@ -17,6 +17,7 @@
 //    TGX_DEVICE_CACHE_POISON=1 fills every block handed out with 0xA5 (tests: nothing may rely on the zero pages a
 //    fresh hipMalloc happens to return).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -36,6 +37,9 @@ struct Pool {
 Pool g_dev, g_host;
 
 thread_local int tl_quiesced = 0;
+// false once tgx_shutdown has emptied the cache (until the next tgx_init): what is released then -- a state destroyed
+// after the shutdown -- goes back to the driver, not into a cache nobody will trim
+std::atomic<bool> g_live{true};
 
 bool cache_enabled() {
   static const bool on = [] {
@@ -125,9 +129,11 @@ hipError_t dev_alloc(void **p, size_t *cap, size_t bytes) {
   return hipSuccess;
 }
 
+void dev_cache_set_live(bool on) { g_live.store(on); }
+
 void dev_free(void *p, size_t cap) {
   if (!p) return;
-  if (!cache_enabled() || cap != cache_size_class(cap) || cap > dev_limit()) {
+  if (!cache_enabled() || !g_live.load() || cap != cache_size_class(cap) || cap > dev_limit()) {
     (void)hipFree(p);  // (waits for the device itself)
     return;
   }
@@ -167,10 +173,12 @@ hipError_t pinned_alloc(void **p, size_t bytes) {
 
 void pinned_free(void *p, size_t bytes) {
   if (!p) return;
-  if (cache_enabled()) {
+  // Only a release inside a QuiescedScope (tgx_state_destroy: the device has been waited for) keeps the block: the
+  // others are the growth paths of the update / flush (arena, descriptors, snapshots, h_pinned), whose blocks are
+  // guarded by their own events -- a device-wide wait there would stall every stream of the device, other states' and
+  // the threaded ranks inside a collective included; hipHostFree only waits for what uses the block
+  if (cache_enabled() && g_live.load() && tl_quiesced > 0) {
     const size_t cap = cache_size_class(bytes);
-    // (a copy engine may still be reading or writing the block)
-    if (tl_quiesced == 0) (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lock(g_host.mu);
     if (g_host.cached_bytes + cap <= kHostLimit) {
       g_host.free_blocks[cap].push_back(p);
@@ -208,7 +216,7 @@ hipError_t stream_acquire(hipStream_t *out, bool high_priority) {
 
 void stream_release(hipStream_t s, bool high_priority) {
   if (!s) return;
-  if (cache_enabled()) {
+  if (cache_enabled() && g_live.load()) {
     std::lock_guard<std::mutex> lock(g_stream_mu);
     auto &pool = g_streams[high_priority ? 1 : 0];
     if (pool.size() < 64) {

@@ -250,6 +250,7 @@ void pinned_free(void *p, size_t bytes);                     // `bytes` as asked
 hipError_t stream_acquire(hipStream_t *out, bool high_priority);
 void stream_release(hipStream_t s, bool high_priority);
 void dev_cache_trim();
+void dev_cache_set_live(bool on);  // tgx_init: true; tgx_shutdown (after its trim): false
 void dev_cache_stats(tgx_cache_stats *out);
 // "the device has been waited for and this thread queues nothing until the scope ends": releases inside it skip the
 // wait that keeps a cached block away from work still in flight (tgx_state_destroy)

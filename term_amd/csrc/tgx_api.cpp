@@ -72,6 +72,7 @@ extern "C" tgx_status tgx_init(const tgx_options *opts, tgx_error *err) try {
   g_ctx.distinct_hint = opts ? opts->distinct_capacity_hint : 0;
   g_ctx.no_coalesce = opts && (opts->flags & TGX_OPT_NO_COALESCE) != 0;
   g_ctx.inited = true;
+  tgx::dev_cache_set_live(true);
   return TGX_OK;
 } catch (...) {
   return tgx::abi_exception(err);
@@ -82,6 +83,7 @@ extern "C" tgx_status tgx_shutdown(void) try {
   std::lock_guard<std::mutex> lock(g_ctx.mu);
   if (g_ctx.inited) {
     (void)hipSetDevice(g_ctx.device);
+    tgx::dev_cache_set_live(false);  // (a state destroyed from here on frees its blocks: nobody would trim them)
     tgx::dev_cache_trim();  // (blocks of destroyed states; live states keep theirs)
   }
   g_ctx.inited = false;
