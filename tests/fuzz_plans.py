@@ -291,6 +291,15 @@ class Case:
             self.world = int(rng.integers(2, 5))
             inner = sorted(int(x) // 64 * 64 for x in rng.integers(0, n + 1, size=self.world - 1))
             self.cuts = [0] + inner + [n]  # one shard per rank (validity bytes are shared: shards start on whole words)
+        # ---- round 6, from a stream of its own: the DISTINCT checks ask for EXACT key sets (TGX_FLAG_EXACT_KEYS: string /
+        # tuple keys kept with their bytes, equal fingerprints confirmed on them) -- nothing about the results may change,
+        # whatever else happens to the state (lists, flushes, merges, blobs, ranks, resume / sync / reuse)
+        rng7 = np.random.default_rng([seed, 7])
+        self.exact_keys = bool(rng7.random() < 0.5)
+        if self.exact_keys:
+            for sp in self.specs:
+                if sp.kind == T.DISTINCT:
+                    sp.flags |= T.FLAG_EXACT_KEYS
         # ---- round 5, drawn from a stream of their own (the cases of earlier seeds stay what they were) ----
         rng5 = np.random.default_rng([seed, 5])
         # HOST batches handed over as TGX_MEM_HOST_RETAINED (kept until the flush): nothing about the results may change
@@ -342,7 +351,8 @@ class Case:
                                             int((~c[3]).sum())) for c, p in zip(self.cols, self.present))
         return "seed %d: n=%d cols=[%s] checks=%s batching=%s(%d) buffers=%s after=%s env=%s" % (
             self.seed, self.n, cols, [e[0] for e in self.expect], self.mode, len(self.cuts) - 1, self.device,
-            self.after + ("" if self.seq == "plain" else "/" + self.seq) + (" kept" if self.retain else ""), self.env)
+            self.after + ("" if self.seq == "plain" else "/" + self.seq) + (" kept" if self.retain else "") +
+            (" exact-keys" if self.exact_keys else ""), self.env)
 
     # ---- the device side ----
     def columns_of(self, lo, hi, on_device):
