@@ -810,6 +810,257 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
 }
 
+// ---- the partition pass with the runs' remainders CARRIED OVER (round 6) ------------------------------------------------
+// partition_kernel pads every (tile, bucket) run to a whole 64-byte line: half a line per run on average, whatever the
+// entry size -- 1.26 of the 3.76 bytes a key of the headline's id column leaves in its list (954 buckets: runs of 34
+// entries), written once and read once by the replay.  Here a workgroup -- which walks many tiles -- keeps what a run
+// leaves beyond whole lines in LDS, per bucket and PACKED AS THE LIST IS (three 20-bit entries to an 8-byte word, at
+// most 23 entries = 8 words a bucket), and the bucket's next run starts with it: only whole lines are ever reserved and
+// written, every entry is a real key, and the padding shrinks to the one line per bucket a workgroup flushes when it
+// is through.  The carry takes 64 KiB for up to 1024 buckets, so a tile is 16 384 keys (its runs may be short now).
+// For the 20-bit lists without multiplicity and keys that do not arrive in order (those take partition_kernel's
+// CLUSTERED form, which this kernel leaves to it by returning at once -- the same probe flag).
+// MEASURED AND LEFT OFF (TGX_PARTITION_CARRY=1 turns it on): 1 G shuffled ids 3.75 ms against partition_kernel's 2.46,
+// the 10^8-value column 3.10 against 2.40; the replay gains what the lists lost (0.72 -> 0.46 ms, 0.55 -> 0.42) but the
+// pass loses three times as much: its cost is per tile and per LDS operation, not per byte written -- half the tile
+// doubles the barriers, scans and reservations per key, and building the carry is ~16 LDS operations per thread and
+// tile next to the 48 of the two counting passes.  With the tile kept at 32 768 keys the carry of 954 buckets does not
+// fit beside it (128 + 16 + 61 KiB).
+template <int THREADS, int KPT, bool VALIDITY, bool STATS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_carry_kernel(
+    PartitionParams p, unsigned long long *counters) {
+  if (__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) return;
+  constexpr int kTile = THREADS * KPT;
+  constexpr int MAXP = THREADS;          // one bucket per thread in the scan, the carry update and the flush
+  constexpr uint32_t NW = THREADS / 64;  // waves
+  constexpr uint32_t kNoList = 0xFFFFFFFFu;
+  static_assert(MAXP == (int)(NW * 64), "a lane of every wave names one bucket in the store phase");
+  __shared__ uint32_t sorted[kTile];
+  __shared__ uint32_t hist[MAXP], toff[MAXP + 1], gbase[MAXP], ccount[MAXP];
+  __shared__ unsigned long long carryw[MAXP * 8];
+  __shared__ uint32_t wave_sums[16];
+  __shared__ uint32_t st_min, st_max;
+  __shared__ unsigned long long st_sum, st_cnt;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool wide = (((uintptr_t)p.values + (uintptr_t)p.offset * 8) & 15) == 0;
+  const uint32_t sub_mask = (uint32_t)((1ull << p.sub_bits) - 1);
+  unsigned long long n_valid = 0, n_out = 0;
+  const int64_t n_tiles = (p.length + kTile - 1) / kTile;
+  ccount[tid] = 0;
+  if (STATS && tid == 0) {
+    st_min = 0xFFFFFFFFu;
+    st_max = 0;
+    st_sum = 0;
+    st_cnt = 0;
+  }
+  // entry i of what bucket b holds: its carry (c entries) first, then the tile's run (from sorted[o])
+  auto carry_get = [&](uint32_t b, uint32_t i) -> uint32_t {
+    return (uint32_t)(carryw[b * 8 + i / 3] >> (20u * (i % 3u))) & 0xFFFFFu;
+  };
+  auto entry = [&](uint32_t b, uint32_t c, uint32_t o, uint32_t i) -> uint32_t {
+    return i < c ? carry_get(b, i) : sorted[o + i - c];
+  };
+  auto word_of = [&](uint32_t b, uint32_t c, uint32_t o, uint32_t first) -> unsigned long long {  // entries first .. first + 2
+    if (first + 3 <= c) return carryw[b * 8 + first / 3];  // (packed alike)
+    return (unsigned long long)entry(b, c, o, first) | ((unsigned long long)entry(b, c, o, first + 1) << 20) |
+           ((unsigned long long)entry(b, c, o, first + 2) << 40);
+  };
+  auto spill = [&](uint32_t b, uint32_t sub_key) {  // straight into the global bitmap (no list, or a full one)
+    const uint64_t r = ((uint64_t)b << p.sub_bits) | sub_key;
+    atomicOr(&p.seen[r >> 5], 1u << (r & 31));
+  };
+  uint32_t rel[KPT];
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint64_t ok;
+    {
+      int64_t key[KPT];
+      uint32_t ok32 = 0;
+      partition_load_tile<THREADS, KPT, VALIDITY>(p, tile, wide, key, ok32);
+      ok = ok32;
+      n_valid += __builtin_popcountll(ok);
+      partition_relative_plain<KPT, STATS>(p, key, rel, ok, n_out);
+    }
+    if (STATS) {
+      uint32_t tmin = 0xFFFFFFFFu, tmax = 0;
+      unsigned long long tsum = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; j++) {
+        const bool in = (ok >> j) & 1;
+        tmin = (in && rel[j] < tmin) ? rel[j] : tmin;
+        tmax = (in && rel[j] > tmax) ? rel[j] : tmax;
+        tsum += in ? rel[j] : 0u;
+      }
+      unsigned long long tcnt = __builtin_popcountll(ok);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t omin = __shfl_down(tmin, d, 64), omax = __shfl_down(tmax, d, 64);
+        tmin = omin < tmin ? omin : tmin;
+        tmax = omax > tmax ? omax : tmax;
+        tsum += __shfl_down(tsum, d, 64);
+        tcnt += __shfl_down(tcnt, d, 64);
+      }
+      if (lane == 0 && tcnt) {
+        atomicMin(&st_min, tmin);
+        atomicMax(&st_max, tmax);
+        atomicAdd(&st_sum, tsum);
+        atomicAdd(&st_cnt, tcnt);
+      }
+    }
+    hist[tid] = 0;
+    __syncthreads();  // hist is zero; the carry of the tile before is in place
+#pragma unroll
+    for (int j = 0; j < KPT; j++)
+      if ((ok >> j) & 1) atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+    __syncthreads();
+    // ---- scan (a bucket per thread) + one reservation per bucket that has whole lines to give ----
+    {
+      const uint32_t h = hist[tid];
+      uint32_t incl = h;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+      }
+      if (lane == 63) wave_sums[wave] = incl;
+      __syncthreads();
+      uint32_t excl = incl - h;
+      for (uint32_t w = 0; w < wave; w++) excl += wave_sums[w];
+      toff[tid] = excl;
+      hist[tid] = excl;  // the placement cursor of pass 2
+      if (tid == THREADS - 1) toff[MAXP] = excl + h;
+      uint32_t g = 0;
+      if (tid - p.bucket0 >= p.n_lists) {
+        g = kNoList;  // (the batch was not expected to touch this bucket: its keys go straight to the bitmap)
+      } else {
+        const uint32_t emit = (ccount[tid] + h) / 24u * 24u;
+        if (emit) {
+          const unsigned long long at = atomicAdd(&p.cursors[tid], (unsigned long long)emit);
+          if (at + emit > p.cap) {
+            atomicMin(&p.cursors[p.n_buckets + tid], at);  // (the list is valid up to the first failure)
+            g = kNoList;
+          } else {
+            g = (uint32_t)at;
+          }
+        }
+      }
+      gbase[tid] = g;
+    }
+    __syncthreads();
+    // ---- pass 2: counting sort into LDS ----
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+      if (!((ok >> j) & 1)) continue;
+      const uint32_t pos = atomicAdd(&hist[rel[j] >> p.sub_bits], 1u);
+      sorted[pos] = rel[j] & sub_mask;
+    }
+    __syncthreads();
+    // ---- whole lines out: wave w owns buckets w, w + NW, ...; four lanes a bucket, 16 bytes (six entries) a lane ----
+    {
+      const uint32_t mb = lane * NW + wave;  // the bucket this lane keeps the bookkeeping of
+      const uint32_t m_o = toff[mb], m_h = toff[mb + 1] - m_o, m_g = gbase[mb], m_c = ccount[mb];
+      const uint32_t grp = lane >> 2, sub = lane & 3;
+      const uint32_t n_meta = p.n_buckets > wave ? (p.n_buckets - wave + NW - 1) / NW : 0;
+      for (uint32_t m0 = 0; m0 < n_meta; m0 += 16) {
+        const uint32_t m = m0 + grp, src = m & 63;
+        const uint32_t o = __shfl(m_o, src, 64), g = __shfl(m_g, src, 64), c = __shfl(m_c, src, 64);
+        uint32_t h = __shfl(m_h, src, 64);
+        if (m >= n_meta) continue;
+        const uint32_t b = m * NW + wave;
+        if (b - p.bucket0 >= p.n_lists) {  // no list: the tile's keys of the bucket (it never carries)
+          for (uint32_t i = sub; i < h; i += 4) spill(b, sorted[o + i]);
+          continue;
+        }
+        const uint32_t emit = (c + h) / 24u * 24u;
+        if (emit == 0) continue;
+        if (g != kNoList) {
+          // cap and g are multiples of 24 entries: a line starts on a 64-byte boundary
+          uint8_t *dst = (uint8_t *)p.lists + ((uint64_t)(b - p.bucket0) * p.cap + g) / 3 * 8;
+          for (uint32_t i = 6u * sub; i < emit; i += 24u) {
+            const unsigned long long w0 = word_of(b, c, o, i), w1 = word_of(b, c, o, i + 3);
+            *(uint4 *)(dst + (uint64_t)(i / 3) * 8) = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+          }
+        } else {
+          for (uint32_t i = sub; i < emit; i += 4) spill(b, entry(b, c, o, i));
+        }
+      }
+    }
+    __syncthreads();  // everybody has read the old carry
+    // ---- the new carry (a bucket per thread): what the lines left over, or the old carry with the run appended ----
+    if (tid - p.bucket0 < p.n_lists) {
+      const uint32_t o = toff[tid], h = toff[tid + 1] - o, c = ccount[tid];
+      const uint32_t total = c + h, emit = total / 24u * 24u;
+      if (emit) {
+        const uint32_t left = total - emit, from = o + emit - c;  // (emit >= 24 > c: the carry is all gone)
+        for (uint32_t q = 0; 3u * q < left; q++) {
+          unsigned long long w = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 3; j++)
+            if (3u * q + j < left) w |= (unsigned long long)sorted[from + 3u * q + j] << (20u * j);
+          carryw[tid * 8 + q] = w;
+        }
+        ccount[tid] = left;
+      } else if (h) {
+        for (uint32_t q = c / 3u; 3u * q < total; q++) {
+          unsigned long long w = 3u * q < c ? carryw[tid * 8 + q] : 0ull;
+#pragma unroll
+          for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t pos = 3u * q + j;
+            if (pos >= c && pos < total) w |= (unsigned long long)sorted[o + pos - c] << (20u * j);
+          }
+          carryw[tid * 8 + q] = w;
+        }
+        ccount[tid] = total;
+      }
+    }
+    // (the next tile's first barrier -- or the one below -- comes before anybody reads carry or `sorted` again)
+  }
+  __syncthreads();
+  // ---- what is left of every bucket: one line, padded by its last entry (a set union is idempotent) ----
+  if (tid - p.bucket0 < p.n_lists) {
+    const uint32_t c = ccount[tid];
+    if (c) {
+      const unsigned long long at = atomicAdd(&p.cursors[tid], 24ull);
+      if (at + 24 > p.cap) {
+        atomicMin(&p.cursors[p.n_buckets + tid], at);
+        for (uint32_t i = 0; i < c; i++) spill(tid, carry_get(tid, i));
+      } else {
+        unsigned long long *dst = (unsigned long long *)((uint8_t *)p.lists + ((uint64_t)(tid - p.bucket0) * p.cap + at) / 3 * 8);
+        const unsigned long long last = carry_get(tid, c - 1);
+        for (uint32_t q = 0; q < 8; q++) {
+          unsigned long long w = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t pos = 3u * q + j;
+            w |= (pos < c ? (unsigned long long)carry_get(tid, pos) : last) << (20u * j);
+          }
+          dst[q] = w;
+        }
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    if (tid == 0) {
+      ScanPartial out;
+      out.min_k = INT64_MAX;
+      out.max_k = INT64_MIN;
+      out.sum_lo = 0;
+      out.sum_hi = 0;
+      out.non_null = (int64_t)st_cnt;
+      out.sum = out.comp = out.s1 = out.s2 = 0.0;
+      if (st_cnt) {
+        out.min_k = (int64_t)((uint64_t)p.base + st_min);
+        out.max_k = (int64_t)((uint64_t)p.base + st_max);
+        const __int128 sum = (__int128)st_sum + (__int128)st_cnt * (__int128)p.base;
+        out.sum_lo = (uint64_t)sum;
+        out.sum_hi = (int64_t)(sum >> 64);
+      }
+      p.stats[blockIdx.x] = out;
+    }
+  }
+  block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
+}
+
 // the outliers' share of the aggregates as one more partial (index `at`), once the partition pass is through
 __global__ void partition_outlier_stats_kernel(const OutlierStats *g, ScanPartial *partials, int at) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1301,6 +1552,29 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
     hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
                        dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
   } while (0)
+  // the 20-bit lists without multiplicity, up to 1024 buckets: the runs' remainders are carried from tile to tile
+  // (partition_carry_kernel; keys in order keep the CLUSTERED form of partition_kernel) -- an experiment that lost
+  // (see the kernel's comment): only with TGX_PARTITION_CARRY=1
+  static const bool carry_on = [] {
+    const char *e = getenv("TGX_PARTITION_CARRY");
+    return e && e[0] == '1';
+  }();
+  if (p.key16 == 2 && carry_on && !p.want_multiplicity && p.n_buckets <= 1024) {
+#define TGX_CARRY(VAL, ST)                                                                                           \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((partition_carry_kernel<kPartitionThreads, 16, VAL, ST>), dim3(grid), dim3(kPartitionThreads), 0,   \
+                       stream, p, d_counters);                                                                      \
+    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
+                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+  } while (0)
+    if (p.stats) {
+      if (p.validity) TGX_CARRY(true, true); else TGX_CARRY(false, true);
+    } else {
+      if (p.validity) TGX_CARRY(true, false); else TGX_CARRY(false, false);
+    }
+#undef TGX_CARRY
+    return;
+  }
   if (p.key16 == 2) {  // 20-bit packed entries
     if (p.stats) {
       if (p.validity) TGX_PART20(true, true); else TGX_PART20(false, true);
