@@ -369,7 +369,7 @@ def main():
         # latest round's: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied;
         # `traffic_source` says so
         traffic, traffic_source = None, None
-        for name in ("r05_pmc_1Brows_16cols.json", "r04_pmc_1Brows_16cols.json", "r03_pmc_1Brows_16cols.json",
+        for name in ("r06_pmc_1Brows_16cols.json", "r05_pmc_1Brows_16cols.json", "r04_pmc_1Brows_16cols.json", "r03_pmc_1Brows_16cols.json",
                      "r02_pmc_1Brows_16cols.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:

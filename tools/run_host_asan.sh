@@ -10,5 +10,5 @@ export TGX_LIB=$PWD/build/tgx_asan/libtgx.so
 export ASAN_OPTIONS=detect_leaks=0:detect_odr_violation=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export LD_PRELOAD=$rt
-python -m pytest tests/test_regex_host.py tests/test_host_logic.py tests/test_analyzers_host.py tests/test_abi.py -x -q 2>&1 | tail -5 || exit 1
+python -m pytest tests/test_regex_host.py tests/test_regex_counted_classes.py tests/test_host_logic.py tests/test_analyzers_host.py tests/test_state_json_tokens.py tests/test_abi.py -x -q -m "not gpu" 2>&1 | tail -5 || exit 1
 python tools/fuzz_patterns.py --seconds "${1:-30}" || exit 1
