@@ -741,7 +741,14 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
                   hipStream_t stream) {
   const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
   const bool direct = dfa.n_classes == 256 && dfa.direct && entries <= 4096;
-  const bool in_lds = direct || entries <= kRegexLdsEntries;
+  // an LDS-resident table: up to kRegexLdsEntries entries as a rule; TGX_REGEX_LDS_ENTRIES raises that (an entry is the
+  // byte offset of a row: the table must stay below 64 KiB) -- two workgroups a CU with a 60 KiB table against seven
+  // walking it from L2 (round 6: measured for the 316-state automaton of `^[\w.@+-]*$`)
+  static const uint64_t lds_entries = [] {
+    const char *e = getenv("TGX_REGEX_LDS_ENTRIES");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)kRegexLdsEntries;
+  }();
+  const bool in_lds = direct || (entries <= lds_entries && entries * 2 <= 65535);
   const RegexLds lds = regex_lds_layout(dfa.n_states, dfa.n_classes, in_lds);
   const bool view = d.views != nullptr;
   // persistent grid: exactly the workgroups that stay resident (LDS, and 7 rather than 8 waves per SIMD at this
@@ -776,6 +783,8 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
   do {                                                                                                           \
     auto k = regex_match_kernel<LDS, DIRECT, VIEW>;                                                              \
     const int64_t blocks = std::min<int64_t>(max_blocks, (int64_t)n_cu * resident(k, ID));                       \
+    if (lds.total > (64u << 10))                                                                                 \
+      (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total);    \
     hipLaunchKernelGGL(k, dim3((int)blocks), block, lds.total, stream, d, dfa, lds, d_counters);                 \
   } while (0)
 #define TGX_RXM(LDS, DIRECT, VIEW, ID)                                                                           \

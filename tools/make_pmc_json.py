@@ -14,8 +14,24 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
-def per_kernel(d):
-    f = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True)[0]
+def per_kernel_summary(path):
+    """the per-kernel means tools/pmc_bench.sh printed (it clears its directory): `name COUNTER dispatches N mean V`"""
+    out = {}
+    for line in open(path):
+        parts = line.split()
+        if "tgx::" not in line or "dispatches" not in parts:
+            continue
+        i = parts.index("dispatches")
+        name = "tgx::" + " ".join(parts[:i - 1]).split("tgx::")[1]
+        out[name] = (int(parts[i + 1]), float(parts[i + 3]))
+    return out
+
+
+def per_kernel(d, tag=None):
+    found = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True)
+    if not found:
+        return per_kernel_summary(os.path.join(ROOT, "gpurun_out", "%s_%s.txt" % (tag, d)))
+    f = found[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
@@ -29,7 +45,7 @@ def per_kernel(d):
 
 def main():
     tag, rows = sys.argv[1], int(sys.argv[2])
-    fetch, write = per_kernel("pmc_fetch"), per_kernel("pmc_write")
+    fetch, write = per_kernel("pmc_fetch", tag), per_kernel("pmc_write", tag)
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         kernels[k] = {"dispatches": fetch.get(k, write.get(k))[0],
