@@ -741,12 +741,14 @@ void launch_regex(const RegexColDesc &d, const DfaView &dfa, unsigned long long 
                   hipStream_t stream) {
   const uint64_t entries = (uint64_t)dfa.n_states * dfa.n_classes;
   const bool direct = dfa.n_classes == 256 && dfa.direct && entries <= 4096;
-  // an LDS-resident table: up to kRegexLdsEntries entries as a rule; TGX_REGEX_LDS_ENTRIES raises that (an entry is the
-  // byte offset of a row: the table must stay below 64 KiB) -- two workgroups a CU with a 60 KiB table against seven
-  // walking it from L2 (round 6: measured for the 316-state automaton of `^[\w.@+-]*$`)
+  // An LDS-resident table: whatever stays below 64 KiB (an entry is the byte offset of a row in 16 bits).  Up to round 5
+  // the limit was kRegexLdsEntries (32 KiB: five to seven workgroups a CU) and bigger automata were walked from L2 by
+  // seven; round 6 measured the 316-state automaton of `^[\w.@+-]*$` (61 KiB: TWO workgroups a CU) at 1.90 ms per
+  // 100 M x 28 B from LDS against 2.96 ms from L2 -- the dependent table read is what a walk waits for.
+  // TGX_REGEX_LDS_ENTRIES overrides (16384: the old rule).
   static const uint64_t lds_entries = [] {
     const char *e = getenv("TGX_REGEX_LDS_ENTRIES");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)kRegexLdsEntries;
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)32767;
   }();
   const bool in_lds = direct || (entries <= lds_entries && entries * 2 <= 65535);
   const RegexLds lds = regex_lds_layout(dfa.n_states, dfa.n_classes, in_lds);
