@@ -260,6 +260,10 @@ impl GpuPlanner {
 
     /// `uniqueness` and the `validates_uniqueness / distinctness / unique_value_ratio / primary_key /
     /// uniqueness_with_nulls` family (check.rs:1480-1740).  `UniqueComposite` stays with the stock constraint.
+    /// String / binary / tuple keys are counted BY VALUE (`TGX_FLAG_EXACT_KEYS`: keyed fingerprints confirmed byte by
+    /// byte -- `COUNT(DISTINCT c)` as the stock constraint's DataFusion query computes it, uniqueness.rs:612-617) unless
+    /// [`GpuPlanner::exact_string_keys`] was turned off.  A run is one state fed by one stream, so nothing of it
+    /// crosses a state boundary (where keys would travel as fingerprints: INTEGRATION.md section 2).
     pub fn uniqueness<I, S>(&self, columns: I, kind: UniquenessType) -> TermResult<GpuConstraint>
     where
         I: IntoIterator<Item = S>,

@@ -40,8 +40,16 @@ def main():
             "LENGTH between 5 and 40": [spec(T.LENGTH, 0, length_min=5, length_max=40)],
             "DISTINCT + LENGTH + '@'": [spec(T.DISTINCT, 0), spec(T.LENGTH, 0, length_min=5, length_max=40),
                                         spec(T.REGEX_MATCH, 0, pattern="@")]}
+    # the same through the TABLE (what small batches, HOST batches and every batch after the first take): the list path
+    # switched off for these rows
+    sets["COUNT(DISTINCT) through the table"] = [spec(T.DISTINCT, 0)]
+    sets["COUNT(DISTINCT) through the table, exact key set (key store: 16 B + the key per distinct key)"] = \
+        [spec(T.DISTINCT, 0, flags=T.FLAG_EXACT_KEYS)]
     plain = col
     for name, specs in sets.items():
+        os.environ.pop("TGX_FP_LISTS_MIN_ROWS", None)
+        if "through the table" in name:
+            os.environ["TGX_FP_LISTS_MIN_ROWS"] = str(10**12)
         col = view_col if "Utf8View" in name else plain
         plan = T.Plan(specs)
         st = T.State(plan)

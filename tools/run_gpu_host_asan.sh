@@ -14,4 +14,4 @@ export LD_PRELOAD=$rt
 timeout 900 python tools/fuzz_device.py --host-only --first 0 --count "${1:-600}" --seed-timeout 120 > gpurun_out/asan_fuzz.log 2>&1
 grep "runtime error" gpurun_out/asan_fuzz.log | sed 's/^.*csrc\///' | sort | uniq -c | sort -rn | head -20
 grep -B2 -A12 "ERROR: AddressSanitizer" gpurun_out/asan_fuzz.log | head -40
-grep "^FAIL\|^STUCK\|cases (seeds" -A2 gpurun_out/asan_fuzz.log | cut -c1-300 | tail -12
+grep "^FAIL\|^STUCK\|cases of" -A2 gpurun_out/asan_fuzz.log | cut -c1-300 | tail -12
