@@ -27,6 +27,11 @@ HashSetView hash_view(const DistinctState &ds) {
   v.store = exact ? ds.key_store.as<uint64_t>() : nullptr;
   v.store_cursor = exact ? ds.key_cursor.as<unsigned long long>() : nullptr;
   v.store_words = exact ? ds.key_store_words : 0;
+  v.pending = exact ? ds.key_pending.as<uint64_t>() : nullptr;
+  v.pending_counts = exact ? ds.key_pending_counts.as<uint32_t>() : nullptr;
+  v.pending_region = exact ? ds.key_pending_region : 0;
+  v.pending_waves = exact ? ds.key_pending_waves : 0;
+  v.pad_ = 0;
   return v;
 }
 
@@ -67,13 +72,21 @@ tgx_status key_store_reserve_measured(tgx_state *st, DistinctState &ds, tgx_erro
   HIP_TRY(hipStreamSynchronize(st->stream));
   return key_store_ensure(st, ds, h[0], h[1], err);
 }
-tgx_status key_store_measure_begin(tgx_state *st, DistinctState &ds, tgx_error *err) {
-  HIP_TRY(hipMemsetAsync(ds.key_cursor.as<unsigned long long>() + 1, 0, 2 * sizeof(unsigned long long), st->stream));
+// before a batch's insert: the measuring pass's scratch and the pending list's fill are zero, and the list has room for
+// `items` new keys (every item of the batch at worst)
+tgx_status key_store_measure_begin(tgx_state *st, DistinctState &ds, uint64_t items, tgx_error *err) {
+  // the pending list of a batch of `items` items: a region per wave of the insert kernel's launch (exact_blocks)
+  ds.key_pending_waves = exact_waves(items);
+  ds.key_pending_region = exact_region(items);
+  HIP_TRY(ds.key_pending.reserve((size_t)ds.key_pending_waves * ds.key_pending_region * 16));
+  HIP_TRY(ds.key_pending_counts.reserve((size_t)ds.key_pending_waves * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(ds.key_pending_counts.p, 0, (size_t)ds.key_pending_waves * sizeof(uint32_t), st->stream));
+  HIP_TRY(hipMemsetAsync(ds.key_cursor.as<unsigned long long>() + 1, 0, 3 * sizeof(unsigned long long), st->stream));
   return TGX_OK;
 }
 // room for the keys of a string column batch (every valid row a new key at worst)
 tgx_status key_store_reserve_utf8(tgx_state *st, DistinctState &ds, const tgx_column &c, tgx_error *err) {
-  TGX_TRY(key_store_measure_begin(st, ds, err));
+  TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)c.length, err));
   const bool view = c.type == TGX_UTF8_VIEW;
   launch_exact_measure_utf8(c.offsets, c.data, view ? c.values : nullptr, view ? c.variadic : nullptr, c.validity, c.offset,
                             c.length, c.type == TGX_LARGE_UTF8, nullptr, ds.key_cursor.as<unsigned long long>() + 1,
@@ -240,7 +253,7 @@ tgx_status distinct_tuple_update(tgx_state *st, size_t slot, const tgx_column *d
   }
   TGX_TRY(hash_ensure(st, ds, task.multiplicity, (uint64_t)d.length, err));
   if (ds.exact) {
-    TGX_TRY(key_store_measure_begin(st, ds, err));
+    TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)d.length, err));
     launch_exact_measure_tuple(d, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
     TGX_TRY(key_store_reserve_measured(st, ds, err));
   }
@@ -448,7 +461,7 @@ tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
                         ds.counters.as<unsigned long long>(), g_ctx.n_cu, st->stream);
     }
     if (ds.exact) {  // room for the referenced entries
-      TGX_TRY(key_store_measure_begin(st, ds, err));
+      TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)dict.length, err));
       launch_exact_measure_utf8(dict.offsets, dict.data, nullptr, nullptr, dict.validity, dict.offset, dict.length,
                                 dict.type == TGX_LARGE_UTF8, u_seen, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
       TGX_TRY(key_store_reserve_measured(st, ds, err));
@@ -933,7 +946,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
         d.key = st->plan->fp_key;
         TGX_TRY(hash_ensure(st, ds, mult, (uint64_t)d.length, err));
         if (ds.exact) {
-          TGX_TRY(key_store_measure_begin(st, ds, err));
+          TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)d.length, err));
           launch_exact_measure_tuple(d, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
           TGX_TRY(key_store_reserve_measured(st, ds, err));
         }
@@ -971,6 +984,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       // (one entry of two words per distinct fingerprint; values that shared one were told apart by the lists and
       //  are one entry from here on)
       TGX_TRY(key_store_ensure(st, ds, cur, 2 * (c[kCntDistinct] + 1), err));
+      TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)kFpFan * kFpFan * l2.cap, err));  // (an item: a record's place)
       HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));  // (counted again as they go in)
       launch_fp_demote(l2, ds.fp_fb_lo.as<uint32_t>(), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
                        st->stream);
@@ -1159,6 +1173,7 @@ tgx_status tgx::distinct_import_records(tgx_state *st, size_t slot, const void *
     HIP_TRY(hipMemcpyAsync(&cur, ds.key_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st->stream));
     HIP_TRY(hipStreamSynchronize(st->stream));
     TGX_TRY(key_store_ensure(st, ds, cur, 2 * n, err));
+    TGX_TRY(key_store_measure_begin(st, ds, n, err));  // (room in the pending list, its fill zeroed)
   }
   // the EMPTY stand-in's rows arrive through counters[2]; [5] is scratch
   if (wide)

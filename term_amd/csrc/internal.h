@@ -342,6 +342,10 @@ struct DistinctState {
   bool exact = false;  // from the plan's task; only consulted when the set is `wide`
   DevBuf key_store, key_cursor;
   uint64_t key_store_words = 0;
+  // (slot, second word) of a batch's new keys between the insert and the commit: a region per wave of the insert kernel
+  DevBuf key_pending, key_pending_counts;
+  uint64_t key_pending_region = 0;
+  uint32_t key_pending_waves = 0;
   uint64_t capacity = 0;         // slots (power of two)
   uint64_t rows_upper_bound = 0; // host-side bound on keys in the table
   // counters (device) + host-side totals

@@ -215,17 +215,18 @@ __device__ __forceinline__ int hash_insert128(const HashSetView &t, uint64_t a, 
 // A row whose first word meets its own in a slot compares the second word (a cheap reject), then length and payload:
 // equal -> the same key; different -> two keys that share a fingerprint (with a secret key: never; with a known one:
 // the tests build them) and the probe moves on, exactly as in any hash table with full-key equality.
-// Visibility: an entry is written with agent-scope stores, then a release fence, then the reference is published;
-// readers load the reference and everything behind it with agent-scope atomic loads (the addresses depend on the
-// loaded reference, so the loads are ordered by the dependency).
+//
+// TWO PHASES per batch, so that nothing written inside a kernel has to be read inside it (the first version wrote the
+// entry, fenced and published its offset -- a release fence at agent scope is an L2 write-back: 100 ms per 100 M new
+// keys).  Phase A (the insert kernels): a new key's owner claims the slot as ever (one CAS on the first word) and
+// publishes `kPendingTag | item` -- the row / dictionary entry / record of THIS batch that holds the key -- with the
+// plain store the fingerprint sets publish their second word with, and notes (slot, second word) in the batch's pending
+// list; a later row with the same first word compares itself with that ITEM of the batch (read-only data: plain loads)
+// or, where the slot holds an offset, with the entry an earlier batch's phase B wrote.  Phase B (exact_commit_*): every
+// pending slot gets its entry (one store-cursor bump per wave of the grid) and the entry's offset replaces the item
+// reference.
 constexpr uint32_t kKindBytes = 0, kKindFpOnly = 1, kKindTuple = 2;
-
-__device__ __forceinline__ uint64_t store_load(const uint64_t *p) {
-  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void store_put(uint64_t *p, uint64_t w) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+constexpr uint64_t kPendingTag = 1ull << 62;  // (kEmptyKey -- not yet published -- has the bit too: tested first)
 
 // a string key: bytes [p, p + len) in global memory
 struct BytesKey {
@@ -236,30 +237,41 @@ struct BytesKey {
   __device__ __forceinline__ void emit(uint64_t *dst) const {
     GlobalWords src{p, len};
     const uint64_t n = payload_words();
-    for (uint64_t k = 0; k < n; k++) store_put(dst + k, src.next());
+    for (uint64_t k = 0; k < n; k++) dst[k] = src.next();
   }
   __device__ __forceinline__ bool equals(const uint64_t *entry, uint64_t entry_meta) const {
     if (entry_meta != meta() || (len >> 32)) return false;
     GlobalWords src{p, len};
     const uint64_t n = payload_words();
     for (uint64_t k = 0; k < n; k++)
-      if (store_load(entry + k) != src.next()) return false;
+      if (entry[k] != src.next()) return false;
+    return true;
+  }
+  __device__ __forceinline__ bool same_as(const BytesKey &o) const {
+    if (len != o.len) return false;
+    if (p == o.p) return true;
+    GlobalWords x{p, len}, y{o.p, o.len};
+    while (x.remaining > 0)
+      if (x.next() != y.next()) return false;
     return true;
   }
 };
-// a key that is only its fingerprint (imports)
+// a key that is only its fingerprint (imports; the lists of an exact set whose batch has been released)
 struct FpOnlyKey {
+  uint64_t b;  // the second fingerprint word (the first is what the slot holds)
   __device__ __forceinline__ uint64_t payload_words() const { return 0; }
   __device__ __forceinline__ uint64_t meta() const { return (uint64_t)kKindFpOnly << 32; }
   __device__ __forceinline__ void emit(uint64_t *) const {}
   __device__ __forceinline__ bool equals(const uint64_t *, uint64_t) const { return true; }  // 128 equal bits is all there is
+  __device__ __forceinline__ bool same_as(const FpOnlyKey &o) const { return b == o.b; }
 };
 
-// returns 1 if the key was new; *became_dup = 1 if this insert marks the key as seen twice
-template <class KEY>
-__device__ __forceinline__ int hash_insert_exact(const HashSetView &t, uint64_t a, uint64_t b, const KEY &key,
-                                                 int want_mult, int weight_two, int *became_dup,
-                                                 unsigned long long *counters) {
+// Phase A.  `item`: which item of the batch holds the key; `make(item)`: that item's key (for the rows that meet a
+// pending slot).  Returns 1 if the key was new (*slot: where); *became_dup = 1 if this insert marks the key as seen twice.
+template <class KEY, class MAKE>
+__device__ __forceinline__ int hash_insert_exact(const HashSetView &t, uint64_t a, uint64_t b, const KEY &key, uint64_t item,
+                                                 const MAKE &make, int want_mult, int weight_two, int *became_dup,
+                                                 uint64_t *slot) {
   uint64_t h = a & t.mask;
   for (;;) {
     unsigned long long *w0 = (unsigned long long *)&t.keys[2 * h];
@@ -267,62 +279,120 @@ __device__ __forceinline__ int hash_insert_exact(const HashSetView &t, uint64_t 
     const unsigned long long old0 = atomicCAS(w0, (unsigned long long)kEmptyKey, (unsigned long long)a);
     const uint32_t bit = 1u << (h & 31);
     if (old0 == kEmptyKey) {
-      // the owner: room in the store, the entry, a release fence, then the reference (lanes that meet the claimed
-      // slot meanwhile go round the loop again without moving on, as in hash_insert128)
-      const uint64_t n = 2 + key.payload_words();
-      // ONE reservation for all lanes of the wave that became owners in this trip round the loop (a cursor bumped
-      // by every new key is a single address: ~1 ns per key chip-wide, 100 ms per 100 M new keys)
-      uint64_t at;
-      {
-        const unsigned long long owners = __builtin_amdgcn_ballot_w64(true);  // the lanes in this branch
-        const int me = (int)(threadIdx.x & 63), first = __builtin_ctzll(owners);
-        uint64_t before = 0, total = 0;
-        for (unsigned long long m = owners; m; m &= m - 1) {
-          const int l = __builtin_ctzll(m);
-          const uint64_t nl = (uint64_t)__shfl((unsigned long long)n, l, 64);
-          before = l == me ? total : before;
-          total += nl;
-        }
-        unsigned long long base = 0;
-        if (me == first) base = atomicAdd(t.store_cursor, (unsigned long long)total);
-        base = __shfl(base, first, 64);
-        at = base + before;
-      }
-      if (at + n > t.store_words) {
-        atomicAdd(&counters[kCntStoreFull], 1ull);  // (the host sized the store for the worst case: never)
-        at = 0;                                      // word 0..1 of the store: a fingerprint-only stand-in entry
-      } else {
-        store_put(t.store + at, b);
-        store_put(t.store + at + 1, key.meta());
-        key.emit(t.store + at + 2);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_store(w1, (unsigned long long)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(w1, (unsigned long long)(kPendingTag | item), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (want_mult && weight_two) {
         const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
         *became_dup = (prev & bit) ? 0 : 1;
       }
+      *slot = h;
       return 1;
     }
     if (old0 == a) {
       const unsigned long long at = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (at == kEmptyKey) continue;  // claimed, the entry is on its way: look at this slot again
-      const uint64_t *e = t.store + at;
-      if (store_load(e) == b) {
-        const uint64_t meta = store_load(e + 1);
+      if (at == kEmptyKey) continue;  // claimed, the reference is on its way: look at this slot again
+      bool same;
+      if (at & kPendingTag) {
+        same = key.same_as(make(at & ~kPendingTag));  // an item of this batch
+      } else {
+        const uint64_t *e = t.store + at;  // an entry an earlier batch committed
         // an entry that is only a fingerprint stands for whatever value made it
-        if ((uint32_t)(meta >> 32) == kKindFpOnly || key.equals(e + 2, meta)) {
-          if (want_mult) {
-            if (!(__hip_atomic_load(&t.dup[h >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
-              const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
-              *became_dup = (prev & bit) ? 0 : 1;
-            }
+        same = e[0] == b && ((uint32_t)(e[1] >> 32) == kKindFpOnly || key.equals(e + 2, e[1]));
+      }
+      if (same) {
+        if (want_mult) {
+          if (!(__hip_atomic_load(&t.dup[h >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
+            const uint32_t prev = atomicOr(&t.dup[h >> 5], bit);
+            *became_dup = (prev & bit) ? 0 : 1;
           }
-          return 0;
         }
+        return 0;
       }
     }
     h = (h + 1) & t.mask;
+  }
+}
+
+// The pending list of a wave of the insert kernel: its own region, its own fill (no atomic).  note() is called once per
+// trip round the kernel's grid-stride loop by EVERY lane that is still in the loop (uniform control flow: the rows a
+// trip skips say `is_new = false`); lane 0 -- the smallest item index of the wave, so the last to leave -- writes the
+// fill when the wave is through.
+struct PendingWriter {
+  uint64_t base;
+  uint32_t count, wave;
+  __device__ __forceinline__ void begin(const HashSetView &t) {
+    wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    base = (uint64_t)wave * t.pending_region;
+    count = 0;
+  }
+  __device__ __forceinline__ void note(const HashSetView &t, bool is_new, uint64_t slot, uint64_t b, unsigned long long *counters) {
+    const unsigned long long owners = __builtin_amdgcn_ballot_w64(is_new);
+    if (is_new) {
+      const uint32_t at = count + (uint32_t)__builtin_popcountll(owners & ((1ull << (threadIdx.x & 63)) - 1ull));
+      if (at < t.pending_region && wave < t.pending_waves) {
+        t.pending[2 * (base + at)] = slot;
+        t.pending[2 * (base + at) + 1] = b;
+      } else {
+        atomicAdd(&counters[kCntStoreFull], 1ull);  // (a region holds every item its wave can see: never)
+      }
+    }
+    count += (uint32_t)__builtin_popcountll(owners);
+  }
+  __device__ __forceinline__ void end(const HashSetView &t) {
+    if ((threadIdx.x & 63) == 0 && wave < t.pending_waves) t.pending_counts[wave] = count < t.pending_region ? count : (uint32_t)t.pending_region;
+  }
+};
+
+// Phase B: the entries of the batch's new keys, wave w taking the region wave w of the insert kernel filled (same launch
+// shape): the region's words are added up, ONE bump of the store cursor makes room for all of them, then they are written.
+template <class MAKE>
+__device__ __forceinline__ void exact_commit(const HashSetView &t, const MAKE &make, unsigned long long *counters) {
+  const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (wave >= t.pending_waves) return;
+  const uint32_t n = t.pending_counts[wave];
+  if (n == 0) return;
+  const uint64_t *mine = t.pending + 2 * (uint64_t)wave * t.pending_region;
+  uint64_t total = 0;
+  for (uint32_t k = lane; k < n; k += 64) {
+    const uint64_t item = t.keys[2 * mine[2 * k] + 1] & ~kPendingTag;
+    total += 2 + make(item).payload_words();
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor((unsigned long long)total, d, 64);
+  unsigned long long at0 = 0;
+  if (lane == 0) at0 = atomicAdd(t.store_cursor, (unsigned long long)total);
+  at0 = __shfl(at0, 0, 64);
+  uint64_t run = at0;
+  for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const bool in = k < n;
+    uint64_t h = 0, b = 0, item = 0, words = 0;
+    if (in) {
+      h = mine[2 * k];
+      b = mine[2 * k + 1];
+      item = t.keys[2 * h + 1] & ~kPendingTag;
+      words = 2 + make(item).payload_words();
+    }
+    uint64_t incl = words;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t up = __shfl_up((unsigned long long)incl, d, 64);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    const uint64_t step = __shfl((unsigned long long)incl, 63, 64);
+    if (in) {
+      uint64_t at = run + incl - words;
+      if (at + words > t.store_words) {
+        atomicAdd(&counters[kCntStoreFull], 1ull);  // (the host sized the store for the worst case: never)
+        at = 0;                                      // words 0..1 of the store: a fingerprint-only stand-in entry
+      } else {
+        const auto key = make(item);
+        t.store[at] = b;
+        t.store[at + 1] = key.meta();
+        key.emit(t.store + at + 2);
+      }
+      t.keys[2 * h + 1] = at;
+    }
+    run += step;
   }
 }
 
@@ -370,24 +440,52 @@ __global__ __launch_bounds__(256) void distinct_utf8_kernel(Utf8ColDesc d, HashS
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   unsigned long long n_new = 0, n_dup = 0, n_valid = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  PendingWriter pw;
+  if (EXACT) pw.begin(t);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
     const int64_t slot = d.offset + i;
-    if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) continue;
-    n_valid++;
-    uintptr_t p;
-    uint64_t len, fa, fb;
-    utf8_value(d, slot, &p, &len);
-    fingerprint(d.key, p, len, &fa, &fb);
-    int became_dup = 0;
-    if (EXACT)
-      n_new += hash_insert_exact(t, fa, fb, BytesKey{p, len}, d.want_multiplicity, 0, &became_dup, counters);
-    else
-      n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
-    n_dup += became_dup;
+    const bool valid = !vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1);
+    bool is_new = false;
+    uint64_t at = 0, fa = 0, fb = 0;
+    if (valid) {
+      n_valid++;
+      uintptr_t p;
+      uint64_t len;
+      utf8_value(d, slot, &p, &len);
+      fingerprint(d.key, p, len, &fa, &fb);
+      int became_dup = 0;
+      if (EXACT) {
+        auto key_of_row = [&](uint64_t row) -> BytesKey {
+          uintptr_t q;
+          uint64_t ql;
+          utf8_value(d, d.offset + (int64_t)row, &q, &ql);
+          return BytesKey{q, ql};
+        };
+        is_new = hash_insert_exact(t, fa, fb, BytesKey{p, len}, (uint64_t)i, key_of_row, d.want_multiplicity, 0, &became_dup,
+                                   &at) != 0;
+        n_new += is_new ? 1 : 0;
+      } else {
+        n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
+      }
+      n_dup += became_dup;
+    }
+    if (EXACT) pw.note(t, is_new, at, fb, counters);
   }
+  if (EXACT) pw.end(t);
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
   __syncthreads();
   block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+// phase B of an exact string batch (rows of the column, or entries of a dictionary: the same layout)
+__global__ __launch_bounds__(256) void exact_commit_utf8_kernel(Utf8ColDesc d, HashSetView t, unsigned long long *counters) {
+  auto key_of_row = [&](uint64_t row) -> BytesKey {
+    uintptr_t q;
+    uint64_t ql;
+    utf8_value(d, d.offset + (int64_t)row, &q, &ql);
+    return BytesKey{q, ql};
+  };
+  exact_commit(t, key_of_row, counters);
 }
 
 // Words of key store a batch can need at most (every valid row a new key): what the host reserves before the batch
@@ -783,18 +881,36 @@ struct ExactUtf8Eq {
 // their bytes are one key if they share all 128 bits.
 __global__ __launch_bounds__(256) void fp_demote_kernel(FpLists l, const uint32_t *fb_lo, HashSetView t, int want_mult,
                                                          unsigned long long *counters) {
-  const uint32_t offered = l.offered[blockIdx.x];
-  const uint32_t n = offered < l.cap ? offered : (uint32_t)l.cap;
-  const ulonglong2 *recs = (const ulonglong2 *)l.recs + (uint64_t)blockIdx.x * l.cap;
+  // an item is a record's place in the lists (list x cap + i); places beyond a list's fill hold nothing
+  const uint64_t n_items = (uint64_t)(kFpFan * kFpFan) * l.cap, stride = (uint64_t)gridDim.x * blockDim.x;
+  const ulonglong2 *recs = (const ulonglong2 *)l.recs;
+  auto second_word = [&](const ulonglong2 &r) -> uint64_t { return (r.y & 0xFFFFFFFF00000000ull) | (uint64_t)fb_lo[(uint32_t)r.y]; };
+  auto key_of_rec = [&](uint64_t at) -> FpOnlyKey { return FpOnlyKey{second_word(recs[at])}; };
   unsigned long long n_new = 0, n_dup = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const ulonglong2 r = recs[i];
-    const uint64_t fb = (r.y & 0xFFFFFFFF00000000ull) | (uint64_t)fb_lo[(uint32_t)r.y];
-    int became_dup = 0;
-    n_new += hash_insert_exact(t, r.x, fb, FpOnlyKey{}, want_mult, 0, &became_dup, counters);
-    n_dup += became_dup;
+  PendingWriter pw;
+  pw.begin(t);
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_items; j += stride) {
+    const uint64_t list = j / l.cap, i = j - list * l.cap;
+    const uint32_t offered = l.offered[list];
+    bool is_new = false;
+    uint64_t at = 0, fb = 0;
+    if (i < (offered < l.cap ? offered : (uint32_t)l.cap)) {
+      const ulonglong2 r = recs[j];
+      fb = second_word(r);
+      int became_dup = 0;
+      is_new = hash_insert_exact(t, r.x, fb, FpOnlyKey{fb}, j, key_of_rec, want_mult, 0, &became_dup, &at) != 0;
+      n_new += is_new ? 1 : 0;
+      n_dup += became_dup;
+    }
+    pw.note(t, is_new, at, fb, counters);
   }
+  pw.end(t);
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
+}
+// phase B of keys that are only their fingerprints (demoted lists, imported records): the second word is in the
+// pending list, the entry has no payload
+__global__ __launch_bounds__(256) void exact_commit_fponly_kernel(HashSetView t, unsigned long long *counters) {
+  exact_commit(t, [](uint64_t) { return FpOnlyKey{0}; }, counters);
 }
 
 // the lists' records into the global table (counted already: no counters)
@@ -843,13 +959,20 @@ __global__ __launch_bounds__(256) void hash_import128_kernel(const KeyRecord128 
 __global__ __launch_bounds__(256) void hash_import_exact_kernel(const KeyRecord128 *recs, uint64_t n, HashSetView dst,
                                                                  int want_mult, unsigned long long *counters) {
   unsigned long long n_new = 0, n_dup = 0;
+  PendingWriter pw;
+  pw.begin(dst);
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const KeyRecord128 r = recs[i];
     int became_dup = 0;
-    n_new += hash_insert_exact(dst, r.a, r.b, FpOnlyKey{}, want_mult, r.count >= 2, &became_dup, counters);
+    uint64_t at = 0;
+    const bool is_new = hash_insert_exact(dst, r.a, r.b, FpOnlyKey{r.b}, i, [&](uint64_t j) { return FpOnlyKey{recs[j].b}; },
+                                          want_mult, r.count >= 2, &became_dup, &at) != 0;
+    n_new += is_new ? 1 : 0;
     n_dup += became_dup;
+    pw.note(dst, is_new, at, r.b, counters);
   }
+  pw.end(dst);
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
@@ -1004,13 +1127,13 @@ struct TupleKey {
   __device__ __forceinline__ void emit(uint64_t *dst) const {
     for (int c = 0; c < d->n_cols; c++) {
       const TupleComp comp = tuple_component(*d, c, row);
-      store_put(dst++, (uint64_t)comp.kind | (comp.len << 32));
+      *dst++ = (uint64_t)comp.kind | (comp.len << 32);
       if (comp.kind == 1) {
-        store_put(dst++, comp.value);
+        *dst++ = comp.value;
       } else if (comp.kind == 2) {
         GlobalWords src{comp.p, comp.len};
         const uint64_t n = (comp.len + 7) >> 3;
-        for (uint64_t k = 0; k < n; k++) store_put(dst++, src.next());
+        for (uint64_t k = 0; k < n; k++) *dst++ = src.next();
       }
     }
   }
@@ -1019,15 +1142,25 @@ struct TupleKey {
     for (int c = 0; c < d->n_cols; c++) {
       const TupleComp comp = tuple_component(*d, c, row);
       if (comp.len >> 32) return false;
-      if (store_load(entry++) != ((uint64_t)comp.kind | (comp.len << 32))) return false;
+      if (*entry++ != ((uint64_t)comp.kind | (comp.len << 32))) return false;
       if (comp.kind == 1) {
-        if (store_load(entry++) != comp.value) return false;
+        if (*entry++ != comp.value) return false;
       } else if (comp.kind == 2) {
         GlobalWords src{comp.p, comp.len};
         const uint64_t n = (comp.len + 7) >> 3;
         for (uint64_t k = 0; k < n; k++)
-          if (store_load(entry++) != src.next()) return false;
+          if (*entry++ != src.next()) return false;
       }
+    }
+    return true;
+  }
+  __device__ __forceinline__ bool same_as(const TupleKey &o) const {
+    if (row == o.row) return true;
+    for (int c = 0; c < d->n_cols; c++) {
+      const TupleComp x = tuple_component(*d, c, row), y = tuple_component(*d, c, o.row);
+      if (x.kind != y.kind) return false;
+      if (x.kind == 1 && x.value != y.value) return false;
+      if (x.kind == 2 && !BytesKey{x.p, x.len}.same_as(BytesKey{y.p, y.len})) return false;
     }
     return true;
   }
@@ -1058,21 +1191,32 @@ template <bool EXACT>
 __global__ __launch_bounds__(256) void distinct_tuple_kernel(TupleDesc d, HashSetView t, unsigned long long *counters) {
   unsigned long long n_new = 0, n_dup = 0, n_valid = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  PendingWriter pw;
+  if (EXACT) pw.begin(t);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.length; i += stride) {
-    uint64_t fa, fb;
-    bool all_valid;
+    uint64_t fa, fb, at = 0;
+    bool all_valid, is_new = false;
     tuple_fingerprint(d, i, &fa, &fb, &all_valid);
     n_valid += all_valid ? 1 : 0;
     int became_dup = 0;
-    if (EXACT)
-      n_new += hash_insert_exact(t, fa, fb, TupleKey{&d, i}, d.want_multiplicity, 0, &became_dup, counters);
-    else
+    if (EXACT) {
+      is_new = hash_insert_exact(t, fa, fb, TupleKey{&d, i}, (uint64_t)i, [&](uint64_t row) { return TupleKey{&d, (int64_t)row}; },
+                                 d.want_multiplicity, 0, &became_dup, &at) != 0;
+      n_new += is_new ? 1 : 0;
+      pw.note(t, is_new, at, fb, counters);
+    } else {
       n_new += hash_insert128(t, fa, fb, d.want_multiplicity, 0, &became_dup);
+    }
     n_dup += became_dup;
   }
+  if (EXACT) pw.end(t);
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
   __syncthreads();
   block_add2w(n_valid, 0ull, &counters[kCntValidRows], &counters[kCntSpare]);
+}
+
+__global__ __launch_bounds__(256) void exact_commit_tuple_kernel(TupleDesc d, HashSetView t, unsigned long long *counters) {
+  exact_commit(t, [&](uint64_t row) { return TupleKey{&d, (int64_t)row}; }, counters);
 }
 
 __global__ __launch_bounds__(256) void exact_measure_tuple_kernel(TupleDesc d, unsigned long long *out) {
@@ -1133,31 +1277,46 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(Utf8ColDesc dict, cons
                                                            unsigned long long *counters) {
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)dict.validity;
   unsigned long long n_new = 0, n_dup = 0;
+  PendingWriter pw;
+  if (EXACT) pw.begin(t);
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < dict.length; e += (int64_t)gridDim.x * 256) {
-    if (!((seen[e >> 5] >> (e & 31)) & 1)) continue;  // unreferenced entry
-    const uint32_t u = (dict.want_multiplicity && ((twice[e >> 5] >> (e & 31)) & 1)) ? 2 : 1;
     const int64_t slot = dict.offset + e;
-    if (vbits && !((vbits[slot >> 3] >> (slot & 7)) & 1)) continue;  // a NULL dictionary value
-    int64_t b, en;
-    if (dict.large_offsets) {
-      global_i64_ptr off = (global_i64_ptr)(uintptr_t)dict.offsets;
-      b = off[slot];
-      en = off[slot + 1];
-    } else {
-      global_i32_ptr off = (global_i32_ptr)(uintptr_t)dict.offsets;
-      b = off[slot];
-      en = off[slot + 1];
+    // an unreferenced entry, or a NULL dictionary value: nothing to insert
+    const bool live = ((seen[e >> 5] >> (e & 31)) & 1) && (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1));
+    bool is_new = false;
+    uint64_t at = 0, fa = 0, fb = 0;
+    if (live) {
+      const uint32_t u = (dict.want_multiplicity && ((twice[e >> 5] >> (e & 31)) & 1)) ? 2 : 1;
+      int64_t b, en;
+      if (dict.large_offsets) {
+        global_i64_ptr off = (global_i64_ptr)(uintptr_t)dict.offsets;
+        b = off[slot];
+        en = off[slot + 1];
+      } else {
+        global_i32_ptr off = (global_i32_ptr)(uintptr_t)dict.offsets;
+        b = off[slot];
+        en = off[slot + 1];
+      }
+      fingerprint(dict.key, (uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b), &fa, &fb);
+      int became_dup = 0;
+      if (EXACT) {
+        is_new = hash_insert_exact(t, fa, fb, BytesKey{(uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b)}, (uint64_t)e,
+                                   [&](uint64_t entry) -> BytesKey {
+                                     uintptr_t q;
+                                     uint64_t ql;
+                                     utf8_value(dict, dict.offset + (int64_t)entry, &q, &ql);
+                                     return BytesKey{q, ql};
+                                   },
+                                   dict.want_multiplicity, u >= 2, &became_dup, &at) != 0;
+        n_new += is_new ? 1 : 0;
+      } else {
+        n_new += hash_insert128(t, fa, fb, dict.want_multiplicity, u >= 2, &became_dup);
+      }
+      n_dup += became_dup;
     }
-    uint64_t fa, fb;
-    fingerprint(dict.key, (uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b), &fa, &fb);
-    int became_dup = 0;
-    if (EXACT)
-      n_new += hash_insert_exact(t, fa, fb, BytesKey{(uintptr_t)dict.data + (uintptr_t)b, (uint64_t)(en - b)},
-                                 dict.want_multiplicity, u >= 2, &became_dup, counters);
-    else
-      n_new += hash_insert128(t, fa, fb, dict.want_multiplicity, u >= 2, &became_dup);
-    n_dup += became_dup;
+    if (EXACT) pw.note(t, is_new, at, fb, counters);
   }
+  if (EXACT) pw.end(t);
   block_add2w(n_new, n_dup, &counters[kCntDistinct], &counters[kCntTwice]);
 }
 
@@ -1179,9 +1338,11 @@ void launch_dict_insert(const void *offsets, const uint8_t *data, const uint8_t 
   int64_t blocks = (length + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  if (t.store)
-    hipLaunchKernelGGL(dict_insert_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
-  else
+  if (t.store) {
+    const dim3 grid(exact_blocks((uint64_t)length));  // (the shape the pending list's regions were laid out for)
+    hipLaunchKernelGGL(dict_insert_kernel<true>, grid, dim3(256), 0, stream, d, seen, twice, t, d_counters);
+    hipLaunchKernelGGL(exact_commit_utf8_kernel, grid, dim3(256), 0, stream, d, t, d_counters);
+  } else
     hipLaunchKernelGGL(dict_insert_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, d, seen, twice, t, d_counters);
 }
 
@@ -1209,10 +1370,11 @@ void launch_distinct_utf8(const void *offsets, const uint8_t *data, const void *
   d.length = length;
   d.large_offsets = large_offsets;
   d.want_multiplicity = want_mult;
-  if (t.store)
-    hipLaunchKernelGGL(distinct_utf8_kernel<true>, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, t,
-                       d_counters);
-  else
+  if (t.store) {
+    const dim3 grid(exact_blocks((uint64_t)length));
+    hipLaunchKernelGGL(distinct_utf8_kernel<true>, grid, dim3(256), 0, stream, d, t, d_counters);
+    hipLaunchKernelGGL(exact_commit_utf8_kernel, grid, dim3(256), 0, stream, d, t, d_counters);
+  } else
     hipLaunchKernelGGL(distinct_utf8_kernel<false>, dim3(grid_for128((uint64_t)length)), dim3(256), 0, stream, d, t,
                        d_counters);
 }
@@ -1345,7 +1507,9 @@ void launch_fp_count_exact_tuple(const FpLists &level2, int want_mult, uint2 *pe
 }
 void launch_fp_demote(const FpLists &level2, const uint32_t *fb_lo, const HashSetView &t, int want_mult,
                       unsigned long long *d_counters, hipStream_t stream) {
-  hipLaunchKernelGGL(fp_demote_kernel, dim3(kFpFan * kFpFan), dim3(256), 0, stream, level2, fb_lo, t, want_mult, d_counters);
+  const dim3 grid(exact_blocks((uint64_t)(kFpFan * kFpFan) * level2.cap));  // (an item: a record's place in the lists)
+  hipLaunchKernelGGL(fp_demote_kernel, grid, dim3(256), 0, stream, level2, fb_lo, t, want_mult, d_counters);
+  hipLaunchKernelGGL(exact_commit_fponly_kernel, grid, dim3(256), 0, stream, t, d_counters);
 }
 
 void launch_fp_insert(const FpLists &level2, const HashSetView &t, int want_mult, hipStream_t stream) {
@@ -1361,10 +1525,11 @@ void launch_hash_rehash128(const HashSetView &src, const HashSetView &dst, int w
 void launch_hash_import128(const KeyRecord128 *recs, uint64_t n, const HashSetView &dst, int want_mult,
                            unsigned long long *d_counters, hipStream_t stream) {
   if (n == 0) return;
-  if (dst.store)
-    hipLaunchKernelGGL(hash_import_exact_kernel, dim3(grid_for128(n)), dim3(256), 0, stream, recs, n, dst, want_mult,
-                       d_counters);
-  else
+  if (dst.store) {
+    const dim3 grid(exact_blocks(n));
+    hipLaunchKernelGGL(hash_import_exact_kernel, grid, dim3(256), 0, stream, recs, n, dst, want_mult, d_counters);
+    hipLaunchKernelGGL(exact_commit_fponly_kernel, grid, dim3(256), 0, stream, dst, d_counters);
+  } else
     hipLaunchKernelGGL(hash_import128_kernel, dim3(grid_for128(n)), dim3(256), 0, stream, recs, n, dst,
                        want_mult, d_counters);
 }
@@ -1383,10 +1548,11 @@ void launch_hash_export_scatter128(const HashSetView &src, uint32_t world, int w
 
 void launch_distinct_tuple(const TupleDesc &d, const HashSetView &t, unsigned long long *d_counters,
                            hipStream_t stream) {
-  if (t.store)
-    hipLaunchKernelGGL(distinct_tuple_kernel<true>, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, t,
-                       d_counters);
-  else
+  if (t.store) {
+    const dim3 grid(exact_blocks((uint64_t)d.length));
+    hipLaunchKernelGGL(distinct_tuple_kernel<true>, grid, dim3(256), 0, stream, d, t, d_counters);
+    hipLaunchKernelGGL(exact_commit_tuple_kernel, grid, dim3(256), 0, stream, d, t, d_counters);
+  } else
     hipLaunchKernelGGL(distinct_tuple_kernel<false>, dim3(grid_for128((uint64_t)d.length)), dim3(256), 0, stream, d, t,
                        d_counters);
 }

@@ -26,7 +26,26 @@ struct HashSetView {
   uint64_t *store;                     // 8-byte words
   unsigned long long *store_cursor;    // next free word (device)
   uint64_t store_words;                // capacity; an entry that would not fit raises counters[kCntStoreFull]
+  // the batch's new keys between its two phases (distinct128.hip): (slot, second fingerprint word) pairs, every WAVE of
+  // the insert kernel filling a region of its own (a fill shared by all waves is one address: ~50 ns per bump, 80 ms per
+  // 100 M new keys -- measured twice, for the list and for the store cursor)
+  uint64_t *pending;
+  uint32_t *pending_counts;            // [waves]: pairs in each wave's region
+  uint64_t pending_region;             // pairs a region holds
+  uint32_t pending_waves, pad_;
 };
+// the launch shape of the insert kernels of an exact set (and of the commit kernels that follow them wave for wave)
+inline uint32_t exact_blocks(uint64_t items) {
+  uint64_t blocks = (items + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (uint32_t)blocks;
+}
+inline uint32_t exact_waves(uint64_t items) { return exact_blocks(items) * 4; }
+inline uint64_t exact_region(uint64_t items) {  // rows a wave of the grid-stride loop sees at most
+  const uint64_t threads = (uint64_t)exact_blocks(items) * 256;
+  return (items + threads - 1) / threads * 64;
+}
 
 // The 128-bit key of the fingerprint function (Chaskey's K, K1 = 2K, K2 = 4K in GF(2^128); distinct128.hip).  Drawn from
 // the OS at tgx_plan_create (or set by the caller: every rank / every state that exchanges keys must hold the same one).
