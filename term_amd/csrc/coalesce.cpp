@@ -1031,9 +1031,19 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
     const DistinctTask &t = plan->distinct[q];
     DistinctState &ds = st->distinct[q];
     ds.batch_range_known = false;
+    ds.batch_bytes_known = false;
     if (!t.tuple.empty() || t.approx_only) continue;
     const CoalesceColumn &cc = co.cols[t.column];
     ds.flush_device_keys = false;
+    // a string key column: the flush's value bytes were added up as its windows were noted (an exact key set sizes its
+    // key store from them without asking the device); a dictionary column: the bytes of the flush's dictionary
+    if (is_string(cc.type) && !cc.segs.empty()) {
+      ds.batch_bytes_known = true;
+      ds.batch_data_bytes = cc.data_bytes;
+    } else if (cc.type == TGX_DICT32_UTF8 && cc.dict && !cc.segs.empty()) {
+      ds.batch_bytes_known = true;
+      ds.batch_data_bytes = cc.dict->data_bytes;
+    }
     if (cc.type == TGX_INT64 && cc.range_known && cc.range_lo <= cc.range_hi && !cc.segs.empty()) {
       ds.batch_range_known = true;
       ds.batch_lo = cc.range_lo;
@@ -1071,6 +1081,7 @@ tgx_status tgx::coalesce_flush(tgx_state *st, tgx_error *err) {
   for (auto &ds : st->distinct) {
     ds.batch_range_known = false;
     ds.flush_device_keys = false;
+    ds.batch_bytes_known = false;
   }
   // views the key sets kept of this flush point into region set `set` -- also when the pass failed half-way: a view
   // that kept the tag of "the caller's memory" would dangle once the set is used again

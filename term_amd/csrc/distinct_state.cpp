@@ -49,6 +49,7 @@ tgx_status key_store_init(tgx_state *st, DistinctState &ds, tgx_error *err) {
   HIP_TRY(hipMemcpyAsync(ds.key_store.p, head, sizeof(head), hipMemcpyHostToDevice, st->stream));
   HIP_TRY(hipMemcpyAsync(ds.key_cursor.p, cur, sizeof(cur), hipMemcpyHostToDevice, st->stream));
   HIP_TRY(hipStreamSynchronize(st->stream));  // (`head` / `cur` are on this stack frame)
+  ds.key_words_ub = 2;
   return TGX_OK;
 }
 // Room for `incoming` more words behind the cursor (`cursor`: its value, just read back).  A bigger block takes the
@@ -70,7 +71,21 @@ tgx_status key_store_reserve_measured(tgx_state *st, DistinctState &ds, tgx_erro
   unsigned long long h[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(h, ds.key_cursor.p, sizeof(h), hipMemcpyDeviceToHost, st->stream));
   HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.key_words_ub = h[0] + h[1];
   return key_store_ensure(st, ds, h[0], h[1], err);
+}
+// ... or against the host's bound on the fill, when the host can bound the batch itself (`worst` words): no wait unless
+// the bound has run out of room -- then the real fill is read, and the store grows only if THAT needs it
+tgx_status key_store_reserve_bound(tgx_state *st, DistinctState &ds, uint64_t worst, tgx_error *err) {
+  if (ds.key_words_ub + worst <= ds.key_store_words) {
+    ds.key_words_ub += worst;
+    return TGX_OK;
+  }
+  unsigned long long cur = 0;
+  HIP_TRY(hipMemcpyAsync(&cur, ds.key_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st->stream));
+  HIP_TRY(hipStreamSynchronize(st->stream));
+  ds.key_words_ub = cur + worst;
+  return key_store_ensure(st, ds, cur, worst, err);
 }
 // before a batch's insert: the measuring pass's scratch and the pending list's fill are zero, and the list has room for
 // `items` new keys (every item of the batch at worst)
@@ -87,6 +102,8 @@ tgx_status key_store_measure_begin(tgx_state *st, DistinctState &ds, uint64_t it
 // room for the keys of a string column batch (every valid row a new key at worst)
 tgx_status key_store_reserve_utf8(tgx_state *st, DistinctState &ds, const tgx_column &c, tgx_error *err) {
   TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)c.length, err));
+  if (ds.batch_bytes_known && c.type != TGX_UTF8_VIEW)  // (an entry: two words + ceil(len / 8) <= len / 8 + 3 words)
+    return key_store_reserve_bound(st, ds, 3 * (uint64_t)c.length + (uint64_t)ds.batch_data_bytes / 8, err);
   const bool view = c.type == TGX_UTF8_VIEW;
   launch_exact_measure_utf8(c.offsets, c.data, view ? c.values : nullptr, view ? c.variadic : nullptr, c.validity, c.offset,
                             c.length, c.type == TGX_LARGE_UTF8, nullptr, ds.key_cursor.as<unsigned long long>() + 1,
@@ -462,9 +479,13 @@ tgx_status distinct_update(tgx_state *st, size_t slot, const tgx_column &c, tgx_
     }
     if (ds.exact) {  // room for the referenced entries
       TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)dict.length, err));
+      if (ds.batch_bytes_known) {
+        TGX_TRY(key_store_reserve_bound(st, ds, 3 * (uint64_t)dict.length + (uint64_t)ds.batch_data_bytes / 8, err));
+      } else {
       launch_exact_measure_utf8(dict.offsets, dict.data, nullptr, nullptr, dict.validity, dict.offset, dict.length,
                                 dict.type == TGX_LARGE_UTF8, u_seen, ds.key_cursor.as<unsigned long long>() + 1, st->stream);
       TGX_TRY(key_store_reserve_measured(st, ds, err));
+      }
     }
     launch_dict_insert(dict.offsets, dict.data, dict.validity, dict.offset, dict.length,
                        dict.type == TGX_LARGE_UTF8, mult ? 1 : 0, u_seen, u_twice, hash_view(ds), st->plan->fp_key,
@@ -984,6 +1005,7 @@ tgx_status tgx::distinct_resolve(tgx_state *st, size_t slot, tgx_error *err) {
       // (one entry of two words per distinct fingerprint; values that shared one were told apart by the lists and
       //  are one entry from here on)
       TGX_TRY(key_store_ensure(st, ds, cur, 2 * (c[kCntDistinct] + 1), err));
+      ds.key_words_ub = cur + 2 * (c[kCntDistinct] + 1);
       TGX_TRY(key_store_measure_begin(st, ds, (uint64_t)kFpFan * kFpFan * l2.cap, err));  // (an item: a record's place)
       HIP_TRY(hipMemsetAsync(ds.counters.p, 0, 2 * sizeof(unsigned long long), st->stream));  // (counted again as they go in)
       launch_fp_demote(l2, ds.fp_fb_lo.as<uint32_t>(), hash_view(ds), mult ? 1 : 0, ds.counters.as<unsigned long long>(),
@@ -1173,6 +1195,7 @@ tgx_status tgx::distinct_import_records(tgx_state *st, size_t slot, const void *
     HIP_TRY(hipMemcpyAsync(&cur, ds.key_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st->stream));
     HIP_TRY(hipStreamSynchronize(st->stream));
     TGX_TRY(key_store_ensure(st, ds, cur, 2 * n, err));
+    ds.key_words_ub = cur + 2 * n;
     TGX_TRY(key_store_measure_begin(st, ds, n, err));  // (room in the pending list, its fill zeroed)
   }
   // the EMPTY stand-in's rows arrive through counters[2]; [5] is scratch

@@ -346,6 +346,12 @@ struct DistinctState {
   DevBuf key_pending, key_pending_counts;
   uint64_t key_pending_region = 0;
   uint32_t key_pending_waves = 0;
+  // host-side bound on the store's fill (the cursor lives on the device): a batch whose worst case the host can bound --
+  // a coalesced flush of a Utf8 / dictionary column: its bytes were counted as they were noted (`batch_data_bytes`) --
+  // reserves against this bound and waits for nothing; only when the bound no longer fits is the real fill read back
+  uint64_t key_words_ub = 0;
+  bool batch_bytes_known = false;
+  int64_t batch_data_bytes = 0;
   uint64_t capacity = 0;         // slots (power of two)
   uint64_t rows_upper_bound = 0; // host-side bound on keys in the table
   // counters (device) + host-side totals

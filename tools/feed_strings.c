@@ -129,16 +129,44 @@ int main(int argc, char **argv) {
   specs[2].length_max = 64;
   tgx_plan *plan = NULL;
   CHECK_TGX(tgx_plan_create(specs, 3, &plan, &err));
-  tgx_result res[3];
+  /* the fourth leg: the Utf8 column again with a uniqueness check BY VALUE on top (an exact key set: what the shim's
+   * `uniqueness` asks for; small batches take the table path, where the keys' bytes are kept) */
+  tgx_check_spec specs_keys[4];
+  memcpy(specs_keys, specs, sizeof(specs));
+  memset(&specs_keys[3], 0, sizeof(specs_keys[3]));
+  specs_keys[3].kind = TGX_CHECK_DISTINCT;
+  specs_keys[3].column = 0;
+  specs_keys[3].column2 = -1;
+  specs_keys[3].flags = getenv("TGX_FEED_FINGERPRINT_KEYS") ? 0 : TGX_FLAG_EXACT_KEYS; /* (for A/B runs) */
+  tgx_plan *plan_keys = NULL;
+  CHECK_TGX(tgx_plan_create(specs_keys, 4, &plan_keys, &err));
+  int64_t n_distinct = 0; /* (the generator's 131 072 draws repeat now and then) */
+  {
+    uint64_t *us = malloc(kDistinct * sizeof(uint64_t));
+    for (int i = 0; i < kDistinct; i++) us[i] = mix64(5 + (uint64_t)i) % 1000000000ull;
+    /* (a shell sort: no libc callback needed) */
+    for (int gap = kDistinct / 2; gap > 0; gap /= 2)
+      for (int i = gap; i < kDistinct; i++) {
+        const uint64_t v = us[i];
+        int j = i;
+        for (; j >= gap && us[j - gap] > v; j -= gap) us[j] = us[j - gap];
+        us[j] = v;
+      }
+    for (int i = 0; i < kDistinct; i++) n_distinct += i == 0 || us[i] != us[i - 1];
+    free(us);
+  }
+  tgx_result res[4];
 
-  const char *layouts[3] = {"utf8", "view", "dict"};
-  const char *names[3] = {"Utf8", "Utf8View", "Dictionary<Int32, Utf8>"};
-  const double row_bytes[3] = {(double)offsets[n] / (double)n + 4.0, (double)offsets[n] / (double)n + 16.0,
-                               4.0 + ((double)dict_bytes + 4.0 * kDistinct) / (double)n};
-  for (int l = 0; l < 3; l++) {
+  const char *layouts[4] = {"utf8", "view", "dict", "utf8keys"};
+  const char *names[4] = {"Utf8", "Utf8View", "Dictionary<Int32, Utf8>", "Utf8"};
+  const double row_bytes[4] = {(double)offsets[n] / (double)n + 4.0, (double)offsets[n] / (double)n + 16.0,
+                               4.0 + ((double)dict_bytes + 4.0 * kDistinct) / (double)n, (double)offsets[n] / (double)n + 4.0};
+  for (int l = 0; l < 4; l++) {
     if (only && strcmp(only, layouts[l]) != 0) continue;
+    const int with_keys = l == 3;
+    tgx_plan *const plan_l = with_keys ? plan_keys : plan;
     tgx_state *st = NULL;
-    CHECK_TGX(tgx_state_create(plan, NULL, &st, &err));
+    CHECK_TGX(tgx_state_create(plan_l, NULL, &st, &err));
     /* the last two legs: the same batches as TGX_MEM_HOST_RETAINED -- buffers the caller keeps as they are until
      * tgx_finalize (what a consumer that holds its RecordBatches can promise): the copies wait for the flush */
     const int64_t batch_sizes[5] = {n, 65536, 8192, 65536, 8192};
@@ -149,7 +177,7 @@ int main(int argc, char **argv) {
       if (only_rows < 0 && (rows != -only_rows || !kept)) continue; /* negative: the kept leg of that size */
       double best = 1e30;
       for (int rep = 0; rep < 4; rep++) { /* the first pass allocates: best of the rest */
-        CHECK_TGX(tgx_state_reset(plan, st, &err));
+        CHECK_TGX(tgx_state_reset(plan_l, st, &err));
         CHECK_HIP(hipDeviceSynchronize());
         const double t0 = now();
         for (int64_t lo = 0; lo < n; lo += rows) {
@@ -160,7 +188,7 @@ int main(int argc, char **argv) {
           c.length = lo + rows <= n ? rows : n - lo;
           c.offset = lo; /* a slice of the column's buffers, as Arrow hands them out */
           c.null_count = 0;
-          if (l == 0) {
+          if (l == 0 || l == 3) {
             c.type = TGX_UTF8;
             c.offsets = offsets;
             c.data = data;
@@ -175,23 +203,25 @@ int main(int argc, char **argv) {
             c.values = indices;
             c.dictionary = &dictionary;
           }
-          CHECK_TGX(tgx_update(plan, st, &c, 1, &err));
+          CHECK_TGX(tgx_update(plan_l, st, &c, 1, &err));
         }
-        CHECK_TGX(tgx_finalize(plan, st, res, 3, &err));
+        CHECK_TGX(tgx_finalize(plan_l, st, res, with_keys ? 4 : 3, &err));
         const double dt = now() - t0;
         if (rep > 0 && dt < best) best = dt;
       }
-      const int ok = res[0].total == n && res[0].non_null == n && res[1].matches == n && res[2].matches == n;
+      const int ok = res[0].total == n && res[0].non_null == n && res[1].matches == n && res[2].matches == n &&
+                     (!with_keys || res[3].distinct == n_distinct);
       const int64_t updates = (n + rows - 1) / rows;
-      printf("{\"workload\": \"HOST %s column%s, %lld rows x %.0f B, completeness + e-mail format + length (plain C)\", "
+      printf("{\"workload\": \"HOST %s column%s%s, %lld rows x %.0f B, completeness + e-mail format + length (plain C)\", "
              "\"batch_rows\": %lld, \"updates\": %lld, \"total_ms\": %.3f, \"us_per_update\": %.3f, \"rows_per_s\": %.4g, "
              "\"host_to_device_GBs\": %.3g, \"verified\": %s}\n",
-             names[l], kept ? " (kept until finalize)" : "", (long long)n, row_bytes[l], (long long)rows, (long long)updates, best * 1e3,
+             names[l], with_keys ? " + uniqueness by value" : "", kept ? " (kept until finalize)" : "", (long long)n, row_bytes[l], (long long)rows, (long long)updates, best * 1e3,
              best * 1e6 / (double)updates, (double)n / best, (double)n * row_bytes[l] / best / 1e9, ok ? "true" : "false");
       fflush(stdout);
     }
     tgx_state_destroy(st);
   }
   tgx_plan_destroy(plan);
+  tgx_plan_destroy(plan_keys);
   return 0;
 }
