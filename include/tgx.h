@@ -193,7 +193,11 @@ enum {
    * bytes -- `COUNT(DISTINCT c)` as DataFusion computes it (hash + equality, TG/constraints/uniqueness.rs:612-617,
    * 671-681, 709-715), for every input including one built against the fingerprint function.  What crosses a state
    * boundary (tgx_merge, state blobs, tgx_distinct_export / tgx_allreduce) travels as keyed fingerprints either way:
-   * bytes never leave the device that was fed them.  Numeric keys are exact regardless of the flag. */
+   * bytes never leave the device that was fed them.  One more place where keys go on as fingerprints: a first DEVICE
+   * batch of 2 Mi rows or more is deduplicated in lists that refer to its rows (equal fingerprints are settled on the
+   * rows' bytes); tgx_finalize hands the batch back to the caller, so a state that is FED AGAIN after tgx_finalize holds
+   * that batch's keys by fingerprint from then on -- tgx_state_sync (instead of, or before, tgx_finalize) moves them
+   * into the table with their bytes.  Numeric keys are exact regardless of the flag. */
   TGX_FLAG_EXACT_KEYS = 1u << 6
 };
 
