@@ -858,6 +858,8 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
       pp.key16 = prep.key16 ? 1 : pack20 ? 2 : 0;
       static const bool no_probe = getenv("TGX_NO_CLUSTERED_PROBE") && atoi(getenv("TGX_NO_CLUSTERED_PROBE")) != 0;
       pp.probe = no_probe ? 0 : 1;
+      static const bool no_force = getenv("TGX_NO_FORM_MEMORY") && atoi(getenv("TGX_NO_FORM_MEMORY")) != 0;
+      pp.force_form = (no_force || no_probe) ? 0 : ds.remembered_form;
       HIP_TRY(ds.lists.reserve(prep.key16 ? (uint64_t)pp.n_lists * pp.cap * sizeof(uint16_t)
                                : pack20   ? (uint64_t)pp.n_lists * pp.cap / 3 * 8
                                           : (uint64_t)pp.n_lists * pp.cap * sizeof(uint32_t)));
@@ -888,8 +890,8 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
         L.cols[0].length = c.length;
         L.cols[0].is_float = 0;
         L.acc_index[0] = stats_slot;
-        launch_partition_outlier_stats(pp.outliers, pp.stats, grid, st->stream);
-        launch_scan_reduce_only(L, 1, grid + 1, pp.stats, st->d_scan_acc.as<ScanAcc>(), st->stream);
+        // (the outliers' share is folded by the same launch: scan_reduce_kernel)
+        launch_scan_reduce_only(L, 1, grid, pp.stats, st->d_scan_acc.as<ScanAcc>(), st->stream, pp.outliers);
       }
     } else {
       ProfScope ps(st, "distinct", bytes);

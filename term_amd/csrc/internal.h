@@ -57,7 +57,7 @@ void launch_comoments_reduce(const ComomentLaunch &L, int n_pairs, int blocks_pe
 // mode: 0 Int32, 1 Float32, 2 Int8, 3 Int16, 4 UInt8, 5 UInt16, 6 UInt32, 7 Boolean (bits) -> Int64 / Float64
 void launch_widen32(const void *src, void *dst, int64_t n, int mode, int n_cu, hipStream_t stream);
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
-                             ScanAcc *d_accs, hipStream_t stream);
+                             ScanAcc *d_accs, hipStream_t stream, const OutlierStats *outliers = nullptr);
 void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,
                   CountAcc *d_accs, hipStream_t stream);
 size_t comoments_partial_bytes();
@@ -375,6 +375,10 @@ struct DistinctState {
   // step of a runner that checks table after table of one shape); forgotten as soon as a repair finds a key outside
   bool remembered = false;
   int64_t remembered_lo = 0, remembered_hi = 0;
+  // ... and which form the partition pass of the column's last batch took (counters[kCntForm]: 1 plain, 2 keys in
+  // order; 0: not known): the next pass launches only that form (PartitionParams::force_form); outlives tgx_state_reset
+  // like the range
+  int32_t remembered_form = 0;
   // some batch since the last look at the counters may have left keys outside the bitmap's range (its range was a
   // sample's, or unknown: DEVICE buffers).  The range must then stay as it is until they have been repaired: the
   // repair walks the retained batches for the keys outside the range, so a bitmap grown over them in the meantime

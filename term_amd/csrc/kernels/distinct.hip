@@ -630,7 +630,8 @@ __device__ __forceinline__ void partition_outlier_stats(const PartitionParams &p
 template <int THREADS, int KPT, int MAXP, int PAD, bool VALIDITY, bool KEY16, bool STATS, bool FORM_CLUSTERED, bool PACK20 = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_kernel(
     PartitionParams p, unsigned long long *counters) {
-  if ((__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) != FORM_CLUSTERED) return;
+  if ((p.force_form ? p.force_form == 2 : __builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) != FORM_CLUSTERED)
+    return;
   constexpr int kTile = THREADS * KPT;
   __shared__ uint32_t sorted[kTile];     // the tile, grouped by bucket
   __shared__ uint32_t hist[MAXP];        // pass 1: keys per bucket; pass 2: placement cursors
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <int THREADS, int KPT, bool VALIDITY, bool STATS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void partition_carry_kernel(
     PartitionParams p, unsigned long long *counters) {
-  if (__builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) return;
+  if (p.force_form ? p.force_form == 2 : __builtin_amdgcn_readfirstlane((int)p.cursors[2 * p.n_buckets]) != 0) return;
   constexpr int kTile = THREADS * KPT;
   constexpr int MAXP = THREADS;          // one bucket per thread in the scan, the carry update and the flush
   constexpr uint32_t NW = THREADS / 64;  // waves
@@ -1538,19 +1539,24 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   // (software-pipelined variants -- next tile requested before this tile's stores -- were measured three times:
   //  with spills 3.3 ms, as 512 threads x 64 keys with 256 registers 6.0 ms, and spill-free 2.9 ms against
   //  2.7 ms without: the load and store phases already run at HBM rate and the other CUs fill the gaps)
+  const bool plain = p.force_form != 2, in_order = p.force_form != 1;  // (force_form 0: both, the flag picks)
 #define TGX_PART(VAL, K16, ST)                                                                                      \
   do {                                                                                                              \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, false>), \
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, true>), \
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+    if (plain)                                                                                                      \
+      hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, false>), \
+                         dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                            \
+    if (in_order)                                                                                                   \
+      hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, K16, ST, true>), \
+                         dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                            \
   } while (0)
 #define TGX_PART20(VAL, ST)                                                                                         \
   do {                                                                                                              \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, false, true>), \
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+    if (plain)                                                                                                      \
+      hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, false, true>), \
+                         dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                            \
+    if (in_order)                                                                                                   \
+      hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
+                         dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                            \
   } while (0)
   // the 20-bit lists without multiplicity, up to 1024 buckets: the runs' remainders are carried from tile to tile
   // (partition_carry_kernel; keys in order keep the CLUSTERED form of partition_kernel) -- an experiment that lost
@@ -1562,10 +1568,12 @@ void launch_partition(const PartitionParams &p, unsigned long long *d_counters, 
   if (p.key16 == 2 && carry_on && !p.want_multiplicity && p.n_buckets <= 1024) {
 #define TGX_CARRY(VAL, ST)                                                                                           \
   do {                                                                                                              \
-    hipLaunchKernelGGL((partition_carry_kernel<kPartitionThreads, 16, VAL, ST>), dim3(grid), dim3(kPartitionThreads), 0,   \
-                       stream, p, d_counters);                                                                      \
-    hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
-                       dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                              \
+    if (p.force_form != 2)                                                                                          \
+      hipLaunchKernelGGL((partition_carry_kernel<kPartitionThreads, 16, VAL, ST>), dim3(grid), dim3(kPartitionThreads), 0, \
+                         stream, p, d_counters);                                                                    \
+    if (p.force_form != 1)                                                                                          \
+      hipLaunchKernelGGL((partition_kernel<kPartitionThreads, kPartitionKeysPerThread, (int)kMaxPartitions, kRunPad4, VAL, false, ST, true, true>), \
+                         dim3(grid), dim3(kPartitionThreads), 0, stream, p, d_counters);                            \
   } while (0)
     if (p.stats) {
       if (p.validity) TGX_CARRY(true, true); else TGX_CARRY(false, true);
@@ -1883,7 +1891,11 @@ __global__ __launch_bounds__(1024) void partition_init_kernel(PartitionParams p,
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) cursors[2 * n_buckets] = (p.probe && asked >= 4 && 4 * agree >= 3 * asked) ? 1ull : 0ull;
+  if (threadIdx.x == 0) {
+    const unsigned long long in_order = (p.probe && asked >= 4 && 4 * agree >= 3 * asked) ? 1ull : 0ull;
+    cursors[2 * n_buckets] = in_order;
+    totals[kCntForm] = 1ull + in_order;  // (the host reads it with the counters: PartitionParams::force_form)
+  }
 }
 
 void launch_partition_init(const PartitionParams &p, unsigned long long *totals, hipStream_t stream) {

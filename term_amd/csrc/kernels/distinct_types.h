@@ -121,7 +121,11 @@ struct PartitionParams {
   // sized for these only; a key that lands in another bucket after all takes the spill path (exact, slow)
   uint32_t bucket0, n_lists;
   int32_t probe;  // 0: partition_init_kernel leaves the clustered flag at 0 (TGX_NO_CLUSTERED_PROBE=1: for A/B runs)
-  int32_t pad_;
+  // 0: the probe's flag picks the form and BOTH forms of partition_kernel are launched (the other one leaves at once:
+  // ~5 us of a 1.6 ms step); 1 / 2: the host remembers which form the column's last batch took (counters[kCntForm]) and
+  // launches only that one -- plain / CLUSTERED -- whatever the probe says: both forms are exact for any keys, a wrong
+  // guess costs time once and is corrected by the next look at the counters
+  int32_t force_form;
 };
 
 // keys outside the bitmap's range enter the column's aggregates through global atomics (they are rare: the range
@@ -179,6 +183,7 @@ enum {
   kCntOutOfRange = 4, // bitmap mode: keys outside [base, base+range); fingerprint lists: overflows -- must stay 0
   kCntSpare = 5,
   kCntStoreFull = 6,  // exact key sets: entries that did not fit the key store -- must stay 0
+  kCntForm = 7,       // the partition pass's last probe: 1 plain, 2 keys in order (PartitionParams::force_form)
   kNumDistinctCounters = 8
 };
 

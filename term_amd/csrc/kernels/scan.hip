@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
+#include "distinct_types.h"
 
 namespace tgx {
 
@@ -1136,10 +1137,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(const ScanPairLau
 
 // Folds the per-block partials of each column (fixed order => bitwise reproducible) and merges
 // the batch into the running per-column state.  grid = columns, block = 64 (one wave).
+// `outliers` (a key column's uniqueness pass took its aggregates along, kernels/distinct.hip: one column per launch):
+// the share of the keys that fell outside the sampled range, collected through global atomics, is one more partial --
+// folded here instead of by a launch of its own (round 6: a launch is ~5 us of a 1.6 ms C2 step whatever it does).
 __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
                                                           const ScanPartial *__restrict__ partials,
                                                           int blocks_per_col,
-                                                          ScanAcc *__restrict__ accs) {
+                                                          ScanAcc *__restrict__ accs,
+                                                          const OutlierStats *__restrict__ outliers) {
   const int col = blockIdx.x;
   const int lane = threadIdx.x;
   if (L.acc_index[col] < 0) return;  // a column scanned only for what rode on it (KLL sampler, co-moments)
@@ -1147,6 +1152,17 @@ __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
   const ScanPartial *p = partials + (size_t)col * blocks_per_col;
   LaneAcc a;
   acc_init(a);
+  if (outliers && lane == 0 && outliers->count) {
+    LaneAcc b;
+    acc_init(b);
+    b.mn = outliers->mn;
+    b.mx = outliers->mx;
+    const __int128 sum = (__int128)(unsigned __int128)outliers->lo32_sum + (((__int128)outliers->hi32_sum) << 32);
+    b.lo = (uint64_t)sum;
+    b.hi = (int64_t)(sum >> 64);
+    b.cnt = (int64_t)outliers->count;
+    acc_merge(a, b, c.is_float);
+  }
   for (int i = lane; i < blocks_per_col; i += 64) {
     LaneAcc b;
     b.mn = p[i].min_k;
@@ -1430,9 +1446,9 @@ void launch_scan_pairs(const ScanPairLaunch &L, int n_pairs, int blocks_per_pair
 }
 
 void launch_scan_reduce_only(const ScanLaunch &L, int n_cols, int blocks_per_col, ScanPartial *d_partials,
-                             ScanAcc *d_accs, hipStream_t stream) {
+                             ScanAcc *d_accs, hipStream_t stream, const OutlierStats *outliers) {
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(n_cols), dim3(64), 0, stream, L, d_partials, blocks_per_col,
-                     d_accs);
+                     d_accs, outliers);
 }
 
 void launch_count(const CountLaunch &L, int n_cols, int blocks_per_col, unsigned long long *d_block_counts,

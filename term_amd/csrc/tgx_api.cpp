@@ -860,6 +860,9 @@ tgx_status gather(tgx_state *st, Gathered *g, tgx_error *err) {
     bool repaired = false;
     for (size_t k = 0; k < st->distinct.size(); k++) {
       DistinctState &ds = st->distinct[k];
+      // (which form the key column's last partition pass took: the next pass launches only that one)
+      if (!all.empty() && (all[k * kNumDistinctCounters + kCntForm] == 1 || all[k * kNumDistinctCounters + kCntForm] == 2))
+        ds.remembered_form = (int32_t)all[k * kNumDistinctCounters + kCntForm];
       if ((ds.speculative || ds.fp_staged) && !ds.retained.empty() && !all.empty() &&
           all[k * kNumDistinctCounters + kCntOutOfRange] != 0) {
         TGX_TRY(distinct_resolve(st, k, err));
