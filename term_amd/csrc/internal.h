@@ -67,7 +67,6 @@ void launch_distinct_hash(const DistinctColDesc &d, const HashSetView &t,
                           unsigned long long *d_counters, hipStream_t stream);
 void launch_distinct_bitmap(const DistinctColDesc &d, const BitmapView &bm,
                             unsigned long long *d_counters, hipStream_t stream);
-void launch_partition_outlier_stats(const OutlierStats *g, ScanPartial *partials, int at, hipStream_t stream);
 int partition_grid(int64_t length, int n_cu);  // workgroups of launch_partition (= ScanPartials it writes with stats)
 void launch_distinct_init(DistinctSample *sample, OutlierStats *outliers, hipStream_t stream);
 void launch_partition_init(const PartitionParams &p, unsigned long long *totals, hipStream_t stream);

@@ -1062,25 +1062,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   block_add2(n_valid, n_out, &counters[kCntValidRows], &counters[kCntOutOfRange]);
 }
 
-// the outliers' share of the aggregates as one more partial (index `at`), once the partition pass is through
-__global__ void partition_outlier_stats_kernel(const OutlierStats *g, ScanPartial *partials, int at) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  ScanPartial out;
-  out.min_k = INT64_MAX;
-  out.max_k = INT64_MIN;
-  out.sum_lo = 0;
-  out.sum_hi = 0;
-  out.non_null = (int64_t)g->count;
-  out.sum = out.comp = out.s1 = out.s2 = 0.0;
-  if (g->count) {
-    out.min_k = g->mn;
-    out.max_k = g->mx;
-    const __int128 sum = (__int128)(unsigned __int128)g->lo32_sum + (((__int128)g->hi32_sum) << 32);
-    out.sum_lo = (uint64_t)sum;
-    out.sum_hi = (int64_t)(sum >> 64);
-  }
-  partials[at] = out;
-}
+// (the outliers' share of the aggregates -- OutlierStats -- is folded by scan_reduce_kernel, kernels/scan.hip)
 
 // A strided sample of the column (at most 2^16 rows, evenly spread): where its keys lie, before anything has read
 // it.  The DISTINCT pass lays its range bitmap out from this estimate (with slack) and takes the column's range
@@ -1807,9 +1789,6 @@ void launch_bitmap_adopt(const uint32_t *seen_slices, const uint32_t *twice_slic
                      twice_slices, n_slices, slice_words, stride_words, out_seen, out_twice, d_counters);
 }
 
-void launch_partition_outlier_stats(const OutlierStats *g, ScanPartial *partials, int at, hipStream_t stream) {
-  hipLaunchKernelGGL(partition_outlier_stats_kernel, dim3(1), dim3(64), 0, stream, g, partials, at);
-}
 
 int partition_grid(int64_t length, int n_cu) {
   int64_t n_tiles = (length + kPartitionTile - 1) / kPartitionTile;
