@@ -426,3 +426,57 @@ def test_states_of_different_keys_do_not_unite():
     s = T.State(n1)
     s.update([T.Column.int64(to_device(np.arange(100, dtype=np.int64)), None)])
     assert T.State.deserialize(n2, s.serialize()).finalize()[0].distinct == 100
+
+
+def test_ranks_with_different_keys_all_refuse_and_with_one_key_agree():
+    """tgx_allreduce: string keys travel between ranks as fingerprints, which mean the same everywhere only under ONE key
+    (tgx_plan_set_fingerprint_key; term_amd.distributed.shared_fingerprint_key broadcasts rank 0's).  Ranks whose plans
+    hold different keys all return TGX_INVALID_ARGUMENT from the facts round -- nobody is left in a collective -- and
+    the same shards under one key give the oracle's counts."""
+    import threading
+
+    import torch
+
+    from term_amd.distributed import ThreadGroup, sharded_suite_step, thread_comm
+
+    rng = np.random.default_rng(21)
+    vals = background(rng, 60_000, 9_000)
+    offs, data, validity = orc.utf8_from_list(vals)
+    want = orc.distinct_utf8(offs, data, validity)
+    cuts = [0, 20_032, 41_024, len(vals)]
+    sp = [spec(T.DISTINCT, 0, flags=T.FLAG_MULTIPLICITY | T.FLAG_EXACT_KEYS), spec(T.COUNT, 0)]
+    T.init()
+
+    def run(keys):
+        group, out = ThreadGroup(3), [None] * 3
+
+        def worker(rank):
+            try:
+                torch.cuda.set_device(0)
+                plan = T.Plan(sp, fingerprint_key=keys[rank])
+                st = T.State(plan)
+                comm = thread_comm(group, rank, device_buffers=True)
+                shard = [column_of(vals[cuts[rank]:cuts[rank + 1]])[0]]
+                out[rank] = ("ok", sharded_suite_step(plan, st, shard, comm))
+            except T.TgxError as e:
+                out[rank] = ("error", e)
+            except Exception as e:  # noqa: BLE001
+                out[rank] = ("crash", e)
+                group.barrier.abort()
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a rank is stuck"
+        return out
+
+    out = run([KEY, KEY, bytes(16)])
+    assert [o[0] for o in out] == ["error"] * 3, out
+    assert all("fingerprint key" in str(o[1]) for o in out), out
+    out = run([KEY, KEY, KEY])
+    assert [o[0] for o in out] == ["ok"] * 3, out
+    for _, res in out:
+        check(res[0], want)
+        assert (res[1].total, res[1].non_null) == (want.total, want.non_null)
