@@ -52,8 +52,11 @@ struct Fp {
 };
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 __device__ __forceinline__ void fp_permute(Fp &s) {
+#ifndef TGX_FP_ROUNDS
+#define TGX_FP_ROUNDS 8  // (Chaskey-8; other values only to measure what the rounds cost: DESIGN.md section 9)
+#endif
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < TGX_FP_ROUNDS; r++) {
     s.v0 += s.v1;
     s.v1 = rotl32(s.v1, 5);
     s.v1 ^= s.v0;
