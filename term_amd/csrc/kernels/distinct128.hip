@@ -87,13 +87,8 @@ __device__ __forceinline__ void fp_block(Fp &s, uint64_t lo, uint64_t hi) {
   s.v3 ^= (uint32_t)(hi >> 32);
   fp_permute(s);
 }
-// the last block: `nb` (0..16) bytes of the value in (lo, hi), the rest zero
-__device__ __forceinline__ void fp_last(Fp &s, uint64_t lo, uint64_t hi, uint32_t nb, const FpKey &key) {
-  if (nb < 8)
-    lo |= 1ull << (8 * nb);
-  else if (nb < 16)
-    hi |= 1ull << (8 * (nb - 8));
-  const bool full = nb == 16;
+// the last block, padded: `full` = the value ended on the block's last byte (no padding byte, K1 instead of K2)
+__device__ __forceinline__ void fp_last_padded(Fp &s, uint64_t lo, uint64_t hi, bool full, const FpKey &key) {
   const uint32_t l0 = full ? key.k1[0] : key.k2[0], l1 = full ? key.k1[1] : key.k2[1];
   const uint32_t l2 = full ? key.k1[2] : key.k2[2], l3 = full ? key.k1[3] : key.k2[3];
   s.v0 ^= (uint32_t)lo ^ l0;
@@ -105,6 +100,14 @@ __device__ __forceinline__ void fp_last(Fp &s, uint64_t lo, uint64_t hi, uint32_
   s.v1 ^= l1;
   s.v2 ^= l2;
   s.v3 ^= l3;
+}
+// the last block: `nb` (0..16) bytes of the value in (lo, hi), the rest zero
+__device__ __forceinline__ void fp_last(Fp &s, uint64_t lo, uint64_t hi, uint32_t nb, const FpKey &key) {
+  if (nb < 8)
+    lo |= 1ull << (8 * nb);
+  else if (nb < 16)
+    hi |= 1ull << (8 * (nb - 8));
+  fp_last_padded(s, lo, hi, nb == 16, key);
 }
 __device__ __forceinline__ void fp_out(const Fp &s, uint64_t *fa, uint64_t *fb) {
   uint64_t a = (uint64_t)s.v0 | ((uint64_t)s.v1 << 32), b = (uint64_t)s.v2 | ((uint64_t)s.v3 << 32);
@@ -533,62 +536,65 @@ __device__ __forceinline__ void fp_tile_scatter16(FpTileLds &s, const ulonglong2
 constexpr uint32_t kFpStageBytes = 4080;  // value bytes of 128 consecutive rows a wave stages at a time (255 blocks)
 constexpr uint32_t kFpStageAlloc = 4096 + 32;  // what the stage holds: 4 blocks per lane + slack for the read-ahead
 
-// fingerprint() of TWO values staged in LDS (same words, same results), walked in lockstep and without branches in
-// the loop body: both chains and all their LDS reads are in flight together.  A value that has ended keeps reading
-// (and discarding) what follows it; the addresses are kept inside the stage.
+// fingerprint() of TWO values staged in LDS (same words, same results).  The kernel that calls it is bound by the
+// instructions it issues (~620 per value before this form, 39 T lane-instructions a second on the chip), so the blocks
+// are cut out of the stage as 32-bit words -- five aligned words and one v_alignbyte per word of the block -- and the
+// work that only a value's LAST block needs (masking off what follows the value, the padding byte, K1 or K2) is done
+// once per value instead of once per block.  The two values walk their plain blocks in lockstep (a lane whose value
+// has no plain block left reads its next block again and discards the result), then both take their last block.
+struct LdsBlock {
+  uint32_t d0, d1, d2, d3;
+};
+__device__ __forceinline__ LdsBlock lds_block16(const uint8_t *stage, uint32_t o) {
+  // o <= 4096 (a value ends inside the staged span): the five words end before kFpStageAlloc
+  const uint32_t *q = (const uint32_t *)(stage + (o & ~3u));
+  const uint32_t y0 = q[0], y1 = q[1], y2 = q[2], y3 = q[3], y4 = q[4];
+  const uint32_t bs = o & 3;
+  LdsBlock b;
+  b.d0 = __builtin_amdgcn_alignbyte(y1, y0, bs);
+  b.d1 = __builtin_amdgcn_alignbyte(y2, y1, bs);
+  b.d2 = __builtin_amdgcn_alignbyte(y3, y2, bs);
+  b.d3 = __builtin_amdgcn_alignbyte(y4, y3, bs);
+  return b;
+}
 __device__ __forceinline__ void fingerprint_lds2(const FpKey &key, const uint8_t *stage, uint32_t o0, uint32_t len0,
                                                  uint32_t o1, uint32_t len1, ulonglong2 *f0, ulonglong2 *f1) {
   Fp s0, s1;
   fp_init(s0, key);
   fp_init(s1, key);
   uint32_t r0 = len0, r1 = len1;
-  bool done0 = false, done1 = false;
-  // the next (up to) 8 bytes of a value as its logical word
-  auto word = [&](uint32_t &o, uint32_t &rem) -> uint64_t {
-    const uint32_t nb = rem < 8 ? rem : 8u;
-    const uint32_t skip = o & 7;
-    uint32_t base = o & ~7u;
-    base = base < 4096u + 16u ? base : 4096u + 16u;
-    const uint64_t lo = *(const uint64_t *)(stage + base), hi = *(const uint64_t *)(stage + base + 8);
-    uint64_t w = lo >> (8 * skip);
-    if (skip) w |= hi << (8 * (8 - skip));  // (bytes past the value are masked off below)
-    w = nb < 8 ? (w & ((1ull << (8 * nb)) - 1)) : w;
-    o += nb;
-    rem -= nb;
-    return w;
-  };
-  // one 16-byte block of one value: a plain block, or its last one (padding and K1 / K2 selected without branches)
-  auto step = [&](Fp &s, uint32_t &o, uint32_t &rem, bool &done) {
-    const bool last = rem <= 16;
-    const uint32_t nb = last ? rem : 16u;
-    uint64_t lo = word(o, rem), hi = word(o, rem);
-    const uint64_t pad_lo = (last && nb < 8) ? 1ull << (8 * (nb & 7)) : 0ull;
-    const uint64_t pad_hi = (last && nb >= 8 && nb < 16) ? 1ull << (8 * (nb & 7)) : 0ull;
-    lo |= pad_lo;
-    hi |= pad_hi;
-    const bool full = nb == 16;
-    const uint32_t l0 = last ? (full ? key.k1[0] : key.k2[0]) : 0u, l1 = last ? (full ? key.k1[1] : key.k2[1]) : 0u;
-    const uint32_t l2 = last ? (full ? key.k1[2] : key.k2[2]) : 0u, l3 = last ? (full ? key.k1[3] : key.k2[3]) : 0u;
+  auto plain = [&](Fp &s, uint32_t &o, uint32_t &rem, bool active) {
+    const LdsBlock b = lds_block16(stage, o);
     Fp t = s;
-    t.v0 ^= (uint32_t)lo ^ l0;
-    t.v1 ^= (uint32_t)(lo >> 32) ^ l1;
-    t.v2 ^= (uint32_t)hi ^ l2;
-    t.v3 ^= (uint32_t)(hi >> 32) ^ l3;
+    t.v0 ^= b.d0;
+    t.v1 ^= b.d1;
+    t.v2 ^= b.d2;
+    t.v3 ^= b.d3;
     fp_permute(t);
-    t.v0 ^= l0;
-    t.v1 ^= l1;
-    t.v2 ^= l2;
-    t.v3 ^= l3;
-    s.v0 = done ? s.v0 : t.v0;
-    s.v1 = done ? s.v1 : t.v1;
-    s.v2 = done ? s.v2 : t.v2;
-    s.v3 = done ? s.v3 : t.v3;
-    done = done || last;
+    s.v0 = active ? t.v0 : s.v0;
+    s.v1 = active ? t.v1 : s.v1;
+    s.v2 = active ? t.v2 : s.v2;
+    s.v3 = active ? t.v3 : s.v3;
+    o += active ? 16u : 0u;
+    rem -= active ? 16u : 0u;
   };
-  do {
-    step(s0, o0, r0, done0);
-    step(s1, o1, r1, done1);
-  } while (!(done0 && done1));
+  for (;;) {
+    const bool a0 = r0 > 16, a1 = r1 > 16;
+    if (!(a0 || a1)) break;
+    plain(s0, o0, r0, a0);
+    plain(s1, o1, r1, a1);
+  }
+  auto last = [&](Fp &s, uint32_t o, uint32_t nb) {  // nb = 0..16 bytes of the value are left
+    const LdsBlock b = lds_block16(stage, o);
+    const uint64_t lo = (uint64_t)b.d0 | ((uint64_t)b.d1 << 32), hi = (uint64_t)b.d2 | ((uint64_t)b.d3 << 32);
+    // what follows the value goes, the padding byte comes: one shifted bit serves both, and no branch
+    const uint64_t bit = 1ull << (8 * (nb & 7)), keep = bit - 1;
+    const bool in_lo = nb < 8, in_hi = nb < 16;
+    const uint64_t cut_lo = (lo & keep) | bit, cut_hi = (hi & keep) | bit;
+    fp_last_padded(s, in_lo ? cut_lo : lo, in_lo ? 0ull : (in_hi ? cut_hi : hi), nb == 16, key);
+  };
+  last(s0, o0, r0);
+  last(s1, o1, r1);
   fp_out(s0, (uint64_t *)&f0->x, (uint64_t *)&f0->y);
   fp_out(s1, (uint64_t *)&f1->x, (uint64_t *)&f1->y);
 }
@@ -610,62 +616,72 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
   typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
   __shared__ FpTileLds s;
   static_assert(kFpStageAlloc <= kRowsPerWave * sizeof(ulonglong2), "a wave's value bytes fit its share of the tile");
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (in a scalar register: what
+  // follows from it -- the wave's first row, its addresses in the offsets and the validity bitmap -- is scalar work)
   // the records stay in registers until every wave is through its rows: until then the tile's LDS holds value bytes
   uint8_t *stage = (uint8_t *)&s.stage[wave * kRowsPerWave];
   ulonglong2 mine[kFpTile / 256];
   fp_tile_begin(s);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
   const uintptr_t data0 = (uintptr_t)d.data;
-  const int64_t wave_first = (int64_t)blockIdx.x * kFpTile + (int64_t)wave * kRowsPerWave;
-  auto offset_at = [&](int64_t row) -> int64_t {  // rows past the end read the end offset: they come out empty
-    const int64_t slot = d.offset + (row < d.length ? row : d.length);
-    return d.large_offsets ? ((global_i64_ptr)(uintptr_t)d.offsets)[slot]
-                           : (int64_t)((global_i32_ptr)(uintptr_t)d.offsets)[slot];
+  // rows are counted from the wave's first one, in 32 bits: r = 0 .. kRowsPerWave, of which the first n_here exist
+  // (rows past the end read the end offset and are not valid: they come out empty)
+  const int64_t wave_row0 = (int64_t)blockIdx.x * kFpTile + (int64_t)wave * kRowsPerWave;
+  const int64_t wave_first = wave_row0 < d.length ? wave_row0 : d.length;
+  const uint32_t n_here = d.length - wave_first < (int64_t)kRowsPerWave ? (uint32_t)(d.length - wave_first) : (uint32_t)kRowsPerWave;
+  const uintptr_t offs0 = (uintptr_t)d.offsets + (uintptr_t)(d.offset + wave_first) * (d.large_offsets ? 8u : 4u);
+  const uintptr_t vbits0 = (uintptr_t)d.validity + (uintptr_t)((d.offset + wave_first) >> 3);
+  const uint32_t vshift0 = (uint32_t)((d.offset + wave_first) & 7);
+  auto offset_at = [&](uint32_t r) -> int64_t {
+    const uint32_t k = r < n_here ? r : n_here;
+    return d.large_offsets ? ((global_i64_ptr)offs0)[k] : (int64_t)((global_i32_ptr)offs0)[k];
   };
-  auto valid_at = [&](int64_t row) -> bool {
-    if (row >= d.length) return false;
-    const int64_t slot = d.offset + row;
-    return !vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1);
+  auto valid_at = [&](uint32_t r) -> bool {
+    if (r >= n_here) return false;
+    const uint32_t q = vshift0 + r;
+    return !vbits || ((((global_u8_ptr)vbits0)[q >> 3] >> (q & 7)) & 1);
   };
+  // A step's offsets are kept RELATIVE to the start of its span -- the first value's start rounded down to a 16-byte
+  // block by ABSOLUTE address (a block that holds a byte of the buffer lies in the buffer's pages) -- so that all the
+  // arithmetic per value is in 32 bits; a span that does not fit the stage (then they may not fit 32 bits either)
+  // takes the path that reads from global memory, which fetches its rows' offsets again.
   struct Step {
-    int64_t b0, b1, tail;
+    int64_t base;             // wave-uniform
+    uint32_t r0, r1, rtail;   // the lane's two starts and the span's end, from `base` (exact when `fits`)
+    bool fits;                // wave-uniform
     bool v0, v1;
   };
   auto fetch = [&](int step) -> Step {
     Step t;
-    const int64_t i0 = wave_first + step * 128 + lane;
-    t.b0 = offset_at(i0);
-    t.b1 = offset_at(i0 + 64);
-    t.tail = offset_at(wave_first + step * 128 + 128);
+    const uint32_t i0 = step * 128 + lane;
+    const int64_t b0 = offset_at(i0), b1 = offset_at(i0 + 64), tail = offset_at(step * 128 + 128);
+    const int64_t b_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)b0 >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)b0));
+    t.base = b_first - (int64_t)((data0 + (uintptr_t)b_first) & 15);
+    t.fits = tail - t.base <= (int64_t)kFpStageBytes;
+    t.r0 = (uint32_t)(b0 - t.base);
+    t.r1 = (uint32_t)(b1 - t.base);
+    t.rtail = (uint32_t)(tail - t.base);
     t.v0 = valid_at(i0);
     t.v1 = valid_at(i0 + 64);
     return t;
   };
-  // the span of a step's values: [base, tail), base rounded down to a 16-byte block by ABSOLUTE address (a block that
-  // holds a byte of the buffer lies in the buffer's pages)
-  auto span_of = [&](const Step &t, int64_t *base) -> bool {
-    const int64_t b_first = __shfl(t.b0, 0, 64);
-    *base = b_first - (int64_t)((data0 + (uintptr_t)b_first) & 15);
-    return t.tail - *base <= (int64_t)kFpStageBytes;  // wave-uniform
-  };
   u32x4 pre[4];
-  auto load_bytes = [&](int64_t base, int64_t tail) {
-    global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)base);
-    const int64_t n16 = (tail - base + 15) >> 4;  // <= 255
+  auto load_bytes = [&](const Step &t) {
+    global_u4_ptr src = (global_u4_ptr)(data0 + (uintptr_t)t.base);
+    const uint32_t n16 = (t.rtail + 15) >> 4;  // <= 255
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int64_t k = lane + 64 * j;
+      const uint32_t k = lane + 64 * j;
       pre[j] = k < n16 ? src[k] : (u32x4)0u;
     }
   };
   Step cur = fetch(0), nxt = fetch(1);
-  int64_t base_cur = 0;
-  bool fit_cur = span_of(cur, &base_cur);
-  if (fit_cur) load_bytes(base_cur, cur.tail);
+  if (cur.fits) load_bytes(cur);
 #pragma unroll
   for (int step = 0; step < kSteps; step++) {
-    if (fit_cur) {
+    if (cur.fits) {
 #pragma unroll
       for (int j = 0; j < 4; j++) *(u32x4 *)(stage + 16 * (lane + 64 * j)) = pre[j];
       __builtin_amdgcn_wave_barrier();
@@ -673,26 +689,30 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
     }
     Step after = nxt;
     if (step + 2 < kSteps) after = fetch(step + 2);
-    int64_t base_nxt = 0;
-    bool fit_nxt = false;
-    if (step + 1 < kSteps) {
-      fit_nxt = span_of(nxt, &base_nxt);
-      if (fit_nxt) load_bytes(base_nxt, nxt.tail);  // lands while this step is fingerprinted
-    }
-    // (every shuffle with all lanes active: a row's end is the next row's start)
-    const int64_t next0 = __shfl_down(cur.b0, 1, 64), next1 = __shfl_down(cur.b1, 1, 64);
-    const int64_t first1 = __shfl(cur.b1, 0, 64);
-    const int64_t e0 = lane < 63 ? next0 : first1, e1 = lane < 63 ? next1 : cur.tail;
+    if (step + 1 < kSteps && nxt.fits) load_bytes(nxt);  // lands while this step is fingerprinted
     ulonglong2 r0, r1;
-    if (fit_cur) {
-      fingerprint_lds2(d.key, stage, (uint32_t)(cur.b0 - base_cur), cur.v0 ? (uint32_t)(e0 - cur.b0) : 0u,
-                       (uint32_t)(cur.b1 - base_cur), cur.v1 ? (uint32_t)(e1 - cur.b1) : 0u, &r0, &r1);
+    if (cur.fits) {
+      // (every shuffle with all lanes active: a row's end is the next row's start)
+      const uint32_t next0 = __shfl_down(cur.r0, 1, 64), next1 = __shfl_down(cur.r1, 1, 64);
+      const uint32_t first1 = __shfl(cur.r1, 0, 64);
+      const uint32_t e0 = lane < 63 ? next0 : first1, e1 = lane < 63 ? next1 : cur.rtail;
+      // (offsets that run backwards are not a column: the lengths are kept inside the stage all the same)
+      const uint32_t len0 = e0 - cur.r0 < kFpStageBytes ? e0 - cur.r0 : kFpStageBytes;
+      const uint32_t len1 = e1 - cur.r1 < kFpStageBytes ? e1 - cur.r1 : kFpStageBytes;
+      fingerprint_lds2(d.key, stage, cur.r0, cur.v0 ? len0 : 0u, cur.r1, cur.v1 ? len1 : 0u, &r0, &r1);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
     } else {
+      const uint32_t i0 = step * 128 + lane;
       r0.x = r1.x = kEmptyKey;
-      if (cur.v0) fingerprint(d.key, data0 + (uintptr_t)cur.b0, (uint64_t)(e0 - cur.b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
-      if (cur.v1) fingerprint(d.key, data0 + (uintptr_t)cur.b1, (uint64_t)(e1 - cur.b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
+      if (cur.v0) {
+        const int64_t b0 = offset_at(i0), e0 = offset_at(i0 + 1);
+        fingerprint(d.key, data0 + (uintptr_t)b0, (uint64_t)(e0 - b0), (uint64_t *)&r0.x, (uint64_t *)&r0.y);
+      }
+      if (cur.v1) {
+        const int64_t b1 = offset_at(i0 + 64), e1 = offset_at(i0 + 65);
+        fingerprint(d.key, data0 + (uintptr_t)b1, (uint64_t)(e1 - b1), (uint64_t *)&r1.x, (uint64_t *)&r1.y);
+      }
     }
     if (!cur.v0) r0.x = kEmptyKey;
     if (!cur.v1) r1.x = kEmptyKey;
@@ -713,8 +733,6 @@ __global__ __launch_bounds__(256) void fp_partition_strings_kernel(Utf8ColDesc d
     mine[2 * step + 1] = r1;
     cur = nxt;
     nxt = after;
-    base_cur = base_nxt;
-    fit_cur = fit_nxt;
   }
   __syncthreads();
   fp_tile_scatter16(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);
