@@ -858,9 +858,11 @@ tgx_status distinct_run_numeric(tgx_state *st, size_t slot, const tgx_column &c,
       pp.key16 = prep.key16 ? 1 : pack20 ? 2 : 0;
       static const bool no_probe = getenv("TGX_NO_CLUSTERED_PROBE") && atoi(getenv("TGX_NO_CLUSTERED_PROBE")) != 0;
       pp.probe = no_probe ? 0 : 1;
-      // (launching only the form the column's last batch took -- PartitionParams::force_form -- spares the launch of the
-      //  form that leaves at once; measured on C2: 1.694 against 1.696 ms, nothing: the queue hides it.  Opt-in.)
-      static const bool form_memory = getenv("TGX_FORM_MEMORY") && atoi(getenv("TGX_FORM_MEMORY")) != 0;
+      // Only the form the column's last batch took is launched (PartitionParams::force_form; either form is correct on
+      // any keys, the probe still runs and the next finalize remembers what it said): the form that would leave at once
+      // still costs its dispatch, 1024 threads x a workgroup per CU -- C2 over 40 steps, three runs each: 1.594 against
+      // 1.606 ms.  TGX_FORM_MEMORY=0 launches both again.
+      static const bool form_memory = !(getenv("TGX_FORM_MEMORY") && atoi(getenv("TGX_FORM_MEMORY")) == 0);
       pp.force_form = (form_memory && !no_probe) ? ds.remembered_form : 0;
       HIP_TRY(ds.lists.reserve(prep.key16 ? (uint64_t)pp.n_lists * pp.cap * sizeof(uint16_t)
                                : pack20   ? (uint64_t)pp.n_lists * pp.cap / 3 * 8

@@ -1848,16 +1848,31 @@ __global__ __launch_bounds__(1024) void partition_init_kernel(PartitionParams p,
   const int64_t n_groups = p.length / 128;
   global_i64_ptr vals = (global_i64_ptr)(uintptr_t)((const int64_t *)p.values + p.offset);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)p.validity;
-  for (uint32_t g = wave; g < 64 && (int64_t)g < n_groups; g += 16) {
+  // (one workgroup, all latency: a wave's four groups are requested together, then looked at)
+  uint64_t rr[4][2];
+  uint32_t vb[4][2];
+  bool have[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t g = wave + 16u * k;
+    have[k] = (int64_t)g < n_groups;  // (g < 64: sixteen waves)
     const int64_t group = n_groups <= 64 ? (int64_t)g : (int64_t)g * (n_groups / 64);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int64_t i = group * 128 + h * 64 + lane;
+      rr[k][h] = have[k] ? (uint64_t)vals[i] - (uint64_t)p.base : ~0ull;
+      vb[k][h] = (have[k] && vbits) ? (uint32_t)((vbits[(p.offset + i) >> 3] >> ((p.offset + i) & 7)) & 1) : 1u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (!have[k]) continue;  // (wave-uniform)
     bool same = true;
     uint32_t b0 = 0xFFFFFFFFu;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const int64_t i = group * 128 + h * 64 + lane;
-      const uint64_t r = (uint64_t)vals[i] - (uint64_t)p.base;
-      bool okr = r < p.range;
-      if (vbits) okr = okr && ((vbits[(p.offset + i) >> 3] >> ((p.offset + i) & 7)) & 1);
+      const uint64_t r = rr[k][h];
+      const bool okr = r < p.range && vb[k][h] != 0;
       const uint64_t act = __ballot(okr);
       if (act == 0) continue;  // (nothing inside the range: a group of outliers agrees -- CLUSTERED is their path too)
       const uint32_t b = (uint32_t)(r >> p.sub_bits);

@@ -1163,18 +1163,28 @@ __global__ __launch_bounds__(64) void scan_reduce_kernel(const ScanLaunch L,
     b.cnt = (int64_t)outliers->count;
     acc_merge(a, b, c.is_float);
   }
-  for (int i = lane; i < blocks_per_col; i += 64) {
-    LaneAcc b;
-    b.mn = p[i].min_k;
-    b.mx = p[i].max_k;
-    b.lo = p[i].sum_lo;
-    b.hi = p[i].sum_hi;
-    b.s = p[i].sum;
-    b.c = p[i].comp;
-    b.s1 = p[i].s1;
-    b.s2 = p[i].s2;
-    b.cnt = p[i].non_null;
-    acc_merge(a, b, c.is_float);
+  // (a launch of one wave per column is all latency: four partials per lane are requested before the first is merged
+  //  -- merged in the order they always were, lane by lane: i, i + 64, i + 128 ...)
+  for (int i0 = lane; i0 < blocks_per_col; i0 += 256) {
+    LaneAcc b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + 64 * u;
+      if (i < blocks_per_col) {
+        b[u].mn = p[i].min_k;
+        b[u].mx = p[i].max_k;
+        b[u].lo = p[i].sum_lo;
+        b[u].hi = p[i].sum_hi;
+        b[u].s = p[i].sum;
+        b[u].c = p[i].comp;
+        b[u].s1 = p[i].s1;
+        b[u].s2 = p[i].s2;
+        b[u].cnt = p[i].non_null;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i0 + 64 * u < blocks_per_col) acc_merge(a, b[u], c.is_float);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {

@@ -2,6 +2,35 @@
 // the plan queued (tgx_update, update_impl).  Split off tgx_api.cpp in round 4; see api_internal.h.
 #include "api_internal.h"
 
+#include <chrono>
+namespace {
+// TGX_UPDATE_TIMING=1: where the HOST's time inside tgx_update goes (microseconds since the call began, at a few marks)
+struct UpdateMarks {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  char line[512];
+  int len = 0;
+  UpdateMarks() {
+    static const bool enabled = getenv("TGX_UPDATE_TIMING") != nullptr;
+    on = enabled;
+    if (on) t0 = std::chrono::steady_clock::now();
+  }
+  void mark(const char *what) {
+    if (!on) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    len += snprintf(line + len, sizeof(line) - (size_t)len > 0 ? sizeof(line) - (size_t)len : 0, " %s %.1f", what, us);
+    if (len > (int)sizeof(line) - 1) len = (int)sizeof(line) - 1;
+  }
+  ~UpdateMarks() {
+    if (on && len) fprintf(stderr, "tgx_update (us):%s\n", line);
+  }
+};
+thread_local UpdateMarks *tl_marks = nullptr;
+inline void update_mark(const char *what) {
+  if (tl_marks) tl_marks->mark(what);
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 // update
 
@@ -278,6 +307,11 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     return fail(err, TGX_INVALID_ARGUMENT, "plan reads column %d but only %zu columns were passed",
                 plan->n_columns_needed - 1, n_columns);
   if (n_columns > 0 && !columns) return fail(err, TGX_INVALID_ARGUMENT, "columns is NULL");
+  UpdateMarks marks;
+  struct MarksScope {
+    MarksScope(UpdateMarks *m) { tl_marks = m->on ? m : nullptr; }
+    ~MarksScope() { tl_marks = nullptr; }
+  } marks_scope(&marks);
   TGX_TRY(need_device(err));
   // TGX_MEM_HOST_RETAINED (include/tgx.h): HOST columns whose copy may wait for the flush.  Below this point such a
   // column is a HOST column; `retained` (all of the batch's HOST columns were given so) travels in the traits.
@@ -320,9 +354,13 @@ extern "C" tgx_status tgx_update(const tgx_plan *plan, tgx_state *st, const tgx_
     TGX_TRY(coalesce_append(plan, st, columns, nrows, traits, &taken, err));
     if (taken) return TGX_OK;
   }
+  update_mark("validated");
   bind_thread();  // (the noted-only path above makes no HIP call: it binds where it does, in the arena set-up and the flush)
   TGX_TRY(coalesce_flush(st, err));  // batches stay in order
-  return update_impl(plan, st, columns, nrows, err);
+  update_mark("flushed");
+  const tgx_status rc = update_impl(plan, st, columns, nrows, err);
+  update_mark("done");
+  return rc;
 } catch (...) {
   return tgx::abi_exception(err);
 }
@@ -365,6 +403,7 @@ tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *co
     }
     TGX_TRY(stage_column(st, columns[i], &dev[i], err, widen));
   }
+  update_mark("staged");
   const bool arena_in_use = st->arena_used != 0;
   if (arena_in_use)
     HIP_TRY(hipMemcpyAsync(st->arena_dev[st->arena_cur].p, st->arena_host[st->arena_cur], st->arena_used,
@@ -452,7 +491,9 @@ tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *co
     // COUNT and COUNT(DISTINCT) together.  Decided here, before the scan is queued, from a sample of the batch.
     std::vector<NumericPrep> dprep(plan->distinct.size());
     std::vector<int> stats_by_partition(plan->scan.size(), -1);
+    update_mark("fused");
     TGX_TRY(distinct_sample_all(st, dev.data(), err));
+    update_mark("sampled");
     for (size_t q = 0; q < plan->distinct.size(); q++) {
       const DistinctTask &t = plan->distinct[q];
       if (!t.tuple.empty() || !is_numeric(dev[t.column].type) || dev[t.column].length == 0 || distinct_idle(q)) continue;
@@ -465,6 +506,7 @@ tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *co
     // marks their end: across ranks the exchange of the key sets (tgx_allreduce) can then run on a second stream
     // while the scan of the other columns below is still running (the >= 6x target is set by the exchange)
     std::vector<char> distinct_done(plan->distinct.size(), 0);
+    update_mark("prepared");
     // BESIDE the scan (round 6, an experiment that stays OFF: TGX_KEYS_BESIDE_SCAN=1 turns it on): the key passes
     // queued on a stream of their own in front of the scan, which then runs next to them instead of behind them.  The
     // key stream starts behind everything the state's stream held when the update began (`batch_in`), and the state's
@@ -508,8 +550,10 @@ tgx_status update_impl(const tgx_plan *plan, tgx_state *st, const tgx_column *co
       TGX_TRY(distinct_update(st, q, dev[t.column], err, nullptr, &dprep[q], stats_slot, &columns[t.column]));
       distinct_done[q] = 1;
     }
+    update_mark("keys_queued");
     if (!st->keys_ready) HIP_TRY(hipEventCreateWithFlags(&st->keys_ready, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(st->keys_ready, st->stream));
+    update_mark("event");
     if (beside) {
       st->stream = key_loan.own;
       key_loan.on = false;
