@@ -39,6 +39,8 @@ HashSetView hash_view(const DistinctState &ds) {
 // A fresh table starts a fresh store: words 0..1 are a stand-in entry (what a key that found no room points at:
 // kCntStoreFull), the cursor starts behind it.
 constexpr uint64_t kKeyStoreMinWords = 1ull << 16;
+constexpr uint64_t kKeyStoreSlackWords = 1ull << 26;  // (512 MiB: what the room for later batches may add at most)
+constexpr uint64_t kHashSlackRows = 1ull << 23;       // (the same for a table's slots: 8 Mi keys' worth)
 tgx_status key_store_init(tgx_state *st, DistinctState &ds, tgx_error *err) {
   if (ds.key_store_words < kKeyStoreMinWords) {
     HIP_TRY(ds.key_store.reserve(kKeyStoreMinWords * 8));
@@ -85,7 +87,10 @@ tgx_status key_store_reserve_bound(tgx_state *st, DistinctState &ds, uint64_t wo
   HIP_TRY(hipMemcpyAsync(&cur, ds.key_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st->stream));
   HIP_TRY(hipStreamSynchronize(st->stream));
   ds.key_words_ub = cur + worst;
-  return key_store_ensure(st, ds, cur, worst, err);
+  // Room for a few batches of this size, not for this one alone: the bound grows by `worst` per batch whatever the
+  // batch adds (a column of repeated values adds next to nothing), and every time it runs out the host WAITS for the
+  // device here -- a stream of flushes of a HOST column then copies and computes in turns instead of side by side.
+  return key_store_ensure(st, ds, cur, worst + std::min<uint64_t>(3 * worst, kKeyStoreSlackWords), err);
 }
 // before a batch's insert: the measuring pass's scratch and the pending list's fill are zero, and the list has room for
 // `items` new keys (every item of the batch at worst)
@@ -135,8 +140,11 @@ tgx_status hash_alloc(tgx_state *st, DevBuf &keys, DevBuf &dup, uint64_t capacit
 // make sure the hash table can take `incoming` more keys at load factor <= 0.5
 tgx_status hash_ensure(tgx_state *st, DistinctState &ds, bool mult, uint64_t incoming,
                               tgx_error *err) {
+  // (room for a few more batches of this size: see key_store_reserve_bound -- the bound below counts every row of every
+  //  batch as a new key, and where it runs out the host waits for the device to read the real count)
+  const uint64_t slack = std::min<uint64_t>(3 * incoming, kHashSlackRows);
   if (ds.capacity == 0) {
-    uint64_t want = std::max<uint64_t>(incoming, g_ctx.distinct_hint);
+    uint64_t want = std::max<uint64_t>(incoming + slack, g_ctx.distinct_hint);
     ds.capacity = next_pow2(std::max<uint64_t>(2 * want, 1024));
     TGX_TRY(hash_alloc(st, ds.keys, ds.dup, ds.capacity, mult, ds.wide, err));
     ds.rows_upper_bound = 0;
@@ -150,11 +158,11 @@ tgx_status hash_ensure(tgx_state *st, DistinctState &ds, bool mult, uint64_t inc
   unsigned long long c[kNumDistinctCounters];
   TGX_TRY(distinct_read_counters(st, ds, c, err));
   uint64_t actual = c[kCntDistinct];
-  if (2 * (actual + incoming) <= ds.capacity) {
+  if (2 * (actual + incoming + slack) <= ds.capacity) {
     ds.rows_upper_bound = actual + incoming;
     return TGX_OK;
   }
-  uint64_t new_cap = next_pow2(2 * (actual + incoming));
+  uint64_t new_cap = next_pow2(2 * (actual + incoming + slack));
   DevBuf nk, nd;
   TGX_TRY(hash_alloc(st, nk, nd, new_cap, mult, ds.wide, err));
   HashSetView src = hash_view(ds);
