@@ -766,23 +766,33 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
   typedef const u32x4 __attribute__((address_space(1))) *global_u4_ptr;
   __shared__ FpTileLds s;
   static_assert(kFpStageAlloc <= kRowsPerWave * sizeof(ulonglong2), "a wave's value bytes fit its share of the tile");
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (scalar: fp_partition_strings_kernel)
   uint8_t *stage = (uint8_t *)&s.stage[wave * kRowsPerWave];  // (the records stay in registers: fp_partition_strings_kernel)
   ulonglong2 mine[kFpTile / 256];
   fp_tile_begin(s);
   global_u8_ptr vbits = (global_u8_ptr)(uintptr_t)d.validity;
+  // rows are counted from the wave's first one, in 32 bits (fp_partition_strings_kernel); a row past the end reads
+  // the view at the wave's base (a view of the column: the launch has rows) and is not valid
   const int64_t wave_first = (int64_t)blockIdx.x * kFpTile + (int64_t)wave * kRowsPerWave;
+  const int64_t safe_first = wave_first < d.length ? wave_first : d.length - 1;
+  const uint32_t n_here = d.length - wave_first <= 0                    ? 0u
+                          : d.length - wave_first < (int64_t)kRowsPerWave ? (uint32_t)(d.length - wave_first)
+                                                                          : (uint32_t)kRowsPerWave;
+  const uintptr_t views0 = (uintptr_t)d.views + (uintptr_t)(d.offset + safe_first) * 16;
+  const uintptr_t vbits0 = (uintptr_t)d.validity + (uintptr_t)((d.offset + safe_first) >> 3);
+  const uint32_t vshift0 = (uint32_t)((d.offset + safe_first) & 7);
   struct Row {
     u32x4 v;     // the view
     bool valid;  // in range and not NULL (the view of a NULL slot is arbitrary: never interpreted)
   };
-  auto row_at = [&](int64_t row) -> Row {
-    Row r;
-    const bool in = row < d.length;
-    const int64_t slot = d.offset + (in ? row : d.length - 1);
-    r.valid = in && (!vbits || ((vbits[slot >> 3] >> (slot & 7)) & 1));
-    r.v = *(global_u4_ptr)((uintptr_t)d.views + (uintptr_t)slot * 16);
-    return r;
+  auto row_at = [&](uint32_t r) -> Row {
+    Row x;
+    const bool in = r < n_here;
+    const uint32_t k = in ? r : 0u, q = vshift0 + k;
+    x.valid = in && (!vbits || ((((global_u8_ptr)vbits0)[q >> 3] >> (q & 7)) & 1));
+    x.v = ((global_u4_ptr)views0)[k];
+    return x;
   };
   auto wave_min = [](uint32_t x) {
 #pragma unroll
@@ -800,48 +810,78 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
     }
     return x;
   };
-  Row n0 = row_at(wave_first + lane), n1 = row_at(wave_first + 64 + lane);
-#pragma unroll
-  for (int step = 0; step < kSteps; step++) {
-    const Row r0 = n0, r1 = n1;
-    if (step + 1 < kSteps) {  // the next step's views are requested before this step's bytes are staged
-      n0 = row_at(wave_first + (step + 1) * 128 + lane);
-      n1 = row_at(wave_first + (step + 1) * 128 + 64 + lane);
-    }
+  // what a step stages (wave-uniform): the long values of its rows lie in ONE buffer within a span that fits
+  struct Span {
+    bool staged;
+    int64_t base;  // of the span, relative to the buffer (up to 15 bytes in front of the first value)
+    uint32_t n16;  // its 16-byte blocks (<= 255)
+    uintptr_t buf;
+  };
+  auto span_of = [&](const Row &r0, const Row &r1) -> Span {
+    Span sp{false, 0, 0, 0};
     const uint32_t len0 = r0.valid ? r0.v.x : 0u, len1 = r1.valid ? r1.v.x : 0u;
     const bool long0 = len0 > 12, long1 = len1 > 12;
-    // one buffer, one short span?  (wave-uniform; a step without long values stages nothing)
     const unsigned long long any_long = __builtin_amdgcn_ballot_w64(long0 || long1);
-    bool staged = false;
-    int64_t base = 0;  // of the staged span, relative to the buffer (up to 15 bytes in front of the first value)
-    uint32_t n16 = 0;
-    uintptr_t buf = 0;
-    if (any_long) {
+    if (any_long) {  // (a step without long values stages nothing)
       const int first_lane = __builtin_ctzll(any_long);
       const uint32_t bi = (uint32_t)__shfl(long0 ? r0.v.z : r1.v.z, first_lane, 64);
       const bool same = (!long0 || r0.v.z == bi) && (!long1 || r1.v.z == bi);
       const uint32_t lo0 = long0 ? r0.v.w : 0xFFFFFFFFu, lo1 = long1 ? r1.v.w : 0xFFFFFFFFu;
       const uint32_t hi0 = long0 ? r0.v.w + len0 : 0u, hi1 = long1 ? r1.v.w + len1 : 0u;  // (< 2^32: both < 2^31)
       const uint32_t lo = wave_min(lo0 < lo1 ? lo0 : lo1), hi = wave_max(hi0 > hi1 ? hi0 : hi1);
-      buf = (uintptr_t)d.buffers[bi];
-      base = (int64_t)lo - (int64_t)((buf + lo) & 15);  // 16-byte blocks by ABSOLUTE address, as in the plain kernel
-      staged = __builtin_amdgcn_ballot_w64(!same) == 0 && (int64_t)hi - base <= (int64_t)kFpStageBytes;
-      n16 = (uint32_t)(((int64_t)hi - base + 15) >> 4);  // <= 255 when staged
+      sp.buf = (uintptr_t)d.buffers[bi];
+      sp.base = (int64_t)lo - (int64_t)((sp.buf + lo) & 15);  // 16-byte blocks by ABSOLUTE address, as in the plain kernel
+      sp.staged = __builtin_amdgcn_ballot_w64(!same) == 0 && (int64_t)hi - sp.base <= (int64_t)kFpStageBytes;
+      sp.n16 = (uint32_t)(((int64_t)hi - sp.base + 15) >> 4);  // <= 255 when staged
     }
+    return sp;
+  };
+  // three steps deep, as the plain kernel: the views of step s + 2 and the bytes of step s + 1 (in registers) are in
+  // flight while step s is fingerprinted
+  u32x4 pre[4];
+  auto load_bytes = [&](const Span &sp) {
+    global_u4_ptr src = (global_u4_ptr)(sp.buf + (uintptr_t)sp.base);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t k = lane + 64 * j;
+      pre[j] = k < sp.n16 ? src[k] : (u32x4)0u;
+    }
+  };
+  Row c0 = row_at(lane), c1 = row_at(64 + lane);
+  Row n0 = c0, n1 = c1;
+  if (kSteps > 1) {
+    n0 = row_at(128 + lane);
+    n1 = row_at(128 + 64 + lane);
+  }
+  Span cur = span_of(c0, c1);
+  if (cur.staged) load_bytes(cur);
+#pragma unroll
+  for (int step = 0; step < kSteps; step++) {
+    const Row r0 = c0, r1 = c1;
+    if (cur.staged) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) *(u32x4 *)(stage + 16 * (lane + 64 * j)) = pre[j];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    Row a0 = n0, a1 = n1;
+    if (step + 2 < kSteps) {
+      a0 = row_at((step + 2) * 128 + lane);
+      a1 = row_at((step + 2) * 128 + 64 + lane);
+    }
+    Span nxt{false, 0, 0, 0};
+    if (step + 1 < kSteps) {
+      nxt = span_of(n0, n1);
+      if (nxt.staged) load_bytes(nxt);  // lands while this step is fingerprinted
+    }
+    const uint32_t len0 = r0.valid ? r0.v.x : 0u, len1 = r1.valid ? r1.v.x : 0u;
+    const bool long0 = len0 > 12, long1 = len1 > 12;
     ulonglong2 f0, f1;
     f0.x = f1.x = kEmptyKey;
     f0.y = f1.y = 0;
-    if (staged) {
-      global_u4_ptr src = (global_u4_ptr)(buf + (uintptr_t)base);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t k = lane + 64 * j;
-        if (k < n16) *(u32x4 *)(stage + 16 * k) = src[k];
-      }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      fingerprint_lds2(d.key, stage, long0 ? (uint32_t)((int64_t)r0.v.w - base) : 0u, long0 ? len0 : 0u,
-                       long1 ? (uint32_t)((int64_t)r1.v.w - base) : 0u, long1 ? len1 : 0u, &f0, &f1);
+    if (cur.staged) {
+      fingerprint_lds2(d.key, stage, long0 ? (uint32_t)((int64_t)r0.v.w - cur.base) : 0u, long0 ? len0 : 0u,
+                       long1 ? (uint32_t)((int64_t)r1.v.w - cur.base) : 0u, long1 ? len1 : 0u, &f0, &f1);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
     } else {
@@ -870,6 +910,11 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
     if (f1.x != kEmptyKey) atomicAdd(&s.hist[f1.x >> 56], 1u);
     mine[2 * step] = f0;
     mine[2 * step + 1] = f1;
+    c0 = n0;
+    c1 = n1;
+    n0 = a0;
+    n1 = a1;
+    cur = nxt;
   }
   __syncthreads();
   fp_tile_scatter16(s, mine, (blockIdx.x % kFpXcds) * kFpFan, out, 56, counters);

@@ -6,6 +6,7 @@ HOST buffers; Arrow offsets), and what happens to the state before it is read (f
 states merged).  Bit-exact wherever the reference is (counts, MIN / MAX, integer sums, DISTINCT, HyperLogLog
 registers -> estimate); 1e-6 relative for floating-point aggregates (north star)."""
 import math
+import sys
 
 import numpy as np
 
@@ -520,9 +521,20 @@ class Case:
                     xa, ya = np.abs(np.asarray(vals, dtype=np.float64)), np.abs(np.asarray(y, dtype=np.float64))
                     overflowing = bool(np.isinf(xa).any() or np.isinf(ya).any() or np.isinf(xa.max(initial=0.0) * ya.max(initial=0.0))
                                        or np.isinf(xa.max(initial=0.0) ** 2) or np.isinf(ya.max(initial=0.0) ** 2))
-                for got, want in ((r.sum_x, o.sum_x), (r.sum_y, o.sum_y), (r.sum_x2, o.sum_x2), (r.sum_y2, o.sum_y2),
-                                  (r.sum_xy, o.sum_xy)):
-                    if math.isnan(want) and math.isinf(got) and overflowing:
+                with np.errstate(all="ignore"):
+                    mx, my = float(xa.max(initial=0.0)), float(ya.max(initial=0.0))
+                    scales = (mx, my, mx * mx, my * my, mx * my)
+                for (got, want), scale in zip(((r.sum_x, o.sum_x), (r.sum_y, o.sum_y), (r.sum_x2, o.sum_x2),
+                                               (r.sum_y2, o.sum_y2), (r.sum_xy, o.sum_xy)), scales):
+                    # what ANY sum of n doubles of that magnitude can be off by: terms next to DBL_MAX that cancel (seed
+                    # 1244830: x = 1e308 twice, against y = -0.47 and 0.47 -- the oracle's extended precision cancels
+                    # them exactly, sum_xy = 0.84; products about a pivot of 1e307 leave -35.5, an error of 1e-306 of
+                    # the terms) are not a difference between two implementations in doubles
+                    # (a product of magnitudes beyond DBL_MAX: the terms are as large as doubles get)
+                    slack = 64.0 * max(1, o.n) * 2.0 ** -53 * (scale if math.isfinite(scale) else sys.float_info.max)
+                    if math.isfinite(want) and math.isfinite(got) and abs(got - want) <= slack:
+                        pass
+                    elif math.isnan(want) and math.isinf(got) and overflowing:
                         # an infinity (or a product beyond DBL_MAX) among the pairs: the raw products the oracle -- and
                         # DataFusion -- adds come out as +inf and -inf and cancel to NaN, the kernels' products about
                         # the pair's pivot overflow with other signs and stay infinite (seed 2001332)
