@@ -880,8 +880,10 @@ __global__ __launch_bounds__(256) void fp_partition_views_kernel(Utf8ColDesc d, 
     f0.x = f1.x = kEmptyKey;
     f0.y = f1.y = 0;
     if (cur.staged) {
-      fingerprint_lds2(d.key, stage, long0 ? (uint32_t)((int64_t)r0.v.w - cur.base) : 0u, long0 ? len0 : 0u,
-                       long1 ? (uint32_t)((int64_t)r1.v.w - cur.base) : 0u, long1 ? len1 : 0u, &f0, &f1);
+      // (a view whose length is not a length is not a column: what is walked stays inside the stage all the same)
+      const uint32_t walk0 = len0 < kFpStageBytes ? len0 : kFpStageBytes, walk1 = len1 < kFpStageBytes ? len1 : kFpStageBytes;
+      fingerprint_lds2(d.key, stage, long0 ? (uint32_t)((int64_t)r0.v.w - cur.base) : 0u, long0 ? walk0 : 0u,
+                       long1 ? (uint32_t)((int64_t)r1.v.w - cur.base) : 0u, long1 ? walk1 : 0u, &f0, &f1);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every lane is done with the stage
     } else {
