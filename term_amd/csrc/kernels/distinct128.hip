@@ -1153,7 +1153,9 @@ __device__ __forceinline__ TupleComp tuple_component(const TupleDesc &d, int c, 
 
 __device__ __forceinline__ void tuple_fingerprint(const TupleDesc &d, int64_t i, uint64_t *out_a, uint64_t *out_b,
                                                   bool *all_valid_out) {
-  // the tuple's message: one 16-byte block per component (ca, cb), then a last block that holds the arity
+  // the tuple's message: one 16-byte block per component (ca, cb) -- 16 x arity bytes, so the last component's block is
+  // the message's last block and a full one (K1): tuples of another arity are messages of another length, which the
+  // MAC tells apart as it does strings of different lengths (rounds 1-6a spent a third permutation on an arity block)
   Fp s;
   fp_init(s, d.key);
   bool all_valid = true;
@@ -1171,9 +1173,11 @@ __device__ __forceinline__ void tuple_fingerprint(const TupleDesc &d, int64_t i,
       fingerprint(d.key, comp.p, comp.len, &ca, &cb);
       cb |= 2;  // (tag space: 0 NULL, 1 numeric, >= 2 string)
     }
-    fp_block(s, ca, cb);
+    if (c + 1 < d.n_cols)
+      fp_block(s, ca, cb);
+    else
+      fp_last_padded(s, ca, cb, true, d.key);
   }
-  fp_last(s, (uint64_t)d.n_cols, 0x454c505554ULL /* "TUPLE" */, 16, d.key);
   fp_out(s, out_a, out_b);
   *all_valid_out = all_valid;
 }
@@ -1341,16 +1345,19 @@ __global__ __launch_bounds__(256) void fp_partition_tuples_kernel(TupleDesc d, F
       r.x = kEmptyKey;
       r.y = 0;
       if (row < d.length) {
-        // (tuple_fingerprint's message: a block per component -- (bits, 1) or the NULL marker --, then the arity block)
+        // (tuple_fingerprint's message: a block per component -- (bits, 1) or the NULL marker --, the last one under K1)
         Fp f;
         fp_init(f, d.key);
 #pragma unroll
         for (int c = 0; c < kTupleNumericFast; c++)
           if (c < d.n_cols) {
             const bool valid = (ok[k] >> c) & 1u;
-            fp_block(f, valid ? val[k][c] : 0x4e554c4c4e554c4cULL, valid ? 1ull : 0ull);
+            const uint64_t ca = valid ? val[k][c] : 0x4e554c4c4e554c4cULL, cb = valid ? 1ull : 0ull;
+            if (c + 1 < d.n_cols)
+              fp_block(f, ca, cb);
+            else
+              fp_last_padded(f, ca, cb, true, d.key);
           }
-        fp_last(f, (uint64_t)d.n_cols, 0x454c505554ULL /* "TUPLE" */, 16, d.key);
         fp_out(f, (uint64_t *)&r.x, (uint64_t *)&r.y);
         const bool all_valid = ok[k] == (1u << d.n_cols) - 1u;
         if (EXACT) {

@@ -109,9 +109,10 @@ def tuple_fingerprint(key, components):
             ca, cb = fingerprint(key, c)
             cb |= 2
         blocks.append(struct.pack("<2Q", ca, cb))
+    # the message is the component blocks: its last block is the last component's, a full one (K1)
     k, k1, _ = subkeys(key)
-    v = state_after(key, blocks)
-    m = struct.unpack("<4I", struct.pack("<2Q", len(components), 0x454C505554))
+    v = state_after(key, blocks[:-1])
+    m = struct.unpack("<4I", blocks[-1])
     v = _permute([a ^ x ^ y for a, x, y in zip(v, m, k1)])
     v = [a ^ y for a, y in zip(v, k1)]
     return v[0] | (v[1] << 32), v[2] | (v[3] << 32)
