@@ -95,6 +95,25 @@ def test_python_reference_matches_the_device_function(pairs):
     assert plan.fingerprint_key() == KEY
 
 
+def test_device_function_reproduces_the_published_chaskey8_vectors():
+    """the kernels' fingerprint of the published messages under the published key IS the published tag (the known
+    answers of the Chaskey authors' reference implementation: tests/test_fingerprint_kat.py has them and holds the
+    Python statement to them on the CPU): the records tgx_distinct_export hands out are (v0 | v1 << 32, v2 | v3 << 32)"""
+    import struct
+
+    from test_fingerprint_kat import KEY as KAT_KEY, KNOWN
+
+    vals = [bytes(range(n)) for n, _ in KNOWN]
+    col, _ = column_of(vals)
+    T.init()
+    plan = T.Plan([spec(T.DISTINCT, 0)], fingerprint_key=KAT_KEY)
+    st = T.State(plan)
+    st.update([col])
+    got = {(int(r[0]), int(r[1])) for r in st.distinct_export_records(0)}
+    assert got == {(w[0] | (w[1] << 32), w[2] | (w[3] << 32)) for _, w in KNOWN}
+    assert struct.unpack("<4I", plan.fingerprint_key()) == struct.unpack("<4I", KAT_KEY)
+
+
 @pytest.mark.parametrize("device", [True, False])
 @pytest.mark.parametrize("large", [False, True])
 def test_small_batches_table_path(pairs, device, large):
