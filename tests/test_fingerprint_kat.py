@@ -2,7 +2,7 @@
 I. Verbauwhede: "Chaskey: An Efficient MAC Algorithm for 32-bit Microcontrollers", SAC 2014): the Python statement of
 it the GPU tests hold the kernels to (tests/fp_reference.py; tests/test_gpu_exact_keys.py compares it with
 `distinct128.hip` record by record) reproduces the known answers of the authors' reference implementation -- key
-833D3433 009F389F 2398E64F 417ACF39 (little-endian words), messages m[i] = i of 0, 1, 2 ... bytes, the tag as four
+833D3433 009F389F 2398E64F 417ACF39 (little-endian words), messages m[i] = i of 0 .. 4 bytes, the tag as four
 little-endian words.  CPU only: no kernel is called here."""
 import struct
 
@@ -14,7 +14,12 @@ KNOWN = [
     (0, (0x792E8FE5, 0x75CE87AA, 0x2D1450B5, 0x1191970B)),
     (1, (0x13A9307B, 0x50E62C89, 0x4577BD88, 0xC0BBDC18)),
     (2, (0x55DF8922, 0x2C7FF577, 0x73809EF4, 0x4E5084C0)),
+    (3, (0x1BDBB264, 0xA07680D8, 0x8E5B2AB8, 0x20660413)),
+    (4, (0x30B2D171, 0xE38532FB, 0x16707C16, 0x73ED45F0)),
 ]
+# (all five are one padded block under K2: what they pin is the permutation, its eight rounds, the subkeys and the
+#  padding; blocks chained and a full last block under K1 are the construction on top, held by the tests below and by
+#  the GPU tests' comparison of the kernels with tests/fp_reference.py over every length class)
 
 
 def test_reference_reproduces_the_published_chaskey8_vectors():
